@@ -1,0 +1,354 @@
+// ORACLE (test infrastructure only) -- never linked, imported or executed by the product path.
+// PARITY UNPINNED (see o_bam.h), and doubly so here: the arithmetic of this stage lives in two un-vendored
+// third parties, GLPK 4.62 `glp_intopt` (reference Makefile:3, call site src/SegmentGraph.cpp:3966) and
+// Boost.Graph 1.55 `stoer_wagner_min_cut` (Makefile:1, call site :3325).  What is restated:
+//   src/SegmentGraph.cpp:3236-3262 Ordering, :3264-3451 MincutRecursion, :3763-3983 GenerateILP (the model).
+// The ILP is solved EXACTLY by enumeration; the optimum VALUE is solver independent.
+// Among equal-value optima GLPK's choice is unknowable here, so the oracle fixes a canonical one:
+//   1. maximum objective;  2. then the smallest orientation mask (bit i set <=> local node i reversed,
+//   node 0 = least significant bit);  3. then the lexicographically smallest left-to-right node sequence.
+// `OrderStats` reports how many components had optima that disagree on the satisfied discordant edges --
+// only those can make `_sv.txt` differ from a GLPK run.
+#pragma once
+#include "o_graph.h"
+
+namespace oracle {
+
+struct LocalEdge { int u, v; bool hu, hv; int w; bool discordant; };  // u < v local indices
+
+struct OrderStats {
+    long components = 0, solved = 0, ambiguous = 0, too_large = 0, mincut_splits = 0;
+};
+
+// does the signed arrangement satisfy edge e?  (rows of GenerateILP, :3803-3931; fwd[i]=y_i, pos[i]=rank)
+inline bool EdgeSatisfied(const LocalEdge& e, const std::vector<int>& fwd, const std::vector<int>& pos) {
+    bool ubefore = pos[e.u] < pos[e.v];
+    bool yu = fwd[e.u], yv = fwd[e.v];
+    if (!e.hu && e.hv) return yu == yv && ubefore == yu;       // tail -> head
+    if (!e.hu && !e.hv) return yu != yv && ubefore == yu;      // tail - tail
+    if (e.hu && e.hv) return yu != yv && ubefore == yv;        // head - head
+    return yu == yv && ubefore == !yu;                          // head -> tail
+}
+
+// arc weights a[x][y] ("x wants to precede y") induced by orientation mask (bit set = reversed)
+inline long BuildArcs(int n, const std::vector<LocalEdge>& E, unsigned mask, std::vector<std::vector<int>>* a) {
+    long ub = 0;
+    if (a) a->assign(n, std::vector<int>(n, 0));
+    for (const LocalEdge& e : E) {
+        bool yu = !((mask >> e.u) & 1), yv = !((mask >> e.v) & 1);
+        bool compat, ufirst;
+        if (!e.hu && e.hv) { compat = yu == yv; ufirst = yu; }
+        else if (!e.hu && !e.hv) { compat = yu != yv; ufirst = yu; }
+        else if (e.hu && e.hv) { compat = yu != yv; ufirst = yv; }
+        else { compat = yu == yv; ufirst = !yu; }
+        if (!compat) continue;
+        ub += e.w;
+        if (a) { if (ufirst) (*a)[e.u][e.v] += e.w; else (*a)[e.v][e.u] += e.w; }
+    }
+    return ub;
+}
+
+// exhaustive reference solver for tiny components: all n! * 2^n signed permutations, explicit comparator
+inline void SolveBrute(int n, const std::vector<LocalEdge>& E, std::vector<int>& order, unsigned& bestmask, long& bestval, bool* ambiguous) {
+    std::vector<int> perm(n), pos(n), fwd(n);
+    for (int i = 0; i < n; i++) perm[i] = i;
+    bestval = -1; bestmask = 0;
+    std::vector<std::vector<bool>> optsets;
+    do {
+        for (int i = 0; i < n; i++) pos[perm[i]] = i;
+        for (unsigned mask = 0; mask < (1u << n); mask++) {
+            for (int i = 0; i < n; i++) fwd[i] = !((mask >> i) & 1);
+            long val = 0;
+            for (const LocalEdge& e : E) if (EdgeSatisfied(e, fwd, pos)) val += e.w;
+            bool better = val > bestval || (val == bestval && (mask < bestmask || (mask == bestmask && perm < order)));
+            if (ambiguous && val >= bestval) {
+                if (val > bestval) optsets.clear();
+                std::vector<bool> s;
+                for (const LocalEdge& e : E) if (e.discordant) s.push_back(EdgeSatisfied(e, fwd, pos));
+                if (std::find(optsets.begin(), optsets.end(), s) == optsets.end()) optsets.push_back(s);
+            }
+            if (better) { bestval = val; bestmask = mask; order = perm; }
+        }
+    } while (std::next_permutation(perm.begin(), perm.end()));
+    if (ambiguous) *ambiguous = optsets.size() > 1;
+}
+
+// ---- linear-ordering sub-problem of one orientation: arcs a[x][y] ("x wants to precede y")
+// Acyclic arc set: every arc can be satisfied; the lexicographically smallest optimal sequence is the
+// smallest-index-first topological order.  Returns false when the arcs contain a cycle.
+inline bool TopoSmallestFirst(int n, const std::vector<std::vector<int>>& a, std::vector<int>& order) {
+    std::vector<int> indeg(n, 0);
+    for (int x = 0; x < n; x++) for (int y = 0; y < n; y++) if (a[x][y] > 0) indeg[y]++;
+    std::vector<bool> done(n, false);
+    order.clear();
+    for (int p = 0; p < n; p++) {
+        int v = -1;
+        for (int c = 0; c < n; c++) if (!done[c] && indeg[c] == 0) { v = c; break; }
+        if (v < 0) return false;
+        done[v] = true;
+        order.push_back(v);
+        for (int y = 0; y < n; y++) if (a[v][y] > 0) indeg[y]--;
+    }
+    return true;
+}
+
+// Cyclic arc set: subset DP.  h[S] = best weight still obtainable once the set S occupies the first |S|
+// positions; gain(S,v) = sum_{u in S} a[u][v] is looked up from two half-mask tables.
+struct OrderDP {
+    int n, lo_bits;
+    std::vector<std::vector<long>> GL, GH;
+    std::vector<long> h;
+    OrderDP(int n, const std::vector<std::vector<int>>& a) : n(n), lo_bits(n / 2) {
+        int hi_bits = n - lo_bits;
+        GL.assign(n, std::vector<long>((size_t)1 << lo_bits, 0));
+        GH.assign(n, std::vector<long>((size_t)1 << hi_bits, 0));
+        for (int v = 0; v < n; v++) {
+            for (size_t m = 1; m < GL[v].size(); m++) { int b = __builtin_ctzl(m); GL[v][m] = GL[v][m & (m - 1)] + a[b][v]; }
+            for (size_t m = 1; m < GH[v].size(); m++) { int b = __builtin_ctzl(m); GH[v][m] = GH[v][m & (m - 1)] + a[lo_bits + b][v]; }
+        }
+    }
+    long gain(size_t S, int v) const { return GL[v][S & (((size_t)1 << lo_bits) - 1)] + GH[v][S >> lo_bits]; }
+    long solve() {
+        const size_t full = ((size_t)1 << n) - 1;
+        h.assign(full + 1, 0);
+        for (size_t S = full; S-- > 0;) {
+            long best = -1;
+            for (int v = 0; v < n; v++) {
+                if ((S >> v) & 1) continue;
+                long t = gain(S, v) + h[S | ((size_t)1 << v)];
+                if (t > best) best = t;
+            }
+            h[S] = best;
+        }
+        return h[0];
+    }
+    void smallest_order(std::vector<int>& order) const {
+        order.clear();
+        size_t S = 0;
+        for (int p = 0; p < n; p++)
+            for (int v = 0; v < n; v++) {
+                if ((S >> v) & 1) continue;
+                if (gain(S, v) + h[S | ((size_t)1 << v)] == h[S]) { order.push_back(v); S |= (size_t)1 << v; break; }
+            }
+    }
+};
+
+// Branch and bound over orientations.  Nodes are fixed from the highest local index down, forward first, and a
+// branch is cut when its optimistic bound cannot STRICTLY beat the incumbent -- so the first incumbent of the
+// final value is the one with the smallest orientation mask (rule 2 of the canonical choice).
+struct BnB {
+    int n;
+    const std::vector<LocalEdge>& E;
+    long bestval = -1;
+    unsigned bestmask = 0;
+    std::vector<int> bestorder;
+    long leaves = 0, dps = 0;
+    BnB(int n, const std::vector<LocalEdge>& E) : n(n), E(E) {}
+    // optimistic value with nodes > k fixed by `mask`, nodes <= k free
+    long bound(unsigned mask, int k) const {
+        long ub = 0;
+        for (const LocalEdge& e : E) {
+            if (e.u <= k) { ub += e.w; continue; }  // u < v, so u free => at least one end free
+            bool yu = !((mask >> e.u) & 1), yv = !((mask >> e.v) & 1);
+            bool sameori = (e.hu != e.hv);  // tail->head / head->tail need equal orientation
+            if (sameori ? (yu == yv) : (yu != yv)) ub += e.w;
+        }
+        return ub;
+    }
+    void leaf(unsigned mask) {
+        leaves++;
+        std::vector<std::vector<int>> a;
+        long ub = BuildArcs(n, E, mask, &a);
+        std::vector<int> order;
+        long val;
+        if (TopoSmallestFirst(n, a, order)) val = ub;
+        else { OrderDP dp(n, a); dps++; val = dp.solve(); if (val > bestval) dp.smallest_order(order); }
+        if (val > bestval) { bestval = val; bestmask = mask; bestorder = order; }
+    }
+    void rec(unsigned mask, int k) {  // node k is the next to fix
+        if (bound(mask, k) <= bestval) return;
+        if (k < 0) { leaf(mask); return; }
+        rec(mask, k - 1);
+        rec(mask | (1u << k), k - 1);
+    }
+    void run() { rec(0, n - 1); }
+};
+
+inline void SolveDP(int n, const std::vector<LocalEdge>& E, std::vector<int>& order, unsigned& bestmask, long& bestval) {
+    BnB b(n, E);
+    b.run();
+    order = b.bestorder; bestmask = b.bestmask; bestval = b.bestval;
+}
+
+class Orderer {
+public:
+    const SegmentGraph_t& G;
+    OrderStats stats;
+    int brute_max = 7;     // components up to this size are solved by plain enumeration (and checked for ambiguity)
+    int exact_max = 26;    // larger ones cannot be solved exactly here (the reference gives GLPK 300 s)
+    explicit Orderer(const SegmentGraph_t& g) : G(g) {}
+
+    // src/SegmentGraph.cpp:3236-3262
+    std::vector<std::vector<int>> Ordering() {
+        int componentsize = 0;
+        for (int l : G.Label) if (l > componentsize) componentsize = l;
+        componentsize++;
+        std::vector<std::vector<int>> BestOrders(componentsize);
+        // bucket nodes/edges per component once (the reference rescans everything per component; same result)
+        std::vector<std::map<int, int>> CompNodes(componentsize);
+        std::vector<std::vector<Edge_t>> CompEdges(componentsize);
+        std::vector<int> cnt(componentsize, 0);
+        for (int j = 0; j < (int)G.Label.size(); j++) CompNodes[G.Label[j]][j] = cnt[G.Label[j]]++;
+        for (const Edge_t& e : G.vEdges)
+            if (e.Ind1 != e.Ind2) {
+                CompEdges[G.Label[e.Ind1]].push_back(e);
+                if (G.Label[e.Ind2] != G.Label[e.Ind1]) CompEdges[G.Label[e.Ind2]].push_back(e);  // cannot happen for a CC labelling
+            }
+        for (int i = 0; i < componentsize; i++) {
+            stats.components++;
+            if (CompNodes[i].size() == 1) { BestOrders[i].push_back(CompNodes[i].begin()->first + 1); continue; }
+            BestOrders[i] = MincutRecursion(CompNodes[i], CompEdges[i]);
+        }
+        return BestOrders;
+    }
+
+private:
+    // backbone edges + exact solve + decode (:3271-3314 and :3326-3370)
+    std::vector<int> SolveWhole(std::map<int, int>& CompNodes, std::vector<Edge_t> CompEdges) {
+        const int n = (int)CompNodes.size();
+        std::vector<int> BestOrder(n, 0);
+        size_t edgeidx = 0;
+        std::map<int, int>::iterator itnodeend = CompNodes.end();
+        itnodeend--;
+        for (std::map<int, int>::iterator itnode = CompNodes.begin(); itnode != itnodeend; itnode++) {
+            bool isfound = false;
+            for (; edgeidx < CompEdges.size() && CompEdges[edgeidx].Ind1 <= itnode->first; edgeidx++)
+                if (CompNodes[CompEdges[edgeidx].Ind1] == itnode->second && CompNodes[CompEdges[edgeidx].Ind2] == itnode->second + 1) { isfound = true; break; }
+            if (!isfound) {
+                std::map<int, int>::iterator tmpit = itnode;
+                tmpit++;
+                CompEdges.push_back(Edge_t(itnode->first, false, tmpit->first, true, 1));  // ledger B17
+            }
+        }
+        std::vector<LocalEdge> E;
+        for (const Edge_t& e : CompEdges) E.push_back(LocalEdge{CompNodes[e.Ind1], CompNodes[e.Ind2], e.Head1, e.Head2, e.Weight, G.IsDiscordant(e)});
+        std::vector<int> order;
+        unsigned mask = 0;
+        long val = 0;
+        if (n <= brute_max) {
+            bool amb = false;
+            SolveBrute(n, E, order, mask, val, &amb);
+            if (amb) stats.ambiguous++;
+            stats.solved++;
+        } else if (n <= exact_max) {
+            SolveDP(n, E, order, mask, val);
+            stats.solved++;
+        } else {
+            // identity order, all forward == what the reference keeps when glp_intopt fails (:3287-3292,3984)
+            std::cerr << "oracle: component of " << n << " nodes exceeds the exact solver; identity order kept\n";
+            stats.too_large++;
+            order.resize(n);
+            for (int i = 0; i < n; i++) order[i] = i;
+            mask = 0;
+        }
+        std::vector<int> ids(n);
+        for (auto& kv : CompNodes) ids[kv.second] = kv.first;
+        for (int p = 0; p < n; p++) {
+            int l = order[p];
+            BestOrder[p] = ((mask >> l) & 1) ? (-ids[l] - 1) : (ids[l] + 1);
+        }
+        return BestOrder;
+    }
+
+    // unit-weight Stoer-Wagner on the multigraph (parallel edges add up).  Tie-breaking is the oracle's own:
+    // start at vertex 0, first maximum in the adjacency search, first strictly smaller cut-of-the-phase wins.
+    static int StoerWagner(int n, const std::vector<std::pair<int, int>>& edges, std::vector<bool>& parity) {
+        std::vector<std::vector<int>> w(n, std::vector<int>(n, 0));
+        for (auto& e : edges) if (e.first != e.second) { w[e.first][e.second]++; w[e.second][e.first]++; }
+        std::vector<std::vector<int>> members(n);
+        for (int i = 0; i < n; i++) members[i].push_back(i);
+        std::vector<int> alive(n);
+        for (int i = 0; i < n; i++) alive[i] = i;
+        int best = std::numeric_limits<int>::max();
+        parity.assign(n, false);
+        while (alive.size() > 1) {
+            std::vector<int> wt(n, 0);
+            std::vector<bool> added(n, false);
+            int prev = -1, last = -1;
+            for (size_t it = 0; it < alive.size(); it++) {
+                int sel = -1;
+                for (int v : alive) if (!added[v] && (sel == -1 || wt[v] > wt[sel])) sel = v;
+                added[sel] = true;
+                prev = last; last = sel;
+                for (int v : alive) if (!added[v]) wt[v] += w[sel][v];
+            }
+            if (wt[last] < best) {
+                best = wt[last];
+                parity.assign(n, false);
+                for (int m : members[last]) parity[m] = true;
+            }
+            for (int m : members[last]) members[prev].push_back(m);
+            for (int v : alive) { w[prev][v] += w[last][v]; w[v][prev] = w[prev][v]; }
+            alive.erase(std::find(alive.begin(), alive.end(), last));
+        }
+        return best;
+    }
+
+    // src/SegmentGraph.cpp:3264-3451
+    std::vector<int> MincutRecursion(std::map<int, int> CompNodes, std::vector<Edge_t> CompEdges) {
+        if (CompNodes.size() == 1) return std::vector<int>(1, CompNodes.begin()->first + 1);
+        if (CompNodes.size() < 20) return SolveWhole(CompNodes, CompEdges);
+        std::vector<std::pair<int, int>> edges;
+        for (const Edge_t& e : CompEdges) edges.push_back(std::make_pair(CompNodes[e.Ind1], CompNodes[e.Ind2]));
+        std::vector<bool> parities;
+        int w = StoerWagner((int)CompNodes.size(), edges, parities);
+        if (w > 1) return SolveWhole(CompNodes, CompEdges);
+        stats.mincut_splits++;
+        std::map<int, int> VertexParty1, VertexParty2;
+        int count1 = 0, count2 = 0;
+        for (auto& kv : CompNodes) {
+            if (parities[kv.second]) VertexParty1[kv.first] = count1++;
+            else VertexParty2[kv.first] = count2++;
+        }
+        std::vector<Edge_t> EdgesParty1, EdgesParty2;
+        Edge_t EdgeMiddle;
+        for (const Edge_t& e : CompEdges) {
+            bool p1 = parities[CompNodes[e.Ind1]], p2 = parities[CompNodes[e.Ind2]];
+            if (p1 && p2) EdgesParty1.push_back(e);
+            else if (!p1 && !p2) EdgesParty2.push_back(e);
+            else EdgeMiddle = e;
+        }
+        std::vector<int> BestParty1 = MincutRecursion(VertexParty1, EdgesParty1);
+        std::vector<int> BestParty2 = MincutRecursion(VertexParty2, EdgesParty2);
+        auto scan = [&](const std::vector<int>& B, int& median, bool& ispositive, bool& ishead) {
+            std::vector<int> tmp;
+            for (int x : B) {
+                tmp.push_back(std::abs(x));
+                if (std::abs(x) == EdgeMiddle.Ind1 + 1) { ispositive = (x > 0); ishead = EdgeMiddle.Head1; }
+                else if (std::abs(x) == EdgeMiddle.Ind2 + 1) { ispositive = (x > 0); ishead = EdgeMiddle.Head2; }
+            }
+            std::sort(tmp.begin(), tmp.end());
+            median = tmp[((int)tmp.size() - 1) / 2];
+        };
+        int median1 = 0, median2 = 0;
+        bool ispositive1 = false, ishead1 = false, ispositive2 = false, ishead2 = false;
+        scan(BestParty1, median1, ispositive1, ishead1);
+        scan(BestParty2, median2, ispositive2, ishead2);
+        auto flip = [](std::vector<int>& B) { std::reverse(B.begin(), B.end()); for (int& x : B) x = -x; };
+        std::vector<int> BestOrder;
+        if (median1 < median2) {
+            if (ispositive1 == ishead1) flip(BestParty1);   // the bridge end must face right in the left block
+            if (ispositive2 != ishead2) flip(BestParty2);   // and face left in the right block
+            BestOrder = BestParty1;
+            BestOrder.insert(BestOrder.end(), BestParty2.begin(), BestParty2.end());
+        } else {
+            if (ispositive2 == ishead2) flip(BestParty2);
+            if (ispositive1 != ishead1) flip(BestParty1);
+            BestOrder = BestParty2;
+            BestOrder.insert(BestOrder.end(), BestParty1.begin(), BestParty1.end());
+        }
+        return BestOrder;
+    }
+};
+
+}  // namespace oracle
