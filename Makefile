@@ -1,0 +1,31 @@
+# Builds every native artefact into build/ (git-ignored, but shipped to the GPU box by gpurun).
+#   build/libsquid_hip.so   product: HIP kernels + host pipeline behind the C ABI of include/squid_hip.h
+#   build/squid             product: drop-in command line
+#   build/gen_synth_bam     synthetic BAM generator (inputs for tests and bench)
+#   build/squid_oracle      CPU oracle (test infrastructure; never linked into the product)
+HIPCC ?= hipcc
+CXX ?= g++
+ARCH ?= gfx950
+B := build
+CSRC := squid_amd/csrc
+LIBSRC := $(CSRC)/sq_kernels.hip $(CSRC)/sq_bam.cpp $(CSRC)/sq_chimeric.cpp $(CSRC)/sq_segment.cpp $(CSRC)/sq_graph.cpp $(CSRC)/sq_order.cpp $(CSRC)/sq_capi.cpp
+
+all: $(B)/libsquid_hip.so $(B)/squid $(B)/gen_synth_bam $(B)/squid_oracle
+
+$(B)/libsquid_hip.so: $(LIBSRC) $(CSRC)/sq_internal.h include/squid_hip.h
+	mkdir -p $(B)
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function -o $@ $(LIBSRC) -lz -lpthread
+
+$(B)/squid: $(CSRC)/squid_main.cpp $(B)/libsquid_hip.so include/squid_hip.h
+	$(HIPCC) -O2 -std=c++17 -o $@ $(CSRC)/squid_main.cpp -L$(B) -lsquid_hip -Wl,-rpath,'$$ORIGIN'
+
+$(B)/gen_synth_bam: squid_amd/synth/gen_synth_bam.cpp
+	mkdir -p $(B)
+	$(CXX) -O2 -std=c++17 -o $@ $< -lz -lpthread
+
+$(B)/squid_oracle: oracle/squid_oracle.cpp oracle/o_bam.h oracle/o_readrec.h oracle/o_graph.h oracle/o_order.h
+	$(MAKE) -C oracle OUT=../$(B)
+
+clean:
+	rm -rf $(B)
+.PHONY: all clean

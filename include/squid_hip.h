@@ -1,0 +1,173 @@
+/*
+ * squid_hip.h -- C ABI of the MI355X-native SQUID hot path (libsquid_hip.so).
+ *
+ * The reference (Kingsford-Group/squid v1.5) has no plugin / FFI boundary: its hot path sits behind C++
+ * signatures inside one process.  Each entry point below names the reference
+ * interface it replaces (file:line under the reference's src/).  Conventions:
+ *   - every function returns 0 on success or a negative SQ_E_* code; sq_strerror() names it;
+ *   - no C++ types or exceptions cross the boundary; inputs are caller-owned and only read during the call;
+ *   - outputs are library-owned views, valid until the next call on the same context or sq_destroy();
+ *   - one context <-> one GPU <-> one host thread at a time (thread-compatible, not thread-safe);
+ *   - the library refuses to work without a HIP device: there is no CPU code path for the GPU stages.
+ */
+#ifndef SQUID_HIP_H
+#define SQUID_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SQ_ABI_VERSION 1
+
+enum {
+    SQ_OK = 0,
+    SQ_E_ARG = -1,       /* bad argument / call order */
+    SQ_E_NODEVICE = -2,  /* no usable HIP device (the product never falls back to the CPU) */
+    SQ_E_HIP = -3,       /* a HIP runtime call failed */
+    SQ_E_IO = -4,        /* cannot open / parse a BAM file */
+    SQ_E_UNSORTED = -5,  /* concordant input is not coordinate sorted (README.md:23 requires it) */
+    SQ_E_ASSERT = -6,    /* the reference would hit one of its live assert()s on this input */
+    SQ_E_CAPACITY = -7,  /* an internal table overflowed */
+    SQ_E_EMPTYCHIM = -8  /* chimeric input has no usable record (reference: out-of-bounds read, ReadRec.cpp:379) */
+};
+
+/* The tuning globals of src/Config.h:23-49 (defaults = src/Config.cpp:11-37), plus device selection. */
+typedef struct sq_params {
+    int32_t abi_version;       /* = SQ_ABI_VERSION */
+    int32_t device;            /* HIP device ordinal */
+    int32_t phred_type;        /* Phred_Type: 1 => offset 33 (Config.cpp:19) */
+    int32_t max_lowphred_len;  /* Max_LowPhred_Len (10) */
+    int32_t min_phred;         /* Min_Phred (4) */
+    int32_t min_mapqual;       /* Min_MapQual; the CLI applies the STAR => 255 rule (Config.cpp:221-222) */
+    int32_t concord_dist_pos;  /* Concord_Dist_Pos (50000) */
+    int32_t concord_dist_idx;  /* Concord_Dist_Idx (20) */
+    int32_t min_edge_weight;   /* Min_Edge_Weight (5) */
+    double discordant_ratio;   /* DiscordantRatio (8) */
+    int32_t max_allowed_degree; /* MaxAllowedDegree (5) */
+    int32_t rank, world_size;  /* chromosome sharding (sq_exchange_*); 0,1 for a single GPU */
+} sq_params;
+
+void sq_default_params(sq_params* p);
+
+typedef struct sq_ctx sq_ctx;
+
+/* SoA batch of decoded alignment records (what BamTools hands the reference one BamAlignment at a time,
+ * src/ReadRec.cpp:10-88; SURVEY.md section 8(d) record layout).  Blocks are the aligned blocks that
+ * ReadRec_t::ReadRec_t keeps, in CIGAR order, with ReadPos already strand-mirrored (ReadRec.cpp:74-75). */
+typedef struct sq_aln_batch {
+    int64_t n_rec, n_blk;
+    const int32_t* refid;      /* BamAlignment::RefID */
+    const int32_t* pos;        /* Position */
+    const int32_t* mate_refid; /* MateRefID */
+    const int32_t* mate_pos;   /* MatePosition */
+    const int32_t* end_pos;    /* GetEndPosition() */
+    const uint16_t* flag;      /* SAM flag */
+    const uint8_t* mapq;       /* MapQuality */
+    const uint8_t* aux;        /* SQ_AUX_* */
+    const uint16_t* totlen;    /* TotalLen of ReadRec.cpp:16-18 */
+    const uint32_t* blk_off;   /* n_rec+1 offsets into the block arrays */
+    const int32_t* b_refpos;
+    const int32_t* b_matchref;
+    const uint16_t* b_readpos;
+    const uint16_t* b_matchread;
+    /* QNAMEs, only read by sq_ingest_chimeric (ReadRec.cpp:11-13,354): n_rec+1 offsets into name_blob */
+    const uint32_t* name_off;
+    const char* name_blob;
+} sq_aln_batch;
+
+#define SQ_AUX_MULTI 0x01    /* HasTag("XA") || IH > 1   (SegmentGraph.cpp:297-302) */
+#define SQ_AUX_INCHIM 0x02   /* raw QNAME is in the chimeric name set (SegmentGraph.cpp:302), see sq_chim_contains */
+#define SQ_AUX_LOWPHRED 0x04 /* low-Phred run longer than Max_LowPhred_Len (ReadRec.cpp:19-44) */
+
+int sq_create(const sq_params* p, sq_ctx** out);
+void sq_destroy(sq_ctx* c);
+const char* sq_strerror(int code);
+const char* sq_last_error(sq_ctx* c); /* free-text detail of the last failure on this context */
+
+/* BuildRefName (src/ReadRec.cpp:267-283): reference lengths in header order. */
+int sq_set_references(sq_ctx* c, int32_t n_ref, const int32_t* ref_len);
+
+/* BuildChimericSBamRecord (src/ReadRec.cpp:329-413): all records of the chimeric BAM in file order; one call. */
+int sq_ingest_chimeric(sq_ctx* c, const sq_aln_batch* b);
+/* binary_search(ChimName, record.Name) of src/SegmentGraph.cpp:302,1584,3136 (incl. the "" entry, ledger B9) */
+int sq_chim_contains(sq_ctx* c, const char* name, size_t len);
+/* The concordant stream, in file order; may be called repeatedly (batches are appended in HBM). */
+int sq_ingest_concordant(sq_ctx* c, const sq_aln_batch* b);
+
+/* Convenience host-side readers (own BGZF/BAM decoder; replaces the BamTools calls listed in SURVEY.md
+ * appendix C).  They decode, fill sq_aln_batch and call the two functions above. */
+int sq_read_header(const char* bam_path, int32_t* n_ref, int32_t* ref_len, char* names, size_t names_cap);
+int sq_ingest_chimeric_file(sq_ctx* c, const char* bam_path);
+int sq_ingest_concordant_file(sq_ctx* c, const char* bam_path, int32_t n_threads);
+
+/* SegmentGraph_t::SegmentGraph_t(RefLength, Chimrecord, bam) -- src/SegmentGraph.cpp:104-124 */
+int sq_build_graph(sq_ctx* c);
+
+typedef struct sq_graph {
+    int32_t n_nodes, n_edges;
+    const int32_t *chr, *pos, *len, *support, *label;  /* Node_t (src/BPNode.h:26-57) + Label */
+    const double* avgdepth;
+    const int32_t *ind1, *ind2, *weight, *groupweight;  /* Edge_t (src/BPEdge.h:24-77) */
+    const uint8_t *head1, *head2;
+} sq_graph;
+/* stage: 0 = final graph (what OutputGraph prints, src/SegmentGraph.cpp:3223-3234);
+ *        1 = after BuildNode_STAR, 2 = after BuildEdges, 3 = after FilterbyWeight, 4 = after FilterEdges,
+ *        5 = after CompressNode  (intermediate snapshots are kept for the parity tests) */
+int sq_graph_view(sq_ctx* c, int32_t stage, sq_graph* g);
+
+/* vector<vector<int>> Ordering() -- src/SegmentGraph.cpp:3236-3262: CSR of signed 1-based node ids */
+typedef struct sq_orders {
+    int32_t n_components;
+    const int32_t* comp_off; /* n_components+1 */
+    const int32_t* nodes;
+} sq_orders;
+int sq_order(sq_ctx* c, sq_orders* o);
+
+/* ExactBreakpoint + ExactBPConcordantSupport + DeMultiplyDisEdges + the row selection of WriteBEDPE
+ * (src/SegmentGraph.cpp:3019-3221,3012-3017; src/WriteIO.cpp:45-124).  One row per printed _sv.txt line. */
+typedef struct sq_sv_table {
+    int32_t n_rows;
+    const int32_t *chr1, *start1, *end1, *chr2, *start2, *end2, *score, *sup1, *sup2;
+    const uint8_t *strand1_minus, *strand2_minus;
+} sq_sv_table;
+int sq_call_sv(sq_ctx* c, sq_sv_table* t);
+
+/* per-edge breakpoint table of the final graph (parity tests): CSR over edges in final sorted order */
+typedef struct sq_bp_table {
+    int32_t n_edges;
+    const int32_t* bp_off;     /* n_edges+1 */
+    const int32_t *bp1, *bp2;  /* -1,-1 when the edge has no split-read breakpoint */
+    const int32_t *sup1, *sup2;
+} sq_bp_table;
+int sq_breakpoints(sq_ctx* c, sq_bp_table* t);
+
+/* Multi-GPU: chromosome-sharded ranks exchange {node table, locally reduced edges}
+ * once.  The library packs/unpacks; the caller moves the bytes (RCCL all-gather via torch.distributed). */
+int sq_exchange_pack(sq_ctx* c, const void** buf, int64_t* nbytes);
+int sq_exchange_unpack(sq_ctx* c, const void* gathered, const int64_t* nbytes_per_rank, int32_t world_size);
+
+/* Timing of the last sq_build_graph/sq_order/sq_call_sv on this context, measured with HIP events on the
+ * library's own stream.  names[i] is a static string; ms[i] the accumulated duration; launches[i] the count. */
+typedef struct sq_timing {
+    int32_t n;
+    const char* const* names;
+    const double* ms;
+    const int64_t* launches;
+    const double* bytes; /* algorithmic bytes moved by the kernel (0 for host stages) */
+} sq_timing;
+int sq_get_timing(sq_ctx* c, sq_timing* t);
+int sq_reset(sq_ctx* c); /* drop graph results, keep ingested records resident in HBM (bench re-runs) */
+
+typedef struct sq_counts {
+    int64_t n_concordant, n_blocks, n_chimeric_records, n_chim_fragments, read_len;
+    int64_t n_kept_p1, n_break, n_kept_p2, n_raw_edges, n_unique_edges;
+} sq_counts;
+int sq_get_counts(sq_ctx* c, sq_counts* k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

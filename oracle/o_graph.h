@@ -573,7 +573,8 @@ inline void SegmentGraph_t::BuildNode_STAR(const std::vector<int>& RefLength, SB
                 }
             }
         }
-        if (tmpNodes.back().Position + tmpNodes.back().Length < vNodes[i].Position) {
+        // (empty tmpNodes + seed at chr 0 pos 0: the reference reads back() of an empty vector; treated as no gap)
+        if (tmpNodes.size() != 0 && tmpNodes.back().Position + tmpNodes.back().Length < vNodes[i].Position) {
             int gap = vNodes[i].Position - tmpNodes.back().Position - tmpNodes.back().Length;
             if (gap > 100) {
                 tmpNodes.push_back(Node_t(vNodes[i].Chr, tmpNodes.back().Position + tmpNodes.back().Length, gap));

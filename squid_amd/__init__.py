@@ -1,0 +1,220 @@
+"""squid_amd -- MI355X-native SQUID hot path (BAM -> segment graph -> ordering -> _sv.txt).
+
+Thin ctypes binding over the C ABI of ``build/libsquid_hip.so`` (``include/squid_hip.h``).  The Python layer
+holds no algorithm: it exists so that tests and ``bench.py`` can drive the same entry points the ``squid``
+command line uses.  Importing the package does not need a GPU; creating a :class:`Context` does, and fails
+loudly without one (there is no CPU path for the GPU stages).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+BUILD = ROOT / "build"
+LIB_PATH = BUILD / "libsquid_hip.so"
+
+EXPORTS = [
+    "sq_default_params", "sq_create", "sq_destroy", "sq_strerror", "sq_last_error", "sq_set_references",
+    "sq_ingest_chimeric", "sq_chim_contains", "sq_ingest_concordant", "sq_read_header", "sq_ingest_chimeric_file",
+    "sq_ingest_concordant_file", "sq_build_graph", "sq_graph_view", "sq_order", "sq_call_sv", "sq_breakpoints",
+    "sq_exchange_pack", "sq_exchange_unpack", "sq_get_timing", "sq_reset", "sq_get_counts",
+]
+
+
+class SqParams(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("phred_type", C.c_int32), ("max_lowphred_len", C.c_int32),
+                ("min_phred", C.c_int32), ("min_mapqual", C.c_int32), ("concord_dist_pos", C.c_int32), ("concord_dist_idx", C.c_int32),
+                ("min_edge_weight", C.c_int32), ("discordant_ratio", C.c_double), ("max_allowed_degree", C.c_int32),
+                ("rank", C.c_int32), ("world_size", C.c_int32)]
+
+
+_P32 = C.POINTER(C.c_int32)
+_PU8 = C.POINTER(C.c_uint8)
+
+
+class SqGraph(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("n_edges", C.c_int32), ("chr", _P32), ("pos", _P32), ("len", _P32), ("support", _P32), ("label", _P32),
+                ("avgdepth", C.POINTER(C.c_double)), ("ind1", _P32), ("ind2", _P32), ("weight", _P32), ("groupweight", _P32), ("head1", _PU8), ("head2", _PU8)]
+
+
+class SqOrders(C.Structure):
+    _fields_ = [("n_components", C.c_int32), ("comp_off", _P32), ("nodes", _P32)]
+
+
+class SqSvTable(C.Structure):
+    _fields_ = [("n_rows", C.c_int32), ("chr1", _P32), ("start1", _P32), ("end1", _P32), ("chr2", _P32), ("start2", _P32), ("end2", _P32),
+                ("score", _P32), ("sup1", _P32), ("sup2", _P32), ("strand1_minus", _PU8), ("strand2_minus", _PU8)]
+
+
+class SqBpTable(C.Structure):
+    _fields_ = [("n_edges", C.c_int32), ("bp_off", _P32), ("bp1", _P32), ("bp2", _P32), ("sup1", _P32), ("sup2", _P32)]
+
+
+class SqTiming(C.Structure):
+    _fields_ = [("n", C.c_int32), ("names", C.POINTER(C.c_char_p)), ("ms", C.POINTER(C.c_double)), ("launches", C.POINTER(C.c_int64)),
+                ("bytes", C.POINTER(C.c_double))]
+
+
+class SqCounts(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ("n_concordant", "n_blocks", "n_chimeric_records", "n_chim_fragments", "read_len", "n_kept_p1", "n_break",
+                                          "n_kept_p2", "n_raw_edges", "n_unique_edges")]
+
+
+class SquidError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def build(force: bool = False) -> None:
+    """Compile every native artefact (hipcc --offload-arch=gfx950 cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", str(ROOT), "clean"])
+    subprocess.check_call(["make", "-C", str(ROOT), "-j4", "all"])
+
+
+def load_library() -> C.CDLL:
+    """dlopen build/libsquid_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise SquidError(f"{LIB_PATH} is missing: run `make` (or __graft_entry__.build()) first; there is no pure-Python path")
+        lib = C.CDLL(str(LIB_PATH))
+        lib.sq_strerror.restype = C.c_char_p
+        lib.sq_last_error.restype = C.c_char_p
+        lib.sq_last_error.argtypes = [C.c_void_p]
+        lib.sq_create.argtypes = [C.POINTER(SqParams), C.POINTER(C.c_void_p)]
+        lib.sq_destroy.argtypes = [C.c_void_p]
+        lib.sq_destroy.restype = None
+        lib.sq_set_references.argtypes = [C.c_void_p, C.c_int32, _P32]
+        lib.sq_ingest_chimeric_file.argtypes = [C.c_void_p, C.c_char_p]
+        lib.sq_ingest_concordant_file.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+        lib.sq_read_header.argtypes = [C.c_char_p, _P32, _P32, C.c_char_p, C.c_size_t]
+        lib.sq_build_graph.argtypes = [C.c_void_p]
+        lib.sq_graph_view.argtypes = [C.c_void_p, C.c_int32, C.POINTER(SqGraph)]
+        lib.sq_order.argtypes = [C.c_void_p, C.POINTER(SqOrders)]
+        lib.sq_call_sv.argtypes = [C.c_void_p, C.POINTER(SqSvTable)]
+        lib.sq_breakpoints.argtypes = [C.c_void_p, C.POINTER(SqBpTable)]
+        lib.sq_get_timing.argtypes = [C.c_void_p, C.POINTER(SqTiming)]
+        lib.sq_get_counts.argtypes = [C.c_void_p, C.POINTER(SqCounts)]
+        lib.sq_reset.argtypes = [C.c_void_p]
+        lib.sq_chim_contains.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        _lib = lib
+    return _lib
+
+
+def read_header(bam_path: str):
+    lib = load_library()
+    n = C.c_int32(1 << 16)
+    lens = (C.c_int32 * (1 << 16))()
+    names = C.create_string_buffer(1 << 22)
+    rc = lib.sq_read_header(str(bam_path).encode(), C.byref(n), lens, names, len(names))
+    if rc:
+        raise SquidError(f"cannot read BAM header of {bam_path}: {lib.sq_strerror(rc).decode()}")
+    return names.value.decode().split("\n")[: n.value], list(lens[: n.value])
+
+
+class Context:
+    """One GPU context (sq_ctx).  Mirrors the reference's fixed pipeline (src/main.cpp:17-76)."""
+
+    def __init__(self, device: int = 0, star_mapq: bool = True, **params):
+        self.lib = load_library()
+        p = SqParams()
+        self.lib.sq_default_params(C.byref(p))
+        p.device = device
+        if star_mapq and "min_mapqual" not in params:
+            p.min_mapqual = 255  # Config.cpp:221-222
+        for k, v in params.items():
+            setattr(p, k, v)
+        self.params = p
+        self.h = C.c_void_p()
+        rc = self.lib.sq_create(C.byref(p), C.byref(self.h))
+        if rc:
+            raise SquidError(f"sq_create failed: {self.lib.sq_strerror(rc).decode()} -- the HIP path is mandatory, no CPU fallback")
+        self.ref_names: list[str] = []
+
+    def _chk(self, rc: int, what: str):
+        if rc:
+            raise SquidError(f"{what}: {self.lib.sq_strerror(rc).decode()} ({self.lib.sq_last_error(self.h).decode()})")
+
+    def close(self):
+        if self.h:
+            self.lib.sq_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def load(self, bam: str, chim_bam: str, threads: int = 8):
+        names, lens = read_header(bam)
+        self.ref_names = names
+        arr = (C.c_int32 * len(lens))(*lens)
+        self._chk(self.lib.sq_set_references(self.h, len(lens), arr), "sq_set_references")
+        self._chk(self.lib.sq_ingest_chimeric_file(self.h, str(chim_bam).encode()), "sq_ingest_chimeric_file")
+        self._chk(self.lib.sq_ingest_concordant_file(self.h, str(bam).encode(), threads), "sq_ingest_concordant_file")
+
+    def reset(self):
+        self._chk(self.lib.sq_reset(self.h), "sq_reset")
+
+    def build_graph(self):
+        self._chk(self.lib.sq_build_graph(self.h), "sq_build_graph")
+
+    def graph(self, stage: int = 0) -> dict:
+        g = SqGraph()
+        self._chk(self.lib.sq_graph_view(self.h, stage, C.byref(g)), "sq_graph_view")
+        n, m = g.n_nodes, g.n_edges
+        return {
+            "nodes": [(g.chr[i], g.pos[i], g.len[i], g.support[i], g.avgdepth[i], g.label[i]) for i in range(n)],
+            "edges": [(g.ind1[i], g.head1[i], g.ind2[i], g.head2[i], g.weight[i], g.groupweight[i]) for i in range(m)],
+        }
+
+    def order(self) -> list[list[int]]:
+        o = SqOrders()
+        self._chk(self.lib.sq_order(self.h, C.byref(o)), "sq_order")
+        return [[o.nodes[j] for j in range(o.comp_off[k], o.comp_off[k + 1])] for k in range(o.n_components)]
+
+    def call_sv(self) -> list[tuple]:
+        t = SqSvTable()
+        self._chk(self.lib.sq_call_sv(self.h, C.byref(t)), "sq_call_sv")
+        return [(t.chr1[i], t.start1[i], t.end1[i], t.chr2[i], t.start2[i], t.end2[i], t.score[i], t.strand1_minus[i], t.strand2_minus[i], t.sup1[i], t.sup2[i])
+                for i in range(t.n_rows)]
+
+    def breakpoints(self) -> list[list[tuple]]:
+        t = SqBpTable()
+        self._chk(self.lib.sq_breakpoints(self.h, C.byref(t)), "sq_breakpoints")
+        return [[(t.bp1[j], t.bp2[j], t.sup1[j], t.sup2[j]) for j in range(t.bp_off[e], t.bp_off[e + 1])] for e in range(t.n_edges)]
+
+    def timing(self) -> dict:
+        t = SqTiming()
+        self._chk(self.lib.sq_get_timing(self.h, C.byref(t)), "sq_get_timing")
+        return {t.names[i].decode(): {"ms": t.ms[i], "launches": t.launches[i], "bytes": t.bytes[i]} for i in range(t.n)}
+
+    def counts(self) -> dict:
+        k = SqCounts()
+        self._chk(self.lib.sq_get_counts(self.h, C.byref(k)), "sq_get_counts")
+        return {f: getattr(k, f) for f, _ in SqCounts._fields_}
+
+    def sv_text(self) -> str:
+        """The `_sv.txt` file content (src/WriteIO.cpp:49-123)."""
+        rows = self.call_sv()
+        out = ["# chrom1\tstart1\tend1\tchrom2\tstart2\tend2\tname\tscore\tstrand1\tstrand2\tnum_concordantfrag_bp1\tnum_concordantfrag_bp2\n"]
+        for r in rows:
+            out.append(f"{self.ref_names[r[0]]}\t{r[1]}\t{r[2]}\t{self.ref_names[r[3]]}\t{r[4]}\t{r[5]}\t.\t{r[6]}\t{'-' if r[7] else '+'}\t{'-' if r[8] else '+'}\t{r[9]}\t{r[10]}\n")
+        return "".join(out)
+
+
+def run_pipeline(bam: str, chim_bam: str, device: int = 0, **params) -> dict:
+    """BAM -> graph -> ordering -> SV rows in one call (what `squid -b -c -o` does)."""
+    with Context(device=device, **params) as ctx:
+        ctx.load(bam, chim_bam)
+        ctx.build_graph()
+        orders = ctx.order()
+        sv = ctx.sv_text()
+        return {"orders": orders, "sv_text": sv, "graph": ctx.graph(0), "timing": ctx.timing(), "counts": ctx.counts()}

@@ -1,0 +1,358 @@
+// Host-side BGZF/BAM decoder of the product: file -> SoA alignment batches (sq_aln_batch).
+// Replaces the BamTools calls of the reference and folds the per-record part of
+// ReadRec_t::ReadRec_t (src/ReadRec.cpp:10-88: TotalLen, low-Phred run, CIGAR -> aligned blocks, poly-A/T
+// filter, strand-mirrored read offsets) into the decode, so that the sequence/quality bytes never have to
+// leave the host.  BGZF blocks are inflated by a small thread pool; records are then walked in file order.
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <thread>
+
+#include "sq_internal.h"
+
+namespace sq {
+
+void HostBatch::clear() {
+    refid.clear(); pos.clear(); mrefid.clear(); mpos.clear(); endpos.clear(); b_refpos.clear(); b_matchref.clear();
+    flag.clear(); totlen.clear(); b_readpos.clear(); b_matchread.clear(); mapq.clear(); aux.clear();
+    blk_off.assign(1, 0); name_off.assign(1, 0); names.clear();
+}
+void HostBatch::view(sq_aln_batch* b, bool with_names) const {
+    std::memset(b, 0, sizeof *b);
+    b->n_rec = (int64_t)refid.size();
+    b->n_blk = (int64_t)b_refpos.size();
+    b->refid = refid.data(); b->pos = pos.data(); b->mate_refid = mrefid.data(); b->mate_pos = mpos.data(); b->end_pos = endpos.data();
+    b->flag = flag.data(); b->mapq = mapq.data(); b->aux = aux.data(); b->totlen = totlen.data(); b->blk_off = blk_off.data();
+    b->b_refpos = b_refpos.data(); b->b_matchref = b_matchref.data(); b->b_readpos = b_readpos.data(); b->b_matchread = b_matchread.data();
+    if (with_names) { b->name_off = name_off.data(); b->name_blob = names.data(); }
+}
+
+namespace {
+
+struct FileBytes {
+    std::vector<uint8_t> data;
+    bool load(const char* path) {
+        FILE* f = std::fopen(path, "rb");
+        if (!f) return false;
+        std::fseek(f, 0, SEEK_END);
+        long n = std::ftell(f);
+        std::fseek(f, 0, SEEK_SET);
+        data.resize((size_t)n);
+        size_t got = n ? std::fread(data.data(), 1, (size_t)n, f) : 0;
+        std::fclose(f);
+        return got == (size_t)n;
+    }
+};
+
+struct BgzfBlock { size_t coff; uint32_t clen, isize; size_t uoff; };
+
+// walk the BGZF container: one entry per block (payload offset/length, inflated size)
+bool index_bgzf(const std::vector<uint8_t>& d, std::vector<BgzfBlock>& blocks, size_t& total) {
+    size_t p = 0;
+    total = 0;
+    while (p + 18 <= d.size()) {
+        if (d[p] != 0x1f || d[p + 1] != 0x8b || !(d[p + 3] & 4)) return false;
+        uint32_t xlen = d[p + 10] | (d[p + 11] << 8);
+        int bsize = -1;
+        for (size_t o = p + 12; o + 4 <= p + 12 + xlen;) {
+            uint32_t slen = d[o + 2] | (d[o + 3] << 8);
+            if (d[o] == 'B' && d[o + 1] == 'C' && slen == 2) bsize = (d[o + 4] | (d[o + 5] << 8)) + 1;
+            o += 4 + slen;
+        }
+        if (bsize < 0 || p + bsize > d.size()) return false;
+        BgzfBlock b;
+        b.coff = p + 12 + xlen;
+        b.clen = (uint32_t)(bsize - 12 - xlen - 8);
+        std::memcpy(&b.isize, &d[p + bsize - 4], 4);
+        b.uoff = total;
+        total += b.isize;
+        blocks.push_back(b);
+        p += bsize;
+    }
+    return p == d.size();
+}
+
+bool inflate_range(const std::vector<uint8_t>& d, const std::vector<BgzfBlock>& blocks, size_t b0, size_t b1, uint8_t* out, size_t out_base, int n_threads) {
+    std::vector<char> ok((size_t)std::max(1, n_threads), 1);
+    auto work = [&](int t) {
+        z_stream zs;
+        for (size_t i = b0 + t; i < b1; i += (size_t)n_threads) {
+            const BgzfBlock& b = blocks[i];
+            if (!b.isize) continue;
+            std::memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) { ok[t] = 0; return; }
+            zs.next_in = (Bytef*)&d[b.coff];
+            zs.avail_in = b.clen;
+            zs.next_out = out + (b.uoff - out_base);
+            zs.avail_out = b.isize;
+            int rc = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END) { ok[t] = 0; return; }
+        }
+    };
+    if (n_threads <= 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; ++t) th.emplace_back(work, t);
+        for (auto& x : th) x.join();
+    }
+    for (char c : ok) if (!c) return false;
+    return true;
+}
+
+inline int32_t rd32(const uint8_t* p) { int32_t v; std::memcpy(&v, p, 4); return v; }
+inline uint16_t rd16(const uint8_t* p) { uint16_t v; std::memcpy(&v, p, 2); return v; }
+
+// aux scan: XA present, IH value (integer typed) -- SegmentGraph.cpp:297-301
+bool scan_tags(const uint8_t* p, const uint8_t* e, bool& has_xa, int& ih) {
+    has_xa = false;
+    bool has_ih = false;
+    ih = 0;
+    while (p + 3 <= e) {
+        uint8_t t0 = p[0], t1 = p[1], ty = p[2];
+        const uint8_t* v = p + 3;
+        size_t sz;
+        switch (ty) {
+            case 'A': case 'c': case 'C': sz = 1; break;
+            case 's': case 'S': sz = 2; break;
+            case 'i': case 'I': case 'f': sz = 4; break;
+            case 'Z': case 'H': { const uint8_t* q = v; while (q < e && *q) ++q; if (q >= e) return false; sz = (size_t)(q - v) + 1; break; }
+            case 'B': {
+                if (v + 5 > e) return false;
+                size_t es = (v[0] == 'c' || v[0] == 'C') ? 1 : ((v[0] == 's' || v[0] == 'S') ? 2 : 4);
+                uint32_t n; std::memcpy(&n, v + 1, 4);
+                sz = 5 + es * n;
+                break;
+            }
+            default: return false;
+        }
+        if (v + sz > e) return false;
+        if (t0 == 'X' && t1 == 'A') has_xa = true;
+        if (t0 == 'I' && t1 == 'H' && !has_ih) {
+            has_ih = true;
+            uint32_t x = 0;
+            if (ty == 'c' || ty == 'C' || ty == 'A') x = v[0];
+            else if (ty == 's' || ty == 'S') x = v[0] | (v[1] << 8);
+            else if (ty == 'i' || ty == 'I') x = v[0] | (v[1] << 8) | (v[2] << 16) | ((uint32_t)v[3] << 24);
+            ih = (int)x;
+        }
+        p = v + sz;
+    }
+    return true;
+}
+
+}  // namespace
+
+int read_bam_header(const char* path, std::vector<std::string>& names, std::vector<int32_t>& lens, std::string& err) {
+    FileBytes fb;
+    if (!fb.load(path)) { err = std::string("cannot open bamfile ") + path; return SQ_E_IO; }
+    std::vector<BgzfBlock> blocks;
+    size_t total;
+    if (!index_bgzf(fb.data, blocks, total)) { err = "not a BGZF file"; return SQ_E_IO; }
+    // the header may span several blocks: inflate until it is complete
+    std::vector<uint8_t> u;
+    size_t nb = 0;
+    auto need = [&](size_t n) {
+        while (u.size() < n && nb < blocks.size()) {
+            size_t old = u.size();
+            u.resize(old + blocks[nb].isize);
+            BgzfBlock b = blocks[nb];
+            std::vector<BgzfBlock> one(1, b);
+            one[0].uoff = 0;
+            if (!inflate_range(fb.data, one, 0, 1, u.data() + old, 0, 1)) return false;
+            ++nb;
+        }
+        return u.size() >= n;
+    };
+    if (!need(12) || std::memcmp(u.data(), "BAM\1", 4) != 0) { err = "not a BAM file"; return SQ_E_IO; }
+    int32_t ltext = rd32(&u[4]);
+    if (!need(12 + (size_t)ltext)) { err = "truncated header"; return SQ_E_IO; }
+    // names and lengths come from the header TEXT, as in ReadRec.cpp:274-279 (stoi on LN)
+    std::string text((const char*)&u[8], (size_t)ltext);
+    names.clear();
+    lens.clear();
+    size_t i = 0;
+    while (i < text.size()) {
+        size_t e = text.find('\n', i);
+        if (e == std::string::npos) e = text.size();
+        if (text.compare(i, 3, "@SQ") == 0) {
+            std::string sn, ln;
+            size_t f = i;
+            while (f < e) {
+                size_t t = text.find('\t', f);
+                if (t == std::string::npos || t > e) t = e;
+                if (text.compare(f, 3, "SN:") == 0) sn = text.substr(f + 3, t - f - 3);
+                if (text.compare(f, 3, "LN:") == 0) ln = text.substr(f + 3, t - f - 3);
+                f = t + 1;
+            }
+            names.push_back(sn);
+            lens.push_back(std::atoi(ln.c_str()));
+        }
+        i = e + 1;
+    }
+    return SQ_OK;
+}
+
+int parse_bam_file(const char* path, const ParseOpts& o, size_t batch_records, int n_threads, std::string& err,
+                   const std::function<int(const HostBatch&)>& sink) {
+    FileBytes fb;
+    if (!fb.load(path)) { err = std::string("cannot open bamfile ") + path; return SQ_E_IO; }
+    std::vector<BgzfBlock> blocks;
+    size_t total;
+    if (!index_bgzf(fb.data, blocks, total)) { err = "not a BGZF file"; return SQ_E_IO; }
+    n_threads = std::max(1, n_threads);
+
+    const size_t kChunkBlocks = 2048;  // <= 128 MiB inflated per round
+    std::vector<uint8_t> u;            // inflated bytes not yet consumed
+    size_t nb = 0;
+    size_t consumed = 0;
+    auto refill = [&]() -> bool {
+        if (nb >= blocks.size()) return false;
+        if (consumed) { u.erase(u.begin(), u.begin() + consumed); consumed = 0; }
+        size_t b1 = std::min(blocks.size(), nb + kChunkBlocks);
+        size_t base = blocks[nb].uoff, bytes = (b1 == blocks.size() ? total : blocks[b1].uoff) - base;
+        size_t old = u.size();
+        u.resize(old + bytes);
+        bool ok = inflate_range(fb.data, blocks, nb, b1, u.data() + old, base, n_threads);
+        nb = b1;
+        return ok;
+    };
+    auto need = [&](size_t n) -> bool {
+        while (u.size() - consumed < n) if (!refill()) return u.size() - consumed >= n;
+        return true;
+    };
+    // ---- header
+    if (!need(12) || std::memcmp(&u[consumed], "BAM\1", 4) != 0) { err = "not a BAM file"; return SQ_E_IO; }
+    int32_t ltext = rd32(&u[consumed + 4]);
+    if (!need(12 + (size_t)ltext)) { err = "truncated header"; return SQ_E_IO; }
+    int32_t nref = rd32(&u[consumed + 8 + ltext]);
+    consumed += 12 + (size_t)ltext;
+    for (int i = 0; i < nref; ++i) {
+        if (!need(4)) { err = "truncated header"; return SQ_E_IO; }
+        int32_t ln = rd32(&u[consumed]);
+        if (!need(8 + (size_t)ln)) { err = "truncated header"; return SQ_E_IO; }
+        consumed += 8 + (size_t)ln;
+    }
+    // ---- records
+    HostBatch hb;
+    hb.clear();
+    const int thr = (signed char)(((o.phred_type ? 33 : 64) + o.min_phred) & 0xff);
+    std::string namebuf;
+    static const char cigops[] = "MIDNSHP=X???????";
+    struct Op { char t; int len; };
+    std::vector<Op> cig;
+    while (need(4)) {
+        int32_t bs = rd32(&u[consumed]);
+        if (bs < 32 || !need(4 + (size_t)bs)) { err = "truncated record"; return SQ_E_IO; }
+        const uint8_t* p = &u[consumed + 4];
+        const uint8_t* pend = p + bs;
+        consumed += 4 + (size_t)bs;
+        int32_t refid = rd32(p), pos = rd32(p + 4);
+        int lname = p[8];
+        int mapq = p[9];
+        int ncig = rd16(p + 12);
+        int flag = rd16(p + 14);
+        int32_t lseq = rd32(p + 16), mrefid = rd32(p + 20), mpos = rd32(p + 24);
+        const uint8_t* name = p + 32;
+        const uint8_t* cg = name + lname;
+        const uint8_t* seq = cg + 4 * (size_t)ncig;
+        const uint8_t* qual = seq + (lseq + 1) / 2;
+        const uint8_t* aux = qual + lseq;
+        if (aux > pend) { err = "corrupt record"; return SQ_E_IO; }
+        size_t nlen = lname > 0 ? (size_t)lname - 1 : 0;
+
+        cig.resize(ncig);
+        int totlen = 0, endpos = pos;
+        for (int i = 0; i < ncig; ++i) {
+            uint32_t v = (uint32_t)rd32(cg + 4 * i);
+            cig[i].t = cigops[v & 0xf];
+            cig[i].len = (int)(v >> 4);
+            char t = cig[i].t;
+            if (t == 'M' || t == 'S' || t == 'H' || t == 'I' || t == '=' || t == 'X') totlen += cig[i].len;
+            if (t == 'M' || t == 'D' || t == 'N' || t == '=' || t == 'X') endpos += cig[i].len;  // GetEndPosition()
+        }
+        // longest run of qualities below the threshold (signed-char compare like the reference)
+        int lowrun = 0, run = 0;
+        for (int i = 0; i < lseq; ++i) {
+            int c = (signed char)((qual[i] + 33) & 0xff);
+            run = (c < thr) ? run + 1 : 0;
+            if (run > lowrun) lowrun = run;
+        }
+        bool has_xa = false;
+        int ih = 0;
+        if (!scan_tags(aux, pend, has_xa, ih)) { err = "corrupt aux data"; return SQ_E_IO; }
+        uint8_t ax = 0;
+        if (has_xa || ih > 1) ax |= SQ_AUX_MULTI;
+        if (lowrun > o.max_lowphred_len) ax |= SQ_AUX_LOWPHRED;
+        if (o.inchim) {
+            namebuf.assign((const char*)name, nlen);
+            if (o.inchim->count(namebuf)) ax |= SQ_AUX_INCHIM;
+        }
+        // CIGAR -> aligned blocks (ReadRec.cpp:45-87)
+        bool rev = flag & 0x10;
+        int readpos = 0, refpos = pos, hardclip = 0;
+        bool violated = false;
+        for (int ic = 0; ic < ncig; ++ic) {
+            char t = cig[ic].t;
+            if (t == 'S' || t == 'H') {
+                readpos += cig[ic].len;
+                if (t == 'H') hardclip += cig[ic].len;
+            } else if (t == 'M' || t == '=') {
+                int tr = 0, tf = 0, ic2;
+                for (ic2 = ic; ic2 < ncig && cig[ic2].t != 'S' && cig[ic2].t != 'H' && cig[ic2].t != 'N'; ++ic2) {
+                    if (cig[ic2].t != 'D') tr += cig[ic2].len;
+                    if (cig[ic2].t != 'I') tf += cig[ic2].len;
+                }
+                int s0 = readpos - hardclip, s1 = readpos + tr - hardclip;
+                if (!(readpos >= hardclip && s1 <= lseq)) { violated = true; break; }  // assert of ReadRec.cpp:64
+                int na = 0, nt = 0;
+                for (int i = s0; i < s1; ++i) {
+                    int code = (seq[i >> 1] >> ((~i & 1) << 2)) & 0xf;
+                    na += code == 1;
+                    nt += code == 8;
+                }
+                if (4 * na < 3 * tr && 4 * nt < 3 * tr) {  // 1.0*count/tmpRead < 0.75, exact in integers
+                    hb.b_refpos.push_back(refpos);
+                    hb.b_matchref.push_back(tf);
+                    hb.b_readpos.push_back((uint16_t)(rev ? totlen - readpos - tr : readpos));
+                    hb.b_matchread.push_back((uint16_t)tr);
+                }
+                readpos += tr;
+                refpos += tf;
+                ic = ic2 - 1;
+            } else if (t == 'N')
+                refpos += cig[ic].len;
+        }
+        if (violated) {
+            // the reference only constructs a ReadRec_t for records that survive its filters; for those the
+            // assert is live (no -DNDEBUG in the Makefile) and the run aborts
+            bool filtered = (ax & (SQ_AUX_MULTI | SQ_AUX_INCHIM)) || (flag & 0x400) || (flag & 0x4) || mapq < 0;
+            if (!filtered && !o.keep_names) { err = "record without stored bases for an aligned block (reference asserts, ReadRec.cpp:64)"; return SQ_E_ASSERT; }
+            if (o.keep_names && !(flag & 0x4) && !(flag & 0x400)) { err = "chimeric record without stored bases (reference asserts, ReadRec.cpp:64)"; return SQ_E_ASSERT; }
+            hb.b_refpos.resize(hb.blk_off.back()); hb.b_matchref.resize(hb.blk_off.back());
+            hb.b_readpos.resize(hb.blk_off.back()); hb.b_matchread.resize(hb.blk_off.back());
+        }
+        hb.refid.push_back(refid); hb.pos.push_back(pos); hb.mrefid.push_back(mrefid); hb.mpos.push_back(mpos); hb.endpos.push_back(endpos);
+        hb.flag.push_back((uint16_t)flag); hb.mapq.push_back((uint8_t)mapq); hb.aux.push_back(ax); hb.totlen.push_back((uint16_t)totlen);
+        hb.blk_off.push_back((uint32_t)hb.b_refpos.size());
+        if (o.keep_names) {
+            hb.names.insert(hb.names.end(), (const char*)name, (const char*)name + nlen);
+            hb.name_off.push_back((uint32_t)hb.names.size());
+        }
+        if (hb.size() >= batch_records) {
+            int rc = sink(hb);
+            if (rc) return rc;
+            hb.clear();
+        }
+    }
+    if (hb.size()) {
+        int rc = sink(hb);
+        if (rc) return rc;
+    }
+    return SQ_OK;
+}
+
+}  // namespace sq

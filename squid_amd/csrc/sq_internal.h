@@ -1,0 +1,186 @@
+// Internal declarations of libsquid_hip.so (host side).  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/squid_hip.h"
+
+namespace sq {
+
+// ---------------------------------------------------------------------------------------------- host model
+// one aligned block of a chimeric fragment (host side is AoS: N_x is ~1 % of N_c)
+struct Blk {
+    int32_t refid, refpos, readpos, matchref, matchread;
+    bool rev;
+    bool first;  // IsFirstRead of the record the block came from (only used by the B11 `Same` quirk)
+};
+struct Frag {  // merged chimeric fragment = ReadRec_t after BuildChimericSBamRecord
+    std::string name;
+    std::vector<Blk> a, b;  // first-in-pair blocks, second-in-pair blocks (sorted by read offset)
+    int atot = 0, btot = 0;
+    bool alow = false, blow = false;
+};
+struct Node {
+    int32_t chr, pos, len, support;
+    double depth;
+};
+struct Edge {
+    int32_t a, b;  // a <= b
+    uint8_t ha, hb;
+    int32_t w, gw;
+};
+inline bool edge_key_less(const Edge& x, const Edge& y) {
+    if (x.a != y.a) return x.a < y.a;
+    if (x.b != y.b) return x.b < y.b;
+    if (x.ha != y.ha) return x.ha < y.ha;
+    return x.hb < y.hb;
+}
+inline bool edge_key_eq(const Edge& x, const Edge& y) { return x.a == y.a && x.b == y.b && x.ha == y.ha && x.hb == y.hb; }
+inline Edge make_edge(int i, bool hi, int j, bool hj, int w = 1) {
+    Edge e;
+    if (i > j) { e.a = j; e.ha = hj; e.b = i; e.hb = hi; }
+    else { e.a = i; e.ha = hi; e.b = j; e.hb = hj; }
+    e.w = w;
+    e.gw = 0;
+    return e;
+}
+inline uint64_t edge_pack(const Edge& e) { return ((uint64_t)(uint32_t)e.a << 32) | ((uint64_t)(uint32_t)e.b << 2) | ((uint64_t)e.ha << 1) | e.hb; }
+
+struct GraphSnap {  // flattened copy for sq_graph_view
+    std::vector<int32_t> chr, pos, len, support, label, ind1, ind2, weight, gweight;
+    std::vector<double> depth;
+    std::vector<uint8_t> h1, h2;
+    void take(const std::vector<Node>& N, const std::vector<Edge>& E, const std::vector<int32_t>* lab);
+    void view(sq_graph* g) const;
+};
+
+// per-record summary of the kept pass-1 stream, produced on the GPU for the host segmentation automaton
+struct StreamRec {
+    int32_t refid, pos;      // record.RefID / record.Position
+    int32_t fb_refpos, fb_matchref;  // first aligned block in CIGAR order (ReadsMain / window element)
+    uint16_t fb_readpos;
+    uint8_t flags;           // SR_* bits
+    uint8_t nrest;           // number of further blocks (saturated at 255)
+    uint32_t rest_off;       // offset of the further blocks in the rest arrays
+};
+enum : uint8_t { SR_HASBLK = 1, SR_CONC = 2, SR_PART = 4, SR_REV = 8, SR_MATE = 16 /* 0x40 or 0x80 set */ };
+
+struct Timer {
+    std::vector<const char*> names;
+    std::vector<double> ms, bytes;
+    std::vector<int64_t> launches;
+    int slot(const char* name);
+    void add(const char* name, double ms_, double bytes_ = 0, int64_t n = 1);
+    void clear();
+};
+
+struct DeviceRecords;  // HBM-resident SoA + scratch (sq_kernels.hip)
+
+}  // namespace sq
+
+struct sq_ctx {
+    sq_params P;
+    std::string err;
+    hipStream_t stream = nullptr;
+    std::vector<int32_t> ref_len;
+    // chimeric side (host)
+    int read_len = 0;
+    std::vector<sq::Frag> frags, frags0;        // frags0: untrimmed copy restored by sq_reset
+    std::vector<std::string> chim_names;        // sorted unique, incl. "" (ledger B9)
+    std::unordered_set<std::string> chim_set;
+    int64_t n_chim_records = 0;
+    // concordant side (device)
+    sq::DeviceRecords* dev = nullptr;
+    // graph state (host, small)
+    std::vector<sq::Node> nodes;
+    std::vector<sq::Edge> edges;
+    std::vector<int32_t> label;
+    sq::GraphSnap snap[6];
+    bool graph_built = false, ordered = false;
+    std::vector<int32_t> ord_off, ord_nodes;
+    // sv output
+    std::vector<int32_t> sv_cols[9];
+    std::vector<uint8_t> sv_s1, sv_s2;
+    std::vector<int32_t> bp_off, bp1, bp2, bsup1, bsup2;
+    sq::Timer timer;
+    sq_counts counts{};
+    std::vector<uint8_t> xbuf;  // exchange pack buffer
+};
+
+namespace sq {
+
+int fail(sq_ctx* c, int code, const std::string& msg);
+
+// ---- sq_bam.cpp
+struct HostBatch {  // owning storage behind an sq_aln_batch
+    std::vector<int32_t> refid, pos, mrefid, mpos, endpos, b_refpos, b_matchref;
+    std::vector<uint16_t> flag, totlen, b_readpos, b_matchread;
+    std::vector<uint8_t> mapq, aux;
+    std::vector<uint32_t> blk_off, name_off;
+    std::vector<char> names;
+    void clear();
+    void view(sq_aln_batch* b, bool with_names) const;
+    size_t size() const { return refid.size(); }
+};
+int read_bam_header(const char* path, std::vector<std::string>& names, std::vector<int32_t>& lens, std::string& err);
+// streams the file; calls sink(batch) every `batch_records` records.  inchim may be null.
+struct ParseOpts { int phred_type, min_phred, max_lowphred_len; bool keep_names; const std::unordered_set<std::string>* inchim; };
+int parse_bam_file(const char* path, const ParseOpts& o, size_t batch_records, int n_threads, std::string& err,
+                   const std::function<int(const HostBatch&)>& sink);
+
+// ---- sq_chimeric.cpp
+int build_fragments(sq_ctx* c, const sq_aln_batch* b);
+bool frag_end_discordant(const Frag& f, bool first);
+bool frag_pair_discordant(const Frag& f, bool needcheck);
+bool frag_single_anchored(const Frag& f);
+bool frag_equal(const Frag& x, const Frag& y);
+
+// ---- sq_segment.cpp  (host control of K2; counting data comes from the GPU summaries)
+struct SegmentInput {
+    const StreamRec* recs; int64_t n;
+    const int32_t* rest_refpos; const int32_t* rest_matchref;
+};
+int segment_genome(sq_ctx* c, const SegmentInput& in, std::vector<Node>& seeds, int64_t& n_break,
+                   std::vector<Blk>& bamdiscordant_sorted);
+int tile_genome(sq_ctx* c, std::vector<Node>& seeds, std::vector<Node>& out);
+
+// ---- sq_graph.cpp
+struct Located { std::vector<int> node; };
+bool edge_discordant(const sq_ctx* c, const std::vector<Node>& N, const Edge& e);
+int locate_fragment(const std::vector<Node>& N, int hint, Frag& f, std::vector<int>& out);  // trims f in place
+int chimeric_edges(sq_ctx* c, std::vector<Edge>& raw);
+void reduce_edges(std::vector<Edge>& raw, std::vector<Edge>& out);
+void filter_by_weight(sq_ctx* c);
+void filter_by_interleaving(sq_ctx* c, std::vector<uint8_t>& keep);
+void filter_edges(sq_ctx* c, const std::vector<uint8_t>& keep);
+int compress_nodes(sq_ctx* c);
+int further_compress(sq_ctx* c);
+void multiply_discordant(sq_ctx* c, bool undo);
+typedef std::map<uint64_t, std::vector<std::pair<int, int>>> BPMap;
+int exact_breakpoints(sq_ctx* c, BPMap& bp);
+
+// ---- sq_order.cpp
+int order_components(sq_ctx* c);
+
+// ---- sq_kernels.hip (device side; every function enqueues on c->stream and records HIP-event timings)
+int dev_create(sq_ctx* c);
+void dev_destroy(sq_ctx* c);
+int dev_append_records(sq_ctx* c, const sq_aln_batch* b);
+int dev_classify_and_summarise(sq_ctx* c, std::vector<StreamRec>& recs, std::vector<int32_t>& rest_refpos, std::vector<int32_t>& rest_matchref);
+int dev_node_depth(sq_ctx* c, const std::vector<Node>& nodes, int64_t n_break, std::vector<int32_t>& support, std::vector<int64_t>& sumlen,
+                   bool& need_exact_other, std::vector<int32_t>& other_chr, std::vector<int32_t>& other_pos, std::vector<int32_t>& other_len);
+int dev_concordant_edges(sq_ctx* c, const std::vector<Node>& nodes, std::vector<Edge>& unique_edges);
+int dev_connected_components(sq_ctx* c, int n_nodes, const std::vector<Edge>& edges, std::vector<int32_t>& label);
+struct SmallProblem { int n; int eoff, ecount; };  // edges: local u,v,hu,hv,w packed as 5 ints each
+int dev_order_small(sq_ctx* c, const std::vector<SmallProblem>& probs, const std::vector<int32_t>& edges5, std::vector<int32_t>& out_mask,
+                    std::vector<int32_t>& out_order, int nmax);
+int dev_breakpoint_support(sq_ctx* c, const std::vector<std::pair<int, int>>& bps_sorted, std::vector<int32_t>& coverage);
+
+}  // namespace sq

@@ -1,0 +1,1244 @@
+// HIP kernels of the SQUID hot path for gfx950 (MI355X) and their launch wrappers.
+//
+// HBM layout (DeviceRecords): the concordant alignment stream as structure-of-arrays, 32 B per record
+// (refid,pos,mate_refid,mate_pos,end_pos i32; flag,totlen u16; mapq,aux u8; blk_off u32) plus 12 B per aligned
+// block (refpos,matchref i32; readpos,matchread u16) -- SURVEY.md section 8(d).  Every kernel below is a
+// coalesced scan over those arrays with one thread per record; the node table (a few thousand entries) and the
+// breakpoint table are binary-searched out of L2.  All work is integer/index work: no MFMA anywhere.
+//
+// Kernel <-> reference loop:
+//   k_classify      record filters + concordant/partial classification   SegmentGraph.cpp:297-303,651-683,1579-1585,3131-3142
+//   k_dedup         consecutive-duplicate drop (ReadRec_t::Equal)         SegmentGraph.cpp:304-318,1587-1600 ; ReadRec.cpp:119-141
+//   k_summarise     window elements for the segmentation automaton        SegmentGraph.cpp:320-337,668-699
+//   k_depth_*       per-node Support / AvgDepth                           SegmentGraph.cpp:781-826
+//   k_block0/k_edges LocateRead chain + raw edge emission + weight count  SegmentGraph.cpp:1207-1293,1601-1686,1943-1949
+//   k_bp_*          breakpoint concordant-fragment support                SegmentGraph.cpp:3129-3166
+//   k_cc_*          connected components (union-find)                     SegmentGraph.cpp:2911-2935,2986-3003
+//   k_order_small   exact ordering of small components, one per workgroup SegmentGraph.cpp:3271-3314,3763-3983
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+
+#include "sq_internal.h"
+
+#define HIPCHK(call)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = (call);                                                                              \
+        if (e_ != hipSuccess) return sq::fail(c, SQ_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+namespace sq {
+
+// ------------------------------------------------------------------------------------------------ device state
+struct RecView {  // raw device pointers, passed by value to kernels
+    int64_t n, nb;
+    const int32_t *refid, *pos, *mrefid, *mpos, *endpos;
+    const uint16_t *flag, *totlen;
+    const uint8_t *mapq, *aux;
+    const uint32_t* blk_off;
+    const int32_t *b_refpos, *b_matchref;
+    const uint16_t *b_readpos, *b_matchread;
+};
+struct NodeView {
+    int32_t n, n_ref;
+    const int32_t *chr, *pos, *len;
+    const int32_t* chr_start;  // n_ref+1: first node index of each chromosome
+};
+
+template <typename T>
+struct DBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 8 + 64;
+        hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    hipError_t grow_keep(size_t used, size_t n, hipStream_t s) {  // keep the first `used` elements
+        if (n <= cap) return hipSuccess;
+        size_t want = std::max(n + n / 2, (size_t)1 << 16);
+        T* q = nullptr;
+        hipError_t e = hipMalloc((void**)&q, want * sizeof(T));
+        if (e != hipSuccess) return e;
+        if (used) e = hipMemcpyAsync(q, p, used * sizeof(T), hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (p) (void)hipFree(p);
+        p = q;
+        cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct DeviceRecords {
+    int64_t n = 0, nb = 0;
+    DBuf<int32_t> refid, pos, mrefid, mpos, endpos, b_refpos, b_matchref;
+    DBuf<uint16_t> flag, totlen, b_readpos, b_matchread;
+    DBuf<uint8_t> mapq, aux;
+    DBuf<uint32_t> blk_off;
+    // derived
+    DBuf<uint8_t> cls, keep;
+    DBuf<int32_t> prev1, prev2, rank1, restoff, scratch_a, scratch_b, scratch_c, spine;
+    DBuf<int32_t> part_prev, part_next, b0_a, b0_b, b0_home;
+    DBuf<StreamRec> srec;
+    DBuf<int32_t> rest_refpos, rest_matchref;
+    // node table
+    DBuf<int32_t> n_chr, n_pos, n_len, n_chr_start;
+    DBuf<int32_t> acc_a, acc_b, acc_c, acc_d;  // per-node accumulators
+    // edge hash
+    DBuf<unsigned long long> h_key;
+    DBuf<uint32_t> h_val;
+    DBuf<long long> gather_key;
+    DBuf<int32_t> flags;  // small device flag/counter block
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int64_t k1 = 0;  // kept pass-1 records
+    RecView view() const {
+        RecView v;
+        v.n = n; v.nb = nb;
+        v.refid = refid.p; v.pos = pos.p; v.mrefid = mrefid.p; v.mpos = mpos.p; v.endpos = endpos.p;
+        v.flag = flag.p; v.totlen = totlen.p; v.mapq = mapq.p; v.aux = aux.p; v.blk_off = blk_off.p;
+        v.b_refpos = b_refpos.p; v.b_matchref = b_matchref.p; v.b_readpos = b_readpos.p; v.b_matchread = b_matchread.p;
+        return v;
+    }
+};
+
+// classification bits (cls)
+enum : uint8_t { C_P2 = 1, C_P1 = 2, C_P3 = 4, C_CONC = 8, C_PART = 16, C_HASSTUB = 32 };
+// keep bits
+enum : uint8_t { K_1 = 1, K_2 = 2, K_BUILD = 4 };
+
+// ------------------------------------------------------------------------------------------------ device helpers
+struct DBlk { int32_t refid, refpos, matchref, readpos, matchread; bool rev; };
+
+// own blocks in read-offset order (SortbyReadPos): CIGAR order on the forward strand, reversed otherwise
+__device__ __forceinline__ DBlk own_block_sorted(const RecView& R, int64_t r, int k, int nblk, bool rev) {
+    uint32_t b = R.blk_off[r] + (rev ? (uint32_t)(nblk - 1 - k) : (uint32_t)k);
+    DBlk x;
+    x.refid = R.refid[r]; x.refpos = R.b_refpos[b]; x.matchref = R.b_matchref[b];
+    x.readpos = R.b_readpos[b]; x.matchread = R.b_matchread[b]; x.rev = rev;
+    return x;
+}
+__device__ __forceinline__ bool has_stub(const RecView& R, int64_t r) { return !(R.flag[r] & 0x8) && R.mrefid[r] != -1; }
+
+// element k of list L (0 = FirstRead, 1 = SecondMate) of the stub-augmented, sorted record (tmpreadrec)
+struct ListRec {
+    int nown; bool first, rev, stub;
+    __device__ int size(int L) const { bool own = (L == 0) == first; return own ? nown : (stub ? 1 : 0); }
+};
+__device__ __forceinline__ ListRec list_rec(const RecView& R, int64_t r) {
+    ListRec l;
+    l.nown = (int)(R.blk_off[r + 1] - R.blk_off[r]);
+    l.first = R.flag[r] & 0x40;
+    l.rev = R.flag[r] & 0x10;
+    l.stub = has_stub(R, r);
+    return l;
+}
+__device__ __forceinline__ void list_key(const RecView& R, int64_t r, const ListRec& l, int L, int k, int& id, int& p, int& m) {
+    bool own = (L == 0) == l.first;
+    if (own) { DBlk b = own_block_sorted(R, r, k, l.nown, l.rev); id = b.refid; p = b.refpos; m = b.matchref; }
+    else { id = R.mrefid[r]; p = R.mpos[r]; m = 15; }
+}
+// ReadRec_t::Equal on two records; q < 0 stands for the empty initial lastreadrec
+__device__ bool rec_equal(const RecView& R, int64_t q, int64_t r) {
+    ListRec lr = list_rec(R, r);
+    ListRec lq;
+    if (q >= 0) lq = list_rec(R, q);
+    else { lq.nown = 0; lq.first = true; lq.rev = false; lq.stub = false; }
+    for (int swap = 0; swap < 2; ++swap) {
+        int q0 = lq.size(swap ? 1 : 0), q1 = lq.size(swap ? 0 : 1);
+        if (q0 != lr.size(0) || q1 != lr.size(1)) continue;
+        bool same = true;
+        for (int L = 0; L < 2 && same; ++L) {
+            int n = lr.size(L);
+            for (int k = 0; k < n; ++k) {
+                int a0, a1, a2, b0, b1, b2;
+                list_key(R, r, lr, L, k, a0, a1, a2);
+                list_key(R, q, lq, swap ? 1 - L : L, k, b0, b1, b2);
+                if (a0 != b0 || a1 != b1 || a2 != b2) { same = false; break; }
+            }
+        }
+        if (same) return true;
+    }
+    return false;
+}
+
+// last node with (chr,pos) <= (c,p); nodes tile every chromosome, so this is the node containing p
+__device__ __forceinline__ int node_home(const NodeView& N, int c, int p) {
+    int lo = N.chr_start[c], hi = N.chr_start[c + 1];  // [lo,hi)
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (N.pos[mid] <= p) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// ------------------------------------------------------------------------------------------------ scans
+// Three-phase device scan over int32 values produced by a functor: tile reduce -> spine -> tile down-sweep.
+constexpr int SCAN_THREADS = 256, SCAN_ITEMS = 8, SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+
+struct OpSum { static __device__ __forceinline__ int id() { return 0; } static __device__ __forceinline__ int op(int a, int b) { return a + b; } };
+struct OpMax { static __device__ __forceinline__ int id() { return INT_MIN; } static __device__ __forceinline__ int op(int a, int b) { return a > b ? a : b; } };
+struct OpMin { static __device__ __forceinline__ int id() { return INT_MAX; } static __device__ __forceinline__ int op(int a, int b) { return a < b ? a : b; } };
+
+template <typename Op>
+__device__ __forceinline__ int block_scan_excl(int v, int& total, int* lds) {  // exclusive scan of one value per thread
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int x = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        int y = __shfl_up(x, d, 64);
+        if (lane >= d) x = Op::op(x, y);
+    }
+    if (lane == 63) lds[wave] = x;
+    __syncthreads();
+    int wprefix = Op::id();
+    int tot = Op::id();
+    for (int w = 0; w < SCAN_THREADS / 64; ++w) {
+        int t = lds[w];
+        if (w < wave) wprefix = Op::op(wprefix, t);
+        tot = Op::op(tot, t);
+    }
+    __syncthreads();
+    total = tot;
+    int incl = Op::op(wprefix, x);
+    int prev = __shfl_up(incl, 1, 64);
+    if (lane == 0) prev = wprefix;
+    return prev;
+}
+
+template <typename Op, typename F>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(int64_t n, F f, int32_t* tile_agg) {
+    __shared__ int lds[SCAN_THREADS / 64];
+    int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+    int acc = Op::id();
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        int64_t idx = base + (int64_t)i * SCAN_THREADS + threadIdx.x;
+        if (idx < n) acc = Op::op(acc, f(idx));
+    }
+    int total;
+    block_scan_excl<Op>(acc, total, lds);
+    if (threadIdx.x == 0) tile_agg[blockIdx.x] = total;
+}
+template <typename Op>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_spine(int ntiles, int32_t* tile_agg, int32_t* grand) {
+    __shared__ int lds[SCAN_THREADS / 64];
+    int carry = Op::id();
+    for (int base = 0; base < ntiles; base += SCAN_THREADS) {
+        int i = base + threadIdx.x;
+        int v = i < ntiles ? tile_agg[i] : Op::id();
+        int total;
+        int ex = block_scan_excl<Op>(v, total, lds);
+        if (i < ntiles) tile_agg[i] = Op::op(carry, ex);
+        carry = Op::op(carry, total);
+    }
+    if (threadIdx.x == 0 && grand) *grand = carry;
+}
+// exclusive (EXCL) or inclusive result; items are laid out blocked per thread so that order is preserved
+template <typename Op, bool EXCL, typename F>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_down(int64_t n, F f, const int32_t* tile_prefix, int32_t* out) {
+    __shared__ int lds[SCAN_THREADS / 64];
+    int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int acc = Op::id();
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        v[i] = (base + i < n) ? f(base + i) : Op::id();
+        acc = Op::op(acc, v[i]);
+    }
+    int total;
+    int ex = block_scan_excl<Op>(acc, total, lds);
+    int run = Op::op(tile_prefix[blockIdx.x], ex);
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        if (base + i < n) {
+            if (EXCL) { out[base + i] = run; run = Op::op(run, v[i]); }
+            else { run = Op::op(run, v[i]); out[base + i] = run; }
+        }
+    }
+}
+// NOTE: k_scan_reduce reads strided while k_scan_down reads blocked; both cover the same tile, and Op is
+// commutative for all three instantiations, so the tile aggregates agree.
+
+template <typename Op, bool EXCL, typename F>
+static hipError_t device_scan(hipStream_t s, int64_t n, F f, int32_t* out, DBuf<int32_t>& spine, int32_t* grand) {
+    if (n <= 0) { if (grand) return hipMemsetAsync(grand, 0, 4, s); return hipSuccess; }
+    int ntiles = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
+    hipError_t e = spine.reserve((size_t)ntiles);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_scan_reduce<Op, F>), dim3(ntiles), dim3(SCAN_THREADS), 0, s, n, f, spine.p);
+    hipLaunchKernelGGL((k_scan_spine<Op>), dim3(1), dim3(SCAN_THREADS), 0, s, ntiles, spine.p, grand);
+    hipLaunchKernelGGL((k_scan_down<Op, EXCL, F>), dim3(ntiles), dim3(SCAN_THREADS), 0, s, n, f, spine.p, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ K1: classify
+__global__ void k_classify(RecView R, int min_mapq, uint8_t* cls) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R.n) return;
+    const int flag = R.flag[r], aux = R.aux[r];
+    const int refid = R.refid[r], pos = R.pos[r], mrefid = R.mrefid[r], mpos = R.mpos[r];
+    const bool mapped = !(flag & 0x4), matemapped = !(flag & 0x8), rev = flag & 0x10, materev = flag & 0x20;
+    const bool first = flag & 0x40, second = flag & 0x80, proper = flag & 0x2, dup = flag & 0x400;
+    uint8_t c = 0;
+    bool p2 = !(aux & SQ_AUX_MULTI) && !(aux & SQ_AUX_INCHIM) && !dup && mapped && (int)R.mapq[r] >= min_mapq;
+    bool p1 = p2 && refid != -1;
+    if (p2) c |= C_P2;
+    if (p1) c |= C_P1;
+    if (p1) {
+        bool skip = (matemapped && mrefid == refid && mpos > pos) || (matemapped && mrefid == refid && mpos == pos && second);
+        if (!skip) c |= C_P3;
+    }
+    if (matemapped && mrefid != -1) c |= C_HASSTUB;
+    const int nblk = (int)(R.blk_off[r + 1] - R.blk_off[r]);
+    bool conc = false;
+    if (mapped && matemapped && mrefid != -1 && refid == mrefid && proper) {
+        if (rev && !materev && pos >= mpos && pos - mpos <= 750000) conc = true;
+        else if (!rev && materev && mpos >= pos && mpos - pos <= 750000) conc = true;
+    }
+    if (conc && nblk > 0) {
+        c |= C_CONC;
+        // partial alignment: clipped by more than 15 bases at either read end and not low-Phred
+        // (the reference tests the record's own mate side; a record with neither 0x40 nor 0x80 matches no branch)
+        if ((first || second) && !(aux & SQ_AUX_LOWPHRED)) {
+            DBlk f = own_block_sorted(R, r, 0, nblk, rev), b = own_block_sorted(R, r, nblk - 1, nblk, rev);
+            if (f.readpos > 15 || (int)R.totlen[r] - b.readpos - b.matchread > 15) c |= C_PART;
+        }
+    }
+    cls[r] = c;
+}
+
+// functors for the scans
+struct FPrev { const uint8_t* cls; uint8_t bit; __device__ int operator()(int64_t i) const { return (cls[i] & bit) ? (int)i : -1; } };
+struct FKeep { const uint8_t* keep; uint8_t bit; __device__ int operator()(int64_t i) const { return (keep[i] & bit) ? 1 : 0; } };
+struct FRest {
+    const uint8_t *keep, *cls; const uint32_t* blk_off;
+    __device__ int operator()(int64_t i) const {
+        if (!(keep[i] & K_1) || !(cls[i] & C_CONC)) return 0;
+        int nb = (int)(blk_off[i + 1] - blk_off[i]);
+        return nb > 1 ? nb - 1 : 0;
+    }
+};
+
+__global__ void k_dedup(RecView R, const uint8_t* cls, const int32_t* prev1, const int32_t* prev2, uint8_t* keep) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R.n) return;
+    uint8_t c = cls[r], k = 0;
+    if (c & C_P1) { if (!rec_equal(R, prev1[r], r)) k |= K_1; }
+    if (c & C_P2) {
+        bool eq = (c & C_P1) && prev1[r] == prev2[r] ? !(k & K_1) : rec_equal(R, prev2[r], r);
+        if (!eq) {
+            k |= K_2;
+            // whetherbuildedge (SegmentGraph.cpp:1601-1605) on the stub-augmented, sorted record
+            ListRec l = list_rec(R, r);
+            bool build;
+            if (l.size(0) == 0 || l.size(1) == 0) build = true;
+            else {
+                // the stub side always has ReadPos 0 <= 15; the own side is tested with its own low-Phred flag
+                DBlk f = own_block_sorted(R, r, 0, l.nown, l.rev);
+                build = f.readpos <= 15 || (R.aux[r] & SQ_AUX_LOWPHRED);
+            }
+            if (build) k |= K_BUILD;
+        }
+    }
+    keep[r] = k;
+}
+
+__global__ void k_summarise(RecView R, const uint8_t* cls, const uint8_t* keep, const int32_t* rank1, const int32_t* restoff,
+                            StreamRec* out, int32_t* rest_refpos, int32_t* rest_matchref) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R.n || !(keep[r] & K_1)) return;
+    StreamRec s;
+    s.refid = R.refid[r]; s.pos = R.pos[r];
+    uint32_t b0 = R.blk_off[r];
+    int nblk = (int)(R.blk_off[r + 1] - b0);
+    uint8_t c = cls[r], fl = 0;
+    s.fb_refpos = 0; s.fb_matchref = 0; s.fb_readpos = 0; s.nrest = 0; s.rest_off = 0;
+    if (nblk > 0) {
+        fl |= SR_HASBLK;
+        s.fb_refpos = R.b_refpos[b0]; s.fb_matchref = R.b_matchref[b0]; s.fb_readpos = R.b_readpos[b0];
+    }
+    if (c & C_CONC) fl |= SR_CONC;
+    if (c & C_PART) fl |= SR_PART;
+    if (R.flag[r] & 0x10) fl |= SR_REV;
+    if (R.flag[r] & 0xC0) fl |= SR_MATE;
+    if ((c & C_CONC) && nblk > 1) {
+        s.nrest = (uint8_t)(nblk - 1 > 255 ? 255 : nblk - 1);
+        s.rest_off = (uint32_t)restoff[r];
+        for (int k = 1; k < nblk; ++k) { rest_refpos[restoff[r] + k - 1] = R.b_refpos[b0 + k]; rest_matchref[restoff[r] + k - 1] = R.b_matchref[b0 + k]; }
+    }
+    s.flags = fl;
+    out[rank1[r]] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ K3: node depth
+// Node at which the reference's monotone cursor (SegmentGraph.cpp:787-799 / :809-821) would first accept a
+// block starting at p: normally the node containing p; a block of <= 3 bases that starts right behind a node
+// boundary still "fits" the previous node(s) because of the +-3 slack.
+__device__ __forceinline__ int depth_early(const NodeView& N, int c, int p, int len, int& home) {
+    home = node_home(N, c, p);
+    int j = home;
+    if (len <= 3) {
+        int lo = N.chr_start[c];
+        while (j - 1 >= lo && N.pos[j - 1] + N.len[j - 1] + 3 >= p + len) --j;
+    }
+    return j;
+}
+struct FEarlyMain {  // first block of every consumed kept record, in stream order
+    RecView R; NodeView N; const uint8_t* keep; const int32_t* rank1; int32_t n_break;
+    __device__ int operator()(int64_t r) const {
+        if (!(keep[r] & K_1) || rank1[r] >= n_break) return -1;
+        uint32_t b0 = R.blk_off[r];
+        if (R.blk_off[r + 1] == b0) return -1;
+        int c = R.refid[r];
+        if (c < 0 || c >= N.n_ref) return -1;
+        int home;
+        return depth_early(N, c, R.b_refpos[b0], R.b_matchref[b0], home);
+    }
+};
+__global__ void k_depth(RecView R, NodeView N, const uint8_t* keep, const int32_t* rank1, int32_t n_break, const int32_t* cursor,
+                        int32_t* main_cnt, int32_t* main_sum, int32_t* other_cnt, int32_t* other_sum, int32_t* flags) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R.n || !(keep[r] & K_1) || rank1[r] >= n_break) return;
+    uint32_t b0 = R.blk_off[r];
+    int nblk = (int)(R.blk_off[r + 1] - b0);
+    if (nblk == 0) return;
+    int c = R.refid[r];
+    if (c < 0 || c >= N.n_ref) { atomicOr(&flags[0], 1); return; }
+    {   // ReadsMain: consumed at the prefix-max cursor
+        int p = R.b_refpos[b0], len = R.b_matchref[b0];
+        int at = cursor[r];
+        if (N.chr[at] != c) atomicOr(&flags[0], 1);  // cursor stuck on another chromosome: stream not sorted
+        else if (p >= N.pos[at] - 3 && p + len <= N.pos[at] + N.len[at] + 3) { atomicAdd(&main_cnt[at], 1); atomicAdd(&main_sum[at], len); }
+    }
+    for (int k = 1; k < nblk; ++k) {  // ReadsOther: sorted by (chr,pos) in the reference => consumed at its home node
+        int p = R.b_refpos[b0 + k], len = R.b_matchref[b0 + k];
+        int home;
+        int early = depth_early(N, c, p, len, home);
+        if (early != home) atomicOr(&flags[0], 2);  // tie-order sensitive corner: host resolves it exactly
+        atomicAdd(&flags[1], 1);
+        if (p + len <= N.pos[home] + N.len[home] + 3) { atomicAdd(&other_cnt[home], 1); atomicAdd(&other_sum[home], len); }
+    }
+}
+__global__ void k_gather_other(RecView R, const uint8_t* keep, const int32_t* rank1, int32_t n_break, int32_t* counter, int32_t* o_chr, int32_t* o_pos, int32_t* o_len,
+                               long long* o_rank) {
+    // slow exact path only: materialise ReadsOther (with its stream rank for the host to restore stream order)
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R.n || !(keep[r] & K_1) || rank1[r] >= n_break) return;
+    uint32_t b0 = R.blk_off[r];
+    int nblk = (int)(R.blk_off[r + 1] - b0);
+    for (int k = 1; k < nblk; ++k) {
+        int slot = atomicAdd(counter, 1);
+        o_chr[slot] = R.refid[r]; o_pos[slot] = R.b_refpos[b0 + k]; o_len[slot] = R.b_matchref[b0 + k];
+        o_rank[slot] = (long long)rank1[r] * 64 + k;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K4/K5: edges
+constexpr int MAXB = 24;  // own blocks + mate stub handled per record
+
+// fitting range [a,b] of nodes for a block (LocateRead's +-5 test, SegmentGraph.cpp:1213) and its home node
+__device__ __forceinline__ void fit_range(const NodeView& N, int c, int p, int end, int& a, int& b, int& home) {
+    int lo = N.chr_start[c], hi = N.chr_start[c + 1];
+    home = node_home(N, c, p);
+    // b = last node on c with pos - 5 <= p
+    int l = home, h = hi;  // pos[home] <= p, so home qualifies
+    while (h - l > 1) { int mid = (l + h) >> 1; if (N.pos[mid] - 5 <= p) l = mid; else h = mid; }
+    b = l;
+    // a = first node on c with pos+len+5 >= end
+    l = lo - 1; h = hi;  // invariant: nodes <= l fail, nodes >= h pass (h == hi means none)
+    while (h - l > 1) { int mid = (l + h) >> 1; if (N.pos[mid] + N.len[mid] + 5 >= end) h = mid; else l = mid; }
+    a = h;
+}
+// LocateRead for one block with running index i; returns node or -1 and updates i exactly like the scan loops
+__device__ __forceinline__ int locate_one(const NodeView& N, int c, int p, int end, int& i, int initialguess) {
+    if (i < 0 || i >= N.n) i = initialguess;
+    if (c < 0 || c >= N.n_ref) {  // no node can match: the scan runs off one end of the table
+        if (N.chr[i] < c) i = N.n; else i = -1;
+        return -1;
+    }
+    int a, b, home;
+    fit_range(N, c, p, end, a, b, home);
+    bool nonempty = a <= b;
+    if (nonempty && N.chr[i] == c && i >= a && i <= b) return i;
+    bool up = N.chr[i] < c || (N.chr[i] == c && N.pos[i] <= p);
+    if (up) {
+        if (nonempty && a >= i) { i = a; return a; }
+        i = N.chr_start[c + 1];  // first node of a later chromosome, or N.n
+        return -1;
+    }
+    if (nonempty && b <= i) { i = b; return b; }
+    i = N.chr_start[c] - 1;
+    return -1;
+}
+
+struct FPart { const uint8_t* keep; __device__ int operator()(int64_t i) const { return (keep[i] & K_BUILD) ? (int)i : -1; } };
+
+// block 0 of the stub-augmented record (the block whose node becomes the next record's hint)
+__device__ __forceinline__ bool rec_block0(const RecView& R, int64_t r, int& c, int& p, int& end) {
+    ListRec l = list_rec(R, r);
+    if (l.size(0) > 0) {
+        int m; list_key(R, r, l, 0, 0, c, p, m); end = p + m; return true;
+    }
+    if (l.size(1) > 0) { int m; list_key(R, r, l, 1, 0, c, p, m); end = p + m; return true; }
+    return false;
+}
+__global__ void k_block0(RecView R, NodeView N, const uint8_t* keep, const int32_t* part_prev, int32_t* part_next, int32_t* b0_a, int32_t* b0_b, int32_t* b0_home) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R.n || !(keep[r] & K_BUILD)) return;
+    if (part_prev[r] >= 0) part_next[part_prev[r]] = (int32_t)r;
+    int c, p, end, a = 1, b = 0, home = -1;
+    if (rec_block0(R, r, c, p, end) && c >= 0 && c < N.n_ref) fit_range(N, c, p, end, a, b, home);
+    b0_a[r] = a; b0_b[r] = b; b0_home[r] = home;
+}
+// hint transfer of one record: x -> node of its block 0 if located, else x (SegmentGraph.cpp:1607-1609)
+__device__ __forceinline__ int hint_step(int x, int a, int b, int home) {
+    if (a > b) return x;
+    if (x >= a && x <= b) return x;
+    if (x < a) return x <= home ? a : x;  // x in (home, a): the downward scan finds nothing (only with nodes < 5 bp)
+    return b;
+}
+
+// wave-aggregated insert of (key,+w) into the global open-addressing table
+__device__ __forceinline__ void hash_add(unsigned long long* hk, uint32_t* hv, uint32_t mask, unsigned long long key, uint32_t w, int32_t* flags) {
+    uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & mask;
+    for (uint32_t probe = 0; probe <= mask; ++probe) {
+        unsigned long long cur = hk[h];
+        if (cur == key) { atomicAdd(&hv[h], w); return; }
+        if (cur == ~0ull) {
+            unsigned long long old = atomicCAS(&hk[h], ~0ull, key);
+            if (old == ~0ull || old == key) { atomicAdd(&hv[h], w); return; }
+        }
+        h = (h + 1) & mask;
+    }
+    atomicOr(&flags[0], 4);  // table full
+}
+__device__ __forceinline__ void emit_edge(unsigned long long* hk, uint32_t* hv, uint32_t mask, int i, bool hi, int j, bool hj, int32_t* flags, int nnodes) {
+    if (i < 0 || j < 0 || i >= nnodes || j >= nnodes) { atomicOr(&flags[0], 8); return; }  // reference: assert(...) aborts
+    int a = i, b = j; bool ha = hi, hb = hj;
+    if (i > j) { a = j; ha = hj; b = i; hb = hi; }
+    unsigned long long key = ((unsigned long long)(uint32_t)a << 32) | ((unsigned long long)(uint32_t)b << 2) | ((unsigned long long)ha << 1) | (unsigned long long)hb;
+    // combine equal keys inside the wave before touching the table (neighbouring records emit the same edge)
+    unsigned long long active = __ballot(1);
+    int lane = threadIdx.x & 63;
+    while (active) {
+        int leader = __ffsll((long long)active) - 1;
+        unsigned long long k = __shfl(key, leader, 64);
+        unsigned long long same = __ballot(key == k) & active;
+        if (lane == leader) hash_add(hk, hv, mask, key, (uint32_t)__popcll(same), flags);
+        if (key == k) break;
+        active &= ~same;
+    }
+    atomicAdd(&flags[2], 1);
+}
+
+struct EdgeParams { int dp, di; };
+__device__ __forceinline__ bool dev_edge_discordant(const NodeView& N, const EdgeParams& P, int i, bool hi, int j, bool hj) {
+    int a = i, b = j; bool ha = hi, hb = hj;
+    if (i > j) { a = j; ha = hj; b = i; hb = hi; }
+    if (N.chr[a] != N.chr[b]) return true;
+    if (N.pos[b] - N.pos[a] - N.len[a] > P.dp && b - a > P.di) return true;
+    if (ha != false || hb != true) return true;
+    return false;
+}
+
+__global__ void k_edges(RecView R, NodeView N, EdgeParams P, const uint8_t* keep, const int32_t* part_prev, const int32_t* part_next, const int32_t* b0_a,
+                        const int32_t* b0_b, const int32_t* b0_home, unsigned long long* hk, uint32_t* hv, uint32_t hmask, int32_t* flags) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R.n || !(keep[r] & K_BUILD)) return;
+    // ---- incoming hint: walk back to a record whose block 0 pins the hint, then replay forward
+    int hint;
+    {
+        int64_t q = part_prev[r];
+        int steps = 0;
+        while (q >= 0 && !(b0_a[q] == b0_b[q])) { q = part_prev[q]; ++steps; }
+        if (q >= 0) hint = b0_a[q]; else { hint = 0; q = -1; }
+        if (steps > 0) {
+            // replay the un-pinned records between the anchor and r (rare)
+            int64_t t = (q >= 0) ? part_next[q] : -2;
+            if (q < 0) {  // no anchor: start from the first participating record
+                int64_t first = r;
+                while (part_prev[first] >= 0) first = part_prev[first];
+                t = first;
+            }
+            while (t != r) { hint = hint_step(hint, b0_a[t], b0_b[t], b0_home[t]); t = part_next[t]; }
+        }
+    }
+    // ---- gather the stub-augmented sorted record
+    ListRec l = list_rec(R, r);
+    const int nf = l.size(0), ns = l.size(1), nt = nf + ns;
+    if (nt > MAXB) { atomicOr(&flags[0], 16); return; }
+    int bc[MAXB], bp[MAXB], bm[MAXB], brp[MAXB], bmr[MAXB], node[MAXB];
+    bool brev[MAXB];
+    for (int k = 0; k < nt; ++k) {
+        int L = k < nf ? 0 : 1, kk = k < nf ? k : k - nf;
+        bool own = (L == 0) == l.first;
+        if (own) { DBlk b = own_block_sorted(R, r, kk, l.nown, l.rev); bc[k] = b.refid; bp[k] = b.refpos; bm[k] = b.matchref; brp[k] = b.readpos; bmr[k] = b.matchread; brev[k] = b.rev; }
+        else { bc[k] = R.mrefid[r]; bp[k] = R.mpos[r]; bm[k] = 15; brp[k] = 0; bmr[k] = 15; brev[k] = R.flag[r] & 0x20; }
+    }
+    // ---- LocateRead with in-register trimming
+    int i = hint;
+    for (int k = 0; k < nt; ++k) {
+        int nd = locate_one(N, bc[k], bp[k], bp[k] + bm[k], i, hint);
+        node[k] = nd;
+        if (nd >= 0) {
+            int np = N.pos[nd], ne = np + N.len[nd];
+            if (bp[k] < np) { int d = np - bp[k]; if (!brev[k]) brp[k] += d; bm[k] -= d; bmr[k] -= d; bp[k] = np; }
+            if (bp[k] + bm[k] > ne) { int d = bp[k] + bm[k] - ne; if (brev[k]) brp[k] += d; bm[k] -= d; bmr[k] -= d; }
+        }
+    }
+    if (nt == 0) return;
+    // ---- boundary edge for every unlocatable block
+    for (int k = 0; k < nt; ++k)
+        if (node[k] == -1) {
+            if (bc[k] < 0 || bc[k] >= N.n_ref) { atomicOr(&flags[0], 8); continue; }
+            int h = node_home(N, bc[k], bp[k]);
+            emit_edge(hk, hv, hmask, h, false, h + 1, true, flags, N.n);
+        }
+    // ---- consecutive blocks of one mate in different nodes
+    for (int k = 0; k + 1 < nt; ++k) {
+        if (k + 1 == nf) continue;  // never across the two lists
+        int a = node[k], b = node[k + 1];
+        if (a != b && a != -1 && b != -1) emit_edge(hk, hv, hmask, a, brev[k], b, !brev[k + 1], flags, N.n);
+    }
+    // ---- pair edge, first-mate records only
+    if (l.first && nf > 0 && ns > 0) {
+        auto enddisc = [&](int lo, int n) {
+            for (int k = lo; k + 1 < lo + n; ++k) {
+                if (bc[k] != bc[k + 1] || brev[k] != brev[k + 1]) return true;
+                bool refup = bp[k] < bp[k + 1], readup = brp[k] < brp[k + 1];
+                if (!brev[k] && refup != readup) return true;
+                if (brev[k] && refup == readup) return true;
+            }
+            return false;
+        };
+        bool ed1 = enddisc(0, nf), ed2 = enddisc(nf, ns);
+        if (!ed1 && !ed2) {
+            int a = node[nf - 1], b = node[nt - 1];
+            bool isoverlap = false;
+            for (int k = 0; k < nf; ++k) if (b == node[k]) isoverlap = true;
+            for (int k = 0; k < ns; ++k) if (a == node[nf + k]) isoverlap = true;
+            int ad = a - b; if (ad < 0) ad = -ad;
+            if (nf > 1 && ad < 3) isoverlap = true;
+            if (ns > 1 && ad < 3) isoverlap = true;
+            if (a != b && a != -1 && b != -1 && !isoverlap) {
+                // IsPairDiscordant(false) on the trimmed record; the absent mate side has TotalLen 0
+                const int ftot = l.first ? (int)R.totlen[r] : 0, stot = l.first ? 0 : (int)R.totlen[r];
+                const int f0 = 0, fb = nf - 1, s0 = nf, sb = nt - 1;
+                bool pd;
+                if (bc[f0] != bc[sb] || brev[f0] == brev[sb]) pd = true;
+                else if (!brev[f0] && bp[f0] - brp[f0] > bp[sb] - (stot - brp[sb] - bmr[sb])) pd = true;
+                else if (!brev[s0] && bp[s0] - brp[s0] > bp[fb] - (ftot - brp[fb] - bmr[fb])) pd = true;
+                else pd = false;
+                if (pd == dev_edge_discordant(N, P, a, brev[fb], b, brev[sb])) emit_edge(hk, hv, hmask, a, brev[fb], b, brev[sb], flags, N.n);
+            }
+        }
+    }
+}
+
+__global__ void k_hash_compact(const unsigned long long* hk, const uint32_t* hv, uint32_t slots, int32_t* counter, unsigned long long* okey, uint32_t* oval) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= slots) return;
+    unsigned long long k = hk[i];
+    if (k == ~0ull) return;
+    int s = atomicAdd(counter, 1);
+    okey[s] = k; oval[s] = hv[i];
+}
+
+// ------------------------------------------------------------------------------------------------ K10: BP support
+// Sorted breakpoint list (chr,pos); the reference walks it with a cursor that advances by at most one entry per
+// kept record (SegmentGraph.cpp:3157-3158).  m(r) = number of breakpoints the record is "beyond"; the cursor
+// after r is  cur(r) = cur(r-1) + [cur(r-1) < m(r)].  With M = prefix-max(m) this is the min-plus scan
+// cur(r) = min(M(r), cur(r-1)+1) whenever the cursor never sits above m(r) while below M(r); the kernels compute
+// that closed form and k_bp_count verifies the recurrence record by record (flag on mismatch -> exact host walk).
+struct BPView { int32_t n; const int32_t *chr, *pos; int dp; };
+__device__ __forceinline__ int bp_lower_bound(const BPView& B, int c, int p) {  // first j with (chr,pos) >= (c,p)
+    int lo = 0, hi = B.n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (B.chr[mid] < c || (B.chr[mid] == c && B.pos[mid] < p)) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+struct FBeyond {  // m(r) for pass-3 records, INT_MIN otherwise (identity of max)
+    RecView R; BPView B; const uint8_t* cls;
+    __device__ int operator()(int64_t r) const {
+        if (!(cls[r] & C_P3)) return INT_MIN;
+        int c = R.refid[r];
+        int st = R.pos[r];
+        if (!(R.flag[r] & 0x8) && R.mrefid[r] == c) st = R.mpos[r];
+        // #j with c > chr_j || (c == chr_j && st > pos_j + dp)  ==  lower_bound over (chr, pos+dp) of (c, st)
+        int lo = 0, hi = B.n;
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (B.chr[mid] < c || (B.chr[mid] == c && B.pos[mid] + B.dp < st)) lo = mid + 1; else hi = mid; }
+        return lo;
+    }
+};
+struct FMinPlus {  // M(r) - rank3(r) for pass-3 records (rank3 = index among pass-3 records), INT_MAX otherwise
+    const uint8_t* cls; const int32_t *M, *rank3;
+    __device__ int operator()(int64_t r) const { return (cls[r] & C_P3) ? M[r] - rank3[r] : INT_MAX; }
+};
+struct FP3 { const uint8_t* cls; __device__ int operator()(int64_t i) const { return (cls[i] & C_P3) ? 1 : 0; } };
+__global__ void k_bp_count(RecView R, BPView B, const uint8_t* cls, const int32_t* M, const int32_t* rank3, const int32_t* minplus, const int32_t* prev3, int32_t* diff,
+                           int32_t* flags) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R.n || !(cls[r] & C_P3)) return;
+    // cursor after this record and after the previous pass-3 record
+    auto cur_at = [&](int64_t q) -> int {
+        int v = minplus[q];  // min over s<=q of M(s) - rank3(s)
+        int byscan = v == INT_MAX ? INT_MAX : v + rank3[q];
+        int bycount = rank3[q] + 1;  // cannot advance more than once per record
+        return byscan < bycount ? byscan : bycount;
+    };
+    int cur = cur_at(r);
+    int64_t q = prev3[r];
+    int before = q >= 0 ? cur_at(q) : 0;
+    FBeyond fb{R, B, cls};
+    int m = fb(r);
+    int expect = before + (before < m ? 1 : 0);
+    if (before >= B.n) return;  // the reference has left its loop (SegmentGraph.cpp:3144-3145)
+    if (expect != cur) { atomicOr(&flags[0], 32); return; }
+    int c = R.refid[r];
+    int st = R.pos[r];
+    if (!(R.flag[r] & 0x8) && R.mrefid[r] == c) st = R.mpos[r];
+    int en = R.endpos[r];
+    int lo = bp_lower_bound(B, c, st), hi = bp_lower_bound(B, c, en);
+    if (lo < cur) lo = cur;
+    if (lo < hi) { atomicAdd(&diff[lo], 1); atomicAdd(&diff[hi], -1); }
+}
+
+// ------------------------------------------------------------------------------------------------ K8: components
+__global__ void k_cc_init(int n, int32_t* parent) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) parent[i] = i;
+}
+__device__ __forceinline__ int cc_find(int32_t* parent, int x) {
+    while (true) {
+        int p = parent[x];
+        if (p == x) return x;
+        int g = parent[p];
+        if (g != p) parent[x] = g;  // path halving
+        x = p;
+    }
+}
+__global__ void k_cc_union(int m, const int32_t* ea, const int32_t* eb, int32_t* parent) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m) return;
+    int a = ea[e], b = eb[e];
+    while (true) {  // hook the larger root under the smaller: the root of a component ends up its smallest node id
+        a = cc_find(parent, a);
+        b = cc_find(parent, b);
+        if (a == b) return;
+        if (a > b) { int t = a; a = b; b = t; }
+        if (atomicCAS(&parent[b], b, a) == b) return;
+    }
+}
+__global__ void k_cc_flatten(int n, int32_t* parent, int32_t* isroot) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int r = i;
+    while (parent[r] != r) r = parent[r];
+    parent[i] = r;
+    isroot[i] = (r == i) ? 1 : 0;
+}
+struct FArr { const int32_t* a; __device__ int operator()(int64_t i) const { return a[i]; } };
+__global__ void k_cc_label(int n, const int32_t* parent, const int32_t* rootrank, int32_t* label) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) label[i] = rootrank[parent[i]];
+}
+
+// ------------------------------------------------------------------------------------------------ K9: small orderings
+// One component per workgroup, one orientation mask per thread (n <= 8 => <= 256 masks).  For its mask a thread
+// builds the "x must precede y" arc weights, takes the smallest-index-first topological order when the arcs are
+// acyclic (every compatible edge satisfied) or solves the linear-ordering subset DP otherwise, and the block then
+// picks the canonical optimum: max value, then smallest mask, then lexicographically smallest sequence.
+constexpr int ORD_NMAX = 8;
+__global__ __launch_bounds__(256) void k_order_small(const SmallProblem* probs, const int32_t* edges5, int32_t* out_mask, int32_t* out_order, int32_t* out_value) {
+    __shared__ int s_best[256];
+    __shared__ int s_h[32][256];  // subset-DP tables, 32 threads at a time (cyclic orientations are rare)
+    const SmallProblem pr = probs[blockIdx.x];
+    const int n = pr.n, nm = 1 << n, mask = threadIdx.x;
+    int arc[ORD_NMAX][ORD_NMAX];
+    int value = -1;
+    bool acyclic = false;
+    if (mask < nm) {
+        for (int x = 0; x < ORD_NMAX; ++x) for (int y = 0; y < ORD_NMAX; ++y) arc[x][y] = 0;
+        int ub = 0;
+        for (int e = 0; e < pr.ecount; ++e) {
+            const int32_t* q = edges5 + 5 * (size_t)(pr.eoff + e);
+            int u = q[0], v = q[1]; bool hu = q[2], hv = q[3]; int w = q[4];
+            bool yu = !((mask >> u) & 1), yv = !((mask >> v) & 1), compat, ufirst;
+            if (!hu && hv) { compat = yu == yv; ufirst = yu; }
+            else if (!hu && !hv) { compat = yu != yv; ufirst = yu; }
+            else if (hu && hv) { compat = yu != yv; ufirst = yv; }
+            else { compat = yu == yv; ufirst = !yu; }
+            if (!compat) continue;
+            ub += w;
+            if (ufirst) arc[u][v] += w; else arc[v][u] += w;
+        }
+        // Kahn, smallest index first
+        int indeg[ORD_NMAX];
+        for (int y = 0; y < n; ++y) { indeg[y] = 0; for (int x = 0; x < n; ++x) if (arc[x][y] > 0) indeg[y]++; }
+        unsigned done = 0;
+        acyclic = true;
+        for (int p = 0; p < n; ++p) {
+            int v = -1;
+            for (int cnd = 0; cnd < n; ++cnd) if (!((done >> cnd) & 1) && indeg[cnd] == 0) { v = cnd; break; }
+            if (v < 0) { acyclic = false; break; }
+            done |= 1u << v;
+            for (int y = 0; y < n; ++y) if (arc[v][y] > 0) indeg[y]--;
+        }
+        if (acyclic) value = ub;
+    }
+    // cyclic masks: subset DP, serialised through the LDS tables in groups of 32 threads (rare path)
+    for (int round = 0; round < 8; ++round) {
+        bool mine = mask < nm && !acyclic && (threadIdx.x >> 5) == round;
+        if (__syncthreads_or(mine)) {
+            if (mine) {
+                int* h = s_h[threadIdx.x & 31];
+                h[nm - 1] = 0;
+                for (int S = nm - 2; S >= 0; --S) {
+                    int best = -1;
+                    for (int v = 0; v < n; ++v) {
+                        if ((S >> v) & 1) continue;
+                        int gain = 0;
+                        for (int u = 0; u < n; ++u) if ((S >> u) & 1) gain += arc[u][v];
+                        int t = gain + h[S | (1 << v)];
+                        if (t > best) best = t;
+                    }
+                    h[S] = best;
+                }
+                value = h[0];
+            }
+            __syncthreads();
+        }
+    }
+    s_best[threadIdx.x] = value;
+    __syncthreads();
+    // canonical winner: max value, smallest mask
+    __shared__ int s_win;
+    if (threadIdx.x == 0) {
+        int bw = 0;
+        for (int m2 = 1; m2 < nm; ++m2) if (s_best[m2] > s_best[bw]) bw = m2;
+        s_win = bw;
+    }
+    __syncthreads();
+    if (mask == s_win) {
+        int order[ORD_NMAX];
+        if (acyclic) {
+            int indeg[ORD_NMAX];
+            for (int y = 0; y < n; ++y) { indeg[y] = 0; for (int x = 0; x < n; ++x) if (arc[x][y] > 0) indeg[y]++; }
+            unsigned done = 0;
+            for (int p = 0; p < n; ++p) {
+                int v = 0;
+                for (int cnd = 0; cnd < n; ++cnd) if (!((done >> cnd) & 1) && indeg[cnd] == 0) { v = cnd; break; }
+                order[p] = v; done |= 1u << v;
+                for (int y = 0; y < n; ++y) if (arc[v][y] > 0) indeg[y]--;
+            }
+        } else {
+            int* h = s_h[threadIdx.x & 31];  // recompute (single thread): the slot may have been reused by a later round
+            h[nm - 1] = 0;
+            for (int S = nm - 2; S >= 0; --S) {
+                int best = -1;
+                for (int v = 0; v < n; ++v) {
+                    if ((S >> v) & 1) continue;
+                    int gain = 0;
+                    for (int u = 0; u < n; ++u) if ((S >> u) & 1) gain += arc[u][v];
+                    int t = gain + h[S | (1 << v)];
+                    if (t > best) best = t;
+                }
+                h[S] = best;
+            }
+            int S = 0;
+            for (int p = 0; p < n; ++p)
+                for (int v = 0; v < n; ++v) {
+                    if ((S >> v) & 1) continue;
+                    int gain = 0;
+                    for (int u = 0; u < n; ++u) if ((S >> u) & 1) gain += arc[u][v];
+                    if (gain + h[S | (1 << v)] == h[S]) { order[p] = v; S |= 1 << v; break; }
+                }
+        }
+        out_mask[blockIdx.x] = mask;
+        out_value[blockIdx.x] = value;
+        for (int p = 0; p < n; ++p) out_order[(size_t)blockIdx.x * ORD_NMAX + p] = order[p];
+    }
+}
+
+// ================================================================================================ host wrappers
+static inline dim3 grid_for(int64_t n, int threads) { return dim3((unsigned)((n + threads - 1) / threads)); }
+
+struct EvTimer {  // HIP-event bracket on the library stream
+    sq_ctx* c; const char* name; double bytes; bool on;
+    EvTimer(sq_ctx* c, const char* name, double bytes) : c(c), name(name), bytes(bytes), on(true) { (void)hipEventRecord(c->dev->ev0, c->stream); }
+    void stop() {
+        if (!on) return;
+        on = false;
+        (void)hipEventRecord(c->dev->ev1, c->stream);
+        (void)hipEventSynchronize(c->dev->ev1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, c->dev->ev0, c->dev->ev1);
+        c->timer.add(name, ms, bytes);
+    }
+    ~EvTimer() { stop(); }
+};
+
+int dev_create(sq_ctx* c) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(c, SQ_E_NODEVICE, "no HIP device visible; libsquid_hip has no CPU path");
+    if (c->P.device < 0 || c->P.device >= ndev) return fail(c, SQ_E_NODEVICE, "device ordinal out of range");
+    HIPCHK(hipSetDevice(c->P.device));
+    HIPCHK(hipStreamCreate(&c->stream));
+    c->dev = new DeviceRecords();
+    HIPCHK(hipEventCreate(&c->dev->ev0));
+    HIPCHK(hipEventCreate(&c->dev->ev1));
+    HIPCHK(c->dev->flags.reserve(64));
+    return SQ_OK;
+}
+
+void dev_destroy(sq_ctx* c) {
+    if (!c->dev) return;
+    DeviceRecords& D = *c->dev;
+    D.refid.release(); D.pos.release(); D.mrefid.release(); D.mpos.release(); D.endpos.release(); D.b_refpos.release(); D.b_matchref.release();
+    D.flag.release(); D.totlen.release(); D.b_readpos.release(); D.b_matchread.release(); D.mapq.release(); D.aux.release(); D.blk_off.release();
+    D.cls.release(); D.keep.release(); D.prev1.release(); D.prev2.release(); D.rank1.release(); D.restoff.release();
+    D.scratch_a.release(); D.scratch_b.release(); D.scratch_c.release(); D.spine.release();
+    D.part_prev.release(); D.part_next.release(); D.b0_a.release(); D.b0_b.release(); D.b0_home.release();
+    D.srec.release(); D.rest_refpos.release(); D.rest_matchref.release();
+    D.n_chr.release(); D.n_pos.release(); D.n_len.release(); D.n_chr_start.release();
+    D.acc_a.release(); D.acc_b.release(); D.acc_c.release(); D.acc_d.release();
+    D.h_key.release(); D.h_val.release(); D.flags.release(); D.gather_key.release();
+    if (D.ev0) (void)hipEventDestroy(D.ev0);
+    if (D.ev1) (void)hipEventDestroy(D.ev1);
+    delete c->dev;
+    c->dev = nullptr;
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    c->stream = nullptr;
+}
+
+int dev_append_records(sq_ctx* c, const sq_aln_batch* b) {
+    DeviceRecords& D = *c->dev;
+    hipStream_t s = c->stream;
+    const size_t n0 = (size_t)D.n, nb0 = (size_t)D.nb, n1 = n0 + (size_t)b->n_rec, nb1 = nb0 + (size_t)b->n_blk;
+    if (nb1 >= 0xffffffffull) return fail(c, SQ_E_CAPACITY, "more than 2^32 aligned blocks");
+#define GROW(buf, used, want) HIPCHK(D.buf.grow_keep(used, want, s))
+    GROW(refid, n0, n1); GROW(pos, n0, n1); GROW(mrefid, n0, n1); GROW(mpos, n0, n1); GROW(endpos, n0, n1);
+    GROW(flag, n0, n1); GROW(totlen, n0, n1); GROW(mapq, n0, n1); GROW(aux, n0, n1);
+    GROW(blk_off, n0 + 1, n1 + 1);
+    GROW(b_refpos, nb0, nb1); GROW(b_matchref, nb0, nb1); GROW(b_readpos, nb0, nb1); GROW(b_matchread, nb0, nb1);
+#undef GROW
+#define UP(buf, src, off, cnt) if (cnt) HIPCHK(hipMemcpyAsync(D.buf.p + (off), (src), (cnt) * sizeof(*D.buf.p), hipMemcpyHostToDevice, s))
+    size_t nr = (size_t)b->n_rec, nbk = (size_t)b->n_blk;
+    UP(refid, b->refid, n0, nr); UP(pos, b->pos, n0, nr); UP(mrefid, b->mate_refid, n0, nr); UP(mpos, b->mate_pos, n0, nr); UP(endpos, b->end_pos, n0, nr);
+    UP(flag, b->flag, n0, nr); UP(totlen, b->totlen, n0, nr); UP(mapq, b->mapq, n0, nr); UP(aux, b->aux, n0, nr);
+    UP(b_refpos, b->b_refpos, nb0, nbk); UP(b_matchref, b->b_matchref, nb0, nbk); UP(b_readpos, b->b_readpos, nb0, nbk); UP(b_matchread, b->b_matchread, nb0, nbk);
+#undef UP
+    // block offsets are rebased onto the resident block arrays
+    std::vector<uint32_t> off(nr + 1);
+    for (size_t i = 0; i <= nr; ++i) off[i] = b->blk_off[i] - b->blk_off[0] + (uint32_t)nb0;
+    HIPCHK(hipMemcpyAsync(D.blk_off.p + n0, off.data(), (nr + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    D.n = (int64_t)n1;
+    D.nb = (int64_t)nb1;
+    c->counts.n_concordant = D.n;
+    c->counts.n_blocks = D.nb;
+    return SQ_OK;
+}
+
+static int upload_nodes(sq_ctx* c, const std::vector<Node>& nodes, NodeView& nv) {
+    DeviceRecords& D = *c->dev;
+    const int n = (int)nodes.size(), nref = (int)c->ref_len.size();
+    std::vector<int32_t> chr(n), pos(n), len(n), cs(nref + 1, n);
+    for (int i = n - 1; i >= 0; --i) { chr[i] = nodes[i].chr; pos[i] = nodes[i].pos; len[i] = nodes[i].len; }
+    // chr_start[k] = first node with chr >= k
+    int j = 0;
+    for (int k = 0; k <= nref; ++k) { while (j < n && nodes[j].chr < k) ++j; cs[k] = j; }
+    HIPCHK(D.n_chr.reserve(n)); HIPCHK(D.n_pos.reserve(n)); HIPCHK(D.n_len.reserve(n)); HIPCHK(D.n_chr_start.reserve(nref + 1));
+    HIPCHK(hipMemcpyAsync(D.n_chr.p, chr.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(D.n_pos.p, pos.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(D.n_len.p, len.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(D.n_chr_start.p, cs.data(), (nref + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    nv.n = n; nv.n_ref = nref; nv.chr = D.n_chr.p; nv.pos = D.n_pos.p; nv.len = D.n_len.p; nv.chr_start = D.n_chr_start.p;
+    return SQ_OK;
+}
+
+// K1: filters, duplicate drop, stream summaries for the segmentation automaton
+int dev_classify_and_summarise(sq_ctx* c, std::vector<StreamRec>& recs, std::vector<int32_t>& rest_refpos, std::vector<int32_t>& rest_matchref) {
+    DeviceRecords& D = *c->dev;
+    hipStream_t s = c->stream;
+    const int64_t n = D.n;
+    RecView R = D.view();
+    HIPCHK(D.cls.reserve(n)); HIPCHK(D.keep.reserve(n)); HIPCHK(D.prev1.reserve(n)); HIPCHK(D.prev2.reserve(n)); HIPCHK(D.rank1.reserve(n)); HIPCHK(D.restoff.reserve(n));
+    int32_t* tot = D.flags.p + 8;
+    int32_t h_tot[2] = {0, 0};
+    if (n > 0) {
+        const double bytes_rec = 32.0 * n + 12.0 * D.nb;
+        { EvTimer t(c, "k_classify", 28.0 * n + 12.0 * D.nb); hipLaunchKernelGGL(k_classify, grid_for(n, 256), dim3(256), 0, s, R, c->P.min_mapqual, D.cls.p); }
+        { EvTimer t(c, "scan_prev", 2.0 * n);
+          HIPCHK((device_scan<OpMax, true>(s, n, FPrev{D.cls.p, C_P1}, D.prev1.p, D.spine, nullptr)));
+          HIPCHK((device_scan<OpMax, true>(s, n, FPrev{D.cls.p, C_P2}, D.prev2.p, D.spine, nullptr))); }
+        { EvTimer t(c, "k_dedup", 2.0 * bytes_rec); hipLaunchKernelGGL(k_dedup, grid_for(n, 256), dim3(256), 0, s, R, D.cls.p, D.prev1.p, D.prev2.p, D.keep.p); }
+        { EvTimer t(c, "scan_rank", 4.0 * n);
+          HIPCHK((device_scan<OpSum, true>(s, n, FKeep{D.keep.p, K_1}, D.rank1.p, D.spine, tot)));
+          HIPCHK((device_scan<OpSum, true>(s, n, FRest{D.keep.p, D.cls.p, D.blk_off.p}, D.restoff.p, D.spine, tot + 1))); }
+        HIPCHK(hipMemcpyAsync(h_tot, tot, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    // exclusive max-scan leaves INT_MIN where nothing precedes: normalise to -1 lazily (k_dedup treats <0 as empty)
+    const int64_t k1 = h_tot[0], nrest = h_tot[1];
+    D.k1 = k1;
+    HIPCHK(D.srec.reserve((size_t)std::max<int64_t>(k1, 1))); HIPCHK(D.rest_refpos.reserve((size_t)std::max<int64_t>(nrest, 1))); HIPCHK(D.rest_matchref.reserve((size_t)std::max<int64_t>(nrest, 1)));
+    recs.resize((size_t)k1); rest_refpos.resize((size_t)nrest); rest_matchref.resize((size_t)nrest);
+    if (n > 0) {
+        { EvTimer t(c, "k_summarise", 28.0 * n + 12.0 * D.nb + 20.0 * k1);
+          hipLaunchKernelGGL(k_summarise, grid_for(n, 256), dim3(256), 0, s, R, D.cls.p, D.keep.p, D.rank1.p, D.restoff.p, D.srec.p, D.rest_refpos.p, D.rest_matchref.p); }
+        auto t0 = std::chrono::steady_clock::now();
+        if (k1) HIPCHK(hipMemcpyAsync(recs.data(), D.srec.p, (size_t)k1 * sizeof(StreamRec), hipMemcpyDeviceToHost, s));
+        if (nrest) { HIPCHK(hipMemcpyAsync(rest_refpos.data(), D.rest_refpos.p, (size_t)nrest * 4, hipMemcpyDeviceToHost, s));
+                     HIPCHK(hipMemcpyAsync(rest_matchref.data(), D.rest_matchref.p, (size_t)nrest * 4, hipMemcpyDeviceToHost, s)); }
+        HIPCHK(hipStreamSynchronize(s));
+        c->timer.add("d2h_stream_summary", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), 0);
+    }
+    c->counts.n_kept_p1 = k1;
+    return SQ_OK;
+}
+
+// K3: per-node read support and summed block length of the consumed stream prefix
+int dev_node_depth(sq_ctx* c, const std::vector<Node>& nodes, int64_t n_break, std::vector<int32_t>& support, std::vector<int64_t>& sumlen, bool& need_exact_other,
+                   std::vector<int32_t>& other_chr, std::vector<int32_t>& other_pos, std::vector<int32_t>& other_len) {
+    DeviceRecords& D = *c->dev;
+    hipStream_t s = c->stream;
+    const int64_t n = D.n;
+    const int nn = (int)nodes.size();
+    NodeView nv;
+    int rc = upload_nodes(c, nodes, nv);
+    if (rc) return rc;
+    HIPCHK(D.acc_a.reserve(nn)); HIPCHK(D.acc_b.reserve(nn)); HIPCHK(D.acc_c.reserve(nn)); HIPCHK(D.acc_d.reserve(nn)); HIPCHK(D.scratch_a.reserve(std::max<int64_t>(n, 1)));
+    HIPCHK(hipMemsetAsync(D.acc_a.p, 0, nn * 4, s)); HIPCHK(hipMemsetAsync(D.acc_b.p, 0, nn * 4, s)); HIPCHK(hipMemsetAsync(D.acc_c.p, 0, nn * 4, s)); HIPCHK(hipMemsetAsync(D.acc_d.p, 0, nn * 4, s));
+    HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
+    RecView R = D.view();
+    const int32_t nbk = (int32_t)std::min<int64_t>(n_break, INT32_MAX);
+    if (n > 0) {
+        { EvTimer t(c, "scan_depth_cursor", 12.0 * n);
+          HIPCHK((device_scan<OpMax, false>(s, n, FEarlyMain{R, nv, D.keep.p, D.rank1.p, nbk}, D.scratch_a.p, D.spine, nullptr))); }
+        { EvTimer t(c, "k_depth", 13.0 * n + 8.0 * D.nb);
+          hipLaunchKernelGGL(k_depth, grid_for(n, 256), dim3(256), 0, s, R, nv, D.keep.p, D.rank1.p, nbk, D.scratch_a.p, D.acc_a.p, D.acc_b.p, D.acc_c.p, D.acc_d.p, D.flags.p); }
+    }
+    std::vector<int32_t> mc(nn), ms(nn), oc(nn), os(nn);
+    int32_t hf[4];
+    HIPCHK(hipMemcpyAsync(mc.data(), D.acc_a.p, nn * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(ms.data(), D.acc_b.p, nn * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(oc.data(), D.acc_c.p, nn * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(os.data(), D.acc_d.p, nn * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hf, D.flags.p, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (hf[0] & 1) return fail(c, SQ_E_UNSORTED, "concordant stream is not coordinate sorted (depth cursor left its chromosome)");
+    need_exact_other = hf[0] & 2;
+    support.assign(nn * 2, 0);
+    sumlen.assign(nn * 2, 0);
+    for (int i = 0; i < nn; ++i) { support[i] = mc[i]; sumlen[i] = ms[i]; support[nn + i] = oc[i]; sumlen[nn + i] = os[i]; }
+    // sumlen layout: [0,nn) main, [nn,2nn) other; element 2nn = |ReadsOther|
+    support.push_back(hf[1]);
+    if (need_exact_other) {
+        // a <=3-base block starts right behind a node boundary: which node counts it depends on the tie order that
+        // std::sort gives ReadsOther (SegmentGraph.cpp:781).  Hand the host the exact multiset in stream order.
+        const int cnt = hf[1];
+        HIPCHK(D.scratch_b.reserve(cnt)); HIPCHK(D.scratch_c.reserve(cnt)); HIPCHK(D.b0_a.reserve(cnt)); HIPCHK(D.gather_key.reserve(cnt));
+        HIPCHK(hipMemsetAsync(D.flags.p + 4, 0, 4, s));
+        hipLaunchKernelGGL(k_gather_other, grid_for(n, 256), dim3(256), 0, s, R, D.keep.p, D.rank1.p, nbk, D.flags.p + 4, D.scratch_b.p, D.scratch_c.p, D.b0_a.p, D.gather_key.p);
+        std::vector<long long> rk(cnt);
+        other_chr.resize(cnt); other_pos.resize(cnt); other_len.resize(cnt);
+        HIPCHK(hipMemcpyAsync(other_chr.data(), D.scratch_b.p, cnt * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(other_pos.data(), D.scratch_c.p, cnt * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(other_len.data(), D.b0_a.p, cnt * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(rk.data(), D.gather_key.p, (size_t)cnt * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        std::vector<int> perm(cnt);
+        for (int i = 0; i < cnt; ++i) perm[i] = i;
+        std::sort(perm.begin(), perm.end(), [&](int a, int b) { return rk[a] < rk[b]; });  // restore stream order (keys are unique)
+        std::vector<int32_t> t(cnt);
+        for (int i = 0; i < cnt; ++i) t[i] = other_chr[perm[i]]; other_chr.swap(t); t.resize(cnt);
+        for (int i = 0; i < cnt; ++i) t[i] = other_pos[perm[i]]; other_pos.swap(t); t.resize(cnt);
+        for (int i = 0; i < cnt; ++i) t[i] = other_len[perm[i]]; other_len.swap(t);
+    }
+    return SQ_OK;
+}
+
+// K4+K5: locate blocks, emit raw edges, count equal keys
+int dev_concordant_edges(sq_ctx* c, const std::vector<Node>& nodes, std::vector<Edge>& unique_edges) {
+    DeviceRecords& D = *c->dev;
+    hipStream_t s = c->stream;
+    const int64_t n = D.n;
+    unique_edges.clear();
+    if (n == 0) return SQ_OK;
+    NodeView nv;
+    int rc = upload_nodes(c, nodes, nv);
+    if (rc) return rc;
+    RecView R = D.view();
+    HIPCHK(D.part_prev.reserve(n)); HIPCHK(D.part_next.reserve(n)); HIPCHK(D.b0_a.reserve(n)); HIPCHK(D.b0_b.reserve(n)); HIPCHK(D.b0_home.reserve(n));
+    const uint32_t slots = 1u << 22;
+    HIPCHK(D.h_key.reserve(slots)); HIPCHK(D.h_val.reserve(slots));
+    HIPCHK(hipMemsetAsync(D.h_key.p, 0xff, (size_t)slots * 8, s));
+    HIPCHK(hipMemsetAsync(D.h_val.p, 0, (size_t)slots * 4, s));
+    HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
+    HIPCHK(hipMemsetAsync(D.part_next.p, 0xff, (size_t)n * 4, s));
+    { EvTimer t(c, "scan_part", 1.0 * n); HIPCHK((device_scan<OpMax, true>(s, n, FPart{D.keep.p}, D.part_prev.p, D.spine, nullptr))); }
+    { EvTimer t(c, "k_block0", 33.0 * n + 12.0 * D.nb);
+      hipLaunchKernelGGL(k_block0, grid_for(n, 256), dim3(256), 0, s, R, nv, D.keep.p, D.part_prev.p, D.part_next.p, D.b0_a.p, D.b0_b.p, D.b0_home.p); }
+    EdgeParams ep{c->P.concord_dist_pos, c->P.concord_dist_idx};
+    { EvTimer t(c, "k_edges", 28.0 * n + 12.0 * D.nb);
+      hipLaunchKernelGGL(k_edges, grid_for(n, 256), dim3(256), 0, s, R, nv, ep, D.keep.p, D.part_prev.p, D.part_next.p, D.b0_a.p, D.b0_b.p, D.b0_home.p, D.h_key.p, D.h_val.p, slots - 1,
+                         D.flags.p); }
+    int32_t hf[4];
+    HIPCHK(hipMemcpyAsync(hf, D.flags.p, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (hf[0] & 4) return fail(c, SQ_E_CAPACITY, "edge hash table full");
+    if (hf[0] & 8) return fail(c, SQ_E_ASSERT, "edge node index out of range (the reference asserts at SegmentGraph.cpp:1617)");
+    if (hf[0] & 16) return fail(c, SQ_E_CAPACITY, "record with more aligned blocks than the edge kernel handles");
+    c->counts.n_raw_edges = hf[2];
+    // compact the table (unique keys are few: reuse the hint scratch for the output)
+    HIPCHK(hipMemsetAsync(D.flags.p + 4, 0, 4, s));
+    DBuf<unsigned long long> okey;
+    DBuf<uint32_t> oval;
+    // upper bound on unique keys = raw edges
+    size_t cap = (size_t)std::max(1, std::min<int>(hf[2], (int)slots));
+    HIPCHK(okey.reserve(cap)); HIPCHK(oval.reserve(cap));
+    { EvTimer t(c, "k_hash_compact", 12.0 * slots); hipLaunchKernelGGL(k_hash_compact, grid_for(slots, 256), dim3(256), 0, s, D.h_key.p, D.h_val.p, slots, D.flags.p + 4, okey.p, oval.p); }
+    int32_t cnt = 0;
+    HIPCHK(hipMemcpyAsync(&cnt, D.flags.p + 4, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    std::vector<unsigned long long> hk(cnt);
+    std::vector<uint32_t> hv(cnt);
+    if (cnt) { HIPCHK(hipMemcpy(hk.data(), okey.p, (size_t)cnt * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(hv.data(), oval.p, (size_t)cnt * 4, hipMemcpyDeviceToHost)); }
+    okey.release(); oval.release();
+    unique_edges.resize(cnt);
+    for (int i = 0; i < cnt; ++i) {
+        Edge e;
+        e.a = (int32_t)(hk[i] >> 32); e.b = (int32_t)((hk[i] & 0xffffffffull) >> 2); e.ha = (hk[i] >> 1) & 1; e.hb = hk[i] & 1; e.w = (int32_t)hv[i]; e.gw = 0;
+        unique_edges[i] = e;
+    }
+    c->counts.n_unique_edges = cnt;
+    return SQ_OK;
+}
+
+// K8: connected components; label = rank of the component's smallest node id
+int dev_connected_components(sq_ctx* c, int n_nodes, const std::vector<Edge>& edges, std::vector<int32_t>& label) {
+    DeviceRecords& D = *c->dev;
+    hipStream_t s = c->stream;
+    const int m = (int)edges.size();
+    label.assign(n_nodes, 0);
+    if (n_nodes == 0) return SQ_OK;
+    std::vector<int32_t> ea(m), eb(m);
+    for (int i = 0; i < m; ++i) { ea[i] = edges[i].a; eb[i] = edges[i].b; }
+    HIPCHK(D.scratch_a.reserve(n_nodes)); HIPCHK(D.scratch_b.reserve(n_nodes)); HIPCHK(D.scratch_c.reserve(n_nodes)); HIPCHK(D.acc_a.reserve(std::max(m, 1))); HIPCHK(D.acc_b.reserve(std::max(m, 1)));
+    HIPCHK(D.acc_c.reserve(n_nodes));
+    if (m) { HIPCHK(hipMemcpyAsync(D.acc_a.p, ea.data(), m * 4, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(D.acc_b.p, eb.data(), m * 4, hipMemcpyHostToDevice, s)); }
+    {
+        EvTimer t(c, "k_cc", 8.0 * m + 16.0 * n_nodes);
+        hipLaunchKernelGGL(k_cc_init, grid_for(n_nodes, 256), dim3(256), 0, s, n_nodes, D.scratch_a.p);
+        if (m) hipLaunchKernelGGL(k_cc_union, grid_for(m, 256), dim3(256), 0, s, m, D.acc_a.p, D.acc_b.p, D.scratch_a.p);
+        hipLaunchKernelGGL(k_cc_flatten, grid_for(n_nodes, 256), dim3(256), 0, s, n_nodes, D.scratch_a.p, D.scratch_b.p);
+        HIPCHK((device_scan<OpSum, true>(s, n_nodes, FArr{D.scratch_b.p}, D.scratch_c.p, D.spine, nullptr)));
+        hipLaunchKernelGGL(k_cc_label, grid_for(n_nodes, 256), dim3(256), 0, s, n_nodes, D.scratch_a.p, D.scratch_c.p, D.acc_c.p);
+    }
+    HIPCHK(hipMemcpyAsync(label.data(), D.acc_c.p, n_nodes * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return SQ_OK;
+}
+
+// K9: batched exact ordering of components with at most ORD_NMAX nodes
+int dev_order_small(sq_ctx* c, const std::vector<SmallProblem>& probs, const std::vector<int32_t>& edges5, std::vector<int32_t>& out_mask, std::vector<int32_t>& out_order,
+                    int nmax) {
+    hipStream_t s = c->stream;
+    const int np = (int)probs.size();
+    out_mask.assign(np, 0);
+    out_order.assign((size_t)np * ORD_NMAX, 0);
+    if (!np) return SQ_OK;
+    if (nmax > ORD_NMAX) return fail(c, SQ_E_ARG, "dev_order_small: nmax too large");
+    DBuf<SmallProblem> dp;
+    DBuf<int32_t> de, dm, dord, dval;
+    HIPCHK(dp.reserve(np)); HIPCHK(de.reserve(std::max<size_t>(edges5.size(), 1))); HIPCHK(dm.reserve(np)); HIPCHK(dord.reserve((size_t)np * ORD_NMAX)); HIPCHK(dval.reserve(np));
+    HIPCHK(hipMemcpyAsync(dp.p, probs.data(), np * sizeof(SmallProblem), hipMemcpyHostToDevice, s));
+    if (edges5.size()) HIPCHK(hipMemcpyAsync(de.p, edges5.data(), edges5.size() * 4, hipMemcpyHostToDevice, s));
+    { EvTimer t(c, "k_order_small", 0); hipLaunchKernelGGL(k_order_small, dim3(np), dim3(256), 0, s, dp.p, de.p, dm.p, dord.p, dval.p); }
+    HIPCHK(hipMemcpyAsync(out_mask.data(), dm.p, np * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out_order.data(), dord.p, (size_t)np * ORD_NMAX * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    dp.release(); de.release(); dm.release(); dord.release(); dval.release();
+    return SQ_OK;
+}
+
+// K10: concordant-fragment support of every breakpoint
+int dev_breakpoint_support(sq_ctx* c, const std::vector<std::pair<int, int>>& bps, std::vector<int32_t>& coverage) {
+    DeviceRecords& D = *c->dev;
+    hipStream_t s = c->stream;
+    const int64_t n = D.n;
+    const int nb = (int)bps.size();
+    coverage.assign(nb, 0);
+    if (!nb || !n) return SQ_OK;
+    std::vector<int32_t> bc(nb), bp(nb);
+    for (int i = 0; i < nb; ++i) { bc[i] = bps[i].first; bp[i] = bps[i].second; }
+    HIPCHK(D.acc_a.reserve(nb)); HIPCHK(D.acc_b.reserve(nb)); HIPCHK(D.acc_c.reserve(nb + 1));
+    HIPCHK(D.scratch_a.reserve(n)); HIPCHK(D.scratch_b.reserve(n)); HIPCHK(D.scratch_c.reserve(n)); HIPCHK(D.part_prev.reserve(n));
+    HIPCHK(hipMemcpyAsync(D.acc_a.p, bc.data(), nb * 4, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(D.acc_b.p, bp.data(), nb * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(D.acc_c.p, 0, (nb + 1) * 4, s));
+    HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
+    RecView R = D.view();
+    BPView B{nb, D.acc_a.p, D.acc_b.p, c->P.concord_dist_pos};
+    { EvTimer t(c, "scan_bp_cursor", 36.0 * n);
+      HIPCHK((device_scan<OpMax, false>(s, n, FBeyond{R, B, D.cls.p}, D.scratch_a.p, D.spine, nullptr)));         // M = prefix max of m
+      HIPCHK((device_scan<OpSum, true>(s, n, FP3{D.cls.p}, D.scratch_b.p, D.spine, nullptr)));                    // rank among pass-3 records
+      HIPCHK((device_scan<OpMin, false>(s, n, FMinPlus{D.cls.p, D.scratch_a.p, D.scratch_b.p}, D.scratch_c.p, D.spine, nullptr)));
+      HIPCHK((device_scan<OpMax, true>(s, n, FPrev{D.cls.p, C_P3}, D.part_prev.p, D.spine, nullptr))); }
+    { EvTimer t(c, "k_bp_count", 24.0 * n);
+      hipLaunchKernelGGL(k_bp_count, grid_for(n, 256), dim3(256), 0, s, R, B, D.cls.p, D.scratch_a.p, D.scratch_b.p, D.scratch_c.p, D.part_prev.p, D.acc_c.p, D.flags.p); }
+    std::vector<int32_t> diff(nb + 1);
+    int32_t hf = 0;
+    HIPCHK(hipMemcpyAsync(diff.data(), D.acc_c.p, (nb + 1) * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&hf, D.flags.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (hf & 32) return 1;  // caller switches to the exact cursor walk
+    int run = 0;
+    for (int i = 0; i < nb; ++i) { run += diff[i]; coverage[i] = run; }
+    return SQ_OK;
+}
+
+// exact but serial cursor walk for the (rare) inputs where the closed form does not hold: the pass-3 records'
+// (chr, start, end) are pulled to the host in stream order.
+__global__ void k_p3_gather(RecView R, const uint8_t* cls, const int32_t* rank3, int32_t* o_chr, int32_t* o_st, int32_t* o_en) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R.n || !(cls[r] & C_P3)) return;
+    int c = R.refid[r], st = R.pos[r];
+    if (!(R.flag[r] & 0x8) && R.mrefid[r] == c) st = R.mpos[r];
+    o_chr[rank3[r]] = c; o_st[rank3[r]] = st; o_en[rank3[r]] = R.endpos[r];
+}
+int dev_breakpoint_support_exact(sq_ctx* c, const std::vector<std::pair<int, int>>& bps, std::vector<int32_t>& coverage) {
+    DeviceRecords& D = *c->dev;
+    hipStream_t s = c->stream;
+    const int64_t n = D.n;
+    RecView R = D.view();
+    int32_t* tot = D.flags.p + 8;
+    HIPCHK(D.scratch_b.reserve(n));
+    HIPCHK((device_scan<OpSum, true>(s, n, FP3{D.cls.p}, D.scratch_b.p, D.spine, tot)));
+    int32_t n3 = 0;
+    HIPCHK(hipMemcpyAsync(&n3, tot, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(D.scratch_a.reserve(std::max(n3, 1))); HIPCHK(D.scratch_c.reserve(std::max(n3, 1))); HIPCHK(D.part_prev.reserve(std::max(n3, 1)));
+    hipLaunchKernelGGL(k_p3_gather, grid_for(n, 256), dim3(256), 0, s, R, D.cls.p, D.scratch_b.p, D.scratch_a.p, D.scratch_c.p, D.part_prev.p);
+    std::vector<int32_t> ch(n3), st(n3), en(n3);
+    HIPCHK(hipMemcpyAsync(ch.data(), D.scratch_a.p, n3 * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(st.data(), D.scratch_c.p, n3 * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(en.data(), D.part_prev.p, n3 * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    auto t0 = std::chrono::steady_clock::now();
+    const size_t nb = bps.size();
+    coverage.assign(nb, 0);
+    size_t ind = 0;
+    for (int i = 0; i < n3 && ind != nb; ++i) {
+        if (ch[i] > bps[ind].first || (ch[i] == bps[ind].first && st[i] > bps[ind].second + c->P.concord_dist_pos)) ind++;
+        for (size_t j = ind; j < nb; ++j) {
+            if (ch[i] == bps[j].first && st[i] <= bps[j].second && en[i] > bps[j].second) coverage[j]++;
+            else if (ch[i] < bps[j].first || (ch[i] == bps[j].first && en[i] <= bps[j].second)) break;
+        }
+    }
+    c->timer.add("host_bp_cursor_exact", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), 0);
+    return SQ_OK;
+}
+
+}  // namespace sq

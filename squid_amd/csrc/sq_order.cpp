@@ -1,0 +1,323 @@
+// Per-component segment ordering (src/SegmentGraph.cpp:3236-3451,3763-3983).
+//
+// The reference builds one ILP per connected component and hands it to GLPK.  Here the model of appendix D is
+// solved exactly and deterministically: components (or the bridge-free pieces MincutRecursion cuts them into)
+// with at most 8 nodes go to the GPU as one batch (k_order_small, one component per workgroup); larger ones are
+// solved on the host by branch-and-bound over orientations with the same canonical optimum:
+//   max objective, then smallest orientation mask (bit i <=> local node i reversed), then the lexicographically
+//   smallest left-to-right sequence.
+// GLPK's pick among equal-valued optima and Boost's pick among equal min-cuts are not reproducible (neither
+// library is available, nothing in the reference pins them); DESIGN.md lists this as "parity unpinned".
+#include <algorithm>
+#include <cstring>
+
+#include "sq_internal.h"
+
+namespace sq {
+
+namespace {
+
+struct LEdge { int u, v; bool hu, hv; int w; };  // u < v (local indices)
+
+struct Piece {  // a leaf of the min-cut recursion (or a whole small component)
+    std::vector<int> ids;       // global node ids, ascending (local index = position)
+    std::vector<LEdge> edges;   // incl. backbone edges
+    std::vector<int> order;     // result: signed 1-based global ids, left to right
+};
+
+struct TreeNode {
+    int left = -1, right = -1, piece = -1;
+    Edge bridge{};
+};
+
+// ---- backbone + local edge list (SegmentGraph.cpp:3275-3286): a weight-1 tail->head edge between consecutive
+// component nodes that no edge joins yet
+void make_piece(const std::vector<int>& ids, const std::vector<Edge>& E, Piece& p) {
+    p.ids = ids;
+    const int n = (int)ids.size();
+    auto local = [&](int g) { return (int)(std::lower_bound(ids.begin(), ids.end(), g) - ids.begin()); };
+    std::vector<char> joined(n, 0);
+    for (const Edge& e : E) {
+        int u = local(e.a), v = local(e.b);
+        p.edges.push_back(LEdge{u, v, (bool)e.ha, (bool)e.hb, e.w});
+        if (v == u + 1) joined[u] = 1;
+    }
+    for (int k = 0; k + 1 < n; ++k)
+        if (!joined[k]) p.edges.push_back(LEdge{k, k + 1, false, true, 1});
+}
+
+// ---- exact host solver for 9..exact_max nodes
+struct HostSolver {
+    int n;
+    const std::vector<LEdge>& E;
+    long best = -1;
+    unsigned bestmask = 0;
+    std::vector<int> bestorder;
+    HostSolver(int n, const std::vector<LEdge>& E) : n(n), E(E) {}
+
+    static bool compat(const LEdge& e, unsigned mask, bool& ufirst) {
+        bool yu = !((mask >> e.u) & 1), yv = !((mask >> e.v) & 1);
+        if (e.hu != e.hv) {  // tail->head or head->tail: equal orientations
+            if (yu != yv) return false;
+            ufirst = e.hv ? yu : !yu;
+        } else {  // tail-tail or head-head: opposite orientations
+            if (yu == yv) return false;
+            ufirst = e.hu ? yv : yu;
+        }
+        return true;
+    }
+    long bound(unsigned mask, int k) const {  // nodes > k fixed, nodes <= k free
+        long ub = 0;
+        for (const LEdge& e : E) {
+            bool uf;
+            if (e.u <= k || compat(e, mask, uf)) ub += e.w;
+        }
+        return ub;
+    }
+    void leaf(unsigned mask) {
+        std::vector<int> a((size_t)n * n, 0);
+        long ub = 0;
+        for (const LEdge& e : E) {
+            bool uf;
+            if (!compat(e, mask, uf)) continue;
+            ub += e.w;
+            if (uf) a[e.u * n + e.v] += e.w; else a[e.v * n + e.u] += e.w;
+        }
+        // smallest-index-first topological order, if the arcs are acyclic
+        std::vector<int> indeg(n, 0), order;
+        for (int x = 0; x < n; ++x) for (int y = 0; y < n; ++y) if (a[x * n + y] > 0) indeg[y]++;
+        unsigned done = 0;
+        bool acyclic = true;
+        for (int p = 0; p < n && acyclic; ++p) {
+            int v = -1;
+            for (int q = 0; q < n; ++q) if (!((done >> q) & 1) && indeg[q] == 0) { v = q; break; }
+            if (v < 0) { acyclic = false; break; }
+            done |= 1u << v;
+            order.push_back(v);
+            for (int y = 0; y < n; ++y) if (a[v * n + y] > 0) indeg[y]--;
+        }
+        long val = ub;
+        if (!acyclic) {
+            // linear ordering by subset DP; gain(S,v) from two half-mask tables
+            const int lob = n / 2, hib = n - lob;
+            std::vector<long> GL((size_t)n << lob, 0), GH((size_t)n << hib, 0);
+            for (int v = 0; v < n; ++v) {
+                for (size_t m = 1; m < ((size_t)1 << lob); ++m) GL[((size_t)v << lob) + m] = GL[((size_t)v << lob) + (m & (m - 1))] + a[__builtin_ctzl(m) * n + v];
+                for (size_t m = 1; m < ((size_t)1 << hib); ++m) GH[((size_t)v << hib) + m] = GH[((size_t)v << hib) + (m & (m - 1))] + a[(lob + __builtin_ctzl(m)) * n + v];
+            }
+            auto gain = [&](size_t S, int v) { return GL[((size_t)v << lob) + (S & (((size_t)1 << lob) - 1))] + GH[((size_t)v << hib) + (S >> lob)]; };
+            const size_t full = ((size_t)1 << n) - 1;
+            std::vector<long> h(full + 1, 0);
+            for (size_t S = full; S-- > 0;) {
+                long b = -1;
+                for (int v = 0; v < n; ++v) if (!((S >> v) & 1)) b = std::max(b, gain(S, v) + h[S | ((size_t)1 << v)]);
+                h[S] = b;
+            }
+            val = h[0];
+            if (val > best) {
+                order.clear();
+                size_t S = 0;
+                for (int p = 0; p < n; ++p)
+                    for (int v = 0; v < n; ++v)
+                        if (!((S >> v) & 1) && gain(S, v) + h[S | ((size_t)1 << v)] == h[S]) { order.push_back(v); S |= (size_t)1 << v; break; }
+            }
+        }
+        if (val > best) { best = val; bestmask = mask; bestorder = order; }
+    }
+    void run() {
+        // depth-first over nodes n-1..0, forward before reversed; a branch must be able to beat the incumbent strictly
+        struct Fr { unsigned mask; int k; };
+        std::vector<Fr> st;
+        st.push_back(Fr{0u, n - 1});
+        while (!st.empty()) {
+            Fr f = st.back();
+            st.pop_back();
+            if (bound(f.mask, f.k) <= best) continue;
+            if (f.k < 0) { leaf(f.mask); continue; }
+            st.push_back(Fr{f.mask | (1u << f.k), f.k - 1});  // explored second
+            st.push_back(Fr{f.mask, f.k - 1});                // explored first
+        }
+    }
+};
+
+// unit-weight Stoer-Wagner on the multigraph; deterministic rule: start at local vertex 0, first maximum in the
+// adjacency search, first strictly smaller cut-of-the-phase wins
+int stoer_wagner(int n, const std::vector<std::pair<int, int>>& edges, std::vector<char>& side) {
+    std::vector<int> w((size_t)n * n, 0);
+    for (auto& e : edges) if (e.first != e.second) { w[e.first * n + e.second]++; w[e.second * n + e.first]++; }
+    std::vector<std::vector<int>> members(n);
+    std::vector<int> alive(n);
+    for (int i = 0; i < n; ++i) { members[i].push_back(i); alive[i] = i; }
+    int best = INT32_MAX;
+    side.assign(n, 0);
+    std::vector<int> wt(n);
+    std::vector<char> added(n);
+    while (alive.size() > 1) {
+        std::fill(wt.begin(), wt.end(), 0);
+        std::fill(added.begin(), added.end(), 0);
+        int prev = -1, last = -1;
+        for (size_t it = 0; it < alive.size(); ++it) {
+            int sel = -1;
+            for (int v : alive) if (!added[v] && (sel == -1 || wt[v] > wt[sel])) sel = v;
+            added[sel] = 1;
+            prev = last; last = sel;
+            for (int v : alive) if (!added[v]) wt[v] += w[sel * n + v];
+        }
+        if (wt[last] < best) {
+            best = wt[last];
+            std::fill(side.begin(), side.end(), 0);
+            for (int mbr : members[last]) side[mbr] = 1;
+        }
+        members[prev].insert(members[prev].end(), members[last].begin(), members[last].end());
+        for (int v : alive) { w[prev * n + v] += w[last * n + v]; w[v * n + prev] = w[prev * n + v]; }
+        alive.erase(std::find(alive.begin(), alive.end(), last));
+    }
+    return best;
+}
+
+struct Builder {
+    std::vector<TreeNode> tree;
+    std::vector<Piece> pieces;
+    // MincutRecursion (SegmentGraph.cpp:3264-3451): returns tree node index
+    int build(const std::vector<int>& ids, const std::vector<Edge>& E) {
+        const int n = (int)ids.size();
+        int me = (int)tree.size();
+        tree.push_back(TreeNode());
+        bool whole = n < 20;
+        std::vector<char> side;
+        if (!whole) {
+            auto local = [&](int g) { return (int)(std::lower_bound(ids.begin(), ids.end(), g) - ids.begin()); };
+            std::vector<std::pair<int, int>> le;
+            for (const Edge& e : E) le.push_back(std::make_pair(local(e.a), local(e.b)));
+            if (stoer_wagner(n, le, side) > 1) whole = true;
+        }
+        if (whole || n == 1) {
+            Piece p;
+            if (n == 1) { p.ids = ids; p.order.assign(1, ids[0] + 1); }
+            else make_piece(ids, E, p);
+            tree[me].piece = (int)pieces.size();
+            pieces.push_back(std::move(p));
+            return me;
+        }
+        std::vector<int> ids1, ids2;
+        for (int k = 0; k < n; ++k) (side[k] ? ids1 : ids2).push_back(ids[k]);
+        std::vector<Edge> e1, e2;
+        Edge mid{};
+        for (const Edge& e : E) {
+            bool s1 = std::binary_search(ids1.begin(), ids1.end(), e.a), s2 = std::binary_search(ids1.begin(), ids1.end(), e.b);
+            if (s1 && s2) e1.push_back(e);
+            else if (!s1 && !s2) e2.push_back(e);
+            else mid = e;
+        }
+        int l = build(ids1, e1), r = build(ids2, e2);
+        tree[me].left = l; tree[me].right = r; tree[me].bridge = mid;
+        return me;
+    }
+    // join two ordered halves over the bridge edge (SegmentGraph.cpp:3393-3448)
+    std::vector<int> combine(int t) {
+        const TreeNode& tn = tree[t];
+        if (tn.piece >= 0) return pieces[tn.piece].order;
+        std::vector<int> A = combine(tn.left), B = combine(tn.right);
+        auto scan = [&](const std::vector<int>& X, int& median, bool& positive, bool& head) {
+            std::vector<int> ab;
+            positive = false; head = false;
+            for (int x : X) {
+                ab.push_back(std::abs(x));
+                if (std::abs(x) == tn.bridge.a + 1) { positive = x > 0; head = tn.bridge.ha; }
+                else if (std::abs(x) == tn.bridge.b + 1) { positive = x > 0; head = tn.bridge.hb; }
+            }
+            std::sort(ab.begin(), ab.end());
+            median = ab[(ab.size() - 1) / 2];
+        };
+        int m1, m2;
+        bool p1, h1, p2, h2;
+        scan(A, m1, p1, h1);
+        scan(B, m2, p2, h2);
+        auto flip = [](std::vector<int>& X) { std::reverse(X.begin(), X.end()); for (int& x : X) x = -x; };
+        if (m1 < m2) {
+            if (p1 == h1) flip(A);
+            if (p2 != h2) flip(B);
+            A.insert(A.end(), B.begin(), B.end());
+            return A;
+        }
+        if (p2 == h2) flip(B);
+        if (p1 != h1) flip(A);
+        B.insert(B.end(), A.begin(), A.end());
+        return B;
+    }
+};
+
+}  // namespace
+
+int order_components(sq_ctx* c) {
+    const int n = (int)c->nodes.size();
+    int ncomp = 0;
+    for (int l : c->label) ncomp = std::max(ncomp, l + 1);
+    // bucket nodes and edges per component (the reference rescans everything per component, :3248-3253)
+    std::vector<std::vector<int>> cn(ncomp);
+    std::vector<std::vector<Edge>> ce(ncomp);
+    for (int i = 0; i < n; ++i) cn[c->label[i]].push_back(i);
+    for (const Edge& e : c->edges) if (e.a != e.b) ce[c->label[e.a]].push_back(e);
+    Builder B;
+    std::vector<int> roots(ncomp);
+    auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < ncomp; ++k) roots[k] = B.build(cn[k], ce[k]);
+    c->timer.add("host_mincut_tree", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    // ---- leaves: <= 8 nodes on the GPU in one batch, the rest on the host
+    const int GPU_NMAX = 8, EXACT_MAX = 26;
+    std::vector<SmallProblem> probs;
+    std::vector<int32_t> edges5;
+    std::vector<int> gpu_piece;
+    for (size_t pi = 0; pi < B.pieces.size(); ++pi) {
+        Piece& p = B.pieces[pi];
+        const int pn = (int)p.ids.size();
+        if (pn == 1) continue;
+        if (pn <= GPU_NMAX) {
+            SmallProblem sp{pn, (int)(edges5.size() / 5), (int)p.edges.size()};
+            for (const LEdge& e : p.edges) { edges5.push_back(e.u); edges5.push_back(e.v); edges5.push_back(e.hu); edges5.push_back(e.hv); edges5.push_back(e.w); }
+            probs.push_back(sp);
+            gpu_piece.push_back((int)pi);
+        }
+    }
+    std::vector<int32_t> gmask, gorder;
+    int rc = dev_order_small(c, probs, edges5, gmask, gorder, GPU_NMAX);
+    if (rc) return rc;
+    for (size_t q = 0; q < gpu_piece.size(); ++q) {
+        Piece& p = B.pieces[gpu_piece[q]];
+        const int pn = (int)p.ids.size();
+        p.order.resize(pn);
+        for (int pos = 0; pos < pn; ++pos) {
+            int l = gorder[q * 8 + pos];
+            p.order[pos] = ((gmask[q] >> l) & 1) ? -(p.ids[l] + 1) : (p.ids[l] + 1);
+        }
+    }
+    t0 = std::chrono::steady_clock::now();
+    for (Piece& p : B.pieces) {
+        const int pn = (int)p.ids.size();
+        if (pn <= GPU_NMAX) continue;
+        p.order.resize(pn);
+        if (pn > EXACT_MAX) {
+            // what the reference keeps when glp_intopt gives up (:3287-3292,3984): identity order, all forward
+            for (int k = 0; k < pn; ++k) p.order[k] = p.ids[k] + 1;
+            continue;
+        }
+        HostSolver hs(pn, p.edges);
+        hs.run();
+        for (int pos = 0; pos < pn; ++pos) {
+            int l = hs.bestorder[pos];
+            p.order[pos] = ((hs.bestmask >> l) & 1) ? -(p.ids[l] + 1) : (p.ids[l] + 1);
+        }
+    }
+    c->timer.add("host_order_large", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    c->ord_off.assign(1, 0);
+    c->ord_nodes.clear();
+    for (int k = 0; k < ncomp; ++k) {
+        std::vector<int> o = B.combine(roots[k]);
+        c->ord_nodes.insert(c->ord_nodes.end(), o.begin(), o.end());
+        c->ord_off.push_back((int32_t)c->ord_nodes.size());
+    }
+    c->ordered = true;
+    return SQ_OK;
+}
+
+}  // namespace sq

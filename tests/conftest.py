@@ -1,0 +1,39 @@
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+BUILD = ROOT / "build"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Native artefacts (generator, oracle, library); built on demand so that a fresh checkout works."""
+    need = [BUILD / "gen_synth_bam", BUILD / "squid_oracle", BUILD / "libsquid_hip.so", BUILD / "squid"]
+    if not all(p.exists() for p in need):
+        subprocess.check_call(["make", "-C", str(ROOT), "-j4", "all"])
+    return BUILD
+
+
+@pytest.fixture(scope="session")
+def synth(built, tmp_path_factory):
+    """Factory: synthetic BAM pair for a generator config -> path prefix (cached per session)."""
+    cache = {}
+
+    def make(config, *extra):
+        key = (config,) + tuple(extra)
+        if key not in cache:
+            d = tmp_path_factory.mktemp("synth_" + config)
+            pre = d / config
+            subprocess.check_call([str(built / "gen_synth_bam"), "--config", config, "--out", str(pre), *extra], stdout=subprocess.DEVNULL)
+            cache[key] = pre
+        return cache[key]
+
+    return make
