@@ -69,7 +69,7 @@ struct DBuf {
         T* q = nullptr;
         hipError_t e = hipMalloc((void**)&q, want * sizeof(T));
         if (e != hipSuccess) return e;
-        if (used) e = hipMemcpyAsync(q, p, used * sizeof(T), hipMemcpyDeviceToDevice, s);
+        if (used && p) e = hipMemcpyAsync(q, p, used * sizeof(T), hipMemcpyDeviceToDevice, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (p) (void)hipFree(p);
         p = q;
@@ -593,11 +593,15 @@ __global__ void k_edges(RecView R, NodeView N, EdgeParams P, const uint8_t* keep
         }
     }
     if (nt == 0) return;
-    // ---- boundary edge for every unlocatable block
+    // ---- boundary edge for every unlocatable block (SegmentGraph.cpp:1612-1618).  The reference scans up from
+    // the refreshed hint while node.end < block.start, then down while node.start > block.start: a block that starts
+    // exactly on a node boundary lands in the node BELOW the boundary when the scan arrives from below.
+    const int ffi = node[0] != -1 ? node[0] : hint;
     for (int k = 0; k < nt; ++k)
         if (node[k] == -1) {
             if (bc[k] < 0 || bc[k] >= N.n_ref) { atomicOr(&flags[0], 8); continue; }
             int h = node_home(N, bc[k], bp[k]);
+            if (N.pos[h] == bp[k] && h > N.chr_start[bc[k]] && ffi <= h - 1) --h;
             emit_edge(hk, hv, hmask, h, false, h + 1, true, flags, N.n);
         }
     // ---- consecutive blocks of one mate in different nodes
@@ -924,7 +928,7 @@ int dev_append_records(sq_ctx* c, const sq_aln_batch* b) {
 #define GROW(buf, used, want) HIPCHK(D.buf.grow_keep(used, want, s))
     GROW(refid, n0, n1); GROW(pos, n0, n1); GROW(mrefid, n0, n1); GROW(mpos, n0, n1); GROW(endpos, n0, n1);
     GROW(flag, n0, n1); GROW(totlen, n0, n1); GROW(mapq, n0, n1); GROW(aux, n0, n1);
-    GROW(blk_off, n0 + 1, n1 + 1);
+    GROW(blk_off, n0 ? n0 + 1 : 0, n1 + 1);
     GROW(b_refpos, nb0, nb1); GROW(b_matchref, nb0, nb1); GROW(b_readpos, nb0, nb1); GROW(b_matchread, nb0, nb1);
 #undef GROW
 #define UP(buf, src, off, cnt) if (cnt) HIPCHK(hipMemcpyAsync(D.buf.p + (off), (src), (cnt) * sizeof(*D.buf.p), hipMemcpyHostToDevice, s))

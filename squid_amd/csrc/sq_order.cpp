@@ -74,6 +74,32 @@ struct HostSolver {
         }
         return ub;
     }
+    // Linear ordering for one orientation.  Arcs between different strongly connected components of the arc
+    // graph can all be satisfied, so only the non-trivial components need the subset DP; the canonical
+    // (lexicographically smallest optimal) sequence is then built greedily: the smallest node whose cross-component
+    // predecessors are placed and whose own component can still reach its optimum.
+    struct SccDP {
+        std::vector<int> mem;      // members, ascending
+        std::vector<long> h;       // h[S] = best weight still obtainable inside the component once S is placed
+        std::vector<int> a;        // local arc weights s x s
+        unsigned placed = 0;
+        long gain(unsigned S, int v) const {
+            const int s = (int)mem.size();
+            long g = 0;
+            for (unsigned m = S; m; m &= m - 1) g += a[__builtin_ctz(m) * s + v];
+            return g;
+        }
+        void solve() {
+            const int s = (int)mem.size();
+            const unsigned full = (1u << s) - 1;
+            h.assign((size_t)full + 1, 0);
+            for (unsigned S = full; S-- > 0;) {
+                long b = -1;
+                for (int v = 0; v < s; ++v) if (!((S >> v) & 1)) b = std::max(b, gain(S, v) + h[S | (1u << v)]);
+                h[S] = b;
+            }
+        }
+    };
     void leaf(unsigned mask) {
         std::vector<int> a((size_t)n * n, 0);
         long ub = 0;
@@ -83,46 +109,50 @@ struct HostSolver {
             ub += e.w;
             if (uf) a[e.u * n + e.v] += e.w; else a[e.v * n + e.u] += e.w;
         }
-        // smallest-index-first topological order, if the arcs are acyclic
-        std::vector<int> indeg(n, 0), order;
-        for (int x = 0; x < n; ++x) for (int y = 0; y < n; ++y) if (a[x * n + y] > 0) indeg[y]++;
+        // reachability closure on bitmasks -> strongly connected components
+        std::vector<unsigned> reach(n, 0);
+        for (int x = 0; x < n; ++x) { reach[x] = 1u << x; for (int y = 0; y < n; ++y) if (a[x * n + y] > 0) reach[x] |= 1u << y; }
+        for (int k = 0; k < n; ++k) for (int x = 0; x < n; ++x) if ((reach[x] >> k) & 1) reach[x] |= reach[k];
+        std::vector<int> comp(n, -1);
+        std::vector<SccDP> sccs;
+        long val = 0;
+        for (int x = 0; x < n; ++x) {
+            if (comp[x] >= 0) continue;
+            SccDP d;
+            for (int y = x; y < n; ++y) if (((reach[x] >> y) & 1) && ((reach[y] >> x) & 1)) { comp[y] = (int)sccs.size(); d.mem.push_back(y); }
+            sccs.push_back(std::move(d));
+        }
+        for (int x = 0; x < n; ++x) for (int y = 0; y < n; ++y) if (comp[x] != comp[y]) val += a[x * n + y];
+        std::vector<int> localidx(n, 0);
+        for (SccDP& d : sccs) {
+            const int s = (int)d.mem.size();
+            for (int i = 0; i < s; ++i) localidx[d.mem[i]] = i;
+            if (s == 1) continue;
+            d.a.assign((size_t)s * s, 0);
+            for (int i = 0; i < s; ++i) for (int j = 0; j < s; ++j) d.a[i * s + j] = a[d.mem[i] * n + d.mem[j]];
+            d.solve();
+            val += d.h[0];
+        }
+        if (!(val > best)) return;
+        std::vector<int> order;
         unsigned done = 0;
-        bool acyclic = true;
-        for (int p = 0; p < n && acyclic; ++p) {
-            int v = -1;
-            for (int q = 0; q < n; ++q) if (!((done >> q) & 1) && indeg[q] == 0) { v = q; break; }
-            if (v < 0) { acyclic = false; break; }
-            done |= 1u << v;
-            order.push_back(v);
-            for (int y = 0; y < n; ++y) if (a[v * n + y] > 0) indeg[y]--;
-        }
-        long val = ub;
-        if (!acyclic) {
-            // linear ordering by subset DP; gain(S,v) from two half-mask tables
-            const int lob = n / 2, hib = n - lob;
-            std::vector<long> GL((size_t)n << lob, 0), GH((size_t)n << hib, 0);
+        for (int p = 0; p < n; ++p)
             for (int v = 0; v < n; ++v) {
-                for (size_t m = 1; m < ((size_t)1 << lob); ++m) GL[((size_t)v << lob) + m] = GL[((size_t)v << lob) + (m & (m - 1))] + a[__builtin_ctzl(m) * n + v];
-                for (size_t m = 1; m < ((size_t)1 << hib); ++m) GH[((size_t)v << hib) + m] = GH[((size_t)v << hib) + (m & (m - 1))] + a[(lob + __builtin_ctzl(m)) * n + v];
+                if ((done >> v) & 1) continue;
+                bool ok = true;
+                for (int x = 0; x < n && ok; ++x) if (a[x * n + v] > 0 && comp[x] != comp[v] && !((done >> x) & 1)) ok = false;
+                if (!ok) continue;
+                SccDP& d = sccs[comp[v]];
+                if (d.mem.size() > 1) {
+                    int lv = localidx[v];
+                    if (d.gain(d.placed, lv) + d.h[d.placed | (1u << lv)] != d.h[d.placed]) continue;
+                    d.placed |= 1u << lv;
+                }
+                order.push_back(v);
+                done |= 1u << v;
+                break;
             }
-            auto gain = [&](size_t S, int v) { return GL[((size_t)v << lob) + (S & (((size_t)1 << lob) - 1))] + GH[((size_t)v << hib) + (S >> lob)]; };
-            const size_t full = ((size_t)1 << n) - 1;
-            std::vector<long> h(full + 1, 0);
-            for (size_t S = full; S-- > 0;) {
-                long b = -1;
-                for (int v = 0; v < n; ++v) if (!((S >> v) & 1)) b = std::max(b, gain(S, v) + h[S | ((size_t)1 << v)]);
-                h[S] = b;
-            }
-            val = h[0];
-            if (val > best) {
-                order.clear();
-                size_t S = 0;
-                for (int p = 0; p < n; ++p)
-                    for (int v = 0; v < n; ++v)
-                        if (!((S >> v) & 1) && gain(S, v) + h[S | ((size_t)1 << v)] == h[S]) { order.push_back(v); S |= (size_t)1 << v; break; }
-            }
-        }
-        if (val > best) { best = val; bestmask = mask; bestorder = order; }
+        best = val; bestmask = mask; bestorder = order;
     }
     void run() {
         // depth-first over nodes n-1..0, forward before reversed; a branch must be able to beat the incumbent strictly
