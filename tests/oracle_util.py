@@ -3,12 +3,14 @@ import subprocess
 from pathlib import Path
 
 
-def run_oracle(build_dir, prefix, outdir, *flags):
+def run_oracle(build_dir, prefix, outdir, *flags, check=True):
     outdir = Path(outdir)
     dump = outdir / "dump"
     dump.mkdir(parents=True, exist_ok=True)
     cmd = [str(Path(build_dir) / "squid_oracle"), "-b", f"{prefix}.bam", "-c", f"{prefix}.chim.bam", "-o", str(outdir / "oracle"), "--dump", str(dump), *flags]
-    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    rc = subprocess.call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL if not check else None)
+    if check and rc:
+        raise subprocess.CalledProcessError(rc, cmd)
     return outdir / "oracle_sv.txt", dump
 
 

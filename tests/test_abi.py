@@ -1,0 +1,54 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol include/squid_hip.h declares,
+and refuses to run its GPU stages without a device (no CPU fallback)."""
+import ctypes as C
+import re
+
+import pytest
+
+import squid_amd
+
+
+def _declared(root):
+    text = (root / "include" / "squid_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sq_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    lib = squid_amd.load_library()
+    names = _declared(squid_amd.ROOT)
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/squid_hip.h but not exported"
+    assert sorted(squid_amd.EXPORTS) == names
+
+
+def test_no_torch_or_cxx_types_in_signatures():
+    text = (squid_amd.ROOT / "include" / "squid_hip.h").read_text()
+    code = re.sub(r"/\*.*?\*/", "", text, flags=re.S)  # comments may mention torch.distributed
+    assert "std::" not in code and "torch" not in code and "at::" not in code and "#include <string>" not in code
+
+
+def test_header_reader_needs_no_gpu(built, synth):
+    pre = synth("C1")
+    names, lens = squid_amd.read_header(f"{pre}.bam")
+    assert names == ["chr1"] and lens == [10000000]
+
+
+def test_strerror_and_defaults(built):
+    lib = squid_amd.load_library()
+    p = squid_amd.SqParams()
+    lib.sq_default_params(C.byref(p))
+    # defaults of src/Config.cpp:19-28
+    assert (p.phred_type, p.max_lowphred_len, p.min_phred, p.min_mapqual) == (1, 10, 4, 1)
+    assert (p.concord_dist_pos, p.concord_dist_idx, p.min_edge_weight, p.discordant_ratio, p.max_allowed_degree) == (50000, 20, 5, 8.0, 5)
+    assert lib.sq_strerror(-2) == b"no usable HIP device"
+
+
+def test_context_fails_loudly_without_gpu(built):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(squid_amd.SquidError, match="no CPU fallback"):
+        squid_amd.Context()
