@@ -1,6 +1,8 @@
 // C-ABI entry points of libsquid_hip.so (include/squid_hip.h) and the stage pipeline behind them.
 #include <algorithm>
 #include <cstring>
+#include <future>
+#include <memory>
 
 #include "sq_internal.h"
 
@@ -44,8 +46,10 @@ struct HostClock {
     ~HostClock() { c->timer.add(name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
 };
 
-// per-node Support / AvgDepth (SegmentGraph.cpp:766-826): discordant blocks on the host, stream blocks from the GPU
-static int node_depth(sq_ctx* c, int64_t n_break, const std::vector<Blk>& disc) {
+// per-node Support / AvgDepth (SegmentGraph.cpp:766-826): discordant blocks on the host, stream blocks from the GPU.
+// Returns a task that finishes the (host-only) tail; it touches only Node::support / Node::depth, so the edge stage
+// can run meanwhile on chr/pos/len.
+static int node_depth(sq_ctx* c, int64_t n_break, const std::vector<Blk>& disc, std::function<void()>& finish) {
     std::vector<Node>& N = c->nodes;
     const int n = (int)N.size();
     {
@@ -59,47 +63,51 @@ static int node_depth(sq_ctx* c, int64_t n_break, const std::vector<Blk>& disc) 
             N[i].depth = sum;
         }
     }
-    std::vector<int32_t> sup, oc, op, ol;
-    std::vector<int64_t> sl;
-    bool exact_other = false;
-    int rc = dev_node_depth(c, N, n_break, sup, sl, exact_other, oc, op, ol);
+    struct Work { std::vector<int32_t> sup, oc, op, ol; std::vector<int64_t> sl; bool exact_other = false; };
+    std::shared_ptr<Work> w = std::make_shared<Work>();
+    int rc = dev_node_depth(c, N, n_break, w->sup, w->sl, w->exact_other, w->oc, w->op, w->ol);
     if (rc) return rc;
-    const int64_t n_other = sup[2 * n];
-    std::vector<int32_t> ocnt(n), osum(n);
-    for (int i = 0; i < n; ++i) { ocnt[i] = sup[n + i]; osum[i] = (int32_t)sl[n + i]; }
-    if (exact_other) {
-        // ReadsOther is sorted by (chr,pos) with an unstable std::sort (SegmentGraph.cpp:781); a <=3-base block right
-        // behind a node boundary is counted for whichever node the sweep cursor is on, which depends on that tie
-        // order.  Reproduce the sort on the same sequence and walk the cursor exactly.
-        HostClock hc(c, "host_depth_other_exact");
-        struct R { int32_t chr, pos, len; };
-        std::vector<R> ro(oc.size());
-        for (size_t i = 0; i < oc.size(); ++i) ro[i] = R{oc[i], op[i], ol[i]};
-        std::sort(ro.begin(), ro.end(), [](const R& a, const R& b) { return a.chr != b.chr ? a.chr < b.chr : a.pos < b.pos; });
-        std::fill(ocnt.begin(), ocnt.end(), 0);
-        std::fill(osum.begin(), osum.end(), 0);
-        size_t it = 0;
-        for (int i = 0; i < n; ++i)
-            for (; it != ro.size(); ++it) {
-                const R& r = ro[it];
-                if (r.chr == N[i].chr && r.pos >= N[i].pos - 3 && r.pos + r.len <= N[i].pos + N[i].len + 3) { ocnt[i]++; osum[i] += r.len; }
-                else if (r.pos >= N[i].pos + N[i].len || r.chr != N[i].chr) break;
-            }
-    }
-    for (int i = 0; i < n; ++i) {
-        N[i].support += sup[i];
-        N[i].depth += (int32_t)sl[i];
-        if (n_other != 0) {
-            N[i].support += ocnt[i];
-            N[i].depth += osum[i];
-            N[i].depth = 1.0 * N[i].depth / N[i].len;  // only when ReadsOther is non-empty (ledger B13)
+    finish = [c, w, n]() {
+        std::vector<Node>& N = c->nodes;
+        auto t0 = std::chrono::steady_clock::now();
+        const int64_t n_other = w->sup[2 * n];
+        std::vector<int32_t> ocnt(n), osum(n);
+        for (int i = 0; i < n; ++i) { ocnt[i] = w->sup[n + i]; osum[i] = (int32_t)w->sl[n + i]; }
+        if (w->exact_other) {
+            // ReadsOther is sorted by (chr,pos) with an unstable std::sort (SegmentGraph.cpp:781); a <=3-base block right
+            // behind a node boundary is counted for whichever node the sweep cursor is on, which depends on that tie
+            // order.  Reproduce the sort on the same sequence (stream order) and walk the cursor exactly.
+            struct R { int32_t chr, pos, len; };
+            std::vector<R> ro(w->oc.size());
+            for (size_t i = 0; i < ro.size(); ++i) ro[i] = R{w->oc[i], w->op[i], w->ol[i]};
+            std::sort(ro.begin(), ro.end(), [](const R& a, const R& b) { return a.chr != b.chr ? a.chr < b.chr : a.pos < b.pos; });
+            std::fill(ocnt.begin(), ocnt.end(), 0);
+            std::fill(osum.begin(), osum.end(), 0);
+            size_t it = 0;
+            for (int i = 0; i < n; ++i)
+                for (; it != ro.size(); ++it) {
+                    const R& r = ro[it];
+                    if (r.chr == N[i].chr && r.pos >= N[i].pos - 3 && r.pos + r.len <= N[i].pos + N[i].len + 3) { ocnt[i]++; osum[i] += r.len; }
+                    else if (r.pos >= N[i].pos + N[i].len || r.chr != N[i].chr) break;
+                }
         }
-    }
+        for (int i = 0; i < n; ++i) {
+            N[i].support += w->sup[i];
+            N[i].depth += (int32_t)w->sl[i];
+            if (n_other != 0) {
+                N[i].support += ocnt[i];
+                N[i].depth += osum[i];
+                N[i].depth = 1.0 * N[i].depth / N[i].len;  // only when ReadsOther is non-empty (ledger B13)
+            }
+        }
+        w->sl.assign(1, (int64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    };
     return SQ_OK;
 }
 
 static int build_graph(sq_ctx* c) {
     c->timer.clear();
+    HostClock wall(c, "wall_build_graph");
     c->graph_built = false;
     c->ordered = false;
     std::vector<StreamRec> recs;
@@ -122,18 +130,26 @@ static int build_graph(sq_ctx* c) {
         rc = tile_genome(c, seedcopy, c->nodes);
         if (rc) return rc;
     }
-    rc = node_depth(c, n_break, disc);
+    std::function<void()> finish_depth;
+    rc = node_depth(c, n_break, disc, finish_depth);
     if (rc) return rc;
+    // the host tail of the depth stage (possibly an exact std::sort of ReadsOther) overlaps the edge stage
+    auto tdepth0 = std::chrono::steady_clock::now();
+    std::future<void> depth_done = std::async(std::launch::async, finish_depth);
     c->edges.clear();
-    c->snap[1].take(c->nodes, c->edges, nullptr);
     std::vector<Edge> raw, conc;
     {
         HostClock hc(c, "host_chimeric_edges");
         rc = chimeric_edges(c, raw);
-        if (rc) return rc;
     }
-    rc = dev_concordant_edges(c, c->nodes, conc);
+    if (!rc) rc = dev_concordant_edges(c, c->nodes, conc);
+    {
+        HostClock hc(c, "host_depth_join_wait");
+        depth_done.get();
+    }
+    (void)tdepth0;
     if (rc) return rc;
+    c->snap[1].take(c->nodes, c->edges, nullptr);
     {
         HostClock hc(c, "host_edge_reduce");
         raw.insert(raw.end(), conc.begin(), conc.end());
@@ -166,6 +182,7 @@ static int build_graph(sq_ctx* c) {
 }
 
 static int call_sv(sq_ctx* c) {
+    HostClock wall(c, "wall_call_sv");
     if (!c->ordered) return fail(c, SQ_E_ARG, "sq_call_sv before sq_order");
     const std::vector<Node>& N = c->nodes;
     std::vector<Edge>& E = c->edges;

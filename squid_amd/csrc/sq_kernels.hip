@@ -95,9 +95,11 @@ struct DeviceRecords {
     DBuf<int32_t> n_chr, n_pos, n_len, n_chr_start;
     DBuf<int32_t> acc_a, acc_b, acc_c, acc_d;  // per-node accumulators
     // edge hash
-    DBuf<unsigned long long> h_key;
-    DBuf<uint32_t> h_val;
-    DBuf<long long> gather_key;
+    DBuf<unsigned long long> h_key, okey;
+    DBuf<uint32_t> h_val, oval;
+    uint32_t h_slots = 1u << 16;
+    DBuf<SmallProblem> ord_p;
+    DBuf<int32_t> ord_e, ord_m, ord_o, ord_v;
     DBuf<int32_t> flags;  // small device flag/counter block
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int64_t k1 = 0;  // kept pass-1 records
@@ -401,41 +403,81 @@ struct FEarlyMain {  // first block of every consumed kept record, in stream ord
         return depth_early(N, c, R.b_refpos[b0], R.b_matchref[b0], home);
     }
 };
+// add (1, len) to node `at` for every lane with `valid`; lanes of a wave that hit the same node are combined first
+// (a wave covers 64 neighbouring records of the sorted stream, which almost always share their node).
+// Must be called by ALL lanes of the wave (the shuffles read every lane).
+__device__ __forceinline__ void node_add(int32_t* cnt, int32_t* sum, bool valid, int at, int len) {
+    unsigned long long active = __ballot(valid);
+    const int lane = threadIdx.x & 63;
+    if (!valid) { at = -1; len = 0; }
+    while (active) {
+        int leader = __ffsll((long long)active) - 1;
+        int k = __shfl(at, leader, 64);
+        unsigned long long same = __ballot(at == k) & active;
+        int v = (at == k) ? len : 0;
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        if (lane == leader) { atomicAdd(&cnt[k], (int)__popcll(same)); atomicAdd(&sum[k], v); }
+        active &= ~same;
+    }
+}
 __global__ void k_depth(RecView R, NodeView N, const uint8_t* keep, const int32_t* rank1, int32_t n_break, const int32_t* cursor,
                         int32_t* main_cnt, int32_t* main_sum, int32_t* other_cnt, int32_t* other_sum, int32_t* flags) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R.n || !(keep[r] & K_1) || rank1[r] >= n_break) return;
-    uint32_t b0 = R.blk_off[r];
-    int nblk = (int)(R.blk_off[r + 1] - b0);
-    if (nblk == 0) return;
-    int c = R.refid[r];
-    if (c < 0 || c >= N.n_ref) { atomicOr(&flags[0], 1); return; }
-    {   // ReadsMain: consumed at the prefix-max cursor
-        int p = R.b_refpos[b0], len = R.b_matchref[b0];
-        int at = cursor[r];
-        if (N.chr[at] != c) atomicOr(&flags[0], 1);  // cursor stuck on another chromosome: stream not sorted
-        else if (p >= N.pos[at] - 3 && p + len <= N.pos[at] + N.len[at] + 3) { atomicAdd(&main_cnt[at], 1); atomicAdd(&main_sum[at], len); }
+    bool live = r < R.n && (keep[r] & K_1) && rank1[r] < n_break;
+    uint32_t b0 = live ? R.blk_off[r] : 0;
+    int nblk = live ? (int)(R.blk_off[r + 1] - b0) : 0;
+    int c = live ? R.refid[r] : 0;
+    if (nblk > 0 && (c < 0 || c >= N.n_ref)) { atomicOr(&flags[0], 1); nblk = 0; }
+    // ReadsMain: consumed at the prefix-max cursor
+    {
+        bool hit = false;
+        int at = 0, len = 0;
+        if (nblk > 0) {
+            int p = R.b_refpos[b0];
+            len = R.b_matchref[b0];
+            at = cursor[r];
+            if (N.chr[at] != c) atomicOr(&flags[0], 1);  // cursor stuck on another chromosome: stream not sorted
+            else hit = p >= N.pos[at] - 3 && p + len <= N.pos[at] + N.len[at] + 3;
+        }
+        node_add(main_cnt, main_sum, hit, at, len);
     }
-    for (int k = 1; k < nblk; ++k) {  // ReadsOther: sorted by (chr,pos) in the reference => consumed at its home node
-        int p = R.b_refpos[b0 + k], len = R.b_matchref[b0 + k];
-        int home;
-        int early = depth_early(N, c, p, len, home);
-        if (early != home) atomicOr(&flags[0], 2);  // tie-order sensitive corner: host resolves it exactly
-        atomicAdd(&flags[1], 1);
-        if (p + len <= N.pos[home] + N.len[home] + 3) { atomicAdd(&other_cnt[home], 1); atomicAdd(&other_sum[home], len); }
+    // ReadsOther: sorted by (chr,pos) in the reference => consumed at its home node
+    int maxb = nblk;
+    for (int d = 32; d >= 1; d >>= 1) { int o = __shfl_xor(maxb, d, 64); maxb = o > maxb ? o : maxb; }
+    for (int k = 1; k < maxb; ++k) {  // wave-uniform trip count
+        bool hit = false;
+        int home = 0, len = 0;
+        if (k < nblk) {
+            int p = R.b_refpos[b0 + k];
+            len = R.b_matchref[b0 + k];
+            int early = depth_early(N, c, p, len, home);
+            if (early != home) atomicOr(&flags[0], 2);  // tie-order sensitive corner: the host resolves it exactly
+            hit = p + len <= N.pos[home] + N.len[home] + 3;
+        }
+        node_add(other_cnt, other_sum, hit, home, len);
     }
+    int no = nblk > 1 ? nblk - 1 : 0;
+    for (int d = 32; d >= 1; d >>= 1) no += __shfl_xor(no, d, 64);
+    if ((threadIdx.x & 63) == 0 && no) atomicAdd(&flags[1], no);
 }
-__global__ void k_gather_other(RecView R, const uint8_t* keep, const int32_t* rank1, int32_t n_break, int32_t* counter, int32_t* o_chr, int32_t* o_pos, int32_t* o_len,
-                               long long* o_rank) {
-    // slow exact path only: materialise ReadsOther (with its stream rank for the host to restore stream order)
+// number of non-first blocks of a consumed kept record (|ReadsOther| contributions), for the ordered gather
+struct FOtherCount {
+    RecView R; const uint8_t* keep; const int32_t* rank1; int32_t n_break;
+    __device__ int operator()(int64_t r) const {
+        if (!(keep[r] & K_1) || rank1[r] >= n_break) return 0;
+        int nb = (int)(R.blk_off[r + 1] - R.blk_off[r]);
+        return nb > 1 ? nb - 1 : 0;
+    }
+};
+__global__ void k_gather_other(RecView R, const uint8_t* keep, const int32_t* rank1, int32_t n_break, const int32_t* off, int32_t* o_chr, int32_t* o_pos, int32_t* o_len) {
+    // slow exact path only: materialise ReadsOther in stream order (offsets from an exclusive scan)
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R.n || !(keep[r] & K_1) || rank1[r] >= n_break) return;
     uint32_t b0 = R.blk_off[r];
     int nblk = (int)(R.blk_off[r + 1] - b0);
     for (int k = 1; k < nblk; ++k) {
-        int slot = atomicAdd(counter, 1);
+        int slot = off[r] + k - 1;
         o_chr[slot] = R.refid[r]; o_pos[slot] = R.b_refpos[b0 + k]; o_len[slot] = R.b_matchref[b0 + k];
-        o_rank[slot] = (long long)rank1[r] * 64 + k;
     }
 }
 
@@ -911,7 +953,8 @@ void dev_destroy(sq_ctx* c) {
     D.srec.release(); D.rest_refpos.release(); D.rest_matchref.release();
     D.n_chr.release(); D.n_pos.release(); D.n_len.release(); D.n_chr_start.release();
     D.acc_a.release(); D.acc_b.release(); D.acc_c.release(); D.acc_d.release();
-    D.h_key.release(); D.h_val.release(); D.flags.release(); D.gather_key.release();
+    D.h_key.release(); D.h_val.release(); D.flags.release(); D.okey.release(); D.oval.release();
+    D.ord_p.release(); D.ord_e.release(); D.ord_m.release(); D.ord_o.release(); D.ord_v.release();
     if (D.ev0) (void)hipEventDestroy(D.ev0);
     if (D.ev1) (void)hipEventDestroy(D.ev1);
     delete c->dev;
@@ -1044,23 +1087,16 @@ int dev_node_depth(sq_ctx* c, const std::vector<Node>& nodes, int64_t n_break, s
     support.push_back(hf[1]);
     if (need_exact_other) {
         // a <=3-base block starts right behind a node boundary: which node counts it depends on the tie order that
-        // std::sort gives ReadsOther (SegmentGraph.cpp:781).  Hand the host the exact multiset in stream order.
+        // std::sort gives ReadsOther (SegmentGraph.cpp:781).  Hand the host the exact sequence in stream order.
         const int cnt = hf[1];
-        HIPCHK(D.scratch_b.reserve(cnt)); HIPCHK(D.scratch_c.reserve(cnt)); HIPCHK(D.b0_a.reserve(cnt)); HIPCHK(D.gather_key.reserve(cnt));
-        HIPCHK(hipMemsetAsync(D.flags.p + 4, 0, 4, s));
-        hipLaunchKernelGGL(k_gather_other, grid_for(n, 256), dim3(256), 0, s, R, D.keep.p, D.rank1.p, nbk, D.flags.p + 4, D.scratch_b.p, D.scratch_c.p, D.b0_a.p, D.gather_key.p);
-        std::vector<long long> rk(cnt);
+        HIPCHK(D.scratch_b.reserve(cnt)); HIPCHK(D.scratch_c.reserve(cnt)); HIPCHK(D.b0_a.reserve(cnt)); HIPCHK(D.b0_b.reserve(std::max<int64_t>(n, 1)));
+        { EvTimer t(c, "k_gather_other", 13.0 * n + 8.0 * D.nb);
+          HIPCHK((device_scan<OpSum, true>(s, n, FOtherCount{R, D.keep.p, D.rank1.p, nbk}, D.b0_b.p, D.spine, nullptr)));
+          hipLaunchKernelGGL(k_gather_other, grid_for(n, 256), dim3(256), 0, s, R, D.keep.p, D.rank1.p, nbk, D.b0_b.p, D.scratch_b.p, D.scratch_c.p, D.b0_a.p); }
         other_chr.resize(cnt); other_pos.resize(cnt); other_len.resize(cnt);
-        HIPCHK(hipMemcpyAsync(other_chr.data(), D.scratch_b.p, cnt * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(other_pos.data(), D.scratch_c.p, cnt * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(other_len.data(), D.b0_a.p, cnt * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(rk.data(), D.gather_key.p, (size_t)cnt * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(other_chr.data(), D.scratch_b.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(other_pos.data(), D.scratch_c.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(other_len.data(), D.b0_a.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        std::vector<int> perm(cnt);
-        for (int i = 0; i < cnt; ++i) perm[i] = i;
-        std::sort(perm.begin(), perm.end(), [&](int a, int b) { return rk[a] < rk[b]; });  // restore stream order (keys are unique)
-        std::vector<int32_t> t(cnt);
-        for (int i = 0; i < cnt; ++i) t[i] = other_chr[perm[i]]; other_chr.swap(t); t.resize(cnt);
-        for (int i = 0; i < cnt; ++i) t[i] = other_pos[perm[i]]; other_pos.swap(t); t.resize(cnt);
-        for (int i = 0; i < cnt; ++i) t[i] = other_len[perm[i]]; other_len.swap(t);
     }
     return SQ_OK;
 }
@@ -1077,31 +1113,35 @@ int dev_concordant_edges(sq_ctx* c, const std::vector<Node>& nodes, std::vector<
     if (rc) return rc;
     RecView R = D.view();
     HIPCHK(D.part_prev.reserve(n)); HIPCHK(D.part_next.reserve(n)); HIPCHK(D.b0_a.reserve(n)); HIPCHK(D.b0_b.reserve(n)); HIPCHK(D.b0_home.reserve(n));
-    const uint32_t slots = 1u << 22;
-    HIPCHK(D.h_key.reserve(slots)); HIPCHK(D.h_val.reserve(slots));
-    HIPCHK(hipMemsetAsync(D.h_key.p, 0xff, (size_t)slots * 8, s));
-    HIPCHK(hipMemsetAsync(D.h_val.p, 0, (size_t)slots * 4, s));
-    HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
-    HIPCHK(hipMemsetAsync(D.part_next.p, 0xff, (size_t)n * 4, s));
     { EvTimer t(c, "scan_part", 1.0 * n); HIPCHK((device_scan<OpMax, true>(s, n, FPart{D.keep.p}, D.part_prev.p, D.spine, nullptr))); }
+    HIPCHK(hipMemsetAsync(D.part_next.p, 0xff, (size_t)n * 4, s));
     { EvTimer t(c, "k_block0", 33.0 * n + 12.0 * D.nb);
       hipLaunchKernelGGL(k_block0, grid_for(n, 256), dim3(256), 0, s, R, nv, D.keep.p, D.part_prev.p, D.part_next.p, D.b0_a.p, D.b0_b.p, D.b0_home.p); }
     EdgeParams ep{c->P.concord_dist_pos, c->P.concord_dist_idx};
-    { EvTimer t(c, "k_edges", 28.0 * n + 12.0 * D.nb);
-      hipLaunchKernelGGL(k_edges, grid_for(n, 256), dim3(256), 0, s, R, nv, ep, D.keep.p, D.part_prev.p, D.part_next.p, D.b0_a.p, D.b0_b.p, D.b0_home.p, D.h_key.p, D.h_val.p, slots - 1,
-                         D.flags.p); }
     int32_t hf[4];
-    HIPCHK(hipMemcpyAsync(hf, D.flags.p, 16, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (hf[0] & 4) return fail(c, SQ_E_CAPACITY, "edge hash table full");
+    for (;;) {  // the table starts small and doubles when it fills up (unique edges are few)
+        const uint32_t slots = D.h_slots;
+        HIPCHK(D.h_key.reserve(slots)); HIPCHK(D.h_val.reserve(slots));
+        HIPCHK(hipMemsetAsync(D.h_key.p, 0xff, (size_t)slots * 8, s));
+        HIPCHK(hipMemsetAsync(D.h_val.p, 0, (size_t)slots * 4, s));
+        HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
+        { EvTimer t(c, "k_edges", 28.0 * n + 12.0 * D.nb);
+          hipLaunchKernelGGL(k_edges, grid_for(n, 256), dim3(256), 0, s, R, nv, ep, D.keep.p, D.part_prev.p, D.part_next.p, D.b0_a.p, D.b0_b.p, D.b0_home.p, D.h_key.p, D.h_val.p, slots - 1,
+                             D.flags.p); }
+        HIPCHK(hipMemcpyAsync(hf, D.flags.p, 16, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (!(hf[0] & 4)) break;
+        if (D.h_slots >= (1u << 28)) return fail(c, SQ_E_CAPACITY, "edge hash table full");
+        D.h_slots <<= 2;
+    }
+    const uint32_t slots = D.h_slots;
     if (hf[0] & 8) return fail(c, SQ_E_ASSERT, "edge node index out of range (the reference asserts at SegmentGraph.cpp:1617)");
     if (hf[0] & 16) return fail(c, SQ_E_CAPACITY, "record with more aligned blocks than the edge kernel handles");
     c->counts.n_raw_edges = hf[2];
-    // compact the table (unique keys are few: reuse the hint scratch for the output)
+    // compact the table
     HIPCHK(hipMemsetAsync(D.flags.p + 4, 0, 4, s));
-    DBuf<unsigned long long> okey;
-    DBuf<uint32_t> oval;
-    // upper bound on unique keys = raw edges
+    DBuf<unsigned long long>& okey = D.okey;
+    DBuf<uint32_t>& oval = D.oval;
     size_t cap = (size_t)std::max(1, std::min<int>(hf[2], (int)slots));
     HIPCHK(okey.reserve(cap)); HIPCHK(oval.reserve(cap));
     { EvTimer t(c, "k_hash_compact", 12.0 * slots); hipLaunchKernelGGL(k_hash_compact, grid_for(slots, 256), dim3(256), 0, s, D.h_key.p, D.h_val.p, slots, D.flags.p + 4, okey.p, oval.p); }
@@ -1110,8 +1150,7 @@ int dev_concordant_edges(sq_ctx* c, const std::vector<Node>& nodes, std::vector<
     HIPCHK(hipStreamSynchronize(s));
     std::vector<unsigned long long> hk(cnt);
     std::vector<uint32_t> hv(cnt);
-    if (cnt) { HIPCHK(hipMemcpy(hk.data(), okey.p, (size_t)cnt * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(hv.data(), oval.p, (size_t)cnt * 4, hipMemcpyDeviceToHost)); }
-    okey.release(); oval.release();
+    if (cnt) { HIPCHK(hipMemcpyAsync(hk.data(), okey.p, (size_t)cnt * 8, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(hv.data(), oval.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); }
     unique_edges.resize(cnt);
     for (int i = 0; i < cnt; ++i) {
         Edge e;
@@ -1156,8 +1195,9 @@ int dev_order_small(sq_ctx* c, const std::vector<SmallProblem>& probs, const std
     out_order.assign((size_t)np * ORD_NMAX, 0);
     if (!np) return SQ_OK;
     if (nmax > ORD_NMAX) return fail(c, SQ_E_ARG, "dev_order_small: nmax too large");
-    DBuf<SmallProblem> dp;
-    DBuf<int32_t> de, dm, dord, dval;
+    DeviceRecords& D = *c->dev;
+    DBuf<SmallProblem>& dp = D.ord_p;
+    DBuf<int32_t>&de = D.ord_e, &dm = D.ord_m, &dord = D.ord_o, &dval = D.ord_v;
     HIPCHK(dp.reserve(np)); HIPCHK(de.reserve(std::max<size_t>(edges5.size(), 1))); HIPCHK(dm.reserve(np)); HIPCHK(dord.reserve((size_t)np * ORD_NMAX)); HIPCHK(dval.reserve(np));
     HIPCHK(hipMemcpyAsync(dp.p, probs.data(), np * sizeof(SmallProblem), hipMemcpyHostToDevice, s));
     if (edges5.size()) HIPCHK(hipMemcpyAsync(de.p, edges5.data(), edges5.size() * 4, hipMemcpyHostToDevice, s));
@@ -1165,7 +1205,6 @@ int dev_order_small(sq_ctx* c, const std::vector<SmallProblem>& probs, const std
     HIPCHK(hipMemcpyAsync(out_mask.data(), dm.p, np * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(out_order.data(), dord.p, (size_t)np * ORD_NMAX * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    dp.release(); de.release(); dm.release(); dord.release(); dval.release();
     return SQ_OK;
 }
 

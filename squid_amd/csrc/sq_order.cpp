@@ -280,6 +280,7 @@ struct Builder {
 }  // namespace
 
 int order_components(sq_ctx* c) {
+    struct W { sq_ctx* c; std::chrono::steady_clock::time_point t0; ~W() { c->timer.add("wall_order", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); } } wall{c, std::chrono::steady_clock::now()};
     const int n = (int)c->nodes.size();
     int ncomp = 0;
     for (int l : c->label) ncomp = std::max(ncomp, l + 1);
