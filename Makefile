@@ -10,7 +10,12 @@ B := build
 CSRC := squid_amd/csrc
 LIBSRC := $(CSRC)/sq_kernels.hip $(CSRC)/sq_bam.cpp $(CSRC)/sq_chimeric.cpp $(CSRC)/sq_segment.cpp $(CSRC)/sq_graph.cpp $(CSRC)/sq_order.cpp $(CSRC)/sq_capi.cpp
 
-all: $(B)/libsquid_hip.so $(B)/squid $(B)/gen_synth_bam $(B)/squid_oracle
+all: $(B)/libsquid_hip.so $(B)/squid $(B)/gen_synth_bam $(B)/squid_oracle ref
+
+# oracle/_ref: the part of the real reference that builds without third-party libraries (flag parser), only when
+# the reference tree is present (authoring container); the GPU box uses the prebuilt binary
+ref:
+	$(MAKE) -C oracle ref
 
 $(B)/libsquid_hip.so: $(LIBSRC) $(CSRC)/sq_internal.h include/squid_hip.h
 	mkdir -p $(B)
@@ -28,4 +33,4 @@ $(B)/squid_oracle: oracle/squid_oracle.cpp oracle/o_bam.h oracle/o_readrec.h ora
 
 clean:
 	rm -rf $(B)
-.PHONY: all clean
+.PHONY: all clean ref

@@ -196,6 +196,14 @@ int main(int argc, char* argv[]) {
     if (argc >= 2 && std::string(argv[1]) == "--selftest") return solver_selftest(argc >= 3 ? std::atoi(argv[2]) : 2000);
     Params P;
     std::string dumpdir;
+    if (argc >= 2 && std::string(argv[1]) == "--print-config") {  // same line as oracle/ref_config_driver.cpp prints for the real parser
+        bool ok = parse_arguments(argc - 1, argv + 1, P, dumpdir);
+        std::printf("ok=%d star=%d pt=%d pl=%d pm=%d mq=%d dp=%d di=%d w=%d r=%.17g a=%d b=%s c=%s f=%s o=%s G=%d CO=%d TO=%d RG=%d\n", (int)ok, (int)P.UsingSTAR, (int)P.Phred_Type,
+                    (int)P.Max_LowPhred_Len, (int)P.Min_Phred, (int)P.Min_MapQual, P.Concord_Dist_Pos, P.Concord_Dist_Idx, P.Min_Edge_Weight, P.DiscordantRatio, P.MaxAllowedDegree,
+                    P.Input_BAM.c_str(), P.Input_Chim_BAM.c_str(), P.Input_FASTA.c_str(), P.Output_Prefix.c_str(), (int)P.Print_Graph, (int)P.Print_Components_Ordering,
+                    (int)P.Print_Total_Ordering, (int)P.Print_Rearranged_Genome);
+        return 0;
+    }
     if (!parse_arguments(argc, argv, P, dumpdir)) return 0;  // the reference's main returns 0 either way
     if (!P.UsingSTAR) { std::fprintf(stderr, "oracle: --bwa is out of scope (SURVEY.md section 8(f) next-1)\n"); return 0; }
     auto T0 = std::chrono::steady_clock::now();
