@@ -1,7 +1,8 @@
 // ORACLE (test infrastructure only) -- never linked, imported or executed by the product path.
 // PARITY UNPINNED (see o_bam.h), and doubly so here: the arithmetic of this stage lives in two un-vendored
 // third parties, GLPK 4.62 `glp_intopt` (reference Makefile:3, call site src/SegmentGraph.cpp:3966) and
-// Boost.Graph 1.55 `stoer_wagner_min_cut` (Makefile:1, call site :3325).  What is restated:
+// Boost.Graph 1.55 `stoer_wagner_min_cut` (Makefile:1, call site :3325; replaced by the bridge rule of BridgeSplit).
+// What is restated:
 //   src/SegmentGraph.cpp:3236-3262 Ordering, :3264-3451 MincutRecursion, :3763-3983 GenerateILP (the model).
 // The ILP is solved EXACTLY by enumeration; the optimum VALUE is solver independent.
 // Among equal-value optima GLPK's choice is unknowable here, so the oracle fixes a canonical one:
@@ -260,38 +261,36 @@ private:
         return BestOrder;
     }
 
-    // unit-weight Stoer-Wagner on the multigraph (parallel edges add up).  Tie-breaking is the oracle's own:
-    // start at vertex 0, first maximum in the adjacency search, first strictly smaller cut-of-the-phase wins.
-    static int StoerWagner(int n, const std::vector<std::pair<int, int>>& edges, std::vector<bool>& parity) {
-        std::vector<std::vector<int>> w(n, std::vector<int>(n, 0));
-        for (auto& e : edges) if (e.first != e.second) { w[e.first][e.second]++; w[e.second][e.first]++; }
-        std::vector<std::vector<int>> members(n);
-        for (int i = 0; i < n; i++) members[i].push_back(i);
-        std::vector<int> alive(n);
-        for (int i = 0; i < n; i++) alive[i] = i;
-        int best = std::numeric_limits<int>::max();
+    // Stand-in for boost::stoer_wagner_min_cut with unit weights (SegmentGraph.cpp:3316-3325).  The reference only
+    // distinguishes "min cut > 1" from "min cut == 1" and, in the latter case, uses the returned bipartition.  A unit
+    // weight cut of 1 is a bridge of the multigraph; WHICH bridge Boost returns is unknowable here (parity unpinned),
+    // so the rule is fixed as: among all bridges take the most balanced one (minimise |n - 2*side|), ties by the
+    // edge's position in the sorted component edge list.  Brute force: drop each candidate edge and flood-fill.
+    static int BridgeSplit(int n, const std::vector<std::pair<int, int>>& edges, std::vector<bool>& parity) {
+        std::vector<std::vector<int>> adj(n);
+        std::map<std::pair<int, int>, int> mult;
+        for (auto& e : edges) { adj[e.first].push_back(e.second); adj[e.second].push_back(e.first); mult[std::minmax(e.first, e.second)]++; }
+        int bestbal = -1;
         parity.assign(n, false);
-        while (alive.size() > 1) {
-            std::vector<int> wt(n, 0);
-            std::vector<bool> added(n, false);
-            int prev = -1, last = -1;
-            for (size_t it = 0; it < alive.size(); it++) {
-                int sel = -1;
-                for (int v : alive) if (!added[v] && (sel == -1 || wt[v] > wt[sel])) sel = v;
-                added[sel] = true;
-                prev = last; last = sel;
-                for (int v : alive) if (!added[v]) wt[v] += w[sel][v];
+        for (size_t ei = 0; ei < edges.size(); ei++) {
+            int u = edges[ei].first, v = edges[ei].second;
+            if (u == v || mult[std::minmax(u, v)] != 1) continue;
+            std::vector<bool> seen(n, false);
+            std::vector<int> st(1, v);
+            seen[v] = true;
+            int cnt = 0;
+            while (!st.empty()) {
+                int x = st.back(); st.pop_back(); cnt++;
+                for (int y : adj[x]) {
+                    if ((x == u && y == v) || (x == v && y == u)) continue;  // the candidate edge (its pair has multiplicity 1)
+                    if (!seen[y]) { seen[y] = true; st.push_back(y); }
+                }
             }
-            if (wt[last] < best) {
-                best = wt[last];
-                parity.assign(n, false);
-                for (int m : members[last]) parity[m] = true;
-            }
-            for (int m : members[last]) members[prev].push_back(m);
-            for (int v : alive) { w[prev][v] += w[last][v]; w[v][prev] = w[prev][v]; }
-            alive.erase(std::find(alive.begin(), alive.end(), last));
+            if (seen[u]) continue;  // still connected: not a bridge
+            int bal = std::abs(n - 2 * cnt);
+            if (bestbal < 0 || bal < bestbal) { bestbal = bal; parity = seen; }
         }
-        return best;
+        return bestbal < 0 ? 2 : 1;  // "2" stands for any cut value above 1
     }
 
     // src/SegmentGraph.cpp:3264-3451
@@ -301,7 +300,7 @@ private:
         std::vector<std::pair<int, int>> edges;
         for (const Edge_t& e : CompEdges) edges.push_back(std::make_pair(CompNodes[e.Ind1], CompNodes[e.Ind2]));
         std::vector<bool> parities;
-        int w = StoerWagner((int)CompNodes.size(), edges, parities);
+        int w = BridgeSplit((int)CompNodes.size(), edges, parities);
         if (w > 1) return SolveWhole(CompNodes, CompEdges);
         stats.mincut_splits++;
         std::map<int, int> VertexParty1, VertexParty2;

@@ -170,39 +170,57 @@ struct HostSolver {
     }
 };
 
-// unit-weight Stoer-Wagner on the multigraph; deterministic rule: start at local vertex 0, first maximum in the
-// adjacency search, first strictly smaller cut-of-the-phase wins
-int stoer_wagner(int n, const std::vector<std::pair<int, int>>& edges, std::vector<char>& side) {
-    std::vector<int> w((size_t)n * n, 0);
-    for (auto& e : edges) if (e.first != e.second) { w[e.first * n + e.second]++; w[e.second * n + e.first]++; }
-    std::vector<std::vector<int>> members(n);
-    std::vector<int> alive(n);
-    for (int i = 0; i < n; ++i) { members[i].push_back(i); alive[i] = i; }
-    int best = INT32_MAX;
-    side.assign(n, 0);
-    std::vector<int> wt(n);
-    std::vector<char> added(n);
-    while (alive.size() > 1) {
-        std::fill(wt.begin(), wt.end(), 0);
-        std::fill(added.begin(), added.end(), 0);
-        int prev = -1, last = -1;
-        for (size_t it = 0; it < alive.size(); ++it) {
-            int sel = -1;
-            for (int v : alive) if (!added[v] && (sel == -1 || wt[v] > wt[sel])) sel = v;
-            added[sel] = 1;
-            prev = last; last = sel;
-            for (int v : alive) if (!added[v]) wt[v] += w[sel * n + v];
+// Replacement for boost::stoer_wagner_min_cut with unit weights (SegmentGraph.cpp:3316-3325): the reference only asks
+// "is the min cut 1?" and then uses the bipartition.  A cut of 1 is a bridge of the multigraph.  Rule (shared with
+// the oracle): take the most balanced bridge (minimise |n - 2*side|), ties by position in the
+// sorted component edge list; no bridge => "cut > 1".  Bridges by an iterative low-link DFS, O(n + m).
+bool bridge_split(int n, const std::vector<std::pair<int, int>>& edges, std::vector<char>& side) {
+    const int m = (int)edges.size();
+    std::vector<int> head(n + 1, 0), adj(2 * (size_t)m), aid(2 * (size_t)m);
+    for (auto& e : edges) { head[e.first + 1]++; head[e.second + 1]++; }
+    for (int i = 0; i < n; ++i) head[i + 1] += head[i];
+    {
+        std::vector<int> fill(head.begin(), head.end() - 1);
+        for (int i = 0; i < m; ++i) {
+            adj[fill[edges[i].first]] = edges[i].second; aid[fill[edges[i].first]++] = i;
+            adj[fill[edges[i].second]] = edges[i].first; aid[fill[edges[i].second]++] = i;
         }
-        if (wt[last] < best) {
-            best = wt[last];
-            std::fill(side.begin(), side.end(), 0);
-            for (int mbr : members[last]) side[mbr] = 1;
-        }
-        members[prev].insert(members[prev].end(), members[last].begin(), members[last].end());
-        for (int v : alive) { w[prev * n + v] += w[last * n + v]; w[v * n + prev] = w[prev * n + v]; }
-        alive.erase(std::find(alive.begin(), alive.end(), last));
     }
-    return best;
+    std::vector<int> disc(n, -1), low(n, 0), parent_edge(n, -1), sub(n, 1), it(n, 0), order;
+    order.reserve(n);
+    std::vector<int> stack(1, 0);
+    int timer = 0;
+    disc[0] = low[0] = timer++;
+    int best_edge = -1, best_bal = -1, best_child = -1;
+    std::vector<int> tin(n, 0), tout(n, 0);
+    tin[0] = 0;
+    while (!stack.empty()) {
+        int x = stack.back();
+        if (it[x] < head[x + 1] - head[x]) {
+            int k = head[x] + it[x]++;
+            int y = adj[k], id = aid[k];
+            if (id == parent_edge[x]) continue;          // the tree edge itself; a PARALLEL edge has another id and counts as a back edge
+            if (disc[y] < 0) { disc[y] = low[y] = timer++; parent_edge[y] = id; stack.push_back(y); }
+            else low[x] = std::min(low[x], disc[y]);
+        } else {
+            stack.pop_back();
+            if (!stack.empty()) {
+                int p = stack.back();
+                low[p] = std::min(low[p], low[x]);
+                sub[p] += sub[x];
+                if (low[x] > disc[p]) {  // bridge p - x
+                    int bal = std::abs(n - 2 * sub[x]);
+                    int id = parent_edge[x];
+                    if (best_bal < 0 || bal < best_bal || (bal == best_bal && id < best_edge)) { best_bal = bal; best_edge = id; best_child = x; }
+                }
+            }
+        }
+    }
+    if (best_edge < 0) return false;
+    // side = subtree of best_child: nodes discovered in [disc[child], disc[child] + sub[child])
+    side.assign(n, 0);
+    for (int v = 0; v < n; ++v) if (disc[v] >= disc[best_child] && disc[v] < disc[best_child] + sub[best_child]) side[v] = 1;
+    return true;
 }
 
 struct Builder {
@@ -219,7 +237,7 @@ struct Builder {
             auto local = [&](int g) { return (int)(std::lower_bound(ids.begin(), ids.end(), g) - ids.begin()); };
             std::vector<std::pair<int, int>> le;
             for (const Edge& e : E) le.push_back(std::make_pair(local(e.a), local(e.b)));
-            if (stoer_wagner(n, le, side) > 1) whole = true;
+            if (!bridge_split(n, le, side)) whole = true;
         }
         if (whole || n == 1) {
             Piece p;

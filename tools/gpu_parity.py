@@ -33,13 +33,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="C1,T2,C2")
     ap.add_argument("--flags", default="")
+    ap.add_argument("--gen", default="", help="extra generator arguments, e.g. '--records 10000000'")
     a = ap.parse_args()
     B = ROOT / "build"
     ok_all = True
     for cfg in a.configs.split(","):
         with tempfile.TemporaryDirectory() as td:
             pre = Path(td) / cfg
-            print(subprocess.check_output([str(B / "gen_synth_bam"), "--config", cfg, "--out", str(pre)]).decode().strip())
+            print(subprocess.check_output([str(B / "gen_synth_bam"), "--config", cfg, "--out", str(pre), "--threads", "16", *a.gen.split()]).decode().strip())
             t0 = time.time()
             sv_path, dump = ou.run_oracle(B, pre, td, *a.flags.split())
             t_or = time.time() - t0
