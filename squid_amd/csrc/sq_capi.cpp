@@ -46,65 +46,6 @@ struct HostClock {
     ~HostClock() { c->timer.add(name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
 };
 
-// per-node Support / AvgDepth (SegmentGraph.cpp:766-826): discordant blocks on the host, stream blocks from the GPU.
-// Returns a task that finishes the (host-only) tail; it touches only Node::support / Node::depth, so the edge stage
-// can run meanwhile on chr/pos/len.
-static int node_depth(sq_ctx* c, int64_t n_break, const std::vector<Blk>& disc, std::function<void()>& finish) {
-    std::vector<Node>& N = c->nodes;
-    const int n = (int)N.size();
-    {
-        HostClock hc(c, "host_depth_discordant");
-        size_t it = 0;
-        for (int i = 0; i < n; ++i) {
-            int cnt = 0, sum = 0;
-            for (; it != disc.size() && disc[it].refid == N[i].chr && disc[it].refpos < N[i].pos + N[i].len; ++it)
-                if (disc[it].refpos >= N[i].pos && disc[it].refpos + disc[it].matchref <= N[i].pos + N[i].len) { ++cnt; sum += disc[it].matchref; }
-            N[i].support = cnt;
-            N[i].depth = sum;
-        }
-    }
-    struct Work { std::vector<int32_t> sup, oc, op, ol; std::vector<int64_t> sl; bool exact_other = false; };
-    std::shared_ptr<Work> w = std::make_shared<Work>();
-    int rc = dev_node_depth(c, N, n_break, w->sup, w->sl, w->exact_other, w->oc, w->op, w->ol);
-    if (rc) return rc;
-    finish = [c, w, n]() {
-        std::vector<Node>& N = c->nodes;
-        auto t0 = std::chrono::steady_clock::now();
-        const int64_t n_other = w->sup[2 * n];
-        std::vector<int32_t> ocnt(n), osum(n);
-        for (int i = 0; i < n; ++i) { ocnt[i] = w->sup[n + i]; osum[i] = (int32_t)w->sl[n + i]; }
-        if (w->exact_other) {
-            // ReadsOther is sorted by (chr,pos) with an unstable std::sort (SegmentGraph.cpp:781); a <=3-base block right
-            // behind a node boundary is counted for whichever node the sweep cursor is on, which depends on that tie
-            // order.  Reproduce the sort on the same sequence (stream order) and walk the cursor exactly.
-            struct R { int32_t chr, pos, len; };
-            std::vector<R> ro(w->oc.size());
-            for (size_t i = 0; i < ro.size(); ++i) ro[i] = R{w->oc[i], w->op[i], w->ol[i]};
-            std::sort(ro.begin(), ro.end(), [](const R& a, const R& b) { return a.chr != b.chr ? a.chr < b.chr : a.pos < b.pos; });
-            std::fill(ocnt.begin(), ocnt.end(), 0);
-            std::fill(osum.begin(), osum.end(), 0);
-            size_t it = 0;
-            for (int i = 0; i < n; ++i)
-                for (; it != ro.size(); ++it) {
-                    const R& r = ro[it];
-                    if (r.chr == N[i].chr && r.pos >= N[i].pos - 3 && r.pos + r.len <= N[i].pos + N[i].len + 3) { ocnt[i]++; osum[i] += r.len; }
-                    else if (r.pos >= N[i].pos + N[i].len || r.chr != N[i].chr) break;
-                }
-        }
-        for (int i = 0; i < n; ++i) {
-            N[i].support += w->sup[i];
-            N[i].depth += (int32_t)w->sl[i];
-            if (n_other != 0) {
-                N[i].support += ocnt[i];
-                N[i].depth += osum[i];
-                N[i].depth = 1.0 * N[i].depth / N[i].len;  // only when ReadsOther is non-empty (ledger B13)
-            }
-        }
-        w->sl.assign(1, (int64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
-    };
-    return SQ_OK;
-}
-
 static int build_graph(sq_ctx* c) {
     c->timer.clear();
     HostClock wall(c, "wall_build_graph");
@@ -117,25 +58,86 @@ static int build_graph(sq_ctx* c) {
     std::vector<Node> seeds;
     std::vector<Blk> disc;
     int64_t n_break = 0;
+    std::shared_ptr<SegPlan> plan;
     {
-        HostClock hc(c, "host_segment_automaton");
-        SegmentInput in{recs.data(), (int64_t)recs.size(), rest_p.data(), rest_m.data()};
-        rc = segment_genome(c, in, seeds, n_break, disc);
+        HostClock hc(c, "host_segment_prepare");
+        rc = segment_prepare(c, plan, n_break, disc);
         if (rc) return rc;
     }
     c->counts.n_break = n_break;
+    // ReadsOther can be materialised as soon as n_break is known; if it holds a <=3-base block the host repeats the
+    // reference's unstable sort of it (SegmentGraph.cpp:781) on a second thread while the automaton runs
+    struct OtherWork { std::vector<int32_t> chr, pos, len; struct R { int32_t chr, pos, len; }; std::vector<R> sorted; bool has_tiny = false; };
+    std::shared_ptr<OtherWork> ow = std::make_shared<OtherWork>();
+    rc = dev_gather_other(c, n_break, ow->has_tiny, ow->chr, ow->pos, ow->len);
+    if (rc) return rc;
+    std::future<void> other_sorted;
+    if (ow->has_tiny)
+        other_sorted = std::async(std::launch::async, [ow]() {
+            ow->sorted.resize(ow->chr.size());
+            for (size_t i = 0; i < ow->sorted.size(); ++i) ow->sorted[i] = OtherWork::R{ow->chr[i], ow->pos[i], ow->len[i]};
+            std::sort(ow->sorted.begin(), ow->sorted.end(), [](const OtherWork::R& a, const OtherWork::R& b) { return a.chr != b.chr ? a.chr < b.chr : a.pos < b.pos; });
+        });
+    {
+        HostClock hc(c, "host_segment_replay");
+        rc = segment_replay(c, *plan, seeds);
+    }
+    if (rc) { if (other_sorted.valid()) other_sorted.get(); return rc; }
     {
         HostClock hc(c, "host_tile_genome");
         std::vector<Node> seedcopy = seeds;
         rc = tile_genome(c, seedcopy, c->nodes);
-        if (rc) return rc;
     }
-    std::function<void()> finish_depth;
-    rc = node_depth(c, n_break, disc, finish_depth);
-    if (rc) return rc;
-    // the host tail of the depth stage (possibly an exact std::sort of ReadsOther) overlaps the edge stage
-    auto tdepth0 = std::chrono::steady_clock::now();
-    std::future<void> depth_done = std::async(std::launch::async, finish_depth);
+    if (rc) { if (other_sorted.valid()) other_sorted.get(); return rc; }
+    // per-node Support / AvgDepth (SegmentGraph.cpp:766-826): discordant blocks on the host, stream blocks from the GPU
+    std::vector<Node>& N = c->nodes;
+    const int nn = (int)N.size();
+    {
+        HostClock hc(c, "host_depth_discordant");
+        size_t it = 0;
+        for (int i = 0; i < nn; ++i) {
+            int cnt = 0, sum = 0;
+            for (; it != disc.size() && disc[it].refid == N[i].chr && disc[it].refpos < N[i].pos + N[i].len; ++it)
+                if (disc[it].refpos >= N[i].pos && disc[it].refpos + disc[it].matchref <= N[i].pos + N[i].len) { ++cnt; sum += disc[it].matchref; }
+            N[i].support = cnt;
+            N[i].depth = sum;
+        }
+    }
+    std::vector<int32_t> sup, dummy1, dummy2, dummy3;
+    std::vector<int64_t> sl;
+    bool exact_other = false;
+    rc = dev_node_depth(c, N, n_break, sup, sl, exact_other, dummy1, dummy2, dummy3);
+    if (rc) { if (other_sorted.valid()) other_sorted.get(); return rc; }
+    // the host tail of the depth stage overlaps the edge stage; it only writes Node::support / Node::depth
+    std::future<void> depth_done = std::async(std::launch::async, [c, ow, nn, exact_other, &other_sorted, sup, sl]() {
+        std::vector<Node>& N = c->nodes;
+        const int64_t n_other = sup[2 * nn];
+        std::vector<int32_t> ocnt(nn), osum(nn);
+        for (int i = 0; i < nn; ++i) { ocnt[i] = sup[nn + i]; osum[i] = (int32_t)sl[nn + i]; }
+        if (other_sorted.valid()) other_sorted.get();
+        if (exact_other) {
+            // a <=3-base block right behind a node boundary is counted for whichever node the sweep cursor is on, which
+            // depends on the tie order of that sort: walk the cursor over the identically sorted list
+            std::fill(ocnt.begin(), ocnt.end(), 0);
+            std::fill(osum.begin(), osum.end(), 0);
+            size_t it = 0;
+            for (int i = 0; i < nn; ++i)
+                for (; it != ow->sorted.size(); ++it) {
+                    const OtherWork::R& r = ow->sorted[it];
+                    if (r.chr == N[i].chr && r.pos >= N[i].pos - 3 && r.pos + r.len <= N[i].pos + N[i].len + 3) { ocnt[i]++; osum[i] += r.len; }
+                    else if (r.pos >= N[i].pos + N[i].len || r.chr != N[i].chr) break;
+                }
+        }
+        for (int i = 0; i < nn; ++i) {
+            N[i].support += sup[i];
+            N[i].depth += (int32_t)sl[i];
+            if (n_other != 0) {
+                N[i].support += ocnt[i];
+                N[i].depth += osum[i];
+                N[i].depth = 1.0 * N[i].depth / N[i].len;  // only when ReadsOther is non-empty (ledger B13)
+            }
+        }
+    });
     c->edges.clear();
     std::vector<Edge> raw, conc;
     {
@@ -147,7 +149,6 @@ static int build_graph(sq_ctx* c) {
         HostClock hc(c, "host_depth_join_wait");
         depth_done.get();
     }
-    (void)tdepth0;
     if (rc) return rc;
     c->snap[1].take(c->nodes, c->edges, nullptr);
     {

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <functional>
 #include <map>
+#include <memory>
 #include <string>
 #include <unordered_set>
 #include <vector>
@@ -98,6 +99,7 @@ struct sq_ctx {
     int64_t n_chim_records = 0;
     // concordant side (device)
     sq::DeviceRecords* dev = nullptr;
+    std::vector<sq::StreamRec> stream_host;     // host mirror of the kept-stream summaries (filled only where replayed)
     // graph state (host, small)
     std::vector<sq::Node> nodes;
     std::vector<sq::Edge> edges;
@@ -143,12 +145,9 @@ bool frag_single_anchored(const Frag& f);
 bool frag_equal(const Frag& x, const Frag& y);
 
 // ---- sq_segment.cpp  (host control of K2; counting data comes from the GPU summaries)
-struct SegmentInput {
-    const StreamRec* recs; int64_t n;
-    const int32_t* rest_refpos; const int32_t* rest_matchref;
-};
-int segment_genome(sq_ctx* c, const SegmentInput& in, std::vector<Node>& seeds, int64_t& n_break,
-                   std::vector<Blk>& bamdiscordant_sorted);
+struct SegPlan;  // sq_segment.cpp
+int segment_prepare(sq_ctx* c, std::shared_ptr<SegPlan>& plan, int64_t& n_break, std::vector<Blk>& bamdiscordant_sorted);
+int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds);
 int tile_genome(sq_ctx* c, std::vector<Node>& seeds, std::vector<Node>& out);
 
 // ---- sq_graph.cpp
@@ -173,7 +172,13 @@ int order_components(sq_ctx* c);
 int dev_create(sq_ctx* c);
 void dev_destroy(sq_ctx* c);
 int dev_append_records(sq_ctx* c, const sq_aln_batch* b);
+struct SegSupport {
+    std::vector<int32_t> trigger, zidx, z_ochr, z_oright, rest_cluster, rest_pos, rest_len;
+};
+int dev_segment_support(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<int32_t>& cl_start, const std::vector<int32_t>& cl_right, int64_t n_rest, SegSupport& out);
+int dev_fetch_stream(sq_ctx* c, const std::vector<std::pair<int64_t, int64_t>>& ranges, StreamRec* dst);
 int dev_classify_and_summarise(sq_ctx* c, std::vector<StreamRec>& recs, std::vector<int32_t>& rest_refpos, std::vector<int32_t>& rest_matchref);
+int dev_gather_other(sq_ctx* c, int64_t n_break, bool& has_tiny, std::vector<int32_t>& other_chr, std::vector<int32_t>& other_pos, std::vector<int32_t>& other_len);
 int dev_node_depth(sq_ctx* c, const std::vector<Node>& nodes, int64_t n_break, std::vector<int32_t>& support, std::vector<int64_t>& sumlen,
                    bool& need_exact_other, std::vector<int32_t>& other_chr, std::vector<int32_t>& other_pos, std::vector<int32_t>& other_len);
 int dev_concordant_edges(sq_ctx* c, const std::vector<Node>& nodes, std::vector<Edge>& unique_edges);

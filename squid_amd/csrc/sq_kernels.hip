@@ -100,6 +100,9 @@ struct DeviceRecords {
     uint32_t h_slots = 1u << 16;
     DBuf<SmallProblem> ord_p;
     DBuf<int32_t> ord_e, ord_m, ord_o, ord_v;
+    DBuf<long long> other64, spine64;
+    DBuf<uint8_t> zflag;
+    DBuf<int32_t> cl_chr, cl_start, cl_right, trig;
     DBuf<int32_t> flags;  // small device flag/counter block
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int64_t k1 = 0;  // kept pass-1 records
@@ -187,57 +190,65 @@ __device__ __forceinline__ int node_home(const NodeView& N, int c, int p) {
 // Three-phase device scan over int32 values produced by a functor: tile reduce -> spine -> tile down-sweep.
 constexpr int SCAN_THREADS = 256, SCAN_ITEMS = 8, SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 
-struct OpSum { static __device__ __forceinline__ int id() { return 0; } static __device__ __forceinline__ int op(int a, int b) { return a + b; } };
-struct OpMax { static __device__ __forceinline__ int id() { return INT_MIN; } static __device__ __forceinline__ int op(int a, int b) { return a > b ? a : b; } };
-struct OpMin { static __device__ __forceinline__ int id() { return INT_MAX; } static __device__ __forceinline__ int op(int a, int b) { return a < b ? a : b; } };
+struct OpSum { typedef int T; static __device__ __forceinline__ int id() { return 0; } static __device__ __forceinline__ int op(int a, int b) { return a + b; } };
+struct OpMax { typedef int T; static __device__ __forceinline__ int id() { return INT_MIN; } static __device__ __forceinline__ int op(int a, int b) { return a > b ? a : b; } };
+struct OpMin { typedef int T; static __device__ __forceinline__ int id() { return INT_MAX; } static __device__ __forceinline__ int op(int a, int b) { return a < b ? a : b; } };
+struct OpMax64 {
+    typedef long long T;
+    static __device__ __forceinline__ long long id() { return LLONG_MIN; }
+    static __device__ __forceinline__ long long op(long long a, long long b) { return a > b ? a : b; }
+};
 
 template <typename Op>
-__device__ __forceinline__ int block_scan_excl(int v, int& total, int* lds) {  // exclusive scan of one value per thread
+__device__ __forceinline__ typename Op::T block_scan_excl(typename Op::T v, typename Op::T& total, typename Op::T* lds) {  // exclusive scan, one value per thread
+    typedef typename Op::T T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int x = v;
+    T x = v;
     for (int d = 1; d < 64; d <<= 1) {
-        int y = __shfl_up(x, d, 64);
+        T y = __shfl_up(x, d, 64);
         if (lane >= d) x = Op::op(x, y);
     }
     if (lane == 63) lds[wave] = x;
     __syncthreads();
-    int wprefix = Op::id();
-    int tot = Op::id();
+    T wprefix = Op::id();
+    T tot = Op::id();
     for (int w = 0; w < SCAN_THREADS / 64; ++w) {
-        int t = lds[w];
+        T t = lds[w];
         if (w < wave) wprefix = Op::op(wprefix, t);
         tot = Op::op(tot, t);
     }
     __syncthreads();
     total = tot;
-    int incl = Op::op(wprefix, x);
-    int prev = __shfl_up(incl, 1, 64);
+    T incl = Op::op(wprefix, x);
+    T prev = __shfl_up(incl, 1, 64);
     if (lane == 0) prev = wprefix;
     return prev;
 }
 
 template <typename Op, typename F>
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(int64_t n, F f, int32_t* tile_agg) {
-    __shared__ int lds[SCAN_THREADS / 64];
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(int64_t n, F f, typename Op::T* tile_agg) {
+    typedef typename Op::T T;
+    __shared__ T lds[SCAN_THREADS / 64];
     int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
-    int acc = Op::id();
+    T acc = Op::id();
     for (int i = 0; i < SCAN_ITEMS; ++i) {
         int64_t idx = base + (int64_t)i * SCAN_THREADS + threadIdx.x;
         if (idx < n) acc = Op::op(acc, f(idx));
     }
-    int total;
+    T total;
     block_scan_excl<Op>(acc, total, lds);
     if (threadIdx.x == 0) tile_agg[blockIdx.x] = total;
 }
 template <typename Op>
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_spine(int ntiles, int32_t* tile_agg, int32_t* grand) {
-    __shared__ int lds[SCAN_THREADS / 64];
-    int carry = Op::id();
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_spine(int ntiles, typename Op::T* tile_agg, typename Op::T* grand) {
+    typedef typename Op::T T;
+    __shared__ T lds[SCAN_THREADS / 64];
+    T carry = Op::id();
     for (int base = 0; base < ntiles; base += SCAN_THREADS) {
         int i = base + threadIdx.x;
-        int v = i < ntiles ? tile_agg[i] : Op::id();
-        int total;
-        int ex = block_scan_excl<Op>(v, total, lds);
+        T v = i < ntiles ? tile_agg[i] : Op::id();
+        T total;
+        T ex = block_scan_excl<Op>(v, total, lds);
         if (i < ntiles) tile_agg[i] = Op::op(carry, ex);
         carry = Op::op(carry, total);
     }
@@ -245,18 +256,19 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_spine(int ntiles, int32_t
 }
 // exclusive (EXCL) or inclusive result; items are laid out blocked per thread so that order is preserved
 template <typename Op, bool EXCL, typename F>
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_down(int64_t n, F f, const int32_t* tile_prefix, int32_t* out) {
-    __shared__ int lds[SCAN_THREADS / 64];
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_down(int64_t n, F f, const typename Op::T* tile_prefix, typename Op::T* out) {
+    typedef typename Op::T T;
+    __shared__ T lds[SCAN_THREADS / 64];
     int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
-    int v[SCAN_ITEMS];
-    int acc = Op::id();
+    T v[SCAN_ITEMS];
+    T acc = Op::id();
     for (int i = 0; i < SCAN_ITEMS; ++i) {
-        v[i] = (base + i < n) ? f(base + i) : Op::id();
+        v[i] = (base + i < n) ? (T)f(base + i) : Op::id();
         acc = Op::op(acc, v[i]);
     }
-    int total;
-    int ex = block_scan_excl<Op>(acc, total, lds);
-    int run = Op::op(tile_prefix[blockIdx.x], ex);
+    T total;
+    T ex = block_scan_excl<Op>(acc, total, lds);
+    T run = Op::op(tile_prefix[blockIdx.x], ex);
     for (int i = 0; i < SCAN_ITEMS; ++i) {
         if (base + i < n) {
             if (EXCL) { out[base + i] = run; run = Op::op(run, v[i]); }
@@ -265,11 +277,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_down(int64_t n, F f, cons
     }
 }
 // NOTE: k_scan_reduce reads strided while k_scan_down reads blocked; both cover the same tile, and Op is
-// commutative for all three instantiations, so the tile aggregates agree.
+// commutative for all instantiations, so the tile aggregates agree.
 
 template <typename Op, bool EXCL, typename F>
-static hipError_t device_scan(hipStream_t s, int64_t n, F f, int32_t* out, DBuf<int32_t>& spine, int32_t* grand) {
-    if (n <= 0) { if (grand) return hipMemsetAsync(grand, 0, 4, s); return hipSuccess; }
+static hipError_t device_scan(hipStream_t s, int64_t n, F f, typename Op::T* out, DBuf<typename Op::T>& spine, typename Op::T* grand) {
+    if (n <= 0) { if (grand) return hipMemsetAsync(grand, 0, sizeof(typename Op::T), s); return hipSuccess; }
     int ntiles = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
     hipError_t e = spine.reserve((size_t)ntiles);
     if (e != hipSuccess) return e;
@@ -378,6 +390,88 @@ __global__ void k_summarise(RecView R, const uint8_t* cls, const uint8_t* keep, 
     out[rank1[r]] = s;
 }
 
+// ------------------------------------------------------------------------------------------------ K2 support
+// The discordant-cluster list is static (it depends only on the sorted chimeric blocks), so everything the
+// segmentation automaton needs from the N_c-sized stream can be computed by scans over the kept records:
+//   * trigger(k): first kept record that has passed cluster k (SegmentGraph.cpp:353),
+//   * the "zero coverage" records (:616-620) -- the only places where a pending node end is flushed and where the
+//     sliding windows are emptied (:621-636); between two of them nothing but window pushes happens unless a cluster
+//     trigger falls there, so the host only replays the stretches that contain triggers,
+//   * the running (otherChr, otherrightmost) pair before each such record (:655-667): with a coordinate-sorted
+//     stream it is a plain 64-bit max-scan of (refid << 32 | first-block end) over concordant records,
+//   * per cluster, the non-first blocks of concordant records that can span one of its break candidates
+//     (the live content of the ConcordRest heap, :387-389,471-473,690-699).
+struct ClusterView { int32_t n; const int32_t *chr, *start, *right; };
+__device__ __forceinline__ int clusters_passed(const ClusterView& C, int refid, int pos) {  // #k with (chr_k,right_k) < (refid,pos)
+    int lo = 0, hi = C.n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (C.chr[mid] < refid || (C.chr[mid] == refid && C.right[mid] < pos)) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+struct FOtherKey {
+    const StreamRec* sr;
+    __device__ long long operator()(int64_t i) const {
+        const StreamRec& r = sr[i];
+        if ((r.flags & (SR_CONC | SR_MATE)) != (SR_CONC | SR_MATE)) return LLONG_MIN;
+        return ((long long)r.refid << 32) | (unsigned int)(r.fb_refpos + r.fb_matchref);
+    }
+};
+__global__ void k_zerocov(const StreamRec* sr, int64_t k, ClusterView C, const long long* other_before, int RL, uint8_t* zflag, int32_t* flags) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    const StreamRec r = sr[i];
+    if (i > 0) {  // the kept stream must be coordinate sorted (README.md:23); everything here relies on it
+        const StreamRec q = sr[i - 1];
+        if (q.refid > r.refid || (q.refid == r.refid && q.pos > r.pos)) atomicOr(&flags[0], 1);
+    }
+    const int K = clusters_passed(C, r.refid, r.pos);
+    const int disChr = K > 0 ? C.chr[K - 1] : 0, disRight = K > 0 ? C.right[K - 1] : 0;
+    const int dnChr = K < C.n ? C.chr[K] : 0, dnPos = K < C.n ? C.start[K] : 0;  // zero sentinel after the last cluster (ledger B21)
+    long long ob = other_before[i];
+    if (ob < 0) ob = 0;  // initial otherChr = 0, otherrightmost = 0
+    const int oChr = (int)(ob >> 32), oRight = (int)(ob & 0xffffffffll);
+    const bool disLead = disChr > oChr || (disChr == oChr && disRight > oRight);
+    const int curRight = disLead ? disRight : oRight, curChr = disChr > oChr ? disChr : oChr;
+    const bool z = (r.refid != curChr || r.pos > curRight + RL) && (curChr < dnChr || (curChr == dnChr && curRight + RL < dnPos));
+    zflag[i] = z ? 1 : 0;
+}
+struct FByte { const uint8_t* a; __device__ int operator()(int64_t i) const { return a[i]; } };
+__global__ void k_zgather(int64_t k, const uint8_t* zflag, const int32_t* zrank, const long long* other_before, int32_t* zidx, int32_t* zchr, int32_t* zright) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k || !zflag[i]) return;
+    long long ob = other_before[i];
+    if (ob < 0) ob = 0;
+    int s = zrank[i];
+    zidx[s] = (int32_t)i; zchr[s] = (int)(ob >> 32); zright[s] = (int)(ob & 0xffffffffll);
+}
+__global__ void k_triggers(const StreamRec* sr, int64_t k, ClusterView C, int32_t* trigger) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C.n) return;
+    int64_t lo = 0, hi = k;  // first record with (refid,pos) > (chr_c, right_c)
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        const int rid = sr[mid].refid, rp = sr[mid].pos;
+        if (rid < C.chr[c] || (rid == C.chr[c] && rp <= C.right[c])) lo = mid + 1; else hi = mid;
+    }
+    trigger[c] = (int32_t)lo;
+}
+__global__ void k_rest_candidates(const StreamRec* sr, int64_t k, ClusterView C, int RL, const int32_t* rest_refpos, const int32_t* rest_matchref, int32_t* counter, int32_t* o_cluster,
+                                  int32_t* o_pos, int32_t* o_len) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    const StreamRec r = sr[i];
+    if ((r.flags & (SR_CONC | SR_MATE)) != (SR_CONC | SR_MATE) || r.nrest == 0) return;
+    for (int b = 0; b < r.nrest; ++b) {
+        const int p = rest_refpos[r.rest_off + b];
+        // first cluster on this chromosome whose right end lies beyond p
+        int lo = 0, hi = C.n;
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (C.chr[mid] < r.refid || (C.chr[mid] == r.refid && C.right[mid] <= p)) lo = mid + 1; else hi = mid; }
+        if (lo < C.n && C.chr[lo] == r.refid && p >= C.start[lo] - RL) {
+            int s = atomicAdd(counter, 1);
+            o_cluster[s] = lo; o_pos[s] = p; o_len[s] = rest_matchref[r.rest_off + b];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ K3: node depth
 // Node at which the reference's monotone cursor (SegmentGraph.cpp:787-799 / :809-821) would first accept a
 // block starting at p: normally the node containing p; a block of <= 3 bases that starts right behind a node
@@ -469,8 +563,9 @@ struct FOtherCount {
         return nb > 1 ? nb - 1 : 0;
     }
 };
-__global__ void k_gather_other(RecView R, const uint8_t* keep, const int32_t* rank1, int32_t n_break, const int32_t* off, int32_t* o_chr, int32_t* o_pos, int32_t* o_len) {
-    // slow exact path only: materialise ReadsOther in stream order (offsets from an exclusive scan)
+__global__ void k_gather_other(RecView R, const uint8_t* keep, const int32_t* rank1, int32_t n_break, const int32_t* off, int32_t* o_chr, int32_t* o_pos, int32_t* o_len, int32_t* flags) {
+    // materialise ReadsOther in stream order (offsets from an exclusive scan); flag blocks of <= 3 bases, the only
+    // ones whose node attribution can depend on the tie order of the reference's unstable sort
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R.n || !(keep[r] & K_1) || rank1[r] >= n_break) return;
     uint32_t b0 = R.blk_off[r];
@@ -478,6 +573,7 @@ __global__ void k_gather_other(RecView R, const uint8_t* keep, const int32_t* ra
     for (int k = 1; k < nblk; ++k) {
         int slot = off[r] + k - 1;
         o_chr[slot] = R.refid[r]; o_pos[slot] = R.b_refpos[b0 + k]; o_len[slot] = R.b_matchref[b0 + k];
+        if (R.b_matchref[b0 + k] <= 3) atomicOr(&flags[0], 64);
     }
 }
 
@@ -953,7 +1049,8 @@ void dev_destroy(sq_ctx* c) {
     D.srec.release(); D.rest_refpos.release(); D.rest_matchref.release();
     D.n_chr.release(); D.n_pos.release(); D.n_len.release(); D.n_chr_start.release();
     D.acc_a.release(); D.acc_b.release(); D.acc_c.release(); D.acc_d.release();
-    D.h_key.release(); D.h_val.release(); D.flags.release(); D.okey.release(); D.oval.release();
+    D.h_key.release(); D.h_val.release(); D.flags.release(); D.okey.release(); D.oval.release(); D.other64.release(); D.spine64.release(); D.zflag.release();
+    D.cl_chr.release(); D.cl_start.release(); D.cl_right.release(); D.trig.release();
     D.ord_p.release(); D.ord_e.release(); D.ord_m.release(); D.ord_o.release(); D.ord_v.release();
     if (D.ev0) (void)hipEventDestroy(D.ev0);
     if (D.ev1) (void)hipEventDestroy(D.ev1);
@@ -1036,18 +1133,118 @@ int dev_classify_and_summarise(sq_ctx* c, std::vector<StreamRec>& recs, std::vec
     const int64_t k1 = h_tot[0], nrest = h_tot[1];
     D.k1 = k1;
     HIPCHK(D.srec.reserve((size_t)std::max<int64_t>(k1, 1))); HIPCHK(D.rest_refpos.reserve((size_t)std::max<int64_t>(nrest, 1))); HIPCHK(D.rest_matchref.reserve((size_t)std::max<int64_t>(nrest, 1)));
-    recs.resize((size_t)k1); rest_refpos.resize((size_t)nrest); rest_matchref.resize((size_t)nrest);
+    (void)recs; (void)rest_refpos; (void)rest_matchref;  // the host fetches only the stretches it replays (dev_fetch_stream)
     if (n > 0) {
-        { EvTimer t(c, "k_summarise", 28.0 * n + 12.0 * D.nb + 20.0 * k1);
-          hipLaunchKernelGGL(k_summarise, grid_for(n, 256), dim3(256), 0, s, R, D.cls.p, D.keep.p, D.rank1.p, D.restoff.p, D.srec.p, D.rest_refpos.p, D.rest_matchref.p); }
-        auto t0 = std::chrono::steady_clock::now();
-        if (k1) HIPCHK(hipMemcpyAsync(recs.data(), D.srec.p, (size_t)k1 * sizeof(StreamRec), hipMemcpyDeviceToHost, s));
-        if (nrest) { HIPCHK(hipMemcpyAsync(rest_refpos.data(), D.rest_refpos.p, (size_t)nrest * 4, hipMemcpyDeviceToHost, s));
-                     HIPCHK(hipMemcpyAsync(rest_matchref.data(), D.rest_matchref.p, (size_t)nrest * 4, hipMemcpyDeviceToHost, s)); }
-        HIPCHK(hipStreamSynchronize(s));
-        c->timer.add("d2h_stream_summary", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), 0);
+        EvTimer t(c, "k_summarise", 28.0 * n + 12.0 * D.nb + 20.0 * k1);
+        hipLaunchKernelGGL(k_summarise, grid_for(n, 256), dim3(256), 0, s, R, D.cls.p, D.keep.p, D.rank1.p, D.restoff.p, D.srec.p, D.rest_refpos.p, D.rest_matchref.p);
     }
+    c->counts.n_kept_p2 = nrest;  // (re-used slot: number of ConcordRest source blocks)
     c->counts.n_kept_p1 = k1;
+    return SQ_OK;
+}
+
+// K2 support: cluster triggers, zero-coverage records (+ running other-state), ConcordRest candidates
+int dev_segment_support(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<int32_t>& cl_start, const std::vector<int32_t>& cl_right, int64_t n_rest, SegSupport& out) {
+    DeviceRecords& D = *c->dev;
+    hipStream_t s = c->stream;
+    const int64_t k = D.k1;
+    const int ncl = (int)cl_chr.size();
+    out.trigger.assign(ncl, (int32_t)k);
+    out.zidx.clear(); out.z_ochr.clear(); out.z_oright.clear(); out.rest_cluster.clear(); out.rest_pos.clear(); out.rest_len.clear();
+    if (k == 0) return SQ_OK;
+    HIPCHK(D.cl_chr.reserve(std::max(ncl, 1))); HIPCHK(D.cl_start.reserve(std::max(ncl, 1))); HIPCHK(D.cl_right.reserve(std::max(ncl, 1))); HIPCHK(D.trig.reserve(std::max(ncl, 1)));
+    if (ncl) {
+        HIPCHK(hipMemcpyAsync(D.cl_chr.p, cl_chr.data(), ncl * 4, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(D.cl_start.p, cl_start.data(), ncl * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(D.cl_right.p, cl_right.data(), ncl * 4, hipMemcpyHostToDevice, s));
+    }
+    ClusterView C{ncl, D.cl_chr.p, D.cl_start.p, D.cl_right.p};
+    HIPCHK(D.other64.reserve(k)); HIPCHK(D.zflag.reserve(k)); HIPCHK(D.scratch_a.reserve(k));
+    HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
+    int32_t* tot = D.flags.p + 8;
+    { EvTimer t(c, "k_segment_support", 3.0 * 20.0 * k);
+      HIPCHK((device_scan<OpMax64, true>(s, k, FOtherKey{D.srec.p}, D.other64.p, D.spine64, nullptr)));
+      hipLaunchKernelGGL(k_zerocov, grid_for(k, 256), dim3(256), 0, s, D.srec.p, k, C, D.other64.p, c->read_len, D.zflag.p, D.flags.p);
+      HIPCHK((device_scan<OpSum, true>(s, k, FByte{D.zflag.p}, D.scratch_a.p, D.spine, tot)));
+      if (ncl) hipLaunchKernelGGL(k_triggers, grid_for(ncl, 64), dim3(64), 0, s, D.srec.p, k, C, D.trig.p); }
+    int32_t hz[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(&hz[0], tot, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&hz[1], D.flags.p, 4, hipMemcpyDeviceToHost, s));
+    if (ncl) HIPCHK(hipMemcpyAsync(out.trigger.data(), D.trig.p, ncl * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (hz[1] & 1) return fail(c, SQ_E_UNSORTED, "concordant BAM is not coordinate sorted (README.md:23 requires it)");
+    const int nz = hz[0];
+    out.zidx.resize(nz); out.z_ochr.resize(nz); out.z_oright.resize(nz);
+    HIPCHK(D.scratch_b.reserve(std::max(nz, 1))); HIPCHK(D.scratch_c.reserve(std::max(nz, 1))); HIPCHK(D.b0_a.reserve(std::max<int64_t>(std::max<int64_t>(nz, n_rest), 1)));
+    HIPCHK(D.b0_b.reserve(std::max<int64_t>(n_rest, 1))); HIPCHK(D.b0_home.reserve(std::max<int64_t>(n_rest, 1))); HIPCHK(D.part_prev.reserve(std::max<int64_t>(n_rest, 1)));
+    if (nz) {
+        EvTimer t(c, "k_zgather", 13.0 * k);
+        hipLaunchKernelGGL(k_zgather, grid_for(k, 256), dim3(256), 0, s, k, D.zflag.p, D.scratch_a.p, D.other64.p, D.scratch_b.p, D.scratch_c.p, D.b0_a.p);
+        HIPCHK(hipMemcpyAsync(out.zidx.data(), D.scratch_b.p, nz * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(out.z_ochr.data(), D.scratch_c.p, nz * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(out.z_oright.data(), D.b0_a.p, nz * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    if (ncl && n_rest) {
+        HIPCHK(hipMemsetAsync(D.flags.p + 4, 0, 4, s));
+        { EvTimer t(c, "k_rest_candidates", 20.0 * k + 8.0 * n_rest);
+          hipLaunchKernelGGL(k_rest_candidates, grid_for(k, 256), dim3(256), 0, s, D.srec.p, k, C, c->read_len, D.rest_refpos.p, D.rest_matchref.p, D.flags.p + 4, D.b0_b.p, D.b0_home.p, D.part_prev.p); }
+        int32_t cnt = 0;
+        HIPCHK(hipMemcpyAsync(&cnt, D.flags.p + 4, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        out.rest_cluster.resize(cnt); out.rest_pos.resize(cnt); out.rest_len.resize(cnt);
+        if (cnt) {
+            HIPCHK(hipMemcpyAsync(out.rest_cluster.data(), D.b0_b.p, cnt * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(out.rest_pos.data(), D.b0_home.p, cnt * 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(out.rest_len.data(), D.part_prev.p, cnt * 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+        }
+    }
+    return SQ_OK;
+}
+
+// copy the stream summaries of the given kept-index ranges [lo,hi) into dst[lo..hi)
+int dev_fetch_stream(sq_ctx* c, const std::vector<std::pair<int64_t, int64_t>>& ranges, StreamRec* dst) {
+    DeviceRecords& D = *c->dev;
+    auto t0 = std::chrono::steady_clock::now();
+    for (auto& r : ranges)
+        if (r.second > r.first) HIPCHK(hipMemcpyAsync(dst + r.first, D.srec.p + r.first, (size_t)(r.second - r.first) * sizeof(StreamRec), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->timer.add("d2h_stream_summary", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), 0);
+    return SQ_OK;
+}
+
+// ReadsOther (non-first blocks of the consumed kept records) in stream order, pulled to the host only when it
+// contains a block of <= 3 bases (see k_gather_other); runs before the nodes exist so that the host can repeat the
+// reference's std::sort in the background
+int dev_gather_other(sq_ctx* c, int64_t n_break, bool& has_tiny, std::vector<int32_t>& other_chr, std::vector<int32_t>& other_pos, std::vector<int32_t>& other_len) {
+    DeviceRecords& D = *c->dev;
+    hipStream_t s = c->stream;
+    const int64_t n = D.n;
+    has_tiny = false;
+    other_chr.clear(); other_pos.clear(); other_len.clear();
+    if (n == 0) return SQ_OK;
+    RecView R = D.view();
+    const int32_t nbk = (int32_t)std::min<int64_t>(n_break, INT32_MAX);
+    int32_t* tot = D.flags.p + 8;
+    HIPCHK(D.b0_b.reserve(n));
+    HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
+    { EvTimer t(c, "scan_other_offsets", 9.0 * n); HIPCHK((device_scan<OpSum, true>(s, n, FOtherCount{R, D.keep.p, D.rank1.p, nbk}, D.b0_b.p, D.spine, tot))); }
+    int32_t cnt = 0;
+    HIPCHK(hipMemcpyAsync(&cnt, tot, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (cnt == 0) return SQ_OK;
+    HIPCHK(D.scratch_b.reserve(cnt)); HIPCHK(D.scratch_c.reserve(cnt)); HIPCHK(D.b0_a.reserve(cnt));
+    { EvTimer t(c, "k_gather_other", 13.0 * n + 8.0 * D.nb + 12.0 * cnt);
+      hipLaunchKernelGGL(k_gather_other, grid_for(n, 256), dim3(256), 0, s, R, D.keep.p, D.rank1.p, nbk, D.b0_b.p, D.scratch_b.p, D.scratch_c.p, D.b0_a.p, D.flags.p); }
+    int32_t hf = 0;
+    HIPCHK(hipMemcpyAsync(&hf, D.flags.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    has_tiny = hf & 64;
+    if (!has_tiny) return SQ_OK;
+    auto t0 = std::chrono::steady_clock::now();
+    other_chr.resize(cnt); other_pos.resize(cnt); other_len.resize(cnt);
+    HIPCHK(hipMemcpyAsync(other_chr.data(), D.scratch_b.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(other_pos.data(), D.scratch_c.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(other_len.data(), D.b0_a.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    c->timer.add("d2h_reads_other", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), 0);
     return SQ_OK;
 }
 
@@ -1085,19 +1282,7 @@ int dev_node_depth(sq_ctx* c, const std::vector<Node>& nodes, int64_t n_break, s
     for (int i = 0; i < nn; ++i) { support[i] = mc[i]; sumlen[i] = ms[i]; support[nn + i] = oc[i]; sumlen[nn + i] = os[i]; }
     // sumlen layout: [0,nn) main, [nn,2nn) other; element 2nn = |ReadsOther|
     support.push_back(hf[1]);
-    if (need_exact_other) {
-        // a <=3-base block starts right behind a node boundary: which node counts it depends on the tie order that
-        // std::sort gives ReadsOther (SegmentGraph.cpp:781).  Hand the host the exact sequence in stream order.
-        const int cnt = hf[1];
-        HIPCHK(D.scratch_b.reserve(cnt)); HIPCHK(D.scratch_c.reserve(cnt)); HIPCHK(D.b0_a.reserve(cnt)); HIPCHK(D.b0_b.reserve(std::max<int64_t>(n, 1)));
-        { EvTimer t(c, "k_gather_other", 13.0 * n + 8.0 * D.nb);
-          HIPCHK((device_scan<OpSum, true>(s, n, FOtherCount{R, D.keep.p, D.rank1.p, nbk}, D.b0_b.p, D.spine, nullptr)));
-          hipLaunchKernelGGL(k_gather_other, grid_for(n, 256), dim3(256), 0, s, R, D.keep.p, D.rank1.p, nbk, D.b0_b.p, D.scratch_b.p, D.scratch_c.p, D.b0_a.p); }
-        other_chr.resize(cnt); other_pos.resize(cnt); other_len.resize(cnt);
-        HIPCHK(hipMemcpyAsync(other_chr.data(), D.scratch_b.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(other_pos.data(), D.scratch_c.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(other_len.data(), D.b0_a.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-    }
+    (void)other_chr; (void)other_pos; (void)other_len;  // gathered ahead of time by dev_gather_other
     return SQ_OK;
 }
 

@@ -1,11 +1,14 @@
 // Genome segmentation (BuildNode_STAR of src/SegmentGraph.cpp:192-761).
 //
-// Split of work: the GPU (k_classify/k_dedup/k_summarise) has already reduced the concordant stream to one
-// 20-byte summary per kept record -- the record key, its first aligned block and its classification -- plus the
-// further blocks of concordant records.  What remains here is the order-dependent control automaton: it walks
-// the kept stream once, keeps two sliding windows (fully aligned / partially aligned concordant first blocks) as
-// index ranges into the summary array, and at every discordant cluster decides the segment boundaries.
-// The reference's automaton carries ~15 variables; the same state lives in `Seg` below.
+// Split of work: the GPU (k_classify/k_dedup/k_summarise) reduces the concordant stream to one 20-byte summary per
+// kept record (record key, first aligned block, classification) and -- because the discordant-cluster list is static
+// -- also finds, with scans over those summaries (dev_segment_support): the trigger record of every cluster, every
+// "zero coverage" record together with the running (otherChr, otherrightmost) pair in front of it, and per cluster
+// the non-first blocks that can span one of its break candidates.  At a zero-coverage record the reference flushes
+// a pending node end and empties both sliding windows (SegmentGraph.cpp:616-636), so the stream falls into
+// stretches that are independent except for the list of nodes emitted so far; only stretches that contain a cluster
+// trigger can emit anything.  The host replays just those stretches with the reference's control automaton (its
+// ~15 carried variables, SURVEY.md A.2b, live in `Seg`) and never touches the rest of the stream.
 #include <algorithm>
 #include <cmath>
 
@@ -22,7 +25,7 @@ struct El {  // a window element = first block of a concordant record
 
 struct Seg {
     const sq_ctx* c;
-    const SegmentInput& in;
+    const StreamRec* recs;  // host copy of the stream summaries, valid only inside the replayed stretches
     const int RL;
     static constexpr int T = 3;     // thresh (SegmentGraph.cpp:286)
     static constexpr int NEAR = 60;  // thresh*20
@@ -31,17 +34,21 @@ struct Seg {
     std::vector<std::pair<int, int>> part;  // PartAlignPos
     std::vector<int32_t> cw, pw;     // windows: indices into in.recs (ConcordantCluster / PartialAlignCluster)
     int co = 0, po = 0;              // window offsets
-    std::vector<std::pair<std::pair<int, int>, int>> rest;  // ConcordRest as a min-heap on (refid,refpos); value = matchref
+    const std::vector<std::pair<int, int>>* rest = nullptr;  // live ConcordRest content of the current cluster: (refpos, matchref) on its chromosome
+    struct Cluster { int ds, de, chr, start, right; };
+    std::vector<Cluster> clusters;
+    std::vector<std::vector<std::pair<int, int>>> rest_by_cluster;
+    int kc = -1;                     // index of the current cluster (ds == clusters[kc].ds)
     std::vector<Node>& out;
     int ds = 0, de = 0, dcur = 0;    // itdisstart / itdisend / itdiscurrent
     size_t ps = 0, pe = 0;
     int disChr = 0, otherChr = 0, nextdisChr = 0, disright = 0, otherright = 0, nextdisright = 0;
     int markStart = -1, markChr = -1;
 
-    Seg(const sq_ctx* c, const SegmentInput& in, std::vector<Node>& out) : c(c), in(in), RL(c->read_len), out(out) {}
+    Seg(const sq_ctx* c, const StreamRec* recs, std::vector<Node>& out) : c(c), recs(recs), RL(c->read_len), out(out) {}
 
     El el(int32_t idx) const {
-        const StreamRec& r = in.recs[idx];
+        const StreamRec& r = recs[idx];
         return El{r.refid, r.fb_refpos, r.fb_matchref, (int32_t)r.fb_readpos, (bool)(r.flags & SR_REV)};
     }
     static bool el_less(const El& a, const El& b) { return a.refid != b.refid ? a.refid < b.refid : a.refpos < b.refpos; }
@@ -49,18 +56,29 @@ struct Seg {
     bool have_back() const { return !out.empty(); }
     int back_end() const { return out.back().pos + out.back().len; }
 
-    void new_cluster() {  // SegmentGraph.cpp:341-348 / 604-611
+    // the clusters are fixed by the sorted discordant blocks alone (SegmentGraph.cpp:341-348 / 604-611)
+    void build_clusters() {
+        int s0 = 0, nr = 0, nc = 0;
+        while (s0 != nd) {
+            int right = D[s0].refpos + D[s0].matchref, e = s0;
+            for (; e != nd && D[e].refid == D[s0].refid && D[e].refpos < right + RL; ++e) right = std::max(right, D[e].refpos + D[e].matchref);
+            clusters.push_back(Cluster{s0, e, D[s0].refid, D[s0].refpos, right});
+            s0 = e;
+        }
+        (void)nr; (void)nc;
+    }
+    void new_cluster() {
+        ++kc;
         disright = nextdisright; disChr = nextdisChr;
-        nextdisright = D[ds].refpos + D[ds].matchref;
-        for (de = ds; de != nd && D[de].refid == D[ds].refid && D[de].refpos < nextdisright + RL; ++de) {
-            nextdisright = std::max(nextdisright, D[de].refpos + D[de].matchref);
-            nextdisChr = D[de].refid;
+        if (kc < (int)clusters.size()) {
+            const Cluster& k = clusters[kc];
+            ds = k.ds; de = k.de; nextdisright = k.right; nextdisChr = k.chr;
+            rest = &rest_by_cluster[kc];
+        } else {  // past the last cluster: the reference reads the zero sentinel (ledger B21); nextdisChr keeps its value
+            ds = de = nd; nextdisright = 0;
+            rest = nullptr;
         }
     }
-
-    // heap helpers (MinHeapComp, SegmentGraph.cpp:15-17): std heap algorithms with the same comparator keep the
-    // same array layout as the reference's heap; only membership matters for the coverage count
-    static bool heap_cmp(const std::pair<std::pair<int, int>, int>& l, const std::pair<std::pair<int, int>, int>& r) { return !(l.first < r.first); }
 
     void close_node(int chr, int& curStart, int& curEnd, int lastC, bool& split) {  // :483-493 / :506-515
         split = true;
@@ -92,10 +110,8 @@ struct Seg {
             if ((hc || hp) && (t.refid < D[ds].refid || (t.refid == D[ds].refid && t.refpos < D[ds].refpos))) curStart = t.refpos;
         }
         curStart = std::max(curStart, markStart);
-        while (!rest.empty() && (rest.front().first.first < D[ds].refid || (rest.front().first.first == D[ds].refid && rest.front().first.second < D[ds].refpos - RL))) {
-            std::pop_heap(rest.begin(), rest.end(), heap_cmp);
-            rest.pop_back();
-        }
+        // ConcordRest: `rest` already holds exactly the heap elements that survive the pops of :387-389 and can span a
+        // break of this cluster (same chromosome, refpos >= start - ReadLen), see k_rest_candidates
         for (; ps != part.size() && (part[ps].first < D[ds].refid || (part[ps].first == D[ds].refid && part[ps].second + RL < D[ds].refpos)); ++ps) {}
         for (pe = ps; pe != part.size() && part[pe].first == D[ds].refid && part[pe].second < nextdisright + RL; ++pe) {}
 
@@ -153,7 +169,7 @@ struct Seg {
                         for (int d = ds; d != de; ++d) if (spans(D[d].refid, D[d].refpos, D[d].matchref)) ++cov;
                         for (int i = po; i != (int)pw.size(); ++i) { El b = el(pw[i]); if (spans(b.refid, b.refpos, b.matchref)) ++cov; }
                         if (sr > std::max(cov - sr, 0) + 2)
-                            for (const auto& h : rest) if (spans(h.first.first, h.first.second, h.second)) ++cov;
+                            if (rest) for (const auto& h : *rest) if (spans(chr, h.first, h.second)) ++cov;
                         if (sr > std::max(cov - sr, 0) + 2) {
                             int sup = std::max(sr + pl, sr + pr);
                             if (lastC == -1 && brk - curStart < NEAR) { markStart = curStart; markChr = chr; }
@@ -218,9 +234,24 @@ struct Seg {
 
 }  // namespace
 
-int segment_genome(sq_ctx* c, const SegmentInput& in, std::vector<Node>& seeds, int64_t& n_break, std::vector<Blk>& disc_sorted) {
-    seeds.clear();
-    Seg S(c, in, seeds);
+struct SegPlan {
+    std::vector<Node> sink;
+    Seg S;
+    SegSupport sup;
+    std::vector<int> active;
+    int64_t K = 0;
+    SegPlan(sq_ctx* c) : S(c, nullptr, sink) {}
+};
+
+// static part: discordant blocks, clip positions, cluster table, GPU scans (triggers, zero-coverage records,
+// ConcordRest candidates), host copies of the stretches that will be replayed
+int segment_prepare(sq_ctx* c, std::shared_ptr<SegPlan>& plan, int64_t& n_break, std::vector<Blk>& disc_sorted) {
+    plan = std::make_shared<SegPlan>(c);
+    const int64_t K = c->counts.n_kept_p1;
+    plan->K = K;
+    if ((int64_t)c->stream_host.size() < K) c->stream_host.resize((size_t)K);  // only the replayed stretches are ever filled in
+    Seg& S = plan->S;
+    S.recs = c->stream_host.data();
     const int RL = c->read_len;
     // ---- discordant blocks and clip positions of the chimeric fragments (SegmentGraph.cpp:203-264)
     S.part.assign(c->ref_len.size(), std::make_pair(0, 0));  // ledger B10
@@ -270,52 +301,120 @@ int segment_genome(sq_ctx* c, const SegmentInput& in, std::vector<Node>& seeds, 
     D.push_back(Blk{0, 0, 0, 0, 0, false, false});  // ledger B21 sentinel
     const int nd = S.nd;
 
-    // ---- the kept stream
-    n_break = in.n;  // all kept records feed the depth pass unless the loop leaves early
-    for (int64_t i = 0; i < in.n; ++i) {
-        const StreamRec& r = in.recs[i];
-        if (S.ds == nd) { n_break = i + 1; break; }  // SegmentGraph.cpp:338-339, ledger B12 (this record is already in ReadsMain)
-        if (S.de - S.ds <= 0) S.new_cluster();
+    // ---- static cluster table; everything stream-sized comes from the GPU
+    S.build_clusters();
+    const int ncl = (int)S.clusters.size();
+    std::vector<int32_t> cl_chr(ncl), cl_start(ncl), cl_right(ncl);
+    for (int k = 0; k < ncl; ++k) { cl_chr[k] = S.clusters[k].chr; cl_start[k] = S.clusters[k].start; cl_right[k] = S.clusters[k].right; }
+    SegSupport& sup = plan->sup;
+    int rc = dev_segment_support(c, cl_chr, cl_start, cl_right, c->counts.n_kept_p2, sup);
+    if (rc) return rc;
+    S.rest_by_cluster.assign(ncl, {});
+    for (size_t i = 0; i < sup.rest_cluster.size(); ++i) S.rest_by_cluster[sup.rest_cluster[i]].push_back(std::make_pair(sup.rest_pos[i], sup.rest_len[i]));
+    // ReadsMain/ReadsOther stop growing at the first record after the last cluster's trigger (SegmentGraph.cpp:338-339, B12)
+    if (ncl == 0) n_break = std::min<int64_t>(K, 1);
+    else n_break = std::min<int64_t>(K, (int64_t)sup.trigger[ncl - 1] + 2);
+    if (nd == 0 || K == 0) return SQ_OK;
+
+    // ---- stretches between zero-coverage records; a stretch j covers: the push step of its first record lo (a
+    // zero-coverage record, or -1 for the head of the stream), full steps of lo+1 .. hi-1, and the cluster events
+    // plus the zero-coverage step of its last record hi (hi == K: the stream ends inside the stretch)
+    const std::vector<int32_t>& Z = sup.zidx;
+    const int nz = (int)Z.size();
+    auto stretch_of = [&](int64_t t) {  // stretch whose (lo, hi] contains t
+        return (int)(std::lower_bound(Z.begin(), Z.end(), (int32_t)t) - Z.begin());
+    };
+    std::vector<int>& active = plan->active;
+    for (int k = 0; k < ncl; ++k) {
+        if (sup.trigger[k] >= K) break;  // never passed by a record: never segmented (the reference leaves its loop first)
+        int j = stretch_of(sup.trigger[k]);
+        if (active.empty() || active.back() != j) active.push_back(j);
+    }
+    std::vector<std::pair<int64_t, int64_t>> ranges;
+    for (int j : active) {
+        int64_t lo = j == 0 ? 0 : Z[j - 1], hi = j < nz ? (int64_t)Z[j] + 1 : K;
+        if (!ranges.empty() && ranges.back().second >= lo) ranges.back().second = std::max(ranges.back().second, hi);
+        else ranges.push_back(std::make_pair(lo, hi));
+    }
+    return dev_fetch_stream(c, ranges, c->stream_host.data());
+}
+
+// order-dependent part: replay the reference's control automaton over the stretches that contain cluster triggers
+int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds) {
+    seeds.clear();
+    Seg& S = plan.S;
+    SegSupport& sup = plan.sup;
+    const std::vector<Blk>& D = S.D;
+    const int nd = S.nd, RL = c->read_len;
+    const int64_t K = plan.K;
+    const std::vector<int32_t>& Z = sup.zidx;
+    const int nz = (int)Z.size();
+    const std::vector<int>& active = plan.active;
+    if (nd == 0 || K == 0) return SQ_OK;
+    std::vector<Node>& sinkref = plan.sink;
+    (void)sinkref;
+
+    auto push_step = [&](int64_t i) {  // SegmentGraph.cpp:649-700 (ConcordRest pushes are covered by rest_by_cluster)
+        const StreamRec& r = S.recs[i];
+        if (!(r.flags & SR_CONC)) return;
+        const int e = r.fb_refpos + r.fb_matchref;
+        if (r.flags & SR_MATE) {  // the reference keys these updates on IsFirstMate()/IsSecondMate()
+            if (S.otherChr == r.refid) S.otherright = std::max(S.otherright, e);
+            else { S.otherright = e; S.otherChr = r.refid; }
+        }
+        if (r.flags & SR_PART) S.pw.push_back((int32_t)i); else S.cw.push_back((int32_t)i);
+    };
+    // events + zero-coverage test + window pruning of record i; returns false when the reference has left its loop
+    auto head_step = [&](int64_t i, bool& zerocov) -> bool {
+        const StreamRec& r = S.recs[i];
+        if (S.ds == nd) return false;  // :338-339
         while (S.ds != nd && (D[S.ds].refid < r.refid || (D[S.ds].refid == r.refid && S.nextdisright < r.pos))) S.process_cluster(r.refid, r.pos);
-        // zero-coverage test for a pending node end (:616-630)
         const bool disLead = S.disChr > S.otherChr || (S.disChr == S.otherChr && S.disright > S.otherright);
         const int curRight = disLead ? S.disright : S.otherright, curChr = std::max(S.disChr, S.otherChr);
         const Blk& dn = D[S.ds];  // the zero sentinel once every cluster is consumed
-        const bool zerocov = (r.refid != curChr || r.pos > curRight + RL) && (curChr < dn.refid || (curChr == dn.refid && curRight + RL < dn.refpos));
-        if (zerocov && S.markStart != -1) {
-            if (curChr == S.markChr && curRight > S.markStart && curRight - S.markStart < Seg::NEAR && !seeds.empty() && S.markStart == S.back_end()) seeds.back().len += curRight - S.markStart;
+        zerocov = (r.refid != curChr || r.pos > curRight + RL) && (curChr < dn.refid || (curChr == dn.refid && curRight + RL < dn.refpos));
+        if (zerocov && S.markStart != -1) {  // :621-630
+            if (curChr == S.markChr && curRight > S.markStart && curRight - S.markStart < Seg::NEAR && S.have_back() && S.markStart == S.back_end()) S.out.back().len += curRight - S.markStart;
             else if (curChr == S.markChr && curRight > S.markStart && curRight - S.markStart >= Seg::NEAR) S.push_node(S.markChr, S.markStart, curRight - S.markStart);
             S.markStart = -1; S.markChr = -1;
         }
-        // prune the windows (:633-646)
-        if (zerocov && (curChr != dn.refid || curRight + RL < dn.refpos)) { S.co = (int)S.cw.size(); S.po = (int)S.pw.size(); }
-        else {
+        if (zerocov) { S.co = (int)S.cw.size(); S.po = (int)S.pw.size(); }  // :633-636 (the extra condition there is implied by zerocov)
+        else {  // :637-646
             auto prune = [&](std::vector<int32_t>& W, int& off) {
                 while ((int)W.size() > off && S.el(W[off]).refid != r.refid) ++off;
                 while ((int)W.size() > off) {
                     El b = S.el(W[off]);
-                    if (b.refid < dn.refid || (!seeds.empty() && b.refid == seeds.back().chr && b.refpos < S.back_end())) ++off; else break;
+                    if (b.refid < dn.refid || (S.have_back() && b.refid == S.out.back().chr && b.refpos < S.back_end())) ++off; else break;
                 }
             };
             prune(S.cw, S.co);
             prune(S.pw, S.po);
         }
-        // push the record (:649-700)
-        if (r.flags & SR_CONC) {
-            const int e = r.fb_refpos + r.fb_matchref;
-            const bool mate = r.flags & SR_MATE;  // the reference keys these updates on IsFirstMate()/IsSecondMate()
-            if (mate) {
-                if (S.otherChr == r.refid) S.otherright = std::max(S.otherright, e);
-                else { S.otherright = e; S.otherChr = r.refid; }
-            }
-            if (r.flags & SR_PART) S.pw.push_back((int32_t)i); else S.cw.push_back((int32_t)i);
-            if (S.ds != nd && mate)
-                for (int k = 0; k < r.nrest; ++k) {
-                    int p = in.rest_refpos[r.rest_off + k], m = in.rest_matchref[r.rest_off + k];
-                    if (p >= D[S.ds].refpos - RL) { S.rest.push_back(std::make_pair(std::make_pair(r.refid, p), m)); std::push_heap(S.rest.begin(), S.rest.end(), Seg::heap_cmp); }
-                }
+        return true;
+    };
+    S.new_cluster();  // the reference does this at its first kept record (:341)
+    for (int j : active) {
+        const int64_t lo = j == 0 ? -1 : Z[j - 1], hi = j < nz ? Z[j] : K;
+        // a zero-coverage record empties the windows and clears the pending node end; the running
+        // (otherChr, otherrightmost) in front of it comes from the GPU scan
+        S.cw.clear(); S.pw.clear(); S.co = S.po = 0;
+        if (lo >= 0) {
+            if (S.markStart != -1) return fail(c, SQ_E_ARG, "internal: pending node end at a zero-coverage record");
+            S.otherChr = sup.z_ochr[j - 1]; S.otherright = sup.z_oright[j - 1];
+            push_step(lo);
         }
+        bool alive = true, z = false;
+        for (int64_t i = lo + 1; i < hi && alive; ++i) {
+            alive = head_step(i, z);
+            if (alive) {
+                if (z) return fail(c, SQ_E_ARG, "internal: zero-coverage record inside a replayed stretch");
+                push_step(i);
+            }
+        }
+        if (alive && hi < K) alive = head_step(hi, z);  // its push step opens the next stretch
+        if (!alive) break;
     }
+    seeds = plan.sink;
     return SQ_OK;
 }
 
