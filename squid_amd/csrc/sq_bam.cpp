@@ -20,6 +20,16 @@ void HostBatch::clear() {
     flag.clear(); totlen.clear(); b_readpos.clear(); b_matchread.clear(); mapq.clear(); aux.clear();
     blk_off.assign(1, 0); name_off.assign(1, 0); names.clear();
 }
+void HostBatch::append(const HostBatch& o) {
+    auto cat = [](auto& d, const auto& s) { d.insert(d.end(), s.begin(), s.end()); };
+    const uint32_t b0 = (uint32_t)b_refpos.size(), n0 = (uint32_t)names.size();
+    cat(refid, o.refid); cat(pos, o.pos); cat(mrefid, o.mrefid); cat(mpos, o.mpos); cat(endpos, o.endpos);
+    cat(flag, o.flag); cat(totlen, o.totlen); cat(mapq, o.mapq); cat(aux, o.aux);
+    cat(b_refpos, o.b_refpos); cat(b_matchref, o.b_matchref); cat(b_readpos, o.b_readpos); cat(b_matchread, o.b_matchread);
+    cat(names, o.names);
+    for (size_t i = 1; i < o.blk_off.size(); ++i) blk_off.push_back(o.blk_off[i] + b0);
+    for (size_t i = 1; i < o.name_off.size(); ++i) name_off.push_back(o.name_off[i] + n0);
+}
 void HostBatch::view(sq_aln_batch* b, bool with_names) const {
     std::memset(b, 0, sizeof *b);
     b->n_rec = (int64_t)refid.size();
@@ -144,6 +154,116 @@ bool scan_tags(const uint8_t* p, const uint8_t* e, bool& has_xa, int& ih) {
     return true;
 }
 
+
+// decodes one BAM record (p = first byte after block_size) into a batch; thread-safe (no shared mutable state)
+struct RecordDecoder {
+    ParseOpts o;
+    int thr;
+    explicit RecordDecoder(const ParseOpts& o) : o(o), thr((signed char)(((o.phred_type ? 33 : 64) + o.min_phred) & 0xff)) {}
+    int decode(const uint8_t* p, int32_t bs, HostBatch& hb, std::string& err) const {
+        static const char cigops[] = "MIDNSHP=X???????";
+        struct Op { char t; int len; };
+        Op cigbuf[64];
+        std::vector<Op> cigdyn;
+        std::string namebuf;
+        const uint8_t* pend = p + bs;
+        int32_t refid = rd32(p), pos = rd32(p + 4);
+        int lname = p[8];
+        int mapq = p[9];
+        int ncig = rd16(p + 12);
+        int flag = rd16(p + 14);
+        int32_t lseq = rd32(p + 16), mrefid = rd32(p + 20), mpos = rd32(p + 24);
+        const uint8_t* name = p + 32;
+        const uint8_t* cg = name + lname;
+        const uint8_t* seq = cg + 4 * (size_t)ncig;
+        const uint8_t* qual = seq + (lseq + 1) / 2;
+        const uint8_t* aux = qual + lseq;
+        if (aux > pend) { err = "corrupt record"; return SQ_E_IO; }
+        size_t nlen = lname > 0 ? (size_t)lname - 1 : 0;
+
+        Op* cig = cigbuf;
+        if (ncig > 64) { cigdyn.resize(ncig); cig = cigdyn.data(); }
+        int totlen = 0, endpos = pos;
+        for (int i = 0; i < ncig; ++i) {
+            uint32_t v = (uint32_t)rd32(cg + 4 * i);
+            cig[i].t = cigops[v & 0xf];
+            cig[i].len = (int)(v >> 4);
+            char t = cig[i].t;
+            if (t == 'M' || t == 'S' || t == 'H' || t == 'I' || t == '=' || t == 'X') totlen += cig[i].len;
+            if (t == 'M' || t == 'D' || t == 'N' || t == '=' || t == 'X') endpos += cig[i].len;  // GetEndPosition()
+        }
+        // longest run of qualities below the threshold (signed-char compare like the reference)
+        int lowrun = 0, run = 0;
+        for (int i = 0; i < lseq; ++i) {
+            int c = (signed char)((qual[i] + 33) & 0xff);
+            run = (c < thr) ? run + 1 : 0;
+            if (run > lowrun) lowrun = run;
+        }
+        bool has_xa = false;
+        int ih = 0;
+        if (!scan_tags(aux, pend, has_xa, ih)) { err = "corrupt aux data"; return SQ_E_IO; }
+        uint8_t ax = 0;
+        if (has_xa || ih > 1) ax |= SQ_AUX_MULTI;
+        if (lowrun > o.max_lowphred_len) ax |= SQ_AUX_LOWPHRED;
+        if (o.inchim) {
+            namebuf.assign((const char*)name, nlen);
+            if (o.inchim->count(namebuf)) ax |= SQ_AUX_INCHIM;
+        }
+        // CIGAR -> aligned blocks (ReadRec.cpp:45-87)
+        bool rev = flag & 0x10;
+        int readpos = 0, refpos = pos, hardclip = 0;
+        bool violated = false;
+        for (int ic = 0; ic < ncig; ++ic) {
+            char t = cig[ic].t;
+            if (t == 'S' || t == 'H') {
+                readpos += cig[ic].len;
+                if (t == 'H') hardclip += cig[ic].len;
+            } else if (t == 'M' || t == '=') {
+                int tr = 0, tf = 0, ic2;
+                for (ic2 = ic; ic2 < ncig && cig[ic2].t != 'S' && cig[ic2].t != 'H' && cig[ic2].t != 'N'; ++ic2) {
+                    if (cig[ic2].t != 'D') tr += cig[ic2].len;
+                    if (cig[ic2].t != 'I') tf += cig[ic2].len;
+                }
+                int s0 = readpos - hardclip, s1 = readpos + tr - hardclip;
+                if (!(readpos >= hardclip && s1 <= lseq)) { violated = true; break; }  // assert of ReadRec.cpp:64
+                int na = 0, nt = 0;
+                for (int i = s0; i < s1; ++i) {
+                    int code = (seq[i >> 1] >> ((~i & 1) << 2)) & 0xf;
+                    na += code == 1;
+                    nt += code == 8;
+                }
+                if (4 * na < 3 * tr && 4 * nt < 3 * tr) {  // 1.0*count/tmpRead < 0.75, exact in integers
+                    hb.b_refpos.push_back(refpos);
+                    hb.b_matchref.push_back(tf);
+                    hb.b_readpos.push_back((uint16_t)(rev ? totlen - readpos - tr : readpos));
+                    hb.b_matchread.push_back((uint16_t)tr);
+                }
+                readpos += tr;
+                refpos += tf;
+                ic = ic2 - 1;
+            } else if (t == 'N')
+                refpos += cig[ic].len;
+        }
+        if (violated) {
+            // the reference only constructs a ReadRec_t for records that survive its filters; for those the
+            // assert is live (no -DNDEBUG in the Makefile) and the run aborts
+            bool filtered = (ax & (SQ_AUX_MULTI | SQ_AUX_INCHIM)) || (flag & 0x400) || (flag & 0x4) || mapq < 0;
+            if (!filtered && !o.keep_names) { err = "record without stored bases for an aligned block (reference asserts, ReadRec.cpp:64)"; return SQ_E_ASSERT; }
+            if (o.keep_names && !(flag & 0x4) && !(flag & 0x400)) { err = "chimeric record without stored bases (reference asserts, ReadRec.cpp:64)"; return SQ_E_ASSERT; }
+            hb.b_refpos.resize(hb.blk_off.back()); hb.b_matchref.resize(hb.blk_off.back());
+            hb.b_readpos.resize(hb.blk_off.back()); hb.b_matchread.resize(hb.blk_off.back());
+        }
+        hb.refid.push_back(refid); hb.pos.push_back(pos); hb.mrefid.push_back(mrefid); hb.mpos.push_back(mpos); hb.endpos.push_back(endpos);
+        hb.flag.push_back((uint16_t)flag); hb.mapq.push_back((uint8_t)mapq); hb.aux.push_back(ax); hb.totlen.push_back((uint16_t)totlen);
+        hb.blk_off.push_back((uint32_t)hb.b_refpos.size());
+        if (o.keep_names) {
+            hb.names.insert(hb.names.end(), (const char*)name, (const char*)name + nlen);
+            hb.name_off.push_back((uint32_t)hb.names.size());
+        }
+        return SQ_OK;
+    }
+};
+
 }  // namespace
 
 int read_bam_header(const char* path, std::vector<std::string>& names, std::vector<int32_t>& lens, std::string& err) {
@@ -236,118 +356,62 @@ int parse_bam_file(const char* path, const ParseOpts& o, size_t batch_records, i
         if (!need(8 + (size_t)ln)) { err = "truncated header"; return SQ_E_IO; }
         consumed += 8 + (size_t)ln;
     }
-    // ---- records
+    // ---- records: the chain of block_size fields is walked serially (a few ns per record); the records of one
+    // inflated chunk are then decoded by the thread pool, each thread filling its own batch slice, and the slices are
+    // appended in file order
     HostBatch hb;
     hb.clear();
-    const int thr = (signed char)(((o.phred_type ? 33 : 64) + o.min_phred) & 0xff);
-    std::string namebuf;
-    static const char cigops[] = "MIDNSHP=X???????";
-    struct Op { char t; int len; };
-    std::vector<Op> cig;
-    while (need(4)) {
-        int32_t bs = rd32(&u[consumed]);
-        if (bs < 32 || !need(4 + (size_t)bs)) { err = "truncated record"; return SQ_E_IO; }
-        const uint8_t* p = &u[consumed + 4];
-        const uint8_t* pend = p + bs;
-        consumed += 4 + (size_t)bs;
-        int32_t refid = rd32(p), pos = rd32(p + 4);
-        int lname = p[8];
-        int mapq = p[9];
-        int ncig = rd16(p + 12);
-        int flag = rd16(p + 14);
-        int32_t lseq = rd32(p + 16), mrefid = rd32(p + 20), mpos = rd32(p + 24);
-        const uint8_t* name = p + 32;
-        const uint8_t* cg = name + lname;
-        const uint8_t* seq = cg + 4 * (size_t)ncig;
-        const uint8_t* qual = seq + (lseq + 1) / 2;
-        const uint8_t* aux = qual + lseq;
-        if (aux > pend) { err = "corrupt record"; return SQ_E_IO; }
-        size_t nlen = lname > 0 ? (size_t)lname - 1 : 0;
-
-        cig.resize(ncig);
-        int totlen = 0, endpos = pos;
-        for (int i = 0; i < ncig; ++i) {
-            uint32_t v = (uint32_t)rd32(cg + 4 * i);
-            cig[i].t = cigops[v & 0xf];
-            cig[i].len = (int)(v >> 4);
-            char t = cig[i].t;
-            if (t == 'M' || t == 'S' || t == 'H' || t == 'I' || t == '=' || t == 'X') totlen += cig[i].len;
-            if (t == 'M' || t == 'D' || t == 'N' || t == '=' || t == 'X') endpos += cig[i].len;  // GetEndPosition()
+    RecordDecoder dec(o);
+    std::vector<size_t> offs;
+    std::vector<HostBatch> parts((size_t)n_threads);
+    std::vector<int> prc((size_t)n_threads);
+    std::vector<std::string> perr((size_t)n_threads);
+    for (;;) {
+        // complete records currently in the buffer
+        offs.clear();
+        size_t p = consumed;
+        for (;;) {
+            if (u.size() - p < 4) break;
+            int32_t bs = rd32(&u[p]);
+            if (bs < 32) { err = "truncated record"; return SQ_E_IO; }
+            if (u.size() - p < 4 + (size_t)bs) break;
+            offs.push_back(p);
+            p += 4 + (size_t)bs;
         }
-        // longest run of qualities below the threshold (signed-char compare like the reference)
-        int lowrun = 0, run = 0;
-        for (int i = 0; i < lseq; ++i) {
-            int c = (signed char)((qual[i] + 33) & 0xff);
-            run = (c < thr) ? run + 1 : 0;
-            if (run > lowrun) lowrun = run;
-        }
-        bool has_xa = false;
-        int ih = 0;
-        if (!scan_tags(aux, pend, has_xa, ih)) { err = "corrupt aux data"; return SQ_E_IO; }
-        uint8_t ax = 0;
-        if (has_xa || ih > 1) ax |= SQ_AUX_MULTI;
-        if (lowrun > o.max_lowphred_len) ax |= SQ_AUX_LOWPHRED;
-        if (o.inchim) {
-            namebuf.assign((const char*)name, nlen);
-            if (o.inchim->count(namebuf)) ax |= SQ_AUX_INCHIM;
-        }
-        // CIGAR -> aligned blocks (ReadRec.cpp:45-87)
-        bool rev = flag & 0x10;
-        int readpos = 0, refpos = pos, hardclip = 0;
-        bool violated = false;
-        for (int ic = 0; ic < ncig; ++ic) {
-            char t = cig[ic].t;
-            if (t == 'S' || t == 'H') {
-                readpos += cig[ic].len;
-                if (t == 'H') hardclip += cig[ic].len;
-            } else if (t == 'M' || t == '=') {
-                int tr = 0, tf = 0, ic2;
-                for (ic2 = ic; ic2 < ncig && cig[ic2].t != 'S' && cig[ic2].t != 'H' && cig[ic2].t != 'N'; ++ic2) {
-                    if (cig[ic2].t != 'D') tr += cig[ic2].len;
-                    if (cig[ic2].t != 'I') tf += cig[ic2].len;
+        if (!offs.empty()) {
+            const size_t nrec = offs.size();
+            const int T = (int)std::min<size_t>((size_t)n_threads, std::max<size_t>(1, nrec / 4096));
+            auto work = [&](int t) {
+                HostBatch& part = parts[t];
+                part.clear();
+                prc[t] = SQ_OK;
+                size_t r0 = nrec * t / T, r1 = nrec * (t + 1) / T;
+                for (size_t r = r0; r < r1; ++r) {
+                    const uint8_t* q = &u[offs[r]];
+                    int rc = dec.decode(q + 4, rd32(q), part, perr[t]);
+                    if (rc) { prc[t] = rc; return; }
                 }
-                int s0 = readpos - hardclip, s1 = readpos + tr - hardclip;
-                if (!(readpos >= hardclip && s1 <= lseq)) { violated = true; break; }  // assert of ReadRec.cpp:64
-                int na = 0, nt = 0;
-                for (int i = s0; i < s1; ++i) {
-                    int code = (seq[i >> 1] >> ((~i & 1) << 2)) & 0xf;
-                    na += code == 1;
-                    nt += code == 8;
+            };
+            if (T == 1) work(0);
+            else {
+                std::vector<std::thread> th;
+                for (int t = 0; t < T; ++t) th.emplace_back(work, t);
+                for (auto& x : th) x.join();
+            }
+            for (int t = 0; t < T; ++t) if (prc[t]) { err = perr[t]; return prc[t]; }
+            for (int t = 0; t < T; ++t) {
+                hb.append(parts[t]);
+                if (hb.size() >= batch_records) {
+                    int rc = sink(hb);
+                    if (rc) return rc;
+                    hb.clear();
                 }
-                if (4 * na < 3 * tr && 4 * nt < 3 * tr) {  // 1.0*count/tmpRead < 0.75, exact in integers
-                    hb.b_refpos.push_back(refpos);
-                    hb.b_matchref.push_back(tf);
-                    hb.b_readpos.push_back((uint16_t)(rev ? totlen - readpos - tr : readpos));
-                    hb.b_matchread.push_back((uint16_t)tr);
-                }
-                readpos += tr;
-                refpos += tf;
-                ic = ic2 - 1;
-            } else if (t == 'N')
-                refpos += cig[ic].len;
+            }
+            consumed = p;
         }
-        if (violated) {
-            // the reference only constructs a ReadRec_t for records that survive its filters; for those the
-            // assert is live (no -DNDEBUG in the Makefile) and the run aborts
-            bool filtered = (ax & (SQ_AUX_MULTI | SQ_AUX_INCHIM)) || (flag & 0x400) || (flag & 0x4) || mapq < 0;
-            if (!filtered && !o.keep_names) { err = "record without stored bases for an aligned block (reference asserts, ReadRec.cpp:64)"; return SQ_E_ASSERT; }
-            if (o.keep_names && !(flag & 0x4) && !(flag & 0x400)) { err = "chimeric record without stored bases (reference asserts, ReadRec.cpp:64)"; return SQ_E_ASSERT; }
-            hb.b_refpos.resize(hb.blk_off.back()); hb.b_matchref.resize(hb.blk_off.back());
-            hb.b_readpos.resize(hb.blk_off.back()); hb.b_matchread.resize(hb.blk_off.back());
-        }
-        hb.refid.push_back(refid); hb.pos.push_back(pos); hb.mrefid.push_back(mrefid); hb.mpos.push_back(mpos); hb.endpos.push_back(endpos);
-        hb.flag.push_back((uint16_t)flag); hb.mapq.push_back((uint8_t)mapq); hb.aux.push_back(ax); hb.totlen.push_back((uint16_t)totlen);
-        hb.blk_off.push_back((uint32_t)hb.b_refpos.size());
-        if (o.keep_names) {
-            hb.names.insert(hb.names.end(), (const char*)name, (const char*)name + nlen);
-            hb.name_off.push_back((uint32_t)hb.names.size());
-        }
-        if (hb.size() >= batch_records) {
-            int rc = sink(hb);
-            if (rc) return rc;
-            hb.clear();
-        }
+        if (!refill()) break;
     }
+    if (u.size() - consumed >= 4) { err = "truncated record"; return SQ_E_IO; }
     if (hb.size()) {
         int rc = sink(hb);
         if (rc) return rc;

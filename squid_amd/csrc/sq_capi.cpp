@@ -373,7 +373,9 @@ int sq_build_graph(sq_ctx* c) {
     if (!c) return SQ_E_ARG;
     if (c->ref_len.empty()) return fail(c, SQ_E_ARG, "sq_set_references first");
     if (c->read_len <= 0) return fail(c, SQ_E_ARG, "sq_ingest_chimeric first (ReadLen comes from the chimeric BAM)");
-    return build_graph(c);
+    int rc = build_graph(c);
+    dev_flush_timers(c);
+    return rc;
 }
 int sq_graph_view(sq_ctx* c, int32_t stage, sq_graph* g) {
     if (!c || !g || stage < 0 || stage > 5 || !c->graph_built) return SQ_E_ARG;
@@ -382,13 +384,14 @@ int sq_graph_view(sq_ctx* c, int32_t stage, sq_graph* g) {
 }
 int sq_order(sq_ctx* c, sq_orders* o) {
     if (!c || !c->graph_built) return SQ_E_ARG;
-    if (!c->ordered) { int rc = order_components(c); if (rc) return rc; }
+    if (!c->ordered) { int rc = order_components(c); dev_flush_timers(c); if (rc) return rc; }
     if (o) { o->n_components = (int32_t)c->ord_off.size() - 1; o->comp_off = c->ord_off.data(); o->nodes = c->ord_nodes.data(); }
     return SQ_OK;
 }
 int sq_call_sv(sq_ctx* c, sq_sv_table* t) {
     if (!c || !c->graph_built) return SQ_E_ARG;
     int rc = call_sv(c);
+    dev_flush_timers(c);
     if (rc) return rc;
     if (t) {
         t->n_rows = (int32_t)c->sv_cols[0].size();

@@ -128,6 +128,7 @@ struct HostBatch {  // owning storage behind an sq_aln_batch
     std::vector<uint32_t> blk_off, name_off;
     std::vector<char> names;
     void clear();
+    void append(const HostBatch& o);  // concatenates (block / name offsets are rebased)
     void view(sq_aln_batch* b, bool with_names) const;
     size_t size() const { return refid.size(); }
 };
@@ -171,6 +172,7 @@ int order_components(sq_ctx* c);
 // ---- sq_kernels.hip (device side; every function enqueues on c->stream and records HIP-event timings)
 int dev_create(sq_ctx* c);
 void dev_destroy(sq_ctx* c);
+void dev_flush_timers(sq_ctx* c);
 int dev_append_records(sq_ctx* c, const sq_aln_batch* b);
 struct SegSupport {
     std::vector<int32_t> trigger, zidx, z_ochr, z_oright, rest_cluster, rest_pos, rest_len;

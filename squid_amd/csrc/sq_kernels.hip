@@ -104,7 +104,10 @@ struct DeviceRecords {
     DBuf<uint8_t> zflag;
     DBuf<int32_t> cl_chr, cl_start, cl_right, trig;
     DBuf<int32_t> flags;  // small device flag/counter block
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    struct Pending { const char* name; double bytes; int slot; };
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    std::vector<Pending> ev_pending;
+    size_t ev_used = 0;
     int64_t k1 = 0;  // kept pass-1 records
     RecView view() const {
         RecView v;
@@ -1010,20 +1013,40 @@ __global__ __launch_bounds__(256) void k_order_small(const SmallProblem* probs, 
 // ================================================================================================ host wrappers
 static inline dim3 grid_for(int64_t n, int threads) { return dim3((unsigned)((n + threads - 1) / threads)); }
 
-struct EvTimer {  // HIP-event bracket on the library stream
-    sq_ctx* c; const char* name; double bytes; bool on;
-    EvTimer(sq_ctx* c, const char* name, double bytes) : c(c), name(name), bytes(bytes), on(true) { (void)hipEventRecord(c->dev->ev0, c->stream); }
+// HIP-event bracket on the library stream.  Events come from a pool and are only read back by dev_flush_timers()
+// (called at the end of every ABI call), so timing a kernel never stalls the host.
+struct EvTimer {
+    sq_ctx* c; int slot; bool on;
+    EvTimer(sq_ctx* c, const char* name, double bytes) : c(c), on(true) {
+        DeviceRecords& D = *c->dev;
+        if (D.ev_used == D.ev_pool.size()) {
+            hipEvent_t a = nullptr, b = nullptr;
+            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+            D.ev_pool.push_back(std::make_pair(a, b));
+        }
+        slot = (int)D.ev_used++;
+        D.ev_pending.push_back(DeviceRecords::Pending{name, bytes, slot});
+        (void)hipEventRecord(D.ev_pool[slot].first, c->stream);
+    }
     void stop() {
         if (!on) return;
         on = false;
-        (void)hipEventRecord(c->dev->ev1, c->stream);
-        (void)hipEventSynchronize(c->dev->ev1);
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, c->dev->ev0, c->dev->ev1);
-        c->timer.add(name, ms, bytes);
+        (void)hipEventRecord(c->dev->ev_pool[slot].second, c->stream);
     }
     ~EvTimer() { stop(); }
 };
+void dev_flush_timers(sq_ctx* c) {
+    if (!c->dev) return;
+    DeviceRecords& D = *c->dev;
+    for (const DeviceRecords::Pending& p : D.ev_pending) {
+        float ms = 0;
+        (void)hipEventSynchronize(D.ev_pool[p.slot].second);
+        (void)hipEventElapsedTime(&ms, D.ev_pool[p.slot].first, D.ev_pool[p.slot].second);
+        c->timer.add(p.name, ms, p.bytes);
+    }
+    D.ev_pending.clear();
+    D.ev_used = 0;
+}
 
 int dev_create(sq_ctx* c) {
     int ndev = 0;
@@ -1032,8 +1055,6 @@ int dev_create(sq_ctx* c) {
     HIPCHK(hipSetDevice(c->P.device));
     HIPCHK(hipStreamCreate(&c->stream));
     c->dev = new DeviceRecords();
-    HIPCHK(hipEventCreate(&c->dev->ev0));
-    HIPCHK(hipEventCreate(&c->dev->ev1));
     HIPCHK(c->dev->flags.reserve(64));
     return SQ_OK;
 }
@@ -1052,8 +1073,7 @@ void dev_destroy(sq_ctx* c) {
     D.h_key.release(); D.h_val.release(); D.flags.release(); D.okey.release(); D.oval.release(); D.other64.release(); D.spine64.release(); D.zflag.release();
     D.cl_chr.release(); D.cl_start.release(); D.cl_right.release(); D.trig.release();
     D.ord_p.release(); D.ord_e.release(); D.ord_m.release(); D.ord_o.release(); D.ord_v.release();
-    if (D.ev0) (void)hipEventDestroy(D.ev0);
-    if (D.ev1) (void)hipEventDestroy(D.ev1);
+    for (auto& e : D.ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete c->dev;
     c->dev = nullptr;
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -100,3 +100,77 @@ def test_streaming_ingest_in_small_batches_is_equivalent(built, synth, tmp_path)
         ctx.build_graph()
         ctx.order()
         assert ctx.sv_text() == want
+
+
+# ---------------------------------------------------------------------------------------------- error paths
+def _tiny_inputs(tmp_path, conc, chim, contigs=(("chrA", 100000), ("chrB", 50000))):
+    import bamwriter as bw
+
+    pre = tmp_path / "tiny"
+    bw.write_bam(f"{pre}.bam", contigs, conc)
+    bw.write_bam(f"{pre}.chim.bam", contigs, chim, sort_order="unsorted")
+    return pre
+
+
+def _pairs(n=40, start=1000):
+    import bamwriter as bw
+
+    recs = []
+    for i in range(n):
+        p = start + 7 * i
+        recs.append((p, bw.record(f"r{i}", 0, p, 255, 0x1 | 0x2 | 0x20 | 0x40, "100M", 0, p + 200)))
+        recs.append((p + 200, bw.record(f"r{i}", 0, p + 200, 255, 0x1 | 0x2 | 0x10 | 0x80, "100M", 0, p)))
+    recs.sort(key=lambda t: t[0])  # coordinate sorted, as the reference requires (README.md:23)
+    return [r for _, r in recs]
+
+
+def test_graph_without_edges_reports_the_reference_assert(built, tmp_path):
+    """a handful of reads leaves no edge after filtering: the reference asserts (SegmentGraph.cpp:2537); the oracle
+    stops there and the library returns SQ_E_ASSERT instead of crashing"""
+    import bamwriter as bw
+
+    chim = [bw.record("q1", 0, 5000, 255, 0x1 | 0x40, "60M40S"), bw.record("q1", 1, 7000, 255, 0x1 | 0x40 | 0x100, "60H40M"),
+            bw.record("q1", 1, 7300, 255, 0x1 | 0x80 | 0x10, "100M")]
+    pre = _tiny_inputs(tmp_path, _pairs(), chim)
+    assert subprocess.call([str(built / "squid_oracle"), "-b", f"{pre}.bam", "-c", f"{pre}.chim.bam", "-o", str(tmp_path / "o")],
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) == 5
+    with squid_amd.Context() as ctx:
+        ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
+        with pytest.raises(squid_amd.SquidError, match="reference assert"):
+            ctx.build_graph()
+
+
+def test_unsorted_concordant_bam_is_rejected(built, tmp_path):
+    import bamwriter as bw
+
+    conc = _pairs(30, 20000) + _pairs(30, 1000)  # second half jumps back
+    chim = [bw.record("q1", 0, 5000, 255, 0x1 | 0x40, "60M40S"), bw.record("q1", 1, 7000, 255, 0x1 | 0x40 | 0x100, "60H40M"),
+            bw.record("q1", 1, 7300, 255, 0x1 | 0x80 | 0x10, "100M")]
+    pre = _tiny_inputs(tmp_path, conc, chim)
+    with squid_amd.Context() as ctx:
+        ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
+        with pytest.raises(squid_amd.SquidError, match="not coordinate sorted"):
+            ctx.build_graph()
+
+
+def test_empty_chimeric_bam_is_rejected(built, tmp_path):
+    """ReadRec.cpp:379 reads sample_ReadLen[0] of an empty vector; the library refuses (SQ_E_EMPTYCHIM)"""
+    import bamwriter as bw
+
+    pre = _tiny_inputs(tmp_path, _pairs(), [bw.record("u", -1, -1, 0, 0x1 | 0x4 | 0x40, "100S")])
+    with squid_amd.Context() as ctx:
+        with pytest.raises(squid_amd.SquidError, match="chimeric input has no usable record"):
+            ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
+
+
+def test_no_discordant_cluster_at_all(built, tmp_path):
+    """chimeric file with only a concordant-looking fragment: bamdiscordant is empty, every chromosome becomes one
+    node, and both implementations stop at the same reference assert (no edges)"""
+    import bamwriter as bw
+
+    chim = [bw.record("c1", 0, 40000, 255, 0x1 | 0x2 | 0x20 | 0x40, "100M"), bw.record("c1", 0, 40300, 255, 0x1 | 0x2 | 0x10 | 0x80, "100M")]
+    pre = _tiny_inputs(tmp_path, _pairs(), chim)
+    with squid_amd.Context() as ctx:
+        ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
+        with pytest.raises(squid_amd.SquidError):
+            ctx.build_graph()
