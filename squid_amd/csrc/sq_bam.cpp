@@ -6,7 +6,9 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <thread>
@@ -44,17 +46,33 @@ namespace {
 
 struct FileBytes {
     std::vector<uint8_t> data;
-    bool load(const char* path) {
+    bool load(const char* path, long limit = -1) {
         FILE* f = std::fopen(path, "rb");
         if (!f) return false;
         std::fseek(f, 0, SEEK_END);
         long n = std::ftell(f);
         std::fseek(f, 0, SEEK_SET);
+        if (limit >= 0 && n > limit) n = limit;
         data.resize((size_t)n);
         size_t got = n ? std::fread(data.data(), 1, (size_t)n, f) : 0;
         std::fclose(f);
         return got == (size_t)n;
     }
+};
+
+// growable byte buffer WITHOUT value-initialisation (std::vector::resize would zero-fill hundreds of MB per chunk)
+struct RawBuf {
+    uint8_t* p = nullptr;
+    size_t n = 0, cap = 0;
+    ~RawBuf() { std::free(p); }
+    size_t size() const { return n; }
+    uint8_t* data() { return p; }
+    uint8_t& operator[](size_t i) { return p[i]; }
+    void resize(size_t m) {
+        if (m > cap) { size_t c = std::max(m, cap + cap / 2); p = (uint8_t*)std::realloc(p, c); cap = c; }
+        n = m;
+    }
+    void drop_front(size_t k) { if (k) { std::memmove(p, p + k, n - k); n -= k; } }
 };
 
 struct BgzfBlock { size_t coff; uint32_t clen, isize; size_t uoff; };
@@ -83,6 +101,31 @@ bool index_bgzf(const std::vector<uint8_t>& d, std::vector<BgzfBlock>& blocks, s
         p += bsize;
     }
     return p == d.size();
+}
+
+// like index_bgzf, but stops quietly at the first incomplete block (for file prefixes)
+void index_bgzf_prefix(const std::vector<uint8_t>& d, std::vector<BgzfBlock>& blocks, size_t& total) {
+    size_t p = 0;
+    total = 0;
+    while (p + 18 <= d.size()) {
+        if (d[p] != 0x1f || d[p + 1] != 0x8b || !(d[p + 3] & 4)) return;
+        uint32_t xlen = d[p + 10] | (d[p + 11] << 8);
+        int bsize = -1;
+        for (size_t o = p + 12; o + 4 <= p + 12 + xlen && o + 6 <= d.size();) {
+            uint32_t slen = d[o + 2] | (d[o + 3] << 8);
+            if (d[o] == 'B' && d[o + 1] == 'C' && slen == 2) bsize = (d[o + 4] | (d[o + 5] << 8)) + 1;
+            o += 4 + slen;
+        }
+        if (bsize < 0 || p + bsize > d.size()) return;
+        BgzfBlock b;
+        b.coff = p + 12 + xlen;
+        b.clen = (uint32_t)(bsize - 12 - xlen - 8);
+        std::memcpy(&b.isize, &d[p + bsize - 4], 4);
+        b.uoff = total;
+        total += b.isize;
+        blocks.push_back(b);
+        p += bsize;
+    }
 }
 
 bool inflate_range(const std::vector<uint8_t>& d, const std::vector<BgzfBlock>& blocks, size_t b0, size_t b1, uint8_t* out, size_t out_base, int n_threads) {
@@ -266,12 +309,26 @@ struct RecordDecoder {
 
 }  // namespace
 
+static int read_bam_header_bytes(const std::vector<uint8_t>& d, bool whole_file, std::vector<std::string>& names, std::vector<int32_t>& lens, std::string& err);
+
 int read_bam_header(const char* path, std::vector<std::string>& names, std::vector<int32_t>& lens, std::string& err) {
+    // the header sits in the leading BGZF blocks: read a prefix and grow it only if the header text is longer
+    for (long limit = 1 << 20;; limit *= 8) {
+        FileBytes probe;
+        if (!probe.load(path, limit)) { err = std::string("cannot open bamfile ") + path; return SQ_E_IO; }
+        int rc = read_bam_header_bytes(probe.data, (long)probe.data.size() < limit, names, lens, err);
+        if (rc != 1) return rc;
+    }
+}
+
+// returns 1 when `d` (a prefix of the file) ends before the header does
+static int read_bam_header_bytes(const std::vector<uint8_t>& d, bool whole_file, std::vector<std::string>& names, std::vector<int32_t>& lens, std::string& err) {
     FileBytes fb;
-    if (!fb.load(path)) { err = std::string("cannot open bamfile ") + path; return SQ_E_IO; }
+    fb.data = d;
     std::vector<BgzfBlock> blocks;
     size_t total;
-    if (!index_bgzf(fb.data, blocks, total)) { err = "not a BGZF file"; return SQ_E_IO; }
+    index_bgzf_prefix(fb.data, blocks, total);
+    if (blocks.empty()) { if (whole_file) { err = "not a BGZF file"; return SQ_E_IO; } return 1; }
     // the header may span several blocks: inflate until it is complete
     std::vector<uint8_t> u;
     size_t nb = 0;
@@ -287,9 +344,10 @@ int read_bam_header(const char* path, std::vector<std::string>& names, std::vect
         }
         return u.size() >= n;
     };
-    if (!need(12) || std::memcmp(u.data(), "BAM\1", 4) != 0) { err = "not a BAM file"; return SQ_E_IO; }
+    if (!need(12)) { if (whole_file) { err = "not a BAM file"; return SQ_E_IO; } return 1; }
+    if (std::memcmp(u.data(), "BAM\1", 4) != 0) { err = "not a BAM file"; return SQ_E_IO; }
     int32_t ltext = rd32(&u[4]);
-    if (!need(12 + (size_t)ltext)) { err = "truncated header"; return SQ_E_IO; }
+    if (!need(12 + (size_t)ltext)) { if (whole_file) { err = "truncated header"; return SQ_E_IO; } return 1; }
     // names and lengths come from the header TEXT, as in ReadRec.cpp:274-279 (stoi on LN)
     std::string text((const char*)&u[8], (size_t)ltext);
     names.clear();
@@ -318,25 +376,33 @@ int read_bam_header(const char* path, std::vector<std::string>& names, std::vect
 
 int parse_bam_file(const char* path, const ParseOpts& o, size_t batch_records, int n_threads, std::string& err,
                    const std::function<int(const HostBatch&)>& sink) {
+    using clk = std::chrono::steady_clock;
+    double t_read = 0, t_inflate = 0, t_walk = 0, t_decode = 0, t_append = 0, t_sink = 0;
+    auto since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+    struct Report { double &a, &b, &c, &d, &e, &f; const char* path; ~Report() { if (std::getenv("SQUID_INGEST_TIMING")) std::fprintf(stderr, "ingest %s: read %.1f inflate %.1f walk %.1f decode %.1f append %.1f sink %.1f ms\n", path, a, b, c, d, e, f); } } report{t_read, t_inflate, t_walk, t_decode, t_append, t_sink, path};
+    auto tr0 = clk::now();
     FileBytes fb;
     if (!fb.load(path)) { err = std::string("cannot open bamfile ") + path; return SQ_E_IO; }
     std::vector<BgzfBlock> blocks;
     size_t total;
     if (!index_bgzf(fb.data, blocks, total)) { err = "not a BGZF file"; return SQ_E_IO; }
+    t_read = since(tr0);
     n_threads = std::max(1, n_threads);
 
     const size_t kChunkBlocks = 2048;  // <= 128 MiB inflated per round
-    std::vector<uint8_t> u;            // inflated bytes not yet consumed
+    RawBuf u;                          // inflated bytes not yet consumed
     size_t nb = 0;
     size_t consumed = 0;
     auto refill = [&]() -> bool {
         if (nb >= blocks.size()) return false;
-        if (consumed) { u.erase(u.begin(), u.begin() + consumed); consumed = 0; }
+        if (consumed) { u.drop_front(consumed); consumed = 0; }
         size_t b1 = std::min(blocks.size(), nb + kChunkBlocks);
         size_t base = blocks[nb].uoff, bytes = (b1 == blocks.size() ? total : blocks[b1].uoff) - base;
         size_t old = u.size();
         u.resize(old + bytes);
+        auto ti0 = clk::now();
         bool ok = inflate_range(fb.data, blocks, nb, b1, u.data() + old, base, n_threads);
+        t_inflate += since(ti0);
         nb = b1;
         return ok;
     };
@@ -356,41 +422,71 @@ int parse_bam_file(const char* path, const ParseOpts& o, size_t batch_records, i
         if (!need(8 + (size_t)ln)) { err = "truncated header"; return SQ_E_IO; }
         consumed += 8 + (size_t)ln;
     }
-    // ---- records: the chain of block_size fields is walked serially (a few ns per record); the records of one
-    // inflated chunk are then decoded by the thread pool, each thread filling its own batch slice, and the slices are
-    // appended in file order
+    // ---- records.  The chain of block_size fields is inherently serial, and walking it through memory that other
+    // cores have just written costs a cache miss per record.  Each decoder thread therefore takes a byte slice of the
+    // inflated chunk, finds the first record boundary inside it by validating a chain of plausible record headers,
+    // and walks + decodes from there; afterwards the slices are stitched: slice t must end exactly where slice t+1
+    // started, otherwise (a false synchronisation -- never seen in practice) the tail of the chunk is redone serially.
     HostBatch hb;
     hb.clear();
     RecordDecoder dec(o);
-    std::vector<size_t> offs;
     std::vector<HostBatch> parts((size_t)n_threads);
     std::vector<int> prc((size_t)n_threads);
     std::vector<std::string> perr((size_t)n_threads);
-    for (;;) {
-        // complete records currently in the buffer
-        offs.clear();
-        size_t p = consumed;
-        for (;;) {
-            if (u.size() - p < 4) break;
-            int32_t bs = rd32(&u[p]);
-            if (bs < 32) { err = "truncated record"; return SQ_E_IO; }
-            if (u.size() - p < 4 + (size_t)bs) break;
-            offs.push_back(p);
-            p += 4 + (size_t)bs;
+    std::vector<size_t> s_begin((size_t)n_threads), s_end((size_t)n_threads);
+    auto plausible = [&](size_t p, size_t limit) -> long {  // record header at p?  returns its block_size or -1
+        if (limit - p < 36) return -1;
+        const uint8_t* q = &u[p];
+        int32_t bs = rd32(q);
+        if (bs < 34 || bs > (1 << 26)) return -1;
+        int32_t refid = rd32(q + 4), pos = rd32(q + 8), mrefid = rd32(q + 24), mpos = rd32(q + 28), lseq = rd32(q + 20);
+        int lname = q[12], ncig = rd16(q + 16);
+        if (refid < -1 || refid >= nref || mrefid < -1 || mrefid >= nref || pos < -1 || mpos < -1 || lseq < 0 || lname < 1) return -1;
+        size_t need_bytes = 32 + (size_t)lname + 4 * (size_t)ncig + ((size_t)lseq + 1) / 2 + (size_t)lseq;
+        if (need_bytes > (size_t)bs) return -1;
+        if (p + 4 + 32 + (size_t)lname <= limit && q[4 + 32 + lname - 1] != 0) return -1;  // QNAME is NUL terminated
+        return bs;
+    };
+    auto sync_from = [&](size_t from, size_t upto, size_t limit) -> size_t {  // first offset in [from,upto) that starts a chain of 4 plausible records
+        for (size_t p = from; p < upto; ++p) {
+            size_t q = p;
+            int ok = 0;
+            bool accept = false;
+            for (;;) {
+                long bs = plausible(q, limit);
+                if (bs < 0) break;
+                if (q + 4 + (size_t)bs > limit) { accept = ok >= 2; break; }  // runs off the buffer: trust it only after two whole records
+                q += 4 + (size_t)bs;
+                if (++ok == 4 || q == limit) { accept = true; break; }
+            }
+            if (accept) ok = 4;
+            if (ok == 4) return p;
         }
-        if (!offs.empty()) {
-            const size_t nrec = offs.size();
-            const int T = (int)std::min<size_t>((size_t)n_threads, std::max<size_t>(1, nrec / 4096));
+        return upto;
+    };
+    for (;;) {
+        const size_t limit = u.size();
+        size_t avail = limit - consumed;
+        if (avail >= 4) {
+            auto td0 = clk::now();
+            const int T = (int)std::min<size_t>((size_t)n_threads, std::max<size_t>(1, avail / ((size_t)1 << 20)));
             auto work = [&](int t) {
                 HostBatch& part = parts[t];
                 part.clear();
                 prc[t] = SQ_OK;
-                size_t r0 = nrec * t / T, r1 = nrec * (t + 1) / T;
-                for (size_t r = r0; r < r1; ++r) {
-                    const uint8_t* q = &u[offs[r]];
-                    int rc = dec.decode(q + 4, rd32(q), part, perr[t]);
-                    if (rc) { prc[t] = rc; return; }
+                size_t lo = consumed + avail * t / T, hi = consumed + avail * (t + 1) / T;
+                size_t p = t == 0 ? consumed : sync_from(lo, hi, limit);
+                s_begin[t] = p;
+                while (p < hi) {
+                    if (limit - p < 4) break;
+                    int32_t bs = rd32(&u[p]);
+                    if (bs < 32) { prc[t] = SQ_E_IO; perr[t] = "truncated record"; break; }
+                    if (limit - p < 4 + (size_t)bs) break;  // incomplete: belongs to the next chunk
+                    int rc = dec.decode(&u[p + 4], bs, part, perr[t]);
+                    if (rc) { prc[t] = rc; break; }
+                    p += 4 + (size_t)bs;
                 }
+                s_end[t] = p;
             };
             if (T == 1) work(0);
             else {
@@ -398,22 +494,58 @@ int parse_bam_file(const char* path, const ParseOpts& o, size_t batch_records, i
                 for (int t = 0; t < T; ++t) th.emplace_back(work, t);
                 for (auto& x : th) x.join();
             }
-            for (int t = 0; t < T; ++t) if (prc[t]) { err = perr[t]; return prc[t]; }
-            for (int t = 0; t < T; ++t) {
+            t_decode += since(td0);
+            // stitch
+            size_t good_end = s_end[0];
+            int good = 1;
+            if (prc[0]) { err = perr[0]; return prc[0]; }
+            for (int t = 1; t < T; ++t) {
+                size_t hi = consumed + avail * (t + 1) / T;
+                if (s_begin[t] >= hi && parts[t].size() == 0 && good_end >= hi) { ++good; continue; }  // slice swallowed by a long record
+                if (s_begin[t] != good_end) { if (std::getenv("SQUID_INGEST_DEBUG")) std::fprintf(stderr, "stitch mismatch at slice %d/%d: begin=%zu expected=%zu lo=%zu hi=%zu\n", t, T, s_begin[t], good_end, consumed + avail * t / T, hi); break; }
+                if (prc[t]) { err = perr[t]; return prc[t]; }
+                good_end = s_end[t];
+                ++good;
+            }
+            for (int t = 0; t < good; ++t) {
+                auto ta0 = clk::now();
                 hb.append(parts[t]);
+                t_append += since(ta0);
                 if (hb.size() >= batch_records) {
+                    auto ts0 = clk::now();
                     int rc = sink(hb);
+                    t_sink += since(ts0);
                     if (rc) return rc;
                     hb.clear();
                 }
             }
-            consumed = p;
+            if (good < T) {  // false synchronisation somewhere: finish this chunk with the plain serial walk
+                auto tw0 = clk::now();
+                size_t p = good_end;
+                HostBatch& part = parts[0];
+                part.clear();
+                for (;;) {
+                    if (limit - p < 4) break;
+                    int32_t bs = rd32(&u[p]);
+                    if (bs < 32) { err = "truncated record"; return SQ_E_IO; }
+                    if (limit - p < 4 + (size_t)bs) break;
+                    int rc = dec.decode(&u[p + 4], bs, part, err);
+                    if (rc) return rc;
+                    p += 4 + (size_t)bs;
+                }
+                hb.append(part);
+                good_end = p;
+                t_walk += since(tw0);
+            }
+            consumed = good_end;
         }
         if (!refill()) break;
     }
     if (u.size() - consumed >= 4) { err = "truncated record"; return SQ_E_IO; }
     if (hb.size()) {
+        auto ts0 = clk::now();
         int rc = sink(hb);
+        t_sink += since(ts0);
         if (rc) return rc;
     }
     return SQ_OK;
