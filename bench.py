@@ -135,7 +135,7 @@ def main() -> None:
     tfile = ROOT / "profiles" / "pmc_traffic.json"  # written by tools/profile.sh from the rocprofv3 --pmc passes
     if tfile.exists():
         try:
-            traffic = json.loads(tfile.read_text()).get(dom)
+            traffic = (json.loads(tfile.read_text()).get(dom) or {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     out = {

@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <climits>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 
@@ -101,6 +102,7 @@ struct DeviceRecords {
     DBuf<SmallProblem> ord_p;
     DBuf<int32_t> ord_e, ord_m, ord_o, ord_v;
     DBuf<long long> other64, spine64;
+    DBuf<int32_t> calib;
     DBuf<uint8_t> zflag;
     DBuf<int32_t> cl_chr, cl_start, cl_right, trig;
     DBuf<int32_t> flags;  // small device flag/counter block
@@ -292,6 +294,15 @@ static hipError_t device_scan(hipStream_t s, int64_t n, F f, typename Op::T* out
     hipLaunchKernelGGL((k_scan_spine<Op>), dim3(1), dim3(SCAN_THREADS), 0, s, ntiles, spine.p, grand);
     hipLaunchKernelGGL((k_scan_down<Op, EXCL, F>), dim3(ntiles), dim3(SCAN_THREADS), 0, s, n, f, spine.p, out);
     return hipGetLastError();
+}
+
+// calibration kernel for the rocprofv3 FETCH_SIZE counter (MI355X_MICROARCH.md, HBM section): a plain coalesced
+// 4-byte-per-lane read of a known number of bytes, the access shape of the record scans
+__global__ void k_calib_read4(const int32_t* a, int64_t n, int32_t* out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int acc = 0;
+    for (; i < n; i += (int64_t)gridDim.x * blockDim.x) acc += a[i];
+    if (acc == 0x7fffffff) out[0] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------ K1: classify
@@ -581,7 +592,6 @@ __global__ void k_gather_other(RecView R, const uint8_t* keep, const int32_t* ra
 }
 
 // ------------------------------------------------------------------------------------------------ K4/K5: edges
-constexpr int MAXB = 24;  // own blocks + mate stub handled per record
 
 // fitting range [a,b] of nodes for a block (LocateRead's +-5 test, SegmentGraph.cpp:1213) and its home node
 __device__ __forceinline__ void fit_range(const NodeView& N, int c, int p, int end, int& a, int& b, int& home) {
@@ -603,10 +613,11 @@ __device__ __forceinline__ int locate_one(const NodeView& N, int c, int p, int e
         if (N.chr[i] < c) i = N.n; else i = -1;
         return -1;
     }
+    // the running node usually still fits (+-5 test of SegmentGraph.cpp:1213): no search needed
+    if (N.chr[i] == c && p >= N.pos[i] - 5 && end <= N.pos[i] + N.len[i] + 5) return i;
     int a, b, home;
     fit_range(N, c, p, end, a, b, home);
     bool nonempty = a <= b;
-    if (nonempty && N.chr[i] == c && i >= a && i <= b) return i;
     bool up = N.chr[i] < c || (N.chr[i] == c && N.pos[i] <= p);
     if (up) {
         if (nonempty && a >= i) { i = a; return a; }
@@ -634,7 +645,12 @@ __global__ void k_block0(RecView R, NodeView N, const uint8_t* keep, const int32
     if (r >= R.n || !(keep[r] & K_BUILD)) return;
     if (part_prev[r] >= 0) part_next[part_prev[r]] = (int32_t)r;
     int c, p, end, a = 1, b = 0, home = -1;
-    if (rec_block0(R, r, c, p, end) && c >= 0 && c < N.n_ref) fit_range(N, c, p, end, a, b, home);
+    if (rec_block0(R, r, c, p, end) && c >= 0 && c < N.n_ref) {
+        home = node_home(N, c, p);
+        const int hp = N.pos[home], he = hp + N.len[home];
+        if (end > hp + 5 && p < he - 5 && end <= he + 5) { a = home; b = home; }  // deep inside its node: no neighbour can fit
+        else fit_range(N, c, p, end, a, b, home);
+    }
     b0_a[r] = a; b0_b[r] = b; b0_home[r] = home;
 }
 // hint transfer of one record: x -> node of its block 0 if located, else x (SegmentGraph.cpp:1607-1609)
@@ -710,78 +726,94 @@ __global__ void k_edges(RecView R, NodeView N, EdgeParams P, const uint8_t* keep
             while (t != r) { hint = hint_step(hint, b0_a[t], b0_b[t], b0_home[t]); t = part_next[t]; }
         }
     }
-    // ---- gather the stub-augmented sorted record
+    // ---- the stub-augmented, read-offset-sorted record is streamed block by block (own blocks first for a first-mate
+    // record, the 15-base mate stub first otherwise); everything LocateRead + the edge rules need is carried in
+    // registers: no per-thread arrays, no scratch
     ListRec l = list_rec(R, r);
-    const int nf = l.size(0), ns = l.size(1), nt = nf + ns;
-    if (nt > MAXB) { atomicOr(&flags[0], 16); return; }
-    int bc[MAXB], bp[MAXB], bm[MAXB], brp[MAXB], bmr[MAXB], node[MAXB];
-    bool brev[MAXB];
-    for (int k = 0; k < nt; ++k) {
-        int L = k < nf ? 0 : 1, kk = k < nf ? k : k - nf;
-        bool own = (L == 0) == l.first;
-        if (own) { DBlk b = own_block_sorted(R, r, kk, l.nown, l.rev); bc[k] = b.refid; bp[k] = b.refpos; bm[k] = b.matchref; brp[k] = b.readpos; bmr[k] = b.matchread; brev[k] = b.rev; }
-        else { bc[k] = R.mrefid[r]; bp[k] = R.mpos[r]; bm[k] = 15; brp[k] = 0; bmr[k] = 15; brev[k] = R.flag[r] & 0x20; }
-    }
-    // ---- LocateRead with in-register trimming
-    int i = hint;
-    for (int k = 0; k < nt; ++k) {
-        int nd = locate_one(N, bc[k], bp[k], bp[k] + bm[k], i, hint);
-        node[k] = nd;
-        if (nd >= 0) {
-            int np = N.pos[nd], ne = np + N.len[nd];
-            if (bp[k] < np) { int d = np - bp[k]; if (!brev[k]) brp[k] += d; bm[k] -= d; bmr[k] -= d; bp[k] = np; }
-            if (bp[k] + bm[k] > ne) { int d = bp[k] + bm[k] - ne; if (brev[k]) brp[k] += d; bm[k] -= d; bmr[k] -= d; }
-        }
-    }
+    const int nown = l.nown, nt = nown + (l.stub ? 1 : 0);
     if (nt == 0) return;
-    // ---- boundary edge for every unlocatable block (SegmentGraph.cpp:1612-1618).  The reference scans up from
-    // the refreshed hint while node.end < block.start, then down while node.start > block.start: a block that starts
-    // exactly on a node boundary lands in the node BELOW the boundary when the scan arrives from below.
-    const int ffi = node[0] != -1 ? node[0] : hint;
-    for (int k = 0; k < nt; ++k)
-        if (node[k] == -1) {
-            if (bc[k] < 0 || bc[k] >= N.n_ref) { atomicOr(&flags[0], 8); continue; }
-            int h = node_home(N, bc[k], bp[k]);
-            if (N.pos[h] == bp[k] && h > N.chr_start[bc[k]] && ffi <= h - 1) --h;
-            emit_edge(hk, hv, hmask, h, false, h + 1, true, flags, N.n);
+    const bool own_first = l.first;            // own blocks form list F (FirstRead) iff first-mate
+    constexpr int OWNCAP = 8;
+    int ownnode[OWNCAP];
+#pragma unroll
+    for (int k = 0; k < OWNCAP; ++k) ownnode[k] = -2;
+    int i = hint, node0 = -1, ffi = hint;
+    // trimmed data of: first own block, last own block, previous own block, stub
+    int of_c = 0, of_p = 0, of_rp = 0; bool of_rev = false;
+    int ol_p = 0, ol_rp = 0, ol_mr = 0, ol_node = -1; bool ol_rev = false;
+    int pv_c = 0, pv_p = 0, pv_rp = 0, pv_node = -1; bool pv_rev = false;
+    int st_c = 0, st_p = 0, st_rp = 0, st_mr = 0, st_node = -1; bool st_rev = false;
+    bool own_enddisc = false;
+    for (int k = 0; k < nt; ++k) {
+        const bool is_stub = l.stub && (own_first ? k == nown : k == 0);
+        const int ko = own_first ? k : k - (l.stub ? 1 : 0);  // index among own blocks
+        int bc, bp, bm, brp, bmr; bool brev;
+        if (is_stub) { bc = R.mrefid[r]; bp = R.mpos[r]; bm = 15; brp = 0; bmr = 15; brev = R.flag[r] & 0x20; }
+        else { DBlk b = own_block_sorted(R, r, ko, nown, l.rev); bc = b.refid; bp = b.refpos; bm = b.matchref; brp = b.readpos; bmr = b.matchread; brev = b.rev; }
+        const int nd = locate_one(N, bc, bp, bp + bm, i, hint);
+        if (nd >= 0) {  // trim to the node (SegmentGraph.cpp:1229-1248)
+            int np = N.pos[nd], ne = np + N.len[nd];
+            if (bp < np) { int d = np - bp; if (!brev) brp += d; bm -= d; bmr -= d; bp = np; }
+            if (bp + bm > ne) { int d = bp + bm - ne; if (brev) brp += d; bm -= d; bmr -= d; }
+        } else {
+            // boundary edge of an unlocatable block (SegmentGraph.cpp:1612-1618).  The reference scans up from the
+            // refreshed hint while node.end < block.start, then down while node.start > block.start: a block that
+            // starts exactly on a node boundary lands in the node BELOW the boundary when the scan arrives from below.
+            if (bc < 0 || bc >= N.n_ref) atomicOr(&flags[0], 8);
+            else {
+                int h = node_home(N, bc, bp);
+                if (N.pos[h] == bp && h > N.chr_start[bc] && ffi <= h - 1) --h;
+                emit_edge(hk, hv, hmask, h, false, h + 1, true, flags, N.n);
+            }
         }
-    // ---- consecutive blocks of one mate in different nodes
-    for (int k = 0; k + 1 < nt; ++k) {
-        if (k + 1 == nf) continue;  // never across the two lists
-        int a = node[k], b = node[k + 1];
-        if (a != b && a != -1 && b != -1) emit_edge(hk, hv, hmask, a, brev[k], b, !brev[k + 1], flags, N.n);
+        if (k == 0) { node0 = nd; ffi = nd != -1 ? nd : hint; }
+        if (is_stub) { st_c = bc; st_p = bp; st_rp = brp; st_mr = bmr; st_node = nd; st_rev = brev; }
+        else {
+            if (ko == 0) { of_c = bc; of_p = bp; of_rp = brp; of_rev = brev; }
+            else {
+                // consecutive blocks of one mate in different nodes (SegmentGraph.cpp:1631-1653)
+                if (pv_node != nd && pv_node != -1 && nd != -1) emit_edge(hk, hv, hmask, pv_node, pv_rev, nd, !brev, flags, N.n);
+                // IsEndDiscordant on the trimmed blocks (ReadRec.cpp:178-209)
+                if (pv_c != bc || pv_rev != brev) own_enddisc = true;
+                else {
+                    bool refup = pv_p < bp, readup = pv_rp < brp;
+                    if (!pv_rev && refup != readup) own_enddisc = true;
+                    if (pv_rev && refup == readup) own_enddisc = true;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < OWNCAP; ++q) if (q == ko) ownnode[q] = nd;
+            pv_c = bc; pv_p = bp; pv_rp = brp; pv_node = nd; pv_rev = brev;
+            ol_p = bp; ol_rp = brp; ol_mr = bmr; ol_node = nd; ol_rev = brev;
+        }
     }
-    // ---- pair edge, first-mate records only
-    if (l.first && nf > 0 && ns > 0) {
-        auto enddisc = [&](int lo, int n) {
-            for (int k = lo; k + 1 < lo + n; ++k) {
-                if (bc[k] != bc[k + 1] || brev[k] != brev[k + 1]) return true;
-                bool refup = bp[k] < bp[k + 1], readup = brp[k] < brp[k + 1];
-                if (!brev[k] && refup != readup) return true;
-                if (brev[k] && refup == readup) return true;
+    (void)node0;
+    // ---- pair edge, first-mate records only: F = own blocks, S = [stub] (SegmentGraph.cpp:1655-1685)
+    if (own_first && nown > 0 && l.stub && !own_enddisc) {
+        const int a = ol_node, b = st_node;
+        bool isoverlap = (a == b);  // "i equals the node of a SecondMate block"
+        if (nown <= OWNCAP) {
+#pragma unroll
+            for (int q = 0; q < OWNCAP; ++q) if (q < nown && ownnode[q] == b) isoverlap = true;
+        } else {
+            // more own blocks than the register file keeps: walk the own list again (same hint chain, same nodes)
+            int i2 = hint;
+            for (int ko = 0; ko < nown; ++ko) {
+                DBlk bb = own_block_sorted(R, r, ko, nown, l.rev);
+                if (locate_one(N, bb.refid, bb.refpos, bb.refpos + bb.matchref, i2, hint) == b) isoverlap = true;
             }
-            return false;
-        };
-        bool ed1 = enddisc(0, nf), ed2 = enddisc(nf, ns);
-        if (!ed1 && !ed2) {
-            int a = node[nf - 1], b = node[nt - 1];
-            bool isoverlap = false;
-            for (int k = 0; k < nf; ++k) if (b == node[k]) isoverlap = true;
-            for (int k = 0; k < ns; ++k) if (a == node[nf + k]) isoverlap = true;
-            int ad = a - b; if (ad < 0) ad = -ad;
-            if (nf > 1 && ad < 3) isoverlap = true;
-            if (ns > 1 && ad < 3) isoverlap = true;
-            if (a != b && a != -1 && b != -1 && !isoverlap) {
-                // IsPairDiscordant(false) on the trimmed record; the absent mate side has TotalLen 0
-                const int ftot = l.first ? (int)R.totlen[r] : 0, stot = l.first ? 0 : (int)R.totlen[r];
-                const int f0 = 0, fb = nf - 1, s0 = nf, sb = nt - 1;
-                bool pd;
-                if (bc[f0] != bc[sb] || brev[f0] == brev[sb]) pd = true;
-                else if (!brev[f0] && bp[f0] - brp[f0] > bp[sb] - (stot - brp[sb] - bmr[sb])) pd = true;
-                else if (!brev[s0] && bp[s0] - brp[s0] > bp[fb] - (ftot - brp[fb] - bmr[fb])) pd = true;
-                else pd = false;
-                if (pd == dev_edge_discordant(N, P, a, brev[fb], b, brev[sb])) emit_edge(hk, hv, hmask, a, brev[fb], b, brev[sb], flags, N.n);
-            }
+        }
+        int ad = a - b; if (ad < 0) ad = -ad;
+        if (nown > 1 && ad < 3) isoverlap = true;
+        if (a != b && a != -1 && b != -1 && !isoverlap) {
+            // IsPairDiscordant(false) on the trimmed record; the absent second mate has TotalLen 0 (ReadRec.cpp:211-228)
+            const int ftot = (int)R.totlen[r], stot = 0;
+            bool pd;
+            if (of_c != st_c || of_rev == st_rev) pd = true;
+            else if (!of_rev && of_p - of_rp > st_p - (stot - st_rp - st_mr)) pd = true;
+            else if (!st_rev && st_p - st_rp > ol_p - (ftot - ol_rp - ol_mr)) pd = true;
+            else pd = false;
+            if (pd == dev_edge_discordant(N, P, a, ol_rev, b, st_rev)) emit_edge(hk, hv, hmask, a, ol_rev, b, st_rev, flags, N.n);
         }
     }
 }
@@ -1070,7 +1102,7 @@ void dev_destroy(sq_ctx* c) {
     D.srec.release(); D.rest_refpos.release(); D.rest_matchref.release();
     D.n_chr.release(); D.n_pos.release(); D.n_len.release(); D.n_chr_start.release();
     D.acc_a.release(); D.acc_b.release(); D.acc_c.release(); D.acc_d.release();
-    D.h_key.release(); D.h_val.release(); D.flags.release(); D.okey.release(); D.oval.release(); D.other64.release(); D.spine64.release(); D.zflag.release();
+    D.h_key.release(); D.h_val.release(); D.flags.release(); D.calib.release(); D.okey.release(); D.oval.release(); D.other64.release(); D.spine64.release(); D.zflag.release();
     D.cl_chr.release(); D.cl_start.release(); D.cl_right.release(); D.trig.release();
     D.ord_p.release(); D.ord_e.release(); D.ord_m.release(); D.ord_o.release(); D.ord_v.release();
     for (auto& e : D.ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -1136,6 +1168,13 @@ int dev_classify_and_summarise(sq_ctx* c, std::vector<StreamRec>& recs, std::vec
     HIPCHK(D.cls.reserve(n)); HIPCHK(D.keep.reserve(n)); HIPCHK(D.prev1.reserve(n)); HIPCHK(D.prev2.reserve(n)); HIPCHK(D.rank1.reserve(n)); HIPCHK(D.restoff.reserve(n));
     int32_t* tot = D.flags.p + 8;
     int32_t h_tot[2] = {0, 0};
+    if (std::getenv("SQUID_CALIB")) {
+        const int64_t words = (int64_t)1 << 28;  // 1 GiB: larger than the 256 MiB Infinity Cache
+        HIPCHK(D.calib.reserve(words));
+        HIPCHK(hipMemsetAsync(D.calib.p, 1, words * 4, s));
+        EvTimer t(c, "k_calib_read4", 4.0 * words);
+        hipLaunchKernelGGL(k_calib_read4, dim3(2048), dim3(256), 0, s, D.calib.p, words, D.flags.p + 16);
+    }
     if (n > 0) {
         const double bytes_rec = 32.0 * n + 12.0 * D.nb;
         { EvTimer t(c, "k_classify", 28.0 * n + 12.0 * D.nb); hipLaunchKernelGGL(k_classify, grid_for(n, 256), dim3(256), 0, s, R, c->P.min_mapqual, D.cls.p); }

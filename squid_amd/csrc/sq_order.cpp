@@ -102,11 +102,9 @@ struct HostSolver {
     };
     void leaf(unsigned mask) {
         std::vector<int> a((size_t)n * n, 0);
-        long ub = 0;
         for (const LEdge& e : E) {
             bool uf;
             if (!compat(e, mask, uf)) continue;
-            ub += e.w;
             if (uf) a[e.u * n + e.v] += e.w; else a[e.v * n + e.u] += e.w;
         }
         // reachability closure on bitmasks -> strongly connected components

@@ -252,7 +252,6 @@ int segment_prepare(sq_ctx* c, std::shared_ptr<SegPlan>& plan, int64_t& n_break,
     if ((int64_t)c->stream_host.size() < K) c->stream_host.resize((size_t)K);  // only the replayed stretches are ever filled in
     Seg& S = plan->S;
     S.recs = c->stream_host.data();
-    const int RL = c->read_len;
     // ---- discordant blocks and clip positions of the chimeric fragments (SegmentGraph.cpp:203-264)
     S.part.assign(c->ref_len.size(), std::make_pair(0, 0));  // ledger B10
     std::vector<Blk>& D = S.D;

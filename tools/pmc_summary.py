@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
+
+Counter units are calibrated on k_calib_read4 (a coalesced 4-byte-per-lane read of exactly 2^30 bytes in the same
+run): bytes_per_count = 2^30 / FETCH_SIZE(k_calib_read4).  WRITE_SIZE is scaled by the same factor (uncalibrated,
+reported separately)."""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+
+def load(path):
+    per = defaultdict(list)
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            name = row.get("Kernel_Name") or row.get("Kernel Name") or ""
+            val = float(row.get("Counter_Value") or row.get("Counter Value") or 0)
+            per[name.split("(")[0].replace("sq::", "").replace("void ", "").strip()].append(val)
+    return per
+
+
+fetch, write = load(sys.argv[1]), load(sys.argv[2])
+cal = [v for k, vs in fetch.items() if "k_calib_read4" in k for v in vs]
+factor = (1 << 30) / (sum(cal) / len(cal)) if cal else None
+out = {"_calibration": {"kernel": "k_calib_read4", "bytes": 1 << 30, "fetch_counts": cal, "bytes_per_count": factor}}
+for k in sorted(fetch):
+    if "k_calib" in k or not (k.startswith("k_") or "k_scan" in k):
+        continue
+    f = sum(fetch[k]) / len(fetch[k])
+    w = sum(write.get(k, [0])) / max(1, len(write.get(k, [0])))
+    out[k] = {"launches": len(fetch[k]), "fetch_bytes_per_launch": f * factor if factor else None, "write_bytes_per_launch": w * factor if factor else None,
+              "hbm_bytes_per_launch": (f + w) * factor if factor else None}
+print(json.dumps(out, indent=1))
