@@ -97,8 +97,14 @@ int sq_chim_contains(sq_ctx* c, const char* name, size_t len);
 /* The concordant stream, in file order; may be called repeatedly (batches are appended in HBM). */
 int sq_ingest_concordant(sq_ctx* c, const sq_aln_batch* b);
 
+/* K0: the inflated BAM record stream itself (no header), `rec_off[i]` = byte offset of record i's block_size field.
+ * The records are parsed on the GPU (k_parse_*): field decode + ReadRec_t::ReadRec_t (src/ReadRec.cpp:10-88) +
+ * tag / QNAME tests (src/SegmentGraph.cpp:297-302).  Needs sq_ingest_chimeric first (QNAME set, quality flags). */
+int sq_ingest_concordant_bam(sq_ctx* c, const uint8_t* bam, size_t nbytes, const uint64_t* rec_off, int64_t n_rec);
+
 /* Convenience host-side readers (own BGZF/BAM decoder; replaces the BamTools calls listed in SURVEY.md
- * appendix C).  They decode, fill sq_aln_batch and call the two functions above. */
+ * appendix C).  The chimeric reader decodes on the host; the concordant reader inflates and finds record boundaries on
+ * the host and parses on the GPU (sq_ingest_concordant_bam), or decodes on host threads when SQUID_HOST_PARSE is set. */
 int sq_read_header(const char* bam_path, int32_t* n_ref, int32_t* ref_len, char* names, size_t names_cap);
 int sq_ingest_chimeric_file(sq_ctx* c, const char* bam_path);
 int sq_ingest_concordant_file(sq_ctx* c, const char* bam_path, int32_t n_threads);
@@ -166,6 +172,9 @@ typedef struct sq_counts {
     int64_t n_kept_p1, n_break, n_kept_p2, n_raw_edges, n_unique_edges;
 } sq_counts;
 int sq_get_counts(sq_ctx* c, sq_counts* k);
+
+/* tests: copy the HBM-resident record SoA back into a library-owned host batch */
+int sq_debug_download(sq_ctx* c, sq_aln_batch* b);
 
 #ifdef __cplusplus
 }

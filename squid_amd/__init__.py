@@ -18,9 +18,9 @@ LIB_PATH = BUILD / "libsquid_hip.so"
 
 EXPORTS = [
     "sq_default_params", "sq_create", "sq_destroy", "sq_strerror", "sq_last_error", "sq_set_references",
-    "sq_ingest_chimeric", "sq_chim_contains", "sq_ingest_concordant", "sq_read_header", "sq_ingest_chimeric_file",
+    "sq_ingest_chimeric", "sq_chim_contains", "sq_ingest_concordant", "sq_ingest_concordant_bam", "sq_read_header", "sq_ingest_chimeric_file",
     "sq_ingest_concordant_file", "sq_build_graph", "sq_graph_view", "sq_order", "sq_call_sv", "sq_breakpoints",
-    "sq_exchange_pack", "sq_exchange_unpack", "sq_get_timing", "sq_reset", "sq_get_counts",
+    "sq_exchange_pack", "sq_exchange_unpack", "sq_get_timing", "sq_reset", "sq_get_counts", "sq_debug_download",
 ]
 
 
@@ -33,6 +33,13 @@ class SqParams(C.Structure):
 
 _P32 = C.POINTER(C.c_int32)
 _PU8 = C.POINTER(C.c_uint8)
+
+
+class SqAlnBatch(C.Structure):
+    _fields_ = [("n_rec", C.c_int64), ("n_blk", C.c_int64), ("refid", _P32), ("pos", _P32), ("mate_refid", _P32), ("mate_pos", _P32), ("end_pos", _P32),
+                ("flag", C.POINTER(C.c_uint16)), ("mapq", _PU8), ("aux", _PU8), ("totlen", C.POINTER(C.c_uint16)), ("blk_off", C.POINTER(C.c_uint32)),
+                ("b_refpos", _P32), ("b_matchref", _P32), ("b_readpos", C.POINTER(C.c_uint16)), ("b_matchread", C.POINTER(C.c_uint16)),
+                ("name_off", C.POINTER(C.c_uint32)), ("name_blob", C.c_char_p)]
 
 
 class SqGraph(C.Structure):
@@ -190,6 +197,23 @@ class Context:
         t = SqBpTable()
         self._chk(self.lib.sq_breakpoints(self.h, C.byref(t)), "sq_breakpoints")
         return [[(t.bp1[j], t.bp2[j], t.sup1[j], t.sup2[j]) for j in range(t.bp_off[e], t.bp_off[e + 1])] for e in range(t.n_edges)]
+
+    def records(self) -> dict:
+        """copy of the HBM-resident record SoA (tests only)"""
+        import numpy as np
+
+        b = SqAlnBatch()
+        self.lib.sq_debug_download.argtypes = [C.c_void_p, C.POINTER(SqAlnBatch)]
+        self._chk(self.lib.sq_debug_download(self.h, C.byref(b)), "sq_debug_download")
+        n, nb = b.n_rec, b.n_blk
+
+        def arr(ptr, cnt, dt):
+            return np.ctypeslib.as_array(ptr, shape=(cnt,)).astype(dt).copy() if cnt else np.zeros(0, dt)
+
+        return {"refid": arr(b.refid, n, "i4"), "pos": arr(b.pos, n, "i4"), "mate_refid": arr(b.mate_refid, n, "i4"), "mate_pos": arr(b.mate_pos, n, "i4"),
+                "end_pos": arr(b.end_pos, n, "i4"), "flag": arr(b.flag, n, "u2"), "mapq": arr(b.mapq, n, "u1"), "aux": arr(b.aux, n, "u1"), "totlen": arr(b.totlen, n, "u2"),
+                "blk_off": arr(b.blk_off, n + 1, "u4"), "b_refpos": arr(b.b_refpos, nb, "i4"), "b_matchref": arr(b.b_matchref, nb, "i4"),
+                "b_readpos": arr(b.b_readpos, nb, "u2"), "b_matchread": arr(b.b_matchread, nb, "u2")}
 
     def timing(self) -> dict:
         t = SqTiming()

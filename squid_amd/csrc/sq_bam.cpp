@@ -374,8 +374,9 @@ static int read_bam_header_bytes(const std::vector<uint8_t>& d, bool whole_file,
     return SQ_OK;
 }
 
-int parse_bam_file(const char* path, const ParseOpts& o, size_t batch_records, int n_threads, std::string& err,
-                   const std::function<int(const HostBatch&)>& sink) {
+typedef std::function<int(const uint8_t*, size_t, const unsigned long long*, int64_t)> RawSink;
+static int parse_bam_impl(const char* path, const ParseOpts& o, size_t batch_records, int n_threads, std::string& err,
+                          const std::function<int(const HostBatch&)>& sink, const RawSink* raw_sink) {
     using clk = std::chrono::steady_clock;
     double t_read = 0, t_inflate = 0, t_walk = 0, t_decode = 0, t_append = 0, t_sink = 0;
     auto since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
@@ -434,6 +435,7 @@ int parse_bam_file(const char* path, const ParseOpts& o, size_t batch_records, i
     std::vector<int> prc((size_t)n_threads);
     std::vector<std::string> perr((size_t)n_threads);
     std::vector<size_t> s_begin((size_t)n_threads), s_end((size_t)n_threads);
+    std::vector<std::vector<unsigned long long>> roffs((size_t)n_threads);  // raw mode: record offsets per slice
     auto plausible = [&](size_t p, size_t limit) -> long {  // record header at p?  returns its block_size or -1
         if (limit - p < 36) return -1;
         const uint8_t* q = &u[p];
@@ -473,6 +475,7 @@ int parse_bam_file(const char* path, const ParseOpts& o, size_t batch_records, i
             auto work = [&](int t) {
                 HostBatch& part = parts[t];
                 part.clear();
+                roffs[t].clear();
                 prc[t] = SQ_OK;
                 size_t lo = consumed + avail * t / T, hi = consumed + avail * (t + 1) / T;
                 size_t p = t == 0 ? consumed : sync_from(lo, hi, limit);
@@ -482,8 +485,11 @@ int parse_bam_file(const char* path, const ParseOpts& o, size_t batch_records, i
                     int32_t bs = rd32(&u[p]);
                     if (bs < 32) { prc[t] = SQ_E_IO; perr[t] = "truncated record"; break; }
                     if (limit - p < 4 + (size_t)bs) break;  // incomplete: belongs to the next chunk
-                    int rc = dec.decode(&u[p + 4], bs, part, perr[t]);
-                    if (rc) { prc[t] = rc; break; }
+                    if (raw_sink) roffs[t].push_back((unsigned long long)(p - consumed));
+                    else {
+                        int rc = dec.decode(&u[p + 4], bs, part, perr[t]);
+                        if (rc) { prc[t] = rc; break; }
+                    }
                     p += 4 + (size_t)bs;
                 }
                 s_end[t] = p;
@@ -501,11 +507,34 @@ int parse_bam_file(const char* path, const ParseOpts& o, size_t batch_records, i
             if (prc[0]) { err = perr[0]; return prc[0]; }
             for (int t = 1; t < T; ++t) {
                 size_t hi = consumed + avail * (t + 1) / T;
-                if (s_begin[t] >= hi && parts[t].size() == 0 && good_end >= hi) { ++good; continue; }  // slice swallowed by a long record
+                if (s_begin[t] >= hi && parts[t].size() == 0 && roffs[t].empty() && good_end >= hi) { ++good; continue; }  // slice swallowed by a long record
                 if (s_begin[t] != good_end) { if (std::getenv("SQUID_INGEST_DEBUG")) std::fprintf(stderr, "stitch mismatch at slice %d/%d: begin=%zu expected=%zu lo=%zu hi=%zu\n", t, T, s_begin[t], good_end, consumed + avail * t / T, hi); break; }
                 if (prc[t]) { err = perr[t]; return prc[t]; }
                 good_end = s_end[t];
                 ++good;
+            }
+            if (raw_sink) {
+                auto ta0 = clk::now();
+                std::vector<unsigned long long> offs;
+                for (int t = 0; t < good; ++t) offs.insert(offs.end(), roffs[t].begin(), roffs[t].end());
+                size_t p = good_end;
+                if (good < T)  // false synchronisation: finish the chunk with the plain serial walk
+                    for (;;) {
+                        if (limit - p < 4) break;
+                        int32_t bs = rd32(&u[p]);
+                        if (bs < 32) { err = "truncated record"; return SQ_E_IO; }
+                        if (limit - p < 4 + (size_t)bs) break;
+                        offs.push_back((unsigned long long)(p - consumed));
+                        p += 4 + (size_t)bs;
+                    }
+                t_append += since(ta0);
+                auto ts0 = clk::now();
+                int rc = (*raw_sink)(&u[consumed], p - consumed, offs.data(), (int64_t)offs.size());
+                t_sink += since(ts0);
+                if (rc) return rc;
+                consumed = p;
+                if (!refill()) break;
+                continue;
             }
             for (int t = 0; t < good; ++t) {
                 auto ta0 = clk::now();
@@ -549,6 +578,14 @@ int parse_bam_file(const char* path, const ParseOpts& o, size_t batch_records, i
         if (rc) return rc;
     }
     return SQ_OK;
+}
+
+int parse_bam_file(const char* path, const ParseOpts& o, size_t batch_records, int n_threads, std::string& err, const std::function<int(const HostBatch&)>& sink) {
+    return parse_bam_impl(path, o, batch_records, n_threads, err, sink, nullptr);
+}
+int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSink& sink) {
+    ParseOpts o{1, 0, 0, false, nullptr};
+    return parse_bam_impl(path, o, (size_t)1 << 40, n_threads, err, [](const HostBatch&) { return 0; }, &sink);
 }
 
 }  // namespace sq

@@ -1,5 +1,6 @@
 // C-ABI entry points of libsquid_hip.so (include/squid_hip.h) and the stage pipeline behind them.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <future>
 #include <memory>
@@ -314,7 +315,7 @@ int sq_ingest_chimeric(sq_ctx* c, const sq_aln_batch* b) {
     int rc = build_fragments(c, b);
     if (rc) return rc;
     c->frags0 = c->frags;
-    return SQ_OK;
+    return dev_upload_chim_names(c);
 }
 int sq_chim_contains(sq_ctx* c, const char* name, size_t len) {
     if (!c) return SQ_E_ARG;
@@ -323,6 +324,12 @@ int sq_chim_contains(sq_ctx* c, const char* name, size_t len) {
 int sq_ingest_concordant(sq_ctx* c, const sq_aln_batch* b) {
     if (!c || !b) return SQ_E_ARG;
     return dev_append_records(c, b);
+}
+int sq_ingest_concordant_bam(sq_ctx* c, const uint8_t* bam, size_t nbytes, const uint64_t* rec_off, int64_t n_rec) {
+    if (!c || (n_rec && (!bam || !rec_off))) return SQ_E_ARG;
+    int rc = dev_parse_append(c, bam, nbytes, (const unsigned long long*)rec_off, n_rec);
+    dev_flush_timers(c);
+    return rc;
 }
 int sq_read_header(const char* path, int32_t* n_ref, int32_t* ref_len, char* names, size_t names_cap) {
     std::vector<std::string> nm;
@@ -362,6 +369,12 @@ int sq_ingest_chimeric_file(sq_ctx* c, const char* path) {
 }
 int sq_ingest_concordant_file(sq_ctx* c, const char* path, int32_t n_threads) {
     if (!c || !path) return SQ_E_ARG;
+    if (!std::getenv("SQUID_HOST_PARSE")) {
+        // default: the host only inflates BGZF and finds record boundaries; K0 parses the records on the GPU
+        int rc = scan_bam_file(path, n_threads, c->err, [&](const uint8_t* bam, size_t nbytes, const unsigned long long* off, int64_t n) { return dev_parse_append(c, bam, nbytes, off, n); });
+        dev_flush_timers(c);
+        return rc;
+    }
     ParseOpts o{c->P.phred_type, c->P.min_phred, c->P.max_lowphred_len, false, &c->chim_set};
     return parse_bam_file(path, o, (size_t)1 << 21, n_threads, c->err, [&](const HostBatch& hb) {
         sq_aln_batch b;
@@ -425,6 +438,14 @@ int sq_reset(sq_ctx* c) {
 int sq_get_counts(sq_ctx* c, sq_counts* k) {
     if (!c || !k) return SQ_E_ARG;
     *k = c->counts;
+    return SQ_OK;
+}
+int sq_debug_download(sq_ctx* c, sq_aln_batch* b) {
+    if (!c || !b) return SQ_E_ARG;
+    static thread_local HostBatch hb;
+    int rc = dev_download_records(c, hb);
+    if (rc) return rc;
+    hb.view(b, false);
     return SQ_OK;
 }
 int sq_exchange_pack(sq_ctx* c, const void** buf, int64_t* nbytes) {

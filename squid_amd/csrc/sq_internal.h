@@ -137,6 +137,8 @@ int read_bam_header(const char* path, std::vector<std::string>& names, std::vect
 struct ParseOpts { int phred_type, min_phred, max_lowphred_len; bool keep_names; const std::unordered_set<std::string>* inchim; };
 int parse_bam_file(const char* path, const ParseOpts& o, size_t batch_records, int n_threads, std::string& err,
                    const std::function<int(const HostBatch&)>& sink);
+// raw mode: inflate + record-boundary walk on the host, hand each chunk (bytes, record offsets) to `sink`
+int scan_bam_file(const char* path, int n_threads, std::string& err, const std::function<int(const uint8_t*, size_t, const unsigned long long*, int64_t)>& sink);
 
 // ---- sq_chimeric.cpp
 int build_fragments(sq_ctx* c, const sq_aln_batch* b);
@@ -174,6 +176,10 @@ int dev_create(sq_ctx* c);
 void dev_destroy(sq_ctx* c);
 void dev_flush_timers(sq_ctx* c);
 int dev_append_records(sq_ctx* c, const sq_aln_batch* b);
+int dev_upload_chim_names(sq_ctx* c);
+int dev_parse_append(sq_ctx* c, const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n_rec);
+struct HostBatch;
+int dev_download_records(sq_ctx* c, HostBatch& hb);
 struct SegSupport {
     std::vector<int32_t> trigger, zidx, z_ochr, z_oright, rest_cluster, rest_pos, rest_len;
 };

@@ -102,6 +102,12 @@ struct DeviceRecords {
     DBuf<SmallProblem> ord_p;
     DBuf<int32_t> ord_e, ord_m, ord_o, ord_v;
     DBuf<long long> other64, spine64;
+    DBuf<uint8_t> bam_chunk;
+    DBuf<unsigned long long> bam_off, chim_hash;
+    DBuf<uint32_t> chim_off, chim_len;
+    DBuf<char> chim_blob;
+    uint32_t chim_mask = 0;
+    DBuf<int32_t> parse_nblk, parse_rel;
     DBuf<int32_t> calib;
     DBuf<uint8_t> zflag;
     DBuf<int32_t> cl_chr, cl_start, cl_right, trig;
@@ -303,6 +309,164 @@ __global__ void k_calib_read4(const int32_t* a, int64_t n, int32_t* out) {
     int acc = 0;
     for (; i < n; i += (int64_t)gridDim.x * blockDim.x) acc += a[i];
     if (acc == 0x7fffffff) out[0] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------ K0: BAM record parse
+// One thread per BAM record of an inflated chunk resident in HBM (record offsets come from the host's boundary
+// walk).  Restates the per-record part of the reference's ingest -- BamTools field decode plus ReadRec_t::ReadRec_t
+// (src/ReadRec.cpp:10-88): TotalLen, longest low-Phred run, CIGAR -> aligned blocks with the poly-A/T filter and
+// strand-mirrored read offsets, GetEndPosition(), XA / IH tags (src/SegmentGraph.cpp:297-301) and the QNAME lookup in
+// the chimeric name set (:302) -- and writes the SoA layout directly.  Two passes: count blocks, scan, write.
+struct ChimSetView { uint32_t mask; const unsigned long long* hash; const uint32_t *off, *len; const char* blob; };
+struct ParseParams { int qual_thr, max_lowphred_len, min_mapq; };
+__device__ __forceinline__ int ld32(const uint8_t* p) { return (int)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); }
+__device__ __forceinline__ int ld16(const uint8_t* p) { return (int)p[0] | ((int)p[1] << 8); }
+__device__ __forceinline__ char cig_type(uint32_t v) { const char ops[] = {'M', 'I', 'D', 'N', 'S', 'H', 'P', '=', 'X', '?', '?', '?', '?', '?', '?', '?'}; return ops[v & 0xf]; }
+__device__ bool chim_contains(const ChimSetView& C, const uint8_t* name, int n) {
+    if (!C.hash) return false;
+    unsigned long long h = 1469598103934665603ull;
+    for (int i = 0; i < n; ++i) { h ^= name[i]; h *= 1099511628211ull; }
+    if (h == 0) h = 1;
+    for (uint32_t s = (uint32_t)(h >> 20) & C.mask, probes = 0; probes <= C.mask; s = (s + 1) & C.mask, ++probes) {
+        unsigned long long e = C.hash[s];
+        if (e == 0) return false;
+        if (e == h && (int)C.len[s] == n) {
+            bool same = true;
+            for (int i = 0; i < n; ++i) if (C.blob[C.off[s] + i] != (char)name[i]) { same = false; break; }
+            if (same) return true;
+        }
+    }
+    return false;
+}
+// WRITE = false: only counts the kept blocks.  Returns the block count, or -1 when the reference's
+// assert(ReadPos >= HardClipOffset && ...) (ReadRec.cpp:64) would fire.
+template <bool WRITE>
+__device__ int parse_blocks(const uint8_t* cg, int ncig, const uint8_t* seq, int lseq, int pos, bool rev, int totlen, int32_t* o_refpos, int32_t* o_matchref, uint16_t* o_readpos,
+                            uint16_t* o_matchread) {
+    int readpos = 0, refpos = pos, hardclip = 0, nb = 0;
+    for (int ic = 0; ic < ncig; ++ic) {
+        uint32_t v = (uint32_t)ld32(cg + 4 * ic);
+        char t = cig_type(v);
+        int len = (int)(v >> 4);
+        if (t == 'S' || t == 'H') {
+            readpos += len;
+            if (t == 'H') hardclip += len;
+        } else if (t == 'M' || t == '=') {
+            int tr = 0, tf = 0, ic2;
+            for (ic2 = ic; ic2 < ncig; ++ic2) {
+                uint32_t v2 = (uint32_t)ld32(cg + 4 * ic2);
+                char t2 = cig_type(v2);
+                if (t2 == 'S' || t2 == 'H' || t2 == 'N') break;
+                if (t2 != 'D') tr += (int)(v2 >> 4);
+                if (t2 != 'I') tf += (int)(v2 >> 4);
+            }
+            int s0 = readpos - hardclip, s1 = readpos + tr - hardclip;
+            if (!(readpos >= hardclip && s1 <= lseq)) return -1;
+            int na = 0, nt = 0;
+            for (int i = s0; i < s1; ++i) {
+                int code = (seq[i >> 1] >> ((~i & 1) << 2)) & 0xf;
+                na += code == 1;
+                nt += code == 8;
+            }
+            if (4 * na < 3 * tr && 4 * nt < 3 * tr) {
+                if (WRITE) {
+                    o_refpos[nb] = refpos; o_matchref[nb] = tf;
+                    o_readpos[nb] = (uint16_t)(rev ? totlen - readpos - tr : readpos); o_matchread[nb] = (uint16_t)tr;
+                }
+                ++nb;
+            }
+            readpos += tr;
+            refpos += tf;
+            ic = ic2 - 1;
+        } else if (t == 'N')
+            refpos += len;
+    }
+    return nb;
+}
+__global__ void k_parse_count(const uint8_t* bam, const unsigned long long* rec_off, int64_t n, int32_t* nblk, int32_t* flags) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const uint8_t* p = bam + rec_off[r] + 4;
+    int lname = p[8], ncig = ld16(p + 12), flag = ld16(p + 14), lseq = ld32(p + 16), pos = ld32(p + 4);
+    const uint8_t* cg = p + 32 + lname;
+    const uint8_t* seq = cg + 4 * (size_t)ncig;
+    int totlen = 0;
+    for (int i = 0; i < ncig; ++i) { uint32_t v = (uint32_t)ld32(cg + 4 * i); char t = cig_type(v); if (t == 'M' || t == 'S' || t == 'H' || t == 'I' || t == '=' || t == 'X') totlen += (int)(v >> 4); }
+    int nb = parse_blocks<false>(cg, ncig, seq, lseq, pos, flag & 0x10, totlen, nullptr, nullptr, nullptr, nullptr);
+    nblk[r] = nb < 0 ? 0 : nb;
+    (void)flags;
+}
+struct FArrN { const int32_t* a; __device__ int operator()(int64_t i) const { return a[i]; } };
+__global__ void k_parse_write(const uint8_t* bam, const unsigned long long* rec_off, int64_t n, ChimSetView C, ParseParams P, const int32_t* blk_rel, uint32_t blk_base, int32_t* o_refid,
+                              int32_t* o_pos, int32_t* o_mrefid, int32_t* o_mpos, int32_t* o_endpos, uint16_t* o_flag, uint16_t* o_totlen, uint8_t* o_mapq, uint8_t* o_aux, uint32_t* o_blkoff,
+                              int32_t* b_refpos, int32_t* b_matchref, uint16_t* b_readpos, uint16_t* b_matchread, int32_t* flags) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const uint8_t* p = bam + rec_off[r] + 4;
+    const int bs = ld32(p - 4);
+    const uint8_t* pend = p + bs;
+    const int refid = ld32(p), pos = ld32(p + 4), lname = p[8], mapq = p[9], ncig = ld16(p + 12), flag = ld16(p + 14), lseq = ld32(p + 16), mrefid = ld32(p + 20), mpos = ld32(p + 24);
+    const uint8_t* name = p + 32;
+    const uint8_t* cg = name + lname;
+    const uint8_t* seq = cg + 4 * (size_t)ncig;
+    const uint8_t* qual = seq + (lseq + 1) / 2;
+    const uint8_t* aux = qual + lseq;
+    if (aux > pend) { atomicOr(&flags[0], 128); return; }
+    int totlen = 0, endpos = pos;
+    for (int i = 0; i < ncig; ++i) {
+        uint32_t v = (uint32_t)ld32(cg + 4 * i);
+        char t = cig_type(v);
+        int len = (int)(v >> 4);
+        if (t == 'M' || t == 'S' || t == 'H' || t == 'I' || t == '=' || t == 'X') totlen += len;
+        if (t == 'M' || t == 'D' || t == 'N' || t == '=' || t == 'X') endpos += len;
+    }
+    int lowrun = 0, run = 0;
+    for (int i = 0; i < lseq; ++i) {
+        int c = (signed char)((qual[i] + 33) & 0xff);
+        run = (c < P.qual_thr) ? run + 1 : 0;
+        if (run > lowrun) lowrun = run;
+    }
+    // aux: XA present, first IH value (integer typed)
+    bool has_xa = false, has_ih = false, bad = false;
+    int ih = 0;
+    for (const uint8_t* q = aux; q + 3 <= pend;) {
+        uint8_t t0 = q[0], t1 = q[1], ty = q[2];
+        const uint8_t* v = q + 3;
+        size_t sz;
+        if (ty == 'A' || ty == 'c' || ty == 'C') sz = 1;
+        else if (ty == 's' || ty == 'S') sz = 2;
+        else if (ty == 'i' || ty == 'I' || ty == 'f') sz = 4;
+        else if (ty == 'Z' || ty == 'H') { const uint8_t* z = v; while (z < pend && *z) ++z; if (z >= pend) { bad = true; break; } sz = (size_t)(z - v) + 1; }
+        else if (ty == 'B') {
+            if (v + 5 > pend) { bad = true; break; }
+            size_t es = (v[0] == 'c' || v[0] == 'C') ? 1 : ((v[0] == 's' || v[0] == 'S') ? 2 : 4);
+            sz = 5 + es * (size_t)(uint32_t)ld32(v + 1);
+        } else { bad = true; break; }
+        if (v + sz > pend) { bad = true; break; }
+        if (t0 == 'X' && t1 == 'A') has_xa = true;
+        if (t0 == 'I' && t1 == 'H' && !has_ih) {
+            has_ih = true;
+            if (ty == 'c' || ty == 'C' || ty == 'A') ih = v[0];
+            else if (ty == 's' || ty == 'S') ih = ld16(v);
+            else if (ty == 'i' || ty == 'I') ih = ld32(v);
+        }
+        q = v + sz;
+    }
+    if (bad) { atomicOr(&flags[0], 128); return; }
+    uint8_t ax = 0;
+    if (has_xa || ih > 1) ax |= SQ_AUX_MULTI;
+    if (lowrun > P.max_lowphred_len) ax |= SQ_AUX_LOWPHRED;
+    if (chim_contains(C, name, lname > 0 ? lname - 1 : 0)) ax |= SQ_AUX_INCHIM;
+    const uint32_t b0 = blk_base + (uint32_t)blk_rel[r];
+    int nb = parse_blocks<true>(cg, ncig, seq, lseq, pos, flag & 0x10, totlen, b_refpos + b0, b_matchref + b0, b_readpos + b0, b_matchread + b0);
+    if (nb < 0) {
+        // the reference constructs a ReadRec_t only for records that pass its filters; for those the assert is live
+        bool filtered = (ax & (SQ_AUX_MULTI | SQ_AUX_INCHIM)) || (flag & 0x400) || (flag & 0x4) || mapq < P.min_mapq;
+        if (!filtered) atomicOr(&flags[0], 256);
+    }
+    o_refid[r] = refid; o_pos[r] = pos; o_mrefid[r] = mrefid; o_mpos[r] = mpos; o_endpos[r] = endpos;
+    o_flag[r] = (uint16_t)flag; o_totlen[r] = (uint16_t)totlen; o_mapq[r] = (uint8_t)mapq; o_aux[r] = ax;
+    o_blkoff[r] = b0;
 }
 
 // ------------------------------------------------------------------------------------------------ K1: classify
@@ -1102,7 +1266,8 @@ void dev_destroy(sq_ctx* c) {
     D.srec.release(); D.rest_refpos.release(); D.rest_matchref.release();
     D.n_chr.release(); D.n_pos.release(); D.n_len.release(); D.n_chr_start.release();
     D.acc_a.release(); D.acc_b.release(); D.acc_c.release(); D.acc_d.release();
-    D.h_key.release(); D.h_val.release(); D.flags.release(); D.calib.release(); D.okey.release(); D.oval.release(); D.other64.release(); D.spine64.release(); D.zflag.release();
+    D.h_key.release(); D.h_val.release(); D.flags.release(); D.bam_chunk.release(); D.bam_off.release(); D.chim_hash.release(); D.chim_off.release(); D.chim_len.release(); D.chim_blob.release(); D.parse_nblk.release(); D.parse_rel.release();
+    D.calib.release(); D.okey.release(); D.oval.release(); D.other64.release(); D.spine64.release(); D.zflag.release();
     D.cl_chr.release(); D.cl_start.release(); D.cl_right.release(); D.trig.release();
     D.ord_p.release(); D.ord_e.release(); D.ord_m.release(); D.ord_o.release(); D.ord_v.release();
     for (auto& e : D.ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -1138,6 +1303,94 @@ int dev_append_records(sq_ctx* c, const sq_aln_batch* b) {
     D.nb = (int64_t)nb1;
     c->counts.n_concordant = D.n;
     c->counts.n_blocks = D.nb;
+    return SQ_OK;
+}
+
+// device copy of the chimeric QNAME set (sorted unique names incl. "", ledger B9) as an open-addressing table
+int dev_upload_chim_names(sq_ctx* c) {
+    DeviceRecords& D = *c->dev;
+    const std::vector<std::string>& names = c->chim_names;
+    uint32_t slots = 16;
+    while (slots < 2 * names.size() + 2) slots <<= 1;
+    std::vector<unsigned long long> hash(slots, 0);
+    std::vector<uint32_t> off(slots, 0), len(slots, 0);
+    std::vector<char> blob(1, 0);
+    for (const std::string& nm : names) {
+        unsigned long long h = 1469598103934665603ull;
+        for (unsigned char ch : nm) { h ^= ch; h *= 1099511628211ull; }
+        if (h == 0) h = 1;
+        uint32_t s = (uint32_t)(h >> 20) & (slots - 1);
+        while (hash[s]) s = (s + 1) & (slots - 1);
+        hash[s] = h; off[s] = (uint32_t)blob.size(); len[s] = (uint32_t)nm.size();
+        blob.insert(blob.end(), nm.begin(), nm.end());
+    }
+    HIPCHK(D.chim_hash.reserve(slots)); HIPCHK(D.chim_off.reserve(slots)); HIPCHK(D.chim_len.reserve(slots)); HIPCHK(D.chim_blob.reserve(blob.size()));
+    HIPCHK(hipMemcpyAsync(D.chim_hash.p, hash.data(), slots * 8, hipMemcpyHostToDevice, c->stream)); HIPCHK(hipMemcpyAsync(D.chim_off.p, off.data(), slots * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(D.chim_len.p, len.data(), slots * 4, hipMemcpyHostToDevice, c->stream)); HIPCHK(hipMemcpyAsync(D.chim_blob.p, blob.data(), blob.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    D.chim_mask = names.empty() ? 0 : slots - 1;
+    return SQ_OK;
+}
+
+// K0: parse `n_rec` BAM records of an inflated chunk on the device and append them to the resident SoA
+int dev_parse_append(sq_ctx* c, const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n_rec) {
+    if (n_rec == 0) return SQ_OK;
+    DeviceRecords& D = *c->dev;
+    hipStream_t s = c->stream;
+    const size_t n0 = (size_t)D.n, nb0 = (size_t)D.nb, n1 = n0 + (size_t)n_rec;
+    HIPCHK(D.bam_chunk.reserve(nbytes + 64)); HIPCHK(D.bam_off.reserve((size_t)n_rec)); HIPCHK(D.parse_nblk.reserve((size_t)n_rec)); HIPCHK(D.parse_rel.reserve((size_t)n_rec));
+    HIPCHK(hipMemcpyAsync(D.bam_chunk.p, bam, nbytes, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(D.bam_off.p, rec_off, (size_t)n_rec * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
+    int32_t* tot = D.flags.p + 8;
+    { EvTimer t(c, "k_parse_count", (double)nbytes);
+      hipLaunchKernelGGL(k_parse_count, grid_for(n_rec, 256), dim3(256), 0, s, D.bam_chunk.p, D.bam_off.p, n_rec, D.parse_nblk.p, D.flags.p);
+      HIPCHK((device_scan<OpSum, true>(s, n_rec, FArrN{D.parse_nblk.p}, D.parse_rel.p, D.spine, tot))); }
+    int32_t nblk_total = 0;
+    HIPCHK(hipMemcpyAsync(&nblk_total, tot, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const size_t nb1 = nb0 + (size_t)nblk_total;
+    if (nb1 >= 0xffffffffull) return fail(c, SQ_E_CAPACITY, "more than 2^32 aligned blocks");
+#define GROW(buf, used, want) HIPCHK(D.buf.grow_keep(used, want, s))
+    GROW(refid, n0, n1); GROW(pos, n0, n1); GROW(mrefid, n0, n1); GROW(mpos, n0, n1); GROW(endpos, n0, n1);
+    GROW(flag, n0, n1); GROW(totlen, n0, n1); GROW(mapq, n0, n1); GROW(aux, n0, n1);
+    GROW(blk_off, n0 ? n0 + 1 : 0, n1 + 1);
+    GROW(b_refpos, nb0, nb1 + 1); GROW(b_matchref, nb0, nb1 + 1); GROW(b_readpos, nb0, nb1 + 1); GROW(b_matchread, nb0, nb1 + 1);
+#undef GROW
+    ChimSetView C{D.chim_mask, D.chim_mask ? D.chim_hash.p : nullptr, D.chim_off.p, D.chim_len.p, D.chim_blob.p};
+    ParseParams P{(int)(signed char)(((c->P.phred_type ? 33 : 64) + c->P.min_phred) & 0xff), c->P.max_lowphred_len, c->P.min_mapqual};
+    { EvTimer t(c, "k_parse_write", (double)nbytes + 32.0 * n_rec + 12.0 * nblk_total);
+      hipLaunchKernelGGL(k_parse_write, grid_for(n_rec, 256), dim3(256), 0, s, D.bam_chunk.p, D.bam_off.p, n_rec, C, P, D.parse_rel.p, (uint32_t)nb0, D.refid.p + n0, D.pos.p + n0, D.mrefid.p + n0,
+                         D.mpos.p + n0, D.endpos.p + n0, D.flag.p + n0, D.totlen.p + n0, D.mapq.p + n0, D.aux.p + n0, D.blk_off.p + n0, D.b_refpos.p, D.b_matchref.p, D.b_readpos.p, D.b_matchread.p,
+                         D.flags.p); }
+    const uint32_t endoff = (uint32_t)nb1;
+    HIPCHK(hipMemcpyAsync(D.blk_off.p + n1, &endoff, 4, hipMemcpyHostToDevice, s));
+    int32_t hf = 0;
+    HIPCHK(hipMemcpyAsync(&hf, D.flags.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (hf & 128) return fail(c, SQ_E_IO, "corrupt BAM record");
+    if (hf & 256) return fail(c, SQ_E_ASSERT, "record without stored bases for an aligned block (reference asserts, ReadRec.cpp:64)");
+    D.n = (int64_t)n1;
+    D.nb = (int64_t)nb1;
+    c->counts.n_concordant = D.n;
+    c->counts.n_blocks = D.nb;
+    return SQ_OK;
+}
+
+// debugging / tests: copy the resident SoA back to the host
+int dev_download_records(sq_ctx* c, HostBatch& hb) {
+    DeviceRecords& D = *c->dev;
+    const size_t n = (size_t)D.n, nb = (size_t)D.nb;
+    hb.clear();
+    hb.refid.resize(n); hb.pos.resize(n); hb.mrefid.resize(n); hb.mpos.resize(n); hb.endpos.resize(n); hb.flag.resize(n); hb.totlen.resize(n); hb.mapq.resize(n); hb.aux.resize(n);
+    hb.blk_off.resize(n + 1); hb.b_refpos.resize(nb); hb.b_matchref.resize(nb); hb.b_readpos.resize(nb); hb.b_matchread.resize(nb);
+    if (n) {
+#define DOWN(dst, src, cnt) HIPCHK(hipMemcpy(hb.dst.data(), D.src.p, (cnt) * sizeof(*D.src.p), hipMemcpyDeviceToHost))
+        DOWN(refid, refid, n); DOWN(pos, pos, n); DOWN(mrefid, mrefid, n); DOWN(mpos, mpos, n); DOWN(endpos, endpos, n); DOWN(flag, flag, n); DOWN(totlen, totlen, n); DOWN(mapq, mapq, n);
+        DOWN(aux, aux, n); DOWN(blk_off, blk_off, n + 1);
+        if (nb) { DOWN(b_refpos, b_refpos, nb); DOWN(b_matchref, b_matchref, nb); DOWN(b_readpos, b_readpos, nb); DOWN(b_matchread, b_matchread, nb); }
+#undef DOWN
+    }
     return SQ_OK;
 }
 

@@ -174,3 +174,67 @@ def test_no_discordant_cluster_at_all(built, tmp_path):
         ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
         with pytest.raises(squid_amd.SquidError):
             ctx.build_graph()
+
+
+# ---------------------------------------------------------------------------------------------- K0: GPU record parse
+@pytest.mark.parametrize("cfg", ["C1", "T2"])
+def test_gpu_record_parse_equals_host_decoder(built, synth, cfg, monkeypatch):
+    """k_parse_* (BAM bytes -> SoA on the GPU) writes exactly the arrays the host decoder of sq_bam.cpp produces"""
+    import numpy as np
+
+    pre = synth(cfg)
+
+    def load(host):
+        if host:
+            monkeypatch.setenv("SQUID_HOST_PARSE", "1")
+        else:
+            monkeypatch.delenv("SQUID_HOST_PARSE", raising=False)
+        with squid_amd.Context() as ctx:
+            ctx.load(f"{pre}.bam", f"{pre}.chim.bam", threads=5)
+            return ctx.records()
+
+    gpu, host = load(False), load(True)
+    assert len(gpu["refid"]) > 1000
+    for k in host:
+        assert np.array_equal(gpu[k], host[k]), k
+
+
+def test_gpu_record_parse_hand_made_records(built, tmp_path, monkeypatch):
+    """CIGAR shapes, clips, poly-A blocks, low-quality runs, XA / IH tags through both decoders"""
+    import bamwriter as bw
+    import numpy as np
+
+    seq_polya = "A" * 45 + "C" * 15 + "ACGT" * 10
+    conc = [
+        bw.record("a", 0, 1000, 255, 0x1 | 0x2 | 0x20 | 0x40, "10S20M5I10M3D15M1000N40M", 0, 2100),
+        bw.record("b", 0, 1005, 255, 0x1 | 0x2 | 0x10 | 0x80, "60M500N40M", 0, 900, seq=seq_polya),
+        bw.record("c", 0, 1010, 3, 0x1 | 0x40, "100M", 0, 1300, tags=b"NHC\x03XAZchr1,+5,100M,0;\x00"),
+        bw.record("d", 0, 1020, 255, 0x1 | 0x40, "100M", 0, 1300, tags=b"IHC\x02"),
+        bw.record("e", 0, 1030, 255, 0x1 | 0x40, "100M", 0, 1300, qual=[30] * 20 + [2] * 11 + [30] * 69, tags=b"IHs\x01\x00"),
+        bw.record("q1", 0, 1040, 255, 0x1 | 0x40, "30H70M", 1, 700),          # name is in the chimeric set
+        bw.record("f", 0, 1050, 255, 0x1 | 0x40 | 0x400, "5M2X3=90M", -1, -1),
+        bw.record("u", -1, -1, 0, 0x1 | 0x4 | 0x40, "", -1, -1, seq="", qual=[]),
+    ]
+    chim = [bw.record("q1", 0, 5000, 255, 0x1 | 0x40, "60M40S"), bw.record("q1", 1, 7000, 255, 0x1 | 0x40 | 0x100, "60H40M"),
+            bw.record("q1", 1, 7300, 255, 0x1 | 0x80 | 0x10, "100M")]
+    pre = _tiny_inputs(tmp_path, conc, chim)
+
+    def load(host):
+        if host:
+            monkeypatch.setenv("SQUID_HOST_PARSE", "1")
+        else:
+            monkeypatch.delenv("SQUID_HOST_PARSE", raising=False)
+        with squid_amd.Context() as ctx:
+            ctx.load(f"{pre}.bam", f"{pre}.chim.bam", threads=2)
+            return ctx.records()
+
+    gpu, host = load(False), load(True)
+    for k in host:
+        assert np.array_equal(gpu[k], host[k]), k
+    # hand-derived: record "a" (forward): TotalLen 100; blocks (refpos, matchref, readpos, matchread) = (1000,48,10,50), (2048,40,60,40)
+    o = host["blk_off"]
+    assert list(zip(host["b_refpos"][o[0]:o[1]], host["b_matchref"][o[0]:o[1]], host["b_readpos"][o[0]:o[1]], host["b_matchread"][o[0]:o[1]])) == [(1000, 48, 10, 50), (2048, 40, 60, 40)]
+    assert host["totlen"][0] == 100 and host["end_pos"][0] == 1000 + 48 + 1000 + 40
+    # record "b": the 75 % poly-A block is dropped, the second block is mirrored on the reverse strand: readpos = 100-60-40 = 0
+    assert list(zip(host["b_refpos"][o[1]:o[2]], host["b_readpos"][o[1]:o[2]])) == [(1565, 0)]
+    assert [int(x) for x in host["aux"][:6]] == [0, 0, 1, 1, 4, 2]  # none, none, XA, IH>1, low-Phred run of 11, QNAME in chimeric set
