@@ -66,19 +66,28 @@ static int build_graph(sq_ctx* c) {
         if (rc) return rc;
     }
     c->counts.n_break = n_break;
-    // ReadsOther can be materialised as soon as n_break is known; if it holds a <=3-base block the host repeats the
-    // reference's unstable sort of it (SegmentGraph.cpp:781) on a second thread while the automaton runs
+    // ReadsOther (non-first blocks) is sorted with an unstable std::sort in the reference (SegmentGraph.cpp:781) and a
+    // block of <= 3 bases right behind a node boundary is counted for whichever node the sweep cursor is on, which
+    // depends on that sort's tie order.  Node depths only feed the coverage-ratio test of FilterEdges, so by default
+    // the GPU reports canonical depths plus bounds over all tie orders and FilterEdges checks that no decision can
+    // change inside the bounds; only then (or when SQUID_EXACT_DEPTH is set, as the stage-parity tests do) is the
+    // reference's sort repeated on the host and the sweep walked exactly.
+    const bool exact_mode = std::getenv("SQUID_EXACT_DEPTH") != nullptr;
     struct OtherWork { std::vector<int32_t> chr, pos, len; struct R { int32_t chr, pos, len; }; std::vector<R> sorted; bool has_tiny = false; };
     std::shared_ptr<OtherWork> ow = std::make_shared<OtherWork>();
-    rc = dev_gather_other(c, n_break, ow->has_tiny, ow->chr, ow->pos, ow->len);
-    if (rc) return rc;
     std::future<void> other_sorted;
-    if (ow->has_tiny)
-        other_sorted = std::async(std::launch::async, [ow]() {
-            ow->sorted.resize(ow->chr.size());
-            for (size_t i = 0; i < ow->sorted.size(); ++i) ow->sorted[i] = OtherWork::R{ow->chr[i], ow->pos[i], ow->len[i]};
-            std::sort(ow->sorted.begin(), ow->sorted.end(), [](const OtherWork::R& a, const OtherWork::R& b) { return a.chr != b.chr ? a.chr < b.chr : a.pos < b.pos; });
-        });
+    auto start_exact_sort = [&]() -> int {
+        int r2 = dev_gather_other(c, n_break, ow->has_tiny, ow->chr, ow->pos, ow->len);
+        if (r2) return r2;
+        if (ow->has_tiny)
+            other_sorted = std::async(std::launch::async, [ow]() {
+                ow->sorted.resize(ow->chr.size());
+                for (size_t i = 0; i < ow->sorted.size(); ++i) ow->sorted[i] = OtherWork::R{ow->chr[i], ow->pos[i], ow->len[i]};
+                std::sort(ow->sorted.begin(), ow->sorted.end(), [](const OtherWork::R& a, const OtherWork::R& b) { return a.chr != b.chr ? a.chr < b.chr : a.pos < b.pos; });
+            });
+        return SQ_OK;
+    };
+    if (exact_mode) { rc = start_exact_sort(); if (rc) return rc; }
     {
         HostClock hc(c, "host_segment_replay");
         rc = segment_replay(c, *plan, seeds);
@@ -93,6 +102,7 @@ static int build_graph(sq_ctx* c) {
     // per-node Support / AvgDepth (SegmentGraph.cpp:766-826): discordant blocks on the host, stream blocks from the GPU
     std::vector<Node>& N = c->nodes;
     const int nn = (int)N.size();
+    std::vector<int32_t> dis_cnt(nn), dis_sum(nn);
     {
         HostClock hc(c, "host_depth_discordant");
         size_t it = 0;
@@ -100,56 +110,64 @@ static int build_graph(sq_ctx* c) {
             int cnt = 0, sum = 0;
             for (; it != disc.size() && disc[it].refid == N[i].chr && disc[it].refpos < N[i].pos + N[i].len; ++it)
                 if (disc[it].refpos >= N[i].pos && disc[it].refpos + disc[it].matchref <= N[i].pos + N[i].len) { ++cnt; sum += disc[it].matchref; }
-            N[i].support = cnt;
-            N[i].depth = sum;
+            dis_cnt[i] = cnt; dis_sum[i] = sum;
         }
     }
-    std::vector<int32_t> sup, dummy1, dummy2, dummy3;
+    std::vector<int32_t> sup, amb_plus, amb_minus, unused;
     std::vector<int64_t> sl;
-    bool exact_other = false;
-    rc = dev_node_depth(c, N, n_break, sup, sl, exact_other, dummy1, dummy2, dummy3);
+    bool tiny_boundary = false;
+    rc = dev_node_depth(c, N, n_break, sup, sl, tiny_boundary, amb_plus, amb_minus, unused);
     if (rc) { if (other_sorted.valid()) other_sorted.get(); return rc; }
-    // the host tail of the depth stage overlaps the edge stage; it only writes Node::support / Node::depth
-    std::future<void> depth_done = std::async(std::launch::async, [c, ow, nn, exact_other, &other_sorted, sup, sl]() {
-        std::vector<Node>& N = c->nodes;
+    // combine in the reference's order: discordant, ReadsMain, ReadsOther, then the division (only when ReadsOther is
+    // non-empty, ledger B13).  `other` = per-node (count, sum) of ReadsOther, either canonical or from the exact sweep.
+    auto set_depths = [&](const std::vector<int32_t>& ocnt, const std::vector<int32_t>& osum, bool bounds) {
         const int64_t n_other = sup[2 * nn];
-        std::vector<int32_t> ocnt(nn), osum(nn);
-        for (int i = 0; i < nn; ++i) { ocnt[i] = sup[nn + i]; osum[i] = (int32_t)sl[nn + i]; }
-        if (other_sorted.valid()) other_sorted.get();
-        if (exact_other) {
-            // a <=3-base block right behind a node boundary is counted for whichever node the sweep cursor is on, which
-            // depends on the tie order of that sort: walk the cursor over the identically sorted list
-            std::fill(ocnt.begin(), ocnt.end(), 0);
-            std::fill(osum.begin(), osum.end(), 0);
-            size_t it = 0;
-            for (int i = 0; i < nn; ++i)
-                for (; it != ow->sorted.size(); ++it) {
-                    const OtherWork::R& r = ow->sorted[it];
-                    if (r.chr == N[i].chr && r.pos >= N[i].pos - 3 && r.pos + r.len <= N[i].pos + N[i].len + 3) { ocnt[i]++; osum[i] += r.len; }
-                    else if (r.pos >= N[i].pos + N[i].len || r.chr != N[i].chr) break;
-                }
-        }
+        c->depth_bounds = bounds;
         for (int i = 0; i < nn; ++i) {
-            N[i].support += sup[i];
-            N[i].depth += (int32_t)sl[i];
+            N[i].support = dis_cnt[i] + sup[i];
+            double d = dis_sum[i];
+            d += (int32_t)sl[i];
+            double lo = d, hi = d;
             if (n_other != 0) {
                 N[i].support += ocnt[i];
-                N[i].depth += osum[i];
-                N[i].depth = 1.0 * N[i].depth / N[i].len;  // only when ReadsOther is non-empty (ledger B13)
+                d += osum[i];
+                lo = d; hi = d;
+                if (bounds) { lo = d - amb_minus[i]; hi = d + amb_plus[i]; }
+                d = 1.0 * d / N[i].len; lo = 1.0 * lo / N[i].len; hi = 1.0 * hi / N[i].len;
             }
+            N[i].depth = d; N[i].depth_lo = lo; N[i].depth_hi = hi;
         }
-    });
+    };
+    auto exact_sweep = [&](std::vector<int32_t>& ocnt, std::vector<int32_t>& osum) {
+        if (other_sorted.valid()) other_sorted.get();
+        ocnt.assign(nn, 0); osum.assign(nn, 0);
+        size_t it = 0;
+        for (int i = 0; i < nn; ++i)
+            for (; it != ow->sorted.size(); ++it) {
+                const OtherWork::R& r = ow->sorted[it];
+                if (r.chr == N[i].chr && r.pos >= N[i].pos - 3 && r.pos + r.len <= N[i].pos + N[i].len + 3) { ocnt[i]++; osum[i] += r.len; }
+                else if (r.pos >= N[i].pos + N[i].len || r.chr != N[i].chr) break;
+            }
+    };
+    std::vector<int32_t> ocnt(nn), osum(nn);
+    for (int i = 0; i < nn; ++i) { ocnt[i] = sup[nn + i]; osum[i] = (int32_t)sl[nn + i]; }
+    c->depth_ambiguous = false;
+    if (exact_mode && tiny_boundary) {
+        HostClock hc(c, "host_depth_exact_sweep");
+        exact_sweep(ocnt, osum);
+        set_depths(ocnt, osum, false);
+    } else {
+        if (other_sorted.valid()) other_sorted.get();
+        set_depths(ocnt, osum, tiny_boundary);
+    }
     c->edges.clear();
     std::vector<Edge> raw, conc;
     {
         HostClock hc(c, "host_chimeric_edges");
         rc = chimeric_edges(c, raw);
+        if (rc) return rc;
     }
-    if (!rc) rc = dev_concordant_edges(c, c->nodes, conc);
-    {
-        HostClock hc(c, "host_depth_join_wait");
-        depth_done.get();
-    }
+    rc = dev_concordant_edges(c, c->nodes, conc);
     if (rc) return rc;
     c->snap[1].take(c->nodes, c->edges, nullptr);
     {
@@ -164,7 +182,20 @@ static int build_graph(sq_ctx* c) {
         c->snap[3].take(c->nodes, c->edges, nullptr);
         std::vector<uint8_t> keep;
         filter_by_interleaving(c, keep);
+        std::vector<Edge> before = c->edges;
         filter_edges(c, keep);
+        if (c->depth_ambiguous) {
+            // some coverage-ratio decision depends on the tie order: repeat the reference's sort and sweep, then redo the
+            // filter with the exact depths
+            HostClock hc2(c, "host_depth_exact_retry");
+            rc = start_exact_sort();
+            if (rc) return rc;
+            exact_sweep(ocnt, osum);
+            set_depths(ocnt, osum, false);
+            c->depth_ambiguous = false;
+            c->edges = before;
+            filter_edges(c, keep);
+        }
         c->snap[4].take(c->nodes, c->edges, nullptr);
     }
     {

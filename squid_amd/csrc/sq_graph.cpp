@@ -3,6 +3,8 @@
 // order-dependent sweeps.  Line references are into the reference's src/SegmentGraph.cpp.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <limits>
 
 #include "sq_internal.h"
@@ -349,9 +351,26 @@ void filter_edges(sq_ctx* c, const std::vector<uint8_t>& keep) {
         bool cond1 = (goodends || nearby) && e.gw > MEW;
         bool cond2 = true;
         if (cond1 && (e.b - e.a > c->P.concord_dist_idx || e.ha != 0 || e.hb != 1)) {
-            double c1 = N[e.a].depth, c2 = N[e.b].depth;
-            double ratio = (c1 > c2) ? c1 / c2 : c2 / c1;  // x/0 = inf deletes, 0/0 = NaN keeps (IEEE, as in the reference)
-            if ((e.w <= MEW + 2 && ratio > 3) || (e.w > MEW + 2 && ratio > 50)) cond2 = false;
+            auto ratio_of = [](double c1, double c2) { return (c1 > c2) ? c1 / c2 : c2 / c1; };  // x/0 = inf deletes, 0/0 = NaN keeps (IEEE, as in the reference)
+            auto passes = [&](double ratio) { return !((e.w <= MEW + 2 && ratio > 3) || (e.w > MEW + 2 && ratio > 50)); };
+            cond2 = passes(ratio_of(N[e.a].depth, N[e.b].depth));
+            const Node &na = N[e.a], &nb = N[e.b];
+            if (c->depth_bounds && (na.depth_lo != na.depth_hi || nb.depth_lo != nb.depth_hi)) {
+                // the depths are only known up to the tie order of the reference's ReadsOther sort: the decision must be
+                // the same over the whole box [lo,hi] x [lo,hi], otherwise the exact (sorted) sweep is required
+                // (a depth of exactly 0 makes the ratio inf -- still a well defined decision -- unless BOTH depths can be 0,
+                // where 0/0 = NaN flips the outcome)
+                bool stable = !(na.depth_lo <= 0 && nb.depth_lo <= 0);
+                if (stable) {
+                    double sup = std::max(ratio_of(na.depth_hi, nb.depth_lo), ratio_of(na.depth_lo, nb.depth_hi));
+                    bool overlap = !(na.depth_lo > nb.depth_hi || nb.depth_lo > na.depth_hi);
+                    double inf = overlap ? 1.0 : std::min(ratio_of(na.depth_lo, nb.depth_hi), ratio_of(na.depth_hi, nb.depth_lo));
+                    stable = passes(sup) == passes(inf) && passes(sup) == cond2;
+                }
+                if (!stable && std::getenv("SQUID_DEBUG_DEPTH"))
+                    std::fprintf(stderr, "depth-ambiguous edge (%d,%d) w=%d: a=[%g,%g,%g] b=[%g,%g,%g]\n", e.a, e.b, e.w, na.depth_lo, na.depth, na.depth_hi, nb.depth_lo, nb.depth, nb.depth_hi);
+                if (!stable) c->depth_ambiguous = true;
+            }
         }
         if (keep[i] && cond1 && cond2) kept.push_back(e);
     }

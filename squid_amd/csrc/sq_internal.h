@@ -31,6 +31,9 @@ struct Frag {  // merged chimeric fragment = ReadRec_t after BuildChimericSBamRe
 struct Node {
     int32_t chr, pos, len, support;
     double depth;
+    // bounds of `depth` over every tie order the reference's unstable ReadsOther sort could produce (== depth when the
+    // value is exact); FilterEdges checks that its coverage-ratio decisions do not depend on where inside they fall
+    double depth_lo = 0, depth_hi = 0;
 };
 struct Edge {
     int32_t a, b;  // a <= b
@@ -106,6 +109,8 @@ struct sq_ctx {
     std::vector<int32_t> label;
     sq::GraphSnap snap[6];
     bool graph_built = false, ordered = false;
+    bool depth_bounds = false;      // node depths are canonical values with [depth_lo, depth_hi] bounds
+    bool depth_ambiguous = false;   // a FilterEdges decision depends on the position inside the bounds
     std::vector<int32_t> ord_off, ord_nodes;
     // sv output
     std::vector<int32_t> sv_cols[9];
@@ -188,7 +193,7 @@ int dev_fetch_stream(sq_ctx* c, const std::vector<std::pair<int64_t, int64_t>>& 
 int dev_classify_and_summarise(sq_ctx* c, std::vector<StreamRec>& recs, std::vector<int32_t>& rest_refpos, std::vector<int32_t>& rest_matchref);
 int dev_gather_other(sq_ctx* c, int64_t n_break, bool& has_tiny, std::vector<int32_t>& other_chr, std::vector<int32_t>& other_pos, std::vector<int32_t>& other_len);
 int dev_node_depth(sq_ctx* c, const std::vector<Node>& nodes, int64_t n_break, std::vector<int32_t>& support, std::vector<int64_t>& sumlen,
-                   bool& need_exact_other, std::vector<int32_t>& other_chr, std::vector<int32_t>& other_pos, std::vector<int32_t>& other_len);
+                   bool& need_exact_other, std::vector<int32_t>& amb_plus, std::vector<int32_t>& amb_minus, std::vector<int32_t>& unused);
 int dev_concordant_edges(sq_ctx* c, const std::vector<Node>& nodes, std::vector<Edge>& unique_edges);
 int dev_connected_components(sq_ctx* c, int n_nodes, const std::vector<Edge>& edges, std::vector<int32_t>& label);
 struct SmallProblem { int n; int eoff, ecount; };  // edges: local u,v,hu,hv,w packed as 5 ints each

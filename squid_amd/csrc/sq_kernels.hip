@@ -94,7 +94,7 @@ struct DeviceRecords {
     DBuf<int32_t> rest_refpos, rest_matchref;
     // node table
     DBuf<int32_t> n_chr, n_pos, n_len, n_chr_start;
-    DBuf<int32_t> acc_a, acc_b, acc_c, acc_d;  // per-node accumulators
+    DBuf<int32_t> acc_a, acc_b, acc_c, acc_d, acc_e, acc_f;  // per-node accumulators
     // edge hash
     DBuf<unsigned long long> h_key, okey;
     DBuf<uint32_t> h_val, oval;
@@ -693,7 +693,7 @@ __device__ __forceinline__ void node_add(int32_t* cnt, int32_t* sum, bool valid,
     }
 }
 __global__ void k_depth(RecView R, NodeView N, const uint8_t* keep, const int32_t* rank1, int32_t n_break, const int32_t* cursor,
-                        int32_t* main_cnt, int32_t* main_sum, int32_t* other_cnt, int32_t* other_sum, int32_t* flags) {
+                        int32_t* main_cnt, int32_t* main_sum, int32_t* other_cnt, int32_t* other_sum, int32_t* amb_plus, int32_t* amb_minus, int32_t* flags) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool live = r < R.n && (keep[r] & K_1) && rank1[r] < n_break;
     uint32_t b0 = live ? R.blk_off[r] : 0;
@@ -723,8 +723,14 @@ __global__ void k_depth(RecView R, NodeView N, const uint8_t* keep, const int32_
             int p = R.b_refpos[b0 + k];
             len = R.b_matchref[b0 + k];
             int early = depth_early(N, c, p, len, home);
-            if (early != home) atomicOr(&flags[0], 2);  // tie-order sensitive corner: the host resolves it exactly
             hit = p + len <= N.pos[home] + N.len[home] + 3;
+            if (early != home) {
+                // a <=3-base block right behind a node boundary: the reference counts it for whichever node its sweep cursor
+                // is on, which depends on the tie order of an unstable sort (SegmentGraph.cpp:781).  Record the bounds.
+                atomicOr(&flags[0], 2);
+                for (int q = early; q < home; ++q) atomicAdd(&amb_plus[q], len);
+                if (hit) atomicAdd(&amb_minus[home], len);
+            }
         }
         node_add(other_cnt, other_sum, hit, home, len);
     }
@@ -1265,7 +1271,7 @@ void dev_destroy(sq_ctx* c) {
     D.part_prev.release(); D.part_next.release(); D.b0_a.release(); D.b0_b.release(); D.b0_home.release();
     D.srec.release(); D.rest_refpos.release(); D.rest_matchref.release();
     D.n_chr.release(); D.n_pos.release(); D.n_len.release(); D.n_chr_start.release();
-    D.acc_a.release(); D.acc_b.release(); D.acc_c.release(); D.acc_d.release();
+    D.acc_a.release(); D.acc_b.release(); D.acc_c.release(); D.acc_d.release(); D.acc_e.release(); D.acc_f.release();
     D.h_key.release(); D.h_val.release(); D.flags.release(); D.bam_chunk.release(); D.bam_off.release(); D.chim_hash.release(); D.chim_off.release(); D.chim_len.release(); D.chim_blob.release(); D.parse_nblk.release(); D.parse_rel.release();
     D.calib.release(); D.okey.release(); D.oval.release(); D.other64.release(); D.spine64.release(); D.zflag.release();
     D.cl_chr.release(); D.cl_start.release(); D.cl_right.release(); D.trig.release();
@@ -1562,7 +1568,7 @@ int dev_gather_other(sq_ctx* c, int64_t n_break, bool& has_tiny, std::vector<int
 
 // K3: per-node read support and summed block length of the consumed stream prefix
 int dev_node_depth(sq_ctx* c, const std::vector<Node>& nodes, int64_t n_break, std::vector<int32_t>& support, std::vector<int64_t>& sumlen, bool& need_exact_other,
-                   std::vector<int32_t>& other_chr, std::vector<int32_t>& other_pos, std::vector<int32_t>& other_len) {
+                   std::vector<int32_t>& amb_plus, std::vector<int32_t>& amb_minus, std::vector<int32_t>& other_len) {
     DeviceRecords& D = *c->dev;
     hipStream_t s = c->stream;
     const int64_t n = D.n;
@@ -1570,8 +1576,10 @@ int dev_node_depth(sq_ctx* c, const std::vector<Node>& nodes, int64_t n_break, s
     NodeView nv;
     int rc = upload_nodes(c, nodes, nv);
     if (rc) return rc;
-    HIPCHK(D.acc_a.reserve(nn)); HIPCHK(D.acc_b.reserve(nn)); HIPCHK(D.acc_c.reserve(nn)); HIPCHK(D.acc_d.reserve(nn)); HIPCHK(D.scratch_a.reserve(std::max<int64_t>(n, 1)));
+    HIPCHK(D.acc_a.reserve(nn)); HIPCHK(D.acc_b.reserve(nn)); HIPCHK(D.acc_c.reserve(nn)); HIPCHK(D.acc_d.reserve(nn)); HIPCHK(D.acc_e.reserve(nn)); HIPCHK(D.acc_f.reserve(nn));
+    HIPCHK(D.scratch_a.reserve(std::max<int64_t>(n, 1)));
     HIPCHK(hipMemsetAsync(D.acc_a.p, 0, nn * 4, s)); HIPCHK(hipMemsetAsync(D.acc_b.p, 0, nn * 4, s)); HIPCHK(hipMemsetAsync(D.acc_c.p, 0, nn * 4, s)); HIPCHK(hipMemsetAsync(D.acc_d.p, 0, nn * 4, s));
+    HIPCHK(hipMemsetAsync(D.acc_e.p, 0, nn * 4, s)); HIPCHK(hipMemsetAsync(D.acc_f.p, 0, nn * 4, s));
     HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
     RecView R = D.view();
     const int32_t nbk = (int32_t)std::min<int64_t>(n_break, INT32_MAX);
@@ -1579,12 +1587,14 @@ int dev_node_depth(sq_ctx* c, const std::vector<Node>& nodes, int64_t n_break, s
         { EvTimer t(c, "scan_depth_cursor", 12.0 * n);
           HIPCHK((device_scan<OpMax, false>(s, n, FEarlyMain{R, nv, D.keep.p, D.rank1.p, nbk}, D.scratch_a.p, D.spine, nullptr))); }
         { EvTimer t(c, "k_depth", 13.0 * n + 8.0 * D.nb);
-          hipLaunchKernelGGL(k_depth, grid_for(n, 256), dim3(256), 0, s, R, nv, D.keep.p, D.rank1.p, nbk, D.scratch_a.p, D.acc_a.p, D.acc_b.p, D.acc_c.p, D.acc_d.p, D.flags.p); }
+          hipLaunchKernelGGL(k_depth, grid_for(n, 256), dim3(256), 0, s, R, nv, D.keep.p, D.rank1.p, nbk, D.scratch_a.p, D.acc_a.p, D.acc_b.p, D.acc_c.p, D.acc_d.p, D.acc_e.p, D.acc_f.p, D.flags.p); }
     }
     std::vector<int32_t> mc(nn), ms(nn), oc(nn), os(nn);
+    amb_plus.assign(nn, 0); amb_minus.assign(nn, 0);
     int32_t hf[4];
     HIPCHK(hipMemcpyAsync(mc.data(), D.acc_a.p, nn * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(ms.data(), D.acc_b.p, nn * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(oc.data(), D.acc_c.p, nn * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(os.data(), D.acc_d.p, nn * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(amb_plus.data(), D.acc_e.p, nn * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(amb_minus.data(), D.acc_f.p, nn * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(hf, D.flags.p, 16, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (hf[0] & 1) return fail(c, SQ_E_UNSORTED, "concordant stream is not coordinate sorted (depth cursor left its chromosome)");
@@ -1594,7 +1604,7 @@ int dev_node_depth(sq_ctx* c, const std::vector<Node>& nodes, int64_t n_break, s
     for (int i = 0; i < nn; ++i) { support[i] = mc[i]; sumlen[i] = ms[i]; support[nn + i] = oc[i]; sumlen[nn + i] = os[i]; }
     // sumlen layout: [0,nn) main, [nn,2nn) other; element 2nn = |ReadsOther|
     support.push_back(hf[1]);
-    (void)other_chr; (void)other_pos; (void)other_len;  // gathered ahead of time by dev_gather_other
+    (void)other_len;
     return SQ_OK;
 }
 

@@ -34,7 +34,11 @@ def main():
     ap.add_argument("--configs", default="C1,T2,C2")
     ap.add_argument("--flags", default="")
     ap.add_argument("--gen", default="", help="extra generator arguments, e.g. '--records 10000000'")
+    ap.add_argument("--default-depth", action="store_true", help="do not force the exact depth sweep (node depth columns are then not compared)")
     a = ap.parse_args()
+    import os
+    if not a.default_depth:
+        os.environ["SQUID_EXACT_DEPTH"] = "1"
     B = ROOT / "build"
     ok_all = True
     for cfg in a.configs.split(","):
@@ -49,12 +53,13 @@ def main():
                 t0 = time.time(); ctx.build_graph(); t_graph = time.time() - t0
                 ok = True
                 g1 = ctx.graph(1)
-                ok &= first_diff([n[:5] for n in g1["nodes"]], ou.read_nodes(dump / "nodes_build.txt"), "nodes_build")
+                kk = 3 if a.default_depth else 5
+                ok &= first_diff([n[:kk] for n in g1["nodes"]], [n[:kk] for n in ou.read_nodes(dump / "nodes_build.txt")], "nodes_build")
                 ok &= first_diff(ctx.graph(2)["edges"][:], [e[:5] + (0,) for e in ou.read_edges(dump / "edges_build.txt")], "edges_build")
                 ok &= first_diff(ctx.graph(3)["edges"], ou.read_edges(dump / "edges_weight.txt"), "edges_weight")
                 ok &= first_diff(ctx.graph(4)["edges"], ou.read_edges(dump / "edges_filter.txt"), "edges_filter")
                 g5 = ctx.graph(5)
-                ok &= first_diff([n[:5] for n in g5["nodes"]], ou.read_nodes(dump / "nodes_compress.txt"), "nodes_compress")
+                ok &= first_diff([n[:kk] for n in g5["nodes"]], [n[:kk] for n in ou.read_nodes(dump / "nodes_compress.txt")], "nodes_compress")
                 g0 = ctx.graph(0)
                 ok &= first_diff(g0["nodes"], ou.read_nodes(dump / "nodes_final.txt"), "nodes_final")
                 ok &= first_diff(g0["edges"], ou.read_edges(dump / "edges_final.txt"), "edges_final")
