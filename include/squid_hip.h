@@ -175,6 +175,9 @@ int sq_get_counts(sq_ctx* c, sq_counts* k);
 
 /* tests: copy the HBM-resident record SoA back into a library-owned host batch */
 int sq_debug_download(sq_ctx* c, sq_aln_batch* b);
+/* tests: ExactBPConcordantSupport's counting loop (src/SegmentGraph.cpp:3129-3166) over the resident records for an
+ * arbitrary sorted breakpoint list; host_walk != 0 takes the serial host restatement instead of the K10 kernels */
+int sq_debug_bp_support(sq_ctx* c, int32_t n_bp, const int32_t* chr, const int32_t* pos, int32_t* coverage, int32_t host_walk);
 
 #ifdef __cplusplus
 }

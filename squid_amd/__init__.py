@@ -20,7 +20,7 @@ EXPORTS = [
     "sq_default_params", "sq_create", "sq_destroy", "sq_strerror", "sq_last_error", "sq_set_references",
     "sq_ingest_chimeric", "sq_chim_contains", "sq_ingest_concordant", "sq_ingest_concordant_bam", "sq_read_header", "sq_ingest_chimeric_file",
     "sq_ingest_concordant_file", "sq_build_graph", "sq_graph_view", "sq_order", "sq_call_sv", "sq_breakpoints",
-    "sq_exchange_pack", "sq_exchange_unpack", "sq_get_timing", "sq_reset", "sq_get_counts", "sq_debug_download",
+    "sq_exchange_pack", "sq_exchange_unpack", "sq_get_timing", "sq_reset", "sq_get_counts", "sq_debug_download", "sq_debug_bp_support",
 ]
 
 
@@ -214,6 +214,18 @@ class Context:
                 "end_pos": arr(b.end_pos, n, "i4"), "flag": arr(b.flag, n, "u2"), "mapq": arr(b.mapq, n, "u1"), "aux": arr(b.aux, n, "u1"), "totlen": arr(b.totlen, n, "u2"),
                 "blk_off": arr(b.blk_off, n + 1, "u4"), "b_refpos": arr(b.b_refpos, nb, "i4"), "b_matchref": arr(b.b_matchref, nb, "i4"),
                 "b_readpos": arr(b.b_readpos, nb, "u2"), "b_matchread": arr(b.b_matchread, nb, "u2")}
+
+    def bp_support(self, chrs, poss, host_walk: bool = False):
+        """coverage of an arbitrary sorted breakpoint list by the resident pass-3 records (tests only)"""
+        import numpy as np
+
+        ch = np.ascontiguousarray(chrs, dtype=np.int32)
+        po = np.ascontiguousarray(poss, dtype=np.int32)
+        out = np.zeros(len(ch), np.int32)
+        I32P = C.POINTER(C.c_int32)
+        self.lib.sq_debug_bp_support.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, C.c_int32]
+        self._chk(self.lib.sq_debug_bp_support(self.h, len(ch), ch.ctypes.data_as(I32P), po.ctypes.data_as(I32P), out.ctypes.data_as(I32P), int(host_walk)), "sq_debug_bp_support")
+        return out
 
     def timing(self) -> dict:
         t = SqTiming()

@@ -239,8 +239,8 @@ static int call_sv(sq_ctx* c) {
     for (const Edge& e : E) { edge_bps(e, tmp, exact); for (auto& p : tmp) { BPs.push_back(p.first); BPs.push_back(p.second); } }
     std::sort(BPs.begin(), BPs.end());
     std::vector<int32_t> cov;
-    int rc = dev_breakpoint_support(c, BPs, cov);
-    if (rc == 1) rc = dev_breakpoint_support_exact(c, BPs, cov);
+    static const bool bp_host = getenv("SQUID_BP_HOST") != nullptr;  // debug cross-check of k_bp_walk
+    int rc = bp_host ? dev_breakpoint_support_exact(c, BPs, cov) : dev_breakpoint_support(c, BPs, cov);
     if (rc) return rc;
     // per-edge table in key order (parity tests) -- before the weight sort
     c->bp_off.assign(1, 0); c->bp1.clear(); c->bp2.clear(); c->bsup1.clear(); c->bsup2.clear();
@@ -477,6 +477,19 @@ int sq_debug_download(sq_ctx* c, sq_aln_batch* b) {
     int rc = dev_download_records(c, hb);
     if (rc) return rc;
     hb.view(b, false);
+    return SQ_OK;
+}
+int sq_debug_bp_support(sq_ctx* c, int32_t n_bp, const int32_t* chr, const int32_t* pos, int32_t* coverage, int32_t host_walk) {
+    if (!c || n_bp < 0 || (n_bp && (!chr || !pos || !coverage))) return SQ_E_ARG;
+    if (!c->graph_built) return fail(c, SQ_E_ARG, "sq_debug_bp_support before sq_build_graph");
+    std::vector<std::pair<int, int>> bps(n_bp);
+    for (int i = 0; i < n_bp; ++i) bps[i] = {chr[i], pos[i]};
+    if (!std::is_sorted(bps.begin(), bps.end())) return fail(c, SQ_E_ARG, "breakpoints must be sorted by (chr, pos)");
+    std::vector<int32_t> cov;
+    int rc = host_walk ? dev_breakpoint_support_exact(c, bps, cov) : dev_breakpoint_support(c, bps, cov);
+    dev_flush_timers(c);
+    if (rc) return rc;
+    std::copy(cov.begin(), cov.end(), coverage);
     return SQ_OK;
 }
 int sq_exchange_pack(sq_ctx* c, const void** buf, int64_t* nbytes) {

@@ -111,6 +111,7 @@ struct DeviceRecords {
     DBuf<int32_t> calib;
     DBuf<uint8_t> zflag;
     DBuf<int32_t> cl_chr, cl_start, cl_right, trig;
+    DBuf<int32_t> bp_ev, bp_end, bp_valid;
     DBuf<int32_t> flags;  // small device flag/counter block
     struct Pending { const char* name; double bytes; int slot; };
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -999,60 +1000,102 @@ __global__ void k_hash_compact(const unsigned long long* hk, const uint32_t* hv,
 
 // ------------------------------------------------------------------------------------------------ K10: BP support
 // Sorted breakpoint list (chr,pos); the reference walks it with a cursor that advances by at most one entry per
-// kept record (SegmentGraph.cpp:3157-3158).  m(r) = number of breakpoints the record is "beyond"; the cursor
-// after r is  cur(r) = cur(r-1) + [cur(r-1) < m(r)].  With M = prefix-max(m) this is the min-plus scan
-// cur(r) = min(M(r), cur(r-1)+1) whenever the cursor never sits above m(r) while below M(r); the kernels compute
-// that closed form and k_bp_count verifies the recurrence record by record (flag on mismatch -> exact host walk).
+// pass-3 record (SegmentGraph.cpp:3157-3158).  m(r) = number of breakpoints record r is "beyond"; the cursor after r
+// is cur(r) = cur(r-1) + [cur(r-1) < m(r)], so cur <= M = prefix-max(m), and once cur == M it stays equal to M until
+// the next record where M grows (an "event").  k_bp_count assumes cur == M everywhere; every event gets a wave
+// (k_bp_walk) that replays the true recurrence from the event until the cursor has caught up and corrects the
+// records it passed.  An event whose start lies inside the walk of an earlier valid one is absorbed by it
+// (k_bp_chain decides that in stream order; events are indexed by their M value, which grows with the stream).
 struct BPView { int32_t n; const int32_t *chr, *pos; int dp; };
 __device__ __forceinline__ int bp_lower_bound(const BPView& B, int c, int p) {  // first j with (chr,pos) >= (c,p)
     int lo = 0, hi = B.n;
     while (lo < hi) { int mid = (lo + hi) >> 1; if (B.chr[mid] < c || (B.chr[mid] == c && B.pos[mid] < p)) lo = mid + 1; else hi = mid; }
     return lo;
 }
-struct FBeyond {  // m(r) for pass-3 records, INT_MIN otherwise (identity of max)
-    RecView R; BPView B; const uint8_t* cls;
-    __device__ int operator()(int64_t r) const {
-        if (!(cls[r] & C_P3)) return INT_MIN;
-        int c = R.refid[r];
-        int st = R.pos[r];
-        if (!(R.flag[r] & 0x8) && R.mrefid[r] == c) st = R.mpos[r];
+__device__ __forceinline__ int bp_start(const RecView& R, int64_t r) {  // SegmentGraph.cpp:3147-3150
+    int c = R.refid[r], st = R.pos[r];
+    if (!(R.flag[r] & 0x8) && R.mrefid[r] == c) st = R.mpos[r];
+    return st;
+}
+__global__ void k_bp_m(RecView R, BPView B, const uint8_t* cls, int32_t* m) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R.n) return;
+    int v = INT_MIN;  // identity of max for records outside pass 3
+    if (cls[r] & C_P3) {
+        int c = R.refid[r], st = bp_start(R, r);
         // #j with c > chr_j || (c == chr_j && st > pos_j + dp)  ==  lower_bound over (chr, pos+dp) of (c, st)
         int lo = 0, hi = B.n;
         while (lo < hi) { int mid = (lo + hi) >> 1; if (B.chr[mid] < c || (B.chr[mid] == c && B.pos[mid] + B.dp < st)) lo = mid + 1; else hi = mid; }
-        return lo;
+        v = lo;
     }
-};
-struct FMinPlus {  // M(r) - rank3(r) for pass-3 records (rank3 = index among pass-3 records), INT_MAX otherwise
-    const uint8_t* cls; const int32_t *M, *rank3;
-    __device__ int operator()(int64_t r) const { return (cls[r] & C_P3) ? M[r] - rank3[r] : INT_MAX; }
-};
-struct FP3 { const uint8_t* cls; __device__ int operator()(int64_t i) const { return (cls[i] & C_P3) ? 1 : 0; } };
-__global__ void k_bp_count(RecView R, BPView B, const uint8_t* cls, const int32_t* M, const int32_t* rank3, const int32_t* minplus, const int32_t* prev3, int32_t* diff,
-                           int32_t* flags) {
+    m[r] = v;
+}
+// +-1 into the difference array for breakpoints [max(first covered, cursor), first not covered)
+__device__ __forceinline__ void bp_contribute(const RecView& R, const BPView& B, int64_t r, int before, int cur, int sign, int32_t* diff) {
+    if (before >= B.n) return;  // the reference has left its loop (SegmentGraph.cpp:3144-3145)
+    int c = R.refid[r];
+    int lo = bp_lower_bound(B, c, bp_start(R, r)), hi = bp_lower_bound(B, c, R.endpos[r]);
+    if (lo < cur) lo = cur;
+    if (lo < hi) { atomicAdd(&diff[lo], sign); atomicAdd(&diff[hi], -sign); }
+}
+__global__ void k_bp_count(RecView R, BPView B, const uint8_t* cls, const int32_t* m, const int32_t* Mx, int32_t* ev_by_M, int32_t* diff) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R.n || !(cls[r] & C_P3)) return;
-    // cursor after this record and after the previous pass-3 record
-    auto cur_at = [&](int64_t q) -> int {
-        int v = minplus[q];  // min over s<=q of M(s) - rank3(s)
-        int byscan = v == INT_MAX ? INT_MAX : v + rank3[q];
-        int bycount = rank3[q] + 1;  // cannot advance more than once per record
-        return byscan < bycount ? byscan : bycount;
-    };
-    int cur = cur_at(r);
-    int64_t q = prev3[r];
-    int before = q >= 0 ? cur_at(q) : 0;
-    FBeyond fb{R, B, cls};
-    int m = fb(r);
-    int expect = before + (before < m ? 1 : 0);
-    if (before >= B.n) return;  // the reference has left its loop (SegmentGraph.cpp:3144-3145)
-    if (expect != cur) { atomicOr(&flags[0], 32); return; }
-    int c = R.refid[r];
-    int st = R.pos[r];
-    if (!(R.flag[r] & 0x8) && R.mrefid[r] == c) st = R.mpos[r];
-    int en = R.endpos[r];
-    int lo = bp_lower_bound(B, c, st), hi = bp_lower_bound(B, c, en);
-    if (lo < cur) lo = cur;
-    if (lo < hi) { atomicAdd(&diff[lo], 1); atomicAdd(&diff[hi], -1); }
+    int before = Mx[r] > 0 ? Mx[r] : 0, M = m[r] > before ? m[r] : before;
+    if (M > before) ev_by_M[M] = (int32_t)r;  // M values of events are distinct and increase along the stream
+    bp_contribute(R, B, r, before, M, 1, diff);
+}
+// one wave per event: APPLY == false records where the cursor catches up, APPLY == true corrects the passed records
+template <bool APPLY>
+__global__ __launch_bounds__(64) void k_bp_walk(RecView R, BPView B, const uint8_t* cls, const int32_t* m, const int32_t* Mx, const int32_t* ev_by_M, int32_t* end_by_M,
+                                               const int32_t* valid, int32_t* diff) {
+    const int v = blockIdx.x + 1, lane = threadIdx.x;
+    const int64_t r0 = ev_by_M[v];
+    if (r0 < 0) return;
+    if (APPLY && !valid[v]) return;
+    int cur = Mx[r0] > 0 ? Mx[r0] : 0;
+    int64_t end = R.n;
+    for (int64_t base = r0; base < R.n; base += 64) {
+        const int64_t r = base + lane;
+        const bool ok = r < R.n && (cls[r] & C_P3);
+        int mm = INT_MIN, MM = 0, before_a = 0;
+        if (ok) { mm = m[r]; before_a = Mx[r] > 0 ? Mx[r] : 0; MM = mm > before_a ? mm : before_a; }
+        int mycur = -1, mybefore = 0, done = -1;
+        unsigned long long todo = __ballot(ok);
+        while (todo) {
+            const int k = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int mk = __builtin_amdgcn_readlane(mm, k), Mk = __builtin_amdgcn_readlane(MM, k);
+            const int b4 = cur;
+            cur += cur < mk ? 1 : 0;
+            if (lane == k) { mycur = cur; mybefore = b4; }
+            if (cur == Mk) { done = k; break; }
+        }
+        if (APPLY && mycur >= 0 && (mycur != MM || mybefore != before_a)) {
+            bp_contribute(R, B, r, before_a, MM, -1, diff);
+            bp_contribute(R, B, r, mybefore, mycur, 1, diff);
+        }
+        if (done >= 0) { end = base + done; break; }
+    }
+    if (!APPLY && lane == 0) end_by_M[v] = (int32_t)(end < R.n ? end : R.n);
+}
+__global__ __launch_bounds__(64) void k_bp_chain(int nb, const int32_t* ev_by_M, const int32_t* end_by_M, int32_t* valid) {
+    const int lane = threadIdx.x;
+    int reach = -1;  // last record covered by a valid walk
+    for (int base = 1; base <= nb; base += 64) {
+        const int v = base + lane;
+        const int ev = v <= nb ? ev_by_M[v] : -1;
+        const int en = ev >= 0 ? end_by_M[v] : -1;
+        int ok = 0;
+        unsigned long long todo = __ballot(ev >= 0);
+        while (todo) {
+            const int k = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int e = __builtin_amdgcn_readlane(ev, k);
+            if (e > reach) { reach = __builtin_amdgcn_readlane(en, k); if (lane == k) ok = 1; }
+        }
+        if (v <= nb) valid[v] = ok;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ K8: components
@@ -1726,32 +1769,33 @@ int dev_breakpoint_support(sq_ctx* c, const std::vector<std::pair<int, int>>& bp
     std::vector<int32_t> bc(nb), bp(nb);
     for (int i = 0; i < nb; ++i) { bc[i] = bps[i].first; bp[i] = bps[i].second; }
     HIPCHK(D.acc_a.reserve(nb)); HIPCHK(D.acc_b.reserve(nb)); HIPCHK(D.acc_c.reserve(nb + 1));
-    HIPCHK(D.scratch_a.reserve(n)); HIPCHK(D.scratch_b.reserve(n)); HIPCHK(D.scratch_c.reserve(n)); HIPCHK(D.part_prev.reserve(n));
+    HIPCHK(D.scratch_a.reserve(n)); HIPCHK(D.scratch_b.reserve(n));
     HIPCHK(hipMemcpyAsync(D.acc_a.p, bc.data(), nb * 4, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(D.acc_b.p, bp.data(), nb * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(D.acc_c.p, 0, (nb + 1) * 4, s));
     HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
     RecView R = D.view();
     BPView B{nb, D.acc_a.p, D.acc_b.p, c->P.concord_dist_pos};
-    { EvTimer t(c, "scan_bp_cursor", 36.0 * n);
-      HIPCHK((device_scan<OpMax, false>(s, n, FBeyond{R, B, D.cls.p}, D.scratch_a.p, D.spine, nullptr)));         // M = prefix max of m
-      HIPCHK((device_scan<OpSum, true>(s, n, FP3{D.cls.p}, D.scratch_b.p, D.spine, nullptr)));                    // rank among pass-3 records
-      HIPCHK((device_scan<OpMin, false>(s, n, FMinPlus{D.cls.p, D.scratch_a.p, D.scratch_b.p}, D.scratch_c.p, D.spine, nullptr)));
-      HIPCHK((device_scan<OpMax, true>(s, n, FPrev{D.cls.p, C_P3}, D.part_prev.p, D.spine, nullptr))); }
-    { EvTimer t(c, "k_bp_count", 24.0 * n);
-      hipLaunchKernelGGL(k_bp_count, grid_for(n, 256), dim3(256), 0, s, R, B, D.cls.p, D.scratch_a.p, D.scratch_b.p, D.scratch_c.p, D.part_prev.p, D.acc_c.p, D.flags.p); }
+    HIPCHK(D.bp_ev.reserve(nb + 1)); HIPCHK(D.bp_end.reserve(nb + 1)); HIPCHK(D.bp_valid.reserve(nb + 1));
+    HIPCHK(hipMemsetAsync(D.bp_ev.p, 0xFF, (nb + 1) * 4, s));
+    int32_t *m = D.scratch_b.p, *Mx = D.scratch_a.p;
+    { EvTimer t(c, "k_bp_m", 27.0 * n); hipLaunchKernelGGL(k_bp_m, grid_for(n, 256), dim3(256), 0, s, R, B, D.cls.p, m); }
+    { EvTimer t(c, "scan_bp_cursor", 12.0 * n); HIPCHK((device_scan<OpMax, true>(s, n, FArr{m}, Mx, D.spine, nullptr))); }  // max of m over earlier records
+    { EvTimer t(c, "k_bp_count", 31.0 * n); hipLaunchKernelGGL(k_bp_count, grid_for(n, 256), dim3(256), 0, s, R, B, D.cls.p, m, Mx, D.bp_ev.p, D.acc_c.p); }
+    { EvTimer t(c, "k_bp_walk", 0);
+      hipLaunchKernelGGL(k_bp_walk<false>, dim3(nb), dim3(64), 0, s, R, B, D.cls.p, m, Mx, D.bp_ev.p, D.bp_end.p, D.bp_valid.p, D.acc_c.p);
+      hipLaunchKernelGGL(k_bp_chain, dim3(1), dim3(64), 0, s, nb, D.bp_ev.p, D.bp_end.p, D.bp_valid.p);
+      hipLaunchKernelGGL(k_bp_walk<true>, dim3(nb), dim3(64), 0, s, R, B, D.cls.p, m, Mx, D.bp_ev.p, D.bp_end.p, D.bp_valid.p, D.acc_c.p); }
     std::vector<int32_t> diff(nb + 1);
-    int32_t hf = 0;
     HIPCHK(hipMemcpyAsync(diff.data(), D.acc_c.p, (nb + 1) * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(&hf, D.flags.p, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (hf & 32) return 1;  // caller switches to the exact cursor walk
     int run = 0;
     for (int i = 0; i < nb; ++i) { run += diff[i]; coverage[i] = run; }
     return SQ_OK;
 }
 
-// exact but serial cursor walk for the (rare) inputs where the closed form does not hold: the pass-3 records'
-// (chr, start, end) are pulled to the host in stream order.
+// serial restatement of the cursor walk on the host (SQUID_BP_HOST=1): the pass-3 records' (chr, start, end) are
+// pulled back in stream order.  Debug cross-check of k_bp_walk only; never taken by default.
+struct FP3 { const uint8_t* cls; __device__ int operator()(int64_t i) const { return (cls[i] & C_P3) ? 1 : 0; } };
 __global__ void k_p3_gather(RecView R, const uint8_t* cls, const int32_t* rank3, int32_t* o_chr, int32_t* o_st, int32_t* o_en) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R.n || !(cls[r] & C_P3)) return;

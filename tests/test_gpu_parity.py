@@ -261,3 +261,64 @@ def test_gpu_record_parse_hand_made_records(built, tmp_path, monkeypatch):
     # record "b": the 75 % poly-A block is dropped, the second block is mirrored on the reverse strand: readpos = 100-60-40 = 0
     assert list(zip(host["b_refpos"][o[1]:o[2]], host["b_readpos"][o[1]:o[2]])) == [(1565, 0)]
     assert [int(x) for x in host["aux"][:6]] == [0, 0, 1, 1, 4, 2]  # none, none, XA, IH>1, low-Phred run of 11, QNAME in chimeric set
+
+
+# ---- K10: the breakpoint cursor of ExactBPConcordantSupport (src/SegmentGraph.cpp:3129-3166) on dense breakpoint lists
+def _bp_support_literal(rec, bps, min_mapq, dp):
+    """the reference's loop, statement by statement, over downloaded records (pass-3 filter :3131-3142)"""
+    cov = [0] * len(bps)
+    ind = 0
+    n = len(rec["refid"])
+    refid, pos, mref, mpos, end, flag, mapq, aux = (rec[k].tolist() for k in ("refid", "pos", "mate_refid", "mate_pos", "end_pos", "flag", "mapq", "aux"))
+    for i in range(n):
+        if ind == len(bps):
+            break
+        f = flag[i]
+        if aux[i] & 3 or f & 0x400 or f & 0x4 or mapq[i] < min_mapq or refid[i] == -1:
+            continue
+        matemapped = not (f & 0x8)
+        if matemapped and mref[i] == refid[i] and (mpos[i] > pos[i] or (mpos[i] == pos[i] and f & 0x80)):
+            continue
+        st = mpos[i] if matemapped and mref[i] == refid[i] else pos[i]
+        c, e = refid[i], end[i]
+        if c > bps[ind][0] or (c == bps[ind][0] and st > bps[ind][1] + dp):
+            ind += 1
+        for j in range(ind, len(bps)):
+            if c == bps[j][0] and st <= bps[j][1] and e > bps[j][1]:
+                cov[j] += 1
+            elif c < bps[j][0] or (c == bps[j][0] and e <= bps[j][1]):
+                break
+    return cov
+
+
+@pytest.mark.parametrize("cfg", ["C1", "T2"])
+def test_breakpoint_cursor_on_dense_breakpoint_lists(built, synth, cfg):
+    import random
+
+    pre = synth(cfg)
+    with squid_amd.Context() as ctx:
+        ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
+        ctx.build_graph()
+        rec = ctx.records()
+        rng = random.Random(7)
+        n = len(rec["pos"])
+        dp = 50000
+        for trial in range(4):
+            bps = []
+            for _ in range(60):
+                i = rng.randrange(n)
+                c, p = int(rec["refid"][i]), int(rec["pos"][i])
+                if c < 0:
+                    continue
+                # clusters of close breakpoints, some repeated, some placed so that the cursor test (pos + dp) falls amid records
+                base = p - (dp if trial % 2 else 0) + rng.randrange(-200, 200)
+                for k in range(rng.randrange(1, 8)):
+                    bps.append((c, max(0, base + rng.randrange(0, 120))))
+                if rng.random() < 0.3:
+                    bps.append(bps[-1])
+            bps.sort()
+            want = _bp_support_literal(rec, bps, 255, dp)
+            got = ctx.bp_support([b[0] for b in bps], [b[1] for b in bps]).tolist()
+            assert got == want, f"trial {trial}"
+            host = ctx.bp_support([b[0] for b in bps], [b[1] for b in bps], host_walk=True).tolist()
+            assert host == want
