@@ -151,7 +151,7 @@ def main() -> None:
                      "all_scan_kernels": {"ms_per_step": gpu_ms, "algorithmic_bytes_per_step": scan_bytes,
                                           "achieved_GBs": scan_bytes / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else None}},
         "e2e_value": total_aln / world / (t_ingest + elapsed / a.steps), "e2e_note": "one sample incl. BAM decode on host cores + H2D (rank 0)",
-        "stage_ms_per_step": {k: round(v["ms"] / a.steps, 4) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:12]},
+        "stage_ms_per_step": {k: round(v["ms"] / a.steps, 4) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:(None if os.environ.get("BENCH_ALL_STAGES") else 12)]},
     }
     ctx.close()
     if not a.no_cpu_baseline and world == 1:

@@ -31,7 +31,8 @@ enum {
     SQ_E_UNSORTED = -5,  /* concordant input is not coordinate sorted (README.md:23 requires it) */
     SQ_E_ASSERT = -6,    /* the reference would hit one of its live assert()s on this input */
     SQ_E_CAPACITY = -7,  /* an internal table overflowed */
-    SQ_E_EMPTYCHIM = -8  /* chimeric input has no usable record (reference: out-of-bounds read, ReadRec.cpp:379) */
+    SQ_E_EMPTYCHIM = -8, /* chimeric input has no usable record (reference: out-of-bounds read, ReadRec.cpp:379) */
+    SQ_NEED_EXCHANGE = 1 /* not an error: a chromosome-sharded run needs an all-gather before it can continue (see below) */
 };
 
 /* The tuning globals of src/Config.h:23-49 (defaults = src/Config.cpp:11-37), plus device selection. */
@@ -47,7 +48,7 @@ typedef struct sq_params {
     int32_t min_edge_weight;   /* Min_Edge_Weight (5) */
     double discordant_ratio;   /* DiscordantRatio (8) */
     int32_t max_allowed_degree; /* MaxAllowedDegree (5) */
-    int32_t rank, world_size;  /* chromosome sharding (sq_exchange_*); 0,1 for a single GPU */
+    int32_t rank, world_size;  /* chromosome sharding (sq_set_shard, sq_exchange_*); 0,1 for a single GPU */
 } sq_params;
 
 void sq_default_params(sq_params* p);
@@ -150,8 +151,18 @@ typedef struct sq_bp_table {
 } sq_bp_table;
 int sq_breakpoints(sq_ctx* c, sq_bp_table* t);
 
-/* Multi-GPU: chromosome-sharded ranks exchange {node table, locally reduced edges}
- * once.  The library packs/unpacks; the caller moves the bytes (RCCL all-gather via torch.distributed). */
+/* Multi-GPU: one context per rank (sq_params.rank / world_size); rank r holds the concordant
+ * records of the RefIDs [first_ref, end_ref) -- contiguous ranges in rank order that cover all references -- and
+ * every rank ingests the whole chimeric BAM (small).  Call sq_set_shard after sq_set_references and before the
+ * concordant ingest; the ingest functions then keep only the records this rank owns.
+ * sq_build_graph and sq_call_sv return SQ_NEED_EXCHANGE whenever they need data from the other shards: the caller
+ * gets this rank's bytes with sq_exchange_pack, all-gathers them (variable length: RCCL / gloo through
+ * torch.distributed, MPI, or a loop over in-process contexts), hands the concatenation back with
+ * sq_exchange_unpack and calls the same function again, until it returns SQ_OK or an error.  All ranks end with
+ * identical graphs, orders and SV tables.  The exchanges of sq_build_graph: three of a few bytes (stream boundaries
+ * and seed nodes) and the data exchange proper -- per-node depth sums of the own chromosomes plus the locally reduced
+ * concordant edges, which closes the inter-chromosomal edges; sq_call_sv: the per-breakpoint coverage counts. */
+int sq_set_shard(sq_ctx* c, int32_t first_ref, int32_t end_ref);
 int sq_exchange_pack(sq_ctx* c, const void** buf, int64_t* nbytes);
 int sq_exchange_unpack(sq_ctx* c, const void* gathered, const int64_t* nbytes_per_rank, int32_t world_size);
 

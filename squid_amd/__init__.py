@@ -20,7 +20,7 @@ EXPORTS = [
     "sq_default_params", "sq_create", "sq_destroy", "sq_strerror", "sq_last_error", "sq_set_references",
     "sq_ingest_chimeric", "sq_chim_contains", "sq_ingest_concordant", "sq_ingest_concordant_bam", "sq_read_header", "sq_ingest_chimeric_file",
     "sq_ingest_concordant_file", "sq_build_graph", "sq_graph_view", "sq_order", "sq_call_sv", "sq_breakpoints",
-    "sq_exchange_pack", "sq_exchange_unpack", "sq_get_timing", "sq_reset", "sq_get_counts", "sq_debug_download", "sq_debug_bp_support",
+    "sq_set_shard", "sq_exchange_pack", "sq_exchange_unpack", "sq_get_timing", "sq_reset", "sq_get_counts", "sq_debug_download", "sq_debug_bp_support",
 ]
 
 
@@ -110,6 +110,9 @@ def load_library() -> C.CDLL:
         lib.sq_get_counts.argtypes = [C.c_void_p, C.POINTER(SqCounts)]
         lib.sq_reset.argtypes = [C.c_void_p]
         lib.sq_chim_contains.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        lib.sq_set_shard.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        lib.sq_exchange_pack.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        lib.sq_exchange_unpack.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.c_int32]
         _lib = lib
     return _lib
 
@@ -128,7 +131,10 @@ def read_header(bam_path: str):
 class Context:
     """One GPU context (sq_ctx).  Mirrors the reference's fixed pipeline (src/main.cpp:17-76)."""
 
-    def __init__(self, device: int = 0, star_mapq: bool = True, **params):
+    def __init__(self, device: int = 0, star_mapq: bool = True, exchange=None, **params):
+        """`exchange`: for a chromosome-sharded context (rank=, world_size=) a callable bytes -> list[bytes] that
+        all-gathers one payload per rank (squid_amd.dist.TorchExchange, or a squid_amd.dist.VirtualWorld drives it)."""
+        self.exchange = exchange
         self.lib = load_library()
         p = SqParams()
         self.lib.sq_default_params(C.byref(p))
@@ -159,19 +165,51 @@ class Context:
     def __exit__(self, *a):
         self.close()
 
-    def load(self, bam: str, chim_bam: str, threads: int = 8):
+    def load(self, bam: str, chim_bam: str, threads: int = 8, shard: tuple | None = None):
+        """`shard` = (first_ref, end_ref): keep only the concordant records of those RefIDs (sq_set_shard)"""
         names, lens = read_header(bam)
         self.ref_names = names
         arr = (C.c_int32 * len(lens))(*lens)
         self._chk(self.lib.sq_set_references(self.h, len(lens), arr), "sq_set_references")
+        if shard is not None:
+            self._chk(self.lib.sq_set_shard(self.h, int(shard[0]), int(shard[1])), "sq_set_shard")
         self._chk(self.lib.sq_ingest_chimeric_file(self.h, str(chim_bam).encode()), "sq_ingest_chimeric_file")
         self._chk(self.lib.sq_ingest_concordant_file(self.h, str(bam).encode(), threads), "sq_ingest_concordant_file")
 
     def reset(self):
         self._chk(self.lib.sq_reset(self.h), "sq_reset")
 
+    # ---- chromosome-sharded runs: the stage functions pause with SQ_NEED_EXCHANGE (include/squid_hip.h)
+    NEED_EXCHANGE = 1
+
+    def exchange_pack(self) -> bytes:
+        buf, n = C.c_void_p(), C.c_int64()
+        self._chk(self.lib.sq_exchange_pack(self.h, C.byref(buf), C.byref(n)), "sq_exchange_pack")
+        return C.string_at(buf, n.value)
+
+    def exchange_unpack(self, parts: list):
+        sizes = (C.c_int64 * len(parts))(*[len(x) for x in parts])
+        self._chk(self.lib.sq_exchange_unpack(self.h, b"".join(parts), sizes, len(parts)), "sq_exchange_unpack")
+
+    def _run_stage(self, step, what: str):
+        while True:
+            rc = step()
+            if rc != self.NEED_EXCHANGE:
+                self._chk(rc, what)
+                return
+            if self.exchange is None:
+                raise SquidError(f"{what}: sharded context without an exchange callable")
+            self.exchange_unpack(self.exchange(self.exchange_pack()))
+
+    def build_graph_step(self) -> int:
+        """one call of sq_build_graph: 0 = done, NEED_EXCHANGE = all-gather exchange_pack() into exchange_unpack()"""
+        rc = self.lib.sq_build_graph(self.h)
+        if rc < 0:
+            self._chk(rc, "sq_build_graph")
+        return rc
+
     def build_graph(self):
-        self._chk(self.lib.sq_build_graph(self.h), "sq_build_graph")
+        self._run_stage(lambda: self.lib.sq_build_graph(self.h), "sq_build_graph")
 
     def graph(self, stage: int = 0) -> dict:
         g = SqGraph()
@@ -187,9 +225,21 @@ class Context:
         self._chk(self.lib.sq_order(self.h, C.byref(o)), "sq_order")
         return [[o.nodes[j] for j in range(o.comp_off[k], o.comp_off[k + 1])] for k in range(o.n_components)]
 
+    def call_sv_step(self) -> int:
+        self._sv = SqSvTable()
+        rc = self.lib.sq_call_sv(self.h, C.byref(self._sv))
+        if rc < 0:
+            self._chk(rc, "sq_call_sv")
+        return rc
+
+    def sv_rows(self) -> list[tuple]:
+        t = self._sv
+        return [(t.chr1[i], t.start1[i], t.end1[i], t.chr2[i], t.start2[i], t.end2[i], t.score[i], t.strand1_minus[i], t.strand2_minus[i], t.sup1[i], t.sup2[i])
+                for i in range(t.n_rows)]
+
     def call_sv(self) -> list[tuple]:
         t = SqSvTable()
-        self._chk(self.lib.sq_call_sv(self.h, C.byref(t)), "sq_call_sv")
+        self._run_stage(lambda: self.lib.sq_call_sv(self.h, C.byref(t)), "sq_call_sv")
         return [(t.chr1[i], t.start1[i], t.end1[i], t.chr2[i], t.start2[i], t.end2[i], t.score[i], t.strand1_minus[i], t.strand2_minus[i], t.sup1[i], t.sup2[i])
                 for i in range(t.n_rows)]
 

@@ -47,64 +47,267 @@ struct HostClock {
     ~HostClock() { c->timer.add(name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
 };
 
-static int build_graph(sq_ctx* c) {
-    c->timer.clear();
-    HostClock wall(c, "wall_build_graph");
-    c->graph_built = false;
-    c->ordered = false;
-    std::vector<StreamRec> recs;
-    std::vector<int32_t> rest_p, rest_m;
-    int rc = dev_classify_and_summarise(c, recs, rest_p, rest_m);
-    if (rc) return rc;
-    std::vector<Node> seeds;
+// ---- exchange payloads (chromosome-sharded runs): plain little-endian PODs appended to a byte vector
+struct Packer {
+    std::vector<uint8_t>& b;
+    explicit Packer(std::vector<uint8_t>& buf) : b(buf) { b.clear(); }
+    template <class T> void put(const T& v) { const uint8_t* p = (const uint8_t*)&v; b.insert(b.end(), p, p + sizeof(T)); }
+    template <class T> void put_vec(const std::vector<T>& v) { put<int64_t>((int64_t)v.size()); const uint8_t* p = (const uint8_t*)v.data(); b.insert(b.end(), p, p + v.size() * sizeof(T)); }
+};
+struct Unpacker {
+    const std::vector<uint8_t>& b; size_t at = 0; bool ok = true;
+    explicit Unpacker(const std::vector<uint8_t>& buf) : b(buf) {}
+    template <class T> T get() { T v{}; if (at + sizeof(T) > b.size()) { ok = false; return v; } std::memcpy(&v, b.data() + at, sizeof(T)); at += sizeof(T); return v; }
+    template <class T> void get_vec(std::vector<T>& v) {
+        int64_t n = get<int64_t>();
+        if (!ok || n < 0 || at + (size_t)n * sizeof(T) > b.size()) { ok = false; v.clear(); return; }
+        v.resize((size_t)n);
+        if (n) std::memcpy(v.data(), b.data() + at, (size_t)n * sizeof(T));
+        at += (size_t)n * sizeof(T);
+    }
+};
+enum : int32_t { X_DEDUP = 0x51a0, X_STREAM, X_SEEDS, X_GRAPH, X_BPSUP };  // payload tags (a mismatch means the ranks are out of step)
+
+// locals of build_graph that have to survive an exchange
+struct GraphBuild {
+    int stage = 0;
+    std::shared_ptr<SegPlan> plan;
     std::vector<Blk> disc;
     int64_t n_break = 0;
-    std::shared_ptr<SegPlan> plan;
-    {
-        HostClock hc(c, "host_segment_prepare");
-        rc = segment_prepare(c, plan, n_break, disc);
+    int64_t trigger_last = 0;
+    std::vector<Node> seeds;
+    std::vector<Edge> raw, conc;
+    std::vector<int32_t> sup, amb_plus, amb_minus;
+    std::vector<int64_t> sl;
+    bool tiny_boundary = false;
+};
+
+static int need_exchange(sq_ctx* c) {
+    c->x_pending = true; c->x_ready = false;
+    return SQ_NEED_EXCHANGE;
+}
+// the gathered payloads of the exchange that has just completed, or an error when the caller skipped it
+static int take_exchange(sq_ctx* c, int32_t tag) {
+    if (!c->x_ready || (int)c->xgot.size() != c->P.world_size) return fail(c, SQ_E_ARG, "sharded run: sq_exchange_unpack has not been called for the pending exchange");
+    c->x_ready = false;
+    for (const auto& v : c->xgot) { int32_t t = 0; if (v.size() < 4) return fail(c, SQ_E_ARG, "sharded run: short exchange payload"); std::memcpy(&t, v.data(), 4); if (t != tag) return fail(c, SQ_E_ARG, "sharded run: ranks are out of step (payload tag mismatch)"); }
+    return SQ_OK;
+}
+
+static int build_graph(sq_ctx* c) {
+    HostClock wall(c, "wall_build_graph");
+    Shard& sh = c->shard;
+    const int W = c->P.world_size, me = c->P.rank;
+    if (!c->gb) c->gb = std::make_shared<GraphBuild>();
+    GraphBuild& g = *c->gb;
+    int rc;
+    if (g.stage == 0) {
+        c->graph_built = false;
+        c->ordered = false;
+        int32_t last[4];
+        rc = dev_classify(c, sh.on ? last : nullptr);
         if (rc) return rc;
+        g.stage = 1;
+        if (sh.on) {  // exchange 1: what the last passing records of every shard look like to ReadRec_t::Equal
+            Packer pk(c->xbuf);
+            pk.put<int32_t>(X_DEDUP);
+            for (int i = 0; i < 4; ++i) pk.put<int32_t>(last[i]);
+            return need_exchange(c);
+        }
     }
-    c->counts.n_break = n_break;
-    // ReadsOther (non-first blocks) is sorted with an unstable std::sort in the reference (SegmentGraph.cpp:781) and a
-    // block of <= 3 bases right behind a node boundary is counted for whichever node the sweep cursor is on, which
-    // depends on that sort's tie order.  Node depths only feed the coverage-ratio test of FilterEdges, so by default
-    // the GPU reports canonical depths plus bounds over all tie orders and FilterEdges checks that no decision can
-    // change inside the bounds; only then (or when SQUID_EXACT_DEPTH is set, as the stage-parity tests do) is the
-    // reference's sort repeated on the host and the sweep walked exactly.
-    const bool exact_mode = std::getenv("SQUID_EXACT_DEPTH") != nullptr;
-    struct OtherWork { std::vector<int32_t> chr, pos, len; struct R { int32_t chr, pos, len; }; std::vector<R> sorted; bool has_tiny = false; };
-    std::shared_ptr<OtherWork> ow = std::make_shared<OtherWork>();
-    std::future<void> other_sorted;
-    auto start_exact_sort = [&]() -> int {
-        int r2 = dev_gather_other(c, n_break, ow->has_tiny, ow->chr, ow->pos, ow->len);
-        if (r2) return r2;
-        if (ow->has_tiny)
-            other_sorted = std::async(std::launch::async, [ow]() {
-                ow->sorted.resize(ow->chr.size());
-                for (size_t i = 0; i < ow->sorted.size(); ++i) ow->sorted[i] = OtherWork::R{ow->chr[i], ow->pos[i], ow->len[i]};
-                std::sort(ow->sorted.begin(), ow->sorted.end(), [](const OtherWork::R& a, const OtherWork::R& b) { return a.chr != b.chr ? a.chr < b.chr : a.pos < b.pos; });
-            });
-        return SQ_OK;
-    };
-    if (exact_mode) { rc = start_exact_sort(); if (rc) return rc; }
-    {
-        HostClock hc(c, "host_segment_replay");
-        rc = segment_replay(c, *plan, seeds);
+    if (g.stage == 1) {
+        if (sh.on) {
+            rc = take_exchange(c, X_DEDUP);
+            if (rc) return rc;
+            sh.dedup_mask = 0;
+            for (int r = 0; r < me; ++r) {
+                Unpacker u(c->xgot[r]);
+                u.get<int32_t>();
+                for (int p = 0; p < 2; ++p) {
+                    int32_t has = u.get<int32_t>(), empty = u.get<int32_t>();
+                    if (has) { if (empty) sh.dedup_mask &= ~(1 << p); else sh.dedup_mask |= 1 << p; }
+                }
+            }
+        }
+        rc = dev_dedup_summarise(c);
+        if (rc) return rc;
+        long long other_max = INT64_MIN;
+        int32_t first_kept[2] = {0, 0};
+        {
+            HostClock hc(c, "host_segment_prepare");
+            rc = segment_static(c, g.plan, g.disc, sh.on, g.trigger_last, other_max, first_kept);
+            if (rc) return rc;
+        }
+        g.stage = 2;
+        if (sh.on) {  // exchange 2: size, first record, running other-pair and last-cluster trigger of every local stream
+            Packer pk(c->xbuf);
+            pk.put<int32_t>(X_STREAM);
+            pk.put<int64_t>(c->counts.n_kept_p1);
+            pk.put<int32_t>(first_kept[0]); pk.put<int32_t>(first_kept[1]);
+            pk.put<int64_t>(other_max);
+            pk.put<int64_t>(g.trigger_last);
+            return need_exchange(c);
+        }
     }
-    if (rc) { if (other_sorted.valid()) other_sorted.get(); return rc; }
-    {
-        HostClock hc(c, "host_tile_genome");
-        std::vector<Node> seedcopy = seeds;
-        rc = tile_genome(c, seedcopy, c->nodes);
+    if (g.stage == 2) {
+        if (sh.on) {
+            rc = take_exchange(c, X_STREAM);
+            if (rc) return rc;
+            std::vector<int64_t> K(W), tl(W), om(W);
+            std::vector<int32_t> fr(W), fp(W);
+            for (int r = 0; r < W; ++r) {
+                Unpacker u(c->xgot[r]);
+                u.get<int32_t>();
+                K[r] = u.get<int64_t>(); fr[r] = u.get<int32_t>(); fp[r] = u.get<int32_t>(); om[r] = u.get<int64_t>(); tl[r] = u.get<int64_t>();
+                if (!u.ok) return fail(c, SQ_E_ARG, "sharded run: malformed stream payload");
+            }
+            sh.kept_before = 0; sh.kept_total = 0; sh.prior_kept = false; sh.other_seed = INT64_MIN; sh.has_terminal = false;
+            for (int r = 0; r < W; ++r) {
+                if (r < me) { sh.kept_before += K[r]; if (K[r] > 0) { sh.prior_kept = true; sh.other_seed = std::max<long long>(sh.other_seed, om[r]); } }
+                if (r > me && K[r] > 0 && !sh.has_terminal) { sh.has_terminal = true; sh.term_refid = fr[r]; sh.term_pos = fp[r]; }
+                sh.kept_total += K[r];
+            }
+            // B12: the consumed prefix ends one record behind the trigger of the globally last cluster
+            if (g.trigger_last < 0) sh.n_break_global = std::min<int64_t>(sh.kept_total, 1);  // no discordant cluster at all
+            else {
+                int64_t T = sh.kept_total, off = 0;
+                for (int r = 0; r < W; ++r) { if (tl[r] >= 0 && tl[r] < K[r]) { T = off + tl[r]; break; } off += K[r]; }
+                sh.n_break_global = std::min<int64_t>(sh.kept_total, T + 2);
+            }
+        }
+        {
+            HostClock hc(c, "host_segment_prepare");
+            rc = segment_prepare(c, *g.plan, g.n_break);
+            if (rc) return rc;
+        }
+        c->counts.n_break = g.n_break;
+        std::vector<Node> seedsB;
+        std::vector<int32_t> sens;
+        {
+            HostClock hc(c, "host_segment_replay");
+            rc = segment_replay(c, *g.plan, g.seeds, false, nullptr);
+            if (!rc && sh.on && sh.prior_kept) rc = segment_replay(c, *g.plan, seedsB, true, &sens);
+        }
+        if (rc) return rc;
+        g.stage = 3;
+        if (sh.on) {  // exchange 3: seed nodes, also under the hypothesis that an earlier shard has emitted a node before
+            auto flat = [](const std::vector<Node>& v) { std::vector<int32_t> f; f.reserve(v.size() * 3); for (const Node& n : v) { f.push_back(n.chr); f.push_back(n.pos); f.push_back(n.len); } return f; };
+            Packer pk(c->xbuf);
+            pk.put<int32_t>(X_SEEDS);
+            pk.put_vec(flat(g.seeds));
+            pk.put<int32_t>(sh.prior_kept ? 1 : 0);
+            pk.put_vec(flat(seedsB));
+            pk.put_vec(sens);
+            return need_exchange(c);
+        }
     }
-    if (rc) { if (other_sorted.valid()) other_sorted.get(); return rc; }
-    // per-node Support / AvgDepth (SegmentGraph.cpp:766-826): discordant blocks on the host, stream blocks from the GPU
+    if (g.stage == 3) {
+        if (sh.on) {
+            rc = take_exchange(c, X_SEEDS);
+            if (rc) return rc;
+            std::vector<Node> all;
+            bool prev = false; int prev_end = 0;
+            for (int r = 0; r < W; ++r) {
+                Unpacker u(c->xgot[r]);
+                u.get<int32_t>();
+                std::vector<int32_t> a, b2, se;
+                u.get_vec(a);
+                int32_t hasB = u.get<int32_t>();
+                u.get_vec(b2); u.get_vec(se);
+                if (!u.ok) return fail(c, SQ_E_ARG, "sharded run: malformed seed payload");
+                const bool useB = prev && hasB;
+                if (useB) for (int32_t v : se) if (v == prev_end)
+                    return fail(c, SQ_E_ASSERT, "sharded run: the reference would extend a node of an earlier chromosome here (SegmentGraph.cpp:623); run unsharded");
+                const std::vector<int32_t>& pick = useB ? b2 : a;
+                for (size_t i = 0; i + 2 < pick.size(); i += 3) all.push_back(Node{pick[i], pick[i + 1], pick[i + 2], 0, 0.0});
+                if (!pick.empty()) { prev = true; prev_end = pick[pick.size() - 2] + pick[pick.size() - 1]; }
+            }
+            g.seeds.swap(all);
+        }
+        {
+            HostClock hc(c, "host_tile_genome");
+            std::vector<Node> seedcopy = g.seeds;
+            rc = tile_genome(c, seedcopy, c->nodes);
+        }
+        if (rc) return rc;
+        std::vector<int32_t> unused;
+        rc = dev_node_depth(c, c->nodes, g.n_break, g.sup, g.sl, g.tiny_boundary, g.amb_plus, g.amb_minus, unused);
+        if (rc) return rc;
+        c->edges.clear();
+        {
+            HostClock hc(c, "host_chimeric_edges");
+            rc = chimeric_edges(c, g.raw);
+            if (rc) return rc;
+        }
+        rc = dev_concordant_edges(c, c->nodes, g.conc);
+        if (rc) return rc;
+        g.stage = 4;
+        if (sh.on) {  // exchange 4 (the data exchange): per-node depth accumulators of the own chromosomes + locally reduced edges
+            const std::vector<Node>& N = c->nodes;
+            const int nn = (int)N.size();
+            int lo = 0, hi = 0;
+            while (lo < nn && N[lo].chr < sh.first_ref) ++lo;
+            hi = lo;
+            while (hi < nn && N[hi].chr < sh.end_ref) ++hi;
+            for (int i = 0; i < nn; ++i)
+                if ((i < lo || i >= hi) && (g.sup[i] || g.sup[nn + i] || g.sl[i] || g.sl[nn + i] || g.amb_plus[i] || g.amb_minus[i]))
+                    return fail(c, SQ_E_ARG, "internal: a record of this shard was counted for a node of another shard");
+            Packer pk(c->xbuf);
+            pk.put<int32_t>(X_GRAPH);
+            pk.put<int32_t>(lo); pk.put<int32_t>(hi);
+            pk.put<int64_t>((int64_t)g.sup[2 * nn]);  // |ReadsOther| of this shard
+            pk.put<int32_t>(g.tiny_boundary ? 1 : 0);
+            std::vector<int32_t> part;
+            auto slice = [&](auto&& get) { part.clear(); for (int i = lo; i < hi; ++i) part.push_back((int32_t)get(i)); pk.put_vec(part); };
+            slice([&](int i) { return g.sup[i]; }); slice([&](int i) { return g.sl[i]; }); slice([&](int i) { return g.sup[nn + i]; }); slice([&](int i) { return g.sl[nn + i]; });
+            slice([&](int i) { return g.amb_plus[i]; }); slice([&](int i) { return g.amb_minus[i]; });
+            std::vector<uint64_t> keys; std::vector<int32_t> ws;
+            for (const Edge& e : g.conc) { keys.push_back(edge_pack(e)); ws.push_back(e.w); }
+            pk.put_vec(keys); pk.put_vec(ws);
+            pk.put<int64_t>(c->counts.n_raw_edges);
+            return need_exchange(c);
+        }
+    }
+    if (g.stage != 4) return fail(c, SQ_E_ARG, "internal: bad build stage");
     std::vector<Node>& N = c->nodes;
     const int nn = (int)N.size();
+    if (sh.on) {
+        rc = take_exchange(c, X_GRAPH);
+        if (rc) return rc;
+        g.sup.assign(2 * nn + 1, 0); g.sl.assign(2 * nn, 0); g.amb_plus.assign(nn, 0); g.amb_minus.assign(nn, 0);
+        g.tiny_boundary = false; g.conc.clear();
+        int64_t n_other = 0, n_raw = 0;
+        for (int r = 0; r < W; ++r) {
+            Unpacker u(c->xgot[r]);
+            u.get<int32_t>();
+            const int lo = u.get<int32_t>(), hi = u.get<int32_t>();
+            n_other += u.get<int64_t>();
+            if (u.get<int32_t>()) g.tiny_boundary = true;
+            std::vector<int32_t> v[6];
+            for (auto& x : v) u.get_vec(x);
+            std::vector<uint64_t> keys; std::vector<int32_t> ws;
+            u.get_vec(keys); u.get_vec(ws);
+            n_raw += u.get<int64_t>();
+            if (!u.ok || lo < 0 || hi > nn || lo > hi || keys.size() != ws.size()) return fail(c, SQ_E_ARG, "sharded run: malformed graph payload");
+            for (auto& x : v) if ((int)x.size() != hi - lo) return fail(c, SQ_E_ARG, "sharded run: malformed graph payload");
+            for (int i = lo; i < hi; ++i) {
+                g.sup[i] += v[0][i - lo]; g.sl[i] += v[1][i - lo]; g.sup[nn + i] += v[2][i - lo]; g.sl[nn + i] += v[3][i - lo];
+                g.amb_plus[i] += v[4][i - lo]; g.amb_minus[i] += v[5][i - lo];
+            }
+            for (size_t i = 0; i < keys.size(); ++i) {
+                Edge e;
+                e.a = (int32_t)(keys[i] >> 32); e.b = (int32_t)((keys[i] & 0xffffffffull) >> 2); e.ha = (keys[i] >> 1) & 1; e.hb = keys[i] & 1; e.w = ws[i]; e.gw = 0;
+                g.conc.push_back(e);
+            }
+        }
+        g.sup[2 * nn] = (int32_t)std::min<int64_t>(n_other, INT32_MAX);
+        c->counts.n_raw_edges = n_raw;
+    }
+    // per-node Support / AvgDepth (SegmentGraph.cpp:766-826): discordant blocks on the host, stream blocks from the GPU
     std::vector<int32_t> dis_cnt(nn), dis_sum(nn);
     {
         HostClock hc(c, "host_depth_discordant");
+        const std::vector<Blk>& disc = g.disc;
         size_t it = 0;
         for (int i = 0; i < nn; ++i) {
             int cnt = 0, sum = 0;
@@ -113,67 +316,71 @@ static int build_graph(sq_ctx* c) {
             dis_cnt[i] = cnt; dis_sum[i] = sum;
         }
     }
-    std::vector<int32_t> sup, amb_plus, amb_minus, unused;
-    std::vector<int64_t> sl;
-    bool tiny_boundary = false;
-    rc = dev_node_depth(c, N, n_break, sup, sl, tiny_boundary, amb_plus, amb_minus, unused);
-    if (rc) { if (other_sorted.valid()) other_sorted.get(); return rc; }
+    // ReadsOther (non-first blocks) is sorted with an unstable std::sort in the reference (SegmentGraph.cpp:781) and a
+    // block of <= 3 bases right behind a node boundary is counted for whichever node the sweep cursor is on, which
+    // depends on that sort's tie order.  Node depths only feed the coverage-ratio test of FilterEdges, so by default
+    // the GPU reports canonical depths plus bounds over all tie orders and FilterEdges checks that no decision can
+    // change inside the bounds; only then (or when SQUID_EXACT_DEPTH is set, as the stage-parity tests do) is the
+    // reference's sort repeated on the host and the sweep walked exactly.  A sharded run cannot repeat that sort (its
+    // tie order depends on the whole list) and fails loudly instead.
+    const bool exact_mode = std::getenv("SQUID_EXACT_DEPTH") != nullptr && !sh.on;
+    struct OtherR { int32_t chr, pos, len; };
+    std::vector<OtherR> other_sorted;
+    auto exact_sort = [&]() -> int {
+        std::vector<int32_t> ochr, opos, olen;
+        bool has_tiny = false;
+        int r2 = dev_gather_other(c, g.n_break, has_tiny, ochr, opos, olen);
+        if (r2) return r2;
+        other_sorted.resize(has_tiny ? ochr.size() : 0);
+        for (size_t i = 0; i < other_sorted.size(); ++i) other_sorted[i] = OtherR{ochr[i], opos[i], olen[i]};
+        std::sort(other_sorted.begin(), other_sorted.end(), [](const OtherR& a, const OtherR& b) { return a.chr != b.chr ? a.chr < b.chr : a.pos < b.pos; });
+        return SQ_OK;
+    };
     // combine in the reference's order: discordant, ReadsMain, ReadsOther, then the division (only when ReadsOther is
     // non-empty, ledger B13).  `other` = per-node (count, sum) of ReadsOther, either canonical or from the exact sweep.
     auto set_depths = [&](const std::vector<int32_t>& ocnt, const std::vector<int32_t>& osum, bool bounds) {
-        const int64_t n_other = sup[2 * nn];
+        const int64_t n_other = g.sup[2 * nn];
         c->depth_bounds = bounds;
         for (int i = 0; i < nn; ++i) {
-            N[i].support = dis_cnt[i] + sup[i];
+            N[i].support = dis_cnt[i] + g.sup[i];
             double d = dis_sum[i];
-            d += (int32_t)sl[i];
+            d += (int32_t)g.sl[i];
             double lo = d, hi = d;
             if (n_other != 0) {
                 N[i].support += ocnt[i];
                 d += osum[i];
                 lo = d; hi = d;
-                if (bounds) { lo = d - amb_minus[i]; hi = d + amb_plus[i]; }
+                if (bounds) { lo = d - g.amb_minus[i]; hi = d + g.amb_plus[i]; }
                 d = 1.0 * d / N[i].len; lo = 1.0 * lo / N[i].len; hi = 1.0 * hi / N[i].len;
             }
             N[i].depth = d; N[i].depth_lo = lo; N[i].depth_hi = hi;
         }
     };
     auto exact_sweep = [&](std::vector<int32_t>& ocnt, std::vector<int32_t>& osum) {
-        if (other_sorted.valid()) other_sorted.get();
         ocnt.assign(nn, 0); osum.assign(nn, 0);
         size_t it = 0;
         for (int i = 0; i < nn; ++i)
-            for (; it != ow->sorted.size(); ++it) {
-                const OtherWork::R& r = ow->sorted[it];
+            for (; it != other_sorted.size(); ++it) {
+                const OtherR& r = other_sorted[it];
                 if (r.chr == N[i].chr && r.pos >= N[i].pos - 3 && r.pos + r.len <= N[i].pos + N[i].len + 3) { ocnt[i]++; osum[i] += r.len; }
                 else if (r.pos >= N[i].pos + N[i].len || r.chr != N[i].chr) break;
             }
     };
     std::vector<int32_t> ocnt(nn), osum(nn);
-    for (int i = 0; i < nn; ++i) { ocnt[i] = sup[nn + i]; osum[i] = (int32_t)sl[nn + i]; }
+    for (int i = 0; i < nn; ++i) { ocnt[i] = g.sup[nn + i]; osum[i] = (int32_t)g.sl[nn + i]; }
     c->depth_ambiguous = false;
-    if (exact_mode && tiny_boundary) {
+    if (exact_mode && g.tiny_boundary) {
         HostClock hc(c, "host_depth_exact_sweep");
-        exact_sweep(ocnt, osum);
-        set_depths(ocnt, osum, false);
-    } else {
-        if (other_sorted.valid()) other_sorted.get();
-        set_depths(ocnt, osum, tiny_boundary);
-    }
-    c->edges.clear();
-    std::vector<Edge> raw, conc;
-    {
-        HostClock hc(c, "host_chimeric_edges");
-        rc = chimeric_edges(c, raw);
+        rc = exact_sort();
         if (rc) return rc;
-    }
-    rc = dev_concordant_edges(c, c->nodes, conc);
-    if (rc) return rc;
+        if (!other_sorted.empty()) exact_sweep(ocnt, osum);
+        set_depths(ocnt, osum, false);
+    } else set_depths(ocnt, osum, g.tiny_boundary);
     c->snap[1].take(c->nodes, c->edges, nullptr);
     {
         HostClock hc(c, "host_edge_reduce");
-        raw.insert(raw.end(), conc.begin(), conc.end());
-        reduce_edges(raw, c->edges);
+        g.raw.insert(g.raw.end(), g.conc.begin(), g.conc.end());
+        reduce_edges(g.raw, c->edges);
     }
     c->snap[2].take(c->nodes, c->edges, nullptr);
     {
@@ -187,8 +394,9 @@ static int build_graph(sq_ctx* c) {
         if (c->depth_ambiguous) {
             // some coverage-ratio decision depends on the tie order: repeat the reference's sort and sweep, then redo the
             // filter with the exact depths
+            if (sh.on) return fail(c, SQ_E_ASSERT, "sharded run: a FilterEdges decision depends on the tie order of the reference's ReadsOther sort; run unsharded");
             HostClock hc2(c, "host_depth_exact_retry");
-            rc = start_exact_sort();
+            rc = exact_sort();
             if (rc) return rc;
             exact_sweep(ocnt, osum);
             set_depths(ocnt, osum, false);
@@ -211,20 +419,28 @@ static int build_graph(sq_ctx* c) {
     multiply_discordant(c, false);
     c->snap[0].take(c->nodes, c->edges, &c->label);
     c->graph_built = true;
+    c->gb.reset();
     return SQ_OK;
 }
+
+struct SvBuild {
+    int stage = 0;
+    BPMap bpmap;
+    std::vector<std::pair<int, int>> BPs;
+    std::vector<int32_t> diff;  // this shard's difference array
+    int cur_prev = 0;
+    BpBoundary bb;
+};
 
 static int call_sv(sq_ctx* c) {
     HostClock wall(c, "wall_call_sv");
     if (!c->ordered) return fail(c, SQ_E_ARG, "sq_call_sv before sq_order");
     const std::vector<Node>& N = c->nodes;
     std::vector<Edge>& E = c->edges;
-    BPMap bpmap;
-    {
-        HostClock hc(c, "host_exact_breakpoints");
-        int rc = exact_breakpoints(c, bpmap);
-        if (rc) return rc;
-    }
+    Shard& sh = c->shard;
+    if (!c->svb) c->svb = std::make_shared<SvBuild>();
+    SvBuild& v = *c->svb;
+    BPMap& bpmap = v.bpmap;
     // breakpoint list of every edge (SegmentGraph.cpp:3091-3109)
     auto edge_bps = [&](const Edge& e, std::vector<std::pair<std::pair<int, int>, std::pair<int, int>>>& out, bool& exact) {
         out.clear();
@@ -233,15 +449,79 @@ static int call_sv(sq_ctx* c) {
         if (exact) for (const auto& p : it->second) out.push_back({{N[e.a].chr, p.first}, {N[e.b].chr, p.second}});
         else out.push_back({{N[e.a].chr, e.ha ? N[e.a].pos : N[e.a].pos + N[e.a].len}, {N[e.b].chr, e.hb ? N[e.b].pos : N[e.b].pos + N[e.b].len}});
     };
-    std::vector<std::pair<int, int>> BPs;
+    std::vector<std::pair<int, int>>& BPs = v.BPs;
     std::vector<std::pair<std::pair<int, int>, std::pair<int, int>>> tmp;
     bool exact;
-    for (const Edge& e : E) { edge_bps(e, tmp, exact); for (auto& p : tmp) { BPs.push_back(p.first); BPs.push_back(p.second); } }
-    std::sort(BPs.begin(), BPs.end());
     std::vector<int32_t> cov;
-    static const bool bp_host = getenv("SQUID_BP_HOST") != nullptr;  // debug cross-check of k_bp_walk
-    int rc = bp_host ? dev_breakpoint_support_exact(c, BPs, cov) : dev_breakpoint_support(c, BPs, cov);
-    if (rc) return rc;
+    int rc;
+    auto pack_bpsup = [&]() {
+        Packer pk(c->xbuf);
+        pk.put<int32_t>(X_BPSUP);
+        pk.put<int32_t>(v.cur_prev); pk.put<int32_t>(v.bb.cur_end); pk.put<int32_t>(v.bb.has_p3 ? 1 : 0); pk.put<int32_t>(v.bb.has_event ? 1 : 0);
+        pk.put<int64_t>(v.bb.n_p3); pk.put<int64_t>(v.bb.absorb);
+        pk.put_vec(v.diff);
+    };
+    if (v.stage == 0) {
+        {
+            HostClock hc(c, "host_exact_breakpoints");
+            rc = exact_breakpoints(c, bpmap);
+            if (rc) return rc;
+        }
+        for (const Edge& e : E) { edge_bps(e, tmp, exact); for (auto& p : tmp) { BPs.push_back(p.first); BPs.push_back(p.second); } }
+        std::sort(BPs.begin(), BPs.end());
+        static const bool bp_host = getenv("SQUID_BP_HOST") != nullptr;  // debug cross-check of k_bp_walk
+        if (!sh.on) {
+            rc = bp_host ? dev_breakpoint_support_exact(c, BPs, cov) : dev_breakpoint_support(c, BPs, cov);
+            if (rc) return rc;
+        } else {
+            // the cursor (SegmentGraph.cpp:3157) is carried from shard to shard: start from the usual state -- every
+            // breakpoint on an earlier chromosome is behind it -- and let the exchange verify that guess
+            v.cur_prev = (int)(std::lower_bound(BPs.begin(), BPs.end(), std::make_pair(sh.first_ref, INT32_MIN)) - BPs.begin());
+            rc = dev_breakpoint_support(c, BPs, v.diff, v.cur_prev, &v.bb, true);
+            if (rc) return rc;
+            pack_bpsup();
+            v.stage = 1;
+            return need_exchange(c);
+        }
+    } else {
+        rc = take_exchange(c, X_BPSUP);
+        if (rc) return rc;
+        const int W = c->P.world_size, me = c->P.rank;
+        const size_t nb = BPs.size();
+        std::vector<int64_t> total(nb + 1, 0);
+        int truth = 0, bad = -1;
+        for (int r = 0; r < W; ++r) {
+            Unpacker u(c->xgot[r]);
+            u.get<int32_t>();
+            const int assumed = u.get<int32_t>(), end = u.get<int32_t>(), has = u.get<int32_t>(), has_event = u.get<int32_t>();
+            const int64_t n_p3 = u.get<int64_t>(), absorb = u.get<int64_t>();
+            std::vector<int32_t> d;
+            u.get_vec(d);
+            if (!u.ok || d.size() != nb + 1) return fail(c, SQ_E_ARG, "sharded run: malformed breakpoint payload");
+            if (!has) continue;  // no pass-3 record: the cursor passes through untouched
+            // a cursor that arrives `lag` entries behind the assumed position catches up one entry per pass-3 record;
+            // every breakpoint it still has to pass lies on an earlier chromosome, so nothing counted here changes as
+            // long as it has caught up before the first record that moves it further
+            const int64_t lag = (int64_t)assumed - truth;
+            if (lag < 0 || lag > absorb) { bad = r; break; }
+            truth = has_event ? end : (int)std::min<int64_t>(assumed, (int64_t)truth + n_p3);
+            for (size_t i = 0; i <= nb; ++i) total[i] += d[i];
+        }
+        if (bad >= 0) {
+            // rank `bad` started from a wrong cursor (an earlier shard ended while the cursor was still catching up): it
+            // recounts from the real one, everybody exchanges again
+            if (bad == me) {
+                v.cur_prev = truth;
+                rc = dev_breakpoint_support(c, BPs, v.diff, v.cur_prev, &v.bb, true);
+                if (rc) return rc;
+            }
+            pack_bpsup();
+            return need_exchange(c);
+        }
+        cov.assign(nb, 0);
+        int64_t run = 0;
+        for (size_t i = 0; i < nb; ++i) { run += total[i]; cov[i] = (int32_t)run; }
+    }
     // per-edge table in key order (parity tests) -- before the weight sort
     c->bp_off.assign(1, 0); c->bp1.clear(); c->bp2.clear(); c->bsup1.clear(); c->bsup2.clear();
     std::map<uint64_t, std::vector<std::pair<int, int>>> support;
@@ -288,6 +568,7 @@ static int call_sv(sq_ctx* c) {
             c->sv_s1.push_back(e.ha); c->sv_s2.push_back(e.hb);
         }
     }
+    c->svb.reset();
     return SQ_OK;
 }
 
@@ -352,13 +633,59 @@ int sq_chim_contains(sq_ctx* c, const char* name, size_t len) {
     if (!c) return SQ_E_ARG;
     return c->chim_set.count(std::string(name, len)) ? 1 : 0;
 }
+// does this shard own records of RefID `id`?  (the unplaced records at the end of a sorted BAM go to the last rank)
+static inline bool shard_owns(const sq_ctx* c, int32_t id) {
+    const Shard& sh = c->shard;
+    if (!sh.on) return true;
+    if (id < 0) return c->P.rank == c->P.world_size - 1;
+    return id >= sh.first_ref && id < sh.end_ref;
+}
 int sq_ingest_concordant(sq_ctx* c, const sq_aln_batch* b) {
     if (!c || !b) return SQ_E_ARG;
-    return dev_append_records(c, b);
+    if (!c->shard.on) return dev_append_records(c, b);
+    // sharded: keep the runs of records this rank owns (one run per batch on a sorted stream)
+    int64_t i = 0;
+    while (i < b->n_rec) {
+        while (i < b->n_rec && !shard_owns(c, b->refid[i])) ++i;
+        int64_t j = i;
+        while (j < b->n_rec && shard_owns(c, b->refid[j])) ++j;
+        if (j > i) {
+            sq_aln_batch v = *b;
+            v.n_rec = j - i; v.n_blk = b->blk_off[j] - b->blk_off[i];
+            v.refid += i; v.pos += i; v.mate_refid += i; v.mate_pos += i; v.end_pos += i; v.flag += i; v.mapq += i; v.aux += i; v.totlen += i; v.blk_off += i;
+            const uint32_t o = b->blk_off[i] - b->blk_off[0];
+            v.b_refpos += o; v.b_matchref += o; v.b_readpos += o; v.b_matchread += o;
+            int rc = dev_append_records(c, &v);
+            if (rc) return rc;
+        }
+        i = j;
+    }
+    return SQ_OK;
+}
+static int ingest_raw(sq_ctx* c, const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n_rec) {
+    if (!c->shard.on) return dev_parse_append(c, bam, nbytes, rec_off, n_rec);
+    // sharded: RefID sits 4 bytes into a record; upload only the byte range of the runs this rank owns
+    auto refid_at = [&](int64_t i) { int32_t v; std::memcpy(&v, bam + rec_off[i] + 4, 4); return v; };
+    int64_t i = 0;
+    std::vector<unsigned long long> off;
+    while (i < n_rec) {
+        while (i < n_rec && (rec_off[i] + 8 > nbytes || !shard_owns(c, refid_at(i)))) ++i;
+        int64_t j = i;
+        while (j < n_rec && rec_off[j] + 8 <= nbytes && shard_owns(c, refid_at(j))) ++j;
+        if (j > i) {
+            const unsigned long long lo = rec_off[i], hi = j < n_rec ? rec_off[j] : (unsigned long long)nbytes;
+            off.resize((size_t)(j - i));
+            for (int64_t k = i; k < j; ++k) off[(size_t)(k - i)] = rec_off[k] - lo;
+            int rc = dev_parse_append(c, bam + lo, (size_t)(hi - lo), off.data(), j - i);
+            if (rc) return rc;
+        }
+        i = j;
+    }
+    return SQ_OK;
 }
 int sq_ingest_concordant_bam(sq_ctx* c, const uint8_t* bam, size_t nbytes, const uint64_t* rec_off, int64_t n_rec) {
     if (!c || (n_rec && (!bam || !rec_off))) return SQ_E_ARG;
-    int rc = dev_parse_append(c, bam, nbytes, (const unsigned long long*)rec_off, n_rec);
+    int rc = ingest_raw(c, bam, nbytes, (const unsigned long long*)rec_off, n_rec);
     dev_flush_timers(c);
     return rc;
 }
@@ -402,7 +729,7 @@ int sq_ingest_concordant_file(sq_ctx* c, const char* path, int32_t n_threads) {
     if (!c || !path) return SQ_E_ARG;
     if (!std::getenv("SQUID_HOST_PARSE")) {
         // default: the host only inflates BGZF and finds record boundaries; K0 parses the records on the GPU
-        int rc = scan_bam_file(path, n_threads, c->err, [&](const uint8_t* bam, size_t nbytes, const unsigned long long* off, int64_t n) { return dev_parse_append(c, bam, nbytes, off, n); });
+        int rc = scan_bam_file(path, n_threads, c->err, [&](const uint8_t* bam, size_t nbytes, const unsigned long long* off, int64_t n) { return ingest_raw(c, bam, nbytes, off, n); });
         dev_flush_timers(c);
         return rc;
     }
@@ -417,8 +744,11 @@ int sq_build_graph(sq_ctx* c) {
     if (!c) return SQ_E_ARG;
     if (c->ref_len.empty()) return fail(c, SQ_E_ARG, "sq_set_references first");
     if (c->read_len <= 0) return fail(c, SQ_E_ARG, "sq_ingest_chimeric first (ReadLen comes from the chimeric BAM)");
+    if (c->shard.on != (c->P.world_size > 1)) return fail(c, SQ_E_ARG, "world_size > 1 needs sq_set_shard (and the other way round)");
+    if (!c->gb) c->timer.clear();
     int rc = build_graph(c);
     dev_flush_timers(c);
+    if (rc < 0) { c->gb.reset(); c->x_pending = false; }
     return rc;
 }
 int sq_graph_view(sq_ctx* c, int32_t stage, sq_graph* g) {
@@ -436,6 +766,7 @@ int sq_call_sv(sq_ctx* c, sq_sv_table* t) {
     if (!c || !c->graph_built) return SQ_E_ARG;
     int rc = call_sv(c);
     dev_flush_timers(c);
+    if (rc < 0) { c->svb.reset(); c->x_pending = false; }
     if (rc) return rc;
     if (t) {
         t->n_rows = (int32_t)c->sv_cols[0].size();
@@ -464,6 +795,7 @@ int sq_reset(sq_ctx* c) {
     c->nodes.clear(); c->edges.clear(); c->label.clear();
     c->graph_built = false; c->ordered = false;
     c->bp_off.clear();
+    c->gb.reset(); c->svb.reset(); c->x_pending = false; c->x_ready = false;
     return SQ_OK;
 }
 int sq_get_counts(sq_ctx* c, sq_counts* k) {
@@ -492,13 +824,36 @@ int sq_debug_bp_support(sq_ctx* c, int32_t n_bp, const int32_t* chr, const int32
     std::copy(cov.begin(), cov.end(), coverage);
     return SQ_OK;
 }
-int sq_exchange_pack(sq_ctx* c, const void** buf, int64_t* nbytes) {
-    (void)buf; (void)nbytes;
-    return fail(c, SQ_E_ARG, "chromosome-sharded exchange is not implemented in this build");
+int sq_set_shard(sq_ctx* c, int32_t first_ref, int32_t end_ref) {
+    if (!c) return SQ_E_ARG;
+    if (c->P.world_size <= 1) return fail(c, SQ_E_ARG, "sq_set_shard needs sq_params.world_size > 1");
+    if (c->P.rank < 0 || c->P.rank >= c->P.world_size) return fail(c, SQ_E_ARG, "sq_params.rank out of range");
+    if (c->ref_len.empty()) return fail(c, SQ_E_ARG, "sq_set_references first");
+    if (first_ref < 0 || end_ref < first_ref || end_ref > (int32_t)c->ref_len.size()) return fail(c, SQ_E_ARG, "bad RefID range");
+    if (c->counts.n_concordant) return fail(c, SQ_E_ARG, "sq_set_shard after concordant records were ingested");
+    c->shard = Shard();
+    c->shard.on = true; c->shard.first_ref = first_ref; c->shard.end_ref = end_ref;
+    return SQ_OK;
 }
-int sq_exchange_unpack(sq_ctx* c, const void* g, const int64_t* n, int32_t w) {
-    (void)g; (void)n; (void)w;
-    return fail(c, SQ_E_ARG, "chromosome-sharded exchange is not implemented in this build");
+int sq_exchange_pack(sq_ctx* c, const void** buf, int64_t* nbytes) {
+    if (!c || !buf || !nbytes) return SQ_E_ARG;
+    if (!c->x_pending) return fail(c, SQ_E_ARG, "no exchange is pending (sq_build_graph / sq_call_sv return SQ_NEED_EXCHANGE first)");
+    *buf = c->xbuf.data(); *nbytes = (int64_t)c->xbuf.size();
+    return SQ_OK;
+}
+int sq_exchange_unpack(sq_ctx* c, const void* gathered, const int64_t* nbytes_per_rank, int32_t world_size) {
+    if (!c || !nbytes_per_rank || world_size != c->P.world_size) return SQ_E_ARG;
+    if (!c->x_pending) return fail(c, SQ_E_ARG, "no exchange is pending");
+    c->xgot.assign(world_size, {});
+    const uint8_t* p = (const uint8_t*)gathered;
+    for (int r = 0; r < world_size; ++r) {
+        if (nbytes_per_rank[r] < 0 || (nbytes_per_rank[r] && !p)) return SQ_E_ARG;
+        c->xgot[r].assign(p, p + nbytes_per_rank[r]);
+        p += nbytes_per_rank[r];
+    }
+    if (c->xgot[c->P.rank] != c->xbuf) return fail(c, SQ_E_ARG, "sq_exchange_unpack: this rank's slot does not hold what sq_exchange_pack returned");
+    c->x_pending = false; c->x_ready = true;
+    return SQ_OK;
 }
 
 }  // extern "C"

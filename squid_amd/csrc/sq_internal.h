@@ -87,6 +87,23 @@ struct Timer {
 
 struct DeviceRecords;  // HBM-resident SoA + scratch (sq_kernels.hip)
 
+// Chromosome sharding: rank r holds the concordant records of a contiguous RefID range and
+// everything that is small (chimeric fragments, cluster table, node and edge tables) is replicated.  The fields
+// below are what a rank learns about the other shards from the exchanges (see build_graph in sq_capi.cpp).
+struct Shard {
+    bool on = false;
+    int first_ref = 0, end_ref = 0;   // owns RefIDs [first_ref, end_ref); the last rank also owns RefID -1
+    int dedup_mask = 0;               // bit0 / bit1: a pass-1 / pass-2 record precedes this shard and its lists are not empty
+    bool prior_kept = false;          // an earlier rank has kept pass-1 records
+    int64_t kept_before = 0, kept_total = 0;
+    bool has_terminal = false;        // a later rank has kept records; its first one closes this shard's last stretch
+    int32_t term_refid = 0, term_pos = 0;
+    long long other_seed = INT64_MIN; // running (otherChr << 32 | otherrightmost) of the earlier ranks
+    int64_t n_break_global = 0;
+};
+struct GraphBuild;  // locals of sq_build_graph that survive an exchange (sq_capi.cpp)
+struct SvBuild;     // same for sq_call_sv
+
 }  // namespace sq
 
 struct sq_ctx {
@@ -118,7 +135,14 @@ struct sq_ctx {
     std::vector<int32_t> bp_off, bp1, bp2, bsup1, bsup2;
     sq::Timer timer;
     sq_counts counts{};
-    std::vector<uint8_t> xbuf;  // exchange pack buffer
+    // chromosome-sharded runs: sq_build_graph / sq_call_sv return SQ_NEED_EXCHANGE with `xbuf` filled; the caller
+    // all-gathers it and hands the result back through sq_exchange_unpack before calling the same function again
+    sq::Shard shard;
+    std::shared_ptr<sq::GraphBuild> gb;
+    std::shared_ptr<sq::SvBuild> svb;
+    std::vector<uint8_t> xbuf;                 // this rank's contribution
+    std::vector<std::vector<uint8_t>> xgot;    // what every rank contributed (by rank), set by sq_exchange_unpack
+    bool x_pending = false, x_ready = false;
 };
 
 namespace sq {
@@ -154,8 +178,14 @@ bool frag_equal(const Frag& x, const Frag& y);
 
 // ---- sq_segment.cpp  (host control of K2; counting data comes from the GPU summaries)
 struct SegPlan;  // sq_segment.cpp
-int segment_prepare(sq_ctx* c, std::shared_ptr<SegPlan>& plan, int64_t& n_break, std::vector<Blk>& bamdiscordant_sorted);
-int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds);
+// static part (cluster table from the chimeric fragments) + the stream scans that need nothing from other shards
+int segment_static(sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::vector<Blk>& bamdiscordant_sorted, bool fetch, int64_t& trigger_last, long long& other_max,
+                   int32_t first_kept[2]);
+// zero-coverage records, stretches to replay, host copies of those stretches; n_break = consumed prefix of the LOCAL stream
+int segment_prepare(sq_ctx* c, SegPlan& plan, int64_t& n_break);
+// `virtual_back`: an earlier shard has emitted a node (it lies on an earlier chromosome); `sens` collects the pending
+// node starts that were compared with that node's end without a chromosome test (SegmentGraph.cpp:623)
+int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds, bool virtual_back, std::vector<int32_t>* sens);
 int tile_genome(sq_ctx* c, std::vector<Node>& seeds, std::vector<Node>& out);
 
 // ---- sq_graph.cpp
@@ -188,9 +218,12 @@ int dev_download_records(sq_ctx* c, HostBatch& hb);
 struct SegSupport {
     std::vector<int32_t> trigger, zidx, z_ochr, z_oright, rest_cluster, rest_pos, rest_len;
 };
-int dev_segment_support(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<int32_t>& cl_start, const std::vector<int32_t>& cl_right, int64_t n_rest, SegSupport& out);
+int dev_stream_scan(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<int32_t>& cl_start, const std::vector<int32_t>& cl_right, bool fetch, SegSupport& out,
+                    long long& other_max, int32_t first_kept[2]);
+int dev_segment_support(sq_ctx* c, int ncl, int64_t n_rest, SegSupport& out);
 int dev_fetch_stream(sq_ctx* c, const std::vector<std::pair<int64_t, int64_t>>& ranges, StreamRec* dst);
-int dev_classify_and_summarise(sq_ctx* c, std::vector<StreamRec>& recs, std::vector<int32_t>& rest_refpos, std::vector<int32_t>& rest_matchref);
+int dev_classify(sq_ctx* c, int32_t last_info[4]);  // last_info (may be null): {has pass-1, its lists empty, has pass-2, its lists empty}
+int dev_dedup_summarise(sq_ctx* c);
 int dev_gather_other(sq_ctx* c, int64_t n_break, bool& has_tiny, std::vector<int32_t>& other_chr, std::vector<int32_t>& other_pos, std::vector<int32_t>& other_len);
 int dev_node_depth(sq_ctx* c, const std::vector<Node>& nodes, int64_t n_break, std::vector<int32_t>& support, std::vector<int64_t>& sumlen,
                    bool& need_exact_other, std::vector<int32_t>& amb_plus, std::vector<int32_t>& amb_minus, std::vector<int32_t>& unused);
@@ -199,6 +232,13 @@ int dev_connected_components(sq_ctx* c, int n_nodes, const std::vector<Edge>& ed
 struct SmallProblem { int n; int eoff, ecount; };  // edges: local u,v,hu,hv,w packed as 5 ints each
 int dev_order_small(sq_ctx* c, const std::vector<SmallProblem>& probs, const std::vector<int32_t>& edges5, std::vector<int32_t>& out_mask,
                     std::vector<int32_t>& out_order, int nmax);
-int dev_breakpoint_support(sq_ctx* c, const std::vector<std::pair<int, int>>& bps_sorted, std::vector<int32_t>& coverage);
+// cur_prev: cursor position left by the records of earlier shards
+struct BpBoundary {  // what the next shard needs to know about the breakpoint cursor (SegmentGraph.cpp:3157)
+    int cur_end = 0;          // cursor after this shard's records, given the cur_prev it started from
+    bool has_p3 = false, has_event = false;
+    int64_t n_p3 = 0, absorb = 0;  // pass-3 records; those in front of the first record that moves the cursor beyond cur_prev
+};
+int dev_breakpoint_support(sq_ctx* c, const std::vector<std::pair<int, int>>& bps_sorted, std::vector<int32_t>& coverage, int cur_prev = 0, BpBoundary* bb = nullptr,
+                           bool raw_diff = false);
 
 }  // namespace sq

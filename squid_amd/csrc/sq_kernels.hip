@@ -518,13 +518,28 @@ struct FRest {
     }
 };
 
-__global__ void k_dedup(RecView R, const uint8_t* cls, const int32_t* prev1, const int32_t* prev2, uint8_t* keep) {
+// what the next shard has to know about the last pass-1 / pass-2 record of this one (last[] = inclusive max of FPrev)
+__global__ void k_last_info(RecView R, const int32_t* last, int32_t* out) {
+    for (int p = 0; p < 2; ++p) {
+        int q = last[p];
+        out[2 * p] = q >= 0 ? 1 : 0;
+        bool empty = false;
+        if (q >= 0) { ListRec l = list_rec(R, q); empty = l.nown == 0 && !l.stub; }
+        out[2 * p + 1] = empty ? 1 : 0;
+    }
+}
+// prior_mask (chromosome-sharded runs): bit0 / bit1 = a pass-1 / pass-2 record with non-empty lists precedes this
+// shard; it lies on another chromosome, so the first passing record here is not Equal to it.  Without the bit the
+// predecessor is the empty initial lastreadrec (or a record whose lists are just as empty).
+__global__ void k_dedup(RecView R, const uint8_t* cls, const int32_t* prev1, const int32_t* prev2, int prior_mask, uint8_t* keep) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R.n) return;
     uint8_t c = cls[r], k = 0;
-    if (c & C_P1) { if (!rec_equal(R, prev1[r], r)) k |= K_1; }
+    if (c & C_P1) { if (!((prev1[r] < 0 && (prior_mask & 1)) ? false : rec_equal(R, prev1[r], r))) k |= K_1; }
     if (c & C_P2) {
-        bool eq = (c & C_P1) && prev1[r] == prev2[r] ? !(k & K_1) : rec_equal(R, prev2[r], r);
+        bool eq;
+        if (prev2[r] < 0) eq = (prior_mask & 2) ? false : rec_equal(R, -1, r);
+        else eq = (c & C_P1) && prev1[r] == prev2[r] ? !(k & K_1) : rec_equal(R, prev2[r], r);
         if (!eq) {
             k |= K_2;
             // whetherbuildedge (SegmentGraph.cpp:1601-1605) on the stub-augmented, sorted record
@@ -594,7 +609,15 @@ struct FOtherKey {
         return ((long long)r.refid << 32) | (unsigned int)(r.fb_refpos + r.fb_matchref);
     }
 };
-__global__ void k_zerocov(const StreamRec* sr, int64_t k, ClusterView C, const long long* other_before, int RL, uint8_t* zflag, int32_t* flags) {
+// k counts the records of the local stream plus, in a sharded run, the appended first kept record of the next shard
+// (index k_own; its running pair is the aggregate of the whole local stream).  `seed` = running pair of earlier shards.
+__device__ __forceinline__ long long other_at(const long long* other_before, const long long* other_all, int64_t k_own, long long seed, int64_t i) {
+    long long ob = i < k_own ? other_before[i] : *other_all;
+    if (ob < seed) ob = seed;
+    return ob < 0 ? 0 : ob;  // initial otherChr = 0, otherrightmost = 0
+}
+__global__ void k_zerocov(const StreamRec* sr, int64_t k, int64_t k_own, ClusterView C, const long long* other_before, const long long* other_all, long long seed, int RL, uint8_t* zflag,
+                          int32_t* flags) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= k) return;
     const StreamRec r = sr[i];
@@ -605,8 +628,7 @@ __global__ void k_zerocov(const StreamRec* sr, int64_t k, ClusterView C, const l
     const int K = clusters_passed(C, r.refid, r.pos);
     const int disChr = K > 0 ? C.chr[K - 1] : 0, disRight = K > 0 ? C.right[K - 1] : 0;
     const int dnChr = K < C.n ? C.chr[K] : 0, dnPos = K < C.n ? C.start[K] : 0;  // zero sentinel after the last cluster (ledger B21)
-    long long ob = other_before[i];
-    if (ob < 0) ob = 0;  // initial otherChr = 0, otherrightmost = 0
+    const long long ob = other_at(other_before, other_all, k_own, seed, i);
     const int oChr = (int)(ob >> 32), oRight = (int)(ob & 0xffffffffll);
     const bool disLead = disChr > oChr || (disChr == oChr && disRight > oRight);
     const int curRight = disLead ? disRight : oRight, curChr = disChr > oChr ? disChr : oChr;
@@ -614,11 +636,11 @@ __global__ void k_zerocov(const StreamRec* sr, int64_t k, ClusterView C, const l
     zflag[i] = z ? 1 : 0;
 }
 struct FByte { const uint8_t* a; __device__ int operator()(int64_t i) const { return a[i]; } };
-__global__ void k_zgather(int64_t k, const uint8_t* zflag, const int32_t* zrank, const long long* other_before, int32_t* zidx, int32_t* zchr, int32_t* zright) {
+__global__ void k_zgather(int64_t k, int64_t k_own, const uint8_t* zflag, const int32_t* zrank, const long long* other_before, const long long* other_all, long long seed, int32_t* zidx,
+                          int32_t* zchr, int32_t* zright) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= k || !zflag[i]) return;
-    long long ob = other_before[i];
-    if (ob < 0) ob = 0;
+    const long long ob = other_at(other_before, other_all, k_own, seed, i);
     int s = zrank[i];
     zidx[s] = (int32_t)i; zchr[s] = (int)(ob >> 32); zright[s] = (int)(ob & 0xffffffffll);
 }
@@ -1038,28 +1060,42 @@ __device__ __forceinline__ void bp_contribute(const RecView& R, const BPView& B,
     if (lo < cur) lo = cur;
     if (lo < hi) { atomicAdd(&diff[lo], sign); atomicAdd(&diff[hi], -sign); }
 }
-__global__ void k_bp_count(RecView R, BPView B, const uint8_t* cls, const int32_t* m, const int32_t* Mx, int32_t* ev_by_M, int32_t* diff) {
+// cur0 = cursor position before the first record (0, or what the records of earlier shards left behind)
+__global__ void k_bp_count(RecView R, BPView B, const uint8_t* cls, const int32_t* m, const int32_t* Mx, int cur0, int32_t* ev_by_M, int32_t* diff) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R.n || !(cls[r] & C_P3)) return;
-    int before = Mx[r] > 0 ? Mx[r] : 0, M = m[r] > before ? m[r] : before;
-    if (M > before) ev_by_M[M] = (int32_t)r;  // M values of events are distinct and increase along the stream
+    int before = Mx[r] > cur0 ? Mx[r] : cur0, M = m[r] > before ? m[r] : before;
+    if (M > before) {
+        ev_by_M[M] = (int32_t)r;  // M values of events are distinct and increase along the stream
+        if (Mx[r] <= cur0) ev_by_M[0] = (int32_t)r;  // slot 0 (no event has M == 0): the first event of the stream
+    }
     bp_contribute(R, B, r, before, M, 1, diff);
+}
+// sharded runs: number of pass-3 records, and how many of them come before the first event (they can absorb a cursor
+// that the earlier shards have left behind schedule without changing anything here)
+__global__ void k_bp_boundary(const uint8_t* cls, int64_t n, const int32_t* ev_by_M, unsigned long long* out) {
+    const int64_t first = ev_by_M[0] < 0 ? n : ev_by_M[0];
+    unsigned long long all = 0, before = 0;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x)
+        if (cls[r] & C_P3) { ++all; if (r < first) ++before; }
+    for (int d = 32; d >= 1; d >>= 1) { all += __shfl_xor(all, d, 64); before += __shfl_xor(before, d, 64); }
+    if ((threadIdx.x & 63) == 0 && all) { atomicAdd(&out[0], all); if (before) atomicAdd(&out[1], before); }
 }
 // one wave per event: APPLY == false records where the cursor catches up, APPLY == true corrects the passed records
 template <bool APPLY>
-__global__ __launch_bounds__(64) void k_bp_walk(RecView R, BPView B, const uint8_t* cls, const int32_t* m, const int32_t* Mx, const int32_t* ev_by_M, int32_t* end_by_M,
-                                               const int32_t* valid, int32_t* diff) {
+__global__ __launch_bounds__(64) void k_bp_walk(RecView R, BPView B, const uint8_t* cls, const int32_t* m, const int32_t* Mx, int cur0, const int32_t* ev_by_M, int32_t* end_by_M,
+                                               const int32_t* valid, int32_t* diff, int32_t* lag_end) {
     const int v = blockIdx.x + 1, lane = threadIdx.x;
     const int64_t r0 = ev_by_M[v];
     if (r0 < 0) return;
     if (APPLY && !valid[v]) return;
-    int cur = Mx[r0] > 0 ? Mx[r0] : 0;
+    int cur = Mx[r0] > cur0 ? Mx[r0] : cur0;
     int64_t end = R.n;
     for (int64_t base = r0; base < R.n; base += 64) {
         const int64_t r = base + lane;
         const bool ok = r < R.n && (cls[r] & C_P3);
         int mm = INT_MIN, MM = 0, before_a = 0;
-        if (ok) { mm = m[r]; before_a = Mx[r] > 0 ? Mx[r] : 0; MM = mm > before_a ? mm : before_a; }
+        if (ok) { mm = m[r]; before_a = Mx[r] > cur0 ? Mx[r] : cur0; MM = mm > before_a ? mm : before_a; }
         int mycur = -1, mybefore = 0, done = -1;
         unsigned long long todo = __ballot(ok);
         while (todo) {
@@ -1078,6 +1114,7 @@ __global__ __launch_bounds__(64) void k_bp_walk(RecView R, BPView B, const uint8
         if (done >= 0) { end = base + done; break; }
     }
     if (!APPLY && lane == 0) end_by_M[v] = (int32_t)(end < R.n ? end : R.n);
+    if (APPLY && lane == 0 && end >= R.n) *lag_end = cur;  // the stream ended before the cursor caught up (only the last valid walk can)
 }
 __global__ __launch_bounds__(64) void k_bp_chain(int nb, const int32_t* ev_by_M, const int32_t* end_by_M, int32_t* valid) {
     const int lane = threadIdx.x;
@@ -1461,15 +1498,13 @@ static int upload_nodes(sq_ctx* c, const std::vector<Node>& nodes, NodeView& nv)
     return SQ_OK;
 }
 
-// K1: filters, duplicate drop, stream summaries for the segmentation automaton
-int dev_classify_and_summarise(sq_ctx* c, std::vector<StreamRec>& recs, std::vector<int32_t>& rest_refpos, std::vector<int32_t>& rest_matchref) {
+// K1a: record filters and the "previous passing record" links
+int dev_classify(sq_ctx* c, int32_t last_info[4]) {
     DeviceRecords& D = *c->dev;
     hipStream_t s = c->stream;
     const int64_t n = D.n;
     RecView R = D.view();
     HIPCHK(D.cls.reserve(n)); HIPCHK(D.keep.reserve(n)); HIPCHK(D.prev1.reserve(n)); HIPCHK(D.prev2.reserve(n)); HIPCHK(D.rank1.reserve(n)); HIPCHK(D.restoff.reserve(n));
-    int32_t* tot = D.flags.p + 8;
-    int32_t h_tot[2] = {0, 0};
     if (std::getenv("SQUID_CALIB")) {
         const int64_t words = (int64_t)1 << 28;  // 1 GiB: larger than the 256 MiB Infinity Cache
         HIPCHK(D.calib.reserve(words));
@@ -1477,24 +1512,41 @@ int dev_classify_and_summarise(sq_ctx* c, std::vector<StreamRec>& recs, std::vec
         EvTimer t(c, "k_calib_read4", 4.0 * words);
         hipLaunchKernelGGL(k_calib_read4, dim3(2048), dim3(256), 0, s, D.calib.p, words, D.flags.p + 16);
     }
+    if (last_info) { last_info[0] = last_info[1] = last_info[2] = last_info[3] = 0; }
+    if (n == 0) return SQ_OK;
+    int32_t* last = D.flags.p + 20;  // [20],[21]: index of the last pass-1 / pass-2 record
+    { EvTimer t(c, "k_classify", 28.0 * n + 12.0 * D.nb); hipLaunchKernelGGL(k_classify, grid_for(n, 256), dim3(256), 0, s, R, c->P.min_mapqual, D.cls.p); }
+    { EvTimer t(c, "scan_prev", 2.0 * n);
+      HIPCHK((device_scan<OpMax, true>(s, n, FPrev{D.cls.p, C_P1}, D.prev1.p, D.spine, last)));
+      HIPCHK((device_scan<OpMax, true>(s, n, FPrev{D.cls.p, C_P2}, D.prev2.p, D.spine, last + 1))); }
+    if (last_info) {
+        hipLaunchKernelGGL(k_last_info, dim3(1), dim3(1), 0, s, R, last, D.flags.p + 24);
+        HIPCHK(hipMemcpyAsync(last_info, D.flags.p + 24, 16, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    return SQ_OK;
+}
+// K1b: duplicate drop, stream summaries for the segmentation automaton
+int dev_dedup_summarise(sq_ctx* c) {
+    DeviceRecords& D = *c->dev;
+    hipStream_t s = c->stream;
+    const int64_t n = D.n;
+    RecView R = D.view();
+    int32_t* tot = D.flags.p + 8;
+    int32_t h_tot[2] = {0, 0};
     if (n > 0) {
         const double bytes_rec = 32.0 * n + 12.0 * D.nb;
-        { EvTimer t(c, "k_classify", 28.0 * n + 12.0 * D.nb); hipLaunchKernelGGL(k_classify, grid_for(n, 256), dim3(256), 0, s, R, c->P.min_mapqual, D.cls.p); }
-        { EvTimer t(c, "scan_prev", 2.0 * n);
-          HIPCHK((device_scan<OpMax, true>(s, n, FPrev{D.cls.p, C_P1}, D.prev1.p, D.spine, nullptr)));
-          HIPCHK((device_scan<OpMax, true>(s, n, FPrev{D.cls.p, C_P2}, D.prev2.p, D.spine, nullptr))); }
-        { EvTimer t(c, "k_dedup", 2.0 * bytes_rec); hipLaunchKernelGGL(k_dedup, grid_for(n, 256), dim3(256), 0, s, R, D.cls.p, D.prev1.p, D.prev2.p, D.keep.p); }
+        { EvTimer t(c, "k_dedup", 2.0 * bytes_rec); hipLaunchKernelGGL(k_dedup, grid_for(n, 256), dim3(256), 0, s, R, D.cls.p, D.prev1.p, D.prev2.p, c->shard.on ? c->shard.dedup_mask : 0, D.keep.p); }
         { EvTimer t(c, "scan_rank", 4.0 * n);
           HIPCHK((device_scan<OpSum, true>(s, n, FKeep{D.keep.p, K_1}, D.rank1.p, D.spine, tot)));
           HIPCHK((device_scan<OpSum, true>(s, n, FRest{D.keep.p, D.cls.p, D.blk_off.p}, D.restoff.p, D.spine, tot + 1))); }
         HIPCHK(hipMemcpyAsync(h_tot, tot, 8, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
     }
-    // exclusive max-scan leaves INT_MIN where nothing precedes: normalise to -1 lazily (k_dedup treats <0 as empty)
     const int64_t k1 = h_tot[0], nrest = h_tot[1];
     D.k1 = k1;
-    HIPCHK(D.srec.reserve((size_t)std::max<int64_t>(k1, 1))); HIPCHK(D.rest_refpos.reserve((size_t)std::max<int64_t>(nrest, 1))); HIPCHK(D.rest_matchref.reserve((size_t)std::max<int64_t>(nrest, 1)));
-    (void)recs; (void)rest_refpos; (void)rest_matchref;  // the host fetches only the stretches it replays (dev_fetch_stream)
+    // one spare slot: a sharded run appends the first kept record of the next shard (Shard::has_terminal)
+    HIPCHK(D.srec.reserve((size_t)k1 + 1)); HIPCHK(D.rest_refpos.reserve((size_t)std::max<int64_t>(nrest, 1))); HIPCHK(D.rest_matchref.reserve((size_t)std::max<int64_t>(nrest, 1)));
     if (n > 0) {
         EvTimer t(c, "k_summarise", 28.0 * n + 12.0 * D.nb + 20.0 * k1);
         hipLaunchKernelGGL(k_summarise, grid_for(n, 256), dim3(256), 0, s, R, D.cls.p, D.keep.p, D.rank1.p, D.restoff.p, D.srec.p, D.rest_refpos.p, D.rest_matchref.p);
@@ -1504,14 +1556,17 @@ int dev_classify_and_summarise(sq_ctx* c, std::vector<StreamRec>& recs, std::vec
     return SQ_OK;
 }
 
-// K2 support: cluster triggers, zero-coverage records (+ running other-state), ConcordRest candidates
-int dev_segment_support(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<int32_t>& cl_start, const std::vector<int32_t>& cl_right, int64_t n_rest, SegSupport& out) {
+// K2 support, part 1 (needs nothing from other shards): cluster table upload, running (otherChr, otherrightmost)
+// scan, trigger record of every cluster.  With `fetch` the triggers, the scan aggregate and the first kept record
+// are copied back here (a sharded run publishes them); otherwise dev_segment_support fetches the triggers.
+int dev_stream_scan(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<int32_t>& cl_start, const std::vector<int32_t>& cl_right, bool fetch, SegSupport& out,
+                    long long& other_max, int32_t first_kept[2]) {
     DeviceRecords& D = *c->dev;
     hipStream_t s = c->stream;
     const int64_t k = D.k1;
     const int ncl = (int)cl_chr.size();
     out.trigger.assign(ncl, (int32_t)k);
-    out.zidx.clear(); out.z_ochr.clear(); out.z_oright.clear(); out.rest_cluster.clear(); out.rest_pos.clear(); out.rest_len.clear();
+    other_max = INT64_MIN;
     if (k == 0) return SQ_OK;
     HIPCHK(D.cl_chr.reserve(std::max(ncl, 1))); HIPCHK(D.cl_start.reserve(std::max(ncl, 1))); HIPCHK(D.cl_right.reserve(std::max(ncl, 1))); HIPCHK(D.trig.reserve(std::max(ncl, 1)));
     if (ncl) {
@@ -1519,18 +1574,48 @@ int dev_segment_support(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std
         HIPCHK(hipMemcpyAsync(D.cl_right.p, cl_right.data(), ncl * 4, hipMemcpyHostToDevice, s));
     }
     ClusterView C{ncl, D.cl_chr.p, D.cl_start.p, D.cl_right.p};
-    HIPCHK(D.other64.reserve(k)); HIPCHK(D.zflag.reserve(k)); HIPCHK(D.scratch_a.reserve(k));
+    HIPCHK(D.other64.reserve(k + 1)); HIPCHK(D.zflag.reserve(k + 1)); HIPCHK(D.scratch_a.reserve(k + 1));
+    { EvTimer t(c, "k_stream_scan", 20.0 * k);
+      HIPCHK((device_scan<OpMax64, true>(s, k, FOtherKey{D.srec.p}, D.other64.p, D.spine64, D.other64.p + k)));  // aggregate behind the last element
+      if (ncl) hipLaunchKernelGGL(k_triggers, grid_for(ncl, 64), dim3(64), 0, s, D.srec.p, k, C, D.trig.p); }
+    if (fetch) {
+        StreamRec first;
+        HIPCHK(hipMemcpyAsync(&other_max, D.other64.p + k, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(&first, D.srec.p, sizeof first, hipMemcpyDeviceToHost, s));
+        if (ncl) HIPCHK(hipMemcpyAsync(out.trigger.data(), D.trig.p, ncl * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        first_kept[0] = first.refid; first_kept[1] = first.pos;
+    }
+    return SQ_OK;
+}
+
+// K2 support, part 2: zero-coverage records (+ the running pair in front of each), ConcordRest candidates.  A sharded
+// run first appends the first kept record of the next shard to the summaries (it ends this shard's last stretch).
+int dev_segment_support(sq_ctx* c, int ncl, int64_t n_rest, SegSupport& out) {
+    DeviceRecords& D = *c->dev;
+    hipStream_t s = c->stream;
+    const Shard& sh = c->shard;
+    const int64_t k_own = D.k1;
+    const bool term = sh.on && sh.has_terminal && k_own > 0;
+    const int64_t k = k_own + (term ? 1 : 0);
+    out.zidx.clear(); out.z_ochr.clear(); out.z_oright.clear(); out.rest_cluster.clear(); out.rest_pos.clear(); out.rest_len.clear();
+    if (k_own == 0) return SQ_OK;
+    if (term) {
+        StreamRec t{};
+        t.refid = sh.term_refid; t.pos = sh.term_pos;
+        HIPCHK(hipMemcpyAsync(D.srec.p + k_own, &t, sizeof t, hipMemcpyHostToDevice, s));
+    }
+    const long long seed = sh.on ? sh.other_seed : INT64_MIN;
+    ClusterView C{ncl, D.cl_chr.p, D.cl_start.p, D.cl_right.p};
     HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
     int32_t* tot = D.flags.p + 8;
-    { EvTimer t(c, "k_segment_support", 3.0 * 20.0 * k);
-      HIPCHK((device_scan<OpMax64, true>(s, k, FOtherKey{D.srec.p}, D.other64.p, D.spine64, nullptr)));
-      hipLaunchKernelGGL(k_zerocov, grid_for(k, 256), dim3(256), 0, s, D.srec.p, k, C, D.other64.p, c->read_len, D.zflag.p, D.flags.p);
-      HIPCHK((device_scan<OpSum, true>(s, k, FByte{D.zflag.p}, D.scratch_a.p, D.spine, tot)));
-      if (ncl) hipLaunchKernelGGL(k_triggers, grid_for(ncl, 64), dim3(64), 0, s, D.srec.p, k, C, D.trig.p); }
+    { EvTimer t(c, "k_segment_support", 2.0 * 20.0 * k);
+      hipLaunchKernelGGL(k_zerocov, grid_for(k, 256), dim3(256), 0, s, D.srec.p, k, k_own, C, D.other64.p, D.other64.p + k_own, seed, c->read_len, D.zflag.p, D.flags.p);
+      HIPCHK((device_scan<OpSum, true>(s, k, FByte{D.zflag.p}, D.scratch_a.p, D.spine, tot))); }
     int32_t hz[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(&hz[0], tot, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&hz[1], D.flags.p, 4, hipMemcpyDeviceToHost, s));
-    if (ncl) HIPCHK(hipMemcpyAsync(out.trigger.data(), D.trig.p, ncl * 4, hipMemcpyDeviceToHost, s));
+    if (ncl && !sh.on) HIPCHK(hipMemcpyAsync(out.trigger.data(), D.trig.p, ncl * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (hz[1] & 1) return fail(c, SQ_E_UNSORTED, "concordant BAM is not coordinate sorted (README.md:23 requires it)");
     const int nz = hz[0];
@@ -1539,15 +1624,15 @@ int dev_segment_support(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std
     HIPCHK(D.b0_b.reserve(std::max<int64_t>(n_rest, 1))); HIPCHK(D.b0_home.reserve(std::max<int64_t>(n_rest, 1))); HIPCHK(D.part_prev.reserve(std::max<int64_t>(n_rest, 1)));
     if (nz) {
         EvTimer t(c, "k_zgather", 13.0 * k);
-        hipLaunchKernelGGL(k_zgather, grid_for(k, 256), dim3(256), 0, s, k, D.zflag.p, D.scratch_a.p, D.other64.p, D.scratch_b.p, D.scratch_c.p, D.b0_a.p);
+        hipLaunchKernelGGL(k_zgather, grid_for(k, 256), dim3(256), 0, s, k, k_own, D.zflag.p, D.scratch_a.p, D.other64.p, D.other64.p + k_own, seed, D.scratch_b.p, D.scratch_c.p, D.b0_a.p);
         HIPCHK(hipMemcpyAsync(out.zidx.data(), D.scratch_b.p, nz * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(out.z_ochr.data(), D.scratch_c.p, nz * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(out.z_oright.data(), D.b0_a.p, nz * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
     }
     if (ncl && n_rest) {
         HIPCHK(hipMemsetAsync(D.flags.p + 4, 0, 4, s));
-        { EvTimer t(c, "k_rest_candidates", 20.0 * k + 8.0 * n_rest);
-          hipLaunchKernelGGL(k_rest_candidates, grid_for(k, 256), dim3(256), 0, s, D.srec.p, k, C, c->read_len, D.rest_refpos.p, D.rest_matchref.p, D.flags.p + 4, D.b0_b.p, D.b0_home.p, D.part_prev.p); }
+        { EvTimer t(c, "k_rest_candidates", 20.0 * k_own + 8.0 * n_rest);
+          hipLaunchKernelGGL(k_rest_candidates, grid_for(k_own, 256), dim3(256), 0, s, D.srec.p, k_own, C, c->read_len, D.rest_refpos.p, D.rest_matchref.p, D.flags.p + 4, D.b0_b.p, D.b0_home.p, D.part_prev.p); }
         int32_t cnt = 0;
         HIPCHK(hipMemcpyAsync(&cnt, D.flags.p + 4, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -1759,12 +1844,13 @@ int dev_order_small(sq_ctx* c, const std::vector<SmallProblem>& probs, const std
 }
 
 // K10: concordant-fragment support of every breakpoint
-int dev_breakpoint_support(sq_ctx* c, const std::vector<std::pair<int, int>>& bps, std::vector<int32_t>& coverage) {
+int dev_breakpoint_support(sq_ctx* c, const std::vector<std::pair<int, int>>& bps, std::vector<int32_t>& coverage, int cur_prev, BpBoundary* bb, bool raw_diff) {
     DeviceRecords& D = *c->dev;
     hipStream_t s = c->stream;
     const int64_t n = D.n;
     const int nb = (int)bps.size();
-    coverage.assign(nb, 0);
+    coverage.assign(raw_diff ? nb + 1 : nb, 0);
+    if (bb) { *bb = BpBoundary(); bb->cur_end = cur_prev; }
     if (!nb || !n) return SQ_OK;
     std::vector<int32_t> bc(nb), bp(nb);
     for (int i = 0; i < nb; ++i) { bc[i] = bps[i].first; bp[i] = bps[i].second; }
@@ -1779,15 +1865,35 @@ int dev_breakpoint_support(sq_ctx* c, const std::vector<std::pair<int, int>>& bp
     HIPCHK(hipMemsetAsync(D.bp_ev.p, 0xFF, (nb + 1) * 4, s));
     int32_t *m = D.scratch_b.p, *Mx = D.scratch_a.p;
     { EvTimer t(c, "k_bp_m", 27.0 * n); hipLaunchKernelGGL(k_bp_m, grid_for(n, 256), dim3(256), 0, s, R, B, D.cls.p, m); }
-    { EvTimer t(c, "scan_bp_cursor", 12.0 * n); HIPCHK((device_scan<OpMax, true>(s, n, FArr{m}, Mx, D.spine, nullptr))); }  // max of m over earlier records
-    { EvTimer t(c, "k_bp_count", 31.0 * n); hipLaunchKernelGGL(k_bp_count, grid_for(n, 256), dim3(256), 0, s, R, B, D.cls.p, m, Mx, D.bp_ev.p, D.acc_c.p); }
+    int32_t* agg = D.flags.p + 28;  // [28] max of m over all records, [29] cursor of a walk that ran into the end of the stream
+    const int32_t minus1 = -1;
+    HIPCHK(hipMemcpyAsync(agg + 1, &minus1, 4, hipMemcpyHostToDevice, s));
+    { EvTimer t(c, "scan_bp_cursor", 12.0 * n); HIPCHK((device_scan<OpMax, true>(s, n, FArr{m}, Mx, D.spine, agg))); }  // max of m over earlier records
+    { EvTimer t(c, "k_bp_count", 31.0 * n); hipLaunchKernelGGL(k_bp_count, grid_for(n, 256), dim3(256), 0, s, R, B, D.cls.p, m, Mx, cur_prev, D.bp_ev.p, D.acc_c.p); }
     { EvTimer t(c, "k_bp_walk", 0);
-      hipLaunchKernelGGL(k_bp_walk<false>, dim3(nb), dim3(64), 0, s, R, B, D.cls.p, m, Mx, D.bp_ev.p, D.bp_end.p, D.bp_valid.p, D.acc_c.p);
+      hipLaunchKernelGGL(k_bp_walk<false>, dim3(nb), dim3(64), 0, s, R, B, D.cls.p, m, Mx, cur_prev, D.bp_ev.p, D.bp_end.p, D.bp_valid.p, D.acc_c.p, agg + 1);
       hipLaunchKernelGGL(k_bp_chain, dim3(1), dim3(64), 0, s, nb, D.bp_ev.p, D.bp_end.p, D.bp_valid.p);
-      hipLaunchKernelGGL(k_bp_walk<true>, dim3(nb), dim3(64), 0, s, R, B, D.cls.p, m, Mx, D.bp_ev.p, D.bp_end.p, D.bp_valid.p, D.acc_c.p); }
+      hipLaunchKernelGGL(k_bp_walk<true>, dim3(nb), dim3(64), 0, s, R, B, D.cls.p, m, Mx, cur_prev, D.bp_ev.p, D.bp_end.p, D.bp_valid.p, D.acc_c.p, agg + 1); }
+    unsigned long long hcnt[3] = {0, 0, 0};
+    if (bb) {
+        HIPCHK(D.okey.reserve(4));
+        HIPCHK(hipMemsetAsync(D.okey.p, 0, 16, s));
+        hipLaunchKernelGGL(k_bp_boundary, dim3(1024), dim3(256), 0, s, D.cls.p, n, D.bp_ev.p, D.okey.p);
+        HIPCHK(hipMemcpyAsync(hcnt, D.okey.p, 16, hipMemcpyDeviceToHost, s));
+    }
     std::vector<int32_t> diff(nb + 1);
+    int32_t hagg[2] = {0, 0}, first_ev = -1;
+    HIPCHK(hipMemcpyAsync(&first_ev, D.bp_ev.p, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(diff.data(), D.acc_c.p, (nb + 1) * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hagg, agg, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    if (bb) {
+        bb->cur_end = hagg[1] >= 0 ? hagg[1] : std::max(hagg[0], cur_prev);
+        bb->has_p3 = hagg[0] != INT_MIN;
+        bb->has_event = first_ev >= 0;
+        bb->n_p3 = (int64_t)hcnt[0]; bb->absorb = (int64_t)hcnt[1];
+    }
+    if (raw_diff) { coverage = diff; return SQ_OK; }
     int run = 0;
     for (int i = 0; i < nb; ++i) { run += diff[i]; coverage[i] = run; }
     return SQ_OK;

@@ -23,21 +23,40 @@ struct El {  // a window element = first block of a concordant record
     bool rev;
 };
 
+struct Cluster { int ds, de, chr, start, right; };
+// what the automaton only reads: fixed by the chimeric fragments (and, for rest_by_cluster, by GPU scans)
+struct SegStatic {
+    std::vector<Blk> D;              // sorted discordant blocks + zero sentinel at [nd] (ledger B21)
+    int nd = 0;
+    std::vector<std::pair<int, int>> part;  // PartAlignPos
+    std::vector<Cluster> clusters;
+    std::vector<std::vector<std::pair<int, int>>> rest_by_cluster;
+    // the clusters are fixed by the sorted discordant blocks alone (SegmentGraph.cpp:341-348 / 604-611)
+    void build_clusters(int RL) {
+        int s0 = 0;
+        while (s0 != nd) {
+            int right = D[s0].refpos + D[s0].matchref, e = s0;
+            for (; e != nd && D[e].refid == D[s0].refid && D[e].refpos < right + RL; ++e) right = std::max(right, D[e].refpos + D[e].matchref);
+            clusters.push_back(Cluster{s0, e, D[s0].refid, D[s0].refpos, right});
+            s0 = e;
+        }
+    }
+};
+
 struct Seg {
     const sq_ctx* c;
     const StreamRec* recs;  // host copy of the stream summaries, valid only inside the replayed stretches
     const int RL;
     static constexpr int T = 3;     // thresh (SegmentGraph.cpp:286)
     static constexpr int NEAR = 60;  // thresh*20
-    std::vector<Blk> D;              // sorted discordant blocks + zero sentinel at [nd] (ledger B21)
-    int nd = 0;
-    std::vector<std::pair<int, int>> part;  // PartAlignPos
+    const std::vector<Blk>& D;
+    const int nd;
+    const std::vector<std::pair<int, int>>& part;
+    const std::vector<Cluster>& clusters;
+    const std::vector<std::vector<std::pair<int, int>>>& rest_by_cluster;
     std::vector<int32_t> cw, pw;     // windows: indices into in.recs (ConcordantCluster / PartialAlignCluster)
     int co = 0, po = 0;              // window offsets
     const std::vector<std::pair<int, int>>* rest = nullptr;  // live ConcordRest content of the current cluster: (refpos, matchref) on its chromosome
-    struct Cluster { int ds, de, chr, start, right; };
-    std::vector<Cluster> clusters;
-    std::vector<std::vector<std::pair<int, int>>> rest_by_cluster;
     int kc = -1;                     // index of the current cluster (ds == clusters[kc].ds)
     std::vector<Node>& out;
     int ds = 0, de = 0, dcur = 0;    // itdisstart / itdisend / itdiscurrent
@@ -45,7 +64,8 @@ struct Seg {
     int disChr = 0, otherChr = 0, nextdisChr = 0, disright = 0, otherright = 0, nextdisright = 0;
     int markStart = -1, markChr = -1;
 
-    Seg(const sq_ctx* c, const StreamRec* recs, std::vector<Node>& out) : c(c), recs(recs), RL(c->read_len), out(out) {}
+    Seg(const sq_ctx* c, const StreamRec* recs, const SegStatic& st, std::vector<Node>& out)
+        : c(c), recs(recs), RL(c->read_len), D(st.D), nd(st.nd), part(st.part), clusters(st.clusters), rest_by_cluster(st.rest_by_cluster), out(out) {}
 
     El el(int32_t idx) const {
         const StreamRec& r = recs[idx];
@@ -56,17 +76,6 @@ struct Seg {
     bool have_back() const { return !out.empty(); }
     int back_end() const { return out.back().pos + out.back().len; }
 
-    // the clusters are fixed by the sorted discordant blocks alone (SegmentGraph.cpp:341-348 / 604-611)
-    void build_clusters() {
-        int s0 = 0, nr = 0, nc = 0;
-        while (s0 != nd) {
-            int right = D[s0].refpos + D[s0].matchref, e = s0;
-            for (; e != nd && D[e].refid == D[s0].refid && D[e].refpos < right + RL; ++e) right = std::max(right, D[e].refpos + D[e].matchref);
-            clusters.push_back(Cluster{s0, e, D[s0].refid, D[s0].refpos, right});
-            s0 = e;
-        }
-        (void)nr; (void)nc;
-    }
     void new_cluster() {
         ++kc;
         disright = nextdisright; disChr = nextdisChr;
@@ -235,23 +244,21 @@ struct Seg {
 }  // namespace
 
 struct SegPlan {
-    std::vector<Node> sink;
-    Seg S;
+    SegStatic st;
     SegSupport sup;
     std::vector<int> active;
-    int64_t K = 0;
-    SegPlan(sq_ctx* c) : S(c, nullptr, sink) {}
+    int64_t K = 0;        // kept records of the local stream
+    int64_t K_eff = 0;    // + the appended first kept record of the next shard
+    int k0 = 0;           // clusters that an earlier shard's closing record has already passed
+    bool skip_first = false;  // the local stream does not start the global one: its first record only opens a stretch
 };
 
-// static part: discordant blocks, clip positions, cluster table, GPU scans (triggers, zero-coverage records,
-// ConcordRest candidates), host copies of the stretches that will be replayed
-int segment_prepare(sq_ctx* c, std::shared_ptr<SegPlan>& plan, int64_t& n_break, std::vector<Blk>& disc_sorted) {
-    plan = std::make_shared<SegPlan>(c);
+// static part: discordant blocks, clip positions, cluster table; stream scans that need nothing from other shards
+int segment_static(sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::vector<Blk>& disc_sorted, bool fetch, int64_t& trigger_last, long long& other_max, int32_t first_kept[2]) {
+    plan = std::make_shared<SegPlan>();
     const int64_t K = c->counts.n_kept_p1;
     plan->K = K;
-    if ((int64_t)c->stream_host.size() < K) c->stream_host.resize((size_t)K);  // only the replayed stretches are ever filled in
-    Seg& S = plan->S;
-    S.recs = c->stream_host.data();
+    SegStatic& S = plan->st;
     // ---- discordant blocks and clip positions of the chimeric fragments (SegmentGraph.cpp:203-264)
     S.part.assign(c->ref_len.size(), std::make_pair(0, 0));  // ledger B10
     std::vector<Blk>& D = S.D;
@@ -298,40 +305,77 @@ int segment_prepare(sq_ctx* c, std::shared_ptr<SegPlan>& plan, int64_t& n_break,
     S.nd = (int)D.size();
     disc_sorted = D;
     D.push_back(Blk{0, 0, 0, 0, 0, false, false});  // ledger B21 sentinel
-    const int nd = S.nd;
 
     // ---- static cluster table; everything stream-sized comes from the GPU
-    S.build_clusters();
+    S.build_clusters(c->read_len);
     const int ncl = (int)S.clusters.size();
     std::vector<int32_t> cl_chr(ncl), cl_start(ncl), cl_right(ncl);
     for (int k = 0; k < ncl; ++k) { cl_chr[k] = S.clusters[k].chr; cl_start[k] = S.clusters[k].start; cl_right[k] = S.clusters[k].right; }
-    SegSupport& sup = plan->sup;
-    int rc = dev_segment_support(c, cl_chr, cl_start, cl_right, c->counts.n_kept_p2, sup);
+    int rc = dev_stream_scan(c, cl_chr, cl_start, cl_right, fetch, plan->sup, other_max, first_kept);
     if (rc) return rc;
+    trigger_last = ncl ? plan->sup.trigger[ncl - 1] : K;  // only meaningful with `fetch`
+    return SQ_OK;
+}
+
+// zero-coverage records, triggers, stretches to replay, host copies of the summaries inside them
+int segment_prepare(sq_ctx* c, SegPlan& P, int64_t& n_break) {
+    SegStatic& S = P.st;
+    const Shard& sh = c->shard;
+    const int64_t K = P.K;
+    const int ncl = (int)S.clusters.size(), nd = S.nd;
+    if ((int64_t)c->stream_host.size() < K + 1) c->stream_host.resize((size_t)K + 1);  // only the replayed stretches are ever filled in
+    SegSupport& sup = P.sup;
+    int rc = dev_segment_support(c, ncl, c->counts.n_kept_p2, sup);
+    if (rc) return rc;
+    const bool term = sh.on && sh.has_terminal && K > 0;
+    P.K_eff = K + (term ? 1 : 0);
+    const int64_t KE = P.K_eff;
+    if (sh.on) {
+        // triggers were computed on the local stream: a cluster nobody here has passed is passed by the appended record
+        // of the next shard if that lies beyond it
+        for (int k = 0; k < ncl; ++k)
+            if (sup.trigger[k] >= K) {
+                const Cluster& cl = S.clusters[k];
+                bool beyond = term && (cl.chr < sh.term_refid || (cl.chr == sh.term_refid && cl.right < sh.term_pos));
+                sup.trigger[k] = (int32_t)(beyond ? K : KE);
+            }
+    }
     S.rest_by_cluster.assign(ncl, {});
     for (size_t i = 0; i < sup.rest_cluster.size(); ++i) S.rest_by_cluster[sup.rest_cluster[i]].push_back(std::make_pair(sup.rest_pos[i], sup.rest_len[i]));
     // ReadsMain/ReadsOther stop growing at the first record after the last cluster's trigger (SegmentGraph.cpp:338-339, B12)
-    if (ncl == 0) n_break = std::min<int64_t>(K, 1);
-    else n_break = std::min<int64_t>(K, (int64_t)sup.trigger[ncl - 1] + 2);
+    if (!sh.on) {
+        if (ncl == 0) n_break = std::min<int64_t>(K, 1);
+        else n_break = std::min<int64_t>(K, (int64_t)sup.trigger[ncl - 1] + 2);
+    } else n_break = std::max<int64_t>(0, std::min<int64_t>(K, sh.n_break_global - sh.kept_before));
+    P.active.clear();
     if (nd == 0 || K == 0) return SQ_OK;
 
     // ---- stretches between zero-coverage records; a stretch j covers: the push step of its first record lo (a
     // zero-coverage record, or -1 for the head of the stream), full steps of lo+1 .. hi-1, and the cluster events
-    // plus the zero-coverage step of its last record hi (hi == K: the stream ends inside the stretch)
+    // plus the zero-coverage step of its last record hi (hi == K_eff: the stream ends inside the stretch)
     const std::vector<int32_t>& Z = sup.zidx;
     const int nz = (int)Z.size();
     auto stretch_of = [&](int64_t t) {  // stretch whose (lo, hi] contains t
         return (int)(std::lower_bound(Z.begin(), Z.end(), (int32_t)t) - Z.begin());
     };
-    std::vector<int>& active = plan->active;
-    for (int k = 0; k < ncl; ++k) {
-        if (sup.trigger[k] >= K) break;  // never passed by a record: never segmented (the reference leaves its loop first)
+    // a shard that does not start the global stream: its first record was the closing record of an earlier shard's
+    // last stretch, which has processed every cluster that record passes
+    P.skip_first = sh.on && sh.prior_kept;
+    P.k0 = 0;
+    if (P.skip_first) {
+        const StreamRec* none = nullptr; (void)none;
+        while (P.k0 < ncl && sup.trigger[P.k0] == 0) ++P.k0;
+        if (P.k0 < ncl && (nz == 0 || Z[0] != 0)) return fail(c, SQ_E_ARG, "internal: first record of a shard is not a zero-coverage record");
+    }
+    std::vector<int>& active = P.active;
+    for (int k = P.k0; k < ncl; ++k) {
+        if (sup.trigger[k] >= KE) break;  // never passed by a record: never segmented (the reference leaves its loop first)
         int j = stretch_of(sup.trigger[k]);
         if (active.empty() || active.back() != j) active.push_back(j);
     }
     std::vector<std::pair<int64_t, int64_t>> ranges;
     for (int j : active) {
-        int64_t lo = j == 0 ? 0 : Z[j - 1], hi = j < nz ? (int64_t)Z[j] + 1 : K;
+        int64_t lo = j == 0 ? 0 : Z[j - 1], hi = j < nz ? (int64_t)Z[j] + 1 : KE;
         if (!ranges.empty() && ranges.back().second >= lo) ranges.back().second = std::max(ranges.back().second, hi);
         else ranges.push_back(std::make_pair(lo, hi));
     }
@@ -339,19 +383,19 @@ int segment_prepare(sq_ctx* c, std::shared_ptr<SegPlan>& plan, int64_t& n_break,
 }
 
 // order-dependent part: replay the reference's control automaton over the stretches that contain cluster triggers
-int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds) {
+int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds, bool virtual_back, std::vector<int32_t>* sens) {
     seeds.clear();
-    Seg& S = plan.S;
+    std::vector<Node> sink;
+    if (virtual_back) sink.push_back(Node{-1, 0, 0, 0, 0.0});  // stands for the last node of the earlier shards (an earlier chromosome)
+    Seg S(c, c->stream_host.data(), plan.st, sink);
     SegSupport& sup = plan.sup;
     const std::vector<Blk>& D = S.D;
     const int nd = S.nd, RL = c->read_len;
-    const int64_t K = plan.K;
+    const int64_t K = plan.K_eff;
     const std::vector<int32_t>& Z = sup.zidx;
     const int nz = (int)Z.size();
     const std::vector<int>& active = plan.active;
-    if (nd == 0 || K == 0) return SQ_OK;
-    std::vector<Node>& sinkref = plan.sink;
-    (void)sinkref;
+    if (nd == 0 || plan.K == 0) return SQ_OK;
 
     auto push_step = [&](int64_t i) {  // SegmentGraph.cpp:649-700 (ConcordRest pushes are covered by rest_by_cluster)
         const StreamRec& r = S.recs[i];
@@ -373,6 +417,9 @@ int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds) {
         const Blk& dn = D[S.ds];  // the zero sentinel once every cluster is consumed
         zerocov = (r.refid != curChr || r.pos > curRight + RL) && (curChr < dn.refid || (curChr == dn.refid && curRight + RL < dn.refpos));
         if (zerocov && S.markStart != -1) {  // :621-630
+            // the first test compares with the end of the last node WITHOUT looking at its chromosome: if that node came from
+            // an earlier shard the caller must check the recorded value against its real end
+            if (sens && virtual_back && sink.size() == 1 && curChr == S.markChr && curRight > S.markStart && curRight - S.markStart < Seg::NEAR) sens->push_back(S.markStart);
             if (curChr == S.markChr && curRight > S.markStart && curRight - S.markStart < Seg::NEAR && S.have_back() && S.markStart == S.back_end()) S.out.back().len += curRight - S.markStart;
             else if (curChr == S.markChr && curRight > S.markStart && curRight - S.markStart >= Seg::NEAR) S.push_node(S.markChr, S.markStart, curRight - S.markStart);
             S.markStart = -1; S.markChr = -1;
@@ -392,6 +439,7 @@ int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds) {
         return true;
     };
     S.new_cluster();  // the reference does this at its first kept record (:341)
+    for (int k = 0; k < plan.k0; ++k) S.new_cluster();  // clusters consumed by the closing record of an earlier shard
     for (int j : active) {
         const int64_t lo = j == 0 ? -1 : Z[j - 1], hi = j < nz ? Z[j] : K;
         // a zero-coverage record empties the windows and clears the pending node end; the running
@@ -413,7 +461,8 @@ int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds) {
         if (alive && hi < K) alive = head_step(hi, z);  // its push step opens the next stretch
         if (!alive) break;
     }
-    seeds = plan.sink;
+    if (virtual_back) sink.erase(sink.begin());
+    seeds = sink;
     return SQ_OK;
 }
 

@@ -1,6 +1,12 @@
-"""Multi-GPU plumbing for the sample-parallel mode (one process per GPU, torch.distributed; backend "nccl" is
-RCCL on ROCm, "gloo" on CPU for tests).  The hot path has no data-path collective in this mode: ranks only agree
-on the slowest rank's time and on the total number of alignments processed."""
+"""Multi-GPU plumbing (one process per GPU, torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" on CPU).
+
+Two modes:
+  * sample-parallel -- independent samples, one per rank, no data-path collective (`assign_samples`);
+  * chromosome-sharded -- one sample, rank r holds the concordant records of a contiguous RefID range
+    (`plan_shards`), and the stage functions of the library pause for variable-length all-gathers
+    (`TorchExchange`; include/squid_hip.h, sq_set_shard).  `VirtualWorld` drives several in-process contexts in
+    lockstep instead (tests, and one-GPU boxes).
+"""
 from __future__ import annotations
 
 
@@ -20,3 +26,110 @@ def reduce_timing(elapsed: float, n_units: float, dist=None, device="cpu"):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     return float(t[0]), float(u[0])
+
+
+def plan_shards(weights: list, world: int) -> list[tuple]:
+    """Contiguous RefID ranges [(first, end), ...], one per rank, in rank order, covering all references, with the
+    smallest possible maximum weight (weights = records per reference if known, else reference lengths).
+    Ranks beyond the number of references get empty ranges."""
+    n = len(weights)
+    if world <= 0:
+        raise ValueError("world must be positive")
+    w = [max(0, int(x)) for x in weights]
+
+    def parts_needed(cap: int) -> int:
+        parts, run = 1, 0
+        for x in w:
+            if x > cap:
+                return world + 1
+            if run + x > cap:
+                parts += 1
+                run = 0
+            run += x
+        return parts
+
+    lo, hi = (max(w) if w else 0), sum(w)
+    while lo < hi:  # smallest capacity that fits into `world` contiguous parts
+        mid = (lo + hi) // 2
+        if parts_needed(mid) <= world:
+            hi = mid
+        else:
+            lo = mid + 1
+    cap = lo
+    out, first, run = [], 0, 0
+    for i, x in enumerate(w):
+        # close the current part when the next reference does not fit (keep enough references for the remaining ranks is
+        # not required: trailing ranks may stay empty)
+        if run + x > cap and i > first:
+            out.append((first, i))
+            first, run = i, 0
+        run += x
+    out.append((first, n))
+    while len(out) < world:
+        out.append((n, n))
+    return out[:world] if len(out) == world else _merge_tail(out, world)
+
+
+def _merge_tail(parts: list, world: int) -> list:
+    head = parts[: world - 1]
+    return head + [(parts[world - 1][0], parts[-1][1])]
+
+
+class TorchExchange:
+    """bytes -> list[bytes]: variable-length all-gather over a torch.distributed group (sizes first, then padded
+    payloads).  With the nccl (= RCCL) backend the payload travels through device tensors."""
+
+    def __init__(self, dist, device="cpu", group=None):
+        self.dist, self.device, self.group = dist, device, group
+        self.calls = 0
+        self.bytes = 0
+
+    def __call__(self, blob: bytes) -> list:
+        import torch
+
+        dist = self.dist
+        world = dist.get_world_size(self.group)
+        n = torch.tensor([len(blob)], dtype=torch.int64, device=self.device)
+        sizes = [torch.zeros(1, dtype=torch.int64, device=self.device) for _ in range(world)]
+        dist.all_gather(sizes, n, group=self.group)
+        sizes = [int(x[0]) for x in sizes]
+        cap = max(max(sizes), 1)
+        mine = torch.zeros(cap, dtype=torch.uint8)
+        if blob:
+            mine[: len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+        mine = mine.to(self.device)
+        got = [torch.zeros(cap, dtype=torch.uint8, device=self.device) for _ in range(world)]
+        dist.all_gather(got, mine, group=self.group)
+        self.calls += 1
+        self.bytes += sum(sizes)
+        return [bytes(g[:s].cpu().numpy().tobytes()) for g, s in zip(got, sizes)]
+
+
+class VirtualWorld:
+    """Drives `world` in-process contexts (one per virtual rank, possibly all on one GPU) in lockstep."""
+
+    def __init__(self, contexts: list):
+        self.ctxs = contexts
+        self.exchanges = 0
+        self.bytes = 0
+
+    def _lockstep(self, step_name: str):
+        pending = list(self.ctxs)
+        while True:
+            rcs = [getattr(c, step_name)() for c in pending]
+            if all(rc == 0 for rc in rcs):
+                return
+            if not all(rc == pending[0].NEED_EXCHANGE for rc in rcs):
+                raise RuntimeError(f"ranks out of step: {rcs}")
+            parts = [c.exchange_pack() for c in pending]
+            self.exchanges += 1
+            self.bytes += sum(len(x) for x in parts)
+            for c in pending:
+                c.exchange_unpack(parts)
+
+    def build_graph(self):
+        self._lockstep("build_graph_step")
+
+    def call_sv(self) -> list:
+        self._lockstep("call_sv_step")
+        return [c.sv_rows() for c in self.ctxs]

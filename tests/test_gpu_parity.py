@@ -322,3 +322,83 @@ def test_breakpoint_cursor_on_dense_breakpoint_lists(built, synth, cfg):
             assert got == want, f"trial {trial}"
             host = ctx.bp_support([b[0] for b in bps], [b[1] for b in bps], host_walk=True).tolist()
             assert host == want
+
+
+# ---------------------------------------------------------------------- chromosome-sharded runs
+def _sharded_contexts(pre, world, plan=None):
+    from squid_amd.dist import plan_shards
+
+    _, lens = squid_amd.read_header(f"{pre}.bam")
+    plan = plan or plan_shards(lens, world)
+    ctxs = [squid_amd.Context(rank=r, world_size=world) for r in range(world)]
+    for r, c in enumerate(ctxs):
+        c.load(f"{pre}.bam", f"{pre}.chim.bam", shard=plan[r])
+    return ctxs
+
+
+class _ShardView:
+    """what _compare needs from a rank of a sharded run whose stage calls were driven by a VirtualWorld"""
+
+    def __init__(self, ctx, sv_rows):
+        self.ctx, self.rows = ctx, sv_rows
+
+    def graph(self, s):
+        return self.ctx.graph(s)
+
+    def order(self):
+        return self.ctx.order()
+
+    def breakpoints(self):
+        return self.ctx.breakpoints()
+
+    def sv_text(self):
+        self.ctx.call_sv = lambda: self.rows
+        return squid_amd.Context.sv_text(self.ctx)
+
+
+@pytest.mark.parametrize("cfg,extra,world,plan", [
+    ("T2", (), 2, None),
+    ("T2", (), 3, [(0, 1), (1, 2), (2, 3)]),
+    ("T2", (), 4, [(0, 0), (0, 2), (2, 2), (2, 3)]),  # empty shards in front and in the middle
+    ("C3", ("--records", "300000"), 4, None),
+    ("C3", ("--records", "300000"), 8, None),
+])
+def test_chromosome_sharded_run_equals_the_oracle_on_every_rank(built, synth, tmp_path, cfg, extra, world, plan, monkeypatch):
+    """one context per (virtual) rank on this GPU, each holding the records of its chromosomes only; the exchanges of
+    include/squid_hip.h are carried by an in-process all-gather.  Every rank must end with the oracle's graph
+    stages, orders, breakpoint table and _sv.txt."""
+    from squid_amd.dist import VirtualWorld
+
+    monkeypatch.delenv("SQUID_EXACT_DEPTH", raising=False)
+    pre = synth(cfg, *extra)
+    sv_path, dump = ou.run_oracle(built, pre, tmp_path)
+    ctxs = _sharded_contexts(pre, world, plan)
+    try:
+        with squid_amd.Context() as whole:
+            whole.load(f"{pre}.bam", f"{pre}.chim.bam")
+            assert sum(c.counts()["n_concordant"] for c in ctxs) == whole.counts()["n_concordant"]
+        vw = VirtualWorld(ctxs)
+        vw.build_graph()
+        for c in ctxs:
+            c.order()
+        rows = vw.call_sv()
+        for r, c in enumerate(ctxs):
+            _compare(_ShardView(c, rows[r]), dump, sv_path, depth_exact=False)
+        assert vw.exchanges <= 5 + world  # 4 for the graph, 1 for the breakpoint counts (+ rare cursor repairs)
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_sharded_context_refuses_to_run_without_its_exchange(built, synth):
+    pre = synth("T2")
+    ctxs = _sharded_contexts(pre, 2)
+    try:
+        with pytest.raises(squid_amd.SquidError):
+            ctxs[0].build_graph()  # no exchange callable
+        assert ctxs[1].build_graph_step() == squid_amd.Context.NEED_EXCHANGE
+        with pytest.raises(squid_amd.SquidError):
+            ctxs[1].build_graph_step()  # the pending exchange was skipped
+    finally:
+        for c in ctxs:
+            c.close()
