@@ -7,8 +7,11 @@ alignment records are already resident in HBM (ingest = host BGZF/BAM decode + H
 region; the file-inclusive rate is reported separately as `e2e_value`).
 
 N = 1: workload = BASELINE.json configs[1] ("hg38 chr17 only, 1M synthetic paired-end reads, ~20 planted
-fusions"), generator config C2.  N > 1: one independent sample per rank (sample-parallel, no data-path
-collective; see DESIGN.md "Multi-GPU"), launched by torch.distributed.run, barrier + max-over-ranks timing.
+fusions"), generator config C2.  N > 1, default `--shard sample`: one independent C2 sample per rank (a single
+chromosome cannot be sharded by chromosome; sample-parallel, no data-path collective, weak scaling).
+`--shard chromosome --workload C3 [--records R]`: ONE full-hg38 sample, rank r holds the records of a contiguous
+chromosome range and the library's exchanges travel as RCCL all-gathers (BASELINE.json configs[3]; strong scaling).
+Launched by torch.distributed.run, barrier + max-over-ranks timing (DESIGN.md "Multi-GPU").
 
 Prints ONE JSON line on rank 0.
 """
@@ -31,11 +34,14 @@ GPU_KERNELS_PREFIX = ("k_", "scan_")
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
 
 
-def synth(config: str, seed: int, outdir: Path) -> Path:
-    pre = outdir / f"{config}_s{seed}"
+def synth(config: str, seed: int, outdir: Path, records: int | None = None) -> Path:
+    pre = outdir / (f"{config}_s{seed}" + (f"_r{records}" if records else ""))
     if not Path(f"{pre}.bam").exists():
-        subprocess.check_call([str(BUILD / "gen_synth_bam"), "--config", config, "--seed", str(seed), "--out", str(pre), "--threads", "8"],
-                              stdout=subprocess.DEVNULL)
+        tmp = Path(f"{pre}.tmp{os.getpid()}")
+        subprocess.check_call([str(BUILD / "gen_synth_bam"), "--config", config, "--seed", str(seed), "--out", str(tmp), "--threads", "8"]
+                              + (["--records", str(records), "--level", "1"] if records else []), stdout=subprocess.DEVNULL)
+        for ext in (".chim.bam", ".truth.txt", ".bam"):
+            os.replace(f"{tmp}{ext}", f"{pre}{ext}")
     return pre
 
 
@@ -45,6 +51,8 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C2", help="generator config (C2 = BASELINE.json configs[1])")
+    ap.add_argument("--records", type=int, default=None, help="override the record count of the workload (generator --records)")
+    ap.add_argument("--shard", choices=["sample", "chromosome"], default="sample", help="what the ranks of a multi-GPU run divide (see the module docstring)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workdir", default=None)
     a = ap.parse_args()
@@ -58,10 +66,17 @@ def main() -> None:
     if world > 1:
         import torch.distributed as dist  # noqa: F811
 
+        # SQUID_DIST_BACKEND=gloo lets several ranks share one GPU (functional checks on a one-GPU box)
+        backend = os.environ.get("SQUID_DIST_BACKEND", "nccl")
+        local_rank %= max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
+    sharded = a.shard == "chromosome" and world > 1
 
     import squid_amd
 
@@ -73,10 +88,15 @@ def main() -> None:
 
     work = Path(a.workdir) if a.workdir else Path(tempfile.gettempdir()) / "squid_bench"
     work.mkdir(parents=True, exist_ok=True)
-    seed = 20180002 + 1000 * rank  # rank 0 of C2 = the generator's default seed for that config
+    srank = 0 if sharded else rank  # a sharded run works on ONE sample
+    seed = 20180002 + 1000 * srank  # rank 0 of C2 = the generator's default seed for that config
     if a.workload != "C2":
-        seed = 20180000 + int(a.workload[1:]) + 1000 * rank if a.workload[1:].isdigit() else 20180007 + 1000 * rank
-    pre = synth(a.workload, seed, work)
+        seed = 20180000 + int(a.workload[1:]) + 1000 * srank if a.workload[1:].isdigit() else 20180007 + 1000 * srank
+    if sharded:
+        if rank == 0:
+            synth(a.workload, seed, work, a.records)
+        dist.barrier()
+    pre = synth(a.workload, seed, work, a.records)
 
     def barrier():
         torch.cuda.synchronize()
@@ -84,11 +104,20 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    ctx = squid_amd.Context(device=local_rank)
+    exchange, plan = None, None
+    if sharded:
+        from squid_amd.dist import TorchExchange, plan_shards
+
+        _, ref_len = squid_amd.read_header(f"{pre}.bam")
+        plan = plan_shards(ref_len, world)  # balanced by reference length (records per chromosome are not known before the decode)
+        exchange = TorchExchange(dist, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        ctx = squid_amd.Context(device=local_rank, rank=rank, world_size=world, exchange=exchange)
+    else:
+        ctx = squid_amd.Context(device=local_rank)
     t_ing0 = time.perf_counter()
-    ctx.load(f"{pre}.bam", f"{pre}.chim.bam", threads=max(1, (os.cpu_count() or 8) // max(1, world)))
+    ctx.load(f"{pre}.bam", f"{pre}.chim.bam", threads=max(1, (os.cpu_count() or 8) // max(1, world)), shard=plan[rank] if sharded else None)
     t_ingest = time.perf_counter() - t_ing0
-    n_aln = ctx.counts()["n_concordant"] + ctx.counts()["n_chimeric_records"]
+    n_aln = ctx.counts()["n_concordant"] + (ctx.counts()["n_chimeric_records"] if (not sharded or rank == 0) else 0)
     sv_path = work / f"bench_rank{rank}_sv.txt"
 
     def step() -> str:
@@ -141,16 +170,17 @@ def main() -> None:
     out = {
         "metric": "paired-end alignments/sec BAM->_sv.txt (records resident in HBM; bit-exact SV calls vs CPU oracle)",
         "value": value, "unit": "alignments/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
         "dtype": "int32", "data": "synthetic",
         "config": {"workload": f"{a.workload}: " + ("hg38 chr17 only, 1M synthetic paired-end records, 20 planted fusions (BASELINE.json configs[1])" if a.workload == "C2" else "generator config " + a.workload),
-                   "records_per_gpu": int(n_aln), "parallelism": "1 sample per GPU, no collective" if world > 1 else "single GPU",
+                   "records_per_gpu": int(n_aln) if not sharded else int(total_aln / world),
+                   "parallelism": ("one sample sharded by chromosome, %d all-gathers per step" % (exchange.calls // max(1, a.steps + a.warmup)) if sharded else "1 sample per GPU, no collective") if world > 1 else "single GPU",
                    "ingest": "excluded from value: host BGZF/BAM decode + H2D, see e2e_value"},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "bytes_per_launch": per_launch_bytes, "us_per_launch": per_launch_ms * 1e3,
                      "all_scan_kernels": {"ms_per_step": gpu_ms, "algorithmic_bytes_per_step": scan_bytes,
                                           "achieved_GBs": scan_bytes / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else None}},
-        "e2e_value": total_aln / world / (t_ingest + elapsed / a.steps), "e2e_note": "one sample incl. BAM decode on host cores + H2D (rank 0)",
+        "e2e_value": (total_aln if sharded else total_aln / world) / (t_ingest + elapsed / a.steps), "e2e_note": "one sample incl. BAM decode on host cores + H2D (rank 0)",
         "stage_ms_per_step": {k: round(v["ms"] / a.steps, 4) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:(None if os.environ.get("BENCH_ALL_STAGES") else 12)]},
     }
     ctx.close()

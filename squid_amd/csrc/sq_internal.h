@@ -119,7 +119,6 @@ struct sq_ctx {
     int64_t n_chim_records = 0;
     // concordant side (device)
     sq::DeviceRecords* dev = nullptr;
-    std::vector<sq::StreamRec> stream_host;     // host mirror of the kept-stream summaries (filled only where replayed)
     // graph state (host, small)
     std::vector<sq::Node> nodes;
     std::vector<sq::Edge> edges;
@@ -221,7 +220,7 @@ struct SegSupport {
 int dev_stream_scan(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<int32_t>& cl_start, const std::vector<int32_t>& cl_right, bool fetch, SegSupport& out,
                     long long& other_max, int32_t first_kept[2]);
 int dev_segment_support(sq_ctx* c, int ncl, int64_t n_rest, SegSupport& out);
-int dev_fetch_stream(sq_ctx* c, const std::vector<std::pair<int64_t, int64_t>>& ranges, StreamRec* dst);
+int dev_fetch_stream(sq_ctx* c, const std::vector<std::pair<int64_t, int64_t>>& ranges, const StreamRec*& compact, std::vector<int64_t>& range_off);
 int dev_classify(sq_ctx* c, int32_t last_info[4]);  // last_info (may be null): {has pass-1, its lists empty, has pass-2, its lists empty}
 int dev_dedup_summarise(sq_ctx* c);
 int dev_gather_other(sq_ctx* c, int64_t n_break, bool& has_tiny, std::vector<int32_t>& other_chr, std::vector<int32_t>& other_pos, std::vector<int32_t>& other_len);

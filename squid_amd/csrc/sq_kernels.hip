@@ -80,8 +80,42 @@ struct DBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// page-locked host staging for the small device->host results of a stage: the copies are queued without blocking and
+// one stream synchronisation makes all of them visible.  A slice stays valid until the next reset().
+struct Pinned {
+    std::vector<std::pair<uint8_t*, size_t>> chunks;
+    size_t used = 0, want = 0;
+    void* take(size_t bytes) {
+        bytes = (bytes + 63) & ~(size_t)63;
+        want += bytes;
+        if (chunks.empty() || used + bytes > chunks.back().second) {
+            size_t cap = std::max<size_t>(bytes, (size_t)4 << 20);
+            uint8_t* p = nullptr;
+            if (hipHostMalloc((void**)&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+            chunks.push_back(std::make_pair(p, cap));
+            used = 0;
+        }
+        void* r = chunks.back().first + used;
+        used += bytes;
+        return r;
+    }
+    template <typename T> T* take_n(size_t n) { return (T*)take(std::max<size_t>(n, 1) * sizeof(T)); }
+    void reset() {  // one chunk big enough for everything the last round asked for
+        if (chunks.size() > 1) {
+            for (auto& ch : chunks) (void)hipHostFree(ch.first);
+            chunks.clear();
+            uint8_t* p = nullptr;
+            size_t cap = want + want / 2;
+            if (hipHostMalloc((void**)&p, cap, hipHostMallocDefault) == hipSuccess) chunks.push_back(std::make_pair(p, cap));
+        }
+        used = 0; want = 0;
+    }
+    void release() { for (auto& ch : chunks) (void)hipHostFree(ch.first); chunks.clear(); used = 0; }
+};
+
 struct DeviceRecords {
     int64_t n = 0, nb = 0;
+    Pinned pin;
     DBuf<int32_t> refid, pos, mrefid, mpos, endpos, b_refpos, b_matchref;
     DBuf<uint16_t> flag, totlen, b_readpos, b_matchread;
     DBuf<uint8_t> mapq, aux;
@@ -1177,115 +1211,124 @@ __global__ void k_cc_label(int n, const int32_t* parent, const int32_t* rootrank
 
 // ------------------------------------------------------------------------------------------------ K9: small orderings
 // One component per workgroup, one orientation mask per thread (n <= 8 => <= 256 masks).  For its mask a thread
-// builds the "x must precede y" arc weights, takes the smallest-index-first topological order when the arcs are
-// acyclic (every compatible edge satisfied) or solves the linear-ordering subset DP otherwise, and the block then
-// picks the canonical optimum: max value, then smallest mask, then lexicographically smallest sequence.
+// collects the "x must precede y" arcs of the compatible edges as an 8x8 bit matrix in one 64-bit register and runs
+// Kahn's algorithm on it with bit operations (smallest index first).  If the arcs are acyclic every compatible edge
+// is satisfied and the value is their weight sum `ub`; a cyclic orientation is worth strictly less than its `ub`, so
+// only those whose `ub` beats the best acyclic value of the block go through the linear-ordering subset DP (in LDS,
+// 32 at a time -- almost never).  The block then picks the canonical optimum: max value, then smallest mask, then
+// the lexicographically smallest sequence.  No per-thread arrays: nothing spills to scratch.
 constexpr int ORD_NMAX = 8;
+struct OrdEdge { int u, v, w; bool hu, hv; };
+__device__ __forceinline__ OrdEdge ord_edge(const int32_t* edges5, int e) {
+    const int32_t* q = edges5 + 5 * (size_t)e;
+    return OrdEdge{q[0], q[1], q[4], q[2] != 0, q[3] != 0};
+}
+// is the edge compatible with the orientation, and if so which end comes first (EdgeSatisfied, SegmentGraph.cpp:3763-3983)
+__device__ __forceinline__ bool ord_arc(const OrdEdge& e, int mask, int& from, int& to) {
+    const bool yu = !((mask >> e.u) & 1), yv = !((mask >> e.v) & 1);
+    bool compat, ufirst;
+    if (!e.hu && e.hv) { compat = yu == yv; ufirst = yu; }
+    else if (!e.hu && !e.hv) { compat = yu != yv; ufirst = yu; }
+    else if (e.hu && e.hv) { compat = yu != yv; ufirst = yv; }
+    else { compat = yu == yv; ufirst = !yu; }
+    from = ufirst ? e.u : e.v; to = ufirst ? e.v : e.u;
+    return compat;
+}
+__device__ __forceinline__ long long block_max_ll(long long v, long long* lds) {
+    for (int d = 32; d >= 1; d >>= 1) { long long o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    long long r = lds[0];
+    for (int i = 1; i < 4; ++i) r = lds[i] > r ? lds[i] : r;
+    __syncthreads();
+    return r;
+}
+// subset DP of one orientation in LDS: h[S] = best weight still obtainable once the nodes of S are placed
+__device__ void ord_dp(const SmallProblem& pr, const int32_t* edges5, int mask, int* arc, int* h, int& value, int* order) {
+    const int n = pr.n, nm = 1 << n;
+    for (int i = 0; i < 64; ++i) arc[i] = 0;
+    for (int e = 0; e < pr.ecount; ++e) {
+        OrdEdge ed = ord_edge(edges5, pr.eoff + e);
+        int from, to;
+        if (ord_arc(ed, mask, from, to)) arc[from * 8 + to] += ed.w;
+    }
+    h[nm - 1] = 0;
+    for (int S = nm - 2; S >= 0; --S) {
+        int best = -1;
+        for (int v = 0; v < n; ++v) {
+            if ((S >> v) & 1) continue;
+            int gain = 0;
+            for (int u = 0; u < n; ++u) if ((S >> u) & 1) gain += arc[u * 8 + v];
+            int t = gain + h[S | (1 << v)];
+            if (t > best) best = t;
+        }
+        h[S] = best;
+    }
+    value = h[0];
+    if (order) {  // lexicographically smallest optimal sequence
+        int S = 0;
+        for (int p = 0; p < n; ++p)
+            for (int v = 0; v < n; ++v) {
+                if ((S >> v) & 1) continue;
+                int gain = 0;
+                for (int u = 0; u < n; ++u) if ((S >> u) & 1) gain += arc[u * 8 + v];
+                if (gain + h[S | (1 << v)] == h[S]) { order[p] = v; S |= 1 << v; break; }
+            }
+    }
+}
 __global__ __launch_bounds__(256) void k_order_small(const SmallProblem* probs, const int32_t* edges5, int32_t* out_mask, int32_t* out_order, int32_t* out_value) {
-    __shared__ int s_best[256];
-    __shared__ int s_h[32][256];  // subset-DP tables, 32 threads at a time (cyclic orientations are rare)
+    __shared__ long long s_red[4];
+    __shared__ int s_h[32][256];
+    __shared__ int s_arc[32][64];
+    __shared__ int s_ub[256];
     const SmallProblem pr = probs[blockIdx.x];
     const int n = pr.n, nm = 1 << n, mask = threadIdx.x;
-    int arc[ORD_NMAX][ORD_NMAX];
-    int value = -1;
+    const bool live = mask < nm;
+    int ub = 0, value = -1;
+    unsigned long long inm = 0;  // bit 8*y + x: x must precede y
     bool acyclic = false;
-    if (mask < nm) {
-        for (int x = 0; x < ORD_NMAX; ++x) for (int y = 0; y < ORD_NMAX; ++y) arc[x][y] = 0;
-        int ub = 0;
+    unsigned packed = 0;         // Kahn order, 3 bits per position
+    if (live) {
         for (int e = 0; e < pr.ecount; ++e) {
-            const int32_t* q = edges5 + 5 * (size_t)(pr.eoff + e);
-            int u = q[0], v = q[1]; bool hu = q[2], hv = q[3]; int w = q[4];
-            bool yu = !((mask >> u) & 1), yv = !((mask >> v) & 1), compat, ufirst;
-            if (!hu && hv) { compat = yu == yv; ufirst = yu; }
-            else if (!hu && !hv) { compat = yu != yv; ufirst = yu; }
-            else if (hu && hv) { compat = yu != yv; ufirst = yv; }
-            else { compat = yu == yv; ufirst = !yu; }
-            if (!compat) continue;
-            ub += w;
-            if (ufirst) arc[u][v] += w; else arc[v][u] += w;
+            OrdEdge ed = ord_edge(edges5, pr.eoff + e);
+            int from, to;
+            if (ord_arc(ed, mask, from, to)) { ub += ed.w; inm |= 1ull << (8 * to + from); }
         }
-        // Kahn, smallest index first
-        int indeg[ORD_NMAX];
-        for (int y = 0; y < n; ++y) { indeg[y] = 0; for (int x = 0; x < n; ++x) if (arc[x][y] > 0) indeg[y]++; }
-        unsigned done = 0;
+        unsigned remaining = (unsigned)nm - 1;
         acyclic = true;
         for (int p = 0; p < n; ++p) {
             int v = -1;
-            for (int cnd = 0; cnd < n; ++cnd) if (!((done >> cnd) & 1) && indeg[cnd] == 0) { v = cnd; break; }
+            for (int cnd = 0; cnd < n; ++cnd)
+                if (((remaining >> cnd) & 1) && !((unsigned)(inm >> (8 * cnd)) & remaining & 0xffu)) { v = cnd; break; }
             if (v < 0) { acyclic = false; break; }
-            done |= 1u << v;
-            for (int y = 0; y < n; ++y) if (arc[v][y] > 0) indeg[y]--;
+            remaining &= ~(1u << v);
+            packed |= (unsigned)v << (3 * p);
         }
         if (acyclic) value = ub;
     }
-    // cyclic masks: subset DP, serialised through the LDS tables in groups of 32 threads (rare path)
-    for (int round = 0; round < 8; ++round) {
-        bool mine = mask < nm && !acyclic && (threadIdx.x >> 5) == round;
-        if (__syncthreads_or(mine)) {
-            if (mine) {
-                int* h = s_h[threadIdx.x & 31];
-                h[nm - 1] = 0;
-                for (int S = nm - 2; S >= 0; --S) {
-                    int best = -1;
-                    for (int v = 0; v < n; ++v) {
-                        if ((S >> v) & 1) continue;
-                        int gain = 0;
-                        for (int u = 0; u < n; ++u) if ((S >> u) & 1) gain += arc[u][v];
-                        int t = gain + h[S | (1 << v)];
-                        if (t > best) best = t;
-                    }
-                    h[S] = best;
-                }
-                value = h[0];
-            }
-            __syncthreads();
-        }
-    }
-    s_best[threadIdx.x] = value;
+    int best = (int)block_max_ll(value, s_red);  // best acyclic value of the block
+    // cyclic orientations that could still win, most promising first: after every round of 32 subset DPs the bar rises
+    const bool cand = live && !acyclic && ub > best;
+    s_ub[threadIdx.x] = cand ? ub : -1;
     __syncthreads();
-    // canonical winner: max value, smallest mask
-    __shared__ int s_win;
-    if (threadIdx.x == 0) {
-        int bw = 0;
-        for (int m2 = 1; m2 < nm; ++m2) if (s_best[m2] > s_best[bw]) bw = m2;
-        s_win = bw;
+    int rank = 0;
+    if (cand) for (int j = 0; j < 256; ++j) { int o = s_ub[j]; rank += (o > ub || (o == ub && j < (int)threadIdx.x)) ? 1 : 0; }
+    for (int base = 0;; base += 32) {
+        const bool mine = cand && rank >= base;
+        const int top = (int)block_max_ll(mine ? ub : -1, s_red);  // largest bound that is still waiting
+        if (top <= best) break;                                      // (a cyclic orientation is worth less than its bound)
+        int got = -1;
+        if (mine && rank < base + 32 && ub > best) { ord_dp(pr, edges5, mask, s_arc[rank - base], s_h[rank - base], value, nullptr); got = value; }
+        const int round_best = (int)block_max_ll(got, s_red);
+        best = round_best > best ? round_best : best;
     }
-    __syncthreads();
-    if (mask == s_win) {
+    // canonical winner: max value, then smallest mask
+    const long long key = live ? (((long long)value << 16) | (long long)(0xffff - mask)) : -1;
+    const long long win = block_max_ll(key, s_red);
+    if (live && key == win) {
         int order[ORD_NMAX];
-        if (acyclic) {
-            int indeg[ORD_NMAX];
-            for (int y = 0; y < n; ++y) { indeg[y] = 0; for (int x = 0; x < n; ++x) if (arc[x][y] > 0) indeg[y]++; }
-            unsigned done = 0;
-            for (int p = 0; p < n; ++p) {
-                int v = 0;
-                for (int cnd = 0; cnd < n; ++cnd) if (!((done >> cnd) & 1) && indeg[cnd] == 0) { v = cnd; break; }
-                order[p] = v; done |= 1u << v;
-                for (int y = 0; y < n; ++y) if (arc[v][y] > 0) indeg[y]--;
-            }
-        } else {
-            int* h = s_h[threadIdx.x & 31];  // recompute (single thread): the slot may have been reused by a later round
-            h[nm - 1] = 0;
-            for (int S = nm - 2; S >= 0; --S) {
-                int best = -1;
-                for (int v = 0; v < n; ++v) {
-                    if ((S >> v) & 1) continue;
-                    int gain = 0;
-                    for (int u = 0; u < n; ++u) if ((S >> u) & 1) gain += arc[u][v];
-                    int t = gain + h[S | (1 << v)];
-                    if (t > best) best = t;
-                }
-                h[S] = best;
-            }
-            int S = 0;
-            for (int p = 0; p < n; ++p)
-                for (int v = 0; v < n; ++v) {
-                    if ((S >> v) & 1) continue;
-                    int gain = 0;
-                    for (int u = 0; u < n; ++u) if ((S >> u) & 1) gain += arc[u][v];
-                    if (gain + h[S | (1 << v)] == h[S]) { order[p] = v; S |= 1 << v; break; }
-                }
-        }
+        if (acyclic) for (int p = 0; p < n; ++p) order[p] = (packed >> (3 * p)) & 7;
+        else ord_dp(pr, edges5, mask, s_arc[0], s_h[0], value, order);  // the tables of its round may have been reused
         out_mask[blockIdx.x] = mask;
         out_value[blockIdx.x] = value;
         for (int p = 0; p < n; ++p) out_order[(size_t)blockIdx.x * ORD_NMAX + p] = order[p];
@@ -1356,6 +1399,7 @@ void dev_destroy(sq_ctx* c) {
     D.calib.release(); D.okey.release(); D.oval.release(); D.other64.release(); D.spine64.release(); D.zflag.release();
     D.cl_chr.release(); D.cl_start.release(); D.cl_right.release(); D.trig.release();
     D.ord_p.release(); D.ord_e.release(); D.ord_m.release(); D.ord_o.release(); D.ord_v.release();
+    D.pin.release(); D.bp_ev.release(); D.bp_end.release(); D.bp_valid.release();
     for (auto& e : D.ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete c->dev;
     c->dev = nullptr;
@@ -1609,50 +1653,75 @@ int dev_segment_support(sq_ctx* c, int ncl, int64_t n_rest, SegSupport& out) {
     ClusterView C{ncl, D.cl_chr.p, D.cl_start.p, D.cl_right.p};
     HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
     int32_t* tot = D.flags.p + 8;
-    { EvTimer t(c, "k_segment_support", 2.0 * 20.0 * k);
-      hipLaunchKernelGGL(k_zerocov, grid_for(k, 256), dim3(256), 0, s, D.srec.p, k, k_own, C, D.other64.p, D.other64.p + k_own, seed, c->read_len, D.zflag.p, D.flags.p);
-      HIPCHK((device_scan<OpSum, true>(s, k, FByte{D.zflag.p}, D.scratch_a.p, D.spine, tot))); }
-    int32_t hz[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(&hz[0], tot, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(&hz[1], D.flags.p, 4, hipMemcpyDeviceToHost, s));
-    if (ncl && !sh.on) HIPCHK(hipMemcpyAsync(out.trigger.data(), D.trig.p, ncl * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (hz[1] & 1) return fail(c, SQ_E_UNSORTED, "concordant BAM is not coordinate sorted (README.md:23 requires it)");
-    const int nz = hz[0];
-    out.zidx.resize(nz); out.z_ochr.resize(nz); out.z_oright.resize(nz);
-    HIPCHK(D.scratch_b.reserve(std::max(nz, 1))); HIPCHK(D.scratch_c.reserve(std::max(nz, 1))); HIPCHK(D.b0_a.reserve(std::max<int64_t>(std::max<int64_t>(nz, n_rest), 1)));
+    // everything is queued without knowing the counts (the compaction targets are sized for the worst case), then one
+    // synchronisation for the counts and one for the compacted arrays
+    HIPCHK(D.scratch_b.reserve(k)); HIPCHK(D.scratch_c.reserve(k)); HIPCHK(D.b0_a.reserve(k));
     HIPCHK(D.b0_b.reserve(std::max<int64_t>(n_rest, 1))); HIPCHK(D.b0_home.reserve(std::max<int64_t>(n_rest, 1))); HIPCHK(D.part_prev.reserve(std::max<int64_t>(n_rest, 1)));
+    { EvTimer t(c, "k_segment_support", 2.0 * 20.0 * k + 13.0 * k);
+      hipLaunchKernelGGL(k_zerocov, grid_for(k, 256), dim3(256), 0, s, D.srec.p, k, k_own, C, D.other64.p, D.other64.p + k_own, seed, c->read_len, D.zflag.p, D.flags.p);
+      HIPCHK((device_scan<OpSum, true>(s, k, FByte{D.zflag.p}, D.scratch_a.p, D.spine, tot)));
+      hipLaunchKernelGGL(k_zgather, grid_for(k, 256), dim3(256), 0, s, k, k_own, D.zflag.p, D.scratch_a.p, D.other64.p, D.other64.p + k_own, seed, D.scratch_b.p, D.scratch_c.p, D.b0_a.p); }
+    const bool want_rest = ncl && n_rest;
+    if (want_rest) {
+        EvTimer t(c, "k_rest_candidates", 20.0 * k_own + 8.0 * n_rest);
+        hipLaunchKernelGGL(k_rest_candidates, grid_for(k_own, 256), dim3(256), 0, s, D.srec.p, k_own, C, c->read_len, D.rest_refpos.p, D.rest_matchref.p, D.flags.p + 4, D.b0_b.p, D.b0_home.p, D.part_prev.p);
+    }
+    D.pin.reset();
+    int32_t* h = D.pin.take_n<int32_t>(16);
+    int32_t* h_trig = D.pin.take_n<int32_t>(ncl);
+    if (!h || !h_trig) return fail(c, SQ_E_HIP, "hipHostMalloc failed");
+    HIPCHK(hipMemcpyAsync(h, D.flags.p, 10 * 4, hipMemcpyDeviceToHost, s));  // [0] flags, [4] rest count, [8] zero-coverage count
+    if (ncl && !sh.on) HIPCHK(hipMemcpyAsync(h_trig, D.trig.p, ncl * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (h[0] & 1) return fail(c, SQ_E_UNSORTED, "concordant BAM is not coordinate sorted (README.md:23 requires it)");
+    if (ncl && !sh.on) out.trigger.assign(h_trig, h_trig + ncl);
+    const int nz = h[8], cnt = want_rest ? h[4] : 0;
+    int32_t *hz = D.pin.take_n<int32_t>(3 * (size_t)nz), *hr = D.pin.take_n<int32_t>(3 * (size_t)cnt);
+    if (!hz || !hr) return fail(c, SQ_E_HIP, "hipHostMalloc failed");
     if (nz) {
-        EvTimer t(c, "k_zgather", 13.0 * k);
-        hipLaunchKernelGGL(k_zgather, grid_for(k, 256), dim3(256), 0, s, k, k_own, D.zflag.p, D.scratch_a.p, D.other64.p, D.other64.p + k_own, seed, D.scratch_b.p, D.scratch_c.p, D.b0_a.p);
-        HIPCHK(hipMemcpyAsync(out.zidx.data(), D.scratch_b.p, nz * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(out.z_ochr.data(), D.scratch_c.p, nz * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(out.z_oright.data(), D.b0_a.p, nz * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipMemcpyAsync(hz, D.scratch_b.p, nz * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(hz + nz, D.scratch_c.p, nz * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hz + 2 * nz, D.b0_a.p, nz * 4, hipMemcpyDeviceToHost, s));
     }
-    if (ncl && n_rest) {
-        HIPCHK(hipMemsetAsync(D.flags.p + 4, 0, 4, s));
-        { EvTimer t(c, "k_rest_candidates", 20.0 * k_own + 8.0 * n_rest);
-          hipLaunchKernelGGL(k_rest_candidates, grid_for(k_own, 256), dim3(256), 0, s, D.srec.p, k_own, C, c->read_len, D.rest_refpos.p, D.rest_matchref.p, D.flags.p + 4, D.b0_b.p, D.b0_home.p, D.part_prev.p); }
-        int32_t cnt = 0;
-        HIPCHK(hipMemcpyAsync(&cnt, D.flags.p + 4, 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        out.rest_cluster.resize(cnt); out.rest_pos.resize(cnt); out.rest_len.resize(cnt);
-        if (cnt) {
-            HIPCHK(hipMemcpyAsync(out.rest_cluster.data(), D.b0_b.p, cnt * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(out.rest_pos.data(), D.b0_home.p, cnt * 4, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipMemcpyAsync(out.rest_len.data(), D.part_prev.p, cnt * 4, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
-        }
+    if (cnt) {
+        HIPCHK(hipMemcpyAsync(hr, D.b0_b.p, cnt * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(hr + cnt, D.b0_home.p, cnt * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hr + 2 * cnt, D.part_prev.p, cnt * 4, hipMemcpyDeviceToHost, s));
     }
+    if (nz || cnt) HIPCHK(hipStreamSynchronize(s));
+    out.zidx.assign(hz, hz + nz); out.z_ochr.assign(hz + nz, hz + 2 * nz); out.z_oright.assign(hz + 2 * nz, hz + 3 * nz);
+    out.rest_cluster.assign(hr, hr + cnt); out.rest_pos.assign(hr + cnt, hr + 2 * cnt); out.rest_len.assign(hr + 2 * cnt, hr + 3 * cnt);
     return SQ_OK;
 }
 
-// copy the stream summaries of the given kept-index ranges [lo,hi) into dst[lo..hi)
-int dev_fetch_stream(sq_ctx* c, const std::vector<std::pair<int64_t, int64_t>>& ranges, StreamRec* dst) {
+// gather the stream summaries of the given kept-index ranges [lo,hi) into one page-locked host buffer (the kernel
+// writes it directly over the bus); range i starts at range_off[i] of `compact`
+__global__ void k_gather_ranges(const uint32_t* src, const long long* lo_words, const long long* off_words, int nranges, long long total_words, uint32_t* dst) {
+    for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < total_words; w += (long long)gridDim.x * blockDim.x) {
+        int a = 0, b = nranges;  // last range with off <= w
+        while (b - a > 1) { int m = (a + b) >> 1; if (off_words[m] <= w) a = m; else b = m; }
+        dst[w] = src[lo_words[a] + (w - off_words[a])];
+    }
+}
+int dev_fetch_stream(sq_ctx* c, const std::vector<std::pair<int64_t, int64_t>>& ranges, const StreamRec*& compact, std::vector<int64_t>& range_off) {
     DeviceRecords& D = *c->dev;
+    hipStream_t s = c->stream;
     auto t0 = std::chrono::steady_clock::now();
-    for (auto& r : ranges)
-        if (r.second > r.first) HIPCHK(hipMemcpyAsync(dst + r.first, D.srec.p + r.first, (size_t)(r.second - r.first) * sizeof(StreamRec), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    const int nr = (int)ranges.size();
+    range_off.assign(nr, 0);
+    compact = nullptr;
+    if (!nr) return SQ_OK;
+    static_assert(sizeof(StreamRec) == 24, "StreamRec is copied as 6 words");
+    std::vector<long long> lo(nr), off(nr);
+    long long total = 0;
+    for (int i = 0; i < nr; ++i) { range_off[i] = total; lo[i] = ranges[i].first * 6; off[i] = total * 6; total += ranges[i].second - ranges[i].first; }
+    StreamRec* dst = D.pin.take_n<StreamRec>((size_t)total);
+    if (!dst) return fail(c, SQ_E_HIP, "hipHostMalloc failed");
+    HIPCHK(D.other64.reserve(2 * (size_t)nr + 2));  // the running-pair scan is not needed any more: reuse its buffer for the range table
+    HIPCHK(hipMemcpyAsync(D.other64.p, lo.data(), nr * 8, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(D.other64.p + nr, off.data(), nr * 8, hipMemcpyHostToDevice, s));
+    const long long words = total * 6;
+    const unsigned grid = (unsigned)std::min<long long>((words + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_gather_ranges, dim3(grid), dim3(256), 0, s, (const uint32_t*)D.srec.p, D.other64.p, D.other64.p + nr, nr, words, (uint32_t*)dst);
+    HIPCHK(hipStreamSynchronize(s));
+    compact = dst;
     c->timer.add("d2h_stream_summary", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), 0);
     return SQ_OK;
 }

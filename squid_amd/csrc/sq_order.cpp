@@ -9,6 +9,8 @@
 // GLPK's pick among equal-valued optima and Boost's pick among equal min-cuts are not reproducible (neither
 // library is available, nothing in the reference pins them); DESIGN.md lists this as "parity unpinned".
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cstring>
 
 #include "sq_internal.h"
@@ -339,7 +341,9 @@ int order_components(sq_ctx* c) {
         }
     }
     t0 = std::chrono::steady_clock::now();
-    for (Piece& p : B.pieces) {
+    std::vector<int> large;
+    for (size_t pi = 0; pi < B.pieces.size(); ++pi) {
+        Piece& p = B.pieces[pi];
         const int pn = (int)p.ids.size();
         if (pn <= GPU_NMAX) continue;
         p.order.resize(pn);
@@ -348,12 +352,27 @@ int order_components(sq_ctx* c) {
             for (int k = 0; k < pn; ++k) p.order[k] = p.ids[k] + 1;
             continue;
         }
+        large.push_back((int)pi);
+    }
+    auto solve = [&](int pi) {
+        Piece& p = B.pieces[pi];
+        const int pn = (int)p.ids.size();
         HostSolver hs(pn, p.edges);
         hs.run();
         for (int pos = 0; pos < pn; ++pos) {
             int l = hs.bestorder[pos];
             p.order[pos] = ((hs.bestmask >> l) & 1) ? -(p.ids[l] + 1) : (p.ids[l] + 1);
         }
+    };
+    // the pieces are independent: solve them on a few host threads (biggest first)
+    std::sort(large.begin(), large.end(), [&](int x, int y) { return B.pieces[x].ids.size() > B.pieces[y].ids.size(); });
+    const int nthr = (int)std::min<size_t>(std::min<size_t>(large.size(), 16), std::max(1u, std::thread::hardware_concurrency()));
+    if (nthr <= 1) for (int pi : large) solve(pi);
+    else {
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthr; ++t) pool.emplace_back([&]() { for (size_t i; (i = next.fetch_add(1)) < large.size();) solve(large[i]); });
+        for (auto& th : pool) th.join();
     }
     c->timer.add("host_order_large", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     c->ord_off.assign(1, 0);

@@ -45,7 +45,9 @@ struct SegStatic {
 
 struct Seg {
     const sq_ctx* c;
-    const StreamRec* recs;  // host copy of the stream summaries, valid only inside the replayed stretches
+    const StreamRec* recs;  // host copy of the stream summaries of the replayed stretches, one after the other
+    int64_t shift = 0;      // kept index of recs[0] for the stretch being replayed
+    const StreamRec& rec(int64_t idx) const { return recs[idx - shift]; }
     const int RL;
     static constexpr int T = 3;     // thresh (SegmentGraph.cpp:286)
     static constexpr int NEAR = 60;  // thresh*20
@@ -68,7 +70,7 @@ struct Seg {
         : c(c), recs(recs), RL(c->read_len), D(st.D), nd(st.nd), part(st.part), clusters(st.clusters), rest_by_cluster(st.rest_by_cluster), out(out) {}
 
     El el(int32_t idx) const {
-        const StreamRec& r = recs[idx];
+        const StreamRec& r = rec(idx);
         return El{r.refid, r.fb_refpos, r.fb_matchref, (int32_t)r.fb_readpos, (bool)(r.flags & SR_REV)};
     }
     static bool el_less(const El& a, const El& b) { return a.refid != b.refid ? a.refid < b.refid : a.refpos < b.refpos; }
@@ -247,6 +249,8 @@ struct SegPlan {
     SegStatic st;
     SegSupport sup;
     std::vector<int> active;
+    std::vector<int64_t> shift;       // per active stretch: kept index that compact[0] would have
+    const StreamRec* compact = nullptr;  // page-locked copy of the summaries inside the replayed stretches
     int64_t K = 0;        // kept records of the local stream
     int64_t K_eff = 0;    // + the appended first kept record of the next shard
     int k0 = 0;           // clusters that an earlier shard's closing record has already passed
@@ -323,7 +327,6 @@ int segment_prepare(sq_ctx* c, SegPlan& P, int64_t& n_break) {
     const Shard& sh = c->shard;
     const int64_t K = P.K;
     const int ncl = (int)S.clusters.size(), nd = S.nd;
-    if ((int64_t)c->stream_host.size() < K + 1) c->stream_host.resize((size_t)K + 1);  // only the replayed stretches are ever filled in
     SegSupport& sup = P.sup;
     int rc = dev_segment_support(c, ncl, c->counts.n_kept_p2, sup);
     if (rc) return rc;
@@ -374,12 +377,19 @@ int segment_prepare(sq_ctx* c, SegPlan& P, int64_t& n_break) {
         if (active.empty() || active.back() != j) active.push_back(j);
     }
     std::vector<std::pair<int64_t, int64_t>> ranges;
+    std::vector<int> range_of;
     for (int j : active) {
         int64_t lo = j == 0 ? 0 : Z[j - 1], hi = j < nz ? (int64_t)Z[j] + 1 : KE;
         if (!ranges.empty() && ranges.back().second >= lo) ranges.back().second = std::max(ranges.back().second, hi);
         else ranges.push_back(std::make_pair(lo, hi));
+        range_of.push_back((int)ranges.size() - 1);
     }
-    return dev_fetch_stream(c, ranges, c->stream_host.data());
+    std::vector<int64_t> range_off;
+    rc = dev_fetch_stream(c, ranges, P.compact, range_off);
+    if (rc) return rc;
+    P.shift.resize(active.size());
+    for (size_t a = 0; a < active.size(); ++a) P.shift[a] = ranges[range_of[a]].first - range_off[range_of[a]];
+    return SQ_OK;
 }
 
 // order-dependent part: replay the reference's control automaton over the stretches that contain cluster triggers
@@ -387,7 +397,7 @@ int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds, bool virt
     seeds.clear();
     std::vector<Node> sink;
     if (virtual_back) sink.push_back(Node{-1, 0, 0, 0, 0.0});  // stands for the last node of the earlier shards (an earlier chromosome)
-    Seg S(c, c->stream_host.data(), plan.st, sink);
+    Seg S(c, plan.compact, plan.st, sink);
     SegSupport& sup = plan.sup;
     const std::vector<Blk>& D = S.D;
     const int nd = S.nd, RL = c->read_len;
@@ -398,7 +408,7 @@ int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds, bool virt
     if (nd == 0 || plan.K == 0) return SQ_OK;
 
     auto push_step = [&](int64_t i) {  // SegmentGraph.cpp:649-700 (ConcordRest pushes are covered by rest_by_cluster)
-        const StreamRec& r = S.recs[i];
+        const StreamRec& r = S.rec(i);
         if (!(r.flags & SR_CONC)) return;
         const int e = r.fb_refpos + r.fb_matchref;
         if (r.flags & SR_MATE) {  // the reference keys these updates on IsFirstMate()/IsSecondMate()
@@ -407,9 +417,24 @@ int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds, bool virt
         }
         if (r.flags & SR_PART) S.pw.push_back((int32_t)i); else S.cw.push_back((int32_t)i);
     };
+    // window pruning as of record (refid): SegmentGraph.cpp:637-646.  Everything it tests except the record's chromosome
+    // only changes when a cluster is processed, so between two cluster triggers it is enough to apply it once, right
+    // before the next trigger, with the chromosome of the record in front of that trigger.
+    auto prune_all = [&](int refid) {
+        const Blk& dn = D[S.ds];
+        auto prune = [&](std::vector<int32_t>& W, int& off) {
+            while ((int)W.size() > off && S.el(W[off]).refid != refid) ++off;
+            while ((int)W.size() > off) {
+                El b = S.el(W[off]);
+                if (b.refid < dn.refid || (S.have_back() && b.refid == S.out.back().chr && b.refpos < S.back_end())) ++off; else break;
+            }
+        };
+        prune(S.cw, S.co);
+        prune(S.pw, S.po);
+    };
     // events + zero-coverage test + window pruning of record i; returns false when the reference has left its loop
     auto head_step = [&](int64_t i, bool& zerocov) -> bool {
-        const StreamRec& r = S.recs[i];
+        const StreamRec& r = S.rec(i);
         if (S.ds == nd) return false;  // :338-339
         while (S.ds != nd && (D[S.ds].refid < r.refid || (D[S.ds].refid == r.refid && S.nextdisright < r.pos))) S.process_cluster(r.refid, r.pos);
         const bool disLead = S.disChr > S.otherChr || (S.disChr == S.otherChr && S.disright > S.otherright);
@@ -425,22 +450,15 @@ int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds, bool virt
             S.markStart = -1; S.markChr = -1;
         }
         if (zerocov) { S.co = (int)S.cw.size(); S.po = (int)S.pw.size(); }  // :633-636 (the extra condition there is implied by zerocov)
-        else {  // :637-646
-            auto prune = [&](std::vector<int32_t>& W, int& off) {
-                while ((int)W.size() > off && S.el(W[off]).refid != r.refid) ++off;
-                while ((int)W.size() > off) {
-                    El b = S.el(W[off]);
-                    if (b.refid < dn.refid || (S.have_back() && b.refid == S.out.back().chr && b.refpos < S.back_end())) ++off; else break;
-                }
-            };
-            prune(S.cw, S.co);
-            prune(S.pw, S.po);
-        }
+        else prune_all(r.refid);
         return true;
     };
+    const int ncl = (int)S.clusters.size();
     S.new_cluster();  // the reference does this at its first kept record (:341)
     for (int k = 0; k < plan.k0; ++k) S.new_cluster();  // clusters consumed by the closing record of an earlier shard
-    for (int j : active) {
+    for (size_t a = 0; a < active.size(); ++a) {
+        const int j = active[a];
+        S.shift = plan.shift[a];
         const int64_t lo = j == 0 ? -1 : Z[j - 1], hi = j < nz ? Z[j] : K;
         // a zero-coverage record empties the windows and clears the pending node end; the running
         // (otherChr, otherrightmost) in front of it comes from the GPU scan
@@ -451,11 +469,24 @@ int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds, bool virt
             push_step(lo);
         }
         bool alive = true, z = false;
-        for (int64_t i = lo + 1; i < hi && alive; ++i) {
+        int64_t i = lo + 1;
+        while (i < hi && alive) {
+            if (S.ds == nd) { alive = false; break; }
+            // records in front of the current cluster's trigger only push (no event, no zero coverage by construction);
+            // the head step of the last of them is the pruning that the trigger record finds
+            const int64_t t = S.kc < ncl ? std::min<int64_t>(sup.trigger[S.kc], hi) : hi;
+            if (i < t) {
+                for (; i < t - 1; ++i) push_step(i);
+                prune_all(S.rec(i).refid);
+                push_step(i);
+                ++i;
+            }
+            if (i >= hi) break;
             alive = head_step(i, z);
             if (alive) {
                 if (z) return fail(c, SQ_E_ARG, "internal: zero-coverage record inside a replayed stretch");
                 push_step(i);
+                ++i;
             }
         }
         if (alive && hi < K) alive = head_step(hi, z);  // its push step opens the next stretch

@@ -402,3 +402,19 @@ def test_sharded_context_refuses_to_run_without_its_exchange(built, synth):
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_sharded_command_line_two_processes(built, synth, tmp_path):
+    """python -m squid_amd.sharded_cli under torch.distributed.run (2 ranks sharing this GPU, gloo transport):
+    rank 0's _sv.txt is the oracle's"""
+    import os
+    import sys
+
+    pre = synth("T2")
+    sv_path, _ = ou.run_oracle(built, pre, tmp_path)
+    out = tmp_path / "sharded"
+    env = dict(os.environ, SQUID_DIST_BACKEND="gloo", PYTHONPATH=str(Path(__file__).resolve().parent.parent))
+    port = 29600 + os.getpid() % 300
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                    "-m", "squid_amd.sharded_cli", "-b", f"{pre}.bam", "-c", f"{pre}.chim.bam", "-o", str(out)], check=True, env=env, timeout=600)
+    assert Path(f"{out}_sv.txt").read_text() == sv_path.read_text()
