@@ -11,6 +11,9 @@
 // ~15 carried variables, SURVEY.md A.2b, live in `Seg`) and never touches the rest of the stream.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <chrono>
 
 #include "sq_internal.h"
 
@@ -43,6 +46,53 @@ struct SegStatic {
     }
 };
 
+// Number of blocks (pos[i], len[i]), i in [from, n), pos ascending, that span a break: pos < brk - T and
+// pos + len >= brk + T -- for many nearby breaks.  The reference walks the whole list per break (SegmentGraph.cpp:
+// 438-470); here the ends of the blocks that can span anything between the smallest and the largest break are sorted
+// once, and a count is  #(pos < brk-T) - #(end < brk+T) + #(pos >= brk-T and end < brk+T), the last term over the
+// few blocks that start within 2T of the break.
+struct SpanIndex {
+    const int32_t *pos = nullptr, *len = nullptr;
+    int base = 0, lim = 0;
+    long long elo = 0;             // ends are counted per coordinate in [elo, elo + width)
+    std::vector<int32_t> below;    // below[x] = #ends < elo + x   (ends behind the last break are never asked about: clamped)
+    std::vector<int32_t> ends;     // fallback for very wide clusters: sorted ends
+    bool wide = false;
+    int lb(long long x, int a, int b) const { while (a < b) { int m = (a + b) >> 1; if (pos[m] < x) a = m + 1; else b = m; } return a; }
+    void build(const int32_t* p, const int32_t* l, int from, int n, int maxlen, int minbrk, int maxbrk, int T) {
+        pos = p; len = l;
+        base = lb((long long)minbrk + T - maxlen, from, n);  // earlier blocks end before minbrk + T
+        lim = lb((long long)maxbrk + T, base, n);            // later blocks start behind every break
+        elo = (long long)minbrk + T - maxlen;
+        const long long width = (long long)maxbrk + T - elo + 2;
+        wide = width > (1 << 16);
+        if (wide) {
+            ends.resize((size_t)(lim - base));
+            for (int i = base; i < lim; ++i) ends[(size_t)(i - base)] = pos[i] + len[i];
+            std::sort(ends.begin(), ends.end());
+            return;
+        }
+        below.assign((size_t)width + 1, 0);
+        for (int i = base; i < lim; ++i) {
+            long long x = (long long)pos[i] + len[i] - elo;  // >= 1: pos >= elo and len >= 1... (a zero-length block still lands at 0)
+            if (x < 0) x = 0;
+            if (x >= width) x = width - 1;
+            below[(size_t)x + 1]++;
+        }
+        for (size_t x = 1; x < below.size(); ++x) below[x] += below[x - 1];
+    }
+    int count(int brk, int T) const {
+        const int a = brk - T, b = brk + T;
+        const int ia = lb(a, base, lim);
+        int less_b;
+        if (wide) less_b = (int)(std::lower_bound(ends.begin(), ends.end(), b) - ends.begin());
+        else { long long x = (long long)b - elo; less_b = x <= 0 ? 0 : below[(size_t)std::min<long long>(x, (long long)below.size() - 1)]; }
+        int tail = 0;
+        for (int i = ia; i < lim && pos[i] < b; ++i) if (pos[i] + len[i] < b) ++tail;
+        return (ia - base) - (less_b - tail);
+    }
+};
+
 struct Seg {
     const sq_ctx* c;
     const StreamRec* recs;  // host copy of the stream summaries of the replayed stretches, one after the other
@@ -58,8 +108,46 @@ struct Seg {
     const std::vector<std::vector<std::pair<int, int>>>& rest_by_cluster;
     std::vector<int32_t> cw, pw;     // windows: indices into in.recs (ConcordantCluster / PartialAlignCluster)
     int co = 0, po = 0;              // window offsets
+    // The reference walks a whole window for every break candidate.  Here the live elements that can span anything
+    // near the cluster are collected once per sub-cluster (one pass over contiguous arrays) and counted through a
+    // SpanIndex; `maxm` bounds the block length.
+    // per window: the elements whose block starts at the record position -- in stream order they are sorted by that start
+    // -- and, apart, the others (first block of a spliced reverse read: an intron further right), which are few
+    struct WinEnt { int32_t pos, len, rid, widx; };
+    struct WinInfo { int maxm = 0; std::vector<WinEnt> norm, shifted; } ci, pi;
+    void win_push(std::vector<int32_t>& W, WinInfo& wi, int32_t idx) {
+        const StreamRec& r = rec(idx);
+        wi.maxm = std::max(wi.maxm, r.fb_matchref);
+        const WinEnt e{r.fb_refpos, r.fb_matchref, r.refid, (int32_t)W.size()};
+        W.push_back(idx);
+        if (r.fb_refpos == r.pos && (wi.norm.empty() || (wi.norm.back().rid == r.refid && wi.norm.back().pos <= r.pos))) wi.norm.push_back(e); else wi.shifted.push_back(e);
+    }
+    void win_clear(std::vector<int32_t>& W, WinInfo& wi, int& off) { W.clear(); off = 0; wi.norm.clear(); wi.shifted.clear(); wi.maxm = 0; }
+    struct SpanSet { std::vector<std::pair<int32_t, int32_t>> tmp; std::vector<int32_t> pos, len; SpanIndex ix; };
+    // blocks of the live window elements (window index >= off) on `chr` that start in [minbrk + T - maxm, maxbrk + T)
+    void span_collect(SpanSet& ss, const WinInfo& wi, int off, int chr, int minbrk, int maxbrk) {
+        const long long lo = (long long)minbrk + T - wi.maxm, hi = (long long)maxbrk + T;
+        ss.tmp.clear();
+        auto it = std::lower_bound(wi.norm.begin(), wi.norm.end(), lo, [](const WinEnt& a, long long b) { return a.pos < b; });
+        for (; it != wi.norm.end() && it->pos < hi; ++it) if (it->widx >= off && it->rid == chr) ss.tmp.push_back(std::make_pair(it->pos, it->len));
+        const size_t sorted_upto = ss.tmp.size();
+        for (const WinEnt& e : wi.shifted) if (e.widx >= off && e.rid == chr && e.pos >= lo && e.pos < hi) ss.tmp.push_back(std::make_pair(e.pos, e.len));
+        if (ss.tmp.size() != sorted_upto) {
+            std::sort(ss.tmp.begin() + sorted_upto, ss.tmp.end());
+            std::inplace_merge(ss.tmp.begin(), ss.tmp.begin() + sorted_upto, ss.tmp.end());
+        }
+        ss.pos.resize(ss.tmp.size()); ss.len.resize(ss.tmp.size());
+        for (size_t i = 0; i < ss.tmp.size(); ++i) { ss.pos[i] = ss.tmp[i].first; ss.len[i] = ss.tmp[i].second; }
+        ss.ix.build(ss.pos.data(), ss.len.data(), 0, (int)ss.pos.size(), wi.maxm, minbrk, maxbrk, T);
+    }
+    SpanSet cset, pset;
     const std::vector<std::pair<int, int>>* rest = nullptr;  // live ConcordRest content of the current cluster: (refpos, matchref) on its chromosome
+    std::vector<int> M_buf, fwd_buf, rev_buf;  // scratch of process_cluster
+    double tsec[6] = {0, 0, 0, 0, 0, 0}; long long nsec[6] = {0, 0, 0, 0, 0, 0}; bool prof = false;
     int kc = -1;                     // index of the current cluster (ds == clusters[kc].ds)
+    int rest_maxm = 0;
+    std::vector<int32_t> rest_pos, rest_len;  // the current cluster's ConcordRest content, sorted by refpos
+    SpanIndex rspan;
     std::vector<Node>& out;
     int ds = 0, de = 0, dcur = 0;    // itdisstart / itdisend / itdiscurrent
     size_t ps = 0, pe = 0;
@@ -85,6 +173,9 @@ struct Seg {
             const Cluster& k = clusters[kc];
             ds = k.ds; de = k.de; nextdisright = k.right; nextdisChr = k.chr;
             rest = &rest_by_cluster[kc];
+            rest_maxm = 0;
+            rest_pos.clear(); rest_len.clear();
+            for (const auto& h : *rest) { rest_maxm = std::max(rest_maxm, h.second); rest_pos.push_back(h.first); rest_len.push_back(h.second); }
         } else {  // past the last cluster: the reference reads the zero sentinel (ledger B21); nextdisChr keeps its value
             ds = de = nd; nextdisright = 0;
             rest = nullptr;
@@ -126,11 +217,15 @@ struct Seg {
         for (; ps != part.size() && (part[ps].first < D[ds].refid || (part[ps].first == D[ds].refid && part[ps].second + RL < D[ds].refpos)); ++ps) {}
         for (pe = ps; pe != part.size() && part[pe].first == D[ds].refid && part[pe].second < nextdisright + RL; ++pe) {}
 
-        std::vector<int> M;  // MarginPositions
+        auto tick = [&]() { return prof ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point(); };
+        auto tock = [&](int k, std::chrono::steady_clock::time_point t0, long long n) { if (prof) { tsec[k] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); nsec[k] += n; } };
+        std::vector<int>& M = M_buf;  // MarginPositions
+        std::vector<int>&fwd_ends = fwd_buf, &rev_starts = rev_buf;
         while (ds != de) {
             const int chr = D[ds].refid;
             if (ds != 0 && D[ds].refid != D[ds - 1].refid && (int)cw.size() == co && (int)pw.size() == po) curStart = D[ds].refpos;
             split = false;
+            auto tA = tick();
             M.clear();
             for (dcur = ds; dcur != de; ++dcur) {
                 M.push_back(D[dcur].refpos);
@@ -158,6 +253,16 @@ struct Seg {
                 }
             }
             std::sort(M.begin(), M.end());
+            fwd_ends.clear(); rev_starts.clear();
+            int dmaxm = 0;
+            for (int d = ds; d != de; ++d) { if (D[d].rev) rev_starts.push_back(D[d].refpos); else fwd_ends.push_back(D[d].refpos + D[d].matchref); dmaxm = std::max(dmaxm, D[d].matchref); }
+            std::sort(fwd_ends.begin(), fwd_ends.end());  // (rev_starts is in block order, i.e. already sorted)
+            // span counters over the two windows and the ConcordRest content (offsets co/po are fixed while the candidates are tested)
+            span_collect(cset, ci, co, chr, M.front(), M.back());
+            span_collect(pset, pi, po, chr, M.front(), M.back());
+            if (rest && !rest->empty()) rspan.build(rest_pos.data(), rest_len.data(), 0, (int)rest_pos.size(), rest_maxm, M.front(), M.back(), T);
+            tock(0, tA, (long long)M.size());
+            auto tB = tick();
 
             int lastC = -1, lastSup = 0;
             for (size_t ib = 0; ib < M.size();) {
@@ -165,22 +270,31 @@ struct Seg {
                 size_t nx = ib;
                 while (nx < M.size() && M[nx] == brk) ++nx;
                 bool skip = have_back() && out.back().chr == chr && brk - back_end() < NEAR;
+                if (prof) nsec[3]++;
                 if (!skip) {
-                    int sr = 0, pl = 0, pr = 0;
-                    for (size_t k = 0; k < M.size() && M[k] < brk + T; ++k) if (std::abs(brk - M[k]) < T) ++sr;
-                    for (int d = ds; d != de; ++d) {
-                        int e = D[d].refpos + D[d].matchref;
-                        if (e < brk && e > brk - RL && !D[d].rev) ++pl;
-                        else if (D[d].refpos > brk && D[d].refpos < brk + RL && D[d].rev) ++pr;
-                    }
+                    auto tq = tick();
+                    // the reference counts these with linear passes over M and over the cluster's blocks for every candidate;
+                    // M, fwd_ends and rev_starts are sorted, so the same counts are differences of binary searches
+                    const int sr = (int)(std::lower_bound(M.begin(), M.end(), brk + T) - std::lower_bound(M.begin(), M.end(), brk - T + 1));        // |brk - M[k]| < T
+                    const int pl = (int)(std::lower_bound(fwd_ends.begin(), fwd_ends.end(), brk) - std::lower_bound(fwd_ends.begin(), fwd_ends.end(), brk - RL + 1));  // forward block ending in (brk-RL, brk)
+                    const int pr = (int)(std::lower_bound(rev_starts.begin(), rev_starts.end(), brk + RL) - std::lower_bound(rev_starts.begin(), rev_starts.end(), brk + 1));  // reverse block starting in (brk, brk+RL)
+                    tock(3, tq, 0);
                     if (sr > 3 || sr + pl > 4 || sr + pr > 4) {
+                        auto tw = tick();
                         auto spans = [&](int id, int p, int m) { return id == chr && p + m >= brk + T && p < brk - T; };
                         int cov = 0;
-                        for (int i = co; i < (int)cw.size(); ++i) { El b = el(cw[i]); if (spans(b.refid, b.refpos, b.matchref)) ++cov; }
-                        for (int d = ds; d != de; ++d) if (spans(D[d].refid, D[d].refpos, D[d].matchref)) ++cov;
-                        for (int i = po; i != (int)pw.size(); ++i) { El b = el(pw[i]); if (spans(b.refid, b.refpos, b.matchref)) ++cov; }
+                        // spans() needs p < brk - T and p + m >= brk + T
+                        cov += cset.ix.count(brk, T);
+                        {   // the cluster's own blocks (sorted by refpos, none longer than dmaxm)
+                            auto blk_lb = [&](long long x) { int a = ds, b = de; while (a < b) { int m = (a + b) >> 1; if (D[m].refpos < x) a = m + 1; else b = m; } return a; };
+                            for (int d = blk_lb((long long)brk + T - dmaxm), d1 = blk_lb((long long)brk - T); d < d1; ++d) if (spans(D[d].refid, D[d].refpos, D[d].matchref)) ++cov;
+                        }
+                        cov += pset.ix.count(brk, T);
+                        tock(4, tw, 1);
+                        auto tr = tick();
                         if (sr > std::max(cov - sr, 0) + 2)
-                            if (rest) for (const auto& h : *rest) if (spans(chr, h.first, h.second)) ++cov;
+                            if (rest && !rest->empty()) cov += rspan.count(brk, T);  // (same chromosome by construction, see k_rest_candidates)
+                        tock(5, tr, 1);
                         if (sr > std::max(cov - sr, 0) + 2) {
                             int sup = std::max(sr + pl, sr + pr);
                             if (lastC == -1 && brk - curStart < NEAR) { markStart = curStart; markChr = chr; }
@@ -191,6 +305,8 @@ struct Seg {
                 }
                 ib = nx;
             }
+            tock(1, tB, rest ? (long long)rest->size() : 0);
+            auto tC = tick();
             if (lastC != -1 && (!split || back_end() != lastC)) close_node(chr, curStart, curEnd, lastC, split);
             if (disStart != -1 && !split && disCount > std::min(5.0, 4.0 * (disEnd - disStart) / RL)) {  // :518-527 (FP64 as in the reference)
                 if (have_back() && out.back().chr == D[de - 1].refid && disEnd - back_end() < NEAR) out.back().len += disEnd - back_end();
@@ -237,6 +353,7 @@ struct Seg {
                 bool f1 = step2(cw, co), f2 = step2(pw, po);
                 if (!f1 && !f2) break;
             } while ((int)cw.size() != co || (int)pw.size() != po);
+            tock(2, tC, (long long)(cw.size() - co + pw.size() - po));
             ds = dcur;
         }
         if (de - ds <= 0) new_cluster();
@@ -345,6 +462,7 @@ int segment_prepare(sq_ctx* c, SegPlan& P, int64_t& n_break) {
     }
     S.rest_by_cluster.assign(ncl, {});
     for (size_t i = 0; i < sup.rest_cluster.size(); ++i) S.rest_by_cluster[sup.rest_cluster[i]].push_back(std::make_pair(sup.rest_pos[i], sup.rest_len[i]));
+    for (auto& v : S.rest_by_cluster) std::sort(v.begin(), v.end());  // only counted, never enumerated in order: sorted for range queries
     // ReadsMain/ReadsOther stop growing at the first record after the last cluster's trigger (SegmentGraph.cpp:338-339, B12)
     if (!sh.on) {
         if (ncl == 0) n_break = std::min<int64_t>(K, 1);
@@ -398,6 +516,7 @@ int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds, bool virt
     std::vector<Node> sink;
     if (virtual_back) sink.push_back(Node{-1, 0, 0, 0, 0.0});  // stands for the last node of the earlier shards (an earlier chromosome)
     Seg S(c, plan.compact, plan.st, sink);
+    S.prof = std::getenv("SQUID_REPLAY_PROF") != nullptr;
     SegSupport& sup = plan.sup;
     const std::vector<Blk>& D = S.D;
     const int nd = S.nd, RL = c->read_len;
@@ -407,6 +526,9 @@ int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds, bool virt
     const std::vector<int>& active = plan.active;
     if (nd == 0 || plan.K == 0) return SQ_OK;
 
+    static const bool prof = std::getenv("SQUID_REPLAY_PROF") != nullptr;
+    long long n_pushed = 0, n_clusters = 0;
+    double t_cluster = 0;
     auto push_step = [&](int64_t i) {  // SegmentGraph.cpp:649-700 (ConcordRest pushes are covered by rest_by_cluster)
         const StreamRec& r = S.rec(i);
         if (!(r.flags & SR_CONC)) return;
@@ -415,7 +537,7 @@ int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds, bool virt
             if (S.otherChr == r.refid) S.otherright = std::max(S.otherright, e);
             else { S.otherright = e; S.otherChr = r.refid; }
         }
-        if (r.flags & SR_PART) S.pw.push_back((int32_t)i); else S.cw.push_back((int32_t)i);
+        if (r.flags & SR_PART) S.win_push(S.pw, S.pi, (int32_t)i); else S.win_push(S.cw, S.ci, (int32_t)i);
     };
     // window pruning as of record (refid): SegmentGraph.cpp:637-646.  Everything it tests except the record's chromosome
     // only changes when a cluster is processed, so between two cluster triggers it is enough to apply it once, right
@@ -436,6 +558,11 @@ int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds, bool virt
     auto head_step = [&](int64_t i, bool& zerocov) -> bool {
         const StreamRec& r = S.rec(i);
         if (S.ds == nd) return false;  // :338-339
+        if (prof) {
+            auto t0 = std::chrono::steady_clock::now();
+            while (S.ds != nd && (D[S.ds].refid < r.refid || (D[S.ds].refid == r.refid && S.nextdisright < r.pos))) { S.process_cluster(r.refid, r.pos); ++n_clusters; }
+            t_cluster += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
         while (S.ds != nd && (D[S.ds].refid < r.refid || (D[S.ds].refid == r.refid && S.nextdisright < r.pos))) S.process_cluster(r.refid, r.pos);
         const bool disLead = S.disChr > S.otherChr || (S.disChr == S.otherChr && S.disright > S.otherright);
         const int curRight = disLead ? S.disright : S.otherright, curChr = std::max(S.disChr, S.otherChr);
@@ -454,6 +581,7 @@ int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds, bool virt
         return true;
     };
     const int ncl = (int)S.clusters.size();
+    const auto t_begin = std::chrono::steady_clock::now();
     S.new_cluster();  // the reference does this at its first kept record (:341)
     for (int k = 0; k < plan.k0; ++k) S.new_cluster();  // clusters consumed by the closing record of an earlier shard
     for (size_t a = 0; a < active.size(); ++a) {
@@ -462,7 +590,7 @@ int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds, bool virt
         const int64_t lo = j == 0 ? -1 : Z[j - 1], hi = j < nz ? Z[j] : K;
         // a zero-coverage record empties the windows and clears the pending node end; the running
         // (otherChr, otherrightmost) in front of it comes from the GPU scan
-        S.cw.clear(); S.pw.clear(); S.co = S.po = 0;
+        S.win_clear(S.cw, S.ci, S.co); S.win_clear(S.pw, S.pi, S.po);
         if (lo >= 0) {
             if (S.markStart != -1) return fail(c, SQ_E_ARG, "internal: pending node end at a zero-coverage record");
             S.otherChr = sup.z_ochr[j - 1]; S.otherright = sup.z_oright[j - 1];
@@ -476,6 +604,7 @@ int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds, bool virt
             // the head step of the last of them is the pruning that the trigger record finds
             const int64_t t = S.kc < ncl ? std::min<int64_t>(sup.trigger[S.kc], hi) : hi;
             if (i < t) {
+                n_pushed += t - i;
                 for (; i < t - 1; ++i) push_step(i);
                 prune_all(S.rec(i).refid);
                 push_step(i);
@@ -492,6 +621,10 @@ int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds, bool virt
         if (alive && hi < K) alive = head_step(hi, z);  // its push step opens the next stretch
         if (!alive) break;
     }
+    if (prof) std::fprintf(stderr, "[replay] M-build %.3f ms (sumM %lld)  brk-loop %.3f ms (sum rest %lld)  tail %.3f ms (win left %lld)\n", S.tsec[0], S.nsec[0], S.tsec[1], S.nsec[1], S.tsec[2], S.nsec[2]);
+    if (prof) std::fprintf(stderr, "[replay] brks %lld  counts %.3f ms  win+blk spans %.3f ms (%lld)  rest %.3f ms (%lld)\n", S.nsec[3], S.tsec[3], S.tsec[4], S.nsec[4], S.tsec[5], S.nsec[5]);
+    if (prof) std::fprintf(stderr, "[replay] stretches=%zu pushed=%lld clusters=%lld t_cluster=%.3f ms total=%.3f ms\n", active.size(), n_pushed, n_clusters, t_cluster,
+                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     if (virtual_back) sink.erase(sink.begin());
     seeds = sink;
     return SQ_OK;
