@@ -230,6 +230,8 @@ static int build_graph(sq_ctx* c) {
             rc = tile_genome(c, seedcopy, c->nodes);
         }
         if (rc) return rc;
+        rc = dev_upload_nodes(c, c->nodes);
+        if (rc) return rc;
         std::vector<int32_t> unused;
         rc = dev_node_depth(c, c->nodes, g.n_break, g.sup, g.sl, g.tiny_boundary, g.amb_plus, g.amb_minus, unused);
         if (rc) return rc;

@@ -48,7 +48,11 @@ struct NodeView {
     int32_t n, n_ref;
     const int32_t *chr, *pos, *len;
     const int32_t* chr_start;  // n_ref+1: first node index of each chromosome
+    // coarse position index: bucket[bucket_off[c] + (p >> NODE_BUCKET_SHIFT)] = node that contains the first base of
+    // that 16 KiB stretch of chromosome c, so a lookup is one load plus a short walk instead of a 17-step binary search
+    const int32_t *bucket, *bucket_off;
 };
+constexpr int NODE_BUCKET_SHIFT = 14;
 
 template <typename T>
 struct DBuf {
@@ -127,7 +131,8 @@ struct DeviceRecords {
     DBuf<StreamRec> srec;
     DBuf<int32_t> rest_refpos, rest_matchref;
     // node table
-    DBuf<int32_t> n_chr, n_pos, n_len, n_chr_start;
+    DBuf<int32_t> n_chr, n_pos, n_len, n_chr_start, n_bucket, n_bucket_off;
+    NodeView nv{};  // the node table of the current graph build (dev_upload_nodes)
     DBuf<int32_t> acc_a, acc_b, acc_c, acc_d, acc_e, acc_f;  // per-node accumulators
     // edge hash
     DBuf<unsigned long long> h_key, okey;
@@ -135,7 +140,7 @@ struct DeviceRecords {
     uint32_t h_slots = 1u << 16;
     DBuf<SmallProblem> ord_p;
     DBuf<int32_t> ord_e, ord_m, ord_o, ord_v;
-    DBuf<long long> other64, spine64;
+    DBuf<long long> other64, spine64, okey64;
     DBuf<uint8_t> bam_chunk;
     DBuf<unsigned long long> bam_off, chim_hash;
     DBuf<uint32_t> chim_off, chim_len;
@@ -145,7 +150,7 @@ struct DeviceRecords {
     DBuf<int32_t> calib;
     DBuf<uint8_t> zflag;
     DBuf<int32_t> cl_chr, cl_start, cl_right, trig;
-    DBuf<int32_t> bp_ev, bp_end, bp_valid;
+    DBuf<int32_t> bp_ev, bp_end, bp_valid, bp_bucket, stripes;
     DBuf<int32_t> flags;  // small device flag/counter block
     struct Pending { const char* name; double bytes; int slot; };
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -223,13 +228,38 @@ __device__ bool rec_equal(const RecView& R, int64_t q, int64_t r) {
 }
 
 // last node with (chr,pos) <= (c,p); nodes tile every chromosome, so this is the node containing p
-__device__ __forceinline__ int node_home(const NodeView& N, int c, int p) {
+__device__ __forceinline__ int node_home_search(const NodeView& N, int c, int p) {
     int lo = N.chr_start[c], hi = N.chr_start[c + 1];  // [lo,hi)
     while (hi - lo > 1) {
         int mid = (lo + hi) >> 1;
         if (N.pos[mid] <= p) lo = mid; else hi = mid;
     }
     return lo;
+}
+// same result, starting from a node h of chromosome c with N.pos[h] <= p: gallop, then bisect
+__device__ __forceinline__ int node_home_from(const NodeView& N, int c, int p, int h) {
+    const int hi = N.chr_start[c + 1];
+    int step = 1;
+    while (h + step < hi && N.pos[h + step] <= p) { h += step; step <<= 1; }
+    int up = h + step < hi ? h + step : hi;
+    while (up - h > 1) {
+        int mid = (h + up) >> 1;
+        if (N.pos[mid] <= p) h = mid; else up = mid;
+    }
+    return h;
+}
+__device__ __forceinline__ int node_home(const NodeView& N, int c, int p) {
+    int b = N.bucket_off[c] + (p < 0 ? 0 : (p >> NODE_BUCKET_SHIFT));
+    const int last = N.bucket_off[c + 1] - 1;
+    if (b > last) b = last;  // a position behind the reference end
+    return node_home_from(N, c, p, N.bucket[b]);
+}
+__global__ void k_node_buckets(NodeView N, int total, int32_t* bucket) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    int lo = 0, hi = N.n_ref;  // chromosome of this bucket: last c with bucket_off[c] <= g
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (N.bucket_off[mid] <= g) lo = mid; else hi = mid; }
+    bucket[g] = node_home_search(N, lo, (g - N.bucket_off[lo]) << NODE_BUCKET_SHIFT);
 }
 
 // ------------------------------------------------------------------------------------------------ scans
@@ -592,7 +622,7 @@ __global__ void k_dedup(RecView R, const uint8_t* cls, const int32_t* prev1, con
 }
 
 __global__ void k_summarise(RecView R, const uint8_t* cls, const uint8_t* keep, const int32_t* rank1, const int32_t* restoff,
-                            StreamRec* out, int32_t* rest_refpos, int32_t* rest_matchref) {
+                            StreamRec* out, int32_t* rest_refpos, int32_t* rest_matchref, long long* other_key) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R.n || !(keep[r] & K_1)) return;
     StreamRec s;
@@ -616,6 +646,8 @@ __global__ void k_summarise(RecView R, const uint8_t* cls, const uint8_t* keep, 
     }
     s.flags = fl;
     out[rank1[r]] = s;
+    // key of the running (otherChr, otherrightmost) pair, SegmentGraph.cpp:655-667 (its max-scan streams 8 B instead of the summary)
+    other_key[rank1[r]] = (fl & (SR_CONC | SR_MATE)) == (SR_CONC | SR_MATE) ? (((long long)s.refid << 32) | (unsigned int)(s.fb_refpos + s.fb_matchref)) : LLONG_MIN;
 }
 
 // ------------------------------------------------------------------------------------------------ K2 support
@@ -635,6 +667,7 @@ __device__ __forceinline__ int clusters_passed(const ClusterView& C, int refid, 
     while (lo < hi) { int mid = (lo + hi) >> 1; if (C.chr[mid] < refid || (C.chr[mid] == refid && C.right[mid] < pos)) lo = mid + 1; else hi = mid; }
     return lo;
 }
+struct FKey64 { const long long* a; __device__ long long operator()(int64_t i) const { return a[i]; } };
 struct FOtherKey {
     const StreamRec* sr;
     __device__ long long operator()(int64_t i) const {
@@ -732,6 +765,13 @@ struct FEarlyMain {  // first block of every consumed kept record, in stream ord
         return depth_early(N, c, R.b_refpos[b0], R.b_matchref[b0], home);
     }
 };
+// statistics counters: one atomic per wave, spread over NSTRIPE addresses (a single hot address serialises in L2:
+// 800 k waves adding to one word cost more than the rest of the kernel); the host sums the stripes
+constexpr int NSTRIPE = 256;
+__device__ __forceinline__ void stripe_add(int32_t* stripes, int v) {
+    atomicAdd(&stripes[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (NSTRIPE - 1)], v);
+}
+
 // add (1, len) to node `at` for every lane with `valid`; lanes of a wave that hit the same node are combined first
 // (a wave covers 64 neighbouring records of the sorted stream, which almost always share their node).
 // Must be called by ALL lanes of the wave (the shuffles read every lane).
@@ -750,7 +790,7 @@ __device__ __forceinline__ void node_add(int32_t* cnt, int32_t* sum, bool valid,
     }
 }
 __global__ void k_depth(RecView R, NodeView N, const uint8_t* keep, const int32_t* rank1, int32_t n_break, const int32_t* cursor,
-                        int32_t* main_cnt, int32_t* main_sum, int32_t* other_cnt, int32_t* other_sum, int32_t* amb_plus, int32_t* amb_minus, int32_t* flags) {
+                        int32_t* main_cnt, int32_t* main_sum, int32_t* other_cnt, int32_t* other_sum, int32_t* amb_plus, int32_t* amb_minus, int32_t* flags, int32_t* stripes) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool live = r < R.n && (keep[r] & K_1) && rank1[r] < n_break;
     uint32_t b0 = live ? R.blk_off[r] : 0;
@@ -773,7 +813,35 @@ __global__ void k_depth(RecView R, NodeView N, const uint8_t* keep, const int32_
     // ReadsOther: sorted by (chr,pos) in the reference => consumed at its home node
     int maxb = nblk;
     for (int d = 32; d >= 1; d >>= 1) { int o = __shfl_xor(maxb, d, 64); maxb = o > maxb ? o : maxb; }
-    for (int k = 1; k < maxb; ++k) {  // wave-uniform trip count
+    // a <=3-base block right behind a node boundary: the reference counts it for whichever node its sweep cursor is on,
+    // which depends on the tie order of an unstable sort (SegmentGraph.cpp:781).  Record the bounds.
+    auto ambiguous = [&](int early, int home, int len, bool hit) {
+        atomicOr(&flags[0], 2);
+        for (int q = early; q < home; ++q) atomicAdd(&amb_plus[q], len);
+        if (hit) atomicAdd(&amb_minus[home], len);
+    };
+    // blocks 1..3 of every record are located together (independent load chains overlap), then added; the rare
+    // records with more blocks finish in the serial loop below
+    constexpr int UNR = 3;
+    int hk[UNR], ek[UNR], lk[UNR];
+    bool hitk[UNR];
+#pragma unroll
+    for (int j = 0; j < UNR; ++j) {
+        hk[j] = 0; ek[j] = 0; lk[j] = 0; hitk[j] = false;
+        if (j + 1 < nblk) {
+            const int p = R.b_refpos[b0 + j + 1];
+            lk[j] = R.b_matchref[b0 + j + 1];
+            ek[j] = depth_early(N, c, p, lk[j], hk[j]);
+            hitk[j] = p + lk[j] <= N.pos[hk[j]] + N.len[hk[j]] + 3;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < UNR; ++j) {
+        if (j + 1 >= maxb) break;  // wave-uniform
+        if (j + 1 < nblk && ek[j] != hk[j]) ambiguous(ek[j], hk[j], lk[j], hitk[j]);
+        node_add(other_cnt, other_sum, hitk[j], hk[j], lk[j]);
+    }
+    for (int k = UNR + 1; k < maxb; ++k) {  // wave-uniform trip count
         bool hit = false;
         int home = 0, len = 0;
         if (k < nblk) {
@@ -781,19 +849,13 @@ __global__ void k_depth(RecView R, NodeView N, const uint8_t* keep, const int32_
             len = R.b_matchref[b0 + k];
             int early = depth_early(N, c, p, len, home);
             hit = p + len <= N.pos[home] + N.len[home] + 3;
-            if (early != home) {
-                // a <=3-base block right behind a node boundary: the reference counts it for whichever node its sweep cursor
-                // is on, which depends on the tie order of an unstable sort (SegmentGraph.cpp:781).  Record the bounds.
-                atomicOr(&flags[0], 2);
-                for (int q = early; q < home; ++q) atomicAdd(&amb_plus[q], len);
-                if (hit) atomicAdd(&amb_minus[home], len);
-            }
+            if (early != home) ambiguous(early, home, len, hit);
         }
         node_add(other_cnt, other_sum, hit, home, len);
     }
     int no = nblk > 1 ? nblk - 1 : 0;
     for (int d = 32; d >= 1; d >>= 1) no += __shfl_xor(no, d, 64);
-    if ((threadIdx.x & 63) == 0 && no) atomicAdd(&flags[1], no);
+    if ((threadIdx.x & 63) == 0 && no) stripe_add(stripes, no);
 }
 // number of non-first blocks of a consumed kept record (|ReadsOther| contributions), for the ordered gather
 struct FOtherCount {
@@ -902,7 +964,7 @@ __device__ __forceinline__ void hash_add(unsigned long long* hk, uint32_t* hv, u
     }
     atomicOr(&flags[0], 4);  // table full
 }
-__device__ __forceinline__ void emit_edge(unsigned long long* hk, uint32_t* hv, uint32_t mask, int i, bool hi, int j, bool hj, int32_t* flags, int nnodes) {
+__device__ __forceinline__ void emit_edge(unsigned long long* hk, uint32_t* hv, uint32_t mask, int i, bool hi, int j, bool hj, int32_t* flags, int32_t* stripes, int nnodes) {
     if (i < 0 || j < 0 || i >= nnodes || j >= nnodes) { atomicOr(&flags[0], 8); return; }  // reference: assert(...) aborts
     int a = i, b = j; bool ha = hi, hb = hj;
     if (i > j) { a = j; ha = hj; b = i; hb = hi; }
@@ -910,6 +972,7 @@ __device__ __forceinline__ void emit_edge(unsigned long long* hk, uint32_t* hv, 
     // combine equal keys inside the wave before touching the table (neighbouring records emit the same edge)
     unsigned long long active = __ballot(1);
     int lane = threadIdx.x & 63;
+    if (lane == __ffsll((long long)active) - 1) stripe_add(stripes, (int)__popcll(active));  // raw edge count
     while (active) {
         int leader = __ffsll((long long)active) - 1;
         unsigned long long k = __shfl(key, leader, 64);
@@ -918,7 +981,6 @@ __device__ __forceinline__ void emit_edge(unsigned long long* hk, uint32_t* hv, 
         if (key == k) break;
         active &= ~same;
     }
-    atomicAdd(&flags[2], 1);
 }
 
 struct EdgeParams { int dp, di; };
@@ -932,7 +994,7 @@ __device__ __forceinline__ bool dev_edge_discordant(const NodeView& N, const Edg
 }
 
 __global__ void k_edges(RecView R, NodeView N, EdgeParams P, const uint8_t* keep, const int32_t* part_prev, const int32_t* part_next, const int32_t* b0_a,
-                        const int32_t* b0_b, const int32_t* b0_home, unsigned long long* hk, uint32_t* hv, uint32_t hmask, int32_t* flags) {
+                        const int32_t* b0_b, const int32_t* b0_home, unsigned long long* hk, uint32_t* hv, uint32_t hmask, int32_t* flags, int32_t* stripes) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R.n || !(keep[r] & K_BUILD)) return;
     // ---- incoming hint: walk back to a record whose block 0 pins the hint, then replay forward
@@ -990,7 +1052,7 @@ __global__ void k_edges(RecView R, NodeView N, EdgeParams P, const uint8_t* keep
             else {
                 int h = node_home(N, bc, bp);
                 if (N.pos[h] == bp && h > N.chr_start[bc] && ffi <= h - 1) --h;
-                emit_edge(hk, hv, hmask, h, false, h + 1, true, flags, N.n);
+                emit_edge(hk, hv, hmask, h, false, h + 1, true, flags, stripes, N.n);
             }
         }
         if (k == 0) { node0 = nd; ffi = nd != -1 ? nd : hint; }
@@ -999,7 +1061,7 @@ __global__ void k_edges(RecView R, NodeView N, EdgeParams P, const uint8_t* keep
             if (ko == 0) { of_c = bc; of_p = bp; of_rp = brp; of_rev = brev; }
             else {
                 // consecutive blocks of one mate in different nodes (SegmentGraph.cpp:1631-1653)
-                if (pv_node != nd && pv_node != -1 && nd != -1) emit_edge(hk, hv, hmask, pv_node, pv_rev, nd, !brev, flags, N.n);
+                if (pv_node != nd && pv_node != -1 && nd != -1) emit_edge(hk, hv, hmask, pv_node, pv_rev, nd, !brev, flags, stripes, N.n);
                 // IsEndDiscordant on the trimmed blocks (ReadRec.cpp:178-209)
                 if (pv_c != bc || pv_rev != brev) own_enddisc = true;
                 else {
@@ -1040,7 +1102,7 @@ __global__ void k_edges(RecView R, NodeView N, EdgeParams P, const uint8_t* keep
             else if (!of_rev && of_p - of_rp > st_p - (stot - st_rp - st_mr)) pd = true;
             else if (!st_rev && st_p - st_rp > ol_p - (ftot - ol_rp - ol_mr)) pd = true;
             else pd = false;
-            if (pd == dev_edge_discordant(N, P, a, ol_rev, b, st_rev)) emit_edge(hk, hv, hmask, a, ol_rev, b, st_rev, flags, N.n);
+            if (pd == dev_edge_discordant(N, P, a, ol_rev, b, st_rev)) emit_edge(hk, hv, hmask, a, ol_rev, b, st_rev, flags, stripes, N.n);
         }
     }
 }
@@ -1062,11 +1124,28 @@ __global__ void k_hash_compact(const unsigned long long* hk, const uint32_t* hv,
 // (k_bp_walk) that replays the true recurrence from the event until the cursor has caught up and corrects the
 // records it passed.  An event whose start lies inside the walk of an earlier valid one is absorbed by it
 // (k_bp_chain decides that in stream order; events are indexed by their M value, which grows with the stream).
-struct BPView { int32_t n; const int32_t *chr, *pos; int dp; };
-__device__ __forceinline__ int bp_lower_bound(const BPView& B, int c, int p) {  // first j with (chr,pos) >= (c,p)
+// `bucket` is the coarse position index of the node table's geometry (NodeView::bucket_off): the answer for the first
+// base of every 16 KiB stretch, so a query is one load and a short walk
+struct BPView { int32_t n; const int32_t *chr, *pos; int dp; const int32_t *bucket, *bucket_off; };
+__device__ __forceinline__ int bp_lower_bound_search(const BPView& B, int c, int p) {  // first j with (chr,pos) >= (c,p)
     int lo = 0, hi = B.n;
     while (lo < hi) { int mid = (lo + hi) >> 1; if (B.chr[mid] < c || (B.chr[mid] == c && B.pos[mid] < p)) lo = mid + 1; else hi = mid; }
     return lo;
+}
+__device__ __forceinline__ int bp_lower_bound(const BPView& B, int c, int p) {
+    const int first = B.bucket_off[c], last = B.bucket_off[c + 1] - 1;
+    int b = first + (p <= 0 ? 0 : (p >> NODE_BUCKET_SHIFT));
+    if (b > last) b = last;
+    int j = B.bucket[b];
+    while (j < B.n && B.chr[j] == c && B.pos[j] < p) ++j;
+    return j;
+}
+__global__ void k_bp_buckets(BPView B, int n_ref, int total, int32_t* bucket) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    int lo = 0, hi = n_ref;  // chromosome of this bucket: last c with bucket_off[c] <= g
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (B.bucket_off[mid] <= g) lo = mid; else hi = mid; }
+    bucket[g] = bp_lower_bound_search(B, lo, (g - B.bucket_off[lo]) << NODE_BUCKET_SHIFT);
 }
 __device__ __forceinline__ int bp_start(const RecView& R, int64_t r) {  // SegmentGraph.cpp:3147-3150
     int c = R.refid[r], st = R.pos[r];
@@ -1079,10 +1158,8 @@ __global__ void k_bp_m(RecView R, BPView B, const uint8_t* cls, int32_t* m) {
     int v = INT_MIN;  // identity of max for records outside pass 3
     if (cls[r] & C_P3) {
         int c = R.refid[r], st = bp_start(R, r);
-        // #j with c > chr_j || (c == chr_j && st > pos_j + dp)  ==  lower_bound over (chr, pos+dp) of (c, st)
-        int lo = 0, hi = B.n;
-        while (lo < hi) { int mid = (lo + hi) >> 1; if (B.chr[mid] < c || (B.chr[mid] == c && B.pos[mid] + B.dp < st)) lo = mid + 1; else hi = mid; }
-        v = lo;
+        // #j with c > chr_j || (c == chr_j && st > pos_j + dp)  ==  first j with (chr_j, pos_j) >= (c, st - dp)
+        v = bp_lower_bound(B, c, st - B.dp);
     }
     m[r] = v;
 }
@@ -1393,13 +1470,13 @@ void dev_destroy(sq_ctx* c) {
     D.scratch_a.release(); D.scratch_b.release(); D.scratch_c.release(); D.spine.release();
     D.part_prev.release(); D.part_next.release(); D.b0_a.release(); D.b0_b.release(); D.b0_home.release();
     D.srec.release(); D.rest_refpos.release(); D.rest_matchref.release();
-    D.n_chr.release(); D.n_pos.release(); D.n_len.release(); D.n_chr_start.release();
+    D.n_chr.release(); D.n_pos.release(); D.n_len.release(); D.n_chr_start.release(); D.n_bucket.release(); D.n_bucket_off.release();
     D.acc_a.release(); D.acc_b.release(); D.acc_c.release(); D.acc_d.release(); D.acc_e.release(); D.acc_f.release();
     D.h_key.release(); D.h_val.release(); D.flags.release(); D.bam_chunk.release(); D.bam_off.release(); D.chim_hash.release(); D.chim_off.release(); D.chim_len.release(); D.chim_blob.release(); D.parse_nblk.release(); D.parse_rel.release();
-    D.calib.release(); D.okey.release(); D.oval.release(); D.other64.release(); D.spine64.release(); D.zflag.release();
+    D.calib.release(); D.okey.release(); D.oval.release(); D.other64.release(); D.spine64.release(); D.okey64.release(); D.zflag.release();
     D.cl_chr.release(); D.cl_start.release(); D.cl_right.release(); D.trig.release();
     D.ord_p.release(); D.ord_e.release(); D.ord_m.release(); D.ord_o.release(); D.ord_v.release();
-    D.pin.release(); D.bp_ev.release(); D.bp_end.release(); D.bp_valid.release();
+    D.pin.release(); D.stripes.release(); D.bp_bucket.release(); D.bp_ev.release(); D.bp_end.release(); D.bp_valid.release();
     for (auto& e : D.ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete c->dev;
     c->dev = nullptr;
@@ -1524,21 +1601,32 @@ int dev_download_records(sq_ctx* c, HostBatch& hb) {
     return SQ_OK;
 }
 
-static int upload_nodes(sq_ctx* c, const std::vector<Node>& nodes, NodeView& nv) {
+int dev_upload_nodes(sq_ctx* c, const std::vector<Node>& nodes) {
     DeviceRecords& D = *c->dev;
+    hipStream_t s = c->stream;
     const int n = (int)nodes.size(), nref = (int)c->ref_len.size();
-    std::vector<int32_t> chr(n), pos(n), len(n), cs(nref + 1, n);
+    std::vector<int32_t> chr(n), pos(n), len(n), cs(nref + 1, n), bo(nref + 1, 0);
     for (int i = n - 1; i >= 0; --i) { chr[i] = nodes[i].chr; pos[i] = nodes[i].pos; len[i] = nodes[i].len; }
     // chr_start[k] = first node with chr >= k
     int j = 0;
     for (int k = 0; k <= nref; ++k) { while (j < n && nodes[j].chr < k) ++j; cs[k] = j; }
+    for (int k = 0; k < nref; ++k) {
+        if (cs[k] == cs[k + 1]) return fail(c, SQ_E_ARG, "internal: a reference without nodes (the tiling covers every chromosome)");
+        bo[k + 1] = bo[k] + (int32_t)(((int64_t)std::max(c->ref_len[k], 1) + (1 << NODE_BUCKET_SHIFT) - 1) >> NODE_BUCKET_SHIFT);
+    }
+    const int total = bo[nref];
     HIPCHK(D.n_chr.reserve(n)); HIPCHK(D.n_pos.reserve(n)); HIPCHK(D.n_len.reserve(n)); HIPCHK(D.n_chr_start.reserve(nref + 1));
-    HIPCHK(hipMemcpyAsync(D.n_chr.p, chr.data(), n * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(D.n_pos.p, pos.data(), n * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(D.n_len.p, len.data(), n * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(D.n_chr_start.p, cs.data(), (nref + 1) * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(D.n_bucket.reserve(std::max(total, 1))); HIPCHK(D.n_bucket_off.reserve(nref + 1));
+    HIPCHK(hipMemcpyAsync(D.n_chr.p, chr.data(), n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(D.n_pos.p, pos.data(), n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(D.n_len.p, len.data(), n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(D.n_chr_start.p, cs.data(), (nref + 1) * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(D.n_bucket_off.p, bo.data(), (nref + 1) * 4, hipMemcpyHostToDevice, s));
+    NodeView& nv = D.nv;
     nv.n = n; nv.n_ref = nref; nv.chr = D.n_chr.p; nv.pos = D.n_pos.p; nv.len = D.n_len.p; nv.chr_start = D.n_chr_start.p;
+    nv.bucket = D.n_bucket.p; nv.bucket_off = D.n_bucket_off.p;
+    if (total) { EvTimer t(c, "k_node_buckets", 4.0 * total); hipLaunchKernelGGL(k_node_buckets, dim3((total + 255) / 256), dim3(256), 0, s, nv, total, D.n_bucket.p); }
+    HIPCHK(hipStreamSynchronize(s));  // the host vectors go out of scope
     return SQ_OK;
 }
 
@@ -1590,10 +1678,11 @@ int dev_dedup_summarise(sq_ctx* c) {
     const int64_t k1 = h_tot[0], nrest = h_tot[1];
     D.k1 = k1;
     // one spare slot: a sharded run appends the first kept record of the next shard (Shard::has_terminal)
+    HIPCHK(D.okey64.reserve((size_t)k1 + 1));
     HIPCHK(D.srec.reserve((size_t)k1 + 1)); HIPCHK(D.rest_refpos.reserve((size_t)std::max<int64_t>(nrest, 1))); HIPCHK(D.rest_matchref.reserve((size_t)std::max<int64_t>(nrest, 1)));
     if (n > 0) {
-        EvTimer t(c, "k_summarise", 28.0 * n + 12.0 * D.nb + 20.0 * k1);
-        hipLaunchKernelGGL(k_summarise, grid_for(n, 256), dim3(256), 0, s, R, D.cls.p, D.keep.p, D.rank1.p, D.restoff.p, D.srec.p, D.rest_refpos.p, D.rest_matchref.p);
+        EvTimer t(c, "k_summarise", 28.0 * n + 12.0 * D.nb + 32.0 * k1);
+        hipLaunchKernelGGL(k_summarise, grid_for(n, 256), dim3(256), 0, s, R, D.cls.p, D.keep.p, D.rank1.p, D.restoff.p, D.srec.p, D.rest_refpos.p, D.rest_matchref.p, D.okey64.p);
     }
     c->counts.n_kept_p2 = nrest;  // (re-used slot: number of ConcordRest source blocks)
     c->counts.n_kept_p1 = k1;
@@ -1619,8 +1708,8 @@ int dev_stream_scan(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::ve
     }
     ClusterView C{ncl, D.cl_chr.p, D.cl_start.p, D.cl_right.p};
     HIPCHK(D.other64.reserve(k + 1)); HIPCHK(D.zflag.reserve(k + 1)); HIPCHK(D.scratch_a.reserve(k + 1));
-    { EvTimer t(c, "k_stream_scan", 20.0 * k);
-      HIPCHK((device_scan<OpMax64, true>(s, k, FOtherKey{D.srec.p}, D.other64.p, D.spine64, D.other64.p + k)));  // aggregate behind the last element
+    { EvTimer t(c, "k_stream_scan", 24.0 * k);
+      HIPCHK((device_scan<OpMax64, true>(s, k, FKey64{D.okey64.p}, D.other64.p, D.spine64, D.other64.p + k)));  // aggregate behind the last element
       if (ncl) hipLaunchKernelGGL(k_triggers, grid_for(ncl, 64), dim3(64), 0, s, D.srec.p, k, C, D.trig.p); }
     if (fetch) {
         StreamRec first;
@@ -1770,37 +1859,43 @@ int dev_node_depth(sq_ctx* c, const std::vector<Node>& nodes, int64_t n_break, s
     hipStream_t s = c->stream;
     const int64_t n = D.n;
     const int nn = (int)nodes.size();
-    NodeView nv;
-    int rc = upload_nodes(c, nodes, nv);
-    if (rc) return rc;
+    if (D.nv.n != nn) return fail(c, SQ_E_ARG, "internal: dev_upload_nodes first");
+    const NodeView nv = D.nv;
     HIPCHK(D.acc_a.reserve(nn)); HIPCHK(D.acc_b.reserve(nn)); HIPCHK(D.acc_c.reserve(nn)); HIPCHK(D.acc_d.reserve(nn)); HIPCHK(D.acc_e.reserve(nn)); HIPCHK(D.acc_f.reserve(nn));
     HIPCHK(D.scratch_a.reserve(std::max<int64_t>(n, 1)));
     HIPCHK(hipMemsetAsync(D.acc_a.p, 0, nn * 4, s)); HIPCHK(hipMemsetAsync(D.acc_b.p, 0, nn * 4, s)); HIPCHK(hipMemsetAsync(D.acc_c.p, 0, nn * 4, s)); HIPCHK(hipMemsetAsync(D.acc_d.p, 0, nn * 4, s));
     HIPCHK(hipMemsetAsync(D.acc_e.p, 0, nn * 4, s)); HIPCHK(hipMemsetAsync(D.acc_f.p, 0, nn * 4, s));
     HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
+    HIPCHK(D.stripes.reserve(NSTRIPE));
+    HIPCHK(hipMemsetAsync(D.stripes.p, 0, NSTRIPE * 4, s));
     RecView R = D.view();
     const int32_t nbk = (int32_t)std::min<int64_t>(n_break, INT32_MAX);
     if (n > 0) {
         { EvTimer t(c, "scan_depth_cursor", 12.0 * n);
           HIPCHK((device_scan<OpMax, false>(s, n, FEarlyMain{R, nv, D.keep.p, D.rank1.p, nbk}, D.scratch_a.p, D.spine, nullptr))); }
         { EvTimer t(c, "k_depth", 13.0 * n + 8.0 * D.nb);
-          hipLaunchKernelGGL(k_depth, grid_for(n, 256), dim3(256), 0, s, R, nv, D.keep.p, D.rank1.p, nbk, D.scratch_a.p, D.acc_a.p, D.acc_b.p, D.acc_c.p, D.acc_d.p, D.acc_e.p, D.acc_f.p, D.flags.p); }
+          hipLaunchKernelGGL(k_depth, grid_for(n, 256), dim3(256), 0, s, R, nv, D.keep.p, D.rank1.p, nbk, D.scratch_a.p, D.acc_a.p, D.acc_b.p, D.acc_c.p, D.acc_d.p, D.acc_e.p, D.acc_f.p, D.flags.p, D.stripes.p); }
     }
-    std::vector<int32_t> mc(nn), ms(nn), oc(nn), os(nn);
-    amb_plus.assign(nn, 0); amb_minus.assign(nn, 0);
-    int32_t hf[4];
-    HIPCHK(hipMemcpyAsync(mc.data(), D.acc_a.p, nn * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(ms.data(), D.acc_b.p, nn * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(oc.data(), D.acc_c.p, nn * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(os.data(), D.acc_d.p, nn * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(amb_plus.data(), D.acc_e.p, nn * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(amb_minus.data(), D.acc_f.p, nn * 4, hipMemcpyDeviceToHost, s));
+    D.pin.reset();
+    int32_t* h = D.pin.take_n<int32_t>(6 * (size_t)nn + 8 + NSTRIPE);
+    if (!h) return fail(c, SQ_E_HIP, "hipHostMalloc failed");
+    int32_t *mc = h, *ms = h + nn, *oc = h + 2 * nn, *os = h + 3 * nn, *ap = h + 4 * nn, *am = h + 5 * nn, *hf = h + 6 * nn, *hs = hf + 8;
+    HIPCHK(hipMemcpyAsync(mc, D.acc_a.p, nn * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(ms, D.acc_b.p, nn * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(oc, D.acc_c.p, nn * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(os, D.acc_d.p, nn * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(ap, D.acc_e.p, nn * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(am, D.acc_f.p, nn * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(hf, D.flags.p, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hs, D.stripes.p, NSTRIPE * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (hf[0] & 1) return fail(c, SQ_E_UNSORTED, "concordant stream is not coordinate sorted (depth cursor left its chromosome)");
     need_exact_other = hf[0] & 2;
+    amb_plus.assign(ap, ap + nn); amb_minus.assign(am, am + nn);
     support.assign(nn * 2, 0);
     sumlen.assign(nn * 2, 0);
     for (int i = 0; i < nn; ++i) { support[i] = mc[i]; sumlen[i] = ms[i]; support[nn + i] = oc[i]; sumlen[nn + i] = os[i]; }
     // sumlen layout: [0,nn) main, [nn,2nn) other; element 2nn = |ReadsOther|
-    support.push_back(hf[1]);
+    long long n_other = 0;
+    for (int i = 0; i < NSTRIPE; ++i) n_other += hs[i];
+    support.push_back((int32_t)std::min<long long>(n_other, INT32_MAX));
     (void)other_len;
     return SQ_OK;
 }
@@ -1812,9 +1907,8 @@ int dev_concordant_edges(sq_ctx* c, const std::vector<Node>& nodes, std::vector<
     const int64_t n = D.n;
     unique_edges.clear();
     if (n == 0) return SQ_OK;
-    NodeView nv;
-    int rc = upload_nodes(c, nodes, nv);
-    if (rc) return rc;
+    if (D.nv.n != (int)nodes.size()) return fail(c, SQ_E_ARG, "internal: dev_upload_nodes first");
+    const NodeView nv = D.nv;
     RecView R = D.view();
     HIPCHK(D.part_prev.reserve(n)); HIPCHK(D.part_next.reserve(n)); HIPCHK(D.b0_a.reserve(n)); HIPCHK(D.b0_b.reserve(n)); HIPCHK(D.b0_home.reserve(n));
     { EvTimer t(c, "scan_part", 1.0 * n); HIPCHK((device_scan<OpMax, true>(s, n, FPart{D.keep.p}, D.part_prev.p, D.spine, nullptr))); }
@@ -1822,39 +1916,40 @@ int dev_concordant_edges(sq_ctx* c, const std::vector<Node>& nodes, std::vector<
     { EvTimer t(c, "k_block0", 33.0 * n + 12.0 * D.nb);
       hipLaunchKernelGGL(k_block0, grid_for(n, 256), dim3(256), 0, s, R, nv, D.keep.p, D.part_prev.p, D.part_next.p, D.b0_a.p, D.b0_b.p, D.b0_home.p); }
     EdgeParams ep{c->P.concord_dist_pos, c->P.concord_dist_idx};
-    int32_t hf[4];
+    D.pin.reset();
+    int32_t* h = D.pin.take_n<int32_t>(8 + NSTRIPE);
+    if (!h) return fail(c, SQ_E_HIP, "hipHostMalloc failed");
+    HIPCHK(D.stripes.reserve(NSTRIPE));
     for (;;) {  // the table starts small and doubles when it fills up (unique edges are few)
         const uint32_t slots = D.h_slots;
         HIPCHK(D.h_key.reserve(slots)); HIPCHK(D.h_val.reserve(slots));
+        HIPCHK(D.okey.reserve(slots)); HIPCHK(D.oval.reserve(slots));
         HIPCHK(hipMemsetAsync(D.h_key.p, 0xff, (size_t)slots * 8, s));
         HIPCHK(hipMemsetAsync(D.h_val.p, 0, (size_t)slots * 4, s));
         HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
+        HIPCHK(hipMemsetAsync(D.stripes.p, 0, NSTRIPE * 4, s));
         { EvTimer t(c, "k_edges", 28.0 * n + 12.0 * D.nb);
           hipLaunchKernelGGL(k_edges, grid_for(n, 256), dim3(256), 0, s, R, nv, ep, D.keep.p, D.part_prev.p, D.part_next.p, D.b0_a.p, D.b0_b.p, D.b0_home.p, D.h_key.p, D.h_val.p, slots - 1,
-                             D.flags.p); }
-        HIPCHK(hipMemcpyAsync(hf, D.flags.p, 16, hipMemcpyDeviceToHost, s));
+                             D.flags.p, D.stripes.p); }
+        // compact right away (wasted only if the table turns out to have overflowed): one synchronisation for both
+        { EvTimer t(c, "k_hash_compact", 12.0 * slots); hipLaunchKernelGGL(k_hash_compact, grid_for(slots, 256), dim3(256), 0, s, D.h_key.p, D.h_val.p, slots, D.flags.p + 4, D.okey.p, D.oval.p); }
+        HIPCHK(hipMemcpyAsync(h, D.flags.p, 8 * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(h + 8, D.stripes.p, NSTRIPE * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        if (!(hf[0] & 4)) break;
+        if (!(h[0] & 4)) break;
         if (D.h_slots >= (1u << 28)) return fail(c, SQ_E_CAPACITY, "edge hash table full");
         D.h_slots <<= 2;
     }
-    const uint32_t slots = D.h_slots;
-    if (hf[0] & 8) return fail(c, SQ_E_ASSERT, "edge node index out of range (the reference asserts at SegmentGraph.cpp:1617)");
-    if (hf[0] & 16) return fail(c, SQ_E_CAPACITY, "record with more aligned blocks than the edge kernel handles");
-    c->counts.n_raw_edges = hf[2];
-    // compact the table
-    HIPCHK(hipMemsetAsync(D.flags.p + 4, 0, 4, s));
-    DBuf<unsigned long long>& okey = D.okey;
-    DBuf<uint32_t>& oval = D.oval;
-    size_t cap = (size_t)std::max(1, std::min<int>(hf[2], (int)slots));
-    HIPCHK(okey.reserve(cap)); HIPCHK(oval.reserve(cap));
-    { EvTimer t(c, "k_hash_compact", 12.0 * slots); hipLaunchKernelGGL(k_hash_compact, grid_for(slots, 256), dim3(256), 0, s, D.h_key.p, D.h_val.p, slots, D.flags.p + 4, okey.p, oval.p); }
-    int32_t cnt = 0;
-    HIPCHK(hipMemcpyAsync(&cnt, D.flags.p + 4, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    std::vector<unsigned long long> hk(cnt);
-    std::vector<uint32_t> hv(cnt);
-    if (cnt) { HIPCHK(hipMemcpyAsync(hk.data(), okey.p, (size_t)cnt * 8, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(hv.data(), oval.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); }
+    if (h[0] & 8) return fail(c, SQ_E_ASSERT, "edge node index out of range (the reference asserts at SegmentGraph.cpp:1617)");
+    if (h[0] & 16) return fail(c, SQ_E_CAPACITY, "record with more aligned blocks than the edge kernel handles");
+    long long n_raw = 0;
+    for (int i = 0; i < NSTRIPE; ++i) n_raw += h[8 + i];
+    c->counts.n_raw_edges = n_raw;
+    const int cnt = h[4];
+    unsigned long long* hk = D.pin.take_n<unsigned long long>((size_t)cnt);
+    uint32_t* hv = D.pin.take_n<uint32_t>((size_t)cnt);
+    if (!hk || !hv) return fail(c, SQ_E_HIP, "hipHostMalloc failed");
+    if (cnt) { HIPCHK(hipMemcpyAsync(hk, D.okey.p, (size_t)cnt * 8, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(hv, D.oval.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); }
     unique_edges.resize(cnt);
     for (int i = 0; i < cnt; ++i) {
         Edge e;
@@ -1929,7 +2024,15 @@ int dev_breakpoint_support(sq_ctx* c, const std::vector<std::pair<int, int>>& bp
     HIPCHK(hipMemsetAsync(D.acc_c.p, 0, (nb + 1) * 4, s));
     HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
     RecView R = D.view();
-    BPView B{nb, D.acc_a.p, D.acc_b.p, c->P.concord_dist_pos};
+    const int n_ref = (int)c->ref_len.size();
+    if (D.nv.n_ref != n_ref || !D.nv.bucket_off) return fail(c, SQ_E_ARG, "internal: breakpoint support before the node table was uploaded");
+    std::vector<int32_t> bo(n_ref + 1, 0);
+    for (int k = 0; k < n_ref; ++k) bo[k + 1] = bo[k] + (int32_t)(((int64_t)std::max(c->ref_len[k], 1) + (1 << NODE_BUCKET_SHIFT) - 1) >> NODE_BUCKET_SHIFT);
+    const int total = bo[n_ref];
+    HIPCHK(D.bp_bucket.reserve(std::max(total, 1)));
+    BPView B{nb, D.acc_a.p, D.acc_b.p, c->P.concord_dist_pos, D.bp_bucket.p, D.nv.bucket_off};
+    for (int i = 0; i < nb; ++i) if (bc[i] < 0 || bc[i] >= n_ref) return fail(c, SQ_E_ARG, "breakpoint on an unknown reference");
+    if (total) hipLaunchKernelGGL(k_bp_buckets, dim3((total + 255) / 256), dim3(256), 0, s, B, n_ref, total, D.bp_bucket.p);
     HIPCHK(D.bp_ev.reserve(nb + 1)); HIPCHK(D.bp_end.reserve(nb + 1)); HIPCHK(D.bp_valid.reserve(nb + 1));
     HIPCHK(hipMemsetAsync(D.bp_ev.p, 0xFF, (nb + 1) * 4, s));
     int32_t *m = D.scratch_b.p, *Mx = D.scratch_a.p;
