@@ -1353,13 +1353,52 @@ __device__ void ord_dp(const SmallProblem& pr, const int32_t* edges5, int mask, 
             }
     }
 }
+// the same DP by one wave: h[S] for all subsets of one size at a time (they only need the next larger size), the gain of
+// appending v to S read from two half tables (low / high four nodes of S) instead of a sum over S
+struct OrdWaveLds { int arc[64]; int half[2][8][16]; int h[256]; };
+// LDS traffic of one wave is processed in issue order; this only keeps the compiler from reordering across the point
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+__device__ int ord_dp_wave(const SmallProblem& pr, const int32_t* edges5, int mask, OrdWaveLds& L) {
+    const int n = pr.n, nm = 1 << n, lane = threadIdx.x & 63;
+    L.arc[lane] = 0;
+    wave_sync();
+    for (int e = lane; e < pr.ecount; e += 64) {
+        OrdEdge ed = ord_edge(edges5, pr.eoff + e);
+        int from, to;
+        if (ord_arc(ed, mask, from, to)) atomicAdd(&L.arc[from * 8 + to], ed.w);
+    }
+    wave_sync();
+    for (int t = lane; t < 256; t += 64) {  // half[hi][v][x] = sum of arc[u][v] over the nodes u of the half-subset x
+        const int hi = t >> 7, v = (t >> 4) & 7, x = t & 15;
+        int g = 0;
+        for (int u = 0; u < 4; ++u) if ((x >> u) & 1) g += L.arc[(u + 4 * hi) * 8 + v];
+        L.half[hi][v][x] = g;
+    }
+    if (lane == 0) L.h[nm - 1] = 0;
+    wave_sync();
+    for (int k = n - 1; k >= 0; --k) {
+        for (int S = lane; S < nm; S += 64) {
+            if (__popc(S) != k) continue;
+            int best = -1;
+            for (int v = 0; v < n; ++v) {
+                if ((S >> v) & 1) continue;
+                const int t = L.half[0][v][S & 15] + L.half[1][v][S >> 4] + L.h[S | (1 << v)];
+                best = t > best ? t : best;
+            }
+            L.h[S] = best;
+        }
+        wave_sync();
+    }
+    return L.h[0];
+}
 __global__ __launch_bounds__(256) void k_order_small(const SmallProblem* probs, const int32_t* edges5, int32_t* out_mask, int32_t* out_order, int32_t* out_value) {
     __shared__ long long s_red[4];
-    __shared__ int s_h[32][256];
-    __shared__ int s_arc[32][64];
-    __shared__ int s_ub[256];
+    __shared__ OrdWaveLds s_wave[4];
+    __shared__ int s_h[256];     // single-thread DP of the winner (traceback)
+    __shared__ int s_arc[64];
+    __shared__ int s_ub[256], s_cmask[256], s_cub[256], s_val[256];
     const SmallProblem pr = probs[blockIdx.x];
-    const int n = pr.n, nm = 1 << n, mask = threadIdx.x;
+    const int n = pr.n, nm = 1 << n, mask = threadIdx.x, wave = threadIdx.x >> 6;
     const bool live = mask < nm;
     int ub = 0, value = -1;
     unsigned long long inm = 0;  // bit 8*y + x: x must precede y
@@ -1384,28 +1423,37 @@ __global__ __launch_bounds__(256) void k_order_small(const SmallProblem* probs, 
         if (acyclic) value = ub;
     }
     int best = (int)block_max_ll(value, s_red);  // best acyclic value of the block
-    // cyclic orientations that could still win, most promising first: after every round of 32 subset DPs the bar rises
+    // cyclic orientations that could still win, most promising first, one per wave at a time; the bar rises as they finish
     const bool cand = live && !acyclic && ub > best;
     s_ub[threadIdx.x] = cand ? ub : -1;
+    s_val[threadIdx.x] = -1;
     __syncthreads();
-    int rank = 0;
-    if (cand) for (int j = 0; j < 256; ++j) { int o = s_ub[j]; rank += (o > ub || (o == ub && j < (int)threadIdx.x)) ? 1 : 0; }
-    for (int base = 0;; base += 32) {
-        const bool mine = cand && rank >= base;
-        const int top = (int)block_max_ll(mine ? ub : -1, s_red);  // largest bound that is still waiting
-        if (top <= best) break;                                      // (a cyclic orientation is worth less than its bound)
-        int got = -1;
-        if (mine && rank < base + 32 && ub > best) { ord_dp(pr, edges5, mask, s_arc[rank - base], s_h[rank - base], value, nullptr); got = value; }
-        const int round_best = (int)block_max_ll(got, s_red);
-        best = round_best > best ? round_best : best;
+    int rank = -1;
+    if (cand) {
+        rank = 0;
+        for (int j = 0; j < 256; ++j) { int o = s_ub[j]; rank += (o > ub || (o == ub && j < (int)threadIdx.x)) ? 1 : 0; }
+        s_cmask[rank] = mask; s_cub[rank] = ub;
     }
+    const int ncand = (int)block_max_ll(rank, s_red) + 1;  // (also publishes s_cmask / s_cub)
+    for (int base = 0; base < ncand; base += 4) {
+        if (s_cub[base] <= best) break;  // sorted by bound: nothing behind can win (a cyclic orientation is worth less than its bound)
+        const int mine = base + wave;
+        if (mine < ncand && s_cub[mine] > best) {
+            const int v = ord_dp_wave(pr, edges5, s_cmask[mine], s_wave[wave]);
+            if ((threadIdx.x & 63) == 0) s_val[mine] = v;
+        }
+        __syncthreads();
+        for (int w = 0; w < 4; ++w) if (base + w < ncand && s_val[base + w] > best) best = s_val[base + w];
+        __syncthreads();
+    }
+    if (cand) value = s_val[rank];
     // canonical winner: max value, then smallest mask
     const long long key = live ? (((long long)value << 16) | (long long)(0xffff - mask)) : -1;
     const long long win = block_max_ll(key, s_red);
     if (live && key == win) {
         int order[ORD_NMAX];
         if (acyclic) for (int p = 0; p < n; ++p) order[p] = (packed >> (3 * p)) & 7;
-        else ord_dp(pr, edges5, mask, s_arc[0], s_h[0], value, order);  // the tables of its round may have been reused
+        else ord_dp(pr, edges5, mask, s_arc, s_h, value, order);
         out_mask[blockIdx.x] = mask;
         out_value[blockIdx.x] = value;
         for (int p = 0; p < n; ++p) out_order[(size_t)blockIdx.x * ORD_NMAX + p] = order[p];

@@ -9,6 +9,8 @@
 // GLPK's pick among equal-valued optima and Boost's pick among equal min-cuts are not reproducible (neither
 // library is available, nothing in the reference pins them); DESIGN.md lists this as "parity unpinned".
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <atomic>
 #include <thread>
 #include <cstring>
@@ -55,6 +57,7 @@ struct HostSolver {
     long best = -1;
     unsigned bestmask = 0;
     std::vector<int> bestorder;
+    long n_nodes = 0, n_leaves = 0, n_cyclic = 0;  // search statistics (SQUID_ORDER_PROF)
     HostSolver(int n, const std::vector<LEdge>& E) : n(n), E(E) {}
 
     static bool compat(const LEdge& e, unsigned mask, bool& ufirst) {
@@ -85,24 +88,55 @@ struct HostSolver {
         std::vector<long> h;       // h[S] = best weight still obtainable inside the component once S is placed
         std::vector<int> a;        // local arc weights s x s
         unsigned placed = 0;
+        // gain of appending v after the set S: read from two half tables (low / high members of S) instead of a sum over S
+        std::vector<long> glo, ghi;
+        int lo_bits = 0;
         long gain(unsigned S, int v) const {
             const int s = (int)mem.size();
-            long g = 0;
-            for (unsigned m = S; m; m &= m - 1) g += a[__builtin_ctz(m) * s + v];
-            return g;
+            return glo[(size_t)(S & ((1u << lo_bits) - 1)) * s + v] + ghi[(size_t)(S >> lo_bits) * s + v];
         }
         void solve() {
             const int s = (int)mem.size();
             const unsigned full = (1u << s) - 1;
+            lo_bits = s / 2;
+            const int hi_bits = s - lo_bits;
+            glo.assign(((size_t)1 << lo_bits) * s, 0); ghi.assign(((size_t)1 << hi_bits) * s, 0);
+            for (unsigned x = 1; x < (1u << lo_bits); ++x) { const int u = __builtin_ctz(x); for (int v = 0; v < s; ++v) glo[(size_t)x * s + v] = glo[(size_t)(x & (x - 1)) * s + v] + a[u * s + v]; }
+            for (unsigned x = 1; x < (1u << hi_bits); ++x) { const int u = __builtin_ctz(x) + lo_bits; for (int v = 0; v < s; ++v) ghi[(size_t)x * s + v] = ghi[(size_t)(x & (x - 1)) * s + v] + a[u * s + v]; }
             h.assign((size_t)full + 1, 0);
             for (unsigned S = full; S-- > 0;) {
                 long b = -1;
-                for (int v = 0; v < s; ++v) if (!((S >> v) & 1)) b = std::max(b, gain(S, v) + h[S | (1u << v)]);
+                const long* gl = &glo[(size_t)(S & ((1u << lo_bits) - 1)) * s];
+                const long* gh = &ghi[(size_t)(S >> lo_bits) * s];
+                for (unsigned m = ~S & full; m; m &= m - 1) { const int v = __builtin_ctz(m); b = std::max(b, gl[v] + gh[v] + h[S | (1u << v)]); }
                 h[S] = b;
             }
         }
     };
+    // all compatible edges satisfied <=> the precedence arcs are acyclic: Kahn on bit masks, smallest index first
+    // (= the lexicographically smallest optimal sequence), no allocation
+    bool leaf_acyclic(unsigned mask, long ub) {
+        unsigned in[32];
+        for (int x = 0; x < n; ++x) in[x] = 0;
+        for (const LEdge& e : E) {
+            bool uf;
+            if (!compat(e, mask, uf)) continue;
+            if (uf) in[e.v] |= 1u << e.u; else in[e.u] |= 1u << e.v;
+        }
+        unsigned remaining = n == 32 ? ~0u : (1u << n) - 1;
+        int ord[32];
+        for (int p = 0; p < n; ++p) {
+            int v = -1;
+            for (unsigned m = remaining; m; m &= m - 1) { int cnd = __builtin_ctz(m); if (!(in[cnd] & remaining)) { v = cnd; break; } }
+            if (v < 0) return false;
+            remaining &= ~(1u << v);
+            ord[p] = v;
+        }
+        if (ub > best) { best = ub; bestmask = mask; bestorder.assign(ord, ord + n); }
+        return true;
+    }
     void leaf(unsigned mask) {
+        ++n_cyclic;
         std::vector<int> a((size_t)n * n, 0);
         for (const LEdge& e : E) {
             bool uf;
@@ -162,10 +196,14 @@ struct HostSolver {
         while (!st.empty()) {
             Fr f = st.back();
             st.pop_back();
-            if (bound(f.mask, f.k) <= best) continue;
-            if (f.k < 0) { leaf(f.mask); continue; }
-            st.push_back(Fr{f.mask | (1u << f.k), f.k - 1});  // explored second
-            st.push_back(Fr{f.mask, f.k - 1});                // explored first
+            ++n_nodes;
+            const long ub = bound(f.mask, f.k);
+            if (ub <= best) continue;
+            if (f.k < 0) { ++n_leaves; if (!leaf_acyclic(f.mask, ub)) leaf(f.mask); continue; }
+            // reversing every node and the whole sequence satisfies the same edges, so the optimum with the smallest mask
+            // keeps the last node forward: the other half of the tree is never needed
+            if (f.k != n - 1) st.push_back(Fr{f.mask | (1u << f.k), f.k - 1});  // explored second
+            st.push_back(Fr{f.mask, f.k - 1});                                  // explored first
         }
     }
 };
@@ -354,11 +392,15 @@ int order_components(sq_ctx* c) {
         }
         large.push_back((int)pi);
     }
+    static const bool order_prof = std::getenv("SQUID_ORDER_PROF") != nullptr;
     auto solve = [&](int pi) {
         Piece& p = B.pieces[pi];
         const int pn = (int)p.ids.size();
         HostSolver hs(pn, p.edges);
+        auto ts = std::chrono::steady_clock::now();
         hs.run();
+        if (order_prof) std::fprintf(stderr, "[order] piece n=%d m=%zu nodes=%ld leaves=%ld cyclic=%ld best=%ld  %.3f ms\n", pn, p.edges.size(), hs.n_nodes, hs.n_leaves, hs.n_cyclic, hs.best,
+                                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts).count());
         for (int pos = 0; pos < pn; ++pos) {
             int l = hs.bestorder[pos];
             p.order[pos] = ((hs.bestmask >> l) & 1) ? -(p.ids[l] + 1) : (p.ids[l] + 1);
@@ -366,7 +408,8 @@ int order_components(sq_ctx* c) {
     };
     // the pieces are independent: solve them on a few host threads (biggest first)
     std::sort(large.begin(), large.end(), [&](int x, int y) { return B.pieces[x].ids.size() > B.pieces[y].ids.size(); });
-    const int nthr = (int)std::min<size_t>(std::min<size_t>(large.size(), 16), std::max(1u, std::thread::hardware_concurrency()));
+    // (a handful of pieces is done before the threads would have started)
+    const int nthr = large.size() <= 8 ? 1 : (int)std::min<size_t>(std::min<size_t>(large.size() / 4, 16), std::max(1u, std::thread::hardware_concurrency()));
     if (nthr <= 1) for (int pi : large) solve(pi);
     else {
         std::atomic<size_t> next{0};
