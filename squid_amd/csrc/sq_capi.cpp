@@ -80,6 +80,12 @@ struct GraphBuild {
     std::vector<int32_t> sup, amb_plus, amb_minus;
     std::vector<int64_t> sl;
     bool tiny_boundary = false;
+    std::vector<int32_t> first_chr;   // sharded: chromosome of every rank's first kept record (-1: none)
+    // sharded seed exchange: this shard's seeds under the three possible pasts (see stage 3)
+    std::vector<Node> seedsA, seedsB, seedsC;
+    std::vector<int32_t> sensB;
+    bool hasC = false;
+    Node seedC{0, 0, 0, 0, 0.0};
 };
 
 static int need_exchange(sq_ctx* c) {
@@ -92,6 +98,19 @@ static int take_exchange(sq_ctx* c, int32_t tag) {
     c->x_ready = false;
     for (const auto& v : c->xgot) { int32_t t = 0; if (v.size() < 4) return fail(c, SQ_E_ARG, "sharded run: short exchange payload"); std::memcpy(&t, v.data(), 4); if (t != tag) return fail(c, SQ_E_ARG, "sharded run: ranks are out of step (payload tag mismatch)"); }
     return SQ_OK;
+}
+
+static void pack_seeds(sq_ctx* c, const GraphBuild& g) {
+    auto flat = [](const std::vector<Node>& v) { std::vector<int32_t> f; f.reserve(v.size() * 3); for (const Node& n : v) { f.push_back(n.chr); f.push_back(n.pos); f.push_back(n.len); } return f; };
+    Packer pk(c->xbuf);
+    pk.put<int32_t>(X_SEEDS);
+    pk.put_vec(flat(g.seedsA));
+    pk.put<int32_t>(c->shard.prior_kept ? 1 : 0);
+    pk.put_vec(flat(g.seedsB));
+    pk.put_vec(g.sensB);
+    pk.put<int32_t>(g.hasC ? 1 : 0);
+    pk.put<int32_t>(g.seedC.chr); pk.put<int32_t>(g.seedC.pos); pk.put<int32_t>(g.seedC.len);
+    pk.put_vec(flat(g.seedsC));
 }
 
 static int build_graph(sq_ctx* c) {
@@ -161,6 +180,8 @@ static int build_graph(sq_ctx* c) {
                 K[r] = u.get<int64_t>(); fr[r] = u.get<int32_t>(); fp[r] = u.get<int32_t>(); om[r] = u.get<int64_t>(); tl[r] = u.get<int64_t>();
                 if (!u.ok) return fail(c, SQ_E_ARG, "sharded run: malformed stream payload");
             }
+            g.first_chr.assign(W, -1);
+            for (int r = 0; r < W; ++r) if (K[r] > 0) g.first_chr[r] = fr[r];
             sh.kept_before = 0; sh.kept_total = 0; sh.prior_kept = false; sh.other_seed = INT64_MIN; sh.has_terminal = false;
             for (int r = 0; r < W; ++r) {
                 if (r < me) { sh.kept_before += K[r]; if (K[r] > 0) { sh.prior_kept = true; sh.other_seed = std::max<long long>(sh.other_seed, om[r]); } }
@@ -181,47 +202,59 @@ static int build_graph(sq_ctx* c) {
             if (rc) return rc;
         }
         c->counts.n_break = g.n_break;
-        std::vector<Node> seedsB;
-        std::vector<int32_t> sens;
         {
             HostClock hc(c, "host_segment_replay");
-            rc = segment_replay(c, *g.plan, g.seeds, false, nullptr);
-            if (!rc && sh.on && sh.prior_kept) rc = segment_replay(c, *g.plan, seedsB, true, &sens);
+            rc = segment_replay(c, *g.plan, g.seeds, false, nullptr, nullptr);
+            g.seedsA = g.seeds; g.seedsB.clear(); g.sensB.clear(); g.hasC = false;
+            if (!rc && sh.on && sh.prior_kept) rc = segment_replay(c, *g.plan, g.seedsB, true, &g.sensB, nullptr);
         }
         if (rc) return rc;
         g.stage = 3;
-        if (sh.on) {  // exchange 3: seed nodes, also under the hypothesis that an earlier shard has emitted a node before
-            auto flat = [](const std::vector<Node>& v) { std::vector<int32_t> f; f.reserve(v.size() * 3); for (const Node& n : v) { f.push_back(n.chr); f.push_back(n.pos); f.push_back(n.len); } return f; };
-            Packer pk(c->xbuf);
-            pk.put<int32_t>(X_SEEDS);
-            pk.put_vec(flat(g.seeds));
-            pk.put<int32_t>(sh.prior_kept ? 1 : 0);
-            pk.put_vec(flat(seedsB));
-            pk.put_vec(sens);
-            return need_exchange(c);
-        }
+        if (sh.on) { pack_seeds(c, g); return need_exchange(c); }
     }
     if (g.stage == 3) {
         if (sh.on) {
             rc = take_exchange(c, X_SEEDS);
             if (rc) return rc;
+            // Seed nodes of all shards, resolved in rank order.  What a shard emits depends on the last node emitted before
+            // it: none (A); one on an earlier chromosome than the shard's records, then only its existence matters (B);
+            // or -- a discordant cluster in front of a chromosome's first kept record is processed by the shard before --
+            // one on the shard's own first chromosome, then the shard replays again behind exactly that node (C) and
+            // everybody exchanges once more.
             std::vector<Node> all;
-            bool prev = false; int prev_end = 0;
-            for (int r = 0; r < W; ++r) {
+            int redo = -1;
+            for (int r = 0; r < W && redo < 0; ++r) {
                 Unpacker u(c->xgot[r]);
                 u.get<int32_t>();
-                std::vector<int32_t> a, b2, se;
+                std::vector<int32_t> a, b2, se, c3;
                 u.get_vec(a);
-                int32_t hasB = u.get<int32_t>();
+                const int32_t hasB = u.get<int32_t>();
                 u.get_vec(b2); u.get_vec(se);
+                const int32_t hasC = u.get<int32_t>();
+                const int32_t cc = u.get<int32_t>(), cp = u.get<int32_t>(), cl = u.get<int32_t>();
+                u.get_vec(c3);
                 if (!u.ok) return fail(c, SQ_E_ARG, "sharded run: malformed seed payload");
-                const bool useB = prev && hasB;
-                if (useB) for (int32_t v : se) if (v == prev_end)
-                    return fail(c, SQ_E_ASSERT, "sharded run: the reference would extend a node of an earlier chromosome here (SegmentGraph.cpp:623); run unsharded");
-                const std::vector<int32_t>& pick = useB ? b2 : a;
-                for (size_t i = 0; i + 2 < pick.size(); i += 3) all.push_back(Node{pick[i], pick[i + 1], pick[i + 2], 0, 0.0});
-                if (!pick.empty()) { prev = true; prev_end = pick[pick.size() - 2] + pick[pick.size() - 1]; }
+                auto append = [&](const std::vector<int32_t>& v, size_t from) { for (size_t i = from; i + 2 < v.size(); i += 3) all.push_back(Node{v[i], v[i + 1], v[i + 2], 0, 0.0}); };
+                if (g.first_chr[r] < 0) continue;                      // no kept record: nothing replayed, nothing emitted
+                if (all.empty() || !hasB) { append(a, 0); continue; }  // nothing has been emitted before this shard
+                const Node& last = all.back();
+                bool exact_needed = last.chr >= g.first_chr[r];
+                for (int32_t v : se) if (v == last.pos + last.len) exact_needed = true;  // the one comparison without a chromosome test (:623)
+                if (!exact_needed) { append(b2, 0); continue; }
+                if (hasC && cc == last.chr && cp == last.pos && cl == last.len && c3.size() >= 3) {
+                    all.back() = Node{c3[0], c3[1], c3[2], 0, 0.0};  // the shard may have extended the node in front of it
+                    append(c3, 3);
+                    continue;
+                }
+                redo = r;
+                if (r == me) {
+                    HostClock hc(c, "host_segment_replay");
+                    g.seedC = last; g.hasC = true;
+                    rc = segment_replay(c, *g.plan, g.seedsC, false, nullptr, &g.seedC);
+                    if (rc) return rc;
+                }
             }
+            if (redo >= 0) { pack_seeds(c, g); return need_exchange(c); }
             g.seeds.swap(all);
         }
         {

@@ -184,7 +184,8 @@ int segment_static(sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::vector<Blk>& 
 int segment_prepare(sq_ctx* c, SegPlan& plan, int64_t& n_break);
 // `virtual_back`: an earlier shard has emitted a node (it lies on an earlier chromosome); `sens` collects the pending
 // node starts that were compared with that node's end without a chromosome test (SegmentGraph.cpp:623)
-int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds, bool virtual_back, std::vector<int32_t>* sens);
+// `seed`: the real last node emitted before this shard (it may get extended: the result then starts with it)
+int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds, bool virtual_back, std::vector<int32_t>* sens, const Node* seed);
 int tile_genome(sq_ctx* c, std::vector<Node>& seeds, std::vector<Node>& out);
 
 // ---- sq_graph.cpp

@@ -10,6 +10,9 @@
 // trigger can emit anything.  The host replays just those stretches with the reference's control automaton (its
 // ~15 carried variables, SURVEY.md A.2b, live in `Seg`) and never touches the rest of the stream.
 #include <algorithm>
+#include <atomic>
+#include <string>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -366,6 +369,7 @@ struct SegPlan {
     SegStatic st;
     SegSupport sup;
     std::vector<int> active;
+    std::vector<int> first_cluster;   // per active stretch: the first cluster whose trigger lies in it
     std::vector<int64_t> shift;       // per active stretch: kept index that compact[0] would have
     const StreamRec* compact = nullptr;  // page-locked copy of the summaries inside the replayed stretches
     int64_t K = 0;        // kept records of the local stream
@@ -468,7 +472,7 @@ int segment_prepare(sq_ctx* c, SegPlan& P, int64_t& n_break) {
         if (ncl == 0) n_break = std::min<int64_t>(K, 1);
         else n_break = std::min<int64_t>(K, (int64_t)sup.trigger[ncl - 1] + 2);
     } else n_break = std::max<int64_t>(0, std::min<int64_t>(K, sh.n_break_global - sh.kept_before));
-    P.active.clear();
+    P.active.clear(); P.first_cluster.clear();
     if (nd == 0 || K == 0) return SQ_OK;
 
     // ---- stretches between zero-coverage records; a stretch j covers: the push step of its first record lo (a
@@ -492,7 +496,7 @@ int segment_prepare(sq_ctx* c, SegPlan& P, int64_t& n_break) {
     for (int k = P.k0; k < ncl; ++k) {
         if (sup.trigger[k] >= KE) break;  // never passed by a record: never segmented (the reference leaves its loop first)
         int j = stretch_of(sup.trigger[k]);
-        if (active.empty() || active.back() != j) active.push_back(j);
+        if (active.empty() || active.back() != j) { active.push_back(j); P.first_cluster.push_back(k); }
     }
     std::vector<std::pair<int64_t, int64_t>> ranges;
     std::vector<int> range_of;
@@ -511,10 +515,15 @@ int segment_prepare(sq_ctx* c, SegPlan& P, int64_t& n_break) {
 }
 
 // order-dependent part: replay the reference's control automaton over the stretches that contain cluster triggers
-int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds, bool virtual_back, std::vector<int32_t>* sens) {
+// Replays the active stretches [a_begin, a_end).  `virtual_back`: a node has been emitted before this range and it lies
+// on an earlier chromosome than anything the range looks at (then only its existence matters); `sens` collects the
+// pending node starts that were compared with that node's end without a chromosome test (SegmentGraph.cpp:623).
+static int replay_range(sq_ctx* c, SegPlan& plan, size_t a_begin, size_t a_end, std::vector<Node>& seeds, bool virtual_back, std::vector<int32_t>* sens, std::string& err,
+                        const Node* seed = nullptr) {
     seeds.clear();
     std::vector<Node> sink;
-    if (virtual_back) sink.push_back(Node{-1, 0, 0, 0, 0.0});  // stands for the last node of the earlier shards (an earlier chromosome)
+    if (seed) sink.push_back(*seed);  // the real node in front (the result keeps it, possibly extended)
+    else if (virtual_back) sink.push_back(Node{-1, 0, 0, 0, 0.0});
     Seg S(c, plan.compact, plan.st, sink);
     S.prof = std::getenv("SQUID_REPLAY_PROF") != nullptr;
     SegSupport& sup = plan.sup;
@@ -524,7 +533,7 @@ int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds, bool virt
     const std::vector<int32_t>& Z = sup.zidx;
     const int nz = (int)Z.size();
     const std::vector<int>& active = plan.active;
-    if (nd == 0 || plan.K == 0) return SQ_OK;
+    if (nd == 0 || plan.K == 0 || a_begin >= a_end) return SQ_OK;
 
     static const bool prof = std::getenv("SQUID_REPLAY_PROF") != nullptr;
     long long n_pushed = 0, n_clusters = 0;
@@ -583,8 +592,9 @@ int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds, bool virt
     const int ncl = (int)S.clusters.size();
     const auto t_begin = std::chrono::steady_clock::now();
     S.new_cluster();  // the reference does this at its first kept record (:341)
-    for (int k = 0; k < plan.k0; ++k) S.new_cluster();  // clusters consumed by the closing record of an earlier shard
-    for (size_t a = 0; a < active.size(); ++a) {
+    // clusters consumed before this range (by earlier stretches, or by the closing record of an earlier shard)
+    for (int k = 0; k < plan.first_cluster[a_begin]; ++k) S.new_cluster();
+    for (size_t a = a_begin; a < a_end; ++a) {
         const int j = active[a];
         S.shift = plan.shift[a];
         const int64_t lo = j == 0 ? -1 : Z[j - 1], hi = j < nz ? Z[j] : K;
@@ -592,7 +602,7 @@ int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds, bool virt
         // (otherChr, otherrightmost) in front of it comes from the GPU scan
         S.win_clear(S.cw, S.ci, S.co); S.win_clear(S.pw, S.pi, S.po);
         if (lo >= 0) {
-            if (S.markStart != -1) return fail(c, SQ_E_ARG, "internal: pending node end at a zero-coverage record");
+            if (S.markStart != -1) { err = "internal: pending node end at a zero-coverage record"; return SQ_E_ARG; }
             S.otherChr = sup.z_ochr[j - 1]; S.otherright = sup.z_oright[j - 1];
             push_step(lo);
         }
@@ -613,7 +623,7 @@ int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds, bool virt
             if (i >= hi) break;
             alive = head_step(i, z);
             if (alive) {
-                if (z) return fail(c, SQ_E_ARG, "internal: zero-coverage record inside a replayed stretch");
+                if (z) { err = "internal: zero-coverage record inside a replayed stretch"; return SQ_E_ARG; }
                 push_step(i);
                 ++i;
             }
@@ -623,10 +633,78 @@ int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds, bool virt
     }
     if (prof) std::fprintf(stderr, "[replay] M-build %.3f ms (sumM %lld)  brk-loop %.3f ms (sum rest %lld)  tail %.3f ms (win left %lld)\n", S.tsec[0], S.nsec[0], S.tsec[1], S.nsec[1], S.tsec[2], S.nsec[2]);
     if (prof) std::fprintf(stderr, "[replay] brks %lld  counts %.3f ms  win+blk spans %.3f ms (%lld)  rest %.3f ms (%lld)\n", S.nsec[3], S.tsec[3], S.tsec[4], S.nsec[4], S.tsec[5], S.nsec[5]);
-    if (prof) std::fprintf(stderr, "[replay] stretches=%zu pushed=%lld clusters=%lld t_cluster=%.3f ms total=%.3f ms\n", active.size(), n_pushed, n_clusters, t_cluster,
+    if (prof) std::fprintf(stderr, "[replay] range %zu..%zu stretches=%zu pushed=%lld clusters=%lld t_cluster=%.3f ms total=%.3f ms\n", a_begin, a_end, active.size(), n_pushed, n_clusters, t_cluster,
                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     if (virtual_back) sink.erase(sink.begin());
     seeds = sink;
+    return SQ_OK;
+}
+
+// order-dependent part: replay the reference's control automaton over the stretches that contain cluster triggers.
+// Stretches only depend on each other through the last node emitted so far, and when all records of a group of
+// stretches lie on later chromosomes than everything before, only the existence of that node matters (replay_range):
+// such groups are replayed concurrently under that assumption, checked afterwards, and redone one after the other if
+// the check fails.
+int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds, bool virtual_back, std::vector<int32_t>* sens, const Node* seed) {
+    seeds.clear();
+    const std::vector<int>& active = plan.active;
+    const size_t na = active.size();
+    std::string err;
+    auto sequential = [&]() {
+        int rc = replay_range(c, plan, 0, na, seeds, virtual_back, sens, err, seed);
+        return rc ? fail(c, rc, err) : SQ_OK;
+    };
+    if (na == 0) { if (seed) seeds.assign(1, *seed); return SQ_OK; }
+    if (seed) return sequential();  // (rare repair path of a sharded run)
+    static const bool serial_only = std::getenv("SQUID_REPLAY_SERIAL") != nullptr;
+    // group boundaries: the stretch opens with a zero-coverage record on a later chromosome than the last record of the
+    // stretch before (which is then that record itself or an earlier one)
+    const std::vector<int32_t>& Z = plan.sup.zidx;
+    const int nz = (int)Z.size();
+    auto rec_at = [&](size_t a, int64_t idx) -> const StreamRec& { return plan.compact[idx - plan.shift[a]]; };
+    std::vector<size_t> starts(1, 0);
+    std::vector<int> first_chr(1, -1);
+    for (size_t a = 1; a < na && !serial_only; ++a) {
+        const int j = active[a], jp = active[a - 1];
+        const int64_t lo = Z[j - 1];                                   // j > 0 here
+        const int64_t hip = jp < nz ? Z[jp] : plan.K_eff - 1;          // last record the previous stretch looks at
+        if (rec_at(a, lo).refid > rec_at(a - 1, hip).refid) { starts.push_back(a); first_chr.push_back(rec_at(a, lo).refid); }
+    }
+    const size_t ng = starts.size();
+    if (ng < 3) return sequential();
+    starts.push_back(na);
+    struct Out { std::vector<Node> seeds; std::vector<int32_t> sens; int rc = 0; std::string err; };
+    std::vector<Out> res(ng);
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (size_t g; (g = next.fetch_add(1)) < ng;)
+            res[g].rc = replay_range(c, plan, starts[g], starts[g + 1], res[g].seeds, g == 0 ? virtual_back : true, &res[g].sens, res[g].err);
+    };
+    const int nthr = (int)std::min<size_t>(std::min<size_t>(ng, 16), std::max(1u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthr; ++t) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+    // check the assumption group by group: a node must exist before the group, on an earlier chromosome than the group's
+    // first record, and none of the recorded comparisons may hit its end
+    bool ok = true, local_have = false;
+    int last_chr = -1, last_end = 0;
+    std::vector<int32_t> up;  // comparisons against a node of an earlier shard: the caller checks them
+    for (size_t g = 0; g < ng && ok; ++g) {
+        if (res[g].rc) { ok = false; break; }
+        if (g == 0 || !local_have) {
+            // nothing emitted here yet: the node in front is the caller's (an earlier shard's), if any
+            if (g > 0 && !virtual_back) ok = false;  // the group assumed a node where there is none
+            up.insert(up.end(), res[g].sens.begin(), res[g].sens.end());
+        } else {
+            if (last_chr >= first_chr[g]) ok = false;
+            for (int32_t v : res[g].sens) if (v == last_end) ok = false;
+        }
+        if (!res[g].seeds.empty()) { local_have = true; last_chr = res[g].seeds.back().chr; last_end = res[g].seeds.back().pos + res[g].seeds.back().len; }
+    }
+    if (!ok) { seeds.clear(); if (sens) sens->clear(); return sequential(); }
+    for (size_t g = 0; g < ng; ++g) seeds.insert(seeds.end(), res[g].seeds.begin(), res[g].seeds.end());
+    if (sens) *sens = up;
     return SQ_OK;
 }
 

@@ -112,11 +112,25 @@ class VirtualWorld:
         self.ctxs = contexts
         self.exchanges = 0
         self.bytes = 0
+        # the ranks run one after the other here; a real run overlaps them, so the time it would take is the sum over
+        # the phases (between two exchanges) of the slowest rank's time in that phase
+        self.projected_s = 0.0
+        self.serial_s = 0.0
+
+    def _timed(self, c, step_name: str):
+        import time
+
+        t0 = time.perf_counter()
+        rc = getattr(c, step_name)()
+        return rc, time.perf_counter() - t0
 
     def _lockstep(self, step_name: str):
         pending = list(self.ctxs)
         while True:
-            rcs = [getattr(c, step_name)() for c in pending]
+            res = [self._timed(c, step_name) for c in pending]
+            rcs = [r[0] for r in res]
+            self.projected_s += max(r[1] for r in res)
+            self.serial_s += sum(r[1] for r in res)
             if all(rc == 0 for rc in rcs):
                 return
             if not all(rc == pending[0].NEED_EXCHANGE for rc in rcs):
