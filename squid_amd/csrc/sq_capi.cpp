@@ -265,17 +265,23 @@ static int build_graph(sq_ctx* c) {
         if (rc) return rc;
         rc = dev_upload_nodes(c, c->nodes);
         if (rc) return rc;
+        // the chimeric edges are host work on the (small) fragment list: do them on a second thread while this one
+        // drives the depth and edge kernels over the concordant stream
+        c->edges.clear();
+        double chim_ms = 0;
+        std::future<int> chim = std::async(std::launch::async, [&]() {
+            const auto t0 = std::chrono::steady_clock::now();
+            const int r2 = chimeric_edges(c, g.raw);
+            chim_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            return r2;
+        });
         std::vector<int32_t> unused;
         rc = dev_node_depth(c, c->nodes, g.n_break, g.sup, g.sl, g.tiny_boundary, g.amb_plus, g.amb_minus, unused);
-        if (rc) return rc;
-        c->edges.clear();
-        {
-            HostClock hc(c, "host_chimeric_edges");
-            rc = chimeric_edges(c, g.raw);
-            if (rc) return rc;
-        }
-        rc = dev_concordant_edges(c, c->nodes, g.conc);
-        if (rc) return rc;
+        int rc_edges = rc ? rc : dev_concordant_edges(c, c->nodes, g.conc);
+        const int rc_chim = chim.get();
+        c->timer.add("host_chimeric_edges", chim_ms);
+        if (rc_chim) return rc_chim;
+        if (rc_edges) return rc_edges;
         g.stage = 4;
         if (sh.on) {  // exchange 4 (the data exchange): per-node depth accumulators of the own chromosomes + locally reduced edges
             const std::vector<Node>& N = c->nodes;
@@ -455,6 +461,14 @@ static int build_graph(sq_ctx* c) {
     c->snap[0].take(c->nodes, c->edges, &c->label);
     c->graph_built = true;
     c->gb.reset();
+    // ExactBreakpoint only needs the final graph and the trimmed fragments: start it now, sq_call_sv collects it
+    c->bp_early = std::make_shared<BPMap>();
+    c->bp_future = std::async(std::launch::async, [c]() {
+        const auto t0 = std::chrono::steady_clock::now();
+        const int r2 = exact_breakpoints(c, *c->bp_early);
+        c->bp_early_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return r2;
+    });
     return SQ_OK;
 }
 
@@ -497,7 +511,13 @@ static int call_sv(sq_ctx* c) {
         pk.put_vec(v.diff);
     };
     if (v.stage == 0) {
-        {
+        if (c->bp_future.valid()) {
+            rc = c->bp_future.get();
+            c->timer.add("host_exact_breakpoints", c->bp_early_ms);
+            if (rc) return rc;
+            bpmap.swap(*c->bp_early);
+            c->bp_early.reset();
+        } else {
             HostClock hc(c, "host_exact_breakpoints");
             rc = exact_breakpoints(c, bpmap);
             if (rc) return rc;
@@ -649,6 +669,7 @@ int sq_create(const sq_params* p, sq_ctx** out) {
 }
 void sq_destroy(sq_ctx* c) {
     if (!c) return;
+    if (c->bp_future.valid()) (void)c->bp_future.get();
     dev_destroy(c);
     delete c;
 }
@@ -780,6 +801,7 @@ int sq_build_graph(sq_ctx* c) {
     if (c->ref_len.empty()) return fail(c, SQ_E_ARG, "sq_set_references first");
     if (c->read_len <= 0) return fail(c, SQ_E_ARG, "sq_ingest_chimeric first (ReadLen comes from the chimeric BAM)");
     if (c->shard.on != (c->P.world_size > 1)) return fail(c, SQ_E_ARG, "world_size > 1 needs sq_set_shard (and the other way round)");
+    if (c->bp_future.valid()) (void)c->bp_future.get();
     if (!c->gb) c->timer.clear();
     int rc = build_graph(c);
     dev_flush_timers(c);
@@ -826,6 +848,7 @@ int sq_get_timing(sq_ctx* c, sq_timing* t) {
 }
 int sq_reset(sq_ctx* c) {
     if (!c) return SQ_E_ARG;
+    if (c->bp_future.valid()) (void)c->bp_future.get();
     c->frags = c->frags0;  // the graph stages trim the chimeric blocks in place, like the reference does
     c->nodes.clear(); c->edges.clear(); c->label.clear();
     c->graph_built = false; c->ordered = false;

@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cstdint>
 #include <functional>
+#include <future>
 #include <map>
 #include <memory>
 #include <string>
@@ -137,6 +138,11 @@ struct sq_ctx {
     // chromosome-sharded runs: sq_build_graph / sq_call_sv return SQ_NEED_EXCHANGE with `xbuf` filled; the caller
     // all-gathers it and hands the result back through sq_exchange_unpack before calling the same function again
     sq::Shard shard;
+    // ExactBreakpoint (host, chimeric fragments only) runs on a second thread from the end of sq_build_graph, next to
+    // sq_order; sq_call_sv collects it
+    std::future<int> bp_future;
+    std::shared_ptr<std::map<uint64_t, std::vector<std::pair<int, int>>>> bp_early;
+    double bp_early_ms = 0;
     std::shared_ptr<sq::GraphBuild> gb;
     std::shared_ptr<sq::SvBuild> svb;
     std::vector<uint8_t> xbuf;                 // this rank's contribution
