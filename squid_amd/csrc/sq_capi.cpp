@@ -86,6 +86,7 @@ struct GraphBuild {
     std::vector<int32_t> sensB;
     bool hasC = false;
     Node seedC{0, 0, 0, 0, 0.0};
+    std::future<double> clusters;     // segment_clusters running next to the record kernels (last member: destroyed, i.e. joined, first)
 };
 
 static int need_exchange(sq_ctx* c) {
@@ -123,9 +124,11 @@ static int build_graph(sq_ctx* c) {
     if (g.stage == 0) {
         c->graph_built = false;
         c->ordered = false;
+        // the cluster table only needs the chimeric fragments: build it on a second thread next to the record kernels
+        g.clusters = std::async(std::launch::async, [c, &g]() { return segment_clusters(c, g.plan, g.disc); });
         int32_t last[4];
         rc = dev_classify(c, sh.on ? last : nullptr);
-        if (rc) return rc;
+        if (rc) { (void)g.clusters.get(); return rc; }
         g.stage = 1;
         if (sh.on) {  // exchange 1: what the last passing records of every shard look like to ReadRec_t::Equal
             Packer pk(c->xbuf);
@@ -149,12 +152,14 @@ static int build_graph(sq_ctx* c) {
             }
         }
         rc = dev_dedup_summarise(c);
+        const double cl_ms = g.clusters.get();
+        c->timer.add("host_cluster_table", cl_ms);
         if (rc) return rc;
         long long other_max = INT64_MIN;
         int32_t first_kept[2] = {0, 0};
         {
             HostClock hc(c, "host_segment_prepare");
-            rc = segment_static(c, g.plan, g.disc, sh.on, g.trigger_last, other_max, first_kept);
+            rc = segment_scan(c, *g.plan, sh.on, g.trigger_last, other_max, first_kept);
             if (rc) return rc;
         }
         g.stage = 2;

@@ -183,9 +183,10 @@ bool frag_equal(const Frag& x, const Frag& y);
 
 // ---- sq_segment.cpp  (host control of K2; counting data comes from the GPU summaries)
 struct SegPlan;  // sq_segment.cpp
-// static part (cluster table from the chimeric fragments) + the stream scans that need nothing from other shards
-int segment_static(sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::vector<Blk>& bamdiscordant_sorted, bool fetch, int64_t& trigger_last, long long& other_max,
-                   int32_t first_kept[2]);
+// static part: cluster table from the chimeric fragments (host only; returns its elapsed milliseconds) ...
+double segment_clusters(const sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::vector<Blk>& bamdiscordant_sorted);
+// ... and the stream scans that need nothing from other shards
+int segment_scan(sq_ctx* c, SegPlan& plan, bool fetch, int64_t& trigger_last, long long& other_max, int32_t first_kept[2]);
 // zero-coverage records, stretches to replay, host copies of those stretches; n_break = consumed prefix of the LOCAL stream
 int segment_prepare(sq_ctx* c, SegPlan& plan, int64_t& n_break);
 // `virtual_back`: an earlier shard has emitted a node (it lies on an earlier chromosome); `sens` collects the pending

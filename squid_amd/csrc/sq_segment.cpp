@@ -36,7 +36,8 @@ struct SegStatic {
     int nd = 0;
     std::vector<std::pair<int, int>> part;  // PartAlignPos
     std::vector<Cluster> clusters;
-    std::vector<std::vector<std::pair<int, int>>> rest_by_cluster;
+    // live ConcordRest content per cluster as CSR, sorted by refpos inside a cluster (only ever counted); rest_max = longest block
+    std::vector<int32_t> rest_off, rest_pos, rest_len, rest_max;
     // the clusters are fixed by the sorted discordant blocks alone (SegmentGraph.cpp:341-348 / 604-611)
     void build_clusters(int RL) {
         int s0 = 0;
@@ -108,7 +109,7 @@ struct Seg {
     const int nd;
     const std::vector<std::pair<int, int>>& part;
     const std::vector<Cluster>& clusters;
-    const std::vector<std::vector<std::pair<int, int>>>& rest_by_cluster;
+    const SegStatic& st;
     std::vector<int32_t> cw, pw;     // windows: indices into in.recs (ConcordantCluster / PartialAlignCluster)
     int co = 0, po = 0;              // window offsets
     // The reference walks a whole window for every break candidate.  Here the live elements that can span anything
@@ -144,12 +145,12 @@ struct Seg {
         ss.ix.build(ss.pos.data(), ss.len.data(), 0, (int)ss.pos.size(), wi.maxm, minbrk, maxbrk, T);
     }
     SpanSet cset, pset;
-    const std::vector<std::pair<int, int>>* rest = nullptr;  // live ConcordRest content of the current cluster: (refpos, matchref) on its chromosome
+    const int32_t *rest_p = nullptr, *rest_l = nullptr;  // live ConcordRest content of the current cluster (refpos, matchref), sorted by refpos
+    int rest_n = 0;
     std::vector<int> M_buf, fwd_buf, rev_buf;  // scratch of process_cluster
     double tsec[6] = {0, 0, 0, 0, 0, 0}; long long nsec[6] = {0, 0, 0, 0, 0, 0}; bool prof = false;
     int kc = -1;                     // index of the current cluster (ds == clusters[kc].ds)
     int rest_maxm = 0;
-    std::vector<int32_t> rest_pos, rest_len;  // the current cluster's ConcordRest content, sorted by refpos
     SpanIndex rspan;
     std::vector<Node>& out;
     int ds = 0, de = 0, dcur = 0;    // itdisstart / itdisend / itdiscurrent
@@ -158,7 +159,7 @@ struct Seg {
     int markStart = -1, markChr = -1;
 
     Seg(const sq_ctx* c, const StreamRec* recs, const SegStatic& st, std::vector<Node>& out)
-        : c(c), recs(recs), RL(c->read_len), D(st.D), nd(st.nd), part(st.part), clusters(st.clusters), rest_by_cluster(st.rest_by_cluster), out(out) {}
+        : c(c), recs(recs), RL(c->read_len), D(st.D), nd(st.nd), part(st.part), clusters(st.clusters), st(st), out(out) {}
 
     El el(int32_t idx) const {
         const StreamRec& r = rec(idx);
@@ -175,13 +176,12 @@ struct Seg {
         if (kc < (int)clusters.size()) {
             const Cluster& k = clusters[kc];
             ds = k.ds; de = k.de; nextdisright = k.right; nextdisChr = k.chr;
-            rest = &rest_by_cluster[kc];
-            rest_maxm = 0;
-            rest_pos.clear(); rest_len.clear();
-            for (const auto& h : *rest) { rest_maxm = std::max(rest_maxm, h.second); rest_pos.push_back(h.first); rest_len.push_back(h.second); }
+            rest_p = st.rest_pos.data() + st.rest_off[kc]; rest_l = st.rest_len.data() + st.rest_off[kc];
+            rest_n = st.rest_off[kc + 1] - st.rest_off[kc];
+            rest_maxm = st.rest_max[kc];
         } else {  // past the last cluster: the reference reads the zero sentinel (ledger B21); nextdisChr keeps its value
             ds = de = nd; nextdisright = 0;
-            rest = nullptr;
+            rest_p = rest_l = nullptr; rest_n = 0;
         }
     }
 
@@ -263,7 +263,7 @@ struct Seg {
             // span counters over the two windows and the ConcordRest content (offsets co/po are fixed while the candidates are tested)
             span_collect(cset, ci, co, chr, M.front(), M.back());
             span_collect(pset, pi, po, chr, M.front(), M.back());
-            if (rest && !rest->empty()) rspan.build(rest_pos.data(), rest_len.data(), 0, (int)rest_pos.size(), rest_maxm, M.front(), M.back(), T);
+            if (rest_n) rspan.build(rest_p, rest_l, 0, rest_n, rest_maxm, M.front(), M.back(), T);
             tock(0, tA, (long long)M.size());
             auto tB = tick();
 
@@ -296,7 +296,7 @@ struct Seg {
                         tock(4, tw, 1);
                         auto tr = tick();
                         if (sr > std::max(cov - sr, 0) + 2)
-                            if (rest && !rest->empty()) cov += rspan.count(brk, T);  // (same chromosome by construction, see k_rest_candidates)
+                            if (rest_n) cov += rspan.count(brk, T);  // (same chromosome by construction, see k_rest_candidates)
                         tock(5, tr, 1);
                         if (sr > std::max(cov - sr, 0) + 2) {
                             int sup = std::max(sr + pl, sr + pr);
@@ -308,7 +308,7 @@ struct Seg {
                 }
                 ib = nx;
             }
-            tock(1, tB, rest ? (long long)rest->size() : 0);
+            tock(1, tB, (long long)rest_n);
             auto tC = tick();
             if (lastC != -1 && (!split || back_end() != lastC)) close_node(chr, curStart, curEnd, lastC, split);
             if (disStart != -1 && !split && disCount > std::min(5.0, 4.0 * (disEnd - disStart) / RL)) {  // :518-527 (FP64 as in the reference)
@@ -379,11 +379,11 @@ struct SegPlan {
 };
 
 // static part: discordant blocks, clip positions, cluster table; stream scans that need nothing from other shards
-int segment_static(sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::vector<Blk>& disc_sorted, bool fetch, int64_t& trigger_last, long long& other_max, int32_t first_kept[2]) {
+// (host only, reads the chimeric fragments: may run next to the record kernels) returns the elapsed milliseconds
+double segment_clusters(const sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::vector<Blk>& disc_sorted) {
     plan = std::make_shared<SegPlan>();
-    const int64_t K = c->counts.n_kept_p1;
-    plan->K = K;
     SegStatic& S = plan->st;
+    const auto t_begin = std::chrono::steady_clock::now();
     // ---- discordant blocks and clip positions of the chimeric fragments (SegmentGraph.cpp:203-264)
     S.part.assign(c->ref_len.size(), std::make_pair(0, 0));  // ledger B10
     std::vector<Blk>& D = S.D;
@@ -433,6 +433,14 @@ int segment_static(sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::vector<Blk>& 
 
     // ---- static cluster table; everything stream-sized comes from the GPU
     S.build_clusters(c->read_len);
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+}
+// stream scans that need nothing from other shards (the cluster table is uploaded here)
+int segment_scan(sq_ctx* c, SegPlan& P, bool fetch, int64_t& trigger_last, long long& other_max, int32_t first_kept[2]) {
+    const int64_t K = c->counts.n_kept_p1;
+    P.K = K;
+    SegStatic& S = P.st;
+    SegPlan* plan = &P;
     const int ncl = (int)S.clusters.size();
     std::vector<int32_t> cl_chr(ncl), cl_start(ncl), cl_right(ncl);
     for (int k = 0; k < ncl; ++k) { cl_chr[k] = S.clusters[k].chr; cl_start[k] = S.clusters[k].start; cl_right[k] = S.clusters[k].right; }
@@ -449,8 +457,11 @@ int segment_prepare(sq_ctx* c, SegPlan& P, int64_t& n_break) {
     const int64_t K = P.K;
     const int ncl = (int)S.clusters.size(), nd = S.nd;
     SegSupport& sup = P.sup;
+    auto t_begin = std::chrono::steady_clock::now();
+    auto lap = [&](const char* name) { auto t = std::chrono::steady_clock::now(); c->timer.add(name, std::chrono::duration<double, std::milli>(t - t_begin).count()); t_begin = t; };
     int rc = dev_segment_support(c, ncl, c->counts.n_kept_p2, sup);
     if (rc) return rc;
+    lap("host_prep_support");
     const bool term = sh.on && sh.has_terminal && K > 0;
     P.K_eff = K + (term ? 1 : 0);
     const int64_t KE = P.K_eff;
@@ -464,9 +475,24 @@ int segment_prepare(sq_ctx* c, SegPlan& P, int64_t& n_break) {
                 sup.trigger[k] = (int32_t)(beyond ? K : KE);
             }
     }
-    S.rest_by_cluster.assign(ncl, {});
-    for (size_t i = 0; i < sup.rest_cluster.size(); ++i) S.rest_by_cluster[sup.rest_cluster[i]].push_back(std::make_pair(sup.rest_pos[i], sup.rest_len[i]));
-    for (auto& v : S.rest_by_cluster) std::sort(v.begin(), v.end());  // only counted, never enumerated in order: sorted for range queries
+    {   // group the candidates by cluster (counting sort), then order each group by refpos
+        const size_t cnt = sup.rest_cluster.size();
+        S.rest_off.assign((size_t)ncl + 1, 0); S.rest_max.assign((size_t)ncl, 0);
+        for (size_t i = 0; i < cnt; ++i) S.rest_off[sup.rest_cluster[i] + 1]++;
+        for (int k = 0; k < ncl; ++k) S.rest_off[k + 1] += S.rest_off[k];
+        std::vector<std::pair<int32_t, int32_t>> tmp(cnt);
+        std::vector<int32_t> fill(S.rest_off.begin(), S.rest_off.end() - 1);
+        for (size_t i = 0; i < cnt; ++i) tmp[(size_t)fill[sup.rest_cluster[i]]++] = std::make_pair(sup.rest_pos[i], sup.rest_len[i]);
+        S.rest_pos.resize(cnt); S.rest_len.resize(cnt);
+        for (int k = 0; k < ncl; ++k) {
+            auto b = tmp.begin() + S.rest_off[k], e = tmp.begin() + S.rest_off[k + 1];
+            if (e - b > 1) std::sort(b, e);
+            int mx = 0;
+            for (auto it = b; it != e; ++it) { const size_t i = (size_t)(it - tmp.begin()); S.rest_pos[i] = it->first; S.rest_len[i] = it->second; mx = std::max(mx, it->second); }
+            S.rest_max[k] = mx;
+        }
+    }
+    lap("host_prep_rest");
     // ReadsMain/ReadsOther stop growing at the first record after the last cluster's trigger (SegmentGraph.cpp:338-339, B12)
     if (!sh.on) {
         if (ncl == 0) n_break = std::min<int64_t>(K, 1);
@@ -506,6 +532,7 @@ int segment_prepare(sq_ctx* c, SegPlan& P, int64_t& n_break) {
         else ranges.push_back(std::make_pair(lo, hi));
         range_of.push_back((int)ranges.size() - 1);
     }
+    lap("host_prep_active");
     std::vector<int64_t> range_off;
     rc = dev_fetch_stream(c, ranges, P.compact, range_off);
     if (rc) return rc;
