@@ -18,6 +18,19 @@ bool edge_discordant(const sq_ctx* c, const std::vector<Node>& N, const Edge& e)
 }
 
 // ---- LocateRead for chimeric fragments (:1207-1293): sequential hint chain, trims the blocks in place
+// The reference walks the node list from the hint, one node at a time, up or down (:1213-1243); with fragments whose
+// blocks lie on different chromosomes that is O(nodes) per block (881 ms on the dense-graph config).  The nodes tile
+// every chromosome, so the nodes a block fits (+-5 bp) form a range [a, bb] found by two binary searches, and the
+// walk ends on the first node of that range it would meet -- or, with an empty range, where it would run out of the
+// chromosome.  Same result, same final position of the walk (the next block starts from it).
+namespace {
+struct ChrRange { int lo, hi; };  // node indices [lo, hi) of a chromosome
+inline ChrRange chr_range(const std::vector<Node>& N, int chr) {
+    auto lo = std::lower_bound(N.begin(), N.end(), chr, [](const Node& x, int c) { return x.chr < c; });
+    auto hi = std::upper_bound(lo, N.end(), chr, [](int c, const Node& x) { return c < x.chr; });
+    return ChrRange{(int)(lo - N.begin()), (int)(hi - N.begin())};
+}
+}  // namespace
 int locate_fragment(const std::vector<Node>& N, int hint, Frag& f, std::vector<int>& out) {
     const int n = (int)N.size();
     out.clear();
@@ -26,8 +39,18 @@ int locate_fragment(const std::vector<Node>& N, int hint, Frag& f, std::vector<i
     auto one = [&](Blk& b) {
         if (i < 0 || i >= n) i = hint;
         if (!fits(i, b)) {
-            if (N[i].chr < b.refid || (N[i].chr == b.refid && N[i].pos <= b.refpos)) { for (; i < n && N[i].chr <= b.refid; ++i) if (fits(i, b)) break; }
-            else { for (; i > -1 && N[i].chr >= b.refid; --i) if (fits(i, b)) break; }
+            const ChrRange cr = chr_range(N, b.refid);
+            // fitting range: pos_k <= refpos + 5 and end_k >= end - 5 (both monotone inside a chromosome)
+            const int a = (int)(std::lower_bound(N.begin() + cr.lo, N.begin() + cr.hi, b.refpos + b.matchref - 5, [](const Node& x, int v) { return x.pos + x.len < v; }) - N.begin());
+            const int bb = (int)(std::upper_bound(N.begin() + cr.lo, N.begin() + cr.hi, b.refpos + 5, [](int v, const Node& x) { return v < x.pos; }) - N.begin()) - 1;
+            const bool any = a <= bb && a < cr.hi && bb >= cr.lo;
+            if (N[i].chr < b.refid || (N[i].chr == b.refid && N[i].pos <= b.refpos)) {
+                // upward: the first fitting node at or above i, else the first node of a later chromosome (or n)
+                if (any && bb >= i) i = std::max(i, a); else i = std::max(i, cr.hi);
+            } else {
+                // downward: the first fitting node at or below i, else the last node of an earlier chromosome (or -1)
+                if (any && a <= i) i = std::min(i, bb); else i = std::min(i, cr.lo - 1);
+            }
         }
         if (i < 0 || i >= n || N[i].chr != b.refid) { out.push_back(-1); return; }
         out.push_back(i);
@@ -40,13 +63,15 @@ int locate_fragment(const std::vector<Node>& N, int hint, Frag& f, std::vector<i
     return SQ_OK;
 }
 
-static int home_node(const std::vector<Node>& N, int start, const Blk& b) {  // :1408-1409
+static int home_node(const std::vector<Node>& N, int start, const Blk& b) {  // :1408-1409, the two walks as binary searches
     const int n = (int)N.size();
-    int i = start;
-    for (; i < n && (N[i].chr < b.refid || (N[i].chr == b.refid && N[i].pos + N[i].len < b.refpos)); ++i) {}
+    // up while the node lies in front of the block
+    const int j0 = (int)(std::partition_point(N.begin(), N.end(), [&](const Node& x) { return x.chr < b.refid || (x.chr == b.refid && x.pos + x.len < b.refpos); }) - N.begin());
+    int i = std::max(start, j0);
     if (i >= n) return -2;
-    for (; i > -1 && (N[i].chr > b.refid || (N[i].chr == b.refid && N[i].pos > b.refpos)); --i) {}
-    return i;
+    // down while the node lies behind the block's start
+    const int j1 = (int)(std::partition_point(N.begin(), N.end(), [&](const Node& x) { return x.chr < b.refid || (x.chr == b.refid && x.pos <= b.refpos); }) - N.begin()) - 1;
+    return std::min(i, j1);
 }
 
 static std::pair<int, int> split_breakpoints(const Blk& x, const Blk& y) {  // :1435-1440

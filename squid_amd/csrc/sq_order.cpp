@@ -9,6 +9,10 @@
 // GLPK's pick among equal-valued optima and Boost's pick among equal min-cuts are not reproducible (neither
 // library is available, nothing in the reference pins them); DESIGN.md lists this as "parity unpinned".
 #include <algorithm>
+#include <deque>
+#include <memory>
+#include <ext/pb_ds/assoc_container.hpp>
+#include <ext/pb_ds/tree_policy.hpp>
 #include <cstdio>
 #include <cstdlib>
 #include <atomic>
@@ -261,75 +265,205 @@ bool bridge_split(int n, const std::vector<std::pair<int, int>>& edges, std::vec
     return true;
 }
 
+// MincutRecursion (SegmentGraph.cpp:3264-3451) without redoing the bridge search at every level: the bridges of a part
+// of the component are exactly the component's bridges inside it (splitting at a bridge breaks no cycle), so the
+// component is contracted ONCE into its tree of 2-edge-connected blobs (low-link DFS) and the recursion runs on that
+// tree -- per split one pass over the blobs of the part instead of one over its nodes and edges (the dense-graph config
+// peels thousands of small trees off a 20 000-node core: 1.9 s -> a few ms).
 struct Builder {
     std::vector<TreeNode> tree;
     std::vector<Piece> pieces;
-    // MincutRecursion (SegmentGraph.cpp:3264-3451): returns tree node index
-    int build(const std::vector<int>& ids, const std::vector<Edge>& E) {
-        const int n = (int)ids.size();
-        int me = (int)tree.size();
-        tree.push_back(TreeNode());
-        bool whole = n < 20;
-        std::vector<char> side;
-        if (!whole) {
-            auto local = [&](int g) { return (int)(std::lower_bound(ids.begin(), ids.end(), g) - ids.begin()); };
-            std::vector<std::pair<int, int>> le;
-            for (const Edge& e : E) le.push_back(std::make_pair(local(e.a), local(e.b)));
-            if (!bridge_split(n, le, side)) whole = true;
-        }
-        if (whole || n == 1) {
-            Piece p;
-            if (n == 1) { p.ids = ids; p.order.assign(1, ids[0] + 1); }
-            else make_piece(ids, E, p);
-            tree[me].piece = (int)pieces.size();
-            pieces.push_back(std::move(p));
-            return me;
-        }
-        std::vector<int> ids1, ids2;
-        for (int k = 0; k < n; ++k) (side[k] ? ids1 : ids2).push_back(ids[k]);
-        std::vector<Edge> e1, e2;
-        Edge mid{};
-        for (const Edge& e : E) {
-            bool s1 = std::binary_search(ids1.begin(), ids1.end(), e.a), s2 = std::binary_search(ids1.begin(), ids1.end(), e.b);
-            if (s1 && s2) e1.push_back(e);
-            else if (!s1 && !s2) e2.push_back(e);
-            else mid = e;
-        }
-        int l = build(ids1, e1), r = build(ids2, e2);
-        tree[me].left = l; tree[me].right = r; tree[me].bridge = mid;
-        return me;
+
+    int leaf_node(Piece&& p) {
+        TreeNode t;
+        t.piece = (int)pieces.size();
+        pieces.push_back(std::move(p));
+        tree.push_back(t);
+        return (int)tree.size() - 1;
     }
-    // join two ordered halves over the bridge edge (SegmentGraph.cpp:3393-3448)
-    std::vector<int> combine(int t) {
-        const TreeNode& tn = tree[t];
-        if (tn.piece >= 0) return pieces[tn.piece].order;
-        std::vector<int> A = combine(tn.left), B = combine(tn.right);
-        auto scan = [&](const std::vector<int>& X, int& median, bool& positive, bool& head) {
-            std::vector<int> ab;
-            positive = false; head = false;
-            for (int x : X) {
-                ab.push_back(std::abs(x));
-                if (std::abs(x) == tn.bridge.a + 1) { positive = x > 0; head = tn.bridge.ha; }
-                else if (std::abs(x) == tn.bridge.b + 1) { positive = x > 0; head = tn.bridge.hb; }
-            }
-            std::sort(ab.begin(), ab.end());
-            median = ab[(ab.size() - 1) / 2];
-        };
-        int m1, m2;
-        bool p1, h1, p2, h2;
-        scan(A, m1, p1, h1);
-        scan(B, m2, p2, h2);
-        auto flip = [](std::vector<int>& X) { std::reverse(X.begin(), X.end()); for (int& x : X) x = -x; };
-        if (m1 < m2) {
-            if (p1 == h1) flip(A);
-            if (p2 != h2) flip(B);
-            A.insert(A.end(), B.begin(), B.end());
-            return A;
+    int build(const std::vector<int>& ids, const std::vector<Edge>& E) {
+        const int n = (int)ids.size(), m = (int)E.size();
+        if (n == 1) { Piece p; p.ids = ids; p.order.assign(1, ids[0] + 1); return leaf_node(std::move(p)); }
+        if (n < 20) { Piece p; make_piece(ids, E, p); return leaf_node(std::move(p)); }
+        auto local = [&](int g) { return (int)(std::lower_bound(ids.begin(), ids.end(), g) - ids.begin()); };
+        std::vector<int> ea(m), eb(m);
+        for (int i = 0; i < m; ++i) { ea[i] = local(E[i].a); eb[i] = local(E[i].b); }
+        // ---- bridges (a parallel edge has another id and counts as a back edge) and blobs
+        std::vector<int> head(n + 1, 0), adj(2 * (size_t)m), aid(2 * (size_t)m);
+        for (int i = 0; i < m; ++i) { head[ea[i] + 1]++; head[eb[i] + 1]++; }
+        for (int i = 0; i < n; ++i) head[i + 1] += head[i];
+        {
+            std::vector<int> fill(head.begin(), head.end() - 1);
+            for (int i = 0; i < m; ++i) { adj[fill[ea[i]]] = eb[i]; aid[fill[ea[i]]++] = i; adj[fill[eb[i]]] = ea[i]; aid[fill[eb[i]]++] = i; }
         }
-        if (p2 == h2) flip(B);
-        if (p1 != h1) flip(A);
-        B.insert(B.end(), A.begin(), A.end());
-        return B;
+        std::vector<int> disc(n, -1), low(n, 0), parent_edge(n, -1), parent(n, -1), it(n, 0), order;
+        std::vector<char> is_bridge(m, 0);
+        order.reserve(n);
+        std::vector<int> stack(1, 0);
+        int timer = 0;
+        disc[0] = low[0] = timer++; order.push_back(0);
+        while (!stack.empty()) {
+            int x = stack.back();
+            if (it[x] < head[x + 1] - head[x]) {
+                int k = head[x] + it[x]++;
+                int y = adj[k], id = aid[k];
+                if (id == parent_edge[x]) continue;
+                if (disc[y] < 0) { disc[y] = low[y] = timer++; parent_edge[y] = id; parent[y] = x; order.push_back(y); stack.push_back(y); }
+                else low[x] = std::min(low[x], disc[y]);
+            } else {
+                stack.pop_back();
+                if (!stack.empty()) {
+                    int p = stack.back();
+                    low[p] = std::min(low[p], low[x]);
+                    if (low[x] > disc[p]) is_bridge[parent_edge[x]] = 1;
+                }
+            }
+        }
+        std::vector<int> blob(n, 0);
+        int nblob = 1;
+        for (int k = 1; k < n; ++k) { int x = order[k]; blob[x] = is_bridge[parent_edge[x]] ? nblob++ : blob[parent[x]]; }
+        std::vector<int> weight(nblob, 0);
+        for (int x = 0; x < n; ++x) weight[blob[x]]++;
+        // ---- blob tree (edges = bridges, keyed by their position in the component's sorted edge list)
+        std::vector<int> th(nblob + 1, 0), tadj, tid;
+        for (int i = 0; i < m; ++i) if (is_bridge[i]) { th[blob[ea[i]] + 1]++; th[blob[eb[i]] + 1]++; }
+        for (int i = 0; i < nblob; ++i) th[i + 1] += th[i];
+        tadj.resize(th[nblob]); tid.resize(th[nblob]);
+        {
+            std::vector<int> fill(th.begin(), th.end() - 1);
+            for (int i = 0; i < m; ++i) if (is_bridge[i]) { int u = blob[ea[i]], v = blob[eb[i]]; tadj[fill[u]] = v; tid[fill[u]++] = i; tadj[fill[v]] = u; tid[fill[v]++] = i; }
+        }
+        // ---- the recursion on the blob tree.  A part = the blobs reachable from `root` over bridges not cut yet.
+        std::vector<char> cut(m, 0);
+        std::vector<int> part_of(nblob, -1);           // final: leaf part id of every blob
+        struct Job { int root, tnode; };
+        const int top = (int)tree.size();
+        tree.push_back(TreeNode());
+        std::vector<Job> jobs(1, Job{0, top});
+        std::vector<int> nodes_of, par_b, par_e, sub;  // scratch of one traversal
+        std::vector<int> leaf_tnode;                   // leaf part id -> tree node
+        par_b.assign(nblob, -1); par_e.assign(nblob, -1); sub.assign(nblob, 0);
+        while (!jobs.empty()) {
+            const Job jb = jobs.back();
+            jobs.pop_back();
+            nodes_of.clear();
+            nodes_of.push_back(jb.root); par_b[jb.root] = -1; par_e[jb.root] = -1;
+            for (size_t q = 0; q < nodes_of.size(); ++q) {  // BFS order: parents before children
+                int u = nodes_of[q];
+                for (int k = th[u]; k < th[u + 1]; ++k) if (!cut[tid[k]] && tid[k] != par_e[u]) { int v = tadj[k]; par_b[v] = u; par_e[v] = tid[k]; nodes_of.push_back(v); }
+            }
+            long W = 0;
+            for (int u : nodes_of) { sub[u] = weight[u]; W += weight[u]; }
+            int best_e = -1, best_child = -1;
+            long best_bal = -1;
+            if (W >= 20) {
+                for (size_t q = nodes_of.size(); q-- > 1;) {
+                    int u = nodes_of[q];
+                    sub[par_b[u]] += sub[u];
+                    long bal = std::labs(W - 2L * sub[u]);
+                    if (best_bal < 0 || bal < best_bal || (bal == best_bal && par_e[u] < best_e)) { best_bal = bal; best_e = par_e[u]; best_child = u; }
+                }
+            }
+            if (best_e < 0) {  // fewer than 20 nodes, or no bridge inside ("min cut > 1"): solved whole
+                const int pid = (int)leaf_tnode.size();
+                for (int u : nodes_of) part_of[u] = pid;
+                leaf_tnode.push_back(jb.tnode);
+                continue;
+            }
+            cut[best_e] = 1;
+            const int l = (int)tree.size(); tree.push_back(TreeNode());
+            const int r = (int)tree.size(); tree.push_back(TreeNode());
+            tree[jb.tnode].left = l; tree[jb.tnode].right = r; tree[jb.tnode].bridge = E[best_e];
+            jobs.push_back(Job{best_child, l});
+            jobs.push_back(Job{jb.root, r});
+        }
+        // ---- leaves: ids ascending, edges in the component's order
+        const int nleaf = (int)leaf_tnode.size();
+        std::vector<std::vector<int>> lids(nleaf);
+        std::vector<std::vector<Edge>> ledges(nleaf);
+        for (int x = 0; x < n; ++x) lids[part_of[blob[x]]].push_back(ids[x]);
+        for (int i = 0; i < m; ++i) { int pa = part_of[blob[ea[i]]], pb = part_of[blob[eb[i]]]; if (pa == pb) ledges[pa].push_back(E[i]); }
+        for (int q = 0; q < nleaf; ++q) {
+            Piece p;
+            if (lids[q].size() == 1) { p.ids = lids[q]; p.order.assign(1, lids[q][0] + 1); }
+            else make_piece(lids[q], ledges[q], p);
+            tree[leaf_tnode[q]].piece = (int)pieces.size();
+            pieces.push_back(std::move(p));
+        }
+        return top;
+    }
+    // join the ordered halves over the bridge edges, bottom-up (SegmentGraph.cpp:3393-3448); children always have larger
+    // tree indices than their parent.  The reference copies, sorts (for the median id) and reverses whole halves at every
+    // level, which is quadratic when thousands of small parts are peeled off one big one.  Here a half is a deque with
+    // a lazy "reversed and negated" flag plus an order-statistics tree of its ids, and the smaller half is always moved
+    // into the larger one: O(n log^2 n) in total, same sequence.
+    struct Seq {
+        std::deque<int> q;
+        bool flipped = false;
+        __gnu_pbds::tree<int, __gnu_pbds::null_type, std::less<int>, __gnu_pbds::rb_tree_tag, __gnu_pbds::tree_order_statistics_node_update> ids;
+        size_t size() const { return q.size(); }
+        int median() const { return *ids.find_by_order((ids.size() - 1) / 2); }
+    };
+    std::vector<int> combine(int root, int end, std::vector<int>& stored_sign /* scratch, indexed by node id */) {
+        std::vector<std::unique_ptr<Seq>> res((size_t)(end - root));
+        auto R = [&](int t) -> std::unique_ptr<Seq>& { return res[(size_t)(t - root)]; };
+        for (int t = end - 1; t >= root; --t) {
+            const TreeNode& tn = tree[t];
+            if (tn.piece >= 0) {
+                std::unique_ptr<Seq> sq(new Seq());
+                for (int x : pieces[tn.piece].order) { sq->q.push_back(x); sq->ids.insert(std::abs(x) - 1); stored_sign[std::abs(x) - 1] = x > 0 ? 1 : -1; }
+                R(t) = std::move(sq);
+                continue;
+            }
+            std::unique_ptr<Seq> A = std::move(R(tn.left)), B = std::move(R(tn.right));
+            auto endpoint = [&](const Seq& X, bool& positive, bool& head) {  // the bridge end that lies in X: its current sign, its head flag
+                const bool a_in = X.ids.find(tn.bridge.a) != X.ids.end();
+                const int v = a_in ? tn.bridge.a : tn.bridge.b;
+                head = a_in ? tn.bridge.ha : tn.bridge.hb;
+                positive = (stored_sign[v] > 0) != X.flipped;
+            };
+            bool p1, h1, p2, h2;
+            endpoint(*A, p1, h1);
+            endpoint(*B, p2, h2);
+            const int m1 = A->median() + 1, m2 = B->median() + 1;
+            Seq *first, *second;
+            if (m1 < m2) {
+                if (p1 == h1) A->flipped = !A->flipped;
+                if (p2 != h2) B->flipped = !B->flipped;
+                first = A.get(); second = B.get();
+            } else {
+                if (p2 == h2) B->flipped = !B->flipped;
+                if (p1 != h1) A->flipped = !A->flipped;
+                first = B.get(); second = A.get();
+            }
+            // logical element i of a half: flipped ? -q[size-1-i] : q[i]
+            if (first->size() >= second->size()) {  // append `second` to `first`
+                const size_t k = second->size();
+                for (size_t i = 0; i < k; ++i) {
+                    const int y = second->flipped ? -second->q[k - 1 - i] : second->q[i];
+                    const int st = first->flipped ? -y : y;
+                    if (!first->flipped) first->q.push_back(st); else first->q.push_front(st);
+                    stored_sign[std::abs(y) - 1] = st > 0 ? 1 : -1;
+                    first->ids.insert(std::abs(y) - 1);
+                }
+                R(t) = first == A.get() ? std::move(A) : std::move(B);
+            } else {                                // prepend `first` to `second`
+                const size_t k = first->size();
+                for (size_t i = k; i-- > 0;) {
+                    const int x = first->flipped ? -first->q[k - 1 - i] : first->q[i];
+                    const int st = second->flipped ? -x : x;
+                    if (!second->flipped) second->q.push_front(st); else second->q.push_back(st);
+                    stored_sign[std::abs(x) - 1] = st > 0 ? 1 : -1;
+                    second->ids.insert(std::abs(x) - 1);
+                }
+                R(t) = second == A.get() ? std::move(A) : std::move(B);
+            }
+        }
+        const Seq& top = *R(root);
+        std::vector<int> out(top.size());
+        const size_t k = top.size();
+        for (size_t i = 0; i < k; ++i) out[i] = top.flipped ? -top.q[k - 1 - i] : top.q[i];
+        return out;
     }
 };
 
@@ -348,7 +482,8 @@ int order_components(sq_ctx* c) {
     Builder B;
     std::vector<int> roots(ncomp);
     auto t0 = std::chrono::steady_clock::now();
-    for (int k = 0; k < ncomp; ++k) roots[k] = B.build(cn[k], ce[k]);
+    std::vector<int> ends(ncomp);
+    for (int k = 0; k < ncomp; ++k) { roots[k] = B.build(cn[k], ce[k]); ends[k] = (int)B.tree.size(); }
     c->timer.add("host_mincut_tree", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     // ---- leaves: <= 8 nodes on the GPU in one batch, the rest on the host
     const int GPU_NMAX = 8, EXACT_MAX = 26;
@@ -418,10 +553,11 @@ int order_components(sq_ctx* c) {
         for (auto& th : pool) th.join();
     }
     c->timer.add("host_order_large", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    std::vector<int> sign_scratch((size_t)n, 1);
     c->ord_off.assign(1, 0);
     c->ord_nodes.clear();
     for (int k = 0; k < ncomp; ++k) {
-        std::vector<int> o = B.combine(roots[k]);
+        std::vector<int> o = B.combine(roots[k], ends[k], sign_scratch);
         c->ord_nodes.insert(c->ord_nodes.end(), o.begin(), o.end());
         c->ord_off.push_back((int32_t)c->ord_nodes.size());
     }

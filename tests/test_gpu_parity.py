@@ -418,3 +418,17 @@ def test_sharded_command_line_two_processes(built, synth, tmp_path):
     subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
                     "-m", "squid_amd.sharded_cli", "-b", f"{pre}.bam", "-c", f"{pre}.chim.bam", "-o", str(out)], check=True, env=env, timeout=600)
     assert Path(f"{out}_sv.txt").read_text() == sv_path.read_text()
+
+
+def test_dense_graph_config_with_a_giant_component(built, synth, tmp_path, monkeypatch):
+    """BASELINE.json configs[4] flags (-w 1 -a 50) on a small dense sample: one component of ~2000 nodes that the
+    min-cut recursion splits ~300 times (bridge tree + small-to-large join in the product), the rest small"""
+    monkeypatch.delenv("SQUID_EXACT_DEPTH", raising=False)
+    pre = synth("C5", "--records", "200000", "--tsv", "400")
+    sv_path, dump = ou.run_oracle(built, pre, tmp_path, "-w", "1", "-a", "50")
+    stats = dict(line.split("\t") for line in (dump / "order_stats.txt").read_text().splitlines())
+    assert int(stats["mincut_splits"]) > 100
+    with squid_amd.Context(min_edge_weight=1, max_allowed_degree=50) as ctx:
+        ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
+        ctx.build_graph()
+        _compare(ctx, dump, sv_path, depth_exact=False)

@@ -130,3 +130,19 @@ def test_argument_errors_print_and_exit_zero(built):
     """Config.cpp:213-229 / main.cpp: bad arguments print 'Check your argument.' and the process exits 0"""
     p = subprocess.run([str(built / "squid_oracle"), "-b", "x.bam"], capture_output=True, text=True)
     assert p.returncode == 0 and "Check your argument." in p.stdout
+
+
+def test_linear_time_bridge_search_agrees_with_the_brute_force(built, synth, tmp_path, monkeypatch):
+    """components above 64 nodes use a chain-decomposition bridge search in the oracle; ORACLE_BRIDGE_CHECK makes it
+    run the quadratic brute force next to it on every call and abort on any difference (dense parameter set: ~300
+    splits of a ~2000-node component)"""
+    import subprocess
+
+    pre = synth("C5", "--records", "200000", "--tsv", "400")
+    monkeypatch.setenv("ORACLE_BRIDGE_CHECK", "1")
+    out = tmp_path / "chk"
+    subprocess.check_call([str(built / "squid_oracle"), "-b", f"{pre}.bam", "-c", f"{pre}.chim.bam", "-o", str(out), "-w", "1", "-a", "50"], stdout=subprocess.DEVNULL)
+    monkeypatch.delenv("ORACLE_BRIDGE_CHECK")
+    out2 = tmp_path / "plain"
+    subprocess.check_call([str(built / "squid_oracle"), "-b", f"{pre}.bam", "-c", f"{pre}.chim.bam", "-o", str(out2), "-w", "1", "-a", "50"], stdout=subprocess.DEVNULL)
+    assert (tmp_path / "chk_sv.txt").read_text() == (tmp_path / "plain_sv.txt").read_text()
