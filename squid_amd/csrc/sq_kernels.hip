@@ -772,12 +772,22 @@ __device__ __forceinline__ void stripe_add(int32_t* stripes, int v) {
     atomicAdd(&stripes[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (NSTRIPE - 1)], v);
 }
 
+__global__ void k_early(int64_t n, FEarlyMain f, int32_t* out) {  // the scan then streams 4 B instead of evaluating the lookup twice
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) out[r] = f(r);
+}
 // add (1, len) to node `at` for every lane with `valid`; lanes of a wave that hit the same node are combined first
 // (a wave covers 64 neighbouring records of the sorted stream, which almost always share their node).
 // Must be called by ALL lanes of the wave (the shuffles read every lane).
-__device__ __forceinline__ void node_add(int32_t* cnt, int32_t* sum, bool valid, int at, int len) {
+// The accumulators exist NODE_STRIPES times (stripe = wave id mod NODE_STRIPES, stride nn): neighbouring waves mostly hit
+// the same node, and atomics onto one word serialise in L2 (on C2 -- one chromosome, a few huge nodes -- they were most
+// of the kernel); k_fold_stripes sums the copies.
+constexpr int NODE_STRIPES = 16;
+__device__ __forceinline__ void node_add(int32_t* cnt, int32_t* sum, int nn, bool valid, int at, int len) {
     unsigned long long active = __ballot(valid);
     const int lane = threadIdx.x & 63;
+    const size_t so = (size_t)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (NODE_STRIPES - 1)) * (size_t)nn;
+    cnt += so; sum += so;
     if (!valid) { at = -1; len = 0; }
     while (active) {
         int leader = __ffsll((long long)active) - 1;
@@ -808,7 +818,7 @@ __global__ void k_depth(RecView R, NodeView N, const uint8_t* keep, const int32_
             if (N.chr[at] != c) atomicOr(&flags[0], 1);  // cursor stuck on another chromosome: stream not sorted
             else hit = p >= N.pos[at] - 3 && p + len <= N.pos[at] + N.len[at] + 3;
         }
-        node_add(main_cnt, main_sum, hit, at, len);
+        node_add(main_cnt, main_sum, N.n, hit, at, len);
     }
     // ReadsOther: sorted by (chr,pos) in the reference => consumed at its home node
     int maxb = nblk;
@@ -839,7 +849,7 @@ __global__ void k_depth(RecView R, NodeView N, const uint8_t* keep, const int32_
     for (int j = 0; j < UNR; ++j) {
         if (j + 1 >= maxb) break;  // wave-uniform
         if (j + 1 < nblk && ek[j] != hk[j]) ambiguous(ek[j], hk[j], lk[j], hitk[j]);
-        node_add(other_cnt, other_sum, hitk[j], hk[j], lk[j]);
+        node_add(other_cnt, other_sum, N.n, hitk[j], hk[j], lk[j]);
     }
     for (int k = UNR + 1; k < maxb; ++k) {  // wave-uniform trip count
         bool hit = false;
@@ -851,11 +861,18 @@ __global__ void k_depth(RecView R, NodeView N, const uint8_t* keep, const int32_
             hit = p + len <= N.pos[home] + N.len[home] + 3;
             if (early != home) ambiguous(early, home, len, hit);
         }
-        node_add(other_cnt, other_sum, hit, home, len);
+        node_add(other_cnt, other_sum, N.n, hit, home, len);
     }
     int no = nblk > 1 ? nblk - 1 : 0;
     for (int d = 32; d >= 1; d >>= 1) no += __shfl_xor(no, d, 64);
     if ((threadIdx.x & 63) == 0 && no) stripe_add(stripes, no);
+}
+__global__ void k_fold_stripes(int nn, int32_t* a, int32_t* b, int32_t* c2, int32_t* d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nn) return;
+    int sa = 0, sb = 0, sc = 0, sd = 0;
+    for (int s = 0; s < NODE_STRIPES; ++s) { const size_t o = (size_t)s * nn + i; sa += a[o]; sb += b[o]; sc += c2[o]; sd += d[o]; }
+    a[i] = sa; b[i] = sb; c2[i] = sc; d[i] = sd;
 }
 // number of non-first blocks of a consumed kept record (|ReadsOther| contributions), for the ordered gather
 struct FOtherCount {
@@ -1163,24 +1180,48 @@ __global__ void k_bp_m(RecView R, BPView B, const uint8_t* cls, int32_t* m) {
     }
     m[r] = v;
 }
-// +-1 into the difference array for breakpoints [max(first covered, cursor), first not covered)
-__device__ __forceinline__ void bp_contribute(const RecView& R, const BPView& B, int64_t r, int before, int cur, int sign, int32_t* diff) {
-    if (before >= B.n) return;  // the reference has left its loop (SegmentGraph.cpp:3144-3145)
-    int c = R.refid[r];
-    int lo = bp_lower_bound(B, c, bp_start(R, r)), hi = bp_lower_bound(B, c, R.endpos[r]);
-    if (lo < cur) lo = cur;
-    if (lo < hi) { atomicAdd(&diff[lo], sign); atomicAdd(&diff[hi], -sign); }
+// +-1 into the difference array for breakpoints [max(first covered, cursor), first not covered).  Neighbouring records
+// cover the same breakpoints, so equal indices inside the wave are combined before the atomic.  WAVE: called by all
+// lanes of a wave (k_bp_count); otherwise by single lanes (k_bp_walk corrections).
+__device__ __forceinline__ void wave_add(int32_t* arr, bool valid, int idx, int val) {
+    unsigned long long active = __ballot(valid);
+    const int lane = threadIdx.x & 63;
+    if (!valid) { idx = -1; val = 0; }
+    while (active) {
+        const int leader = __ffsll((long long)active) - 1;
+        const int k = __shfl(idx, leader, 64);
+        const unsigned long long same = __ballot(idx == k) & active;
+        int v = idx == k ? val : 0;
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        if (lane == leader && v) atomicAdd(&arr[k], v);
+        active &= ~same;
+    }
+}
+template <bool WAVE>
+__device__ __forceinline__ void bp_contribute(const RecView& R, const BPView& B, int64_t r, bool live, int before, int cur, int sign, int32_t* diff) {
+    int lo = 0, hi = 0;
+    if (live && before < B.n) {  // (else: the reference has left its loop, SegmentGraph.cpp:3144-3145)
+        const int c = R.refid[r];
+        lo = bp_lower_bound(B, c, bp_start(R, r)); hi = bp_lower_bound(B, c, R.endpos[r]);
+        if (lo < cur) lo = cur;
+    }
+    const bool on = lo < hi;
+    if (WAVE) { wave_add(diff, on, lo, sign); wave_add(diff, on, hi, -sign); }
+    else if (on) { atomicAdd(&diff[lo], sign); atomicAdd(&diff[hi], -sign); }
 }
 // cur0 = cursor position before the first record (0, or what the records of earlier shards left behind)
 __global__ void k_bp_count(RecView R, BPView B, const uint8_t* cls, const int32_t* m, const int32_t* Mx, int cur0, int32_t* ev_by_M, int32_t* diff) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R.n || !(cls[r] & C_P3)) return;
-    int before = Mx[r] > cur0 ? Mx[r] : cur0, M = m[r] > before ? m[r] : before;
-    if (M > before) {
-        ev_by_M[M] = (int32_t)r;  // M values of events are distinct and increase along the stream
-        if (Mx[r] <= cur0) ev_by_M[0] = (int32_t)r;  // slot 0 (no event has M == 0): the first event of the stream
+    const bool live = r < R.n && (cls[r] & C_P3);
+    int before = 0, M = 0;
+    if (live) {
+        before = Mx[r] > cur0 ? Mx[r] : cur0; M = m[r] > before ? m[r] : before;
+        if (M > before) {
+            ev_by_M[M] = (int32_t)r;  // M values of events are distinct and increase along the stream
+            if (Mx[r] <= cur0) ev_by_M[0] = (int32_t)r;  // slot 0 (no event has M == 0): the first event of the stream
+        }
     }
-    bp_contribute(R, B, r, before, M, 1, diff);
+    bp_contribute<true>(R, B, r, live, before, M, 1, diff);
 }
 // sharded runs: number of pass-3 records, and how many of them come before the first event (they can absorb a cursor
 // that the earlier shards have left behind schedule without changing anything here)
@@ -1219,8 +1260,8 @@ __global__ __launch_bounds__(64) void k_bp_walk(RecView R, BPView B, const uint8
             if (cur == Mk) { done = k; break; }
         }
         if (APPLY && mycur >= 0 && (mycur != MM || mybefore != before_a)) {
-            bp_contribute(R, B, r, before_a, MM, -1, diff);
-            bp_contribute(R, B, r, mybefore, mycur, 1, diff);
+            bp_contribute<false>(R, B, r, true, before_a, MM, -1, diff);
+            bp_contribute<false>(R, B, r, true, mybefore, mycur, 1, diff);
         }
         if (done >= 0) { end = base + done; break; }
     }
@@ -1909,9 +1950,10 @@ int dev_node_depth(sq_ctx* c, const std::vector<Node>& nodes, int64_t n_break, s
     const int nn = (int)nodes.size();
     if (D.nv.n != nn) return fail(c, SQ_E_ARG, "internal: dev_upload_nodes first");
     const NodeView nv = D.nv;
-    HIPCHK(D.acc_a.reserve(nn)); HIPCHK(D.acc_b.reserve(nn)); HIPCHK(D.acc_c.reserve(nn)); HIPCHK(D.acc_d.reserve(nn)); HIPCHK(D.acc_e.reserve(nn)); HIPCHK(D.acc_f.reserve(nn));
+    const size_t nst = (size_t)nn * NODE_STRIPES;
+    HIPCHK(D.acc_a.reserve(nst)); HIPCHK(D.acc_b.reserve(nst)); HIPCHK(D.acc_c.reserve(nst)); HIPCHK(D.acc_d.reserve(nst)); HIPCHK(D.acc_e.reserve(nn)); HIPCHK(D.acc_f.reserve(nn));
     HIPCHK(D.scratch_a.reserve(std::max<int64_t>(n, 1)));
-    HIPCHK(hipMemsetAsync(D.acc_a.p, 0, nn * 4, s)); HIPCHK(hipMemsetAsync(D.acc_b.p, 0, nn * 4, s)); HIPCHK(hipMemsetAsync(D.acc_c.p, 0, nn * 4, s)); HIPCHK(hipMemsetAsync(D.acc_d.p, 0, nn * 4, s));
+    HIPCHK(hipMemsetAsync(D.acc_a.p, 0, nst * 4, s)); HIPCHK(hipMemsetAsync(D.acc_b.p, 0, nst * 4, s)); HIPCHK(hipMemsetAsync(D.acc_c.p, 0, nst * 4, s)); HIPCHK(hipMemsetAsync(D.acc_d.p, 0, nst * 4, s));
     HIPCHK(hipMemsetAsync(D.acc_e.p, 0, nn * 4, s)); HIPCHK(hipMemsetAsync(D.acc_f.p, 0, nn * 4, s));
     HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
     HIPCHK(D.stripes.reserve(NSTRIPE));
@@ -1919,10 +1961,13 @@ int dev_node_depth(sq_ctx* c, const std::vector<Node>& nodes, int64_t n_break, s
     RecView R = D.view();
     const int32_t nbk = (int32_t)std::min<int64_t>(n_break, INT32_MAX);
     if (n > 0) {
-        { EvTimer t(c, "scan_depth_cursor", 12.0 * n);
-          HIPCHK((device_scan<OpMax, false>(s, n, FEarlyMain{R, nv, D.keep.p, D.rank1.p, nbk}, D.scratch_a.p, D.spine, nullptr))); }
+        HIPCHK(D.b0_home.reserve(n));
+        { EvTimer t(c, "scan_depth_cursor", 25.0 * n + 12.0 * n);
+          hipLaunchKernelGGL(k_early, grid_for(n, 256), dim3(256), 0, s, n, FEarlyMain{R, nv, D.keep.p, D.rank1.p, nbk}, D.b0_home.p);
+          HIPCHK((device_scan<OpMax, false>(s, n, FArr{D.b0_home.p}, D.scratch_a.p, D.spine, nullptr))); }
         { EvTimer t(c, "k_depth", 13.0 * n + 8.0 * D.nb);
-          hipLaunchKernelGGL(k_depth, grid_for(n, 256), dim3(256), 0, s, R, nv, D.keep.p, D.rank1.p, nbk, D.scratch_a.p, D.acc_a.p, D.acc_b.p, D.acc_c.p, D.acc_d.p, D.acc_e.p, D.acc_f.p, D.flags.p, D.stripes.p); }
+          hipLaunchKernelGGL(k_depth, grid_for(n, 256), dim3(256), 0, s, R, nv, D.keep.p, D.rank1.p, nbk, D.scratch_a.p, D.acc_a.p, D.acc_b.p, D.acc_c.p, D.acc_d.p, D.acc_e.p, D.acc_f.p, D.flags.p, D.stripes.p);
+          if (nn) hipLaunchKernelGGL(k_fold_stripes, dim3((nn + 255) / 256), dim3(256), 0, s, nn, D.acc_a.p, D.acc_b.p, D.acc_c.p, D.acc_d.p); }
     }
     D.pin.reset();
     int32_t* h = D.pin.take_n<int32_t>(6 * (size_t)nn + 8 + NSTRIPE);
