@@ -448,10 +448,32 @@ __device__ int parse_blocks(const uint8_t* cg, int ncig, const uint8_t* seq, int
     }
     return nb;
 }
-__global__ void k_parse_count(const uint8_t* bam, const unsigned long long* rec_off, int64_t n, int32_t* nblk, int32_t* flags) {
+// The records of a workgroup are one contiguous byte range of the chunk (64 records, ~17 KB).  Parsing walks them byte by
+// byte per lane, 260 bytes apart from the neighbouring lane: straight from global memory every load touches 64 cache
+// lines and the chunk is fetched from HBM ~20 times over.  So the range is first copied into LDS with coalesced 16-byte
+// loads and the lanes parse from there (a range that does not fit -- very long records -- is parsed in place).
+constexpr int PARSE_THREADS = 64, PARSE_LDS = 32768;
+__device__ __forceinline__ const uint8_t* stage_records(const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n, uint8_t* lds) {
+    const int64_t r0 = (int64_t)blockIdx.x * blockDim.x, r1 = r0 + blockDim.x < n ? r0 + blockDim.x : n;
+    const unsigned long long lo = rec_off[r0] & ~15ull, hi = r1 < n ? rec_off[r1] : (unsigned long long)nbytes;
+    const bool fits = hi - lo <= (unsigned long long)PARSE_LDS;  // uniform over the workgroup
+    if (fits) {
+        const uint4* src = (const uint4*)(bam + lo);  // (the chunk buffer is 256-byte aligned and padded by 64 bytes)
+        uint4* dst = (uint4*)lds;
+        const int words = (int)((hi - lo + 15) >> 4);
+        for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int64_t r = r0 + threadIdx.x;
+    if (r >= n) return nullptr;
+    return fits ? lds + (rec_off[r] - lo) : bam + rec_off[r];
+}
+__global__ __launch_bounds__(PARSE_THREADS) void k_parse_count(const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n, int32_t* nblk, int32_t* flags) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[PARSE_LDS];
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const uint8_t* p = bam + rec_off[r] + 4;
+    const uint8_t* rec = stage_records(bam, nbytes, rec_off, n, lds);
+    if (!rec) return;
+    const uint8_t* p = rec + 4;
     int lname = p[8], ncig = ld16(p + 12), flag = ld16(p + 14), lseq = ld32(p + 16), pos = ld32(p + 4);
     const uint8_t* cg = p + 32 + lname;
     const uint8_t* seq = cg + 4 * (size_t)ncig;
@@ -462,12 +484,14 @@ __global__ void k_parse_count(const uint8_t* bam, const unsigned long long* rec_
     (void)flags;
 }
 struct FArrN { const int32_t* a; __device__ int operator()(int64_t i) const { return a[i]; } };
-__global__ void k_parse_write(const uint8_t* bam, const unsigned long long* rec_off, int64_t n, ChimSetView C, ParseParams P, const int32_t* blk_rel, uint32_t blk_base, int32_t* o_refid,
+__global__ __launch_bounds__(PARSE_THREADS) void k_parse_write(const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n, ChimSetView C, ParseParams P, const int32_t* blk_rel, uint32_t blk_base, int32_t* o_refid,
                               int32_t* o_pos, int32_t* o_mrefid, int32_t* o_mpos, int32_t* o_endpos, uint16_t* o_flag, uint16_t* o_totlen, uint8_t* o_mapq, uint8_t* o_aux, uint32_t* o_blkoff,
                               int32_t* b_refpos, int32_t* b_matchref, uint16_t* b_readpos, uint16_t* b_matchread, int32_t* flags) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[PARSE_LDS];
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const uint8_t* p = bam + rec_off[r] + 4;
+    const uint8_t* rec = stage_records(bam, nbytes, rec_off, n, lds);
+    if (!rec) return;
+    const uint8_t* p = rec + 4;
     const int bs = ld32(p - 4);
     const uint8_t* pend = p + bs;
     const int refid = ld32(p), pos = ld32(p + 4), lname = p[8], mapq = p[9], ncig = ld16(p + 12), flag = ld16(p + 14), lseq = ld32(p + 16), mrefid = ld32(p + 20), mpos = ld32(p + 24);
@@ -1640,7 +1664,7 @@ int dev_parse_append(sq_ctx* c, const uint8_t* bam, size_t nbytes, const unsigne
     HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
     int32_t* tot = D.flags.p + 8;
     { EvTimer t(c, "k_parse_count", (double)nbytes);
-      hipLaunchKernelGGL(k_parse_count, grid_for(n_rec, 256), dim3(256), 0, s, D.bam_chunk.p, D.bam_off.p, n_rec, D.parse_nblk.p, D.flags.p);
+      hipLaunchKernelGGL(k_parse_count, grid_for(n_rec, PARSE_THREADS), dim3(PARSE_THREADS), 0, s, D.bam_chunk.p, nbytes, D.bam_off.p, n_rec, D.parse_nblk.p, D.flags.p);
       HIPCHK((device_scan<OpSum, true>(s, n_rec, FArrN{D.parse_nblk.p}, D.parse_rel.p, D.spine, tot))); }
     int32_t nblk_total = 0;
     HIPCHK(hipMemcpyAsync(&nblk_total, tot, 4, hipMemcpyDeviceToHost, s));
@@ -1656,7 +1680,7 @@ int dev_parse_append(sq_ctx* c, const uint8_t* bam, size_t nbytes, const unsigne
     ChimSetView C{D.chim_mask, D.chim_mask ? D.chim_hash.p : nullptr, D.chim_off.p, D.chim_len.p, D.chim_blob.p};
     ParseParams P{(int)(signed char)(((c->P.phred_type ? 33 : 64) + c->P.min_phred) & 0xff), c->P.max_lowphred_len, c->P.min_mapqual};
     { EvTimer t(c, "k_parse_write", (double)nbytes + 32.0 * n_rec + 12.0 * nblk_total);
-      hipLaunchKernelGGL(k_parse_write, grid_for(n_rec, 256), dim3(256), 0, s, D.bam_chunk.p, D.bam_off.p, n_rec, C, P, D.parse_rel.p, (uint32_t)nb0, D.refid.p + n0, D.pos.p + n0, D.mrefid.p + n0,
+      hipLaunchKernelGGL(k_parse_write, grid_for(n_rec, PARSE_THREADS), dim3(PARSE_THREADS), 0, s, D.bam_chunk.p, nbytes, D.bam_off.p, n_rec, C, P, D.parse_rel.p, (uint32_t)nb0, D.refid.p + n0, D.pos.p + n0, D.mrefid.p + n0,
                          D.mpos.p + n0, D.endpos.p + n0, D.flag.p + n0, D.totlen.p + n0, D.mapq.p + n0, D.aux.p + n0, D.blk_off.p + n0, D.b_refpos.p, D.b_matchref.p, D.b_readpos.p, D.b_matchread.p,
                          D.flags.p); }
     const uint32_t endoff = (uint32_t)nb1;
