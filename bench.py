@@ -162,7 +162,7 @@ def main() -> None:
     scan_bytes = sum(v["bytes"] for v in gk.values()) / a.steps
     traffic = None
     tfile = ROOT / "profiles" / "pmc_traffic.json"  # written by tools/profile.sh from the rocprofv3 --pmc passes
-    if tfile.exists():
+    if tfile.exists() and a.workload == "C2" and not a.records:  # the counters were collected on the default workload
         try:
             traffic = (json.loads(tfile.read_text()).get(dom) or {}).get("hbm_bytes_per_launch")
         except Exception:
