@@ -189,6 +189,10 @@ int sq_debug_download(sq_ctx* c, sq_aln_batch* b);
 /* tests: ExactBPConcordantSupport's counting loop (src/SegmentGraph.cpp:3129-3166) over the resident records for an
  * arbitrary sorted breakpoint list; host_walk != 0 takes the serial host restatement instead of the K10 kernels */
 int sq_debug_bp_support(sq_ctx* c, int32_t n_bp, const int32_t* chr, const int32_t* pos, int32_t* coverage, int32_t host_walk);
+/* tests: one instance of the per-component ordering problem (GenerateILP, src/SegmentGraph.cpp:3763-3983) on local nodes
+ * 0..n-1; edges5 = n_edges x {u, v, head_u, head_v, weight}, u < v.  use_gpu: k_order_small (n <= 8), else the host solver
+ * (n <= 26).  Returns the canonical optimum: orientation mask (bit i = node i reversed) and left-to-right node order. */
+int sq_debug_order(sq_ctx* c, int32_t n, int32_t n_edges, const int32_t* edges5, int32_t use_gpu, int32_t* mask, int32_t* order, int64_t* value);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,7 @@ EXPORTS = [
     "sq_default_params", "sq_create", "sq_destroy", "sq_strerror", "sq_last_error", "sq_set_references",
     "sq_ingest_chimeric", "sq_chim_contains", "sq_ingest_concordant", "sq_ingest_concordant_bam", "sq_read_header", "sq_ingest_chimeric_file",
     "sq_ingest_concordant_file", "sq_build_graph", "sq_graph_view", "sq_order", "sq_call_sv", "sq_breakpoints",
-    "sq_set_shard", "sq_exchange_pack", "sq_exchange_unpack", "sq_get_timing", "sq_reset", "sq_get_counts", "sq_debug_download", "sq_debug_bp_support",
+    "sq_set_shard", "sq_exchange_pack", "sq_exchange_unpack", "sq_get_timing", "sq_reset", "sq_get_counts", "sq_debug_download", "sq_debug_bp_support", "sq_debug_order",
 ]
 
 
@@ -276,6 +276,14 @@ class Context:
         self.lib.sq_debug_bp_support.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, C.c_int32]
         self._chk(self.lib.sq_debug_bp_support(self.h, len(ch), ch.ctypes.data_as(I32P), po.ctypes.data_as(I32P), out.ctypes.data_as(I32P), int(host_walk)), "sq_debug_bp_support")
         return out
+
+    def order_problem(self, n: int, edges: list, use_gpu: bool):
+        """canonical optimum (mask, order, value) of one ordering problem; edges = [(u, v, head_u, head_v, w)], u < v (tests only)"""
+        flat = (C.c_int32 * (5 * len(edges)))(*[int(x) for e in edges for x in e])
+        mask, value, order = C.c_int32(), C.c_int64(), (C.c_int32 * n)()
+        self.lib.sq_debug_order.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+        self._chk(self.lib.sq_debug_order(self.h, n, len(edges), flat, int(use_gpu), C.byref(mask), order, C.byref(value)), "sq_debug_order")
+        return mask.value, list(order), value.value
 
     def timing(self) -> dict:
         t = SqTiming()

@@ -887,6 +887,17 @@ int sq_debug_bp_support(sq_ctx* c, int32_t n_bp, const int32_t* chr, const int32
     std::copy(cov.begin(), cov.end(), coverage);
     return SQ_OK;
 }
+int sq_debug_order(sq_ctx* c, int32_t n, int32_t n_edges, const int32_t* edges5, int32_t use_gpu, int32_t* mask, int32_t* order, int64_t* value) {
+    if (!c || n_edges < 0 || (n_edges && !edges5) || !mask || !order || !value) return SQ_E_ARG;
+    std::vector<int32_t> e(edges5, edges5 + 5 * (size_t)n_edges), o;
+    int32_t m = 0; int64_t v = 0;
+    int rc = order_problem_debug(c, n, e, use_gpu != 0, m, o, v);
+    dev_flush_timers(c);
+    if (rc) return rc;
+    *mask = m; *value = v;
+    std::copy(o.begin(), o.end(), order);
+    return SQ_OK;
+}
 int sq_set_shard(sq_ctx* c, int32_t first_ref, int32_t end_ref) {
     if (!c) return SQ_E_ARG;
     if (c->P.world_size <= 1) return fail(c, SQ_E_ARG, "sq_set_shard needs sq_params.world_size > 1");

@@ -212,6 +212,7 @@ int exact_breakpoints(sq_ctx* c, BPMap& bp);
 
 // ---- sq_order.cpp
 int order_components(sq_ctx* c);
+int order_problem_debug(sq_ctx* c, int n, const std::vector<int32_t>& edges5, bool use_gpu, int32_t& mask, std::vector<int32_t>& order, int64_t& value);
 
 // ---- sq_kernels.hip (device side; every function enqueues on c->stream and records HIP-event timings)
 int dev_create(sq_ctx* c);

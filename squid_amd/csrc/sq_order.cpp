@@ -565,4 +565,30 @@ int order_components(sq_ctx* c) {
     return SQ_OK;
 }
 
+// tests: one ordering problem (local nodes 0..n-1, edges as u,v,hu,hv,w with u < v) through the GPU kernel or the host solver
+int order_problem_debug(sq_ctx* c, int n, const std::vector<int32_t>& edges5, bool use_gpu, int32_t& mask, std::vector<int32_t>& order, int64_t& value) {
+    if (n < 2 || n > 26 || edges5.size() % 5) return fail(c, SQ_E_ARG, "bad ordering problem");
+    for (size_t i = 0; i < edges5.size(); i += 5)
+        if (edges5[i] < 0 || edges5[i] >= edges5[i + 1] || edges5[i + 1] >= n || edges5[i + 4] <= 0) return fail(c, SQ_E_ARG, "bad ordering problem edge");
+    order.assign(n, 0);
+    if (use_gpu) {
+        if (n > 8) return fail(c, SQ_E_ARG, "the GPU kernel takes at most 8 nodes");
+        std::vector<SmallProblem> probs(1, SmallProblem{n, 0, (int)(edges5.size() / 5)});
+        std::vector<int32_t> gm, go;
+        int rc = dev_order_small(c, probs, edges5, gm, go, 8);
+        if (rc) return rc;
+        mask = gm[0];
+        for (int p = 0; p < n; ++p) order[p] = go[p];
+        value = -1;  // (the kernel's value stays on the device; the caller evaluates the result)
+        return SQ_OK;
+    }
+    std::vector<LEdge> E;
+    for (size_t i = 0; i < edges5.size(); i += 5) E.push_back(LEdge{edges5[i], edges5[i + 1], edges5[i + 2] != 0, edges5[i + 3] != 0, edges5[i + 4]});
+    HostSolver hs(n, E);
+    hs.run();
+    mask = (int32_t)hs.bestmask; value = hs.best;
+    for (int p = 0; p < n; ++p) order[p] = hs.bestorder[p];
+    return SQ_OK;
+}
+
 }  // namespace sq

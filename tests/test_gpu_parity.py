@@ -432,3 +432,82 @@ def test_dense_graph_config_with_a_giant_component(built, synth, tmp_path, monke
         ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
         ctx.build_graph()
         _compare(ctx, dump, sv_path, depth_exact=False)
+
+
+# ---- K9 on adversarial inputs: random small problems with conflicting edges against an exhaustive search
+def _order_value(n, edges, mask, order):
+    """weight of the edges satisfied by (orientation mask, left-to-right order): the four head patterns of
+    GenerateILP (src/SegmentGraph.cpp:3763-3983) as restated in oracle/o_order.h EdgeSatisfied"""
+    pos = {v: i for i, v in enumerate(order)}
+    tot = 0
+    for u, v, hu, hv, w in edges:
+        yu, yv = not (mask >> u) & 1, not (mask >> v) & 1
+        if not hu and hv:
+            ok, ufirst = yu == yv, yu
+        elif not hu and not hv:
+            ok, ufirst = yu != yv, yu
+        elif hu and hv:
+            ok, ufirst = yu != yv, yv
+        else:
+            ok, ufirst = yu == yv, not yu
+        if ok and (pos[u] < pos[v]) == bool(ufirst):
+            tot += w
+    return tot
+
+
+def _order_brute(n, edges):
+    import itertools
+
+    best = None
+    for mask in range(1 << n):
+        for perm in itertools.permutations(range(n)):
+            key = (-_order_value(n, edges, mask, perm), mask, perm)
+            if best is None or key < best:
+                best = key
+    return -best[0], best[1], list(best[2])
+
+
+def test_ordering_solvers_on_random_conflicting_problems(built):
+    import random
+
+    rng = random.Random(11)
+    with squid_amd.Context() as ctx:
+        for trial in range(60):
+            n = rng.randrange(2, 7) if trial < 40 else rng.randrange(7, 9)
+            pairs = [(u, v) for u in range(n) for v in range(u + 1, n)]
+            rng.shuffle(pairs)
+            edges = []
+            for u, v in pairs[: rng.randrange(1, min(len(pairs), 2 * n) + 1)]:
+                for _ in range(rng.choice([1, 1, 2])):  # parallel edges with different head patterns: conflicts
+                    edges.append((u, v, rng.randrange(2), rng.randrange(2), rng.randrange(1, 9)))
+            gm, go, _ = ctx.order_problem(n, edges, use_gpu=True)
+            hm, ho, hv = ctx.order_problem(n, edges, use_gpu=False)
+            assert (gm, go) == (hm, ho), f"GPU kernel and host solver disagree on trial {trial}: {edges}"
+            assert _order_value(n, edges, hm, ho) == hv
+            if n <= 6:
+                bv, bm, bo = _order_brute(n, edges)
+                assert (hv, hm, ho) == (bv, bm, bo), f"trial {trial}: {edges}"
+
+
+def test_replay_concurrent_across_chromosomes_equals_the_serial_replay(built, synth, monkeypatch):
+    """the segmentation replay speculates per chromosome group and verifies; SQUID_REPLAY_SERIAL forces the plain
+    stretch-after-stretch replay.  Same seed nodes, hence the same graph, on a 25-chromosome sample."""
+    pre = synth("C3", "--records", "300000")
+
+    def run():
+        with squid_amd.Context() as ctx:
+            ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
+            ctx.build_graph()
+            return ctx.graph(1)["nodes"], ctx.graph(0), ctx.order(), ctx.sv_text()
+
+    monkeypatch.delenv("SQUID_REPLAY_SERIAL", raising=False)
+    par = run()
+    import subprocess, sys, json  # the switch is read once per process: run the serial variant in a child
+    code = ("import sys, json; sys.path.insert(0, %r); import squid_amd\n"
+            "ctx = squid_amd.Context(); ctx.load(%r, %r); ctx.build_graph()\n"
+            "print(json.dumps([ctx.graph(1)['nodes'], ctx.order(), ctx.sv_text()]))") % (str(Path(__file__).resolve().parent.parent), f"{pre}.bam", f"{pre}.chim.bam")
+    import os
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SQUID_REPLAY_SERIAL="1"), capture_output=True, text=True, check=True).stdout
+    ser = json.loads(out.strip().splitlines()[-1])
+    assert [list(n) for n in par[0]] == ser[0]
+    assert par[2] == ser[1] and par[3] == ser[2]
