@@ -19,14 +19,14 @@ ref:
 
 $(B)/libsquid_hip.so: $(LIBSRC) $(CSRC)/sq_internal.h include/squid_hip.h
 	mkdir -p $(B)
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function -o $@ $(LIBSRC) -lz -lpthread
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function -o $@ $(LIBSRC) -lz -lpthread -ldl
 
 $(B)/squid: $(CSRC)/squid_main.cpp $(B)/libsquid_hip.so include/squid_hip.h
 	$(HIPCC) -O2 -std=c++17 -o $@ $(CSRC)/squid_main.cpp -L$(B) -lsquid_hip -Wl,-rpath,'$$ORIGIN'
 
 $(B)/gen_synth_bam: squid_amd/synth/gen_synth_bam.cpp
 	mkdir -p $(B)
-	$(CXX) -O2 -std=c++17 -o $@ $< -lz -lpthread
+	$(CXX) -O2 -std=c++17 -o $@ $< -lz -lpthread -ldl
 
 $(B)/squid_oracle: oracle/squid_oracle.cpp oracle/o_bam.h oracle/o_readrec.h oracle/o_graph.h oracle/o_order.h
 	$(MAKE) -C oracle OUT=../$(B)

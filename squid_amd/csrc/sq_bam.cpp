@@ -6,6 +6,15 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <dlfcn.h>
+#include <unistd.h>
+#include <sys/stat.h>
+#include <sys/mman.h>
+#include <fcntl.h>
+#include <mutex>
+#include <future>
+#include <condition_variable>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -583,9 +592,291 @@ static int parse_bam_impl(const char* path, const ParseOpts& o, size_t batch_rec
 int parse_bam_file(const char* path, const ParseOpts& o, size_t batch_records, int n_threads, std::string& err, const std::function<int(const HostBatch&)>& sink) {
     return parse_bam_impl(path, o, batch_records, n_threads, err, sink, nullptr);
 }
-int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSink& sink) {
-    ParseOpts o{1, 0, 0, false, nullptr};
-    return parse_bam_impl(path, o, (size_t)1 << 40, n_threads, err, [](const HostBatch&) { return 0; }, &sink);
+// ---------------------------------------------------------------------------------------------- raw (K0) reader
+// File -> inflated record stream for the GPU parser, as a pipeline: the file is memory-mapped (no read copy), a pool of
+// threads inflates the next 64 MiB of BGZF blocks and finds the record boundaries in it while the previous chunk is
+// being copied to the GPU and parsed there (the sink runs on its own thread, one chunk in flight, two buffers).
+namespace {
+struct FileMap {
+    const uint8_t* p = nullptr;
+    size_t n = 0;
+    bool open(const char* path) {
+        int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0) { ::close(fd); return false; }
+        n = (size_t)st.st_size;
+        if (n) {
+            void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);  // (populate: the block index walks every page anyway, one fault at a time)
+            if (m == MAP_FAILED) { ::close(fd); return false; }
+            madvise(m, n, MADV_SEQUENTIAL);
+            p = (const uint8_t*)m;
+        }
+        ::close(fd);
+        return true;
+    }
+    ~FileMap() { if (p) munmap((void*)p, n); }
+};
+// `count` jobs on the calling thread + helpers; the helpers live as long as the pool (no spawn per chunk)
+struct Pool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv, done_cv;
+    const std::function<void(int)>* job = nullptr;
+    int job_count = 0, next = 0, running = 0, epoch = 0;
+    bool stop = false;
+    explicit Pool(int helpers) {
+        for (int i = 0; i < helpers; ++i) th.emplace_back([this]() {
+            int seen = 0;
+            std::unique_lock<std::mutex> lk(mu);
+            for (;;) {
+                cv.wait(lk, [&]() { return stop || epoch != seen; });
+                if (stop) return;
+                seen = epoch;
+                while (next < job_count) { int i = next++; ++running; lk.unlock(); (*job)(i); lk.lock(); --running; }
+                if (running == 0) done_cv.notify_all();
+            }
+        });
+    }
+    void run(int count, const std::function<void(int)>& f) {
+        std::unique_lock<std::mutex> lk(mu);
+        job = &f; job_count = count; next = 0; ++epoch;
+        cv.notify_all();
+        while (next < job_count) { int i = next++; ++running; lk.unlock(); f(i); lk.lock(); --running; }
+        done_cv.wait(lk, [&]() { return running == 0 && next >= job_count; });
+        job = nullptr;
+    }
+    ~Pool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (auto& t : th) t.join(); }
+};
+bool index_bgzf_view(const uint8_t* d, size_t n, std::vector<BgzfBlock>& blocks, size_t& total) {
+    size_t p = 0;
+    total = 0;
+    while (p + 18 <= n) {
+        if (d[p] != 0x1f || d[p + 1] != 0x8b || !(d[p + 3] & 4)) return false;
+        uint32_t xlen = d[p + 10] | (d[p + 11] << 8);
+        int bsize = -1;
+        for (size_t o = p + 12; o + 4 <= p + 12 + xlen && o + 6 <= n;) {
+            uint32_t slen = d[o + 2] | (d[o + 3] << 8);
+            if (d[o] == 'B' && d[o + 1] == 'C' && slen == 2) bsize = (d[o + 4] | (d[o + 5] << 8)) + 1;
+            o += 4 + slen;
+        }
+        if (bsize < 0 || p + bsize > n) return false;
+        BgzfBlock b;
+        b.coff = p + 12 + xlen;
+        b.clen = (uint32_t)(bsize - 12 - xlen - 8);
+        std::memcpy(&b.isize, &d[p + bsize - 4], 4);
+        b.uoff = total;
+        total += b.isize;
+        blocks.push_back(b);
+        p += bsize;
+    }
+    return p == n;
+}
+// raw-DEFLATE decoder of libdeflate (2-3x faster than zlib's inflate), bound at run time when the shared library is on
+// the system (no header needed: three functions of its stable C API); zlib otherwise
+struct FastInflate {
+    typedef void* (*alloc_fn)();
+    typedef int (*run_fn)(void*, const void*, size_t, void*, size_t, size_t*);
+    typedef void (*free_fn)(void*);
+    alloc_fn alloc = nullptr; run_fn run = nullptr; free_fn release = nullptr;
+    FastInflate() {
+        if (std::getenv("SQUID_ZLIB_ONLY")) return;
+        void* h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        alloc = (alloc_fn)dlsym(h, "libdeflate_alloc_decompressor");
+        run = (run_fn)dlsym(h, "libdeflate_deflate_decompress");
+        release = (free_fn)dlsym(h, "libdeflate_free_decompressor");
+        if (!alloc || !run || !release) { alloc = nullptr; run = nullptr; release = nullptr; }
+    }
+};
+const FastInflate& fast_inflate() { static FastInflate f; return f; }
+struct ThreadDecompressor { void* d = nullptr; ~ThreadDecompressor() { if (d) fast_inflate().release(d); } };
+bool inflate_one(const uint8_t* d, const BgzfBlock& b, uint8_t* out) {
+    if (!b.isize) return true;
+    const FastInflate& fi = fast_inflate();
+    if (fi.run) {
+        static thread_local ThreadDecompressor td;
+        if (!td.d) td.d = fi.alloc();
+        size_t got = 0;
+        if (td.d && fi.run(td.d, d + b.coff, b.clen, out, b.isize, &got) == 0 && got == b.isize) return true;
+        // (fall through: let zlib have a look before calling the block corrupt)
+    }
+    z_stream zs;
+    std::memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    zs.next_in = (Bytef*)(d + b.coff);
+    zs.avail_in = b.clen;
+    zs.next_out = out;
+    zs.avail_out = b.isize;
+    int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    return rc == Z_STREAM_END;
+}
+// record boundaries in u[begin, limit): slices find their first boundary by validating a chain of plausible record
+// headers and walk from there; the slices are stitched, and a false synchronisation (never seen) is redone serially.
+// offs are relative to `begin`; `end` = end of the last whole record.
+int find_records(const uint8_t* u, size_t begin, size_t limit, int nref, Pool& pool, int n_threads, std::vector<unsigned long long>& offs, size_t& end, std::string& err) {
+    auto plausible = [&](size_t p) -> long {
+        if (limit - p < 36) return -1;
+        const uint8_t* q = u + p;
+        int32_t bs = rd32(q);
+        if (bs < 34 || bs > (1 << 26)) return -1;
+        int32_t refid = rd32(q + 4), pos = rd32(q + 8), mrefid = rd32(q + 24), mpos = rd32(q + 28), lseq = rd32(q + 20);
+        int lname = q[12], ncig = rd16(q + 16);
+        if (refid < -1 || refid >= nref || mrefid < -1 || mrefid >= nref || pos < -1 || mpos < -1 || lseq < 0 || lname < 1) return -1;
+        size_t need_bytes = 32 + (size_t)lname + 4 * (size_t)ncig + ((size_t)lseq + 1) / 2 + (size_t)lseq;
+        if (need_bytes > (size_t)bs) return -1;
+        if (p + 4 + 32 + (size_t)lname <= limit && q[4 + 32 + lname - 1] != 0) return -1;  // QNAME is NUL terminated
+        return bs;
+    };
+    auto sync_from = [&](size_t from, size_t upto) -> size_t {
+        for (size_t p = from; p < upto; ++p) {
+            size_t q = p;
+            int ok = 0;
+            bool accept = false;
+            for (;;) {
+                long bs = plausible(q);
+                if (bs < 0) break;
+                if (q + 4 + (size_t)bs > limit) { accept = ok >= 2; break; }  // runs off the buffer: trust it only after two whole records
+                q += 4 + (size_t)bs;
+                if (++ok == 4 || q == limit) { accept = true; break; }
+            }
+            if (accept) return p;
+        }
+        return upto;
+    };
+    offs.clear();
+    end = begin;
+    const size_t avail = limit - begin;
+    if (avail < 4) return SQ_OK;
+    const int T = (int)std::min<size_t>((size_t)std::max(1, n_threads), std::max<size_t>(1, avail / ((size_t)1 << 20)));
+    std::vector<std::vector<unsigned long long>> roffs((size_t)T);
+    std::vector<size_t> s_begin((size_t)T), s_end((size_t)T);
+    std::vector<int> bad((size_t)T, 0);
+    pool.run(T, [&](int t) {
+        size_t lo = begin + avail * t / T, hi = begin + avail * (t + 1) / T;
+        size_t p = t == 0 ? begin : sync_from(lo, hi);
+        s_begin[t] = p;
+        while (p < hi) {
+            if (limit - p < 4) break;
+            int32_t bs = rd32(u + p);
+            if (bs < 32) { bad[t] = 1; break; }
+            if (limit - p < 4 + (size_t)bs) break;  // incomplete: belongs to the next chunk
+            roffs[t].push_back((unsigned long long)(p - begin));
+            p += 4 + (size_t)bs;
+        }
+        s_end[t] = p;
+    });
+    if (bad[0]) { err = "truncated record"; return SQ_E_IO; }
+    size_t good_end = s_end[0];
+    int good = 1;
+    for (int t = 1; t < T; ++t) {
+        size_t hi = begin + avail * (t + 1) / T;
+        if (s_begin[t] >= hi && roffs[t].empty() && good_end >= hi) { ++good; continue; }  // slice swallowed by a long record
+        if (s_begin[t] != good_end) break;
+        if (bad[t]) { err = "truncated record"; return SQ_E_IO; }
+        good_end = s_end[t];
+        ++good;
+    }
+    size_t total = 0;
+    for (int t = 0; t < good; ++t) total += roffs[t].size();
+    offs.reserve(total);
+    for (int t = 0; t < good; ++t) offs.insert(offs.end(), roffs[t].begin(), roffs[t].end());
+    size_t p = good_end;
+    if (good < T)
+        for (;;) {
+            if (limit - p < 4) break;
+            int32_t bs = rd32(u + p);
+            if (bs < 32) { err = "truncated record"; return SQ_E_IO; }
+            if (limit - p < 4 + (size_t)bs) break;
+            offs.push_back((unsigned long long)(p - begin));
+            p += 4 + (size_t)bs;
+        }
+    end = p;
+    return SQ_OK;
+}
+}  // namespace
+
+int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSink& sink, const std::function<void(size_t)>& on_total) {
+    using clk = std::chrono::steady_clock;
+    auto since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+    double t_map = 0, t_inflate = 0, t_find = 0, t_wait = 0;
+    const auto t_all = clk::now();
+    FileMap fm;
+    if (!fm.open(path)) { err = std::string("cannot open bamfile ") + path; return SQ_E_IO; }
+    std::vector<BgzfBlock> blocks;
+    size_t total = 0;
+    if (!index_bgzf_view(fm.p, fm.n, blocks, total)) { err = "not a BGZF file"; return SQ_E_IO; }
+    t_map = since(t_all);
+    if (on_total) on_total(total);  // inflated size of the whole file: lets the sink size its arrays once
+    n_threads = std::min(std::max(1, n_threads), 64);  // more helpers than that only cost their start-up
+    Pool pool(n_threads - 1);
+    const size_t kChunkBlocks = 1024;  // <= 64 MiB inflated per round (two such buffers; small enough to stay cheap to fault in and to free)
+    RawBuf buf[2];
+    std::vector<unsigned long long> offs[2];
+    std::future<int> inflight;
+    size_t nb = 0, carry = 0;
+    const uint8_t* carry_src = nullptr;
+    int cur = 0, nref = -1;
+    bool header_done = false;
+    int rc = SQ_OK;
+    while (nb < blocks.size()) {
+        const size_t b1 = std::min(blocks.size(), nb + kChunkBlocks);
+        const size_t base = blocks[nb].uoff, bytes = (b1 == blocks.size() ? total : blocks[b1].uoff) - base;
+        RawBuf& u = buf[cur];
+        u.resize(carry + bytes + 64);
+        if (carry) std::memcpy(u.data(), carry_src, carry);  // (the buffer it comes from is only being read by the sink)
+        auto ti0 = clk::now();
+        std::atomic<bool> ok{true};
+        const size_t first = nb;
+        uint8_t* out = u.data() + carry;
+        pool.run((int)(b1 - nb), [&](int i) { const BgzfBlock& b = blocks[first + (size_t)i]; if (!inflate_one(fm.p, b, out + (b.uoff - base))) ok = false; });
+        t_inflate += since(ti0);
+        if (!ok) { err = "corrupt BGZF block"; rc = SQ_E_IO; break; }
+        nb = b1;
+        const size_t limit = carry + bytes;
+        size_t begin = 0;
+        if (!header_done) {
+            // BAM header: magic, text, reference dictionary (everything the caller needs from it came through sq_read_header)
+            auto need = [&](size_t n) { return limit >= n; };
+            if (!need(12) || std::memcmp(u.data(), "BAM\1", 4) != 0) { err = "not a BAM file"; rc = SQ_E_IO; break; }
+            const int32_t ltext = rd32(u.data() + 4);
+            if (!need(12 + (size_t)ltext)) { if (nb < blocks.size()) { carry = limit; carry_src = u.data(); cur ^= 1; continue; } err = "truncated header"; rc = SQ_E_IO; break; }
+            nref = rd32(u.data() + 8 + ltext);
+            size_t p = 12 + (size_t)ltext;
+            bool complete = true;
+            for (int i = 0; i < nref; ++i) {
+                if (!need(p + 4)) { complete = false; break; }
+                const int32_t ln = rd32(u.data() + p);
+                if (!need(p + 8 + (size_t)ln)) { complete = false; break; }
+                p += 8 + (size_t)ln;
+            }
+            if (!complete) { if (nb < blocks.size()) { carry = limit; carry_src = u.data(); cur ^= 1; continue; } err = "truncated header"; rc = SQ_E_IO; break; }
+            header_done = true;
+            begin = p;
+        }
+        auto tf0 = clk::now();
+        size_t end = begin;
+        rc = find_records(u.data(), begin, limit, nref, pool, n_threads, offs[cur], end, err);
+        t_find += since(tf0);
+        if (rc) break;
+        auto tw0 = clk::now();
+        if (inflight.valid()) { rc = inflight.get(); if (rc) break; }
+        t_wait += since(tw0);
+        if (!offs[cur].empty()) {
+            const uint8_t* data = u.data() + begin;
+            const size_t nbytes = end - begin;
+            const std::vector<unsigned long long>* o = &offs[cur];
+            inflight = std::async(std::launch::async, [&sink, data, nbytes, o]() { return sink(data, nbytes, o->data(), (int64_t)o->size()); });
+        }
+        carry = limit - end;
+        carry_src = u.data() + end;
+        cur ^= 1;
+    }
+    if (inflight.valid()) { auto tw0 = clk::now(); int r2 = inflight.get(); t_wait += since(tw0); if (!rc) rc = r2; }
+    if (std::getenv("SQUID_INGEST_TIMING"))
+        std::fprintf(stderr, "ingest %s: map+index %.1f inflate %.1f boundaries %.1f waiting for the GPU sink %.1f total %.1f ms (%d threads)\n", path, t_map, t_inflate, t_find, t_wait, since(t_all), n_threads);
+    return rc;
 }
 
 }  // namespace sq

@@ -790,7 +790,10 @@ int sq_ingest_concordant_file(sq_ctx* c, const char* path, int32_t n_threads) {
     if (!c || !path) return SQ_E_ARG;
     if (!std::getenv("SQUID_HOST_PARSE")) {
         // default: the host only inflates BGZF and finds record boundaries; K0 parses the records on the GPU
-        int rc = scan_bam_file(path, n_threads, c->err, [&](const uint8_t* bam, size_t nbytes, const unsigned long long* off, int64_t n) { return ingest_raw(c, bam, nbytes, off, n); });
+        c->ingest_total_bytes = 0; c->ingest_seen_bytes = 0;
+        int rc = scan_bam_file(path, n_threads, c->err, [&](const uint8_t* bam, size_t nbytes, const unsigned long long* off, int64_t n) { c->ingest_seen_bytes += nbytes; return ingest_raw(c, bam, nbytes, off, n); },
+                               [&](size_t total) { c->ingest_total_bytes = c->shard.on ? 0 : total; });
+        c->ingest_total_bytes = 0;
         dev_flush_timers(c);
         return rc;
     }

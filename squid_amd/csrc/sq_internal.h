@@ -137,6 +137,7 @@ struct sq_ctx {
     sq_counts counts{};
     // chromosome-sharded runs: sq_build_graph / sq_call_sv return SQ_NEED_EXCHANGE with `xbuf` filled; the caller
     // all-gathers it and hands the result back through sq_exchange_unpack before calling the same function again
+    size_t ingest_total_bytes = 0, ingest_seen_bytes = 0;  // file ingest in progress: inflated bytes in the file / handed to the GPU so far
     sq::Shard shard;
     // ExactBreakpoint (host, chimeric fragments only) runs on a second thread from the end of sq_build_graph, next to
     // sq_order; sq_call_sv collects it
@@ -172,7 +173,8 @@ struct ParseOpts { int phred_type, min_phred, max_lowphred_len; bool keep_names;
 int parse_bam_file(const char* path, const ParseOpts& o, size_t batch_records, int n_threads, std::string& err,
                    const std::function<int(const HostBatch&)>& sink);
 // raw mode: inflate + record-boundary walk on the host, hand each chunk (bytes, record offsets) to `sink`
-int scan_bam_file(const char* path, int n_threads, std::string& err, const std::function<int(const uint8_t*, size_t, const unsigned long long*, int64_t)>& sink);
+int scan_bam_file(const char* path, int n_threads, std::string& err, const std::function<int(const uint8_t*, size_t, const unsigned long long*, int64_t)>& sink,
+                  const std::function<void(size_t)>& on_total = nullptr);
 
 // ---- sq_chimeric.cpp
 int build_fragments(sq_ctx* c, const sq_aln_batch* b);

@@ -1655,6 +1655,7 @@ int dev_upload_chim_names(sq_ctx* c) {
 // K0: parse `n_rec` BAM records of an inflated chunk on the device and append them to the resident SoA
 int dev_parse_append(sq_ctx* c, const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n_rec) {
     if (n_rec == 0) return SQ_OK;
+    HIPCHK(hipSetDevice(c->P.device));  // the file reader calls this from its sink thread (the current device is per thread)
     DeviceRecords& D = *c->dev;
     hipStream_t s = c->stream;
     const size_t n0 = (size_t)D.n, nb0 = (size_t)D.nb, n1 = n0 + (size_t)n_rec;
@@ -1671,11 +1672,19 @@ int dev_parse_append(sq_ctx* c, const uint8_t* bam, size_t nbytes, const unsigne
     HIPCHK(hipStreamSynchronize(s));
     const size_t nb1 = nb0 + (size_t)nblk_total;
     if (nb1 >= 0xffffffffull) return fail(c, SQ_E_CAPACITY, "more than 2^32 aligned blocks");
+    // a file ingest tells how much is still to come: size the arrays for all of it at the first growth instead of
+    // reallocating (and copying) them chunk after chunk
+    size_t rec_want = n1, blk_want = nb1 + 1;
+    if (c->ingest_total_bytes && c->ingest_seen_bytes) {
+        const double scale = 1.02 * (double)c->ingest_total_bytes / (double)c->ingest_seen_bytes;
+        rec_want = std::max(rec_want, (size_t)((double)n1 * scale) + 1024);
+        blk_want = std::max(blk_want, (size_t)((double)(nb1 + 1) * scale) + 1024);
+    }
 #define GROW(buf, used, want) HIPCHK(D.buf.grow_keep(used, want, s))
-    GROW(refid, n0, n1); GROW(pos, n0, n1); GROW(mrefid, n0, n1); GROW(mpos, n0, n1); GROW(endpos, n0, n1);
-    GROW(flag, n0, n1); GROW(totlen, n0, n1); GROW(mapq, n0, n1); GROW(aux, n0, n1);
-    GROW(blk_off, n0 ? n0 + 1 : 0, n1 + 1);
-    GROW(b_refpos, nb0, nb1 + 1); GROW(b_matchref, nb0, nb1 + 1); GROW(b_readpos, nb0, nb1 + 1); GROW(b_matchread, nb0, nb1 + 1);
+    if (D.refid.cap < n1) { GROW(refid, n0, rec_want); GROW(pos, n0, rec_want); GROW(mrefid, n0, rec_want); GROW(mpos, n0, rec_want); GROW(endpos, n0, rec_want);
+                            GROW(flag, n0, rec_want); GROW(totlen, n0, rec_want); GROW(mapq, n0, rec_want); GROW(aux, n0, rec_want); }
+    if (D.blk_off.cap < n1 + 1) GROW(blk_off, n0 ? n0 + 1 : 0, rec_want + 1);
+    if (D.b_refpos.cap < nb1 + 1) { GROW(b_refpos, nb0, blk_want); GROW(b_matchref, nb0, blk_want); GROW(b_readpos, nb0, blk_want); GROW(b_matchread, nb0, blk_want); }
 #undef GROW
     ChimSetView C{D.chim_mask, D.chim_mask ? D.chim_hash.p : nullptr, D.chim_off.p, D.chim_len.p, D.chim_blob.p};
     ParseParams P{(int)(signed char)(((c->P.phred_type ? 33 : 64) + c->P.min_phred) & 0xff), c->P.max_lowphred_len, c->P.min_mapqual};
