@@ -715,7 +715,8 @@ bool inflate_one(const uint8_t* d, const BgzfBlock& b, uint8_t* out) {
 // record boundaries in u[begin, limit): slices find their first boundary by validating a chain of plausible record
 // headers and walk from there; the slices are stitched, and a false synchronisation (never seen) is redone serially.
 // offs are relative to `begin`; `end` = end of the last whole record.
-int find_records(const uint8_t* u, size_t begin, size_t limit, int nref, Pool& pool, int n_threads, std::vector<unsigned long long>& offs, size_t& end, std::string& err) {
+int find_records(const uint8_t* u, size_t begin, size_t limit, int nref, Pool& pool, int n_threads, std::vector<unsigned long long>& offs, size_t& end, std::string& err,
+                 bool begin_unsynced = false, size_t* first_record = nullptr) {
     auto plausible = [&](size_t p) -> long {
         if (limit - p < 36) return -1;
         const uint8_t* q = u + p;
@@ -755,7 +756,7 @@ int find_records(const uint8_t* u, size_t begin, size_t limit, int nref, Pool& p
     std::vector<int> bad((size_t)T, 0);
     pool.run(T, [&](int t) {
         size_t lo = begin + avail * t / T, hi = begin + avail * (t + 1) / T;
-        size_t p = t == 0 ? begin : sync_from(lo, hi);
+        size_t p = (t == 0 && !begin_unsynced) ? begin : sync_from(lo, hi);
         s_begin[t] = p;
         while (p < hi) {
             if (limit - p < 4) break;
@@ -768,6 +769,7 @@ int find_records(const uint8_t* u, size_t begin, size_t limit, int nref, Pool& p
         s_end[t] = p;
     });
     if (bad[0]) { err = "truncated record"; return SQ_E_IO; }
+    if (first_record) *first_record = s_begin[0];
     size_t good_end = s_end[0];
     int good = 1;
     for (int t = 1; t < T; ++t) {
@@ -797,7 +799,7 @@ int find_records(const uint8_t* u, size_t begin, size_t limit, int nref, Pool& p
 }
 }  // namespace
 
-int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSink& sink, const std::function<void(size_t)>& on_total) {
+int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSink& sink, const std::function<void(size_t)>& on_total, const RefRange* only) {
     using clk = std::chrono::steady_clock;
     auto since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
     double t_map = 0, t_inflate = 0, t_find = 0, t_wait = 0;
@@ -811,17 +813,66 @@ int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSi
     if (on_total) on_total(total);  // inflated size of the whole file: lets the sink size its arrays once
     n_threads = std::min(std::max(1, n_threads), 64);  // more helpers than that only cost their start-up
     Pool pool(n_threads - 1);
+    size_t only_begin = 0;
     const size_t kChunkBlocks = 1024;  // <= 64 MiB inflated per round (two such buffers; small enough to stay cheap to fault in and to free)
     RawBuf buf[2];
     std::vector<unsigned long long> offs[2];
     std::future<int> inflight;
-    size_t nb = 0, carry = 0;
+    size_t nb = 0, carry = 0, nb_end = blocks.size();
     const uint8_t* carry_src = nullptr;
     int cur = 0, nref = -1;
-    bool header_done = false;
+    bool header_done = false, unsynced = false;
     int rc = SQ_OK;
-    while (nb < blocks.size()) {
-        const size_t b1 = std::min(blocks.size(), nb + kChunkBlocks);
+    if (only) {
+        // A chromosome shard only inflates the blocks that can hold its records.  f(b) = RefID of the first record that
+        // starts at or behind block b (found by the same plausible-chain search that the slices use) is monotone in a
+        // coordinate-sorted file, unplaced records (-1) counting as behind every reference: two binary searches.
+        std::vector<uint8_t> hdr;  // the header first: the number of references is part of the plausibility test
+        size_t hb = 0;
+        auto hneed = [&](size_t n) { while (hdr.size() < n && hb < blocks.size()) { size_t o = hdr.size(); hdr.resize(o + blocks[hb].isize); if (!inflate_one(fm.p, blocks[hb], hdr.data() + o)) return false; ++hb; } return hdr.size() >= n; };
+        if (!hneed(12) || std::memcmp(hdr.data(), "BAM\1", 4) != 0) { err = "not a BAM file"; return SQ_E_IO; }
+        const int32_t ltext = rd32(hdr.data() + 4);
+        if (!hneed(12 + (size_t)ltext)) { err = "truncated header"; return SQ_E_IO; }
+        nref = rd32(hdr.data() + 8 + ltext);
+        size_t hp = 12 + (size_t)ltext;
+        for (int i = 0; i < nref; ++i) { if (!hneed(hp + 4)) { err = "truncated header"; return SQ_E_IO; } int32_t ln = rd32(hdr.data() + hp); if (!hneed(hp + 8 + (size_t)ln)) { err = "truncated header"; return SQ_E_IO; } hp += 8 + (size_t)ln; }
+        const size_t first_rec_block = (size_t)(std::upper_bound(blocks.begin(), blocks.end(), hp, [](size_t v, const BgzfBlock& b) { return v < b.uoff; }) - blocks.begin()) - 1;
+        std::vector<uint8_t> tmp;
+        std::vector<unsigned long long> toffs;
+        auto first_ref_from = [&](size_t b) -> int {  // nref when no record starts at or behind block b
+            for (size_t span = 4;; span *= 2) {
+                const size_t e = std::min(blocks.size(), b + span);
+                const size_t base = blocks[b].uoff, bytes = (e == blocks.size() ? total : blocks[e].uoff) - base;
+                tmp.resize(bytes + 64);
+                for (size_t i = b; i < e; ++i) if (!inflate_one(fm.p, blocks[i], tmp.data() + (blocks[i].uoff - base))) return -2;
+                size_t endp = 0, first = bytes;
+                const size_t begin = b == first_rec_block ? hp - base : 0;
+                Pool one(0);
+                std::string e2;
+                if (find_records(tmp.data(), begin, bytes, nref, one, 1, toffs, endp, e2, b != first_rec_block, &first)) return -2;
+                if (!toffs.empty()) { int32_t r = rd32(tmp.data() + begin + toffs[0] + 4); return r < 0 ? nref : r; }
+                if (e == blocks.size()) return nref;
+            }
+        };
+        auto lower = [&](int ref) -> size_t {  // first block b in [first_rec_block, nblocks] with f(b) >= ref
+            size_t lo = first_rec_block, hi = blocks.size();
+            while (lo < hi) { size_t mid = (lo + hi) / 2; int f = first_ref_from(mid); if (f == -2) return (size_t)-1; if (f >= ref) hi = mid; else lo = mid + 1; }
+            return lo;
+        };
+        const size_t bl = lower(only->first_ref), bh = only->with_unplaced ? blocks.size() : lower(only->end_ref);
+        if (bl == (size_t)-1 || bh == (size_t)-1) { err = "corrupt BGZF block"; return SQ_E_IO; }
+        nb = bl > first_rec_block ? bl - 1 : first_rec_block;   // records of the range may start in the block before
+        nb_end = std::min(blocks.size(), bh + 2);                // the last owned record may run into the next blocks
+        header_done = true;
+        unsynced = nb != first_rec_block;
+        if (nb == first_rec_block) { carry = 0; }  // the first chunk then starts inside the header block: skip to the first record below
+        if (nb >= nb_end) return SQ_OK;
+        if (!unsynced) {  // start exactly at the first record: emulate by a carry-less chunk whose begin is the header end
+            only_begin = hp - blocks[nb].uoff;
+        }
+    }
+    while (nb < nb_end) {
+        const size_t b1 = std::min(nb_end, nb + kChunkBlocks);
         const size_t base = blocks[nb].uoff, bytes = (b1 == blocks.size() ? total : blocks[b1].uoff) - base;
         RawBuf& u = buf[cur];
         u.resize(carry + bytes + 64);
@@ -841,7 +892,7 @@ int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSi
             auto need = [&](size_t n) { return limit >= n; };
             if (!need(12) || std::memcmp(u.data(), "BAM\1", 4) != 0) { err = "not a BAM file"; rc = SQ_E_IO; break; }
             const int32_t ltext = rd32(u.data() + 4);
-            if (!need(12 + (size_t)ltext)) { if (nb < blocks.size()) { carry = limit; carry_src = u.data(); cur ^= 1; continue; } err = "truncated header"; rc = SQ_E_IO; break; }
+            if (!need(12 + (size_t)ltext)) { if (nb < nb_end) { carry = limit; carry_src = u.data(); cur ^= 1; continue; } err = "truncated header"; rc = SQ_E_IO; break; }
             nref = rd32(u.data() + 8 + ltext);
             size_t p = 12 + (size_t)ltext;
             bool complete = true;
@@ -851,13 +902,15 @@ int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSi
                 if (!need(p + 8 + (size_t)ln)) { complete = false; break; }
                 p += 8 + (size_t)ln;
             }
-            if (!complete) { if (nb < blocks.size()) { carry = limit; carry_src = u.data(); cur ^= 1; continue; } err = "truncated header"; rc = SQ_E_IO; break; }
+            if (!complete) { if (nb < nb_end) { carry = limit; carry_src = u.data(); cur ^= 1; continue; } err = "truncated header"; rc = SQ_E_IO; break; }
             header_done = true;
             begin = p;
         }
+        if (only_begin) { begin = only_begin; only_begin = 0; }
         auto tf0 = clk::now();
         size_t end = begin;
-        rc = find_records(u.data(), begin, limit, nref, pool, n_threads, offs[cur], end, err);
+        rc = find_records(u.data(), begin, limit, nref, pool, n_threads, offs[cur], end, err, unsynced);
+        unsynced = false;
         t_find += since(tf0);
         if (rc) break;
         auto tw0 = clk::now();

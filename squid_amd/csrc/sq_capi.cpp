@@ -791,8 +791,9 @@ int sq_ingest_concordant_file(sq_ctx* c, const char* path, int32_t n_threads) {
     if (!std::getenv("SQUID_HOST_PARSE")) {
         // default: the host only inflates BGZF and finds record boundaries; K0 parses the records on the GPU
         c->ingest_total_bytes = 0; c->ingest_seen_bytes = 0;
+        const RefRange rr{c->shard.first_ref, c->shard.end_ref, c->P.rank == c->P.world_size - 1};
         int rc = scan_bam_file(path, n_threads, c->err, [&](const uint8_t* bam, size_t nbytes, const unsigned long long* off, int64_t n) { c->ingest_seen_bytes += nbytes; return ingest_raw(c, bam, nbytes, off, n); },
-                               [&](size_t total) { c->ingest_total_bytes = c->shard.on ? 0 : total; });
+                               [&](size_t total) { c->ingest_total_bytes = c->shard.on ? 0 : total; }, c->shard.on ? &rr : nullptr);
         c->ingest_total_bytes = 0;
         dev_flush_timers(c);
         return rc;

@@ -173,8 +173,9 @@ struct ParseOpts { int phred_type, min_phred, max_lowphred_len; bool keep_names;
 int parse_bam_file(const char* path, const ParseOpts& o, size_t batch_records, int n_threads, std::string& err,
                    const std::function<int(const HostBatch&)>& sink);
 // raw mode: inflate + record-boundary walk on the host, hand each chunk (bytes, record offsets) to `sink`
+struct RefRange { int first_ref, end_ref; bool with_unplaced; };  // chromosome shard: only the blocks that can hold its records are inflated
 int scan_bam_file(const char* path, int n_threads, std::string& err, const std::function<int(const uint8_t*, size_t, const unsigned long long*, int64_t)>& sink,
-                  const std::function<void(size_t)>& on_total = nullptr);
+                  const std::function<void(size_t)>& on_total = nullptr, const RefRange* only = nullptr);
 
 // ---- sq_chimeric.cpp
 int build_fragments(sq_ctx* c, const sq_aln_batch* b);
