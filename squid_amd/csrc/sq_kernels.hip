@@ -157,6 +157,7 @@ struct DeviceRecords {
     std::vector<Pending> ev_pending;
     size_t ev_used = 0;
     int64_t k1 = 0;  // kept pass-1 records
+    int cl_n = 0;    // clusters in the packed table cl_chr
     RecView view() const {
         RecView v;
         v.n = n; v.nb = nb;
@@ -891,12 +892,12 @@ __global__ void k_depth(RecView R, NodeView N, const uint8_t* keep, const int32_
     for (int d = 32; d >= 1; d >>= 1) no += __shfl_xor(no, d, 64);
     if ((threadIdx.x & 63) == 0 && no) stripe_add(stripes, no);
 }
-__global__ void k_fold_stripes(int nn, int32_t* a, int32_t* b, int32_t* c2, int32_t* d) {
+__global__ void k_fold_stripes(int nn, const int32_t* a, const int32_t* b, const int32_t* c2, const int32_t* d, int32_t* out /* 4 x nn */) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nn) return;
     int sa = 0, sb = 0, sc = 0, sd = 0;
     for (int s = 0; s < NODE_STRIPES; ++s) { const size_t o = (size_t)s * nn + i; sa += a[o]; sb += b[o]; sc += c2[o]; sd += d[o]; }
-    a[i] = sa; b[i] = sb; c2[i] = sc; d[i] = sd;
+    out[i] = sa; out[(size_t)nn + i] = sb; out[2 * (size_t)nn + i] = sc; out[3 * (size_t)nn + i] = sd;
 }
 // number of non-first blocks of a consumed kept record (|ReadsOther| contributions), for the ordered gather
 struct FOtherCount {
@@ -1737,16 +1738,18 @@ int dev_upload_nodes(sq_ctx* c, const std::vector<Node>& nodes) {
         bo[k + 1] = bo[k] + (int32_t)(((int64_t)std::max(c->ref_len[k], 1) + (1 << NODE_BUCKET_SHIFT) - 1) >> NODE_BUCKET_SHIFT);
     }
     const int total = bo[nref];
-    HIPCHK(D.n_chr.reserve(n)); HIPCHK(D.n_pos.reserve(n)); HIPCHK(D.n_len.reserve(n)); HIPCHK(D.n_chr_start.reserve(nref + 1));
-    HIPCHK(D.n_bucket.reserve(std::max(total, 1))); HIPCHK(D.n_bucket_off.reserve(nref + 1));
-    HIPCHK(hipMemcpyAsync(D.n_chr.p, chr.data(), n * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(D.n_pos.p, pos.data(), n * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(D.n_len.p, len.data(), n * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(D.n_chr_start.p, cs.data(), (nref + 1) * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(D.n_bucket_off.p, bo.data(), (nref + 1) * 4, hipMemcpyHostToDevice, s));
+    // one packed upload: chr | pos | len | chr_start | bucket_off
+    const size_t words = 3 * (size_t)n + 2 * ((size_t)nref + 1);
+    HIPCHK(D.n_chr.reserve(words)); HIPCHK(D.n_bucket.reserve(std::max(total, 1)));
+    D.pin.reset();
+    int32_t* h = D.pin.take_n<int32_t>(words);
+    if (!h) return fail(c, SQ_E_HIP, "hipHostMalloc failed");
+    std::memcpy(h, chr.data(), (size_t)n * 4); std::memcpy(h + n, pos.data(), (size_t)n * 4); std::memcpy(h + 2 * (size_t)n, len.data(), (size_t)n * 4);
+    std::memcpy(h + 3 * (size_t)n, cs.data(), ((size_t)nref + 1) * 4); std::memcpy(h + 3 * (size_t)n + nref + 1, bo.data(), ((size_t)nref + 1) * 4);
+    HIPCHK(hipMemcpyAsync(D.n_chr.p, h, words * 4, hipMemcpyHostToDevice, s));
     NodeView& nv = D.nv;
-    nv.n = n; nv.n_ref = nref; nv.chr = D.n_chr.p; nv.pos = D.n_pos.p; nv.len = D.n_len.p; nv.chr_start = D.n_chr_start.p;
-    nv.bucket = D.n_bucket.p; nv.bucket_off = D.n_bucket_off.p;
+    nv.n = n; nv.n_ref = nref; nv.chr = D.n_chr.p; nv.pos = D.n_chr.p + n; nv.len = D.n_chr.p + 2 * (size_t)n; nv.chr_start = D.n_chr.p + 3 * (size_t)n;
+    nv.bucket = D.n_bucket.p; nv.bucket_off = D.n_chr.p + 3 * (size_t)n + nref + 1;
     if (total) { EvTimer t(c, "k_node_buckets", 4.0 * total); hipLaunchKernelGGL(k_node_buckets, dim3((total + 255) / 256), dim3(256), 0, s, nv, total, D.n_bucket.p); }
     HIPCHK(hipStreamSynchronize(s));  // the host vectors go out of scope
     return SQ_OK;
@@ -1823,12 +1826,14 @@ int dev_stream_scan(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::ve
     out.trigger.assign(ncl, (int32_t)k);
     other_max = INT64_MIN;
     if (k == 0) return SQ_OK;
-    HIPCHK(D.cl_chr.reserve(std::max(ncl, 1))); HIPCHK(D.cl_start.reserve(std::max(ncl, 1))); HIPCHK(D.cl_right.reserve(std::max(ncl, 1))); HIPCHK(D.trig.reserve(std::max(ncl, 1)));
-    if (ncl) {
-        HIPCHK(hipMemcpyAsync(D.cl_chr.p, cl_chr.data(), ncl * 4, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(D.cl_start.p, cl_start.data(), ncl * 4, hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(D.cl_right.p, cl_right.data(), ncl * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(D.cl_chr.reserve(3 * (size_t)std::max(ncl, 1))); HIPCHK(D.trig.reserve(std::max(ncl, 1)));
+    if (ncl) {  // one packed upload: chr | start | right
+        std::vector<int32_t> pack(3 * (size_t)ncl);
+        std::copy(cl_chr.begin(), cl_chr.end(), pack.begin()); std::copy(cl_start.begin(), cl_start.end(), pack.begin() + ncl); std::copy(cl_right.begin(), cl_right.end(), pack.begin() + 2 * (size_t)ncl);
+        HIPCHK(hipMemcpy(D.cl_chr.p, pack.data(), pack.size() * 4, hipMemcpyHostToDevice));
     }
-    ClusterView C{ncl, D.cl_chr.p, D.cl_start.p, D.cl_right.p};
+    D.cl_n = ncl;
+    ClusterView C{ncl, D.cl_chr.p, D.cl_chr.p + ncl, D.cl_chr.p + 2 * (size_t)ncl};
     HIPCHK(D.other64.reserve(k + 1)); HIPCHK(D.zflag.reserve(k + 1)); HIPCHK(D.scratch_a.reserve(k + 1));
     { EvTimer t(c, "k_stream_scan", 24.0 * k);
       HIPCHK((device_scan<OpMax64, true>(s, k, FKey64{D.okey64.p}, D.other64.p, D.spine64, D.other64.p + k)));  // aggregate behind the last element
@@ -1861,7 +1866,7 @@ int dev_segment_support(sq_ctx* c, int ncl, int64_t n_rest, SegSupport& out) {
         HIPCHK(hipMemcpyAsync(D.srec.p + k_own, &t, sizeof t, hipMemcpyHostToDevice, s));
     }
     const long long seed = sh.on ? sh.other_seed : INT64_MIN;
-    ClusterView C{ncl, D.cl_chr.p, D.cl_start.p, D.cl_right.p};
+    ClusterView C{ncl, D.cl_chr.p, D.cl_chr.p + ncl, D.cl_chr.p + 2 * (size_t)ncl};
     HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
     int32_t* tot = D.flags.p + 8;
     // everything is queued without knowing the counts (the compaction targets are sized for the worst case), then one
@@ -1983,14 +1988,17 @@ int dev_node_depth(sq_ctx* c, const std::vector<Node>& nodes, int64_t n_break, s
     const int nn = (int)nodes.size();
     if (D.nv.n != nn) return fail(c, SQ_E_ARG, "internal: dev_upload_nodes first");
     const NodeView nv = D.nv;
+    // one accumulator block: [main cnt | main sum | other cnt | other sum | amb+ | amb-] (the copies of the first four sit
+    // behind it), one memset; counters: flags[0..7] and the stripes right behind them, one memset
     const size_t nst = (size_t)nn * NODE_STRIPES;
-    HIPCHK(D.acc_a.reserve(nst)); HIPCHK(D.acc_b.reserve(nst)); HIPCHK(D.acc_c.reserve(nst)); HIPCHK(D.acc_d.reserve(nst)); HIPCHK(D.acc_e.reserve(nn)); HIPCHK(D.acc_f.reserve(nn));
+    HIPCHK(D.acc_a.reserve(6 * (size_t)nn + 4 * nst));
     HIPCHK(D.scratch_a.reserve(std::max<int64_t>(n, 1)));
-    HIPCHK(hipMemsetAsync(D.acc_a.p, 0, nst * 4, s)); HIPCHK(hipMemsetAsync(D.acc_b.p, 0, nst * 4, s)); HIPCHK(hipMemsetAsync(D.acc_c.p, 0, nst * 4, s)); HIPCHK(hipMemsetAsync(D.acc_d.p, 0, nst * 4, s));
-    HIPCHK(hipMemsetAsync(D.acc_e.p, 0, nn * 4, s)); HIPCHK(hipMemsetAsync(D.acc_f.p, 0, nn * 4, s));
-    HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
-    HIPCHK(D.stripes.reserve(NSTRIPE));
-    HIPCHK(hipMemsetAsync(D.stripes.p, 0, NSTRIPE * 4, s));
+    int32_t* acc = D.acc_a.p;
+    int32_t *a_mc = acc + 6 * (size_t)nn, *a_ms = a_mc + nst, *a_oc = a_ms + nst, *a_os = a_oc + nst, *a_ap = acc + 4 * (size_t)nn, *a_am = acc + 5 * (size_t)nn;
+    HIPCHK(hipMemsetAsync(acc, 0, (6 * (size_t)nn + 4 * nst) * 4, s));
+    HIPCHK(D.flags.reserve(64 + NSTRIPE));
+    int32_t* stripes = D.flags.p + 64;
+    HIPCHK(hipMemsetAsync(D.flags.p, 0, (64 + NSTRIPE) * 4, s));
     RecView R = D.view();
     const int32_t nbk = (int32_t)std::min<int64_t>(n_break, INT32_MAX);
     if (n > 0) {
@@ -1999,18 +2007,16 @@ int dev_node_depth(sq_ctx* c, const std::vector<Node>& nodes, int64_t n_break, s
           hipLaunchKernelGGL(k_early, grid_for(n, 256), dim3(256), 0, s, n, FEarlyMain{R, nv, D.keep.p, D.rank1.p, nbk}, D.b0_home.p);
           HIPCHK((device_scan<OpMax, false>(s, n, FArr{D.b0_home.p}, D.scratch_a.p, D.spine, nullptr))); }
         { EvTimer t(c, "k_depth", 13.0 * n + 8.0 * D.nb);
-          hipLaunchKernelGGL(k_depth, grid_for(n, 256), dim3(256), 0, s, R, nv, D.keep.p, D.rank1.p, nbk, D.scratch_a.p, D.acc_a.p, D.acc_b.p, D.acc_c.p, D.acc_d.p, D.acc_e.p, D.acc_f.p, D.flags.p, D.stripes.p);
-          if (nn) hipLaunchKernelGGL(k_fold_stripes, dim3((nn + 255) / 256), dim3(256), 0, s, nn, D.acc_a.p, D.acc_b.p, D.acc_c.p, D.acc_d.p); }
+          hipLaunchKernelGGL(k_depth, grid_for(n, 256), dim3(256), 0, s, R, nv, D.keep.p, D.rank1.p, nbk, D.scratch_a.p, a_mc, a_ms, a_oc, a_os, a_ap, a_am, D.flags.p, stripes);
+          if (nn) hipLaunchKernelGGL(k_fold_stripes, dim3((nn + 255) / 256), dim3(256), 0, s, nn, a_mc, a_ms, a_oc, a_os, acc); }
     }
     D.pin.reset();
     int32_t* h = D.pin.take_n<int32_t>(6 * (size_t)nn + 8 + NSTRIPE);
     if (!h) return fail(c, SQ_E_HIP, "hipHostMalloc failed");
     int32_t *mc = h, *ms = h + nn, *oc = h + 2 * nn, *os = h + 3 * nn, *ap = h + 4 * nn, *am = h + 5 * nn, *hf = h + 6 * nn, *hs = hf + 8;
-    HIPCHK(hipMemcpyAsync(mc, D.acc_a.p, nn * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(ms, D.acc_b.p, nn * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(oc, D.acc_c.p, nn * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(os, D.acc_d.p, nn * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(ap, D.acc_e.p, nn * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(am, D.acc_f.p, nn * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(hf, D.flags.p, 16, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(hs, D.stripes.p, NSTRIPE * 4, hipMemcpyDeviceToHost, s));
+    if (nn) HIPCHK(hipMemcpyAsync(h, acc, 6 * (size_t)nn * 4, hipMemcpyDeviceToHost, s));  // folded sums + the two bound arrays
+    HIPCHK(hipMemcpyAsync(hf, D.flags.p, 8 * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hs, stripes, NSTRIPE * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (hf[0] & 1) return fail(c, SQ_E_UNSORTED, "concordant stream is not coordinate sorted (depth cursor left its chromosome)");
     need_exact_other = hf[0] & 2;
@@ -2093,15 +2099,16 @@ int dev_connected_components(sq_ctx* c, int n_nodes, const std::vector<Edge>& ed
     const int m = (int)edges.size();
     label.assign(n_nodes, 0);
     if (n_nodes == 0) return SQ_OK;
-    std::vector<int32_t> ea(m), eb(m);
-    for (int i = 0; i < m; ++i) { ea[i] = edges[i].a; eb[i] = edges[i].b; }
-    HIPCHK(D.scratch_a.reserve(n_nodes)); HIPCHK(D.scratch_b.reserve(n_nodes)); HIPCHK(D.scratch_c.reserve(n_nodes)); HIPCHK(D.acc_a.reserve(std::max(m, 1))); HIPCHK(D.acc_b.reserve(std::max(m, 1)));
+    std::vector<int32_t> eab(2 * (size_t)m);
+    for (int i = 0; i < m; ++i) { eab[i] = edges[i].a; eab[(size_t)m + i] = edges[i].b; }
+    HIPCHK(D.scratch_a.reserve(n_nodes)); HIPCHK(D.scratch_b.reserve(n_nodes)); HIPCHK(D.scratch_c.reserve(n_nodes)); HIPCHK(D.acc_b.reserve(2 * (size_t)std::max(m, 1)));
     HIPCHK(D.acc_c.reserve(n_nodes));
-    if (m) { HIPCHK(hipMemcpyAsync(D.acc_a.p, ea.data(), m * 4, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(D.acc_b.p, eb.data(), m * 4, hipMemcpyHostToDevice, s)); }
+    if (m) HIPCHK(hipMemcpy(D.acc_b.p, eab.data(), eab.size() * 4, hipMemcpyHostToDevice));
+    int32_t *d_ea = D.acc_b.p, *d_eb = D.acc_b.p + m;
     {
         EvTimer t(c, "k_cc", 8.0 * m + 16.0 * n_nodes);
         hipLaunchKernelGGL(k_cc_init, grid_for(n_nodes, 256), dim3(256), 0, s, n_nodes, D.scratch_a.p);
-        if (m) hipLaunchKernelGGL(k_cc_union, grid_for(m, 256), dim3(256), 0, s, m, D.acc_a.p, D.acc_b.p, D.scratch_a.p);
+        if (m) hipLaunchKernelGGL(k_cc_union, grid_for(m, 256), dim3(256), 0, s, m, d_ea, d_eb, D.scratch_a.p);
         hipLaunchKernelGGL(k_cc_flatten, grid_for(n_nodes, 256), dim3(256), 0, s, n_nodes, D.scratch_a.p, D.scratch_b.p);
         HIPCHK((device_scan<OpSum, true>(s, n_nodes, FArr{D.scratch_b.p}, D.scratch_c.p, D.spine, nullptr)));
         hipLaunchKernelGGL(k_cc_label, grid_for(n_nodes, 256), dim3(256), 0, s, n_nodes, D.scratch_a.p, D.scratch_c.p, D.acc_c.p);
