@@ -2128,15 +2128,23 @@ int dev_order_small(sq_ctx* c, const std::vector<SmallProblem>& probs, const std
     if (!np) return SQ_OK;
     if (nmax > ORD_NMAX) return fail(c, SQ_E_ARG, "dev_order_small: nmax too large");
     DeviceRecords& D = *c->dev;
-    DBuf<SmallProblem>& dp = D.ord_p;
-    DBuf<int32_t>&de = D.ord_e, &dm = D.ord_m, &dord = D.ord_o, &dval = D.ord_v;
-    HIPCHK(dp.reserve(np)); HIPCHK(de.reserve(std::max<size_t>(edges5.size(), 1))); HIPCHK(dm.reserve(np)); HIPCHK(dord.reserve((size_t)np * ORD_NMAX)); HIPCHK(dval.reserve(np));
-    HIPCHK(hipMemcpyAsync(dp.p, probs.data(), np * sizeof(SmallProblem), hipMemcpyHostToDevice, s));
-    if (edges5.size()) HIPCHK(hipMemcpyAsync(de.p, edges5.data(), edges5.size() * 4, hipMemcpyHostToDevice, s));
-    { EvTimer t(c, "k_order_small", 0); hipLaunchKernelGGL(k_order_small, dim3(np), dim3(256), 0, s, dp.p, de.p, dm.p, dord.p, dval.p); }
-    HIPCHK(hipMemcpyAsync(out_mask.data(), dm.p, np * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(out_order.data(), dord.p, (size_t)np * ORD_NMAX * 4, hipMemcpyDeviceToHost, s));
+    // one packed upload (problems | edges) and one packed download (masks | orders) through page-locked staging
+    static_assert(sizeof(SmallProblem) == 12, "SmallProblem travels as three ints");
+    const size_t in_words = 3 * (size_t)np + edges5.size(), out_words = (size_t)np * (1 + ORD_NMAX);
+    DBuf<int32_t>&din = D.ord_e, &dout = D.ord_o, &dval = D.ord_v;
+    HIPCHK(din.reserve(in_words + 1)); HIPCHK(dout.reserve(out_words)); HIPCHK(dval.reserve(np));
+    D.pin.reset();
+    int32_t *hin = D.pin.take_n<int32_t>(in_words), *hout = D.pin.take_n<int32_t>(out_words);
+    if (!hin || !hout) return fail(c, SQ_E_HIP, "hipHostMalloc failed");
+    std::memcpy(hin, probs.data(), (size_t)np * 12);
+    if (edges5.size()) std::memcpy(hin + 3 * (size_t)np, edges5.data(), edges5.size() * 4);
+    HIPCHK(hipMemcpyAsync(din.p, hin, in_words * 4, hipMemcpyHostToDevice, s));
+    { EvTimer t(c, "k_order_small", 0);
+      hipLaunchKernelGGL(k_order_small, dim3(np), dim3(256), 0, s, (const SmallProblem*)din.p, din.p + 3 * (size_t)np, dout.p, dout.p + np, dval.p); }
+    HIPCHK(hipMemcpyAsync(hout, dout.p, out_words * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    out_mask.assign(hout, hout + np);
+    out_order.assign(hout + np, hout + out_words);
     return SQ_OK;
 }
 
@@ -2151,9 +2159,10 @@ int dev_breakpoint_support(sq_ctx* c, const std::vector<std::pair<int, int>>& bp
     if (!nb || !n) return SQ_OK;
     std::vector<int32_t> bc(nb), bp(nb);
     for (int i = 0; i < nb; ++i) { bc[i] = bps[i].first; bp[i] = bps[i].second; }
-    HIPCHK(D.acc_a.reserve(nb)); HIPCHK(D.acc_b.reserve(nb)); HIPCHK(D.acc_c.reserve(nb + 1));
+    HIPCHK(D.acc_b.reserve(2 * (size_t)nb)); HIPCHK(D.acc_c.reserve(nb + 1));
     HIPCHK(D.scratch_a.reserve(n)); HIPCHK(D.scratch_b.reserve(n));
-    HIPCHK(hipMemcpyAsync(D.acc_a.p, bc.data(), nb * 4, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(D.acc_b.p, bp.data(), nb * 4, hipMemcpyHostToDevice, s));
+    bc.insert(bc.end(), bp.begin(), bp.end());  // one packed upload: chr | pos
+    HIPCHK(hipMemcpy(D.acc_b.p, bc.data(), 2 * (size_t)nb * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemsetAsync(D.acc_c.p, 0, (nb + 1) * 4, s));
     HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
     RecView R = D.view();
@@ -2163,7 +2172,7 @@ int dev_breakpoint_support(sq_ctx* c, const std::vector<std::pair<int, int>>& bp
     for (int k = 0; k < n_ref; ++k) bo[k + 1] = bo[k] + (int32_t)(((int64_t)std::max(c->ref_len[k], 1) + (1 << NODE_BUCKET_SHIFT) - 1) >> NODE_BUCKET_SHIFT);
     const int total = bo[n_ref];
     HIPCHK(D.bp_bucket.reserve(std::max(total, 1)));
-    BPView B{nb, D.acc_a.p, D.acc_b.p, c->P.concord_dist_pos, D.bp_bucket.p, D.nv.bucket_off};
+    BPView B{nb, D.acc_b.p, D.acc_b.p + nb, c->P.concord_dist_pos, D.bp_bucket.p, D.nv.bucket_off};
     for (int i = 0; i < nb; ++i) if (bc[i] < 0 || bc[i] >= n_ref) return fail(c, SQ_E_ARG, "breakpoint on an unknown reference");
     if (total) hipLaunchKernelGGL(k_bp_buckets, dim3((total + 255) / 256), dim3(256), 0, s, B, n_ref, total, D.bp_bucket.p);
     HIPCHK(D.bp_ev.reserve(nb + 1)); HIPCHK(D.bp_end.reserve(nb + 1)); HIPCHK(D.bp_valid.reserve(nb + 1));
