@@ -58,6 +58,7 @@ struct SegStatic {
 struct SpanIndex {
     const int32_t *pos = nullptr, *len = nullptr;
     int base = 0, lim = 0;
+    mutable int cur = 0;           // first block with pos >= brk - T for the last break asked about (breaks come in ascending order)
     long long elo = 0;             // ends are counted per coordinate in [elo, elo + width)
     std::vector<int32_t> below;    // below[x] = #ends < elo + x   (ends behind the last break are never asked about: clamped)
     std::vector<int32_t> ends;     // fallback for very wide clusters: sorted ends
@@ -67,6 +68,7 @@ struct SpanIndex {
         pos = p; len = l;
         base = lb((long long)minbrk + T - maxlen, from, n);  // earlier blocks end before minbrk + T
         lim = lb((long long)maxbrk + T, base, n);            // later blocks start behind every break
+        cur = base;
         elo = (long long)minbrk + T - maxlen;
         const long long width = (long long)maxbrk + T - elo + 2;
         wide = width > (1 << 16);
@@ -87,7 +89,8 @@ struct SpanIndex {
     }
     int count(int brk, int T) const {
         const int a = brk - T, b = brk + T;
-        const int ia = lb(a, base, lim);
+        while (cur < lim && pos[cur] < a) ++cur;
+        const int ia = cur;
         int less_b;
         if (wide) less_b = (int)(std::lower_bound(ends.begin(), ends.end(), b) - ends.begin());
         else { long long x = (long long)b - elo; less_b = x <= 0 ? 0 : below[(size_t)std::min<long long>(x, (long long)below.size() - 1)]; }
@@ -268,6 +271,7 @@ struct Seg {
             auto tB = tick();
 
             int lastC = -1, lastSup = 0;
+            size_t m_lo = 0, m_hi = 0, f_lo = 0, f_hi = 0, r_lo = 0, r_hi = 0;
             for (size_t ib = 0; ib < M.size();) {
                 const int brk = M[ib];
                 size_t nx = ib;
@@ -278,9 +282,11 @@ struct Seg {
                     auto tq = tick();
                     // the reference counts these with linear passes over M and over the cluster's blocks for every candidate;
                     // M, fwd_ends and rev_starts are sorted, so the same counts are differences of binary searches
-                    const int sr = (int)(std::lower_bound(M.begin(), M.end(), brk + T) - std::lower_bound(M.begin(), M.end(), brk - T + 1));        // |brk - M[k]| < T
-                    const int pl = (int)(std::lower_bound(fwd_ends.begin(), fwd_ends.end(), brk) - std::lower_bound(fwd_ends.begin(), fwd_ends.end(), brk - RL + 1));  // forward block ending in (brk-RL, brk)
-                    const int pr = (int)(std::lower_bound(rev_starts.begin(), rev_starts.end(), brk + RL) - std::lower_bound(rev_starts.begin(), rev_starts.end(), brk + 1));  // reverse block starting in (brk, brk+RL)
+                    // (the candidates come in ascending order: every bound only moves forward)
+                    auto adv = [](const std::vector<int>& v, size_t& it, int x) { while (it < v.size() && v[it] < x) ++it; return (int)it; };
+                    const int sr = adv(M, m_hi, brk + T) - adv(M, m_lo, brk - T + 1);                        // |brk - M[k]| < T
+                    const int pl = adv(fwd_ends, f_hi, brk) - adv(fwd_ends, f_lo, brk - RL + 1);              // forward block ending in (brk-RL, brk)
+                    const int pr = adv(rev_starts, r_hi, brk + RL) - adv(rev_starts, r_lo, brk + 1);          // reverse block starting in (brk, brk+RL)
                     tock(3, tq, 0);
                     if (sr > 3 || sr + pl > 4 || sr + pr > 4) {
                         auto tw = tick();
