@@ -131,15 +131,14 @@ struct DeviceRecords {
     DBuf<StreamRec> srec;
     DBuf<int32_t> rest_refpos, rest_matchref;
     // node table
-    DBuf<int32_t> n_chr, n_pos, n_len, n_chr_start, n_bucket, n_bucket_off;
+    DBuf<int32_t> n_chr, n_bucket;  // n_chr: packed node table chr | pos | len | chr_start | bucket_off
     NodeView nv{};  // the node table of the current graph build (dev_upload_nodes)
-    DBuf<int32_t> acc_a, acc_b, acc_c, acc_d, acc_e, acc_f;  // per-node accumulators
+    DBuf<int32_t> acc_a, acc_b, acc_c;  // per-node accumulator block / small tables of the later stages
     // edge hash
     DBuf<unsigned long long> h_key, okey;
     DBuf<uint32_t> h_val, oval;
     uint32_t h_slots = 1u << 16;
-    DBuf<SmallProblem> ord_p;
-    DBuf<int32_t> ord_e, ord_m, ord_o, ord_v;
+    DBuf<int32_t> ord_e, ord_o, ord_v;  // ordering kernel: packed input, packed output, values
     DBuf<long long> other64, spine64, okey64;
     DBuf<uint8_t> bam_chunk;
     DBuf<unsigned long long> bam_off, chim_hash;
@@ -149,7 +148,7 @@ struct DeviceRecords {
     DBuf<int32_t> parse_nblk, parse_rel;
     DBuf<int32_t> calib;
     DBuf<uint8_t> zflag;
-    DBuf<int32_t> cl_chr, cl_start, cl_right, trig;
+    DBuf<int32_t> cl_chr, trig;  // cl_chr: packed cluster table chr | start | right
     DBuf<int32_t> bp_ev, bp_end, bp_valid, bp_bucket, stripes;
     DBuf<int32_t> flags;  // small device flag/counter block
     struct Pending { const char* name; double bytes; int slot; };
@@ -693,14 +692,6 @@ __device__ __forceinline__ int clusters_passed(const ClusterView& C, int refid, 
     return lo;
 }
 struct FKey64 { const long long* a; __device__ long long operator()(int64_t i) const { return a[i]; } };
-struct FOtherKey {
-    const StreamRec* sr;
-    __device__ long long operator()(int64_t i) const {
-        const StreamRec& r = sr[i];
-        if ((r.flags & (SR_CONC | SR_MATE)) != (SR_CONC | SR_MATE)) return LLONG_MIN;
-        return ((long long)r.refid << 32) | (unsigned int)(r.fb_refpos + r.fb_matchref);
-    }
-};
 // k counts the records of the local stream plus, in a sharded run, the appended first kept record of the next shard
 // (index k_own; its running pair is the aggregate of the whole local stream).  `seed` = running pair of earlier shards.
 __device__ __forceinline__ long long other_at(const long long* other_before, const long long* other_all, int64_t k_own, long long seed, int64_t i) {
@@ -1584,12 +1575,12 @@ void dev_destroy(sq_ctx* c) {
     D.scratch_a.release(); D.scratch_b.release(); D.scratch_c.release(); D.spine.release();
     D.part_prev.release(); D.part_next.release(); D.b0_a.release(); D.b0_b.release(); D.b0_home.release();
     D.srec.release(); D.rest_refpos.release(); D.rest_matchref.release();
-    D.n_chr.release(); D.n_pos.release(); D.n_len.release(); D.n_chr_start.release(); D.n_bucket.release(); D.n_bucket_off.release();
-    D.acc_a.release(); D.acc_b.release(); D.acc_c.release(); D.acc_d.release(); D.acc_e.release(); D.acc_f.release();
+    D.n_chr.release(); D.n_bucket.release();
+    D.acc_a.release(); D.acc_b.release(); D.acc_c.release();
     D.h_key.release(); D.h_val.release(); D.flags.release(); D.bam_chunk.release(); D.bam_off.release(); D.chim_hash.release(); D.chim_off.release(); D.chim_len.release(); D.chim_blob.release(); D.parse_nblk.release(); D.parse_rel.release();
     D.calib.release(); D.okey.release(); D.oval.release(); D.other64.release(); D.spine64.release(); D.okey64.release(); D.zflag.release();
-    D.cl_chr.release(); D.cl_start.release(); D.cl_right.release(); D.trig.release();
-    D.ord_p.release(); D.ord_e.release(); D.ord_m.release(); D.ord_o.release(); D.ord_v.release();
+    D.cl_chr.release(); D.trig.release();
+    D.ord_e.release(); D.ord_o.release(); D.ord_v.release();
     D.pin.release(); D.stripes.release(); D.bp_bucket.release(); D.bp_ev.release(); D.bp_end.release(); D.bp_valid.release();
     for (auto& e : D.ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete c->dev;

@@ -213,58 +213,9 @@ struct HostSolver {
 };
 
 // Replacement for boost::stoer_wagner_min_cut with unit weights (SegmentGraph.cpp:3316-3325): the reference only asks
-// "is the min cut 1?" and then uses the bipartition.  A cut of 1 is a bridge of the multigraph.  Rule (shared with
-// the oracle): take the most balanced bridge (minimise |n - 2*side|), ties by position in the
-// sorted component edge list; no bridge => "cut > 1".  Bridges by an iterative low-link DFS, O(n + m).
-bool bridge_split(int n, const std::vector<std::pair<int, int>>& edges, std::vector<char>& side) {
-    const int m = (int)edges.size();
-    std::vector<int> head(n + 1, 0), adj(2 * (size_t)m), aid(2 * (size_t)m);
-    for (auto& e : edges) { head[e.first + 1]++; head[e.second + 1]++; }
-    for (int i = 0; i < n; ++i) head[i + 1] += head[i];
-    {
-        std::vector<int> fill(head.begin(), head.end() - 1);
-        for (int i = 0; i < m; ++i) {
-            adj[fill[edges[i].first]] = edges[i].second; aid[fill[edges[i].first]++] = i;
-            adj[fill[edges[i].second]] = edges[i].first; aid[fill[edges[i].second]++] = i;
-        }
-    }
-    std::vector<int> disc(n, -1), low(n, 0), parent_edge(n, -1), sub(n, 1), it(n, 0), order;
-    order.reserve(n);
-    std::vector<int> stack(1, 0);
-    int timer = 0;
-    disc[0] = low[0] = timer++;
-    int best_edge = -1, best_bal = -1, best_child = -1;
-    std::vector<int> tin(n, 0), tout(n, 0);
-    tin[0] = 0;
-    while (!stack.empty()) {
-        int x = stack.back();
-        if (it[x] < head[x + 1] - head[x]) {
-            int k = head[x] + it[x]++;
-            int y = adj[k], id = aid[k];
-            if (id == parent_edge[x]) continue;          // the tree edge itself; a PARALLEL edge has another id and counts as a back edge
-            if (disc[y] < 0) { disc[y] = low[y] = timer++; parent_edge[y] = id; stack.push_back(y); }
-            else low[x] = std::min(low[x], disc[y]);
-        } else {
-            stack.pop_back();
-            if (!stack.empty()) {
-                int p = stack.back();
-                low[p] = std::min(low[p], low[x]);
-                sub[p] += sub[x];
-                if (low[x] > disc[p]) {  // bridge p - x
-                    int bal = std::abs(n - 2 * sub[x]);
-                    int id = parent_edge[x];
-                    if (best_bal < 0 || bal < best_bal || (bal == best_bal && id < best_edge)) { best_bal = bal; best_edge = id; best_child = x; }
-                }
-            }
-        }
-    }
-    if (best_edge < 0) return false;
-    // side = subtree of best_child: nodes discovered in [disc[child], disc[child] + sub[child])
-    side.assign(n, 0);
-    for (int v = 0; v < n; ++v) if (disc[v] >= disc[best_child] && disc[v] < disc[best_child] + sub[best_child]) side[v] = 1;
-    return true;
-}
-
+// "is the min cut 1?" and then uses the bipartition.  A cut of 1 is a bridge of the multigraph.  Rule (shared with the
+// oracle): take the most balanced bridge (minimise |n - 2*side|), ties by position in the
+// sorted component edge list; no bridge => "cut > 1".
 // MincutRecursion (SegmentGraph.cpp:3264-3451) without redoing the bridge search at every level: the bridges of a part
 // of the component are exactly the component's bridges inside it (splitting at a bridge breaks no cycle), so the
 // component is contracted ONCE into its tree of 2-edge-connected blobs (low-link DFS) and the recursion runs on that
