@@ -256,6 +256,7 @@ int main(int argc, char** argv) {
     long records = -1;
     int ntsv = -1, level = 6, threads = 4, genes_override = -1;
     double chim_copy_frac = 0.2;
+    double indel_frac = 0.0;  // fraction of concordant pairs whose left read gets an I / D / =X CIGAR variant (off by default: C1..C5 unchanged)
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto val = [&]() { return std::string(i + 1 < argc ? argv[++i] : ""); };
@@ -268,6 +269,7 @@ int main(int argc, char** argv) {
         else if (a == "--threads") threads = std::atoi(val().c_str());
         else if (a == "--genes") genes_override = std::atoi(val().c_str());
         else if (a == "--chim-copy-frac") chim_copy_frac = std::atof(val().c_str());
+        else if (a == "--indel-frac") indel_frac = std::atof(val().c_str());
         else { std::fprintf(stderr, "unknown arg %s\n", a.c_str()); return 2; }
     }
     std::vector<Contig> contigs;
@@ -513,6 +515,20 @@ int main(int argc, char** argv) {
             if (clipside == 1) clip(pl, false, cliplen, g, s, s + RL);
             if (clipside == 2) clip(pr, true, cliplen, g, s + L - RL, s + L);
             if (clipside == 3) clip(pr, false, cliplen, g, s + L - RL, s + L);
+            if (indel_frac > 0 && (double)((dice >> 8) & 0xffff) / 65536.0 < indel_frac) {
+                // CIGAR variants of the same alignment: M a, I 2, M b / M a, D 3, M b / = a, X 1, = b on the first long match
+                for (size_t ci = 0; ci < pl.cig.size(); ++ci) {
+                    if (pl.cig[ci].op != 'M' || pl.cig[ci].len < 30) continue;
+                    const int len = pl.cig[ci].len, a = 10 + (int)((dice >> 24) % 8), kind = (int)((dice >> 32) % 3);
+                    std::vector<CigarOp> rep;
+                    if (kind == 0) { rep = {{'M', a}, {'I', 2}, {'M', len - a - 2}}; pl.reflen -= 2; }
+                    else if (kind == 1) { rep = {{'M', a}, {'D', 3}, {'M', len - a}}; pl.reflen += 3; }
+                    else rep = {{'=', a}, {'X', 1}, {'=', len - a - 1}};
+                    pl.cig.erase(pl.cig.begin() + ci);
+                    pl.cig.insert(pl.cig.begin() + ci, rep.begin(), rep.end());
+                    break;
+                }
+            }
             int fl = 0x1 | 0x2 | 0x20 | (m1left ? 0x40 : 0x80) | (dup ? 0x400 : 0);
             int fr = 0x1 | 0x2 | 0x10 | (m1left ? 0x80 : 0x40) | (dup ? 0x400 : 0);
             int mq = multi ? 3 : 255, nh = multi ? 3 : 1;

@@ -531,3 +531,14 @@ def test_parity_on_other_seeds(built, synth, tmp_path, seed, monkeypatch):
         ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
         ctx.build_graph()
         _compare(ctx, dump, sv_path, depth_exact=False)
+
+
+def test_parity_with_indel_and_match_mismatch_cigars(built, synth, tmp_path, exact_depth):
+    """20 % of the concordant pairs carry I, D or =/X operations (ReadRec.cpp:52-60: a block runs from M/= to the next
+    S/H/N, D adds reference only, I read only): K0's CIGAR walk against the oracle's, all stages"""
+    pre = synth("T2", "--indel-frac", "0.2")
+    sv_path, dump = ou.run_oracle(built, pre, tmp_path)
+    with squid_amd.Context() as ctx:
+        ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
+        ctx.build_graph()
+        _compare(ctx, dump, sv_path)
