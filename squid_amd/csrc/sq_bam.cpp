@@ -6,6 +6,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <cctype>
 #include <dlfcn.h>
 #include <unistd.h>
 #include <sys/stat.h>
@@ -384,6 +385,7 @@ static int read_bam_header_bytes(const std::vector<uint8_t>& d, bool whole_file,
 }
 
 typedef std::function<int(const uint8_t*, size_t, const unsigned long long*, int64_t)> RawSink;
+typedef std::function<int(const uint8_t*, const std::vector<BgzfRange>&, size_t, size_t, size_t, bool, int)> GpuIngest;
 static int parse_bam_impl(const char* path, const ParseOpts& o, size_t batch_records, int n_threads, std::string& err,
                           const std::function<int(const HostBatch&)>& sink, const RawSink* raw_sink) {
     using clk = std::chrono::steady_clock;
@@ -728,6 +730,30 @@ int find_records(const uint8_t* u, size_t begin, size_t limit, int nref, Pool& p
         size_t need_bytes = 32 + (size_t)lname + 4 * (size_t)ncig + ((size_t)lseq + 1) / 2 + (size_t)lseq;
         if (need_bytes > (size_t)bs) return -1;
         if (p + 4 + 32 + (size_t)lname <= limit && q[4 + 32 + lname - 1] != 0) return -1;  // QNAME is NUL terminated
+        // the optional fields must tile the rest of the record exactly: a header read one or two bytes early can pass all of
+        // the above and even run into true records (seen: 1 slice in 8000), but its "fields" are other records
+        if (p + 4 + (size_t)bs <= limit) {
+            const uint8_t *a = q + 4 + need_bytes, *e = q + 4 + bs;
+            while (a < e) {
+                if (e - a < 3) return -1;
+                if (!std::isalpha(a[0]) || !std::isalnum(a[1])) return -1;
+                const uint8_t ty = a[2];
+                const uint8_t* v = a + 3;
+                size_t sz;
+                if (ty == 'A' || ty == 'c' || ty == 'C') sz = 1;
+                else if (ty == 's' || ty == 'S') sz = 2;
+                else if (ty == 'i' || ty == 'I' || ty == 'f') sz = 4;
+                else if (ty == 'Z' || ty == 'H') { const uint8_t* z = v; while (z < e && *z) ++z; if (z >= e) return -1; sz = (size_t)(z - v) + 1; }
+                else if (ty == 'B') {
+                    if (e - v < 5) return -1;
+                    const size_t es = (v[0] == 'c' || v[0] == 'C') ? 1 : ((v[0] == 's' || v[0] == 'S') ? 2 : ((v[0] == 'i' || v[0] == 'I' || v[0] == 'f') ? 4 : 0));
+                    if (!es) return -1;
+                    sz = 5 + es * (size_t)(uint32_t)rd32(v + 1);
+                } else return -1;
+                if (sz > (size_t)(e - v)) return -1;
+                a = v + sz;
+            }
+        }
         return bs;
     };
     auto sync_from = [&](size_t from, size_t upto) -> size_t {
@@ -799,7 +825,7 @@ int find_records(const uint8_t* u, size_t begin, size_t limit, int nref, Pool& p
 }
 }  // namespace
 
-int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSink& sink, const std::function<void(size_t)>& on_total, const RefRange* only) {
+int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSink& sink, const std::function<void(size_t)>& on_total, const RefRange* only, const GpuIngest& gpu) {
     using clk = std::chrono::steady_clock;
     auto since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
     double t_map = 0, t_inflate = 0, t_find = 0, t_wait = 0;
@@ -823,20 +849,28 @@ int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSi
     int cur = 0, nref = -1;
     bool header_done = false, unsynced = false;
     int rc = SQ_OK;
-    if (only) {
-        // A chromosome shard only inflates the blocks that can hold its records.  f(b) = RefID of the first record that
-        // starts at or behind block b (found by the same plausible-chain search that the slices use) is monotone in a
-        // coordinate-sorted file, unplaced records (-1) counting as behind every reference: two binary searches.
-        std::vector<uint8_t> hdr;  // the header first: the number of references is part of the plausibility test
+    const bool try_gpu = gpu && std::getenv("SQUID_GPU_INFLATE");  // experimental (see k_inflate): the host pipeline below is faster on this box
+    size_t hp = 0, first_rec_block = 0;
+    if (only || try_gpu) {
+        // the header first (a few blocks, inflated here): the number of references is part of the plausibility test
+        std::vector<uint8_t> hdr;
         size_t hb = 0;
         auto hneed = [&](size_t n) { while (hdr.size() < n && hb < blocks.size()) { size_t o = hdr.size(); hdr.resize(o + blocks[hb].isize); if (!inflate_one(fm.p, blocks[hb], hdr.data() + o)) return false; ++hb; } return hdr.size() >= n; };
         if (!hneed(12) || std::memcmp(hdr.data(), "BAM\1", 4) != 0) { err = "not a BAM file"; return SQ_E_IO; }
         const int32_t ltext = rd32(hdr.data() + 4);
         if (!hneed(12 + (size_t)ltext)) { err = "truncated header"; return SQ_E_IO; }
         nref = rd32(hdr.data() + 8 + ltext);
-        size_t hp = 12 + (size_t)ltext;
+        hp = 12 + (size_t)ltext;
         for (int i = 0; i < nref; ++i) { if (!hneed(hp + 4)) { err = "truncated header"; return SQ_E_IO; } int32_t ln = rd32(hdr.data() + hp); if (!hneed(hp + 8 + (size_t)ln)) { err = "truncated header"; return SQ_E_IO; } hp += 8 + (size_t)ln; }
-        const size_t first_rec_block = (size_t)(std::upper_bound(blocks.begin(), blocks.end(), hp, [](size_t v, const BgzfBlock& b) { return v < b.uoff; }) - blocks.begin()) - 1;
+        first_rec_block = (size_t)(std::upper_bound(blocks.begin(), blocks.end(), hp, [](size_t v, const BgzfBlock& b) { return v < b.uoff; }) - blocks.begin()) - 1;
+        header_done = true;
+        nb = first_rec_block;
+        only_begin = hp - blocks[nb].uoff;
+    }
+    if (only) {
+        // A chromosome shard only inflates the blocks that can hold its records.  f(b) = RefID of the first record that
+        // starts at or behind block b (found by the same plausible-chain search that the slices use) is monotone in a
+        // coordinate-sorted file, unplaced records (-1) counting as behind every reference: two binary searches.
         std::vector<uint8_t> tmp;
         std::vector<unsigned long long> toffs;
         auto first_ref_from = [&](size_t b) -> int {  // nref when no record starts at or behind block b
@@ -863,13 +897,18 @@ int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSi
         if (bl == (size_t)-1 || bh == (size_t)-1) { err = "corrupt BGZF block"; return SQ_E_IO; }
         nb = bl > first_rec_block ? bl - 1 : first_rec_block;   // records of the range may start in the block before
         nb_end = std::min(blocks.size(), bh + 2);                // the last owned record may run into the next blocks
-        header_done = true;
         unsynced = nb != first_rec_block;
-        if (nb == first_rec_block) { carry = 0; }  // the first chunk then starts inside the header block: skip to the first record below
         if (nb >= nb_end) return SQ_OK;
-        if (!unsynced) {  // start exactly at the first record: emulate by a carry-less chunk whose begin is the header end
-            only_begin = hp - blocks[nb].uoff;
-        }
+        only_begin = unsynced ? 0 : hp - blocks[nb].uoff;  // (a range that starts in the header block begins right behind the header)
+    }
+    if (try_gpu && nb < nb_end) {
+        // everything else on the GPU: the compressed blocks are copied as they are, inflated, cut into records and parsed there
+        std::vector<BgzfRange> br(blocks.size());
+        for (size_t i = 0; i < blocks.size(); ++i) br[i] = BgzfRange{blocks[i].coff, blocks[i].clen, blocks[i].isize, blocks[i].uoff};
+        const int r2 = gpu(fm.p, br, nb, nb_end, only_begin, !unsynced, nref);
+        if (std::getenv("SQUID_INGEST_TIMING")) std::fprintf(stderr, "ingest %s: map+index %.1f, GPU inflate+parse path total %.1f ms (rc %d)\n", path, t_map, since(t_all), r2);
+        if (r2 != 2) return r2;
+        // (the device-side checks were not satisfied: nothing was appended, continue with the host pipeline)
     }
     while (nb < nb_end) {
         const size_t b1 = std::min(nb_end, nb + kChunkBlocks);

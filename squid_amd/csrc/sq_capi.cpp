@@ -793,7 +793,9 @@ int sq_ingest_concordant_file(sq_ctx* c, const char* path, int32_t n_threads) {
         c->ingest_total_bytes = 0; c->ingest_seen_bytes = 0;
         const RefRange rr{c->shard.first_ref, c->shard.end_ref, c->P.rank == c->P.world_size - 1};
         int rc = scan_bam_file(path, n_threads, c->err, [&](const uint8_t* bam, size_t nbytes, const unsigned long long* off, int64_t n) { c->ingest_seen_bytes += nbytes; return ingest_raw(c, bam, nbytes, off, n); },
-                               [&](size_t total) { c->ingest_total_bytes = c->shard.on ? 0 : total; }, c->shard.on ? &rr : nullptr);
+                               [&](size_t total) { c->ingest_total_bytes = c->shard.on ? 0 : total; }, c->shard.on ? &rr : nullptr,
+                               [&](const uint8_t* file, const std::vector<BgzfRange>& blocks, size_t b0, size_t b1, size_t begin, bool synced, int nref) {
+                                   return dev_ingest_bgzf(c, file, blocks, b0, b1, begin, synced, nref); });
         c->ingest_total_bytes = 0;
         dev_flush_timers(c);
         return rc;

@@ -24,6 +24,8 @@
 #include <cstring>
 #include <functional>
 
+#include <zlib.h>
+
 #include "sq_internal.h"
 
 #define HIPCHK(call)                                                                                         \
@@ -84,6 +86,7 @@ struct DBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+struct InflBlock { unsigned long long coff; uint32_t clen, isize; unsigned long long uoff; };  // one BGZF block for k_inflate
 // page-locked host staging for the small device->host results of a stage: the copies are queued without blocking and
 // one stream synchronisation makes all of them visible.  A slice stays valid until the next reset().
 struct Pinned {
@@ -140,7 +143,10 @@ struct DeviceRecords {
     uint32_t h_slots = 1u << 16;
     DBuf<int32_t> ord_e, ord_o, ord_v;  // ordering kernel: packed input, packed output, values
     DBuf<long long> other64, spine64, okey64;
-    DBuf<uint8_t> bam_chunk;
+    DBuf<uint8_t> bam_chunk, bgzf_in, bgzf_out;
+    DBuf<InflBlock> bgzf_tab;
+    DBuf<long long> rec_sync, rec_end;
+    DBuf<int32_t> rec_cnt, rec_base;
     DBuf<unsigned long long> bam_off, chim_hash;
     DBuf<uint32_t> chim_off, chim_len;
     DBuf<char> chim_blob;
@@ -1517,6 +1523,278 @@ __global__ __launch_bounds__(256) void k_order_small(const SmallProblem* probs, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ K-1: BGZF inflate
+// One wave per BGZF block (raw DEFLATE, <= 64 KiB out).  Every lane runs the same bit-serial decode on the same data
+// (uniform control flow, broadcast loads; the Huffman tables of the wave live in LDS): lane 0 stores the literals, all
+// lanes share the copy of a match.  A match reads bytes this wave has just written through global memory, so a fence
+// (which also drops stale L1 lines) is placed in front of every copy whose source reaches behind the last fence.
+// EXPERIMENTAL, off by default (SQUID_GPU_INFLATE=1): bit-exact against zlib on every test file, but a wave spends ~2 us per
+// symbol on what is scalar work (27-90 ms per 64 KiB block, all blocks of a 1 M-record file at once), so it only pays
+// for files with >> 10^5 blocks; the 16 host cores of the GPU box inflate ~9 GB/s with libdeflate.  Kept as the
+// starting point for a lane-per-block version.
+constexpr int INFL_LB = 10, INFL_DB = 8;
+struct InflHuff { uint16_t cnt[16]; uint16_t sym[288]; };
+struct InflLds { InflHuff ll, dd; uint16_t fast_ll[1 << INFL_LB]; uint16_t fast_dd[1 << INFL_DB]; uint8_t lens[352]; };
+// bit reader: 64-bit window refilled 32 bits at a time from a word that was requested one refill earlier (the load's
+// latency hides behind the decoding of the symbols in between; a byte-at-a-time reader costs a memory round trip per byte)
+struct InflBits { const uint8_t* p; uint32_t n, pos; unsigned long long buf; int cnt; uint32_t ahead; bool bad; };
+__device__ __forceinline__ uint32_t infl_word(const uint8_t* p) { uint32_t w; __builtin_memcpy(&w, p, 4); return w; }
+__device__ __forceinline__ void infl_init(InflBits& b) { b.buf = 0; b.cnt = 0; b.pos = 0; b.bad = false; b.ahead = infl_word(b.p); }
+__device__ __forceinline__ void infl_refill(InflBits& b) {
+    if (b.cnt <= 32) {
+        b.buf |= (unsigned long long)b.ahead << b.cnt;
+        b.cnt += 32; b.pos += 4;
+        if (b.pos > b.n + 8) b.bad = true;   // ran far past the end of the compressed block (its buffer is padded)
+        b.ahead = infl_word(b.p + b.pos);
+    }
+}
+__device__ __forceinline__ uint32_t infl_take(InflBits& b, int k) {  // k <= 16
+    infl_refill(b);
+    const uint32_t v = (uint32_t)(b.buf & ((1ull << k) - 1));
+    b.buf >>= k; b.cnt -= k;
+    return v;
+}
+// canonical Huffman code from lens[0..n): count/symbol arrays (slow path) + a 2^FB-entry table (sym << 4 | len) for the
+// codes of at most FB bits.  Returns false for an over-subscribed set.
+__device__ __noinline__ bool infl_build(InflHuff& H, uint16_t* fast, int FB, const uint8_t* lens, int n) {
+    for (int i = 0; i < 16; ++i) H.cnt[i] = 0;
+    for (int i = 0; i < n; ++i) H.cnt[lens[i]]++;
+    int left = 1;
+    for (int l = 1; l <= 15; ++l) { left <<= 1; left -= H.cnt[l]; if (left < 0) return false; }
+    uint16_t offs[16], next[16];
+    offs[1] = 0;
+    for (int l = 1; l < 15; ++l) offs[l + 1] = offs[l] + H.cnt[l];
+    for (int i = 0; i < n; ++i) if (lens[i]) H.sym[offs[lens[i]]++] = (uint16_t)i;
+    int code = 0;
+    next[0] = 0;
+    for (int l = 1; l <= 15; ++l) { code = (code + H.cnt[l - 1] * (l > 1 ? 1 : 0)) << 1; next[l] = (uint16_t)code; }
+    for (int i = 0; i < (1 << FB); ++i) fast[i] = 0;
+    for (int i = 0; i < n; ++i) {
+        const int l = lens[i];
+        if (!l) continue;
+        const uint32_t c = next[l]++;
+        if (l > FB) continue;
+        const uint32_t rev = __brev(c) >> (32 - l);
+        for (uint32_t j = rev; j < (1u << FB); j += 1u << l) fast[j] = (uint16_t)((i << 4) | l);
+    }
+    return true;
+}
+__device__ __noinline__ int infl_decode_slow(InflBits& b, const InflHuff& H) {
+    int code = 0, first = 0, index = 0;
+    unsigned long long bb = b.buf;
+    for (int len = 1; len <= 15; ++len) {
+        code |= (int)(bb & 1); bb >>= 1;
+        const int count = H.cnt[len];
+        if (code - count < first) { b.buf >>= len; b.cnt -= len; return H.sym[index + (code - first)]; }
+        index += count; first += count; first <<= 1; code <<= 1;
+    }
+    b.bad = true;
+    return -1;
+}
+__device__ __forceinline__ int infl_decode(InflBits& b, const InflHuff& H, const uint16_t* fast, int FB) {
+    infl_refill(b);
+    const uint16_t e = fast[b.buf & ((1u << FB) - 1)];
+    if (e & 15) { const int l = e & 15; b.buf >>= l; b.cnt -= l; return e >> 4; }
+    return infl_decode_slow(b, H);
+}
+__constant__ uint16_t c_lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ uint8_t c_lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ uint16_t c_dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ uint8_t c_dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ uint8_t c_clorder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+__global__ __launch_bounds__(256) void k_inflate(const uint8_t* file, const InflBlock* blocks, int first, int nblocks, unsigned long long out_base, uint8_t* outbuf, int32_t* flags) {
+    __shared__ InflLds lds[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int bi = blockIdx.x * 4 + wave;
+    if (bi >= nblocks) return;
+    const InflBlock blk = blocks[first + bi];
+    if (!blk.isize) return;
+    InflLds& L = lds[wave];
+    uint8_t* out = outbuf + (blk.uoff - out_base);
+    InflBits b;
+    b.p = file + blk.coff; b.n = blk.clen;
+    infl_init(b);
+    uint32_t outpos = 0, fenced = 0;
+    bool err = false;
+    for (bool last = false; !last && !err;) {
+        last = infl_take(b, 1);
+        const uint32_t type = infl_take(b, 2);
+        if (b.bad) { err = true; break; }
+        if (type == 0) {  // stored
+            b.buf >>= (b.cnt & 7); b.cnt -= (b.cnt & 7);
+            const uint32_t len = infl_take(b, 16), nlen = infl_take(b, 16);
+            if (b.bad || (len ^ 0xffff) != nlen) { err = true; break; }
+            // the bit window holds whole bytes now: hand them back and copy from the byte position
+            uint32_t at = b.pos - (uint32_t)(b.cnt >> 3);
+            if (at + len > b.n || outpos + len > blk.isize) { err = true; break; }
+            for (uint32_t i = lane; i < len; i += 64) out[outpos + i] = b.p[at + i];
+            outpos += len;
+            b.pos = at + len; b.buf = 0; b.cnt = 0; b.ahead = infl_word(b.p + b.pos);
+            continue;
+        }
+        if (type == 3) { err = true; break; }
+        if (type == 1) {  // fixed code
+            for (int i = 0; i < 144; ++i) L.lens[i] = 8;
+            for (int i = 144; i < 256; ++i) L.lens[i] = 9;
+            for (int i = 256; i < 280; ++i) L.lens[i] = 7;
+            for (int i = 280; i < 288; ++i) L.lens[i] = 8;
+            infl_build(L.ll, L.fast_ll, INFL_LB, L.lens, 288);
+            for (int i = 0; i < 30; ++i) L.lens[i] = 5;
+            infl_build(L.dd, L.fast_dd, INFL_DB, L.lens, 30);
+        } else {  // dynamic code
+            const int nlen = (int)infl_take(b, 5) + 257, ndist = (int)infl_take(b, 5) + 1, ncode = (int)infl_take(b, 4) + 4;
+            if (b.bad || nlen > 286 || ndist > 30) { err = true; break; }
+            for (int i = 0; i < 19; ++i) L.lens[i] = 0;
+            for (int i = 0; i < ncode; ++i) L.lens[c_clorder[i]] = (uint8_t)infl_take(b, 3);
+            if (b.bad || !infl_build(L.ll, L.fast_ll, 7, L.lens, 19)) { err = true; break; }  // (the code-length code, built in the litlen slot)
+            int idx = 0;
+            // the lengths are written behind each other: litlen [0, nlen), dist [nlen, nlen + ndist)
+            uint8_t tmp_prev = 0;
+            while (idx < nlen + ndist) {
+                int sym = infl_decode(b, L.ll, L.fast_ll, 7);
+                if (sym < 0) { err = true; break; }
+                if (sym < 16) { L.lens[19 + idx++] = (uint8_t)sym; tmp_prev = (uint8_t)sym; }
+                else {
+                    int rep; uint8_t v = 0;
+                    if (sym == 16) { if (idx == 0) { err = true; break; } v = tmp_prev; rep = 3 + (int)infl_take(b, 2); }
+                    else if (sym == 17) rep = 3 + (int)infl_take(b, 3);
+                    else rep = 11 + (int)infl_take(b, 7);
+                    if (b.bad || idx + rep > nlen + ndist) { err = true; break; }
+                    while (rep--) L.lens[19 + idx++] = v;
+                    tmp_prev = v;
+                }
+            }
+            if (err) break;
+            if (L.lens[19 + 256] == 0) { err = true; break; }  // no end-of-block code
+            // (lens[19..] is read by infl_build before it overwrites anything it still needs: the tables are separate arrays)
+            if (!infl_build(L.ll, L.fast_ll, INFL_LB, L.lens + 19, nlen)) { err = true; break; }
+            if (!infl_build(L.dd, L.fast_dd, INFL_DB, L.lens + 19 + nlen, ndist)) { err = true; break; }
+        }
+        for (;;) {  // symbols of this block
+            const int sym = infl_decode(b, L.ll, L.fast_ll, INFL_LB);
+            if (sym < 0) { err = true; break; }
+            if (sym < 256) {
+                if (outpos >= blk.isize) { err = true; break; }
+                if (lane == 0) out[outpos] = (uint8_t)sym;
+                ++outpos;
+                continue;
+            }
+            if (sym == 256) break;
+            const int ls = sym - 257;
+            if (ls >= 29) { err = true; break; }
+            const uint32_t len = c_lbase[ls] + infl_take(b, c_lext[ls]);
+            const int ds = infl_decode(b, L.dd, L.fast_dd, INFL_DB);
+            if (ds < 0 || ds >= 30) { err = true; break; }
+            const uint32_t dist = c_dbase[ds] + infl_take(b, c_dext[ds]);
+            if (b.bad || dist > outpos || outpos + len > blk.isize) { err = true; break; }
+            const uint32_t src = outpos - dist;
+            if (src + (dist < len ? dist : len) > fenced) { __threadfence(); fenced = outpos; }
+            for (uint32_t i = lane; i < len; i += 64) out[outpos + i] = out[src + (dist >= len ? i : i % dist)];
+            outpos += len;
+        }
+    }
+    if (err || outpos != blk.isize) { if (lane == 0) atomicOr(&flags[0], 512); }
+}
+
+// Record boundaries of the inflated stream, on the device: 8 KiB slices find their first boundary by validating a chain of
+// plausible record headers (as the host reader does), walk from there, and a check kernel verifies that every slice ends
+// exactly where the next one started (any disagreement sends the file through the host reader instead).
+constexpr int REC_SLICE = 8192;
+struct RecScan { const uint8_t* u; unsigned long long begin, limit; int nref; int first_ref, end_ref, with_unplaced; /* first_ref < 0: keep everything */ };
+__device__ __forceinline__ int ld32u(const uint8_t* p) { return (int)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); }
+__device__ __forceinline__ long rec_plausible(const RecScan& S, unsigned long long p) {
+    if (S.limit - p < 36) return -1;
+    const uint8_t* q = S.u + p;
+    const int bs = ld32u(q);
+    if (bs < 34 || bs > (1 << 26)) return -1;
+    const int refid = ld32u(q + 4), pos = ld32u(q + 8), mrefid = ld32u(q + 24), mpos = ld32u(q + 28), lseq = ld32u(q + 20);
+    const int lname = q[12], ncig = q[16] | (q[17] << 8);
+    if (refid < -1 || refid >= S.nref || mrefid < -1 || mrefid >= S.nref || pos < -1 || mpos < -1 || lseq < 0 || lname < 1) return -1;
+    const unsigned long long need = 32ull + lname + 4ull * ncig + ((unsigned long long)lseq + 1) / 2 + lseq;
+    if (need > (unsigned long long)bs) return -1;
+    if (p + 4 + 32 + lname <= S.limit && q[4 + 32 + lname - 1] != 0) return -1;
+    // the optional fields must tile the rest of the record exactly (a header read one or two bytes early can pass
+    // everything above and even continue into true records: its "fields" are 50 KB of other records and never tile)
+    if (p + 4 + (unsigned long long)bs <= S.limit) {
+        const uint8_t *a = q + 4 + need, *e = q + 4 + bs;
+        while (a < e) {
+            if (e - a < 3) return -1;
+            const uint8_t ty = a[2];
+            const bool alpha0 = (a[0] >= 'A' && a[0] <= 'Z') || (a[0] >= 'a' && a[0] <= 'z');
+            const bool alnum1 = (a[1] >= 'A' && a[1] <= 'Z') || (a[1] >= 'a' && a[1] <= 'z') || (a[1] >= '0' && a[1] <= '9');
+            if (!alpha0 || !alnum1) return -1;
+            const uint8_t* v = a + 3;
+            unsigned long long sz;
+            if (ty == 'A' || ty == 'c' || ty == 'C') sz = 1;
+            else if (ty == 's' || ty == 'S') sz = 2;
+            else if (ty == 'i' || ty == 'I' || ty == 'f') sz = 4;
+            else if (ty == 'Z' || ty == 'H') { const uint8_t* z = v; while (z < e && *z) ++z; if (z >= e) return -1; sz = (unsigned long long)(z - v) + 1; }
+            else if (ty == 'B') {
+                if (e - v < 5) return -1;
+                const uint8_t st = v[0];
+                const unsigned long long es = (st == 'c' || st == 'C') ? 1 : ((st == 's' || st == 'S') ? 2 : ((st == 'i' || st == 'I' || st == 'f') ? 4 : 0));
+                if (!es) return -1;
+                sz = 5 + es * (unsigned long long)(uint32_t)ld32u(v + 1);
+            } else return -1;
+            if (sz > (unsigned long long)(e - v)) return -1;
+            a = v + sz;
+        }
+    }
+    return bs;
+}
+__global__ void k_rec_sync(RecScan S, long long nslices, int synced, long long* sync) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nslices) return;
+    const unsigned long long lo = S.begin + (unsigned long long)s * REC_SLICE, hi = lo + REC_SLICE < S.limit ? lo + REC_SLICE : S.limit;
+    if (s == 0 && synced) { sync[0] = (long long)S.begin; return; }
+    long long found = -1;
+    for (unsigned long long p = lo; p < hi && found < 0; ++p) {
+        unsigned long long q = p;
+        int ok = 0;
+        for (;;) {
+            const long bs = rec_plausible(S, q);
+            if (bs < 0) break;
+            if (q + 4 + (unsigned long long)bs > S.limit) { if (ok >= 2) found = (long long)p; break; }
+            q += 4 + (unsigned long long)bs;
+            if (++ok == 4 || q == S.limit) { found = (long long)p; break; }
+        }
+    }
+    sync[s] = found;
+}
+__device__ __forceinline__ bool rec_owned(const RecScan& S, int refid) {
+    if (S.first_ref < 0) return true;
+    if (refid < 0) return S.with_unplaced != 0;
+    return refid >= S.first_ref && refid < S.end_ref;
+}
+template <bool EMIT>
+__global__ void k_rec_walk(RecScan S, long long nslices, const long long* sync, int32_t* count, long long* end_p, const int32_t* base, unsigned long long* offs) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nslices) return;
+    const unsigned long long lo = S.begin + (unsigned long long)s * REC_SLICE, hi = lo + REC_SLICE < S.limit ? lo + REC_SLICE : S.limit;
+    long long p0 = sync[s];
+    int n = 0;
+    unsigned long long p = p0 < 0 ? hi : (unsigned long long)p0;
+    int32_t at = EMIT ? base[s] : 0;
+    if (p0 >= 0)
+        while (p < hi) {
+            if (S.limit - p < 4) break;
+            const int bs = ld32u(S.u + p);
+            if (bs < 32 || S.limit - p < 4ull + (unsigned long long)bs) break;  // incomplete (or corrupt: the parser will say so)
+            if (rec_owned(S, ld32u(S.u + p + 4))) { if (EMIT) offs[at + n] = p; ++n; }
+            p += 4ull + (unsigned long long)bs;
+        }
+    if (!EMIT) { count[s] = n; end_p[s] = p0 < 0 ? -1 : (long long)p; }
+}
+__global__ void k_rec_check(long long nslices, const long long* sync, const long long* end_p, int32_t* flags) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nslices || s == 0) return;
+    // every slice must start where the one before stopped; a slice without a boundary is only fine behind the last record
+    if (sync[s] >= 0) { if (sync[s - 1] < 0 || end_p[s - 1] != sync[s]) atomicOr(&flags[0], 1024); }
+    else if (sync[s - 1] >= 0 && end_p[s - 1] >= 0) {
+        // (the previous slice stopped inside or in front of this one: then this slice holds only an incomplete tail)
+    }
+}
+
 // ================================================================================================ host wrappers
 static inline dim3 grid_for(int64_t n, int threads) { return dim3((unsigned)((n + threads - 1) / threads)); }
 
@@ -1581,7 +1859,7 @@ void dev_destroy(sq_ctx* c) {
     D.calib.release(); D.okey.release(); D.oval.release(); D.other64.release(); D.spine64.release(); D.okey64.release(); D.zflag.release();
     D.cl_chr.release(); D.trig.release();
     D.ord_e.release(); D.ord_o.release(); D.ord_v.release();
-    D.pin.release(); D.stripes.release(); D.bp_bucket.release(); D.bp_ev.release(); D.bp_end.release(); D.bp_valid.release();
+    D.pin.release(); D.bgzf_in.release(); D.bgzf_out.release(); D.bgzf_tab.release(); D.rec_sync.release(); D.rec_end.release(); D.rec_cnt.release(); D.rec_base.release(); D.stripes.release(); D.bp_bucket.release(); D.bp_ev.release(); D.bp_end.release(); D.bp_valid.release();
     for (auto& e : D.ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete c->dev;
     c->dev = nullptr;
@@ -1645,19 +1923,27 @@ int dev_upload_chim_names(sq_ctx* c) {
 }
 
 // K0: parse `n_rec` BAM records of an inflated chunk on the device and append them to the resident SoA
+static int parse_device(sq_ctx* c, const uint8_t* d_bam, size_t nbytes, const unsigned long long* d_off, int64_t n_rec);
 int dev_parse_append(sq_ctx* c, const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n_rec) {
     if (n_rec == 0) return SQ_OK;
     HIPCHK(hipSetDevice(c->P.device));  // the file reader calls this from its sink thread (the current device is per thread)
     DeviceRecords& D = *c->dev;
     hipStream_t s = c->stream;
-    const size_t n0 = (size_t)D.n, nb0 = (size_t)D.nb, n1 = n0 + (size_t)n_rec;
-    HIPCHK(D.bam_chunk.reserve(nbytes + 64)); HIPCHK(D.bam_off.reserve((size_t)n_rec)); HIPCHK(D.parse_nblk.reserve((size_t)n_rec)); HIPCHK(D.parse_rel.reserve((size_t)n_rec));
+    HIPCHK(D.bam_chunk.reserve(nbytes + 64)); HIPCHK(D.bam_off.reserve((size_t)n_rec));
     HIPCHK(hipMemcpyAsync(D.bam_chunk.p, bam, nbytes, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(D.bam_off.p, rec_off, (size_t)n_rec * 8, hipMemcpyHostToDevice, s));
+    return parse_device(c, D.bam_chunk.p, nbytes, D.bam_off.p, n_rec);
+}
+// the records at d_off[0..n_rec) of the inflated bytes d_bam (both in device memory) -> appended to the resident SoA
+static int parse_device(sq_ctx* c, const uint8_t* d_bam, size_t nbytes, const unsigned long long* d_off, int64_t n_rec) {
+    DeviceRecords& D = *c->dev;
+    hipStream_t s = c->stream;
+    const size_t n0 = (size_t)D.n, nb0 = (size_t)D.nb, n1 = n0 + (size_t)n_rec;
+    HIPCHK(D.parse_nblk.reserve((size_t)n_rec)); HIPCHK(D.parse_rel.reserve((size_t)n_rec));
     HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
     int32_t* tot = D.flags.p + 8;
     { EvTimer t(c, "k_parse_count", (double)nbytes);
-      hipLaunchKernelGGL(k_parse_count, grid_for(n_rec, PARSE_THREADS), dim3(PARSE_THREADS), 0, s, D.bam_chunk.p, nbytes, D.bam_off.p, n_rec, D.parse_nblk.p, D.flags.p);
+      hipLaunchKernelGGL(k_parse_count, grid_for(n_rec, PARSE_THREADS), dim3(PARSE_THREADS), 0, s, d_bam, nbytes, d_off, n_rec, D.parse_nblk.p, D.flags.p);
       HIPCHK((device_scan<OpSum, true>(s, n_rec, FArrN{D.parse_nblk.p}, D.parse_rel.p, D.spine, tot))); }
     int32_t nblk_total = 0;
     HIPCHK(hipMemcpyAsync(&nblk_total, tot, 4, hipMemcpyDeviceToHost, s));
@@ -1681,7 +1967,7 @@ int dev_parse_append(sq_ctx* c, const uint8_t* bam, size_t nbytes, const unsigne
     ChimSetView C{D.chim_mask, D.chim_mask ? D.chim_hash.p : nullptr, D.chim_off.p, D.chim_len.p, D.chim_blob.p};
     ParseParams P{(int)(signed char)(((c->P.phred_type ? 33 : 64) + c->P.min_phred) & 0xff), c->P.max_lowphred_len, c->P.min_mapqual};
     { EvTimer t(c, "k_parse_write", (double)nbytes + 32.0 * n_rec + 12.0 * nblk_total);
-      hipLaunchKernelGGL(k_parse_write, grid_for(n_rec, PARSE_THREADS), dim3(PARSE_THREADS), 0, s, D.bam_chunk.p, nbytes, D.bam_off.p, n_rec, C, P, D.parse_rel.p, (uint32_t)nb0, D.refid.p + n0, D.pos.p + n0, D.mrefid.p + n0,
+      hipLaunchKernelGGL(k_parse_write, grid_for(n_rec, PARSE_THREADS), dim3(PARSE_THREADS), 0, s, d_bam, nbytes, d_off, n_rec, C, P, D.parse_rel.p, (uint32_t)nb0, D.refid.p + n0, D.pos.p + n0, D.mrefid.p + n0,
                          D.mpos.p + n0, D.endpos.p + n0, D.flag.p + n0, D.totlen.p + n0, D.mapq.p + n0, D.aux.p + n0, D.blk_off.p + n0, D.b_refpos.p, D.b_matchref.p, D.b_readpos.p, D.b_matchread.p,
                          D.flags.p); }
     const uint32_t endoff = (uint32_t)nb1;
@@ -1695,6 +1981,78 @@ int dev_parse_append(sq_ctx* c, const uint8_t* bam, size_t nbytes, const unsigne
     D.nb = (int64_t)nb1;
     c->counts.n_concordant = D.n;
     c->counts.n_blocks = D.nb;
+    return SQ_OK;
+}
+
+// K-1 + K0 for a whole file (or a shard's block range): compressed bytes -> HBM, inflate, record boundaries, parse -- the
+// host only indexes the BGZF blocks.  Returns 2 when the device-side boundary check (or the inflate) is not satisfied;
+// nothing has been appended then and the caller takes the host reader.
+int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, const std::vector<BgzfRange>& blocks, size_t b0, size_t b1, size_t begin, bool synced, int nref) {
+    if (b1 <= b0) return SQ_OK;
+    HIPCHK(hipSetDevice(c->P.device));
+    DeviceRecords& D = *c->dev;
+    hipStream_t s = c->stream;
+    const unsigned long long coff0 = blocks[b0].coff, coff1 = blocks[b1 - 1].coff + blocks[b1 - 1].clen, ubase = blocks[b0].uoff;
+    const unsigned long long ubytes = blocks[b1 - 1].uoff + blocks[b1 - 1].isize - ubase;
+    const int nblk = (int)(b1 - b0);
+    std::vector<InflBlock> tab((size_t)nblk);
+    for (int i = 0; i < nblk; ++i) tab[i] = InflBlock{blocks[b0 + i].coff - coff0, blocks[b0 + i].clen, blocks[b0 + i].isize, blocks[b0 + i].uoff};
+    HIPCHK(D.bgzf_in.reserve((size_t)(coff1 - coff0) + 64)); HIPCHK(D.bgzf_out.reserve((size_t)ubytes + 64)); HIPCHK(D.bgzf_tab.reserve((size_t)nblk));
+    HIPCHK(hipMemcpyAsync(D.bgzf_in.p, file + coff0, (size_t)(coff1 - coff0), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(D.bgzf_tab.p, tab.data(), (size_t)nblk * sizeof(InflBlock), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
+    { EvTimer t(c, "k_inflate", (double)(coff1 - coff0) + (double)ubytes);
+      hipLaunchKernelGGL(k_inflate, dim3((nblk + 3) / 4), dim3(256), 0, s, D.bgzf_in.p, D.bgzf_tab.p, 0, nblk, ubase, D.bgzf_out.p, D.flags.p); }
+    const Shard& sh = c->shard;
+    RecScan S{D.bgzf_out.p, (unsigned long long)begin, ubytes, nref, sh.on ? sh.first_ref : -1, sh.on ? sh.end_ref : 0, (sh.on && c->P.rank == c->P.world_size - 1) ? 1 : 0};
+    const long long nsl = (long long)((ubytes - begin + REC_SLICE - 1) / REC_SLICE);
+    if (nsl <= 0) return SQ_OK;
+    HIPCHK(D.rec_sync.reserve((size_t)nsl)); HIPCHK(D.rec_end.reserve((size_t)nsl)); HIPCHK(D.rec_cnt.reserve((size_t)nsl)); HIPCHK(D.rec_base.reserve((size_t)nsl));
+    int32_t* tot = D.flags.p + 8;
+    { EvTimer t(c, "k_rec_boundaries", 2.0 * (double)ubytes);
+      hipLaunchKernelGGL(k_rec_sync, grid_for(nsl, 256), dim3(256), 0, s, S, nsl, synced ? 1 : 0, D.rec_sync.p);
+      hipLaunchKernelGGL(k_rec_walk<false>, grid_for(nsl, 256), dim3(256), 0, s, S, nsl, D.rec_sync.p, D.rec_cnt.p, D.rec_end.p, nullptr, nullptr);
+      hipLaunchKernelGGL(k_rec_check, grid_for(nsl, 256), dim3(256), 0, s, nsl, D.rec_sync.p, D.rec_end.p, D.flags.p);
+      HIPCHK((device_scan<OpSum, true>(s, nsl, FArr{D.rec_cnt.p}, D.rec_base.p, D.spine, tot))); }
+    int32_t h[10];
+    HIPCHK(hipMemcpyAsync(h, D.flags.p, 10 * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (std::getenv("SQUID_INFLATE_CHECK")) {  // debugging: every block against zlib
+        std::vector<uint8_t> got((size_t)ubytes), want;
+        HIPCHK(hipMemcpy(got.data(), D.bgzf_out.p, (size_t)ubytes, hipMemcpyDeviceToHost));
+        long bad = 0;
+        for (int i = 0; i < nblk; ++i) {
+            const BgzfRange& b = blocks[b0 + i];
+            want.resize(b.isize);
+            z_stream zs; std::memset(&zs, 0, sizeof zs);
+            inflateInit2(&zs, -15);
+            zs.next_in = (Bytef*)(file + b.coff); zs.avail_in = b.clen; zs.next_out = want.data(); zs.avail_out = b.isize;
+            inflate(&zs, Z_FINISH); inflateEnd(&zs);
+            if (std::memcmp(want.data(), got.data() + (b.uoff - ubase), b.isize) != 0) {
+                if (bad < 5) { size_t k = 0; while (want[k] == got[(b.uoff - ubase) + k]) ++k; std::fprintf(stderr, "[inflate check] block %d (isize %u clen %u) differs at byte %zu: want %02x got %02x\n", i, b.isize, b.clen, k, want[k], got[(b.uoff - ubase) + k]); }
+                ++bad;
+            }
+        }
+        std::fprintf(stderr, "[inflate check] %ld of %d blocks differ, flags %d, records %d\n", bad, nblk, h[0], h[8]);
+        std::vector<long long> hs((size_t)nsl), he((size_t)nsl);
+        HIPCHK(hipMemcpy(hs.data(), D.rec_sync.p, (size_t)nsl * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(he.data(), D.rec_end.p, (size_t)nsl * 8, hipMemcpyDeviceToHost));
+        int shown = 0;
+        for (long long i = 1; i < nsl && shown < 6; ++i)
+            if (hs[i] >= 0 ? (hs[i - 1] < 0 || he[i - 1] != hs[i]) : false) { std::fprintf(stderr, "[boundary check] slice %lld of %lld: lo %llu sync %lld, previous sync %lld end %lld\n", i, nsl, (unsigned long long)begin + (unsigned long long)i * REC_SLICE, hs[i], hs[i - 1], he[i - 1]); ++shown; }
+    }
+    if (h[0] & (512 | 1024)) return 2;
+    const int64_t n_rec = h[8];
+    if (n_rec == 0) return SQ_OK;
+    HIPCHK(D.bam_off.reserve((size_t)n_rec));
+    hipLaunchKernelGGL(k_rec_walk<true>, grid_for(nsl, 256), dim3(256), 0, s, S, nsl, D.rec_sync.p, nullptr, nullptr, D.rec_base.p, D.bam_off.p);
+    // parse in batches (the per-batch temporaries and the 32-bit block counters stay small)
+    const int64_t kBatch = (int64_t)1 << 24;
+    for (int64_t at = 0; at < n_rec; at += kBatch) {
+        c->ingest_total_bytes = (size_t)n_rec; c->ingest_seen_bytes = (size_t)std::min(at + kBatch, n_rec);  // (in records here: sizes the arrays for all batches at once)
+        int rc = parse_device(c, D.bgzf_out.p, (size_t)ubytes, D.bam_off.p + at, std::min(kBatch, n_rec - at));
+        c->ingest_total_bytes = 0; c->ingest_seen_bytes = 0;
+        if (rc) return rc;
+    }
     return SQ_OK;
 }
 

@@ -116,6 +116,7 @@ class VirtualWorld:
         # the phases (between two exchanges) of the slowest rank's time in that phase
         self.projected_s = 0.0
         self.serial_s = 0.0
+        self.phases = []  # (step name, slowest rank's seconds) per phase between two exchanges
 
     def _timed(self, c, step_name: str):
         import time
@@ -130,6 +131,7 @@ class VirtualWorld:
             res = [self._timed(c, step_name) for c in pending]
             rcs = [r[0] for r in res]
             self.projected_s += max(r[1] for r in res)
+            self.phases.append((step_name, max(r[1] for r in res)))
             self.serial_s += sum(r[1] for r in res)
             if all(rc == 0 for rc in rcs):
                 return

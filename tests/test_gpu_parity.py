@@ -542,3 +542,23 @@ def test_parity_with_indel_and_match_mismatch_cigars(built, synth, tmp_path, exa
         ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
         ctx.build_graph()
         _compare(ctx, dump, sv_path)
+
+
+def test_gpu_bgzf_inflate_and_boundary_search_give_the_same_records(built, synth):
+    """SQUID_GPU_INFLATE=1 (experimental): BGZF blocks inflated by k_inflate, record boundaries found by k_rec_*, against
+    the default host pipeline -- identical SoA"""
+    import json
+    import os
+    import sys
+
+    pre = synth("T2", "--indel-frac", "0.2")
+    code = ("import sys, json, hashlib; sys.path.insert(0, %r); import squid_amd\n"
+            "ctx = squid_amd.Context(); ctx.load(%r, %r); r = ctx.records()\n"
+            "print(json.dumps({k: hashlib.sha256(v.tobytes()).hexdigest() for k, v in r.items()}))") % (str(Path(__file__).resolve().parent.parent), f"{pre}.bam", f"{pre}.chim.bam")
+    outs = []
+    for env in ({}, {"SQUID_GPU_INFLATE": "1", "SQUID_INGEST_TIMING": "1"}):
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, check=True)
+        outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
+        if env:
+            assert "GPU inflate+parse path" in p.stderr and "(rc 0)" in p.stderr
+    assert outs[0] == outs[1]

@@ -49,10 +49,12 @@ for w in worlds:
             rows = vw.call_sv()
             if it:
                 proj.append(vw.projected_s + max(od))
+                last_phases = vw.phases + [("order", max(od))]
         ctxs[0].call_sv = lambda: rows[0]
         same = squid_amd.Context.sv_text(ctxs[0]) == ref
         p = sum(proj) / len(proj)
         shard_n = [c.counts()["n_concordant"] for c in ctxs]
+        print("   phases (ms): " + ", ".join(f"{n.replace('_step','')} {t*1e3:.2f}" for n, t in last_phases))
         print(f"W={w}: projected {p * 1e3:.2f} ms/step -> {base / p:.2f}x  (largest shard {max(shard_n) / n:.1%} of the records, {vw.exchanges} exchanges, {vw.bytes} B, sv identical: {same})")
     finally:
         for c in ctxs:
