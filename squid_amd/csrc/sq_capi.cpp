@@ -790,6 +790,7 @@ int sq_ingest_concordant_file(sq_ctx* c, const char* path, int32_t n_threads) {
     if (!c || !path) return SQ_E_ARG;
     if (!std::getenv("SQUID_HOST_PARSE")) {
         // default: the host only inflates BGZF and finds record boundaries; K0 parses the records on the GPU
+        const auto t_file0 = std::chrono::steady_clock::now();
         c->ingest_total_bytes = 0; c->ingest_seen_bytes = 0;
         const RefRange rr{c->shard.first_ref, c->shard.end_ref, c->P.rank == c->P.world_size - 1};
         int rc = scan_bam_file(path, n_threads, c->err, [&](const uint8_t* bam, size_t nbytes, const unsigned long long* off, int64_t n) { c->ingest_seen_bytes += nbytes; return ingest_raw(c, bam, nbytes, off, n); },
@@ -797,7 +798,9 @@ int sq_ingest_concordant_file(sq_ctx* c, const char* path, int32_t n_threads) {
                                [&](const uint8_t* file, const std::vector<BgzfRange>& blocks, size_t b0, size_t b1, size_t begin, bool synced, int nref) {
                                    return dev_ingest_bgzf(c, file, blocks, b0, b1, begin, synced, nref); });
         c->ingest_total_bytes = 0;
+        const double t_scan = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_file0).count();
         dev_flush_timers(c);
+        if (std::getenv("SQUID_INGEST_TIMING")) std::fprintf(stderr, "ingest %s: reader returned after %.1f ms, timers flushed after %.1f ms\n", path, t_scan, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_file0).count());
         return rc;
     }
     ParseOpts o{c->P.phred_type, c->P.min_phred, c->P.max_lowphred_len, false, &c->chim_set};
