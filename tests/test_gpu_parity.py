@@ -362,6 +362,9 @@ class _ShardView:
     ("T2", (), 4, [(0, 0), (0, 2), (2, 2), (2, 3)]),  # empty shards in front and in the middle
     ("C3", ("--records", "300000"), 4, None),
     ("C3", ("--records", "300000"), 8, None),
+    ("T2", ("--seed", "909", "--tsv", "15"), 3, [(0, 1), (1, 2), (2, 3)]),
+    ("T2", ("--seed", "1234", "--records", "60000"), 2, [(0, 2), (2, 3)]),
+    ("C3", ("--seed", "77", "--records", "200000", "--tsv", "60"), 5, None),
 ])
 def test_chromosome_sharded_run_equals_the_oracle_on_every_rank(built, synth, tmp_path, cfg, extra, world, plan, monkeypatch):
     """one context per (virtual) rank on this GPU, each holding the records of its chromosomes only; the exchanges of
