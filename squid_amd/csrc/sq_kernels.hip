@@ -2241,6 +2241,7 @@ int dev_segment_support(sq_ctx* c, int ncl, int64_t n_rest, SegSupport& out) {
     if (h[0] & 1) return fail(c, SQ_E_UNSORTED, "concordant BAM is not coordinate sorted (README.md:23 requires it)");
     if (ncl && !sh.on) out.trigger.assign(h_trig, h_trig + ncl);
     const int nz = h[8], cnt = want_rest ? h[4] : 0;
+    if (std::getenv("SQUID_PREP_DEBUG")) std::fprintf(stderr, "[prepare] kept %lld zero-coverage records %d ConcordRest candidates %d clusters %d\n", (long long)k, nz, cnt, ncl);
     int32_t *hz = D.pin.take_n<int32_t>(3 * (size_t)nz), *hr = D.pin.take_n<int32_t>(3 * (size_t)cnt);
     if (!hz || !hr) return fail(c, SQ_E_HIP, "hipHostMalloc failed");
     if (nz) {
