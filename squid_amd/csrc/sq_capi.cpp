@@ -209,9 +209,12 @@ static int build_graph(sq_ctx* c) {
         c->counts.n_break = g.n_break;
         {
             HostClock hc(c, "host_segment_replay");
+            g.seedsB.clear(); g.sensB.clear(); g.hasC = false;
+            std::future<int> hypB;  // a shard that does not start the stream replays under both pasts, side by side
+            if (sh.on && sh.prior_kept) hypB = std::async(std::launch::async, [&]() { return segment_replay(c, *g.plan, g.seedsB, true, &g.sensB, nullptr); });
             rc = segment_replay(c, *g.plan, g.seeds, false, nullptr, nullptr);
-            g.seedsA = g.seeds; g.seedsB.clear(); g.sensB.clear(); g.hasC = false;
-            if (!rc && sh.on && sh.prior_kept) rc = segment_replay(c, *g.plan, g.seedsB, true, &g.sensB, nullptr);
+            g.seedsA = g.seeds;
+            if (hypB.valid()) { const int rb = hypB.get(); if (!rc) rc = rb; }
         }
         if (rc) return rc;
         g.stage = 3;
