@@ -86,7 +86,8 @@ struct GraphBuild {
     std::vector<int32_t> sensB;
     bool hasC = false;
     Node seedC{0, 0, 0, 0, 0.0};
-    std::future<double> clusters;     // segment_clusters running next to the record kernels (last member: destroyed, i.e. joined, first)
+    std::future<double> clusters;     // segment_clusters running next to the record kernels
+    ~GraphBuild() { if (clusters.valid()) clusters.wait(); }  // (a pooled task's future does not wait by itself; the task writes into this object)
 };
 
 static int need_exchange(sq_ctx* c) {
@@ -125,7 +126,7 @@ static int build_graph(sq_ctx* c) {
         c->graph_built = false;
         c->ordered = false;
         // the cluster table only needs the chimeric fragments: build it on a second thread next to the record kernels
-        g.clusters = std::async(std::launch::async, [c, &g]() { return segment_clusters(c, g.plan, g.disc); });
+        g.clusters = c->pool->submit([c, &g]() { return segment_clusters(c, g.plan, g.disc); });
         int32_t last[4];
         rc = dev_classify(c, sh.on ? last : nullptr);
         if (rc) { (void)g.clusters.get(); return rc; }
@@ -211,7 +212,7 @@ static int build_graph(sq_ctx* c) {
             HostClock hc(c, "host_segment_replay");
             g.seedsB.clear(); g.sensB.clear(); g.hasC = false;
             std::future<int> hypB;  // a shard that does not start the stream replays under both pasts, side by side
-            if (sh.on && sh.prior_kept) hypB = std::async(std::launch::async, [&]() { return segment_replay(c, *g.plan, g.seedsB, true, &g.sensB, nullptr); });
+            if (sh.on && sh.prior_kept) hypB = c->pool->submit([&]() { return segment_replay(c, *g.plan, g.seedsB, true, &g.sensB, nullptr); });
             rc = segment_replay(c, *g.plan, g.seeds, false, nullptr, nullptr);
             g.seedsA = g.seeds;
             if (hypB.valid()) { const int rb = hypB.get(); if (!rc) rc = rb; }
@@ -277,7 +278,7 @@ static int build_graph(sq_ctx* c) {
         // drives the depth and edge kernels over the concordant stream
         c->edges.clear();
         double chim_ms = 0;
-        std::future<int> chim = std::async(std::launch::async, [&]() {
+        std::future<int> chim = c->pool->submit([&]() {
             const auto t0 = std::chrono::steady_clock::now();
             const int r2 = chimeric_edges(c, g.raw);
             chim_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -471,7 +472,7 @@ static int build_graph(sq_ctx* c) {
     c->gb.reset();
     // ExactBreakpoint only needs the final graph and the trimmed fragments: start it now, sq_call_sv collects it
     c->bp_early = std::make_shared<BPMap>();
-    c->bp_future = std::async(std::launch::async, [c]() {
+    c->bp_future = c->pool->submit([c]() {
         const auto t0 = std::chrono::steady_clock::now();
         const int r2 = exact_breakpoints(c, *c->bp_early);
         c->bp_early_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -670,6 +671,7 @@ int sq_create(const sq_params* p, sq_ctx** out) {
     if (!p || !out || p->abi_version != SQ_ABI_VERSION) return SQ_E_ARG;
     sq_ctx* c = new sq_ctx();
     c->P = *p;
+    c->pool.reset(new HostPool((int)std::min(15u, std::max(1u, std::thread::hardware_concurrency()) - 1)));
     int rc = dev_create(c);
     if (rc) { std::fprintf(stderr, "libsquid_hip: %s\n", c->err.c_str()); dev_destroy(c); delete c; return rc; }
     *out = c;

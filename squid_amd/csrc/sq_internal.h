@@ -3,6 +3,11 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <thread>
+#include <mutex>
+#include <deque>
+#include <condition_variable>
+#include <atomic>
 #include <cstdint>
 #include <functional>
 #include <future>
@@ -86,6 +91,47 @@ struct Timer {
     void clear();
 };
 
+// Host threads of a context, started once (sq_create): single tasks that run next to the GPU work of the calling thread
+// (submit) and index loops (parallel_for; the caller takes part, so a loop started from a pooled task cannot starve).
+class HostPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> q;
+    bool stop = false;
+
+public:
+    explicit HostPool(int n) {
+        for (int i = 0; i < n; ++i) th.emplace_back([this]() {
+            for (;;) {
+                std::function<void()> f;
+                { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return stop || !q.empty(); }); if (stop && q.empty()) return; f = std::move(q.front()); q.pop_front(); }
+                f();
+            }
+        });
+    }
+    ~HostPool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (auto& t : th) t.join(); }
+    int size() const { return (int)th.size(); }
+    template <class F> auto submit(F f) -> std::future<decltype(f())> {
+        auto task = std::make_shared<std::packaged_task<decltype(f())()>>(std::move(f));
+        auto fut = task->get_future();
+        if (th.empty()) { (*task)(); return fut; }
+        { std::lock_guard<std::mutex> lk(mu); q.emplace_back([task]() { (*task)(); }); }
+        cv.notify_one();
+        return fut;
+    }
+    void parallel_for(int count, int max_helpers, const std::function<void(int)>& f) {
+        if (count <= 0) return;
+        auto next = std::make_shared<std::atomic<int>>(0);
+        auto body = [next, count, &f]() { for (int i; (i = next->fetch_add(1)) < count;) f(i); };
+        std::vector<std::future<void>> helpers;
+        const int nh = std::min(std::min(count - 1, max_helpers), size());
+        for (int h = 0; h < nh; ++h) helpers.push_back(submit(body));
+        body();
+        for (auto& h : helpers) h.get();
+    }
+};
+
 struct DeviceRecords;  // HBM-resident SoA + scratch (sq_kernels.hip)
 
 // Chromosome sharding: rank r holds the concordant records of a contiguous RefID range and
@@ -138,6 +184,7 @@ struct sq_ctx {
     // chromosome-sharded runs: sq_build_graph / sq_call_sv return SQ_NEED_EXCHANGE with `xbuf` filled; the caller
     // all-gathers it and hands the result back through sq_exchange_unpack before calling the same function again
     size_t ingest_total_bytes = 0, ingest_seen_bytes = 0;  // file ingest in progress: inflated bytes in the file / handed to the GPU so far
+    std::unique_ptr<sq::HostPool> pool;  // host threads of this context
     sq::Shard shard;
     // ExactBreakpoint (host, chimeric fragments only) runs on a second thread from the end of sq_build_graph, next to
     // sq_order; sq_call_sv collects it

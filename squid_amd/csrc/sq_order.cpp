@@ -495,14 +495,9 @@ int order_components(sq_ctx* c) {
     // the pieces are independent: solve them on a few host threads (biggest first)
     std::sort(large.begin(), large.end(), [&](int x, int y) { return B.pieces[x].ids.size() > B.pieces[y].ids.size(); });
     // (a handful of pieces is done before the threads would have started)
-    const int nthr = large.size() <= 8 ? 1 : (int)std::min<size_t>(std::min<size_t>(large.size() / 4, 16), std::max(1u, std::thread::hardware_concurrency()));
-    if (nthr <= 1) for (int pi : large) solve(pi);
-    else {
-        std::atomic<size_t> next{0};
-        std::vector<std::thread> pool;
-        for (int t = 0; t < nthr; ++t) pool.emplace_back([&]() { for (size_t i; (i = next.fetch_add(1)) < large.size();) solve(large[i]); });
-        for (auto& th : pool) th.join();
-    }
+    // (a handful of pieces is done before a helper would have picked one up)
+    if (large.size() <= 4) for (int pi : large) solve(pi);
+    else c->pool->parallel_for((int)large.size(), 15, [&](int i) { solve(large[(size_t)i]); });
     c->timer.add("host_order_large", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     std::vector<int> sign_scratch((size_t)n, 1);
     c->ord_off.assign(1, 0);

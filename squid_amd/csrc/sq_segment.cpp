@@ -708,16 +708,10 @@ int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds, bool virt
     starts.push_back(na);
     struct Out { std::vector<Node> seeds; std::vector<int32_t> sens; int rc = 0; std::string err; };
     std::vector<Out> res(ng);
-    std::atomic<size_t> next{0};
-    auto work = [&]() {
-        for (size_t g; (g = next.fetch_add(1)) < ng;)
-            res[g].rc = replay_range(c, plan, starts[g], starts[g + 1], res[g].seeds, g == 0 ? virtual_back : true, &res[g].sens, res[g].err);
-    };
-    const int nthr = (int)std::min<size_t>(std::min<size_t>(ng, 16), std::max(1u, std::thread::hardware_concurrency()));
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nthr; ++t) pool.emplace_back(work);
-    work();
-    for (auto& th : pool) th.join();
+    c->pool->parallel_for((int)ng, 15, [&](int gi) {
+        const size_t g = (size_t)gi;
+        res[g].rc = replay_range(c, plan, starts[g], starts[g + 1], res[g].seeds, g == 0 ? virtual_back : true, &res[g].sens, res[g].err);
+    });
     // check the assumption group by group: a node must exist before the group, on an earlier chromosome than the group's
     // first record, and none of the recorded comparisons may hit its end
     bool ok = true, local_have = false;
