@@ -176,6 +176,8 @@ typedef struct sq_timing {
     const double* bytes; /* algorithmic bytes moved by the kernel (0 for host stages) */
 } sq_timing;
 int sq_get_timing(sq_ctx* c, sq_timing* t);
+/* keep = 1: sq_build_graph no longer clears the timing table, so it accumulates over repeated runs (bench loops read it once) */
+int sq_timing_accumulate(sq_ctx* c, int32_t keep);
 int sq_reset(sq_ctx* c); /* drop graph results, keep ingested records resident in HBM (bench re-runs) */
 
 typedef struct sq_counts {

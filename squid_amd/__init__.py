@@ -20,7 +20,7 @@ EXPORTS = [
     "sq_default_params", "sq_create", "sq_destroy", "sq_strerror", "sq_last_error", "sq_set_references",
     "sq_ingest_chimeric", "sq_chim_contains", "sq_ingest_concordant", "sq_ingest_concordant_bam", "sq_read_header", "sq_ingest_chimeric_file",
     "sq_ingest_concordant_file", "sq_build_graph", "sq_graph_view", "sq_order", "sq_call_sv", "sq_breakpoints",
-    "sq_set_shard", "sq_exchange_pack", "sq_exchange_unpack", "sq_get_timing", "sq_reset", "sq_get_counts", "sq_debug_download", "sq_debug_bp_support", "sq_debug_order",
+    "sq_set_shard", "sq_exchange_pack", "sq_exchange_unpack", "sq_get_timing", "sq_timing_accumulate", "sq_reset", "sq_get_counts", "sq_debug_download", "sq_debug_bp_support", "sq_debug_order",
 ]
 
 
@@ -284,6 +284,11 @@ class Context:
         self.lib.sq_debug_order.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
         self._chk(self.lib.sq_debug_order(self.h, n, len(edges), flat, int(use_gpu), C.byref(mask), order, C.byref(value)), "sq_debug_order")
         return mask.value, list(order), value.value
+
+    def timing_accumulate(self, keep: bool = True):
+        """let the timing table accumulate over repeated build_graph/order/call_sv runs (read it once with timing())"""
+        self.lib.sq_timing_accumulate.argtypes = [C.c_void_p, C.c_int32]
+        self._chk(self.lib.sq_timing_accumulate(self.h, int(keep)), "sq_timing_accumulate")
 
     def timing(self) -> dict:
         t = SqTiming()

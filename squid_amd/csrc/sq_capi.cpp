@@ -821,7 +821,7 @@ int sq_build_graph(sq_ctx* c) {
     if (c->read_len <= 0) return fail(c, SQ_E_ARG, "sq_ingest_chimeric first (ReadLen comes from the chimeric BAM)");
     if (c->shard.on != (c->P.world_size > 1)) return fail(c, SQ_E_ARG, "world_size > 1 needs sq_set_shard (and the other way round)");
     if (c->bp_future.valid()) (void)c->bp_future.get();
-    if (!c->gb) c->timer.clear();
+    if (!c->gb && !c->timer_keep) c->timer.clear();
     int rc = build_graph(c);
     dev_flush_timers(c);
     if (rc < 0) { c->gb.reset(); c->x_pending = false; }
@@ -863,6 +863,12 @@ int sq_get_timing(sq_ctx* c, sq_timing* t) {
     if (!c || !t) return SQ_E_ARG;
     t->n = (int32_t)c->timer.names.size();
     t->names = c->timer.names.data(); t->ms = c->timer.ms.data(); t->launches = c->timer.launches.data(); t->bytes = c->timer.bytes.data();
+    return SQ_OK;
+}
+int sq_timing_accumulate(sq_ctx* c, int32_t keep) {
+    if (!c) return SQ_E_ARG;
+    c->timer_keep = keep != 0;
+    if (keep) c->timer.clear();
     return SQ_OK;
 }
 int sq_reset(sq_ctx* c) {

@@ -180,6 +180,7 @@ struct sq_ctx {
     std::vector<uint8_t> sv_s1, sv_s2;
     std::vector<int32_t> bp_off, bp1, bp2, bsup1, bsup2;
     sq::Timer timer;
+    bool timer_keep = false;  // sq_timing_accumulate
     sq_counts counts{};
     // chromosome-sharded runs: sq_build_graph / sq_call_sv return SQ_NEED_EXCHANGE with `xbuf` filled; the caller
     // all-gathers it and hands the result back through sq_exchange_unpack before calling the same function again
