@@ -146,6 +146,8 @@ struct DeviceRecords {
     DBuf<uint8_t> bam_chunk, bgzf_in, bgzf_out;
     DBuf<InflBlock> bgzf_tab;
     DBuf<long long> rec_sync, rec_end;
+    DBuf<uint32_t> il_tok;
+    DBuf<int32_t> il_ntok;
     DBuf<int32_t> rec_cnt, rec_base;
     DBuf<unsigned long long> bam_off, chim_hash;
     DBuf<uint32_t> chim_off, chim_len;
@@ -389,16 +391,26 @@ __global__ void k_calib_read4(const int32_t* a, int64_t n, int32_t* out) {
 // strand-mirrored read offsets, GetEndPosition(), XA / IH tags (src/SegmentGraph.cpp:297-301) and the QNAME lookup in
 // the chimeric name set (:302) -- and writes the SoA layout directly.  Two passes: count blocks, scan, write.
 struct ChimSetView { uint32_t mask; const unsigned long long* hash; const uint32_t *off, *len; const char* blob; };
-struct ParseParams { int qual_thr, max_lowphred_len, min_mapq; };
+struct ParseParams { int qual_thr, max_lowphred_len, min_mapq, skip; };
 __device__ __forceinline__ int ld32(const uint8_t* p) { return (int)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); }
 __device__ __forceinline__ int ld16(const uint8_t* p) { return (int)p[0] | ((int)p[1] << 8); }
-__device__ __forceinline__ char cig_type(uint32_t v) { const char ops[] = {'M', 'I', 'D', 'N', 'S', 'H', 'P', '=', 'X', '?', '?', '?', '?', '?', '?', '?'}; return ops[v & 0xf]; }
+__device__ __forceinline__ char cig_type(uint32_t v) {  // "MIDNSHP=X", packed into registers (an indexed local array becomes a memory load per op)
+    const unsigned long long lo = 0x3d5048534e44494dull;  // 'M' 'I' 'D' 'N' 'S' 'H' 'P' '='
+    const uint32_t k = v & 0xf;
+    return k < 8 ? (char)(lo >> (8 * k)) : (k == 8 ? 'X' : '?');
+}
+// slot of a name hash: FNV-1a of short, nearly sequential names ("r1234567") leaves its middle bits clustered -- probe chains
+// hundreds of slots long -- so the hash goes through a 64-bit finaliser first
+__host__ __device__ __forceinline__ uint32_t chim_slot(unsigned long long h, uint32_t mask) {
+    h ^= h >> 33; h *= 0xff51afd7ed558ccdull; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 33;
+    return (uint32_t)h & mask;
+}
 __device__ bool chim_contains(const ChimSetView& C, const uint8_t* name, int n) {
     if (!C.hash) return false;
     unsigned long long h = 1469598103934665603ull;
     for (int i = 0; i < n; ++i) { h ^= name[i]; h *= 1099511628211ull; }
     if (h == 0) h = 1;
-    for (uint32_t s = (uint32_t)(h >> 20) & C.mask, probes = 0; probes <= C.mask; s = (s + 1) & C.mask, ++probes) {
+    for (uint32_t s = chim_slot(h, C.mask), probes = 0; probes <= C.mask; s = (s + 1) & C.mask, ++probes) {
         unsigned long long e = C.hash[s];
         if (e == 0) return false;
         if (e == h && (int)C.len[s] == n) {
@@ -516,7 +528,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_parse_write(const uint8_t* ba
         if (t == 'M' || t == 'D' || t == 'N' || t == '=' || t == 'X') endpos += len;
     }
     int lowrun = 0, run = 0;
-    for (int i = 0; i < lseq; ++i) {
+    if (!(P.skip & 2)) for (int i = 0; i < lseq; ++i) {
         int c = (signed char)((qual[i] + 33) & 0xff);
         run = (c < P.qual_thr) ? run + 1 : 0;
         if (run > lowrun) lowrun = run;
@@ -524,7 +536,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_parse_write(const uint8_t* ba
     // aux: XA present, first IH value (integer typed)
     bool has_xa = false, has_ih = false, bad = false;
     int ih = 0;
-    for (const uint8_t* q = aux; q + 3 <= pend;) {
+    if (!(P.skip & 4)) for (const uint8_t* q = aux; q + 3 <= pend;) {
         uint8_t t0 = q[0], t1 = q[1], ty = q[2];
         const uint8_t* v = q + 3;
         size_t sz;
@@ -551,14 +563,15 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_parse_write(const uint8_t* ba
     uint8_t ax = 0;
     if (has_xa || ih > 1) ax |= SQ_AUX_MULTI;
     if (lowrun > P.max_lowphred_len) ax |= SQ_AUX_LOWPHRED;
-    if (chim_contains(C, name, lname > 0 ? lname - 1 : 0)) ax |= SQ_AUX_INCHIM;
+    if (!(P.skip & 1) && chim_contains(C, name, lname > 0 ? lname - 1 : 0)) ax |= SQ_AUX_INCHIM;
     const uint32_t b0 = blk_base + (uint32_t)blk_rel[r];
-    int nb = parse_blocks<true>(cg, ncig, seq, lseq, pos, flag & 0x10, totlen, b_refpos + b0, b_matchref + b0, b_readpos + b0, b_matchread + b0);
+    int nb = (P.skip & 8) ? 0 : parse_blocks<true>(cg, ncig, seq, lseq, pos, flag & 0x10, totlen, b_refpos + b0, b_matchref + b0, b_readpos + b0, b_matchread + b0);
     if (nb < 0) {
         // the reference constructs a ReadRec_t only for records that pass its filters; for those the assert is live
         bool filtered = (ax & (SQ_AUX_MULTI | SQ_AUX_INCHIM)) || (flag & 0x400) || (flag & 0x4) || mapq < P.min_mapq;
         if (!filtered) atomicOr(&flags[0], 256);
     }
+    if (P.skip & 16) return;
     o_refid[r] = refid; o_pos[r] = pos; o_mrefid[r] = mrefid; o_mpos[r] = mpos; o_endpos[r] = endpos;
     o_flag[r] = (uint16_t)flag; o_totlen[r] = (uint16_t)totlen; o_mapq[r] = (uint8_t)mapq; o_aux[r] = ax;
     o_blkoff[r] = b0;
@@ -1696,6 +1709,391 @@ __global__ __launch_bounds__(256) void k_inflate(const uint8_t* file, const Infl
     if (err || outpos != blk.isize) { if (lane == 0) atomicOr(&flags[0], 512); }
 }
 
+// Lane-per-block variant: every lane of a wave inflates its own BGZF block (64 independent streams in lockstep), so the
+// vector unit does 64 symbols per step instead of one.  Per lane: fast tables in LDS (9-bit literal/length, 6-bit
+// distance, interleaved by lane), the count/symbol arrays of the slow path and the code-length scratch in global memory.
+// A lane either decodes one symbol or copies up to 8 bytes of a pending match per step, so long matches do not stall
+// the other lanes.  A lane only reads what it wrote itself: program order makes that visible, no fences.
+constexpr int IL_LB = 9, IL_DB = 7, IL_STAGE = 8;
+constexpr size_t IL_LDS_BYTES = (size_t)((1 << IL_LB) + (1 << IL_DB) + 2 * 16 + 288 + 32 + 2 * 2) * 64 * sizeof(uint16_t) + (size_t)(IL_STAGE + 32) * 64 * 4;  // (32 = IL_RING)
+// The compressed bytes of a lane go through a ring of IL_RING words in LDS (ring[(word % IL_RING) * 64], already offset
+// by the lane): the bit buffer refills from LDS, and the ring is topped up from global memory by all lanes in the same
+// step, when any of them runs low.  A load issued by one lane in one step would otherwise make the whole wave wait a
+// memory round trip in the next (the counters that order memory operations are per wave, not per lane).
+// org: byte offset of ring word 0 in the block; rd / ld: words moved into the bit buffer / loaded into the ring.
+constexpr int IL_RING = 32;
+struct ILane {
+    const uint8_t* p; uint32_t* ring; uint32_t n, org; int rd, ld; unsigned long long buf; int cnt;
+};
+__device__ __forceinline__ uint4 il_load16(const uint8_t* p) { uint4 w; __builtin_memcpy(&w, p, 16); return w; }
+__device__ __forceinline__ uint32_t il_pos(const ILane& b) { return b.org + 4u * (uint32_t)b.rd; }  // bytes moved into the bit buffer
+__device__ __forceinline__ bool il_low(const ILane& b) { return b.ld - b.rd < 6; }  // (a step takes at most 56 bits, the fixed part of a block header 74)
+__device__ __forceinline__ void il_topup(ILane& b) {  // as many 16-byte pieces as fit, loads first, then the LDS stores
+    constexpr int PIECES = IL_RING / 4;
+    uint4 w[PIECES];
+    const int free_pieces = (IL_RING - (b.ld - b.rd)) >> 2;
+    const uint8_t* src = b.p + b.org + 4u * (uint32_t)b.ld;
+#pragma unroll
+    for (int k = 0; k < PIECES; ++k) if (k < free_pieces) w[k] = il_load16(src + 16 * k);
+#pragma unroll
+    for (int k = 0; k < PIECES; ++k)
+        if (k < free_pieces) {
+            const int at = b.ld + 4 * k;
+            b.ring[((at + 0) & (IL_RING - 1)) * 64] = w[k].x; b.ring[((at + 1) & (IL_RING - 1)) * 64] = w[k].y;
+            b.ring[((at + 2) & (IL_RING - 1)) * 64] = w[k].z; b.ring[((at + 3) & (IL_RING - 1)) * 64] = w[k].w;
+        }
+    b.ld += 4 * free_pieces;
+}
+__device__ __forceinline__ void il_start(ILane& b, uint32_t at) {
+    b.org = at; b.rd = 0; b.ld = 0; b.buf = 0; b.cnt = 0;
+    il_topup(b);
+}
+__device__ __forceinline__ void il_refill(ILane& b) {
+    if (b.cnt <= 32) {
+        const uint32_t w = b.ring[(b.rd & (IL_RING - 1)) * 64];
+        b.buf |= (unsigned long long)w << b.cnt; b.cnt += 32; ++b.rd;
+    }
+}
+__device__ __forceinline__ uint32_t il_take(ILane& b, int k) {
+    il_refill(b);
+    const uint32_t v = (uint32_t)(b.buf & ((1ull << k) - 1));
+    b.buf >>= k; b.cnt -= k;
+    return v;
+}
+// One Huffman code of every lane, all of it in LDS and interleaved by lane ([entry * 64 + lane]): fast[1 << FB] (symbol << 4
+// | length for codes of at most FB bits), cnt[16] codes per length, sym[] the symbols in canonical order, fst[2] the
+// canonical decoder's (first code, symbol index) after FB lengths -- where the slow path picks up.  Anything a lane has
+// to fetch from global memory costs the whole wave a memory round trip per step: with 64 streams some lane is on the slow
+// path nearly every step.
+struct ITab { uint16_t *fast, *cnt, *sym, *fst; int FB; };
+// Tables of lane T, built by the whole wave from the code lengths in sh_lens[0..n) (LDS).  sh_tmp: 64 words of LDS
+// scratch.  Returns false (uniformly) for an over-subscribed set.
+__device__ bool il_build_coop(const ITab& t, int T, const uint8_t* sh_lens, int n, int* sh_tmp) {
+    const int lane = threadIdx.x, FB = t.FB;
+    if (lane < 16) sh_tmp[lane] = 0;
+    wave_sync();
+    for (int i = lane; i < n; i += 64) atomicAdd(&sh_tmp[sh_lens[i]], 1);
+    wave_sync();
+    // lane 0: over-subscription test, first code and first sym slot per length -> sh_tmp[16 + l], sh_tmp[32 + l]
+    if (lane == 0) {
+        int left = 1, code = 0, off = 0, ok = 1;
+        for (int l = 1; l <= 15; ++l) {
+            left <<= 1; left -= sh_tmp[l]; if (left < 0) ok = 0;
+            code = (code + (l > 1 ? sh_tmp[l - 1] : 0)) << 1;
+            sh_tmp[16 + l] = code; sh_tmp[32 + l] = off;
+            off += sh_tmp[l];
+        }
+        sh_tmp[48] = ok;
+        int first = 0, index = 0;
+        for (int l = 1; l <= FB; ++l) { index += sh_tmp[l]; first += sh_tmp[l]; first <<= 1; }
+        t.fst[T] = (uint16_t)first; t.fst[64 + T] = (uint16_t)index;
+    }
+    wave_sync();
+    if (!sh_tmp[48]) return false;
+    if (lane < 16) t.cnt[lane * 64 + T] = lane ? (uint16_t)sh_tmp[lane] : 0;
+    for (int e = lane; e < (1 << FB); e += 64) t.fast[e * 64 + T] = 0;
+    wave_sync();
+    // symbols in chunks of 64, in order: rank among the symbols of the same length = canonical index
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const int l = i < n ? sh_lens[i] : 0;
+        int rank = 0, code0 = 0, slot0 = 0;
+        for (int L = 1; L <= 15; ++L) {
+            const unsigned long long m = __ballot(l == L);
+            if (!m) continue;
+            if (l == L) { rank = __popcll(m & ((1ull << lane) - 1)); code0 = sh_tmp[16 + L]; slot0 = sh_tmp[32 + L]; }
+            wave_sync();
+            if (lane == 0) { sh_tmp[16 + L] += __popcll(m); sh_tmp[32 + L] += __popcll(m); }
+            wave_sync();
+        }
+        if (l) {
+            t.sym[(slot0 + rank) * 64 + T] = (uint16_t)i;
+            if (l <= FB) {
+                const uint32_t c = (uint32_t)(code0 + rank);
+                const uint32_t rev = __brev(c) >> (32 - l);
+                for (uint32_t j = rev; j < (1u << FB); j += 1u << l) t.fast[j * 64 + T] = (uint16_t)((i << 4) | l);
+            }
+        }
+    }
+    wave_sync();
+    return true;
+}
+__device__ __forceinline__ int il_decode(ILane& b, const ITab& t, int lane) {
+    il_refill(b);
+    const uint32_t root = (uint32_t)b.buf & ((1u << t.FB) - 1);
+    const uint16_t e = t.fast[root * 64 + lane];
+    if (e & 15) { const int l = e & 15; b.buf >>= l; b.cnt -= l; return e >> 4; }
+    // longer than FB bits: the canonical decoder, entered after FB lengths
+    int code = (int)(__brev(root) >> (32 - t.FB)) << 1, first = t.fst[lane], index = t.fst[64 + lane];
+    unsigned long long bb = b.buf >> t.FB;
+    for (int len = t.FB + 1; len <= 15; ++len) {
+        code |= (int)(bb & 1); bb >>= 1;
+        const int count = t.cnt[len * 64 + lane];
+        if (code - count < first) { b.buf >>= len; b.cnt -= len; return t.sym[(index + (code - first)) * 64 + lane]; }
+        index += count; first += count; first <<= 1; code <<= 1;
+    }
+    return -1;
+}
+// TOK: instead of the bytes, the lane writes its block's LZ77 tokens (a literal: the byte; a match: bit 31, length in bits
+// 16..24, distance - 1 in bits 0..14) at tok[uoff - out_base ...] and their number at ntok[block]; k_lz_resolve turns them
+// into bytes.  Decoding alone never reads what it wrote, so the lanes run without waiting for their stores.
+template <bool TOK>
+__global__ __launch_bounds__(64) void k_inflate_lanes(const uint8_t* file, const InflBlock* blocks, int nblocks, unsigned long long out_base, uint8_t* outbuf, int32_t* flags, uint32_t* tok, int32_t* ntok) {
+    extern __shared__ uint16_t il_lds[];  // IL_LDS_BYTES: the two ITabs, then [IL_STAGE] x 64 token words
+    __shared__ uint16_t sh_lb[32], sh_db[32];
+    __shared__ uint8_t sh_le[32], sh_de[32];
+    __shared__ uint8_t sh_lens[352];
+    __shared__ int sh_tmp[64];
+    __shared__ int sh_hdr[4];
+    ITab LL, DD;
+    LL.FB = IL_LB; DD.FB = IL_DB;
+    LL.fast = il_lds;                       DD.fast = LL.fast + (1 << IL_LB) * 64;
+    LL.cnt = DD.fast + (1 << IL_DB) * 64;   DD.cnt = LL.cnt + 16 * 64;
+    LL.sym = DD.cnt + 16 * 64;              DD.sym = LL.sym + 288 * 64;
+    LL.fst = DD.sym + 32 * 64;              DD.fst = LL.fst + 2 * 64;
+    uint32_t* stage = (uint32_t*)(DD.fst + 2 * 64);
+    uint32_t* ring = stage + IL_STAGE * 64;  // tokens on their way out: stage[(k % IL_STAGE) * 64 + lane]
+    const int lane = threadIdx.x;
+    if (lane < 29) { sh_lb[lane] = c_lbase[lane]; sh_le[lane] = c_lext[lane]; }
+    if (lane < 30) { sh_db[lane] = c_dbase[lane]; sh_de[lane] = c_dext[lane]; }
+    wave_sync();
+    const int bi = blockIdx.x * 64 + lane;
+    const bool have = bi < nblocks;
+    InflBlock blk{0, 0, 0, 0};
+    if (have) blk = blocks[bi];
+    uint8_t* out = outbuf + (blk.uoff - out_base);
+    uint32_t* tk = TOK ? tok + (blk.uoff - out_base) : nullptr;
+    uint32_t nt = 0;
+    auto emit = [&](uint32_t v) {
+        stage[(nt % IL_STAGE) * 64 + lane] = v;
+        if ((++nt % IL_STAGE) == 0) {  // a full stage: IL_STAGE consecutive tokens in wide stores
+            uint32_t* dst = tk + nt - IL_STAGE;
+#pragma unroll
+            for (int q = 0; q < IL_STAGE; q += 4) {
+                uint4 w{stage[q * 64 + lane], stage[(q + 1) * 64 + lane], stage[(q + 2) * 64 + lane], stage[(q + 3) * 64 + lane]};
+                __builtin_memcpy(dst + q, &w, 16);
+            }
+        }
+    };
+    ILane b;
+    b.p = file + blk.coff; b.n = blk.clen; b.ring = ring + lane;
+    il_start(b, 0);
+    uint32_t outpos = 0, pend_len = 0, pend_src = 0;
+    bool done = !have || blk.isize == 0, err = false, in_block = false, last = false, stored = false;
+    uint32_t stored_left = 0, stored_at = 0;
+    int dbg_iter = 0, dbg_hdr = 0;
+    long long dbg_t0 = wall_clock64(), dbg_th = 0, dbg_tt = 0;
+    while (__any(!done)) {
+        ++dbg_iter;
+        // ---- block headers: one lane at a time reads its header, the whole wave builds that lane's tables
+        unsigned long long need = __ballot(!done && !in_block && !pend_len && !stored);
+        const long long dbg_h0 = wall_clock64();
+        while (need) {
+            const int T = __ffsll((long long)need) - 1;
+            need &= need - 1;
+            ++dbg_hdr;
+            if (lane == T) {
+                int kind = -1, nlen = 0, ndist = 0;
+                if (il_low(b)) il_topup(b);
+                if (il_pos(b) <= b.n + 8) {
+                    last = il_take(b, 1);
+                    const uint32_t type = il_take(b, 2);
+                    if (type == 0) {
+                        b.buf >>= (b.cnt & 7); b.cnt -= (b.cnt & 7);
+                        const uint32_t len = il_take(b, 16), nl = il_take(b, 16);
+                        stored_at = il_pos(b) - (uint32_t)(b.cnt >> 3);
+                        if ((len ^ 0xffff) == nl && stored_at + len <= b.n && outpos + len <= blk.isize) {
+                            kind = 0;
+                            stored_left = len;
+                            if (len) stored = true; else { il_start(b, stored_at); if (last) done = true; }
+                        }
+                    } else if (type == 1) {
+                        for (int i = 0; i < 144; ++i) sh_lens[i] = 8;
+                        for (int i = 144; i < 256; ++i) sh_lens[i] = 9;
+                        for (int i = 256; i < 280; ++i) sh_lens[i] = 7;
+                        for (int i = 280; i < 288; ++i) sh_lens[i] = 8;
+                        for (int i = 0; i < 30; ++i) sh_lens[288 + i] = 5;
+                        kind = 1; nlen = 288; ndist = 30;
+                    } else if (type == 2) {
+                        nlen = (int)il_take(b, 5) + 257; ndist = (int)il_take(b, 5) + 1;
+                        const int ncode = (int)il_take(b, 4) + 4;
+                        if (nlen <= 286 && ndist <= 30) {
+                            for (int i = 0; i < 19; ++i) sh_lens[i] = 0;
+                            for (int i = 0; i < ncode; ++i) sh_lens[c_clorder[i]] = (uint8_t)il_take(b, 3);
+                            kind = 2;
+                        }
+                    }
+                }
+                sh_hdr[0] = kind; sh_hdr[1] = nlen; sh_hdr[2] = ndist;
+            }
+            wave_sync();
+            int kind = sh_hdr[0];
+            const int nlen = sh_hdr[1], ndist = sh_hdr[2];
+            if (kind == 2) {
+                // the code-length code (19 symbols), then lane T reads the litlen + dist lengths with it
+                bool ok = il_build_coop(DD, T, sh_lens, 19, sh_tmp);
+                if (lane == T) {
+                    int idx = 0;
+                    uint8_t prev = 0;
+                    while (ok && idx < nlen + ndist) {
+                        if (il_low(b)) il_topup(b);
+                        const int sym = il_decode(b, DD, lane);
+                        if (sym < 0 || il_pos(b) > b.n + 8) { ok = false; break; }
+                        if (sym < 16) { sh_lens[idx++] = (uint8_t)sym; prev = (uint8_t)sym; }
+                        else {
+                            int rep; uint8_t v = 0;
+                            if (sym == 16) { if (idx == 0) { ok = false; break; } v = prev; rep = 3 + (int)il_take(b, 2); }
+                            else if (sym == 17) rep = 3 + (int)il_take(b, 3);
+                            else rep = 11 + (int)il_take(b, 7);
+                            if (idx + rep > nlen + ndist) { ok = false; break; }
+                            while (rep--) sh_lens[idx++] = v;
+                            prev = v;
+                        }
+                    }
+                    if (ok && sh_lens[256] == 0) ok = false;  // no end-of-block code
+                    sh_hdr[0] = ok ? 2 : -1;
+                }
+                wave_sync();
+                kind = sh_hdr[0];
+            }
+            if (kind == 1 || kind == 2) {
+                const bool ok = il_build_coop(LL, T, sh_lens, nlen, sh_tmp) && il_build_coop(DD, T, sh_lens + nlen, ndist, sh_tmp);
+                if (!ok) kind = -1;
+            }
+            if (lane == T) { if (kind < 0) { err = true; done = true; } else if (kind > 0) in_block = true; }
+            wave_sync();
+        }
+        const long long dbg_h1 = wall_clock64();
+        dbg_th += dbg_h1 - dbg_h0;
+        if (__any(!done && il_low(b))) { if (!done) il_topup(b); dbg_tt += wall_clock64() - dbg_h1; }  // every lane, in the same step
+        if (done) continue;
+        if (!TOK && pend_len) {  // a slice of a pending match (source bytes were written by this lane)
+            // eight bytes per step: one wide load, one wide store (byte-wise, every byte waits for a memory round trip)
+            const uint32_t k = pend_len < 8 ? pend_len : 8, dist = outpos - pend_src;
+            unsigned long long w;
+            __builtin_memcpy(&w, out + pend_src, 8);  // (reads at most 7 bytes past what is written: inside the padded buffer)
+            if (dist < 8) {  // overlapping match: the first `dist` bytes repeat
+                unsigned long long r = 0;
+                for (uint32_t i = 0; i < 8; ++i) r |= ((w >> (8 * (i % dist))) & 0xffull) << (8 * i);
+                w = r;
+            }
+            if (k == 8) __builtin_memcpy(out + outpos, &w, 8);
+            else for (uint32_t i = 0; i < k; ++i) out[outpos + i] = (uint8_t)(w >> (8 * i));
+            outpos += k; pend_len -= k;
+            pend_src += k;  // (the distance stays the same: the next slice again starts from `dist` valid bytes)
+            continue;
+        }
+        if (stored) {  // a slice of a stored block
+            const uint32_t k = stored_left < 16 ? stored_left : 16;
+            if (TOK) for (uint32_t i = 0; i < k; ++i) emit(b.p[stored_at + i]);
+            else for (uint32_t i = 0; i < k; ++i) out[outpos + i] = b.p[stored_at + i];
+            outpos += k; stored_at += k; stored_left -= k;
+            if (!stored_left) { stored = false; il_start(b, stored_at); if (last) done = true; }
+            continue;
+        }
+        if (!in_block) continue;  // (its header is read at the top of the next round)
+        // one symbol
+        const int sym = il_decode(b, LL, lane);
+        if (sym < 0 || il_pos(b) > b.n + 8) { err = true; done = true; continue; }
+        if (sym < 256) {
+            if (outpos >= blk.isize) { err = true; done = true; continue; }
+            if (TOK) { emit((uint32_t)sym); ++outpos; } else out[outpos++] = (uint8_t)sym;
+            continue;
+        }
+        if (sym == 256) { in_block = false; if (last) done = true; continue; }
+        const int ls = sym - 257;
+        if (ls >= 29) { err = true; done = true; continue; }
+        const uint32_t len = sh_lb[ls] + il_take(b, sh_le[ls]);
+        const int ds = il_decode(b, DD, lane);
+        if (ds < 0 || ds >= 30) { err = true; done = true; continue; }
+        const uint32_t dist = sh_db[ds] + il_take(b, sh_de[ds]);
+        if (dist > outpos || outpos + len > blk.isize) { err = true; done = true; continue; }
+        if (TOK) { emit(0x80000000u | (len << 16) | (dist - 1)); outpos += len; }
+        else { pend_len = len; pend_src = outpos - dist; }
+    }
+    if (have && (err || outpos != blk.isize)) atomicOr(&flags[0], 512);
+    if (lane == 0) { atomicAdd(&flags[2], dbg_iter); atomicAdd(&flags[3], dbg_hdr); atomicAdd(&flags[5], (int)(dbg_th / 100)); atomicAdd(&flags[6], (int)(dbg_tt / 100)); atomicAdd(&flags[7], (int)((wall_clock64() - dbg_t0) / 100)); }
+    if (TOK && have) atomicAdd(&flags[4], (int)(nt >> 4));
+    if (TOK && have) {
+        for (uint32_t k = nt - nt % IL_STAGE; k < nt; ++k) tk[k] = stage[(k % IL_STAGE) * 64 + lane];
+        ntok[bi] = (int32_t)nt;
+    }
+}
+
+
+// Inclusive prefix sum over the wave with DPP row shifts (no LDS traffic).
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return x;
+}
+// LZ77 resolution: one wave per BGZF block, the block's output (<= 64 KiB) in LDS.  64 tokens per round: a prefix sum of
+// their lengths places them, literals are stored at once, and the matches copy in as few sub-rounds as their dependencies
+// allow -- a match is ready when its source lies below the output of the first match still pending (everything below
+// that is final); a match overlapping its own output only needs the bytes in front of it, its pattern repeats.
+__global__ __launch_bounds__(64) void k_lz_resolve(const uint32_t* tok, const int32_t* ntok, const InflBlock* blocks, int nblocks, unsigned long long out_base, uint8_t* outbuf, int32_t* flags) {
+    extern __shared__ uint8_t lz_win[];
+    const int lane = threadIdx.x;
+    const InflBlock blk = blocks[blockIdx.x];
+    const uint32_t* t = tok + (blk.uoff - out_base);
+    const int n = ntok[blockIdx.x];
+    uint32_t base = 0;
+    uint32_t nxt = lane < n ? t[lane] : 0;
+    bool bad = false;
+    for (int r0 = 0; r0 < n; r0 += 64) {
+        const uint32_t tk = nxt;
+        const int i = r0 + lane;
+        if (i + 64 < n) nxt = t[i + 64];
+        const bool valid = i < n, is_m = valid && (tk >> 31);
+        const uint32_t len = !valid ? 0u : (is_m ? (tk >> 16) & 0x1ffu : 1u);
+        const uint32_t inc = wave_scan_incl(len);
+        const uint32_t o = base + inc - len;
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        if (base + total > blk.isize) { bad = true; break; }  // (uniform)
+        if (valid && !is_m) lz_win[o] = (uint8_t)tk;
+        const uint32_t dist = (tk & 0x7fffu) + 1;
+        bool pending = is_m;
+        if (pending && dist > o) { bad = true; pending = false; }
+        const uint32_t src = o - dist;
+        const uint32_t ready_at = src + len < o ? src + len : o;  // the match needs the bytes below this
+        unsigned long long pm = __ballot(pending);
+        while (pm) {
+            const int first = __ffsll((long long)pm) - 1;
+            const uint32_t hwm = (uint32_t)__builtin_amdgcn_readlane((int)o, __builtin_amdgcn_readfirstlane(first));
+            wave_sync();
+            if (pending && ready_at <= hwm) {
+                // every byte comes from [src, src + min(dist, len)): final, so the reads of a slice go out together
+                uint32_t j = 0;  // k mod dist
+                for (uint32_t k = 0; k < len; k += 8) {
+                    uint8_t v[8];
+                    uint32_t jj = j;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { v[q] = lz_win[src + jj]; if (++jj == dist) jj = 0; }
+                    j = jj;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) if (k + q < len) lz_win[o + k + q] = v[q];
+                }
+                pending = false;
+            }
+            pm = __ballot(pending);
+        }
+        base += total;
+    }
+    if (__any(bad) || base != blk.isize) { if (lane == 0) atomicOr(&flags[0], 512); return; }
+    wave_sync();
+    uint8_t* out = outbuf + (blk.uoff - out_base);
+    if ((((uintptr_t)out) & 15) == 0) {
+        const uint32_t words = blk.isize >> 4;
+        for (uint32_t w = lane; w < words; w += 64) ((uint4*)out)[w] = ((const uint4*)lz_win)[w];
+        for (uint32_t k = (words << 4) + lane; k < blk.isize; k += 64) out[k] = lz_win[k];
+    } else
+        for (uint32_t k = lane; k < blk.isize; k += 64) out[k] = lz_win[k];
+}
+
 // Record boundaries of the inflated stream, on the device: 8 KiB slices find their first boundary by validating a chain of
 // plausible record headers (as the host reader does), walk from there, and a check kernel verifies that every slice ends
 // exactly where the next one started (any disagreement sends the file through the host reader instead).
@@ -1859,7 +2257,7 @@ void dev_destroy(sq_ctx* c) {
     D.calib.release(); D.okey.release(); D.oval.release(); D.other64.release(); D.spine64.release(); D.okey64.release(); D.zflag.release();
     D.cl_chr.release(); D.trig.release();
     D.ord_e.release(); D.ord_o.release(); D.ord_v.release();
-    D.pin.release(); D.bgzf_in.release(); D.bgzf_out.release(); D.bgzf_tab.release(); D.rec_sync.release(); D.rec_end.release(); D.rec_cnt.release(); D.rec_base.release(); D.stripes.release(); D.bp_bucket.release(); D.bp_ev.release(); D.bp_end.release(); D.bp_valid.release();
+    D.pin.release(); D.il_tok.release(); D.il_ntok.release(); D.bgzf_in.release(); D.bgzf_out.release(); D.bgzf_tab.release(); D.rec_sync.release(); D.rec_end.release(); D.rec_cnt.release(); D.rec_base.release(); D.stripes.release(); D.bp_bucket.release(); D.bp_ev.release(); D.bp_end.release(); D.bp_valid.release();
     for (auto& e : D.ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete c->dev;
     c->dev = nullptr;
@@ -1909,7 +2307,7 @@ int dev_upload_chim_names(sq_ctx* c) {
         unsigned long long h = 1469598103934665603ull;
         for (unsigned char ch : nm) { h ^= ch; h *= 1099511628211ull; }
         if (h == 0) h = 1;
-        uint32_t s = (uint32_t)(h >> 20) & (slots - 1);
+        uint32_t s = chim_slot(h, slots - 1);
         while (hash[s]) s = (s + 1) & (slots - 1);
         hash[s] = h; off[s] = (uint32_t)blob.size(); len[s] = (uint32_t)nm.size();
         blob.insert(blob.end(), nm.begin(), nm.end());
@@ -1965,7 +2363,7 @@ static int parse_device(sq_ctx* c, const uint8_t* d_bam, size_t nbytes, const un
     if (D.b_refpos.cap < nb1 + 1) { GROW(b_refpos, nb0, blk_want); GROW(b_matchref, nb0, blk_want); GROW(b_readpos, nb0, blk_want); GROW(b_matchread, nb0, blk_want); }
 #undef GROW
     ChimSetView C{D.chim_mask, D.chim_mask ? D.chim_hash.p : nullptr, D.chim_off.p, D.chim_len.p, D.chim_blob.p};
-    ParseParams P{(int)(signed char)(((c->P.phred_type ? 33 : 64) + c->P.min_phred) & 0xff), c->P.max_lowphred_len, c->P.min_mapqual};
+    ParseParams P{(int)(signed char)(((c->P.phred_type ? 33 : 64) + c->P.min_phred) & 0xff), c->P.max_lowphred_len, c->P.min_mapqual, std::getenv("SQUID_PARSE_SKIP") ? std::atoi(std::getenv("SQUID_PARSE_SKIP")) : 0};
     { EvTimer t(c, "k_parse_write", (double)nbytes + 32.0 * n_rec + 12.0 * nblk_total);
       hipLaunchKernelGGL(k_parse_write, grid_for(n_rec, PARSE_THREADS), dim3(PARSE_THREADS), 0, s, d_bam, nbytes, d_off, n_rec, C, P, D.parse_rel.p, (uint32_t)nb0, D.refid.p + n0, D.pos.p + n0, D.mrefid.p + n0,
                          D.mpos.p + n0, D.endpos.p + n0, D.flag.p + n0, D.totlen.p + n0, D.mapq.p + n0, D.aux.p + n0, D.blk_off.p + n0, D.b_refpos.p, D.b_matchref.p, D.b_readpos.p, D.b_matchread.p,
@@ -1997,12 +2395,38 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, const std::vector<BgzfRange>
     const int nblk = (int)(b1 - b0);
     std::vector<InflBlock> tab((size_t)nblk);
     for (int i = 0; i < nblk; ++i) tab[i] = InflBlock{blocks[b0 + i].coff - coff0, blocks[b0 + i].clen, blocks[b0 + i].isize, blocks[b0 + i].uoff};
-    HIPCHK(D.bgzf_in.reserve((size_t)(coff1 - coff0) + 64)); HIPCHK(D.bgzf_out.reserve((size_t)ubytes + 64)); HIPCHK(D.bgzf_tab.reserve((size_t)nblk));
+    HIPCHK(D.bgzf_in.reserve((size_t)(coff1 - coff0) + 256)); /* (the input rings read up to 144 bytes ahead) */ HIPCHK(D.bgzf_out.reserve((size_t)ubytes + 64)); HIPCHK(D.bgzf_tab.reserve((size_t)nblk));
     HIPCHK(hipMemcpyAsync(D.bgzf_in.p, file + coff0, (size_t)(coff1 - coff0), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(D.bgzf_tab.p, tab.data(), (size_t)nblk * sizeof(InflBlock), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
     { EvTimer t(c, "k_inflate", (double)(coff1 - coff0) + (double)ubytes);
-      hipLaunchKernelGGL(k_inflate, dim3((nblk + 3) / 4), dim3(256), 0, s, D.bgzf_in.p, D.bgzf_tab.p, 0, nblk, ubase, D.bgzf_out.p, D.flags.p); }
+      if (std::getenv("SQUID_GPU_INFLATE_WAVE"))  // one wave per block (the first version)
+          hipLaunchKernelGGL(k_inflate, dim3((nblk + 3) / 4), dim3(256), 0, s, D.bgzf_in.p, D.bgzf_tab.p, 0, nblk, ubase, D.bgzf_out.p, D.flags.p);
+      else {
+          // two passes over batches of blocks: tokens (lane per block), then bytes (wave per block, window in LDS)
+          const size_t lds_bytes = IL_LDS_BYTES;
+          const bool one_pass = std::getenv("SQUID_GPU_INFLATE_ONEPASS") != nullptr;
+          const unsigned long long tok_cap = 6ull << 30;  // tokens of one batch: 4 bytes per inflated byte at most
+          HIPCHK(hipFuncSetAttribute((const void*)k_inflate_lanes<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+          HIPCHK(hipFuncSetAttribute((const void*)k_inflate_lanes<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+          HIPCHK(hipFuncSetAttribute((const void*)k_lz_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16));
+          for (int at = 0; at < nblk;) {
+              int end = at;
+              while (end < nblk && (end == at || tab[end].uoff + tab[end].isize - tab[at].uoff <= tok_cap)) ++end;
+              const int nb = end - at, waves = (nb + 63) / 64;
+              const unsigned long long bbase = tab[at].uoff, bbytes = tab[end - 1].uoff + tab[end - 1].isize - bbase;
+              if (one_pass)
+                  hipLaunchKernelGGL(k_inflate_lanes<false>, dim3(waves), dim3(64), lds_bytes, s, D.bgzf_in.p, D.bgzf_tab.p + at, nb, bbase, D.bgzf_out.p + (bbase - ubase), D.flags.p, nullptr, nullptr);
+              else {
+                  HIPCHK(D.il_tok.reserve((size_t)bbytes + 64)); HIPCHK(D.il_ntok.reserve((size_t)nb));
+                  { EvTimer t1(c, "k_inflate_tokens", (double)bbytes * 4);
+                    hipLaunchKernelGGL(k_inflate_lanes<true>, dim3(waves), dim3(64), lds_bytes, s, D.bgzf_in.p, D.bgzf_tab.p + at, nb, bbase, nullptr, D.flags.p, D.il_tok.p, D.il_ntok.p); }
+                  EvTimer t2(c, "k_lz_resolve", (double)bbytes * 5);
+                  hipLaunchKernelGGL(k_lz_resolve, dim3(nb), dim3(64), 65536 + 16, s, D.il_tok.p, D.il_ntok.p, D.bgzf_tab.p + at, nb, bbase, D.bgzf_out.p + (bbase - ubase), D.flags.p);
+              }
+              at = end;
+          }
+      } }
     const Shard& sh = c->shard;
     RecScan S{D.bgzf_out.p, (unsigned long long)begin, ubytes, nref, sh.on ? sh.first_ref : -1, sh.on ? sh.end_ref : 0, (sh.on && c->P.rank == c->P.world_size - 1) ? 1 : 0};
     const long long nsl = (long long)((ubytes - begin + REC_SLICE - 1) / REC_SLICE);
@@ -2033,7 +2457,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, const std::vector<BgzfRange>
                 ++bad;
             }
         }
-        std::fprintf(stderr, "[inflate check] %ld of %d blocks differ, flags %d, records %d\n", bad, nblk, h[0], h[8]);
+        std::fprintf(stderr, "[inflate check] %ld of %d blocks differ, flags %d, records %d; wave iterations %d, headers %d, tokens/16 %d; us summed over waves: headers %d, top-ups %d, total %d\n", bad, nblk, h[0], h[8], h[2], h[3], h[4], h[5], h[6], h[7]);
         std::vector<long long> hs((size_t)nsl), he((size_t)nsl);
         HIPCHK(hipMemcpy(hs.data(), D.rec_sync.p, (size_t)nsl * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(he.data(), D.rec_end.p, (size_t)nsl * 8, hipMemcpyDeviceToHost));
         int shown = 0;
