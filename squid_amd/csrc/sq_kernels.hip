@@ -391,7 +391,7 @@ __global__ void k_calib_read4(const int32_t* a, int64_t n, int32_t* out) {
 // strand-mirrored read offsets, GetEndPosition(), XA / IH tags (src/SegmentGraph.cpp:297-301) and the QNAME lookup in
 // the chimeric name set (:302) -- and writes the SoA layout directly.  Two passes: count blocks, scan, write.
 struct ChimSetView { uint32_t mask; const unsigned long long* hash; const uint32_t *off, *len; const char* blob; };
-struct ParseParams { int qual_thr, max_lowphred_len, min_mapq, skip; };
+struct ParseParams { int qual_thr, max_lowphred_len, min_mapq; };
 __device__ __forceinline__ int ld32(const uint8_t* p) { return (int)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); }
 __device__ __forceinline__ int ld16(const uint8_t* p) { return (int)p[0] | ((int)p[1] << 8); }
 __device__ __forceinline__ char cig_type(uint32_t v) {  // "MIDNSHP=X", packed into registers (an indexed local array becomes a memory load per op)
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_parse_write(const uint8_t* ba
         if (t == 'M' || t == 'D' || t == 'N' || t == '=' || t == 'X') endpos += len;
     }
     int lowrun = 0, run = 0;
-    if (!(P.skip & 2)) for (int i = 0; i < lseq; ++i) {
+    for (int i = 0; i < lseq; ++i) {
         int c = (signed char)((qual[i] + 33) & 0xff);
         run = (c < P.qual_thr) ? run + 1 : 0;
         if (run > lowrun) lowrun = run;
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_parse_write(const uint8_t* ba
     // aux: XA present, first IH value (integer typed)
     bool has_xa = false, has_ih = false, bad = false;
     int ih = 0;
-    if (!(P.skip & 4)) for (const uint8_t* q = aux; q + 3 <= pend;) {
+    for (const uint8_t* q = aux; q + 3 <= pend;) {
         uint8_t t0 = q[0], t1 = q[1], ty = q[2];
         const uint8_t* v = q + 3;
         size_t sz;
@@ -563,15 +563,14 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_parse_write(const uint8_t* ba
     uint8_t ax = 0;
     if (has_xa || ih > 1) ax |= SQ_AUX_MULTI;
     if (lowrun > P.max_lowphred_len) ax |= SQ_AUX_LOWPHRED;
-    if (!(P.skip & 1) && chim_contains(C, name, lname > 0 ? lname - 1 : 0)) ax |= SQ_AUX_INCHIM;
+    if (chim_contains(C, name, lname > 0 ? lname - 1 : 0)) ax |= SQ_AUX_INCHIM;
     const uint32_t b0 = blk_base + (uint32_t)blk_rel[r];
-    int nb = (P.skip & 8) ? 0 : parse_blocks<true>(cg, ncig, seq, lseq, pos, flag & 0x10, totlen, b_refpos + b0, b_matchref + b0, b_readpos + b0, b_matchread + b0);
+    int nb = parse_blocks<true>(cg, ncig, seq, lseq, pos, flag & 0x10, totlen, b_refpos + b0, b_matchref + b0, b_readpos + b0, b_matchread + b0);
     if (nb < 0) {
         // the reference constructs a ReadRec_t only for records that pass its filters; for those the assert is live
         bool filtered = (ax & (SQ_AUX_MULTI | SQ_AUX_INCHIM)) || (flag & 0x400) || (flag & 0x4) || mapq < P.min_mapq;
         if (!filtered) atomicOr(&flags[0], 256);
     }
-    if (P.skip & 16) return;
     o_refid[r] = refid; o_pos[r] = pos; o_mrefid[r] = mrefid; o_mpos[r] = mpos; o_endpos[r] = endpos;
     o_flag[r] = (uint16_t)flag; o_totlen[r] = (uint16_t)totlen; o_mapq[r] = (uint8_t)mapq; o_aux[r] = ax;
     o_blkoff[r] = b0;
@@ -1709,19 +1708,19 @@ __global__ __launch_bounds__(256) void k_inflate(const uint8_t* file, const Infl
     if (err || outpos != blk.isize) { if (lane == 0) atomicOr(&flags[0], 512); }
 }
 
-// Lane-per-block variant: every lane of a wave inflates its own BGZF block (64 independent streams in lockstep), so the
-// vector unit does 64 symbols per step instead of one.  Per lane: fast tables in LDS (9-bit literal/length, 6-bit
-// distance, interleaved by lane), the count/symbol arrays of the slow path and the code-length scratch in global memory.
-// A lane either decodes one symbol or copies up to 8 bytes of a pending match per step, so long matches do not stall
-// the other lanes.  A lane only reads what it wrote itself: program order makes that visible, no fences.
-constexpr int IL_LB = 9, IL_DB = 7, IL_STAGE = 8;
-constexpr size_t IL_LDS_BYTES = (size_t)((1 << IL_LB) + (1 << IL_DB) + 2 * 16 + 288 + 32 + 2 * 2) * 64 * sizeof(uint16_t) + (size_t)(IL_STAGE + 32) * 64 * 4;  // (32 = IL_RING)
+// Lane-per-block variant: every lane of a wave decodes its own BGZF block (64 independent DEFLATE streams in lockstep),
+// so the vector unit takes 64 symbols per step instead of one.  Two kernels: k_inflate_lanes<true> turns the streams
+// into LZ77 tokens, k_lz_resolve (one wave per block, the 64 KiB window in LDS) turns the tokens into bytes.  The
+// one-kernel form k_inflate_lanes<false> (each lane also copies its matches, in global memory, eight bytes per step)
+// is kept behind SQUID_GPU_INFLATE_ONEPASS for comparison: a lane that reads back what it has just written makes the
+// whole wave wait for its stores.
+constexpr int IL_LB = 9, IL_DB = 6, IL_STAGE = 8;
 // The compressed bytes of a lane go through a ring of IL_RING words in LDS (ring[(word % IL_RING) * 64], already offset
 // by the lane): the bit buffer refills from LDS, and the ring is topped up from global memory by all lanes in the same
 // step, when any of them runs low.  A load issued by one lane in one step would otherwise make the whole wave wait a
 // memory round trip in the next (the counters that order memory operations are per wave, not per lane).
 // org: byte offset of ring word 0 in the block; rd / ld: words moved into the bit buffer / loaded into the ring.
-constexpr int IL_RING = 32;
+constexpr int IL_RING = 16;
 struct ILane {
     const uint8_t* p; uint32_t* ring; uint32_t n, org; int rd, ld; unsigned long long buf; int cnt;
 };
@@ -1760,102 +1759,157 @@ __device__ __forceinline__ uint32_t il_take(ILane& b, int k) {
     b.buf >>= k; b.cnt -= k;
     return v;
 }
-// One Huffman code of every lane, all of it in LDS and interleaved by lane ([entry * 64 + lane]): fast[1 << FB] (symbol << 4
-// | length for codes of at most FB bits), cnt[16] codes per length, sym[] the symbols in canonical order, fst[2] the
-// canonical decoder's (first code, symbol index) after FB lengths -- where the slow path picks up.  Anything a lane has
-// to fetch from global memory costs the whole wave a memory round trip per step: with 64 streams some lane is on the slow
-// path nearly every step.
-struct ITab { uint16_t *fast, *cnt, *sym, *fst; int FB; };
-// Tables of lane T, built by the whole wave from the code lengths in sh_lens[0..n) (LDS).  sh_tmp: 64 words of LDS
-// scratch.  Returns false (uniformly) for an over-subscribed set.
-__device__ bool il_build_coop(const ITab& t, int T, const uint8_t* sh_lens, int n, int* sh_tmp) {
-    const int lane = threadIdx.x, FB = t.FB;
-    if (lane < 16) sh_tmp[lane] = 0;
-    wave_sync();
-    for (int i = lane; i < n; i += 64) atomicAdd(&sh_tmp[sh_lens[i]], 1);
-    wave_sync();
-    // lane 0: over-subscription test, first code and first sym slot per length -> sh_tmp[16 + l], sh_tmp[32 + l]
-    if (lane == 0) {
-        int left = 1, code = 0, off = 0, ok = 1;
-        for (int l = 1; l <= 15; ++l) {
-            left <<= 1; left -= sh_tmp[l]; if (left < 0) ok = 0;
-            code = (code + (l > 1 ? sh_tmp[l - 1] : 0)) << 1;
-            sh_tmp[16 + l] = code; sh_tmp[32 + l] = off;
-            off += sh_tmp[l];
-        }
-        sh_tmp[48] = ok;
-        int first = 0, index = 0;
-        for (int l = 1; l <= FB; ++l) { index += sh_tmp[l]; first += sh_tmp[l]; first <<= 1; }
-        t.fst[T] = (uint16_t)first; t.fst[64 + T] = (uint16_t)index;
-    }
-    wave_sync();
-    if (!sh_tmp[48]) return false;
-    if (lane < 16) t.cnt[lane * 64 + T] = lane ? (uint16_t)sh_tmp[lane] : 0;
-    for (int e = lane; e < (1 << FB); e += 64) t.fast[e * 64 + T] = 0;
-    wave_sync();
-    // symbols in chunks of 64, in order: rank among the symbols of the same length = canonical index
-    for (int base = 0; base < n; base += 64) {
-        const int i = base + lane;
-        const int l = i < n ? sh_lens[i] : 0;
-        int rank = 0, code0 = 0, slot0 = 0;
-        for (int L = 1; L <= 15; ++L) {
-            const unsigned long long m = __ballot(l == L);
-            if (!m) continue;
-            if (l == L) { rank = __popcll(m & ((1ull << lane) - 1)); code0 = sh_tmp[16 + L]; slot0 = sh_tmp[32 + L]; }
-            wave_sync();
-            if (lane == 0) { sh_tmp[16 + L] += __popcll(m); sh_tmp[32 + L] += __popcll(m); }
-            wave_sync();
-        }
-        if (l) {
-            t.sym[(slot0 + rank) * 64 + T] = (uint16_t)i;
-            if (l <= FB) {
-                const uint32_t c = (uint32_t)(code0 + rank);
-                const uint32_t rev = __brev(c) >> (32 - l);
-                for (uint32_t j = rev; j < (1u << FB); j += 1u << l) t.fast[j * 64 + T] = (uint16_t)((i << 4) | l);
-            }
-        }
-    }
-    wave_sync();
-    return true;
-}
-__device__ __forceinline__ int il_decode(ILane& b, const ITab& t, int lane) {
+// Per-lane decoding tables, all in LDS and interleaved by lane (entry e of lane l at [e * 64 + l]); anything a lane
+// fetched from global memory would cost the whole wave a memory round trip per step, and with 64 streams some lane is on
+// the rare path nearly every step:
+//   literal/length code: two-level table as in zlib -- root[1 << IL_LB] (symbol << 4 | length, or 0x8000 | first
+//     sub-entry << 4 | sub-table bits) and sub[IL_SUB] (340 entries bound the sub-tables of a 9-bit root: zlib's ENOUGH);
+//   distance code (and the code-length code while a header is read): root[1 << IL_DB] plus the canonical decoder's
+//     cnt[16] / sym[32] / (first code, symbol index) after IL_DB lengths for the few longer codes.
+// Headers are read and tables are built by every lane for itself, in lockstep with the other lanes that are at a block
+// header: zlib closes a block every 16383 symbols and a lane takes one symbol per step, so the lanes of a wave arrive
+// together (a lane that is early waits up to IL_HDR_WAIT steps for company).
+constexpr int IL_SUB = 340, IL_LENS = 344, IL_HDR_WAIT = 48;
+struct ILds {
+    uint16_t *root_ll, *sub_ll, *root_dd, *cnt_dd, *sym_dd, *fst_dd, *tmp_a, *tmp_b;  // tmp_a/tmp_b: [16] per lane, builders' scratch
+    uint8_t* lens;  // [IL_LENS] per lane: code lengths 0..317, the code-length code's own lengths at 320..338
+};
+constexpr size_t IL_LDS_BYTES = (size_t)((1 << IL_LB) + IL_SUB + (1 << IL_DB) + 16 + 32 + 2 + 16 + 16) * 64 * sizeof(uint16_t) + (size_t)IL_LENS * 64 + (size_t)(IL_STAGE + IL_RING) * 64 * 4;
+__device__ __forceinline__ int il_decode_ll(ILane& b, const ILds& L, int lane) {
     il_refill(b);
-    const uint32_t root = (uint32_t)b.buf & ((1u << t.FB) - 1);
-    const uint16_t e = t.fast[root * 64 + lane];
+    uint32_t e = L.root_ll[((uint32_t)b.buf & ((1u << IL_LB) - 1)) * 64 + lane];
+    if (e & 0x8000u) {
+        const uint32_t sb = e & 15, off = (e >> 4) & 0x7ff;
+        e = L.sub_ll[(off + ((uint32_t)(b.buf >> IL_LB) & ((1u << sb) - 1))) * 64 + lane];
+    }
+    const int l = e & 15;
+    if (!l) return -1;
+    b.buf >>= l; b.cnt -= l;
+    return (int)(e >> 4);
+}
+__device__ __forceinline__ int il_decode_dd(ILane& b, const ILds& L, int lane) {
+    il_refill(b);
+    const uint32_t root = (uint32_t)b.buf & ((1u << IL_DB) - 1);
+    const uint16_t e = L.root_dd[root * 64 + lane];
     if (e & 15) { const int l = e & 15; b.buf >>= l; b.cnt -= l; return e >> 4; }
-    // longer than FB bits: the canonical decoder, entered after FB lengths
-    int code = (int)(__brev(root) >> (32 - t.FB)) << 1, first = t.fst[lane], index = t.fst[64 + lane];
-    unsigned long long bb = b.buf >> t.FB;
-    for (int len = t.FB + 1; len <= 15; ++len) {
+    // longer than IL_DB bits: the canonical decoder, entered after IL_DB lengths
+    int code = (int)(__brev(root) >> (32 - IL_DB)) << 1, first = L.fst_dd[lane], index = L.fst_dd[64 + lane];
+    unsigned long long bb = b.buf >> IL_DB;
+    for (int len = IL_DB + 1; len <= 15; ++len) {
         code |= (int)(bb & 1); bb >>= 1;
-        const int count = t.cnt[len * 64 + lane];
-        if (code - count < first) { b.buf >>= len; b.cnt -= len; return t.sym[(index + (code - first)) * 64 + lane]; }
+        const int count = L.cnt_dd[len * 64 + lane];
+        if (code - count < first) { b.buf >>= len; b.cnt -= len; return L.sym_dd[(index + (code - first)) * 64 + lane]; }
         index += count; first += count; first <<= 1; code <<= 1;
     }
     return -1;
+}
+// Builders: called by the lanes that are at a header (me), each for its own table; n and lo differ per lane, the loops
+// run to the longest.  Return false for an over-subscribed set of lengths.
+__device__ bool il_build_dd(const ILds& L, int lane, bool me, int lo, int n) {
+    uint16_t *cnt = L.cnt_dd + lane, *code = L.tmp_a + lane, *slot = L.tmp_b + lane;
+    const uint8_t* lens = L.lens + lane;
+    bool ok = true;
+    if (me) {
+        for (int l = 0; l < 16; ++l) cnt[l * 64] = 0;
+        for (int i = 0; i < n; ++i) { const int l = lens[(lo + i) * 64]; ++cnt[l * 64]; }
+        cnt[0] = 0;
+        int left = 1, c = 0, off = 0, first = 0, index = 0;
+        for (int l = 1; l <= 15; ++l) {
+            const int k = cnt[l * 64];
+            left <<= 1; left -= k; if (left < 0) ok = false;
+            c = (c + (l > 1 ? (int)cnt[(l - 1) * 64] : 0)) << 1;
+            code[l * 64] = (uint16_t)c; slot[l * 64] = (uint16_t)off;
+            off += k;
+            if (l <= IL_DB) { index += k; first += k; first <<= 1; }
+        }
+        L.fst_dd[lane] = (uint16_t)first; L.fst_dd[64 + lane] = (uint16_t)index;
+        for (int e = 0; e < (1 << IL_DB); ++e) L.root_dd[e * 64 + lane] = 0;
+        if (ok)
+            for (int i = 0; i < n; ++i) {
+                const int l = lens[(lo + i) * 64];
+                if (!l) continue;
+                const uint32_t c2 = code[l * 64]++; const int s2 = slot[l * 64]++;
+                L.sym_dd[s2 * 64 + lane] = (uint16_t)i;
+                if (l <= IL_DB) {
+                    const uint32_t rev = __brev(c2) >> (32 - l);
+                    for (uint32_t j = rev; j < (1u << IL_DB); j += 1u << l) L.root_dd[j * 64 + lane] = (uint16_t)((i << 4) | l);
+                }
+            }
+    }
+    return ok;
+}
+__device__ bool il_build_ll(const ILds& L, int lane, bool me, int n) {
+    uint16_t *cnt = L.tmp_a + lane, *code = L.tmp_b + lane, *root = L.root_ll + lane, *sub = L.sub_ll + lane;
+    const uint8_t* lens = L.lens + lane;
+    bool ok = true;
+    if (me) {
+        for (int l = 0; l < 16; ++l) cnt[l * 64] = 0;
+        for (int i = 0; i < n; ++i) { const int l = lens[i * 64]; ++cnt[l * 64]; }
+        cnt[0] = 0;
+        int left = 1;
+        for (int l = 1; l <= 15; ++l) { left <<= 1; left -= cnt[l * 64]; if (left < 0) ok = false; }
+        for (int e = 0; e < (1 << IL_LB); ++e) root[e * 64] = 0;
+        if (ok) {
+            // pass 1: codes of at most IL_LB bits fill the root; longer ones leave their length at their root slot
+            int c = 0;
+            for (int l = 1; l <= 15; ++l) { c = (c + (l > 1 ? (int)cnt[(l - 1) * 64] : 0)) << 1; code[l * 64] = (uint16_t)c; }
+            for (int i = 0; i < n; ++i) {
+                const int l = lens[i * 64];
+                if (!l) continue;
+                const uint32_t c2 = code[l * 64]++;
+                const uint32_t rev = __brev(c2) >> (32 - l);
+                if (l <= IL_LB)
+                    for (uint32_t j = rev; j < (1u << IL_LB); j += 1u << l) root[j * 64] = (uint16_t)((i << 4) | l);
+                else {
+                    const uint32_t r = rev & ((1u << IL_LB) - 1), m = root[r * 64] & 15u;
+                    if ((uint32_t)(l - IL_LB) > m) root[r * 64] = (uint16_t)(0x4000u | (uint32_t)(l - IL_LB));
+                }
+            }
+            // sub-tables: one per marked root slot, sized by the longest code below it
+            uint32_t off = 0;
+            for (int r = 0; r < (1 << IL_LB); ++r) {
+                const uint32_t e = root[r * 64];
+                if (e & 0x4000u) { const uint32_t sb = e & 15; root[r * 64] = (uint16_t)(0x8000u | (off << 4) | sb); off += 1u << sb; }
+            }
+            if (off > (uint32_t)IL_SUB) ok = false;
+            else {
+                for (uint32_t k = 0; k < off; ++k) sub[k * 64] = 0;
+                // pass 2: the long codes again, into their sub-tables
+                c = 0;
+                for (int l = 1; l <= 15; ++l) { c = (c + (l > 1 ? (int)cnt[(l - 1) * 64] : 0)) << 1; code[l * 64] = (uint16_t)c; }
+                for (int i = 0; i < n; ++i) {
+                    const int l = lens[i * 64];
+                    if (l <= IL_LB) continue;
+                    const uint32_t c2 = code[l * 64]++;
+                    const uint32_t rev = __brev(c2) >> (32 - l);
+                    const uint32_t e = root[(rev & ((1u << IL_LB) - 1)) * 64], sb = e & 15, o = (e >> 4) & 0x7ff;
+                    for (uint32_t j = rev >> IL_LB; j < (1u << sb); j += 1u << (l - IL_LB)) sub[(o + j) * 64] = (uint16_t)((i << 4) | l);
+                }
+            }
+        }
+    }
+    return ok;
 }
 // TOK: instead of the bytes, the lane writes its block's LZ77 tokens (a literal: the byte; a match: bit 31, length in bits
 // 16..24, distance - 1 in bits 0..14) at tok[uoff - out_base ...] and their number at ntok[block]; k_lz_resolve turns them
 // into bytes.  Decoding alone never reads what it wrote, so the lanes run without waiting for their stores.
 template <bool TOK>
 __global__ __launch_bounds__(64) void k_inflate_lanes(const uint8_t* file, const InflBlock* blocks, int nblocks, unsigned long long out_base, uint8_t* outbuf, int32_t* flags, uint32_t* tok, int32_t* ntok) {
-    extern __shared__ uint16_t il_lds[];  // IL_LDS_BYTES: the two ITabs, then [IL_STAGE] x 64 token words
+    extern __shared__ uint16_t il_lds[];  // IL_LDS_BYTES
     __shared__ uint16_t sh_lb[32], sh_db[32];
-    __shared__ uint8_t sh_le[32], sh_de[32];
-    __shared__ uint8_t sh_lens[352];
-    __shared__ int sh_tmp[64];
-    __shared__ int sh_hdr[4];
-    ITab LL, DD;
-    LL.FB = IL_LB; DD.FB = IL_DB;
-    LL.fast = il_lds;                       DD.fast = LL.fast + (1 << IL_LB) * 64;
-    LL.cnt = DD.fast + (1 << IL_DB) * 64;   DD.cnt = LL.cnt + 16 * 64;
-    LL.sym = DD.cnt + 16 * 64;              DD.sym = LL.sym + 288 * 64;
-    LL.fst = DD.sym + 32 * 64;              DD.fst = LL.fst + 2 * 64;
-    uint32_t* stage = (uint32_t*)(DD.fst + 2 * 64);
-    uint32_t* ring = stage + IL_STAGE * 64;  // tokens on their way out: stage[(k % IL_STAGE) * 64 + lane]
+    __shared__ uint8_t sh_le[32], sh_de[32], sh_clo[32];
+    ILds L;
+    L.root_ll = il_lds;                          L.sub_ll = L.root_ll + (1 << IL_LB) * 64;
+    L.root_dd = L.sub_ll + IL_SUB * 64;          L.cnt_dd = L.root_dd + (1 << IL_DB) * 64;
+    L.sym_dd = L.cnt_dd + 16 * 64;               L.fst_dd = L.sym_dd + 32 * 64;
+    L.tmp_a = L.fst_dd + 2 * 64;                 L.tmp_b = L.tmp_a + 16 * 64;
+    L.lens = (uint8_t*)(L.tmp_b + 16 * 64);
+    uint32_t* stage = (uint32_t*)(L.lens + IL_LENS * 64);  // tokens on their way out: stage[(k % IL_STAGE) * 64 + lane]
+    uint32_t* ring = stage + IL_STAGE * 64;
     const int lane = threadIdx.x;
     if (lane < 29) { sh_lb[lane] = c_lbase[lane]; sh_le[lane] = c_lext[lane]; }
     if (lane < 30) { sh_db[lane] = c_dbase[lane]; sh_de[lane] = c_dext[lane]; }
+    if (lane < 19) sh_clo[lane] = c_clorder[lane];
     wave_sync();
     const int bi = blockIdx.x * 64 + lane;
     const bool have = bi < nblocks;
@@ -1878,22 +1932,19 @@ __global__ __launch_bounds__(64) void k_inflate_lanes(const uint8_t* file, const
     ILane b;
     b.p = file + blk.coff; b.n = blk.clen; b.ring = ring + lane;
     il_start(b, 0);
+    uint8_t* lens = L.lens + lane;
     uint32_t outpos = 0, pend_len = 0, pend_src = 0;
     bool done = !have || blk.isize == 0, err = false, in_block = false, last = false, stored = false;
     uint32_t stored_left = 0, stored_at = 0;
-    int dbg_iter = 0, dbg_hdr = 0;
-    long long dbg_t0 = wall_clock64(), dbg_th = 0, dbg_tt = 0;
+    int hdr_wait = 0;
     while (__any(!done)) {
-        ++dbg_iter;
-        // ---- block headers: one lane at a time reads its header, the whole wave builds that lane's tables
-        unsigned long long need = __ballot(!done && !in_block && !pend_len && !stored);
-        const long long dbg_h0 = wall_clock64();
-        while (need) {
-            const int T = __ffsll((long long)need) - 1;
-            need &= need - 1;
-            ++dbg_hdr;
-            if (lane == T) {
-                int kind = -1, nlen = 0, ndist = 0;
+        // ---- block headers, by all the lanes that are at one
+        const unsigned long long need = __ballot(!done && !in_block && !pend_len && !stored);
+        if (need && (need == __ballot(!done) || ++hdr_wait >= IL_HDR_WAIT)) {
+            hdr_wait = 0;
+            const bool me = (need >> lane) & 1;
+            int kind = -1, nlen = 0, ndist = 0;  // 0 stored, 1 fixed code, 2 dynamic code, -1 corrupt
+            if (me) {
                 if (il_low(b)) il_topup(b);
                 if (il_pos(b) <= b.n + 8) {
                     last = il_take(b, 1);
@@ -1908,64 +1959,59 @@ __global__ __launch_bounds__(64) void k_inflate_lanes(const uint8_t* file, const
                             if (len) stored = true; else { il_start(b, stored_at); if (last) done = true; }
                         }
                     } else if (type == 1) {
-                        for (int i = 0; i < 144; ++i) sh_lens[i] = 8;
-                        for (int i = 144; i < 256; ++i) sh_lens[i] = 9;
-                        for (int i = 256; i < 280; ++i) sh_lens[i] = 7;
-                        for (int i = 280; i < 288; ++i) sh_lens[i] = 8;
-                        for (int i = 0; i < 30; ++i) sh_lens[288 + i] = 5;
+                        for (int i = 0; i < 144; ++i) lens[i * 64] = 8;
+                        for (int i = 144; i < 256; ++i) lens[i * 64] = 9;
+                        for (int i = 256; i < 280; ++i) lens[i * 64] = 7;
+                        for (int i = 280; i < 288; ++i) lens[i * 64] = 8;
+                        for (int i = 0; i < 30; ++i) lens[(288 + i) * 64] = 5;
                         kind = 1; nlen = 288; ndist = 30;
                     } else if (type == 2) {
                         nlen = (int)il_take(b, 5) + 257; ndist = (int)il_take(b, 5) + 1;
                         const int ncode = (int)il_take(b, 4) + 4;
                         if (nlen <= 286 && ndist <= 30) {
-                            for (int i = 0; i < 19; ++i) sh_lens[i] = 0;
-                            for (int i = 0; i < ncode; ++i) sh_lens[c_clorder[i]] = (uint8_t)il_take(b, 3);
+                            for (int i = 0; i < 19; ++i) lens[(320 + i) * 64] = 0;
+                            for (int i = 0; i < ncode; ++i) lens[(320 + sh_clo[i]) * 64] = (uint8_t)il_take(b, 3);
                             kind = 2;
                         }
                     }
                 }
-                sh_hdr[0] = kind; sh_hdr[1] = nlen; sh_hdr[2] = ndist;
             }
-            wave_sync();
-            int kind = sh_hdr[0];
-            const int nlen = sh_hdr[1], ndist = sh_hdr[2];
-            if (kind == 2) {
-                // the code-length code (19 symbols), then lane T reads the litlen + dist lengths with it
-                bool ok = il_build_coop(DD, T, sh_lens, 19, sh_tmp);
-                if (lane == T) {
-                    int idx = 0;
-                    uint8_t prev = 0;
-                    while (ok && idx < nlen + ndist) {
+            if (__any(me && kind == 2)) {
+                // the code-length code (19 symbols) in the distance tables, then the literal/length + distance lengths with it
+                const bool dyn = me && kind == 2;
+                bool ok = il_build_dd(L, lane, dyn, 320, 19);
+                int idx = 0;
+                uint8_t prev = 0;
+                bool busy = dyn && ok;
+                while (__any(busy)) {
+                    if (busy) {
                         if (il_low(b)) il_topup(b);
-                        const int sym = il_decode(b, DD, lane);
-                        if (sym < 0 || il_pos(b) > b.n + 8) { ok = false; break; }
-                        if (sym < 16) { sh_lens[idx++] = (uint8_t)sym; prev = (uint8_t)sym; }
+                        const int sym = il_decode_dd(b, L, lane);
+                        if (sym < 0 || il_pos(b) > b.n + 8) { ok = false; busy = false; }
+                        else if (sym < 16) { lens[idx++ * 64] = (uint8_t)sym; prev = (uint8_t)sym; }
                         else {
                             int rep; uint8_t v = 0;
-                            if (sym == 16) { if (idx == 0) { ok = false; break; } v = prev; rep = 3 + (int)il_take(b, 2); }
+                            if (sym == 16) { v = prev; rep = 3 + (int)il_take(b, 2); if (idx == 0) ok = false; }
                             else if (sym == 17) rep = 3 + (int)il_take(b, 3);
                             else rep = 11 + (int)il_take(b, 7);
-                            if (idx + rep > nlen + ndist) { ok = false; break; }
-                            while (rep--) sh_lens[idx++] = v;
-                            prev = v;
+                            if (!ok || idx + rep > nlen + ndist) { ok = false; busy = false; }
+                            else { while (rep--) lens[idx++ * 64] = v; prev = v; }
                         }
+                        if (busy && idx >= nlen + ndist) busy = false;
                     }
-                    if (ok && sh_lens[256] == 0) ok = false;  // no end-of-block code
-                    sh_hdr[0] = ok ? 2 : -1;
                 }
-                wave_sync();
-                kind = sh_hdr[0];
+                if (dyn && ok && lens[256 * 64] == 0) ok = false;  // no end-of-block code
+                if (dyn && !ok) kind = -1;
             }
-            if (kind == 1 || kind == 2) {
-                const bool ok = il_build_coop(LL, T, sh_lens, nlen, sh_tmp) && il_build_coop(DD, T, sh_lens + nlen, ndist, sh_tmp);
-                if (!ok) kind = -1;
+            if (__any(me && kind > 0)) {
+                const bool bld = me && kind > 0;
+                const bool ok_ll = il_build_ll(L, lane, bld, nlen), ok_dd = il_build_dd(L, lane, bld, nlen, ndist);
+                const bool ok = ok_ll && ok_dd;
+                if (bld && !ok) kind = -1;
             }
-            if (lane == T) { if (kind < 0) { err = true; done = true; } else if (kind > 0) in_block = true; }
-            wave_sync();
+            if (me) { if (kind < 0) { err = true; done = true; } else if (kind > 0) in_block = true; }
         }
-        const long long dbg_h1 = wall_clock64();
-        dbg_th += dbg_h1 - dbg_h0;
-        if (__any(!done && il_low(b))) { if (!done) il_topup(b); dbg_tt += wall_clock64() - dbg_h1; }  // every lane, in the same step
+        if (__any(!done && il_low(b))) { if (!done) il_topup(b); }  // every lane, in the same step
         if (done) continue;
         if (!TOK && pend_len) {  // a slice of a pending match (source bytes were written by this lane)
             // eight bytes per step: one wide load, one wide store (byte-wise, every byte waits for a memory round trip)
@@ -1991,9 +2037,9 @@ __global__ __launch_bounds__(64) void k_inflate_lanes(const uint8_t* file, const
             if (!stored_left) { stored = false; il_start(b, stored_at); if (last) done = true; }
             continue;
         }
-        if (!in_block) continue;  // (its header is read at the top of the next round)
+        if (!in_block) continue;  // (waiting at a header)
         // one symbol
-        const int sym = il_decode(b, LL, lane);
+        const int sym = il_decode_ll(b, L, lane);
         if (sym < 0 || il_pos(b) > b.n + 8) { err = true; done = true; continue; }
         if (sym < 256) {
             if (outpos >= blk.isize) { err = true; done = true; continue; }
@@ -2004,7 +2050,7 @@ __global__ __launch_bounds__(64) void k_inflate_lanes(const uint8_t* file, const
         const int ls = sym - 257;
         if (ls >= 29) { err = true; done = true; continue; }
         const uint32_t len = sh_lb[ls] + il_take(b, sh_le[ls]);
-        const int ds = il_decode(b, DD, lane);
+        const int ds = il_decode_dd(b, L, lane);
         if (ds < 0 || ds >= 30) { err = true; done = true; continue; }
         const uint32_t dist = sh_db[ds] + il_take(b, sh_de[ds]);
         if (dist > outpos || outpos + len > blk.isize) { err = true; done = true; continue; }
@@ -2012,14 +2058,11 @@ __global__ __launch_bounds__(64) void k_inflate_lanes(const uint8_t* file, const
         else { pend_len = len; pend_src = outpos - dist; }
     }
     if (have && (err || outpos != blk.isize)) atomicOr(&flags[0], 512);
-    if (lane == 0) { atomicAdd(&flags[2], dbg_iter); atomicAdd(&flags[3], dbg_hdr); atomicAdd(&flags[5], (int)(dbg_th / 100)); atomicAdd(&flags[6], (int)(dbg_tt / 100)); atomicAdd(&flags[7], (int)((wall_clock64() - dbg_t0) / 100)); }
-    if (TOK && have) atomicAdd(&flags[4], (int)(nt >> 4));
     if (TOK && have) {
         for (uint32_t k = nt - nt % IL_STAGE; k < nt; ++k) tk[k] = stage[(k % IL_STAGE) * 64 + lane];
         ntok[bi] = (int32_t)nt;
     }
 }
-
 
 // Inclusive prefix sum over the wave with DPP row shifts (no LDS traffic).
 __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
@@ -2363,7 +2406,7 @@ static int parse_device(sq_ctx* c, const uint8_t* d_bam, size_t nbytes, const un
     if (D.b_refpos.cap < nb1 + 1) { GROW(b_refpos, nb0, blk_want); GROW(b_matchref, nb0, blk_want); GROW(b_readpos, nb0, blk_want); GROW(b_matchread, nb0, blk_want); }
 #undef GROW
     ChimSetView C{D.chim_mask, D.chim_mask ? D.chim_hash.p : nullptr, D.chim_off.p, D.chim_len.p, D.chim_blob.p};
-    ParseParams P{(int)(signed char)(((c->P.phred_type ? 33 : 64) + c->P.min_phred) & 0xff), c->P.max_lowphred_len, c->P.min_mapqual, std::getenv("SQUID_PARSE_SKIP") ? std::atoi(std::getenv("SQUID_PARSE_SKIP")) : 0};
+    ParseParams P{(int)(signed char)(((c->P.phred_type ? 33 : 64) + c->P.min_phred) & 0xff), c->P.max_lowphred_len, c->P.min_mapqual};
     { EvTimer t(c, "k_parse_write", (double)nbytes + 32.0 * n_rec + 12.0 * nblk_total);
       hipLaunchKernelGGL(k_parse_write, grid_for(n_rec, PARSE_THREADS), dim3(PARSE_THREADS), 0, s, d_bam, nbytes, d_off, n_rec, C, P, D.parse_rel.p, (uint32_t)nb0, D.refid.p + n0, D.pos.p + n0, D.mrefid.p + n0,
                          D.mpos.p + n0, D.endpos.p + n0, D.flag.p + n0, D.totlen.p + n0, D.mapq.p + n0, D.aux.p + n0, D.blk_off.p + n0, D.b_refpos.p, D.b_matchref.p, D.b_readpos.p, D.b_matchread.p,
@@ -2395,7 +2438,12 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, const std::vector<BgzfRange>
     const int nblk = (int)(b1 - b0);
     std::vector<InflBlock> tab((size_t)nblk);
     for (int i = 0; i < nblk; ++i) tab[i] = InflBlock{blocks[b0 + i].coff - coff0, blocks[b0 + i].clen, blocks[b0 + i].isize, blocks[b0 + i].uoff};
-    HIPCHK(D.bgzf_in.reserve((size_t)(coff1 - coff0) + 256)); /* (the input rings read up to 144 bytes ahead) */ HIPCHK(D.bgzf_out.reserve((size_t)ubytes + 64)); HIPCHK(D.bgzf_tab.reserve((size_t)nblk));
+    const bool report = std::getenv("SQUID_INGEST_TIMING") != nullptr;
+    const auto w0 = std::chrono::steady_clock::now();
+    auto since_ms = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+    HIPCHK(D.bgzf_in.reserve((size_t)(coff1 - coff0) + 256));  /* (the input rings read up to 80 bytes ahead) */
+    HIPCHK(D.bgzf_out.reserve((size_t)ubytes + 64)); HIPCHK(D.bgzf_tab.reserve((size_t)nblk));
+    const double w_alloc = since_ms(w0);
     HIPCHK(hipMemcpyAsync(D.bgzf_in.p, file + coff0, (size_t)(coff1 - coff0), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(D.bgzf_tab.p, tab.data(), (size_t)nblk * sizeof(InflBlock), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
@@ -2406,7 +2454,8 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, const std::vector<BgzfRange>
           // two passes over batches of blocks: tokens (lane per block), then bytes (wave per block, window in LDS)
           const size_t lds_bytes = IL_LDS_BYTES;
           const bool one_pass = std::getenv("SQUID_GPU_INFLATE_ONEPASS") != nullptr;
-          const unsigned long long tok_cap = 6ull << 30;  // tokens of one batch: 4 bytes per inflated byte at most
+          // one batch: about one wave per CU in the token pass, tokens of 4 bytes per inflated byte at most (4 GiB)
+          const unsigned long long tok_cap = std::getenv("SQUID_TOK_CAP_MB") ? (unsigned long long)std::atoll(std::getenv("SQUID_TOK_CAP_MB")) << 20 : 3ull << 30;
           HIPCHK(hipFuncSetAttribute((const void*)k_inflate_lanes<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
           HIPCHK(hipFuncSetAttribute((const void*)k_inflate_lanes<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
           HIPCHK(hipFuncSetAttribute((const void*)k_lz_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16));
@@ -2418,7 +2467,9 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, const std::vector<BgzfRange>
               if (one_pass)
                   hipLaunchKernelGGL(k_inflate_lanes<false>, dim3(waves), dim3(64), lds_bytes, s, D.bgzf_in.p, D.bgzf_tab.p + at, nb, bbase, D.bgzf_out.p + (bbase - ubase), D.flags.p, nullptr, nullptr);
               else {
-                  HIPCHK(D.il_tok.reserve((size_t)bbytes + 64)); HIPCHK(D.il_ntok.reserve((size_t)nb));
+                  { const auto wa = std::chrono::steady_clock::now();
+                    HIPCHK(D.il_tok.reserve((size_t)bbytes + 64)); HIPCHK(D.il_ntok.reserve((size_t)nb));
+                    if (report && at == 0) std::fprintf(stderr, "GPU ingest: token buffer of %.1f GB allocated in %.1f ms\n", (double)D.il_tok.cap * 4e-9, since_ms(wa)); }
                   { EvTimer t1(c, "k_inflate_tokens", (double)bbytes * 4);
                     hipLaunchKernelGGL(k_inflate_lanes<true>, dim3(waves), dim3(64), lds_bytes, s, D.bgzf_in.p, D.bgzf_tab.p + at, nb, bbase, nullptr, D.flags.p, D.il_tok.p, D.il_ntok.p); }
                   EvTimer t2(c, "k_lz_resolve", (double)bbytes * 5);
@@ -2441,6 +2492,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, const std::vector<BgzfRange>
     int32_t h[10];
     HIPCHK(hipMemcpyAsync(h, D.flags.p, 10 * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    const double w_inflate = since_ms(w0);
     if (std::getenv("SQUID_INFLATE_CHECK")) {  // debugging: every block against zlib
         std::vector<uint8_t> got((size_t)ubytes), want;
         HIPCHK(hipMemcpy(got.data(), D.bgzf_out.p, (size_t)ubytes, hipMemcpyDeviceToHost));
@@ -2457,7 +2509,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, const std::vector<BgzfRange>
                 ++bad;
             }
         }
-        std::fprintf(stderr, "[inflate check] %ld of %d blocks differ, flags %d, records %d; wave iterations %d, headers %d, tokens/16 %d; us summed over waves: headers %d, top-ups %d, total %d\n", bad, nblk, h[0], h[8], h[2], h[3], h[4], h[5], h[6], h[7]);
+        std::fprintf(stderr, "[inflate check] %ld of %d blocks differ, flags %d, records %d\n", bad, nblk, h[0], h[8]);
         std::vector<long long> hs((size_t)nsl), he((size_t)nsl);
         HIPCHK(hipMemcpy(hs.data(), D.rec_sync.p, (size_t)nsl * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(he.data(), D.rec_end.p, (size_t)nsl * 8, hipMemcpyDeviceToHost));
         int shown = 0;
@@ -2477,6 +2529,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, const std::vector<BgzfRange>
         c->ingest_total_bytes = 0; c->ingest_seen_bytes = 0;
         if (rc) return rc;
     }
+    if (report) std::fprintf(stderr, "GPU ingest: buffers %.1f, copy + inflate + boundaries until %.1f, parse until %.1f ms\n", w_alloc, w_inflate, since_ms(w0));
     return SQ_OK;
 }
 

@@ -547,21 +547,61 @@ def test_parity_with_indel_and_match_mismatch_cigars(built, synth, tmp_path, exa
         _compare(ctx, dump, sv_path)
 
 
-def test_gpu_bgzf_inflate_and_boundary_search_give_the_same_records(built, synth):
-    """SQUID_GPU_INFLATE=1 (experimental): BGZF blocks inflated by k_inflate, record boundaries found by k_rec_*, against
-    the default host pipeline -- identical SoA"""
+def _rebgzf(src, dst, plan):
+    """rewrite a BGZF file block by block: plan(i) -> (level, strategy) of block i (same inflated bytes, other DEFLATE
+    block types: level 0 = stored blocks, Z_FIXED = the fixed Huffman code)"""
+    import struct
+    import zlib
+
+    data = Path(src).read_bytes()
+    out, at, i = bytearray(), 0, 0
+    while at < len(data):
+        bsize = struct.unpack_from("<H", data, at + 16)[0] + 1
+        raw = zlib.decompress(data[at + 18:at + bsize - 8], -15)
+        level, strategy = plan(i)
+        co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+        cd = co.compress(raw) + co.flush()
+        assert len(cd) + 26 <= 65536
+        out += bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0]) + struct.pack("<H", len(cd) + 25) + cd + struct.pack("<II", zlib.crc32(raw), len(raw))
+        at += bsize
+        i += 1
+    Path(dst).write_bytes(bytes(out))
+
+
+def test_gpu_bgzf_inflate_and_boundary_search_give_the_same_records(built, synth, tmp_path):
+    """SQUID_GPU_INFLATE=1: BGZF blocks inflated by k_inflate_lanes + k_lz_resolve, record boundaries found by k_rec_*,
+    against the default host pipeline -- identical SoA.  Also: one block per token batch, the one-kernel forms, and the
+    same file rewritten with stored blocks, the fixed Huffman code, and all block types mixed inside one wave"""
     import json
     import os
     import sys
+    import zlib
 
     pre = synth("T2", "--indel-frac", "0.2")
     code = ("import sys, json, hashlib; sys.path.insert(0, %r); import squid_amd\n"
-            "ctx = squid_amd.Context(); ctx.load(%r, %r); r = ctx.records()\n"
-            "print(json.dumps({k: hashlib.sha256(v.tobytes()).hexdigest() for k, v in r.items()}))") % (str(Path(__file__).resolve().parent.parent), f"{pre}.bam", f"{pre}.chim.bam")
-    outs = []
-    for env in ({}, {"SQUID_GPU_INFLATE": "1", "SQUID_INGEST_TIMING": "1"}):
-        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, check=True)
-        outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
+            "ctx = squid_amd.Context(); ctx.load(sys.argv[1], %r); r = ctx.records()\n"
+            "print(json.dumps({k: hashlib.sha256(v.tobytes()).hexdigest() for k, v in r.items()}))") % (str(Path(__file__).resolve().parent.parent), f"{pre}.chim.bam")
+
+    def run(bam, env):
+        p = subprocess.run([sys.executable, "-c", code, str(bam)], env=dict(os.environ, **env), capture_output=True, text=True, check=True)
         if env:
-            assert "GPU inflate+parse path" in p.stderr and "(rc 0)" in p.stderr
-    assert outs[0] == outs[1]
+            assert "GPU inflate+parse path" in p.stderr and "(rc 0)" in p.stderr, p.stderr
+        return json.loads(p.stdout.strip().splitlines()[-1])
+
+    want = run(f"{pre}.bam", {})
+    gpu = {"SQUID_GPU_INFLATE": "1", "SQUID_INGEST_TIMING": "1"}
+    assert run(f"{pre}.bam", gpu) == want
+    assert run(f"{pre}.bam", dict(gpu, SQUID_TOK_CAP_MB="0")) == want
+    assert run(f"{pre}.bam", dict(gpu, SQUID_GPU_INFLATE_ONEPASS="1")) == want
+    assert run(f"{pre}.bam", dict(gpu, SQUID_GPU_INFLATE_WAVE="1")) == want
+    plans = {
+        "stored": lambda i: (0, zlib.Z_DEFAULT_STRATEGY),
+        "fixed": lambda i: (6, zlib.Z_FIXED),
+        "mixed": lambda i: [(0, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (9, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE)][i % 5],
+    }
+    for name, plan in plans.items():
+        alt = tmp_path / f"{name}.bam"
+        _rebgzf(f"{pre}.bam", alt, plan)
+        assert run(alt, {}) == want, name
+        assert run(alt, gpu) == want, name
+        assert run(alt, dict(gpu, SQUID_GPU_INFLATE_ONEPASS="1")) == want, name
