@@ -849,7 +849,15 @@ int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSi
     int cur = 0, nref = -1;
     bool header_done = false, unsynced = false;
     int rc = SQ_OK;
-    const bool try_gpu = gpu && std::getenv("SQUID_GPU_INFLATE");  // experimental (see k_inflate): the host pipeline below is faster on this box
+    // BGZF inflate on the GPU (k_inflate_lanes + k_lz_resolve): ~11 GB/s of inflated bytes on an
+    // MI355X against ~0.5 GB/s per host thread, after a fixed start-up -- taken for files of at least 2 GiB inflated
+    // when the caller gives at most 24 threads.  SQUID_GPU_INFLATE=1 / =0 forces / forbids it.
+    bool try_gpu = false;
+    if (gpu) {
+        const char* e = std::getenv("SQUID_GPU_INFLATE");
+        if (e) try_gpu = std::atoi(e) != 0;
+        else try_gpu = blocks.size() >= 32768 && n_threads <= 24;
+    }
     size_t hp = 0, first_rec_block = 0;
     if (only || try_gpu) {
         // the header first (a few blocks, inflated here): the number of references is part of the plausibility test
@@ -907,7 +915,12 @@ int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSi
         for (size_t i = 0; i < blocks.size(); ++i) br[i] = BgzfRange{blocks[i].coff, blocks[i].clen, blocks[i].isize, blocks[i].uoff};
         const int r2 = gpu(fm.p, br, nb, nb_end, only_begin, !unsynced, nref);
         if (std::getenv("SQUID_INGEST_TIMING")) std::fprintf(stderr, "ingest %s: map+index %.1f, GPU inflate+parse path total %.1f ms (rc %d)\n", path, t_map, since(t_all), r2);
-        if (r2 != 2) return r2;
+        if (r2 != 2) {
+            // (unmapping 6 GB takes ~100 ms: off the caller's path, as at the end of the host pipeline)
+            const uint8_t* mp = fm.p; const size_t mn = fm.n; fm.p = nullptr;
+            std::thread([mp, mn]() { if (mp) munmap((void*)mp, mn); }).detach();
+            return r2;
+        }
         // (the device-side checks were not satisfied: nothing was appended, continue with the host pipeline)
     }
     while (nb < nb_end) {

@@ -143,11 +143,12 @@ struct DeviceRecords {
     uint32_t h_slots = 1u << 16;
     DBuf<int32_t> ord_e, ord_o, ord_v;  // ordering kernel: packed input, packed output, values
     DBuf<long long> other64, spine64, okey64;
-    DBuf<uint8_t> bam_chunk, bgzf_in, bgzf_out;
-    DBuf<InflBlock> bgzf_tab;
+    DBuf<uint8_t> bam_chunk, bgzf_out, bgzf_carry;
     DBuf<long long> rec_sync, rec_end;
-    DBuf<uint32_t> il_tok;
-    DBuf<int32_t> il_ntok;
+    // GPU ingest, two batches in flight: compressed bytes + block table + tokens of a batch
+    struct InflSet { DBuf<uint8_t> in; DBuf<InflBlock> tab; DBuf<uint32_t> tok; DBuf<int32_t> ntok, flags; hipEvent_t ready = nullptr, freed = nullptr; std::vector<InflBlock> host_tab; };
+    InflSet il_set[2];
+    hipStream_t il_stream[2] = {nullptr, nullptr};  // one per set: the token passes of consecutive batches overlap
     DBuf<int32_t> rec_cnt, rec_base;
     DBuf<unsigned long long> bam_off, chim_hash;
     DBuf<uint32_t> chim_off, chim_len;
@@ -2226,9 +2227,12 @@ __global__ void k_rec_walk(RecScan S, long long nslices, const long long* sync, 
         }
     if (!EMIT) { count[s] = n; end_p[s] = p0 < 0 ? -1 : (long long)p; }
 }
-__global__ void k_rec_check(long long nslices, const long long* sync, const long long* end_p, int32_t* flags) {
+__global__ void k_rec_check(long long nslices, const long long* sync, const long long* end_p, int32_t* flags, long long* tail) {
     const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nslices || s == 0) return;
+    if (s >= nslices) return;
+    // the walk of the last slice that has a boundary stops at the incomplete tail of the range (slices are chained, so that is the largest stop)
+    if (sync[s] >= 0 && (s + 1 == nslices || sync[s + 1] < 0)) atomicMax((unsigned long long*)tail, (unsigned long long)end_p[s]);
+    if (s == 0) return;
     // every slice must start where the one before stopped; a slice without a boundary is only fine behind the last record
     if (sync[s] >= 0) { if (sync[s - 1] < 0 || end_p[s - 1] != sync[s]) atomicOr(&flags[0], 1024); }
     else if (sync[s - 1] >= 0 && end_p[s - 1] >= 0) {
@@ -2242,8 +2246,8 @@ static inline dim3 grid_for(int64_t n, int threads) { return dim3((unsigned)((n 
 // HIP-event bracket on the library stream.  Events come from a pool and are only read back by dev_flush_timers()
 // (called at the end of every ABI call), so timing a kernel never stalls the host.
 struct EvTimer {
-    sq_ctx* c; int slot; bool on;
-    EvTimer(sq_ctx* c, const char* name, double bytes) : c(c), on(true) {
+    sq_ctx* c; int slot; bool on; hipStream_t st;
+    EvTimer(sq_ctx* c, const char* name, double bytes, hipStream_t on_stream = nullptr) : c(c), on(true), st(on_stream ? on_stream : c->stream) {
         DeviceRecords& D = *c->dev;
         if (D.ev_used == D.ev_pool.size()) {
             hipEvent_t a = nullptr, b = nullptr;
@@ -2252,12 +2256,12 @@ struct EvTimer {
         }
         slot = (int)D.ev_used++;
         D.ev_pending.push_back(DeviceRecords::Pending{name, bytes, slot});
-        (void)hipEventRecord(D.ev_pool[slot].first, c->stream);
+        (void)hipEventRecord(D.ev_pool[slot].first, st);
     }
     void stop() {
         if (!on) return;
         on = false;
-        (void)hipEventRecord(c->dev->ev_pool[slot].second, c->stream);
+        (void)hipEventRecord(c->dev->ev_pool[slot].second, st);
     }
     ~EvTimer() { stop(); }
 };
@@ -2300,7 +2304,9 @@ void dev_destroy(sq_ctx* c) {
     D.calib.release(); D.okey.release(); D.oval.release(); D.other64.release(); D.spine64.release(); D.okey64.release(); D.zflag.release();
     D.cl_chr.release(); D.trig.release();
     D.ord_e.release(); D.ord_o.release(); D.ord_v.release();
-    D.pin.release(); D.il_tok.release(); D.il_ntok.release(); D.bgzf_in.release(); D.bgzf_out.release(); D.bgzf_tab.release(); D.rec_sync.release(); D.rec_end.release(); D.rec_cnt.release(); D.rec_base.release(); D.stripes.release(); D.bp_bucket.release(); D.bp_ev.release(); D.bp_end.release(); D.bp_valid.release();
+    D.pin.release(); for (auto& st : D.il_set) { st.in.release(); st.tab.release(); st.tok.release(); st.ntok.release(); st.flags.release(); if (st.ready) (void)hipEventDestroy(st.ready); if (st.freed) (void)hipEventDestroy(st.freed); st.ready = st.freed = nullptr; }
+    for (auto& q : D.il_stream) if (q) { (void)hipStreamDestroy(q); q = nullptr; }
+    D.bgzf_out.release(); D.bgzf_carry.release(); D.rec_sync.release(); D.rec_end.release(); D.rec_cnt.release(); D.rec_base.release(); D.stripes.release(); D.bp_bucket.release(); D.bp_ev.release(); D.bp_end.release(); D.bp_valid.release();
     for (auto& e : D.ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete c->dev;
     c->dev = nullptr;
@@ -2426,110 +2432,156 @@ static int parse_device(sq_ctx* c, const uint8_t* d_bam, size_t nbytes, const un
 }
 
 // K-1 + K0 for a whole file (or a shard's block range): compressed bytes -> HBM, inflate, record boundaries, parse -- the
-// host only indexes the BGZF blocks.  Returns 2 when the device-side boundary check (or the inflate) is not satisfied;
-// nothing has been appended then and the caller takes the host reader.
+// host only indexes the BGZF blocks.  The range is streamed in batches of SQUID_TOK_CAP_MB of inflated bytes (fixed-size
+// device buffers whatever the file size), two in flight: while batch k is resolved, cut into records and parsed on the
+// library stream, the compressed bytes of batches k+1 and k+2 are copied and turned into tokens on two more streams
+// (the token pass of a batch ends with a few long waves; the next batch fills the CUs they leave idle).  The incomplete record at
+// the end of a batch is carried in front of the next one.  Returns 2 when the device-side boundary check (or the
+// inflate) is not satisfied: the records appended so far are dropped again and the caller takes the host reader.
 int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, const std::vector<BgzfRange>& blocks, size_t b0, size_t b1, size_t begin, bool synced, int nref) {
     if (b1 <= b0) return SQ_OK;
     HIPCHK(hipSetDevice(c->P.device));
     DeviceRecords& D = *c->dev;
     hipStream_t s = c->stream;
-    const unsigned long long coff0 = blocks[b0].coff, coff1 = blocks[b1 - 1].coff + blocks[b1 - 1].clen, ubase = blocks[b0].uoff;
-    const unsigned long long ubytes = blocks[b1 - 1].uoff + blocks[b1 - 1].isize - ubase;
-    const int nblk = (int)(b1 - b0);
-    std::vector<InflBlock> tab((size_t)nblk);
-    for (int i = 0; i < nblk; ++i) tab[i] = InflBlock{blocks[b0 + i].coff - coff0, blocks[b0 + i].clen, blocks[b0 + i].isize, blocks[b0 + i].uoff};
-    const bool report = std::getenv("SQUID_INGEST_TIMING") != nullptr;
+    const int64_t n_save = D.n, nb_save = D.nb;
+    auto give_up = [&]() { (void)hipDeviceSynchronize(); D.n = n_save; D.nb = nb_save; c->counts.n_concordant = D.n; c->counts.n_blocks = D.nb; return 2; };
+    const bool report = std::getenv("SQUID_INGEST_TIMING") != nullptr, check = std::getenv("SQUID_INFLATE_CHECK") != nullptr;
     const auto w0 = std::chrono::steady_clock::now();
     auto since_ms = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
-    HIPCHK(D.bgzf_in.reserve((size_t)(coff1 - coff0) + 256));  /* (the input rings read up to 80 bytes ahead) */
-    HIPCHK(D.bgzf_out.reserve((size_t)ubytes + 64)); HIPCHK(D.bgzf_tab.reserve((size_t)nblk));
-    const double w_alloc = since_ms(w0);
-    HIPCHK(hipMemcpyAsync(D.bgzf_in.p, file + coff0, (size_t)(coff1 - coff0), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(D.bgzf_tab.p, tab.data(), (size_t)nblk * sizeof(InflBlock), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
-    { EvTimer t(c, "k_inflate", (double)(coff1 - coff0) + (double)ubytes);
-      if (std::getenv("SQUID_GPU_INFLATE_WAVE"))  // one wave per block (the first version)
-          hipLaunchKernelGGL(k_inflate, dim3((nblk + 3) / 4), dim3(256), 0, s, D.bgzf_in.p, D.bgzf_tab.p, 0, nblk, ubase, D.bgzf_out.p, D.flags.p);
-      else {
-          // two passes over batches of blocks: tokens (lane per block), then bytes (wave per block, window in LDS)
-          const size_t lds_bytes = IL_LDS_BYTES;
-          const bool one_pass = std::getenv("SQUID_GPU_INFLATE_ONEPASS") != nullptr;
-          // one batch: about one wave per CU in the token pass, tokens of 4 bytes per inflated byte at most (4 GiB)
-          const unsigned long long tok_cap = std::getenv("SQUID_TOK_CAP_MB") ? (unsigned long long)std::atoll(std::getenv("SQUID_TOK_CAP_MB")) << 20 : 3ull << 30;
-          HIPCHK(hipFuncSetAttribute((const void*)k_inflate_lanes<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-          HIPCHK(hipFuncSetAttribute((const void*)k_inflate_lanes<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-          HIPCHK(hipFuncSetAttribute((const void*)k_lz_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16));
-          for (int at = 0; at < nblk;) {
-              int end = at;
-              while (end < nblk && (end == at || tab[end].uoff + tab[end].isize - tab[at].uoff <= tok_cap)) ++end;
-              const int nb = end - at, waves = (nb + 63) / 64;
-              const unsigned long long bbase = tab[at].uoff, bbytes = tab[end - 1].uoff + tab[end - 1].isize - bbase;
-              if (one_pass)
-                  hipLaunchKernelGGL(k_inflate_lanes<false>, dim3(waves), dim3(64), lds_bytes, s, D.bgzf_in.p, D.bgzf_tab.p + at, nb, bbase, D.bgzf_out.p + (bbase - ubase), D.flags.p, nullptr, nullptr);
-              else {
-                  { const auto wa = std::chrono::steady_clock::now();
-                    HIPCHK(D.il_tok.reserve((size_t)bbytes + 64)); HIPCHK(D.il_ntok.reserve((size_t)nb));
-                    if (report && at == 0) std::fprintf(stderr, "GPU ingest: token buffer of %.1f GB allocated in %.1f ms\n", (double)D.il_tok.cap * 4e-9, since_ms(wa)); }
-                  { EvTimer t1(c, "k_inflate_tokens", (double)bbytes * 4);
-                    hipLaunchKernelGGL(k_inflate_lanes<true>, dim3(waves), dim3(64), lds_bytes, s, D.bgzf_in.p, D.bgzf_tab.p + at, nb, bbase, nullptr, D.flags.p, D.il_tok.p, D.il_ntok.p); }
-                  EvTimer t2(c, "k_lz_resolve", (double)bbytes * 5);
-                  hipLaunchKernelGGL(k_lz_resolve, dim3(nb), dim3(64), 65536 + 16, s, D.il_tok.p, D.il_ntok.p, D.bgzf_tab.p + at, nb, bbase, D.bgzf_out.p + (bbase - ubase), D.flags.p);
-              }
-              at = end;
-          }
-      } }
+    const unsigned long long cap = std::getenv("SQUID_TOK_CAP_MB") ? (unsigned long long)std::atoll(std::getenv("SQUID_TOK_CAP_MB")) << 20 : 1ull << 30;
+    const int variant = std::getenv("SQUID_GPU_INFLATE_WAVE") ? 2 : (std::getenv("SQUID_GPU_INFLATE_ONEPASS") ? 1 : 0);  // 0: tokens + resolve
+    HIPCHK(hipFuncSetAttribute((const void*)k_inflate_lanes<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)IL_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)k_inflate_lanes<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)IL_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)k_lz_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16));
+    for (auto& q : D.il_stream) if (!q) HIPCHK(hipStreamCreate(&q));
+    for (auto& st : D.il_set) {
+        if (!st.ready) HIPCHK(hipEventCreateWithFlags(&st.ready, hipEventDisableTiming));
+        if (!st.freed) HIPCHK(hipEventCreateWithFlags(&st.freed, hipEventDisableTiming));
+    }
+    struct Batch { size_t at, end; unsigned long long coff0, cbytes, bbase, bbytes; };
+    std::vector<Batch> batches;
+    for (size_t at = b0; at < b1;) {
+        size_t end = at;
+        while (end < b1 && (end == at || blocks[end].uoff + blocks[end].isize - blocks[at].uoff <= cap)) ++end;
+        batches.push_back(Batch{at, end, blocks[at].coff, blocks[end - 1].coff + blocks[end - 1].clen - blocks[at].coff, blocks[at].uoff, blocks[end - 1].uoff + blocks[end - 1].isize - blocks[at].uoff});
+        at = end;
+    }
+    const unsigned long long range_bytes = blocks[b1 - 1].uoff + blocks[b1 - 1].isize - blocks[b0].uoff;
     const Shard& sh = c->shard;
-    RecScan S{D.bgzf_out.p, (unsigned long long)begin, ubytes, nref, sh.on ? sh.first_ref : -1, sh.on ? sh.end_ref : 0, (sh.on && c->P.rank == c->P.world_size - 1) ? 1 : 0};
-    const long long nsl = (long long)((ubytes - begin + REC_SLICE - 1) / REC_SLICE);
-    if (nsl <= 0) return SQ_OK;
-    HIPCHK(D.rec_sync.reserve((size_t)nsl)); HIPCHK(D.rec_end.reserve((size_t)nsl)); HIPCHK(D.rec_cnt.reserve((size_t)nsl)); HIPCHK(D.rec_base.reserve((size_t)nsl));
-    int32_t* tot = D.flags.p + 8;
-    { EvTimer t(c, "k_rec_boundaries", 2.0 * (double)ubytes);
-      hipLaunchKernelGGL(k_rec_sync, grid_for(nsl, 256), dim3(256), 0, s, S, nsl, synced ? 1 : 0, D.rec_sync.p);
-      hipLaunchKernelGGL(k_rec_walk<false>, grid_for(nsl, 256), dim3(256), 0, s, S, nsl, D.rec_sync.p, D.rec_cnt.p, D.rec_end.p, nullptr, nullptr);
-      hipLaunchKernelGGL(k_rec_check, grid_for(nsl, 256), dim3(256), 0, s, nsl, D.rec_sync.p, D.rec_end.p, D.flags.p);
-      HIPCHK((device_scan<OpSum, true>(s, nsl, FArr{D.rec_cnt.p}, D.rec_base.p, D.spine, tot))); }
-    int32_t h[10];
-    HIPCHK(hipMemcpyAsync(h, D.flags.p, 10 * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    const double w_inflate = since_ms(w0);
-    if (std::getenv("SQUID_INFLATE_CHECK")) {  // debugging: every block against zlib
-        std::vector<uint8_t> got((size_t)ubytes), want;
-        HIPCHK(hipMemcpy(got.data(), D.bgzf_out.p, (size_t)ubytes, hipMemcpyDeviceToHost));
-        long bad = 0;
-        for (int i = 0; i < nblk; ++i) {
-            const BgzfRange& b = blocks[b0 + i];
-            want.resize(b.isize);
-            z_stream zs; std::memset(&zs, 0, sizeof zs);
-            inflateInit2(&zs, -15);
-            zs.next_in = (Bytef*)(file + b.coff); zs.avail_in = b.clen; zs.next_out = want.data(); zs.avail_out = b.isize;
-            inflate(&zs, Z_FINISH); inflateEnd(&zs);
-            if (std::memcmp(want.data(), got.data() + (b.uoff - ubase), b.isize) != 0) {
-                if (bad < 5) { size_t k = 0; while (want[k] == got[(b.uoff - ubase) + k]) ++k; std::fprintf(stderr, "[inflate check] block %d (isize %u clen %u) differs at byte %zu: want %02x got %02x\n", i, b.isize, b.clen, k, want[k], got[(b.uoff - ubase) + k]); }
-                ++bad;
+    // stage A of batch k: compressed bytes and block table to the device, token pass
+    auto stage_a = [&](size_t k) -> int {
+        const Batch& B = batches[k];
+        DeviceRecords::InflSet& st = D.il_set[k & 1];
+        hipStream_t sa = variant == 0 ? D.il_stream[k & 1] : s;  // (the other forms write the bytes themselves: one stream)
+        const int nb = (int)(B.end - B.at);
+        // largest compressed blocks first: the lanes of a wave get blocks of similar length (a wave takes as long as its
+        // longest lane) and the long waves start first
+        st.host_tab.resize((size_t)nb);
+        for (int i = 0; i < nb; ++i) { const BgzfRange& b = blocks[B.at + (size_t)i]; st.host_tab[(size_t)i] = InflBlock{b.coff - B.coff0, b.clen, b.isize, b.uoff}; }
+        std::stable_sort(st.host_tab.begin(), st.host_tab.end(), [](const InflBlock& x, const InflBlock& y) { return x.clen > y.clen; });
+        if (k >= 2) HIPCHK(hipStreamWaitEvent(sa, st.freed, 0));  // the resolve of batch k - 2 has read its tokens
+        HIPCHK(st.in.reserve((size_t)B.cbytes + 256));  // (the input rings read up to 80 bytes ahead)
+        HIPCHK(st.tab.reserve((size_t)nb)); HIPCHK(st.flags.reserve(4));
+        if (variant == 0) { HIPCHK(st.tok.reserve((size_t)B.bbytes + 64)); HIPCHK(st.ntok.reserve((size_t)nb)); }
+        HIPCHK(hipMemcpyAsync(st.in.p, file + B.coff0, (size_t)B.cbytes, hipMemcpyHostToDevice, sa));
+        HIPCHK(hipMemcpyAsync(st.tab.p, st.host_tab.data(), (size_t)nb * sizeof(InflBlock), hipMemcpyHostToDevice, sa));
+        HIPCHK(hipMemsetAsync(st.flags.p, 0, 4 * 4, sa));
+        if (variant == 0) {
+            EvTimer t1(c, "k_inflate_tokens", (double)B.cbytes + (double)B.bbytes * 2, sa);
+            hipLaunchKernelGGL(k_inflate_lanes<true>, dim3((nb + 63) / 64), dim3(64), IL_LDS_BYTES, sa, st.in.p, st.tab.p, nb, B.bbase, nullptr, st.flags.p, st.tok.p, st.ntok.p);
+        }
+        HIPCHK(hipEventRecord(st.ready, sa));
+        return SQ_OK;
+    };
+    { int rc = stage_a(0); if (rc) return rc; }
+    if (batches.size() > 1) { int rc = stage_a(1); if (rc) return rc; }
+    const double w_first = since_ms(w0);
+    unsigned long long carry = 0;  // bytes of the incomplete record in front of the batch (kept in D.bgzf_carry)
+    long check_bad = 0;
+    for (size_t k = 0; k < batches.size(); ++k) {
+        const Batch& B = batches[k];
+        DeviceRecords::InflSet& st = D.il_set[k & 1];
+        const int nb = (int)(B.end - B.at);
+        const unsigned long long pad = (16 - carry % 16) % 16;  // the batch's own bytes start 16-byte aligned
+        const unsigned long long limit = pad + carry + B.bbytes;
+        HIPCHK(D.bgzf_out.reserve((size_t)limit + 64));
+        HIPCHK(hipMemsetAsync(D.flags.p, 0, 10 * 4, s));
+        if (carry) HIPCHK(hipMemcpyAsync(D.bgzf_out.p + pad, D.bgzf_carry.p, (size_t)carry, hipMemcpyDeviceToDevice, s));
+        uint8_t* out = D.bgzf_out.p + pad + carry;
+        HIPCHK(hipStreamWaitEvent(s, st.ready, 0));
+        if (variant == 2) {  // one wave per block (the first version)
+            EvTimer t(c, "k_inflate", (double)B.cbytes + (double)B.bbytes);
+            hipLaunchKernelGGL(k_inflate, dim3((nb + 3) / 4), dim3(256), 0, s, st.in.p, st.tab.p, 0, nb, B.bbase, out, D.flags.p);
+        } else if (variant == 1) {
+            EvTimer t(c, "k_inflate", (double)B.cbytes + (double)B.bbytes);
+            hipLaunchKernelGGL(k_inflate_lanes<false>, dim3((nb + 63) / 64), dim3(64), IL_LDS_BYTES, s, st.in.p, st.tab.p, nb, B.bbase, out, D.flags.p, nullptr, nullptr);
+        } else {
+            EvTimer t2(c, "k_lz_resolve", (double)B.bbytes * 3);
+            hipLaunchKernelGGL(k_lz_resolve, dim3(nb), dim3(64), 65536 + 16, s, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, out, D.flags.p);
+        }
+        HIPCHK(hipEventRecord(st.freed, s));
+        RecScan S{D.bgzf_out.p, k == 0 ? (unsigned long long)begin : pad, limit, nref, sh.on ? sh.first_ref : -1, sh.on ? sh.end_ref : 0, (sh.on && c->P.rank == c->P.world_size - 1) ? 1 : 0};
+        const long long nsl = S.limit > S.begin ? (long long)((S.limit - S.begin + REC_SLICE - 1) / REC_SLICE) : 0;
+        int32_t h[10] = {0}, ha[4] = {0};
+        long long tail = 0;
+        if (nsl > 0) {
+            HIPCHK(D.rec_sync.reserve((size_t)nsl)); HIPCHK(D.rec_end.reserve((size_t)nsl + 1)); HIPCHK(D.rec_cnt.reserve((size_t)nsl)); HIPCHK(D.rec_base.reserve((size_t)nsl));
+            int32_t* tot = D.flags.p + 8;
+            long long* tail_d = D.rec_end.p + nsl;  // where the walk stopped: the start of the incomplete tail
+            HIPCHK(hipMemsetAsync(tail_d, 0, 8, s));
+            { EvTimer t(c, "k_rec_boundaries", 2.0 * (double)(S.limit - S.begin));
+              hipLaunchKernelGGL(k_rec_sync, grid_for(nsl, 256), dim3(256), 0, s, S, nsl, (k > 0 || synced) ? 1 : 0, D.rec_sync.p);
+              hipLaunchKernelGGL(k_rec_walk<false>, grid_for(nsl, 256), dim3(256), 0, s, S, nsl, D.rec_sync.p, D.rec_cnt.p, D.rec_end.p, nullptr, nullptr);
+              hipLaunchKernelGGL(k_rec_check, grid_for(nsl, 256), dim3(256), 0, s, nsl, D.rec_sync.p, D.rec_end.p, D.flags.p, tail_d);
+              HIPCHK((device_scan<OpSum, true>(s, nsl, FArr{D.rec_cnt.p}, D.rec_base.p, D.spine, tot))); }
+            HIPCHK(hipMemcpyAsync(&tail, tail_d, 8, hipMemcpyDeviceToHost, s));
+        }
+        HIPCHK(hipMemcpyAsync(h, D.flags.p, 10 * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(ha, st.flags.p, 4 * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (check) {  // debugging: every block against zlib
+            std::vector<uint8_t> got((size_t)B.bbytes), want;
+            HIPCHK(hipMemcpy(got.data(), out, (size_t)B.bbytes, hipMemcpyDeviceToHost));
+            for (size_t i = B.at; i < B.end; ++i) {
+                const BgzfRange& b = blocks[i];
+                want.resize(b.isize);
+                z_stream zs; std::memset(&zs, 0, sizeof zs);
+                inflateInit2(&zs, -15);
+                zs.next_in = (Bytef*)(file + b.coff); zs.avail_in = b.clen; zs.next_out = want.data(); zs.avail_out = b.isize;
+                inflate(&zs, Z_FINISH); inflateEnd(&zs);
+                if (std::memcmp(want.data(), got.data() + (b.uoff - B.bbase), b.isize) != 0) {
+                    if (check_bad < 5) { size_t q = 0; while (want[q] == got[(b.uoff - B.bbase) + q]) ++q; std::fprintf(stderr, "[inflate check] block %zu (isize %u clen %u) differs at byte %zu: want %02x got %02x\n", i - b0, b.isize, b.clen, q, want[q], got[(b.uoff - B.bbase) + q]); }
+                    ++check_bad;
+                }
+            }
+            std::fprintf(stderr, "[inflate check] blocks %zu..%zu of %zu: %ld differ so far, flags %d|%d, records %d, carry in %llu\n", B.at - b0, B.end - b0, b1 - b0, check_bad, h[0], ha[0], h[8], carry);
+        }
+        if ((h[0] | ha[0]) & (512 | 1024)) return give_up();
+        // the token pass of the batch after the next can start: its buffers are free once this batch's resolve is through
+        if (k + 2 < batches.size()) { int rc = stage_a(k + 2); if (rc) { (void)give_up(); return rc; } }
+        const int64_t n_rec = h[8];
+        if (n_rec > 0) {
+            HIPCHK(D.bam_off.reserve((size_t)n_rec));
+            hipLaunchKernelGGL(k_rec_walk<true>, grid_for(nsl, 256), dim3(256), 0, s, S, nsl, D.rec_sync.p, nullptr, nullptr, D.rec_base.p, D.bam_off.p);
+            // (sub-batches: the per-launch temporaries and the 32-bit block counters stay small)
+            const int64_t kBatch = (int64_t)1 << 24;
+            for (int64_t r0 = 0; r0 < n_rec; r0 += kBatch) {
+                c->ingest_total_bytes = (size_t)range_bytes; c->ingest_seen_bytes = (size_t)(B.bbase + B.bbytes - blocks[b0].uoff);  // sizes the arrays for the whole range at once
+                int rc = parse_device(c, D.bgzf_out.p, (size_t)limit, D.bam_off.p + r0, std::min(kBatch, n_rec - r0));
+                c->ingest_total_bytes = 0; c->ingest_seen_bytes = 0;
+                if (rc) { (void)give_up(); return rc; }
             }
         }
-        std::fprintf(stderr, "[inflate check] %ld of %d blocks differ, flags %d, records %d\n", bad, nblk, h[0], h[8]);
-        std::vector<long long> hs((size_t)nsl), he((size_t)nsl);
-        HIPCHK(hipMemcpy(hs.data(), D.rec_sync.p, (size_t)nsl * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(he.data(), D.rec_end.p, (size_t)nsl * 8, hipMemcpyDeviceToHost));
-        int shown = 0;
-        for (long long i = 1; i < nsl && shown < 6; ++i)
-            if (hs[i] >= 0 ? (hs[i - 1] < 0 || he[i - 1] != hs[i]) : false) { std::fprintf(stderr, "[boundary check] slice %lld of %lld: lo %llu sync %lld, previous sync %lld end %lld\n", i, nsl, (unsigned long long)begin + (unsigned long long)i * REC_SLICE, hs[i], hs[i - 1], he[i - 1]); ++shown; }
+        // the bytes behind the last complete record go in front of the next batch
+        const unsigned long long tail_at = tail > 0 ? (unsigned long long)tail : S.begin;
+        carry = limit > tail_at ? limit - tail_at : 0;
+        if (carry && k + 1 < batches.size()) {
+            HIPCHK(D.bgzf_carry.reserve((size_t)carry + 64));
+            HIPCHK(hipMemcpyAsync(D.bgzf_carry.p, D.bgzf_out.p + tail_at, (size_t)carry, hipMemcpyDeviceToDevice, s));
+        }
     }
-    if (h[0] & (512 | 1024)) return 2;
-    const int64_t n_rec = h[8];
-    if (n_rec == 0) return SQ_OK;
-    HIPCHK(D.bam_off.reserve((size_t)n_rec));
-    hipLaunchKernelGGL(k_rec_walk<true>, grid_for(nsl, 256), dim3(256), 0, s, S, nsl, D.rec_sync.p, nullptr, nullptr, D.rec_base.p, D.bam_off.p);
-    // parse in batches (the per-batch temporaries and the 32-bit block counters stay small)
-    const int64_t kBatch = (int64_t)1 << 24;
-    for (int64_t at = 0; at < n_rec; at += kBatch) {
-        c->ingest_total_bytes = (size_t)n_rec; c->ingest_seen_bytes = (size_t)std::min(at + kBatch, n_rec);  // (in records here: sizes the arrays for all batches at once)
-        int rc = parse_device(c, D.bgzf_out.p, (size_t)ubytes, D.bam_off.p + at, std::min(kBatch, n_rec - at));
-        c->ingest_total_bytes = 0; c->ingest_seen_bytes = 0;
-        if (rc) return rc;
-    }
-    if (report) std::fprintf(stderr, "GPU ingest: buffers %.1f, copy + inflate + boundaries until %.1f, parse until %.1f ms\n", w_alloc, w_inflate, since_ms(w0));
+    for (auto& q : D.il_stream) HIPCHK(hipStreamSynchronize(q));
+    if (report) std::fprintf(stderr, "GPU ingest: first two batches queued after %.1f ms, all %zu batches through after %.1f ms (%llu MB per batch, %llu bytes left incomplete at the end)\n", w_first, batches.size(), since_ms(w0), cap >> 20, carry);
     return SQ_OK;
 }
 

@@ -579,11 +579,11 @@ def test_gpu_bgzf_inflate_and_boundary_search_give_the_same_records(built, synth
 
     pre = synth("T2", "--indel-frac", "0.2")
     code = ("import sys, json, hashlib; sys.path.insert(0, %r); import squid_amd\n"
-            "ctx = squid_amd.Context(); ctx.load(sys.argv[1], %r); r = ctx.records()\n"
+            "ctx = squid_amd.Context(CTX); ctx.load(sys.argv[1], %r, shard=SHARD); r = ctx.records()\n"
             "print(json.dumps({k: hashlib.sha256(v.tobytes()).hexdigest() for k, v in r.items()}))") % (str(Path(__file__).resolve().parent.parent), f"{pre}.chim.bam")
 
-    def run(bam, env):
-        p = subprocess.run([sys.executable, "-c", code, str(bam)], env=dict(os.environ, **env), capture_output=True, text=True, check=True)
+    def run(bam, env, shard="None", ctx=""):
+        p = subprocess.run([sys.executable, "-c", code.replace("SHARD", shard).replace("CTX", ctx), str(bam)], env=dict(os.environ, **env), capture_output=True, text=True, check=True)
         if env:
             assert "GPU inflate+parse path" in p.stderr and "(rc 0)" in p.stderr, p.stderr
         return json.loads(p.stdout.strip().splitlines()[-1])
@@ -594,6 +594,15 @@ def test_gpu_bgzf_inflate_and_boundary_search_give_the_same_records(built, synth
     assert run(f"{pre}.bam", dict(gpu, SQUID_TOK_CAP_MB="0")) == want
     assert run(f"{pre}.bam", dict(gpu, SQUID_GPU_INFLATE_ONEPASS="1")) == want
     assert run(f"{pre}.bam", dict(gpu, SQUID_GPU_INFLATE_WAVE="1")) == want
+    # a chromosome shard reads a block range that starts and ends inside records
+    names, _ = squid_amd.read_header(f"{pre}.bam")
+    n = len(names)
+    for rank, shard in enumerate(("(0, 1)", f"(1, {n - 1})", f"({n - 1}, {n})")):
+        ctx = f"rank={rank}, world_size=3"
+        want_shard = run(f"{pre}.bam", {}, shard, ctx)
+        assert want_shard != want
+        assert run(f"{pre}.bam", gpu, shard, ctx) == want_shard, shard
+        assert run(f"{pre}.bam", dict(gpu, SQUID_TOK_CAP_MB="0"), shard, ctx) == want_shard, shard
     plans = {
         "stored": lambda i: (0, zlib.Z_DEFAULT_STRATEGY),
         "fixed": lambda i: (6, zlib.Z_FIXED),
