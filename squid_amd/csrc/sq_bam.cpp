@@ -12,6 +12,7 @@
 #include <sys/stat.h>
 #include <sys/mman.h>
 #include <fcntl.h>
+#include <memory>
 #include <mutex>
 #include <future>
 #include <condition_variable>
@@ -385,7 +386,6 @@ static int read_bam_header_bytes(const std::vector<uint8_t>& d, bool whole_file,
 }
 
 typedef std::function<int(const uint8_t*, size_t, const unsigned long long*, int64_t)> RawSink;
-typedef std::function<int(const uint8_t*, const std::vector<BgzfRange>&, size_t, size_t, size_t, bool, int)> GpuIngest;
 static int parse_bam_impl(const char* path, const ParseOpts& o, size_t batch_records, int n_threads, std::string& err,
                           const std::function<int(const HostBatch&)>& sink, const RawSink* raw_sink) {
     using clk = std::chrono::steady_clock;
@@ -602,14 +602,14 @@ namespace {
 struct FileMap {
     const uint8_t* p = nullptr;
     size_t n = 0;
-    bool open(const char* path) {
+    bool open(const char* path, bool populate = true) {
         int fd = ::open(path, O_RDONLY);
         if (fd < 0) return false;
         struct stat st;
         if (fstat(fd, &st) != 0) { ::close(fd); return false; }
         n = (size_t)st.st_size;
         if (n) {
-            void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);  // (populate: the block index walks every page anyway, one fault at a time)
+            void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE | (populate ? MAP_POPULATE : 0), fd, 0);  // (populate: the block index walks every page anyway, one fault at a time)
             if (m == MAP_FAILED) { ::close(fd); return false; }
             madvise(m, n, MADV_SEQUENTIAL);
             p = (const uint8_t*)m;
@@ -650,29 +650,41 @@ struct Pool {
     }
     ~Pool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (auto& t : th) t.join(); }
 };
-bool index_bgzf_view(const uint8_t* d, size_t n, std::vector<BgzfBlock>& blocks, size_t& total) {
-    size_t p = 0;
-    total = 0;
-    while (p + 18 <= n) {
-        if (d[p] != 0x1f || d[p + 1] != 0x8b || !(d[p + 3] & 4)) return false;
-        uint32_t xlen = d[p + 10] | (d[p + 11] << 8);
-        int bsize = -1;
-        for (size_t o = p + 12; o + 4 <= p + 12 + xlen && o + 6 <= n;) {
-            uint32_t slen = d[o + 2] | (d[o + 3] << 8);
-            if (d[o] == 'B' && d[o + 1] == 'C' && slen == 2) bsize = (d[o + 4] | (d[o + 5] << 8)) + 1;
-            o += 4 + slen;
+// walks the BGZF container of a mapped file, a piece at a time
+struct BgzfIndexer {
+    const uint8_t* d; size_t n, p = 0, total = 0; bool bad = false;
+    bool at_end() const { return bad || p + 18 > n; }
+    bool complete() const { return !bad && p == n; }
+    bool more(std::vector<BgzfBlock>& blocks, size_t max_new) {  // false: nothing was added
+        size_t added = 0;
+        while (added < max_new && p + 18 <= n) {
+            if (d[p] != 0x1f || d[p + 1] != 0x8b || !(d[p + 3] & 4)) { bad = true; break; }
+            uint32_t xlen = d[p + 10] | (d[p + 11] << 8);
+            int bsize = -1;
+            for (size_t o = p + 12; o + 4 <= p + 12 + xlen && o + 6 <= n;) {
+                uint32_t slen = d[o + 2] | (d[o + 3] << 8);
+                if (d[o] == 'B' && d[o + 1] == 'C' && slen == 2) bsize = (d[o + 4] | (d[o + 5] << 8)) + 1;
+                o += 4 + slen;
+            }
+            if (bsize < 0 || p + bsize > n) { bad = true; break; }
+            BgzfBlock b;
+            b.coff = p + 12 + xlen;
+            b.clen = (uint32_t)(bsize - 12 - xlen - 8);
+            std::memcpy(&b.isize, &d[p + bsize - 4], 4);
+            b.uoff = total;
+            total += b.isize;
+            blocks.push_back(b);
+            p += bsize;
+            ++added;
         }
-        if (bsize < 0 || p + bsize > n) return false;
-        BgzfBlock b;
-        b.coff = p + 12 + xlen;
-        b.clen = (uint32_t)(bsize - 12 - xlen - 8);
-        std::memcpy(&b.isize, &d[p + bsize - 4], 4);
-        b.uoff = total;
-        total += b.isize;
-        blocks.push_back(b);
-        p += bsize;
+        return added > 0;
     }
-    return p == n;
+};
+bool index_bgzf_view(const uint8_t* d, size_t n, std::vector<BgzfBlock>& blocks, size_t& total) {
+    BgzfIndexer ix{d, n};
+    while (ix.more(blocks, (size_t)1 << 20)) {}
+    total = ix.total;
+    return ix.complete();
 }
 // raw-DEFLATE decoder of libdeflate (2-3x faster than zlib's inflate), bound at run time when the shared library is on
 // the system (no header needed: three functions of its stable C API); zlib otherwise
@@ -830,15 +842,59 @@ int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSi
     auto since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
     double t_map = 0, t_inflate = 0, t_find = 0, t_wait = 0;
     const auto t_all = clk::now();
+    // BGZF inflate on the GPU (k_inflate_lanes + k_lz_resolve, DESIGN.md section 4): ~11 GB/s of inflated bytes on an
+    // MI355X against ~0.5 GB/s per host thread, after a fixed start-up -- taken for files of at least 1 GiB when the
+    // caller gives at most 24 threads.  SQUID_GPU_INFLATE=1 / =0 forces / forbids it.  For a whole file the block index
+    // is then built batch by batch while the GPU works (`lazy`: no page-table fill and no index walk up front).
+    const char* gpu_env = std::getenv("SQUID_GPU_INFLATE");
+    struct stat fst;
+    const size_t file_bytes = ::stat(path, &fst) == 0 ? (size_t)fst.st_size : 0;
+    const bool gpu_auto = file_bytes >= ((size_t)1 << 30) && n_threads <= 24;
+    bool try_gpu = gpu && (gpu_env ? std::atoi(gpu_env) != 0 : gpu_auto);
+    const bool lazy = try_gpu && !only;
     FileMap fm;
-    if (!fm.open(path)) { err = std::string("cannot open bamfile ") + path; return SQ_E_IO; }
+    if (!fm.open(path, !lazy)) { err = std::string("cannot open bamfile ") + path; return SQ_E_IO; }
+    // lazy: a helper fills the page tables front to back (24 GB/s, far ahead of the ~6 GB/s the GPU pipeline reads at):
+    // the copies to the device and the index walk then run over mapped pages instead of taking a fault every 4 KiB
+    struct Prefault {
+        std::thread th; std::atomic<bool> stop{false}; std::atomic<size_t> upto{0};  // upto: fill the tables up to this file offset, then wait
+        void start(const uint8_t* p, size_t n) {
+#ifdef MADV_POPULATE_READ
+            th = std::thread([this, p, n]() {
+                const size_t step = (size_t)32 << 20;
+                for (size_t o = 0; o < n && !stop.load(std::memory_order_relaxed);) {
+                    if (o >= upto.load(std::memory_order_relaxed)) { std::this_thread::sleep_for(std::chrono::microseconds(500)); continue; }
+                    if (madvise((void*)(p + o), std::min(step, n - o), MADV_POPULATE_READ) != 0) break;  // (then the readers fault the pages themselves)
+                    o += step;
+                }
+            });
+#else
+            (void)p; (void)n;
+#endif
+        }
+        void finish() { stop = true; if (th.joinable()) th.join(); }
+        ~Prefault() { finish(); }
+    } prefault;
+    // (it stays about two batches ahead of the index walk: while it runs, everything that maps or unmaps memory -- device
+    // allocations, thread stacks, large vectors -- queues behind it)
+    const size_t prefault_ahead = (size_t)1400 << 20;
+    prefault.upto = prefault_ahead;
+    if (lazy) prefault.start(fm.p, fm.n);
     std::vector<BgzfBlock> blocks;
     size_t total = 0;
-    if (!index_bgzf_view(fm.p, fm.n, blocks, total)) { err = "not a BGZF file"; return SQ_E_IO; }
+    BgzfIndexer ix{fm.p, fm.n};
+    if (lazy) { (void)ix.more(blocks, 64); if (ix.bad || blocks.empty()) { err = "not a BGZF file"; return SQ_E_IO; } }
+    else {
+        while (ix.more(blocks, (size_t)1 << 20)) {}
+        if (!ix.complete()) { err = "not a BGZF file"; return SQ_E_IO; }
+        total = ix.total;
+    }
     t_map = since(t_all);
-    if (on_total) on_total(total);  // inflated size of the whole file: lets the sink size its arrays once
+    if (!lazy && on_total) on_total(total);  // inflated size of the whole file: lets the sink size its arrays once
     n_threads = std::min(std::max(1, n_threads), 64);  // more helpers than that only cost their start-up
-    Pool pool(n_threads - 1);
+    // (the helpers are only started when the host pipeline runs: creating 15 threads next to the page-table helper costs 150+ ms)
+    std::unique_ptr<Pool> pool_holder;
+    if (!lazy) pool_holder.reset(new Pool(n_threads - 1));
     size_t only_begin = 0;
     const size_t kChunkBlocks = 1024;  // <= 64 MiB inflated per round (two such buffers; small enough to stay cheap to fault in and to free)
     RawBuf buf[2];
@@ -849,21 +905,12 @@ int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSi
     int cur = 0, nref = -1;
     bool header_done = false, unsynced = false;
     int rc = SQ_OK;
-    // BGZF inflate on the GPU (k_inflate_lanes + k_lz_resolve, DESIGN.md section 4): ~11 GB/s of inflated bytes on an
-    // MI355X against ~0.5 GB/s per host thread, after a fixed start-up -- taken for files of at least 2 GiB inflated
-    // when the caller gives at most 24 threads.  SQUID_GPU_INFLATE=1 / =0 forces / forbids it.
-    bool try_gpu = false;
-    if (gpu) {
-        const char* e = std::getenv("SQUID_GPU_INFLATE");
-        if (e) try_gpu = std::atoi(e) != 0;
-        else try_gpu = blocks.size() >= 32768 && n_threads <= 24;
-    }
     size_t hp = 0, first_rec_block = 0;
     if (only || try_gpu) {
         // the header first (a few blocks, inflated here): the number of references is part of the plausibility test
         std::vector<uint8_t> hdr;
         size_t hb = 0;
-        auto hneed = [&](size_t n) { while (hdr.size() < n && hb < blocks.size()) { size_t o = hdr.size(); hdr.resize(o + blocks[hb].isize); if (!inflate_one(fm.p, blocks[hb], hdr.data() + o)) return false; ++hb; } return hdr.size() >= n; };
+        auto hneed = [&](size_t n) { while (hdr.size() < n && (hb < blocks.size() || (lazy && ix.more(blocks, 64)))) { size_t o = hdr.size(); hdr.resize(o + blocks[hb].isize); if (!inflate_one(fm.p, blocks[hb], hdr.data() + o)) return false; ++hb; } return hdr.size() >= n; };
         if (!hneed(12) || std::memcmp(hdr.data(), "BAM\1", 4) != 0) { err = "not a BAM file"; return SQ_E_IO; }
         const int32_t ltext = rd32(hdr.data() + 4);
         if (!hneed(12 + (size_t)ltext)) { err = "truncated header"; return SQ_E_IO; }
@@ -913,16 +960,40 @@ int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSi
         // everything else on the GPU: the compressed blocks are copied as they are, inflated, cut into records and parsed there
         std::vector<BgzfRange> br(blocks.size());
         for (size_t i = 0; i < blocks.size(); ++i) br[i] = BgzfRange{blocks[i].coff, blocks[i].clen, blocks[i].isize, blocks[i].uoff};
-        const int r2 = gpu(fm.p, br, nb, nb_end, only_begin, !unsynced, nref);
-        if (std::getenv("SQUID_INGEST_TIMING")) std::fprintf(stderr, "ingest %s: map+index %.1f, GPU inflate+parse path total %.1f ms (rc %d)\n", path, t_map, since(t_all), r2);
+        const IndexMore more = [&](std::vector<BgzfRange>& v) -> bool {
+            const size_t before = blocks.size();
+            prefault.upto = ix.p + prefault_ahead;
+            const bool any = ix.more(blocks, 16384);
+            for (size_t i = before; i < blocks.size(); ++i) v.push_back(BgzfRange{blocks[i].coff, blocks[i].clen, blocks[i].isize, blocks[i].uoff});
+            return any;
+        };
+        const double t_before_gpu = since(t_all);
+        const int r2 = gpu(fm.p, br, nb, lazy ? (size_t)-1 : nb_end, only_begin, !unsynced, nref, lazy ? more : IndexMore(), fm.n);
+        if (std::getenv("SQUID_INGEST_TIMING")) std::fprintf(stderr, "ingest %s: map+index %.1f, header %.1f, GPU inflate+parse path total %.1f ms (rc %d)\n", path, t_map, t_before_gpu, since(t_all), r2);
         if (r2 != 2) {
-            // (unmapping 6 GB takes ~100 ms: off the caller's path, as at the end of the host pipeline)
+            if (r2 == SQ_OK && lazy && !ix.complete()) { err = "not a BGZF file"; return SQ_E_IO; }
+            // unmapping 6 GB takes ~150 ms: off the caller's path, as at the end of the host pipeline -- together with the
+            // large vectors (freeing those unmaps too and would wait for the big one)
+            prefault.finish();
             const uint8_t* mp = fm.p; const size_t mn = fm.n; fm.p = nullptr;
-            std::thread([mp, mn]() { if (mp) munmap((void*)mp, mn); }).detach();
+            auto* junk = new std::pair<std::vector<BgzfBlock>, std::vector<BgzfRange>>(std::move(blocks), std::move(br));
+            std::thread([mp, mn, junk]() { if (mp) munmap((void*)mp, mn); delete junk; }).detach();
+            if (std::getenv("SQUID_INGEST_TIMING")) std::fprintf(stderr, "ingest %s: returning after %.1f ms\n", path, since(t_all));
             return r2;
+        }
+        if (lazy) {  // the host pipeline wants the whole index (and its helpers)
+            prefault.finish();
+            pool_holder.reset(new Pool(n_threads - 1));
+            while (ix.more(blocks, (size_t)1 << 20)) {}
+            if (!ix.complete()) { err = "not a BGZF file"; return SQ_E_IO; }
+            total = ix.total;
+            nb_end = blocks.size();
+            if (on_total) on_total(total);
         }
         // (the device-side checks were not satisfied: nothing was appended, continue with the host pipeline)
     }
+    if (!pool_holder) pool_holder.reset(new Pool(n_threads - 1));
+    Pool& pool = *pool_holder;
     while (nb < nb_end) {
         const size_t b1 = std::min(nb_end, nb + kChunkBlocks);
         const size_t base = blocks[nb].uoff, bytes = (b1 == blocks.size() ? total : blocks[b1].uoff) - base;

@@ -800,8 +800,8 @@ int sq_ingest_concordant_file(sq_ctx* c, const char* path, int32_t n_threads) {
         const RefRange rr{c->shard.first_ref, c->shard.end_ref, c->P.rank == c->P.world_size - 1};
         int rc = scan_bam_file(path, n_threads, c->err, [&](const uint8_t* bam, size_t nbytes, const unsigned long long* off, int64_t n) { c->ingest_seen_bytes += nbytes; return ingest_raw(c, bam, nbytes, off, n); },
                                [&](size_t total) { c->ingest_total_bytes = c->shard.on ? 0 : total; }, c->shard.on ? &rr : nullptr,
-                               [&](const uint8_t* file, const std::vector<BgzfRange>& blocks, size_t b0, size_t b1, size_t begin, bool synced, int nref) {
-                                   return dev_ingest_bgzf(c, file, blocks, b0, b1, begin, synced, nref); });
+                               [&](const uint8_t* file, std::vector<BgzfRange>& blocks, size_t b0, size_t b1, size_t begin, bool synced, int nref, const IndexMore& more, size_t file_bytes) {
+                                   return dev_ingest_bgzf(c, file, blocks, b0, b1, begin, synced, nref, more, file_bytes); });
         c->ingest_total_bytes = 0;
         const double t_scan = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_file0).count();
         dev_flush_timers(c);

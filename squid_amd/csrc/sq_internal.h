@@ -223,9 +223,14 @@ int parse_bam_file(const char* path, const ParseOpts& o, size_t batch_records, i
 // raw mode: inflate + record-boundary walk on the host, hand each chunk (bytes, record offsets) to `sink`
 struct BgzfRange { unsigned long long coff; uint32_t clen, isize; unsigned long long uoff; };  // one BGZF block: payload offset/length in the file, inflated size/offset
 struct RefRange { int first_ref, end_ref; bool with_unplaced; };  // chromosome shard: only the blocks that can hold its records are inflated
+// the GPU reader: (file, blocks, first block, end block or npos, offset of the first record, starts on a record, n_ref,
+// index_more, file bytes).  index_more (may be null) appends the next blocks of the file to `blocks` and returns false at
+// the end of the file: the block index is then built batch by batch, while the GPU works on the batches before
+typedef std::function<bool(std::vector<BgzfRange>&)> IndexMore;
+typedef std::function<int(const uint8_t*, std::vector<BgzfRange>&, size_t, size_t, size_t, bool, int, const IndexMore&, size_t)> GpuIngest;
 int scan_bam_file(const char* path, int n_threads, std::string& err, const std::function<int(const uint8_t*, size_t, const unsigned long long*, int64_t)>& sink,
                   const std::function<void(size_t)>& on_total = nullptr, const RefRange* only = nullptr,
-                  const std::function<int(const uint8_t*, const std::vector<BgzfRange>&, size_t, size_t, size_t, bool, int)>& gpu = nullptr);
+                  const GpuIngest& gpu = nullptr);
 
 // ---- sq_chimeric.cpp
 int build_fragments(sq_ctx* c, const sq_aln_batch* b);
@@ -274,7 +279,7 @@ void dev_flush_timers(sq_ctx* c);
 int dev_append_records(sq_ctx* c, const sq_aln_batch* b);
 int dev_upload_chim_names(sq_ctx* c);
 int dev_parse_append(sq_ctx* c, const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n_rec);
-int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, const std::vector<BgzfRange>& blocks, size_t b0, size_t b1, size_t begin, bool synced, int nref);
+int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& blocks, size_t b0, size_t b1, size_t begin, bool synced, int nref, const IndexMore& index_more, size_t file_bytes);
 struct HostBatch;
 int dev_download_records(sq_ctx* c, HostBatch& hb);
 struct SegSupport {

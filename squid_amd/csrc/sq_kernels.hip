@@ -2438,8 +2438,9 @@ static int parse_device(sq_ctx* c, const uint8_t* d_bam, size_t nbytes, const un
 // (the token pass of a batch ends with a few long waves; the next batch fills the CUs they leave idle).  The incomplete record at
 // the end of a batch is carried in front of the next one.  Returns 2 when the device-side boundary check (or the
 // inflate) is not satisfied: the records appended so far are dropped again and the caller takes the host reader.
-int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, const std::vector<BgzfRange>& blocks, size_t b0, size_t b1, size_t begin, bool synced, int nref) {
+int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& blocks, size_t b0, size_t b1, size_t begin, bool synced, int nref, const IndexMore& index_more, size_t file_bytes) {
     if (b1 <= b0) return SQ_OK;
+    const auto w_entry = std::chrono::steady_clock::now();
     HIPCHK(hipSetDevice(c->P.device));
     DeviceRecords& D = *c->dev;
     hipStream_t s = c->stream;
@@ -2460,17 +2461,35 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, const std::vector<BgzfRange>
     }
     struct Batch { size_t at, end; unsigned long long coff0, cbytes, bbase, bbytes; };
     std::vector<Batch> batches;
-    for (size_t at = b0; at < b1;) {
-        size_t end = at;
-        while (end < b1 && (end == at || blocks[end].uoff + blocks[end].isize - blocks[at].uoff <= cap)) ++end;
-        batches.push_back(Batch{at, end, blocks[at].coff, blocks[end - 1].coff + blocks[end - 1].clen - blocks[at].coff, blocks[at].uoff, blocks[end - 1].uoff + blocks[end - 1].isize - blocks[at].uoff});
-        at = end;
-    }
-    const unsigned long long range_bytes = blocks[b1 - 1].uoff + blocks[b1 - 1].isize - blocks[b0].uoff;
+    // batches are planned as they are needed: with index_more the block index itself grows batch by batch (b1 = npos)
+    bool more_blocks = (bool)index_more;
+    size_t plan_at = b0;
+    auto plan = [&](size_t k) -> bool {  // makes batches[k] exist; false when the range is used up
+        while (batches.size() <= k) {
+            const size_t at = plan_at;
+            while (more_blocks && (blocks.size() <= at || blocks.back().uoff + blocks.back().isize - blocks[at].uoff <= cap)) more_blocks = index_more(blocks);
+            const size_t stop = more_blocks || b1 == (size_t)-1 ? blocks.size() : std::min(b1, blocks.size());
+            if (at >= stop) return false;
+            size_t end = at;
+            while (end < stop && (end == at || blocks[end].uoff + blocks[end].isize - blocks[at].uoff <= cap)) ++end;
+            batches.push_back(Batch{at, end, blocks[at].coff, blocks[end - 1].coff + blocks[end - 1].clen - blocks[at].coff, blocks[at].uoff, blocks[end - 1].uoff + blocks[end - 1].isize - blocks[at].uoff});
+            plan_at = end;
+        }
+        return true;
+    };
+    const unsigned long long first_uoff = blocks[b0].uoff;
+    // inflated size of the whole range, for sizing the record arrays once: exact with a full index, else from the file size
+    auto range_bytes_estimate = [&]() -> unsigned long long {
+        if (!index_more) { const size_t e = std::min(b1, blocks.size()); return blocks[e - 1].uoff + blocks[e - 1].isize - first_uoff; }
+        const BgzfRange& l = blocks.back();
+        const double ratio = (double)(l.uoff + l.isize) / (double)(l.coff + l.clen);
+        return (unsigned long long)(ratio * 1.03 * (double)file_bytes);
+    };
     const Shard& sh = c->shard;
     // stage A of batch k: compressed bytes and block table to the device, token pass
-    auto stage_a = [&](size_t k) -> int {
-        const Batch& B = batches[k];
+    auto stage_a = [&](size_t k) -> int {  // (SQ_OK also when there is no batch k)
+        if (!plan(k)) return SQ_OK;
+        const Batch B = batches[k];
         DeviceRecords::InflSet& st = D.il_set[k & 1];
         hipStream_t sa = variant == 0 ? D.il_stream[k & 1] : s;  // (the other forms write the bytes themselves: one stream)
         const int nb = (int)(B.end - B.at);
@@ -2494,12 +2513,12 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, const std::vector<BgzfRange>
         return SQ_OK;
     };
     { int rc = stage_a(0); if (rc) return rc; }
-    if (batches.size() > 1) { int rc = stage_a(1); if (rc) return rc; }
+    { int rc = stage_a(1); if (rc) return rc; }
     const double w_first = since_ms(w0);
     unsigned long long carry = 0;  // bytes of the incomplete record in front of the batch (kept in D.bgzf_carry)
     long check_bad = 0;
     for (size_t k = 0; k < batches.size(); ++k) {
-        const Batch& B = batches[k];
+        const Batch B = batches[k];
         DeviceRecords::InflSet& st = D.il_set[k & 1];
         const int nb = (int)(B.end - B.at);
         const unsigned long long pad = (16 - carry % 16) % 16;  // the batch's own bytes start 16-byte aligned
@@ -2558,7 +2577,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, const std::vector<BgzfRange>
         }
         if ((h[0] | ha[0]) & (512 | 1024)) return give_up();
         // the token pass of the batch after the next can start: its buffers are free once this batch's resolve is through
-        if (k + 2 < batches.size()) { int rc = stage_a(k + 2); if (rc) { (void)give_up(); return rc; } }
+        { int rc = stage_a(k + 2); if (rc) { (void)give_up(); return rc; } }
         const int64_t n_rec = h[8];
         if (n_rec > 0) {
             HIPCHK(D.bam_off.reserve((size_t)n_rec));
@@ -2566,7 +2585,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, const std::vector<BgzfRange>
             // (sub-batches: the per-launch temporaries and the 32-bit block counters stay small)
             const int64_t kBatch = (int64_t)1 << 24;
             for (int64_t r0 = 0; r0 < n_rec; r0 += kBatch) {
-                c->ingest_total_bytes = (size_t)range_bytes; c->ingest_seen_bytes = (size_t)(B.bbase + B.bbytes - blocks[b0].uoff);  // sizes the arrays for the whole range at once
+                c->ingest_total_bytes = (size_t)range_bytes_estimate(); c->ingest_seen_bytes = (size_t)(B.bbase + B.bbytes - first_uoff);  // sizes the arrays for the whole range at once
                 int rc = parse_device(c, D.bgzf_out.p, (size_t)limit, D.bam_off.p + r0, std::min(kBatch, n_rec - r0));
                 c->ingest_total_bytes = 0; c->ingest_seen_bytes = 0;
                 if (rc) { (void)give_up(); return rc; }
@@ -2575,13 +2594,13 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, const std::vector<BgzfRange>
         // the bytes behind the last complete record go in front of the next batch
         const unsigned long long tail_at = tail > 0 ? (unsigned long long)tail : S.begin;
         carry = limit > tail_at ? limit - tail_at : 0;
-        if (carry && k + 1 < batches.size()) {
+        if (carry && plan(k + 1)) {
             HIPCHK(D.bgzf_carry.reserve((size_t)carry + 64));
             HIPCHK(hipMemcpyAsync(D.bgzf_carry.p, D.bgzf_out.p + tail_at, (size_t)carry, hipMemcpyDeviceToDevice, s));
         }
     }
     for (auto& q : D.il_stream) HIPCHK(hipStreamSynchronize(q));
-    if (report) std::fprintf(stderr, "GPU ingest: first two batches queued after %.1f ms, all %zu batches through after %.1f ms (%llu MB per batch, %llu bytes left incomplete at the end)\n", w_first, batches.size(), since_ms(w0), cap >> 20, carry);
+    if (report) std::fprintf(stderr, "GPU ingest: first two batches queued after %.1f ms, all %zu batches through after %.1f ms (%.1f ms since entry; %llu MB per batch, %llu bytes left incomplete at the end)\n", w_first, batches.size(), since_ms(w0), since_ms(w_entry), cap >> 20, carry);
     return SQ_OK;
 }
 
