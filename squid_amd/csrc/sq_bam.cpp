@@ -9,6 +9,7 @@
 #include <cctype>
 #include <dlfcn.h>
 #include <unistd.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <sys/mman.h>
 #include <fcntl.h>
@@ -837,19 +838,41 @@ int find_records(const uint8_t* u, size_t begin, size_t limit, int nref, Pool& p
 }
 }  // namespace
 
+// CPUs this process can really use: the affinity mask, cut by the cgroup's CPU quota (a container may see 256 logical
+// CPUs and be allowed 16 of them)
+static int usable_cpus() {
+    int n = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+        char q[32]; long long period = 0;
+        if (std::fscanf(f, "%31s %lld", q, &period) == 2 && period > 0 && std::strcmp(q, "max") != 0) {
+            const long long quota = std::atoll(q);
+            if (quota > 0) n = std::min<long long>(n, (quota + period - 1) / period);
+        }
+        std::fclose(f);
+    } else if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
+        long long quota = -1, period = 0;
+        if (std::fscanf(g, "%lld", &quota) != 1) quota = -1;
+        std::fclose(g);
+        if (FILE* h = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(h, "%lld", &period) != 1) period = 0; std::fclose(h); }
+        if (quota > 0 && period > 0) n = std::min<long long>(n, (quota + period - 1) / period);
+    }
+    return std::max(1, n);
+}
 int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSink& sink, const std::function<void(size_t)>& on_total, const RefRange* only, const GpuIngest& gpu) {
     using clk = std::chrono::steady_clock;
     auto since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
     double t_map = 0, t_inflate = 0, t_find = 0, t_wait = 0;
     const auto t_all = clk::now();
     // BGZF inflate on the GPU (k_inflate_lanes + k_lz_resolve): ~11 GB/s of inflated bytes on an
-    // MI355X against ~0.5 GB/s per host thread, after a fixed start-up -- taken for files of at least 1 GiB when the
-    // caller gives at most 24 threads.  SQUID_GPU_INFLATE=1 / =0 forces / forbids it.  For a whole file the block index
+    // MI355X against ~0.5 GB/s per host thread, after a fixed start-up -- taken for files of at least 1 GiB when at
+    // most 24 threads can really run (the caller's count, the affinity mask, the cgroup quota).  SQUID_GPU_INFLATE=1 / =0 forces / forbids it.  For a whole file the block index
     // is then built batch by batch while the GPU works (`lazy`: no page-table fill and no index walk up front).
     const char* gpu_env = std::getenv("SQUID_GPU_INFLATE");
     struct stat fst;
     const size_t file_bytes = ::stat(path, &fst) == 0 ? (size_t)fst.st_size : 0;
-    const bool gpu_auto = file_bytes >= ((size_t)1 << 30) && n_threads <= 24;
+    const bool gpu_auto = file_bytes >= ((size_t)1 << 30) && std::min(n_threads, usable_cpus()) <= 24;
     bool try_gpu = gpu && (gpu_env ? std::atoi(gpu_env) != 0 : gpu_auto);
     const bool lazy = try_gpu && !only;
     FileMap fm;
