@@ -986,7 +986,7 @@ int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSi
         const IndexMore more = [&](std::vector<BgzfRange>& v) -> bool {
             const size_t before = blocks.size();
             prefault.upto = ix.p + prefault_ahead;
-            const bool any = ix.more(blocks, 16384);
+            const bool any = ix.more(blocks, blocks.size() < 8192 ? 2048 : 16384);
             for (size_t i = before; i < blocks.size(); ++i) v.push_back(BgzfRange{blocks[i].coff, blocks[i].clen, blocks[i].isize, blocks[i].uoff});
             return any;
         };

@@ -1788,8 +1788,9 @@ __device__ __forceinline__ int il_decode_ll(ILane& b, const ILds& L, int lane) {
     b.buf >>= l; b.cnt -= l;
     return (int)(e >> 4);
 }
+template <bool REFILL = true>
 __device__ __forceinline__ int il_decode_dd(ILane& b, const ILds& L, int lane) {
-    il_refill(b);
+    if (REFILL) il_refill(b);
     const uint32_t root = (uint32_t)b.buf & ((1u << IL_DB) - 1);
     const uint16_t e = L.root_dd[root * 64 + lane];
     if (e & 15) { const int l = e & 15; b.buf >>= l; b.cnt -= l; return e >> 4; }
@@ -1897,8 +1898,7 @@ __device__ bool il_build_ll(const ILds& L, int lane, bool me, int n) {
 template <bool TOK>
 __global__ __launch_bounds__(64) void k_inflate_lanes(const uint8_t* file, const InflBlock* blocks, int nblocks, unsigned long long out_base, uint8_t* outbuf, int32_t* flags, uint32_t* tok, int32_t* ntok) {
     extern __shared__ uint16_t il_lds[];  // IL_LDS_BYTES
-    __shared__ uint16_t sh_lb[32], sh_db[32];
-    __shared__ uint8_t sh_le[32], sh_de[32], sh_clo[32];
+    __shared__ uint8_t sh_clo[32];
     ILds L;
     L.root_ll = il_lds;                          L.sub_ll = L.root_ll + (1 << IL_LB) * 64;
     L.root_dd = L.sub_ll + IL_SUB * 64;          L.cnt_dd = L.root_dd + (1 << IL_DB) * 64;
@@ -1908,8 +1908,6 @@ __global__ __launch_bounds__(64) void k_inflate_lanes(const uint8_t* file, const
     uint32_t* stage = (uint32_t*)(L.lens + IL_LENS * 64);  // tokens on their way out: stage[(k % IL_STAGE) * 64 + lane]
     uint32_t* ring = stage + IL_STAGE * 64;
     const int lane = threadIdx.x;
-    if (lane < 29) { sh_lb[lane] = c_lbase[lane]; sh_le[lane] = c_lext[lane]; }
-    if (lane < 30) { sh_db[lane] = c_dbase[lane]; sh_de[lane] = c_dext[lane]; }
     if (lane < 19) sh_clo[lane] = c_clorder[lane];
     wave_sync();
     const int bi = blockIdx.x * 64 + lane;
@@ -2050,10 +2048,20 @@ __global__ __launch_bounds__(64) void k_inflate_lanes(const uint8_t* file, const
         if (sym == 256) { in_block = false; if (last) done = true; continue; }
         const int ls = sym - 257;
         if (ls >= 29) { err = true; done = true; continue; }
-        const uint32_t len = sh_lb[ls] + il_take(b, sh_le[ls]);
-        const int ds = il_decode_dd(b, L, lane);
+        // base and extra bits of the length / distance symbol by arithmetic (RFC 1951 3.2.5: four symbols per extra-bit count,
+        // two for distances) rather than from tables: every table lookup is an LDS round trip in the longest path of the step.
+        // One refill covers the rest of the step: 5 + 15 + 13 bits at most.
+        il_refill(b);
+        const uint32_t lx = ls < 8 || ls == 28 ? 0u : (uint32_t)(ls - 4) >> 2;
+        const uint32_t lbase = ls < 8 ? 3u + (uint32_t)ls : (ls == 28 ? 258u : 3u + ((4u + ((uint32_t)ls & 3u)) << lx));
+        const uint32_t len = lbase + ((uint32_t)b.buf & ((1u << lx) - 1));
+        b.buf >>= lx; b.cnt -= (int)lx;
+        const int ds = il_decode_dd<false>(b, L, lane);
         if (ds < 0 || ds >= 30) { err = true; done = true; continue; }
-        const uint32_t dist = sh_db[ds] + il_take(b, sh_de[ds]);
+        const uint32_t dx = ds < 4 ? 0u : (uint32_t)(ds - 2) >> 1;
+        const uint32_t dbase = ds < 4 ? 1u + (uint32_t)ds : 1u + ((2u + ((uint32_t)ds & 1u)) << dx);
+        const uint32_t dist = dbase + ((uint32_t)b.buf & ((1u << dx) - 1));
+        b.buf >>= dx; b.cnt -= (int)dx;
         if (dist > outpos || outpos + len > blk.isize) { err = true; done = true; continue; }
         if (TOK) { emit(0x80000000u | (len << 16) | (dist - 1)); outpos += len; }
         else { pend_len = len; pend_src = outpos - dist; }
@@ -2454,7 +2462,14 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     HIPCHK(hipFuncSetAttribute((const void*)k_inflate_lanes<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)IL_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_inflate_lanes<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)IL_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_lz_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16));
-    for (auto& q : D.il_stream) if (!q) HIPCHK(hipStreamCreate(&q));
+    for (auto& q : D.il_stream)
+        if (!q) {
+            // lowest priority: a token wave holds its CU for tens of milliseconds, and the resolve / boundary / parse kernels
+            // of the batch in front (library stream) should get the CUs that come free first
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            if (hipStreamCreateWithPriority(&q, hipStreamNonBlocking, lo) != hipSuccess) { (void)hipGetLastError(); HIPCHK(hipStreamCreate(&q)); }
+        }
     for (auto& st : D.il_set) {
         if (!st.ready) HIPCHK(hipEventCreateWithFlags(&st.ready, hipEventDisableTiming));
         if (!st.freed) HIPCHK(hipEventCreateWithFlags(&st.freed, hipEventDisableTiming));
@@ -2467,11 +2482,13 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     auto plan = [&](size_t k) -> bool {  // makes batches[k] exist; false when the range is used up
         while (batches.size() <= k) {
             const size_t at = plan_at;
-            while (more_blocks && (blocks.size() <= at || blocks.back().uoff + blocks.back().isize - blocks[at].uoff <= cap)) more_blocks = index_more(blocks);
+            // the first batches are small, so that the GPU has work after a few milliseconds of index walk and copy
+            const unsigned long long ramp = (unsigned long long)128 << (20 + std::min<size_t>(batches.size(), 8)), bcap = std::min(cap, ramp);
+            while (more_blocks && (blocks.size() <= at || blocks.back().uoff + blocks.back().isize - blocks[at].uoff <= bcap)) more_blocks = index_more(blocks);
             const size_t stop = more_blocks || b1 == (size_t)-1 ? blocks.size() : std::min(b1, blocks.size());
             if (at >= stop) return false;
             size_t end = at;
-            while (end < stop && (end == at || blocks[end].uoff + blocks[end].isize - blocks[at].uoff <= cap)) ++end;
+            while (end < stop && (end == at || blocks[end].uoff + blocks[end].isize - blocks[at].uoff <= bcap)) ++end;
             batches.push_back(Batch{at, end, blocks[at].coff, blocks[end - 1].coff + blocks[end - 1].clen - blocks[at].coff, blocks[at].uoff, blocks[end - 1].uoff + blocks[end - 1].isize - blocks[at].uoff});
             plan_at = end;
         }
@@ -2499,10 +2516,13 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         for (int i = 0; i < nb; ++i) { const BgzfRange& b = blocks[B.at + (size_t)i]; st.host_tab[(size_t)i] = InflBlock{b.coff - B.coff0, b.clen, b.isize, b.uoff}; }
         std::stable_sort(st.host_tab.begin(), st.host_tab.end(), [](const InflBlock& x, const InflBlock& y) { return x.clen > y.clen; });
         if (k >= 2) HIPCHK(hipStreamWaitEvent(sa, st.freed, 0));  // the resolve of batch k - 2 has read its tokens
+        const auto wa0 = std::chrono::steady_clock::now();
         HIPCHK(st.in.reserve((size_t)B.cbytes + 256));  // (the input rings read up to 80 bytes ahead)
         HIPCHK(st.tab.reserve((size_t)nb)); HIPCHK(st.flags.reserve(4));
         if (variant == 0) { HIPCHK(st.tok.reserve((size_t)B.bbytes + 64)); HIPCHK(st.ntok.reserve((size_t)nb)); }
+        const double wa1 = since_ms(wa0);
         HIPCHK(hipMemcpyAsync(st.in.p, file + B.coff0, (size_t)B.cbytes, hipMemcpyHostToDevice, sa));
+        if (report && k < 3) std::fprintf(stderr, "GPU ingest: batch %zu planned at %.1f ms, buffers %.1f ms, copy of %.2f GB returned after %.1f ms\n", k, std::chrono::duration<double, std::milli>(wa0 - w0).count(), wa1, (double)B.cbytes * 1e-9, since_ms(wa0) - wa1);
         HIPCHK(hipMemcpyAsync(st.tab.p, st.host_tab.data(), (size_t)nb * sizeof(InflBlock), hipMemcpyHostToDevice, sa));
         HIPCHK(hipMemsetAsync(st.flags.p, 0, 4 * 4, sa));
         if (variant == 0) {
