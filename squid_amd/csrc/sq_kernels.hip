@@ -2452,6 +2452,10 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     HIPCHK(hipSetDevice(c->P.device));
     DeviceRecords& D = *c->dev;
     hipStream_t s = c->stream;
+    {   // the batch buffers take ~12 GB next to the record arrays: on a GPU that is short of memory the host reader runs instead
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < ((size_t)20 << 30)) { (void)hipGetLastError(); return 2; }
+    }
     const int64_t n_save = D.n, nb_save = D.nb;
     auto give_up = [&]() { (void)hipDeviceSynchronize(); D.n = n_save; D.nb = nb_save; c->counts.n_concordant = D.n; c->counts.n_blocks = D.nb; return 2; };
     const bool report = std::getenv("SQUID_INGEST_TIMING") != nullptr, check = std::getenv("SQUID_INFLATE_CHECK") != nullptr;
