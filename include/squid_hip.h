@@ -109,6 +109,15 @@ int sq_ingest_concordant_bam(sq_ctx* c, const uint8_t* bam, size_t nbytes, const
 int sq_read_header(const char* bam_path, int32_t* n_ref, int32_t* ref_len, char* names, size_t names_cap);
 int sq_ingest_chimeric_file(sq_ctx* c, const char* bam_path);
 int sq_ingest_concordant_file(sq_ctx* c, const char* bam_path, int32_t n_threads);
+/* On-disk cache of the resident concordant records: parameter sweeps over -w/-r/-a/-dp/-di/-mq
+ * re-run sq_build_graph..sq_call_sv on the same records and can skip the BAM decode (the three BamReader passes of
+ * SegmentGraph.cpp:260-347, :1553-1621, :3098-3178).  sq_save_records writes what the ingest calls have made resident;
+ * sq_load_records replaces sq_ingest_concordant_file (call it after sq_set_references and sq_ingest_chimeric*: the
+ * records carry the "QNAME is in the chimeric BAM" bit).  The file records the parse parameters (-pt/-pl/-pm), the
+ * number of references and a hash of the chimeric name set; sq_load_records returns SQ_E_ARG when they differ from
+ * the context's.  A chromosome-sharded context keeps only the records of its shard. */
+int sq_save_records(sq_ctx* c, const char* cache_path);
+int sq_load_records(sq_ctx* c, const char* cache_path);
 
 /* SegmentGraph_t::SegmentGraph_t(RefLength, Chimrecord, bam) -- src/SegmentGraph.cpp:104-124 */
 int sq_build_graph(sq_ctx* c);

@@ -20,7 +20,7 @@ EXPORTS = [
     "sq_default_params", "sq_create", "sq_destroy", "sq_strerror", "sq_last_error", "sq_set_references",
     "sq_ingest_chimeric", "sq_chim_contains", "sq_ingest_concordant", "sq_ingest_concordant_bam", "sq_read_header", "sq_ingest_chimeric_file",
     "sq_ingest_concordant_file", "sq_build_graph", "sq_graph_view", "sq_order", "sq_call_sv", "sq_breakpoints",
-    "sq_set_shard", "sq_exchange_pack", "sq_exchange_unpack", "sq_get_timing", "sq_timing_accumulate", "sq_reset", "sq_get_counts", "sq_debug_download", "sq_debug_bp_support", "sq_debug_order",
+    "sq_set_shard", "sq_exchange_pack", "sq_exchange_unpack", "sq_get_timing", "sq_timing_accumulate", "sq_reset", "sq_save_records", "sq_load_records", "sq_get_counts", "sq_debug_download", "sq_debug_bp_support", "sq_debug_order",
 ]
 
 
@@ -100,6 +100,8 @@ def load_library() -> C.CDLL:
         lib.sq_set_references.argtypes = [C.c_void_p, C.c_int32, _P32]
         lib.sq_ingest_chimeric_file.argtypes = [C.c_void_p, C.c_char_p]
         lib.sq_ingest_concordant_file.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+        lib.sq_save_records.argtypes = [C.c_void_p, C.c_char_p]
+        lib.sq_load_records.argtypes = [C.c_void_p, C.c_char_p]
         lib.sq_read_header.argtypes = [C.c_char_p, _P32, _P32, C.c_char_p, C.c_size_t]
         lib.sq_build_graph.argtypes = [C.c_void_p]
         lib.sq_graph_view.argtypes = [C.c_void_p, C.c_int32, C.POINTER(SqGraph)]
@@ -178,6 +180,22 @@ class Context:
 
     def reset(self):
         self._chk(self.lib.sq_reset(self.h), "sq_reset")
+
+    def save_records(self, path: str):
+        """write the resident concordant records to a cache file (sq_save_records)"""
+        self._chk(self.lib.sq_save_records(self.h, str(path).encode()), "sq_save_records")
+
+    def load_cached(self, bam: str, chim_bam: str, cache: str, shard: tuple | None = None):
+        """as load(), with the concordant records from a cache file written by save_records (the BAM is only opened
+        for its header)"""
+        names, lens = read_header(bam)
+        self.ref_names = names
+        arr = (C.c_int32 * len(lens))(*lens)
+        self._chk(self.lib.sq_set_references(self.h, len(lens), arr), "sq_set_references")
+        if shard is not None:
+            self._chk(self.lib.sq_set_shard(self.h, int(shard[0]), int(shard[1])), "sq_set_shard")
+        self._chk(self.lib.sq_ingest_chimeric_file(self.h, str(chim_bam).encode()), "sq_ingest_chimeric_file")
+        self._chk(self.lib.sq_load_records(self.h, str(cache).encode()), "sq_load_records")
 
     # ---- chromosome-sharded runs: the stage functions pause with SQ_NEED_EXCHANGE (include/squid_hip.h)
     NEED_EXCHANGE = 1

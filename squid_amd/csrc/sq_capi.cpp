@@ -815,6 +815,117 @@ int sq_ingest_concordant_file(sq_ctx* c, const char* path, int32_t n_threads) {
         return sq_ingest_concordant(c, &b);
     });
 }
+// ---- record cache (include/squid_hip.h): header, then the arrays of DeviceRecords / sq_aln_batch, each 64-byte aligned
+namespace {
+struct CacheHeader {
+    char magic[8];  // "SQSOA1\0\0"
+    int64_t n_rec, n_blk;
+    int32_t phred_type, min_phred, max_lowphred_len, n_ref;
+    uint64_t chim_hash;
+    uint64_t reserved[3];
+};
+uint64_t chim_set_hash(const sq_ctx* c) {  // order-independent
+    uint64_t sum = 0x9e3779b97f4a7c15ull * (c->chim_names.size() + 1);
+    for (const std::string& nm : c->chim_names) {
+        uint64_t h = 1469598103934665603ull;
+        for (unsigned char ch : nm) { h ^= ch; h *= 1099511628211ull; }
+        h ^= h >> 33; h *= 0xff51afd7ed558ccdull; h ^= h >> 33;
+        sum += h;
+    }
+    return sum;
+}
+CacheHeader cache_header(const sq_ctx* c, int64_t n_rec, int64_t n_blk) {
+    CacheHeader h;
+    std::memset(&h, 0, sizeof h);
+    std::memcpy(h.magic, "SQSOA1", 6);
+    h.n_rec = n_rec; h.n_blk = n_blk;
+    h.phred_type = c->P.phred_type; h.min_phred = c->P.min_phred; h.max_lowphred_len = c->P.max_lowphred_len; h.n_ref = (int32_t)c->ref_len.size();
+    h.chim_hash = chim_set_hash(c);
+    return h;
+}
+size_t pad64(size_t n) { return (n + 63) & ~(size_t)63; }
+}  // namespace
+int sq_save_records(sq_ctx* c, const char* path) {
+    if (!c || !path) return SQ_E_ARG;
+    HostBatch hb;
+    int rc = dev_download_records(c, hb);
+    if (rc) return rc;
+    const size_t n = hb.refid.size(), nb = hb.b_refpos.size();
+    if (hb.blk_off.size() != n + 1) hb.blk_off.assign(n + 1, 0);  // (no record: the offsets array is just {0})
+    const CacheHeader h = cache_header(c, (int64_t)n, (int64_t)nb);
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return fail(c, SQ_E_IO, std::string("cannot write ") + path);
+    bool ok = std::fwrite(&h, sizeof h, 1, f) == 1;
+    static const char zeros[64] = {0};
+    auto put = [&](const void* p, size_t bytes) {
+        if (bytes) ok = ok && std::fwrite(p, 1, bytes, f) == bytes;
+        if (pad64(bytes) > bytes) ok = ok && std::fwrite(zeros, 1, pad64(bytes) - bytes, f) == pad64(bytes) - bytes;
+    };
+    put(hb.refid.data(), n * 4); put(hb.pos.data(), n * 4); put(hb.mrefid.data(), n * 4); put(hb.mpos.data(), n * 4); put(hb.endpos.data(), n * 4);
+    put(hb.flag.data(), n * 2); put(hb.totlen.data(), n * 2); put(hb.mapq.data(), n); put(hb.aux.data(), n); put(hb.blk_off.data(), (n + 1) * 4);
+    put(hb.b_refpos.data(), nb * 4); put(hb.b_matchref.data(), nb * 4); put(hb.b_readpos.data(), nb * 2); put(hb.b_matchread.data(), nb * 2);
+    ok = std::fclose(f) == 0 && ok;
+    if (!ok) return fail(c, SQ_E_IO, std::string("short write to ") + path);
+    return SQ_OK;
+}
+int sq_load_records(sq_ctx* c, const char* path) {
+    if (!c || !path) return SQ_E_ARG;
+    if (c->ref_len.empty()) return fail(c, SQ_E_ARG, "sq_set_references first");
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return fail(c, SQ_E_IO, std::string("cannot open ") + path);
+    CacheHeader h;
+    if (std::fread(&h, sizeof h, 1, f) != 1 || std::memcmp(h.magic, "SQSOA1\0", 8) != 0 || h.n_rec < 0 || h.n_blk < 0) { std::fclose(f); return fail(c, SQ_E_IO, std::string(path) + " is not a record cache"); }
+    const CacheHeader want = cache_header(c, h.n_rec, h.n_blk);
+    if (h.phred_type != want.phred_type || h.min_phred != want.min_phred || h.max_lowphred_len != want.max_lowphred_len || h.n_ref != want.n_ref || h.chim_hash != want.chim_hash) {
+        std::fclose(f);
+        return fail(c, SQ_E_ARG, "record cache was written with other -pt/-pl/-pm, another reference list or another chimeric BAM");
+    }
+    // in pieces of 16 M records: bounded host memory whatever the size of the cache
+    const size_t n = (size_t)h.n_rec, nb = (size_t)h.n_blk;
+    size_t at = sizeof h;
+    const size_t o_refid = at; at += pad64(n * 4);
+    const size_t o_pos = at; at += pad64(n * 4);
+    const size_t o_mrefid = at; at += pad64(n * 4);
+    const size_t o_mpos = at; at += pad64(n * 4);
+    const size_t o_endpos = at; at += pad64(n * 4);
+    const size_t o_flag = at; at += pad64(n * 2);
+    const size_t o_totlen = at; at += pad64(n * 2);
+    const size_t o_mapq = at; at += pad64(n);
+    const size_t o_aux = at; at += pad64(n);
+    const size_t o_blkoff = at; at += pad64((n + 1) * 4);
+    const size_t o_brefpos = at; at += pad64(nb * 4);
+    const size_t o_bmatchref = at; at += pad64(nb * 4);
+    const size_t o_breadpos = at; at += pad64(nb * 2);
+    const size_t o_bmatchread = at;
+    bool ok = true;
+    auto get = [&](void* dst, size_t off, size_t bytes) { if (bytes) ok = ok && fseeko(f, (off_t)off, SEEK_SET) == 0 && std::fread(dst, 1, bytes, f) == bytes; };
+    const size_t piece = (size_t)1 << 24;
+    HostBatch hb;
+    int rc = SQ_OK;
+    for (size_t r0 = 0; r0 < n && ok && rc == SQ_OK; r0 += piece) {
+        const size_t r1 = std::min(n, r0 + piece), k = r1 - r0;
+        hb.clear();
+        hb.refid.resize(k); hb.pos.resize(k); hb.mrefid.resize(k); hb.mpos.resize(k); hb.endpos.resize(k); hb.flag.resize(k); hb.totlen.resize(k); hb.mapq.resize(k); hb.aux.resize(k); hb.blk_off.resize(k + 1);
+        get(hb.refid.data(), o_refid + r0 * 4, k * 4); get(hb.pos.data(), o_pos + r0 * 4, k * 4); get(hb.mrefid.data(), o_mrefid + r0 * 4, k * 4); get(hb.mpos.data(), o_mpos + r0 * 4, k * 4);
+        get(hb.endpos.data(), o_endpos + r0 * 4, k * 4); get(hb.flag.data(), o_flag + r0 * 2, k * 2); get(hb.totlen.data(), o_totlen + r0 * 2, k * 2); get(hb.mapq.data(), o_mapq + r0, k);
+        get(hb.aux.data(), o_aux + r0, k); get(hb.blk_off.data(), o_blkoff + r0 * 4, (k + 1) * 4);
+        if (!ok) break;
+        const uint32_t bo0 = hb.blk_off[0], bo1 = hb.blk_off[k];
+        if (bo1 < bo0 || bo1 > nb) { ok = false; break; }
+        const size_t kb = bo1 - bo0;
+        hb.b_refpos.resize(kb); hb.b_matchref.resize(kb); hb.b_readpos.resize(kb); hb.b_matchread.resize(kb);
+        get(hb.b_refpos.data(), o_brefpos + (size_t)bo0 * 4, kb * 4); get(hb.b_matchref.data(), o_bmatchref + (size_t)bo0 * 4, kb * 4);
+        get(hb.b_readpos.data(), o_breadpos + (size_t)bo0 * 2, kb * 2); get(hb.b_matchread.data(), o_bmatchread + (size_t)bo0 * 2, kb * 2);
+        if (!ok) break;
+        for (uint32_t& o : hb.blk_off) o -= bo0;
+        sq_aln_batch b;
+        hb.view(&b, false);
+        rc = sq_ingest_concordant(c, &b);
+    }
+    std::fclose(f);
+    if (!ok) return fail(c, SQ_E_IO, std::string("truncated or corrupt record cache ") + path);
+    return rc;
+}
 int sq_build_graph(sq_ctx* c) {
     if (!c) return SQ_E_ARG;
     if (c->ref_len.empty()) return fail(c, SQ_E_ARG, "sq_set_references first");

@@ -614,3 +614,53 @@ def test_gpu_bgzf_inflate_and_boundary_search_give_the_same_records(built, synth
         assert run(alt, {}) == want, name
         assert run(alt, gpu) == want, name
         assert run(alt, dict(gpu, SQUID_GPU_INFLATE_ONEPASS="1")) == want, name
+
+
+def test_record_cache_round_trip_and_refusals(built, synth, tmp_path):
+    """sq_save_records / sq_load_records: a second context that loads the cache instead of the
+    BAM holds the same arrays and writes the same _sv.txt (also with other graph parameters: -w sweep); a cache written
+    with other parse parameters or another chimeric BAM is refused; `squid --cache` writes it once and reads it after"""
+    import hashlib
+
+    pre = synth("T2")
+    sv_path, _ = ou.run_oracle(built, pre, tmp_path)
+    cache = tmp_path / "t2.sqsoa"
+
+    def digest(ctx):
+        return {k: hashlib.sha256(v.tobytes()).hexdigest() for k, v in ctx.records().items()}
+
+    with squid_amd.Context() as ctx:
+        ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
+        want = digest(ctx)
+        ctx.save_records(cache)
+    with squid_amd.Context() as ctx:
+        ctx.load_cached(f"{pre}.bam", f"{pre}.chim.bam", cache)
+        assert digest(ctx) == want
+        ctx.build_graph()
+        ctx.order()
+        assert ctx.sv_text() == sv_path.read_text()
+    # a parameter sweep on the cached records against the oracle run from the BAM files
+    sv_w2, _ = ou.run_oracle(built, pre, tmp_path / "w2", "-w", "2")
+    with squid_amd.Context(min_edge_weight=2) as ctx:
+        ctx.load_cached(f"{pre}.bam", f"{pre}.chim.bam", cache)
+        ctx.build_graph()
+        ctx.order()
+        assert ctx.sv_text() == sv_w2.read_text()
+    # refusals: other parse parameter, other chimeric BAM, not a cache
+    with squid_amd.Context(min_phred=20) as ctx:
+        with pytest.raises(squid_amd.SquidError, match="record cache was written with other"):
+            ctx.load_cached(f"{pre}.bam", f"{pre}.chim.bam", cache)
+    other = synth("C1")
+    with squid_amd.Context() as ctx:
+        with pytest.raises(squid_amd.SquidError):
+            ctx.load_cached(f"{pre}.bam", f"{other}.chim.bam", cache)
+    with squid_amd.Context() as ctx:
+        with pytest.raises(squid_amd.SquidError, match="not a record cache"):
+            ctx.load_cached(f"{pre}.bam", f"{pre}.chim.bam", f"{pre}.bam")
+    # command line: first run writes the cache, second run reads it (the concordant BAM path may then even be wrong,
+    # only its header is read -- here it is the same file)
+    cli_cache = tmp_path / "cli.sqsoa"
+    for out in ("c1", "c2"):
+        subprocess.check_call([str(built / "squid"), "-b", f"{pre}.bam", "-c", f"{pre}.chim.bam", "-o", str(tmp_path / out), "--cache", str(cli_cache)], stdout=subprocess.DEVNULL)
+        assert cli_cache.exists()
+        assert (tmp_path / f"{out}_sv.txt").read_bytes() == sv_path.read_bytes()
