@@ -147,8 +147,9 @@ struct DeviceRecords {
     DBuf<long long> rec_sync, rec_end;
     // GPU ingest, two batches in flight: compressed bytes + block table + tokens of a batch
     struct InflSet { DBuf<uint8_t> in; DBuf<InflBlock> tab; DBuf<uint32_t> tok; DBuf<int32_t> ntok, flags; hipEvent_t ready = nullptr, freed = nullptr; std::vector<InflBlock> host_tab; };
-    InflSet il_set[2];
-    hipStream_t il_stream[2] = {nullptr, nullptr};  // one per set: the token passes of consecutive batches overlap
+    static constexpr int IL_DEPTH = 2;  // batches in flight (three were not faster: the token passes are CU-bound, not starved)
+    InflSet il_set[IL_DEPTH];
+    hipStream_t il_stream[IL_DEPTH] = {};  // one per set: the token passes of consecutive batches overlap
     DBuf<int32_t> rec_cnt, rec_base;
     DBuf<unsigned long long> bam_off, chim_hash;
     DBuf<uint32_t> chim_off, chim_len;
@@ -2511,15 +2512,15 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     auto stage_a = [&](size_t k) -> int {  // (SQ_OK also when there is no batch k)
         if (!plan(k)) return SQ_OK;
         const Batch B = batches[k];
-        DeviceRecords::InflSet& st = D.il_set[k & 1];
-        hipStream_t sa = variant == 0 ? D.il_stream[k & 1] : s;  // (the other forms write the bytes themselves: one stream)
+        DeviceRecords::InflSet& st = D.il_set[k % DeviceRecords::IL_DEPTH];
+        hipStream_t sa = variant == 0 ? D.il_stream[k % DeviceRecords::IL_DEPTH] : s;  // (the other forms write the bytes themselves: one stream)
         const int nb = (int)(B.end - B.at);
         // largest compressed blocks first: the lanes of a wave get blocks of similar length (a wave takes as long as its
         // longest lane) and the long waves start first
         st.host_tab.resize((size_t)nb);
         for (int i = 0; i < nb; ++i) { const BgzfRange& b = blocks[B.at + (size_t)i]; st.host_tab[(size_t)i] = InflBlock{b.coff - B.coff0, b.clen, b.isize, b.uoff}; }
         std::stable_sort(st.host_tab.begin(), st.host_tab.end(), [](const InflBlock& x, const InflBlock& y) { return x.clen > y.clen; });
-        if (k >= 2) HIPCHK(hipStreamWaitEvent(sa, st.freed, 0));  // the resolve of batch k - 2 has read its tokens
+        if (k >= (size_t)DeviceRecords::IL_DEPTH) HIPCHK(hipStreamWaitEvent(sa, st.freed, 0));  // the resolve of batch k - IL_DEPTH has read its tokens
         const auto wa0 = std::chrono::steady_clock::now();
         HIPCHK(st.in.reserve((size_t)B.cbytes + 256));  // (the input rings read up to 80 bytes ahead)
         HIPCHK(st.tab.reserve((size_t)nb)); HIPCHK(st.flags.reserve(4));
@@ -2537,13 +2538,13 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         return SQ_OK;
     };
     { int rc = stage_a(0); if (rc) return rc; }
-    { int rc = stage_a(1); if (rc) return rc; }
+    for (int k = 1; k < DeviceRecords::IL_DEPTH; ++k) { int rc = stage_a((size_t)k); if (rc) return rc; }
     const double w_first = since_ms(w0);
     unsigned long long carry = 0;  // bytes of the incomplete record in front of the batch (kept in D.bgzf_carry)
     long check_bad = 0;
     for (size_t k = 0; k < batches.size(); ++k) {
         const Batch B = batches[k];
-        DeviceRecords::InflSet& st = D.il_set[k & 1];
+        DeviceRecords::InflSet& st = D.il_set[k % DeviceRecords::IL_DEPTH];
         const int nb = (int)(B.end - B.at);
         const unsigned long long pad = (16 - carry % 16) % 16;  // the batch's own bytes start 16-byte aligned
         const unsigned long long limit = pad + carry + B.bbytes;
@@ -2601,7 +2602,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         }
         if ((h[0] | ha[0]) & (512 | 1024)) return give_up();
         // the token pass of the batch after the next can start: its buffers are free once this batch's resolve is through
-        { int rc = stage_a(k + 2); if (rc) { (void)give_up(); return rc; } }
+        { int rc = stage_a(k + DeviceRecords::IL_DEPTH); if (rc) { (void)give_up(); return rc; } }
         const int64_t n_rec = h[8];
         if (n_rec > 0) {
             HIPCHK(D.bam_off.reserve((size_t)n_rec));
