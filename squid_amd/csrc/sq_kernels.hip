@@ -2119,9 +2119,15 @@ __global__ __launch_bounds__(64) void k_lz_resolve(const uint32_t* tok, const in
             const uint32_t hwm = (uint32_t)__builtin_amdgcn_readlane((int)o, __builtin_amdgcn_readfirstlane(first));
             wave_sync();
             if (pending && ready_at <= hwm) {
+                if (dist >= 8) {  // eight bytes per load and store (the source of a slice lies at least 8 bytes below its target)
+                    uint32_t k = 0;
+                    for (; k + 8 <= len; k += 8) { unsigned long long w; __builtin_memcpy(&w, lz_win + src + k, 8); __builtin_memcpy(lz_win + o + k, &w, 8); }
+                    for (; k < len; ++k) lz_win[o + k] = lz_win[src + k];
+                    pending = false;
+                }
                 // every byte comes from [src, src + min(dist, len)): final, so the reads of a slice go out together
                 uint32_t j = 0;  // k mod dist
-                for (uint32_t k = 0; k < len; k += 8) {
+                for (uint32_t k = 0; pending && k < len; k += 8) {
                     uint8_t v[8];
                     uint32_t jj = j;
 #pragma unroll
