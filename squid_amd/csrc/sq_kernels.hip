@@ -2528,9 +2528,13 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         std::stable_sort(st.host_tab.begin(), st.host_tab.end(), [](const InflBlock& x, const InflBlock& y) { return x.clen > y.clen; });
         if (k >= (size_t)DeviceRecords::IL_DEPTH) HIPCHK(hipStreamWaitEvent(sa, st.freed, 0));  // the resolve of batch k - IL_DEPTH has read its tokens
         const auto wa0 = std::chrono::steady_clock::now();
-        HIPCHK(st.in.reserve((size_t)B.cbytes + 256));  // (the input rings read up to 80 bytes ahead)
-        HIPCHK(st.tab.reserve((size_t)nb)); HIPCHK(st.flags.reserve(4));
-        if (variant == 0) { HIPCHK(st.tok.reserve((size_t)B.bbytes + 64)); HIPCHK(st.ntok.reserve((size_t)nb)); }
+        // sized for a full batch at once (the first batches are small): growing a buffer later frees the old one, and freeing
+        // device memory waits for the kernels of the other batches
+        const unsigned long long full = std::max<unsigned long long>(B.bbytes, std::min<unsigned long long>(cap, range_bytes_estimate()));
+        const double cratio = (double)B.cbytes / (double)std::max<unsigned long long>(B.bbytes, 1);
+        HIPCHK(st.in.reserve(std::max((size_t)B.cbytes, (size_t)(cratio * 1.1 * (double)full)) + 256));  // (the input rings read up to 80 bytes ahead)
+        HIPCHK(st.tab.reserve(std::max((size_t)nb, (size_t)(full / 60000)))); HIPCHK(st.flags.reserve(4));
+        if (variant == 0) { HIPCHK(st.tok.reserve((size_t)full + 64)); HIPCHK(st.ntok.reserve(std::max((size_t)nb, (size_t)(full / 60000)))); }
         const double wa1 = since_ms(wa0);
         HIPCHK(hipMemcpyAsync(st.in.p, file + B.coff0, (size_t)B.cbytes, hipMemcpyHostToDevice, sa));
         if (report && k < 3) std::fprintf(stderr, "GPU ingest: batch %zu planned at %.1f ms, buffers %.1f ms, copy of %.2f GB returned after %.1f ms\n", k, std::chrono::duration<double, std::milli>(wa0 - w0).count(), wa1, (double)B.cbytes * 1e-9, since_ms(wa0) - wa1);
@@ -2554,7 +2558,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         const int nb = (int)(B.end - B.at);
         const unsigned long long pad = (16 - carry % 16) % 16;  // the batch's own bytes start 16-byte aligned
         const unsigned long long limit = pad + carry + B.bbytes;
-        HIPCHK(D.bgzf_out.reserve((size_t)limit + 64));
+        HIPCHK(D.bgzf_out.reserve(std::max((size_t)limit, (size_t)std::min<unsigned long long>(cap, range_bytes_estimate()) + ((size_t)1 << 20)) + 64));
         HIPCHK(hipMemsetAsync(D.flags.p, 0, 10 * 4, s));
         if (carry) HIPCHK(hipMemcpyAsync(D.bgzf_out.p + pad, D.bgzf_carry.p, (size_t)carry, hipMemcpyDeviceToDevice, s));
         uint8_t* out = D.bgzf_out.p + pad + carry;
