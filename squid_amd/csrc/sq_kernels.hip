@@ -1716,7 +1716,7 @@ __global__ __launch_bounds__(256) void k_inflate(const uint8_t* file, const Infl
 // one-kernel form k_inflate_lanes<false> (each lane also copies its matches, in global memory, eight bytes per step)
 // is kept behind SQUID_GPU_INFLATE_ONEPASS for comparison: a lane that reads back what it has just written makes the
 // whole wave wait for its stores.
-constexpr int IL_LB = 9, IL_DB = 6, IL_STAGE = 8;
+constexpr int IL_LB = 9, IL_DB = 7, IL_STAGE = 8;
 // The compressed bytes of a lane go through a ring of IL_RING words in LDS (ring[(word % IL_RING) * 64], already offset
 // by the lane): the bit buffer refills from LDS, and the ring is topped up from global memory by all lanes in the same
 // step, when any of them runs low.  A load issued by one lane in one step would otherwise make the whole wave wait a
@@ -1771,10 +1771,10 @@ __device__ __forceinline__ uint32_t il_take(ILane& b, int k) {
 // Headers are read and tables are built by every lane for itself, in lockstep with the other lanes that are at a block
 // header: zlib closes a block every 16383 symbols and a lane takes one symbol per step, so the lanes of a wave arrive
 // together (a lane that is early waits up to IL_HDR_WAIT steps for company).
-constexpr int IL_SUB = 340, IL_LENS = 344, IL_HDR_WAIT = 48;
+constexpr int IL_SUB = 340, IL_LENS = 337, IL_CL_AT = 318, IL_HDR_WAIT = 48;  // (sizes to the byte: 160 KB of LDS per wave)
 struct ILds {
     uint16_t *root_ll, *sub_ll, *root_dd, *cnt_dd, *sym_dd, *fst_dd, *tmp_a, *tmp_b;  // tmp_a/tmp_b: [16] per lane, builders' scratch
-    uint8_t* lens;  // [IL_LENS] per lane: code lengths 0..317, the code-length code's own lengths at 320..338
+    uint8_t* lens;  // [IL_LENS] per lane: code lengths 0..317, the code-length code's own lengths at IL_CL_AT..IL_CL_AT + 18
 };
 constexpr size_t IL_LDS_BYTES = (size_t)((1 << IL_LB) + IL_SUB + (1 << IL_DB) + 16 + 32 + 2 + 16 + 16) * 64 * sizeof(uint16_t) + (size_t)IL_LENS * 64 + (size_t)(IL_STAGE + IL_RING) * 64 * 4;
 __device__ __forceinline__ int il_decode_ll(ILane& b, const ILds& L, int lane) {
@@ -1969,8 +1969,8 @@ __global__ __launch_bounds__(64) void k_inflate_lanes(const uint8_t* file, const
                         nlen = (int)il_take(b, 5) + 257; ndist = (int)il_take(b, 5) + 1;
                         const int ncode = (int)il_take(b, 4) + 4;
                         if (nlen <= 286 && ndist <= 30) {
-                            for (int i = 0; i < 19; ++i) lens[(320 + i) * 64] = 0;
-                            for (int i = 0; i < ncode; ++i) lens[(320 + sh_clo[i]) * 64] = (uint8_t)il_take(b, 3);
+                            for (int i = 0; i < 19; ++i) lens[(IL_CL_AT + i) * 64] = 0;
+                            for (int i = 0; i < ncode; ++i) lens[(IL_CL_AT + sh_clo[i]) * 64] = (uint8_t)il_take(b, 3);
                             kind = 2;
                         }
                     }
@@ -1979,7 +1979,7 @@ __global__ __launch_bounds__(64) void k_inflate_lanes(const uint8_t* file, const
             if (__any(me && kind == 2)) {
                 // the code-length code (19 symbols) in the distance tables, then the literal/length + distance lengths with it
                 const bool dyn = me && kind == 2;
-                bool ok = il_build_dd(L, lane, dyn, 320, 19);
+                bool ok = il_build_dd(L, lane, dyn, IL_CL_AT, 19);
                 int idx = 0;
                 uint8_t prev = 0;
                 bool busy = dyn && ok;
