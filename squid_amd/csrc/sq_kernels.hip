@@ -2247,12 +2247,12 @@ __global__ void k_rec_check(long long nslices, const long long* sync, const long
     if (s >= nslices) return;
     // the walk of the last slice that has a boundary stops at the incomplete tail of the range (slices are chained, so that is the largest stop)
     if (sync[s] >= 0 && (s + 1 == nslices || sync[s + 1] < 0)) atomicMax((unsigned long long*)tail, (unsigned long long)end_p[s]);
-    if (s == 0) return;
-    // every slice must start where the one before stopped; a slice without a boundary is only fine behind the last record
-    if (sync[s] >= 0) { if (sync[s - 1] < 0 || end_p[s - 1] != sync[s]) atomicOr(&flags[0], 1024); }
-    else if (sync[s - 1] >= 0 && end_p[s - 1] >= 0) {
-        // (the previous slice stopped inside or in front of this one: then this slice holds only an incomplete tail)
-    }
+    if (s == 0 || sync[s] < 0) return;  // (a slice without a boundary lies inside a record longer than a slice, or behind the last complete one)
+    // a slice must start where the last slice before it that has a boundary stopped (the slices in between lie inside one
+    // long record)
+    long long t = s - 1;
+    while (t >= 0 && sync[t] < 0) --t;
+    if (t >= 0 && end_p[t] != sync[s]) atomicOr(&flags[0], 1024);
 }
 
 // ================================================================================================ host wrappers

@@ -664,3 +664,55 @@ def test_record_cache_round_trip_and_refusals(built, synth, tmp_path):
         subprocess.check_call([str(built / "squid"), "-b", f"{pre}.bam", "-c", f"{pre}.chim.bam", "-o", str(tmp_path / out), "--cache", str(cli_cache)], stdout=subprocess.DEVNULL)
         assert cli_cache.exists()
         assert (tmp_path / f"{out}_sv.txt").read_bytes() == sv_path.read_bytes()
+
+
+def test_gpu_reader_carries_records_larger_than_a_block(built, tmp_path):
+    """records with 100-200 KB of optional fields span several BGZF blocks: with one block per batch the GPU reader
+    carries their front part over several batches; empty BGZF blocks in the middle of the file hold no bytes at all.
+    Same arrays as the host reader"""
+    import hashlib
+    import os
+    import random
+    import struct
+    import sys
+
+    import bamwriter as bw
+
+    rng = random.Random(7)
+    recs = []
+    for i in range(120):
+        p = 1000 + 11 * i
+        big = i % 17 == 3
+        tags = b"NHC\x01" + (b"ZZZ" + bytes(rng.choice(b"ACGTNacgtn0123456789") for _ in range(rng.randrange(100000, 200000))) + b"\0" if big else b"")
+        recs.append(bw.record(f"r{i}", 0, p, 255, 0x1 | 0x2 | 0x20 | 0x40, "100M", 0, p + 200, tags=tags))
+    chim = [bw.record("q1", 0, 5000, 255, 0x1 | 0x40, "60M40S"), bw.record("q1", 1, 7000, 255, 0x1 | 0x40 | 0x100, "60H40M"),
+            bw.record("q1", 1, 7300, 255, 0x1 | 0x80 | 0x10, "100M")]
+    pre = _tiny_inputs(tmp_path, recs, chim)
+    # the same file with an empty BGZF block after every third block
+    data = Path(f"{pre}.bam").read_bytes()
+    out, at, i = bytearray(), 0, 0
+    while at < len(data):
+        bsize = struct.unpack_from("<H", data, at + 16)[0] + 1
+        out += data[at:at + bsize]
+        at += bsize
+        i += 1
+        if i % 3 == 0 and at < len(data):
+            out += bw._EOF
+    holes = tmp_path / "holes.bam"
+    holes.write_bytes(bytes(out))
+    code = ("import sys, json, hashlib; sys.path.insert(0, %r); import squid_amd\n"
+            "ctx = squid_amd.Context(); ctx.load(sys.argv[1], %r); r = ctx.records()\n"
+            "print(json.dumps({k: hashlib.sha256(v.tobytes()).hexdigest() for k, v in r.items()}), ctx.counts()['n_concordant'])") % (str(Path(__file__).resolve().parent.parent), f"{pre}.chim.bam")
+
+    def run(bam, env):
+        p = subprocess.run([sys.executable, "-c", code, str(bam)], env=dict(os.environ, **env), capture_output=True, text=True, check=True)
+        if env.get("SQUID_GPU_INFLATE") == "1":
+            assert "(rc 0)" in p.stderr, p.stderr
+        return p.stdout.strip().splitlines()[-1]
+
+    want = run(f"{pre}.bam", {"SQUID_GPU_INFLATE": "0"})
+    assert want.endswith(" 120")
+    for bam in (f"{pre}.bam", holes):
+        assert run(bam, {"SQUID_GPU_INFLATE": "0"}) == want
+        for cap in ("0", "1", "1024"):
+            assert run(bam, {"SQUID_GPU_INFLATE": "1", "SQUID_INGEST_TIMING": "1", "SQUID_TOK_CAP_MB": cap}) == want, (bam, cap)
