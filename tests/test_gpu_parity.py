@@ -716,3 +716,41 @@ def test_gpu_reader_carries_records_larger_than_a_block(built, tmp_path):
         assert run(bam, {"SQUID_GPU_INFLATE": "0"}) == want
         for cap in ("0", "1", "1024"):
             assert run(bam, {"SQUID_GPU_INFLATE": "1", "SQUID_INGEST_TIMING": "1", "SQUID_TOK_CAP_MB": cap}) == want, (bam, cap)
+
+
+def test_damaged_files_are_reported_by_both_readers(built, synth, tmp_path):
+    """a flipped byte inside a DEFLATE stream, a file cut in the middle of a block, a file cut between blocks (no EOF
+    marker, last record incomplete): the host reader and the GPU reader (which hands a file it cannot decode to the host
+    reader) end in the same state -- an error for the first two, the complete records for the third"""
+    import os
+    import struct
+    import sys
+
+    pre = synth("T2")
+    data = Path(f"{pre}.bam").read_bytes()
+    offs, at = [], 0
+    while at < len(data):
+        offs.append(at)
+        at += struct.unpack_from("<H", data, at + 16)[0] + 1
+    mid = offs[len(offs) // 2]
+    flipped = bytearray(data)
+    for k in range(40, 60):
+        flipped[mid + 18 + k] ^= 0x5a
+    cases = {"flipped": bytes(flipped), "cut_in_block": data[:mid + 1000], "cut_between_blocks": data[:mid]}
+    code = ("import sys, json; sys.path.insert(0, %r); import squid_amd\n"
+            "ctx = squid_amd.Context()\n"
+            "try:\n"
+            "    ctx.load(sys.argv[1], %r); print('ok', ctx.counts()['n_concordant'])\n"
+            "except squid_amd.SquidError as e:\n"
+            "    print('error', str(e)[:60])\n") % (str(Path(__file__).resolve().parent.parent), f"{pre}.chim.bam")
+    for name, blob in cases.items():
+        bam = tmp_path / f"{name}.bam"
+        bam.write_bytes(blob)
+        outs = []
+        for mode in ("0", "1"):
+            p = subprocess.run([sys.executable, "-c", code, str(bam)], env=dict(os.environ, SQUID_GPU_INFLATE=mode), capture_output=True, text=True, check=True)
+            outs.append(p.stdout.strip().splitlines()[-1])
+        assert outs[0].split()[0] == outs[1].split()[0], (name, outs)
+        if outs[0].startswith("ok"):
+            assert outs[0] == outs[1], (name, outs)
+        assert outs[0].startswith("ok" if name == "cut_between_blocks" else "error"), (name, outs)
