@@ -146,10 +146,11 @@ struct DeviceRecords {
     DBuf<uint8_t> bam_chunk, bgzf_out, bgzf_carry;
     DBuf<long long> rec_sync, rec_end;
     // GPU ingest, two batches in flight: compressed bytes + block table + tokens of a batch
-    struct InflSet { DBuf<uint8_t> in; DBuf<InflBlock> tab; DBuf<uint32_t> tok; DBuf<int32_t> ntok, flags; hipEvent_t ready = nullptr, freed = nullptr; std::vector<InflBlock> host_tab; };
-    static constexpr int IL_DEPTH = 2;  // batches in flight (three were not faster: the token passes are CU-bound, not starved)
+    struct InflSet { DBuf<uint8_t> in; DBuf<InflBlock> tab; DBuf<uint32_t> tok; DBuf<int32_t> ntok, flags; hipEvent_t ready = nullptr, freed = nullptr, copied = nullptr; std::vector<InflBlock> host_tab; };
+    static constexpr int IL_DEPTH = 3;  // buffer sets: batch k is resolved / parsed, k+1 is in the token pass, k+2 is being copied
     InflSet il_set[IL_DEPTH];
-    hipStream_t il_stream[IL_DEPTH] = {};  // one per set: the token passes of consecutive batches overlap
+    hipStream_t il_stream[IL_DEPTH] = {};  // one per set: its host->device copies
+    hipStream_t il_tok_stream = nullptr;   // the token passes, one after the other
     DBuf<int32_t> rec_cnt, rec_base;
     DBuf<unsigned long long> bam_off, chim_hash;
     DBuf<uint32_t> chim_off, chim_len;
@@ -2319,7 +2320,8 @@ void dev_destroy(sq_ctx* c) {
     D.calib.release(); D.okey.release(); D.oval.release(); D.other64.release(); D.spine64.release(); D.okey64.release(); D.zflag.release();
     D.cl_chr.release(); D.trig.release();
     D.ord_e.release(); D.ord_o.release(); D.ord_v.release();
-    D.pin.release(); for (auto& st : D.il_set) { st.in.release(); st.tab.release(); st.tok.release(); st.ntok.release(); st.flags.release(); if (st.ready) (void)hipEventDestroy(st.ready); if (st.freed) (void)hipEventDestroy(st.freed); st.ready = st.freed = nullptr; }
+    D.pin.release(); for (auto& st : D.il_set) { st.in.release(); st.tab.release(); st.tok.release(); st.ntok.release(); st.flags.release(); if (st.ready) (void)hipEventDestroy(st.ready); if (st.freed) (void)hipEventDestroy(st.freed); if (st.copied) (void)hipEventDestroy(st.copied); st.ready = st.freed = st.copied = nullptr; }
+    if (D.il_tok_stream) { (void)hipStreamDestroy(D.il_tok_stream); D.il_tok_stream = nullptr; }
     for (auto& q : D.il_stream) if (q) { (void)hipStreamDestroy(q); q = nullptr; }
     D.bgzf_out.release(); D.bgzf_carry.release(); D.rec_sync.release(); D.rec_end.release(); D.rec_cnt.release(); D.rec_base.release(); D.stripes.release(); D.bp_bucket.release(); D.bp_ev.release(); D.bp_end.release(); D.bp_valid.release();
     for (auto& e : D.ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -2468,7 +2470,9 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     const bool report = std::getenv("SQUID_INGEST_TIMING") != nullptr, check = std::getenv("SQUID_INFLATE_CHECK") != nullptr;
     const auto w0 = std::chrono::steady_clock::now();
     auto since_ms = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
-    const unsigned long long cap = std::getenv("SQUID_TOK_CAP_MB") ? (unsigned long long)std::atoll(std::getenv("SQUID_TOK_CAP_MB")) << 20 : 1ull << 30;
+    // a batch = 180 waves of the token pass: one token kernel runs at a time, its waves all resident (one per CU), and the
+    // other ~76 CUs (plus those of the waves that finish early) take the resolve / boundary / parse kernels of the batch before
+    const unsigned long long cap = std::getenv("SQUID_TOK_CAP_MB") ? (unsigned long long)std::atoll(std::getenv("SQUID_TOK_CAP_MB")) << 20 : 180ull * 64 * 65536;
     const int variant = std::getenv("SQUID_GPU_INFLATE_WAVE") ? 2 : (std::getenv("SQUID_GPU_INFLATE_ONEPASS") ? 1 : 0);  // 0: tokens + resolve
     HIPCHK(hipFuncSetAttribute((const void*)k_inflate_lanes<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)IL_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_inflate_lanes<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)IL_LDS_BYTES));
@@ -2481,9 +2485,15 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
             (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
             if (hipStreamCreateWithPriority(&q, hipStreamNonBlocking, lo) != hipSuccess) { (void)hipGetLastError(); HIPCHK(hipStreamCreate(&q)); }
         }
+    if (!D.il_tok_stream) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&D.il_tok_stream, hipStreamNonBlocking, lo) != hipSuccess) { (void)hipGetLastError(); HIPCHK(hipStreamCreate(&D.il_tok_stream)); }
+    }
     for (auto& st : D.il_set) {
         if (!st.ready) HIPCHK(hipEventCreateWithFlags(&st.ready, hipEventDisableTiming));
         if (!st.freed) HIPCHK(hipEventCreateWithFlags(&st.freed, hipEventDisableTiming));
+        if (!st.copied) HIPCHK(hipEventCreateWithFlags(&st.copied, hipEventDisableTiming));
     }
     struct Batch { size_t at, end; unsigned long long coff0, cbytes, bbase, bbytes; };
     std::vector<Batch> batches;
@@ -2541,6 +2551,9 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         HIPCHK(hipMemcpyAsync(st.tab.p, st.host_tab.data(), (size_t)nb * sizeof(InflBlock), hipMemcpyHostToDevice, sa));
         HIPCHK(hipMemsetAsync(st.flags.p, 0, 4 * 4, sa));
         if (variant == 0) {
+            HIPCHK(hipEventRecord(st.copied, sa));
+            sa = D.il_tok_stream;
+            HIPCHK(hipStreamWaitEvent(sa, st.copied, 0));
             EvTimer t1(c, "k_inflate_tokens", (double)B.cbytes + (double)B.bbytes * 2, sa);
             hipLaunchKernelGGL(k_inflate_lanes<true>, dim3((nb + 63) / 64), dim3(64), IL_LDS_BYTES, sa, st.in.p, st.tab.p, nb, B.bbase, nullptr, st.flags.p, st.tok.p, st.ntok.p);
         }
@@ -2548,11 +2561,14 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         return SQ_OK;
     };
     { int rc = stage_a(0); if (rc) return rc; }
-    for (int k = 1; k < DeviceRecords::IL_DEPTH; ++k) { int rc = stage_a((size_t)k); if (rc) return rc; }
+    { int rc = stage_a(1); if (rc) return rc; }
     const double w_first = since_ms(w0);
     unsigned long long carry = 0;  // bytes of the incomplete record in front of the batch (kept in D.bgzf_carry)
     long check_bad = 0;
     for (size_t k = 0; k < batches.size(); ++k) {
+        // the copy of batch k+2 and its token pass (queued behind that of batch k+1) go out first: the host blocks in the copy
+        // while the GPU works on the batches before
+        { int rc = stage_a(k + 2); if (rc) { (void)give_up(); return rc; } }
         const Batch B = batches[k];
         DeviceRecords::InflSet& st = D.il_set[k % DeviceRecords::IL_DEPTH];
         const int nb = (int)(B.end - B.at);
@@ -2611,8 +2627,6 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
             std::fprintf(stderr, "[inflate check] blocks %zu..%zu of %zu: %ld differ so far, flags %d|%d, records %d, carry in %llu\n", B.at - b0, B.end - b0, b1 - b0, check_bad, h[0], ha[0], h[8], carry);
         }
         if ((h[0] | ha[0]) & (512 | 1024)) return give_up();
-        // the token pass of the batch after the next can start: its buffers are free once this batch's resolve is through
-        { int rc = stage_a(k + DeviceRecords::IL_DEPTH); if (rc) { (void)give_up(); return rc; } }
         const int64_t n_rec = h[8];
         if (n_rec > 0) {
             HIPCHK(D.bam_off.reserve((size_t)n_rec));
@@ -2635,6 +2649,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         }
     }
     for (auto& q : D.il_stream) HIPCHK(hipStreamSynchronize(q));
+    HIPCHK(hipStreamSynchronize(D.il_tok_stream));
     if (report) std::fprintf(stderr, "GPU ingest: first two batches queued after %.1f ms, all %zu batches through after %.1f ms (%.1f ms since entry; %llu MB per batch, %llu bytes left incomplete at the end)\n", w_first, batches.size(), since_ms(w0), since_ms(w_entry), cap >> 20, carry);
     return SQ_OK;
 }
