@@ -166,6 +166,7 @@ struct DeviceRecords {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     std::vector<Pending> ev_pending;
     size_t ev_used = 0;
+    std::mutex ev_mu;  // (the GPU reader's helper thread brackets its kernel too)
     int64_t k1 = 0;  // kept pass-1 records
     int cl_n = 0;    // clusters in the packed table cl_chr
     RecView view() const {
@@ -2265,6 +2266,7 @@ struct EvTimer {
     sq_ctx* c; int slot; bool on; hipStream_t st;
     EvTimer(sq_ctx* c, const char* name, double bytes, hipStream_t on_stream = nullptr) : c(c), on(true), st(on_stream ? on_stream : c->stream) {
         DeviceRecords& D = *c->dev;
+        std::lock_guard<std::mutex> lk(D.ev_mu);
         if (D.ev_used == D.ev_pool.size()) {
             hipEvent_t a = nullptr, b = nullptr;
             (void)hipEventCreate(&a); (void)hipEventCreate(&b);
@@ -2277,6 +2279,7 @@ struct EvTimer {
     void stop() {
         if (!on) return;
         on = false;
+        std::lock_guard<std::mutex> lk(c->dev->ev_mu);
         (void)hipEventRecord(c->dev->ev_pool[slot].second, st);
     }
     ~EvTimer() { stop(); }
@@ -2560,15 +2563,23 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         HIPCHK(hipEventRecord(st.ready, sa));
         return SQ_OK;
     };
+    // stage A runs on a helper thread (one at a time): the copy of pageable memory blocks its caller for its whole duration
+    struct Joined { std::future<int> f; int get() { return f.valid() ? f.get() : SQ_OK; } ~Joined() { if (f.valid()) (void)f.get(); } } helper;
+    auto stage_a_async = [&](size_t k) -> int {
+        int rc = helper.get();  // the one before (it reads `batches` and `blocks`: nothing of those changes while it runs)
+        if (rc || !plan(k)) return rc;
+        helper.f = std::async(std::launch::async, [&stage_a, c, k]() { if (hipSetDevice(c->P.device) != hipSuccess) return (int)SQ_E_HIP; return stage_a(k); });
+        return SQ_OK;
+    };
     { int rc = stage_a(0); if (rc) return rc; }
-    { int rc = stage_a(1); if (rc) return rc; }
+    { int rc = stage_a_async(1); if (rc) return rc; }
     const double w_first = since_ms(w0);
     unsigned long long carry = 0;  // bytes of the incomplete record in front of the batch (kept in D.bgzf_carry)
     long check_bad = 0;
     for (size_t k = 0; k < batches.size(); ++k) {
         // the copy of batch k+2 and its token pass (queued behind that of batch k+1) go out first: the host blocks in the copy
         // while the GPU works on the batches before
-        { int rc = stage_a(k + 2); if (rc) { (void)give_up(); return rc; } }
+        { int rc = stage_a_async(k + 2); if (rc) { (void)give_up(); return rc; } }
         const Batch B = batches[k];
         DeviceRecords::InflSet& st = D.il_set[k % DeviceRecords::IL_DEPTH];
         const int nb = (int)(B.end - B.at);
