@@ -13,7 +13,7 @@ os.environ["SQUID_GPU_INFLATE"] = "1"
 with tempfile.TemporaryDirectory() as td:
     pre = Path(td) / cfg
     subprocess.check_call([str(ROOT / "build" / "gen_synth_bam"), "--config", cfg, "--out", str(pre), "--threads", "32"], stdout=subprocess.DEVNULL)
-    for cap in (640, 800, 880, 720):
+    for cap in (720, 880, 1000, 600):
         os.environ["SQUID_TOK_CAP_MB"] = str(cap)
         t0 = time.time()
         with squid_amd.Context() as ctx:
