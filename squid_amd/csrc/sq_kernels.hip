@@ -1939,7 +1939,10 @@ __global__ __launch_bounds__(64) void k_inflate_lanes(const uint8_t* file, const
     bool done = !have || blk.isize == 0, err = false, in_block = false, last = false, stored = false;
     uint32_t stored_left = 0, stored_at = 0;
     int hdr_wait = 0;
+    uint32_t token = 0;       // what the step has decoded: stored at the top of the next step, where the lanes that took the
+    bool have_token = false;  // literal path and those that took the match path are together again (one copy of the store code)
     while (__any(!done)) {
+        if (TOK && have_token) { emit(token); have_token = false; }
         // ---- block headers, by all the lanes that are at one
         const unsigned long long need = __ballot(!done && !in_block && !pend_len && !stored);
         if (need && (need == __ballot(!done) || ++hdr_wait >= IL_HDR_WAIT)) {
@@ -2045,7 +2048,7 @@ __global__ __launch_bounds__(64) void k_inflate_lanes(const uint8_t* file, const
         if (sym < 0 || il_pos(b) > b.n + 8) { err = true; done = true; continue; }
         if (sym < 256) {
             if (outpos >= blk.isize) { err = true; done = true; continue; }
-            if (TOK) { emit((uint32_t)sym); ++outpos; } else out[outpos++] = (uint8_t)sym;
+            if (TOK) { token = (uint32_t)sym; have_token = true; ++outpos; } else out[outpos++] = (uint8_t)sym;
             continue;
         }
         if (sym == 256) { in_block = false; if (last) done = true; continue; }
@@ -2066,9 +2069,10 @@ __global__ __launch_bounds__(64) void k_inflate_lanes(const uint8_t* file, const
         const uint32_t dist = dbase + ((uint32_t)b.buf & ((1u << dx) - 1));
         b.buf >>= dx; b.cnt -= (int)dx;
         if (dist > outpos || outpos + len > blk.isize) { err = true; done = true; continue; }
-        if (TOK) { emit(0x80000000u | (len << 16) | (dist - 1)); outpos += len; }
+        if (TOK) { token = 0x80000000u | (len << 16) | (dist - 1); have_token = true; outpos += len; }
         else { pend_len = len; pend_src = outpos - dist; }
     }
+    if (TOK && have_token) emit(token);
     if (have && (err || outpos != blk.isize)) atomicOr(&flags[0], 512);
     if (TOK && have) {
         for (uint32_t k = nt - nt % IL_STAGE; k < nt; ++k) tk[k] = stage[(k % IL_STAGE) * 64 + lane];
