@@ -10,7 +10,7 @@ B := build
 CSRC := squid_amd/csrc
 LIBSRC := $(CSRC)/sq_kernels.hip $(CSRC)/sq_bam.cpp $(CSRC)/sq_chimeric.cpp $(CSRC)/sq_segment.cpp $(CSRC)/sq_graph.cpp $(CSRC)/sq_order.cpp $(CSRC)/sq_capi.cpp
 
-all: $(B)/libsquid_hip.so $(B)/squid $(B)/gen_synth_bam $(B)/squid_oracle ref
+all: $(B)/libsquid_hip.so $(B)/squid $(B)/gen_synth_bam $(B)/squid_oracle $(B)/oracle_singlebamrec ref
 
 # oracle/_ref: the part of the real reference that builds without third-party libraries (flag parser), only when
 # the reference tree is present (authoring container); the GPU box uses the prebuilt binary
@@ -30,6 +30,9 @@ $(B)/gen_synth_bam: squid_amd/synth/gen_synth_bam.cpp
 
 $(B)/squid_oracle: oracle/squid_oracle.cpp oracle/o_bam.h oracle/o_readrec.h oracle/o_graph.h oracle/o_order.h
 	$(MAKE) -C oracle OUT=../$(B)
+
+$(B)/oracle_singlebamrec: oracle/singlebamrec_driver.cpp oracle/o_readrec.h oracle/o_bam.h
+	$(MAKE) -C oracle OUT=../$(B) ../$(B)/oracle_singlebamrec
 
 clean:
 	rm -rf $(B)

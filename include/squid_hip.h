@@ -109,6 +109,13 @@ int sq_ingest_concordant_bam(sq_ctx* c, const uint8_t* bam, size_t nbytes, const
 int sq_read_header(const char* bam_path, int32_t* n_ref, int32_t* ref_len, char* names, size_t names_cap);
 int sq_ingest_chimeric_file(sq_ctx* c, const char* bam_path);
 int sq_ingest_concordant_file(sq_ctx* c, const char* bam_path, int32_t n_threads);
+/* Benchmarks and repeated runs: sq_stage_bam copies the compressed bytes of a BAM file into HBM once; a later
+ * sq_ingest_concordant_file on the same path then takes the GPU reader (BGZF inflate, record boundaries and record parse
+ * on the device) straight from that copy, with no host->device transfer of the file (the host still walks the BGZF block
+ * headers of the mapped file).  sq_clear_records drops the resident concordant records and every graph result but keeps
+ * the device buffers, so the same context can ingest again (replaces destroying and re-creating the context). */
+int sq_stage_bam(sq_ctx* c, const char* bam_path);
+int sq_clear_records(sq_ctx* c);
 /* On-disk cache of the resident concordant records: parameter sweeps over -w/-r/-a/-dp/-di/-mq
  * re-run sq_build_graph..sq_call_sv on the same records and can skip the BAM decode (the three BamReader passes of
  * SegmentGraph.cpp:260-347, :1553-1621, :3098-3178).  sq_save_records writes what the ingest calls have made resident;
@@ -204,6 +211,12 @@ int sq_debug_bp_support(sq_ctx* c, int32_t n_bp, const int32_t* chr, const int32
  * 0..n-1; edges5 = n_edges x {u, v, head_u, head_v, weight}, u < v.  use_gpu: k_order_small (n <= 8), else the host solver
  * (n <= 26).  Returns the canonical optimum: orientation mask (bit i = node i reversed) and left-to-right node order. */
 int sq_debug_order(sq_ctx* c, int32_t n, int32_t n_edges, const int32_t* edges5, int32_t use_gpu, int32_t* mask, int32_t* order, int64_t* value);
+
+/* tests: the library's aligned-block comparators (SingleBamRec_t operator<, operator>, operator==, Same, CompReadPos --
+ * src/SingleBamRec.h:39-58) on n blocks given as n x {RefID, RefPos, ReadPos, MatchRef, MatchRead, IsReverse, IsFirstRead}:
+ * rel5 receives the five n*n relation matrices (0/1 bytes, in that order), perm_pos / perm_readpos the permutations the
+ * library's sorts produce with operator< (SegmentGraph.cpp:264) and CompReadPos (ReadRec.cpp:144-145). */
+int sq_debug_blocks(int32_t n, const int32_t* fields7, uint8_t* rel5, int32_t* perm_pos, int32_t* perm_readpos);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,7 @@ EXPORTS = [
     "sq_default_params", "sq_create", "sq_destroy", "sq_strerror", "sq_last_error", "sq_set_references",
     "sq_ingest_chimeric", "sq_chim_contains", "sq_ingest_concordant", "sq_ingest_concordant_bam", "sq_read_header", "sq_ingest_chimeric_file",
     "sq_ingest_concordant_file", "sq_build_graph", "sq_graph_view", "sq_order", "sq_call_sv", "sq_breakpoints",
-    "sq_set_shard", "sq_exchange_pack", "sq_exchange_unpack", "sq_get_timing", "sq_timing_accumulate", "sq_reset", "sq_save_records", "sq_load_records", "sq_get_counts", "sq_debug_download", "sq_debug_bp_support", "sq_debug_order",
+    "sq_set_shard", "sq_exchange_pack", "sq_exchange_unpack", "sq_get_timing", "sq_timing_accumulate", "sq_reset", "sq_stage_bam", "sq_clear_records", "sq_save_records", "sq_load_records", "sq_get_counts", "sq_debug_download", "sq_debug_bp_support", "sq_debug_order", "sq_debug_blocks",
 ]
 
 
@@ -100,6 +100,8 @@ def load_library() -> C.CDLL:
         lib.sq_set_references.argtypes = [C.c_void_p, C.c_int32, _P32]
         lib.sq_ingest_chimeric_file.argtypes = [C.c_void_p, C.c_char_p]
         lib.sq_ingest_concordant_file.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+        lib.sq_stage_bam.argtypes = [C.c_void_p, C.c_char_p]
+        lib.sq_clear_records.argtypes = [C.c_void_p]
         lib.sq_save_records.argtypes = [C.c_void_p, C.c_char_p]
         lib.sq_load_records.argtypes = [C.c_void_p, C.c_char_p]
         lib.sq_read_header.argtypes = [C.c_char_p, _P32, _P32, C.c_char_p, C.c_size_t]
@@ -180,6 +182,14 @@ class Context:
 
     def reset(self):
         self._chk(self.lib.sq_reset(self.h), "sq_reset")
+
+    def stage_bam(self, bam: str):
+        """copy the compressed bytes of `bam` into HBM; a later load() of the same path reads them there (sq_stage_bam)"""
+        self._chk(self.lib.sq_stage_bam(self.h, str(bam).encode()), "sq_stage_bam")
+
+    def clear_records(self):
+        """drop the resident concordant records and all results, keep the device buffers (sq_clear_records)"""
+        self._chk(self.lib.sq_clear_records(self.h), "sq_clear_records")
 
     def save_records(self, path: str):
         """write the resident concordant records to a cache file (sq_save_records)"""

@@ -860,7 +860,7 @@ static int usable_cpus() {
     }
     return std::max(1, n);
 }
-int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSink& sink, const std::function<void(size_t)>& on_total, const RefRange* only, const GpuIngest& gpu) {
+int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSink& sink, const std::function<void(size_t)>& on_total, const RefRange* only, const GpuIngest& gpu, bool force_gpu) {
     using clk = std::chrono::steady_clock;
     auto since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
     double t_map = 0, t_inflate = 0, t_find = 0, t_wait = 0;
@@ -873,7 +873,7 @@ int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSi
     struct stat fst;
     const size_t file_bytes = ::stat(path, &fst) == 0 ? (size_t)fst.st_size : 0;
     const bool gpu_auto = file_bytes >= ((size_t)1 << 30) && std::min(n_threads, usable_cpus()) <= 24;
-    bool try_gpu = gpu && (gpu_env ? std::atoi(gpu_env) != 0 : gpu_auto);
+    bool try_gpu = gpu && (force_gpu || (gpu_env ? std::atoi(gpu_env) != 0 : gpu_auto));
     const bool lazy = try_gpu && !only;
     FileMap fm;
     if (!fm.open(path, !lazy)) { err = std::string("cannot open bamfile ") + path; return SQ_E_IO; }

@@ -798,10 +798,14 @@ int sq_ingest_concordant_file(sq_ctx* c, const char* path, int32_t n_threads) {
         const auto t_file0 = std::chrono::steady_clock::now();
         c->ingest_total_bytes = 0; c->ingest_seen_bytes = 0;
         const RefRange rr{c->shard.first_ref, c->shard.end_ref, c->P.rank == c->P.world_size - 1};
+        const bool staged = !c->staged_path.empty() && c->staged_path == path;  // compressed bytes already in HBM (sq_stage_bam)
+        struct DfileGuard { sq_ctx* c; ~DfileGuard() { c->ingest_dfile = nullptr; } } dfile_guard{c};
+        if (staged) { int r0 = dev_stage_file(c, nullptr, 0, &c->ingest_dfile); if (r0) return r0; }
         int rc = scan_bam_file(path, n_threads, c->err, [&](const uint8_t* bam, size_t nbytes, const unsigned long long* off, int64_t n) { c->ingest_seen_bytes += nbytes; return ingest_raw(c, bam, nbytes, off, n); },
                                [&](size_t total) { c->ingest_total_bytes = c->shard.on ? 0 : total; }, c->shard.on ? &rr : nullptr,
                                [&](const uint8_t* file, std::vector<BgzfRange>& blocks, size_t b0, size_t b1, size_t begin, bool synced, int nref, const IndexMore& more, size_t file_bytes) {
-                                   return dev_ingest_bgzf(c, file, blocks, b0, b1, begin, synced, nref, more, file_bytes); });
+                                   if (staged && file_bytes != c->staged_bytes) return fail(c, SQ_E_IO, "the file changed since sq_stage_bam");
+                                   return dev_ingest_bgzf(c, file, blocks, b0, b1, begin, synced, nref, more, file_bytes); }, staged);
         c->ingest_total_bytes = 0;
         const double t_scan = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_file0).count();
         dev_flush_timers(c);
@@ -814,6 +818,33 @@ int sq_ingest_concordant_file(sq_ctx* c, const char* path, int32_t n_threads) {
         hb.view(&b, false);
         return sq_ingest_concordant(c, &b);
     });
+}
+int sq_stage_bam(sq_ctx* c, const char* path) {
+    if (!c || !path) return SQ_E_ARG;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return fail(c, SQ_E_IO, std::string("cannot open bamfile ") + path);
+    std::vector<uint8_t> bytes;
+    bool ok = fseeko(f, 0, SEEK_END) == 0;
+    const off_t n = ok ? ftello(f) : -1;
+    ok = ok && n >= 0 && fseeko(f, 0, SEEK_SET) == 0;
+    if (ok) { bytes.resize((size_t)n); ok = std::fread(bytes.data(), 1, (size_t)n, f) == (size_t)n; }
+    std::fclose(f);
+    if (!ok) return fail(c, SQ_E_IO, std::string("cannot read ") + path);
+    c->staged_path.clear(); c->staged_bytes = 0;
+    const uint8_t* d = nullptr;
+    int rc = dev_stage_file(c, bytes.data(), bytes.size(), &d);
+    if (rc) return rc;
+    c->staged_path = path; c->staged_bytes = bytes.size();
+    return SQ_OK;
+}
+int sq_clear_records(sq_ctx* c) {
+    if (!c) return SQ_E_ARG;
+    int rc = sq_reset(c);
+    if (rc) return rc;
+    dev_clear_records(c);
+    c->counts = sq_counts{};
+    c->counts.n_chimeric_records = c->n_chim_records; c->counts.n_chim_fragments = (int64_t)c->frags.size(); c->counts.read_len = c->read_len;
+    return SQ_OK;
 }
 // ---- record cache (include/squid_hip.h): header, then the arrays of DeviceRecords / sq_aln_batch, each 64-byte aligned
 namespace {
@@ -1027,6 +1058,28 @@ int sq_debug_order(sq_ctx* c, int32_t n, int32_t n_edges, const int32_t* edges5,
     if (rc) return rc;
     *mask = m; *value = v;
     std::copy(o.begin(), o.end(), order);
+    return SQ_OK;
+}
+int sq_debug_blocks(int32_t n, const int32_t* f, uint8_t* rel5, int32_t* perm_pos, int32_t* perm_readpos) {
+    if (n < 0 || (n && (!f || !rel5 || !perm_pos || !perm_readpos))) return SQ_E_ARG;
+    std::vector<Blk> v((size_t)n);
+    for (int i = 0; i < n; ++i) v[(size_t)i] = Blk{f[7 * i], f[7 * i + 1], f[7 * i + 2], f[7 * i + 3], f[7 * i + 4], f[7 * i + 5] != 0, f[7 * i + 6] != 0};
+    const size_t nn = (size_t)n * (size_t)n;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            const size_t at = (size_t)i * (size_t)n + (size_t)j;
+            rel5[at] = blk_less_pos(v[i], v[j]); rel5[nn + at] = blk_greater_pos(v[i], v[j]); rel5[2 * nn + at] = blk_eq_pos(v[i], v[j]);
+            rel5[3 * nn + at] = blk_same(v[i], v[j]); rel5[4 * nn + at] = blk_less_readpos(v[i], v[j]);
+        }
+    // the library sorts the blocks themselves (sq_segment.cpp: bamdiscordant; sq_chimeric.cpp: SortbyReadPos); the input
+    // index rides along in a parallel array by sorting (block, index) pairs with the same comparator
+    std::vector<std::pair<Blk, int32_t>> s((size_t)n);
+    for (int i = 0; i < n; ++i) s[(size_t)i] = {v[(size_t)i], i};
+    std::sort(s.begin(), s.end(), [](const std::pair<Blk, int32_t>& x, const std::pair<Blk, int32_t>& y) { return blk_less_pos(x.first, y.first); });
+    for (int i = 0; i < n; ++i) perm_pos[i] = s[(size_t)i].second;
+    for (int i = 0; i < n; ++i) s[(size_t)i] = {v[(size_t)i], i};
+    std::sort(s.begin(), s.end(), [](const std::pair<Blk, int32_t>& x, const std::pair<Blk, int32_t>& y) { return blk_less_readpos(x.first, y.first); });
+    for (int i = 0; i < n; ++i) perm_readpos[i] = s[(size_t)i].second;
     return SQ_OK;
 }
 int sq_set_shard(sq_ctx* c, int32_t first_ref, int32_t end_ref) {

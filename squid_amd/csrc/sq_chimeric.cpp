@@ -45,7 +45,7 @@ bool frag_equal(const Frag& x, const Frag& y) {  // ReadRec.cpp:119-141
 }
 
 static bool front_smaller(const Frag& l, const Frag& r) {  // ReadRec.cpp:90-117 (not a strict weak order; kept)
-    auto lt = [](const Blk& p, const Blk& q) { return p.refid != q.refid ? p.refid < q.refid : p.refpos < q.refpos; };
+    auto lt = blk_less_pos;
     if (!l.a.empty() && !r.a.empty()) return lt(l.a.front(), r.a.front());
     if (!l.b.empty() && !r.b.empty()) return lt(l.b.front(), r.b.front());
     if (!l.a.empty() && !r.b.empty()) return lt(l.a.front(), r.b.front());
@@ -94,7 +94,7 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
             m.b.insert(m.b.end(), r.b.begin(), r.b.end());
         }
     }
-    auto by_readpos = [](const Blk& p, const Blk& q) { return p.readpos < q.readpos; };
+    auto by_readpos = blk_less_readpos;
     for (Frag& m : merged) {  // SortbyReadPos (ReadRec.cpp:143-146)
         std::sort(m.a.begin(), m.a.end(), by_readpos);
         std::sort(m.b.begin(), m.b.end(), by_readpos);

@@ -28,6 +28,15 @@ struct Blk {
     bool rev;
     bool first;  // IsFirstRead of the record the block came from (only used by the B11 `Same` quirk)
 };
+// SingleBamRec_t's comparators (src/SingleBamRec.h:39-58) on the host block type; every sort / comparison of blocks in
+// the library goes through these, and tests/test_ref_pin.py checks them against the reference header compiled in place
+inline bool blk_less_pos(const Blk& x, const Blk& y) { return x.refid != y.refid ? x.refid < y.refid : x.refpos < y.refpos; }       // operator<
+inline bool blk_greater_pos(const Blk& x, const Blk& y) { return x.refid != y.refid ? x.refid > y.refid : x.refpos > y.refpos; }    // operator>
+inline bool blk_eq_pos(const Blk& x, const Blk& y) { return x.refid == y.refid && x.refpos == y.refpos; }                           // operator==
+inline bool blk_less_readpos(const Blk& x, const Blk& y) { return x.readpos < y.readpos; }                                          // CompReadPos
+inline bool blk_same(const Blk& x, const Blk& y) {                                                                                  // Same
+    return x.refid == y.refid && x.refpos == y.refpos && x.readpos == y.readpos && x.matchread == y.matchread && x.matchref == y.matchref && x.rev == y.rev && x.first == y.first;
+}
 struct Frag {  // merged chimeric fragment = ReadRec_t after BuildChimericSBamRecord
     std::string name;
     std::vector<Blk> a, b;  // first-in-pair blocks, second-in-pair blocks (sorted by read offset)
@@ -184,6 +193,9 @@ struct sq_ctx {
     sq_counts counts{};
     // chromosome-sharded runs: sq_build_graph / sq_call_sv return SQ_NEED_EXCHANGE with `xbuf` filled; the caller
     // all-gathers it and hands the result back through sq_exchange_unpack before calling the same function again
+    std::string staged_path;               // sq_stage_bam: the file whose compressed bytes are resident in HBM (DeviceRecords::staged)
+    size_t staged_bytes = 0;
+    const uint8_t* ingest_dfile = nullptr; // device copy of the file being ingested (set for the duration of the call)
     size_t ingest_total_bytes = 0, ingest_seen_bytes = 0;  // file ingest in progress: inflated bytes in the file / handed to the GPU so far
     std::unique_ptr<sq::HostPool> pool;  // host threads of this context
     sq::Shard shard;
@@ -230,7 +242,7 @@ typedef std::function<bool(std::vector<BgzfRange>&)> IndexMore;
 typedef std::function<int(const uint8_t*, std::vector<BgzfRange>&, size_t, size_t, size_t, bool, int, const IndexMore&, size_t)> GpuIngest;
 int scan_bam_file(const char* path, int n_threads, std::string& err, const std::function<int(const uint8_t*, size_t, const unsigned long long*, int64_t)>& sink,
                   const std::function<void(size_t)>& on_total = nullptr, const RefRange* only = nullptr,
-                  const GpuIngest& gpu = nullptr);
+                  const GpuIngest& gpu = nullptr, bool force_gpu = false);
 
 // ---- sq_chimeric.cpp
 int build_fragments(sq_ctx* c, const sq_aln_batch* b);
@@ -277,6 +289,8 @@ int dev_create(sq_ctx* c);
 void dev_destroy(sq_ctx* c);
 void dev_flush_timers(sq_ctx* c);
 int dev_append_records(sq_ctx* c, const sq_aln_batch* b);
+void dev_clear_records(sq_ctx* c);
+int dev_stage_file(sq_ctx* c, const uint8_t* bytes, size_t n, const uint8_t** dptr);
 int dev_upload_chim_names(sq_ctx* c);
 int dev_parse_append(sq_ctx* c, const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n_rec);
 int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& blocks, size_t b0, size_t b1, size_t begin, bool synced, int nref, const IndexMore& index_more, size_t file_bytes);

@@ -144,9 +144,10 @@ struct DeviceRecords {
     DBuf<int32_t> ord_e, ord_o, ord_v;  // ordering kernel: packed input, packed output, values
     DBuf<long long> other64, spine64, okey64;
     DBuf<uint8_t> bam_chunk, bgzf_out, bgzf_carry;
+    DBuf<uint8_t> staged;  // sq_stage_bam: the compressed bytes of a whole BAM file (+ padding for the input rings' read-ahead)
     DBuf<long long> rec_sync, rec_end;
     // GPU ingest, two batches in flight: compressed bytes + block table + tokens of a batch
-    struct InflSet { DBuf<uint8_t> in; DBuf<InflBlock> tab; DBuf<uint32_t> tok; DBuf<int32_t> ntok, flags; hipEvent_t ready = nullptr, freed = nullptr, copied = nullptr; std::vector<InflBlock> host_tab; };
+    struct InflSet { DBuf<uint8_t> in; DBuf<InflBlock> tab; DBuf<uint32_t> tok; DBuf<int32_t> ntok, flags; hipEvent_t ready = nullptr, freed = nullptr, copied = nullptr; std::vector<InflBlock> host_tab; const uint8_t* src = nullptr; /* compressed bytes of the batch: `in`, or inside the staged file */ };
     static constexpr int IL_DEPTH = 3;  // buffer sets: batch k is resolved / parsed, k+1 is in the token pass, k+2 is being copied
     InflSet il_set[IL_DEPTH];
     hipStream_t il_stream[IL_DEPTH] = {};  // one per set: its host->device copies
@@ -2330,7 +2331,7 @@ void dev_destroy(sq_ctx* c) {
     D.pin.release(); for (auto& st : D.il_set) { st.in.release(); st.tab.release(); st.tok.release(); st.ntok.release(); st.flags.release(); if (st.ready) (void)hipEventDestroy(st.ready); if (st.freed) (void)hipEventDestroy(st.freed); if (st.copied) (void)hipEventDestroy(st.copied); st.ready = st.freed = st.copied = nullptr; }
     if (D.il_tok_stream) { (void)hipStreamDestroy(D.il_tok_stream); D.il_tok_stream = nullptr; }
     for (auto& q : D.il_stream) if (q) { (void)hipStreamDestroy(q); q = nullptr; }
-    D.bgzf_out.release(); D.bgzf_carry.release(); D.rec_sync.release(); D.rec_end.release(); D.rec_cnt.release(); D.rec_base.release(); D.stripes.release(); D.bp_bucket.release(); D.bp_ev.release(); D.bp_end.release(); D.bp_valid.release();
+    D.bgzf_out.release(); D.bgzf_carry.release(); D.staged.release(); D.rec_sync.release(); D.rec_end.release(); D.rec_cnt.release(); D.rec_base.release(); D.stripes.release(); D.bp_bucket.release(); D.bp_ev.release(); D.bp_end.release(); D.bp_valid.release();
     for (auto& e : D.ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete c->dev;
     c->dev = nullptr;
@@ -2364,6 +2365,24 @@ int dev_append_records(sq_ctx* c, const sq_aln_batch* b) {
     D.nb = (int64_t)nb1;
     c->counts.n_concordant = D.n;
     c->counts.n_blocks = D.nb;
+    return SQ_OK;
+}
+
+void dev_clear_records(sq_ctx* c) {
+    if (!c->dev) return;
+    c->dev->n = 0; c->dev->nb = 0; c->dev->k1 = 0;
+}
+// sq_stage_bam: bytes != null copies a file into HBM; bytes == null returns the resident copy
+int dev_stage_file(sq_ctx* c, const uint8_t* bytes, size_t n, const uint8_t** dptr) {
+    DeviceRecords& D = *c->dev;
+    HIPCHK(hipSetDevice(c->P.device));
+    if (bytes) {
+        HIPCHK(D.staged.reserve(n + 512));
+        HIPCHK(hipMemcpy(D.staged.p, bytes, n, hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(D.staged.p + n, 0, 512));
+    }
+    if (!D.staged.p) return fail(c, SQ_E_ARG, "no staged file");
+    *dptr = D.staged.p;
     return SQ_OK;
 }
 
@@ -2549,11 +2568,13 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         // device memory waits for the kernels of the other batches
         const unsigned long long full = std::max<unsigned long long>(B.bbytes, std::min<unsigned long long>(cap, range_bytes_estimate()));
         const double cratio = (double)B.cbytes / (double)std::max<unsigned long long>(B.bbytes, 1);
-        HIPCHK(st.in.reserve(std::max((size_t)B.cbytes, (size_t)(cratio * 1.1 * (double)full)) + 256));  // (the input rings read up to 80 bytes ahead)
+        const uint8_t* dfile = c->ingest_dfile;  // the file is resident in HBM (sq_stage_bam): no copy, the kernels read it in place
+        if (!dfile) HIPCHK(st.in.reserve(std::max((size_t)B.cbytes, (size_t)(cratio * 1.1 * (double)full)) + 256));  // (the input rings read up to 80 bytes ahead)
+        st.src = dfile ? dfile + B.coff0 : st.in.p;
         HIPCHK(st.tab.reserve(std::max((size_t)nb, (size_t)(full / 60000)))); HIPCHK(st.flags.reserve(4));
         if (variant == 0) { HIPCHK(st.tok.reserve((size_t)full + 64)); HIPCHK(st.ntok.reserve(std::max((size_t)nb, (size_t)(full / 60000)))); }
         const double wa1 = since_ms(wa0);
-        HIPCHK(hipMemcpyAsync(st.in.p, file + B.coff0, (size_t)B.cbytes, hipMemcpyHostToDevice, sa));
+        if (!dfile) HIPCHK(hipMemcpyAsync(st.in.p, file + B.coff0, (size_t)B.cbytes, hipMemcpyHostToDevice, sa));
         if (report && k < 3) std::fprintf(stderr, "GPU ingest: batch %zu planned at %.1f ms, buffers %.1f ms, copy of %.2f GB returned after %.1f ms\n", k, std::chrono::duration<double, std::milli>(wa0 - w0).count(), wa1, (double)B.cbytes * 1e-9, since_ms(wa0) - wa1);
         HIPCHK(hipMemcpyAsync(st.tab.p, st.host_tab.data(), (size_t)nb * sizeof(InflBlock), hipMemcpyHostToDevice, sa));
         HIPCHK(hipMemsetAsync(st.flags.p, 0, 4 * 4, sa));
@@ -2562,7 +2583,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
             sa = D.il_tok_stream;
             HIPCHK(hipStreamWaitEvent(sa, st.copied, 0));
             EvTimer t1(c, "k_inflate_tokens", (double)B.cbytes + (double)B.bbytes * 2, sa);
-            hipLaunchKernelGGL(k_inflate_lanes<true>, dim3((nb + 63) / 64), dim3(64), IL_LDS_BYTES, sa, st.in.p, st.tab.p, nb, B.bbase, nullptr, st.flags.p, st.tok.p, st.ntok.p);
+            hipLaunchKernelGGL(k_inflate_lanes<true>, dim3((nb + 63) / 64), dim3(64), IL_LDS_BYTES, sa, st.src, st.tab.p, nb, B.bbase, nullptr, st.flags.p, st.tok.p, st.ntok.p);
         }
         HIPCHK(hipEventRecord(st.ready, sa));
         return SQ_OK;
@@ -2596,10 +2617,10 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         HIPCHK(hipStreamWaitEvent(s, st.ready, 0));
         if (variant == 2) {  // one wave per block (the first version)
             EvTimer t(c, "k_inflate", (double)B.cbytes + (double)B.bbytes);
-            hipLaunchKernelGGL(k_inflate, dim3((nb + 3) / 4), dim3(256), 0, s, st.in.p, st.tab.p, 0, nb, B.bbase, out, D.flags.p);
+            hipLaunchKernelGGL(k_inflate, dim3((nb + 3) / 4), dim3(256), 0, s, st.src, st.tab.p, 0, nb, B.bbase, out, D.flags.p);
         } else if (variant == 1) {
             EvTimer t(c, "k_inflate", (double)B.cbytes + (double)B.bbytes);
-            hipLaunchKernelGGL(k_inflate_lanes<false>, dim3((nb + 63) / 64), dim3(64), IL_LDS_BYTES, s, st.in.p, st.tab.p, nb, B.bbase, out, D.flags.p, nullptr, nullptr);
+            hipLaunchKernelGGL(k_inflate_lanes<false>, dim3((nb + 63) / 64), dim3(64), IL_LDS_BYTES, s, st.src, st.tab.p, nb, B.bbase, out, D.flags.p, nullptr, nullptr);
         } else {
             EvTimer t2(c, "k_lz_resolve", (double)B.bbytes * 3);
             hipLaunchKernelGGL(k_lz_resolve, dim3(nb), dim3(64), 65536 + 16, s, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, out, D.flags.p);

@@ -426,13 +426,13 @@ double segment_clusters(const sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::ve
                 Blk z{0, 0, 0, 0, 0, false, false};
                 const Blk& l = D.empty() ? z : D.back();
                 const Blk& s = f.b.back();
-                bool same = l.refid == s.refid && l.refpos == s.refpos && l.readpos == s.readpos && l.matchread == s.matchread && l.matchref == s.matchref && l.rev == s.rev && l.first == s.first;
+                const bool same = blk_same(l, s);
                 if (!same) S.part.push_back(clip(s, false));
             }
         }
     }
     std::sort(S.part.begin(), S.part.end());
-    std::sort(D.begin(), D.end(), [](const Blk& x, const Blk& y) { return x.refid != y.refid ? x.refid < y.refid : x.refpos < y.refpos; });  // ledger B8
+    std::sort(D.begin(), D.end(), blk_less_pos);  // ledger B8
     S.nd = (int)D.size();
     disc_sorted = D;
     D.push_back(Blk{0, 0, 0, 0, 0, false, false});  // ledger B21 sentinel
