@@ -123,6 +123,11 @@ int sq_clear_records(sq_ctx* c);
  * records carry the "QNAME is in the chimeric BAM" bit).  The file records the parse parameters (-pt/-pl/-pm), the
  * number of references and a hash of the chimeric name set; sq_load_records returns SQ_E_ARG when they differ from
  * the context's.  A chromosome-sharded context keeps only the records of its shard. */
+/* The cache is also bound to the concordant BAM it was decoded from (size and modification time): sq_ingest_concordant_file
+ * records them by itself; before sq_load_records the caller names the BAM with sq_set_source, and a cache written from
+ * another (or a re-aligned) file is refused with SQ_E_ARG.  sq_load_records also refuses a context that already holds
+ * concordant records. */
+int sq_set_source(sq_ctx* c, const char* bam_path);
 int sq_save_records(sq_ctx* c, const char* cache_path);
 int sq_load_records(sq_ctx* c, const char* cache_path);
 

@@ -67,8 +67,8 @@ struct BamAlignment {
         switch (*t) {
             case 'c': case 'C': case 'A': v = t[1]; break;
             case 's': case 'S': v = t[1] | (t[2] << 8); break;
-            case 'i': case 'I': v = t[1] | (t[2] << 8) | (t[3] << 16) | ((uint32_t)t[4] << 24); break;
-            default: return false;
+            case 'i': v = t[1] | (t[2] << 8) | (t[3] << 16) | ((uint32_t)t[4] << 24); break;
+            default: return false;  // incl. 'I': BamTools' TagTypeHelper<int32_t>::CanConvertFrom refuses UINT32 (dst keeps its value)
         }
         dst = (int)v;
         return true;

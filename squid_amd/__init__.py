@@ -20,7 +20,7 @@ EXPORTS = [
     "sq_default_params", "sq_create", "sq_destroy", "sq_strerror", "sq_last_error", "sq_set_references",
     "sq_ingest_chimeric", "sq_chim_contains", "sq_ingest_concordant", "sq_ingest_concordant_bam", "sq_read_header", "sq_ingest_chimeric_file",
     "sq_ingest_concordant_file", "sq_build_graph", "sq_graph_view", "sq_order", "sq_call_sv", "sq_breakpoints",
-    "sq_set_shard", "sq_exchange_pack", "sq_exchange_unpack", "sq_get_timing", "sq_timing_accumulate", "sq_reset", "sq_stage_bam", "sq_clear_records", "sq_save_records", "sq_load_records", "sq_get_counts", "sq_debug_download", "sq_debug_bp_support", "sq_debug_order", "sq_debug_blocks",
+    "sq_set_shard", "sq_exchange_pack", "sq_exchange_unpack", "sq_get_timing", "sq_timing_accumulate", "sq_reset", "sq_stage_bam", "sq_clear_records", "sq_set_source", "sq_save_records", "sq_load_records", "sq_get_counts", "sq_debug_download", "sq_debug_bp_support", "sq_debug_order", "sq_debug_blocks",
 ]
 
 
@@ -102,6 +102,7 @@ def load_library() -> C.CDLL:
         lib.sq_ingest_concordant_file.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
         lib.sq_stage_bam.argtypes = [C.c_void_p, C.c_char_p]
         lib.sq_clear_records.argtypes = [C.c_void_p]
+        lib.sq_set_source.argtypes = [C.c_void_p, C.c_char_p]
         lib.sq_save_records.argtypes = [C.c_void_p, C.c_char_p]
         lib.sq_load_records.argtypes = [C.c_void_p, C.c_char_p]
         lib.sq_read_header.argtypes = [C.c_char_p, _P32, _P32, C.c_char_p, C.c_size_t]
@@ -205,6 +206,7 @@ class Context:
         if shard is not None:
             self._chk(self.lib.sq_set_shard(self.h, int(shard[0]), int(shard[1])), "sq_set_shard")
         self._chk(self.lib.sq_ingest_chimeric_file(self.h, str(chim_bam).encode()), "sq_ingest_chimeric_file")
+        self._chk(self.lib.sq_set_source(self.h, str(bam).encode()), "sq_set_source")
         self._chk(self.lib.sq_load_records(self.h, str(cache).encode()), "sq_load_records")
 
     # ---- chromosome-sharded runs: the stage functions pause with SQ_NEED_EXCHANGE (include/squid_hip.h)

@@ -5,6 +5,8 @@
 #include <future>
 #include <memory>
 
+#include <sys/stat.h>
+
 #include "sq_internal.h"
 
 namespace sq {
@@ -791,8 +793,17 @@ int sq_ingest_chimeric_file(sq_ctx* c, const char* path) {
     all.view(&b, true);
     return sq_ingest_chimeric(c, &b);
 }
+int sq_set_source(sq_ctx* c, const char* path) {
+    if (!c || !path) return SQ_E_ARG;
+    struct stat st;
+    if (::stat(path, &st) != 0) return fail(c, SQ_E_IO, std::string("cannot open bamfile ") + path);
+    c->source_size = (uint64_t)st.st_size;
+    c->source_mtime = (uint64_t)st.st_mtim.tv_sec * 1000000000ull + (uint64_t)st.st_mtim.tv_nsec;
+    return SQ_OK;
+}
 int sq_ingest_concordant_file(sq_ctx* c, const char* path, int32_t n_threads) {
     if (!c || !path) return SQ_E_ARG;
+    { int r0 = sq_set_source(c, path); if (r0) return r0; }
     if (!std::getenv("SQUID_HOST_PARSE")) {
         // default: the host only inflates BGZF and finds record boundaries; K0 parses the records on the GPU
         const auto t_file0 = std::chrono::steady_clock::now();
@@ -872,6 +883,7 @@ CacheHeader cache_header(const sq_ctx* c, int64_t n_rec, int64_t n_blk) {
     h.n_rec = n_rec; h.n_blk = n_blk;
     h.phred_type = c->P.phred_type; h.min_phred = c->P.min_phred; h.max_lowphred_len = c->P.max_lowphred_len; h.n_ref = (int32_t)c->ref_len.size();
     h.chim_hash = chim_set_hash(c);
+    h.reserved[0] = c->source_size; h.reserved[1] = c->source_mtime;  // (0,0: written from host batches, no file to bind to)
     return h;
 }
 size_t pad64(size_t n) { return (n + 63) & ~(size_t)63; }
@@ -906,7 +918,12 @@ int sq_load_records(sq_ctx* c, const char* path) {
     if (!f) return fail(c, SQ_E_IO, std::string("cannot open ") + path);
     CacheHeader h;
     if (std::fread(&h, sizeof h, 1, f) != 1 || std::memcmp(h.magic, "SQSOA1\0", 8) != 0 || h.n_rec < 0 || h.n_blk < 0) { std::fclose(f); return fail(c, SQ_E_IO, std::string(path) + " is not a record cache"); }
+    if (c->counts.n_concordant != 0) { std::fclose(f); return fail(c, SQ_E_ARG, "sq_load_records on a context that already holds concordant records"); }
     const CacheHeader want = cache_header(c, h.n_rec, h.n_blk);
+    if ((h.reserved[0] || h.reserved[1]) && (want.reserved[0] || want.reserved[1]) && (h.reserved[0] != want.reserved[0] || h.reserved[1] != want.reserved[1])) {
+        std::fclose(f);
+        return fail(c, SQ_E_ARG, "record cache was written from another concordant BAM (size or modification time differ)");
+    }
     if (h.phred_type != want.phred_type || h.min_phred != want.min_phred || h.max_lowphred_len != want.max_lowphred_len || h.n_ref != want.n_ref || h.chim_hash != want.chim_hash) {
         std::fclose(f);
         return fail(c, SQ_E_ARG, "record cache was written with other -pt/-pl/-pm, another reference list or another chimeric BAM");

@@ -193,6 +193,7 @@ struct sq_ctx {
     sq_counts counts{};
     // chromosome-sharded runs: sq_build_graph / sq_call_sv return SQ_NEED_EXCHANGE with `xbuf` filled; the caller
     // all-gathers it and hands the result back through sq_exchange_unpack before calling the same function again
+    uint64_t source_size = 0, source_mtime = 0;  // identity of the concordant BAM (sq_set_source / sq_ingest_concordant_file); 0,0 = unknown
     std::string staged_path;               // sq_stage_bam: the file whose compressed bytes are resident in HBM (DeviceRecords::staged)
     size_t staged_bytes = 0;
     const uint8_t* ingest_dfile = nullptr; // device copy of the file being ingested (set for the duration of the call)

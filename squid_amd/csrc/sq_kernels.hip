@@ -476,10 +476,14 @@ __device__ int parse_blocks(const uint8_t* cg, int ncig, const uint8_t* seq, int
 // lines and the chunk is fetched from HBM ~20 times over.  So the range is first copied into LDS with coalesced 16-byte
 // loads and the lanes parse from there (a range that does not fit -- very long records -- is parsed in place).
 constexpr int PARSE_THREADS = 64, PARSE_LDS = 32768;
-__device__ __forceinline__ const uint8_t* stage_records(const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n, uint8_t* lds) {
+// `avail` receives the bytes the record may occupy: up to the next record's offset, the end of the chunk and (when staged) the
+// end of the staged range; -1 when the offsets handed in by the caller are not ascending or lie outside the chunk.
+__device__ __forceinline__ const uint8_t* stage_records(const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n, uint8_t* lds, long long& avail) {
     const int64_t r0 = (int64_t)blockIdx.x * blockDim.x, r1 = r0 + blockDim.x < n ? r0 + blockDim.x : n;
-    const unsigned long long lo = rec_off[r0] & ~15ull, hi = r1 < n ? rec_off[r1] : (unsigned long long)nbytes;
-    const bool fits = hi - lo <= (unsigned long long)PARSE_LDS;  // uniform over the workgroup
+    const unsigned long long first = rec_off[r0], lo = first & ~15ull;
+    unsigned long long hi = r1 < n ? rec_off[r1] : (unsigned long long)nbytes;
+    if (hi > (unsigned long long)nbytes) hi = (unsigned long long)nbytes;
+    const bool fits = first <= hi && hi - lo <= (unsigned long long)PARSE_LDS;  // uniform over the workgroup
     if (fits) {
         const uint4* src = (const uint4*)(bam + lo);  // (the chunk buffer is 256-byte aligned and padded by 64 bytes)
         uint4* dst = (uint4*)lds;
@@ -488,14 +492,33 @@ __device__ __forceinline__ const uint8_t* stage_records(const uint8_t* bam, size
     }
     __syncthreads();
     const int64_t r = r0 + threadIdx.x;
+    avail = -1;
     if (r >= n) return nullptr;
-    return fits ? lds + (rec_off[r] - lo) : bam + rec_off[r];
+    const unsigned long long o = rec_off[r], e = r + 1 < n ? rec_off[r + 1] : (unsigned long long)nbytes;
+    if (o > (unsigned long long)nbytes || e > (unsigned long long)nbytes || e < o) return bam;  // (avail stays -1: the caller flags the record)
+    const bool staged = fits && o >= first && o <= hi;
+    const unsigned long long lim = staged ? hi - o : (unsigned long long)nbytes - o;
+    avail = (long long)(e - o < lim ? e - o : lim);
+    return staged ? lds + (o - lo) : bam + o;
+}
+// block_size and the fixed fields must fit into `avail`, the variable-length fields into block_size (a malformed record would
+// otherwise send the cigar / sequence / quality / tag walks past the chunk or the 32 KB staging buffer)
+__device__ __forceinline__ bool rec_header_ok(const uint8_t* rec, long long avail) {
+    if (avail < 36) return false;
+    const long long bs = ld32(rec);
+    if (bs < 32 || 4 + bs > avail) return false;
+    const uint8_t* p = rec + 4;
+    const long long lname = p[8], ncig = ld16(p + 12), lseq = ld32(p + 16);
+    if (lseq < 0) return false;
+    return 32 + lname + 4 * ncig + (lseq + 1) / 2 + lseq <= bs;
 }
 __global__ __launch_bounds__(PARSE_THREADS) void k_parse_count(const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n, int32_t* nblk, int32_t* flags) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[PARSE_LDS];
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint8_t* rec = stage_records(bam, nbytes, rec_off, n, lds);
+    long long avail;
+    const uint8_t* rec = stage_records(bam, nbytes, rec_off, n, lds, avail);
     if (!rec) return;
+    if (!rec_header_ok(rec, avail)) { atomicOr(&flags[0], 128); nblk[r] = 0; return; }
     const uint8_t* p = rec + 4;
     int lname = p[8], ncig = ld16(p + 12), flag = ld16(p + 14), lseq = ld32(p + 16), pos = ld32(p + 4);
     const uint8_t* cg = p + 32 + lname;
@@ -504,7 +527,6 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_parse_count(const uint8_t* ba
     for (int i = 0; i < ncig; ++i) { uint32_t v = (uint32_t)ld32(cg + 4 * i); char t = cig_type(v); if (t == 'M' || t == 'S' || t == 'H' || t == 'I' || t == '=' || t == 'X') totlen += (int)(v >> 4); }
     int nb = parse_blocks<false>(cg, ncig, seq, lseq, pos, flag & 0x10, totlen, nullptr, nullptr, nullptr, nullptr);
     nblk[r] = nb < 0 ? 0 : nb;
-    (void)flags;
 }
 struct FArrN { const int32_t* a; __device__ int operator()(int64_t i) const { return a[i]; } };
 __global__ __launch_bounds__(PARSE_THREADS) void k_parse_write(const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n, ChimSetView C, ParseParams P, const int32_t* blk_rel, uint32_t blk_base, int32_t* o_refid,
@@ -512,8 +534,10 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_parse_write(const uint8_t* ba
                               int32_t* b_refpos, int32_t* b_matchref, uint16_t* b_readpos, uint16_t* b_matchread, int32_t* flags) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[PARSE_LDS];
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint8_t* rec = stage_records(bam, nbytes, rec_off, n, lds);
+    long long avail;
+    const uint8_t* rec = stage_records(bam, nbytes, rec_off, n, lds, avail);
     if (!rec) return;
+    if (!rec_header_ok(rec, avail)) { atomicOr(&flags[0], 128); return; }
     const uint8_t* p = rec + 4;
     const int bs = ld32(p - 4);
     const uint8_t* pend = p + bs;
@@ -560,7 +584,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_parse_write(const uint8_t* ba
             has_ih = true;
             if (ty == 'c' || ty == 'C' || ty == 'A') ih = v[0];
             else if (ty == 's' || ty == 'S') ih = ld16(v);
-            else if (ty == 'i' || ty == 'I') ih = ld32(v);
+            else if (ty == 'i') ih = ld32(v);  // (BamTools' GetTag<int> refuses a UINT32 value: IHtagvalue stays 0)
         }
         q = v + sz;
     }
@@ -571,6 +595,9 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_parse_write(const uint8_t* ba
     if (chim_contains(C, name, lname > 0 ? lname - 1 : 0)) ax |= SQ_AUX_INCHIM;
     const uint32_t b0 = blk_base + (uint32_t)blk_rel[r];
     int nb = parse_blocks<true>(cg, ncig, seq, lseq, pos, flag & 0x10, totlen, b_refpos + b0, b_matchref + b0, b_readpos + b0, b_matchread + b0);
+    // the SoA keeps TotalLen and the read offsets in 16 bits and the segmentation summary counts a record's further blocks in
+    // 8 bits: longer reads / more blocks are refused instead of wrapping silently
+    if (totlen > 65535 || nb > 256) atomicOr(&flags[0], 2048);
     if (nb < 0) {
         // the reference constructs a ReadRec_t only for records that pass its filters; for those the assert is live
         bool filtered = (ax & (SQ_AUX_MULTI | SQ_AUX_INCHIM)) || (flag & 0x400) || (flag & 0x4) || mapq < P.min_mapq;
@@ -2344,6 +2371,8 @@ int dev_append_records(sq_ctx* c, const sq_aln_batch* b) {
     hipStream_t s = c->stream;
     const size_t n0 = (size_t)D.n, nb0 = (size_t)D.nb, n1 = n0 + (size_t)b->n_rec, nb1 = nb0 + (size_t)b->n_blk;
     if (nb1 >= 0xffffffffull) return fail(c, SQ_E_CAPACITY, "more than 2^32 aligned blocks");
+    for (int64_t i = 0; i < b->n_rec; ++i)
+        if (b->blk_off[i + 1] - b->blk_off[i] > 256) return fail(c, SQ_E_CAPACITY, "a record with more than 256 aligned blocks");
 #define GROW(buf, used, want) HIPCHK(D.buf.grow_keep(used, want, s))
     GROW(refid, n0, n1); GROW(pos, n0, n1); GROW(mrefid, n0, n1); GROW(mpos, n0, n1); GROW(endpos, n0, n1);
     GROW(flag, n0, n1); GROW(totlen, n0, n1); GROW(mapq, n0, n1); GROW(aux, n0, n1);
@@ -2466,6 +2495,7 @@ static int parse_device(sq_ctx* c, const uint8_t* d_bam, size_t nbytes, const un
     HIPCHK(hipMemcpyAsync(&hf, D.flags.p, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (hf & 128) return fail(c, SQ_E_IO, "corrupt BAM record");
+    if (hf & 2048) return fail(c, SQ_E_CAPACITY, "a read longer than 65535 bases or with more than 256 aligned blocks (the record layout keeps 16-bit read offsets)");
     if (hf & 256) return fail(c, SQ_E_ASSERT, "record without stored bases for an aligned block (reference asserts, ReadRec.cpp:64)");
     D.n = (int64_t)n1;
     D.nb = (int64_t)nb1;

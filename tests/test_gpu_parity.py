@@ -236,6 +236,8 @@ def test_gpu_record_parse_hand_made_records(built, tmp_path, monkeypatch):
         bw.record("e", 0, 1030, 255, 0x1 | 0x40, "100M", 0, 1300, qual=[30] * 20 + [2] * 11 + [30] * 69, tags=b"IHs\x01\x00"),
         bw.record("q1", 0, 1040, 255, 0x1 | 0x40, "30H70M", 1, 700),          # name is in the chimeric set
         bw.record("f", 0, 1050, 255, 0x1 | 0x40 | 0x400, "5M2X3=90M", -1, -1),
+        bw.record("g", 0, 1060, 255, 0x1 | 0x40, "100M", 0, 1300, tags=b"IHI\x02\x00\x00\x00"),   # UINT32: BamTools' GetTag<int> refuses it, IH stays 0
+        bw.record("h", 0, 1070, 255, 0x1 | 0x40, "100M", 0, 1300, tags=b"IHi\x02\x00\x00\x00"),
         bw.record("u", -1, -1, 0, 0x1 | 0x4 | 0x40, "", -1, -1, seq="", qual=[]),
     ]
     chim = [bw.record("q1", 0, 5000, 255, 0x1 | 0x40, "60M40S"), bw.record("q1", 1, 7000, 255, 0x1 | 0x40 | 0x100, "60H40M"),
@@ -261,6 +263,7 @@ def test_gpu_record_parse_hand_made_records(built, tmp_path, monkeypatch):
     # record "b": the 75 % poly-A block is dropped, the second block is mirrored on the reverse strand: readpos = 100-60-40 = 0
     assert list(zip(host["b_refpos"][o[1]:o[2]], host["b_readpos"][o[1]:o[2]])) == [(1565, 0)]
     assert [int(x) for x in host["aux"][:6]] == [0, 0, 1, 1, 4, 2]  # none, none, XA, IH>1, low-Phred run of 11, QNAME in chimeric set
+    assert [int(x) for x in host["aux"][7:9]] == [0, 1]             # IH:I:2 is not convertible (stays 0), IH:i:2 counts
 
 
 # ---- K10: the breakpoint cursor of ExactBPConcordantSupport (src/SegmentGraph.cpp:3129-3166) on dense breakpoint lists
@@ -654,6 +657,18 @@ def test_record_cache_round_trip_and_refusals(built, synth, tmp_path):
     with squid_amd.Context() as ctx:
         with pytest.raises(squid_amd.SquidError):
             ctx.load_cached(f"{pre}.bam", f"{other}.chim.bam", cache)
+    # ... a cache decoded from another concordant BAM (here: a byte-identical copy with another modification time), and a
+    # context that already holds records
+    import os, shutil
+    shutil.copy(f"{pre}.bam", tmp_path / "copy.bam")
+    os.utime(tmp_path / "copy.bam", (1_500_000_000, 1_500_000_000))
+    with squid_amd.Context() as ctx:
+        with pytest.raises(squid_amd.SquidError, match="another concordant BAM"):
+            ctx.load_cached(tmp_path / "copy.bam", f"{pre}.chim.bam", cache)
+    with squid_amd.Context() as ctx:
+        ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
+        with pytest.raises(squid_amd.SquidError, match="already holds"):
+            ctx._chk(ctx.lib.sq_load_records(ctx.h, str(cache).encode()), "sq_load_records")
     with squid_amd.Context() as ctx:
         with pytest.raises(squid_amd.SquidError, match="not a record cache"):
             ctx.load_cached(f"{pre}.bam", f"{pre}.chim.bam", f"{pre}.bam")
