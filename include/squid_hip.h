@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SQ_ABI_VERSION 1
+#define SQ_ABI_VERSION 2
 
 enum {
     SQ_OK = 0,
@@ -204,6 +204,8 @@ int sq_reset(sq_ctx* c); /* drop graph results, keep ingested records resident i
 typedef struct sq_counts {
     int64_t n_concordant, n_blocks, n_chimeric_records, n_chim_fragments, read_len;
     int64_t n_kept_p1, n_break, n_kept_p2, n_raw_edges, n_unique_edges;
+    int64_t n_order_unsolved; /* components whose ordering problem was beyond the exact solver: identity order kept, what the reference
+                                 keeps when GLPK fails within its 300 s (SegmentGraph.cpp:3287-3292,3964,3984); 0 on every test input */
 } sq_counts;
 int sq_get_counts(sq_ctx* c, sq_counts* k);
 
@@ -213,8 +215,9 @@ int sq_debug_download(sq_ctx* c, sq_aln_batch* b);
  * arbitrary sorted breakpoint list; host_walk != 0 takes the serial host restatement instead of the K10 kernels */
 int sq_debug_bp_support(sq_ctx* c, int32_t n_bp, const int32_t* chr, const int32_t* pos, int32_t* coverage, int32_t host_walk);
 /* tests: one instance of the per-component ordering problem (GenerateILP, src/SegmentGraph.cpp:3763-3983) on local nodes
- * 0..n-1; edges5 = n_edges x {u, v, head_u, head_v, weight}, u < v.  use_gpu: k_order_small (n <= 8), else the host solver
- * (n <= 26).  Returns the canonical optimum: orientation mask (bit i = node i reversed) and left-to-right node order. */
+ * 0..n-1; edges5 = n_edges x {u, v, head_u, head_v, weight}, u < v.  use_gpu: k_order_small (n <= 8) / k_order_mid (9..19), else
+ * the host solver (n <= 128).  Returns the canonical optimum: order[p] = local node at position p, bit-complemented (~node)
+ * when the node is reversed; mask = orientation mask (bit i = node i reversed) when n <= 31, else -1. */
 int sq_debug_order(sq_ctx* c, int32_t n, int32_t n_edges, const int32_t* edges5, int32_t use_gpu, int32_t* mask, int32_t* order, int64_t* value);
 
 /* tests: the library's aligned-block comparators (SingleBamRec_t operator<, operator>, operator==, Same, CompReadPos --

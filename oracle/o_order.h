@@ -18,7 +18,7 @@ namespace oracle {
 struct LocalEdge { int u, v; bool hu, hv; int w; bool discordant; };  // u < v local indices
 
 struct OrderStats {
-    long components = 0, solved = 0, ambiguous = 0, too_large = 0, mincut_splits = 0;
+    long components = 0, solved = 0, ambiguous = 0, too_large = 0, mincut_splits = 0, ambiguity_checked = 0;
 };
 
 // does the signed arrangement satisfy edge e?  (rows of GenerateILP, :3803-3931; fwd[i]=y_i, pos[i]=rank)
@@ -181,12 +181,144 @@ inline void SolveDP(int n, const std::vector<LocalEdge>& E, std::vector<int>& or
     order = b.bestorder; bestmask = b.bestmask; bestval = b.bestval;
 }
 
+// ---- components of more than 26 nodes (MincutRecursion hands them to GenerateILP whole when no weight-1 cut exists,
+// :3326-3349; GLPK gets 300 s).  Same canonical optimum as above -- max value, then the smallest orientation mask read as a
+// number (bit i = node i reversed), then the lexicographically smallest sequence -- found by an orientation search on
+// std::vector<bool> and, per orientation, Tarjan's strongly connected components: arcs between components are all
+// satisfiable, each non-trivial component gets the subset DP.  `steps` is a work budget; on exhaustion `ok` is false and
+// the caller keeps the identity order (what the reference keeps when GLPK fails, :3287-3292,3984).
+struct WideSolver {
+    int n;
+    const std::vector<LocalEdge>& E;
+    long bestval = -1;
+    std::vector<bool> bestrev;
+    std::vector<int> bestorder;
+    long steps = 0, budget;
+    bool ok = true;
+    WideSolver(int n, const std::vector<LocalEdge>& E, long budget) : n(n), E(E), budget(budget) {}
+    static bool Compat(const LocalEdge& e, const std::vector<bool>& rev, bool& ufirst) {
+        bool yu = !rev[e.u], yv = !rev[e.v];
+        bool compat;
+        if (!e.hu && e.hv) { compat = yu == yv; ufirst = yu; }
+        else if (!e.hu && !e.hv) { compat = yu != yv; ufirst = yu; }
+        else if (e.hu && e.hv) { compat = yu != yv; ufirst = yv; }
+        else { compat = yu == yv; ufirst = !yu; }
+        return compat;
+    }
+    // nodes above k are fixed.  Upper bound: compatible edges among fixed nodes, all edges among free nodes, and for every free
+    // node the heavier of the two edge sets towards fixed nodes that its forward / its reversed orientation would allow
+    long Bound(const std::vector<bool>& rev, int k) const {
+        long ub = 0;
+        std::vector<long> asfwd(k + 1 > 0 ? k + 1 : 0, 0), asrev(k + 1 > 0 ? k + 1 : 0, 0);
+        for (const LocalEdge& e : E) {
+            if (e.u > k) { bool uf; if (Compat(e, rev, uf)) ub += e.w; }
+            else if (e.v <= k) ub += e.w;
+            else {
+                // (one of the two orientations of u always fits: equal orientations for tail->head / head->tail edges, opposite otherwise)
+                const bool v_forward = !rev[e.v], need_equal = e.hu != e.hv;
+                if (need_equal == v_forward) asfwd[e.u] += e.w; else asrev[e.u] += e.w;
+            }
+        }
+        for (int u = 0; u <= k; u++) ub += std::max(asfwd[u], asrev[u]);
+        return ub;
+    }
+    void Leaf(const std::vector<bool>& rev) {
+        std::vector<std::vector<int>> a(n, std::vector<int>(n, 0));
+        long ub = 0;
+        for (const LocalEdge& e : E) { bool uf; if (!Compat(e, rev, uf)) continue; ub += e.w; if (uf) a[e.u][e.v] += e.w; else a[e.v][e.u] += e.w; }
+        std::vector<int> order;
+        long val;
+        if (TopoSmallestFirst(n, a, order)) val = ub;
+        else {
+            order.clear();
+            // Tarjan
+            std::vector<int> idx(n, -1), low(n, 0), comp(n, -1), stk;
+            std::vector<bool> on(n, false);
+            int counter = 0, ncomp = 0;
+            std::vector<std::pair<int, int>> call;  // (node, next neighbour)
+            for (int r = 0; r < n; r++) {
+                if (idx[r] >= 0) continue;
+                call.push_back({r, 0});
+                idx[r] = low[r] = counter++; stk.push_back(r); on[r] = true;
+                while (!call.empty()) {
+                    int x = call.back().first, &y = call.back().second;
+                    if (y < n) {
+                        int t = y++;
+                        if (a[x][t] <= 0) continue;
+                        if (idx[t] < 0) { idx[t] = low[t] = counter++; stk.push_back(t); on[t] = true; call.push_back({t, 0}); }
+                        else if (on[t]) low[x] = std::min(low[x], idx[t]);
+                    } else {
+                        if (low[x] == idx[x]) { int t; do { t = stk.back(); stk.pop_back(); on[t] = false; comp[t] = ncomp; } while (t != x); ncomp++; }
+                        call.pop_back();
+                        if (!call.empty()) low[call.back().first] = std::min(low[call.back().first], low[x]);
+                    }
+                }
+            }
+            std::vector<std::vector<int>> mem(ncomp);
+            for (int x = 0; x < n; x++) mem[comp[x]].push_back(x);
+            val = 0;
+            for (int x = 0; x < n; x++) for (int y = 0; y < n; y++) if (comp[x] != comp[y]) val += a[x][y];
+            std::vector<OrderDP*> dps(ncomp, nullptr);
+            std::vector<size_t> placed(ncomp, 0);
+            for (int c = 0; c < ncomp && ok; c++) {
+                int sz = (int)mem[c].size();
+                if (sz < 2) continue;
+                if (sz > 22) {
+                    // no table for that many subsets.  At least one arc of the component is violated, so the orientation is worth at most
+                    // ub - (its lightest arc): enough to discard it when the incumbent is at least as good; otherwise give up
+                    int lightest = 0;
+                    for (int i : mem[c]) for (int j : mem[c]) if (a[i][j] > 0 && (lightest == 0 || a[i][j] < lightest)) lightest = a[i][j];
+                    if (ub - lightest <= bestval) { val = -1; break; }
+                    ok = false; break;
+                }
+                std::vector<std::vector<int>> sub(sz, std::vector<int>(sz, 0));
+                for (int i = 0; i < sz; i++) for (int j = 0; j < sz; j++) sub[i][j] = a[mem[c][i]][mem[c][j]];
+                dps[c] = new OrderDP(sz, sub);
+                steps += (long)1 << sz;
+                val += dps[c]->solve();
+            }
+            if (ok && val < 0) { for (OrderDP* d : dps) delete d; return; }  // discarded by the cycle bound
+            if (ok && val > bestval) {
+                std::vector<bool> done(n, false);
+                for (int p = 0; p < n; p++)
+                    for (int v = 0; v < n; v++) {
+                        if (done[v]) continue;
+                        bool free = true;
+                        for (int x = 0; x < n && free; x++) if (a[x][v] > 0 && comp[x] != comp[v] && !done[x]) free = false;
+                        if (!free) continue;
+                        int c = comp[v];
+                        if (dps[c]) {
+                            int lv = (int)(std::find(mem[c].begin(), mem[c].end(), v) - mem[c].begin());
+                            if (dps[c]->gain(placed[c], lv) + dps[c]->h[placed[c] | ((size_t)1 << lv)] != dps[c]->h[placed[c]]) continue;
+                            placed[c] |= (size_t)1 << lv;
+                        }
+                        order.push_back(v); done[v] = true;
+                        break;
+                    }
+            }
+            for (OrderDP* d : dps) delete d;
+            if (!ok) return;
+        }
+        if (val > bestval) { bestval = val; bestrev = rev; bestorder = order; }
+    }
+    void Rec(std::vector<bool>& rev, int k) {
+        if (!ok) return;
+        if (++steps > budget) { ok = false; return; }
+        if (Bound(rev, k) <= bestval) return;
+        if (k < 0) { Leaf(rev); return; }
+        Rec(rev, k - 1);                       // forward first: masks are met in increasing numeric order
+        if (k != n - 1) { rev[k] = true; Rec(rev, k - 1); rev[k] = false; }  // (the mirror image of a solution has the last node reversed and a larger mask)
+    }
+    void Run() { std::vector<bool> rev(n, false); Rec(rev, n - 1); if (!ok) bestval = -1; }
+};
+
 class Orderer {
 public:
     const SegmentGraph_t& G;
     OrderStats stats;
     int brute_max = 7;     // components up to this size are solved by plain enumeration (and checked for ambiguity)
-    int exact_max = 26;    // larger ones cannot be solved exactly here (the reference gives GLPK 300 s)
+    int exact_max = 19;    // up to here: branch and bound with a whole-component subset DP; 20..128: WideSolver; beyond: identity
+    long wide_budget = 20000000L;
     explicit Orderer(const SegmentGraph_t& g) : G(g) {}
 
     // src/SegmentGraph.cpp:3236-3262
@@ -211,6 +343,31 @@ public:
             BestOrders[i] = MincutRecursion(CompNodes[i], CompEdges[i]);
         }
         return BestOrders;
+    }
+
+    // Uniqueness certificate for 8..19 nodes (too many for the enumeration of SolveBrute): is the set of satisfied DISCORDANT
+    // edges the same in every optimal solution?  For a discordant edge e satisfied by the canonical optimum, delete it: if the
+    // optimum of the rest is still `val`, some optimal solution does not satisfy e.  For one that is not satisfied, add 1 to
+    // its weight: if the optimum becomes val + 1, some optimal solution satisfies it.
+    static bool Ambiguous(int n, const std::vector<LocalEdge>& E, const std::vector<int>& order, unsigned mask, long val) {
+        std::vector<int> pos(n), fwd(n);
+        for (int p = 0; p < n; p++) pos[order[p]] = p;
+        for (int i = 0; i < n; i++) fwd[i] = !((mask >> i) & 1);
+        for (size_t k = 0; k < E.size(); k++) {
+            if (!E[k].discordant) continue;
+            std::vector<LocalEdge> F = E;
+            std::vector<int> o2; unsigned m2; long v2;
+            if (EdgeSatisfied(E[k], fwd, pos)) {
+                F.erase(F.begin() + (long)k);
+                SolveDP(n, F, o2, m2, v2);
+                if (v2 == val) return true;
+            } else {
+                F[k].w += 1;
+                SolveDP(n, F, o2, m2, v2);
+                if (v2 == val + 1) return true;
+            }
+        }
+        return false;
     }
 
 private:
@@ -244,6 +401,22 @@ private:
         } else if (n <= exact_max) {
             SolveDP(n, E, order, mask, val);
             stats.solved++;
+            if (n < 20 && Ambiguous(n, E, order, mask, val)) stats.ambiguous++;
+        } else if (n <= 128) {
+            WideSolver ws(n, E, wide_budget);
+            ws.Run();
+            if (ws.ok && ws.bestval >= 0) {
+                stats.solved++;
+                std::vector<int> ids(n);
+                for (auto& kv : CompNodes) ids[kv.second] = kv.first;
+                for (int p = 0; p < n; p++) { int l = ws.bestorder[p]; BestOrder[p] = ws.bestrev[l] ? (-ids[l] - 1) : (ids[l] + 1); }
+                return BestOrder;
+            }
+            std::cerr << "oracle: component of " << n << " nodes exhausted the exact solver's budget; identity order kept\n";
+            stats.too_large++;
+            order.resize(n);
+            for (int i = 0; i < n; i++) order[i] = i;
+            mask = 0;
         } else {
             // identity order, all forward == what the reference keeps when glp_intopt fails (:3287-3292,3984)
             std::cerr << "oracle: component of " << n << " nodes exceeds the exact solver; identity order kept\n";

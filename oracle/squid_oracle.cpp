@@ -192,8 +192,40 @@ static int solver_selftest(int rounds) {
     return 0;
 }
 
+// one ordering problem from stdin ("n m" then m lines "u v head_u head_v weight", u < v): prints "value s_1 ... s_n" with
+// s = +(node + 1) / -(node + 1) left to right.  method: brute (all signed permutations), bnb (n <= 26), wide (n <= 128)
+static int solve_order_cli(const std::string& method) {
+    int n = 0, m = 0;
+    if (std::scanf("%d %d", &n, &m) != 2 || n < 2 || n > 128) return 2;
+    std::vector<LocalEdge> E;
+    for (int i = 0; i < m; i++) {
+        int u, v, hu, hv, w;
+        if (std::scanf("%d %d %d %d %d", &u, &v, &hu, &hv, &w) != 5 || u < 0 || u >= v || v >= n) return 2;
+        E.push_back(LocalEdge{u, v, hu != 0, hv != 0, w, true});
+    }
+    std::vector<int> order;
+    std::vector<bool> rev(n, false);
+    long val = -1;
+    if (method == "wide") {
+        WideSolver ws(n, E, 50000000L);
+        ws.Run();
+        if (!ws.ok) { std::printf("FAILED\n"); return 0; }
+        order = ws.bestorder; rev = ws.bestrev; val = ws.bestval;
+    } else {
+        unsigned mask = 0;
+        if (method == "brute") { if (n > 9) return 2; SolveBrute(n, E, order, mask, val, nullptr); }
+        else { if (n > 26) return 2; SolveDP(n, E, order, mask, val); }
+        for (int i = 0; i < n; i++) rev[i] = (mask >> i) & 1;
+    }
+    std::printf("%ld", val);
+    for (int p = 0; p < n; p++) std::printf(" %d", rev[order[p]] ? -(order[p] + 1) : order[p] + 1);
+    std::printf("\n");
+    return 0;
+}
+
 int main(int argc, char* argv[]) {
     if (argc >= 2 && std::string(argv[1]) == "--selftest") return solver_selftest(argc >= 3 ? std::atoi(argv[2]) : 2000);
+    if (argc >= 3 && std::string(argv[1]) == "--solve-order") return solve_order_cli(argv[2]);
     Params P;
     std::string dumpdir;
     if (argc >= 2 && std::string(argv[1]) == "--print-config") {  // same line as oracle/ref_config_driver.cpp prints for the real parser

@@ -67,7 +67,7 @@ class SqTiming(C.Structure):
 
 class SqCounts(C.Structure):
     _fields_ = [(k, C.c_int64) for k in ("n_concordant", "n_blocks", "n_chimeric_records", "n_chim_fragments", "read_len", "n_kept_p1", "n_break",
-                                          "n_kept_p2", "n_raw_edges", "n_unique_edges")]
+                                          "n_kept_p2", "n_raw_edges", "n_unique_edges", "n_order_unsolved")]
 
 
 class SquidError(RuntimeError):
@@ -313,7 +313,9 @@ class Context:
         mask, value, order = C.c_int32(), C.c_int64(), (C.c_int32 * n)()
         self.lib.sq_debug_order.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
         self._chk(self.lib.sq_debug_order(self.h, n, len(edges), flat, int(use_gpu), C.byref(mask), order, C.byref(value)), "sq_debug_order")
-        return mask.value, list(order), value.value
+        o = list(order)
+        m = sum(1 << (~x) for x in o if x < 0)  # reversed nodes come back bit-complemented
+        return m, [x if x >= 0 else ~x for x in o], value.value
 
     def timing_accumulate(self, keep: bool = True):
         """let the timing table accumulate over repeated build_graph/order/call_sv runs (read it once with timing())"""

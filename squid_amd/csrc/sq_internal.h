@@ -315,6 +315,9 @@ int dev_connected_components(sq_ctx* c, int n_nodes, const std::vector<Edge>& ed
 struct SmallProblem { int n; int eoff, ecount; };  // edges: local u,v,hu,hv,w packed as 5 ints each
 int dev_order_small(sq_ctx* c, const std::vector<SmallProblem>& probs, const std::vector<int32_t>& edges5, std::vector<int32_t>& out_mask,
                     std::vector<int32_t>& out_order, int nmax);
+constexpr int ORDER_MID_NMAX = 19;  // k_order_mid: components of 9..19 nodes (out_order has this stride)
+int dev_order_mid(sq_ctx* c, const std::vector<SmallProblem>& probs, const std::vector<int32_t>& edges5, std::vector<int32_t>& out_mask, std::vector<int32_t>& out_order,
+                  std::vector<int32_t>& out_value, std::vector<int32_t>& out_status);
 // cur_prev: cursor position left by the records of earlier shards
 struct BpBoundary {  // what the next shard needs to know about the breakpoint cursor (SegmentGraph.cpp:3157)
     int cur_end = 0;          // cursor after this shard's records, given the cur_prev it started from

@@ -142,6 +142,7 @@ struct DeviceRecords {
     DBuf<uint32_t> h_val, oval;
     uint32_t h_slots = 1u << 16;
     DBuf<int32_t> ord_e, ord_o, ord_v;  // ordering kernel: packed input, packed output, values
+    DBuf<int32_t> ord_me, ord_mo;       // k_order_mid: packed input, packed output
     DBuf<long long> other64, spine64, okey64;
     DBuf<uint8_t> bam_chunk, bgzf_out, bgzf_carry;
     DBuf<uint8_t> staged;  // sq_stage_bam: the compressed bytes of a whole BAM file (+ padding for the input rings' read-ahead)
@@ -1567,6 +1568,263 @@ __global__ __launch_bounds__(256) void k_order_small(const SmallProblem* probs, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ K9b: mid-size orderings
+// Components of 9..19 nodes (MincutRecursion's n < 20 branch, SegmentGraph.cpp:3271-3314), one per workgroup.  The last node
+// stays forward (reversing every node and the sequence satisfies the same edges), so there are 2^(n-1) orientation masks.
+//   * masks are visited in increasing order, 256 at a time: the high bits `h` select a batch, a thread takes one low-bit
+//     pattern.  A batch is skipped when the optimistic bound of `h` (every edge with a free end counts) cannot beat the best
+//     value so far STRICTLY (bounds of 256 batches are computed in parallel, the batches then run in order, so the first
+//     optimum found has the smallest mask);
+//   * a thread whose own bound `ub` (weight of the compatible edges) beats the bar runs Kahn on its precedence rows (LDS, one
+//     column per thread): acyclic => every compatible edge is satisfied, value = ub; cyclic => worth less than ub, the mask
+//     goes onto the candidate list;
+//   * candidates whose ub still beats the best acyclic value get the exact value from a wave: strongly connected components
+//     of the arc graph (reachability closure by lane shuffles), arcs between different components are all satisfiable, every
+//     non-trivial component goes through the subset DP h[S] = best weight obtainable inside it once S is placed (LDS, one
+//     popcount layer at a time);
+//   * canonical winner = max value, then smallest mask; its sequence = the lexicographically smallest optimal one (Kahn
+//     smallest-first, or the greedy walk over the DP tables, as the host solver does).
+// Anything that does not fit (more than OM_EMAX edges, a weight >= 2^20, more than OM_CAND live candidates, a strongly
+// connected component of more than OM_SMAX nodes) sets status 1 and the host solver takes that component.
+constexpr int OM_NMAX = 19, OM_EMAX = 512, OM_CAND = 2048, OM_SMAX = 12, OM_DPW = (1 << OM_SMAX) + 64;
+struct OrdMidLds {
+    uint32_t edge[OM_EMAX];            // u | v << 5 | hu << 10 | hv << 11 | w << 12
+    uint32_t rows[OM_NMAX][256];       // rows[y][t]: nodes that must precede y under thread t's mask
+    uint32_t cand_mask[OM_CAND];
+    int cand_ub[OM_CAND];
+    int bnd[256];
+    unsigned long long best_key;       // (value + 1) << 20 | (0xFFFFF - mask); 0 = nothing yet
+    int ncand, status;
+    int arc[4][OM_NMAX * OM_NMAX];     // per wave: arc weights of one orientation
+    int dp[4][OM_DPW];                 // per wave: h[] of one strongly connected component (the final walk uses all four areas)
+};
+__device__ __forceinline__ bool om_arc(uint32_t e, uint32_t mask, int& from, int& to, int& w) {
+    const int u = e & 31, v = (e >> 5) & 31;
+    const bool hu = (e >> 10) & 1, hv = (e >> 11) & 1;
+    w = (int)(e >> 12);
+    const bool yu = !((mask >> u) & 1), yv = !((mask >> v) & 1);
+    bool compat, ufirst;
+    if (hu != hv) { compat = yu == yv; ufirst = hv ? yu : !yu; }
+    else { compat = yu != yv; ufirst = hu ? yv : yu; }
+    from = ufirst ? u : v; to = ufirst ? v : u;
+    return compat;
+}
+// exact value of one (cyclic) orientation by one wave; -1 when a strongly connected component exceeds OM_SMAX.
+// With `walk` (wave 0 only, at the end) the DP tables of all components are kept (dp areas of all four waves) and lane 0
+// builds the canonical sequence into order[].
+__device__ int om_scc_value(OrdMidLds& L, int n, int m, uint32_t mask, int wave, bool walk, int* order) {
+    const int lane = threadIdx.x & 63;
+    int* a = L.arc[wave];
+    for (int i = lane; i < n * n; i += 64) a[i] = 0;
+    wave_sync();
+    for (int e = lane; e < m; e += 64) {
+        int from, to, w;
+        if (om_arc(L.edge[e], mask, from, to, w)) atomicAdd(&a[from * n + to], w);
+    }
+    wave_sync();
+    // reachability closure: lane x holds the set reachable from x
+    uint32_t r = 0;
+    if (lane < n) { r = 1u << lane; for (int y = 0; y < n; ++y) if (a[lane * n + y] > 0) r |= 1u << y; }
+    for (int k = 0; k < n; ++k) { const uint32_t rk = (uint32_t)__shfl((int)r, k, 64); if ((r >> k) & 1) r |= rk; }
+    uint32_t mutual = 0;
+    for (int y = 0; y < n; ++y) { const uint32_t ry = (uint32_t)__shfl((int)r, y, 64); if (lane < n && ((ry >> lane) & 1) && ((r >> y) & 1)) mutual |= 1u << y; }
+    const int rep = lane < n ? __ffs((int)mutual) - 1 : -1;
+    // arcs between different components: all satisfiable
+    int val = 0;
+    for (int y = 0; y < n; ++y) { const int ry = __shfl(rep, y, 64); if (lane < n && ry != rep) val += a[lane * n + y]; }
+    for (int d = 32; d >= 1; d >>= 1) val += __shfl_xor(val, d, 64);
+    int* const dp0 = walk ? L.dp[0] : L.dp[wave];
+    const int dpcap = walk ? 4 * OM_DPW : OM_DPW;
+    int dpoff = 0;
+    for (int x = 0; x < n; ++x) {  // components in order of their smallest member (uniform loop)
+        const uint32_t mem = (uint32_t)__shfl((int)mutual, x, 64);
+        const int rx = __shfl(rep, x, 64);
+        if (rx != x || __popc(mem) < 2) continue;
+        const int sz = __popc(mem), full = (1 << sz) - 1;
+        if (sz > OM_SMAX || dpoff + full + 1 > dpcap) return -1;
+        int* h = dp0 + dpoff;
+        // member list: i-th set bit of mem
+        auto member = [&](int i) { uint32_t t = mem; for (int q = 0; q < i; ++q) t &= t - 1; return __ffs((int)t) - 1; };
+        if (lane == 0) h[full] = 0;
+        wave_sync();
+        for (int k = sz - 1; k >= 0; --k) {
+            for (int S = lane; S <= full; S += 64) {
+                if (__popc(S) != k) continue;
+                int best = -1;
+                for (int vi = 0; vi < sz; ++vi) {
+                    if ((S >> vi) & 1) continue;
+                    const int v = member(vi);
+                    int g = 0;
+                    for (int ui = 0; ui < sz; ++ui) if ((S >> ui) & 1) g += a[member(ui) * n + v];
+                    const int t = g + h[S | (1 << vi)];
+                    best = t > best ? t : best;
+                }
+                h[S] = best;
+            }
+            wave_sync();
+        }
+        val += h[0];
+        if (walk) dpoff += full + 1;
+    }
+    if (walk) {  // (component sets and representatives through LDS: the walk below is lane 0's alone)
+        if (lane < n) { L.bnd[lane] = (int)mutual; L.bnd[32 + lane] = rep; }
+        wave_sync();
+    }
+    if (walk && lane == 0) {
+        // lexicographically smallest optimal sequence: the smallest node whose predecessors from other components are placed
+        // and whose own component can still reach its optimum (sq_order.cpp HostSolver::leaf)
+        uint32_t done = 0;
+        const uint32_t* mut = (const uint32_t*)L.bnd;
+        const int* reps = L.bnd + 32;
+        for (int p = 0; p < n; ++p)
+            for (int v = 0; v < n; ++v) {
+                if ((done >> v) & 1) continue;
+                bool ok = true;
+                for (int x = 0; x < n && ok; ++x) if (a[x * n + v] > 0 && reps[x] != reps[v] && !((done >> x) & 1)) ok = false;
+                if (!ok) continue;
+                const uint32_t mem = mut[v];
+                if (__popc(mem) > 1) {
+                    // offset of this component's table: components are stored in order of their smallest member
+                    int off = 0;
+                    for (int x = 0; x < reps[v]; ++x) if (reps[x] == x && __popc(mut[x]) > 1) off += 1 << __popc(mut[x]);
+                    const int* h = dp0 + off;
+                    // placed subset and local index of v inside the component
+                    int S = 0, lv = 0, idx = 0;
+                    for (uint32_t t = mem; t; t &= t - 1, ++idx) { const int y = __ffs((int)t) - 1; if ((done >> y) & 1) S |= 1 << idx; if (y == v) lv = idx; }
+                    int g = 0; idx = 0;
+                    for (uint32_t t = mem; t; t &= t - 1, ++idx) { const int y = __ffs((int)t) - 1; if ((S >> idx) & 1) g += a[y * n + v]; }
+                    if (g + h[S | (1 << lv)] != h[S]) continue;
+                }
+                order[p] = v;
+                done |= 1u << v;
+                break;
+            }
+    }
+    return val;
+}
+__global__ __launch_bounds__(256) void k_order_mid(const SmallProblem* probs, const int32_t* edges5, int32_t* out_mask, int32_t* out_order, int32_t* out_value, int32_t* out_status) {
+    extern __shared__ unsigned long long om_raw[];
+    OrdMidLds& L = *(OrdMidLds*)om_raw;
+    const SmallProblem pr = probs[blockIdx.x];
+    const int n = pr.n, m = pr.ecount, tid = threadIdx.x, wave = tid >> 6;
+    if (tid == 0) { L.best_key = 0; L.ncand = 0; L.status = (n < 2 || n > OM_NMAX || m > OM_EMAX) ? 1 : 0; }
+    __syncthreads();
+    if (L.status == 0)
+        for (int e = tid; e < m; e += 256) {
+            const int32_t* q = edges5 + 5 * (size_t)(pr.eoff + e);
+            if (q[4] >= (1 << 20) || q[4] < 0) L.status = 1;
+            L.edge[e] = (uint32_t)q[0] | ((uint32_t)q[1] << 5) | ((uint32_t)(q[2] != 0) << 10) | ((uint32_t)(q[3] != 0) << 11) | ((uint32_t)q[4] << 12);
+        }
+    __syncthreads();
+    if (L.status) { if (tid == 0) { out_status[blockIdx.x] = 1; out_mask[blockIdx.x] = 0; out_value[blockIdx.x] = -1; } return; }
+    const int lowb = n - 1 < 8 ? n - 1 : 8, nlow = 1 << lowb, H = 1 << (n - 1 - lowb);
+    for (int hbase = 0; hbase < H; hbase += 256) {
+        {   // bound of batch h: nodes >= lowb fixed by h, nodes < lowb free (u < v, so a free v means a free u)
+            const int h = hbase + tid;
+            int b = -1;
+            if (h < H) {
+                const uint32_t hm = (uint32_t)h << lowb;
+                b = 0;
+                for (int e = 0; e < m; ++e) {
+                    const uint32_t ed = L.edge[e];
+                    int from, to, w;
+                    if ((int)(ed & 31) < lowb || om_arc(ed, hm, from, to, w)) b += (int)(ed >> 12);
+                }
+            }
+            L.bnd[tid] = b;
+        }
+        __syncthreads();
+        const int nb = H - hbase < 256 ? H - hbase : 256;
+        for (int j = 0; j < nb; ++j) {
+            const int bar = (int)(L.best_key >> 20) - 1;  // best value so far (-1: none)
+            __syncthreads();                               // (every thread has read the same bar before anybody raises it)
+            if (L.bnd[j] <= bar) continue;
+            if (tid < nlow) {
+                const uint32_t mask = ((uint32_t)(hbase + j) << lowb) | (uint32_t)tid;
+                int ub = 0;
+                for (int e = 0; e < m; ++e) { int from, to, w; if (om_arc(L.edge[e], mask, from, to, w)) ub += w; }
+                if (ub > bar) {
+                    for (int y = 0; y < n; ++y) L.rows[y][tid] = 0;
+                    for (int e = 0; e < m; ++e) { int from, to, w; if (om_arc(L.edge[e], mask, from, to, w)) L.rows[to][tid] |= 1u << from; }
+                    uint32_t remaining = (1u << n) - 1;
+                    bool acyclic = true;
+                    for (int p = 0; p < n && acyclic; ++p) {
+                        int v = -1;
+                        for (uint32_t t = remaining; t; t &= t - 1) { const int cnd = __ffs((int)t) - 1; if (!(L.rows[cnd][tid] & remaining)) { v = cnd; break; } }
+                        if (v < 0) acyclic = false; else remaining &= ~(1u << v);
+                    }
+                    if (acyclic) atomicMax(&L.best_key, ((unsigned long long)(ub + 1) << 20) | (unsigned long long)(0xFFFFFu - mask));
+                    else {
+                        const int at = atomicAdd(&L.ncand, 1);
+                        if (at < OM_CAND) { L.cand_mask[at] = mask; L.cand_ub[at] = ub; }
+                    }
+                }
+            }
+            __syncthreads();
+            // drop the candidates the new bar has overtaken (keeps the list short: thread 0, in place)
+            const bool trim = L.ncand > OM_CAND / 2;
+            __syncthreads();
+            if (trim) {
+                if (tid == 0) {
+                    const int bar2 = (int)(L.best_key >> 20) - 1;
+                    const int nc = L.ncand < OM_CAND ? L.ncand : OM_CAND;
+                    if (L.ncand > OM_CAND) L.status = 1;
+                    int k = 0;
+                    for (int i = 0; i < nc; ++i) if (L.cand_ub[i] > bar2) { L.cand_mask[k] = L.cand_mask[i]; L.cand_ub[k] = L.cand_ub[i]; ++k; }
+                    L.ncand = k;
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && L.ncand > OM_CAND) L.status = 1;
+    __syncthreads();
+    if (!L.status) {
+        // exact values of the cyclic candidates, one per wave at a time; the bar only rises
+        const int nc = L.ncand;
+        for (int i = wave; i < nc; i += 4) {
+            const int bar = (int)(L.best_key >> 20) - 1;
+            if (L.cand_ub[i] <= bar) continue;  // (uniform per wave)
+            const int v = om_scc_value(L, n, m, L.cand_mask[i], wave, false, nullptr);
+            if (v < 0) { if ((tid & 63) == 0) L.status = 1; }
+            else if ((tid & 63) == 0) atomicMax(&L.best_key, ((unsigned long long)(v + 1) << 20) | (unsigned long long)(0xFFFFFu - L.cand_mask[i]));
+        }
+    }
+    __syncthreads();
+    if (L.status) { if (tid == 0) { out_status[blockIdx.x] = 1; out_mask[blockIdx.x] = 0; out_value[blockIdx.x] = -1; } return; }
+    if (wave != 0) return;
+    // the winner's sequence (wave 0)
+    const unsigned long long key = L.best_key;
+    const uint32_t mask = 0xFFFFFu - (uint32_t)(key & 0xFFFFFu);
+    const int value = (int)(key >> 20) - 1;
+    __shared__ int s_order[OM_NMAX];
+    __shared__ int s_acyclic;
+    if (tid == 0) {
+        for (int y = 0; y < n; ++y) L.rows[y][0] = 0;
+        for (int e = 0; e < m; ++e) { int from, to, w; if (om_arc(L.edge[e], mask, from, to, w)) L.rows[to][0] |= 1u << from; }
+        uint32_t remaining = (1u << n) - 1;
+        bool acyclic = true;
+        for (int p = 0; p < n && acyclic; ++p) {
+            int v = -1;
+            for (uint32_t t = remaining; t; t &= t - 1) { const int cnd = __ffs((int)t) - 1; if (!(L.rows[cnd][0] & remaining)) { v = cnd; break; } }
+            if (v < 0) acyclic = false; else { remaining &= ~(1u << v); s_order[p] = v; }
+        }
+        s_acyclic = acyclic ? 1 : 0;
+    }
+    wave_sync();
+    int status = 0;
+    if (!s_acyclic) {
+        const int v = om_scc_value(L, n, m, mask, 0, true, s_order);
+        if (v != value) status = 1;  // (tables of all components did not fit side by side: the host solver takes it)
+    }
+    wave_sync();
+    if (tid == 0) {
+        out_status[blockIdx.x] = status; out_mask[blockIdx.x] = (int32_t)mask; out_value[blockIdx.x] = value;
+        for (int p = 0; p < n; ++p) out_order[(size_t)blockIdx.x * OM_NMAX + p] = s_order[p];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ K-1: BGZF inflate
 // One wave per BGZF block (raw DEFLATE, <= 64 KiB out).  Every lane runs the same bit-serial decode on the same data
 // (uniform control flow, broadcast loads; the Huffman tables of the wave live in LDS): lane 0 stores the literals, all
@@ -2354,7 +2612,7 @@ void dev_destroy(sq_ctx* c) {
     D.h_key.release(); D.h_val.release(); D.flags.release(); D.bam_chunk.release(); D.bam_off.release(); D.chim_hash.release(); D.chim_off.release(); D.chim_len.release(); D.chim_blob.release(); D.parse_nblk.release(); D.parse_rel.release();
     D.calib.release(); D.okey.release(); D.oval.release(); D.other64.release(); D.spine64.release(); D.okey64.release(); D.zflag.release();
     D.cl_chr.release(); D.trig.release();
-    D.ord_e.release(); D.ord_o.release(); D.ord_v.release();
+    D.ord_e.release(); D.ord_o.release(); D.ord_v.release(); D.ord_me.release(); D.ord_mo.release();
     D.pin.release(); for (auto& st : D.il_set) { st.in.release(); st.tab.release(); st.tok.release(); st.ntok.release(); st.flags.release(); if (st.ready) (void)hipEventDestroy(st.ready); if (st.freed) (void)hipEventDestroy(st.freed); if (st.copied) (void)hipEventDestroy(st.copied); st.ready = st.freed = st.copied = nullptr; }
     if (D.il_tok_stream) { (void)hipStreamDestroy(D.il_tok_stream); D.il_tok_stream = nullptr; }
     for (auto& q : D.il_stream) if (q) { (void)hipStreamDestroy(q); q = nullptr; }
@@ -3159,6 +3417,34 @@ int dev_order_small(sq_ctx* c, const std::vector<SmallProblem>& probs, const std
     HIPCHK(hipStreamSynchronize(s));
     out_mask.assign(hout, hout + np);
     out_order.assign(hout + np, hout + out_words);
+    return SQ_OK;
+}
+
+// K9b: components of 9..19 nodes; status[i] != 0 => the kernel's capacities were exceeded, the caller solves problem i on the host
+int dev_order_mid(sq_ctx* c, const std::vector<SmallProblem>& probs, const std::vector<int32_t>& edges5, std::vector<int32_t>& out_mask, std::vector<int32_t>& out_order,
+                  std::vector<int32_t>& out_value, std::vector<int32_t>& out_status) {
+    hipStream_t s = c->stream;
+    const int np = (int)probs.size();
+    out_mask.assign(np, 0); out_value.assign(np, -1); out_status.assign(np, 1);
+    out_order.assign((size_t)np * OM_NMAX, 0);
+    if (!np) return SQ_OK;
+    DeviceRecords& D = *c->dev;
+    const size_t in_words = 3 * (size_t)np + edges5.size(), out_words = (size_t)np * (3 + OM_NMAX);
+    DBuf<int32_t>&din = D.ord_me, &dout = D.ord_mo;
+    HIPCHK(din.reserve(in_words + 1)); HIPCHK(dout.reserve(out_words));
+    std::vector<int32_t> hin(in_words), hout(out_words);
+    std::memcpy(hin.data(), probs.data(), (size_t)np * 12);
+    if (edges5.size()) std::memcpy(hin.data() + 3 * (size_t)np, edges5.data(), edges5.size() * 4);
+    HIPCHK(hipMemcpyAsync(din.p, hin.data(), in_words * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipFuncSetAttribute((const void*)k_order_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(OrdMidLds)));
+    { EvTimer t(c, "k_order_mid", 0);
+      hipLaunchKernelGGL(k_order_mid, dim3(np), dim3(256), sizeof(OrdMidLds), s, (const SmallProblem*)din.p, din.p + 3 * (size_t)np, dout.p, dout.p + 3 * (size_t)np, dout.p + np, dout.p + 2 * (size_t)np); }
+    HIPCHK(hipMemcpyAsync(hout.data(), dout.p, out_words * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    out_mask.assign(hout.begin(), hout.begin() + np);
+    out_value.assign(hout.begin() + np, hout.begin() + 2 * (size_t)np);
+    out_status.assign(hout.begin() + 2 * (size_t)np, hout.begin() + 3 * (size_t)np);
+    out_order.assign(hout.begin() + 3 * (size_t)np, hout.end());
     return SQ_OK;
 }
 

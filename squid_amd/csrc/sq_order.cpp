@@ -54,18 +54,26 @@ void make_piece(const std::vector<int>& ids, const std::vector<Edge>& E, Piece& 
         if (!joined[k]) p.edges.push_back(LEdge{k, k + 1, false, true, 1});
 }
 
-// ---- exact host solver for 9..exact_max nodes
+// ---- exact host solver: components the GPU kernels do not take (more than 19 nodes, or their capacities exceeded), up to 128
+// nodes.  Orientation masks are 128-bit; the search is bounded by a node budget (the reference gives GLPK 300 s, :3964, and
+// keeps the identity order when it fails, :3287-3292,3984 -- `failed` reports that case).
+typedef unsigned __int128 Mask;
+inline int mask_ctz(Mask m) { const uint64_t lo = (uint64_t)m; return lo ? __builtin_ctzll(lo) : 64 + __builtin_ctzll((uint64_t)(m >> 64)); }
+inline bool mask_bit(Mask m, int i) { return (bool)((m >> i) & 1); }
+constexpr int HOST_NMAX = 128, SCC_MAX = 22;
 struct HostSolver {
     int n;
     const std::vector<LEdge>& E;
     long best = -1;
-    unsigned bestmask = 0;
+    Mask bestmask = 0;
     std::vector<int> bestorder;
     long n_nodes = 0, n_leaves = 0, n_cyclic = 0;  // search statistics (SQUID_ORDER_PROF)
-    HostSolver(int n, const std::vector<LEdge>& E) : n(n), E(E) {}
+    long budget;
+    bool failed = false;
+    HostSolver(int n, const std::vector<LEdge>& E, long budget = 20000000L) : n(n), E(E), budget(budget) {}
 
-    static bool compat(const LEdge& e, unsigned mask, bool& ufirst) {
-        bool yu = !((mask >> e.u) & 1), yv = !((mask >> e.v) & 1);
+    static bool compat(const LEdge& e, Mask mask, bool& ufirst) {
+        bool yu = !mask_bit(mask, e.u), yv = !mask_bit(mask, e.v);
         if (e.hu != e.hv) {  // tail->head or head->tail: equal orientations
             if (yu != yv) return false;
             ufirst = e.hv ? yu : !yu;
@@ -75,12 +83,26 @@ struct HostSolver {
         }
         return true;
     }
-    long bound(unsigned mask, int k) const {  // nodes > k fixed, nodes <= k free
+    // Optimistic value with nodes > k fixed and nodes <= k free: an edge between two free nodes counts, an edge between two fixed
+    // nodes counts when it is compatible, and an edge from a free node u to a fixed node is compatible with exactly one of u's
+    // two orientations -- u gets the better of its two sums.  (Much tighter than "every edge with a free end counts" once a
+    // component has a few dozen nodes: conflicting evidence around a node is priced as soon as its neighbours are fixed.)
+    mutable std::vector<long> gain_f, gain_r;
+    long bound(Mask mask, int k) const {
         long ub = 0;
+        if (k >= 0) { gain_f.assign((size_t)k + 1, 0); gain_r.assign((size_t)k + 1, 0); }
         for (const LEdge& e : E) {
+            if (e.v <= k) { ub += e.w; continue; }   // u < v <= k: both free
+            if (e.u <= k) {                          // u free, v fixed
+                const bool yv = !mask_bit(mask, e.v);
+                const bool want_yu = (e.hu != e.hv) ? yv : !yv;  // the orientation of u under which the edge is compatible
+                (want_yu ? gain_f : gain_r)[(size_t)e.u] += e.w;
+                continue;
+            }
             bool uf;
-            if (e.u <= k || compat(e, mask, uf)) ub += e.w;
+            if (compat(e, mask, uf)) ub += e.w;
         }
+        for (int u = 0; u <= k; ++u) ub += std::max(gain_f[(size_t)u], gain_r[(size_t)u]);
         return ub;
     }
     // Linear ordering for one orientation.  Arcs between different strongly connected components of the arc
@@ -119,27 +141,27 @@ struct HostSolver {
     };
     // all compatible edges satisfied <=> the precedence arcs are acyclic: Kahn on bit masks, smallest index first
     // (= the lexicographically smallest optimal sequence), no allocation
-    bool leaf_acyclic(unsigned mask, long ub) {
-        unsigned in[32];
+    bool leaf_acyclic(Mask mask, long ub) {
+        Mask in[HOST_NMAX];
         for (int x = 0; x < n; ++x) in[x] = 0;
         for (const LEdge& e : E) {
             bool uf;
             if (!compat(e, mask, uf)) continue;
-            if (uf) in[e.v] |= 1u << e.u; else in[e.u] |= 1u << e.v;
+            if (uf) in[e.v] |= (Mask)1 << e.u; else in[e.u] |= (Mask)1 << e.v;
         }
-        unsigned remaining = n == 32 ? ~0u : (1u << n) - 1;
-        int ord[32];
+        Mask remaining = n == HOST_NMAX ? ~(Mask)0 : (((Mask)1 << n) - 1);
+        int ord[HOST_NMAX];
         for (int p = 0; p < n; ++p) {
             int v = -1;
-            for (unsigned m = remaining; m; m &= m - 1) { int cnd = __builtin_ctz(m); if (!(in[cnd] & remaining)) { v = cnd; break; } }
+            for (Mask m = remaining; m; m &= m - 1) { int cnd = mask_ctz(m); if (!(in[cnd] & remaining)) { v = cnd; break; } }
             if (v < 0) return false;
-            remaining &= ~(1u << v);
+            remaining &= ~((Mask)1 << v);
             ord[p] = v;
         }
         if (ub > best) { best = ub; bestmask = mask; bestorder.assign(ord, ord + n); }
         return true;
     }
-    void leaf(unsigned mask) {
+    void leaf(Mask mask) {
         ++n_cyclic;
         std::vector<int> a((size_t)n * n, 0);
         for (const LEdge& e : E) {
@@ -148,16 +170,27 @@ struct HostSolver {
             if (uf) a[e.u * n + e.v] += e.w; else a[e.v * n + e.u] += e.w;
         }
         // reachability closure on bitmasks -> strongly connected components
-        std::vector<unsigned> reach(n, 0);
-        for (int x = 0; x < n; ++x) { reach[x] = 1u << x; for (int y = 0; y < n; ++y) if (a[x * n + y] > 0) reach[x] |= 1u << y; }
-        for (int k = 0; k < n; ++k) for (int x = 0; x < n; ++x) if ((reach[x] >> k) & 1) reach[x] |= reach[k];
+        std::vector<Mask> reach(n, 0);
+        for (int x = 0; x < n; ++x) { reach[x] = (Mask)1 << x; for (int y = 0; y < n; ++y) if (a[x * n + y] > 0) reach[x] |= (Mask)1 << y; }
+        for (int k = 0; k < n; ++k) for (int x = 0; x < n; ++x) if (mask_bit(reach[x], k)) reach[x] |= reach[k];
         std::vector<int> comp(n, -1);
         std::vector<SccDP> sccs;
         long val = 0;
         for (int x = 0; x < n; ++x) {
             if (comp[x] >= 0) continue;
             SccDP d;
-            for (int y = x; y < n; ++y) if (((reach[x] >> y) & 1) && ((reach[y] >> x) & 1)) { comp[y] = (int)sccs.size(); d.mem.push_back(y); }
+            for (int y = x; y < n; ++y) if (mask_bit(reach[x], y) && mask_bit(reach[y], x)) { comp[y] = (int)sccs.size(); d.mem.push_back(y); }
+            if ((int)d.mem.size() > SCC_MAX) {
+                // its subset table would not fit.  One arc of the component at least is violated: the orientation is worth at most
+                // ub - (lightest arc inside), which settles it when the incumbent is at least that good; otherwise give up
+                long ub = 0;
+                int lightest = 0;
+                for (int i = 0; i < n * n; ++i) ub += a[i];
+                for (int i : d.mem) for (int j : d.mem) if (a[i * n + j] > 0 && (lightest == 0 || a[i * n + j] < lightest)) lightest = a[i * n + j];
+                if (ub - lightest <= best) return;
+                failed = true;
+                return;
+            }
             sccs.push_back(std::move(d));
         }
         for (int x = 0; x < n; ++x) for (int y = 0; y < n; ++y) if (comp[x] != comp[y]) val += a[x * n + y];
@@ -169,16 +202,17 @@ struct HostSolver {
             d.a.assign((size_t)s * s, 0);
             for (int i = 0; i < s; ++i) for (int j = 0; j < s; ++j) d.a[i * s + j] = a[d.mem[i] * n + d.mem[j]];
             d.solve();
+            n_nodes += (long)1 << s;  // (the tables count against the budget too)
             val += d.h[0];
         }
         if (!(val > best)) return;
         std::vector<int> order;
-        unsigned done = 0;
+        Mask done = 0;
         for (int p = 0; p < n; ++p)
             for (int v = 0; v < n; ++v) {
-                if ((done >> v) & 1) continue;
+                if (mask_bit(done, v)) continue;
                 bool ok = true;
-                for (int x = 0; x < n && ok; ++x) if (a[x * n + v] > 0 && comp[x] != comp[v] && !((done >> x) & 1)) ok = false;
+                for (int x = 0; x < n && ok; ++x) if (a[x * n + v] > 0 && comp[x] != comp[v] && !mask_bit(done, x)) ok = false;
                 if (!ok) continue;
                 SccDP& d = sccs[comp[v]];
                 if (d.mem.size() > 1) {
@@ -187,28 +221,30 @@ struct HostSolver {
                     d.placed |= 1u << lv;
                 }
                 order.push_back(v);
-                done |= 1u << v;
+                done |= (Mask)1 << v;
                 break;
             }
         best = val; bestmask = mask; bestorder = order;
     }
     void run() {
         // depth-first over nodes n-1..0, forward before reversed; a branch must be able to beat the incumbent strictly
-        struct Fr { unsigned mask; int k; };
+        struct Fr { Mask mask; int k; };
         std::vector<Fr> st;
-        st.push_back(Fr{0u, n - 1});
+        st.push_back(Fr{0, n - 1});
         while (!st.empty()) {
             Fr f = st.back();
             st.pop_back();
-            ++n_nodes;
+            if (++n_nodes > budget) failed = true;
+            if (failed) { best = -1; return; }
             const long ub = bound(f.mask, f.k);
             if (ub <= best) continue;
             if (f.k < 0) { ++n_leaves; if (!leaf_acyclic(f.mask, ub)) leaf(f.mask); continue; }
             // reversing every node and the whole sequence satisfies the same edges, so the optimum with the smallest mask
             // keeps the last node forward: the other half of the tree is never needed
-            if (f.k != n - 1) st.push_back(Fr{f.mask | (1u << f.k), f.k - 1});  // explored second
-            st.push_back(Fr{f.mask, f.k - 1});                                  // explored first
+            if (f.k != n - 1) st.push_back(Fr{f.mask | ((Mask)1 << f.k), f.k - 1});  // explored second
+            st.push_back(Fr{f.mask, f.k - 1});                                        // explored first
         }
+        if (failed) best = -1;
     }
 };
 
@@ -436,21 +472,25 @@ int order_components(sq_ctx* c) {
     std::vector<int> ends(ncomp);
     for (int k = 0; k < ncomp; ++k) { roots[k] = B.build(cn[k], ce[k]); ends[k] = (int)B.tree.size(); }
     c->timer.add("host_mincut_tree", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-    // ---- leaves: <= 8 nodes on the GPU in one batch, the rest on the host
-    const int GPU_NMAX = 8, EXACT_MAX = 26;
-    std::vector<SmallProblem> probs;
-    std::vector<int32_t> edges5;
-    std::vector<int> gpu_piece;
+    // ---- leaves: <= 8 nodes and 9..19 nodes on the GPU (one batch each, one component per workgroup); larger bridge-free
+    // pieces -- and the few the mid-size kernel hands back -- on host threads
+    const int GPU_NMAX = 8;
+    static const long order_budget = std::getenv("SQUID_ORDER_BUDGET") ? std::atol(std::getenv("SQUID_ORDER_BUDGET")) : 20000000L;
+    static const bool order_host_mid = std::getenv("SQUID_ORDER_HOST_MID") != nullptr;  // debugging: 9..19 nodes on the host as well
+    std::vector<SmallProblem> probs, mprobs;
+    std::vector<int32_t> edges5, medges5;
+    std::vector<int> gpu_piece, mid_piece, large;
     for (size_t pi = 0; pi < B.pieces.size(); ++pi) {
         Piece& p = B.pieces[pi];
         const int pn = (int)p.ids.size();
         if (pn == 1) continue;
-        if (pn <= GPU_NMAX) {
-            SmallProblem sp{pn, (int)(edges5.size() / 5), (int)p.edges.size()};
-            for (const LEdge& e : p.edges) { edges5.push_back(e.u); edges5.push_back(e.v); edges5.push_back(e.hu); edges5.push_back(e.hv); edges5.push_back(e.w); }
-            probs.push_back(sp);
-            gpu_piece.push_back((int)pi);
-        }
+        const bool small = pn <= GPU_NMAX, mid = !small && pn <= ORDER_MID_NMAX && !order_host_mid;
+        if (!small && !mid) { large.push_back((int)pi); continue; }
+        std::vector<int32_t>& e5 = small ? edges5 : medges5;
+        SmallProblem sp{pn, (int)(e5.size() / 5), (int)p.edges.size()};
+        for (const LEdge& e : p.edges) { e5.push_back(e.u); e5.push_back(e.v); e5.push_back(e.hu); e5.push_back(e.hv); e5.push_back(e.w); }
+        (small ? probs : mprobs).push_back(sp);
+        (small ? gpu_piece : mid_piece).push_back((int)pi);
     }
     std::vector<int32_t> gmask, gorder;
     int rc = dev_order_small(c, probs, edges5, gmask, gorder, GPU_NMAX);
@@ -464,40 +504,55 @@ int order_components(sq_ctx* c) {
             p.order[pos] = ((gmask[q] >> l) & 1) ? -(p.ids[l] + 1) : (p.ids[l] + 1);
         }
     }
-    t0 = std::chrono::steady_clock::now();
-    std::vector<int> large;
-    for (size_t pi = 0; pi < B.pieces.size(); ++pi) {
-        Piece& p = B.pieces[pi];
-        const int pn = (int)p.ids.size();
-        if (pn <= GPU_NMAX) continue;
-        p.order.resize(pn);
-        if (pn > EXACT_MAX) {
-            // what the reference keeps when glp_intopt gives up (:3287-3292,3984): identity order, all forward
-            for (int k = 0; k < pn; ++k) p.order[k] = p.ids[k] + 1;
-            continue;
+    if (!mprobs.empty()) {
+        std::vector<int32_t> mmask, morder, mvalue, mstatus;
+        rc = dev_order_mid(c, mprobs, medges5, mmask, morder, mvalue, mstatus);
+        if (rc) return rc;
+        for (size_t q = 0; q < mid_piece.size(); ++q) {
+            Piece& p = B.pieces[mid_piece[q]];
+            if (mstatus[q]) { large.push_back(mid_piece[q]); continue; }  // beyond the kernel's capacities: host solver
+            const int pn = (int)p.ids.size();
+            p.order.resize(pn);
+            for (int pos = 0; pos < pn; ++pos) {
+                int l = morder[q * ORDER_MID_NMAX + pos];
+                p.order[pos] = ((mmask[q] >> l) & 1) ? -(p.ids[l] + 1) : (p.ids[l] + 1);
+            }
         }
-        large.push_back((int)pi);
     }
+    t0 = std::chrono::steady_clock::now();
     static const bool order_prof = std::getenv("SQUID_ORDER_PROF") != nullptr;
+    std::atomic<long> unsolved{0};
     auto solve = [&](int pi) {
         Piece& p = B.pieces[pi];
         const int pn = (int)p.ids.size();
-        HostSolver hs(pn, p.edges);
-        auto ts = std::chrono::steady_clock::now();
-        hs.run();
-        if (order_prof) std::fprintf(stderr, "[order] piece n=%d m=%zu nodes=%ld leaves=%ld cyclic=%ld best=%ld  %.3f ms\n", pn, p.edges.size(), hs.n_nodes, hs.n_leaves, hs.n_cyclic, hs.best,
-                                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts).count());
-        for (int pos = 0; pos < pn; ++pos) {
-            int l = hs.bestorder[pos];
-            p.order[pos] = ((hs.bestmask >> l) & 1) ? -(p.ids[l] + 1) : (p.ids[l] + 1);
+        p.order.resize(pn);
+        bool ok = pn <= HOST_NMAX;
+        if (ok) {
+            HostSolver hs(pn, p.edges, order_budget);
+            auto ts = std::chrono::steady_clock::now();
+            hs.run();
+            if (order_prof) std::fprintf(stderr, "[order] piece n=%d m=%zu nodes=%ld leaves=%ld cyclic=%ld best=%ld%s  %.3f ms\n", pn, p.edges.size(), hs.n_nodes, hs.n_leaves, hs.n_cyclic, hs.best,
+                                         hs.failed ? " GAVE UP" : "", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts).count());
+            ok = !hs.failed && hs.best >= 0;
+            if (ok)
+                for (int pos = 0; pos < pn; ++pos) {
+                    int l = hs.bestorder[pos];
+                    p.order[pos] = mask_bit(hs.bestmask, l) ? -(p.ids[l] + 1) : (p.ids[l] + 1);
+                }
+        }
+        if (!ok) {
+            // what the reference keeps when glp_intopt gives up (:3287-3292,3984): identity order, all forward -- never silently
+            for (int k = 0; k < pn; ++k) p.order[k] = p.ids[k] + 1;
+            ++unsolved;
         }
     };
     // the pieces are independent: solve them on a few host threads (biggest first)
     std::sort(large.begin(), large.end(), [&](int x, int y) { return B.pieces[x].ids.size() > B.pieces[y].ids.size(); });
-    // (a handful of pieces is done before the threads would have started)
     // (a handful of pieces is done before a helper would have picked one up)
     if (large.size() <= 4) for (int pi : large) solve(pi);
     else c->pool->parallel_for((int)large.size(), 15, [&](int i) { solve(large[(size_t)i]); });
+    c->counts.n_order_unsolved = unsolved.load();
+    if (unsolved.load()) std::fprintf(stderr, "libsquid_hip: %ld component(s) beyond the exact ordering solver (more than %d nodes without a bridge, or search budget exhausted): identity order kept, as the reference does when GLPK gives up\n", unsolved.load(), HOST_NMAX);
     c->timer.add("host_order_large", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     std::vector<int> sign_scratch((size_t)n, 1);
     c->ord_off.assign(1, 0);
@@ -511,29 +566,43 @@ int order_components(sq_ctx* c) {
     return SQ_OK;
 }
 
-// tests: one ordering problem (local nodes 0..n-1, edges as u,v,hu,hv,w with u < v) through the GPU kernel or the host solver
+// tests: one ordering problem (local nodes 0..n-1, edges as u,v,hu,hv,w with u < v) through the GPU kernels (use_gpu: n <= 8
+// k_order_small, 9..19 k_order_mid) or the host solver (n <= 128).  order[p] = local node at position p, bit-complemented when
+// the node is reversed; mask = the orientation mask when n <= 31, else -1.
 int order_problem_debug(sq_ctx* c, int n, const std::vector<int32_t>& edges5, bool use_gpu, int32_t& mask, std::vector<int32_t>& order, int64_t& value) {
-    if (n < 2 || n > 26 || edges5.size() % 5) return fail(c, SQ_E_ARG, "bad ordering problem");
+    if (n < 2 || n > HOST_NMAX || edges5.size() % 5) return fail(c, SQ_E_ARG, "bad ordering problem");
     for (size_t i = 0; i < edges5.size(); i += 5)
         if (edges5[i] < 0 || edges5[i] >= edges5[i + 1] || edges5[i + 1] >= n || edges5[i + 4] <= 0) return fail(c, SQ_E_ARG, "bad ordering problem edge");
     order.assign(n, 0);
+    Mask bm = 0;
     if (use_gpu) {
-        if (n > 8) return fail(c, SQ_E_ARG, "the GPU kernel takes at most 8 nodes");
+        if (n > ORDER_MID_NMAX) return fail(c, SQ_E_ARG, "the GPU kernels take at most 19 nodes");
         std::vector<SmallProblem> probs(1, SmallProblem{n, 0, (int)(edges5.size() / 5)});
-        std::vector<int32_t> gm, go;
-        int rc = dev_order_small(c, probs, edges5, gm, go, 8);
-        if (rc) return rc;
-        mask = gm[0];
+        std::vector<int32_t> gm, go, gv, gs;
+        if (n <= 8) {
+            int rc = dev_order_small(c, probs, edges5, gm, go, 8);
+            if (rc) return rc;
+            value = -1;  // (the kernel's value stays on the device; the caller evaluates the result)
+        } else {
+            int rc = dev_order_mid(c, probs, edges5, gm, go, gv, gs);
+            if (rc) return rc;
+            if (gs[0]) return fail(c, SQ_E_CAPACITY, "k_order_mid handed the problem back (capacity)");
+            value = gv[0];
+        }
+        bm = (Mask)(uint32_t)gm[0];
         for (int p = 0; p < n; ++p) order[p] = go[p];
-        value = -1;  // (the kernel's value stays on the device; the caller evaluates the result)
-        return SQ_OK;
+    } else {
+        std::vector<LEdge> E;
+        for (size_t i = 0; i < edges5.size(); i += 5) E.push_back(LEdge{edges5[i], edges5[i + 1], edges5[i + 2] != 0, edges5[i + 3] != 0, edges5[i + 4]});
+        static const long order_budget = std::getenv("SQUID_ORDER_BUDGET") ? std::atol(std::getenv("SQUID_ORDER_BUDGET")) : 20000000L;
+        HostSolver hs(n, E, order_budget);
+        hs.run();
+        if (hs.failed || hs.best < 0) return fail(c, SQ_E_CAPACITY, "ordering problem beyond the exact solver's budget");
+        bm = hs.bestmask; value = hs.best;
+        for (int p = 0; p < n; ++p) order[p] = hs.bestorder[p];
     }
-    std::vector<LEdge> E;
-    for (size_t i = 0; i < edges5.size(); i += 5) E.push_back(LEdge{edges5[i], edges5[i + 1], edges5[i + 2] != 0, edges5[i + 3] != 0, edges5[i + 4]});
-    HostSolver hs(n, E);
-    hs.run();
-    mask = (int32_t)hs.bestmask; value = hs.best;
-    for (int p = 0; p < n; ++p) order[p] = hs.bestorder[p];
+    mask = n <= 31 ? (int32_t)(uint32_t)bm : -1;
+    for (int p = 0; p < n; ++p) if (mask_bit(bm, order[p])) order[p] = ~order[p];
     return SQ_OK;
 }
 

@@ -493,6 +493,53 @@ def test_ordering_solvers_on_random_conflicting_problems(built):
             if n <= 6:
                 bv, bm, bo = _order_brute(n, edges)
                 assert (hv, hm, ho) == (bv, bm, bo), f"trial {trial}: {edges}"
+            assert ou.solve_order(built, "brute", n, edges) == (hv, hm, ho), f"trial {trial}: {edges}"   # the oracle's enumeration (C++), n <= 8
+
+
+def test_mid_size_ordering_kernel_against_host_solver_and_oracle(built):
+    """k_order_mid (9..19 nodes, one component per workgroup) == the library's host solver == the oracle's branch and bound,
+    on component-like problems and on dense conflicting ones (many cyclic orientations: the candidate list and the
+    per-component subset DP in LDS)"""
+    import random
+
+    rng = random.Random(12)
+    with squid_amd.Context() as ctx:
+        for trial in range(48):
+            n = 9 + trial % 11
+            if trial % 3 == 2:  # dense and conflicting
+                pairs = [(u, v) for u in range(n) for v in range(u + 1, n)]
+                rng.shuffle(pairs)
+                edges = [(u, v, rng.randrange(2), rng.randrange(2), rng.randrange(1, 9)) for u, v in pairs[: rng.randrange(n, 2 * n)]]
+            else:
+                edges = ou.random_order_problem(rng, n, conflict=0.5 if trial % 3 else 0.1)
+            want = ou.solve_order(built, "bnb", n, edges)
+            hm, ho, hv = ctx.order_problem(n, edges, use_gpu=False)
+            assert (hv, hm, ho) == want, f"host solver, trial {trial}: n={n} {edges}"
+            try:
+                gm, go, gv = ctx.order_problem(n, edges, use_gpu=True)
+            except squid_amd.SquidError as e:  # the kernel may hand a problem back (capacity); the pipeline then solves it on the host
+                assert "capacity" in str(e)
+                continue
+            assert (gv, gm, go) == want, f"k_order_mid, trial {trial}: n={n} {edges}"
+
+
+def test_host_solver_on_components_above_26_nodes_against_oracle(built):
+    """bridge-free components of 27..128 nodes (MincutRecursion solves them whole, SegmentGraph.cpp:3326-3349): the library's
+    128-bit branch and bound == the oracle's wide solver"""
+    import random
+
+    rng = random.Random(13)
+    compared = 0
+    with squid_amd.Context() as ctx:
+        for n in (27, 31, 32, 33, 48, 64, 65, 100, 128, 40, 80, 120):
+            edges = ou.random_order_problem(rng, n, conflict=0.25, extra=5)
+            want = ou.solve_order(built, "wide", n, edges)
+            if want is None:  # beyond the oracle's budget: nothing to compare with (the library may or may not get there)
+                continue
+            hm, ho, hv = ctx.order_problem(n, edges, use_gpu=False)
+            assert (hv, hm, ho) == want, f"n={n} {edges}"
+            compared += 1
+    assert compared >= 7
 
 
 def test_replay_concurrent_across_chromosomes_equals_the_serial_replay(built, synth, monkeypatch):
