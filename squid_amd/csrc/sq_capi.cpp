@@ -435,14 +435,17 @@ static int build_graph(sq_ctx* c) {
         reduce_edges(g.raw, c->edges);
     }
     c->snap[2].take(c->nodes, c->edges, nullptr);
+    // K6 / K7 run on the device (sq_graph_kernels.inc); SQUID_HOST_FILTERS=1 takes the host restatements of sq_graph.cpp instead
+    // (kept as a cross-check: tests compare the two stage by stage)
+    static const bool host_filters = std::getenv("SQUID_HOST_FILTERS") != nullptr;
     {
-        HostClock hc(c, "host_filters");
-        filter_by_weight(c);
+        HostClock hc(c, host_filters ? "host_filters" : "wall_filters");
+        if (host_filters) filter_by_weight(c); else if ((rc = dev_filter_by_weight(c))) return rc;
         c->snap[3].take(c->nodes, c->edges, nullptr);
         std::vector<uint8_t> keep;
-        filter_by_interleaving(c, keep);
+        if (host_filters) filter_by_interleaving(c, keep); else if ((rc = dev_filter_by_interleaving(c, keep))) return rc;
         std::vector<Edge> before = c->edges;
-        filter_edges(c, keep);
+        if (host_filters) filter_edges(c, keep); else if ((rc = dev_filter_edges(c, keep))) return rc;
         if (c->depth_ambiguous) {
             // some coverage-ratio decision depends on the tie order: repeat the reference's sort and sweep, then redo the
             // filter with the exact depths
@@ -454,16 +457,17 @@ static int build_graph(sq_ctx* c) {
             set_depths(ocnt, osum, false);
             c->depth_ambiguous = false;
             c->edges = before;
-            filter_edges(c, keep);
+            if (host_filters) filter_edges(c, keep); else if ((rc = dev_filter_edges(c, keep))) return rc;
         }
         c->snap[4].take(c->nodes, c->edges, nullptr);
     }
     {
-        HostClock hc(c, "host_compress");
-        rc = compress_nodes(c);
+        HostClock hc(c, host_filters ? "host_compress" : "wall_compress");
+        rc = host_filters ? compress_nodes(c) : dev_compress_nodes(c);
         if (rc) return rc;
         c->snap[5].take(c->nodes, c->edges, nullptr);
-        rc = further_compress(c);
+        rc = host_filters ? further_compress(c) : dev_further_compress(c);
+        if (rc == 2) rc = further_compress(c);  // a node with more discordant edges than the kernel's lists hold
         if (rc) return rc;
     }
     rc = dev_connected_components(c, (int)c->nodes.size(), c->edges, c->label);

@@ -311,6 +311,12 @@ int dev_upload_nodes(sq_ctx* c, const std::vector<Node>& nodes);  // node table 
 int dev_node_depth(sq_ctx* c, const std::vector<Node>& nodes, int64_t n_break, std::vector<int32_t>& support, std::vector<int64_t>& sumlen,
                    bool& need_exact_other, std::vector<int32_t>& amb_plus, std::vector<int32_t>& amb_minus, std::vector<int32_t>& unused);
 int dev_concordant_edges(sq_ctx* c, const std::vector<Node>& nodes, std::vector<Edge>& unique_edges);
+// K6 / K7 on the device (sq_graph_kernels.inc); the host versions in sq_graph.cpp stay as cross-checks (SQUID_HOST_FILTERS=1)
+int dev_filter_by_weight(sq_ctx* c);
+int dev_filter_by_interleaving(sq_ctx* c, std::vector<uint8_t>& keep);
+int dev_filter_edges(sq_ctx* c, const std::vector<uint8_t>& keep);
+int dev_compress_nodes(sq_ctx* c);
+int dev_further_compress(sq_ctx* c);  // 2: capacity exceeded, take the host version
 int dev_connected_components(sq_ctx* c, int n_nodes, const std::vector<Edge>& edges, std::vector<int32_t>& label);
 struct SmallProblem { int n; int eoff, ecount; };  // edges: local u,v,hu,hv,w packed as 5 ints each
 int dev_order_small(sq_ctx* c, const std::vector<SmallProblem>& probs, const std::vector<int32_t>& edges5, std::vector<int32_t>& out_mask,

@@ -143,6 +143,9 @@ struct DeviceRecords {
     uint32_t h_slots = 1u << 16;
     DBuf<int32_t> ord_e, ord_o, ord_v;  // ordering kernel: packed input, packed output, values
     DBuf<int32_t> ord_me, ord_mo;       // k_order_mid: packed input, packed output
+    DBuf<int32_t> g_i, g_x;             // K6 / K7 (sq_graph_kernels.inc): graph ints + scratch, CSR / neighbour scratch
+    DBuf<double> g_d;
+    DBuf<uint8_t> g_b;
     DBuf<long long> other64, spine64, okey64;
     DBuf<uint8_t> bam_chunk, bgzf_out, bgzf_carry;
     DBuf<uint8_t> staged;  // sq_stage_bam: the compressed bytes of a whole BAM file (+ padding for the input rings' read-ahead)
@@ -2612,7 +2615,7 @@ void dev_destroy(sq_ctx* c) {
     D.h_key.release(); D.h_val.release(); D.flags.release(); D.bam_chunk.release(); D.bam_off.release(); D.chim_hash.release(); D.chim_off.release(); D.chim_len.release(); D.chim_blob.release(); D.parse_nblk.release(); D.parse_rel.release();
     D.calib.release(); D.okey.release(); D.oval.release(); D.other64.release(); D.spine64.release(); D.okey64.release(); D.zflag.release();
     D.cl_chr.release(); D.trig.release();
-    D.ord_e.release(); D.ord_o.release(); D.ord_v.release(); D.ord_me.release(); D.ord_mo.release();
+    D.ord_e.release(); D.ord_o.release(); D.ord_v.release(); D.ord_me.release(); D.ord_mo.release(); D.g_i.release(); D.g_x.release(); D.g_d.release(); D.g_b.release();
     D.pin.release(); for (auto& st : D.il_set) { st.in.release(); st.tab.release(); st.tok.release(); st.ntok.release(); st.flags.release(); if (st.ready) (void)hipEventDestroy(st.ready); if (st.freed) (void)hipEventDestroy(st.freed); if (st.copied) (void)hipEventDestroy(st.copied); st.ready = st.freed = st.copied = nullptr; }
     if (D.il_tok_stream) { (void)hipStreamDestroy(D.il_tok_stream); D.il_tok_stream = nullptr; }
     for (auto& q : D.il_stream) if (q) { (void)hipStreamDestroy(q); q = nullptr; }
@@ -3554,5 +3557,7 @@ int dev_breakpoint_support_exact(sq_ctx* c, const std::vector<std::pair<int, int
     c->timer.add("host_bp_cursor_exact", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), 0);
     return SQ_OK;
 }
+
+#include "sq_graph_kernels.inc"
 
 }  // namespace sq

@@ -438,6 +438,34 @@ def test_dense_graph_config_with_a_giant_component(built, synth, tmp_path, monke
         ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
         ctx.build_graph()
         _compare(ctx, dump, sv_path, depth_exact=False)
+        # a component neither solver can order exactly keeps the identity order on both sides, and is reported (here: the
+        # 2-edge-connected core of ~1000 nodes; the reference would hand it to GLPK for up to 300 s, SegmentGraph.cpp:3326-3349,3964)
+        assert ctx.counts()["n_order_unsolved"] == int(stats["too_large"])
+        # K6 / K7 ran on the device
+        assert {"k_filter_weight", "k_filter_interleave", "k_filter_edges", "k_compress_nodes", "k_further_compress"} <= set(ctx.timing())
+
+
+def test_device_filters_equal_the_host_restatements(built, synth, tmp_path):
+    """K6 / K7 (k_filter_weight, k_filter_interleave, k_fe_*, k_cn_*, k_further_compress) against the host versions of
+    sq_graph.cpp (SQUID_HOST_FILTERS=1, read once per process: child processes), stage by stage, default and dense parameters"""
+    import json, os, sys
+
+    code = ("import sys, json; sys.path.insert(0, %r); import squid_amd\n"
+            "kw = json.loads(sys.argv[3])\n"
+            "ctx = squid_amd.Context(**kw); ctx.load(sys.argv[1], sys.argv[2]); ctx.build_graph()\n"
+            "print(json.dumps([[ctx.graph(k) for k in (3, 4, 5, 0)], ctx.order(), ctx.sv_text(), sorted(ctx.timing())]))") % str(Path(__file__).resolve().parent.parent)
+    for cfg, extra, kw in (("T2", [], {}), ("C5", ["--records", "200000", "--tsv", "400"], {"min_edge_weight": 1, "max_allowed_degree": 50})):
+        pre = synth(cfg, *extra)
+        res = {}
+        for mode in ("gpu", "host"):
+            env = dict(os.environ)
+            env.pop("SQUID_HOST_FILTERS", None)
+            if mode == "host":
+                env["SQUID_HOST_FILTERS"] = "1"
+            out = subprocess.run([sys.executable, "-c", code, f"{pre}.bam", f"{pre}.chim.bam", json.dumps(kw)], env=env, capture_output=True, text=True, check=True).stdout
+            res[mode] = json.loads(out.strip().splitlines()[-1])
+        assert res["gpu"][:3] == res["host"][:3], cfg
+        assert "k_filter_weight" in res["gpu"][3] and "host_filters" in res["host"][3]
 
 
 # ---- K9 on adversarial inputs: random small problems with conflicting edges against an exhaustive search
