@@ -1,6 +1,7 @@
 # Builds every native artefact into build/ (git-ignored, but shipped to the GPU box by gpurun).
 #   build/libsquid_hip.so   product: HIP kernels + host pipeline behind the C ABI of include/squid_hip.h
 #   build/squid             product: drop-in command line
+#   build/squid_annotate    product: counterpart of utils/AnnotateSQUIDOutput.py (GTF join over _sv.txt)
 #   build/gen_synth_bam     synthetic BAM generator (inputs for tests and bench)
 #   build/squid_oracle      CPU oracle (test infrastructure; never linked into the product)
 HIPCC ?= hipcc
@@ -10,7 +11,7 @@ B := build
 CSRC := squid_amd/csrc
 LIBSRC := $(CSRC)/sq_kernels.hip $(CSRC)/sq_bam.cpp $(CSRC)/sq_chimeric.cpp $(CSRC)/sq_segment.cpp $(CSRC)/sq_graph.cpp $(CSRC)/sq_order.cpp $(CSRC)/sq_capi.cpp
 
-all: $(B)/libsquid_hip.so $(B)/squid $(B)/gen_synth_bam $(B)/squid_oracle $(B)/oracle_singlebamrec ref
+all: $(B)/libsquid_hip.so $(B)/squid $(B)/squid_annotate $(B)/gen_synth_bam $(B)/squid_oracle $(B)/oracle_singlebamrec ref
 
 # oracle/_ref: the part of the real reference that builds without third-party libraries (flag parser), only when
 # the reference tree is present (authoring container); the GPU box uses the prebuilt binary
@@ -23,6 +24,10 @@ $(B)/libsquid_hip.so: $(LIBSRC) $(CSRC)/sq_internal.h $(CSRC)/sq_graph_kernels.i
 
 $(B)/squid: $(CSRC)/squid_main.cpp $(B)/libsquid_hip.so include/squid_hip.h
 	$(HIPCC) -O2 -std=c++17 -o $@ $(CSRC)/squid_main.cpp -L$(B) -lsquid_hip -Wl,-rpath,'$$ORIGIN'
+
+$(B)/squid_annotate: $(CSRC)/squid_annotate.cpp
+	mkdir -p $(B)
+	$(CXX) -O2 -std=c++17 -Wall -o $@ $<
 
 $(B)/gen_synth_bam: squid_amd/synth/gen_synth_bam.cpp
 	mkdir -p $(B)
