@@ -152,7 +152,7 @@ struct DeviceRecords {
     DBuf<long long> rec_sync, rec_end;
     // GPU ingest, two batches in flight: compressed bytes + block table + tokens of a batch
     struct InflSet { DBuf<uint8_t> in; DBuf<InflBlock> tab; DBuf<uint32_t> tok; DBuf<int32_t> ntok, flags; hipEvent_t ready = nullptr, freed = nullptr, copied = nullptr; std::vector<InflBlock> host_tab; const uint8_t* src = nullptr; /* compressed bytes of the batch: `in`, or inside the staged file */ };
-    static constexpr int IL_DEPTH = 3;  // buffer sets: batch k is resolved / parsed, k+1 is in the token pass, k+2 is being copied
+    static constexpr int IL_DEPTH = 5;  // buffer sets: batch k is resolved / parsed, the three behind it are in the token pass, the next is being copied
     InflSet il_set[IL_DEPTH];
     hipStream_t il_stream[IL_DEPTH] = {};  // one per set: its host->device copies
     hipStream_t il_tok_stream = nullptr;   // the token passes, one after the other
@@ -1016,18 +1016,22 @@ __device__ __forceinline__ bool rec_block0(const RecView& R, int64_t r, int& c, 
     if (l.size(1) > 0) { int m; list_key(R, r, l, 1, 0, c, p, m); end = p + m; return true; }
     return false;
 }
+constexpr int B0_DEEP = 1 << 30;
 __global__ void k_block0(RecView R, NodeView N, const uint8_t* keep, const int32_t* part_prev, int32_t* part_next, int32_t* b0_a, int32_t* b0_b, int32_t* b0_home) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R.n || !(keep[r] & K_BUILD)) return;
     if (part_prev[r] >= 0) part_next[part_prev[r]] = (int32_t)r;
     int c, p, end, a = 1, b = 0, home = -1;
+    bool deep = false;
     if (rec_block0(R, r, c, p, end) && c >= 0 && c < N.n_ref) {
         home = node_home(N, c, p);
         const int hp = N.pos[home], he = hp + N.len[home];
-        if (end > hp + 5 && p < he - 5 && end <= he + 5) { a = home; b = home; }  // deep inside its node: no neighbour can fit
+        if (end > hp + 5 && p < he - 5 && end <= he + 5) { a = home; b = home; deep = true; }  // deep inside its node: no neighbour can fit
         else fit_range(N, c, p, end, a, b, home);
     }
-    b0_a[r] = a; b0_b[r] = b; b0_home[r] = home;
+    // B0_DEEP: whatever hint arrives, LocateRead puts block 0 into `home` (from a node below the walk goes up to the first
+    // fitting node, from one above it comes down to the last, and `home` is the only one) -- k_edges then needs no incoming hint
+    b0_a[r] = a; b0_b[r] = b; b0_home[r] = deep ? (home | B0_DEEP) : home;
 }
 // hint transfer of one record: x -> node of its block 0 if located, else x (SegmentGraph.cpp:1607-1609)
 __device__ __forceinline__ int hint_step(int x, int a, int b, int home) {
@@ -1084,13 +1088,16 @@ __global__ void k_edges(RecView R, NodeView N, EdgeParams P, const uint8_t* keep
                         const int32_t* b0_b, const int32_t* b0_home, unsigned long long* hk, uint32_t* hv, uint32_t hmask, int32_t* flags, int32_t* stripes) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R.n || !(keep[r] & K_BUILD)) return;
-    // ---- incoming hint: walk back to a record whose block 0 pins the hint, then replay forward
-    int hint;
-    {
+    // ---- incoming hint: walk back to a record whose block 0 pins the hint, then replay forward.  Most records never need it:
+    // when block 0 lies deep inside its node (B0_DEEP) every incoming hint leads to that node, so the chain of dependent loads
+    // (previous record -> its fitting range -> ...) is only followed by the few records that really consult the hint
+    // (block 0 near a node boundary; an unlocatable block that leaves the running index outside the table; > OWNCAP blocks).
+    auto incoming_hint = [&]() -> int {
+        int h;
         int64_t q = part_prev[r];
         int steps = 0;
         while (q >= 0 && !(b0_a[q] == b0_b[q])) { q = part_prev[q]; ++steps; }
-        if (q >= 0) hint = b0_a[q]; else { hint = 0; q = -1; }
+        if (q >= 0) h = b0_a[q]; else { h = 0; q = -1; }
         if (steps > 0) {
             // replay the un-pinned records between the anchor and r (rare)
             int64_t t = (q >= 0) ? part_next[q] : -2;
@@ -1099,9 +1106,14 @@ __global__ void k_edges(RecView R, NodeView N, EdgeParams P, const uint8_t* keep
                 while (part_prev[first] >= 0) first = part_prev[first];
                 t = first;
             }
-            while (t != r) { hint = hint_step(hint, b0_a[t], b0_b[t], b0_home[t]); t = part_next[t]; }
+            while (t != r) { h = hint_step(h, b0_a[t], b0_b[t], b0_home[t] & ~B0_DEEP); t = part_next[t]; }
         }
-    }
+        return h;
+    };
+    const int home0 = b0_home[r];
+    const bool deep0 = home0 >= 0 && (home0 & B0_DEEP);
+    bool hint_known = !deep0;
+    int hint = deep0 ? (home0 & ~B0_DEEP) : incoming_hint();
     // ---- the stub-augmented, read-offset-sorted record is streamed block by block (own blocks first for a first-mate
     // record, the 15-base mate stub first otherwise); everything LocateRead + the edge rules need is carried in
     // registers: no per-thread arrays, no scratch
@@ -1126,6 +1138,7 @@ __global__ void k_edges(RecView R, NodeView N, EdgeParams P, const uint8_t* keep
         int bc, bp, bm, brp, bmr; bool brev;
         if (is_stub) { bc = R.mrefid[r]; bp = R.mpos[r]; bm = 15; brp = 0; bmr = 15; brev = R.flag[r] & 0x20; }
         else { DBlk b = own_block_sorted(R, r, ko, nown, l.rev); bc = b.refid; bp = b.refpos; bm = b.matchref; brp = b.readpos; bmr = b.matchread; brev = b.rev; }
+        if ((i < 0 || i >= N.n) && !hint_known) { hint = incoming_hint(); hint_known = true; }  // (locate_one falls back to the incoming hint)
         const int nd = locate_one(N, bc, bp, bp + bm, i, hint);
         if (nd >= 0) {  // trim to the node (SegmentGraph.cpp:1229-1248)
             int np = N.pos[nd], ne = np + N.len[nd];
@@ -1173,6 +1186,7 @@ __global__ void k_edges(RecView R, NodeView N, EdgeParams P, const uint8_t* keep
             for (int q = 0; q < OWNCAP; ++q) if (q < nown && ownnode[q] == b) isoverlap = true;
         } else {
             // more own blocks than the register file keeps: walk the own list again (same hint chain, same nodes)
+            if (!hint_known) { hint = incoming_hint(); hint_known = true; }
             int i2 = hint;
             for (int ko = 0; ko < nown; ++ko) {
                 DBlk bb = own_block_sorted(R, r, ko, nown, l.rev);
@@ -2369,6 +2383,242 @@ __global__ __launch_bounds__(64) void k_inflate_lanes(const uint8_t* file, const
     }
 }
 
+// ---- The token pass, second form (default): canonical Huffman decoding with the code limits in REGISTERS.
+// k_inflate_lanes keeps two-level lookup tables per lane -- 2.5 KB, 160 KB per wave, ONE wave per CU -- and every step is a chain
+// of dependent LDS round trips with nobody to hide them.  A canonical code needs no table of codes: with the next 15 bits of
+// the stream read MSB-first as a number v, the codes of length L occupy [first[L] << (15 - L), (first[L] + count[L]) << (15 - L)),
+// ranges that ascend with L.  So the length of the next code is 1 + #{L : v >= limit[L]} -- fourteen compares against values
+// that live in 15 registers per code (literal/length and distance) -- and the symbol is sym[(v >> (15 - len)) + K[len]].  What
+// stays in LDS per lane: the symbol permutation as bytes (288 + 32; a literal/length symbol >= 256 is told from its rank inside
+// its length group, where the literals come first), two 16-entry tables per code, the code lengths packed to 4 bits while a
+// header is read (170), the input ring and the token stage: 746 bytes, 46.6 KB per wave, THREE waves per CU -- three times the
+// streams in flight, and a step is two LDS round trips per code instead of up to nine.
+constexpr int T2_SYM_LL = 288, T2_SYM_DD = 32, T2_CL_AT = 320, T2_LENS4 = 170;
+constexpr size_t T2_LDS_BYTES = (size_t)(T2_SYM_LL + T2_SYM_DD + T2_LENS4) * 64 + (size_t)(5 * 16) * 64 * 2 + (size_t)(IL_STAGE + IL_RING) * 64 * 4;
+struct T2Lds {
+    uint8_t *sym_ll, *sym_dd, *lens4;        // [e * 64 + lane]
+    int16_t *k_ll, *k_dd;                    // [len * 64 + lane]: symbol slot of a code = (v >> (15 - len)) + k[len]
+    uint16_t *nl_ll, *tmp_a, *tmp_b;         // nl_ll[len]: slot where the symbols >= 256 of that length begin; tmp: builders' scratch
+};
+__device__ __forceinline__ int t2_getlen(const T2Lds& L, int lane, int i) { return (L.lens4[(i >> 1) * 64 + lane] >> ((i & 1) << 2)) & 15; }
+__device__ __forceinline__ void t2_setlen(const T2Lds& L, int lane, int i, int v) {
+    uint8_t* p = L.lens4 + (i >> 1) * 64 + lane;
+    const int sh = (i & 1) << 2;
+    *p = (uint8_t)((*p & (0xf0 >> sh)) | (v << sh));
+}
+// canonical tables of one code from the lengths lens[lo .. lo + n): limits into lim[1..15], slots / symbols into LDS.
+// Called by the lanes that are at a header (me), each for its own code.  Returns false for an over-subscribed set.
+template <bool LL>
+__device__ bool t2_build(const T2Lds& L, int lane, bool me, int lo, int n, uint32_t (&lim)[16], uint8_t* symtab, int16_t* ktab) {
+    bool ok = true;
+    if (me) {
+        uint16_t *cnt = L.tmp_a + lane, *slot = L.tmp_b + lane;
+        for (int l = 0; l < 16; ++l) cnt[l * 64] = 0;
+        for (int i = 0; i < n; ++i) ++cnt[t2_getlen(L, lane, lo + i) * 64];
+        int left = 1, first = 0, off = 0;
+#pragma unroll
+        for (int l = 1; l <= 15; ++l) {
+            const int k = cnt[l * 64];
+            left = (left << 1) - k;
+            if (left < 0) ok = false;
+            lim[l] = (uint32_t)(first + k) << (15 - l);
+            ktab[l * 64 + lane] = (int16_t)(off - first);
+            slot[l * 64] = (uint16_t)off;
+            if (LL) L.nl_ll[l * 64 + lane] = (uint16_t)off;
+            off += k;
+            first = (first + k) << 1;
+        }
+        if (ok)
+            for (int i = 0; i < n; ++i) {
+                const int l = t2_getlen(L, lane, lo + i);
+                if (!l) continue;
+                const int at = slot[l * 64]++;
+                symtab[at * 64 + lane] = (uint8_t)i;
+                if (LL && i < 256) ++L.nl_ll[l * 64 + lane];
+            }
+    }
+    return ok;
+}
+// length of the next code and its symbol slot; -1 for a bit pattern no code of the set covers
+__device__ __forceinline__ int t2_slot(ILane& b, const uint32_t (&lim)[16], const int16_t* ktab, int lane, int& len) {
+    const uint32_t v = __brev((uint32_t)b.buf) >> 17;
+    int l = 1;
+#pragma unroll
+    for (int q = 1; q <= 14; ++q) l += v >= lim[q] ? 1 : 0;
+    len = l;
+    if (v >= lim[15]) return -1;
+    const int idx = (int)(v >> (15 - l)) + (int)ktab[l * 64 + lane];
+    b.buf >>= l; b.cnt -= l;
+    return idx;
+}
+__global__ __launch_bounds__(64) void k_inflate_tok2(const uint8_t* file, const InflBlock* blocks, int nblocks, unsigned long long out_base, int32_t* flags, uint32_t* tok, int32_t* ntok) {
+    extern __shared__ uint16_t il_lds[];  // T2_LDS_BYTES
+    __shared__ uint8_t sh_clo[32];
+    T2Lds L;
+    L.k_ll = (int16_t*)il_lds;                 L.k_dd = L.k_ll + 16 * 64;
+    L.nl_ll = (uint16_t*)(L.k_dd + 16 * 64);   L.tmp_a = L.nl_ll + 16 * 64;   L.tmp_b = L.tmp_a + 16 * 64;
+    uint32_t* stage = (uint32_t*)(L.tmp_b + 16 * 64);  // tokens on their way out: stage[(k % IL_STAGE) * 64 + lane]
+    uint32_t* ring = stage + IL_STAGE * 64;
+    L.sym_ll = (uint8_t*)(ring + IL_RING * 64);  L.sym_dd = L.sym_ll + T2_SYM_LL * 64;  L.lens4 = L.sym_dd + T2_SYM_DD * 64;
+    const int lane = threadIdx.x;
+    if (lane < 19) sh_clo[lane] = c_clorder[lane];
+    wave_sync();
+    const int bi = blockIdx.x * 64 + lane;
+    const bool have = bi < nblocks;
+    InflBlock blk{0, 0, 0, 0};
+    if (have) blk = blocks[bi];
+    uint32_t* tk = tok + (blk.uoff - out_base);
+    uint32_t nt = 0;
+    auto emit = [&](uint32_t v) {
+        stage[(nt % IL_STAGE) * 64 + lane] = v;
+        if ((++nt % IL_STAGE) == 0) {  // a full stage: IL_STAGE consecutive tokens in wide stores
+            uint32_t* dst = tk + nt - IL_STAGE;
+#pragma unroll
+            for (int q = 0; q < IL_STAGE; q += 4) {
+                uint4 w{stage[q * 64 + lane], stage[(q + 1) * 64 + lane], stage[(q + 2) * 64 + lane], stage[(q + 3) * 64 + lane]};
+                __builtin_memcpy(dst + q, &w, 16);
+            }
+        }
+    };
+    ILane b;
+    b.p = file + blk.coff; b.n = blk.clen; b.ring = ring + lane;
+    il_start(b, 0);
+    uint32_t lim_ll[16], lim_dd[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { lim_ll[q] = 0; lim_dd[q] = 0; }
+    uint32_t outpos = 0;
+    bool done = !have || blk.isize == 0, err = false, in_block = false, last = false, stored = false;
+    uint32_t stored_left = 0, stored_at = 0;
+    int hdr_wait = 0;
+    uint32_t token = 0;       // what the step has decoded: stored at the top of the next step, where the lanes that took the
+    bool have_token = false;  // literal path and those that took the match path are together again (one copy of the store code)
+    while (__any(!done)) {
+        if (have_token) { emit(token); have_token = false; }
+        // ---- block headers, by all the lanes that are at one
+        const unsigned long long need = __ballot(!done && !in_block && !stored);
+        if (need && (need == __ballot(!done) || ++hdr_wait >= IL_HDR_WAIT)) {
+            hdr_wait = 0;
+            const bool me = (need >> lane) & 1;
+            int kind = -1, nlen = 0, ndist = 0;  // 0 stored, 1 fixed code, 2 dynamic code, -1 corrupt
+            if (me) {
+                if (il_low(b)) il_topup(b);
+                if (il_pos(b) <= b.n + 8) {
+                    last = il_take(b, 1);
+                    const uint32_t type = il_take(b, 2);
+                    if (type == 0) {
+                        b.buf >>= (b.cnt & 7); b.cnt -= (b.cnt & 7);
+                        const uint32_t len = il_take(b, 16), nl = il_take(b, 16);
+                        stored_at = il_pos(b) - (uint32_t)(b.cnt >> 3);
+                        if ((len ^ 0xffff) == nl && stored_at + len <= b.n && outpos + len <= blk.isize) {
+                            kind = 0;
+                            stored_left = len;
+                            if (len) stored = true; else { il_start(b, stored_at); if (last) done = true; }
+                        }
+                    } else if (type == 1) {
+                        for (int i = 0; i < 144; ++i) t2_setlen(L, lane, i, 8);
+                        for (int i = 144; i < 256; ++i) t2_setlen(L, lane, i, 9);
+                        for (int i = 256; i < 280; ++i) t2_setlen(L, lane, i, 7);
+                        for (int i = 280; i < 288; ++i) t2_setlen(L, lane, i, 8);
+                        for (int i = 0; i < 30; ++i) t2_setlen(L, lane, 288 + i, 5);
+                        kind = 1; nlen = 288; ndist = 30;
+                    } else if (type == 2) {
+                        nlen = (int)il_take(b, 5) + 257; ndist = (int)il_take(b, 5) + 1;
+                        const int ncode = (int)il_take(b, 4) + 4;
+                        if (nlen <= 286 && ndist <= 30) {
+                            for (int i = 0; i < 19; ++i) t2_setlen(L, lane, T2_CL_AT + i, 0);
+                            for (int i = 0; i < ncode; ++i) t2_setlen(L, lane, T2_CL_AT + sh_clo[i], (int)il_take(b, 3));
+                            kind = 2;
+                        }
+                    }
+                }
+            }
+            if (__any(me && kind == 2)) {
+                // the code-length code (19 symbols) in the distance tables, then the literal/length + distance lengths with it
+                const bool dyn = me && kind == 2;
+                bool ok = t2_build<false>(L, lane, dyn, T2_CL_AT, 19, lim_dd, L.sym_dd, L.k_dd);
+                int idx = 0, prev = 0;
+                bool busy = dyn && ok;
+                while (__any(busy)) {
+                    if (busy) {
+                        if (il_low(b)) il_topup(b);
+                        il_refill(b);
+                        int cl;
+                        const int at = t2_slot(b, lim_dd, L.k_dd, lane, cl);
+                        const int sym = at < 0 ? -1 : (int)L.sym_dd[(at & 31) * 64 + lane];
+                        if (sym < 0 || sym > 18 || il_pos(b) > b.n + 8) { ok = false; busy = false; }
+                        else if (sym < 16) { t2_setlen(L, lane, idx++, sym); prev = sym; }
+                        else {
+                            int rep, v = 0;
+                            if (sym == 16) { v = prev; rep = 3 + (int)il_take(b, 2); if (idx == 0) ok = false; }
+                            else if (sym == 17) rep = 3 + (int)il_take(b, 3);
+                            else rep = 11 + (int)il_take(b, 7);
+                            if (!ok || idx + rep > nlen + ndist) { ok = false; busy = false; }
+                            else { while (rep--) t2_setlen(L, lane, idx++, v); prev = v; }
+                        }
+                        if (busy && idx >= nlen + ndist) busy = false;
+                    }
+                }
+                if (dyn && ok && t2_getlen(L, lane, 256) == 0) ok = false;  // no end-of-block code
+                if (dyn && !ok) kind = -1;
+            }
+            if (__any(me && kind > 0)) {
+                const bool bld = me && kind > 0;
+                const bool ok_ll = t2_build<true>(L, lane, bld, 0, nlen, lim_ll, L.sym_ll, L.k_ll);
+                const bool ok_dd = t2_build<false>(L, lane, bld, nlen, ndist, lim_dd, L.sym_dd, L.k_dd);
+                if (bld && !(ok_ll && ok_dd)) kind = -1;
+            }
+            if (me) { if (kind < 0) { err = true; done = true; } else if (kind > 0) in_block = true; }
+        }
+        if (__any(!done && il_low(b))) { if (!done) il_topup(b); }  // every lane, in the same step
+        if (done) continue;
+        if (stored) {  // a slice of a stored block
+            const uint32_t k = stored_left < 16 ? stored_left : 16;
+            for (uint32_t i = 0; i < k; ++i) emit(b.p[stored_at + i]);
+            outpos += k; stored_at += k; stored_left -= k;
+            if (!stored_left) { stored = false; il_start(b, stored_at); if (last) done = true; }
+            continue;
+        }
+        if (!in_block) continue;  // (waiting at a header)
+        // ---- one symbol
+        il_refill(b);
+        int cl;
+        const int at = t2_slot(b, lim_ll, L.k_ll, lane, cl);
+        if (at < 0 || at >= T2_SYM_LL || il_pos(b) > b.n + 8) { err = true; done = true; continue; }
+        const int sym = (int)L.sym_ll[at * 64 + lane] + (at >= (int)L.nl_ll[cl * 64 + lane] ? 256 : 0);
+        if (sym < 256) {
+            if (outpos >= blk.isize) { err = true; done = true; continue; }
+            token = (uint32_t)sym; have_token = true; ++outpos;
+            continue;
+        }
+        if (sym == 256) { in_block = false; if (last) done = true; continue; }
+        const int ls = sym - 257;
+        if (ls >= 29) { err = true; done = true; continue; }
+        // base and extra bits of the length / distance symbol by arithmetic (RFC 1951 3.2.5).  One refill covers the rest of the
+        // step: 5 + 15 + 13 bits at most.
+        il_refill(b);
+        const uint32_t lx = ls < 8 || ls == 28 ? 0u : (uint32_t)(ls - 4) >> 2;
+        const uint32_t lbase = ls < 8 ? 3u + (uint32_t)ls : (ls == 28 ? 258u : 3u + ((4u + ((uint32_t)ls & 3u)) << lx));
+        const uint32_t len = lbase + ((uint32_t)b.buf & ((1u << lx) - 1));
+        b.buf >>= lx; b.cnt -= (int)lx;
+        int dl;
+        const int dat = t2_slot(b, lim_dd, L.k_dd, lane, dl);
+        const int ds = dat < 0 ? -1 : (int)L.sym_dd[(dat & 31) * 64 + lane];
+        if (ds < 0 || ds >= 30) { err = true; done = true; continue; }
+        const uint32_t dx = ds < 4 ? 0u : (uint32_t)(ds - 2) >> 1;
+        const uint32_t dbase = ds < 4 ? 1u + (uint32_t)ds : 1u + ((2u + ((uint32_t)ds & 1u)) << dx);
+        const uint32_t dist = dbase + ((uint32_t)b.buf & ((1u << dx) - 1));
+        b.buf >>= dx; b.cnt -= (int)dx;
+        if (dist > outpos || outpos + len > blk.isize) { err = true; done = true; continue; }
+        token = 0x80000000u | (len << 16) | (dist - 1); have_token = true; outpos += len;
+    }
+    if (have_token) emit(token);
+    if (have && (err || outpos != blk.isize)) atomicOr(&flags[0], 512);
+    if (have) {
+        for (uint32_t k = nt - nt % IL_STAGE; k < nt; ++k) tk[k] = stage[(k % IL_STAGE) * 64 + lane];
+        ntok[bi] = (int32_t)nt;
+    }
+}
+
 // Inclusive prefix sum over the wave with DPP row shifts (no LDS traffic).
 __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
     x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
@@ -2794,6 +3044,8 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     HIPCHK(hipFuncSetAttribute((const void*)k_inflate_lanes<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)IL_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_inflate_lanes<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)IL_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_lz_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16));
+    HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T2_LDS_BYTES));
+    static const bool tok_v1 = std::getenv("SQUID_TOK_V1") != nullptr;  // the table-driven token pass (one wave per CU), kept for comparison
     for (auto& q : D.il_stream)
         if (!q) {
             // lowest priority: a token wave holds its CU for tens of milliseconds, and the resolve / boundary / parse kernels
@@ -2869,12 +3121,15 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         if (report && k < 3) std::fprintf(stderr, "GPU ingest: batch %zu planned at %.1f ms, buffers %.1f ms, copy of %.2f GB returned after %.1f ms\n", k, std::chrono::duration<double, std::milli>(wa0 - w0).count(), wa1, (double)B.cbytes * 1e-9, since_ms(wa0) - wa1);
         HIPCHK(hipMemcpyAsync(st.tab.p, st.host_tab.data(), (size_t)nb * sizeof(InflBlock), hipMemcpyHostToDevice, sa));
         HIPCHK(hipMemsetAsync(st.flags.p, 0, 4 * 4, sa));
-        if (variant == 0) {
+        if (variant == 0 && tok_v1) {  // (one table-driven token kernel at a time: its waves fill a CU's LDS each)
             HIPCHK(hipEventRecord(st.copied, sa));
             sa = D.il_tok_stream;
             HIPCHK(hipStreamWaitEvent(sa, st.copied, 0));
+        }
+        if (variant == 0) {  // k_inflate_tok2 stays on the set's own stream: the token kernels of up to four batches run side by side
             EvTimer t1(c, "k_inflate_tokens", (double)B.cbytes + (double)B.bbytes * 2, sa);
-            hipLaunchKernelGGL(k_inflate_lanes<true>, dim3((nb + 63) / 64), dim3(64), IL_LDS_BYTES, sa, st.src, st.tab.p, nb, B.bbase, nullptr, st.flags.p, st.tok.p, st.ntok.p);
+            if (tok_v1) hipLaunchKernelGGL(k_inflate_lanes<true>, dim3((nb + 63) / 64), dim3(64), IL_LDS_BYTES, sa, st.src, st.tab.p, nb, B.bbase, nullptr, st.flags.p, st.tok.p, st.ntok.p);
+            else hipLaunchKernelGGL(k_inflate_tok2, dim3((nb + 63) / 64), dim3(64), T2_LDS_BYTES, sa, st.src, st.tab.p, nb, B.bbase, st.flags.p, st.tok.p, st.ntok.p);
         }
         HIPCHK(hipEventRecord(st.ready, sa));
         return SQ_OK;
@@ -2887,15 +3142,16 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         helper.f = std::async(std::launch::async, [&stage_a, c, k]() { if (hipSetDevice(c->P.device) != hipSuccess) return (int)SQ_E_HIP; return stage_a(k); });
         return SQ_OK;
     };
+    const size_t look = tok_v1 ? 2 : (size_t)DeviceRecords::IL_DEPTH - 1;  // batches queued ahead of the one being resolved
     { int rc = stage_a(0); if (rc) return rc; }
-    { int rc = stage_a_async(1); if (rc) return rc; }
+    for (size_t j = 1; j < look; ++j) { int rc = stage_a_async(j); if (rc) return rc; }
     const double w_first = since_ms(w0);
     unsigned long long carry = 0;  // bytes of the incomplete record in front of the batch (kept in D.bgzf_carry)
     long check_bad = 0;
     for (size_t k = 0; k < batches.size(); ++k) {
         // the copy of batch k+2 and its token pass (queued behind that of batch k+1) go out first: the host blocks in the copy
         // while the GPU works on the batches before
-        { int rc = stage_a_async(k + 2); if (rc) { (void)give_up(); return rc; } }
+        { int rc = stage_a_async(k + look); if (rc) { (void)give_up(); return rc; } }
         const Batch B = batches[k];
         DeviceRecords::InflSet& st = D.il_set[k % DeviceRecords::IL_DEPTH];
         const int nb = (int)(B.end - B.at);
