@@ -57,7 +57,7 @@ def synth(config: str, seed: int, outdir: Path, records: int | None = None, leve
         if level is not None:
             cmd += ["--level", str(level)]
         subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
-        for ext in (".chim.bam", ".truth.txt", ".bam"):
+        for ext in (".chim.bam", ".truth.txt", ".bam.bai", ".bam"):
             os.replace(f"{tmp}{ext}", f"{pre}{ext}")
     return pre
 
@@ -81,8 +81,16 @@ def self_launch(a) -> None:
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
            str(Path(__file__).resolve())] + sys.argv[1:]
-    r = subprocess.run(cmd, env=env)
-    raise SystemExit(r.returncode)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    # rank 0 prints the result line; anything else on stdout (transport banners of the ranks) goes to stderr
+    lines = r.stdout.splitlines()
+    result = [l for l in lines if l.startswith('{"metric"')]
+    for l in lines:
+        if not l.startswith('{"metric"'):
+            print(l, file=sys.stderr)
+    if result:
+        print(result[-1])
+    raise SystemExit(r.returncode if r.returncode else (0 if result else 1))
 
 
 def main() -> None:

@@ -682,11 +682,12 @@ struct Pool {
 // walks the BGZF container of a mapped file, a piece at a time
 struct BgzfIndexer {
     const uint8_t* d; size_t n, p = 0, total = 0; bool bad = false;
+    size_t stop = (size_t)-1;  // the last block to take starts at this file offset (a shard's range)
     bool at_end() const { return bad || p + 18 > n; }
-    bool complete() const { return !bad && p == n; }
+    bool complete() const { return !bad && (p == n || p > stop); }
     bool more(std::vector<BgzfBlock>& blocks, size_t max_new) {  // false: nothing was added
         size_t added = 0;
-        while (added < max_new && p + 18 <= n) {
+        while (added < max_new && p + 18 <= n && p <= stop) {
             if (d[p] != 0x1f || d[p + 1] != 0x8b || !(d[p + 3] & 4)) { bad = true; break; }
             uint32_t xlen = d[p + 10] | (d[p + 11] << 8);
             int bsize = -1;
@@ -715,6 +716,58 @@ bool index_bgzf_view(const uint8_t* d, size_t n, std::vector<BgzfBlock>& blocks,
     total = ix.total;
     return ix.complete();
 }
+// ---- BAI (SAM spec 5.2): what a chromosome shard needs from it is, per reference, the virtual file offset of its first record
+// (coffset << 16 | offset inside the inflated block) -- from the metadata pseudo-bin 37450 when the writer left one (samtools,
+// the generator), else the smallest chunk start over its bins.  `<bam>.bai` or `<bam minus extension>.bai`.
+struct BaiIndex {
+    std::vector<unsigned long long> ref_beg;  // ~0ull: the reference has no record
+    bool load(const std::string& bam_path, int n_ref_expected) {
+        std::string cand[2] = {bam_path + ".bai", bam_path.size() > 4 ? bam_path.substr(0, bam_path.size() - 4) + ".bai" : std::string()};
+        for (const std::string& pth : cand) {
+            if (pth.empty()) continue;
+            FILE* f = std::fopen(pth.c_str(), "rb");
+            if (!f) continue;
+            std::vector<uint8_t> d;
+            uint8_t buf[65536];
+            for (size_t k; (k = std::fread(buf, 1, sizeof buf, f)) > 0;) d.insert(d.end(), buf, buf + k);
+            std::fclose(f);
+            if (parse(d, n_ref_expected)) return true;
+        }
+        return false;
+    }
+    bool parse(const std::vector<uint8_t>& d, int n_ref_expected) {
+        size_t p = 0;
+        auto u32 = [&](uint32_t& v) { if (p + 4 > d.size()) return false; std::memcpy(&v, &d[p], 4); p += 4; return true; };
+        auto u64 = [&](unsigned long long& v) { if (p + 8 > d.size()) return false; std::memcpy(&v, &d[p], 8); p += 8; return true; };
+        if (d.size() < 8 || std::memcmp(d.data(), "BAI\1", 4) != 0) return false;
+        p = 4;
+        uint32_t nref = 0;
+        if (!u32(nref) || (n_ref_expected >= 0 && (int)nref != n_ref_expected)) return false;
+        ref_beg.assign(nref, ~0ull);
+        for (uint32_t r = 0; r < nref; ++r) {
+            uint32_t nbin = 0;
+            if (!u32(nbin)) return false;
+            unsigned long long best = ~0ull, meta = ~0ull;
+            for (uint32_t b = 0; b < nbin; ++b) {
+                uint32_t bin = 0, nchunk = 0;
+                if (!u32(bin) || !u32(nchunk)) return false;
+                for (uint32_t k = 0; k < nchunk; ++k) {
+                    unsigned long long beg = 0, end = 0;
+                    if (!u64(beg) || !u64(end)) return false;
+                    if (bin == 37450) { if (k == 0) meta = beg; }
+                    else if (beg < best) best = beg;
+                }
+            }
+            uint32_t nintv = 0;
+            if (!u32(nintv)) return false;
+            if (p + 8ull * nintv > d.size()) return false;
+            p += 8ull * nintv;
+            ref_beg[r] = meta != ~0ull ? meta : best;
+        }
+        return true;
+    }
+};
+
 // raw-DEFLATE decoder of libdeflate (2-3x faster than zlib's inflate), bound at run time when the shared library is on
 // the system (no header needed: three functions of its stable C API); zlib otherwise
 struct FastInflate {
@@ -888,7 +941,7 @@ static int usable_cpus() {
     }
     return std::max(1, n);
 }
-int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSink& sink, const std::function<void(size_t)>& on_total, const RefRange* only, const GpuIngest& gpu, bool force_gpu) {
+int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSink& sink, const std::function<void(size_t)>& on_total, const RefRange* only, const GpuIngest& gpu, bool force_gpu, bool allow_bai) {
     using clk = std::chrono::steady_clock;
     auto since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
     double t_map = 0, t_inflate = 0, t_find = 0, t_wait = 0;
@@ -902,7 +955,12 @@ int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSi
     const size_t file_bytes = ::stat(path, &fst) == 0 ? (size_t)fst.st_size : 0;
     const bool gpu_auto = file_bytes >= ((size_t)1 << 30) && std::min(n_threads, usable_cpus()) <= 24;
     bool try_gpu = gpu && (force_gpu || (gpu_env ? std::atoi(gpu_env) != 0 : gpu_auto));
-    const bool lazy = try_gpu && !only;
+    // A chromosome shard with a .bai next to the BAM starts at the virtual offset of its first record and walks only the BGZF
+    // blocks of its own range (lazily, like a whole file); without one, the whole file is indexed and the range is found by probing.
+    BaiIndex bai;
+    static const bool no_bai_env = std::getenv("SQUID_NO_BAI") != nullptr;
+    bool use_bai = only && try_gpu && allow_bai && !no_bai_env && bai.load(path, -1);
+    const bool lazy = try_gpu && (!only || use_bai);
     bool map_reused = false;
     std::shared_ptr<FileMap> fm_hold = g_map_cache.acquire(path, !lazy, map_reused);
     if (!fm_hold) { err = std::string("cannot open bamfile ") + path; return SQ_E_IO; }
@@ -911,11 +969,14 @@ int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSi
     // the copies to the device and the index walk then run over mapped pages instead of taking a fault every 4 KiB
     struct Prefault {
         std::thread th; std::atomic<bool> stop{false}; std::atomic<size_t> upto{0};  // upto: fill the tables up to this file offset, then wait
+        std::atomic<size_t> from{0};  // (a shard: the fill starts at its own range)
         void start(const uint8_t* p, size_t n) {
 #ifdef MADV_POPULATE_READ
             th = std::thread([this, p, n]() {
                 const size_t step = (size_t)32 << 20;
-                for (size_t o = 0; o < n && !stop.load(std::memory_order_relaxed);) {
+                size_t o = 0;
+                for (size_t f0 = from.load(); o < n && !stop.load(std::memory_order_relaxed);) {
+                    if (from.load(std::memory_order_relaxed) != f0) { f0 = from.load(); o = f0 & ~(step - 1); }
                     if (o >= upto.load(std::memory_order_relaxed)) { std::this_thread::sleep_for(std::chrono::microseconds(500)); continue; }
                     if (madvise((void*)(p + o), std::min(step, n - o), MADV_POPULATE_READ) != 0) break;  // (then the readers fault the pages themselves)
                     o += step;
@@ -975,7 +1036,38 @@ int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSi
         nb = first_rec_block;
         only_begin = hp - blocks[nb].uoff;
     }
-    if (only) {
+    size_t gpu_file_bytes = fm.n;
+    if (only && use_bai && (int)bai.ref_beg.size() != nref) {
+        // an index of another file: take the probing path (it wants the whole block index)
+        return scan_bam_file(path, n_threads, err, sink, on_total, only, gpu, force_gpu, false);
+    }
+    if (only && use_bai) {
+        // first record of the first owned reference that has records; the range ends at the first record of the first later
+        // reference that has records (the last rank also owns the unplaced records: to the end of the file)
+        unsigned long long vb = ~0ull, ve = ~0ull;
+        for (int r = only->first_ref; r < only->end_ref && r < nref; ++r) if (bai.ref_beg[(size_t)r] != ~0ull) { vb = bai.ref_beg[(size_t)r]; break; }
+        for (int r = only->end_ref; r < nref && !only->with_unplaced; ++r) if (bai.ref_beg[(size_t)r] != ~0ull) { ve = bai.ref_beg[(size_t)r]; break; }
+        if (vb == ~0ull && only->with_unplaced) {
+            // no owned reference has records, but the unplaced ones (behind every mapped record) are this rank's: start at the
+            // last reference that has records -- the device side keeps only what the rank owns
+            for (int r = nref - 1; r >= 0; --r) if (bai.ref_beg[(size_t)r] != ~0ull) { vb = bai.ref_beg[(size_t)r]; break; }
+            if (vb == ~0ull) return scan_bam_file(path, n_threads, err, sink, on_total, only, gpu, force_gpu, false);  // (no mapped record at all: probing path)
+        }
+        if (vb == ~0ull) return SQ_OK;  // nothing of this rank's in the file
+        const size_t cb = (size_t)(vb >> 16), ce = ve == ~0ull ? (size_t)-1 : (size_t)(ve >> 16);
+        if (cb >= fm.n || (ce != (size_t)-1 && ce < cb)) return scan_bam_file(path, n_threads, err, sink, on_total, only, gpu, force_gpu, false);  // (a stale index)
+        blocks.clear();
+        ix.p = cb; ix.total = 0; ix.stop = ce; ix.bad = false;
+        prefault.from = cb;
+        prefault.upto = cb + prefault_ahead;
+        if (!ix.more(blocks, 64) || ix.bad) return scan_bam_file(path, n_threads, err, sink, on_total, only, gpu, force_gpu, false);
+        nb = 0; first_rec_block = 0;
+        only_begin = (size_t)(vb & 0xffff);
+        unsynced = false;
+        if (only_begin >= blocks[0].isize) return scan_bam_file(path, n_threads, err, sink, on_total, only, gpu, force_gpu, false);
+        gpu_file_bytes = (ce == (size_t)-1 ? fm.n : std::min(fm.n, ce + (size_t)(1 << 17))) - cb;  // sizes the record arrays: the shard's share of the file
+    }
+    if (only && !use_bai) {
         // A chromosome shard only inflates the blocks that can hold its records.  f(b) = RefID of the first record that
         // starts at or behind block b (found by the same plausible-chain search that the slices use) is monotone in a
         // coordinate-sorted file, unplaced records (-1) counting as behind every reference: two binary searches.
@@ -1021,7 +1113,7 @@ int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSi
             return any;
         };
         const double t_before_gpu = since(t_all);
-        const int r2 = gpu(fm.p, br, nb, lazy ? (size_t)-1 : nb_end, only_begin, !unsynced, nref, lazy ? more : IndexMore(), fm.n);
+        const int r2 = gpu(fm.p, br, nb, lazy ? (size_t)-1 : nb_end, only_begin, !unsynced, nref, lazy ? more : IndexMore(), gpu_file_bytes);
         if (std::getenv("SQUID_INGEST_TIMING")) std::fprintf(stderr, "ingest %s: map+index %.1f, header %.1f, GPU inflate+parse path total %.1f ms (rc %d)\n", path, t_map, t_before_gpu, since(t_all), r2);
         if (r2 != 2) {
             if (r2 == SQ_OK && lazy && !ix.complete()) { err = "not a BGZF file"; return SQ_E_IO; }
@@ -1033,6 +1125,7 @@ int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSi
             if (std::getenv("SQUID_INGEST_TIMING")) std::fprintf(stderr, "ingest %s: returning after %.1f ms\n", path, since(t_all));
             return r2;
         }
+        if (lazy && use_bai) { prefault.finish(); return scan_bam_file(path, n_threads, err, sink, on_total, only, gpu, force_gpu, false); }  // (start over on the probing path)
         if (lazy) {  // the host pipeline wants the whole index (and its helpers)
             prefault.finish();
             pool_holder.reset(new Pool(n_threads - 1));

@@ -6,6 +6,9 @@
 #include <memory>
 
 #include <sys/stat.h>
+#include <sys/mman.h>
+#include <fcntl.h>
+#include <unistd.h>
 
 #include "sq_internal.h"
 
@@ -815,11 +818,15 @@ int sq_ingest_concordant_file(sq_ctx* c, const char* path, int32_t n_threads) {
         const RefRange rr{c->shard.first_ref, c->shard.end_ref, c->P.rank == c->P.world_size - 1};
         const bool staged = !c->staged_path.empty() && c->staged_path == path;  // compressed bytes already in HBM (sq_stage_bam)
         struct DfileGuard { sq_ctx* c; ~DfileGuard() { c->ingest_dfile = nullptr; } } dfile_guard{c};
-        if (staged) { int r0 = dev_stage_file(c, nullptr, 0, &c->ingest_dfile); if (r0) return r0; }
+        if (staged) {
+            struct stat st;
+            if (::stat(path, &st) != 0 || (size_t)st.st_size != c->staged_bytes) return fail(c, SQ_E_IO, "the file changed since sq_stage_bam");
+            int r0 = dev_stage_file(c, nullptr, 0, &c->ingest_dfile);
+            if (r0) return r0;
+        }
         int rc = scan_bam_file(path, n_threads, c->err, [&](const uint8_t* bam, size_t nbytes, const unsigned long long* off, int64_t n) { c->ingest_seen_bytes += nbytes; return ingest_raw(c, bam, nbytes, off, n); },
                                [&](size_t total) { c->ingest_total_bytes = c->shard.on ? 0 : total; }, c->shard.on ? &rr : nullptr,
                                [&](const uint8_t* file, std::vector<BgzfRange>& blocks, size_t b0, size_t b1, size_t begin, bool synced, int nref, const IndexMore& more, size_t file_bytes) {
-                                   if (staged && file_bytes != c->staged_bytes) return fail(c, SQ_E_IO, "the file changed since sq_stage_bam");
                                    return dev_ingest_bgzf(c, file, blocks, b0, b1, begin, synced, nref, more, file_bytes); }, staged);
         c->ingest_total_bytes = 0;
         const double t_scan = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_file0).count();
@@ -836,20 +843,20 @@ int sq_ingest_concordant_file(sq_ctx* c, const char* path, int32_t n_threads) {
 }
 int sq_stage_bam(sq_ctx* c, const char* path) {
     if (!c || !path) return SQ_E_ARG;
-    FILE* f = std::fopen(path, "rb");
-    if (!f) return fail(c, SQ_E_IO, std::string("cannot open bamfile ") + path);
-    std::vector<uint8_t> bytes;
-    bool ok = fseeko(f, 0, SEEK_END) == 0;
-    const off_t n = ok ? ftello(f) : -1;
-    ok = ok && n >= 0 && fseeko(f, 0, SEEK_SET) == 0;
-    if (ok) { bytes.resize((size_t)n); ok = std::fread(bytes.data(), 1, (size_t)n, f) == (size_t)n; }
-    std::fclose(f);
-    if (!ok) return fail(c, SQ_E_IO, std::string("cannot read ") + path);
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) return fail(c, SQ_E_IO, std::string("cannot open bamfile ") + path);
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size <= 0) { ::close(fd); return fail(c, SQ_E_IO, std::string("cannot read ") + path); }
+    const size_t n = (size_t)st.st_size;
+    void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);  // (straight from the page cache: no second host copy of the file)
+    ::close(fd);
+    if (m == MAP_FAILED) return fail(c, SQ_E_IO, std::string("cannot map ") + path);
     c->staged_path.clear(); c->staged_bytes = 0;
     const uint8_t* d = nullptr;
-    int rc = dev_stage_file(c, bytes.data(), bytes.size(), &d);
+    int rc = dev_stage_file(c, (const uint8_t*)m, n, &d);
+    munmap(m, n);
     if (rc) return rc;
-    c->staged_path = path; c->staged_bytes = bytes.size();
+    c->staged_path = path; c->staged_bytes = n;
     return SQ_OK;
 }
 int sq_clear_records(sq_ctx* c) {

@@ -243,7 +243,7 @@ typedef std::function<bool(std::vector<BgzfRange>&)> IndexMore;
 typedef std::function<int(const uint8_t*, std::vector<BgzfRange>&, size_t, size_t, size_t, bool, int, const IndexMore&, size_t)> GpuIngest;
 int scan_bam_file(const char* path, int n_threads, std::string& err, const std::function<int(const uint8_t*, size_t, const unsigned long long*, int64_t)>& sink,
                   const std::function<void(size_t)>& on_total = nullptr, const RefRange* only = nullptr,
-                  const GpuIngest& gpu = nullptr, bool force_gpu = false);
+                  const GpuIngest& gpu = nullptr, bool force_gpu = false, bool allow_bai = true);
 
 // ---- sq_chimeric.cpp
 int build_fragments(sq_ctx* c, const sq_aln_batch* b);

@@ -50,8 +50,13 @@ public:
         if (!fp_) { std::perror(path.c_str()); std::exit(1); }
         buf_.reserve(kBatch * kBlock);
     }
+    // uncompressed offset of the next byte / file offset of every finished BGZF block: what a virtual file offset is made of
+    unsigned long long tell() const { return utotal_; }
+    const std::vector<unsigned long long>& block_offsets() const { return block_coff_; }
+    static constexpr size_t block_size() { return kBlock; }
     void write(const void* p, size_t n) {
         const uint8_t* b = (const uint8_t*)p;
+        utotal_ += n;
         buf_.insert(buf_.end(), b, b + n);
         if (buf_.size() >= (size_t)kBatch * kBlock) flush_full_blocks(false);
     }
@@ -110,13 +115,15 @@ private:
             for (int t = 0; t < threads_; ++t) th.emplace_back(work, t);
             for (auto& x : th) x.join();
         }
-        for (auto& o : outs) std::fwrite(o.data(), 1, o.size(), fp_);
+        for (auto& o : outs) { block_coff_.push_back(cpos_); std::fwrite(o.data(), 1, o.size(), fp_); cpos_ += o.size(); }
         size_t consumed = std::min(buf_.size(), nblocks * kBlock);
         buf_.erase(buf_.begin(), buf_.begin() + consumed);
     }
     FILE* fp_;
     int level_, threads_;
     std::vector<uint8_t> buf_;
+    unsigned long long utotal_ = 0, cpos_ = 0;
+    std::vector<unsigned long long> block_coff_;
 };
 
 // ---------------------------------------------------------------- BAM record builder
@@ -482,6 +489,12 @@ int main(int argc, char** argv) {
     write_header(bw, text);
     long nrec = 0, nblocks = 0, frag_id = 0;
     std::vector<Rec> recs;
+    // for the .bai: per reference the uncompressed stream offsets of its first record / behind its last, the record count, and
+    // per 16 kb window the offset of the first record that overlaps it (the linear index)
+    struct RefIdx { unsigned long long ubeg = 0, uend = 0; long n = 0; std::vector<unsigned long long> win; };
+    std::vector<RefIdx> ridx(contigs.size());
+    unsigned long long u_unplaced = 0;
+    long n_unplaced = 0;
     for (size_t gi = 0; gi < genes.size(); ++gi) {
         const Gene& g = genes[gi];
         long nf = (long)std::llround((double)nfrag_total * g.weight * g.tlen() / wsum);
@@ -543,21 +556,64 @@ int main(int argc, char** argv) {
         for (auto& r : gene_extra[gi]) recs.push_back(r);
         std::stable_sort(recs.begin(), recs.end(), [](const Rec& a, const Rec& b) { return a.pos < b.pos; });
         for (auto& r : recs) {
+            const unsigned long long u0 = bw.tell();
             bw.write(r.bytes.data(), r.bytes.size());
             ++nrec;
-            uint16_t ncig;
-            std::memcpy(&ncig, r.bytes.data() + 16, 2);
-            (void)ncig;
+            if (r.refid >= 0 && r.refid < (int)ridx.size()) {
+                RefIdx& x = ridx[(size_t)r.refid];
+                if (!x.n) x.ubeg = u0;
+                x.uend = bw.tell();
+                ++x.n;
+                // reference span of the record from its cigar (ops M, D, N, =, X)
+                uint16_t ncig;
+                std::memcpy(&ncig, r.bytes.data() + 16, 2);
+                const uint8_t* cg = r.bytes.data() + 36 + r.bytes[12];
+                int reflen = 0;
+                for (int k = 0; k < ncig; ++k) { uint32_t v; std::memcpy(&v, cg + 4 * k, 4); const int op = v & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += (int)(v >> 4); }
+                const size_t w0 = (size_t)(r.pos >> 14), w1 = (size_t)((r.pos + std::max(reflen, 1) - 1) >> 14);
+                if (x.win.size() <= w1) x.win.resize(w1 + 1, ~0ull);
+                for (size_t w = w0; w <= w1; ++w) if (x.win[w] == ~0ull) x.win[w] = u0;
+            }
         }
     }
     // unmapped tail (refid -1): ignored by every pass, but must parse
     for (int i = 0; i < 3; ++i) {
         Rec r = make_record(rng, "unm" + std::to_string(i), -1, -1, 0, 0x1 | 0x4 | 0x8 | 0x40, {}, -1, -1, 0, 0, false);
         // give the unmapped record 100 bases so that seq/qual parsing is exercised
+        if (!n_unplaced) u_unplaced = bw.tell();
+        ++n_unplaced;
         bw.write(r.bytes.data(), r.bytes.size());
         ++nrec;
     }
     bw.close();
+    // ---- <out>.bam.bai (SAM spec 5.2).  Coarse but valid: per reference one real bin (bin 0, one chunk over all its records),
+    // the metadata pseudo-bin 37450 (first / end virtual offset, mapped / unmapped counts) and the 16 kb linear index.
+    {
+        const std::vector<unsigned long long>& bc = bw.block_offsets();
+        auto voff = [&](unsigned long long u) -> unsigned long long {
+            const size_t blk = (size_t)(u / BgzfWriter::block_size());
+            // (an offset exactly at the end of the data lies at the start of the EOF marker block = end of the last data block)
+            if (blk >= bc.size()) return bc.empty() ? 0 : ((bc.back() << 16) | (unsigned long long)(u - (bc.size() - 1) * BgzfWriter::block_size()));
+            return (bc[blk] << 16) | (unsigned long long)(u % BgzfWriter::block_size());
+        };
+        FILE* bf = std::fopen((out + ".bam.bai").c_str(), "wb");
+        auto w32 = [&](uint32_t v) { std::fwrite(&v, 4, 1, bf); };
+        auto w64 = [&](unsigned long long v) { std::fwrite(&v, 8, 1, bf); };
+        std::fwrite("BAI\1", 1, 4, bf);
+        w32((uint32_t)ridx.size());
+        for (const RefIdx& x : ridx) {
+            if (!x.n) { w32(0); w32(0); continue; }
+            w32(2);
+            w32(0); w32(1); w64(voff(x.ubeg)); w64(voff(x.uend));
+            w32(37450); w32(2); w64(voff(x.ubeg)); w64(voff(x.uend)); w64((unsigned long long)x.n); w64(0);
+            w32((uint32_t)x.win.size());
+            unsigned long long lastv = voff(x.ubeg);
+            for (unsigned long long u : x.win) { if (u != ~0ull) lastv = voff(u); w64(lastv); }
+        }
+        w64((unsigned long long)n_unplaced);
+        std::fclose(bf);
+        (void)u_unplaced;
+    }
 
     // ---- chimeric BAM (unsorted; shuffle so that name order != file order)
     {

@@ -679,8 +679,13 @@ def test_gpu_bgzf_inflate_and_boundary_search_give_the_same_records(built, synth
         ctx = f"rank={rank}, world_size=3"
         want_shard = run(f"{pre}.bam", {}, shard, ctx)
         assert want_shard != want
+        # (the generator writes <bam>.bai: the shard starts at the virtual offset of its first record, sq_bam.cpp BaiIndex;
+        # "BAI shard" in the timing log tells that this path was taken)
         assert run(f"{pre}.bam", gpu, shard, ctx) == want_shard, shard
         assert run(f"{pre}.bam", dict(gpu, SQUID_TOK_CAP_MB="0"), shard, ctx) == want_shard, shard
+        assert run(f"{pre}.bam", dict(gpu, SQUID_NO_BAI="1"), shard, ctx) == want_shard, shard   # without the index: block range by probing
+        assert run(f"{pre}.bam", dict(gpu, SQUID_TOK_V1="1"), shard, ctx) == want_shard, shard    # the table-driven token pass
+    assert run(f"{pre}.bam", dict(gpu, SQUID_TOK_V1="1")) == want
     plans = {
         "stored": lambda i: (0, zlib.Z_DEFAULT_STRATEGY),
         "fixed": lambda i: (6, zlib.Z_FIXED),
