@@ -143,6 +143,7 @@ struct DeviceRecords {
     uint32_t h_slots = 1u << 16;
     DBuf<int32_t> ord_e, ord_o, ord_v;  // ordering kernel: packed input, packed output, values
     DBuf<int32_t> ord_me, ord_mo;       // k_order_mid: packed input, packed output
+    DBuf<unsigned long long> tok_prof;  // SQUID_TOK_PROF
     DBuf<int32_t> g_i, g_x;             // K6 / K7 (sq_graph_kernels.inc): graph ints + scratch, CSR / neighbour scratch
     DBuf<double> g_d;
     DBuf<uint8_t> g_b;
@@ -479,7 +480,7 @@ __device__ int parse_blocks(const uint8_t* cg, int ncig, const uint8_t* seq, int
 // byte per lane, 260 bytes apart from the neighbouring lane: straight from global memory every load touches 64 cache
 // lines and the chunk is fetched from HBM ~20 times over.  So the range is first copied into LDS with coalesced 16-byte
 // loads and the lanes parse from there (a range that does not fit -- very long records -- is parsed in place).
-constexpr int PARSE_THREADS = 64, PARSE_LDS = 32768;
+constexpr int PARSE_THREADS = 128, PARSE_LDS = 40960;  // 4 workgroups = 8 waves per CU (64 threads x 32 KB gave 5)
 // `avail` receives the bytes the record may occupy: up to the next record's offset, the end of the chunk and (when staged) the
 // end of the staged range; -1 when the offsets handed in by the caller are not ascending or lie outside the chunk.
 __device__ __forceinline__ const uint8_t* stage_records(const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n, uint8_t* lds, long long& avail) {
@@ -2393,7 +2394,7 @@ __global__ __launch_bounds__(64) void k_inflate_lanes(const uint8_t* file, const
 // its length group, where the literals come first), two 16-entry tables per code, the code lengths packed to 4 bits while a
 // header is read (170), the input ring and the token stage: 746 bytes, 46.6 KB per wave, THREE waves per CU -- three times the
 // streams in flight, and a step is two LDS round trips per code instead of up to nine.
-constexpr int T2_SYM_LL = 288, T2_SYM_DD = 32, T2_CL_AT = 320, T2_LENS4 = 170;
+constexpr int T2_SYM_LL = 288, T2_SYM_DD = 32, T2_CL_AT = 320, T2_LENS4 = 170, T2_LITS = 4;
 constexpr size_t T2_LDS_BYTES = (size_t)(T2_SYM_LL + T2_SYM_DD + T2_LENS4) * 64 + (size_t)(5 * 16) * 64 * 2 + (size_t)(IL_STAGE + IL_RING) * 64 * 4;
 struct T2Lds {
     uint8_t *sym_ll, *sym_dd, *lens4;        // [e * 64 + lane]
@@ -2408,8 +2409,13 @@ __device__ __forceinline__ void t2_setlen(const T2Lds& L, int lane, int i, int v
 }
 // canonical tables of one code from the lengths lens[lo .. lo + n): limits into lim[1..15], slots / symbols into LDS.
 // Called by the lanes that are at a header (me), each for its own code.  Returns false for an over-subscribed set.
+// canonical tables of one code from the lengths lens[lo .. lo + n).  The code limits go into REGISTERS, two 16-bit values per
+// register (limit - 1, so that the sign of (limit - 1 - v) in 16 bits says v >= limit): lp[j] holds lengths 2j + 1 and 2j + 2,
+// lp[7] the limit of length 15 alone.  Slots / symbols go into LDS.  Called by the lanes that are at a header (me), each for
+// its own code.  Returns false for an over-subscribed set.
+typedef short t2_s16x2 __attribute__((ext_vector_type(2)));
 template <bool LL>
-__device__ bool t2_build(const T2Lds& L, int lane, bool me, int lo, int n, uint32_t (&lim)[16], uint8_t* symtab, int16_t* ktab) {
+__device__ bool t2_build(const T2Lds& L, int lane, bool me, int lo, int n, uint32_t (&lp)[8], uint8_t* symtab, int16_t* ktab) {
     bool ok = true;
     if (me) {
         uint16_t *cnt = L.tmp_a + lane, *slot = L.tmp_b + lane;
@@ -2417,11 +2423,14 @@ __device__ bool t2_build(const T2Lds& L, int lane, bool me, int lo, int n, uint3
         for (int i = 0; i < n; ++i) ++cnt[t2_getlen(L, lane, lo + i) * 64];
         int left = 1, first = 0, off = 0;
 #pragma unroll
+        for (int j = 0; j < 8; ++j) lp[j] = 0;
+#pragma unroll
         for (int l = 1; l <= 15; ++l) {
             const int k = cnt[l * 64];
             left = (left << 1) - k;
             if (left < 0) ok = false;
-            lim[l] = (uint32_t)(first + k) << (15 - l);
+            const uint32_t lim = (uint32_t)(first + k) << (15 - l);  // <= 32768
+            lp[(l - 1) >> 1] |= ((lim - 1u) & 0xffffu) << (((l - 1) & 1) << 4);
             ktab[l * 64 + lane] = (int16_t)(off - first);
             slot[l * 64] = (uint16_t)off;
             if (LL) L.nl_ll[l * 64 + lane] = (uint16_t)off;
@@ -2439,20 +2448,46 @@ __device__ bool t2_build(const T2Lds& L, int lane, bool me, int lo, int n, uint3
     }
     return ok;
 }
-// length of the next code and its symbol slot; -1 for a bit pattern no code of the set covers
-__device__ __forceinline__ int t2_slot(ILane& b, const uint32_t (&lim)[16], const int16_t* ktab, int lane, int& len) {
+// length of the next code and its symbol slot; -1 for a bit pattern no code of the set covers.  Seven packed 16-bit
+// subtractions decide fourteen "v >= limit" at once (a lone wave per SIMD pays every dependent vector instruction in full:
+// the fewer, the better), one more the length-15 limit; the slot offset of the length comes from LDS.
+__device__ __forceinline__ int t2_slot(ILane& b, const uint32_t (&lp)[8], const int16_t* ktab, int lane, int& len) {
     const uint32_t v = __brev((uint32_t)b.buf) >> 17;
-    int l = 1;
+    const uint32_t vv = v | (v << 16);
+    t2_s16x2 acc = {0, 0};
 #pragma unroll
-    for (int q = 1; q <= 14; ++q) l += v >= lim[q] ? 1 : 0;
+    for (int j = 0; j < 7; ++j) {
+        t2_s16x2 d = __builtin_bit_cast(t2_s16x2, lp[j]) - __builtin_bit_cast(t2_s16x2, vv);
+        acc += d >> 15;  // -1 where v >= limit
+    }
+    const int l = 1 - ((int)acc.x + (int)acc.y);
     len = l;
-    if (v >= lim[15]) return -1;
+    if ((int)(short)(lp[7] & 0xffffu) - (int)v < 0) return -1;  // v >= limit of length 15
     const int idx = (int)(v >> (15 - l)) + (int)ktab[l * 64 + lane];
     b.buf >>= l; b.cnt -= l;
     return idx;
 }
-__global__ __launch_bounds__(64) void k_inflate_tok2(const uint8_t* file, const InflBlock* blocks, int nblocks, unsigned long long out_base, int32_t* flags, uint32_t* tok, int32_t* ntok) {
+// bit buffer refill with the next ring word already in a register (loaded at the refill before: its LDS round trip is over by
+// the time it is needed)
+__device__ __forceinline__ void t2_refill(ILane& b, uint32_t& ahead) {
+    if (b.cnt <= 32) {
+        b.buf |= (unsigned long long)ahead << b.cnt; b.cnt += 32; ++b.rd;
+        ahead = b.ring[(b.rd & (IL_RING - 1)) * 64];
+    }
+}
+__device__ __forceinline__ uint32_t t2_take(ILane& b, uint32_t& ahead, int k) {
+    t2_refill(b, ahead);
+    const uint32_t v = (uint32_t)(b.buf & ((1ull << k) - 1));
+    b.buf >>= k; b.cnt -= k;
+    return v;
+}
+template <bool PROF>
+__global__ __launch_bounds__(64, 1) void k_inflate_tok2(const uint8_t* file, const InflBlock* blocks, int nblocks, unsigned long long out_base, int32_t* flags, uint32_t* tok, int32_t* ntok,
+                                                    unsigned long long* prof) {
     extern __shared__ uint16_t il_lds[];  // T2_LDS_BYTES
+    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pc = 0;
+    auto tick = [&](int k) { if (PROF) { const unsigned long long now = __builtin_amdgcn_s_memtime(); pt[k] += now - pc; pc = now; } };
+    if (PROF) pc = __builtin_amdgcn_s_memtime();
     __shared__ uint8_t sh_clo[32];
     T2Lds L;
     L.k_ll = (int16_t*)il_lds;                 L.k_dd = L.k_ll + 16 * 64;
@@ -2483,17 +2518,28 @@ __global__ __launch_bounds__(64) void k_inflate_tok2(const uint8_t* file, const 
     ILane b;
     b.p = file + blk.coff; b.n = blk.clen; b.ring = ring + lane;
     il_start(b, 0);
-    uint32_t lim_ll[16], lim_dd[16];
+    uint32_t lp_ll[8], lp_dd[8];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) { lim_ll[q] = 0; lim_dd[q] = 0; }
+    for (int q = 0; q < 8; ++q) { lp_ll[q] = 0; lp_dd[q] = 0; }
+    uint32_t ahead = b.ring[0];  // (il_start has filled the ring)
     uint32_t outpos = 0;
     bool done = !have || blk.isize == 0, err = false, in_block = false, last = false, stored = false;
     uint32_t stored_left = 0, stored_at = 0;
     int hdr_wait = 0;
-    uint32_t token = 0;       // what the step has decoded: stored at the top of the next step, where the lanes that took the
-    bool have_token = false;  // literal path and those that took the match path are together again (one copy of the store code)
+    // what the step has produced -- with four literal/length symbols per step at most three tokens (two pending literals + one
+    // fill a token, two more wait, a match flushes them and adds its own): stored at the top of the next step, where all lanes
+    // are together again (one copy of the store code)
+    uint32_t tq0 = 0, tq1 = 0, tq2 = 0;
+    int ntq = 0;
+    auto push = [&](uint32_t t_) { tq0 = ntq == 0 ? t_ : tq0; tq1 = ntq == 1 ? t_ : tq1; tq2 = ntq == 2 ? t_ : tq2; ++ntq; };  // (selects: the three stay in registers)
+    static_assert(T2_LITS <= 4, "the token queue of a step holds three tokens");
+    uint32_t lit = 0;         // literals waiting for company (up to three per token)
+    int nlit = 0;
     while (__any(!done)) {
-        if (have_token) { emit(token); have_token = false; }
+        tick(7);
+        if (ntq) { emit(tq0); if (ntq > 1) emit(tq1); if (ntq > 2) emit(tq2); ntq = 0; }
+        if (PROF) ++pt[6];
+        tick(0);
         // ---- block headers, by all the lanes that are at one
         const unsigned long long need = __ballot(!done && !in_block && !stored);
         if (need && (need == __ballot(!done) || ++hdr_wait >= IL_HDR_WAIT)) {
@@ -2503,16 +2549,16 @@ __global__ __launch_bounds__(64) void k_inflate_tok2(const uint8_t* file, const 
             if (me) {
                 if (il_low(b)) il_topup(b);
                 if (il_pos(b) <= b.n + 8) {
-                    last = il_take(b, 1);
-                    const uint32_t type = il_take(b, 2);
+                    last = t2_take(b, ahead, 1);
+                    const uint32_t type = t2_take(b, ahead, 2);
                     if (type == 0) {
                         b.buf >>= (b.cnt & 7); b.cnt -= (b.cnt & 7);
-                        const uint32_t len = il_take(b, 16), nl = il_take(b, 16);
+                        const uint32_t len = t2_take(b, ahead, 16), nl = t2_take(b, ahead, 16);
                         stored_at = il_pos(b) - (uint32_t)(b.cnt >> 3);
                         if ((len ^ 0xffff) == nl && stored_at + len <= b.n && outpos + len <= blk.isize) {
                             kind = 0;
                             stored_left = len;
-                            if (len) stored = true; else { il_start(b, stored_at); if (last) done = true; }
+                            if (len) stored = true; else { il_start(b, stored_at); ahead = b.ring[0]; if (last) done = true; }
                         }
                     } else if (type == 1) {
                         for (int i = 0; i < 144; ++i) t2_setlen(L, lane, i, 8);
@@ -2522,11 +2568,11 @@ __global__ __launch_bounds__(64) void k_inflate_tok2(const uint8_t* file, const 
                         for (int i = 0; i < 30; ++i) t2_setlen(L, lane, 288 + i, 5);
                         kind = 1; nlen = 288; ndist = 30;
                     } else if (type == 2) {
-                        nlen = (int)il_take(b, 5) + 257; ndist = (int)il_take(b, 5) + 1;
-                        const int ncode = (int)il_take(b, 4) + 4;
+                        nlen = (int)t2_take(b, ahead, 5) + 257; ndist = (int)t2_take(b, ahead, 5) + 1;
+                        const int ncode = (int)t2_take(b, ahead, 4) + 4;
                         if (nlen <= 286 && ndist <= 30) {
                             for (int i = 0; i < 19; ++i) t2_setlen(L, lane, T2_CL_AT + i, 0);
-                            for (int i = 0; i < ncode; ++i) t2_setlen(L, lane, T2_CL_AT + sh_clo[i], (int)il_take(b, 3));
+                            for (int i = 0; i < ncode; ++i) t2_setlen(L, lane, T2_CL_AT + sh_clo[i], (int)t2_take(b, ahead, 3));
                             kind = 2;
                         }
                     }
@@ -2535,23 +2581,23 @@ __global__ __launch_bounds__(64) void k_inflate_tok2(const uint8_t* file, const 
             if (__any(me && kind == 2)) {
                 // the code-length code (19 symbols) in the distance tables, then the literal/length + distance lengths with it
                 const bool dyn = me && kind == 2;
-                bool ok = t2_build<false>(L, lane, dyn, T2_CL_AT, 19, lim_dd, L.sym_dd, L.k_dd);
+                bool ok = t2_build<false>(L, lane, dyn, T2_CL_AT, 19, lp_dd, L.sym_dd, L.k_dd);
                 int idx = 0, prev = 0;
                 bool busy = dyn && ok;
                 while (__any(busy)) {
                     if (busy) {
                         if (il_low(b)) il_topup(b);
-                        il_refill(b);
+                        t2_refill(b, ahead);
                         int cl;
-                        const int at = t2_slot(b, lim_dd, L.k_dd, lane, cl);
+                        const int at = t2_slot(b, lp_dd, L.k_dd, lane, cl);
                         const int sym = at < 0 ? -1 : (int)L.sym_dd[(at & 31) * 64 + lane];
                         if (sym < 0 || sym > 18 || il_pos(b) > b.n + 8) { ok = false; busy = false; }
                         else if (sym < 16) { t2_setlen(L, lane, idx++, sym); prev = sym; }
                         else {
                             int rep, v = 0;
-                            if (sym == 16) { v = prev; rep = 3 + (int)il_take(b, 2); if (idx == 0) ok = false; }
-                            else if (sym == 17) rep = 3 + (int)il_take(b, 3);
-                            else rep = 11 + (int)il_take(b, 7);
+                            if (sym == 16) { v = prev; rep = 3 + (int)t2_take(b, ahead, 2); if (idx == 0) ok = false; }
+                            else if (sym == 17) rep = 3 + (int)t2_take(b, ahead, 3);
+                            else rep = 11 + (int)t2_take(b, ahead, 7);
                             if (!ok || idx + rep > nlen + ndist) { ok = false; busy = false; }
                             else { while (rep--) t2_setlen(L, lane, idx++, v); prev = v; }
                         }
@@ -2563,45 +2609,60 @@ __global__ __launch_bounds__(64) void k_inflate_tok2(const uint8_t* file, const 
             }
             if (__any(me && kind > 0)) {
                 const bool bld = me && kind > 0;
-                const bool ok_ll = t2_build<true>(L, lane, bld, 0, nlen, lim_ll, L.sym_ll, L.k_ll);
-                const bool ok_dd = t2_build<false>(L, lane, bld, nlen, ndist, lim_dd, L.sym_dd, L.k_dd);
+                const bool ok_ll = t2_build<true>(L, lane, bld, 0, nlen, lp_ll, L.sym_ll, L.k_ll);
+                const bool ok_dd = t2_build<false>(L, lane, bld, nlen, ndist, lp_dd, L.sym_dd, L.k_dd);
                 if (bld && !(ok_ll && ok_dd)) kind = -1;
             }
             if (me) { if (kind < 0) { err = true; done = true; } else if (kind > 0) in_block = true; }
         }
+        tick(1);
         if (__any(!done && il_low(b))) { if (!done) il_topup(b); }  // every lane, in the same step
+        tick(2);
         if (done) continue;
         if (stored) {  // a slice of a stored block
             const uint32_t k = stored_left < 16 ? stored_left : 16;
             for (uint32_t i = 0; i < k; ++i) emit(b.p[stored_at + i]);
             outpos += k; stored_at += k; stored_left -= k;
-            if (!stored_left) { stored = false; il_start(b, stored_at); if (last) done = true; }
+            if (!stored_left) { stored = false; il_start(b, stored_at); ahead = b.ring[0]; if (last) done = true; }
             continue;
         }
         if (!in_block) continue;  // (waiting at a header)
-        // ---- one symbol
-        il_refill(b);
-        int cl;
-        const int at = t2_slot(b, lim_ll, L.k_ll, lane, cl);
-        if (at < 0 || at >= T2_SYM_LL || il_pos(b) > b.n + 8) { err = true; done = true; continue; }
-        const int sym = (int)L.sym_ll[at * 64 + lane] + (at >= (int)L.nl_ll[cl * 64 + lane] ? 256 : 0);
-        if (sym < 256) {
-            if (outpos >= blk.isize) { err = true; done = true; continue; }
-            token = (uint32_t)sym; have_token = true; ++outpos;
-            continue;
+        // ---- up to T2_LITS literal/length symbols per step.  The distance half of a step (below) is executed whenever ANY lane has
+        // a match, i.e. nearly every step, for the few lanes that have one; it costs more than a literal/length decode.  So the
+        // lanes keep decoding literals -- most symbols of a BAM stream -- until they meet a length symbol or the end of the block,
+        // and the wave goes through the distance half once per step for all of them.  Literals travel three to a token (bits
+        // 24..25 = how many, the bytes in bits 0..23): the resolve pass takes 64 tokens per round.
+        int sym = -1;  // the length / end-of-block symbol the lane stopped at
+        bool go = true;
+#pragma unroll
+        for (int rep = 0; rep < T2_LITS; ++rep) {
+            if (!go) continue;
+            t2_refill(b, ahead);
+            int cl;
+            const int at = t2_slot(b, lp_ll, L.k_ll, lane, cl);
+            if (at < 0 || at >= T2_SYM_LL || il_pos(b) > b.n + 8) { err = true; done = true; go = false; continue; }
+            const int sy = (int)L.sym_ll[at * 64 + lane] + (at >= (int)L.nl_ll[cl * 64 + lane] ? 256 : 0);
+            if (sy >= 256) { sym = sy; go = false; continue; }
+            if (outpos >= blk.isize) { err = true; done = true; go = false; continue; }
+            lit |= (uint32_t)sy << (8 * nlit);
+            ++nlit; ++outpos;
+            if (nlit == 3) { push(lit | (3u << 24)); lit = 0; nlit = 0; }
         }
+        tick(3);
+        if (done || sym < 0) continue;
+        if (nlit) { push(lit | ((uint32_t)nlit << 24)); lit = 0; nlit = 0; }  // the literals in front of a match / the end of the block
         if (sym == 256) { in_block = false; if (last) done = true; continue; }
         const int ls = sym - 257;
         if (ls >= 29) { err = true; done = true; continue; }
         // base and extra bits of the length / distance symbol by arithmetic (RFC 1951 3.2.5).  One refill covers the rest of the
         // step: 5 + 15 + 13 bits at most.
-        il_refill(b);
+        t2_refill(b, ahead);
         const uint32_t lx = ls < 8 || ls == 28 ? 0u : (uint32_t)(ls - 4) >> 2;
         const uint32_t lbase = ls < 8 ? 3u + (uint32_t)ls : (ls == 28 ? 258u : 3u + ((4u + ((uint32_t)ls & 3u)) << lx));
         const uint32_t len = lbase + ((uint32_t)b.buf & ((1u << lx) - 1));
         b.buf >>= lx; b.cnt -= (int)lx;
         int dl;
-        const int dat = t2_slot(b, lim_dd, L.k_dd, lane, dl);
+        const int dat = t2_slot(b, lp_dd, L.k_dd, lane, dl);
         const int ds = dat < 0 ? -1 : (int)L.sym_dd[(dat & 31) * 64 + lane];
         if (ds < 0 || ds >= 30) { err = true; done = true; continue; }
         const uint32_t dx = ds < 4 ? 0u : (uint32_t)(ds - 2) >> 1;
@@ -2609,9 +2670,11 @@ __global__ __launch_bounds__(64) void k_inflate_tok2(const uint8_t* file, const 
         const uint32_t dist = dbase + ((uint32_t)b.buf & ((1u << dx) - 1));
         b.buf >>= dx; b.cnt -= (int)dx;
         if (dist > outpos || outpos + len > blk.isize) { err = true; done = true; continue; }
-        token = 0x80000000u | (len << 16) | (dist - 1); have_token = true; outpos += len;
+        push(0x80000000u | (len << 16) | (dist - 1)); outpos += len;
+        tick(4);
     }
-    if (have_token) emit(token);
+    if (PROF && lane == 0) { for (int k = 0; k < 8; ++k) prof[(size_t)blockIdx.x * 8 + k] = pt[k]; }
+    if (ntq) { emit(tq0); if (ntq > 1) emit(tq1); if (ntq > 2) emit(tq2); }
     if (have && (err || outpos != blk.isize)) atomicOr(&flags[0], 512);
     if (have) {
         for (uint32_t k = nt - nt % IL_STAGE; k < nt; ++k) tk[k] = stage[(k % IL_STAGE) * 64 + lane];
@@ -2647,12 +2710,13 @@ __global__ __launch_bounds__(64) void k_lz_resolve(const uint32_t* tok, const in
         const int i = r0 + lane;
         if (i + 64 < n) nxt = t[i + 64];
         const bool valid = i < n, is_m = valid && (tk >> 31);
-        const uint32_t len = !valid ? 0u : (is_m ? (tk >> 16) & 0x1ffu : 1u);
+        const uint32_t nl = (tk >> 24) & 3u;  // a literal token carries 1..3 bytes (0 stands for 1: the one-literal tokens of the first token pass)
+        const uint32_t len = !valid ? 0u : (is_m ? (tk >> 16) & 0x1ffu : (nl ? nl : 1u));
         const uint32_t inc = wave_scan_incl(len);
         const uint32_t o = base + inc - len;
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         if (base + total > blk.isize) { bad = true; break; }  // (uniform)
-        if (valid && !is_m) lz_win[o] = (uint8_t)tk;
+        if (valid && !is_m) { lz_win[o] = (uint8_t)tk; if (len > 1) lz_win[o + 1] = (uint8_t)(tk >> 8); if (len > 2) lz_win[o + 2] = (uint8_t)(tk >> 16); }
         const uint32_t dist = (tk & 0x7fffu) + 1;
         bool pending = is_m;
         if (pending && dist > o) { bad = true; pending = false; }
@@ -3044,7 +3108,10 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     HIPCHK(hipFuncSetAttribute((const void*)k_inflate_lanes<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)IL_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_inflate_lanes<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)IL_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_lz_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16));
-    HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T2_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T2_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T2_LDS_BYTES));
+    static const bool tok_prof = std::getenv("SQUID_TOK_PROF") != nullptr;
+    if (tok_prof) HIPCHK(D.tok_prof.reserve(8 * 4096));
     static const bool tok_v1 = std::getenv("SQUID_TOK_V1") != nullptr;  // the table-driven token pass (one wave per CU), kept for comparison
     for (auto& q : D.il_stream)
         if (!q) {
@@ -3129,7 +3196,8 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         if (variant == 0) {  // k_inflate_tok2 stays on the set's own stream: the token kernels of up to four batches run side by side
             EvTimer t1(c, "k_inflate_tokens", (double)B.cbytes + (double)B.bbytes * 2, sa);
             if (tok_v1) hipLaunchKernelGGL(k_inflate_lanes<true>, dim3((nb + 63) / 64), dim3(64), IL_LDS_BYTES, sa, st.src, st.tab.p, nb, B.bbase, nullptr, st.flags.p, st.tok.p, st.ntok.p);
-            else hipLaunchKernelGGL(k_inflate_tok2, dim3((nb + 63) / 64), dim3(64), T2_LDS_BYTES, sa, st.src, st.tab.p, nb, B.bbase, st.flags.p, st.tok.p, st.ntok.p);
+            else if (tok_prof && k == 8) hipLaunchKernelGGL(k_inflate_tok2<true>, dim3((nb + 63) / 64), dim3(64), T2_LDS_BYTES, sa, st.src, st.tab.p, nb, B.bbase, st.flags.p, st.tok.p, st.ntok.p, D.tok_prof.p);
+            else hipLaunchKernelGGL(k_inflate_tok2<false>, dim3((nb + 63) / 64), dim3(64), T2_LDS_BYTES, sa, st.src, st.tab.p, nb, B.bbase, st.flags.p, st.tok.p, st.ntok.p, nullptr);
         }
         HIPCHK(hipEventRecord(st.ready, sa));
         return SQ_OK;
@@ -3233,6 +3301,16 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     }
     for (auto& q : D.il_stream) HIPCHK(hipStreamSynchronize(q));
     HIPCHK(hipStreamSynchronize(D.il_tok_stream));
+    if (tok_prof && batches.size() > 8) {  // (batch 8 ran the instrumented kernel)
+        const int nw = (int)((batches[8].end - batches[8].at + 63) / 64);
+        std::vector<unsigned long long> hp(8 * (size_t)nw);
+        HIPCHK(hipMemcpy(hp.data(), D.tok_prof.p, hp.size() * 8, hipMemcpyDeviceToHost));
+        double sum[8] = {0};
+        for (int w = 0; w < nw; ++w) for (int q = 0; q < 8; ++q) sum[q] += (double)hp[8 * (size_t)w + q];
+        const double steps = sum[6] / nw;
+        std::fprintf(stderr, "token pass profile (batch 8, %d waves, %.0f steps per wave; s_memtime ticks per step): emit+header %.1f, header->topup-check %.1f, topup %.1f, ll decode %.1f, match path %.1f, loop/literal %.1f\n",
+                     nw, steps, sum[0] / sum[6], sum[1] / sum[6], sum[2] / sum[6], sum[3] / sum[6], sum[4] / sum[6], sum[7] / sum[6]);
+    }
     if (report) std::fprintf(stderr, "GPU ingest: first two batches queued after %.1f ms, all %zu batches through after %.1f ms (%.1f ms since entry; %llu MB per batch, %llu bytes left incomplete at the end)\n", w_first, batches.size(), since_ms(w0), since_ms(w_entry), cap >> 20, carry);
     return SQ_OK;
 }
