@@ -661,28 +661,35 @@ struct FRest {
     }
 };
 
-// what the next shard has to know about the last pass-1 / pass-2 record of this one (last[] = inclusive max of FPrev)
-__global__ void k_last_info(RecView R, const int32_t* last, int32_t* out) {
+// what the next shard has to know about the last pass-1 / pass-2 record of this one
+__global__ void k_last_info(RecView R, const uint8_t* cls, int32_t* out) {
     for (int p = 0; p < 2; ++p) {
-        int q = last[p];
+        const uint8_t bit = p ? C_P2 : C_P1;
+        int64_t q = R.n - 1;
+        while (q >= 0 && !(cls[q] & bit)) --q;
         out[2 * p] = q >= 0 ? 1 : 0;
         bool empty = false;
         if (q >= 0) { ListRec l = list_rec(R, q); empty = l.nown == 0 && !l.stub; }
         out[2 * p + 1] = empty ? 1 : 0;
     }
 }
+// The record a passing record is compared with is the previous one that passes the same filter: nearly always the neighbour, so
+// the kernel looks for it itself (a byte per step back through cls[]) instead of reading it from two prefix-max scans.
 // prior_mask (chromosome-sharded runs): bit0 / bit1 = a pass-1 / pass-2 record with non-empty lists precedes this
 // shard; it lies on another chromosome, so the first passing record here is not Equal to it.  Without the bit the
 // predecessor is the empty initial lastreadrec (or a record whose lists are just as empty).
-__global__ void k_dedup(RecView R, const uint8_t* cls, const int32_t* prev1, const int32_t* prev2, int prior_mask, uint8_t* keep) {
+__global__ void k_dedup(RecView R, const uint8_t* cls, int prior_mask, uint8_t* keep) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R.n) return;
     uint8_t c = cls[r], k = 0;
-    if (c & C_P1) { if (!((prev1[r] < 0 && (prior_mask & 1)) ? false : rec_equal(R, prev1[r], r))) k |= K_1; }
+    auto prev_of = [&](uint8_t bit) { int64_t q = r - 1; while (q >= 0 && !(cls[q] & bit)) --q; return q; };
+    int64_t p1 = -1;
+    if (c & C_P1) { p1 = prev_of(C_P1); if (!((p1 < 0 && (prior_mask & 1)) ? false : rec_equal(R, p1, r))) k |= K_1; }
     if (c & C_P2) {
+        const int64_t p2 = prev_of(C_P2);
         bool eq;
-        if (prev2[r] < 0) eq = (prior_mask & 2) ? false : rec_equal(R, -1, r);
-        else eq = (c & C_P1) && prev1[r] == prev2[r] ? !(k & K_1) : rec_equal(R, prev2[r], r);
+        if (p2 < 0) eq = (prior_mask & 2) ? false : rec_equal(R, -1, r);
+        else eq = (c & C_P1) && p1 == p2 ? !(k & K_1) : rec_equal(R, p2, r);
         if (!eq) {
             k |= K_2;
             // whetherbuildedge (SegmentGraph.cpp:1601-1605) on the stub-augmented, sorted record
@@ -1017,22 +1024,18 @@ __device__ __forceinline__ bool rec_block0(const RecView& R, int64_t r, int& c, 
     if (l.size(1) > 0) { int m; list_key(R, r, l, 1, 0, c, p, m); end = p + m; return true; }
     return false;
 }
-constexpr int B0_DEEP = 1 << 30;
-__global__ void k_block0(RecView R, NodeView N, const uint8_t* keep, const int32_t* part_prev, int32_t* part_next, int32_t* b0_a, int32_t* b0_b, int32_t* b0_home) {
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R.n || !(keep[r] & K_BUILD)) return;
-    if (part_prev[r] >= 0) part_next[part_prev[r]] = (int32_t)r;
-    int c, p, end, a = 1, b = 0, home = -1;
-    bool deep = false;
+// block 0 of record r against the node table: fitting range [a, b] (a > b: none), home node, and `deep`: block 0 lies deep inside
+// its home node -- then, whatever hint arrives, LocateRead puts it into `home` (from a node below the walk goes up to the first
+// fitting node, from one above it comes down to the last, and `home` is the only one), so the record needs no incoming hint
+__device__ __forceinline__ void block0_fit(const RecView& R, const NodeView& N, int64_t r, int& a, int& b, int& home, bool& deep) {
+    int c, p, end;
+    a = 1; b = 0; home = -1; deep = false;
     if (rec_block0(R, r, c, p, end) && c >= 0 && c < N.n_ref) {
         home = node_home(N, c, p);
         const int hp = N.pos[home], he = hp + N.len[home];
         if (end > hp + 5 && p < he - 5 && end <= he + 5) { a = home; b = home; deep = true; }  // deep inside its node: no neighbour can fit
         else fit_range(N, c, p, end, a, b, home);
     }
-    // B0_DEEP: whatever hint arrives, LocateRead puts block 0 into `home` (from a node below the walk goes up to the first
-    // fitting node, from one above it comes down to the last, and `home` is the only one) -- k_edges then needs no incoming hint
-    b0_a[r] = a; b0_b[r] = b; b0_home[r] = deep ? (home | B0_DEEP) : home;
 }
 // hint transfer of one record: x -> node of its block 0 if located, else x (SegmentGraph.cpp:1607-1609)
 __device__ __forceinline__ int hint_step(int x, int a, int b, int home) {
@@ -1085,36 +1088,35 @@ __device__ __forceinline__ bool dev_edge_discordant(const NodeView& N, const Edg
     return false;
 }
 
-__global__ void k_edges(RecView R, NodeView N, EdgeParams P, const uint8_t* keep, const int32_t* part_prev, const int32_t* part_next, const int32_t* b0_a,
-                        const int32_t* b0_b, const int32_t* b0_home, unsigned long long* hk, uint32_t* hv, uint32_t hmask, int32_t* flags, int32_t* stripes) {
+__global__ void k_edges(RecView R, NodeView N, EdgeParams P, const uint8_t* keep, unsigned long long* hk, uint32_t* hv, uint32_t hmask, int32_t* flags, int32_t* stripes) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R.n || !(keep[r] & K_BUILD)) return;
-    // ---- incoming hint: walk back to a record whose block 0 pins the hint, then replay forward.  Most records never need it:
-    // when block 0 lies deep inside its node (B0_DEEP) every incoming hint leads to that node, so the chain of dependent loads
-    // (previous record -> its fitting range -> ...) is only followed by the few records that really consult the hint
-    // (block 0 near a node boundary; an unlocatable block that leaves the running index outside the table; > OWNCAP blocks).
+    // ---- incoming hint (SegmentGraph.cpp:1607-1609: the node of the previous record's block 0).  Most records never need it: when
+    // block 0 lies deep inside its node every incoming hint leads to that node (block0_fit), and that node is where the running
+    // index starts.  Only the few that really consult the hint -- block 0 near a node boundary, an unlocatable block that leaves
+    // the running index outside the table, more than OWNCAP blocks -- walk back through the participating records (keep[] &
+    // K_BUILD) to one whose block 0 pins the hint, then replay forward; their block-0 fits are recomputed on the way (no
+    // per-record arrays, no separate pass).
+    auto prev_part = [&](int64_t q) { --q; while (q >= 0 && !(keep[q] & K_BUILD)) --q; return q; };
+    auto next_part = [&](int64_t q) { ++q; while (q < R.n && !(keep[q] & K_BUILD)) ++q; return q; };
     auto incoming_hint = [&]() -> int {
-        int h;
-        int64_t q = part_prev[r];
-        int steps = 0;
-        while (q >= 0 && !(b0_a[q] == b0_b[q])) { q = part_prev[q]; ++steps; }
-        if (q >= 0) h = b0_a[q]; else { h = 0; q = -1; }
-        if (steps > 0) {
-            // replay the un-pinned records between the anchor and r (rare)
-            int64_t t = (q >= 0) ? part_next[q] : -2;
-            if (q < 0) {  // no anchor: start from the first participating record
-                int64_t first = r;
-                while (part_prev[first] >= 0) first = part_prev[first];
-                t = first;
-            }
-            while (t != r) { h = hint_step(h, b0_a[t], b0_b[t], b0_home[t] & ~B0_DEEP); t = part_next[t]; }
+        int h = 0, a, b, home;
+        bool deep;
+        int64_t q = prev_part(r), anchor = -1;
+        while (q >= 0) {
+            block0_fit(R, N, q, a, b, home, deep);
+            if (a == b) { anchor = q; h = a; break; }
+            q = prev_part(q);
         }
+        // replay the un-pinned records between the anchor (or the start of the stream, hint 0) and r
+        for (int64_t t = next_part(anchor); t < r; t = next_part(t)) { block0_fit(R, N, t, a, b, home, deep); h = hint_step(h, a, b, home); }
         return h;
     };
-    const int home0 = b0_home[r];
-    const bool deep0 = home0 >= 0 && (home0 & B0_DEEP);
+    int a0, b0, home0;
+    bool deep0;
+    block0_fit(R, N, r, a0, b0, home0, deep0);
     bool hint_known = !deep0;
-    int hint = deep0 ? (home0 & ~B0_DEEP) : incoming_hint();
+    int hint = deep0 ? home0 : incoming_hint();
     // ---- the stub-augmented, read-offset-sorted record is streamed block by block (own blocks first for a first-mate
     // record, the 15-base mate stub first otherwise); everything LocateRead + the edge rules need is carried in
     // registers: no per-thread arrays, no scratch
@@ -3369,7 +3371,7 @@ int dev_classify(sq_ctx* c, int32_t last_info[4]) {
     hipStream_t s = c->stream;
     const int64_t n = D.n;
     RecView R = D.view();
-    HIPCHK(D.cls.reserve(n)); HIPCHK(D.keep.reserve(n)); HIPCHK(D.prev1.reserve(n)); HIPCHK(D.prev2.reserve(n)); HIPCHK(D.rank1.reserve(n)); HIPCHK(D.restoff.reserve(n));
+    HIPCHK(D.cls.reserve(n)); HIPCHK(D.keep.reserve(n)); HIPCHK(D.rank1.reserve(n)); HIPCHK(D.restoff.reserve(n));
     if (std::getenv("SQUID_CALIB")) {
         const int64_t words = (int64_t)1 << 28;  // 1 GiB: larger than the 256 MiB Infinity Cache
         HIPCHK(D.calib.reserve(words));
@@ -3379,13 +3381,9 @@ int dev_classify(sq_ctx* c, int32_t last_info[4]) {
     }
     if (last_info) { last_info[0] = last_info[1] = last_info[2] = last_info[3] = 0; }
     if (n == 0) return SQ_OK;
-    int32_t* last = D.flags.p + 20;  // [20],[21]: index of the last pass-1 / pass-2 record
     { EvTimer t(c, "k_classify", 28.0 * n + 12.0 * D.nb); hipLaunchKernelGGL(k_classify, grid_for(n, 256), dim3(256), 0, s, R, c->P.min_mapqual, D.cls.p); }
-    { EvTimer t(c, "scan_prev", 2.0 * n);
-      HIPCHK((device_scan<OpMax, true>(s, n, FPrev{D.cls.p, C_P1}, D.prev1.p, D.spine, last)));
-      HIPCHK((device_scan<OpMax, true>(s, n, FPrev{D.cls.p, C_P2}, D.prev2.p, D.spine, last + 1))); }
     if (last_info) {
-        hipLaunchKernelGGL(k_last_info, dim3(1), dim3(1), 0, s, R, last, D.flags.p + 24);
+        hipLaunchKernelGGL(k_last_info, dim3(1), dim3(1), 0, s, R, D.cls.p, D.flags.p + 24);
         HIPCHK(hipMemcpyAsync(last_info, D.flags.p + 24, 16, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
     }
@@ -3401,7 +3399,7 @@ int dev_dedup_summarise(sq_ctx* c) {
     int32_t h_tot[2] = {0, 0};
     if (n > 0) {
         const double bytes_rec = 32.0 * n + 12.0 * D.nb;
-        { EvTimer t(c, "k_dedup", 2.0 * bytes_rec); hipLaunchKernelGGL(k_dedup, grid_for(n, 256), dim3(256), 0, s, R, D.cls.p, D.prev1.p, D.prev2.p, c->shard.on ? c->shard.dedup_mask : 0, D.keep.p); }
+        { EvTimer t(c, "k_dedup", bytes_rec + 1.0 * n); hipLaunchKernelGGL(k_dedup, grid_for(n, 256), dim3(256), 0, s, R, D.cls.p, c->shard.on ? c->shard.dedup_mask : 0, D.keep.p); }
         { EvTimer t(c, "scan_rank", 4.0 * n);
           HIPCHK((device_scan<OpSum, true>(s, n, FKeep{D.keep.p, K_1}, D.rank1.p, D.spine, tot)));
           HIPCHK((device_scan<OpSum, true>(s, n, FRest{D.keep.p, D.cls.p, D.blk_off.p}, D.restoff.p, D.spine, tot + 1))); }
@@ -3651,11 +3649,6 @@ int dev_concordant_edges(sq_ctx* c, const std::vector<Node>& nodes, std::vector<
     if (D.nv.n != (int)nodes.size()) return fail(c, SQ_E_ARG, "internal: dev_upload_nodes first");
     const NodeView nv = D.nv;
     RecView R = D.view();
-    HIPCHK(D.part_prev.reserve(n)); HIPCHK(D.part_next.reserve(n)); HIPCHK(D.b0_a.reserve(n)); HIPCHK(D.b0_b.reserve(n)); HIPCHK(D.b0_home.reserve(n));
-    { EvTimer t(c, "scan_part", 1.0 * n); HIPCHK((device_scan<OpMax, true>(s, n, FPart{D.keep.p}, D.part_prev.p, D.spine, nullptr))); }
-    HIPCHK(hipMemsetAsync(D.part_next.p, 0xff, (size_t)n * 4, s));
-    { EvTimer t(c, "k_block0", 33.0 * n + 12.0 * D.nb);
-      hipLaunchKernelGGL(k_block0, grid_for(n, 256), dim3(256), 0, s, R, nv, D.keep.p, D.part_prev.p, D.part_next.p, D.b0_a.p, D.b0_b.p, D.b0_home.p); }
     EdgeParams ep{c->P.concord_dist_pos, c->P.concord_dist_idx};
     D.pin.reset();
     int32_t* h = D.pin.take_n<int32_t>(8 + NSTRIPE);
@@ -3669,9 +3662,8 @@ int dev_concordant_edges(sq_ctx* c, const std::vector<Node>& nodes, std::vector<
         HIPCHK(hipMemsetAsync(D.h_val.p, 0, (size_t)slots * 4, s));
         HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
         HIPCHK(hipMemsetAsync(D.stripes.p, 0, NSTRIPE * 4, s));
-        { EvTimer t(c, "k_edges", 28.0 * n + 12.0 * D.nb);
-          hipLaunchKernelGGL(k_edges, grid_for(n, 256), dim3(256), 0, s, R, nv, ep, D.keep.p, D.part_prev.p, D.part_next.p, D.b0_a.p, D.b0_b.p, D.b0_home.p, D.h_key.p, D.h_val.p, slots - 1,
-                             D.flags.p, D.stripes.p); }
+        { EvTimer t(c, "k_edges", 29.0 * n + 12.0 * D.nb);
+          hipLaunchKernelGGL(k_edges, grid_for(n, 256), dim3(256), 0, s, R, nv, ep, D.keep.p, D.h_key.p, D.h_val.p, slots - 1, D.flags.p, D.stripes.p); }
         // compact right away (wasted only if the table turns out to have overflowed): one synchronisation for both
         { EvTimer t(c, "k_hash_compact", 12.0 * slots); hipLaunchKernelGGL(k_hash_compact, grid_for(slots, 256), dim3(256), 0, s, D.h_key.p, D.h_val.p, slots, D.flags.p + 4, D.okey.p, D.oval.p); }
         HIPCHK(hipMemcpyAsync(h, D.flags.p, 8 * 4, hipMemcpyDeviceToHost, s));

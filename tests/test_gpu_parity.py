@@ -699,6 +699,36 @@ def test_gpu_bgzf_inflate_and_boundary_search_give_the_same_records(built, synth
         assert run(alt, dict(gpu, SQUID_GPU_INFLATE_ONEPASS="1")) == want, name
 
 
+def test_gpu_reader_end_to_end_against_the_oracle(built, synth, tmp_path):
+    """the GPU reader (k_inflate_tok2 / k_inflate_lanes, k_lz_resolve, k_rec_*, K0) feeding the whole pipeline, checked against the
+    ORACLE (which reads the files with its own zlib-based BAM reader) -- not only against the library's host reader: `squid`
+    with SQUID_GPU_INFLATE=1 on the generator's file and on the same records re-compressed as stored blocks, with the fixed
+    Huffman code and with every block type mixed inside one wave; _sv.txt and _graph.txt byte for byte"""
+    import os
+    import zlib
+
+    pre = synth("T2", "--indel-frac", "0.2")
+    sv_path, _ = ou.run_oracle(built, pre, tmp_path / "o", "-G", "1")
+    want_sv, want_graph = sv_path.read_text(), (tmp_path / "o" / "oracle_graph.txt").read_text()
+    plans = {
+        "asis": None,
+        "stored": lambda i: (0, zlib.Z_DEFAULT_STRATEGY),
+        "fixed": lambda i: (6, zlib.Z_FIXED),
+        "mixed": lambda i: [(0, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (9, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE)][i % 5],
+    }
+    for name, plan in plans.items():
+        bam = Path(f"{pre}.bam")
+        if plan is not None:
+            bam = tmp_path / f"{name}.bam"
+            _rebgzf(f"{pre}.bam", bam, plan)
+        for env in ({"SQUID_GPU_INFLATE": "1"}, {"SQUID_GPU_INFLATE": "1", "SQUID_TOK_V1": "1"}):
+            out = tmp_path / f"gpu_{name}_{len(env)}"
+            subprocess.run([str(built / "squid"), "-b", str(bam), "-c", f"{pre}.chim.bam", "-o", str(out), "-G", "1"], check=True, env=dict(os.environ, **env),
+                           stdout=subprocess.DEVNULL)
+            assert Path(f"{out}_sv.txt").read_text() == want_sv, (name, env)
+            assert Path(f"{out}_graph.txt").read_text() == want_graph, (name, env)
+
+
 def test_record_cache_round_trip_and_refusals(built, synth, tmp_path):
     """sq_save_records / sq_load_records: a second context that loads the cache instead of the
     BAM holds the same arrays and writes the same _sv.txt (also with other graph parameters: -w sweep); a cache written

@@ -23,7 +23,8 @@ def load(path):
 fetch, write = load(sys.argv[1]), load(sys.argv[2])
 cal = [v for k, vs in fetch.items() if "k_calib_read4" in k for v in vs]
 factor = (1 << 30) / (sum(cal) / len(cal)) if cal else None
-out = {"_calibration": {"kernel": "k_calib_read4", "bytes": 1 << 30, "fetch_counts": cal, "bytes_per_count": factor}}
+out = {"_workload": sys.argv[3] if len(sys.argv) > 3 else None,
+       "_calibration": {"kernel": "k_calib_read4", "bytes": 1 << 30, "fetch_counts": cal, "bytes_per_count": factor}}
 for k in sorted(fetch):
     if "k_calib" in k or not (k.startswith("k_") or "k_scan" in k):
         continue
