@@ -45,6 +45,7 @@ struct RecView {  // raw device pointers, passed by value to kernels
     const uint32_t* blk_off;
     const int32_t *b_refpos, *b_matchref;
     const uint16_t *b_readpos, *b_matchread;
+    const int4* b_pack;  // the same block as ONE 16-byte load: refpos, matchref, readpos | matchread << 16, 0 (k_pack_blocks; used by k_edges)
 };
 struct NodeView {
     int32_t n, n_ref;
@@ -53,6 +54,7 @@ struct NodeView {
     // coarse position index: bucket[bucket_off[c] + (p >> NODE_BUCKET_SHIFT)] = node that contains the first base of
     // that 16 KiB stretch of chromosome c, so a lookup is one load plus a short walk instead of a 17-step binary search
     const int32_t *bucket, *bucket_off;
+    const int4* pack;  // chr, pos, len, 0 of a node as one 16-byte load (k_node_pack)
 };
 constexpr int NODE_BUCKET_SHIFT = 14;
 
@@ -127,6 +129,7 @@ struct DeviceRecords {
     DBuf<uint16_t> flag, totlen, b_readpos, b_matchread;
     DBuf<uint8_t> mapq, aux;
     DBuf<uint32_t> blk_off;
+    DBuf<int4> b_pack, n_pack;
     // derived
     DBuf<uint8_t> cls, keep;
     DBuf<int32_t> prev1, prev2, rank1, restoff, scratch_a, scratch_b, scratch_c, spine;
@@ -180,7 +183,7 @@ struct DeviceRecords {
         v.n = n; v.nb = nb;
         v.refid = refid.p; v.pos = pos.p; v.mrefid = mrefid.p; v.mpos = mpos.p; v.endpos = endpos.p;
         v.flag = flag.p; v.totlen = totlen.p; v.mapq = mapq.p; v.aux = aux.p; v.blk_off = blk_off.p;
-        v.b_refpos = b_refpos.p; v.b_matchref = b_matchref.p; v.b_readpos = b_readpos.p; v.b_matchread = b_matchread.p;
+        v.b_refpos = b_refpos.p; v.b_matchref = b_matchref.p; v.b_readpos = b_readpos.p; v.b_matchread = b_matchread.p; v.b_pack = b_pack.p;
         return v;
     }
 };
@@ -197,8 +200,9 @@ struct DBlk { int32_t refid, refpos, matchref, readpos, matchread; bool rev; };
 __device__ __forceinline__ DBlk own_block_sorted(const RecView& R, int64_t r, int k, int nblk, bool rev) {
     uint32_t b = R.blk_off[r] + (rev ? (uint32_t)(nblk - 1 - k) : (uint32_t)k);
     DBlk x;
-    x.refid = R.refid[r]; x.refpos = R.b_refpos[b]; x.matchref = R.b_matchref[b];
-    x.readpos = R.b_readpos[b]; x.matchread = R.b_matchread[b]; x.rev = rev;
+    const int4 q = R.b_pack[b];  // refpos, matchref, readpos | matchread << 16: one 16-byte load instead of four
+    x.refid = R.refid[r]; x.refpos = q.x; x.matchref = q.y;
+    x.readpos = (int)((uint32_t)q.z & 0xffffu); x.matchread = (int)((uint32_t)q.z >> 16); x.rev = rev;
     return x;
 }
 __device__ __forceinline__ bool has_stub(const RecView& R, int64_t r) { return !(R.flag[r] & 0x8) && R.mrefid[r] != -1; }
@@ -278,6 +282,15 @@ __global__ void k_node_buckets(NodeView N, int total, int32_t* bucket) {
     int lo = 0, hi = N.n_ref;  // chromosome of this bucket: last c with bucket_off[c] <= g
     while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (N.bucket_off[mid] <= g) lo = mid; else hi = mid; }
     bucket[g] = node_home_search(N, lo, (g - N.bucket_off[lo]) << NODE_BUCKET_SHIFT);
+}
+
+__global__ void k_node_pack(int n, const int32_t* chr, const int32_t* pos, const int32_t* len, int4* pack) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pack[i] = make_int4(chr[i], pos[i], len[i], 0);
+}
+__global__ void k_pack_blocks(int64_t from, int64_t to, const int32_t* refpos, const int32_t* matchref, const uint16_t* readpos, const uint16_t* matchread, int4* pack) {
+    const int64_t b = from + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < to) pack[b] = make_int4(refpos[b], matchref[b], (int)((uint32_t)readpos[b] | ((uint32_t)matchread[b] << 16)), 0);
 }
 
 // ------------------------------------------------------------------------------------------------ scans
@@ -661,6 +674,44 @@ struct FRest {
     }
 };
 
+// ReadRec_t::Equal (ReadRec.cpp:119-141) on two records whose fixed fields are already in registers: the loads of both records are
+// issued together and up front (rec_equal above re-reads them field by field inside its loops, one dependent round trip each)
+struct RecKey { int nown, rid, mrid, mp; uint32_t bo; bool first, rev, stub; int4 e0; };  // e0: the first own block in read order
+__device__ __forceinline__ RecKey rec_key(const RecView& R, int64_t r) {
+    RecKey k;
+    k.e0 = make_int4(0, 0, 0, 0);
+    if (r < 0) { k.nown = 0; k.rid = 0; k.mrid = 0; k.mp = 0; k.bo = 0; k.first = true; k.rev = false; k.stub = false; return k; }  // the empty initial lastreadrec
+    const int flag = R.flag[r];
+    const uint32_t b0 = R.blk_off[r], b1 = R.blk_off[r + 1];
+    k.rid = R.refid[r]; k.mrid = R.mrefid[r]; k.mp = R.mpos[r];
+    k.nown = (int)(b1 - b0); k.bo = b0; k.first = flag & 0x40; k.rev = flag & 0x10; k.stub = !(flag & 0x8) && k.mrid != -1;
+    if (k.nown > 0) k.e0 = R.b_pack[b0 + (k.rev ? (uint32_t)(k.nown - 1) : 0u)];
+    return k;
+}
+__device__ __forceinline__ int key_size(const RecKey& k, int L) { const bool own = (L == 0) == k.first; return own ? k.nown : (k.stub ? 1 : 0); }
+__device__ __forceinline__ void key_elem(const RecView& R, const RecKey& k, int L, int e, int& id, int& p, int& m) {
+    const bool own = (L == 0) == k.first;
+    if (own) { const int4 q = e == 0 ? k.e0 : R.b_pack[k.bo + (k.rev ? (uint32_t)(k.nown - 1 - e) : (uint32_t)e)]; id = k.rid; p = q.x; m = q.y; }
+    else { id = k.mrid; p = k.mp; m = 15; }
+}
+__device__ bool key_equal(const RecView& R, const RecKey& kq, const RecKey& kr) {
+    for (int swap = 0; swap < 2; ++swap) {
+        const int q0 = key_size(kq, swap ? 1 : 0), q1 = key_size(kq, swap ? 0 : 1);
+        if (q0 != key_size(kr, 0) || q1 != key_size(kr, 1)) continue;
+        bool same = true;
+        for (int L = 0; L < 2 && same; ++L) {
+            const int n = key_size(kr, L);
+            for (int e = 0; e < n; ++e) {
+                int a0, a1, a2, b0, b1, b2;
+                key_elem(R, kr, L, e, a0, a1, a2);
+                key_elem(R, kq, swap ? 1 - L : L, e, b0, b1, b2);
+                if (a0 != b0 || a1 != b1 || a2 != b2) { same = false; break; }
+            }
+        }
+        if (same) return true;
+    }
+    return false;
+}
 // what the next shard has to know about the last pass-1 / pass-2 record of this one
 __global__ void k_last_info(RecView R, const uint8_t* cls, int32_t* out) {
     for (int p = 0; p < 2; ++p) {
@@ -681,25 +732,28 @@ __global__ void k_last_info(RecView R, const uint8_t* cls, int32_t* out) {
 __global__ void k_dedup(RecView R, const uint8_t* cls, int prior_mask, uint8_t* keep) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R.n) return;
+    // this record and its predecessor (nearly always the previous passing record of both passes) are loaded together, before
+    // the class bytes say whether either is needed: two round trips instead of a chain of five
+    const RecKey kr = rec_key(R, r), km = rec_key(R, r - 1);
     uint8_t c = cls[r], k = 0;
+    if (!(c & (C_P1 | C_P2))) { keep[r] = 0; return; }
     auto prev_of = [&](uint8_t bit) { int64_t q = r - 1; while (q >= 0 && !(cls[q] & bit)) --q; return q; };
+    auto key_of = [&](int64_t q) { return q == r - 1 ? km : rec_key(R, q); };
     int64_t p1 = -1;
-    if (c & C_P1) { p1 = prev_of(C_P1); if (!((p1 < 0 && (prior_mask & 1)) ? false : rec_equal(R, p1, r))) k |= K_1; }
+    if (c & C_P1) { p1 = prev_of(C_P1); if (!((p1 < 0 && (prior_mask & 1)) ? false : key_equal(R, key_of(p1), kr))) k |= K_1; }
     if (c & C_P2) {
         const int64_t p2 = prev_of(C_P2);
         bool eq;
-        if (p2 < 0) eq = (prior_mask & 2) ? false : rec_equal(R, -1, r);
-        else eq = (c & C_P1) && p1 == p2 ? !(k & K_1) : rec_equal(R, p2, r);
+        if (p2 < 0) eq = (prior_mask & 2) ? false : key_equal(R, rec_key(R, -1), kr);
+        else eq = (c & C_P1) && p1 == p2 ? !(k & K_1) : key_equal(R, key_of(p2), kr);
         if (!eq) {
             k |= K_2;
             // whetherbuildedge (SegmentGraph.cpp:1601-1605) on the stub-augmented, sorted record
-            ListRec l = list_rec(R, r);
             bool build;
-            if (l.size(0) == 0 || l.size(1) == 0) build = true;
+            if (key_size(kr, 0) == 0 || key_size(kr, 1) == 0) build = true;
             else {
                 // the stub side always has ReadPos 0 <= 15; the own side is tested with its own low-Phred flag
-                DBlk f = own_block_sorted(R, r, 0, l.nown, l.rev);
-                build = f.readpos <= 15 || (R.aux[r] & SQ_AUX_LOWPHRED);
+                build = (int)((uint32_t)kr.e0.z & 0xffffu) <= 15 || (R.aux[r] & SQ_AUX_LOWPHRED);
             }
             if (build) k |= K_BUILD;
         }
@@ -994,15 +1048,16 @@ __device__ __forceinline__ void fit_range(const NodeView& N, int c, int p, int e
 __device__ __forceinline__ int locate_one(const NodeView& N, int c, int p, int end, int& i, int initialguess) {
     if (i < 0 || i >= N.n) i = initialguess;
     if (c < 0 || c >= N.n_ref) {  // no node can match: the scan runs off one end of the table
-        if (N.chr[i] < c) i = N.n; else i = -1;
+        if (N.pack[i].x < c) i = N.n; else i = -1;
         return -1;
     }
     // the running node usually still fits (+-5 test of SegmentGraph.cpp:1213): no search needed
-    if (N.chr[i] == c && p >= N.pos[i] - 5 && end <= N.pos[i] + N.len[i] + 5) return i;
+    const int4 ni = N.pack[i];  // chr, pos, len in one load
+    if (ni.x == c && p >= ni.y - 5 && end <= ni.y + ni.z + 5) return i;
     int a, b, home;
     fit_range(N, c, p, end, a, b, home);
     bool nonempty = a <= b;
-    bool up = N.chr[i] < c || (N.chr[i] == c && N.pos[i] <= p);
+    bool up = ni.x < c || (ni.x == c && ni.y <= p);
     if (up) {
         if (nonempty && a >= i) { i = a; return a; }
         i = N.chr_start[c + 1];  // first node of a later chromosome, or N.n
@@ -1032,7 +1087,8 @@ __device__ __forceinline__ void block0_fit(const RecView& R, const NodeView& N, 
     a = 1; b = 0; home = -1; deep = false;
     if (rec_block0(R, r, c, p, end) && c >= 0 && c < N.n_ref) {
         home = node_home(N, c, p);
-        const int hp = N.pos[home], he = hp + N.len[home];
+        const int4 nh = N.pack[home];
+        const int hp = nh.y, he = hp + nh.z;
         if (end > hp + 5 && p < he - 5 && end <= he + 5) { a = home; b = home; deep = true; }  // deep inside its node: no neighbour can fit
         else fit_range(N, c, p, end, a, b, home);
     }
@@ -1082,15 +1138,19 @@ struct EdgeParams { int dp, di; };
 __device__ __forceinline__ bool dev_edge_discordant(const NodeView& N, const EdgeParams& P, int i, bool hi, int j, bool hj) {
     int a = i, b = j; bool ha = hi, hb = hj;
     if (i > j) { a = j; ha = hj; b = i; hb = hi; }
-    if (N.chr[a] != N.chr[b]) return true;
-    if (N.pos[b] - N.pos[a] - N.len[a] > P.dp && b - a > P.di) return true;
+    const int4 na = N.pack[a], nb = N.pack[b];
+    if (na.x != nb.x) return true;
+    if (nb.y - na.y - na.z > P.dp && b - a > P.di) return true;
     if (ha != false || hb != true) return true;
     return false;
 }
 
-__global__ void k_edges(RecView R, NodeView N, EdgeParams P, const uint8_t* keep, unsigned long long* hk, uint32_t* hv, uint32_t hmask, int32_t* flags, int32_t* stripes) {
+struct EdgeParams2 { int dp, di, ablate; };
+__global__ void k_edges(RecView R, NodeView N, EdgeParams2 P2, const uint8_t* keep, unsigned long long* hk, uint32_t* hv, uint32_t hmask, int32_t* flags, int32_t* stripes) {
+    const EdgeParams P{P2.dp, P2.di};
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R.n || !(keep[r] & K_BUILD)) return;
+    if (P2.ablate & 4) { if (R.flag[r] == 0xffff) flags[1] = 1; return; }
     // ---- incoming hint (SegmentGraph.cpp:1607-1609: the node of the previous record's block 0).  Most records never need it: when
     // block 0 lies deep inside its node every incoming hint leads to that node (block0_fit), and that node is where the running
     // index starts.  Only the few that really consult the hint -- block 0 near a node boundary, an unlocatable block that leaves
@@ -1112,18 +1172,61 @@ __global__ void k_edges(RecView R, NodeView N, EdgeParams P, const uint8_t* keep
         for (int64_t t = next_part(anchor); t < r; t = next_part(t)) { block0_fit(R, N, t, a, b, home, deep); h = hint_step(h, a, b, home); }
         return h;
     };
-    int a0, b0, home0;
-    bool deep0;
-    block0_fit(R, N, r, a0, b0, home0, deep0);
+    // ---- everything the record itself needs, loaded up front and independently of each other (one memory round trip instead of a
+    // chain of them): the fixed fields, both block offsets, and -- speculatively -- its first own block in read-offset order
+    const int flag = R.flag[r], rid = R.refid[r], mrid = R.mrefid[r], mp = R.mpos[r];
+    const uint32_t bo = R.blk_off[r], bo1 = R.blk_off[r + 1];
+    ListRec l;
+    l.nown = (int)(bo1 - bo); l.first = flag & 0x40; l.rev = flag & 0x10; l.stub = !(flag & 0x8) && mrid != -1;
+    const int nown = l.nown, nt = nown + (l.stub ? 1 : 0);
+    int4 q0 = make_int4(0, 0, 0, 0);
+    if (nown > 0) q0 = R.b_pack[bo + (l.rev ? (uint32_t)(nown - 1) : 0u)];
+    if (nt == 0) return;
+    const bool own_first = l.first;            // own blocks form list F (FirstRead) iff first-mate
+    // block 0 of the stub-augmented record (rec_block0): the first element of list F if it has one, else of list S
+    int c0, p0, e0;
+    {
+        const bool own0 = own_first ? nown > 0 : !l.stub;  // is block 0 an own block?  (F = own blocks iff first-mate; the other list is [stub])
+        if (own0) { c0 = rid; p0 = q0.x; e0 = q0.x + q0.y; } else { c0 = mrid; p0 = mp; e0 = mp + 15; }
+    }
+    int a0 = 1, b0 = 0, home0 = -1;
+    bool deep0 = false;
+    int ci = -1;                         // one-entry cache of the node table: most records stay inside one node
+    int4 cp = make_int4(0, 0, 0, 0);
+    if (c0 >= 0 && c0 < N.n_ref) {
+        home0 = node_home(N, c0, p0);
+        cp = N.pack[home0]; ci = home0;
+        const int hp = cp.y, he = hp + cp.z;
+        if (e0 > hp + 5 && p0 < he - 5 && e0 <= he + 5) { a0 = home0; b0 = home0; deep0 = true; }
+        else fit_range(N, c0, p0, e0, a0, b0, home0);
+    }
+    (void)a0; (void)b0;
     bool hint_known = !deep0;
     int hint = deep0 ? home0 : incoming_hint();
+    if (P2.ablate & 2) { if (hint == -12345) flags[1] = 1; return; }
+    auto node_pack = [&](int i) -> int4 { if (i != ci) { cp = N.pack[i]; ci = i; } return cp; };
+    // LocateRead for one block with running index i (locate_one), the running node's fields through the cache
+    auto locate = [&](int c, int p, int end, int& i) -> int {
+        if (i < 0 || i >= N.n) i = hint;
+        const int4 ni = node_pack(i);
+        if (c < 0 || c >= N.n_ref) { if (ni.x < c) i = N.n; else i = -1; return -1; }
+        if (ni.x == c && p >= ni.y - 5 && end <= ni.y + ni.z + 5) return i;  // the running node still fits (+-5 test of SegmentGraph.cpp:1213)
+        int a, b, home;
+        fit_range(N, c, p, end, a, b, home);
+        const bool nonempty = a <= b;
+        const bool up = ni.x < c || (ni.x == c && ni.y <= p);
+        if (up) {
+            if (nonempty && a >= i) { i = a; return a; }
+            i = N.chr_start[c + 1];
+            return -1;
+        }
+        if (nonempty && b <= i) { i = b; return b; }
+        i = N.chr_start[c] - 1;
+        return -1;
+    };
     // ---- the stub-augmented, read-offset-sorted record is streamed block by block (own blocks first for a first-mate
     // record, the 15-base mate stub first otherwise); everything LocateRead + the edge rules need is carried in
     // registers: no per-thread arrays, no scratch
-    ListRec l = list_rec(R, r);
-    const int nown = l.nown, nt = nown + (l.stub ? 1 : 0);
-    if (nt == 0) return;
-    const bool own_first = l.first;            // own blocks form list F (FirstRead) iff first-mate
     constexpr int OWNCAP = 8;
     int ownnode[OWNCAP];
 #pragma unroll
@@ -1139,12 +1242,16 @@ __global__ void k_edges(RecView R, NodeView N, EdgeParams P, const uint8_t* keep
         const bool is_stub = l.stub && (own_first ? k == nown : k == 0);
         const int ko = own_first ? k : k - (l.stub ? 1 : 0);  // index among own blocks
         int bc, bp, bm, brp, bmr; bool brev;
-        if (is_stub) { bc = R.mrefid[r]; bp = R.mpos[r]; bm = 15; brp = 0; bmr = 15; brev = R.flag[r] & 0x20; }
-        else { DBlk b = own_block_sorted(R, r, ko, nown, l.rev); bc = b.refid; bp = b.refpos; bm = b.matchref; brp = b.readpos; bmr = b.matchread; brev = b.rev; }
-        if ((i < 0 || i >= N.n) && !hint_known) { hint = incoming_hint(); hint_known = true; }  // (locate_one falls back to the incoming hint)
-        const int nd = locate_one(N, bc, bp, bp + bm, i, hint);
+        if (is_stub) { bc = mrid; bp = mp; bm = 15; brp = 0; bmr = 15; brev = flag & 0x20; }
+        else {
+            const int4 q = ko == 0 ? q0 : R.b_pack[bo + (l.rev ? (uint32_t)(nown - 1 - ko) : (uint32_t)ko)];
+            bc = rid; bp = q.x; bm = q.y; brp = (int)((uint32_t)q.z & 0xffffu); bmr = (int)((uint32_t)q.z >> 16); brev = l.rev;
+        }
+        if ((i < 0 || i >= N.n) && !hint_known) { hint = incoming_hint(); hint_known = true; }  // (the walk falls back to the incoming hint)
+        const int nd = locate(bc, bp, bp + bm, i);
         if (nd >= 0) {  // trim to the node (SegmentGraph.cpp:1229-1248)
-            int np = N.pos[nd], ne = np + N.len[nd];
+            const int4 nn = node_pack(nd);
+            int np = nn.y, ne = np + nn.z;
             if (bp < np) { int d = np - bp; if (!brev) brp += d; bm -= d; bmr -= d; bp = np; }
             if (bp + bm > ne) { int d = bp + bm - ne; if (brev) brp += d; bm -= d; bmr -= d; }
         } else {
@@ -1155,7 +1262,7 @@ __global__ void k_edges(RecView R, NodeView N, EdgeParams P, const uint8_t* keep
             else {
                 int h = node_home(N, bc, bp);
                 if (N.pos[h] == bp && h > N.chr_start[bc] && ffi <= h - 1) --h;
-                emit_edge(hk, hv, hmask, h, false, h + 1, true, flags, stripes, N.n);
+                if (!(P2.ablate & 1)) emit_edge(hk, hv, hmask, h, false, h + 1, true, flags, stripes, N.n);
             }
         }
         if (k == 0) { node0 = nd; ffi = nd != -1 ? nd : hint; }
@@ -1164,7 +1271,7 @@ __global__ void k_edges(RecView R, NodeView N, EdgeParams P, const uint8_t* keep
             if (ko == 0) { of_c = bc; of_p = bp; of_rp = brp; of_rev = brev; }
             else {
                 // consecutive blocks of one mate in different nodes (SegmentGraph.cpp:1631-1653)
-                if (pv_node != nd && pv_node != -1 && nd != -1) emit_edge(hk, hv, hmask, pv_node, pv_rev, nd, !brev, flags, stripes, N.n);
+                if (pv_node != nd && pv_node != -1 && nd != -1) if (!(P2.ablate & 1)) emit_edge(hk, hv, hmask, pv_node, pv_rev, nd, !brev, flags, stripes, N.n);
                 // IsEndDiscordant on the trimmed blocks (ReadRec.cpp:178-209)
                 if (pv_c != bc || pv_rev != brev) own_enddisc = true;
                 else {
@@ -1206,7 +1313,7 @@ __global__ void k_edges(RecView R, NodeView N, EdgeParams P, const uint8_t* keep
             else if (!of_rev && of_p - of_rp > st_p - (stot - st_rp - st_mr)) pd = true;
             else if (!st_rev && st_p - st_rp > ol_p - (ftot - ol_rp - ol_mr)) pd = true;
             else pd = false;
-            if (pd == dev_edge_discordant(N, P, a, ol_rev, b, st_rev)) emit_edge(hk, hv, hmask, a, ol_rev, b, st_rev, flags, stripes, N.n);
+            if (pd == dev_edge_discordant(N, P, a, ol_rev, b, st_rev)) if (!(P2.ablate & 1)) emit_edge(hk, hv, hmask, a, ol_rev, b, st_rev, flags, stripes, N.n);
         }
     }
 }
@@ -2921,6 +3028,7 @@ void dev_destroy(sq_ctx* c) {
     if (!c->dev) return;
     DeviceRecords& D = *c->dev;
     D.refid.release(); D.pos.release(); D.mrefid.release(); D.mpos.release(); D.endpos.release(); D.b_refpos.release(); D.b_matchref.release();
+    D.b_pack.release(); D.n_pack.release();
     D.flag.release(); D.totlen.release(); D.b_readpos.release(); D.b_matchread.release(); D.mapq.release(); D.aux.release(); D.blk_off.release();
     D.cls.release(); D.keep.release(); D.prev1.release(); D.prev2.release(); D.rank1.release(); D.restoff.release();
     D.scratch_a.release(); D.scratch_b.release(); D.scratch_c.release(); D.spine.release();
@@ -2966,6 +3074,8 @@ int dev_append_records(sq_ctx* c, const sq_aln_batch* b) {
     std::vector<uint32_t> off(nr + 1);
     for (size_t i = 0; i <= nr; ++i) off[i] = b->blk_off[i] - b->blk_off[0] + (uint32_t)nb0;
     HIPCHK(hipMemcpyAsync(D.blk_off.p + n0, off.data(), (nr + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(D.b_pack.grow_keep(nb0, nb1, s));
+    if (nb1 > nb0) hipLaunchKernelGGL(k_pack_blocks, dim3((unsigned)((nb1 - nb0 + 255) / 256)), dim3(256), 0, s, (int64_t)nb0, (int64_t)nb1, D.b_refpos.p, D.b_matchref.p, D.b_readpos.p, D.b_matchread.p, D.b_pack.p);
     HIPCHK(hipStreamSynchronize(s));
     D.n = (int64_t)n1;
     D.nb = (int64_t)nb1;
@@ -3059,6 +3169,7 @@ static int parse_device(sq_ctx* c, const uint8_t* d_bam, size_t nbytes, const un
                             GROW(flag, n0, rec_want); GROW(totlen, n0, rec_want); GROW(mapq, n0, rec_want); GROW(aux, n0, rec_want); }
     if (D.blk_off.cap < n1 + 1) GROW(blk_off, n0 ? n0 + 1 : 0, rec_want + 1);
     if (D.b_refpos.cap < nb1 + 1) { GROW(b_refpos, nb0, blk_want); GROW(b_matchref, nb0, blk_want); GROW(b_readpos, nb0, blk_want); GROW(b_matchread, nb0, blk_want); }
+    if (D.b_pack.cap < nb1 + 1) GROW(b_pack, nb0, blk_want);
 #undef GROW
     ChimSetView C{D.chim_mask, D.chim_mask ? D.chim_hash.p : nullptr, D.chim_off.p, D.chim_len.p, D.chim_blob.p};
     ParseParams P{(int)(signed char)(((c->P.phred_type ? 33 : 64) + c->P.min_phred) & 0xff), c->P.max_lowphred_len, c->P.min_mapqual};
@@ -3066,6 +3177,7 @@ static int parse_device(sq_ctx* c, const uint8_t* d_bam, size_t nbytes, const un
       hipLaunchKernelGGL(k_parse_write, grid_for(n_rec, PARSE_THREADS), dim3(PARSE_THREADS), 0, s, d_bam, nbytes, d_off, n_rec, C, P, D.parse_rel.p, (uint32_t)nb0, D.refid.p + n0, D.pos.p + n0, D.mrefid.p + n0,
                          D.mpos.p + n0, D.endpos.p + n0, D.flag.p + n0, D.totlen.p + n0, D.mapq.p + n0, D.aux.p + n0, D.blk_off.p + n0, D.b_refpos.p, D.b_matchref.p, D.b_readpos.p, D.b_matchread.p,
                          D.flags.p); }
+    if (nb1 > nb0) hipLaunchKernelGGL(k_pack_blocks, dim3((unsigned)((nb1 - nb0 + 255) / 256)), dim3(256), 0, s, (int64_t)nb0, (int64_t)nb1, D.b_refpos.p, D.b_matchref.p, D.b_readpos.p, D.b_matchread.p, D.b_pack.p);
     const uint32_t endoff = (uint32_t)nb1;
     HIPCHK(hipMemcpyAsync(D.blk_off.p + n1, &endoff, 4, hipMemcpyHostToDevice, s));
     int32_t hf = 0;
@@ -3360,6 +3472,9 @@ int dev_upload_nodes(sq_ctx* c, const std::vector<Node>& nodes) {
     NodeView& nv = D.nv;
     nv.n = n; nv.n_ref = nref; nv.chr = D.n_chr.p; nv.pos = D.n_chr.p + n; nv.len = D.n_chr.p + 2 * (size_t)n; nv.chr_start = D.n_chr.p + 3 * (size_t)n;
     nv.bucket = D.n_bucket.p; nv.bucket_off = D.n_chr.p + 3 * (size_t)n + nref + 1;
+    HIPCHK(D.n_pack.reserve((size_t)std::max(n, 1)));
+    nv.pack = D.n_pack.p;
+    if (n) hipLaunchKernelGGL(k_node_pack, dim3((n + 255) / 256), dim3(256), 0, s, n, nv.chr, nv.pos, nv.len, D.n_pack.p);
     if (total) { EvTimer t(c, "k_node_buckets", 4.0 * total); hipLaunchKernelGGL(k_node_buckets, dim3((total + 255) / 256), dim3(256), 0, s, nv, total, D.n_bucket.p); }
     HIPCHK(hipStreamSynchronize(s));  // the host vectors go out of scope
     return SQ_OK;
@@ -3649,7 +3764,7 @@ int dev_concordant_edges(sq_ctx* c, const std::vector<Node>& nodes, std::vector<
     if (D.nv.n != (int)nodes.size()) return fail(c, SQ_E_ARG, "internal: dev_upload_nodes first");
     const NodeView nv = D.nv;
     RecView R = D.view();
-    EdgeParams ep{c->P.concord_dist_pos, c->P.concord_dist_idx};
+    EdgeParams2 ep{c->P.concord_dist_pos, c->P.concord_dist_idx, std::getenv("SQUID_EDGES_ABLATE") ? std::atoi(std::getenv("SQUID_EDGES_ABLATE")) : 0};  // (debugging: parts of k_edges switched off, timing only)
     D.pin.reset();
     int32_t* h = D.pin.take_n<int32_t>(8 + NSTRIPE);
     if (!h) return fail(c, SQ_E_HIP, "hipHostMalloc failed");
