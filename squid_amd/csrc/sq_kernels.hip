@@ -51,12 +51,15 @@ struct NodeView {
     int32_t n, n_ref;
     const int32_t *chr, *pos, *len;
     const int32_t* chr_start;  // n_ref+1: first node index of each chromosome
-    // coarse position index: bucket[bucket_off[c] + (p >> NODE_BUCKET_SHIFT)] = node that contains the first base of
-    // that 16 KiB stretch of chromosome c, so a lookup is one load plus a short walk instead of a 17-step binary search
-    const int32_t *bucket, *bucket_off;
+    // position index: fine[fine_off[c] + (p >> NODE_FINE_SHIFT)] = node that contains the first base of that 1 KiB stretch of
+    // chromosome c, and one more entry per chromosome = its last node.  The node of p lies between the entries of its
+    // stretch and the next one: two loads side by side and, inside a gene, a bisection of one to three steps (round 1:
+    // a 16 KiB index, a gallop and a bisection, a dozen dependent loads)
+    const int32_t *fine, *fine_off;
+    const int32_t* bucket_off;  // geometry of the 16 KiB index the breakpoint table uses (BPView)
     const int4* pack;  // chr, pos, len, 0 of a node as one 16-byte load (k_node_pack)
 };
-constexpr int NODE_BUCKET_SHIFT = 14;
+constexpr int NODE_BUCKET_SHIFT = 14, NODE_FINE_SHIFT = 10;
 
 template <typename T>
 struct DBuf {
@@ -137,7 +140,7 @@ struct DeviceRecords {
     DBuf<StreamRec> srec;
     DBuf<int32_t> rest_refpos, rest_matchref;
     // node table
-    DBuf<int32_t> n_chr, n_bucket;  // n_chr: packed node table chr | pos | len | chr_start | bucket_off
+    DBuf<int32_t> n_chr, n_bucket;  // n_chr: packed node table chr | pos | len | chr_start | bucket_off | fine_off; n_bucket: the fine index
     NodeView nv{};  // the node table of the current graph build (dev_upload_nodes)
     DBuf<int32_t> acc_a, acc_b, acc_c;  // per-node accumulator block / small tables of the later stages
     // edge hash
@@ -258,30 +261,35 @@ __device__ __forceinline__ int node_home_search(const NodeView& N, int c, int p)
     }
     return lo;
 }
-// same result, starting from a node h of chromosome c with N.pos[h] <= p: gallop, then bisect
-__device__ __forceinline__ int node_home_from(const NodeView& N, int c, int p, int h) {
-    const int hi = N.chr_start[c + 1];
-    int step = 1;
-    while (h + step < hi && N.pos[h + step] <= p) { h += step; step <<= 1; }
-    int up = h + step < hi ? h + step : hi;
-    while (up - h > 1) {
-        int mid = (h + up) >> 1;
-        if (N.pos[mid] <= p) h = mid; else up = mid;
-    }
-    return h;
-}
+// same result through the fine index
 __device__ __forceinline__ int node_home(const NodeView& N, int c, int p) {
-    int b = N.bucket_off[c] + (p < 0 ? 0 : (p >> NODE_BUCKET_SHIFT));
-    const int last = N.bucket_off[c + 1] - 1;
+    const int first = N.fine_off[c], last = N.fine_off[c + 1] - 2;  // last stretch of c (the entry behind it is the chromosome's last node)
+    int b = first + (p < 0 ? 0 : (p >> NODE_FINE_SHIFT));
     if (b > last) b = last;  // a position behind the reference end
-    return node_home_from(N, c, p, N.bucket[b]);
+    int lo = N.fine[b], hi = N.fine[b + 1];
+    while (hi > lo) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (N.pos[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    return lo;
 }
-__global__ void k_node_buckets(NodeView N, int total, int32_t* bucket) {
+// the same with the chromosome's index geometry (fine_off[c], fine_off[c + 1]) already in registers
+__device__ __forceinline__ int node_home_geo(const NodeView& N, int first, int next, int p) {
+    int b = first + (p < 0 ? 0 : (p >> NODE_FINE_SHIFT));
+    if (b > next - 2) b = next - 2;
+    int lo = N.fine[b], hi = N.fine[b + 1];
+    while (hi > lo) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (N.pos[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+__global__ void k_node_buckets(NodeView N, int total, int32_t* fine) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
-    int lo = 0, hi = N.n_ref;  // chromosome of this bucket: last c with bucket_off[c] <= g
-    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (N.bucket_off[mid] <= g) lo = mid; else hi = mid; }
-    bucket[g] = node_home_search(N, lo, (g - N.bucket_off[lo]) << NODE_BUCKET_SHIFT);
+    int lo = 0, hi = N.n_ref;  // chromosome of this entry: last c with fine_off[c] <= g
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (N.fine_off[mid] <= g) lo = mid; else hi = mid; }
+    fine[g] = g == N.fine_off[lo + 1] - 1 ? N.chr_start[lo + 1] - 1 : node_home_search(N, lo, (g - N.fine_off[lo]) << NODE_FINE_SHIFT);
 }
 
 __global__ void k_node_pack(int n, const int32_t* chr, const int32_t* pos, const int32_t* len, int4* pack) {
@@ -738,14 +746,18 @@ __global__ void k_dedup(RecView R, const uint8_t* cls, int prior_mask, uint8_t* 
     uint8_t c = cls[r], k = 0;
     if (!(c & (C_P1 | C_P2))) { keep[r] = 0; return; }
     auto prev_of = [&](uint8_t bit) { int64_t q = r - 1; while (q >= 0 && !(cls[q] & bit)) --q; return q; };
-    auto key_of = [&](int64_t q) { return q == r - 1 ? km : rec_key(R, q); };
     int64_t p1 = -1;
-    if (c & C_P1) { p1 = prev_of(C_P1); if (!((p1 < 0 && (prior_mask & 1)) ? false : key_equal(R, key_of(p1), kr))) k |= K_1; }
+    if (c & C_P1) {
+        p1 = prev_of(C_P1);
+        bool eq = false;
+        if (!(p1 < 0 && (prior_mask & 1))) eq = p1 == r - 1 ? key_equal(R, km, kr) : key_equal(R, rec_key(R, p1), kr);
+        if (!eq) k |= K_1;
+    }
     if (c & C_P2) {
         const int64_t p2 = prev_of(C_P2);
         bool eq;
         if (p2 < 0) eq = (prior_mask & 2) ? false : key_equal(R, rec_key(R, -1), kr);
-        else eq = (c & C_P1) && p1 == p2 ? !(k & K_1) : key_equal(R, key_of(p2), kr);
+        else eq = (c & C_P1) && p1 == p2 ? !(k & K_1) : p2 == r - 1 ? key_equal(R, km, kr) : key_equal(R, rec_key(R, p2), kr);
         if (!eq) {
             k |= K_2;
             // whetherbuildedge (SegmentGraph.cpp:1601-1605) on the stub-augmented, sorted record
@@ -1032,17 +1044,31 @@ __global__ void k_gather_other(RecView R, const uint8_t* keep, const int32_t* ra
 // ------------------------------------------------------------------------------------------------ K4/K5: edges
 
 // fitting range [a,b] of nodes for a block (LocateRead's +-5 test, SegmentGraph.cpp:1213) and its home node
-__device__ __forceinline__ void fit_range(const NodeView& N, int c, int p, int end, int& a, int& b, int& home) {
-    int lo = N.chr_start[c], hi = N.chr_start[c + 1];
+// The nodes tile every chromosome (tile_genome: the first starts at 0, each starts where the one before ends), so both ends of
+// the range lie next to the home node and are reached by short walks from it -- for a block inside its home node without a
+// single further load (round 1: two bisections over the whole chromosome, two dozen dependent loads).
+__device__ __forceinline__ void fit_around(const NodeView& N, int c, int p, int end, int home, const int4& nh, int& a, int& b) {
+    const int lo = N.chr_start[c], hi = N.chr_start[c + 1];
+    // b = last node on c with pos - 5 <= p (home qualifies; the nodes behind it start at the running end)
+    b = home;
+    for (int nxt = nh.y + nh.z; b + 1 < hi && nxt - 5 <= p;) { ++b; nxt += N.len[b]; }
+    // a = first node on c with pos + len + 5 >= end (a == hi: none)
+    if (nh.y + nh.z + 5 >= end) {
+        a = home;
+        for (int pe = nh.y; a - 1 >= lo && pe + 5 >= end;) { --a; pe = N.pos[a]; }  // pe = end of node a - 1 = start of node a
+    } else {
+        a = home + 1;
+        for (int e = nh.y + nh.z; a < hi; ++a) { e += N.len[a]; if (e + 5 >= end) break; }
+    }
+}
+__device__ __forceinline__ void fit_range(const NodeView& N, int c, int p, int end, int& a, int& b, int& home, int4& nh) {
     home = node_home(N, c, p);
-    // b = last node on c with pos - 5 <= p
-    int l = home, h = hi;  // pos[home] <= p, so home qualifies
-    while (h - l > 1) { int mid = (l + h) >> 1; if (N.pos[mid] - 5 <= p) l = mid; else h = mid; }
-    b = l;
-    // a = first node on c with pos+len+5 >= end
-    l = lo - 1; h = hi;  // invariant: nodes <= l fail, nodes >= h pass (h == hi means none)
-    while (h - l > 1) { int mid = (l + h) >> 1; if (N.pos[mid] + N.len[mid] + 5 >= end) h = mid; else l = mid; }
-    a = h;
+    nh = N.pack[home];
+    fit_around(N, c, p, end, home, nh, a, b);
+}
+__device__ __forceinline__ void fit_range(const NodeView& N, int c, int p, int end, int& a, int& b, int& home) {
+    int4 nh;
+    fit_range(N, c, p, end, a, b, home, nh);
 }
 // LocateRead for one block with running index i; returns node or -1 and updates i exactly like the scan loops
 __device__ __forceinline__ int locate_one(const NodeView& N, int c, int p, int end, int& i, int initialguess) {
@@ -1090,7 +1116,7 @@ __device__ __forceinline__ void block0_fit(const RecView& R, const NodeView& N, 
         const int4 nh = N.pack[home];
         const int hp = nh.y, he = hp + nh.z;
         if (end > hp + 5 && p < he - 5 && end <= he + 5) { a = home; b = home; deep = true; }  // deep inside its node: no neighbour can fit
-        else fit_range(N, c, p, end, a, b, home);
+        else fit_around(N, c, p, end, home, nh, a, b);
     }
 }
 // hint transfer of one record: x -> node of its block 0 if located, else x (SegmentGraph.cpp:1607-1609)
@@ -1149,8 +1175,15 @@ struct EdgeParams2 { int dp, di, ablate; };
 __global__ void k_edges(RecView R, NodeView N, EdgeParams2 P2, const uint8_t* keep, unsigned long long* hk, uint32_t* hv, uint32_t hmask, int32_t* flags, int32_t* stripes) {
     const EdgeParams P{P2.dp, P2.di};
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R.n || !(keep[r] & K_BUILD)) return;
-    if (P2.ablate & 4) { if (R.flag[r] == 0xffff) flags[1] = 1; return; }
+    if (r >= R.n) return;
+    // ---- everything the record itself needs is loaded up front, the loads independent of each other (one memory round trip
+    // instead of a chain of them) and not waiting for the keep byte: the fixed fields and both block offsets; behind them, again
+    // together, the first two own blocks in read-offset order and the index geometry of the record's chromosome
+    const uint8_t kp = keep[r];
+    const int flag = R.flag[r], rid = R.refid[r], mrid = R.mrefid[r], mp = R.mpos[r];
+    const uint32_t bo = R.blk_off[r], bo1 = R.blk_off[r + 1];
+    if (!(kp & K_BUILD)) return;
+    if (P2.ablate & 4) { if (flag == 0xffff) flags[1] = 1; return; }
     // ---- incoming hint (SegmentGraph.cpp:1607-1609: the node of the previous record's block 0).  Most records never need it: when
     // block 0 lies deep inside its node every incoming hint leads to that node (block0_fit), and that node is where the running
     // index starts.  Only the few that really consult the hint -- block 0 near a node boundary, an unlocatable block that leaves
@@ -1172,15 +1205,16 @@ __global__ void k_edges(RecView R, NodeView N, EdgeParams2 P2, const uint8_t* ke
         for (int64_t t = next_part(anchor); t < r; t = next_part(t)) { block0_fit(R, N, t, a, b, home, deep); h = hint_step(h, a, b, home); }
         return h;
     };
-    // ---- everything the record itself needs, loaded up front and independently of each other (one memory round trip instead of a
-    // chain of them): the fixed fields, both block offsets, and -- speculatively -- its first own block in read-offset order
-    const int flag = R.flag[r], rid = R.refid[r], mrid = R.mrefid[r], mp = R.mpos[r];
-    const uint32_t bo = R.blk_off[r], bo1 = R.blk_off[r + 1];
     ListRec l;
     l.nown = (int)(bo1 - bo); l.first = flag & 0x40; l.rev = flag & 0x10; l.stub = !(flag & 0x8) && mrid != -1;
     const int nown = l.nown, nt = nown + (l.stub ? 1 : 0);
     int4 q0 = make_int4(0, 0, 0, 0);
+    int4 q1 = q0;  // and the second one (spliced reads: nearly half of the records)
     if (nown > 0) q0 = R.b_pack[bo + (l.rev ? (uint32_t)(nown - 1) : 0u)];
+    if (nown > 1) q1 = R.b_pack[bo + (l.rev ? (uint32_t)(nown - 2) : 1u)];
+    int geo_c = -1, geo0 = 0, geo1 = 0;  // fine_off[geo_c], fine_off[geo_c + 1]
+    if (rid >= 0 && rid < N.n_ref) { geo_c = rid; geo0 = N.fine_off[rid]; geo1 = N.fine_off[rid + 1]; }
+    auto home_of = [&](int c, int p) { return c == geo_c ? node_home_geo(N, geo0, geo1, p) : node_home(N, c, p); };
     if (nt == 0) return;
     const bool own_first = l.first;            // own blocks form list F (FirstRead) iff first-mate
     // block 0 of the stub-augmented record (rec_block0): the first element of list F if it has one, else of list S
@@ -1194,11 +1228,11 @@ __global__ void k_edges(RecView R, NodeView N, EdgeParams2 P2, const uint8_t* ke
     int ci = -1;                         // one-entry cache of the node table: most records stay inside one node
     int4 cp = make_int4(0, 0, 0, 0);
     if (c0 >= 0 && c0 < N.n_ref) {
-        home0 = node_home(N, c0, p0);
+        home0 = home_of(c0, p0);
         cp = N.pack[home0]; ci = home0;
         const int hp = cp.y, he = hp + cp.z;
         if (e0 > hp + 5 && p0 < he - 5 && e0 <= he + 5) { a0 = home0; b0 = home0; deep0 = true; }
-        else fit_range(N, c0, p0, e0, a0, b0, home0);
+        else fit_around(N, c0, p0, e0, home0, cp, a0, b0);
     }
     (void)a0; (void)b0;
     bool hint_known = !deep0;
@@ -1211,8 +1245,11 @@ __global__ void k_edges(RecView R, NodeView N, EdgeParams2 P2, const uint8_t* ke
         const int4 ni = node_pack(i);
         if (c < 0 || c >= N.n_ref) { if (ni.x < c) i = N.n; else i = -1; return -1; }
         if (ni.x == c && p >= ni.y - 5 && end <= ni.y + ni.z + 5) return i;  // the running node still fits (+-5 test of SegmentGraph.cpp:1213)
-        int a, b, home;
-        fit_range(N, c, p, end, a, b, home);
+        int a, b;
+        const int home = home_of(c, p);
+        const int4 nh = N.pack[home];
+        fit_around(N, c, p, end, home, nh, a, b);
+        ci = home; cp = nh;  // the block's home node is nearly always the answer and the next running node
         const bool nonempty = a <= b;
         const bool up = ni.x < c || (ni.x == c && ni.y <= p);
         if (up) {
@@ -1232,6 +1269,7 @@ __global__ void k_edges(RecView R, NodeView N, EdgeParams2 P2, const uint8_t* ke
 #pragma unroll
     for (int k = 0; k < OWNCAP; ++k) ownnode[k] = -2;
     int i = hint, node0 = -1, ffi = hint;
+    int4 qc = q0, qn = q1;
     // trimmed data of: first own block, last own block, previous own block, stub
     int of_c = 0, of_p = 0, of_rp = 0; bool of_rev = false;
     int ol_p = 0, ol_rp = 0, ol_mr = 0, ol_node = -1; bool ol_rev = false;
@@ -1244,7 +1282,9 @@ __global__ void k_edges(RecView R, NodeView N, EdgeParams2 P2, const uint8_t* ke
         int bc, bp, bm, brp, bmr; bool brev;
         if (is_stub) { bc = mrid; bp = mp; bm = 15; brp = 0; bmr = 15; brev = flag & 0x20; }
         else {
-            const int4 q = ko == 0 ? q0 : R.b_pack[bo + (l.rev ? (uint32_t)(nown - 1 - ko) : (uint32_t)ko)];
+            const int4 q = qc;  // own blocks arrive one iteration ahead of their use
+            qc = qn;
+            if (ko + 2 < nown) qn = R.b_pack[bo + (l.rev ? (uint32_t)(nown - 3 - ko) : (uint32_t)(ko + 2))];
             bc = rid; bp = q.x; bm = q.y; brp = (int)((uint32_t)q.z & 0xffffu); bmr = (int)((uint32_t)q.z >> 16); brev = l.rev;
         }
         if ((i < 0 || i >= N.n) && !hint_known) { hint = incoming_hint(); hint_known = true; }  // (the walk falls back to the incoming hint)
@@ -3450,7 +3490,7 @@ int dev_upload_nodes(sq_ctx* c, const std::vector<Node>& nodes) {
     DeviceRecords& D = *c->dev;
     hipStream_t s = c->stream;
     const int n = (int)nodes.size(), nref = (int)c->ref_len.size();
-    std::vector<int32_t> chr(n), pos(n), len(n), cs(nref + 1, n), bo(nref + 1, 0);
+    std::vector<int32_t> chr(n), pos(n), len(n), cs(nref + 1, n), bo(nref + 1, 0), fo(nref + 1, 0);
     for (int i = n - 1; i >= 0; --i) { chr[i] = nodes[i].chr; pos[i] = nodes[i].pos; len[i] = nodes[i].len; }
     // chr_start[k] = first node with chr >= k
     int j = 0;
@@ -3458,20 +3498,24 @@ int dev_upload_nodes(sq_ctx* c, const std::vector<Node>& nodes) {
     for (int k = 0; k < nref; ++k) {
         if (cs[k] == cs[k + 1]) return fail(c, SQ_E_ARG, "internal: a reference without nodes (the tiling covers every chromosome)");
         bo[k + 1] = bo[k] + (int32_t)(((int64_t)std::max(c->ref_len[k], 1) + (1 << NODE_BUCKET_SHIFT) - 1) >> NODE_BUCKET_SHIFT);
+        const int64_t f = (int64_t)fo[k] + (((int64_t)std::max(c->ref_len[k], 1) + (1 << NODE_FINE_SHIFT) - 1) >> NODE_FINE_SHIFT) + 1;
+        if (f > INT32_MAX) return fail(c, SQ_E_CAPACITY, "references too long for the node position index");
+        fo[k + 1] = (int32_t)f;
     }
-    const int total = bo[nref];
-    // one packed upload: chr | pos | len | chr_start | bucket_off
-    const size_t words = 3 * (size_t)n + 2 * ((size_t)nref + 1);
+    const int total = fo[nref];
+    // one packed upload: chr | pos | len | chr_start | bucket_off | fine_off
+    const size_t words = 3 * (size_t)n + 3 * ((size_t)nref + 1);
     HIPCHK(D.n_chr.reserve(words)); HIPCHK(D.n_bucket.reserve(std::max(total, 1)));
     D.pin.reset();
     int32_t* h = D.pin.take_n<int32_t>(words);
     if (!h) return fail(c, SQ_E_HIP, "hipHostMalloc failed");
     std::memcpy(h, chr.data(), (size_t)n * 4); std::memcpy(h + n, pos.data(), (size_t)n * 4); std::memcpy(h + 2 * (size_t)n, len.data(), (size_t)n * 4);
     std::memcpy(h + 3 * (size_t)n, cs.data(), ((size_t)nref + 1) * 4); std::memcpy(h + 3 * (size_t)n + nref + 1, bo.data(), ((size_t)nref + 1) * 4);
+    std::memcpy(h + 3 * (size_t)n + 2 * ((size_t)nref + 1), fo.data(), ((size_t)nref + 1) * 4);
     HIPCHK(hipMemcpyAsync(D.n_chr.p, h, words * 4, hipMemcpyHostToDevice, s));
     NodeView& nv = D.nv;
     nv.n = n; nv.n_ref = nref; nv.chr = D.n_chr.p; nv.pos = D.n_chr.p + n; nv.len = D.n_chr.p + 2 * (size_t)n; nv.chr_start = D.n_chr.p + 3 * (size_t)n;
-    nv.bucket = D.n_bucket.p; nv.bucket_off = D.n_chr.p + 3 * (size_t)n + nref + 1;
+    nv.fine = D.n_bucket.p; nv.bucket_off = D.n_chr.p + 3 * (size_t)n + nref + 1; nv.fine_off = D.n_chr.p + 3 * (size_t)n + 2 * ((size_t)nref + 1);
     HIPCHK(D.n_pack.reserve((size_t)std::max(n, 1)));
     nv.pack = D.n_pack.p;
     if (n) hipLaunchKernelGGL(k_node_pack, dim3((n + 255) / 256), dim3(256), 0, s, n, nv.chr, nv.pos, nv.len, D.n_pack.p);
