@@ -1172,10 +1172,56 @@ __device__ __forceinline__ bool dev_edge_discordant(const NodeView& N, const Edg
 }
 
 struct EdgeParams2 { int dp, di, ablate; };
-__global__ void k_edges(RecView R, NodeView N, EdgeParams2 P2, const uint8_t* keep, unsigned long long* hk, uint32_t* hv, uint32_t hmask, int32_t* flags, int32_t* stripes) {
+// Pass 1 of the edge stage: the records that cannot emit anything are recognised and dropped here, the others go on a work list
+// for k_edges.  A record emits no edge, sets no flag and needs no incoming hint when block 0 of its stub-augmented form lies deep
+// inside its home node h (block0_fit: every hint leads to h, which becomes the running node) and every other element -- own
+// blocks and mate stub -- passes LocateRead's +-5 test against h (SegmentGraph.cpp:1213): all blocks are then located in h, so
+// there is no unlocatable block (:1612-1618), no pair of consecutive blocks in different nodes (:1631-1653) and the pair rule
+// sees both mates in one node (:1655-1685).  That is 99 % of the records of an RNA-seq sample.  This kernel is a plain
+// scan -- fixed fields, first and last own block, one node lookup -- in 40-odd registers, where the full rule set below
+// needs 90 and runs five waves per SIMD.
+__global__ void k_edges_near(RecView R, NodeView N, const uint8_t* keep, uint32_t* list, int32_t* count) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool need = false;
+    if (r < R.n) {
+        const uint8_t kp = keep[r];  // (the loads below do not wait for it: one memory round trip)
+        const int flag = R.flag[r], rid = R.refid[r], mrid = R.mrefid[r], mp = R.mpos[r];
+        const uint32_t bo = R.blk_off[r], bo1 = R.blk_off[r + 1];
+        if (kp & K_BUILD) {
+            const int nown = (int)(bo1 - bo);
+            const bool first = flag & 0x40, rev = flag & 0x10, stub = !(flag & 0x8) && mrid != -1;
+            if (nown + (stub ? 1 : 0) > 0) {
+                need = true;
+                int4 qa = make_int4(0, 0, 0, 0), qb = qa;  // first and last own block in CIGAR order
+                if (nown > 0) { qa = R.b_pack[bo]; qb = R.b_pack[bo1 - 1]; }
+                const bool own0 = first ? nown > 0 : !stub;  // is block 0 an own block?  (rec_block0)
+                const int4 q0 = rev ? qb : qa;               // the first own block in read-offset order
+                const int c0 = own0 ? rid : mrid, p0 = own0 ? q0.x : mp, e0 = own0 ? q0.x + q0.y : mp + 15;
+                if (c0 >= 0 && c0 < N.n_ref) {
+                    const int4 nh = N.pack[node_home(N, c0, p0)];
+                    const int hp = nh.y, he = hp + nh.z;
+                    auto fits = [&](int c, int p, int end) { return c == nh.x && p >= hp - 5 && end <= he + 5; };
+                    if (e0 > hp + 5 && p0 < he - 5 && e0 <= he + 5) {  // deep inside its node
+                        bool ok = !stub || fits(mrid, mp, mp + 15);
+                        if (nown > 0) ok = ok && fits(rid, qa.x, qa.x + qa.y) && fits(rid, qb.x, qb.x + qb.y);
+                        for (int k = 1; ok && k + 1 < nown; ++k) { const int4 q = R.b_pack[bo + (uint32_t)k]; ok = fits(rid, q.x, q.x + q.y); }
+                        need = !ok;
+                    }
+                }
+            }
+        }
+    }
+    const unsigned long long m = __ballot(need);
+    if (!m) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(count, (int)__popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1, 64);
+    if (need) list[base + (int)__popcll(m & ((1ull << lane) - 1))] = (uint32_t)r;
+}
+// Pass 2: the full rule set for one record of the work list
+__device__ __forceinline__ void edges_record(const RecView& R, const NodeView& N, const EdgeParams2& P2, const uint8_t* keep, int64_t r, unsigned long long* hk, uint32_t* hv, uint32_t hmask, int32_t* flags, int32_t* stripes) {
     const EdgeParams P{P2.dp, P2.di};
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R.n) return;
     // ---- everything the record itself needs is loaded up front, the loads independent of each other (one memory round trip
     // instead of a chain of them) and not waiting for the keep byte: the fixed fields and both block offsets; behind them, again
     // together, the first two own blocks in read-offset order and the index geometry of the record's chromosome
@@ -1357,6 +1403,12 @@ __global__ void k_edges(RecView R, NodeView N, EdgeParams2 P2, const uint8_t* ke
         }
     }
 }
+__global__ void k_edges(RecView R, NodeView N, EdgeParams2 P2, const uint8_t* keep, const uint32_t* list, const int32_t* count, unsigned long long* hk, uint32_t* hv, uint32_t hmask, int32_t* flags, int32_t* stripes) {
+    const int n = *count;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x)
+        edges_record(R, N, P2, keep, (int64_t)list[idx], hk, hv, hmask, flags, stripes);
+}
+
 
 __global__ void k_hash_compact(const unsigned long long* hk, const uint32_t* hv, uint32_t slots, int32_t* counter, unsigned long long* okey, uint32_t* oval) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3813,6 +3865,8 @@ int dev_concordant_edges(sq_ctx* c, const std::vector<Node>& nodes, std::vector<
     int32_t* h = D.pin.take_n<int32_t>(8 + NSTRIPE);
     if (!h) return fail(c, SQ_E_HIP, "hipHostMalloc failed");
     HIPCHK(D.stripes.reserve(NSTRIPE));
+    if (n >= 0xffffffffll) return fail(c, SQ_E_CAPACITY, "more than 2^32 records");
+    HIPCHK(D.scratch_a.reserve((size_t)n));  // the work list of the edge stage
     for (;;) {  // the table starts small and doubles when it fills up (unique edges are few)
         const uint32_t slots = D.h_slots;
         HIPCHK(D.h_key.reserve(slots)); HIPCHK(D.h_val.reserve(slots));
@@ -3821,8 +3875,14 @@ int dev_concordant_edges(sq_ctx* c, const std::vector<Node>& nodes, std::vector<
         HIPCHK(hipMemsetAsync(D.h_val.p, 0, (size_t)slots * 4, s));
         HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
         HIPCHK(hipMemsetAsync(D.stripes.p, 0, NSTRIPE * 4, s));
-        { EvTimer t(c, "k_edges", 29.0 * n + 12.0 * D.nb);
-          hipLaunchKernelGGL(k_edges, grid_for(n, 256), dim3(256), 0, s, R, nv, ep, D.keep.p, D.h_key.p, D.h_val.p, slots - 1, D.flags.p, D.stripes.p); }
+        // pass 1 reads keep 1 + flag 2 + refid, mate refid, mate pos, block offset 4 each = 19 B per record and 16 B per block;
+        // pass 2 sees the ~1 % of the records that pass 1 could not clear (its bytes are not counted)
+        uint32_t* list = (uint32_t*)D.scratch_a.p;
+        int32_t* count = D.flags.p + 6;
+        { EvTimer t(c, "k_edges_near", 19.0 * n + 16.0 * D.nb);
+          hipLaunchKernelGGL(k_edges_near, grid_for(n, 256), dim3(256), 0, s, R, nv, D.keep.p, list, count); }
+        { EvTimer t(c, "k_edges", 0);
+          hipLaunchKernelGGL(k_edges, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, s, R, nv, ep, D.keep.p, list, count, D.h_key.p, D.h_val.p, slots - 1, D.flags.p, D.stripes.p); }
         // compact right away (wasted only if the table turns out to have overflowed): one synchronisation for both
         { EvTimer t(c, "k_hash_compact", 12.0 * slots); hipLaunchKernelGGL(k_hash_compact, grid_for(slots, 256), dim3(256), 0, s, D.h_key.p, D.h_val.p, slots, D.flags.p + 4, D.okey.p, D.oval.p); }
         HIPCHK(hipMemcpyAsync(h, D.flags.p, 8 * 4, hipMemcpyDeviceToHost, s));
