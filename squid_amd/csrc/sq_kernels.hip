@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
@@ -394,11 +395,99 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_down(int64_t n, F f, cons
 // NOTE: k_scan_reduce reads strided while k_scan_down reads blocked; both cover the same tile, and Op is
 // commutative for all instantiations, so the tile aggregates agree.
 
+// Single-pass scan with decoupled look-back (Merrill & Garland) for the 32-bit operators: every tile takes a ticket (tiles start
+// in ticket order, so a tile only ever waits for tiles that are already running), reads its 2048 inputs ONCE, publishes its
+// aggregate, looks back over the status words of the tiles in front of it -- one wave, 64 tiles per look -- until it meets an
+// inclusive prefix, publishes its own inclusive prefix and writes its outputs.  One launch and one read of the input instead of
+// reduce + spine + down-sweep (three launches, two reads).  A status word is (epoch << 2 | state) : value in 64 bits, written
+// and read with agent-scope atomics (the L2s of the XCDs are not coherent with each other); the epoch grows with every scan,
+// so the words never need clearing, and the tile that takes the last ticket puts the ticket counter back to zero.
+static std::atomic<uint32_t> g_scan_epoch{0};
+template <typename Op, bool EXCL, typename F>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(int64_t n, F f, int* out, unsigned long long* state /* [0]: ticket counter, [1 + tile]: status */, uint32_t epoch, int ntiles, int* grand) {
+    __shared__ int lds[SCAN_THREADS / 64];
+    __shared__ int s_tile, s_prefix;
+    if (threadIdx.x == 0) {
+        const int t = atomicAdd((int*)state, 1);
+        if (t == ntiles - 1) __hip_atomic_store((int*)state, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_tile = t;
+    }
+    __syncthreads();
+    const int tile = s_tile;
+    unsigned long long* st = state + 1;
+    const int64_t base = (int64_t)tile * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int acc = Op::id();
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        v[i] = (base + i < n) ? (int)f(base + i) : Op::id();
+        acc = Op::op(acc, v[i]);
+    }
+    int total;
+    const int ex = block_scan_excl<Op>(acc, total, lds);
+    const unsigned long long tag = (unsigned long long)epoch << 34;  // state 1: aggregate, state 2: inclusive prefix
+    if (threadIdx.x < 64) {  // wave 0 publishes and looks back
+        const int lane = threadIdx.x;
+        int prefix = Op::id();
+        if (tile == 0) { if (lane == 0) __hip_atomic_store(&st[0], tag | (2ull << 32) | (uint32_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        else {
+            if (lane == 0) __hip_atomic_store(&st[tile], tag | (1ull << 32) | (uint32_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int look = tile - 1; look >= 0; look -= 64) {
+                const int j = look - lane;  // this lane's tile, nearest first
+                unsigned long long w = 0;
+                for (;;) {
+                    if (j >= 0) w = __hip_atomic_load(&st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool ready = j < 0 || ((w >> 34) == epoch && ((w >> 32) & 3));
+                    if (__all(ready)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const bool incl = j >= 0 && ((w >> 32) & 3) == 2;
+                const unsigned long long im = __ballot(incl);
+                const int stop = im ? __ffsll((long long)im) - 1 : 63;  // lanes 0..stop contribute (stop holds an inclusive prefix, or the window ends)
+                int x = (j >= 0 && lane <= stop) ? (int)(uint32_t)w : Op::id();
+                for (int d = 32; d >= 1; d >>= 1) x = Op::op(x, __shfl_xor(x, d, 64));
+                prefix = Op::op(x, prefix);
+                if (im) break;
+            }
+            if (lane == 0) __hip_atomic_store(&st[tile], tag | (2ull << 32) | (uint32_t)Op::op(prefix, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) { s_prefix = prefix; if (grand && tile == ntiles - 1) *grand = Op::op(prefix, total); }
+    }
+    __syncthreads();
+    int run = Op::op(s_prefix, ex);
+    int o[SCAN_ITEMS];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        if (EXCL) { o[i] = run; run = Op::op(run, v[i]); }
+        else { run = Op::op(run, v[i]); o[i] = run; }
+    }
+    static_assert(SCAN_ITEMS == 8, "two 16-byte stores per thread");
+    if (base + SCAN_ITEMS <= n && (((uintptr_t)(out + base)) & 15) == 0) {
+        ((int4*)(out + base))[0] = make_int4(o[0], o[1], o[2], o[3]);
+        ((int4*)(out + base))[1] = make_int4(o[4], o[5], o[6], o[7]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; ++i) if (base + i < n) out[base + i] = o[i];
+    }
+}
+
 template <typename Op, bool EXCL, typename F>
 static hipError_t device_scan(hipStream_t s, int64_t n, F f, typename Op::T* out, DBuf<typename Op::T>& spine, typename Op::T* grand) {
     if (n <= 0) { if (grand) return hipMemsetAsync(grand, 0, sizeof(typename Op::T), s); return hipSuccess; }
     int ntiles = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
-    hipError_t e = spine.reserve((size_t)ntiles);
+    if constexpr (sizeof(typename Op::T) == 4) {
+        static const bool three_phase = std::getenv("SQUID_SCAN_3PHASE") != nullptr;  // (the round-1 scan, for comparison)
+        if (!three_phase) {
+            const size_t cap_before = spine.cap;
+            hipError_t e = spine.reserve(2 * (size_t)ntiles + 4);
+            if (e != hipSuccess) return e;
+            if (spine.cap != cap_before) { e = hipMemsetAsync(spine.p, 0, spine.cap * sizeof(typename Op::T), s); if (e != hipSuccess) return e; }  // fresh memory: no stale status words, ticket counter at zero
+            const uint32_t epoch = (g_scan_epoch.fetch_add(1) + 1) & 0x3fffffffu;
+            hipLaunchKernelGGL((k_scan_lookback<Op, EXCL, F>), dim3(ntiles), dim3(SCAN_THREADS), 0, s, n, f, (int*)out, (unsigned long long*)spine.p, epoch, ntiles, (int*)grand);
+            return hipGetLastError();
+        }
+    }
+    hipError_t e = spine.reserve(2 * (size_t)ntiles + 4);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_scan_reduce<Op, F>), dim3(ntiles), dim3(SCAN_THREADS), 0, s, n, f, spine.p);
     hipLaunchKernelGGL((k_scan_spine<Op>), dim3(1), dim3(SCAN_THREADS), 0, s, ntiles, spine.p, grand);
