@@ -304,7 +304,7 @@ __global__ void k_pack_blocks(int64_t from, int64_t to, const int32_t* refpos, c
 
 // ------------------------------------------------------------------------------------------------ scans
 // Three-phase device scan over int32 values produced by a functor: tile reduce -> spine -> tile down-sweep.
-constexpr int SCAN_THREADS = 256, SCAN_ITEMS = 8, SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+constexpr int SCAN_THREADS = 256, SCAN_ITEMS = 16, SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 
 struct OpSum { typedef int T; static __device__ __forceinline__ int id() { return 0; } static __device__ __forceinline__ int op(int a, int b) { return a + b; } };
 struct OpMax { typedef int T; static __device__ __forceinline__ int id() { return INT_MIN; } static __device__ __forceinline__ int op(int a, int b) { return a > b ? a : b; } };
@@ -398,7 +398,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_down(int64_t n, F f, cons
 // Single-pass scan with decoupled look-back (Merrill & Garland) for the 32-bit operators: every tile takes a ticket (tiles start
 // in ticket order, so a tile only ever waits for tiles that are already running), reads its 2048 inputs ONCE, publishes its
 // aggregate, looks back over the status words of the tiles in front of it -- one wave, 64 tiles per look -- until it meets an
-// inclusive prefix, publishes its own inclusive prefix and writes its outputs.  One launch and one read of the input instead of
+// inclusive prefix, publishes its own inclusive prefix and writes its outputs (inputs and outputs cross LDS, so that global
+// memory is always touched with consecutive lanes on consecutive elements).  One launch and one read of the input instead of
 // reduce + spine + down-sweep (three launches, two reads).  A status word is (epoch << 2 | state) : value in 64 bits, written
 // and read with agent-scope atomics (the L2s of the XCDs are not coherent with each other); the epoch grows with every scan,
 // so the words never need clearing, and the tile that takes the last ticket puts the ticket counter back to zero.
@@ -415,12 +416,22 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(int64_t n, F f, 
     __syncthreads();
     const int tile = s_tile;
     unsigned long long* st = state + 1;
-    const int64_t base = (int64_t)tile * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    // the inputs are evaluated with consecutive lanes on consecutive elements (coalesced, whatever the functor reads) and turned
+    // into the blocked order of the scan through LDS; one padding word per 32 keeps both access shapes free of bank conflicts
+    __shared__ int tilebuf[SCAN_TILE + SCAN_TILE / 32];
+    auto pad = [](int i) { return i + (i >> 5); };
+    const int64_t tbase = (int64_t)tile * SCAN_TILE;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const int64_t idx = tbase + i * SCAN_THREADS + threadIdx.x;
+        tilebuf[pad(i * SCAN_THREADS + (int)threadIdx.x)] = idx < n ? (int)f(idx) : Op::id();
+    }
+    __syncthreads();
     int v[SCAN_ITEMS];
     int acc = Op::id();
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i) {
-        v[i] = (base + i < n) ? (int)f(base + i) : Op::id();
+        v[i] = tilebuf[pad((int)threadIdx.x * SCAN_ITEMS + i)];
         acc = Op::op(acc, v[i]);
     }
     int total;
@@ -455,19 +466,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(int64_t n, F f, 
     }
     __syncthreads();
     int run = Op::op(s_prefix, ex);
-    int o[SCAN_ITEMS];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {  // (every thread read its inputs before the barriers of the block scan: the buffer is free)
+        int o;
+        if (EXCL) { o = run; run = Op::op(run, v[i]); }
+        else { run = Op::op(run, v[i]); o = run; }
+        tilebuf[pad((int)threadIdx.x * SCAN_ITEMS + i)] = o;
+    }
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i) {
-        if (EXCL) { o[i] = run; run = Op::op(run, v[i]); }
-        else { run = Op::op(run, v[i]); o[i] = run; }
-    }
-    static_assert(SCAN_ITEMS == 8, "two 16-byte stores per thread");
-    if (base + SCAN_ITEMS <= n && (((uintptr_t)(out + base)) & 15) == 0) {
-        ((int4*)(out + base))[0] = make_int4(o[0], o[1], o[2], o[3]);
-        ((int4*)(out + base))[1] = make_int4(o[4], o[5], o[6], o[7]);
-    } else {
-#pragma unroll
-        for (int i = 0; i < SCAN_ITEMS; ++i) if (base + i < n) out[base + i] = o[i];
+        const int64_t idx = tbase + i * SCAN_THREADS + threadIdx.x;
+        if (idx < n) out[idx] = tilebuf[pad(i * SCAN_THREADS + (int)threadIdx.x)];
     }
 }
 
@@ -1035,21 +1045,31 @@ __device__ __forceinline__ void node_add(int32_t* cnt, int32_t* sum, int nn, boo
 __global__ void k_depth(RecView R, NodeView N, const uint8_t* keep, const int32_t* rank1, int32_t n_break, const int32_t* cursor,
                         int32_t* main_cnt, int32_t* main_sum, int32_t* other_cnt, int32_t* other_sum, int32_t* amb_plus, int32_t* amb_minus, int32_t* flags, int32_t* stripes) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool live = r < R.n && (keep[r] & K_1) && rank1[r] < n_break;
-    uint32_t b0 = live ? R.blk_off[r] : 0;
-    int nblk = live ? (int)(R.blk_off[r + 1] - b0) : 0;
-    int c = live ? R.refid[r] : 0;
+    // everything the record needs is requested up front, the loads independent of each other (as in k_edges_near): the fixed
+    // fields and the cursor in one memory round trip, behind them the first two blocks, the cursor's node and the index
+    // geometry of the chromosome together in a second
+    const bool inr = r < R.n;
+    const uint8_t kp = inr ? keep[r] : 0;
+    const int32_t rk = inr ? rank1[r] : 0, cur = inr ? cursor[r] : 0;
+    const uint32_t b0 = inr ? R.blk_off[r] : 0, b1 = inr ? R.blk_off[r + 1] : 0;
+    int c = inr ? R.refid[r] : 0;
+    const bool live = inr && (kp & K_1) && rk < n_break;
+    int nblk = live ? (int)(b1 - b0) : 0;
     if (nblk > 0 && (c < 0 || c >= N.n_ref)) { atomicOr(&flags[0], 1); nblk = 0; }
+    int4 q0 = make_int4(0, 0, 0, 0), q1 = q0, ncur = q0;
+    int geo0 = 0, geo1 = 2;
+    if (nblk > 0) { q0 = R.b_pack[b0]; ncur = N.pack[cur]; }
+    if (nblk > 1) { q1 = R.b_pack[b0 + 1]; geo0 = N.fine_off[c]; geo1 = N.fine_off[c + 1]; }
     // ReadsMain: consumed at the prefix-max cursor
     {
         bool hit = false;
         int at = 0, len = 0;
         if (nblk > 0) {
-            int p = R.b_refpos[b0];
-            len = R.b_matchref[b0];
-            at = cursor[r];
-            if (N.chr[at] != c) atomicOr(&flags[0], 1);  // cursor stuck on another chromosome: stream not sorted
-            else hit = p >= N.pos[at] - 3 && p + len <= N.pos[at] + N.len[at] + 3;
+            const int p = q0.x;
+            len = q0.y;
+            at = cur;
+            if (ncur.x != c) atomicOr(&flags[0], 1);  // cursor stuck on another chromosome: stream not sorted
+            else hit = p >= ncur.y - 3 && p + len <= ncur.y + ncur.z + 3;
         }
         node_add(main_cnt, main_sum, N.n, hit, at, len);
     }
@@ -1072,10 +1092,14 @@ __global__ void k_depth(RecView R, NodeView N, const uint8_t* keep, const int32_
     for (int j = 0; j < UNR; ++j) {
         hk[j] = 0; ek[j] = 0; lk[j] = 0; hitk[j] = false;
         if (j + 1 < nblk) {
-            const int p = R.b_refpos[b0 + j + 1];
-            lk[j] = R.b_matchref[b0 + j + 1];
-            ek[j] = depth_early(N, c, p, lk[j], hk[j]);
-            hitk[j] = p + lk[j] <= N.pos[hk[j]] + N.len[hk[j]] + 3;
+            const int4 q = j == 0 ? q1 : R.b_pack[b0 + j + 1];
+            const int p = q.x;
+            lk[j] = q.y;
+            hk[j] = node_home_geo(N, geo0, geo1, p);
+            ek[j] = hk[j];
+            if (lk[j] <= 3) ek[j] = depth_early(N, c, p, lk[j], hk[j]);  // (only a block of <= 3 bases can be accepted before its home node)
+            const int4 nh = N.pack[hk[j]];
+            hitk[j] = p + lk[j] <= nh.y + nh.z + 3;
         }
     }
 #pragma unroll
@@ -3700,8 +3724,9 @@ int dev_dedup_summarise(sq_ctx* c) {
     if (n > 0) {
         const double bytes_rec = 32.0 * n + 12.0 * D.nb;
         { EvTimer t(c, "k_dedup", bytes_rec + 1.0 * n); hipLaunchKernelGGL(k_dedup, grid_for(n, 256), dim3(256), 0, s, R, D.cls.p, c->shard.on ? c->shard.dedup_mask : 0, D.keep.p); }
-        { EvTimer t(c, "scan_rank", 4.0 * n);
-          HIPCHK((device_scan<OpSum, true>(s, n, FKeep{D.keep.p, K_1}, D.rank1.p, D.spine, tot)));
+        { EvTimer t(c, "scan_rank", 5.0 * n);  // keep 1 in, rank 4 out
+          HIPCHK((device_scan<OpSum, true>(s, n, FKeep{D.keep.p, K_1}, D.rank1.p, D.spine, tot))); }
+        { EvTimer t(c, "scan_restoff", 10.0 * n);  // keep 1, class 1, block offset 4 in, offset 4 out
           HIPCHK((device_scan<OpSum, true>(s, n, FRest{D.keep.p, D.cls.p, D.blk_off.p}, D.restoff.p, D.spine, tot + 1))); }
         HIPCHK(hipMemcpyAsync(h_tot, tot, 8, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -3779,9 +3804,12 @@ int dev_segment_support(sq_ctx* c, int ncl, int64_t n_rest, SegSupport& out) {
     // synchronisation for the counts and one for the compacted arrays
     HIPCHK(D.scratch_b.reserve(k)); HIPCHK(D.scratch_c.reserve(k)); HIPCHK(D.b0_a.reserve(k));
     HIPCHK(D.b0_b.reserve(std::max<int64_t>(n_rest, 1))); HIPCHK(D.b0_home.reserve(std::max<int64_t>(n_rest, 1))); HIPCHK(D.part_prev.reserve(std::max<int64_t>(n_rest, 1)));
-    { EvTimer t(c, "k_segment_support", 2.0 * 20.0 * k + 13.0 * k);
-      hipLaunchKernelGGL(k_zerocov, grid_for(k, 256), dim3(256), 0, s, D.srec.p, k, k_own, C, D.other64.p, D.other64.p + k_own, seed, c->read_len, D.zflag.p, D.flags.p);
-      HIPCHK((device_scan<OpSum, true>(s, k, FByte{D.zflag.p}, D.scratch_a.p, D.spine, tot)));
+    // (one timer per kernel, named like the kernel: the figures can be compared with rocprofv3's)
+    { EvTimer t(c, "k_zerocov", 24.0 * k + 8.0 * k + 1.0 * k);  // summary 24 + running pair 8 in, flag 1 out
+      hipLaunchKernelGGL(k_zerocov, grid_for(k, 256), dim3(256), 0, s, D.srec.p, k, k_own, C, D.other64.p, D.other64.p + k_own, seed, c->read_len, D.zflag.p, D.flags.p); }
+    { EvTimer t(c, "scan_zerocov", 5.0 * k);
+      HIPCHK((device_scan<OpSum, true>(s, k, FByte{D.zflag.p}, D.scratch_a.p, D.spine, tot))); }
+    { EvTimer t(c, "k_zgather", 5.0 * k);  // flag 1 + offset 4 per kept record; the gathered rows are few
       hipLaunchKernelGGL(k_zgather, grid_for(k, 256), dim3(256), 0, s, k, k_own, D.zflag.p, D.scratch_a.p, D.other64.p, D.other64.p + k_own, seed, D.scratch_b.p, D.scratch_c.p, D.b0_a.p); }
     const bool want_rest = ncl && n_rest;
     if (want_rest) {
@@ -3909,11 +3937,13 @@ int dev_node_depth(sq_ctx* c, const std::vector<Node>& nodes, int64_t n_break, s
     RecView R = D.view();
     const int32_t nbk = (int32_t)std::min<int64_t>(n_break, INT32_MAX);
     if (n > 0) {
+        // (the lookup stays a kernel of its own: evaluated inside the scan it is no faster -- 0.72 ms against 0.44 + 0.24)
         HIPCHK(D.b0_home.reserve(n));
-        { EvTimer t(c, "scan_depth_cursor", 25.0 * n + 12.0 * n);
-          hipLaunchKernelGGL(k_early, grid_for(n, 256), dim3(256), 0, s, n, FEarlyMain{R, nv, D.keep.p, D.rank1.p, nbk}, D.b0_home.p);
+        { EvTimer t(c, "k_early", 17.0 * n + 8.0 * D.nb * ((double)D.k1 / (double)n) + 4.0 * n);  // keep 1 + rank 4 for all, block offset 8 + refid 4 + first block 8 for the consumed ones; 4 out
+          hipLaunchKernelGGL(k_early, grid_for(n, 256), dim3(256), 0, s, n, FEarlyMain{R, nv, D.keep.p, D.rank1.p, nbk}, D.b0_home.p); }
+        { EvTimer t(c, "scan_depth_cursor", 8.0 * n);
           HIPCHK((device_scan<OpMax, false>(s, n, FArr{D.b0_home.p}, D.scratch_a.p, D.spine, nullptr))); }
-        { EvTimer t(c, "k_depth", 13.0 * n + 8.0 * D.nb);
+        { EvTimer t(c, "k_depth", 17.0 * n + 16.0 * D.nb * ((double)D.k1 / (double)n));  // keep 1, rank, cursor, block offset, refid 4 each; 16 B per block of a consumed record
           hipLaunchKernelGGL(k_depth, grid_for(n, 256), dim3(256), 0, s, R, nv, D.keep.p, D.rank1.p, nbk, D.scratch_a.p, a_mc, a_ms, a_oc, a_os, a_ap, a_am, D.flags.p, stripes);
           if (nn) hipLaunchKernelGGL(k_fold_stripes, dim3((nn + 255) / 256), dim3(256), 0, s, nn, a_mc, a_ms, a_oc, a_os, acc); }
     }
@@ -4115,11 +4145,12 @@ int dev_breakpoint_support(sq_ctx* c, const std::vector<std::pair<int, int>>& bp
     HIPCHK(D.bp_ev.reserve(nb + 1)); HIPCHK(D.bp_end.reserve(nb + 1)); HIPCHK(D.bp_valid.reserve(nb + 1));
     HIPCHK(hipMemsetAsync(D.bp_ev.p, 0xFF, (nb + 1) * 4, s));
     int32_t *m = D.scratch_b.p, *Mx = D.scratch_a.p;
-    { EvTimer t(c, "k_bp_m", 27.0 * n); hipLaunchKernelGGL(k_bp_m, grid_for(n, 256), dim3(256), 0, s, R, B, D.cls.p, m); }
+
     int32_t* agg = D.flags.p + 28;  // [28] max of m over all records, [29] cursor of a walk that ran into the end of the stream
     const int32_t minus1 = -1;
     HIPCHK(hipMemcpyAsync(agg + 1, &minus1, 4, hipMemcpyHostToDevice, s));
-    { EvTimer t(c, "scan_bp_cursor", 12.0 * n); HIPCHK((device_scan<OpMax, true>(s, n, FArr{m}, Mx, D.spine, agg))); }  // max of m over earlier records
+    { EvTimer t(c, "k_bp_m", 27.0 * n); hipLaunchKernelGGL(k_bp_m, grid_for(n, 256), dim3(256), 0, s, R, B, D.cls.p, m); }
+    { EvTimer t(c, "scan_bp_cursor", 8.0 * n); HIPCHK((device_scan<OpMax, true>(s, n, FArr{m}, Mx, D.spine, agg))); }  // max of m over earlier records
     { EvTimer t(c, "k_bp_count", 31.0 * n); hipLaunchKernelGGL(k_bp_count, grid_for(n, 256), dim3(256), 0, s, R, B, D.cls.p, m, Mx, cur_prev, D.bp_ev.p, D.acc_c.p); }
     { EvTimer t(c, "k_bp_walk", 0);
       hipLaunchKernelGGL(k_bp_walk<false>, dim3(nb), dim3(64), 0, s, R, B, D.cls.p, m, Mx, cur_prev, D.bp_ev.p, D.bp_end.p, D.bp_valid.p, D.acc_c.p, agg + 1);

@@ -2,8 +2,9 @@
 """Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
 
 Counter units are calibrated on k_calib_read4 (a coalesced 4-byte-per-lane read of exactly 2^30 bytes in the same
-run): bytes_per_count = 2^30 / FETCH_SIZE(k_calib_read4).  WRITE_SIZE is scaled by the same factor (uncalibrated,
-reported separately)."""
+run): bytes_per_count = 2^30 / FETCH_SIZE(k_calib_read4) (2048 on gfx950: KiB, and the guide's factor of two for coalesced
+reads).  WRITE_SIZE does not carry the factor of two: the scan that writes exactly 4 B per record (203.3 MB at C3) shows
+200 690 counts, i.e. 1024 B per count -- so writes are scaled by half the read factor."""
 import csv
 import json
 import sys
@@ -30,6 +31,6 @@ for k in sorted(fetch):
         continue
     f = sum(fetch[k]) / len(fetch[k])
     w = sum(write.get(k, [0])) / max(1, len(write.get(k, [0])))
-    out[k] = {"launches": len(fetch[k]), "fetch_bytes_per_launch": f * factor if factor else None, "write_bytes_per_launch": w * factor if factor else None,
-              "hbm_bytes_per_launch": (f + w) * factor if factor else None}
+    out[k] = {"launches": len(fetch[k]), "fetch_bytes_per_launch": f * factor if factor else None, "write_bytes_per_launch": w * factor / 2 if factor else None,
+              "hbm_bytes_per_launch": (f + w / 2) * factor if factor else None}
 print(json.dumps(out, indent=1))
