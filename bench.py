@@ -162,10 +162,10 @@ def main() -> None:
     exchange, plan = None, None
     host_threads = max(1, (os.cpu_count() or 8) // max(1, world))
     if sharded:
-        from squid_amd.dist import TorchExchange, plan_shards
+        from squid_amd.dist import TorchExchange, plan_shards, shard_weights
 
         _, ref_len = squid_amd.read_header(bam)
-        plan = plan_shards(ref_len, world)  # balanced by reference length (records per chromosome are not known before the decode)
+        plan = plan_shards(shard_weights(bam, ref_len), world)  # balanced by compressed bytes per chromosome (from the .bai), else by reference length
         exchange = TorchExchange(dist, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         ctx = squid_amd.Context(device=local_rank, rank=rank, world_size=world, exchange=exchange)
     else:

@@ -28,6 +28,50 @@ def reduce_timing(elapsed: float, n_units: float, dist=None, device="cpu"):
     return float(t[0]), float(u[0])
 
 
+def bai_ref_weights(bai_path, n_ref: int):
+    """Compressed bytes of the BAM per reference, from its `.bai` (SAM spec 5.2): the file range in the metadata pseudo-bin 37450
+    where the index has one, else from the smallest chunk start to the largest chunk end of the reference's bins.  These are
+    the bytes a shard has to inflate -- a better balance for `plan_shards` than the reference lengths.  None when there is no
+    usable index (callers fall back to the lengths)."""
+    import struct
+    try:
+        data = open(bai_path, "rb").read()
+    except OSError:
+        return None
+    try:
+        if data[:4] != b"BAI\1":
+            return None
+        (n,) = struct.unpack_from("<i", data, 4)
+        if n != n_ref:
+            return None
+        at, out = 8, []
+        for _ in range(n):
+            (n_bin,) = struct.unpack_from("<i", data, at); at += 4
+            lo, hi, meta = None, None, None
+            for _ in range(n_bin):
+                b, n_chunk = struct.unpack_from("<Ii", data, at); at += 8
+                chunks = struct.unpack_from("<%dQ" % (2 * n_chunk), data, at); at += 16 * n_chunk
+                if b == 37450:
+                    if n_chunk >= 1:
+                        meta = (chunks[0], chunks[1])
+                    continue
+                for k in range(n_chunk):
+                    lo = chunks[2 * k] if lo is None else min(lo, chunks[2 * k])
+                    hi = chunks[2 * k + 1] if hi is None else max(hi, chunks[2 * k + 1])
+            (n_intv,) = struct.unpack_from("<i", data, at); at += 4 + 8 * n_intv
+            beg, end = meta if meta else (lo, hi)
+            out.append(0 if beg is None or end is None else max(0, (end >> 16) - (beg >> 16)) + (1 if end > beg else 0))
+        return out if sum(out) > 0 else None
+    except (struct.error, IndexError):
+        return None
+
+
+def shard_weights(bam_path: str, ref_len: list) -> list:
+    """what `plan_shards` should balance for this BAM: compressed bytes per reference when `<bam>.bai` is there, else lengths"""
+    w = bai_ref_weights(str(bam_path) + ".bai", len(ref_len))
+    return w if w is not None else list(ref_len)
+
+
 def plan_shards(weights: list, world: int) -> list[tuple]:
     """Contiguous RefID ranges [(first, end), ...], one per rank, in rank order, covering all references, with the
     smallest possible maximum weight (weights = records per reference if known, else reference lengths).

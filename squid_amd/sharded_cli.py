@@ -15,7 +15,7 @@ import sys
 from pathlib import Path
 
 import squid_amd
-from squid_amd.dist import TorchExchange, plan_shards
+from squid_amd.dist import TorchExchange, plan_shards, shard_weights
 
 
 def parse_flags(argv: list) -> dict:
@@ -45,7 +45,7 @@ def main(argv: list) -> int:
     shard, exchange = None, None
     if world > 1:
         _, ref_len = squid_amd.read_header(cfg["b"])
-        shard = plan_shards(ref_len, world)[rank]
+        shard = plan_shards(shard_weights(cfg["b"], ref_len), world)[rank]
         exchange = TorchExchange(dist, device="cuda" if backend == "nccl" else "cpu")
         params.update(rank=rank, world_size=world)
     with squid_amd.Context(device=local, star_mapq=False, exchange=exchange, **params) as ctx:

@@ -143,3 +143,27 @@ def test_virtual_world_lockstep():
     vw = VirtualWorld(ctxs)
     vw.build_graph()
     assert vw.exchanges == 2 and all(c.round == 2 for c in ctxs)
+
+
+def test_shard_weights_come_from_the_bam_index(synth):
+    """`shard_weights` reads the compressed bytes per reference from <bam>.bai (the generator writes one): they add up to the file
+    (minus header and EOF block), every reference with records has a weight, and a plan over them is contiguous and complete."""
+    import squid_amd
+    from squid_amd.dist import bai_ref_weights, plan_shards, shard_weights
+
+    pre = synth("C3", "--records", "200000")
+    bam = f"{pre}.bam"
+    _, ref_len = squid_amd.read_header(bam)
+    w = shard_weights(bam, ref_len)
+    assert w == bai_ref_weights(bam + ".bai", len(ref_len)) and len(w) == len(ref_len)
+    size = os.path.getsize(bam)
+    assert 0.9 * size <= sum(w) <= size + len(ref_len)  # neighbouring references share the BGZF block at their border
+    assert sum(1 for x in w if x > 0) >= 20
+    for world in (2, 4, 8):
+        plan = plan_shards(w, world)
+        assert plan[0][0] == 0 and plan[-1][1] == len(ref_len) and all(a[1] == b[0] for a, b in zip(plan, plan[1:]))
+        loads = [sum(w[a:b]) for a, b in plan]
+        assert max(loads) <= 1.6 * sum(w) / world  # chr1 alone is 8 % of hg38: 8 contiguous parts cannot be perfectly even
+    # no index, a wrong reference count, or garbage -> the lengths
+    assert shard_weights(str(pre) + ".missing.bam", ref_len) == list(ref_len)
+    assert bai_ref_weights(bam + ".bai", len(ref_len) + 1) is None
