@@ -272,6 +272,9 @@ def main() -> None:
                                    "achieved_GBs": sec8d_bytes / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else None,
                                    "frac": sec8d_bytes / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if gpu_ms > 0 else None,
                                    "sum_of_kernel_bytes_per_pass": scan_bytes},
+                     # every record-streaming kernel of the pass: us per launch, achieved GB/s of its algorithmic bytes, fraction of the HBM peak
+                     "record_kernels": {k: {"us": round(v["ms"] / v["launches"] * 1e3, 1), "GBs": round(v["bytes"] / v["ms"] / 1e6, 1), "frac": round(v["bytes"] / v["ms"] / 1e6 / HBM_PEAK_GBS, 3)}
+                                        for k, v in sorted(gk.items(), key=lambda kv: -kv[1]["ms"]) if v["ms"] > 0},
                      "note": "dominant record-streaming kernel of the graph pass (SURVEY.md 8(d) passes P1-P3); the BGZF inflate kernels are latency-bound bit-serial decoders, listed under ingest_kernels"},
         "ingest_kernels": {k: {"ms_per_step": round(v["ms"] / a.steps, 3), "GBs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)} for k, v in ing.items()},
         "from_file_value": total_aln / t_file, "from_file_note": "same step with the BAM read from the page cache: host->device copy of the compressed bytes inside the step",

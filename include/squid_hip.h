@@ -109,6 +109,10 @@ int sq_ingest_concordant_bam(sq_ctx* c, const uint8_t* bam, size_t nbytes, const
 int sq_read_header(const char* bam_path, int32_t* n_ref, int32_t* ref_len, char* names, size_t names_cap);
 int sq_ingest_chimeric_file(sq_ctx* c, const char* bam_path);
 int sq_ingest_concordant_file(sq_ctx* c, const char* bam_path, int32_t n_threads);
+/* Both files in one call, the chimeric BAM decoded on a host thread while the GPU reader works on the concordant BAM (the
+ * reference reads them one after the other: src/main.cpp:33-36 and src/SegmentGraph.cpp:293).  Same state afterwards as
+ * sq_ingest_chimeric_file followed by sq_ingest_concordant_file; an error of either file is returned. */
+int sq_ingest_files(sq_ctx* c, const char* chim_bam_path, const char* bam_path, int32_t n_threads);
 /* Benchmarks and repeated runs: sq_stage_bam copies the compressed bytes of a BAM file into HBM once; a later
  * sq_ingest_concordant_file on the same path then takes the GPU reader (BGZF inflate, record boundaries and record parse
  * on the device) straight from that copy, with no host->device transfer of the file (the host still walks the BGZF block

@@ -20,7 +20,7 @@ EXPORTS = [
     "sq_default_params", "sq_create", "sq_destroy", "sq_strerror", "sq_last_error", "sq_set_references",
     "sq_ingest_chimeric", "sq_chim_contains", "sq_ingest_concordant", "sq_ingest_concordant_bam", "sq_read_header", "sq_ingest_chimeric_file",
     "sq_ingest_concordant_file", "sq_build_graph", "sq_graph_view", "sq_order", "sq_call_sv", "sq_breakpoints",
-    "sq_set_shard", "sq_exchange_pack", "sq_exchange_unpack", "sq_get_timing", "sq_timing_accumulate", "sq_reset", "sq_stage_bam", "sq_clear_records", "sq_set_source", "sq_save_records", "sq_load_records", "sq_get_counts", "sq_debug_download", "sq_debug_bp_support", "sq_debug_order", "sq_debug_blocks",
+    "sq_set_shard", "sq_exchange_pack", "sq_exchange_unpack", "sq_get_timing", "sq_timing_accumulate", "sq_reset", "sq_ingest_files", "sq_stage_bam", "sq_clear_records", "sq_set_source", "sq_save_records", "sq_load_records", "sq_get_counts", "sq_debug_download", "sq_debug_bp_support", "sq_debug_order", "sq_debug_blocks",
 ]
 
 
@@ -100,6 +100,7 @@ def load_library() -> C.CDLL:
         lib.sq_set_references.argtypes = [C.c_void_p, C.c_int32, _P32]
         lib.sq_ingest_chimeric_file.argtypes = [C.c_void_p, C.c_char_p]
         lib.sq_ingest_concordant_file.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+        lib.sq_ingest_files.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int32]
         lib.sq_stage_bam.argtypes = [C.c_void_p, C.c_char_p]
         lib.sq_clear_records.argtypes = [C.c_void_p]
         lib.sq_set_source.argtypes = [C.c_void_p, C.c_char_p]
@@ -178,8 +179,7 @@ class Context:
         self._chk(self.lib.sq_set_references(self.h, len(lens), arr), "sq_set_references")
         if shard is not None:
             self._chk(self.lib.sq_set_shard(self.h, int(shard[0]), int(shard[1])), "sq_set_shard")
-        self._chk(self.lib.sq_ingest_chimeric_file(self.h, str(chim_bam).encode()), "sq_ingest_chimeric_file")
-        self._chk(self.lib.sq_ingest_concordant_file(self.h, str(bam).encode(), threads), "sq_ingest_concordant_file")
+        self._chk(self.lib.sq_ingest_files(self.h, str(chim_bam).encode(), str(bam).encode(), threads), "sq_ingest_files")
 
     def reset(self):
         self._chk(self.lib.sq_reset(self.h), "sq_reset")

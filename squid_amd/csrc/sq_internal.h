@@ -203,6 +203,7 @@ struct sq_ctx {
     // ExactBreakpoint (host, chimeric fragments only) runs on a second thread from the end of sq_build_graph, next to
     // sq_order; sq_call_sv collects it
     std::future<int> bp_future;
+    std::future<int> chim_future;  // sq_ingest_files: the chimeric decode running next to the concordant ingest (chim_join)
     std::shared_ptr<std::map<uint64_t, std::vector<std::pair<int, int>>>> bp_early;
     double bp_early_ms = 0;
     std::shared_ptr<sq::GraphBuild> gb;
@@ -215,6 +216,8 @@ struct sq_ctx {
 namespace sq {
 
 int fail(sq_ctx* c, int code, const std::string& msg);
+// waits for the chimeric decode started by sq_ingest_files and uploads its QNAME set; called in front of the first record parse
+int chim_join(sq_ctx* c);
 
 // ---- sq_bam.cpp
 struct HostBatch {  // owning storage behind an sq_aln_batch

@@ -3347,6 +3347,7 @@ int dev_parse_append(sq_ctx* c, const uint8_t* bam, size_t nbytes, const unsigne
 }
 // the records at d_off[0..n_rec) of the inflated bytes d_bam (both in device memory) -> appended to the resident SoA
 static int parse_device(sq_ctx* c, const uint8_t* d_bam, size_t nbytes, const unsigned long long* d_off, int64_t n_rec) {
+    { const int rc = chim_join(c); if (rc) return rc; }  // the QNAME set of the chimeric BAM (sq_ingest_files reads that file meanwhile)
     DeviceRecords& D = *c->dev;
     hipStream_t s = c->stream;
     const size_t n0 = (size_t)D.n, nb0 = (size_t)D.nb, n1 = n0 + (size_t)n_rec;

@@ -879,3 +879,38 @@ def test_damaged_files_are_reported_by_both_readers(built, synth, tmp_path):
         if outs[0].startswith("ok"):
             assert outs[0] == outs[1], (name, outs)
         assert outs[0].startswith("ok" if name == "cut_between_blocks" else "error"), (name, outs)
+
+
+@pytest.mark.gpu
+def test_both_files_in_one_call_equal_the_two_calls_and_report_errors(built, synth, tmp_path, monkeypatch):
+    """sq_ingest_files (chimeric BAM decoded on a host thread next to the GPU ingest of the concordant BAM) leaves the same
+    records, fragments and _sv.txt as sq_ingest_chimeric_file + sq_ingest_concordant_file, with the GPU reader and with the
+    host inflate; a missing or empty chimeric file, or a missing concordant file, comes back as an error from that call"""
+    import hashlib
+
+    pre = synth("T2")
+    sv_path, _ = ou.run_oracle(built, pre, tmp_path)
+
+    def run():
+        with squid_amd.Context() as ctx:
+            ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
+            recs = {k: hashlib.sha256(v.tobytes()).hexdigest() for k, v in ctx.records().items()}
+            counts = ctx.counts()
+            ctx.build_graph()
+            ctx.order()
+            return recs, counts["n_chim_fragments"], counts["n_chimeric_records"], ctx.sv_text()
+
+    for gpu_reader in ("0", "1"):
+        monkeypatch.setenv("SQUID_GPU_INFLATE", gpu_reader)
+        monkeypatch.delenv("SQUID_SERIAL_LOAD", raising=False)
+        together = run()
+        monkeypatch.setenv("SQUID_SERIAL_LOAD", "1")
+        assert run() == together
+        assert together[3] == sv_path.read_text()
+    monkeypatch.delenv("SQUID_SERIAL_LOAD", raising=False)
+    with squid_amd.Context() as ctx:
+        with pytest.raises(squid_amd.SquidError):
+            ctx.load(f"{pre}.bam", str(tmp_path / "missing.chim.bam"))
+    with squid_amd.Context() as ctx:
+        with pytest.raises(squid_amd.SquidError):
+            ctx.load(str(tmp_path / "missing.bam"), f"{pre}.chim.bam")
