@@ -137,7 +137,7 @@ struct DeviceRecords {
     // derived
     DBuf<uint8_t> cls, keep;
     DBuf<int32_t> prev1, prev2, rank1, restoff, scratch_a, scratch_b, scratch_c, spine;
-    DBuf<int32_t> part_prev, part_next, b0_a, b0_b, b0_home;
+    DBuf<int32_t> part_prev, part_next, b0_a, b0_b, b0_home, fc_seg;
     DBuf<StreamRec> srec;
     DBuf<int32_t> rest_refpos, rest_matchref;
     // node table
@@ -3237,7 +3237,7 @@ void dev_destroy(sq_ctx* c) {
     D.flag.release(); D.totlen.release(); D.b_readpos.release(); D.b_matchread.release(); D.mapq.release(); D.aux.release(); D.blk_off.release();
     D.cls.release(); D.keep.release(); D.prev1.release(); D.prev2.release(); D.rank1.release(); D.restoff.release();
     D.scratch_a.release(); D.scratch_b.release(); D.scratch_c.release(); D.spine.release();
-    D.part_prev.release(); D.part_next.release(); D.b0_a.release(); D.b0_b.release(); D.b0_home.release();
+    D.part_prev.release(); D.part_next.release(); D.b0_a.release(); D.b0_b.release(); D.b0_home.release(); D.fc_seg.release();
     D.srec.release(); D.rest_refpos.release(); D.rest_matchref.release();
     D.n_chr.release(); D.n_bucket.release();
     D.acc_a.release(); D.acc_b.release(); D.acc_c.release();
