@@ -164,6 +164,12 @@ struct DeviceRecords {
     InflSet il_set[IL_DEPTH];
     hipStream_t il_stream[IL_DEPTH] = {};  // one per set: its host->device copies
     hipStream_t il_tok_stream = nullptr;   // the token passes, one after the other
+    // everything behind the token pass exists twice: while batch k is parsed (parse stream), batch k + 1 is resolved and cut into
+    // records (library stream)
+    struct PostSet { DBuf<uint8_t> out; DBuf<long long> rec_sync, rec_end; DBuf<int32_t> rec_cnt, rec_base, flags, spine; DBuf<unsigned long long> bam_off; };
+    PostSet il_post[2];
+    hipStream_t il_parse_stream = nullptr;
+    int32_t* il_host = nullptr;            // page-locked: the small results of the two sets (32 ints each)
     DBuf<int32_t> rec_cnt, rec_base;
     DBuf<unsigned long long> bam_off, chim_hash;
     DBuf<uint32_t> chim_off, chim_len;
@@ -3248,6 +3254,9 @@ void dev_destroy(sq_ctx* c) {
     D.pin.release(); for (auto& st : D.il_set) { st.in.release(); st.tab.release(); st.tok.release(); st.ntok.release(); st.flags.release(); if (st.ready) (void)hipEventDestroy(st.ready); if (st.freed) (void)hipEventDestroy(st.freed); if (st.copied) (void)hipEventDestroy(st.copied); st.ready = st.freed = st.copied = nullptr; }
     if (D.il_tok_stream) { (void)hipStreamDestroy(D.il_tok_stream); D.il_tok_stream = nullptr; }
     for (auto& q : D.il_stream) if (q) { (void)hipStreamDestroy(q); q = nullptr; }
+    for (auto& ps : D.il_post) { ps.out.release(); ps.rec_sync.release(); ps.rec_end.release(); ps.rec_cnt.release(); ps.rec_base.release(); ps.flags.release(); ps.spine.release(); ps.bam_off.release(); }
+    if (D.il_parse_stream) { (void)hipStreamDestroy(D.il_parse_stream); D.il_parse_stream = nullptr; }
+    if (D.il_host) { (void)hipHostFree(D.il_host); D.il_host = nullptr; }
     D.bgzf_out.release(); D.bgzf_carry.release(); D.staged.release(); D.rec_sync.release(); D.rec_end.release(); D.rec_cnt.release(); D.rec_base.release(); D.stripes.release(); D.bp_bucket.release(); D.bp_ev.release(); D.bp_end.release(); D.bp_valid.release();
     for (auto& e : D.ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete c->dev;
@@ -3334,7 +3343,7 @@ int dev_upload_chim_names(sq_ctx* c) {
 }
 
 // K0: parse `n_rec` BAM records of an inflated chunk on the device and append them to the resident SoA
-static int parse_device(sq_ctx* c, const uint8_t* d_bam, size_t nbytes, const unsigned long long* d_off, int64_t n_rec);
+static int parse_device(sq_ctx* c, const uint8_t* d_bam, size_t nbytes, const unsigned long long* d_off, int64_t n_rec, hipStream_t on = nullptr, int32_t* flags16 = nullptr, DBuf<int32_t>* scan_state = nullptr);
 int dev_parse_append(sq_ctx* c, const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n_rec) {
     if (n_rec == 0) return SQ_OK;
     HIPCHK(hipSetDevice(c->P.device));  // the file reader calls this from its sink thread (the current device is per thread)
@@ -3346,17 +3355,20 @@ int dev_parse_append(sq_ctx* c, const uint8_t* bam, size_t nbytes, const unsigne
     return parse_device(c, D.bam_chunk.p, nbytes, D.bam_off.p, n_rec);
 }
 // the records at d_off[0..n_rec) of the inflated bytes d_bam (both in device memory) -> appended to the resident SoA
-static int parse_device(sq_ctx* c, const uint8_t* d_bam, size_t nbytes, const unsigned long long* d_off, int64_t n_rec) {
+// (`on`, `flags16`, `scan_state`: the stream, a 16-int flag block and the scan state to use -- the file ingest parses on its own stream)
+static int parse_device(sq_ctx* c, const uint8_t* d_bam, size_t nbytes, const unsigned long long* d_off, int64_t n_rec, hipStream_t on, int32_t* flags16, DBuf<int32_t>* scan_state) {
     { const int rc = chim_join(c); if (rc) return rc; }  // the QNAME set of the chimeric BAM (sq_ingest_files reads that file meanwhile)
     DeviceRecords& D = *c->dev;
-    hipStream_t s = c->stream;
+    hipStream_t s = on ? on : c->stream;
+    int32_t* const fl = flags16 ? flags16 : D.flags.p;
+    DBuf<int32_t>& spine = scan_state ? *scan_state : D.spine;
     const size_t n0 = (size_t)D.n, nb0 = (size_t)D.nb, n1 = n0 + (size_t)n_rec;
     HIPCHK(D.parse_nblk.reserve((size_t)n_rec)); HIPCHK(D.parse_rel.reserve((size_t)n_rec));
-    HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
-    int32_t* tot = D.flags.p + 8;
-    { EvTimer t(c, "k_parse_count", (double)nbytes);
-      hipLaunchKernelGGL(k_parse_count, grid_for(n_rec, PARSE_THREADS), dim3(PARSE_THREADS), 0, s, d_bam, nbytes, d_off, n_rec, D.parse_nblk.p, D.flags.p);
-      HIPCHK((device_scan<OpSum, true>(s, n_rec, FArrN{D.parse_nblk.p}, D.parse_rel.p, D.spine, tot))); }
+    HIPCHK(hipMemsetAsync(fl, 0, 8 * 4, s));
+    int32_t* tot = fl + 8;
+    { EvTimer t(c, "k_parse_count", (double)nbytes, s);
+      hipLaunchKernelGGL(k_parse_count, grid_for(n_rec, PARSE_THREADS), dim3(PARSE_THREADS), 0, s, d_bam, nbytes, d_off, n_rec, D.parse_nblk.p, fl);
+      HIPCHK((device_scan<OpSum, true>(s, n_rec, FArrN{D.parse_nblk.p}, D.parse_rel.p, spine, tot))); }
     int32_t nblk_total = 0;
     HIPCHK(hipMemcpyAsync(&nblk_total, tot, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -3379,15 +3391,15 @@ static int parse_device(sq_ctx* c, const uint8_t* d_bam, size_t nbytes, const un
 #undef GROW
     ChimSetView C{D.chim_mask, D.chim_mask ? D.chim_hash.p : nullptr, D.chim_off.p, D.chim_len.p, D.chim_blob.p};
     ParseParams P{(int)(signed char)(((c->P.phred_type ? 33 : 64) + c->P.min_phred) & 0xff), c->P.max_lowphred_len, c->P.min_mapqual};
-    { EvTimer t(c, "k_parse_write", (double)nbytes + 32.0 * n_rec + 12.0 * nblk_total);
+    { EvTimer t(c, "k_parse_write", (double)nbytes + 32.0 * n_rec + 12.0 * nblk_total, s);
       hipLaunchKernelGGL(k_parse_write, grid_for(n_rec, PARSE_THREADS), dim3(PARSE_THREADS), 0, s, d_bam, nbytes, d_off, n_rec, C, P, D.parse_rel.p, (uint32_t)nb0, D.refid.p + n0, D.pos.p + n0, D.mrefid.p + n0,
                          D.mpos.p + n0, D.endpos.p + n0, D.flag.p + n0, D.totlen.p + n0, D.mapq.p + n0, D.aux.p + n0, D.blk_off.p + n0, D.b_refpos.p, D.b_matchref.p, D.b_readpos.p, D.b_matchread.p,
-                         D.flags.p); }
+                         fl); }
     if (nb1 > nb0) hipLaunchKernelGGL(k_pack_blocks, dim3((unsigned)((nb1 - nb0 + 255) / 256)), dim3(256), 0, s, (int64_t)nb0, (int64_t)nb1, D.b_refpos.p, D.b_matchref.p, D.b_readpos.p, D.b_matchread.p, D.b_pack.p);
     const uint32_t endoff = (uint32_t)nb1;
     HIPCHK(hipMemcpyAsync(D.blk_off.p + n1, &endoff, 4, hipMemcpyHostToDevice, s));
     int32_t hf = 0;
-    HIPCHK(hipMemcpyAsync(&hf, D.flags.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&hf, fl, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (hf & 128) return fail(c, SQ_E_IO, "corrupt BAM record");
     if (hf & 2048) return fail(c, SQ_E_CAPACITY, "a read longer than 65535 bases or with more than 256 aligned blocks (the record layout keeps 16-bit read offsets)");
@@ -3460,7 +3472,8 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         while (batches.size() <= k) {
             const size_t at = plan_at;
             // the first batches are small, so that the GPU has work after a few milliseconds of index walk and copy
-            const unsigned long long ramp = (unsigned long long)128 << (20 + std::min<size_t>(batches.size(), 8)), bcap = std::min(cap, ramp);
+            static const unsigned long long ramp0 = std::getenv("SQUID_TOK_RAMP_MB") ? (unsigned long long)std::atoll(std::getenv("SQUID_TOK_RAMP_MB")) : 128;
+            const unsigned long long ramp = ramp0 << (20 + std::min<size_t>(batches.size(), 8)), bcap = std::min(cap, ramp);
             while (more_blocks && (blocks.size() <= at || blocks.back().uoff + blocks.back().isize - blocks[at].uoff <= bcap)) more_blocks = index_more(blocks);
             const size_t stop = more_blocks || b1 == (size_t)-1 ? blocks.size() : std::min(b1, blocks.size());
             if (at >= stop) return false;
@@ -3534,53 +3547,81 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     { int rc = stage_a(0); if (rc) return rc; }
     for (size_t j = 1; j < look; ++j) { int rc = stage_a_async(j); if (rc) return rc; }
     const double w_first = since_ms(w0);
-    unsigned long long carry = 0;  // bytes of the incomplete record in front of the batch (kept in D.bgzf_carry)
+    // Everything behind the token pass is double-buffered (DeviceRecords::PostSet): the front of batch k + 1 -- resolve, slice
+    // boundaries -- is queued on the library stream before batch k is parsed on the parse stream, so the two overlap; in round 1
+    // resolve -> boundaries -> parse of one batch after the other was the chain the wall time followed.  The front needs the
+    // bytes of the incomplete record at the end of the batch before (`carry`, known once that batch's boundaries are): they are
+    // copied from the one inflated buffer to the front of the other.
+    if (!D.il_parse_stream) HIPCHK(hipStreamCreateWithFlags(&D.il_parse_stream, hipStreamNonBlocking));
+    if (!D.il_host) HIPCHK(hipHostMalloc((void**)&D.il_host, 64 * sizeof(int32_t)));
+    hipStream_t sp = D.il_parse_stream;
+    struct Front { unsigned long long pad = 0, carry = 0, limit = 0; long long nsl = 0; RecScan S{}; };
+    Front fr[2];
+    auto issue_front = [&](size_t k, unsigned long long carry_in, const uint8_t* carry_src) -> int {
+        const Batch B = batches[k];
+        DeviceRecords::InflSet& st = D.il_set[k % DeviceRecords::IL_DEPTH];
+        DeviceRecords::PostSet& P = D.il_post[k & 1];
+        Front& F = fr[k & 1];
+        int32_t* hk = D.il_host + 32 * (k & 1);  // [0..9] flags of the front, [10..13] of the token pass, [16..17] where the walk stopped
+        const int nb = (int)(B.end - B.at);
+        F.carry = carry_in;
+        F.pad = (16 - carry_in % 16) % 16;  // the batch's own bytes start 16-byte aligned
+        F.limit = F.pad + carry_in + B.bbytes;
+        HIPCHK(P.out.reserve(std::max((size_t)F.limit, (size_t)std::min<unsigned long long>(cap, range_bytes_estimate()) + ((size_t)1 << 20)) + 64));
+        HIPCHK(P.flags.reserve(16));
+        HIPCHK(hipMemsetAsync(P.flags.p, 0, 16 * 4, s));
+        if (carry_in) HIPCHK(hipMemcpyAsync(P.out.p + F.pad, carry_src, (size_t)carry_in, hipMemcpyDeviceToDevice, s));
+        uint8_t* out = P.out.p + F.pad + carry_in;
+        HIPCHK(hipStreamWaitEvent(s, st.ready, 0));
+        if (variant == 2) {  // one wave per block (the first version)
+            EvTimer t(c, "k_inflate", (double)B.cbytes + (double)B.bbytes);
+            hipLaunchKernelGGL(k_inflate, dim3((nb + 3) / 4), dim3(256), 0, s, st.src, st.tab.p, 0, nb, B.bbase, out, P.flags.p);
+        } else if (variant == 1) {
+            EvTimer t(c, "k_inflate", (double)B.cbytes + (double)B.bbytes);
+            hipLaunchKernelGGL(k_inflate_lanes<false>, dim3((nb + 63) / 64), dim3(64), IL_LDS_BYTES, s, st.src, st.tab.p, nb, B.bbase, out, P.flags.p, nullptr, nullptr);
+        } else {
+            EvTimer t2(c, "k_lz_resolve", (double)B.bbytes * 3);
+            hipLaunchKernelGGL(k_lz_resolve, dim3(nb), dim3(64), 65536 + 16, s, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, out, P.flags.p);
+        }
+        HIPCHK(hipEventRecord(st.freed, s));
+        F.S = RecScan{P.out.p, k == 0 ? (unsigned long long)begin : F.pad, F.limit, nref, sh.on ? sh.first_ref : -1, sh.on ? sh.end_ref : 0, (sh.on && c->P.rank == c->P.world_size - 1) ? 1 : 0};
+        F.nsl = F.S.limit > F.S.begin ? (long long)((F.S.limit - F.S.begin + REC_SLICE - 1) / REC_SLICE) : 0;
+        hk[16] = 0; hk[17] = 0;
+        if (F.nsl > 0) {
+            const long long nsl = F.nsl;
+            HIPCHK(P.rec_sync.reserve((size_t)nsl)); HIPCHK(P.rec_end.reserve((size_t)nsl + 1)); HIPCHK(P.rec_cnt.reserve((size_t)nsl)); HIPCHK(P.rec_base.reserve((size_t)nsl));
+            int32_t* tot = P.flags.p + 8;
+            long long* tail_d = P.rec_end.p + nsl;  // where the walk stopped: the start of the incomplete tail
+            HIPCHK(hipMemsetAsync(tail_d, 0, 8, s));
+            { EvTimer t(c, "k_rec_boundaries", 2.0 * (double)(F.S.limit - F.S.begin));
+              hipLaunchKernelGGL(k_rec_sync, grid_for(nsl, 256), dim3(256), 0, s, F.S, nsl, (k > 0 || synced) ? 1 : 0, P.rec_sync.p);
+              hipLaunchKernelGGL(k_rec_walk<false>, grid_for(nsl, 256), dim3(256), 0, s, F.S, nsl, P.rec_sync.p, P.rec_cnt.p, P.rec_end.p, nullptr, nullptr);
+              hipLaunchKernelGGL(k_rec_check, grid_for(nsl, 256), dim3(256), 0, s, nsl, P.rec_sync.p, P.rec_end.p, P.flags.p, tail_d);
+              HIPCHK((device_scan<OpSum, true>(s, nsl, FArr{P.rec_cnt.p}, P.rec_base.p, P.spine, tot))); }
+            HIPCHK(hipMemcpyAsync(hk + 16, tail_d, 8, hipMemcpyDeviceToHost, s));
+        }
+        HIPCHK(hipMemcpyAsync(hk, P.flags.p, 10 * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hk + 10, st.flags.p, 4 * 4, hipMemcpyDeviceToHost, s));
+        return SQ_OK;
+    };
     long check_bad = 0;
+    { int rc = issue_front(0, 0, nullptr); if (rc) { (void)give_up(); return rc; } }
     for (size_t k = 0; k < batches.size(); ++k) {
         // the copy of batch k+2 and its token pass (queued behind that of batch k+1) go out first: the host blocks in the copy
         // while the GPU works on the batches before
         { int rc = stage_a_async(k + look); if (rc) { (void)give_up(); return rc; } }
         const Batch B = batches[k];
-        DeviceRecords::InflSet& st = D.il_set[k % DeviceRecords::IL_DEPTH];
-        const int nb = (int)(B.end - B.at);
-        const unsigned long long pad = (16 - carry % 16) % 16;  // the batch's own bytes start 16-byte aligned
-        const unsigned long long limit = pad + carry + B.bbytes;
-        HIPCHK(D.bgzf_out.reserve(std::max((size_t)limit, (size_t)std::min<unsigned long long>(cap, range_bytes_estimate()) + ((size_t)1 << 20)) + 64));
-        HIPCHK(hipMemsetAsync(D.flags.p, 0, 10 * 4, s));
-        if (carry) HIPCHK(hipMemcpyAsync(D.bgzf_out.p + pad, D.bgzf_carry.p, (size_t)carry, hipMemcpyDeviceToDevice, s));
-        uint8_t* out = D.bgzf_out.p + pad + carry;
-        HIPCHK(hipStreamWaitEvent(s, st.ready, 0));
-        if (variant == 2) {  // one wave per block (the first version)
-            EvTimer t(c, "k_inflate", (double)B.cbytes + (double)B.bbytes);
-            hipLaunchKernelGGL(k_inflate, dim3((nb + 3) / 4), dim3(256), 0, s, st.src, st.tab.p, 0, nb, B.bbase, out, D.flags.p);
-        } else if (variant == 1) {
-            EvTimer t(c, "k_inflate", (double)B.cbytes + (double)B.bbytes);
-            hipLaunchKernelGGL(k_inflate_lanes<false>, dim3((nb + 63) / 64), dim3(64), IL_LDS_BYTES, s, st.src, st.tab.p, nb, B.bbase, out, D.flags.p, nullptr, nullptr);
-        } else {
-            EvTimer t2(c, "k_lz_resolve", (double)B.bbytes * 3);
-            hipLaunchKernelGGL(k_lz_resolve, dim3(nb), dim3(64), 65536 + 16, s, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, out, D.flags.p);
-        }
-        HIPCHK(hipEventRecord(st.freed, s));
-        RecScan S{D.bgzf_out.p, k == 0 ? (unsigned long long)begin : pad, limit, nref, sh.on ? sh.first_ref : -1, sh.on ? sh.end_ref : 0, (sh.on && c->P.rank == c->P.world_size - 1) ? 1 : 0};
-        const long long nsl = S.limit > S.begin ? (long long)((S.limit - S.begin + REC_SLICE - 1) / REC_SLICE) : 0;
-        int32_t h[10] = {0}, ha[4] = {0};
+        DeviceRecords::PostSet& P = D.il_post[k & 1];
+        const Front F = fr[k & 1];
+        const int32_t* hk = D.il_host + 32 * (k & 1);
+        HIPCHK(hipStreamSynchronize(s));  // the front of batch k
+        int32_t h[10], ha[4];
+        for (int q = 0; q < 10; ++q) h[q] = hk[q];
+        for (int q = 0; q < 4; ++q) ha[q] = hk[10 + q];
         long long tail = 0;
-        if (nsl > 0) {
-            HIPCHK(D.rec_sync.reserve((size_t)nsl)); HIPCHK(D.rec_end.reserve((size_t)nsl + 1)); HIPCHK(D.rec_cnt.reserve((size_t)nsl)); HIPCHK(D.rec_base.reserve((size_t)nsl));
-            int32_t* tot = D.flags.p + 8;
-            long long* tail_d = D.rec_end.p + nsl;  // where the walk stopped: the start of the incomplete tail
-            HIPCHK(hipMemsetAsync(tail_d, 0, 8, s));
-            { EvTimer t(c, "k_rec_boundaries", 2.0 * (double)(S.limit - S.begin));
-              hipLaunchKernelGGL(k_rec_sync, grid_for(nsl, 256), dim3(256), 0, s, S, nsl, (k > 0 || synced) ? 1 : 0, D.rec_sync.p);
-              hipLaunchKernelGGL(k_rec_walk<false>, grid_for(nsl, 256), dim3(256), 0, s, S, nsl, D.rec_sync.p, D.rec_cnt.p, D.rec_end.p, nullptr, nullptr);
-              hipLaunchKernelGGL(k_rec_check, grid_for(nsl, 256), dim3(256), 0, s, nsl, D.rec_sync.p, D.rec_end.p, D.flags.p, tail_d);
-              HIPCHK((device_scan<OpSum, true>(s, nsl, FArr{D.rec_cnt.p}, D.rec_base.p, D.spine, tot))); }
-            HIPCHK(hipMemcpyAsync(&tail, tail_d, 8, hipMemcpyDeviceToHost, s));
-        }
-        HIPCHK(hipMemcpyAsync(h, D.flags.p, 10 * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(ha, st.flags.p, 4 * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        std::memcpy(&tail, hk + 16, 8);
         if (check) {  // debugging: every block against zlib
+            const uint8_t* out = P.out.p + F.pad + F.carry;
             std::vector<uint8_t> got((size_t)B.bbytes), want;
             HIPCHK(hipMemcpy(got.data(), out, (size_t)B.bbytes, hipMemcpyDeviceToHost));
             for (size_t i = B.at; i < B.end; ++i) {
@@ -3595,30 +3636,30 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
                     ++check_bad;
                 }
             }
-            std::fprintf(stderr, "[inflate check] blocks %zu..%zu of %zu: %ld differ so far, flags %d|%d, records %d, carry in %llu\n", B.at - b0, B.end - b0, b1 - b0, check_bad, h[0], ha[0], h[8], carry);
+            std::fprintf(stderr, "[inflate check] blocks %zu..%zu of %zu: %ld differ so far, flags %d|%d, records %d, carry in %llu\n", B.at - b0, B.end - b0, b1 - b0, check_bad, h[0], ha[0], h[8], F.carry);
         }
         if ((h[0] | ha[0]) & (512 | 1024)) return give_up();
+        // the bytes behind the last complete record go in front of the next batch, whose front is queued now: it runs while this
+        // batch is parsed
+        const unsigned long long tail_at = tail > 0 ? (unsigned long long)tail : F.S.begin;
+        const unsigned long long carry = F.limit > tail_at ? F.limit - tail_at : 0;
+        if (plan(k + 1)) { int rc = issue_front(k + 1, carry, P.out.p + tail_at); if (rc) { (void)give_up(); return rc; } }
         const int64_t n_rec = h[8];
         if (n_rec > 0) {
-            HIPCHK(D.bam_off.reserve((size_t)n_rec));
-            hipLaunchKernelGGL(k_rec_walk<true>, grid_for(nsl, 256), dim3(256), 0, s, S, nsl, D.rec_sync.p, nullptr, nullptr, D.rec_base.p, D.bam_off.p);
+            HIPCHK(P.bam_off.reserve((size_t)n_rec));
+            hipLaunchKernelGGL(k_rec_walk<true>, grid_for(F.nsl, 256), dim3(256), 0, sp, F.S, F.nsl, P.rec_sync.p, nullptr, nullptr, P.rec_base.p, P.bam_off.p);
             // (sub-batches: the per-launch temporaries and the 32-bit block counters stay small)
             const int64_t kBatch = (int64_t)1 << 24;
             for (int64_t r0 = 0; r0 < n_rec; r0 += kBatch) {
                 c->ingest_total_bytes = (size_t)range_bytes_estimate(); c->ingest_seen_bytes = (size_t)(B.bbase + B.bbytes - first_uoff);  // sizes the arrays for the whole range at once
-                int rc = parse_device(c, D.bgzf_out.p, (size_t)limit, D.bam_off.p + r0, std::min(kBatch, n_rec - r0));
+                int rc = parse_device(c, P.out.p, (size_t)F.limit, P.bam_off.p + r0, std::min(kBatch, n_rec - r0), sp, P.flags.p, &P.spine);
                 c->ingest_total_bytes = 0; c->ingest_seen_bytes = 0;
                 if (rc) { (void)give_up(); return rc; }
             }
         }
-        // the bytes behind the last complete record go in front of the next batch
-        const unsigned long long tail_at = tail > 0 ? (unsigned long long)tail : S.begin;
-        carry = limit > tail_at ? limit - tail_at : 0;
-        if (carry && plan(k + 1)) {
-            HIPCHK(D.bgzf_carry.reserve((size_t)carry + 64));
-            HIPCHK(hipMemcpyAsync(D.bgzf_carry.p, D.bgzf_out.p + tail_at, (size_t)carry, hipMemcpyDeviceToDevice, s));
-        }
+        if (k + 1 == batches.size() && report) std::fprintf(stderr, "GPU ingest: %llu bytes left incomplete at the end\n", carry);
     }
+    HIPCHK(hipStreamSynchronize(sp));
     for (auto& q : D.il_stream) HIPCHK(hipStreamSynchronize(q));
     HIPCHK(hipStreamSynchronize(D.il_tok_stream));
     if (tok_prof && batches.size() > 8) {  // (batch 8 ran the instrumented kernel)
@@ -3631,7 +3672,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         std::fprintf(stderr, "token pass profile (batch 8, %d waves, %.0f steps per wave; s_memtime ticks per step): emit+header %.1f, header->topup-check %.1f, topup %.1f, ll decode %.1f, match path %.1f, loop/literal %.1f\n",
                      nw, steps, sum[0] / sum[6], sum[1] / sum[6], sum[2] / sum[6], sum[3] / sum[6], sum[4] / sum[6], sum[7] / sum[6]);
     }
-    if (report) std::fprintf(stderr, "GPU ingest: first two batches queued after %.1f ms, all %zu batches through after %.1f ms (%.1f ms since entry; %llu MB per batch, %llu bytes left incomplete at the end)\n", w_first, batches.size(), since_ms(w0), since_ms(w_entry), cap >> 20, carry);
+    if (report) std::fprintf(stderr, "GPU ingest: first two batches queued after %.1f ms, all %zu batches through after %.1f ms (%.1f ms since entry; %llu MB per batch)\n", w_first, batches.size(), since_ms(w0), since_ms(w_entry), cap >> 20);
     return SQ_OK;
 }
 
