@@ -42,3 +42,7 @@ for t, d, n in ev:
     hist[min(k, 4)] += t - prev; prev = t
     active[n] += d
 print("distinct kernels running at once:", {k: f"{v / 1e6:.1f} ms" for k, v in sorted(hist.items())})
+if len(sys.argv) > 2 and sys.argv[2] == "--list":  # every dispatch of more than 0.3 ms, in start order
+    for s, e, n in rows:
+        if e - s > 300_000:
+            print(f"  {(s - t0) / 1e6:8.2f} .. {(e - t0) / 1e6:8.2f}  {(e - s) / 1e6:7.2f} ms  {n[:40]}")

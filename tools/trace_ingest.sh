@@ -10,7 +10,7 @@ mkdir -p /tmp/c3 gpurun_out/trace_$TAG
 [ -f /tmp/c3/C3.bam ] || build/gen_synth_bam --config C3 --out /tmp/c3/C3 --threads 64 > /dev/null
 ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $REPO/gpurun_out/trace_$TAG -o trace -- python3 $REPO/tools/ingest_twice.py /tmp/c3/C3 ) > gpurun_out/trace_$TAG/stdout.log 2>&1
 T=$(find gpurun_out/trace_$TAG -name "*kernel_trace.csv" | head -1)
-python3 tools/timeline_summary.py "$T" > gpurun_out/ingest_timeline_$TAG.txt
+python3 tools/timeline_summary.py "$T" --list > gpurun_out/ingest_timeline_$TAG.txt
 rm -f gpurun_out/trace_$TAG/*.db "$T"
 tail -3 gpurun_out/trace_$TAG/stdout.log
-cat gpurun_out/ingest_timeline_$TAG.txt
+head -20 gpurun_out/ingest_timeline_$TAG.txt
