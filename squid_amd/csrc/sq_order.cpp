@@ -320,49 +320,138 @@ struct Builder {
             std::vector<int> fill(th.begin(), th.end() - 1);
             for (int i = 0; i < m; ++i) if (is_bridge[i]) { int u = blob[ea[i]], v = blob[eb[i]]; tadj[fill[u]] = v; tid[fill[u]++] = i; tadj[fill[v]] = u; tid[fill[v]++] = i; }
         }
-        // ---- the recursion on the blob tree.  A part = the blobs reachable from `root` over bridges not cut yet.
+        // ---- the recursion on the blob tree.  A part = the blobs reachable from `root` over bridges not cut yet; it is split at its
+        // most balanced bridge (minimal |W - 2 * weight of the far side|, ties by the bridge's position in the edge list).
         std::vector<char> cut(m, 0);
         std::vector<int> part_of(nblob, -1);           // final: leaf part id of every blob
-        struct Job { int root, tnode; };
         const int top = (int)tree.size();
         tree.push_back(TreeNode());
-        std::vector<Job> jobs(1, Job{0, top});
-        std::vector<int> nodes_of, par_b, par_e, sub;  // scratch of one traversal
         std::vector<int> leaf_tnode;                   // leaf part id -> tree node
-        par_b.assign(nblob, -1); par_e.assign(nblob, -1); sub.assign(nblob, 0);
-        while (!jobs.empty()) {
-            const Job jb = jobs.back();
-            jobs.pop_back();
-            nodes_of.clear();
-            nodes_of.push_back(jb.root); par_b[jb.root] = -1; par_e[jb.root] = -1;
-            for (size_t q = 0; q < nodes_of.size(); ++q) {  // BFS order: parents before children
-                int u = nodes_of[q];
-                for (int k = th[u]; k < th[u + 1]; ++k) if (!cut[tid[k]] && tid[k] != par_e[u]) { int v = tadj[k]; par_b[v] = u; par_e[v] = tid[k]; nodes_of.push_back(v); }
-            }
-            long W = 0;
-            for (int u : nodes_of) { sub[u] = weight[u]; W += weight[u]; }
-            int best_e = -1, best_child = -1;
-            long best_bal = -1;
-            if (W >= 20) {
-                for (size_t q = nodes_of.size(); q-- > 1;) {
+        const bool simple_recursion = std::getenv("SQUID_MINCUT_SIMPLE") != nullptr;  // the one-traversal-per-split form (cross-check)
+        if (simple_recursion) {
+            struct Job { int root, tnode; };
+            std::vector<Job> jobs(1, Job{0, top});
+            std::vector<int> nodes_of, par_b, par_e, sub;  // scratch of one traversal
+            par_b.assign(nblob, -1); par_e.assign(nblob, -1); sub.assign(nblob, 0);
+            while (!jobs.empty()) {
+                const Job jb = jobs.back();
+                jobs.pop_back();
+                nodes_of.clear();
+                nodes_of.push_back(jb.root); par_b[jb.root] = -1; par_e[jb.root] = -1;
+                for (size_t q = 0; q < nodes_of.size(); ++q) {  // BFS order: parents before children
                     int u = nodes_of[q];
-                    sub[par_b[u]] += sub[u];
-                    long bal = std::labs(W - 2L * sub[u]);
-                    if (best_bal < 0 || bal < best_bal || (bal == best_bal && par_e[u] < best_e)) { best_bal = bal; best_e = par_e[u]; best_child = u; }
+                    for (int k = th[u]; k < th[u + 1]; ++k) if (!cut[tid[k]] && tid[k] != par_e[u]) { int v = tadj[k]; par_b[v] = u; par_e[v] = tid[k]; nodes_of.push_back(v); }
                 }
+                long W = 0;
+                for (int u : nodes_of) { sub[u] = weight[u]; W += weight[u]; }
+                int best_e = -1, best_child = -1;
+                long best_bal = -1;
+                if (W >= 20) {
+                    for (size_t q = nodes_of.size(); q-- > 1;) {
+                        int u = nodes_of[q];
+                        sub[par_b[u]] += sub[u];
+                        long bal = std::labs(W - 2L * sub[u]);
+                        if (best_bal < 0 || bal < best_bal || (bal == best_bal && par_e[u] < best_e)) { best_bal = bal; best_e = par_e[u]; best_child = u; }
+                    }
+                }
+                if (best_e < 0) {  // fewer than 20 nodes, or no bridge inside ("min cut > 1"): solved whole
+                    const int pid = (int)leaf_tnode.size();
+                    for (int u : nodes_of) part_of[u] = pid;
+                    leaf_tnode.push_back(jb.tnode);
+                    continue;
+                }
+                cut[best_e] = 1;
+                const int l = (int)tree.size(); tree.push_back(TreeNode());
+                const int r = (int)tree.size(); tree.push_back(TreeNode());
+                tree[jb.tnode].left = l; tree[jb.tnode].right = r; tree[jb.tnode].bridge = E[best_e];
+                jobs.push_back(Job{best_child, l});
+                jobs.push_back(Job{jb.root, r});
             }
-            if (best_e < 0) {  // fewer than 20 nodes, or no bridge inside ("min cut > 1"): solved whole
-                const int pid = (int)leaf_tnode.size();
-                for (int u : nodes_of) part_of[u] = pid;
-                leaf_tnode.push_back(jb.tnode);
-                continue;
+        } else {
+            // The same splits without a traversal of the whole part per split (a star-shaped blob tree -- thousands of small parts
+            // hanging off one core, the dense-graph config -- made that quadratic: 2.3 s at 20 M records).  The tree is rooted
+            // once; a part is a root plus what hangs below it, so "far side of a bridge" is always the subtree of its lower
+            // end.  Per part: an ordered set of (subtree weight, bridge) over its blobs except the root; the most balanced bridge
+            // is a neighbour of W / 2 in it.  A split takes the lower end's subtree out: the weights of its ancestors inside the
+            // part drop (re-keyed one by one), and the set is divided by moving the entries of the SMALLER side into a new
+            // set (each entry moves O(log n) times).
+            std::vector<int> pb(nblob, -1), pe(nblob, -1), bfs;
+            std::vector<long> sub(nblob, 0);
+            std::vector<int> cnt(nblob, 1), child_of(m, -1);
+            bfs.reserve(nblob);
+            bfs.push_back(0);
+            for (size_t q = 0; q < bfs.size(); ++q) {
+                const int u = bfs[q];
+                for (int k = th[u]; k < th[u + 1]; ++k) if (tid[k] != pe[u]) { const int v = tadj[k]; pb[v] = u; pe[v] = tid[k]; child_of[tid[k]] = v; bfs.push_back(v); }
             }
-            cut[best_e] = 1;
-            const int l = (int)tree.size(); tree.push_back(TreeNode());
-            const int r = (int)tree.size(); tree.push_back(TreeNode());
-            tree[jb.tnode].left = l; tree[jb.tnode].right = r; tree[jb.tnode].bridge = E[best_e];
-            jobs.push_back(Job{best_child, l});
-            jobs.push_back(Job{jb.root, r});
+            for (int u = 0; u < nblob; ++u) sub[u] = weight[u];
+            for (size_t q = bfs.size(); q-- > 1;) { const int u = bfs[q]; sub[pb[u]] += sub[u]; cnt[pb[u]] += cnt[u]; }
+            typedef std::set<std::pair<long, int>> KeySet;  // (weight below the bridge, bridge): unique per blob
+            struct Job { int root, tnode; std::unique_ptr<KeySet> keys; };
+            std::vector<Job> jobs;
+            {
+                std::unique_ptr<KeySet> all(new KeySet());
+                for (int u = 1; u < nblob; ++u) all->insert(std::make_pair(sub[u], pe[u]));
+                jobs.push_back(Job{0, top, std::move(all)});
+            }
+            std::vector<int> walk;
+            auto below = [&](int root, bool with_root, int skip_edge) {  // blobs of the part hanging below `root` (not crossing skip_edge)
+                walk.clear();
+                walk.push_back(root);
+                for (size_t q = 0; q < walk.size(); ++q) {
+                    const int u = walk[q];
+                    for (int k = th[u]; k < th[u + 1]; ++k) if (tid[k] != pe[u] && !cut[tid[k]] && tid[k] != skip_edge) walk.push_back(tadj[k]);
+                }
+                if (!with_root) walk.erase(walk.begin());
+            };
+            while (!jobs.empty()) {
+                Job jb = std::move(jobs.back());
+                jobs.pop_back();
+                KeySet& S = *jb.keys;
+                const long W = sub[jb.root];
+                int best_e = -1;
+                if (W >= 20 && !S.empty()) {
+                    // candidates: the lightest subtree with 2 * weight >= W and the heaviest below that (its smallest bridge id)
+                    KeySet::iterator hi = S.lower_bound(std::make_pair((W + 1) / 2, INT_MIN));
+                    long bal_hi = -1, bal_lo = -1;
+                    int e_hi = -1, e_lo = -1;
+                    if (hi != S.end()) { bal_hi = 2 * hi->first - W; e_hi = hi->second; }
+                    if (hi != S.begin()) {
+                        KeySet::iterator lo = std::prev(hi);
+                        lo = S.lower_bound(std::make_pair(lo->first, INT_MIN));
+                        bal_lo = W - 2 * lo->first; e_lo = lo->second;
+                    }
+                    if (e_hi >= 0 && (e_lo < 0 || bal_hi < bal_lo || (bal_hi == bal_lo && e_hi < e_lo))) best_e = e_hi; else best_e = e_lo;
+                }
+                if (best_e < 0) {  // fewer than 20 nodes, or no bridge inside ("min cut > 1"): solved whole
+                    const int pid = (int)leaf_tnode.size();
+                    below(jb.root, true, -1);
+                    for (int u : walk) part_of[u] = pid;
+                    leaf_tnode.push_back(jb.tnode);
+                    continue;
+                }
+                const int child = child_of[best_e];
+                const long d = sub[child];
+                const int dc = cnt[child], total = cnt[jb.root];
+                S.erase(std::make_pair(sub[child], best_e));
+                for (int a = pb[child]; ; a = pb[a]) {  // the ancestors inside the part lose the subtree
+                    if (a != jb.root) S.erase(std::make_pair(sub[a], pe[a]));
+                    sub[a] -= d; cnt[a] -= dc;
+                    if (a == jb.root) break;
+                    S.insert(std::make_pair(sub[a], pe[a]));
+                }
+                std::unique_ptr<KeySet> other(new KeySet());
+                const bool move_child_side = dc - 1 <= total - dc - 1;
+                if (move_child_side) below(child, false, -1); else below(jb.root, false, best_e);
+                for (int u : walk) { const std::pair<long, int> key(sub[u], pe[u]); S.erase(key); other->insert(key); }
+                cut[best_e] = 1;
+                const int l = (int)tree.size(); tree.push_back(TreeNode());
+                const int r = (int)tree.size(); tree.push_back(TreeNode());
+                tree[jb.tnode].left = l; tree[jb.tnode].right = r; tree[jb.tnode].bridge = E[best_e];
+                std::unique_ptr<KeySet> mine = std::move(jb.keys);
+                jobs.push_back(Job{child, l, move_child_side ? std::move(other) : std::move(mine)});
+                jobs.push_back(Job{jb.root, r, move_child_side ? std::move(mine) : std::move(other)});
+            }
         }
         // ---- leaves: ids ascending, edges in the component's order
         const int nleaf = (int)leaf_tnode.size();

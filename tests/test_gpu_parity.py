@@ -443,6 +443,13 @@ def test_dense_graph_config_with_a_giant_component(built, synth, tmp_path, monke
         assert ctx.counts()["n_order_unsolved"] == int(stats["too_large"])
         # K6 / K7 ran on the device
         assert {"k_filter_weight", "k_filter_interleave", "k_filter_edges", "k_compress_nodes", "k_further_compress"} <= set(ctx.timing())
+        # the min-cut recursion with its ordered sets (default) and with one traversal per split choose the same bridges
+        fast = ctx.order()
+        monkeypatch.setenv("SQUID_MINCUT_SIMPLE", "1")
+        ctx.reset()
+        ctx.build_graph()
+        assert ctx.order() == fast
+        monkeypatch.delenv("SQUID_MINCUT_SIMPLE")
 
 
 def test_device_filters_equal_the_host_restatements(built, synth, tmp_path):
