@@ -800,7 +800,9 @@ int sq_ingest_chimeric_file(sq_ctx* c, const char* path) {
     HostBatch all;
     all.clear();
     bool got = false;
-    int rc = parse_bam_file(path, o, (size_t)1 << 40, 1, c->err, [&](const HostBatch& hb) { all = hb; got = true; return 0; });
+    // (inflate and decode on a few threads: a dense sample has millions of chimeric records; the result does not depend on the count)
+    const int nt = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 4));
+    int rc = parse_bam_file(path, o, (size_t)1 << 40, nt, c->err, [&](const HostBatch& hb) { all = hb; got = true; return 0; });
     if (rc) return rc;
     if (!got) return fail(c, SQ_E_EMPTYCHIM, "chimeric BAM holds no record");
     sq_aln_batch b;
@@ -817,13 +819,13 @@ int sq_ingest_files(sq_ctx* c, const char* chim_path, const char* bam_path, int3
         return rc ? rc : sq_ingest_concordant_file(c, bam_path, n_threads);
     }
     const std::string chim = chim_path;
-    c->chim_future = std::async(std::launch::async, [c, chim]() {
+    c->chim_future = std::async(std::launch::async, [c, chim, n_threads]() {
         ParseOpts o{c->P.phred_type, c->P.min_phred, c->P.max_lowphred_len, true, nullptr};
         HostBatch all;
         all.clear();
         bool got = false;
         std::string err;
-        int rc = parse_bam_file(chim.c_str(), o, (size_t)1 << 40, 1, err, [&](const HostBatch& hb) { all = hb; got = true; return 0; });
+        int rc = parse_bam_file(chim.c_str(), o, (size_t)1 << 40, std::max(1, std::min(n_threads, 16)), err, [&](const HostBatch& hb) { all = hb; got = true; return 0; });
         if (rc) return fail(c, rc, err);
         if (!got) return fail(c, SQ_E_EMPTYCHIM, "chimeric BAM holds no record");
         sq_aln_batch b;
