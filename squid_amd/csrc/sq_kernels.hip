@@ -1299,7 +1299,7 @@ struct EdgeParams2 { int dp, di, ablate; };
 // sees both mates in one node (:1655-1685).  That is 99 % of the records of an RNA-seq sample.  This kernel is a plain
 // scan -- fixed fields, first and last own block, one node lookup -- in 40-odd registers, where the full rule set below
 // needs 90 and runs five waves per SIMD.
-__global__ void k_edges_near(RecView R, NodeView N, const uint8_t* keep, uint32_t* list, int32_t* count) {
+__global__ void k_edges_near(RecView R, NodeView N, const uint8_t* keep, uint32_t* list, int32_t* count, int all /* SQUID_EDGES_ALL: clear nothing, every record takes the full rule set (cross-check) */) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool need = false;
     if (r < R.n) {
@@ -1320,7 +1320,7 @@ __global__ void k_edges_near(RecView R, NodeView N, const uint8_t* keep, uint32_
                     const int4 nh = N.pack[node_home(N, c0, p0)];
                     const int hp = nh.y, he = hp + nh.z;
                     auto fits = [&](int c, int p, int end) { return c == nh.x && p >= hp - 5 && end <= he + 5; };
-                    if (e0 > hp + 5 && p0 < he - 5 && e0 <= he + 5) {  // deep inside its node
+                    if (!all && e0 > hp + 5 && p0 < he - 5 && e0 <= he + 5) {  // deep inside its node
                         bool ok = !stub || fits(mrid, mp, mp + 15);
                         if (nown > 0) ok = ok && fits(rid, qa.x, qa.x + qa.y) && fits(rid, qb.x, qb.x + qb.y);
                         for (int k = 1; ok && k + 1 < nown; ++k) { const int4 q = R.b_pack[bo + (uint32_t)k]; ok = fits(rid, q.x, q.x + q.y); }
@@ -4041,7 +4041,7 @@ int dev_concordant_edges(sq_ctx* c, const std::vector<Node>& nodes, std::vector<
         uint32_t* list = (uint32_t*)D.scratch_a.p;
         int32_t* count = D.flags.p + 6;
         { EvTimer t(c, "k_edges_near", 19.0 * n + 16.0 * D.nb);
-          hipLaunchKernelGGL(k_edges_near, grid_for(n, 256), dim3(256), 0, s, R, nv, D.keep.p, list, count); }
+          hipLaunchKernelGGL(k_edges_near, grid_for(n, 256), dim3(256), 0, s, R, nv, D.keep.p, list, count, std::getenv("SQUID_EDGES_ALL") ? 1 : 0); }
         { EvTimer t(c, "k_edges", 0);
           hipLaunchKernelGGL(k_edges, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, s, R, nv, ep, D.keep.p, list, count, D.h_key.p, D.h_val.p, slots - 1, D.flags.p, D.stripes.p); }
         // compact right away (wasted only if the table turns out to have overflowed): one synchronisation for both

@@ -921,3 +921,25 @@ def test_both_files_in_one_call_equal_the_two_calls_and_report_errors(built, syn
     with squid_amd.Context() as ctx:
         with pytest.raises(squid_amd.SquidError):
             ctx.load(str(tmp_path / "missing.bam"), f"{pre}.chim.bam")
+
+
+@pytest.mark.gpu
+def test_edge_stage_pass_one_clears_only_records_that_emit_nothing(built, synth, monkeypatch):
+    """k_edges_near drops the records whose blocks and mate stub all sit in the home node of block 0; with SQUID_EDGES_ALL every
+    participating record goes through the full rule set of k_edges instead -- same raw edge count, same edges, same calls"""
+    for cfg, extra, kw in (("T2", [], {}), ("C2", [], {}), ("C5", ["--records", "200000", "--tsv", "400"], {"min_edge_weight": 1, "max_allowed_degree": 50})):
+        pre = synth(cfg, *extra)
+        got = {}
+        for mode in ("near", "all"):
+            if mode == "all":
+                monkeypatch.setenv("SQUID_EDGES_ALL", "1")
+            else:
+                monkeypatch.delenv("SQUID_EDGES_ALL", raising=False)
+            with squid_amd.Context(**kw) as ctx:
+                ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
+                ctx.build_graph()
+                k = ctx.counts()
+                got[mode] = (k["n_raw_edges"], k["n_unique_edges"], ctx.graph(2), ctx.order(), ctx.sv_text())
+        monkeypatch.delenv("SQUID_EDGES_ALL", raising=False)
+        assert got["near"] == got["all"], cfg
+        assert got["near"][0] > 0
