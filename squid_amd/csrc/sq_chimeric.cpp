@@ -4,6 +4,7 @@
 // (ledger B8) are issued on index arrays with the same comparators, so libstdc++'s introsort takes the same
 // decisions as it does on the reference's objects.
 #include <algorithm>
+#include <cstring>
 
 #include "sq_internal.h"
 
@@ -80,7 +81,23 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
     // sort by QNAME (ReadRec.cpp:354): same comparator on an index array => same permutation
     std::vector<int> idx(recs.size());
     for (size_t i = 0; i < idx.size(); ++i) idx[i] = (int)i;
-    std::sort(idx.begin(), idx.end(), [&](int x, int y) { return recs[x].name < recs[y].name; });
+    // (the first 16 bytes of every name as two big-endian words next to the index: most comparisons are decided without touching the
+    // strings; the comparison results, and with them the permutation introsort produces, are those of `name < name`)
+    struct NameKey { uint64_t hi, lo; };
+    std::vector<NameKey> nk(recs.size());
+    for (size_t i = 0; i < recs.size(); ++i) {
+        unsigned char buf[16] = {0};
+        std::memcpy(buf, recs[i].name.data(), std::min<size_t>(16, recs[i].name.size()));
+        uint64_t h = 0, l = 0;
+        for (int k = 0; k < 8; ++k) { h = (h << 8) | buf[k]; l = (l << 8) | buf[8 + k]; }
+        nk[i] = NameKey{h, l};
+    }
+    std::sort(idx.begin(), idx.end(), [&](int x, int y) {
+        const NameKey &a = nk[(size_t)x], &b = nk[(size_t)y];
+        if (a.hi != b.hi) return a.hi < b.hi;
+        if (a.lo != b.lo) return a.lo < b.lo;
+        return recs[x].name < recs[y].name;
+    });
     // merge equal names (ReadRec.cpp:356-373)
     std::vector<Frag> merged;
     for (int id : idx) {
