@@ -849,8 +849,9 @@ __global__ void k_dedup(RecView R, const uint8_t* cls, int prior_mask, uint8_t* 
     // the class bytes say whether either is needed: two round trips instead of a chain of five
     const RecKey kr = rec_key(R, r), km = rec_key(R, r - 1);
     uint8_t c = cls[r], k = 0;
+    const uint8_t cm = r > 0 ? cls[r - 1] : 0;  // (with cls[r], not behind it: the walk back usually ends at r - 1)
     if (!(c & (C_P1 | C_P2))) { keep[r] = 0; return; }
-    auto prev_of = [&](uint8_t bit) { int64_t q = r - 1; while (q >= 0 && !(cls[q] & bit)) --q; return q; };
+    auto prev_of = [&](uint8_t bit) { if (r > 0 && (cm & bit)) return r - 1; int64_t q = r - 2; while (q >= 0 && !(cls[q] & bit)) --q; return q; };
     int64_t p1 = -1;
     if (c & C_P1) {
         p1 = prev_of(C_P1);
