@@ -943,3 +943,27 @@ def test_edge_stage_pass_one_clears_only_records_that_emit_nothing(built, synth,
         monkeypatch.delenv("SQUID_EDGES_ALL", raising=False)
         assert got["near"] == got["all"], cfg
         assert got["near"][0] > 0
+
+
+@pytest.mark.gpu
+def test_c3_at_four_million_records_through_the_gpu_reader(built, synth, tmp_path, monkeypatch):
+    """full hg38 (BASELINE.json configs[2] geometry: 25 contigs, 200 planted TSVs) at 4 M records -- several token batches with
+    carried records, the double-buffered resolve / parse, every graph stage -- against the oracle, stage by stage; the GPU reader
+    forced (the file is below its 1 GiB threshold), once with both files in one call and once staged in HBM as bench.py does"""
+    monkeypatch.delenv("SQUID_EXACT_DEPTH", raising=False)
+    monkeypatch.setenv("SQUID_GPU_INFLATE", "1")
+    monkeypatch.setenv("SQUID_TOK_CAP_MB", "96")  # (small batches: 4 M records become ~16 of them)
+    pre = synth("C3", "--records", "4000000")
+    sv_path, dump = ou.run_oracle(built, pre, tmp_path)
+    with squid_amd.Context() as ctx:
+        ctx.load(f"{pre}.bam", f"{pre}.chim.bam", threads=8)
+        assert ctx.counts()["n_concordant"] > 3_900_000
+        ctx.build_graph()
+        sv = _compare(ctx, dump, sv_path, depth_exact=False)
+        ctx.stage_bam(f"{pre}.bam")
+        for _ in range(2):
+            ctx.clear_records()
+            ctx.load(f"{pre}.bam", f"{pre}.chim.bam", threads=8)
+            ctx.build_graph()
+            ctx.order()
+            assert ctx.sv_text() == sv
