@@ -3083,6 +3083,96 @@ __global__ __launch_bounds__(64) void k_lz_resolve(const uint32_t* tok, const in
         for (uint32_t k = lane; k < blk.isize; k += 64) out[k] = lz_win[k];
 }
 
+// The same with TWO waves per block, taking turns.  A round has two halves: (1) fetch 64 tokens, prefix-sum their lengths, store
+// the literals -- needs only where the round's output starts; (2) copy the matches -- needs everything the rounds before have
+// produced.  A wave that is alone on its SIMD pays every dependent instruction in full, and (2) is three times as long as (1);
+// so wave A copies the matches of round r while wave B prepares round r + 1 (its literals land behind everything round r
+// writes), one barrier, then B copies and A prepares round r + 2.  Same window, same LDS, the preparation of every round
+// hidden behind the copies of the one before.
+__global__ __launch_bounds__(128) void k_lz_resolve2(const uint32_t* tok, const int32_t* ntok, const InflBlock* blocks, int nblocks, unsigned long long out_base, uint8_t* outbuf, int32_t* flags) {
+    extern __shared__ uint8_t lz_win[];
+    __shared__ uint32_t s_base[2];  // [r & 1]: where the output of round r starts (written by the wave that prepares round r - 1 ... see below)
+    __shared__ int s_bad;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const InflBlock blk = blocks[blockIdx.x];
+    const uint32_t* t = tok + (blk.uoff - out_base);
+    const int n = ntok[blockIdx.x];
+    const int nr = (n + 63) / 64;  // rounds; wave w prepares and copies the rounds r with (r & 1) == w
+    if (threadIdx.x == 0) { s_base[0] = 0; s_base[1] = 0; s_bad = 0; }
+    __syncthreads();
+    uint32_t nxt = wave * 64 + lane < n ? t[wave * 64 + lane] : 0;  // tokens of this wave's next round
+    // state of the round this wave has prepared and not yet copied
+    uint32_t o = 0, len = 0, dist = 1, src = 0, ready_at = 0;
+    bool pending = false;
+    for (int step = 0; step <= nr; ++step) {
+        const bool bad_now = s_bad != 0;
+        if (!bad_now && step < nr && (step & 1) == wave) {
+            // ---- half 1 of round `step`
+            const int r0 = step * 64;
+            const uint32_t tk = nxt;
+            const int i = r0 + lane;
+            if (i + 128 < n) nxt = t[i + 128];
+            const bool valid = i < n, is_m = valid && (tk >> 31);
+            const uint32_t nl = (tk >> 24) & 3u;  // a literal token carries 1..3 bytes (0 stands for 1: the one-literal tokens of the first token pass)
+            len = !valid ? 0u : (is_m ? (tk >> 16) & 0x1ffu : (nl ? nl : 1u));
+            const uint32_t inc = wave_scan_incl(len);
+            const uint32_t base = s_base[step & 1];
+            o = base + inc - len;
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            bool bad = base + total > blk.isize;  // (uniform)
+            if (!bad) {
+                if (valid && !is_m) { lz_win[o] = (uint8_t)tk; if (len > 1) lz_win[o + 1] = (uint8_t)(tk >> 8); if (len > 2) lz_win[o + 2] = (uint8_t)(tk >> 16); }
+                dist = (tk & 0x7fffu) + 1;
+                pending = is_m;
+                if (pending && dist > o) { bad = true; pending = false; }
+                src = o - dist;
+                ready_at = src + len < o ? src + len : o;  // the match needs the bytes below this
+            } else pending = false;
+            if (__any(bad)) { if (lane == 0) s_bad = 1; pending = false; }
+            if (lane == 0) s_base[(step + 1) & 1] = base + total;  // (the slot of round step - 1, which has been read)
+        } else if (!bad_now && step >= 1 && ((step - 1) & 1) == wave) {
+            // ---- half 2 of round `step - 1`: the matches, in as few sub-rounds as their dependencies allow
+            unsigned long long pm = __ballot(pending);
+            while (pm) {
+                const int first = __ffsll((long long)pm) - 1;
+                const uint32_t hwm = (uint32_t)__builtin_amdgcn_readlane((int)o, __builtin_amdgcn_readfirstlane(first));
+                wave_sync();
+                if (pending && ready_at <= hwm) {
+                    if (dist >= 8) {  // eight bytes per load and store (the source of a slice lies at least 8 bytes below its target)
+                        uint32_t k = 0;
+                        for (; k + 8 <= len; k += 8) { unsigned long long w; __builtin_memcpy(&w, lz_win + src + k, 8); __builtin_memcpy(lz_win + o + k, &w, 8); }
+                        for (; k < len; ++k) lz_win[o + k] = lz_win[src + k];
+                        pending = false;
+                    }
+                    // every byte comes from [src, src + min(dist, len)): final, so the reads of a slice go out together
+                    uint32_t j = 0;  // k mod dist
+                    for (uint32_t k = 0; pending && k < len; k += 8) {
+                        uint8_t v[8];
+                        uint32_t jj = j;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { v[q] = lz_win[src + jj]; if (++jj == dist) jj = 0; }
+                        j = jj;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) if (k + q < len) lz_win[o + k + q] = v[q];
+                    }
+                    pending = false;
+                }
+                pm = __ballot(pending);
+            }
+        }
+        __syncthreads();
+    }
+    const uint32_t produced = s_base[nr & 1];
+    if (s_bad || produced != blk.isize) { if (threadIdx.x == 0) atomicOr(&flags[0], 512); return; }
+    uint8_t* out = outbuf + (blk.uoff - out_base);
+    if ((((uintptr_t)out) & 15) == 0) {
+        const uint32_t words = blk.isize >> 4;
+        for (uint32_t w = threadIdx.x; w < words; w += 128) ((uint4*)out)[w] = ((const uint4*)lz_win)[w];
+        for (uint32_t k = (words << 4) + threadIdx.x; k < blk.isize; k += 128) out[k] = lz_win[k];
+    } else
+        for (uint32_t k = threadIdx.x; k < blk.isize; k += 128) out[k] = lz_win[k];
+}
+
 // Record boundaries of the inflated stream, on the device: 8 KiB slices find their first boundary by validating a chain of
 // plausible record headers (as the host reader does), walk from there, and a check kernel verifies that every slice ends
 // exactly where the next one started (any disagreement sends the file through the host reader instead).
@@ -3441,6 +3531,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     HIPCHK(hipFuncSetAttribute((const void*)k_inflate_lanes<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)IL_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_inflate_lanes<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)IL_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_lz_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16));
+    HIPCHK(hipFuncSetAttribute((const void*)k_lz_resolve2, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16));
     HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T2_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T2_LDS_BYTES));
     static const bool tok_prof = std::getenv("SQUID_TOK_PROF") != nullptr;
@@ -3582,7 +3673,9 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
             hipLaunchKernelGGL(k_inflate_lanes<false>, dim3((nb + 63) / 64), dim3(64), IL_LDS_BYTES, s, st.src, st.tab.p, nb, B.bbase, out, P.flags.p, nullptr, nullptr);
         } else {
             EvTimer t2(c, "k_lz_resolve", (double)B.bbytes * 3);
-            hipLaunchKernelGGL(k_lz_resolve, dim3(nb), dim3(64), 65536 + 16, s, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, out, P.flags.p);
+            static const bool one_wave = std::getenv("SQUID_RESOLVE_1WAVE") != nullptr;  // one wave per block (round 1), for comparison
+            if (one_wave) hipLaunchKernelGGL(k_lz_resolve, dim3(nb), dim3(64), 65536 + 16, s, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, out, P.flags.p);
+            else hipLaunchKernelGGL(k_lz_resolve2, dim3(nb), dim3(128), 65536 + 16, s, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, out, P.flags.p);
         }
         HIPCHK(hipEventRecord(st.freed, s));
         F.S = RecScan{P.out.p, k == 0 ? (unsigned long long)begin : F.pad, F.limit, nref, sh.on ? sh.first_ref : -1, sh.on ? sh.end_ref : 0, (sh.on && c->P.rank == c->P.world_size - 1) ? 1 : 0};
