@@ -1049,8 +1049,39 @@ __device__ __forceinline__ void node_add(int32_t* cnt, int32_t* sum, int nn, boo
         active &= ~same;
     }
 }
+// the same through a small per-workgroup table in LDS (4 nodes per accumulator pair: the 256 neighbouring records of a workgroup
+// rarely touch more); what does not fit goes to global memory directly.  k_depth flushes the table at its end: a quarter of the
+// global atomics, and those were what its waves queued for (all waves in flight add to the same few nodes).
+struct NodeAcc { int key[4], cnt[4], sum[4]; };
+__device__ __forceinline__ void node_add_lds(NodeAcc& A, int32_t* cnt, int32_t* sum, int nn, bool valid, int at, int len) {
+    unsigned long long active = __ballot(valid);
+    const int lane = threadIdx.x & 63;
+    if (!valid) { at = -1; len = 0; }
+    while (active) {
+        int leader = __ffsll((long long)active) - 1;
+        int k = __shfl(at, leader, 64);
+        unsigned long long same = __ballot(at == k) & active;
+        int v = (at == k) ? len : 0;
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        if (lane == leader) {
+            bool done = false;
+            for (int q = 0; q < 4 && !done; ++q) {
+                const int old = atomicCAS(&A.key[q], -1, k);
+                if (old == -1 || old == k) { atomicAdd(&A.cnt[q], (int)__popcll(same)); atomicAdd(&A.sum[q], v); done = true; }
+            }
+            if (!done) {
+                const size_t so = (size_t)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (NODE_STRIPES - 1)) * (size_t)nn;
+                atomicAdd(&cnt[so + k], (int)__popcll(same)); atomicAdd(&sum[so + k], v);
+            }
+        }
+        active &= ~same;
+    }
+}
 __global__ void k_depth(RecView R, NodeView N, const uint8_t* keep, const int32_t* rank1, int32_t n_break, const int32_t* cursor,
                         int32_t* main_cnt, int32_t* main_sum, int32_t* other_cnt, int32_t* other_sum, int32_t* amb_plus, int32_t* amb_minus, int32_t* flags, int32_t* stripes) {
+    __shared__ NodeAcc s_acc[2];  // [0] ReadsMain, [1] ReadsOther
+    if (threadIdx.x < 8) { s_acc[threadIdx.x >> 2].key[threadIdx.x & 3] = -1; s_acc[threadIdx.x >> 2].cnt[threadIdx.x & 3] = 0; s_acc[threadIdx.x >> 2].sum[threadIdx.x & 3] = 0; }
+    __syncthreads();
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     // everything the record needs is requested up front, the loads independent of each other (as in k_edges_near): the fixed
     // fields and the cursor in one memory round trip, behind them the first two blocks, the cursor's node and the index
@@ -1078,7 +1109,7 @@ __global__ void k_depth(RecView R, NodeView N, const uint8_t* keep, const int32_
             if (ncur.x != c) atomicOr(&flags[0], 1);  // cursor stuck on another chromosome: stream not sorted
             else hit = p >= ncur.y - 3 && p + len <= ncur.y + ncur.z + 3;
         }
-        node_add(main_cnt, main_sum, N.n, hit, at, len);
+        node_add_lds(s_acc[0], main_cnt, main_sum, N.n, hit, at, len);
     }
     // ReadsOther: sorted by (chr,pos) in the reference => consumed at its home node
     int maxb = nblk;
@@ -1113,7 +1144,7 @@ __global__ void k_depth(RecView R, NodeView N, const uint8_t* keep, const int32_
     for (int j = 0; j < UNR; ++j) {
         if (j + 1 >= maxb) break;  // wave-uniform
         if (j + 1 < nblk && ek[j] != hk[j]) ambiguous(ek[j], hk[j], lk[j], hitk[j]);
-        node_add(other_cnt, other_sum, N.n, hitk[j], hk[j], lk[j]);
+        node_add_lds(s_acc[1], other_cnt, other_sum, N.n, hitk[j], hk[j], lk[j]);
     }
     for (int k = UNR + 1; k < maxb; ++k) {  // wave-uniform trip count
         bool hit = false;
@@ -1125,11 +1156,21 @@ __global__ void k_depth(RecView R, NodeView N, const uint8_t* keep, const int32_
             hit = p + len <= N.pos[home] + N.len[home] + 3;
             if (early != home) ambiguous(early, home, len, hit);
         }
-        node_add(other_cnt, other_sum, N.n, hit, home, len);
+        node_add_lds(s_acc[1], other_cnt, other_sum, N.n, hit, home, len);
     }
     int no = nblk > 1 ? nblk - 1 : 0;
     for (int d = 32; d >= 1; d >>= 1) no += __shfl_xor(no, d, 64);
     if ((threadIdx.x & 63) == 0 && no) stripe_add(stripes, no);
+    __syncthreads();
+    if (threadIdx.x < 8) {  // the workgroup's table -> the striped global accumulators
+        const NodeAcc& A = s_acc[threadIdx.x >> 2];
+        const int q = threadIdx.x & 3, k = A.key[q];
+        if (k >= 0) {
+            const size_t so = (size_t)(blockIdx.x & (NODE_STRIPES - 1)) * (size_t)N.n;
+            int32_t *gc = threadIdx.x < 4 ? main_cnt : other_cnt, *gs = threadIdx.x < 4 ? main_sum : other_sum;
+            atomicAdd(&gc[so + k], A.cnt[q]); atomicAdd(&gs[so + k], A.sum[q]);
+        }
+    }
 }
 __global__ void k_fold_stripes(int nn, const int32_t* a, const int32_t* b, const int32_t* c2, const int32_t* d, int32_t* out /* 4 x nn */) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
