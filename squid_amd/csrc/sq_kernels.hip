@@ -3180,9 +3180,26 @@ __global__ __launch_bounds__(128) void k_lz_resolve2(const uint32_t* tok, const 
                 wave_sync();
                 if (pending && ready_at <= hwm) {
                     if (dist >= 8) {  // eight bytes per load and store (the source of a slice lies at least 8 bytes below its target)
-                        uint32_t k = 0;
-                        for (; k + 8 <= len; k += 8) { unsigned long long w; __builtin_memcpy(&w, lz_win + src + k, 8); __builtin_memcpy(lz_win + o + k, &w, 8); }
-                        for (; k < len; ++k) lz_win[o + k] = lz_win[src + k];
+                        if (len <= 8) {
+                            // most matches of a BAM stream: one load, two overlapping stores (bytes 0..3 and len-4..len-1; a match of
+                            // three bytes: 0..1 and 2) instead of a byte loop whose every step waits for its own load
+                            unsigned long long w;
+                            __builtin_memcpy(&w, lz_win + src, 8);  // (the bytes behind the match are read, not stored)
+                            if (len >= 4) {
+                                const uint32_t lo4 = (uint32_t)w, hi4 = (uint32_t)(w >> (8 * (len - 4)));
+                                __builtin_memcpy(lz_win + o, &lo4, 4); __builtin_memcpy(lz_win + o + len - 4, &hi4, 4);
+                            } else {
+                                const uint16_t lo2 = (uint16_t)w; const uint8_t b2 = (uint8_t)(w >> 16);
+                                __builtin_memcpy(lz_win + o, &lo2, 2); lz_win[o + 2] = b2;
+                            }
+                        } else {
+                            uint32_t k = 0;
+                            for (; k + 8 <= len; k += 8) { unsigned long long w; __builtin_memcpy(&w, lz_win + src + k, 8); __builtin_memcpy(lz_win + o + k, &w, 8); }
+                            if (k < len) {  // the tail the same way: the last eight bytes of the match, overlapping what is already there
+                                unsigned long long w;
+                                __builtin_memcpy(&w, lz_win + src + len - 8, 8); __builtin_memcpy(lz_win + o + len - 8, &w, 8);
+                            }
+                        }
                         pending = false;
                     }
                     // every byte comes from [src, src + min(dist, len)): final, so the reads of a slice go out together
