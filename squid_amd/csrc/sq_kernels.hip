@@ -2844,9 +2844,14 @@ __device__ __forceinline__ uint32_t t2_take(ILane& b, uint32_t& ahead, int k) {
     return v;
 }
 template <bool PROF>
-__global__ __launch_bounds__(64, 1) void k_inflate_tok2(const uint8_t* file, const InflBlock* blocks, int nblocks, unsigned long long out_base, int32_t* flags, uint32_t* tok, int32_t* ntok,
+__global__ __launch_bounds__(128, 1) void k_inflate_tok2(const uint8_t* file, const InflBlock* blocks, int nblocks, unsigned long long out_base, int32_t* flags, uint32_t* tok, int32_t* ntok,
                                                     unsigned long long* prof) {
-    extern __shared__ uint16_t il_lds[];  // T2_LDS_BYTES
+    // One or two waves per workgroup, each with its own T2_LDS_BYTES and its own 64 blocks; they never talk to each other.  Two
+    // waves make a workgroup of 96 KB: a CU takes one of them and no second -- at most two token waves per CU, and the 64 KB
+    // that remain are exactly the slot of a resolve workgroup (with single-wave workgroups a CU fills up with three token
+    // waves for 36 ms and the resolve, which is what the wall time follows, finds no room there).
+    extern __shared__ uint16_t il_lds_all[];  // T2_LDS_BYTES per wave
+    uint16_t* il_lds = il_lds_all + (size_t)(threadIdx.x >> 6) * (T2_LDS_BYTES / 2);
     unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pc = 0;
     auto tick = [&](int k) { if (PROF) { const unsigned long long now = __builtin_amdgcn_s_memtime(); pt[k] += now - pc; pc = now; } };
     if (PROF) pc = __builtin_amdgcn_s_memtime();
@@ -2857,10 +2862,10 @@ __global__ __launch_bounds__(64, 1) void k_inflate_tok2(const uint8_t* file, con
     uint32_t* stage = (uint32_t*)(L.tmp_b + 16 * 64);  // tokens on their way out: stage[(k % IL_STAGE) * 64 + lane]
     uint32_t* ring = stage + IL_STAGE * 64;
     L.sym_ll = (uint8_t*)(ring + IL_RING * 64);  L.sym_dd = L.sym_ll + T2_SYM_LL * 64;  L.lens4 = L.sym_dd + T2_SYM_DD * 64;
-    const int lane = threadIdx.x;
-    if (lane < 19) sh_clo[lane] = c_clorder[lane];
+    const int lane = threadIdx.x & 63;
+    if (lane < 19) sh_clo[lane] = c_clorder[lane];  // (both waves write the same values)
     wave_sync();
-    const int bi = blockIdx.x * 64 + lane;
+    const int bi = (blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6)) * 64 + lane;
     const bool have = bi < nblocks;
     InflBlock blk{0, 0, 0, 0};
     if (have) blk = blocks[bi];
@@ -3590,8 +3595,9 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     HIPCHK(hipFuncSetAttribute((const void*)k_inflate_lanes<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)IL_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_lz_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16));
     HIPCHK(hipFuncSetAttribute((const void*)k_lz_resolve2, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16));
-    HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T2_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T2_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)T2_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)T2_LDS_BYTES));
+    static const int tok_wpb = std::getenv("SQUID_TOK_WPB") ? std::max(1, std::min(2, std::atoi(std::getenv("SQUID_TOK_WPB")))) : 2;  // token waves per workgroup
     static const bool tok_prof = std::getenv("SQUID_TOK_PROF") != nullptr;
     if (tok_prof) HIPCHK(D.tok_prof.reserve(8 * 4096));
     static const bool tok_v1 = std::getenv("SQUID_TOK_V1") != nullptr;  // the table-driven token pass (one wave per CU), kept for comparison
@@ -3680,7 +3686,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
             EvTimer t1(c, "k_inflate_tokens", (double)B.cbytes + (double)B.bbytes * 2, sa);
             if (tok_v1) hipLaunchKernelGGL(k_inflate_lanes<true>, dim3((nb + 63) / 64), dim3(64), IL_LDS_BYTES, sa, st.src, st.tab.p, nb, B.bbase, nullptr, st.flags.p, st.tok.p, st.ntok.p);
             else if (tok_prof && k == 8) hipLaunchKernelGGL(k_inflate_tok2<true>, dim3((nb + 63) / 64), dim3(64), T2_LDS_BYTES, sa, st.src, st.tab.p, nb, B.bbase, st.flags.p, st.tok.p, st.ntok.p, D.tok_prof.p);
-            else hipLaunchKernelGGL(k_inflate_tok2<false>, dim3((nb + 63) / 64), dim3(64), T2_LDS_BYTES, sa, st.src, st.tab.p, nb, B.bbase, st.flags.p, st.tok.p, st.ntok.p, nullptr);
+            else hipLaunchKernelGGL(k_inflate_tok2<false>, dim3(((nb + 63) / 64 + tok_wpb - 1) / tok_wpb), dim3(64 * tok_wpb), tok_wpb * T2_LDS_BYTES, sa, st.src, st.tab.p, nb, B.bbase, st.flags.p, st.tok.p, st.ntok.p, nullptr);
         }
         HIPCHK(hipEventRecord(st.ready, sa));
         return SQ_OK;
