@@ -10,7 +10,8 @@ from step to step except device buffers (sq_clear_records).
 Workload: BASELINE.json configs[2] -- "Full hg38, 50M-read synthetic STAR concordant+chimeric BAM, 1xMI355X" --
 generator config C3 (50.8 M concordant records, zlib level 6), the largest single-GPU configuration.
 `value` = alignments/s with the compressed BAM bytes resident in HBM when the timed region starts (sq_stage_bam);
-`from_file_value` = the same step reading the BAM from the page cache (host->device copy of the file included).
+`from_file_value` = the same step reading the BAM from the page cache (host->device copy of the file included), measured
+after the timed region in a fresh context.
 `resident_pass_value` = the graph pass alone over records already decoded in HBM (what round 1 reported).
 
 N > 1 (`--gpus N`; the script launches its own ranks through torch.distributed.run when WORLD_SIZE is not set):
