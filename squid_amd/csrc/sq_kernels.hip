@@ -3578,18 +3578,18 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     HIPCHK(hipSetDevice(c->P.device));
     DeviceRecords& D = *c->dev;
     hipStream_t s = c->stream;
-    {   // the batch buffers take ~12 GB next to the record arrays: on a GPU that is short of memory the host reader runs instead
+    {   // the batch buffers take ~25 GB next to the record arrays: on a GPU that is short of memory the host reader runs instead
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < ((size_t)20 << 30)) { (void)hipGetLastError(); return 2; }
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < ((size_t)32 << 30)) { (void)hipGetLastError(); return 2; }
     }
     const int64_t n_save = D.n, nb_save = D.nb;
     auto give_up = [&]() { (void)hipDeviceSynchronize(); D.n = n_save; D.nb = nb_save; c->counts.n_concordant = D.n; c->counts.n_blocks = D.nb; return 2; };
     const bool report = std::getenv("SQUID_INGEST_TIMING") != nullptr, check = std::getenv("SQUID_INFLATE_CHECK") != nullptr;
     const auto w0 = std::chrono::steady_clock::now();
     auto since_ms = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
-    // a batch = 180 waves of the token pass: one token kernel runs at a time, its waves all resident (one per CU), and the
-    // other ~76 CUs (plus those of the waves that finish early) take the resolve / boundary / parse kernels of the batch before
-    const unsigned long long cap = std::getenv("SQUID_TOK_CAP_MB") ? (unsigned long long)std::atoll(std::getenv("SQUID_TOK_CAP_MB")) << 20 : 180ull * 64 * 65536;
+    // a batch = 256 waves of the token pass (1 GiB inflated): the token workgroups take two waves of every CU (see k_inflate_tok2),
+    // 512 in all, so two batches fill the machine exactly; measured at C3: 512 MB 303 ms, 720 MB 238, 1 GiB 233, 1.4 GB 244, 2 GB 256
+    const unsigned long long cap = std::getenv("SQUID_TOK_CAP_MB") ? (unsigned long long)std::atoll(std::getenv("SQUID_TOK_CAP_MB")) << 20 : 256ull * 64 * 65536;
     const int variant = std::getenv("SQUID_GPU_INFLATE_WAVE") ? 2 : (std::getenv("SQUID_GPU_INFLATE_ONEPASS") ? 1 : 0);  // 0: tokens + resolve
     HIPCHK(hipFuncSetAttribute((const void*)k_inflate_lanes<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)IL_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_inflate_lanes<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)IL_LDS_BYTES));
