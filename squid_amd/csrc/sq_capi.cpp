@@ -164,10 +164,8 @@ static int build_graph(sq_ctx* c) {
                 }
             }
         }
-        rc = dev_dedup_summarise(c);
-        const double cl_ms = g.clusters.get();
+        const double cl_ms = g.clusters.get();  // (k_pass1 needs the cluster table up front: it reads the records once, for everything)
         c->timer.add("host_cluster_table", cl_ms);
-        if (rc) return rc;
         long long other_max = INT64_MIN;
         int32_t first_kept[2] = {0, 0};
         {

@@ -126,6 +126,9 @@ struct Pinned {
     void release() { for (auto& ch : chunks) (void)hipHostFree(ch.first); chunks.clear(); used = 0; }
 };
 
+// one tile of k_summarise_tiles: kept records [lo, hi) of the tile at rec_base (rank_base kept records in front of it); output index = dst + (rank - lo)
+struct SumItem { int64_t rec_base; int32_t rank_base, lo, hi; int64_t dst; };
+
 struct DeviceRecords {
     int64_t n = 0, nb = 0;
     Pinned pin;
@@ -179,7 +182,15 @@ struct DeviceRecords {
     DBuf<int32_t> calib;
     DBuf<uint8_t> zflag;
     DBuf<int32_t> cl_chr, trig;  // cl_chr: packed cluster table chr | start | right
-    DBuf<int32_t> bp_ev, bp_end, bp_valid, bp_bucket, stripes;
+    DBuf<int32_t> bp_ev, bp_before, bp_end, bp_valid, bp_bucket, stripes;
+    // pass 1 (k_pass1): look-back status words, kept records in front of every tile, tile sort keys, the three lists, scalars
+    DBuf<unsigned long long> lb;
+    DBuf<int32_t> tile_rank, z_idx, z_chr, z_right, rc_cluster, rc_pos, rc_len, p1_sc;
+    DBuf<long long> tile_first, tile_max, r_break;
+    DBuf<SumItem> sum_items;
+    size_t zcap = (size_t)1 << 20, rc_cap = (size_t)1 << 18;
+    int p1_nz = 0, p1_rest = 0, p1_ntiles = 0;
+    std::vector<int32_t> h_tile_rank;  // host copy of tile_rank (dev_segment_support)
     DBuf<int32_t> flags;  // small device flag/counter block
     struct Pending { const char* name; double bytes; int slot; };
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -739,54 +750,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_parse_write(const uint8_t* ba
     o_blkoff[r] = b0;
 }
 
-// ------------------------------------------------------------------------------------------------ K1: classify
-__global__ void k_classify(RecView R, int min_mapq, uint8_t* cls) {
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R.n) return;
-    const int flag = R.flag[r], aux = R.aux[r];
-    const int refid = R.refid[r], pos = R.pos[r], mrefid = R.mrefid[r], mpos = R.mpos[r];
-    const bool mapped = !(flag & 0x4), matemapped = !(flag & 0x8), rev = flag & 0x10, materev = flag & 0x20;
-    const bool first = flag & 0x40, second = flag & 0x80, proper = flag & 0x2, dup = flag & 0x400;
-    uint8_t c = 0;
-    bool p2 = !(aux & SQ_AUX_MULTI) && !(aux & SQ_AUX_INCHIM) && !dup && mapped && (int)R.mapq[r] >= min_mapq;
-    bool p1 = p2 && refid != -1;
-    if (p2) c |= C_P2;
-    if (p1) c |= C_P1;
-    if (p1) {
-        bool skip = (matemapped && mrefid == refid && mpos > pos) || (matemapped && mrefid == refid && mpos == pos && second);
-        if (!skip) c |= C_P3;
-    }
-    if (matemapped && mrefid != -1) c |= C_HASSTUB;
-    const int nblk = (int)(R.blk_off[r + 1] - R.blk_off[r]);
-    bool conc = false;
-    if (mapped && matemapped && mrefid != -1 && refid == mrefid && proper) {
-        if (rev && !materev && pos >= mpos && pos - mpos <= 750000) conc = true;
-        else if (!rev && materev && mpos >= pos && mpos - pos <= 750000) conc = true;
-    }
-    if (conc && nblk > 0) {
-        c |= C_CONC;
-        // partial alignment: clipped by more than 15 bases at either read end and not low-Phred
-        // (the reference tests the record's own mate side; a record with neither 0x40 nor 0x80 matches no branch)
-        if ((first || second) && !(aux & SQ_AUX_LOWPHRED)) {
-            DBlk f = own_block_sorted(R, r, 0, nblk, rev), b = own_block_sorted(R, r, nblk - 1, nblk, rev);
-            if (f.readpos > 15 || (int)R.totlen[r] - b.readpos - b.matchread > 15) c |= C_PART;
-        }
-    }
-    cls[r] = c;
-}
-
-// functors for the scans
-struct FPrev { const uint8_t* cls; uint8_t bit; __device__ int operator()(int64_t i) const { return (cls[i] & bit) ? (int)i : -1; } };
-struct FKeep { const uint8_t* keep; uint8_t bit; __device__ int operator()(int64_t i) const { return (keep[i] & bit) ? 1 : 0; } };
-struct FRest {
-    const uint8_t *keep, *cls; const uint32_t* blk_off;
-    __device__ int operator()(int64_t i) const {
-        if (!(keep[i] & K_1) || !(cls[i] & C_CONC)) return 0;
-        int nb = (int)(blk_off[i + 1] - blk_off[i]);
-        return nb > 1 ? nb - 1 : 0;
-    }
-};
-
+// ------------------------------------------------------------------------------------------------ K1: record keys (the filters, the duplicate drop and the stream scans are k_pass1, sq_pass_kernels.inc)
 // ReadRec_t::Equal (ReadRec.cpp:119-141) on two records whose fixed fields are already in registers: the loads of both records are
 // issued together and up front (rec_equal above re-reads them field by field inside its loops, one dependent round trip each)
 struct RecKey { int nown, rid, mrid, mp; uint32_t bo; bool first, rev, stub; int4 e0; };  // e0: the first own block in read order
@@ -825,89 +789,6 @@ __device__ bool key_equal(const RecView& R, const RecKey& kq, const RecKey& kr) 
     }
     return false;
 }
-// what the next shard has to know about the last pass-1 / pass-2 record of this one
-__global__ void k_last_info(RecView R, const uint8_t* cls, int32_t* out) {
-    for (int p = 0; p < 2; ++p) {
-        const uint8_t bit = p ? C_P2 : C_P1;
-        int64_t q = R.n - 1;
-        while (q >= 0 && !(cls[q] & bit)) --q;
-        out[2 * p] = q >= 0 ? 1 : 0;
-        bool empty = false;
-        if (q >= 0) { ListRec l = list_rec(R, q); empty = l.nown == 0 && !l.stub; }
-        out[2 * p + 1] = empty ? 1 : 0;
-    }
-}
-// The record a passing record is compared with is the previous one that passes the same filter: nearly always the neighbour, so
-// the kernel looks for it itself (a byte per step back through cls[]) instead of reading it from two prefix-max scans.
-// prior_mask (chromosome-sharded runs): bit0 / bit1 = a pass-1 / pass-2 record with non-empty lists precedes this
-// shard; it lies on another chromosome, so the first passing record here is not Equal to it.  Without the bit the
-// predecessor is the empty initial lastreadrec (or a record whose lists are just as empty).
-__global__ void k_dedup(RecView R, const uint8_t* cls, int prior_mask, uint8_t* keep) {
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R.n) return;
-    // this record and its predecessor (nearly always the previous passing record of both passes) are loaded together, before
-    // the class bytes say whether either is needed: two round trips instead of a chain of five
-    const RecKey kr = rec_key(R, r), km = rec_key(R, r - 1);
-    uint8_t c = cls[r], k = 0;
-    const uint8_t cm = r > 0 ? cls[r - 1] : 0;  // (with cls[r], not behind it: the walk back usually ends at r - 1)
-    if (!(c & (C_P1 | C_P2))) { keep[r] = 0; return; }
-    auto prev_of = [&](uint8_t bit) { if (r > 0 && (cm & bit)) return r - 1; int64_t q = r - 2; while (q >= 0 && !(cls[q] & bit)) --q; return q; };
-    int64_t p1 = -1;
-    if (c & C_P1) {
-        p1 = prev_of(C_P1);
-        bool eq = false;
-        if (!(p1 < 0 && (prior_mask & 1))) eq = p1 == r - 1 ? key_equal(R, km, kr) : key_equal(R, rec_key(R, p1), kr);
-        if (!eq) k |= K_1;
-    }
-    if (c & C_P2) {
-        const int64_t p2 = prev_of(C_P2);
-        bool eq;
-        if (p2 < 0) eq = (prior_mask & 2) ? false : key_equal(R, rec_key(R, -1), kr);
-        else eq = (c & C_P1) && p1 == p2 ? !(k & K_1) : p2 == r - 1 ? key_equal(R, km, kr) : key_equal(R, rec_key(R, p2), kr);
-        if (!eq) {
-            k |= K_2;
-            // whetherbuildedge (SegmentGraph.cpp:1601-1605) on the stub-augmented, sorted record
-            bool build;
-            if (key_size(kr, 0) == 0 || key_size(kr, 1) == 0) build = true;
-            else {
-                // the stub side always has ReadPos 0 <= 15; the own side is tested with its own low-Phred flag
-                build = (int)((uint32_t)kr.e0.z & 0xffffu) <= 15 || (R.aux[r] & SQ_AUX_LOWPHRED);
-            }
-            if (build) k |= K_BUILD;
-        }
-    }
-    keep[r] = k;
-}
-
-__global__ void k_summarise(RecView R, const uint8_t* cls, const uint8_t* keep, const int32_t* rank1, const int32_t* restoff,
-                            StreamRec* out, int32_t* rest_refpos, int32_t* rest_matchref, long long* other_key) {
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R.n || !(keep[r] & K_1)) return;
-    StreamRec s;
-    s.refid = R.refid[r]; s.pos = R.pos[r];
-    uint32_t b0 = R.blk_off[r];
-    int nblk = (int)(R.blk_off[r + 1] - b0);
-    uint8_t c = cls[r], fl = 0;
-    s.fb_refpos = 0; s.fb_matchref = 0; s.fb_readpos = 0; s.nrest = 0; s.rest_off = 0;
-    if (nblk > 0) {
-        fl |= SR_HASBLK;
-        s.fb_refpos = R.b_refpos[b0]; s.fb_matchref = R.b_matchref[b0]; s.fb_readpos = R.b_readpos[b0];
-    }
-    if (c & C_CONC) fl |= SR_CONC;
-    if (c & C_PART) fl |= SR_PART;
-    if (R.flag[r] & 0x10) fl |= SR_REV;
-    if (R.flag[r] & 0xC0) fl |= SR_MATE;
-    if ((c & C_CONC) && nblk > 1) {
-        s.nrest = (uint8_t)(nblk - 1 > 255 ? 255 : nblk - 1);
-        s.rest_off = (uint32_t)restoff[r];
-        for (int k = 1; k < nblk; ++k) { rest_refpos[restoff[r] + k - 1] = R.b_refpos[b0 + k]; rest_matchref[restoff[r] + k - 1] = R.b_matchref[b0 + k]; }
-    }
-    s.flags = fl;
-    out[rank1[r]] = s;
-    // key of the running (otherChr, otherrightmost) pair, SegmentGraph.cpp:655-667 (its max-scan streams 8 B instead of the summary)
-    other_key[rank1[r]] = (fl & (SR_CONC | SR_MATE)) == (SR_CONC | SR_MATE) ? (((long long)s.refid << 32) | (unsigned int)(s.fb_refpos + s.fb_matchref)) : LLONG_MIN;
-}
-
 // ------------------------------------------------------------------------------------------------ K2 support
 // The discordant-cluster list is static (it depends only on the sorted chimeric blocks), so everything the
 // segmentation automaton needs from the N_c-sized stream can be computed by scans over the kept records:
@@ -925,71 +806,6 @@ __device__ __forceinline__ int clusters_passed(const ClusterView& C, int refid, 
     while (lo < hi) { int mid = (lo + hi) >> 1; if (C.chr[mid] < refid || (C.chr[mid] == refid && C.right[mid] < pos)) lo = mid + 1; else hi = mid; }
     return lo;
 }
-struct FKey64 { const long long* a; __device__ long long operator()(int64_t i) const { return a[i]; } };
-// k counts the records of the local stream plus, in a sharded run, the appended first kept record of the next shard
-// (index k_own; its running pair is the aggregate of the whole local stream).  `seed` = running pair of earlier shards.
-__device__ __forceinline__ long long other_at(const long long* other_before, const long long* other_all, int64_t k_own, long long seed, int64_t i) {
-    long long ob = i < k_own ? other_before[i] : *other_all;
-    if (ob < seed) ob = seed;
-    return ob < 0 ? 0 : ob;  // initial otherChr = 0, otherrightmost = 0
-}
-__global__ void k_zerocov(const StreamRec* sr, int64_t k, int64_t k_own, ClusterView C, const long long* other_before, const long long* other_all, long long seed, int RL, uint8_t* zflag,
-                          int32_t* flags) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= k) return;
-    const StreamRec r = sr[i];
-    if (i > 0) {  // the kept stream must be coordinate sorted (README.md:23); everything here relies on it
-        const StreamRec q = sr[i - 1];
-        if (q.refid > r.refid || (q.refid == r.refid && q.pos > r.pos)) atomicOr(&flags[0], 1);
-    }
-    const int K = clusters_passed(C, r.refid, r.pos);
-    const int disChr = K > 0 ? C.chr[K - 1] : 0, disRight = K > 0 ? C.right[K - 1] : 0;
-    const int dnChr = K < C.n ? C.chr[K] : 0, dnPos = K < C.n ? C.start[K] : 0;  // zero sentinel after the last cluster (ledger B21)
-    const long long ob = other_at(other_before, other_all, k_own, seed, i);
-    const int oChr = (int)(ob >> 32), oRight = (int)(ob & 0xffffffffll);
-    const bool disLead = disChr > oChr || (disChr == oChr && disRight > oRight);
-    const int curRight = disLead ? disRight : oRight, curChr = disChr > oChr ? disChr : oChr;
-    const bool z = (r.refid != curChr || r.pos > curRight + RL) && (curChr < dnChr || (curChr == dnChr && curRight + RL < dnPos));
-    zflag[i] = z ? 1 : 0;
-}
-struct FByte { const uint8_t* a; __device__ int operator()(int64_t i) const { return a[i]; } };
-__global__ void k_zgather(int64_t k, int64_t k_own, const uint8_t* zflag, const int32_t* zrank, const long long* other_before, const long long* other_all, long long seed, int32_t* zidx,
-                          int32_t* zchr, int32_t* zright) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= k || !zflag[i]) return;
-    const long long ob = other_at(other_before, other_all, k_own, seed, i);
-    int s = zrank[i];
-    zidx[s] = (int32_t)i; zchr[s] = (int)(ob >> 32); zright[s] = (int)(ob & 0xffffffffll);
-}
-__global__ void k_triggers(const StreamRec* sr, int64_t k, ClusterView C, int32_t* trigger) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C.n) return;
-    int64_t lo = 0, hi = k;  // first record with (refid,pos) > (chr_c, right_c)
-    while (lo < hi) {
-        int64_t mid = (lo + hi) >> 1;
-        const int rid = sr[mid].refid, rp = sr[mid].pos;
-        if (rid < C.chr[c] || (rid == C.chr[c] && rp <= C.right[c])) lo = mid + 1; else hi = mid;
-    }
-    trigger[c] = (int32_t)lo;
-}
-__global__ void k_rest_candidates(const StreamRec* sr, int64_t k, ClusterView C, int RL, const int32_t* rest_refpos, const int32_t* rest_matchref, int32_t* counter, int32_t* o_cluster,
-                                  int32_t* o_pos, int32_t* o_len) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= k) return;
-    const StreamRec r = sr[i];
-    if ((r.flags & (SR_CONC | SR_MATE)) != (SR_CONC | SR_MATE) || r.nrest == 0) return;
-    for (int b = 0; b < r.nrest; ++b) {
-        const int p = rest_refpos[r.rest_off + b];
-        // first cluster on this chromosome whose right end lies beyond p
-        int lo = 0, hi = C.n;
-        while (lo < hi) { int mid = (lo + hi) >> 1; if (C.chr[mid] < r.refid || (C.chr[mid] == r.refid && C.right[mid] <= p)) lo = mid + 1; else hi = mid; }
-        if (lo < C.n && C.chr[lo] == r.refid && p >= C.start[lo] - RL) {
-            int s = atomicAdd(counter, 1);
-            o_cluster[s] = lo; o_pos[s] = p; o_len[s] = rest_matchref[r.rest_off + b];
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ K3: node depth
 // Node at which the reference's monotone cursor (SegmentGraph.cpp:787-799 / :809-821) would first accept a
 // block starting at p: normally the node containing p; a block of <= 3 bases that starts right behind a node
@@ -1003,18 +819,6 @@ __device__ __forceinline__ int depth_early(const NodeView& N, int c, int p, int 
     }
     return j;
 }
-struct FEarlyMain {  // first block of every consumed kept record, in stream order
-    RecView R; NodeView N; const uint8_t* keep; const int32_t* rank1; int32_t n_break;
-    __device__ int operator()(int64_t r) const {
-        if (!(keep[r] & K_1) || rank1[r] >= n_break) return -1;
-        uint32_t b0 = R.blk_off[r];
-        if (R.blk_off[r + 1] == b0) return -1;
-        int c = R.refid[r];
-        if (c < 0 || c >= N.n_ref) return -1;
-        int home;
-        return depth_early(N, c, R.b_refpos[b0], R.b_matchref[b0], home);
-    }
-};
 // statistics counters: one atomic per wave, spread over NSTRIPE addresses (a single hot address serialises in L2:
 // 800 k waves adding to one word cost more than the rest of the kernel); the host sums the stripes
 constexpr int NSTRIPE = 256;
@@ -1022,10 +826,6 @@ __device__ __forceinline__ void stripe_add(int32_t* stripes, int v) {
     atomicAdd(&stripes[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (NSTRIPE - 1)], v);
 }
 
-__global__ void k_early(int64_t n, FEarlyMain f, int32_t* out) {  // the scan then streams 4 B instead of evaluating the lookup twice
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n) out[r] = f(r);
-}
 // add (1, len) to node `at` for every lane with `valid`; lanes of a wave that hit the same node are combined first
 // (a wave covers 64 neighbouring records of the sorted stream, which almost always share their node).
 // Must be called by ALL lanes of the wave (the shuffles read every lane).
@@ -1077,101 +877,6 @@ __device__ __forceinline__ void node_add_lds(NodeAcc& A, int32_t* cnt, int32_t* 
         active &= ~same;
     }
 }
-__global__ void k_depth(RecView R, NodeView N, const uint8_t* keep, const int32_t* rank1, int32_t n_break, const int32_t* cursor,
-                        int32_t* main_cnt, int32_t* main_sum, int32_t* other_cnt, int32_t* other_sum, int32_t* amb_plus, int32_t* amb_minus, int32_t* flags, int32_t* stripes) {
-    __shared__ NodeAcc s_acc[2];  // [0] ReadsMain, [1] ReadsOther
-    if (threadIdx.x < 8) { s_acc[threadIdx.x >> 2].key[threadIdx.x & 3] = -1; s_acc[threadIdx.x >> 2].cnt[threadIdx.x & 3] = 0; s_acc[threadIdx.x >> 2].sum[threadIdx.x & 3] = 0; }
-    __syncthreads();
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    // everything the record needs is requested up front, the loads independent of each other (as in k_edges_near): the fixed
-    // fields and the cursor in one memory round trip, behind them the first two blocks, the cursor's node and the index
-    // geometry of the chromosome together in a second
-    const bool inr = r < R.n;
-    const uint8_t kp = inr ? keep[r] : 0;
-    const int32_t rk = inr ? rank1[r] : 0, cur = inr ? cursor[r] : 0;
-    const uint32_t b0 = inr ? R.blk_off[r] : 0, b1 = inr ? R.blk_off[r + 1] : 0;
-    int c = inr ? R.refid[r] : 0;
-    const bool live = inr && (kp & K_1) && rk < n_break;
-    int nblk = live ? (int)(b1 - b0) : 0;
-    if (nblk > 0 && (c < 0 || c >= N.n_ref)) { atomicOr(&flags[0], 1); nblk = 0; }
-    int4 q0 = make_int4(0, 0, 0, 0), q1 = q0, ncur = q0;
-    int geo0 = 0, geo1 = 2;
-    if (nblk > 0) { q0 = R.b_pack[b0]; ncur = N.pack[cur]; }
-    if (nblk > 1) { q1 = R.b_pack[b0 + 1]; geo0 = N.fine_off[c]; geo1 = N.fine_off[c + 1]; }
-    // ReadsMain: consumed at the prefix-max cursor
-    {
-        bool hit = false;
-        int at = 0, len = 0;
-        if (nblk > 0) {
-            const int p = q0.x;
-            len = q0.y;
-            at = cur;
-            if (ncur.x != c) atomicOr(&flags[0], 1);  // cursor stuck on another chromosome: stream not sorted
-            else hit = p >= ncur.y - 3 && p + len <= ncur.y + ncur.z + 3;
-        }
-        node_add_lds(s_acc[0], main_cnt, main_sum, N.n, hit, at, len);
-    }
-    // ReadsOther: sorted by (chr,pos) in the reference => consumed at its home node
-    int maxb = nblk;
-    for (int d = 32; d >= 1; d >>= 1) { int o = __shfl_xor(maxb, d, 64); maxb = o > maxb ? o : maxb; }
-    // a <=3-base block right behind a node boundary: the reference counts it for whichever node its sweep cursor is on,
-    // which depends on the tie order of an unstable sort (SegmentGraph.cpp:781).  Record the bounds.
-    auto ambiguous = [&](int early, int home, int len, bool hit) {
-        atomicOr(&flags[0], 2);
-        for (int q = early; q < home; ++q) atomicAdd(&amb_plus[q], len);
-        if (hit) atomicAdd(&amb_minus[home], len);
-    };
-    // blocks 1..3 of every record are located together (independent load chains overlap), then added; the rare
-    // records with more blocks finish in the serial loop below
-    constexpr int UNR = 3;
-    int hk[UNR], ek[UNR], lk[UNR];
-    bool hitk[UNR];
-#pragma unroll
-    for (int j = 0; j < UNR; ++j) {
-        hk[j] = 0; ek[j] = 0; lk[j] = 0; hitk[j] = false;
-        if (j + 1 < nblk) {
-            const int4 q = j == 0 ? q1 : R.b_pack[b0 + j + 1];
-            const int p = q.x;
-            lk[j] = q.y;
-            hk[j] = node_home_geo(N, geo0, geo1, p);
-            ek[j] = hk[j];
-            if (lk[j] <= 3) ek[j] = depth_early(N, c, p, lk[j], hk[j]);  // (only a block of <= 3 bases can be accepted before its home node)
-            const int4 nh = N.pack[hk[j]];
-            hitk[j] = p + lk[j] <= nh.y + nh.z + 3;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < UNR; ++j) {
-        if (j + 1 >= maxb) break;  // wave-uniform
-        if (j + 1 < nblk && ek[j] != hk[j]) ambiguous(ek[j], hk[j], lk[j], hitk[j]);
-        node_add_lds(s_acc[1], other_cnt, other_sum, N.n, hitk[j], hk[j], lk[j]);
-    }
-    for (int k = UNR + 1; k < maxb; ++k) {  // wave-uniform trip count
-        bool hit = false;
-        int home = 0, len = 0;
-        if (k < nblk) {
-            int p = R.b_refpos[b0 + k];
-            len = R.b_matchref[b0 + k];
-            int early = depth_early(N, c, p, len, home);
-            hit = p + len <= N.pos[home] + N.len[home] + 3;
-            if (early != home) ambiguous(early, home, len, hit);
-        }
-        node_add_lds(s_acc[1], other_cnt, other_sum, N.n, hit, home, len);
-    }
-    int no = nblk > 1 ? nblk - 1 : 0;
-    for (int d = 32; d >= 1; d >>= 1) no += __shfl_xor(no, d, 64);
-    if ((threadIdx.x & 63) == 0 && no) stripe_add(stripes, no);
-    __syncthreads();
-    if (threadIdx.x < 8) {  // the workgroup's table -> the striped global accumulators
-        const NodeAcc& A = s_acc[threadIdx.x >> 2];
-        const int q = threadIdx.x & 3, k = A.key[q];
-        if (k >= 0) {
-            const size_t so = (size_t)(blockIdx.x & (NODE_STRIPES - 1)) * (size_t)N.n;
-            int32_t *gc = threadIdx.x < 4 ? main_cnt : other_cnt, *gs = threadIdx.x < 4 ? main_sum : other_sum;
-            atomicAdd(&gc[so + k], A.cnt[q]); atomicAdd(&gs[so + k], A.sum[q]);
-        }
-    }
-}
 __global__ void k_fold_stripes(int nn, const int32_t* a, const int32_t* b, const int32_t* c2, const int32_t* d, int32_t* out /* 4 x nn */) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nn) return;
@@ -1181,18 +886,18 @@ __global__ void k_fold_stripes(int nn, const int32_t* a, const int32_t* b, const
 }
 // number of non-first blocks of a consumed kept record (|ReadsOther| contributions), for the ordered gather
 struct FOtherCount {
-    RecView R; const uint8_t* keep; const int32_t* rank1; int32_t n_break;
+    RecView R; const uint8_t* keep; const long long* r_break;  // records at or behind *r_break are not consumed (ledger B12)
     __device__ int operator()(int64_t r) const {
-        if (!(keep[r] & K_1) || rank1[r] >= n_break) return 0;
+        if (!(keep[r] & K_1) || r >= *r_break) return 0;
         int nb = (int)(R.blk_off[r + 1] - R.blk_off[r]);
         return nb > 1 ? nb - 1 : 0;
     }
 };
-__global__ void k_gather_other(RecView R, const uint8_t* keep, const int32_t* rank1, int32_t n_break, const int32_t* off, int32_t* o_chr, int32_t* o_pos, int32_t* o_len, int32_t* flags) {
+__global__ void k_gather_other(RecView R, const uint8_t* keep, const long long* r_break, const int32_t* off, int32_t* o_chr, int32_t* o_pos, int32_t* o_len, int32_t* flags) {
     // materialise ReadsOther in stream order (offsets from an exclusive scan); flag blocks of <= 3 bases, the only
     // ones whose node attribution can depend on the tie order of the reference's unstable sort
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R.n || !(keep[r] & K_1) || rank1[r] >= n_break) return;
+    if (r >= R.n || !(keep[r] & K_1) || r >= *r_break) return;
     uint32_t b0 = R.blk_off[r];
     int nblk = (int)(R.blk_off[r + 1] - b0);
     for (int k = 1; k < nblk; ++k) {
@@ -1616,17 +1321,6 @@ __device__ __forceinline__ int bp_start(const RecView& R, int64_t r) {  // Segme
     if (!(R.flag[r] & 0x8) && R.mrefid[r] == c) st = R.mpos[r];
     return st;
 }
-__global__ void k_bp_m(RecView R, BPView B, const uint8_t* cls, int32_t* m) {
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R.n) return;
-    int v = INT_MIN;  // identity of max for records outside pass 3
-    if (cls[r] & C_P3) {
-        int c = R.refid[r], st = bp_start(R, r);
-        // #j with c > chr_j || (c == chr_j && st > pos_j + dp)  ==  first j with (chr_j, pos_j) >= (c, st - dp)
-        v = bp_lower_bound(B, c, st - B.dp);
-    }
-    m[r] = v;
-}
 // +-1 into the difference array for breakpoints [max(first covered, cursor), first not covered).  Neighbouring records
 // cover the same breakpoints, so equal indices inside the wave are combined before the atomic.  WAVE: called by all
 // lanes of a wave (k_bp_count); otherwise by single lanes (k_bp_walk corrections).
@@ -1656,20 +1350,6 @@ __device__ __forceinline__ void bp_contribute(const RecView& R, const BPView& B,
     if (WAVE) { wave_add(diff, on, lo, sign); wave_add(diff, on, hi, -sign); }
     else if (on) { atomicAdd(&diff[lo], sign); atomicAdd(&diff[hi], -sign); }
 }
-// cur0 = cursor position before the first record (0, or what the records of earlier shards left behind)
-__global__ void k_bp_count(RecView R, BPView B, const uint8_t* cls, const int32_t* m, const int32_t* Mx, int cur0, int32_t* ev_by_M, int32_t* diff) {
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = r < R.n && (cls[r] & C_P3);
-    int before = 0, M = 0;
-    if (live) {
-        before = Mx[r] > cur0 ? Mx[r] : cur0; M = m[r] > before ? m[r] : before;
-        if (M > before) {
-            ev_by_M[M] = (int32_t)r;  // M values of events are distinct and increase along the stream
-            if (Mx[r] <= cur0) ev_by_M[0] = (int32_t)r;  // slot 0 (no event has M == 0): the first event of the stream
-        }
-    }
-    bp_contribute<true>(R, B, r, live, before, M, 1, diff);
-}
 // sharded runs: number of pass-3 records, and how many of them come before the first event (they can absorb a cursor
 // that the earlier shards have left behind schedule without changing anything here)
 __global__ void k_bp_boundary(const uint8_t* cls, int64_t n, const int32_t* ev_by_M, unsigned long long* out) {
@@ -1679,41 +1359,6 @@ __global__ void k_bp_boundary(const uint8_t* cls, int64_t n, const int32_t* ev_b
         if (cls[r] & C_P3) { ++all; if (r < first) ++before; }
     for (int d = 32; d >= 1; d >>= 1) { all += __shfl_xor(all, d, 64); before += __shfl_xor(before, d, 64); }
     if ((threadIdx.x & 63) == 0 && all) { atomicAdd(&out[0], all); if (before) atomicAdd(&out[1], before); }
-}
-// one wave per event: APPLY == false records where the cursor catches up, APPLY == true corrects the passed records
-template <bool APPLY>
-__global__ __launch_bounds__(64) void k_bp_walk(RecView R, BPView B, const uint8_t* cls, const int32_t* m, const int32_t* Mx, int cur0, const int32_t* ev_by_M, int32_t* end_by_M,
-                                               const int32_t* valid, int32_t* diff, int32_t* lag_end) {
-    const int v = blockIdx.x + 1, lane = threadIdx.x;
-    const int64_t r0 = ev_by_M[v];
-    if (r0 < 0) return;
-    if (APPLY && !valid[v]) return;
-    int cur = Mx[r0] > cur0 ? Mx[r0] : cur0;
-    int64_t end = R.n;
-    for (int64_t base = r0; base < R.n; base += 64) {
-        const int64_t r = base + lane;
-        const bool ok = r < R.n && (cls[r] & C_P3);
-        int mm = INT_MIN, MM = 0, before_a = 0;
-        if (ok) { mm = m[r]; before_a = Mx[r] > cur0 ? Mx[r] : cur0; MM = mm > before_a ? mm : before_a; }
-        int mycur = -1, mybefore = 0, done = -1;
-        unsigned long long todo = __ballot(ok);
-        while (todo) {
-            const int k = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const int mk = __builtin_amdgcn_readlane(mm, k), Mk = __builtin_amdgcn_readlane(MM, k);
-            const int b4 = cur;
-            cur += cur < mk ? 1 : 0;
-            if (lane == k) { mycur = cur; mybefore = b4; }
-            if (cur == Mk) { done = k; break; }
-        }
-        if (APPLY && mycur >= 0 && (mycur != MM || mybefore != before_a)) {
-            bp_contribute<false>(R, B, r, true, before_a, MM, -1, diff);
-            bp_contribute<false>(R, B, r, true, mybefore, mycur, 1, diff);
-        }
-        if (done >= 0) { end = base + done; break; }
-    }
-    if (!APPLY && lane == 0) end_by_M[v] = (int32_t)(end < R.n ? end : R.n);
-    if (APPLY && lane == 0 && end >= R.n) *lag_end = cur;  // the stream ended before the cursor caught up (only the last valid walk can)
 }
 __global__ __launch_bounds__(64) void k_bp_chain(int nb, const int32_t* ev_by_M, const int32_t* end_by_M, int32_t* valid) {
     const int lane = threadIdx.x;
@@ -1733,6 +1378,8 @@ __global__ __launch_bounds__(64) void k_bp_chain(int nb, const int32_t* ev_by_M,
         if (v <= nb) valid[v] = ok;
     }
 }
+
+#include "sq_pass_kernels.inc"
 
 // ------------------------------------------------------------------------------------------------ K8: components
 __global__ void k_cc_init(int n, int32_t* parent) {
@@ -3395,6 +3042,8 @@ void dev_destroy(sq_ctx* c) {
     D.refid.release(); D.pos.release(); D.mrefid.release(); D.mpos.release(); D.endpos.release(); D.b_refpos.release(); D.b_matchref.release();
     D.b_pack.release(); D.n_pack.release();
     D.flag.release(); D.totlen.release(); D.b_readpos.release(); D.b_matchread.release(); D.mapq.release(); D.aux.release(); D.blk_off.release();
+    D.lb.release(); D.tile_rank.release(); D.z_idx.release(); D.z_chr.release(); D.z_right.release(); D.rc_cluster.release(); D.rc_pos.release(); D.rc_len.release(); D.p1_sc.release();
+    D.tile_first.release(); D.tile_max.release(); D.r_break.release(); D.sum_items.release(); D.bp_before.release();
     D.cls.release(); D.keep.release(); D.prev1.release(); D.prev2.release(); D.rank1.release(); D.restoff.release();
     D.scratch_a.release(); D.scratch_b.release(); D.scratch_c.release(); D.spine.release();
     D.part_prev.release(); D.part_next.release(); D.b0_a.release(); D.b0_b.release(); D.b0_home.release(); D.fc_seg.release();
@@ -3889,13 +3538,21 @@ int dev_upload_nodes(sq_ctx* c, const std::vector<Node>& nodes) {
     return SQ_OK;
 }
 
-// K1a: record filters and the "previous passing record" links
+// the look-back status memory of one fused launch (sq_pass_kernels.inc): zeroed in front of every launch
+static hipError_t lb_prepare(DBuf<unsigned long long>& buf, size_t words, hipStream_t s) {
+    hipError_t e = buf.reserve(words);
+    if (e != hipSuccess) return e;
+    return hipMemsetAsync(buf.p, 0, words * sizeof(unsigned long long), s);
+}
+
+// sharded runs, exchange 1: what the last passing records of this shard look like to ReadRec_t::Equal.  (Unsharded: nothing to do --
+// the filters run inside k_pass1.)
 int dev_classify(sq_ctx* c, int32_t last_info[4]) {
     DeviceRecords& D = *c->dev;
     hipStream_t s = c->stream;
     const int64_t n = D.n;
     RecView R = D.view();
-    HIPCHK(D.cls.reserve(n)); HIPCHK(D.keep.reserve(n)); HIPCHK(D.rank1.reserve(n)); HIPCHK(D.restoff.reserve(n));
+    HIPCHK(D.cls.reserve(n + 4)); HIPCHK(D.keep.reserve(n + 4));
     if (std::getenv("SQUID_CALIB")) {
         const int64_t words = (int64_t)1 << 28;  // 1 GiB: larger than the 256 MiB Infinity Cache
         HIPCHK(D.calib.reserve(words));
@@ -3904,59 +3561,27 @@ int dev_classify(sq_ctx* c, int32_t last_info[4]) {
         hipLaunchKernelGGL(k_calib_read4, dim3(2048), dim3(256), 0, s, D.calib.p, words, D.flags.p + 16);
     }
     if (last_info) { last_info[0] = last_info[1] = last_info[2] = last_info[3] = 0; }
-    if (n == 0) return SQ_OK;
-    { EvTimer t(c, "k_classify", 28.0 * n + 12.0 * D.nb); hipLaunchKernelGGL(k_classify, grid_for(n, 256), dim3(256), 0, s, R, c->P.min_mapqual, D.cls.p); }
-    if (last_info) {
-        hipLaunchKernelGGL(k_last_info, dim3(1), dim3(1), 0, s, R, D.cls.p, D.flags.p + 24);
-        HIPCHK(hipMemcpyAsync(last_info, D.flags.p + 24, 16, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-    }
-    return SQ_OK;
-}
-// K1b: duplicate drop, stream summaries for the segmentation automaton
-int dev_dedup_summarise(sq_ctx* c) {
-    DeviceRecords& D = *c->dev;
-    hipStream_t s = c->stream;
-    const int64_t n = D.n;
-    RecView R = D.view();
-    int32_t* tot = D.flags.p + 8;
-    int32_t h_tot[2] = {0, 0};
-    if (n > 0) {
-        const double bytes_rec = 32.0 * n + 12.0 * D.nb;
-        { EvTimer t(c, "k_dedup", bytes_rec + 1.0 * n); hipLaunchKernelGGL(k_dedup, grid_for(n, 256), dim3(256), 0, s, R, D.cls.p, c->shard.on ? c->shard.dedup_mask : 0, D.keep.p); }
-        { EvTimer t(c, "scan_rank", 5.0 * n);  // keep 1 in, rank 4 out
-          HIPCHK((device_scan<OpSum, true>(s, n, FKeep{D.keep.p, K_1}, D.rank1.p, D.spine, tot))); }
-        { EvTimer t(c, "scan_restoff", 10.0 * n);  // keep 1, class 1, block offset 4 in, offset 4 out
-          HIPCHK((device_scan<OpSum, true>(s, n, FRest{D.keep.p, D.cls.p, D.blk_off.p}, D.restoff.p, D.spine, tot + 1))); }
-        HIPCHK(hipMemcpyAsync(h_tot, tot, 8, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-    }
-    const int64_t k1 = h_tot[0], nrest = h_tot[1];
-    D.k1 = k1;
-    // one spare slot: a sharded run appends the first kept record of the next shard (Shard::has_terminal)
-    HIPCHK(D.okey64.reserve((size_t)k1 + 1));
-    HIPCHK(D.srec.reserve((size_t)k1 + 1)); HIPCHK(D.rest_refpos.reserve((size_t)std::max<int64_t>(nrest, 1))); HIPCHK(D.rest_matchref.reserve((size_t)std::max<int64_t>(nrest, 1)));
-    if (n > 0) {
-        EvTimer t(c, "k_summarise", 28.0 * n + 12.0 * D.nb + 32.0 * k1);
-        hipLaunchKernelGGL(k_summarise, grid_for(n, 256), dim3(256), 0, s, R, D.cls.p, D.keep.p, D.rank1.p, D.restoff.p, D.srec.p, D.rest_refpos.p, D.rest_matchref.p, D.okey64.p);
-    }
-    c->counts.n_kept_p2 = nrest;  // (re-used slot: number of ConcordRest source blocks)
-    c->counts.n_kept_p1 = k1;
+    if (n == 0 || !last_info) return SQ_OK;
+    hipLaunchKernelGGL(k_last_info_raw, dim3(1), dim3(1), 0, s, R, c->P.min_mapqual, D.flags.p + 24);
+    HIPCHK(hipMemcpyAsync(last_info, D.flags.p + 24, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
     return SQ_OK;
 }
 
-// K2 support, part 1 (needs nothing from other shards): cluster table upload, running (otherChr, otherrightmost)
-// scan, trigger record of every cluster.  With `fetch` the triggers, the scan aggregate and the first kept record
-// are copied back here (a sharded run publishes them); otherwise dev_segment_support fetches the triggers.
-int dev_stream_scan(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<int32_t>& cl_start, const std::vector<int32_t>& cl_right, bool fetch, SegSupport& out,
-                    long long& other_max, int32_t first_kept[2]) {
+// Pass 1 over the resident records (k_pass1): filters, duplicate drop, and everything the segmentation automaton needs from the
+// stream -- zero-coverage records, cluster triggers, ConcordRest candidates -- in ONE read of the records.  The lists stay on the
+// device (dev_segment_support fetches them); the scalars come back here.  `seed`: running other-pair of earlier shards.
+int dev_pass1(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<int32_t>& cl_start, const std::vector<int32_t>& cl_right, long long seed, Pass1Result& out) {
     DeviceRecords& D = *c->dev;
     hipStream_t s = c->stream;
-    const int64_t k = D.k1;
+    const int64_t n = D.n;
     const int ncl = (int)cl_chr.size();
-    out.trigger.assign(ncl, (int32_t)k);
-    other_max = INT64_MIN;
-    if (k == 0) return SQ_OK;
+    out = Pass1Result();
+    out.other_max = INT64_MIN;
+    D.k1 = 0; D.p1_nz = 0; D.p1_rest = 0; D.p1_ntiles = 0;
+    D.h_tile_rank.assign(1, 0);
+    c->counts.n_kept_p1 = 0; c->counts.n_kept_p2 = 0;
+    if (n >= ((int64_t)1 << 31) - P1_TILE) return fail(c, SQ_E_CAPACITY, "more than 2^31 records on one device");
     HIPCHK(D.cl_chr.reserve(3 * (size_t)std::max(ncl, 1))); HIPCHK(D.trig.reserve(std::max(ncl, 1)));
     if (ncl) {  // one packed upload: chr | start | right
         std::vector<int32_t> pack(3 * (size_t)ncl);
@@ -3964,95 +3589,94 @@ int dev_stream_scan(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::ve
         HIPCHK(hipMemcpy(D.cl_chr.p, pack.data(), pack.size() * 4, hipMemcpyHostToDevice));
     }
     D.cl_n = ncl;
+    if (n == 0) return SQ_OK;
+    for (int32_t len : c->ref_len) (void)len;
+    if (c->ref_len.size() >= ((size_t)1 << 30)) return fail(c, SQ_E_CAPACITY, "too many references");
+    const int ntiles = (int)((n + P1_TILE - 1) / P1_TILE);
     ClusterView C{ncl, D.cl_chr.p, D.cl_chr.p + ncl, D.cl_chr.p + 2 * (size_t)ncl};
-    HIPCHK(D.other64.reserve(k + 1)); HIPCHK(D.zflag.reserve(k + 1)); HIPCHK(D.scratch_a.reserve(k + 1));
-    { EvTimer t(c, "k_stream_scan", 24.0 * k);
-      HIPCHK((device_scan<OpMax64, true>(s, k, FKey64{D.okey64.p}, D.other64.p, D.spine64, D.other64.p + k)));  // aggregate behind the last element
-      if (ncl) hipLaunchKernelGGL(k_triggers, grid_for(ncl, 64), dim3(64), 0, s, D.srec.p, k, C, D.trig.p); }
-    if (fetch) {
-        StreamRec first;
-        HIPCHK(hipMemcpyAsync(&other_max, D.other64.p + k, 8, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(&first, D.srec.p, sizeof first, hipMemcpyDeviceToHost, s));
-        if (ncl) HIPCHK(hipMemcpyAsync(out.trigger.data(), D.trig.p, ncl * 4, hipMemcpyDeviceToHost, s));
+    RecView R = D.view();
+    HIPCHK(D.cls.reserve(n + 4)); HIPCHK(D.keep.reserve(n + 4));
+    HIPCHK(D.tile_rank.reserve((size_t)ntiles + 1)); HIPCHK(D.tile_first.reserve(ntiles)); HIPCHK(D.tile_max.reserve(ntiles));
+    HIPCHK(D.p1_sc.reserve(P1S_WORDS));
+    int32_t sc[P1S_WORDS], trig_last = INT32_MAX;
+    for (;;) {  // the two lists start small and grow when they overflow (the counts are exact either way)
+        HIPCHK(D.z_idx.reserve(D.zcap)); HIPCHK(D.z_chr.reserve(D.zcap)); HIPCHK(D.z_right.reserve(D.zcap));
+        HIPCHK(D.rc_cluster.reserve(D.rc_cap)); HIPCHK(D.rc_pos.reserve(D.rc_cap)); HIPCHK(D.rc_len.reserve(D.rc_cap));
+        const size_t w1 = LbView<2>::words(ntiles), w2 = LbView<1>::words(ntiles);
+        HIPCHK(lb_prepare(D.lb, w1 + w2, s));
+        HIPCHK(hipMemsetAsync(D.p1_sc.p, 0, P1S_WORDS * 4, s));
+        if (ncl) HIPCHK(hipMemsetAsync(D.trig.p, 0x7f, (size_t)ncl * 4, s));
+        P1Args A;
+        A.min_mapq = c->P.min_mapqual; A.prior_mask = c->shard.on ? c->shard.dedup_mask : 0; A.RL = c->read_len; A.seed = seed;
+        A.cls = D.cls.p; A.keep = D.keep.p; A.tile_rank = D.tile_rank.p; A.tile_first = D.tile_first.p; A.tile_max = D.tile_max.p;
+        A.zidx = D.z_idx.p; A.zchr = D.z_chr.p; A.zright = D.z_right.p; A.zcap = (int)D.zcap;
+        A.trig = D.trig.p; A.rc_cluster = D.rc_cluster.p; A.rc_pos = D.rc_pos.p; A.rc_len = D.rc_len.p; A.rc_cap = (int)D.rc_cap;
+        A.sc = D.p1_sc.p;
+        {   // reads: 26 B of fixed fields per record + its first and last block (16 B each); writes: class and keep byte
+            EvTimer t(c, "k_pass1", 28.0 * n + 16.0 * D.nb);
+            hipLaunchKernelGGL(k_pass1, dim3(ntiles), dim3(P1_THREADS), 0, s, R, C, LbView<2>{D.lb.p}, LbView<1>{D.lb.p + w1}, ntiles, A);
+            hipLaunchKernelGGL(k_tile_order_check, dim3((ntiles + 255) / 256), dim3(256), 0, s, ntiles, D.tile_first.p, D.tile_max.p, D.p1_sc.p);
+        }
+        HIPCHK(hipMemcpyAsync(sc, D.p1_sc.p, sizeof sc, hipMemcpyDeviceToHost, s));
+        if (ncl) HIPCHK(hipMemcpyAsync(&trig_last, D.trig.p + (ncl - 1), 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        first_kept[0] = first.refid; first_kept[1] = first.pos;
+        if (sc[P1S_FLAGS] & P1F_UNSORTED) return fail(c, SQ_E_UNSORTED, "concordant BAM is not coordinate sorted (README.md:23 requires it)");
+        if (sc[P1S_FLAGS] & P1F_NEGATIVE_END) return fail(c, SQ_E_CAPACITY, "a concordant record ends at a negative reference position");
+        bool again = false;
+        if ((size_t)sc[P1S_NZ] > D.zcap) { D.zcap = (size_t)sc[P1S_NZ] + (size_t)sc[P1S_NZ] / 4 + 1024; again = true; }
+        if ((size_t)sc[P1S_REST] > D.rc_cap) { D.rc_cap = (size_t)sc[P1S_REST] + (size_t)sc[P1S_REST] / 4 + 1024; again = true; }
+        if (!again) break;
     }
+    D.k1 = sc[P1S_KEPT]; D.p1_nz = sc[P1S_NZ]; D.p1_rest = sc[P1S_REST]; D.p1_ntiles = ntiles;
+    out.trigger_last = trig_last;  // (first kept record behind the last cluster; >= kept: none)
+    out.kept = sc[P1S_KEPT]; out.nz = sc[P1S_NZ]; out.n_rest = sc[P1S_REST];
+    out.first_kept[0] = sc[P1S_FIRST_REFID]; out.first_kept[1] = sc[P1S_FIRST_POS];
+    out.other_max = (long long)(((unsigned long long)(uint32_t)sc[P1S_OTHER_HI] << 32) | (uint32_t)sc[P1S_OTHER_LO]);
+    c->counts.n_kept_p1 = out.kept;
+    c->counts.n_kept_p2 = out.n_rest;  // (re-used slot: ConcordRest candidates)
     return SQ_OK;
 }
 
-// K2 support, part 2: zero-coverage records (+ the running pair in front of each), ConcordRest candidates.  A sharded
-// run first appends the first kept record of the next shard to the summaries (it ends this shard's last stretch).
-int dev_segment_support(sq_ctx* c, int ncl, int64_t n_rest, SegSupport& out) {
+// The lists of pass 1: zero-coverage records (+ the running pair in front of each), trigger record of every cluster, ConcordRest
+// candidates, kept records in front of every tile.  One synchronisation.
+int dev_segment_support(sq_ctx* c, int ncl, SegSupport& out) {
     DeviceRecords& D = *c->dev;
     hipStream_t s = c->stream;
-    const Shard& sh = c->shard;
-    const int64_t k_own = D.k1;
-    const bool term = sh.on && sh.has_terminal && k_own > 0;
-    const int64_t k = k_own + (term ? 1 : 0);
+    const int64_t k = D.k1;
     out.zidx.clear(); out.z_ochr.clear(); out.z_oright.clear(); out.rest_cluster.clear(); out.rest_pos.clear(); out.rest_len.clear();
-    if (k_own == 0) return SQ_OK;
-    if (term) {
-        StreamRec t{};
-        t.refid = sh.term_refid; t.pos = sh.term_pos;
-        HIPCHK(hipMemcpyAsync(D.srec.p + k_own, &t, sizeof t, hipMemcpyHostToDevice, s));
-    }
-    const long long seed = sh.on ? sh.other_seed : INT64_MIN;
-    ClusterView C{ncl, D.cl_chr.p, D.cl_chr.p + ncl, D.cl_chr.p + 2 * (size_t)ncl};
-    HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
-    int32_t* tot = D.flags.p + 8;
-    // everything is queued without knowing the counts (the compaction targets are sized for the worst case), then one
-    // synchronisation for the counts and one for the compacted arrays
-    HIPCHK(D.scratch_b.reserve(k)); HIPCHK(D.scratch_c.reserve(k)); HIPCHK(D.b0_a.reserve(k));
-    HIPCHK(D.b0_b.reserve(std::max<int64_t>(n_rest, 1))); HIPCHK(D.b0_home.reserve(std::max<int64_t>(n_rest, 1))); HIPCHK(D.part_prev.reserve(std::max<int64_t>(n_rest, 1)));
-    // (one timer per kernel, named like the kernel: the figures can be compared with rocprofv3's)
-    { EvTimer t(c, "k_zerocov", 24.0 * k + 8.0 * k + 1.0 * k);  // summary 24 + running pair 8 in, flag 1 out
-      hipLaunchKernelGGL(k_zerocov, grid_for(k, 256), dim3(256), 0, s, D.srec.p, k, k_own, C, D.other64.p, D.other64.p + k_own, seed, c->read_len, D.zflag.p, D.flags.p); }
-    { EvTimer t(c, "scan_zerocov", 5.0 * k);
-      HIPCHK((device_scan<OpSum, true>(s, k, FByte{D.zflag.p}, D.scratch_a.p, D.spine, tot))); }
-    { EvTimer t(c, "k_zgather", 5.0 * k);  // flag 1 + offset 4 per kept record; the gathered rows are few
-      hipLaunchKernelGGL(k_zgather, grid_for(k, 256), dim3(256), 0, s, k, k_own, D.zflag.p, D.scratch_a.p, D.other64.p, D.other64.p + k_own, seed, D.scratch_b.p, D.scratch_c.p, D.b0_a.p); }
-    const bool want_rest = ncl && n_rest;
-    if (want_rest) {
-        EvTimer t(c, "k_rest_candidates", 20.0 * k_own + 8.0 * n_rest);
-        hipLaunchKernelGGL(k_rest_candidates, grid_for(k_own, 256), dim3(256), 0, s, D.srec.p, k_own, C, c->read_len, D.rest_refpos.p, D.rest_matchref.p, D.flags.p + 4, D.b0_b.p, D.b0_home.p, D.part_prev.p);
-    }
+    out.trigger.assign(ncl, (int32_t)k);
+    const int nz = D.p1_nz, cnt = D.p1_rest, ntiles = D.p1_ntiles;
+    D.h_tile_rank.assign((size_t)ntiles + 1, 0);
+    if (D.n == 0) return SQ_OK;
     D.pin.reset();
-    int32_t* h = D.pin.take_n<int32_t>(16);
-    int32_t* h_trig = D.pin.take_n<int32_t>(ncl);
-    if (!h || !h_trig) return fail(c, SQ_E_HIP, "hipHostMalloc failed");
-    HIPCHK(hipMemcpyAsync(h, D.flags.p, 10 * 4, hipMemcpyDeviceToHost, s));  // [0] flags, [4] rest count, [8] zero-coverage count
-    if (ncl && !sh.on) HIPCHK(hipMemcpyAsync(h_trig, D.trig.p, ncl * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (h[0] & 1) return fail(c, SQ_E_UNSORTED, "concordant BAM is not coordinate sorted (README.md:23 requires it)");
-    if (ncl && !sh.on) out.trigger.assign(h_trig, h_trig + ncl);
-    const int nz = h[8], cnt = want_rest ? h[4] : 0;
-    if (std::getenv("SQUID_PREP_DEBUG")) std::fprintf(stderr, "[prepare] kept %lld zero-coverage records %d ConcordRest candidates %d clusters %d\n", (long long)k, nz, cnt, ncl);
-    int32_t *hz = D.pin.take_n<int32_t>(3 * (size_t)nz), *hr = D.pin.take_n<int32_t>(3 * (size_t)cnt);
-    if (!hz || !hr) return fail(c, SQ_E_HIP, "hipHostMalloc failed");
+    int32_t *hz = D.pin.take_n<int32_t>(3 * (size_t)nz), *hr = D.pin.take_n<int32_t>(3 * (size_t)cnt), *ht = D.pin.take_n<int32_t>(ncl), *hk = D.pin.take_n<int32_t>((size_t)ntiles + 1);
+    if (!hz || !hr || !ht || !hk) return fail(c, SQ_E_HIP, "hipHostMalloc failed");
     if (nz) {
-        HIPCHK(hipMemcpyAsync(hz, D.scratch_b.p, nz * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(hz + nz, D.scratch_c.p, nz * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(hz + 2 * nz, D.b0_a.p, nz * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hz, D.z_idx.p, (size_t)nz * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(hz + nz, D.z_chr.p, (size_t)nz * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hz + 2 * (size_t)nz, D.z_right.p, (size_t)nz * 4, hipMemcpyDeviceToHost, s));
     }
     if (cnt) {
-        HIPCHK(hipMemcpyAsync(hr, D.b0_b.p, cnt * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(hr + cnt, D.b0_home.p, cnt * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(hr + 2 * cnt, D.part_prev.p, cnt * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hr, D.rc_cluster.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(hr + cnt, D.rc_pos.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hr + 2 * (size_t)cnt, D.rc_len.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, s));
     }
-    if (nz || cnt) HIPCHK(hipStreamSynchronize(s));
-    out.zidx.assign(hz, hz + nz); out.z_ochr.assign(hz + nz, hz + 2 * nz); out.z_oright.assign(hz + 2 * nz, hz + 3 * nz);
-    out.rest_cluster.assign(hr, hr + cnt); out.rest_pos.assign(hr + cnt, hr + 2 * cnt); out.rest_len.assign(hr + 2 * cnt, hr + 3 * cnt);
+    if (ncl) HIPCHK(hipMemcpyAsync(ht, D.trig.p, (size_t)ncl * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hk, D.tile_rank.p, ((size_t)ntiles + 1) * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    out.zidx.assign(hz, hz + nz); out.z_ochr.assign(hz + nz, hz + 2 * (size_t)nz); out.z_oright.assign(hz + 2 * (size_t)nz, hz + 3 * (size_t)nz);
+    out.rest_cluster.assign(hr, hr + cnt); out.rest_pos.assign(hr + cnt, hr + 2 * (size_t)cnt); out.rest_len.assign(hr + 2 * (size_t)cnt, hr + 3 * (size_t)cnt);
+    // trigger of cluster c = first kept record with more than c clusters behind it: the kernel left, per cluster, the first record
+    // with exactly c + 1 behind it
+    int32_t run = (int32_t)k;
+    for (int q = ncl - 1; q >= 0; --q) { if (ht[q] < run) run = ht[q]; out.trigger[q] = run; }
+    D.h_tile_rank.assign(hk, hk + ntiles + 1);
+    if (std::getenv("SQUID_PREP_DEBUG")) std::fprintf(stderr, "[prepare] kept %lld zero-coverage records %d ConcordRest candidates %d clusters %d\n", (long long)k, nz, cnt, ncl);
     return SQ_OK;
 }
 
-// gather the stream summaries of the given kept-index ranges [lo,hi) into one page-locked host buffer (the kernel
-// writes it directly over the bus); range i starts at range_off[i] of `compact`
-__global__ void k_gather_ranges(const uint32_t* src, const long long* lo_words, const long long* off_words, int nranges, long long total_words, uint32_t* dst) {
-    for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < total_words; w += (long long)gridDim.x * blockDim.x) {
-        int a = 0, b = nranges;  // last range with off <= w
-        while (b - a > 1) { int m = (a + b) >> 1; if (off_words[m] <= w) a = m; else b = m; }
-        dst[w] = src[lo_words[a] + (w - off_words[a])];
-    }
-}
-int dev_fetch_stream(sq_ctx* c, const std::vector<std::pair<int64_t, int64_t>>& ranges, const StreamRec*& compact, std::vector<int64_t>& range_off) {
+// The window elements of the given kept-index ranges [lo,hi), built from the records of the tiles that hold them (k_summarise_tiles)
+// and copied into one page-locked host buffer; range i starts at range_off[i] of `compact`.  `term` (sharded runs): the record with
+// kept index D.k1, i.e. the first kept record of the next shard, which is not resident here.
+int dev_fetch_stream(sq_ctx* c, const std::vector<std::pair<int64_t, int64_t>>& ranges, const StreamRec*& compact, std::vector<int64_t>& range_off, const StreamRec* term) {
     DeviceRecords& D = *c->dev;
     hipStream_t s = c->stream;
     auto t0 = std::chrono::steady_clock::now();
@@ -4060,20 +3684,63 @@ int dev_fetch_stream(sq_ctx* c, const std::vector<std::pair<int64_t, int64_t>>& 
     range_off.assign(nr, 0);
     compact = nullptr;
     if (!nr) return SQ_OK;
-    static_assert(sizeof(StreamRec) == 24, "StreamRec is copied as 6 words");
-    std::vector<long long> lo(nr), off(nr);
+    static_assert(sizeof(StreamRec) == 24, "StreamRec is six words");
+    const std::vector<int32_t>& TR = D.h_tile_rank;
+    const int ntiles = D.p1_ntiles;
+    const int64_t K = D.k1;
+    std::vector<SumItem> items;
     long long total = 0;
-    for (int i = 0; i < nr; ++i) { range_off[i] = total; lo[i] = ranges[i].first * 6; off[i] = total * 6; total += ranges[i].second - ranges[i].first; }
+    std::vector<std::pair<int, int64_t>> patch;  // (range, offset) of the appended record
+    for (int i = 0; i < nr; ++i) {
+        range_off[i] = total;
+        const int64_t lo = ranges[i].first, hi = ranges[i].second;
+        const int64_t hi_own = std::min<int64_t>(hi, K);
+        if (lo < hi_own) {
+            // first tile with kept records behind index lo, then every tile that starts in front of hi
+            int t = (int)(std::upper_bound(TR.begin() + 1, TR.begin() + 1 + ntiles, (int32_t)lo) - (TR.begin() + 1));
+            for (; t < ntiles && TR[t] < hi_own; ++t) {
+                if (TR[t + 1] == TR[t]) continue;
+                items.push_back(SumItem{(int64_t)t * P1_TILE, TR[t], (int32_t)lo, (int32_t)hi_own, (int64_t)total});
+            }
+        }
+        if (hi > K) {
+            if (!term || hi != K + 1 || lo > K) return fail(c, SQ_E_ARG, "internal: stream range beyond the kept records");
+            patch.push_back(std::make_pair(i, total + (K - lo)));
+        }
+        total += hi - lo;
+    }
     StreamRec* dst = D.pin.take_n<StreamRec>((size_t)total);
     if (!dst) return fail(c, SQ_E_HIP, "hipHostMalloc failed");
-    HIPCHK(D.other64.reserve(2 * (size_t)nr + 2));  // the running-pair scan is not needed any more: reuse its buffer for the range table
-    HIPCHK(hipMemcpyAsync(D.other64.p, lo.data(), nr * 8, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(D.other64.p + nr, off.data(), nr * 8, hipMemcpyHostToDevice, s));
-    const long long words = total * 6;
-    const unsigned grid = (unsigned)std::min<long long>((words + 255) / 256, 2048);
-    hipLaunchKernelGGL(k_gather_ranges, dim3(grid), dim3(256), 0, s, (const uint32_t*)D.srec.p, D.other64.p, D.other64.p + nr, nr, words, (uint32_t*)dst);
-    HIPCHK(hipStreamSynchronize(s));
+    if (!items.empty()) {
+        HIPCHK(D.srec.reserve((size_t)total)); HIPCHK(D.sum_items.reserve(items.size()));
+        HIPCHK(hipMemcpyAsync(D.sum_items.p, items.data(), items.size() * sizeof(SumItem), hipMemcpyHostToDevice, s));
+        {   // per summarised tile: keep 1 + class 1 + the fixed fields and the first block of its kept records in, 24 B out
+            EvTimer t(c, "k_summarise_tiles", (double)items.size() * P1_TILE * 34.0 + 24.0 * (double)total);
+            hipLaunchKernelGGL(k_summarise_tiles, dim3((unsigned)items.size()), dim3(P1_THREADS), 0, s, D.view(), D.cls.p, D.keep.p, D.sum_items.p, D.srec.p);
+        }
+        HIPCHK(hipMemcpyAsync(dst, D.srec.p, (size_t)total * sizeof(StreamRec), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));  // (items goes out of scope)
+    }
+    for (const auto& pt : patch) dst[pt.second] = *term;
     compact = dst;
     c->timer.add("d2h_stream_summary", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), 0);
+    return SQ_OK;
+}
+
+// *D.r_break = index of the kept record with rank n_break: the records at or behind it are not consumed (SegmentGraph.cpp:338-339)
+static int set_r_break(sq_ctx* c, int64_t n_break) {
+    DeviceRecords& D = *c->dev;
+    hipStream_t s = c->stream;
+    HIPCHK(D.r_break.reserve(1));
+    const long long all = (long long)D.n;
+    HIPCHK(hipMemcpyAsync(D.r_break.p, &all, 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));  // (`all` is a local)
+    if (n_break >= D.k1 || D.p1_ntiles == 0) return SQ_OK;
+    const std::vector<int32_t>& TR = D.h_tile_rank;
+    if ((int)TR.size() != D.p1_ntiles + 1) return fail(c, SQ_E_ARG, "internal: dev_segment_support first");
+    const int t = (int)(std::upper_bound(TR.begin() + 1, TR.begin() + 1 + D.p1_ntiles, (int32_t)n_break) - (TR.begin() + 1));  // first tile that ends behind rank n_break
+    if (t >= D.p1_ntiles) return SQ_OK;
+    hipLaunchKernelGGL(k_find_rank, dim3(1), dim3(P1_THREADS), 0, s, D.n, D.keep.p, (int64_t)t * P1_TILE, TR[t], (int32_t)n_break, D.r_break.p);
     return SQ_OK;
 }
 
@@ -4088,18 +3755,18 @@ int dev_gather_other(sq_ctx* c, int64_t n_break, bool& has_tiny, std::vector<int
     other_chr.clear(); other_pos.clear(); other_len.clear();
     if (n == 0) return SQ_OK;
     RecView R = D.view();
-    const int32_t nbk = (int32_t)std::min<int64_t>(n_break, INT32_MAX);
+    { const int rb = set_r_break(c, n_break); if (rb) return rb; }
     int32_t* tot = D.flags.p + 8;
     HIPCHK(D.b0_b.reserve(n));
     HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
-    { EvTimer t(c, "scan_other_offsets", 9.0 * n); HIPCHK((device_scan<OpSum, true>(s, n, FOtherCount{R, D.keep.p, D.rank1.p, nbk}, D.b0_b.p, D.spine, tot))); }
+    { EvTimer t(c, "scan_other_offsets", 9.0 * n); HIPCHK((device_scan<OpSum, true>(s, n, FOtherCount{R, D.keep.p, D.r_break.p}, D.b0_b.p, D.spine, tot))); }
     int32_t cnt = 0;
     HIPCHK(hipMemcpyAsync(&cnt, tot, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (cnt == 0) return SQ_OK;
     HIPCHK(D.scratch_b.reserve(cnt)); HIPCHK(D.scratch_c.reserve(cnt)); HIPCHK(D.b0_a.reserve(cnt));
     { EvTimer t(c, "k_gather_other", 13.0 * n + 8.0 * D.nb + 12.0 * cnt);
-      hipLaunchKernelGGL(k_gather_other, grid_for(n, 256), dim3(256), 0, s, R, D.keep.p, D.rank1.p, nbk, D.b0_b.p, D.scratch_b.p, D.scratch_c.p, D.b0_a.p, D.flags.p); }
+      hipLaunchKernelGGL(k_gather_other, grid_for(n, 256), dim3(256), 0, s, R, D.keep.p, D.r_break.p, D.b0_b.p, D.scratch_b.p, D.scratch_c.p, D.b0_a.p, D.flags.p); }
     int32_t hf = 0;
     HIPCHK(hipMemcpyAsync(&hf, D.flags.p, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -4127,7 +3794,6 @@ int dev_node_depth(sq_ctx* c, const std::vector<Node>& nodes, int64_t n_break, s
     // behind it), one memset; counters: flags[0..7] and the stripes right behind them, one memset
     const size_t nst = (size_t)nn * NODE_STRIPES;
     HIPCHK(D.acc_a.reserve(6 * (size_t)nn + 4 * nst));
-    HIPCHK(D.scratch_a.reserve(std::max<int64_t>(n, 1)));
     int32_t* acc = D.acc_a.p;
     int32_t *a_mc = acc + 6 * (size_t)nn, *a_ms = a_mc + nst, *a_oc = a_ms + nst, *a_os = a_oc + nst, *a_ap = acc + 4 * (size_t)nn, *a_am = acc + 5 * (size_t)nn;
     HIPCHK(hipMemsetAsync(acc, 0, (6 * (size_t)nn + 4 * nst) * 4, s));
@@ -4135,16 +3801,13 @@ int dev_node_depth(sq_ctx* c, const std::vector<Node>& nodes, int64_t n_break, s
     int32_t* stripes = D.flags.p + 64;
     HIPCHK(hipMemsetAsync(D.flags.p, 0, (64 + NSTRIPE) * 4, s));
     RecView R = D.view();
-    const int32_t nbk = (int32_t)std::min<int64_t>(n_break, INT32_MAX);
     if (n > 0) {
-        // (the lookup stays a kernel of its own: evaluated inside the scan it is no faster -- 0.72 ms against 0.44 + 0.24)
-        HIPCHK(D.b0_home.reserve(n));
-        { EvTimer t(c, "k_early", 17.0 * n + 8.0 * D.nb * ((double)D.k1 / (double)n) + 4.0 * n);  // keep 1 + rank 4 for all, block offset 8 + refid 4 + first block 8 for the consumed ones; 4 out
-          hipLaunchKernelGGL(k_early, grid_for(n, 256), dim3(256), 0, s, n, FEarlyMain{R, nv, D.keep.p, D.rank1.p, nbk}, D.b0_home.p); }
-        { EvTimer t(c, "scan_depth_cursor", 8.0 * n);
-          HIPCHK((device_scan<OpMax, false>(s, n, FArr{D.b0_home.p}, D.scratch_a.p, D.spine, nullptr))); }
-        { EvTimer t(c, "k_depth", 17.0 * n + 16.0 * D.nb * ((double)D.k1 / (double)n));  // keep 1, rank, cursor, block offset, refid 4 each; 16 B per block of a consumed record
-          hipLaunchKernelGGL(k_depth, grid_for(n, 256), dim3(256), 0, s, R, nv, D.keep.p, D.rank1.p, nbk, D.scratch_a.p, a_mc, a_ms, a_oc, a_os, a_ap, a_am, D.flags.p, stripes);
+        { const int rb = set_r_break(c, n_break); if (rb) return rb; }
+        const int ntiles = (int)((n + ST_TILE - 1) / ST_TILE);
+        HIPCHK(lb_prepare(D.lb, LbView<1>::words(ntiles), s));
+        // keep 1 + block offset 4 + refid 4 per record; 16 B per block of a consumed record (the cursor never leaves the kernel)
+        { EvTimer t(c, "k_depth2", 9.0 * n + 16.0 * D.nb * ((double)D.k1 / (double)n));
+          hipLaunchKernelGGL(k_depth2, dim3(ntiles), dim3(ST_THREADS), 0, s, R, nv, D.keep.p, D.r_break.p, LbView<1>{D.lb.p}, ntiles, a_mc, a_ms, a_oc, a_os, a_ap, a_am, D.flags.p, stripes);
           if (nn) hipLaunchKernelGGL(k_fold_stripes, dim3((nn + 255) / 256), dim3(256), 0, s, nn, a_mc, a_ms, a_oc, a_os, acc); }
     }
     D.pin.reset();
@@ -4327,7 +3990,6 @@ int dev_breakpoint_support(sq_ctx* c, const std::vector<std::pair<int, int>>& bp
     std::vector<int32_t> bc(nb), bp(nb);
     for (int i = 0; i < nb; ++i) { bc[i] = bps[i].first; bp[i] = bps[i].second; }
     HIPCHK(D.acc_b.reserve(2 * (size_t)nb)); HIPCHK(D.acc_c.reserve(nb + 1));
-    HIPCHK(D.scratch_a.reserve(n)); HIPCHK(D.scratch_b.reserve(n));
     bc.insert(bc.end(), bp.begin(), bp.end());  // one packed upload: chr | pos
     HIPCHK(hipMemcpy(D.acc_b.p, bc.data(), 2 * (size_t)nb * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemsetAsync(D.acc_c.p, 0, (nb + 1) * 4, s));
@@ -4342,20 +4004,22 @@ int dev_breakpoint_support(sq_ctx* c, const std::vector<std::pair<int, int>>& bp
     BPView B{nb, D.acc_b.p, D.acc_b.p + nb, c->P.concord_dist_pos, D.bp_bucket.p, D.nv.bucket_off};
     for (int i = 0; i < nb; ++i) if (bc[i] < 0 || bc[i] >= n_ref) return fail(c, SQ_E_ARG, "breakpoint on an unknown reference");
     if (total) hipLaunchKernelGGL(k_bp_buckets, dim3((total + 255) / 256), dim3(256), 0, s, B, n_ref, total, D.bp_bucket.p);
-    HIPCHK(D.bp_ev.reserve(nb + 1)); HIPCHK(D.bp_end.reserve(nb + 1)); HIPCHK(D.bp_valid.reserve(nb + 1));
+    HIPCHK(D.bp_ev.reserve(nb + 1)); HIPCHK(D.bp_before.reserve(nb + 1)); HIPCHK(D.bp_end.reserve(nb + 1)); HIPCHK(D.bp_valid.reserve(nb + 1));
     HIPCHK(hipMemsetAsync(D.bp_ev.p, 0xFF, (nb + 1) * 4, s));
-    int32_t *m = D.scratch_b.p, *Mx = D.scratch_a.p;
 
     int32_t* agg = D.flags.p + 28;  // [28] max of m over all records, [29] cursor of a walk that ran into the end of the stream
     const int32_t minus1 = -1;
     HIPCHK(hipMemcpyAsync(agg + 1, &minus1, 4, hipMemcpyHostToDevice, s));
-    { EvTimer t(c, "k_bp_m", 27.0 * n); hipLaunchKernelGGL(k_bp_m, grid_for(n, 256), dim3(256), 0, s, R, B, D.cls.p, m); }
-    { EvTimer t(c, "scan_bp_cursor", 8.0 * n); HIPCHK((device_scan<OpMax, true>(s, n, FArr{m}, Mx, D.spine, agg))); }  // max of m over earlier records
-    { EvTimer t(c, "k_bp_count", 31.0 * n); hipLaunchKernelGGL(k_bp_count, grid_for(n, 256), dim3(256), 0, s, R, B, D.cls.p, m, Mx, cur_prev, D.bp_ev.p, D.acc_c.p); }
+    {   // class 1 + refid, pos, mate refid, mate pos, end 4 each + flag 2 per record; nothing written per record
+        const int ntiles = (int)((n + ST_TILE - 1) / ST_TILE);
+        HIPCHK(lb_prepare(D.lb, LbView<1>::words(ntiles), s));
+        EvTimer t(c, "k_bp2", 23.0 * n);
+        hipLaunchKernelGGL(k_bp2, dim3(ntiles), dim3(ST_THREADS), 0, s, R, B, D.cls.p, cur_prev, LbView<1>{D.lb.p}, ntiles, D.bp_ev.p, D.bp_before.p, D.acc_c.p, agg);
+    }
     { EvTimer t(c, "k_bp_walk", 0);
-      hipLaunchKernelGGL(k_bp_walk<false>, dim3(nb), dim3(64), 0, s, R, B, D.cls.p, m, Mx, cur_prev, D.bp_ev.p, D.bp_end.p, D.bp_valid.p, D.acc_c.p, agg + 1);
+      hipLaunchKernelGGL(k_bp_walk2<false>, dim3(nb), dim3(64), 0, s, R, B, D.cls.p, cur_prev, D.bp_ev.p, D.bp_before.p, D.bp_end.p, D.bp_valid.p, D.acc_c.p, agg + 1);
       hipLaunchKernelGGL(k_bp_chain, dim3(1), dim3(64), 0, s, nb, D.bp_ev.p, D.bp_end.p, D.bp_valid.p);
-      hipLaunchKernelGGL(k_bp_walk<true>, dim3(nb), dim3(64), 0, s, R, B, D.cls.p, m, Mx, cur_prev, D.bp_ev.p, D.bp_end.p, D.bp_valid.p, D.acc_c.p, agg + 1); }
+      hipLaunchKernelGGL(k_bp_walk2<true>, dim3(nb), dim3(64), 0, s, R, B, D.cls.p, cur_prev, D.bp_ev.p, D.bp_before.p, D.bp_end.p, D.bp_valid.p, D.acc_c.p, agg + 1); }
     unsigned long long hcnt[3] = {0, 0, 0};
     if (bb) {
         HIPCHK(D.okey.reserve(4));

@@ -381,6 +381,8 @@ struct SegPlan {
     int64_t K = 0;        // kept records of the local stream
     int64_t K_eff = 0;    // + the appended first kept record of the next shard
     int k0 = 0;           // clusters that an earlier shard's closing record has already passed
+    std::vector<int32_t> cl_chr, cl_start, cl_right;  // the cluster table as uploaded
+    long long other_max_local = INT64_MIN;  // running (otherChr, otherrightmost) pair over the whole local stream
     bool skip_first = false;  // the local stream does not start the global one: its first record only opens a stretch
 };
 
@@ -441,18 +443,23 @@ double segment_clusters(const sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::ve
     S.build_clusters(c->read_len);
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
 }
-// stream scans that need nothing from other shards (the cluster table is uploaded here)
+// pass 1 over the records (k_pass1; the cluster table is uploaded here).  A sharded run calls this before it knows the running pair
+// of the earlier shards: everything it publishes (stream size, first kept record, running pair, trigger of the last cluster) is
+// independent of that seed; segment_prepare repeats the pass with the seed when there is one.
 int segment_scan(sq_ctx* c, SegPlan& P, bool fetch, int64_t& trigger_last, long long& other_max, int32_t first_kept[2]) {
-    const int64_t K = c->counts.n_kept_p1;
-    P.K = K;
     SegStatic& S = P.st;
-    SegPlan* plan = &P;
     const int ncl = (int)S.clusters.size();
-    std::vector<int32_t> cl_chr(ncl), cl_start(ncl), cl_right(ncl);
-    for (int k = 0; k < ncl; ++k) { cl_chr[k] = S.clusters[k].chr; cl_start[k] = S.clusters[k].start; cl_right[k] = S.clusters[k].right; }
-    int rc = dev_stream_scan(c, cl_chr, cl_start, cl_right, fetch, plan->sup, other_max, first_kept);
+    P.cl_chr.resize(ncl); P.cl_start.resize(ncl); P.cl_right.resize(ncl);
+    for (int k = 0; k < ncl; ++k) { P.cl_chr[k] = S.clusters[k].chr; P.cl_start[k] = S.clusters[k].start; P.cl_right[k] = S.clusters[k].right; }
+    Pass1Result res;
+    int rc = dev_pass1(c, P.cl_chr, P.cl_start, P.cl_right, c->shard.on ? c->shard.other_seed : INT64_MIN, res);
     if (rc) return rc;
-    trigger_last = ncl ? plan->sup.trigger[ncl - 1] : K;  // only meaningful with `fetch`
+    P.K = res.kept;
+    P.other_max_local = res.other_max;
+    other_max = res.other_max;
+    first_kept[0] = res.first_kept[0]; first_kept[1] = res.first_kept[1];
+    trigger_last = ncl ? std::min<int64_t>(res.trigger_last, res.kept) : -1;  // (-1: no discordant cluster at all)
+    (void)fetch;
     return SQ_OK;
 }
 
@@ -460,17 +467,43 @@ int segment_scan(sq_ctx* c, SegPlan& P, bool fetch, int64_t& trigger_last, long 
 int segment_prepare(sq_ctx* c, SegPlan& P, int64_t& n_break) {
     SegStatic& S = P.st;
     const Shard& sh = c->shard;
-    const int64_t K = P.K;
     const int ncl = (int)S.clusters.size(), nd = S.nd;
     SegSupport& sup = P.sup;
     auto t_begin = std::chrono::steady_clock::now();
     auto lap = [&](const char* name) { auto t = std::chrono::steady_clock::now(); c->timer.add(name, std::chrono::duration<double, std::milli>(t - t_begin).count()); t_begin = t; };
-    int rc = dev_segment_support(c, ncl, c->counts.n_kept_p2, sup);
+    int rc;
+    if (sh.on && sh.other_seed != INT64_MIN) {  // the zero-coverage test looks at the running pair, which earlier shards feed
+        Pass1Result res;
+        rc = dev_pass1(c, P.cl_chr, P.cl_start, P.cl_right, sh.other_seed, res);
+        if (rc) return rc;
+        if (res.kept != P.K) return fail(c, SQ_E_ARG, "internal: pass 1 is not repeatable");
+    }
+    const int64_t K = P.K;
+    rc = dev_segment_support(c, ncl, sup);
     if (rc) return rc;
     lap("host_prep_support");
     const bool term = sh.on && sh.has_terminal && K > 0;
     P.K_eff = K + (term ? 1 : 0);
     const int64_t KE = P.K_eff;
+    StreamRec term_rec{};
+    if (term) {
+        // the first kept record of the next shard closes this shard's last stretch: its zero-coverage test (SegmentGraph.cpp:616-620)
+        // with the running pair of the whole local stream in front of it
+        term_rec.refid = sh.term_refid; term_rec.pos = sh.term_pos;
+        int Kt = 0;
+        while (Kt < ncl && (S.clusters[Kt].chr < sh.term_refid || (S.clusters[Kt].chr == sh.term_refid && S.clusters[Kt].right < sh.term_pos))) ++Kt;
+        const int disChr = Kt > 0 ? S.clusters[Kt - 1].chr : 0, disRight = Kt > 0 ? S.clusters[Kt - 1].right : 0;
+        const int dnChr = Kt < ncl ? S.clusters[Kt].chr : 0, dnPos = Kt < ncl ? S.clusters[Kt].start : 0;  // zero sentinel after the last cluster (ledger B21)
+        long long ob = std::max<long long>(P.other_max_local, sh.other_seed);
+        if (ob < 0) ob = 0;
+        const int oChr = (int)(ob >> 32), oRight = (int)(ob & 0xffffffffll);
+        const bool disLead = disChr > oChr || (disChr == oChr && disRight > oRight);
+        const int curRight = disLead ? disRight : oRight, curChr = std::max(disChr, oChr);
+        const int RLt = c->read_len;
+        if ((sh.term_refid != curChr || sh.term_pos > curRight + RLt) && (curChr < dnChr || (curChr == dnChr && curRight + RLt < dnPos))) {
+            sup.zidx.push_back((int32_t)K); sup.z_ochr.push_back(oChr); sup.z_oright.push_back(oRight);
+        }
+    }
     if (sh.on) {
         // triggers were computed on the local stream: a cluster nobody here has passed is passed by the appended record
         // of the next shard if that lies beyond it
@@ -540,7 +573,7 @@ int segment_prepare(sq_ctx* c, SegPlan& P, int64_t& n_break) {
     }
     lap("host_prep_active");
     std::vector<int64_t> range_off;
-    rc = dev_fetch_stream(c, ranges, P.compact, range_off);
+    rc = dev_fetch_stream(c, ranges, P.compact, range_off, term ? &term_rec : nullptr);
     if (rc) return rc;
     P.shift.resize(active.size());
     for (size_t a = 0; a < active.size(); ++a) P.shift[a] = ranges[range_of[a]].first - range_off[range_of[a]];
