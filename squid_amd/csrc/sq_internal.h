@@ -304,9 +304,9 @@ struct SegSupport {
     std::vector<int32_t> trigger, zidx, z_ochr, z_oright, rest_cluster, rest_pos, rest_len;
 };
 // pass 1 over the resident records (k_pass1): scalar results; the lists stay on the device until dev_segment_support
-struct Pass1Result { int64_t kept = 0, trigger_last = 0; int32_t nz = 0, n_rest = 0; int32_t first_kept[2] = {0, 0}; long long other_max = INT64_MIN; };
-int dev_pass1(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<int32_t>& cl_start, const std::vector<int32_t>& cl_right, long long seed, Pass1Result& out);
-int dev_segment_support(sq_ctx* c, int ncl, SegSupport& out);
+struct Pass1Result { int64_t kept = 0, trigger_last = 0; int32_t n_rest = 0; int32_t first_kept[2] = {0, 0}; long long other_max = INT64_MIN; };
+int dev_pass1(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<int32_t>& cl_start, const std::vector<int32_t>& cl_right, Pass1Result& out);
+int dev_segment_support(sq_ctx* c, int ncl, long long seed, SegSupport& out);
 int dev_fetch_stream(sq_ctx* c, const std::vector<std::pair<int64_t, int64_t>>& ranges, const StreamRec*& compact, std::vector<int64_t>& range_off, const StreamRec* term);
 int dev_classify(sq_ctx* c, int32_t last_info[4]);  // last_info (may be null): {has pass-1, its lists empty, has pass-2, its lists empty}
 int dev_gather_other(sq_ctx* c, int64_t n_break, bool& has_tiny, std::vector<int32_t>& other_chr, std::vector<int32_t>& other_pos, std::vector<int32_t>& other_len);

@@ -185,11 +185,13 @@ struct DeviceRecords {
     DBuf<int32_t> bp_ev, bp_before, bp_end, bp_valid, bp_bucket, stripes;
     // pass 1 (k_pass1): look-back status words, kept records in front of every tile, tile sort keys, the three lists, scalars
     DBuf<unsigned long long> lb;
-    DBuf<int32_t> tile_rank, z_idx, z_chr, z_right, rc_cluster, rc_pos, rc_len, p1_sc;
+    DBuf<int32_t> tile_cnt, tile_zcnt2, zc_v, zc_K, zc_refid, zc_pos;
+    DBuf<unsigned long long> tile_ob, zc_ob;  // tile_ob: [ntiles] pair of every tile | [ntiles] pair in front of every tile
+    DBuf<int32_t> tile_rank, tile_zbase, tile_zcnt, z_idx, z_chr, z_right, rc_cluster, rc_pos, rc_len, p1_sc;
     DBuf<long long> tile_first, tile_max, r_break;
     DBuf<SumItem> sum_items;
     size_t zcap = (size_t)1 << 20, rc_cap = (size_t)1 << 18;
-    int p1_nz = 0, p1_rest = 0, p1_ntiles = 0;
+    int p1_zc = 0, p1_rest = 0, p1_ntiles = 0;
     std::vector<int32_t> h_tile_rank;  // host copy of tile_rank (dev_segment_support)
     DBuf<int32_t> flags;  // small device flag/counter block
     struct Pending { const char* name; double bytes; int slot; };
@@ -3042,7 +3044,8 @@ void dev_destroy(sq_ctx* c) {
     D.refid.release(); D.pos.release(); D.mrefid.release(); D.mpos.release(); D.endpos.release(); D.b_refpos.release(); D.b_matchref.release();
     D.b_pack.release(); D.n_pack.release();
     D.flag.release(); D.totlen.release(); D.b_readpos.release(); D.b_matchread.release(); D.mapq.release(); D.aux.release(); D.blk_off.release();
-    D.lb.release(); D.tile_rank.release(); D.z_idx.release(); D.z_chr.release(); D.z_right.release(); D.rc_cluster.release(); D.rc_pos.release(); D.rc_len.release(); D.p1_sc.release();
+    D.tile_cnt.release(); D.tile_zcnt2.release(); D.zc_v.release(); D.zc_K.release(); D.zc_refid.release(); D.zc_pos.release(); D.tile_ob.release(); D.zc_ob.release();
+    D.lb.release(); D.tile_rank.release(); D.tile_zbase.release(); D.tile_zcnt.release(); D.z_idx.release(); D.z_chr.release(); D.z_right.release(); D.rc_cluster.release(); D.rc_pos.release(); D.rc_len.release(); D.p1_sc.release();
     D.tile_first.release(); D.tile_max.release(); D.r_break.release(); D.sum_items.release(); D.bp_before.release();
     D.cls.release(); D.keep.release(); D.prev1.release(); D.prev2.release(); D.rank1.release(); D.restoff.release();
     D.scratch_a.release(); D.scratch_b.release(); D.scratch_c.release(); D.spine.release();
@@ -3571,14 +3574,14 @@ int dev_classify(sq_ctx* c, int32_t last_info[4]) {
 // Pass 1 over the resident records (k_pass1): filters, duplicate drop, and everything the segmentation automaton needs from the
 // stream -- zero-coverage records, cluster triggers, ConcordRest candidates -- in ONE read of the records.  The lists stay on the
 // device (dev_segment_support fetches them); the scalars come back here.  `seed`: running other-pair of earlier shards.
-int dev_pass1(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<int32_t>& cl_start, const std::vector<int32_t>& cl_right, long long seed, Pass1Result& out) {
+int dev_pass1(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<int32_t>& cl_start, const std::vector<int32_t>& cl_right, Pass1Result& out) {
     DeviceRecords& D = *c->dev;
     hipStream_t s = c->stream;
     const int64_t n = D.n;
     const int ncl = (int)cl_chr.size();
     out = Pass1Result();
     out.other_max = INT64_MIN;
-    D.k1 = 0; D.p1_nz = 0; D.p1_rest = 0; D.p1_ntiles = 0;
+    D.k1 = 0; D.p1_zc = 0; D.p1_rest = 0; D.p1_ntiles = 0;
     D.h_tile_rank.assign(1, 0);
     c->counts.n_kept_p1 = 0; c->counts.n_kept_p2 = 0;
     if (n >= ((int64_t)1 << 31) - P1_TILE) return fail(c, SQ_E_CAPACITY, "more than 2^31 records on one device");
@@ -3596,26 +3599,39 @@ int dev_pass1(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<i
     ClusterView C{ncl, D.cl_chr.p, D.cl_chr.p + ncl, D.cl_chr.p + 2 * (size_t)ncl};
     RecView R = D.view();
     HIPCHK(D.cls.reserve(n + 4)); HIPCHK(D.keep.reserve(n + 4));
-    HIPCHK(D.tile_rank.reserve((size_t)ntiles + 1)); HIPCHK(D.tile_first.reserve(ntiles)); HIPCHK(D.tile_max.reserve(ntiles));
+    HIPCHK(D.tile_rank.reserve((size_t)ntiles + 1)); HIPCHK(D.tile_first.reserve(ntiles)); HIPCHK(D.tile_max.reserve(ntiles)); HIPCHK(D.tile_zbase.reserve(ntiles)); HIPCHK(D.tile_zcnt.reserve(ntiles));
+    HIPCHK(D.tile_cnt.reserve(ntiles)); HIPCHK(D.tile_zcnt2.reserve(ntiles)); HIPCHK(D.tile_ob.reserve(2 * (size_t)ntiles));
     HIPCHK(D.p1_sc.reserve(P1S_WORDS));
     int32_t sc[P1S_WORDS], trig_last = INT32_MAX;
     for (;;) {  // the two lists start small and grow when they overflow (the counts are exact either way)
         HIPCHK(D.z_idx.reserve(D.zcap)); HIPCHK(D.z_chr.reserve(D.zcap)); HIPCHK(D.z_right.reserve(D.zcap));
+        HIPCHK(D.zc_v.reserve(D.zcap)); HIPCHK(D.zc_K.reserve(D.zcap)); HIPCHK(D.zc_refid.reserve(D.zcap)); HIPCHK(D.zc_pos.reserve(D.zcap)); HIPCHK(D.zc_ob.reserve(D.zcap));
         HIPCHK(D.rc_cluster.reserve(D.rc_cap)); HIPCHK(D.rc_pos.reserve(D.rc_cap)); HIPCHK(D.rc_len.reserve(D.rc_cap));
-        const size_t w1 = LbView<2>::words(ntiles), w2 = LbView<1>::words(ntiles);
-        HIPCHK(lb_prepare(D.lb, w1 + w2, s));
         HIPCHK(hipMemsetAsync(D.p1_sc.p, 0, P1S_WORDS * 4, s));
         if (ncl) HIPCHK(hipMemsetAsync(D.trig.p, 0x7f, (size_t)ncl * 4, s));
         P1Args A;
-        A.min_mapq = c->P.min_mapqual; A.prior_mask = c->shard.on ? c->shard.dedup_mask : 0; A.RL = c->read_len; A.seed = seed;
-        A.cls = D.cls.p; A.keep = D.keep.p; A.tile_rank = D.tile_rank.p; A.tile_first = D.tile_first.p; A.tile_max = D.tile_max.p;
-        A.zidx = D.z_idx.p; A.zchr = D.z_chr.p; A.zright = D.z_right.p; A.zcap = (int)D.zcap;
+        A.min_mapq = c->P.min_mapqual; A.prior_mask = c->shard.on ? c->shard.dedup_mask : 0; A.RL = c->read_len;
+        A.cls = D.cls.p; A.keep = D.keep.p; A.tile_cnt = D.tile_cnt.p; A.tile_ob = D.tile_ob.p; A.tile_first = D.tile_first.p; A.tile_max = D.tile_max.p;
+        A.zc_v = D.zc_v.p; A.zc_K = D.zc_K.p; A.zc_refid = D.zc_refid.p; A.zc_pos = D.zc_pos.p; A.zc_ob = D.zc_ob.p; A.zcap = (int)D.zcap; A.tile_zbase = D.tile_zbase.p; A.tile_zcnt = D.tile_zcnt.p;
         A.trig = D.trig.p; A.rc_cluster = D.rc_cluster.p; A.rc_pos = D.rc_pos.p; A.rc_len = D.rc_len.p; A.rc_cap = (int)D.rc_cap;
         A.sc = D.p1_sc.p;
         {   // reads: 26 B of fixed fields per record + its first and last block (16 B each); writes: class and keep byte
             EvTimer t(c, "k_pass1", 28.0 * n + 16.0 * D.nb);
-            hipLaunchKernelGGL(k_pass1, dim3(ntiles), dim3(P1_THREADS), 0, s, R, C, LbView<2>{D.lb.p}, LbView<1>{D.lb.p + w1}, ntiles, A);
-            hipLaunchKernelGGL(k_tile_order_check, dim3((ntiles + 255) / 256), dim3(256), 0, s, ntiles, D.tile_first.p, D.tile_max.p, D.p1_sc.p);
+            static const bool prof = std::getenv("SQUID_P1_PROF") != nullptr;  // s_memtime sums per section of a tile (thread 0 of every workgroup)
+            if (prof) {
+                HIPCHK(D.tok_prof.reserve(16)); HIPCHK(hipMemsetAsync(D.tok_prof.p, 0, 16 * 8, s));
+                hipLaunchKernelGGL(k_pass1<true>, dim3(ntiles), dim3(P1_THREADS), 0, s, R, C, A, D.tok_prof.p);
+                unsigned long long hp[8];
+                HIPCHK(hipMemcpyAsync(hp, D.tok_prof.p, sizeof hp, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+                static const char* nm[7] = {"start", "load+classify+dedup", "scan", "clusters+z+triggers+rest", "run of slots", "emit", "-"};
+                for (int q = 0; q < 7; ++q) std::fprintf(stderr, "[k_pass1] %-28s %10.0f ticks per tile\n", nm[q], (double)hp[q] / (double)std::max<unsigned long long>(hp[7], 1));
+            } else {
+                hipLaunchKernelGGL(k_pass1<false>, dim3(ntiles), dim3(P1_THREADS), 0, s, R, C, A, (unsigned long long*)nullptr);
+            }
+        }
+        {   // per tile: count 4 + pair 8 + two keys 16 in, rank 4 + pair 8 out
+            EvTimer t(c, "k_tile_scan", 40.0 * ntiles);
+            hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(TS_THREADS), 0, s, ntiles, D.tile_cnt.p, D.tile_ob.p, D.tile_first.p, D.tile_max.p, D.tile_rank.p, D.tile_ob.p + ntiles, ncl, D.trig.p, D.p1_sc.p);
         }
         HIPCHK(hipMemcpyAsync(sc, D.p1_sc.p, sizeof sc, hipMemcpyDeviceToHost, s));
         if (ncl) HIPCHK(hipMemcpyAsync(&trig_last, D.trig.p + (ncl - 1), 4, hipMemcpyDeviceToHost, s));
@@ -3623,13 +3639,13 @@ int dev_pass1(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<i
         if (sc[P1S_FLAGS] & P1F_UNSORTED) return fail(c, SQ_E_UNSORTED, "concordant BAM is not coordinate sorted (README.md:23 requires it)");
         if (sc[P1S_FLAGS] & P1F_NEGATIVE_END) return fail(c, SQ_E_CAPACITY, "a concordant record ends at a negative reference position");
         bool again = false;
-        if ((size_t)sc[P1S_NZ] > D.zcap) { D.zcap = (size_t)sc[P1S_NZ] + (size_t)sc[P1S_NZ] / 4 + 1024; again = true; }
+        if ((size_t)sc[P1S_ZC] > D.zcap) { D.zcap = (size_t)sc[P1S_ZC] + (size_t)sc[P1S_ZC] / 4 + 1024; again = true; }
         if ((size_t)sc[P1S_REST] > D.rc_cap) { D.rc_cap = (size_t)sc[P1S_REST] + (size_t)sc[P1S_REST] / 4 + 1024; again = true; }
         if (!again) break;
     }
-    D.k1 = sc[P1S_KEPT]; D.p1_nz = sc[P1S_NZ]; D.p1_rest = sc[P1S_REST]; D.p1_ntiles = ntiles;
+    D.k1 = sc[P1S_KEPT]; D.p1_zc = sc[P1S_ZC]; D.p1_rest = sc[P1S_REST]; D.p1_ntiles = ntiles;
     out.trigger_last = trig_last;  // (first kept record behind the last cluster; >= kept: none)
-    out.kept = sc[P1S_KEPT]; out.nz = sc[P1S_NZ]; out.n_rest = sc[P1S_REST];
+    out.kept = sc[P1S_KEPT]; out.n_rest = sc[P1S_REST];
     out.first_kept[0] = sc[P1S_FIRST_REFID]; out.first_kept[1] = sc[P1S_FIRST_POS];
     out.other_max = (long long)(((unsigned long long)(uint32_t)sc[P1S_OTHER_HI] << 32) | (uint32_t)sc[P1S_OTHER_LO]);
     c->counts.n_kept_p1 = out.kept;
@@ -3637,23 +3653,31 @@ int dev_pass1(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<i
     return SQ_OK;
 }
 
-// The lists of pass 1: zero-coverage records (+ the running pair in front of each), trigger record of every cluster, ConcordRest
-// candidates, kept records in front of every tile.  One synchronisation.
-int dev_segment_support(sq_ctx* c, int ncl, SegSupport& out) {
+// The lists of pass 1: zero-coverage records (+ the running pair in front of each; k_zfinal settles the candidates of k_pass1 with
+// the running pair of everything in front of their tile, `seed` = that of earlier shards), trigger record of every cluster,
+// ConcordRest candidates, kept records in front of every tile.  One synchronisation.
+int dev_segment_support(sq_ctx* c, int ncl, long long seed, SegSupport& out) {
     DeviceRecords& D = *c->dev;
     hipStream_t s = c->stream;
     const int64_t k = D.k1;
     out.zidx.clear(); out.z_ochr.clear(); out.z_oright.clear(); out.rest_cluster.clear(); out.rest_pos.clear(); out.rest_len.clear();
     out.trigger.assign(ncl, (int32_t)k);
-    const int nz = D.p1_nz, cnt = D.p1_rest, ntiles = D.p1_ntiles;
+    const int zc = D.p1_zc, cnt = D.p1_rest, ntiles = D.p1_ntiles;
     D.h_tile_rank.assign((size_t)ntiles + 1, 0);
     if (D.n == 0) return SQ_OK;
+    ClusterView C{ncl, D.cl_chr.p, D.cl_chr.p + ncl, D.cl_chr.p + 2 * (size_t)ncl};
+    {   // per candidate 24 B in, per zero-coverage record 12 B out; per tile its run descriptor
+        EvTimer t(c, "k_zfinal", 24.0 * zc + 24.0 * ntiles);
+        hipLaunchKernelGGL(k_zfinal, dim3((ntiles + 3) / 4), dim3(256), 0, s, ntiles, C, seed, c->read_len, D.tile_rank.p, D.tile_ob.p + ntiles, D.tile_zbase.p, D.tile_zcnt.p, (int)D.zcap, D.zc_v.p, D.zc_K.p, D.zc_ob.p,
+                           D.zc_refid.p, D.zc_pos.p, D.tile_zcnt2.p, D.z_idx.p, D.z_chr.p, D.z_right.p);
+    }
     D.pin.reset();
-    int32_t *hz = D.pin.take_n<int32_t>(3 * (size_t)nz), *hr = D.pin.take_n<int32_t>(3 * (size_t)cnt), *ht = D.pin.take_n<int32_t>(ncl), *hk = D.pin.take_n<int32_t>((size_t)ntiles + 1);
+    int32_t *hz = D.pin.take_n<int32_t>(3 * (size_t)zc), *hr = D.pin.take_n<int32_t>(3 * (size_t)cnt), *ht = D.pin.take_n<int32_t>(ncl), *hk = D.pin.take_n<int32_t>(3 * (size_t)ntiles + 1);
     if (!hz || !hr || !ht || !hk) return fail(c, SQ_E_HIP, "hipHostMalloc failed");
-    if (nz) {
-        HIPCHK(hipMemcpyAsync(hz, D.z_idx.p, (size_t)nz * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(hz + nz, D.z_chr.p, (size_t)nz * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(hz + 2 * (size_t)nz, D.z_right.p, (size_t)nz * 4, hipMemcpyDeviceToHost, s));
+    if (zc) {
+        HIPCHK(hipMemcpyAsync(hz, D.z_idx.p, (size_t)zc * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(hz + zc, D.z_chr.p, (size_t)zc * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hz + 2 * (size_t)zc, D.z_right.p, (size_t)zc * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hk + ntiles + 1, D.tile_zbase.p, (size_t)ntiles * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(hk + 2 * (size_t)ntiles + 1, D.tile_zcnt2.p, (size_t)ntiles * 4, hipMemcpyDeviceToHost, s));
     }
     if (cnt) {
         HIPCHK(hipMemcpyAsync(hr, D.rc_cluster.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(hr + cnt, D.rc_pos.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, s));
@@ -3662,7 +3686,17 @@ int dev_segment_support(sq_ctx* c, int ncl, SegSupport& out) {
     if (ncl) HIPCHK(hipMemcpyAsync(ht, D.trig.p, (size_t)ncl * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(hk, D.tile_rank.p, ((size_t)ntiles + 1) * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    out.zidx.assign(hz, hz + nz); out.z_ochr.assign(hz + nz, hz + 2 * (size_t)nz); out.z_oright.assign(hz + 2 * (size_t)nz, hz + 3 * (size_t)nz);
+    // the zero-coverage records in stream order: the tiles' runs one after the other
+    if (zc) {
+        const int32_t *zb = hk + ntiles + 1, *zn = hk + 2 * (size_t)ntiles + 1;
+        for (int t = 0; t < ntiles; ++t) {
+            const int32_t b = zb[t], m = zn[t];
+            if (!m) continue;
+            if (b < 0 || (size_t)b + (size_t)m > (size_t)zc) return fail(c, SQ_E_ARG, "internal: zero-coverage run outside the list");
+            out.zidx.insert(out.zidx.end(), hz + b, hz + b + m); out.z_ochr.insert(out.z_ochr.end(), hz + zc + b, hz + zc + b + m); out.z_oright.insert(out.z_oright.end(), hz + 2 * (size_t)zc + b, hz + 2 * (size_t)zc + b + m);
+        }
+    }
+    const int nz = (int)out.zidx.size();
     out.rest_cluster.assign(hr, hr + cnt); out.rest_pos.assign(hr + cnt, hr + 2 * (size_t)cnt); out.rest_len.assign(hr + 2 * (size_t)cnt, hr + 3 * (size_t)cnt);
     // trigger of cluster c = first kept record with more than c clusters behind it: the kernel left, per cluster, the first record
     // with exactly c + 1 behind it

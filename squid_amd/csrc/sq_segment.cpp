@@ -452,7 +452,7 @@ int segment_scan(sq_ctx* c, SegPlan& P, bool fetch, int64_t& trigger_last, long 
     P.cl_chr.resize(ncl); P.cl_start.resize(ncl); P.cl_right.resize(ncl);
     for (int k = 0; k < ncl; ++k) { P.cl_chr[k] = S.clusters[k].chr; P.cl_start[k] = S.clusters[k].start; P.cl_right[k] = S.clusters[k].right; }
     Pass1Result res;
-    int rc = dev_pass1(c, P.cl_chr, P.cl_start, P.cl_right, c->shard.on ? c->shard.other_seed : INT64_MIN, res);
+    int rc = dev_pass1(c, P.cl_chr, P.cl_start, P.cl_right, res);
     if (rc) return rc;
     P.K = res.kept;
     P.other_max_local = res.other_max;
@@ -471,15 +471,9 @@ int segment_prepare(sq_ctx* c, SegPlan& P, int64_t& n_break) {
     SegSupport& sup = P.sup;
     auto t_begin = std::chrono::steady_clock::now();
     auto lap = [&](const char* name) { auto t = std::chrono::steady_clock::now(); c->timer.add(name, std::chrono::duration<double, std::milli>(t - t_begin).count()); t_begin = t; };
-    int rc;
-    if (sh.on && sh.other_seed != INT64_MIN) {  // the zero-coverage test looks at the running pair, which earlier shards feed
-        Pass1Result res;
-        rc = dev_pass1(c, P.cl_chr, P.cl_start, P.cl_right, sh.other_seed, res);
-        if (rc) return rc;
-        if (res.kept != P.K) return fail(c, SQ_E_ARG, "internal: pass 1 is not repeatable");
-    }
     const int64_t K = P.K;
-    rc = dev_segment_support(c, ncl, sup);
+    // (the zero-coverage test looks at the running pair, which earlier shards feed: their pair is the seed)
+    int rc = dev_segment_support(c, ncl, sh.on ? sh.other_seed : INT64_MIN, sup);
     if (rc) return rc;
     lap("host_prep_support");
     const bool term = sh.on && sh.has_terminal && K > 0;
