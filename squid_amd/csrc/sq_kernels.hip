@@ -181,7 +181,7 @@ struct DeviceRecords {
     DBuf<int32_t> parse_nblk, parse_rel;
     DBuf<int32_t> calib;
     DBuf<uint8_t> zflag;
-    DBuf<int32_t> cl_chr, trig;  // cl_chr: packed cluster table chr | start | right
+    DBuf<int32_t> cl_chr, trig, cl_bucket;  // cl_chr: packed cluster table chr | start | right; cl_bucket: bucket_off | position index of the cluster table
     DBuf<int32_t> bp_ev, bp_before, bp_end, bp_valid, bp_bucket, stripes;
     // pass 1 (k_pass1): look-back status words, kept records in front of every tile, tile sort keys, the three lists, scalars
     DBuf<unsigned long long> lb;
@@ -802,7 +802,7 @@ __device__ bool key_equal(const RecView& R, const RecKey& kq, const RecKey& kr) 
 //     stream it is a plain 64-bit max-scan of (refid << 32 | first-block end) over concordant records,
 //   * per cluster, the non-first blocks of concordant records that can span one of its break candidates
 //     (the live content of the ConcordRest heap, :387-389,471-473,690-699).
-struct ClusterView { int32_t n; const int32_t *chr, *start, *right; };
+struct ClusterView { int32_t n; const int32_t *chr, *start, *right; int32_t n_ref; const int32_t *bucket_off, *bucket; /* position index (k_cluster_buckets): 16 KiB stretches, the geometry of NodeView::bucket_off */ };
 __device__ __forceinline__ int clusters_passed(const ClusterView& C, int refid, int pos) {  // #k with (chr_k,right_k) < (refid,pos)
     int lo = 0, hi = C.n;
     while (lo < hi) { int mid = (lo + hi) >> 1; if (C.chr[mid] < refid || (C.chr[mid] == refid && C.right[mid] < pos)) lo = mid + 1; else hi = mid; }
@@ -3055,7 +3055,7 @@ void dev_destroy(sq_ctx* c) {
     D.acc_a.release(); D.acc_b.release(); D.acc_c.release();
     D.h_key.release(); D.h_val.release(); D.flags.release(); D.bam_chunk.release(); D.bam_off.release(); D.chim_hash.release(); D.chim_off.release(); D.chim_len.release(); D.chim_blob.release(); D.parse_nblk.release(); D.parse_rel.release();
     D.calib.release(); D.okey.release(); D.oval.release(); D.other64.release(); D.spine64.release(); D.okey64.release(); D.zflag.release();
-    D.cl_chr.release(); D.trig.release();
+    D.cl_chr.release(); D.trig.release(); D.cl_bucket.release();
     D.ord_e.release(); D.ord_o.release(); D.ord_v.release(); D.ord_me.release(); D.ord_mo.release(); D.g_i.release(); D.g_x.release(); D.g_d.release(); D.g_b.release();
     D.pin.release(); for (auto& st : D.il_set) { st.in.release(); st.tab.release(); st.tok.release(); st.ntok.release(); st.flags.release(); if (st.ready) (void)hipEventDestroy(st.ready); if (st.freed) (void)hipEventDestroy(st.freed); if (st.copied) (void)hipEventDestroy(st.copied); st.ready = st.freed = st.copied = nullptr; }
     if (D.il_tok_stream) { (void)hipStreamDestroy(D.il_tok_stream); D.il_tok_stream = nullptr; }
@@ -3592,17 +3592,30 @@ int dev_pass1(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<i
         HIPCHK(hipMemcpy(D.cl_chr.p, pack.data(), pack.size() * 4, hipMemcpyHostToDevice));
     }
     D.cl_n = ncl;
+    // position index of the cluster table (16 KiB stretches per reference)
+    const int n_ref = (int)c->ref_len.size();
+    std::vector<int32_t> bo(n_ref + 1, 0);
+    for (int k = 0; k < n_ref; ++k) {
+        const int64_t nb = (int64_t)bo[k] + (((int64_t)std::max(c->ref_len[k], 1) + (1 << NODE_BUCKET_SHIFT) - 1) >> NODE_BUCKET_SHIFT);
+        if (nb > INT32_MAX) return fail(c, SQ_E_CAPACITY, "references too long for the position index");
+        bo[k + 1] = (int32_t)nb;
+    }
+    const int cl_total = bo[n_ref];
+    HIPCHK(D.cl_bucket.reserve((size_t)n_ref + 1 + (size_t)std::max(cl_total, 1)));
+    HIPCHK(hipMemcpy(D.cl_bucket.p, bo.data(), ((size_t)n_ref + 1) * 4, hipMemcpyHostToDevice));
     if (n == 0) return SQ_OK;
     for (int32_t len : c->ref_len) (void)len;
     if (c->ref_len.size() >= ((size_t)1 << 30)) return fail(c, SQ_E_CAPACITY, "too many references");
     const int ntiles = (int)((n + P1_TILE - 1) / P1_TILE);
-    ClusterView C{ncl, D.cl_chr.p, D.cl_chr.p + ncl, D.cl_chr.p + 2 * (size_t)ncl};
+    ClusterView C{ncl, D.cl_chr.p, D.cl_chr.p + ncl, D.cl_chr.p + 2 * (size_t)ncl, n_ref, D.cl_bucket.p, D.cl_bucket.p + n_ref + 1};
+    if (ncl && cl_total) hipLaunchKernelGGL(k_cluster_buckets, dim3((cl_total + 255) / 256), dim3(256), 0, s, C, cl_total, D.cl_bucket.p + n_ref + 1);
     RecView R = D.view();
     HIPCHK(D.cls.reserve(n + 4)); HIPCHK(D.keep.reserve(n + 4));
     HIPCHK(D.tile_rank.reserve((size_t)ntiles + 1)); HIPCHK(D.tile_first.reserve(ntiles)); HIPCHK(D.tile_max.reserve(ntiles)); HIPCHK(D.tile_zbase.reserve(ntiles)); HIPCHK(D.tile_zcnt.reserve(ntiles));
     HIPCHK(D.tile_cnt.reserve(ntiles)); HIPCHK(D.tile_zcnt2.reserve(ntiles)); HIPCHK(D.tile_ob.reserve(2 * (size_t)ntiles));
     HIPCHK(D.p1_sc.reserve(P1S_WORDS));
     int32_t sc[P1S_WORDS], trig_last = INT32_MAX;
+    if (D.zcap < (size_t)ntiles * P1_ZFIX + ((size_t)1 << 16)) D.zcap = (size_t)ntiles * P1_ZFIX + ((size_t)1 << 16);
     for (;;) {  // the two lists start small and grow when they overflow (the counts are exact either way)
         HIPCHK(D.z_idx.reserve(D.zcap)); HIPCHK(D.z_chr.reserve(D.zcap)); HIPCHK(D.z_right.reserve(D.zcap));
         HIPCHK(D.zc_v.reserve(D.zcap)); HIPCHK(D.zc_K.reserve(D.zcap)); HIPCHK(D.zc_refid.reserve(D.zcap)); HIPCHK(D.zc_pos.reserve(D.zcap)); HIPCHK(D.zc_ob.reserve(D.zcap));
@@ -3612,7 +3625,7 @@ int dev_pass1(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<i
         P1Args A;
         A.min_mapq = c->P.min_mapqual; A.prior_mask = c->shard.on ? c->shard.dedup_mask : 0; A.RL = c->read_len;
         A.cls = D.cls.p; A.keep = D.keep.p; A.tile_cnt = D.tile_cnt.p; A.tile_ob = D.tile_ob.p; A.tile_first = D.tile_first.p; A.tile_max = D.tile_max.p;
-        A.zc_v = D.zc_v.p; A.zc_K = D.zc_K.p; A.zc_refid = D.zc_refid.p; A.zc_pos = D.zc_pos.p; A.zc_ob = D.zc_ob.p; A.zcap = (int)D.zcap; A.tile_zbase = D.tile_zbase.p; A.tile_zcnt = D.tile_zcnt.p;
+        A.zc_v = D.zc_v.p; A.zc_K = D.zc_K.p; A.zc_refid = D.zc_refid.p; A.zc_pos = D.zc_pos.p; A.zc_ob = D.zc_ob.p; A.zcap = (int)D.zcap; A.zfix_end = ntiles * P1_ZFIX; A.tile_zbase = D.tile_zbase.p; A.tile_zcnt = D.tile_zcnt.p;
         A.trig = D.trig.p; A.rc_cluster = D.rc_cluster.p; A.rc_pos = D.rc_pos.p; A.rc_len = D.rc_len.p; A.rc_cap = (int)D.rc_cap;
         A.sc = D.p1_sc.p;
         {   // reads: 26 B of fixed fields per record + its first and last block (16 B each); writes: class and keep byte
@@ -3631,7 +3644,8 @@ int dev_pass1(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<i
         }
         {   // per tile: count 4 + pair 8 + two keys 16 in, rank 4 + pair 8 out
             EvTimer t(c, "k_tile_scan", 40.0 * ntiles);
-            hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(TS_THREADS), 0, s, ntiles, D.tile_cnt.p, D.tile_ob.p, D.tile_first.p, D.tile_max.p, D.tile_rank.p, D.tile_ob.p + ntiles, ncl, D.trig.p, D.p1_sc.p);
+            hipLaunchKernelGGL(k_tile_scan, dim3((ntiles + TS_THREADS - 1) / TS_THREADS), dim3(TS_THREADS), 0, s, ntiles, D.tile_cnt.p, D.tile_ob.p, D.tile_first.p, D.tile_max.p, D.tile_rank.p, D.tile_ob.p + ntiles, D.p1_sc.p);
+            if (ncl) hipLaunchKernelGGL(k_trig_rank, dim3((ncl + 255) / 256), dim3(256), 0, s, ncl, ntiles, D.tile_rank.p, D.trig.p);
         }
         HIPCHK(hipMemcpyAsync(sc, D.p1_sc.p, sizeof sc, hipMemcpyDeviceToHost, s));
         if (ncl) HIPCHK(hipMemcpyAsync(&trig_last, D.trig.p + (ncl - 1), 4, hipMemcpyDeviceToHost, s));
@@ -3639,11 +3653,12 @@ int dev_pass1(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<i
         if (sc[P1S_FLAGS] & P1F_UNSORTED) return fail(c, SQ_E_UNSORTED, "concordant BAM is not coordinate sorted (README.md:23 requires it)");
         if (sc[P1S_FLAGS] & P1F_NEGATIVE_END) return fail(c, SQ_E_CAPACITY, "a concordant record ends at a negative reference position");
         bool again = false;
-        if ((size_t)sc[P1S_ZC] > D.zcap) { D.zcap = (size_t)sc[P1S_ZC] + (size_t)sc[P1S_ZC] / 4 + 1024; again = true; }
+        const size_t zneed = (size_t)ntiles * P1_ZFIX + (size_t)sc[P1S_ZC];
+        if (zneed > D.zcap) { D.zcap = zneed + zneed / 4 + 1024; again = true; }
         if ((size_t)sc[P1S_REST] > D.rc_cap) { D.rc_cap = (size_t)sc[P1S_REST] + (size_t)sc[P1S_REST] / 4 + 1024; again = true; }
         if (!again) break;
     }
-    D.k1 = sc[P1S_KEPT]; D.p1_zc = sc[P1S_ZC]; D.p1_rest = sc[P1S_REST]; D.p1_ntiles = ntiles;
+    D.k1 = sc[P1S_KEPT]; D.p1_zc = ntiles * P1_ZFIX + sc[P1S_ZC]; D.p1_rest = sc[P1S_REST]; D.p1_ntiles = ntiles;
     out.trigger_last = trig_last;  // (first kept record behind the last cluster; >= kept: none)
     out.kept = sc[P1S_KEPT]; out.n_rest = sc[P1S_REST];
     out.first_kept[0] = sc[P1S_FIRST_REFID]; out.first_kept[1] = sc[P1S_FIRST_POS];
@@ -3665,7 +3680,8 @@ int dev_segment_support(sq_ctx* c, int ncl, long long seed, SegSupport& out) {
     const int zc = D.p1_zc, cnt = D.p1_rest, ntiles = D.p1_ntiles;
     D.h_tile_rank.assign((size_t)ntiles + 1, 0);
     if (D.n == 0) return SQ_OK;
-    ClusterView C{ncl, D.cl_chr.p, D.cl_chr.p + ncl, D.cl_chr.p + 2 * (size_t)ncl};
+    const int n_ref = (int)c->ref_len.size();
+    ClusterView C{ncl, D.cl_chr.p, D.cl_chr.p + ncl, D.cl_chr.p + 2 * (size_t)ncl, n_ref, D.cl_bucket.p, D.cl_bucket.p + n_ref + 1};
     {   // per candidate 24 B in, per zero-coverage record 12 B out; per tile its run descriptor
         EvTimer t(c, "k_zfinal", 24.0 * zc + 24.0 * ntiles);
         hipLaunchKernelGGL(k_zfinal, dim3((ntiles + 3) / 4), dim3(256), 0, s, ntiles, C, seed, c->read_len, D.tile_rank.p, D.tile_ob.p + ntiles, D.tile_zbase.p, D.tile_zcnt.p, (int)D.zcap, D.zc_v.p, D.zc_K.p, D.zc_ob.p,
