@@ -3624,6 +3624,7 @@ int dev_pass1(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<i
         if (ncl) HIPCHK(hipMemsetAsync(D.trig.p, 0x7f, (size_t)ncl * 4, s));
         P1Args A;
         A.min_mapq = c->P.min_mapqual; A.prior_mask = c->shard.on ? c->shard.dedup_mask : 0; A.RL = c->read_len;
+        A.ablate = std::getenv("SQUID_P1_ABLATE") ? std::atoi(std::getenv("SQUID_P1_ABLATE")) : 0;
         A.cls = D.cls.p; A.keep = D.keep.p; A.tile_cnt = D.tile_cnt.p; A.tile_ob = D.tile_ob.p; A.tile_first = D.tile_first.p; A.tile_max = D.tile_max.p;
         A.zc_v = D.zc_v.p; A.zc_K = D.zc_K.p; A.zc_refid = D.zc_refid.p; A.zc_pos = D.zc_pos.p; A.zc_ob = D.zc_ob.p; A.zcap = (int)D.zcap; A.zfix_end = ntiles * P1_ZFIX; A.tile_zbase = D.tile_zbase.p; A.tile_zcnt = D.tile_zcnt.p;
         A.trig = D.trig.p; A.rc_cluster = D.rc_cluster.p; A.rc_pos = D.rc_pos.p; A.rc_len = D.rc_len.p; A.rc_cap = (int)D.rc_cap;
