@@ -1297,7 +1297,7 @@ __global__ void k_hash_compact(const unsigned long long* hk, const uint32_t* hv,
 // (k_bp_chain decides that in stream order; events are indexed by their M value, which grows with the stream).
 // `bucket` is the coarse position index of the node table's geometry (NodeView::bucket_off): the answer for the first
 // base of every 16 KiB stretch, so a query is one load and a short walk
-struct BPView { int32_t n; const int32_t *chr, *pos; int dp; const int32_t *bucket, *bucket_off; };
+struct BPView { int32_t n; const int32_t *chr, *pos; int dp; const int32_t *bucket, *bucket_off; int32_t n_ref; };
 __device__ __forceinline__ int bp_lower_bound_search(const BPView& B, int c, int p) {  // first j with (chr,pos) >= (c,p)
     int lo = 0, hi = B.n;
     while (lo < hi) { int mid = (lo + hi) >> 1; if (B.chr[mid] < c || (B.chr[mid] == c && B.pos[mid] < p)) lo = mid + 1; else hi = mid; }
@@ -3858,7 +3858,7 @@ int dev_node_depth(sq_ctx* c, const std::vector<Node>& nodes, int64_t n_break, s
         HIPCHK(lb_prepare(D.lb, LbView<1>::words(ntiles), s));
         // keep 1 + block offset 4 + refid 4 per record; 16 B per block of a consumed record (the cursor never leaves the kernel)
         { EvTimer t(c, "k_depth2", 9.0 * n + 16.0 * D.nb * ((double)D.k1 / (double)n));
-          hipLaunchKernelGGL(k_depth2, dim3(ntiles), dim3(ST_THREADS), 0, s, R, nv, D.keep.p, D.r_break.p, LbView<1>{D.lb.p}, ntiles, a_mc, a_ms, a_oc, a_os, a_ap, a_am, D.flags.p, stripes);
+          hipLaunchKernelGGL(k_depth2, dim3(ntiles), dim3(ST_THREADS), 0, s, R, nv, D.keep.p, D.r_break.p, LbView<1>{D.lb.p, std::getenv("SQUID_LB_SKIP") ? 1 : 0}, ntiles, a_mc, a_ms, a_oc, a_os, a_ap, a_am, D.flags.p, stripes);
           if (nn) hipLaunchKernelGGL(k_fold_stripes, dim3((nn + 255) / 256), dim3(256), 0, s, nn, a_mc, a_ms, a_oc, a_os, acc); }
     }
     D.pin.reset();
@@ -4052,7 +4052,7 @@ int dev_breakpoint_support(sq_ctx* c, const std::vector<std::pair<int, int>>& bp
     for (int k = 0; k < n_ref; ++k) bo[k + 1] = bo[k] + (int32_t)(((int64_t)std::max(c->ref_len[k], 1) + (1 << NODE_BUCKET_SHIFT) - 1) >> NODE_BUCKET_SHIFT);
     const int total = bo[n_ref];
     HIPCHK(D.bp_bucket.reserve(std::max(total, 1)));
-    BPView B{nb, D.acc_b.p, D.acc_b.p + nb, c->P.concord_dist_pos, D.bp_bucket.p, D.nv.bucket_off};
+    BPView B{nb, D.acc_b.p, D.acc_b.p + nb, c->P.concord_dist_pos, D.bp_bucket.p, D.nv.bucket_off, n_ref};
     for (int i = 0; i < nb; ++i) if (bc[i] < 0 || bc[i] >= n_ref) return fail(c, SQ_E_ARG, "breakpoint on an unknown reference");
     if (total) hipLaunchKernelGGL(k_bp_buckets, dim3((total + 255) / 256), dim3(256), 0, s, B, n_ref, total, D.bp_bucket.p);
     HIPCHK(D.bp_ev.reserve(nb + 1)); HIPCHK(D.bp_before.reserve(nb + 1)); HIPCHK(D.bp_end.reserve(nb + 1)); HIPCHK(D.bp_valid.reserve(nb + 1));
@@ -4065,7 +4065,7 @@ int dev_breakpoint_support(sq_ctx* c, const std::vector<std::pair<int, int>>& bp
         const int ntiles = (int)((n + ST_TILE - 1) / ST_TILE);
         HIPCHK(lb_prepare(D.lb, LbView<1>::words(ntiles), s));
         EvTimer t(c, "k_bp2", 23.0 * n);
-        hipLaunchKernelGGL(k_bp2, dim3(ntiles), dim3(ST_THREADS), 0, s, R, B, D.cls.p, cur_prev, LbView<1>{D.lb.p}, ntiles, D.bp_ev.p, D.bp_before.p, D.acc_c.p, agg);
+        hipLaunchKernelGGL(k_bp2, dim3(ntiles), dim3(ST_THREADS), 0, s, R, B, D.cls.p, cur_prev, LbView<1>{D.lb.p, std::getenv("SQUID_LB_SKIP") ? 1 : 0}, ntiles, D.bp_ev.p, D.bp_before.p, D.acc_c.p, agg);
     }
     { EvTimer t(c, "k_bp_walk", 0);
       hipLaunchKernelGGL(k_bp_walk2<false>, dim3(nb), dim3(64), 0, s, R, B, D.cls.p, cur_prev, D.bp_ev.p, D.bp_before.p, D.bp_end.p, D.bp_valid.p, D.acc_c.p, agg + 1);
