@@ -711,7 +711,7 @@ int sq_ingest_chimeric(sq_ctx* c, const sq_aln_batch* b) {
 }
 int sq_chim_contains(sq_ctx* c, const char* name, size_t len) {
     if (!c) return SQ_E_ARG;
-    return c->chim_set.count(std::string(name, len)) ? 1 : 0;
+    return std::binary_search(c->chim_names.begin(), c->chim_names.end(), std::string(name, len)) ? 1 : 0;
 }
 // does this shard own records of RefID `id`?  (the unplaced records at the end of a sorted BAM go to the last rank)
 static inline bool shard_owns(const sq_ctx* c, int32_t id) {
@@ -871,6 +871,7 @@ int sq_ingest_concordant_file(sq_ctx* c, const char* path, int32_t n_threads) {
         if (std::getenv("SQUID_INGEST_TIMING")) std::fprintf(stderr, "ingest %s: reader returned after %.1f ms, timers flushed after %.1f ms\n", path, t_scan, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_file0).count());
         return rc;
     }
+    if (c->chim_set.size() != c->chim_names.size()) { c->chim_set.clear(); c->chim_set.insert(c->chim_names.begin(), c->chim_names.end()); }
     ParseOpts o{c->P.phred_type, c->P.min_phred, c->P.max_lowphred_len, false, &c->chim_set};
     return parse_bam_file(path, o, (size_t)1 << 21, n_threads, c->err, [&](const HostBatch& hb) {
         sq_aln_batch b;

@@ -5,6 +5,7 @@
 // decisions as it does on the reference's objects.
 #include <algorithm>
 #include <cstring>
+#include <functional>
 
 #include "sq_internal.h"
 
@@ -45,7 +46,7 @@ bool frag_equal(const Frag& x, const Frag& y) {  // ReadRec.cpp:119-141
     return (same(x.a, y.a) && same(x.b, y.b)) || (same(x.a, y.b) && same(x.b, y.a));
 }
 
-static bool front_smaller(const Frag& l, const Frag& r) {  // ReadRec.cpp:90-117 (not a strict weak order; kept)
+[[maybe_unused]] static bool front_smaller(const Frag& l, const Frag& r) {  // ReadRec.cpp:90-117 (not a strict weak order; kept)
     auto lt = blk_less_pos;
     if (!l.a.empty() && !r.a.empty()) return lt(l.a.front(), r.a.front());
     if (!l.b.empty() && !r.b.empty()) return lt(l.b.front(), r.b.front());
@@ -56,99 +57,136 @@ static bool front_smaller(const Frag& l, const Frag& r) {  // ReadRec.cpp:90-117
 
 int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
     if (!b->name_off || !b->name_blob) return fail(c, SQ_E_ARG, "chimeric batch needs names");
+    HostPool* pool = c->pool.get();
+    auto par = [&](int64_t n, const std::function<void(int64_t, int64_t)>& f) {  // [lo, hi) pieces on the context's host threads
+        const int pieces = (int)std::min<int64_t>(std::max<int64_t>(1, n / 4096), pool ? 4 * (pool->size() + 1) : 1);
+        if (pieces <= 1 || !pool) { f(0, n); return; }
+        pool->parallel_for(pieces, 15, [&](int k) { f(n * k / pieces, n * (k + 1) / pieces); });
+    };
     // one single-record fragment per usable record (mapped, not duplicate: ReadRec.cpp:344)
-    std::vector<Frag> recs;
-    std::vector<uint16_t> sample;
-    for (int64_t i = 0; i < b->n_rec; ++i) {
-        int flag = b->flag[i];
-        if ((flag & 0x4) || (flag & 0x400)) continue;
-        Frag f;
-        f.name.assign(b->name_blob + b->name_off[i], b->name_blob + b->name_off[i + 1]);
-        size_t L = f.name.size();
-        if (L >= 2 && f.name[L - 2] == '/' && (f.name[L - 1] == '1' || f.name[L - 1] == '2')) f.name.resize(L - 2);
-        bool first = flag & 0x40, rev = flag & 0x10;
-        std::vector<Blk>& dst = first ? f.a : f.b;
-        for (uint32_t k = b->blk_off[i]; k < b->blk_off[i + 1]; ++k)
-            dst.push_back(Blk{b->refid[i], b->b_refpos[k], (int32_t)b->b_readpos[k], b->b_matchref[k], (int32_t)b->b_matchread[k], rev, first});
-        bool low = b->aux[i] & SQ_AUX_LOWPHRED;
-        if (first) { f.atot = b->totlen[i]; f.alow = low; }
-        else { f.btot = b->totlen[i]; f.blow = low; }
-        if (sample.size() < 5) sample.push_back((uint16_t)std::max(f.atot, f.btot));
-        recs.push_back(std::move(f));
-    }
+    std::vector<int64_t> usable;
+    usable.reserve((size_t)b->n_rec);
+    for (int64_t i = 0; i < b->n_rec; ++i) if (!(b->flag[i] & 0x4) && !(b->flag[i] & 0x400)) usable.push_back(i);
     c->n_chim_records = b->n_rec;
-    if (sample.empty()) return fail(c, SQ_E_EMPTYCHIM, "chimeric input has no mapped, non-duplicate record");
-    // sort by QNAME (ReadRec.cpp:354): same comparator on an index array => same permutation
-    std::vector<int> idx(recs.size());
-    for (size_t i = 0; i < idx.size(); ++i) idx[i] = (int)i;
-    // (the first 16 bytes of every name as two big-endian words next to the index: most comparisons are decided without touching the
-    // strings; the comparison results, and with them the permutation introsort produces, are those of `name < name`)
-    struct NameKey { uint64_t hi, lo; };
-    std::vector<NameKey> nk(recs.size());
-    for (size_t i = 0; i < recs.size(); ++i) {
-        unsigned char buf[16] = {0};
-        std::memcpy(buf, recs[i].name.data(), std::min<size_t>(16, recs[i].name.size()));
-        uint64_t h = 0, l = 0;
-        for (int k = 0; k < 8; ++k) { h = (h << 8) | buf[k]; l = (l << 8) | buf[8 + k]; }
-        nk[i] = NameKey{h, l};
-    }
-    std::sort(idx.begin(), idx.end(), [&](int x, int y) {
-        const NameKey &a = nk[(size_t)x], &b = nk[(size_t)y];
-        if (a.hi != b.hi) return a.hi < b.hi;
-        if (a.lo != b.lo) return a.lo < b.lo;
-        return recs[x].name < recs[y].name;
-    });
-    // merge equal names (ReadRec.cpp:356-373)
-    std::vector<Frag> merged;
-    for (int id : idx) {
-        Frag& r = recs[id];
-        if (merged.empty() || r.name != merged.back().name) merged.push_back(std::move(r));
-        else {
-            Frag& m = merged.back();
-            if (m.atot == 0 && r.atot != 0) { m.atot = r.atot; m.alow = r.alow; }
-            if (m.btot == 0 && r.btot != 0) { m.btot = r.btot; m.blow = r.blow; }
-            m.a.insert(m.a.end(), r.a.begin(), r.a.end());
-            m.b.insert(m.b.end(), r.b.begin(), r.b.end());
+    if (usable.empty()) return fail(c, SQ_E_EMPTYCHIM, "chimeric input has no mapped, non-duplicate record");
+    std::vector<uint16_t> sample;  // ReadLen = median of max(FirstTotalLen, SecondTotalLen) of the first five (ReadRec.cpp:336,347-348)
+    for (size_t k = 0; k < usable.size() && k < 5; ++k) sample.push_back((uint16_t)b->totlen[usable[k]]);
+    const size_t nr = usable.size();
+    std::vector<Frag> recs(nr);
+    // sort by QNAME (ReadRec.cpp:354).  What is sorted is (first 16 bytes of the name as two big-endian words, index): most comparisons
+    // are decided inside the 24-byte elements, without touching the strings; the comparison results, and with them the permutation
+    // libstdc++'s introsort produces (ledger B8), are those of `name < name` on the reference's objects
+    struct NameKey { uint64_t hi, lo; int32_t idx; };
+    std::vector<NameKey> nk(nr);
+    par((int64_t)nr, [&](int64_t lo, int64_t hi) {
+        for (int64_t k = lo; k < hi; ++k) {
+            const int64_t i = usable[(size_t)k];
+            Frag& f = recs[(size_t)k];
+            const int flag = b->flag[i];
+            f.name.assign(b->name_blob + b->name_off[i], b->name_blob + b->name_off[i + 1]);
+            size_t L = f.name.size();
+            if (L >= 2 && f.name[L - 2] == '/' && (f.name[L - 1] == '1' || f.name[L - 1] == '2')) f.name.resize(L - 2);
+            const bool first = flag & 0x40, rev = flag & 0x10;
+            std::vector<Blk>& dst = first ? f.a : f.b;
+            dst.reserve(b->blk_off[i + 1] - b->blk_off[i]);
+            for (uint32_t q = b->blk_off[i]; q < b->blk_off[i + 1]; ++q)
+                dst.push_back(Blk{b->refid[i], b->b_refpos[q], (int32_t)b->b_readpos[q], b->b_matchref[q], (int32_t)b->b_matchread[q], rev, first});
+            const bool low = b->aux[i] & SQ_AUX_LOWPHRED;
+            if (first) { f.atot = b->totlen[i]; f.alow = low; }
+            else { f.btot = b->totlen[i]; f.blow = low; }
+            unsigned char buf[16] = {0};
+            std::memcpy(buf, f.name.data(), std::min<size_t>(16, f.name.size()));
+            uint64_t h = 0, l = 0;
+            for (int q = 0; q < 8; ++q) { h = (h << 8) | buf[q]; l = (l << 8) | buf[8 + q]; }
+            nk[(size_t)k] = NameKey{h, l, (int32_t)k};
         }
+    });
+    std::sort(nk.begin(), nk.end(), [&](const NameKey& x, const NameKey& y) {
+        if (x.hi != y.hi) return x.hi < y.hi;
+        if (x.lo != y.lo) return x.lo < y.lo;
+        return recs[(size_t)x.idx].name < recs[(size_t)y.idx].name;
+    });
+    // merge equal names (ReadRec.cpp:356-373): runs of equal names in the sorted order; the runs are independent of each other
+    std::vector<size_t> run_start;
+    for (size_t k = 0; k < nr; ++k) {
+        const NameKey &x = nk[k];
+        if (k == 0 || x.hi != nk[k - 1].hi || x.lo != nk[k - 1].lo || recs[(size_t)x.idx].name != recs[(size_t)nk[k - 1].idx].name) run_start.push_back(k);
     }
+    run_start.push_back(nr);
+    const size_t nm = run_start.size() - 1;
+    std::vector<Frag> merged(nm);
     auto by_readpos = blk_less_readpos;
-    for (Frag& m : merged) {  // SortbyReadPos (ReadRec.cpp:143-146)
-        std::sort(m.a.begin(), m.a.end(), by_readpos);
-        std::sort(m.b.begin(), m.b.end(), by_readpos);
-    }
+    par((int64_t)nm, [&](int64_t lo, int64_t hi) {
+        for (int64_t j = lo; j < hi; ++j) {
+            Frag& m = merged[(size_t)j];
+            m = std::move(recs[(size_t)nk[run_start[(size_t)j]].idx]);
+            for (size_t k = run_start[(size_t)j] + 1; k < run_start[(size_t)j + 1]; ++k) {
+                Frag& r = recs[(size_t)nk[k].idx];
+                if (m.atot == 0 && r.atot != 0) { m.atot = r.atot; m.alow = r.alow; }
+                if (m.btot == 0 && r.btot != 0) { m.btot = r.btot; m.blow = r.blow; }
+                m.a.insert(m.a.end(), r.a.begin(), r.a.end());
+                m.b.insert(m.b.end(), r.b.begin(), r.b.end());
+            }
+            std::sort(m.a.begin(), m.a.end(), by_readpos);  // SortbyReadPos (ReadRec.cpp:143-146)
+            std::sort(m.b.begin(), m.b.end(), by_readpos);
+        }
+    });
     std::sort(sample.begin(), sample.end());
     c->read_len = sample[sample.size() / 2];  // ReadRec.cpp:378-379
-    // sort by front position (ReadRec.cpp:382)
-    idx.resize(merged.size());
-    for (size_t i = 0; i < idx.size(); ++i) idx[i] = (int)i;
-    std::sort(idx.begin(), idx.end(), [&](int x, int y) { return front_smaller(merged[x], merged[y]); });
+    // sort by front position (ReadRec.cpp:382; FrontSmallerThan is not a strict weak order, kept): again on small elements that
+    // carry everything the comparator looks at
+    struct FrontKey { Blk a, b; bool has_a, has_b; int32_t idx; };
+    std::vector<FrontKey> fk(nm);
+    par((int64_t)nm, [&](int64_t lo, int64_t hi) {
+        for (int64_t j = lo; j < hi; ++j) {
+            const Frag& m = merged[(size_t)j];
+            FrontKey k{};
+            k.has_a = !m.a.empty(); k.has_b = !m.b.empty(); k.idx = (int32_t)j;
+            if (k.has_a) k.a = m.a.front();
+            if (k.has_b) k.b = m.b.front();
+            fk[(size_t)j] = k;
+        }
+    });
+    std::sort(fk.begin(), fk.end(), [](const FrontKey& l, const FrontKey& r) {  // == front_smaller(merged[l.idx], merged[r.idx])
+        if (l.has_a && r.has_a) return blk_less_pos(l.a, r.a);
+        if (l.has_b && r.has_b) return blk_less_pos(l.b, r.b);
+        if (l.has_a && r.has_b) return blk_less_pos(l.a, r.b);
+        if (l.has_b && r.has_a) return blk_less_pos(l.b, r.a);
+        return false;
+    });
     // PCR duplicate removal (ReadRec.cpp:387-409)
     c->frags.clear();
     std::vector<Frag>& out = c->frags;
-    for (int id : idx) {
-        Frag& f = merged[id];
+    out.reserve(nm);
+    std::vector<uint8_t> kept(nm, 0);
+    for (const FrontKey& k : fk) {
+        Frag& f = merged[(size_t)k.idx];
         bool keep;
         if (out.empty()) keep = true;
         else if (f.a.empty() || out.back().a.empty()) keep = true;
         else if (f.a.front().refid != out.back().a.front().refid || f.a.front().refpos != out.back().a.front().refpos) keep = true;
         else {
             keep = true;
-            for (size_t k = out.size(); k-- > 0;) {
-                const Frag& g = out[k];
+            for (size_t q = out.size(); q-- > 0;) {
+                const Frag& g = out[q];
                 if (g.a.empty() || f.a.front().refid != g.a.front().refid || f.a.front().refpos != g.a.front().refpos) break;
                 if (frag_equal(f, g)) { keep = false; break; }
             }
         }
-        if (keep) out.push_back(std::move(f));
+        if (keep) { kept[(size_t)k.idx] = 1; out.push_back(std::move(f)); }
     }
-    // ChimName: Chimrecord.size() empty strings + every Qname, sorted unique (SegmentGraph.cpp:196-201, ledger B9)
+    // ChimName: Chimrecord.size() empty strings + every Qname, sorted unique (SegmentGraph.cpp:196-201, ledger B9).  `merged` is in name
+    // order and holds every name once, so the kept names in that order are already the sorted unique list (the names were moved into
+    // `out`: read them back through a map from merged index to output position)
     c->chim_names.clear();
-    if (!out.empty()) c->chim_names.push_back("");
-    for (const Frag& f : out) c->chim_names.push_back(f.name);
-    std::sort(c->chim_names.begin(), c->chim_names.end());
-    c->chim_names.erase(std::unique(c->chim_names.begin(), c->chim_names.end()), c->chim_names.end());
-    c->chim_set.clear();
-    c->chim_set.insert(c->chim_names.begin(), c->chim_names.end());
+    if (!out.empty()) {
+        std::vector<int32_t> where(nm, -1);
+        { int32_t o = 0; for (const FrontKey& k : fk) if (kept[(size_t)k.idx]) where[(size_t)k.idx] = o++; }
+        c->chim_names.reserve(out.size() + 1);
+        c->chim_names.push_back("");  // (sorts in front of everything; a fragment with an empty name falls together with it)
+        for (size_t j = 0; j < nm; ++j) if (where[j] >= 0 && !out[(size_t)where[j]].name.empty()) c->chim_names.push_back(out[(size_t)where[j]].name);
+    }
+    c->chim_set.clear();  // (only the host parser looks names up in a set: built there)
     c->counts.n_chimeric_records = b->n_rec;
     c->counts.n_chim_fragments = (int64_t)out.size();
     c->counts.read_len = c->read_len;

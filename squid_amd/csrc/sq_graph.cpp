@@ -98,49 +98,119 @@ static bool pair_overlap(const Frag& f, const std::vector<int>& rn, int i, int j
     return ov;
 }
 
+// ---- the fragment loops of RawEdgesChim / ExactBreakpoint on the context's host threads.
+// LocateRead carries its position from fragment to fragment (`firstfrontindex`, :1402-1403): the node of a fragment's first block is
+// where the search for the next fragment starts.  That matters only when a block fits more than one node; a first block that lies
+// deep inside a node (more than 5 bases from both ends) is located there from ANY start.  So the fragments are cut into pieces, and
+// the start of every piece is the node of the last such fragment in front of it, provided every fragment between that one and the
+// piece has a first block no node can take (then it leaves the position alone).  If a piece boundary cannot be settled that way the
+// whole loop runs on one thread -- same results either way.
+namespace {
+struct FirstFit { bool deep, none; int node; };
+inline FirstFit first_block_fit(const std::vector<Node>& N, const Frag& f) {
+    const Blk& b = !f.a.empty() ? f.a.front() : f.b.front();
+    const ChrRange cr = chr_range(N, b.refid);
+    const int end = b.refpos + b.matchref;
+    const int a = (int)(std::lower_bound(N.begin() + cr.lo, N.begin() + cr.hi, end - 5, [](const Node& x, int v) { return x.pos + x.len < v; }) - N.begin());
+    const int bb = (int)(std::upper_bound(N.begin() + cr.lo, N.begin() + cr.hi, b.refpos + 5, [](int v, const Node& x) { return v < x.pos; }) - N.begin()) - 1;
+    const bool any = a <= bb && a < cr.hi && bb >= cr.lo;
+    if (!any) return FirstFit{false, true, -1};
+    if (a == bb) { const Node& u = N[a]; if (b.refpos >= u.pos && end <= u.pos + u.len && end > u.pos + 5 && b.refpos < u.pos + u.len - 5) return FirstFit{true, false, a}; }
+    return FirstFit{false, false, -1};
+}
+// piece boundaries over the fragments `skip` does not drop, and the search start of every piece; false: run serially
+template <class Skip>
+bool plan_pieces(const sq_ctx* c, const std::vector<Node>& N, Skip skip, std::vector<size_t>& cut, std::vector<int>& start) {
+    const std::vector<Frag>& F = c->frags;
+    const int threads = c->pool ? c->pool->size() + 1 : 1;
+    const size_t want = (size_t)std::max(1, 4 * threads), n = F.size();
+    cut.assign(1, 0); start.assign(1, 0);
+    if (threads <= 1 || n < 20000) { cut.push_back(n); return true; }
+    for (size_t k = 1; k < want; ++k) {
+        const size_t at = n * k / want;
+        if (at <= cut.back()) continue;
+        int node = -1;
+        bool ok = false;
+        for (size_t q = at; q-- > 0 && at - q < 4096;) {  // backwards from the cut to the last fragment that pins the position
+            const Frag& f = F[q];
+            if (skip(f)) continue;
+            const FirstFit ff = first_block_fit(N, f);
+            if (ff.deep) { node = ff.node; ok = true; break; }
+            if (!ff.none) break;
+        }
+        if (!ok) return false;
+        cut.push_back(at); start.push_back(node);
+    }
+    cut.push_back(n);
+    return true;
+}
+}  // namespace
+
 // RawEdgesChim (:1394-1555).  Trims c->frags in place, like the reference trims Chimrecord.
 int chimeric_edges(sq_ctx* c, std::vector<Edge>& raw) {
     const std::vector<Node>& N = c->nodes;
     const int n = (int)N.size();
-    int hint = 0;
-    std::map<uint64_t, int> discordant;  // key -> number of supporting junctions (Weight, :1551)
-    std::vector<int> rn;
-    for (Frag& f : c->frags) {
-        if (f.a.empty() && f.b.empty()) continue;
-        locate_fragment(N, hint, f, rn);
-        if (rn[0] != -1) hint = rn[0];
-        const int na = (int)f.a.size();
-        for (int k = 0; k < (int)rn.size(); ++k)
-            if (rn[k] == -1) {
-                const Blk& b = k < na ? f.a[k] : f.b[k - na];
-                int i = home_node(N, hint, b);
-                if (i < 0 || i + 1 >= n) return fail(c, SQ_E_ASSERT, "chimeric block outside the node table (reference: out-of-range edge, SegmentGraph.cpp:1410)");
-                raw.push_back(make_edge(i, false, i + 1, true));
-            }
-        auto split = [&](const std::vector<Blk>& R, int base) {
-            for (int k = 0; k + 1 < (int)R.size(); ++k) {
-                int i = rn[base + k], j = rn[base + k + 1];
-                if (i == j || i == -1 || j == -1) continue;
-                Edge e = make_edge(i, R[k].rev, j, !R[k + 1].rev);
-                if (!edge_discordant(c, N, e)) raw.push_back(e);
-                else discordant[edge_pack(e)]++;
-            }
-        };
-        split(f.a, 0);
-        split(f.b, na);
-        if (!f.a.empty() && !f.b.empty() && !frag_end_discordant(f, true) && !frag_end_discordant(f, false)) {
-            int i = rn[na - 1], j = rn.back();
-            if (i != j && i != -1 && j != -1 && !pair_overlap(f, rn, i, j)) {
-                Edge e = make_edge(i, f.a.back().rev, j, f.b.back().rev);
-                if (!edge_discordant(c, N, e)) raw.push_back(e);
-                else if (frag_pair_discordant(f, false)) discordant[edge_pack(e)]++;
+    auto skip = [](const Frag& f) { return f.a.empty() && f.b.empty(); };
+    std::vector<size_t> cut;
+    std::vector<int> start;
+    if (!plan_pieces(c, N, skip, cut, start)) { cut = {0, c->frags.size()}; start = {0}; }
+    const int np = (int)cut.size() - 1;
+    struct Piece { std::vector<Edge> raw; std::vector<uint64_t> disc; bool bad = false; };
+    std::vector<Piece> out((size_t)np);
+    auto run = [&](int pi) {
+        Piece& P = out[(size_t)pi];
+        int hint = start[(size_t)pi];
+        std::vector<int> rn;
+        for (size_t fi = cut[(size_t)pi]; fi < cut[(size_t)pi + 1]; ++fi) {
+            Frag& f = c->frags[fi];
+            if (skip(f)) continue;
+            locate_fragment(N, hint, f, rn);
+            if (rn[0] != -1) hint = rn[0];
+            const int na = (int)f.a.size();
+            for (int k = 0; k < (int)rn.size(); ++k)
+                if (rn[k] == -1) {
+                    const Blk& b = k < na ? f.a[k] : f.b[k - na];
+                    int i = home_node(N, hint, b);
+                    if (i < 0 || i + 1 >= n) { P.bad = true; return; }
+                    P.raw.push_back(make_edge(i, false, i + 1, true));
+                }
+            auto split = [&](const std::vector<Blk>& R, int base) {
+                for (int k = 0; k + 1 < (int)R.size(); ++k) {
+                    int i = rn[base + k], j = rn[base + k + 1];
+                    if (i == j || i == -1 || j == -1) continue;
+                    Edge e = make_edge(i, R[k].rev, j, !R[k + 1].rev);
+                    if (!edge_discordant(c, N, e)) P.raw.push_back(e);
+                    else P.disc.push_back(edge_pack(e));
+                }
+            };
+            split(f.a, 0);
+            split(f.b, na);
+            if (!f.a.empty() && !f.b.empty() && !frag_end_discordant(f, true) && !frag_end_discordant(f, false)) {
+                int i = rn[na - 1], j = rn.back();
+                if (i != j && i != -1 && j != -1 && !pair_overlap(f, rn, i, j)) {
+                    Edge e = make_edge(i, f.a.back().rev, j, f.b.back().rev);
+                    if (!edge_discordant(c, N, e)) P.raw.push_back(e);
+                    else if (frag_pair_discordant(f, false)) P.disc.push_back(edge_pack(e));
+                }
             }
         }
+    };
+    if (np > 1 && c->pool) c->pool->parallel_for(np, 15, [&](int pi) { run(pi); }); else for (int pi = 0; pi < np; ++pi) run(pi);
+    std::vector<uint64_t> disc;
+    for (Piece& P : out) {
+        if (P.bad) return fail(c, SQ_E_ASSERT, "chimeric block outside the node table (reference: out-of-range edge, SegmentGraph.cpp:1410)");
+        raw.insert(raw.end(), P.raw.begin(), P.raw.end());
+        disc.insert(disc.end(), P.disc.begin(), P.disc.end());
     }
-    for (auto& kv : discordant) {  // map order = Edge_t order; the later sort makes the order irrelevant anyway
+    // discordant edges: one raw edge per key, Weight = number of supporting junctions (:1551); the later sort makes the order irrelevant
+    std::sort(disc.begin(), disc.end());
+    for (size_t i = 0; i < disc.size();) {
+        size_t j = i;
+        while (j < disc.size() && disc[j] == disc[i]) ++j;
         Edge e;
-        e.a = (int32_t)(kv.first >> 32); e.b = (int32_t)((kv.first & 0xffffffffull) >> 2); e.ha = (kv.first >> 1) & 1; e.hb = kv.first & 1; e.w = kv.second; e.gw = 0;
+        e.a = (int32_t)(disc[i] >> 32); e.b = (int32_t)((disc[i] & 0xffffffffull) >> 2); e.ha = (disc[i] >> 1) & 1; e.hb = disc[i] & 1; e.w = (int32_t)(j - i); e.gw = 0;
         raw.push_back(e);
+        i = j;
     }
     return SQ_OK;
 }
@@ -563,25 +633,56 @@ static void count_top(const Edge& e, std::vector<std::pair<int, int>>& x) {
 int exact_breakpoints(sq_ctx* c, BPMap& bp) {
     bp.clear();
     const std::vector<Node>& N = c->nodes;
-    int hint = 0;
-    std::vector<int> rn;
-    std::map<uint64_t, Edge> keyedge;
-    for (Frag& f : c->frags) {
-        if (f.a.size() <= 1 && f.b.size() <= 1) continue;
-        locate_fragment(N, hint, f, rn);
-        if (rn[0] != -1) hint = rn[0];
-        auto collect = [&](const std::vector<Blk>& R, int base) {
-            for (int k = 0; k + 1 < (int)R.size(); ++k) {
-                int i = rn[base + k], j = rn[base + k + 1];
-                if (i == j || i == -1 || j == -1) continue;
-                Edge e = make_edge(i, R[k].rev, j, !R[k + 1].rev);
-                if (edge_discordant(c, N, e)) { bp[edge_pack(e)].push_back(split_breakpoints(R[k], R[k + 1])); keyedge[edge_pack(e)] = e; }
-            }
-        };
-        collect(f.a, 0);
-        collect(f.b, (int)f.a.size());
-    }
-    for (auto& kv : bp) count_top(keyedge[kv.first], kv.second);
+    auto skip = [](const Frag& f) { return f.a.size() <= 1 && f.b.size() <= 1; };
+    std::vector<size_t> cut;
+    std::vector<int> start;
+    if (!plan_pieces(c, N, skip, cut, start)) { cut = {0, c->frags.size()}; start = {0}; }
+    const int np = (int)cut.size() - 1;
+    struct Hit { uint64_t key; int b1, b2; };
+    std::vector<std::vector<Hit>> out((size_t)np);
+    auto run = [&](int pi) {
+        std::vector<Hit>& H = out[(size_t)pi];
+        int hint = start[(size_t)pi];
+        std::vector<int> rn;
+        for (size_t fi = cut[(size_t)pi]; fi < cut[(size_t)pi + 1]; ++fi) {
+            Frag& f = c->frags[fi];
+            if (skip(f)) continue;
+            locate_fragment(N, hint, f, rn);
+            if (rn[0] != -1) hint = rn[0];
+            auto collect = [&](const std::vector<Blk>& R, int base) {
+                for (int k = 0; k + 1 < (int)R.size(); ++k) {
+                    int i = rn[base + k], j = rn[base + k + 1];
+                    if (i == j || i == -1 || j == -1) continue;
+                    Edge e = make_edge(i, R[k].rev, j, !R[k + 1].rev);
+                    if (edge_discordant(c, N, e)) { const std::pair<int, int> q = split_breakpoints(R[k], R[k + 1]); H.push_back(Hit{edge_pack(e), q.first, q.second}); }
+                }
+            };
+            collect(f.a, 0);
+            collect(f.b, (int)f.a.size());
+        }
+    };
+    if (np > 1 && c->pool) c->pool->parallel_for(np, 15, [&](int pi) { run(pi); }); else for (int pi = 0; pi < np; ++pi) run(pi);
+    std::vector<Hit> all;
+    for (auto& H : out) all.insert(all.end(), H.begin(), H.end());
+    std::sort(all.begin(), all.end(), [](const Hit& x, const Hit& y) { return x.key != y.key ? x.key < y.key : (x.b1 != y.b1 ? x.b1 < y.b1 : x.b2 < y.b2); });  // (count_top sorts the pairs anyway)
+    std::vector<size_t> grp;
+    for (size_t i = 0; i < all.size(); ++i) if (i == 0 || all[i].key != all[i - 1].key) grp.push_back(i);
+    grp.push_back(all.size());
+    const int ng = (int)grp.size() - 1;
+    std::vector<std::vector<std::pair<int, int>>> lists((size_t)ng);
+    auto top = [&](int g) {
+        std::vector<std::pair<int, int>>& x = lists[(size_t)g];
+        for (size_t i = grp[(size_t)g]; i < grp[(size_t)g + 1]; ++i) x.push_back(std::make_pair(all[i].b1, all[i].b2));
+        const uint64_t key = all[grp[(size_t)g]].key;
+        Edge e;
+        e.a = (int32_t)(key >> 32); e.b = (int32_t)((key & 0xffffffffull) >> 2); e.ha = (key >> 1) & 1; e.hb = key & 1; e.w = 1; e.gw = 0;
+        count_top(e, x);
+    };
+    if (ng > 256 && c->pool) {
+        const int pieces = std::min(ng, 8 * (c->pool->size() + 1));
+        c->pool->parallel_for(pieces, 15, [&](int k) { for (int g = (int)((int64_t)ng * k / pieces); g < (int)((int64_t)ng * (k + 1) / pieces); ++g) top(g); });
+    } else for (int g = 0; g < ng; ++g) top(g);
+    for (int g = 0; g < ng; ++g) bp.emplace_hint(bp.end(), all[grp[(size_t)g]].key, std::move(lists[(size_t)g]));
     return SQ_OK;
 }
 

@@ -395,7 +395,18 @@ double segment_clusters(const sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::ve
     // ---- discordant blocks and clip positions of the chimeric fragments (SegmentGraph.cpp:203-264)
     S.part.assign(c->ref_len.size(), std::make_pair(0, 0));  // ledger B10
     std::vector<Blk>& D = S.D;
-    for (const Frag& f : c->frags) {
+    // (the fragments are independent of each other here, except for one look at the last discordant block collected so far -- ledger
+    // B11 -- : pieces of the list are worked on by the context's host threads, each with its own output, and strung together in order;
+    // a piece that needs that block before it has collected one of its own asks for a second, serial visit)
+    struct Out { std::vector<Blk> D; std::vector<std::pair<int, int>> part; std::vector<std::pair<size_t, Blk>> ask; /* (position in part, block to compare with the last discordant block) */ };
+    const size_t nf = c->frags.size();
+    const int pieces = (c->pool && nf > 20000) ? 4 * (c->pool->size() + 1) : 1;
+    std::vector<Out> outs((size_t)pieces);
+    auto work = [&](int pi) {
+        Out& O = outs[(size_t)pi];
+        std::vector<Blk>& D = O.D;
+        for (size_t fi = nf * (size_t)pi / (size_t)pieces; fi < nf * ((size_t)pi + 1) / (size_t)pieces; ++fi) {
+        const Frag& f = c->frags[fi];
         if (frag_end_discordant(f, true) || frag_end_discordant(f, false) || frag_single_anchored(f) || frag_pair_discordant(f, true)) {
             D.insert(D.end(), f.a.begin(), f.a.end());
             D.insert(D.end(), f.b.begin(), f.b.end());
@@ -420,21 +431,42 @@ double segment_clusters(const sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::ve
         }
         if (!ains && !bins) {
             auto clip = [&](const Blk& b, bool leftEnd) { return std::make_pair(b.refid, (leftEnd == b.rev) ? b.refpos + b.matchref : b.refpos); };
-            if (!f.a.empty() && f.a.front().readpos > 15 && !f.alow) S.part.push_back(clip(f.a.front(), true));
-            if (!f.a.empty() && f.atot - f.a.back().readpos - f.a.back().matchread > 15 && !f.alow) S.part.push_back(clip(f.a.back(), false));
-            if (!f.b.empty() && f.b.front().readpos > 15 && !f.blow) S.part.push_back(clip(f.b.front(), true));
+            if (!f.a.empty() && f.a.front().readpos > 15 && !f.alow) O.part.push_back(clip(f.a.front(), true));
+            if (!f.a.empty() && f.atot - f.a.back().readpos - f.a.back().matchread > 15 && !f.alow) O.part.push_back(clip(f.a.back(), false));
+            if (!f.b.empty() && f.b.front().readpos > 15 && !f.blow) O.part.push_back(clip(f.b.front(), true));
             if (!f.b.empty() && f.btot - f.b.back().readpos - f.b.back().matchread > 15 && !f.blow) {
-                // ledger B11: compared with bamdiscordant.back() even when that vector is empty (zero block here)
-                Blk z{0, 0, 0, 0, 0, false, false};
-                const Blk& l = D.empty() ? z : D.back();
+                // ledger B11: compared with bamdiscordant.back() even when that vector is empty (zero block there)
                 const Blk& s = f.b.back();
-                const bool same = blk_same(l, s);
-                if (!same) S.part.push_back(clip(s, false));
+                if (D.empty()) { O.ask.push_back(std::make_pair(O.part.size(), s)); O.part.push_back(clip(s, false)); }  // (settled below, once the pieces in front are known)
+                else if (!blk_same(D.back(), s)) O.part.push_back(clip(s, false));
             }
         }
+        }
+    };
+    if (pieces > 1) c->pool->parallel_for(pieces, 15, work); else work(0);
+    for (Out& O : outs) {
+        // the entries that were waiting for the last discordant block of the pieces in front: drop those that are the `Same` block
+        std::vector<char> drop(O.part.size(), 0);
+        for (const auto& q : O.ask) {
+            Blk z{0, 0, 0, 0, 0, false, false};
+            const Blk& l = D.empty() ? z : D.back();
+            if (blk_same(l, q.second)) drop[q.first] = 1;
+        }
+        for (size_t i = 0; i < O.part.size(); ++i) if (!drop[i]) S.part.push_back(O.part[i]);
+        D.insert(D.end(), O.D.begin(), O.D.end());
     }
     std::sort(S.part.begin(), S.part.end());
-    std::sort(D.begin(), D.end(), blk_less_pos);  // ledger B8
+    {   // ledger B8: operator< looks at (RefID, RefPos) only and the sort is not stable.  Sorting 12-byte (key, index) elements with the
+        // same comparison takes libstdc++'s introsort through the same decisions, hence to the same permutation, at a fraction of
+        // the memory traffic of sorting the blocks themselves
+        struct PK { int32_t refid, refpos, idx; };
+        std::vector<PK> pk(D.size());
+        for (size_t i = 0; i < D.size(); ++i) pk[i] = PK{D[i].refid, D[i].refpos, (int32_t)i};
+        std::sort(pk.begin(), pk.end(), [](const PK& x, const PK& y) { return x.refid != y.refid ? x.refid < y.refid : x.refpos < y.refpos; });
+        std::vector<Blk> sorted(D.size());
+        for (size_t i = 0; i < D.size(); ++i) sorted[i] = D[(size_t)pk[i].idx];
+        D.swap(sorted);
+    }
     S.nd = (int)D.size();
     disc_sorted = D;
     D.push_back(Blk{0, 0, 0, 0, 0, false, false});  // ledger B21 sentinel

@@ -263,6 +263,7 @@ int main(int argc, char** argv) {
     long records = -1;
     int ntsv = -1, level = 6, threads = 4, genes_override = -1;
     double chim_copy_frac = 0.2;
+    bool small_cc = false;  // config C5: compact genes, junctions in the last exon (see below)
     double indel_frac = 0.0;  // fraction of concordant pairs whose left read gets an I / D / =X CIGAR variant (off by default: C1..C5 unchanged)
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -283,11 +284,17 @@ int main(int argc, char** argv) {
     int cfgno = 1;
     if (config == "C1") { contigs = {{"chr1", 10000000}}; if (records < 0) records = 20000; if (ntsv < 0) ntsv = 5; cfgno = 1; }
     else if (config == "C2") { contigs = {{"chr17", 83257441}}; if (records < 0) records = 1000000; if (ntsv < 0) ntsv = 20; cfgno = 2; }
-    else if (config == "C3" || config == "C4" || config == "C5") {
+    else if (config == "C3" || config == "C4" || config == "C5" || config == "C5g") {
+        // C5 = BASELINE.json configs[4]: >= 1e5 small components (every junction sits in the LAST exon of both of its genes, so no
+        // concordant read crosses from a junction's segments into the next gene: components stay below 20 nodes even with -w 1 -a 50);
+        // C5g = the round-2 shape of that config (junctions at inner exons: the segments chain into one giant component)
+        const bool giant = config == "C5g";
+        if (giant) config = "C5";
+        small_cc = config == "C5" && !giant;
         contigs.assign(kHg38, kHg38 + 25);
         cfgno = config[1] - '0';
         if (records < 0) records = config == "C3" ? 50000000 : (config == "C4" ? 200000000 : 100000000);
-        if (ntsv < 0) ntsv = config == "C5" ? 100000 : 200;
+        if (ntsv < 0) ntsv = config == "C5" ? (giant ? 100000 : 110000) : 200;
     } else if (config == "T2") {  // two small contigs: inter-chromosomal test case
         contigs = {{"chrA", 3000000}, {"chrB", 2000000}, {"chrC", 50000}};
         if (records < 0) records = 30000; if (ntsv < 0) ntsv = 8; cfgno = 7;
@@ -303,7 +310,7 @@ int main(int argc, char** argv) {
     std::vector<Gene> genes;
     for (size_t c = 0; c < contigs.size(); ++c) {
         int n = (int)((double)ngenes * contigs[c].len / total_len + 0.5);
-        const int span = 45000;  // max island extent incl. margin
+        const int span = small_cc ? 12000 : 45000;  // max island extent incl. margin
         int maxn = contigs[c].len / span - 1;
         if (n > maxn) n = std::max(0, maxn);
         if (contigs[c].len < 2 * span) n = 0;
@@ -314,14 +321,14 @@ int main(int argc, char** argv) {
             int start = (int)(slot + 1000 + (slotw > span ? rng.next() % (uint64_t)(slotw - span + 1) : 0));
             Gene g;
             g.chr = (int)c;
-            int nex = rng.range(3, 8), p = start;
+            int nex = small_cc ? rng.range(3, 5) : rng.range(3, 8), p = start;
             g.cum.push_back(0);
             for (int e = 0; e < nex; ++e) {
-                int el = rng.range(100, 300);
+                int el = small_cc && e == nex - 1 ? rng.range(450, 600) : rng.range(100, 300);
                 g.es.push_back(p);
                 g.ee.push_back(p + el);
                 g.cum.push_back(g.cum.back() + el);
-                p += el + rng.range(500, 5000);
+                p += el + (small_cc ? rng.range(500, 2000) : rng.range(500, 5000));
             }
             g.weight = std::exp(rng.normal());
             genes.push_back(g);
@@ -347,10 +354,10 @@ int main(int argc, char** argv) {
             const Gene& gy = genes[v.gy];
             // tail side: breakpoint at an exon end leaving >=1 exon upstream; head: exon start
             int nx = (int)gx.es.size(), ny = (int)gy.es.size();
-            if (!v.xhead) { v.ex = rng.range(1, nx - 2); v.bpx = gx.ee[v.ex]; v.txx = gx.cum[v.ex + 1]; }
-            else { v.ex = rng.range(1, nx - 2); v.bpx = gx.es[v.ex]; v.txx = gx.cum[v.ex]; }
-            if (v.yhead) { v.ey = rng.range(1, ny - 2); v.bpy = gy.es[v.ey]; v.txy = gy.cum[v.ey]; }
-            else { v.ey = rng.range(1, ny - 2); v.bpy = gy.ee[v.ey]; v.txy = gy.cum[v.ey + 1]; }
+            if (!v.xhead) { v.ex = small_cc ? nx - 1 : rng.range(1, nx - 2); v.bpx = gx.ee[v.ex]; v.txx = gx.cum[v.ex + 1]; }
+            else { v.ex = small_cc ? nx - 1 : rng.range(1, nx - 2); v.bpx = gx.es[v.ex]; v.txx = gx.cum[v.ex]; }
+            if (v.yhead) { v.ey = small_cc ? ny - 1 : rng.range(1, ny - 2); v.bpy = gy.es[v.ey]; v.txy = gy.cum[v.ey]; }
+            else { v.ey = small_cc ? ny - 1 : rng.range(1, ny - 2); v.bpy = gy.ee[v.ey]; v.txy = gy.cum[v.ey + 1]; }
             int sup = rng.range(10, 60);
             v.nsplit = sup / 2;
             v.npair = sup - v.nsplit;

@@ -430,7 +430,7 @@ def test_dense_graph_config_with_a_giant_component(built, synth, tmp_path, monke
     """BASELINE.json configs[4] flags (-w 1 -a 50) on a small dense sample: one component of ~2000 nodes that the
     min-cut recursion splits ~300 times (bridge tree + small-to-large join in the product), the rest small"""
     monkeypatch.delenv("SQUID_EXACT_DEPTH", raising=False)
-    pre = synth("C5", "--records", "200000", "--tsv", "400")
+    pre = synth("C5g", "--records", "200000", "--tsv", "400")
     sv_path, dump = ou.run_oracle(built, pre, tmp_path, "-w", "1", "-a", "50")
     stats = dict(line.split("\t") for line in (dump / "order_stats.txt").read_text().splitlines())
     assert int(stats["mincut_splits"]) > 100
@@ -461,7 +461,7 @@ def test_device_filters_equal_the_host_restatements(built, synth, tmp_path):
             "kw = json.loads(sys.argv[3])\n"
             "ctx = squid_amd.Context(**kw); ctx.load(sys.argv[1], sys.argv[2]); ctx.build_graph()\n"
             "print(json.dumps([[ctx.graph(k) for k in (3, 4, 5, 0)], ctx.order(), ctx.sv_text(), sorted(ctx.timing())]))") % str(Path(__file__).resolve().parent.parent)
-    for cfg, extra, kw in (("T2", [], {}), ("C5", ["--records", "200000", "--tsv", "400"], {"min_edge_weight": 1, "max_allowed_degree": 50})):
+    for cfg, extra, kw in (("T2", [], {}), ("C5g", ["--records", "200000", "--tsv", "400"], {"min_edge_weight": 1, "max_allowed_degree": 50})):
         pre = synth(cfg, *extra)
         res = {}
         for mode in ("gpu", "host"):
@@ -927,7 +927,7 @@ def test_both_files_in_one_call_equal_the_two_calls_and_report_errors(built, syn
 def test_edge_stage_pass_one_clears_only_records_that_emit_nothing(built, synth, monkeypatch):
     """k_edges_near drops the records whose blocks and mate stub all sit in the home node of block 0; with SQUID_EDGES_ALL every
     participating record goes through the full rule set of k_edges instead -- same raw edge count, same edges, same calls"""
-    for cfg, extra, kw in (("T2", [], {}), ("C2", [], {}), ("C5", ["--records", "200000", "--tsv", "400"], {"min_edge_weight": 1, "max_allowed_degree": 50})):
+    for cfg, extra, kw in (("T2", [], {}), ("C2", [], {}), ("C5g", ["--records", "200000", "--tsv", "400"], {"min_edge_weight": 1, "max_allowed_degree": 50})):
         pre = synth(cfg, *extra)
         got = {}
         for mode in ("near", "all"):

@@ -138,7 +138,7 @@ def test_linear_time_bridge_search_agrees_with_the_brute_force(built, synth, tmp
     splits of a ~2000-node component)"""
     import subprocess
 
-    pre = synth("C5", "--records", "200000", "--tsv", "400")
+    pre = synth("C5g", "--records", "200000", "--tsv", "400")
     monkeypatch.setenv("ORACLE_BRIDGE_CHECK", "1")
     out = tmp_path / "chk"
     subprocess.check_call([str(built / "squid_oracle"), "-b", f"{pre}.bam", "-c", f"{pre}.chim.bam", "-o", str(out), "-w", "1", "-a", "50"], stdout=subprocess.DEVNULL)
