@@ -4,18 +4,26 @@
 One "step" = ONE whole run of the hot path on one synthetic sample: chimeric BAM decode (host), concordant BAM
 decode on the GPU (BGZF inflate -> record boundaries -> record parse = the reference's three BamReader passes,
 SegmentGraph.cpp:293-296,1570-1577,3126-3129, done once), record filters -> segmentation -> edges -> filters ->
-compression -> components -> ordering -> breakpoints -> support -> `_sv.txt` written and closed.  Nothing is kept
-from step to step except device buffers (sq_clear_records).
+compression -> components -> ordering -> breakpoints -> support -> `_sv.txt` written and closed.  Records, graph and
+results are dropped between steps (sq_clear_records); device buffers, the staged compressed bytes, the mapping of the
+file and its BGZF block index stay.
 
 Workload: BASELINE.json configs[2] -- "Full hg38, 50M-read synthetic STAR concordant+chimeric BAM, 1xMI355X" --
 generator config C3 (50.8 M concordant records, zlib level 6), the largest single-GPU configuration.
-`value` = alignments/s with the compressed BAM bytes resident in HBM when the timed region starts (sq_stage_bam);
-`from_file_value` = the same step reading the BAM from the page cache (host->device copy of the file included), measured
-after the timed region in a fresh context.
-`resident_pass_value` = the graph pass alone over records already decoded in HBM (what round 1 reported).
+`--workload C5` = configs[4], the dense-graph stress (-w 1 -a 50, >= 1e5 small components): reports components/s.
+
+  value            alignments/s with the COMPRESSED BAM BYTES STAGED IN HBM when the timed region starts (sq_stage_bam)
+  from_file_value  the same step from the file in the page cache, the mapping / block index dropped before every step
+                   (sq_drop_file_cache): page-table fill, BGZF header walk and host->device copy inside the step
+  cold_cli         ONE fresh `build/squid -b -c -o` process (wall clock from exec to exit, page cache warm, nothing staged)
+  resident_pass    the graph pass alone over records already decoded in HBM
+  roofline         SURVEY.md 8(d): N_c * (80 + 24 b) algorithmic bytes / summed time of the record-streaming kernels of one
+                   pass / 8 TB/s; the per-kernel table sits beside it
+  cpu_baseline     the CPU oracle (a port of the reference, 1 core, pinned) on THE BENCH'S OWN BAM files; its _sv.txt is
+                   compared with the timed steps' (`--cpu-sample-records N` times it on a smaller sample instead)
 
 N > 1 (`--gpus N`; the script launches its own ranks through torch.distributed.run when WORLD_SIZE is not set):
-ONE C3 sample sharded by chromosome (BASELINE.json configs[3] layout), rank r decodes and holds the records of a
+ONE sample sharded by chromosome (BASELINE.json configs[3] layout), rank r decodes and holds the records of a
 contiguous RefID range, the library's exchanges travel as RCCL all-gathers; "scaling": "strong".
 `--shard sample` instead runs one independent sample per rank (no collective, weak scaling).
 
@@ -24,6 +32,7 @@ Prints ONE JSON line on rank 0.
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import shutil
@@ -39,22 +48,29 @@ sys.path.insert(0, str(ROOT))
 BUILD = ROOT / "build"
 
 GPU_KERNELS_PREFIX = ("k_", "scan_")
-INGEST_KERNELS = ("k_inflate_tokens", "k_lz_resolve", "k_rec_boundaries", "k_parse_count", "k_parse_write", "k_inflate")
+# timers of the BGZF reader, named like the kernels they bracket (profiles/*_kernel_stats.csv carries the same names)
+INGEST_KERNELS = ("k_inflate_tok2", "k_lz_resolve2", "k_rec_sync+walk+check", "k_parse_count", "k_parse_write", "k_inflate")
+SMALL_GRAPH_KERNELS = ("k_filter_weight", "k_filter_interleave", "k_filter_edges", "k_compress_nodes", "k_further_compress", "k_order_small", "k_order_mid", "k_cc", "k_hash_compact",
+                       "k_node_buckets", "k_bp_walk")
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
 WORKLOADS = {
     "C2": "hg38 chr17 only, 1M synthetic paired-end records, 20 planted fusions (BASELINE.json configs[1])",
     "C3": "full hg38, 50M-record synthetic STAR concordant+chimeric BAM, 200 planted TSVs, zlib level 6 (BASELINE.json configs[2])",
-    "C5": "dense-graph stress (-w 1 -a 50) (BASELINE.json configs[4])",
+    "C5": "dense-graph stress (-w 1 -a 50): full hg38, 100M records, >= 1e5 planted TSVs in >= 1e5 small components (BASELINE.json configs[4])",
+    "C5g": "dense-graph stress (-w 1 -a 50), round-2 shape: junctions at inner exons, the segments chain into one giant component",
 }
+DENSE = {"min_edge_weight": 1, "max_allowed_degree": 50}  # -w 1 -a 50
 
 
-def synth(config: str, seed: int, outdir: Path, records: int | None = None, level: int | None = None) -> Path:
-    pre = outdir / (f"{config}_s{seed}" + (f"_r{records}" if records else "") + (f"_l{level}" if level is not None else ""))
+def synth(config: str, seed: int, outdir: Path, records: int | None = None, level: int | None = None, tsv: int | None = None) -> Path:
+    pre = outdir / (f"{config}_s{seed}" + (f"_r{records}" if records else "") + (f"_t{tsv}" if tsv else "") + (f"_l{level}" if level is not None else ""))
     if not Path(f"{pre}.bam").exists():
         tmp = Path(f"{pre}.tmp{os.getpid()}")
         cmd = [str(BUILD / "gen_synth_bam"), "--config", config, "--seed", str(seed), "--out", str(tmp), "--threads", str(max(1, os.cpu_count() or 8))]
         if records:
             cmd += ["--records", str(records)]
+        if tsv:
+            cmd += ["--tsv", str(tsv)]
         if level is not None:
             cmd += ["--level", str(level)]
         subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
@@ -99,11 +115,13 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="C3", help="generator config (C3 = BASELINE.json configs[2], the largest single-GPU configuration)")
+    ap.add_argument("--workload", default="C3", help="generator config (C3 = BASELINE.json configs[2], the largest single-GPU configuration; C5 = configs[4])")
     ap.add_argument("--records", type=int, default=None, help="override the record count of the workload (generator --records)")
+    ap.add_argument("--tsv", type=int, default=None, help="override the number of planted junctions (generator --tsv)")
     ap.add_argument("--shard", choices=["sample", "chromosome"], default="chromosome", help="what the ranks of a multi-GPU run divide (see the module docstring)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-records", type=int, default=5_000_000, help="records of the bounded sample the CPU oracle is timed on")
+    ap.add_argument("--no-cold-cli", action="store_true")
+    ap.add_argument("--cpu-sample-records", type=int, default=0, help="time the CPU oracle on a sample of this many records instead of the bench's own BAM (0 = the bench's BAM)")
     ap.add_argument("--resident-steps", type=int, default=5, help="extra (untimed for `value`) graph passes over resident records, for the per-kernel roofline figures")
     ap.add_argument("--workdir", default=None)
     a = ap.parse_args()
@@ -131,6 +149,9 @@ def main() -> None:
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
     sharded = a.shard == "chromosome" and world > 1
+    dense = a.workload.startswith("C5")
+    params = dict(DENSE) if dense else {}
+    cli_flags = ["-w", "1", "-a", "50"] if dense else []
 
     import squid_amd
 
@@ -143,14 +164,14 @@ def main() -> None:
     work = Path(a.workdir) if a.workdir else Path(tempfile.gettempdir()) / "squid_bench"
     work.mkdir(parents=True, exist_ok=True)
     srank = 0 if sharded else rank  # a sharded run works on ONE sample
-    cfgnum = int(a.workload[1:]) if a.workload[1:].isdigit() else 7
+    cfgnum = int(a.workload[1:2]) if a.workload[1:2].isdigit() else 7
     seed = 20180000 + cfgnum + 1000 * srank  # rank 0 = the generator's default seed for that config
     t_gen0 = time.perf_counter()
     if sharded:
         if rank == 0:
-            synth(a.workload, seed, work, a.records)
+            synth(a.workload, seed, work, a.records, tsv=a.tsv)
         dist.barrier()
-    pre = synth(a.workload, seed, work, a.records)
+    pre = synth(a.workload, seed, work, a.records, tsv=a.tsv)
     t_gen = time.perf_counter() - t_gen0
     bam, chim = f"{pre}.bam", f"{pre}.chim.bam"
 
@@ -162,21 +183,27 @@ def main() -> None:
 
     exchange, plan = None, None
     host_threads = max(1, (os.cpu_count() or 8) // max(1, world))
+
+    def new_context():
+        if sharded:
+            return squid_amd.Context(device=local_rank, rank=rank, world_size=world, exchange=exchange, **params)
+        return squid_amd.Context(device=local_rank, **params)
+
     if sharded:
         from squid_amd.dist import TorchExchange, plan_shards, shard_weights
 
         _, ref_len = squid_amd.read_header(bam)
         plan = plan_shards(shard_weights(bam, ref_len), world)  # balanced by compressed bytes per chromosome (from the .bai), else by reference length
         exchange = TorchExchange(dist, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        ctx = squid_amd.Context(device=local_rank, rank=rank, world_size=world, exchange=exchange)
-    else:
-        ctx = squid_amd.Context(device=local_rank)
+    ctx = new_context()
     sv_path = work / f"bench_rank{rank}_sv.txt"
+    comp_sizes = None
 
     def graph_pass() -> str:
+        nonlocal comp_sizes
         ctx.build_graph()
-        ctx.order()
-        text = ctx.sv_text()
+        comp_sizes = ctx.order_sizes()
+        text = ctx.sv_text_fast()
         if rank == 0 or not sharded:
             with open(sv_path, "w") as f:
                 f.write(text)
@@ -193,14 +220,19 @@ def main() -> None:
         step()
     barrier()
     ctx.timing_accumulate(True)  # the library sums its HIP-event / host timers over the timed steps; read once afterwards
+    digests = []
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        text = step()
+        digests.append(hashlib.sha256(step().encode()).hexdigest())
     barrier()
     elapsed = time.perf_counter() - t0
+    text = sv_path.read_text() if (rank == 0 or not sharded) else ""
+    if len(set(digests)) != 1:
+        raise SystemExit(f"the timed steps wrote different _sv.txt files: {sorted(set(digests))}")
     e2e: dict[str, dict] = {k: dict(v) for k, v in ctx.timing().items()}
-    n_aln = ctx.counts()["n_concordant"] + (ctx.counts()["n_chimeric_records"] if (not sharded or rank == 0) else 0)
-    n_conc, n_blk = ctx.counts()["n_concordant"], ctx.counts()["n_blocks"]
+    counts = ctx.counts()
+    n_aln = counts["n_concordant"] + (counts["n_chimeric_records"] if (not sharded or rank == 0) else 0)
+    n_conc, n_blk = counts["n_concordant"], counts["n_blocks"]
 
     # ---- graph pass alone over the resident records: per-kernel figures for the roofline
     ctx.timing_accumulate(True)
@@ -213,19 +245,24 @@ def main() -> None:
     t_res = (time.perf_counter() - t0) / max(1, a.resident_steps)
     agg: dict[str, dict] = {k: dict(v) for k, v in ctx.timing().items()}
 
-    # ---- the same step from the files in the page cache (host -> device copy of the compressed bytes inside the step), in a
-    # fresh context and AFTER the timed region: a context that has copied the mapped file to the device runs its later
-    # ingests ~20 ms slower (measured; tools/bench_step_parts.py), which is not what `value` is defined on
+    # ---- the same step from the file in the page cache, nothing kept from earlier reads: the mapping and the block index are dropped
+    # before every step (page-table fill + BGZF header walk + host -> device copy of the compressed bytes inside the step), in a
+    # fresh context and AFTER the timed region
     ctx.close()
-    ctx = squid_amd.Context(device=local_rank, rank=rank, world_size=world, exchange=exchange) if sharded else squid_amd.Context(device=local_rank)
+    ctx = new_context()
+    squid_amd.drop_file_cache()
     step()
     barrier()
-    t0 = time.perf_counter()
     n_file_steps = 2
+    t_file = 0.0
     for _ in range(n_file_steps):
+        squid_amd.drop_file_cache()
+        barrier()
+        t0 = time.perf_counter()
         step()
-    barrier()
-    t_file = (time.perf_counter() - t0) / n_file_steps
+        barrier()
+        t_file += time.perf_counter() - t0
+    t_file /= n_file_steps
 
     from squid_amd.dist import reduce_timing
 
@@ -240,69 +277,107 @@ def main() -> None:
 
     value = total_aln * a.steps / elapsed
     R = max(1, a.resident_steps)
-    # dominant record-streaming kernel of the graph pass, by accumulated HIP-event time on the library stream
-    gk = {k: v for k, v in agg.items() if k.startswith(GPU_KERNELS_PREFIX) and v["bytes"] > 0 and k not in INGEST_KERNELS}
+    # the record-streaming kernels of the graph pass (K1-K5, K10), by accumulated HIP-event time on the library stream
+    gk = {k: v for k, v in agg.items() if k.startswith(GPU_KERNELS_PREFIX) and v["bytes"] > 0 and k not in INGEST_KERNELS and k not in SMALL_GRAPH_KERNELS}
+    gk_all = dict(gk)
+    if "k_edges" in agg:
+        gk_all["k_edges"] = agg["k_edges"]  # (pass 2 of the edge stage: its time counts, its bytes are not priced)
     dom = max(gk, key=lambda k: gk[k]["ms"])
     d = gk[dom]
-    per_launch_bytes = d["bytes"] / d["launches"]
-    per_launch_ms = d["ms"] / d["launches"]
-    achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
-    gpu_ms = sum(v["ms"] for v in gk.values()) / R  # the record-streaming kernels (K1-K5, K10), not the small-graph ones
+    gpu_ms = sum(v["ms"] for v in gk_all.values()) / R
     scan_bytes = sum(v["bytes"] for v in gk.values()) / R
-    # N_c * (80 + 24 * blocks per record) algorithmic bytes over the summed time of the record-streaming kernels
     bbar = total_blk / max(1.0, total_conc)
     sec8d_bytes = total_conc / world * (80.0 + 24.0 * bbar) if sharded else n_conc * (80.0 + 24.0 * bbar)
+    achieved = sec8d_bytes / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else 0.0
     traffic = None
     tfile = ROOT / "profiles" / "pmc_traffic.json"  # written by tools/profile_pmc.sh from the rocprofv3 --pmc passes
+    per_kernel_traffic = {}
     if tfile.exists():
         try:
             tj = json.loads(tfile.read_text())
             if tj.get("_workload") == a.workload and not a.records and world == 1:  # the counters were collected on this workload
-                traffic = (tj.get(dom) or {}).get("hbm_bytes_per_launch")
+                per_kernel_traffic = {k: (tj.get(k) or {}).get("hbm_bytes_per_launch") for k in gk_all}
+                if all(per_kernel_traffic.get(k) is not None for k in gk):
+                    traffic = sum(per_kernel_traffic[k] * (gk[k]["launches"] / R) for k in gk)  # HBM bytes of the record-streaming kernels of one pass
         except Exception:
             traffic = None
     ing = {k: e2e[k] for k in INGEST_KERNELS if k in e2e and e2e[k]["ms"] > 0}
     out = {
-        "metric": "paired-end alignments/sec BAM->_sv.txt (BGZF/BAM decode included; bit-exact SV calls vs CPU oracle)",
+        "metric": "paired-end alignments/sec BAM->_sv.txt (BGZF/BAM decode included, compressed BAM bytes staged in HBM; bit-exact SV calls vs CPU oracle)",
         "value": value, "unit": "alignments/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
+        "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if sharded else ("weak" if world > 1 else "single GPU"), "vs_baseline": None,
         "dtype": "int32", "data": "synthetic",
-        "config": {"workload": f"{a.workload}: " + WORKLOADS.get(a.workload, "generator config " + a.workload) + (f", --records {a.records}" if a.records else ""),
-                   "records": int(total_aln), "records_per_gpu": int(total_aln / world), "blocks_per_record": round(bbar, 4),
+        "config": {"workload": f"{a.workload}: " + WORKLOADS.get(a.workload, "generator config " + a.workload) + (f", --records {a.records}" if a.records else "") + (f", --tsv {a.tsv}" if a.tsv else ""),
+                   "records": int(total_aln), "records_per_gpu": int(total_aln / world), "blocks_per_record": round(bbar, 4), "flags": " ".join(cli_flags) or "defaults",
                    "parallelism": ("one sample sharded by chromosome over %d ranks, %d all-gathers (%.0f bytes) per step" % (world, exchange.calls // max(1, a.steps + a.warmup + n_file_steps + 1 + a.resident_steps), exchange.bytes / max(1, exchange.calls)) if sharded else "1 sample per GPU, no collective") if world > 1 else "single GPU",
                    "step": "chimeric BAM decode (host) + concordant BAM decode on the GPU (BGZF inflate, record boundaries, record parse) + graph + ordering + SV calls + _sv.txt written; compressed BAM bytes resident in HBM at the start of every step"},
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "bytes_per_launch": per_launch_bytes, "us_per_launch": per_launch_ms * 1e3,
-                     "survey_8d": {"algorithmic_bytes_per_pass": sec8d_bytes, "scan_kernels_ms_per_pass": gpu_ms,
-                                   "achieved_GBs": sec8d_bytes / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else None,
-                                   "frac": sec8d_bytes / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if gpu_ms > 0 else None,
-                                   "sum_of_kernel_bytes_per_pass": scan_bytes},
-                     # every record-streaming kernel of the pass: us per launch, achieved GB/s of its algorithmic bytes, fraction of the HBM peak
-                     "record_kernels": {k: {"us": round(v["ms"] / v["launches"] * 1e3, 1), "GBs": round(v["bytes"] / v["ms"] / 1e6, 1), "frac": round(v["bytes"] / v["ms"] / 1e6 / HBM_PEAK_GBS, 3)}
-                                        for k, v in sorted(gk.items(), key=lambda kv: -kv[1]["ms"]) if v["ms"] > 0},
-                     "note": "dominant record-streaming kernel of the graph pass (SURVEY.md 8(d) passes P1-P3); the BGZF inflate kernels are latency-bound bit-serial decoders, listed under ingest_kernels"},
-        "ingest_kernels": {k: {"ms_per_step": round(v["ms"] / a.steps, 3), "GBs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)} for k, v in ing.items()},
-        "from_file_value": total_aln / t_file, "from_file_note": "same step with the BAM read from the page cache: host->device copy of the compressed bytes inside the step",
+        "sv_sha256": digests[0], "sv_rows": text.count("\n") - 1, "steps_identical": True,
+        "roofline": {"bound": "hbm", "kernel": "record-streaming kernels of one graph pass: " + " + ".join(sorted(gk_all, key=lambda k: -gk_all[k]["ms"])),
+                     "definition": "SURVEY.md 8(d): N_c * (80 + 24 * blocks per record) algorithmic bytes / summed HIP-event time of those kernels",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "bytes_per_launch": sec8d_bytes, "us_per_launch": gpu_ms * 1e3,
+                     "sum_of_kernel_bytes_per_pass": scan_bytes, "kernel_bytes_over_algorithmic": scan_bytes / sec8d_bytes if sec8d_bytes else None,
+                     "frac_of_measured_copy_peak_6290": achieved / 6290.0,
+                     "dominant_kernel": {"name": dom, "us": d["ms"] / d["launches"] * 1e3, "bytes_per_launch": d["bytes"] / d["launches"], "GBs": d["bytes"] / d["ms"] / 1e6,
+                                         "frac": d["bytes"] / d["ms"] / 1e6 / HBM_PEAK_GBS, "traffic": per_kernel_traffic.get(dom)},
+                     # every record-streaming kernel of the pass: us per launch, achieved GB/s of its own bytes, fraction of the HBM peak
+                     "record_kernels": {k: {"us": round(v["ms"] / v["launches"] * 1e3, 1), "launches_per_pass": round(v["launches"] / R, 2), "GBs": round(v["bytes"] / v["ms"] / 1e6, 1),
+                                            "frac": round(v["bytes"] / v["ms"] / 1e6 / HBM_PEAK_GBS, 3)} for k, v in sorted(gk_all.items(), key=lambda kv: -kv[1]["ms"]) if v["ms"] > 0},
+                     "note": "the BGZF inflate kernels dominate the step's GPU time but are latency-bound bit-serial decoders, not HBM streams: listed under ingest_kernels"},
+        # BGZF reader: its kernels run on several streams and overlap.  busy_ms_per_step = time during which at least one launch of the
+        # name was running; us_per_launch = average duration of one launch (what rocprofv3 --stats reports per kernel)
+        "ingest_kernels": {k: {"launches_per_step": round(v["launches"] / a.steps, 1), "us_per_launch": round(v["ms"] / v["launches"] * 1e3, 1), "busy_ms_per_step": round(v["busy_ms"] / a.steps, 3),
+                               "GBs_over_busy_time": round(v["bytes"] / max(v["busy_ms"], 1e-9) / 1e6, 1)} for k, v in ing.items()},
+        "from_file_value": total_aln / t_file, "from_file_ms": t_file * 1e3,
+        "from_file_note": "same step from the BAM in the page cache with nothing kept from earlier reads (mapping and block index dropped before every step): page-table fill, BGZF header walk and host->device copy inside the step",
         "resident_pass_value": total_aln / t_res, "resident_pass_ms": t_res * 1e3,
-        "stage_ms_per_step": {k: round(v["ms"] / a.steps, 4) for k, v in sorted(e2e.items(), key=lambda kv: -kv[1]["ms"])[:(None if os.environ.get("BENCH_ALL_STAGES") else 14)]},
-        "resident_stage_ms": {k: round(v["ms"] / R, 4) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:(None if os.environ.get("BENCH_ALL_STAGES") else 16)]},
+        "stage_ms_per_step": {k: round(v["ms"] / a.steps, 4) for k, v in sorted(e2e.items(), key=lambda kv: -kv[1]["ms"]) if k not in INGEST_KERNELS and (os.environ.get("BENCH_ALL_STAGES") or v["ms"] / a.steps >= 0.5)},
+        "resident_stage_ms": {k: round(v["ms"] / R, 4) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:(None if os.environ.get("BENCH_ALL_STAGES") else 18)]},
         "synth_s": round(t_gen, 1),
     }
+    if comp_sizes is not None and len(comp_sizes):
+        import numpy as np
+
+        # K9: components per second of the ordering stage and of the whole step, sizes as a histogram
+        order_ms = agg.get("wall_order", {}).get("ms", 0.0) / R
+        hist = np.bincount(np.minimum(comp_sizes, 20))
+        out["components"] = {"n": int(len(comp_sizes)), "n_with_2_or_more_nodes": int((comp_sizes >= 2).sum()), "largest": int(comp_sizes.max()),
+                             "size_histogram": {("20+" if s == 20 else str(s)): int(c) for s, c in enumerate(hist) if c},
+                             "ccs_per_s_ordering_stage": len(comp_sizes) / (order_ms * 1e-3) if order_ms > 0 else None,
+                             "ccs_per_s_whole_step": len(comp_sizes) * a.steps / elapsed, "ordering_ms_per_pass": order_ms,
+                             "n_order_unsolved": int(counts["n_order_unsolved"])}
     ctx.close()
-    if not a.no_cpu_baseline and world == 1:
-        # CPU oracle (a port of the reference, 1 thread, pinned) on a bounded sample of the same workload, timed on this box;
-        # the GPU path runs the same sample and the two _sv.txt files are compared
-        spre = synth(a.workload, seed, work, a.cpu_sample_records)
-        pin = ["taskset", "-c", "0"] if shutil.which("taskset") else []
+    if not a.no_cold_cli and world == 1:
+        # what a user runs once: a fresh process, nothing staged, nothing cached inside the process (the page cache is warm)
+        cold_pre = work / "cold_cli"
         t0 = time.perf_counter()
-        subprocess.check_call(pin + [str(BUILD / "squid_oracle"), "-b", f"{spre}.bam", "-c", f"{spre}.chim.bam", "-o", str(work / "cpu_baseline")], stdout=subprocess.DEVNULL)
+        r = subprocess.run([str(BUILD / "squid"), "-b", bam, "-c", chim, "-o", str(cold_pre)] + cli_flags, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
         tc = time.perf_counter() - t0
-        res = squid_amd.run_pipeline(f"{spre}.bam", f"{spre}.chim.bam", device=local_rank)
-        n_s = res["counts"]["n_concordant"] + res["counts"]["n_chimeric_records"]
-        same = (work / "cpu_baseline_sv.txt").read_text() == res["sv_text"]
+        same = r.returncode == 0 and Path(f"{cold_pre}_sv.txt").exists() and Path(f"{cold_pre}_sv.txt").read_text() == text
+        out["cold_cli"] = {"value": total_aln / tc, "unit": "alignments/s", "wall_s": round(tc, 3), "sv_identical_to_steps": same,
+                           "what": "one `build/squid -b -c -o` process, exec to exit: context creation, device allocations, both BAM files -> _sv.txt"}
+    if not a.no_cpu_baseline and world == 1:
+        # CPU oracle (a port of the reference, 1 thread, pinned) timed on this box: on the bench's own BAM files (its _sv.txt must equal
+        # the timed steps'), or with --cpu-sample-records on a smaller sample of the same workload that the GPU path then runs too
+        pin = ["taskset", "-c", "0"] if shutil.which("taskset") else []
+        if a.cpu_sample_records:
+            spre = synth(a.workload, seed, work, a.cpu_sample_records, tsv=a.tsv)
+            sample = f"{a.workload} generated with --records {a.cpu_sample_records}"
+        else:
+            spre, sample = pre, "the bench's own BAM files"
+        t0 = time.perf_counter()
+        subprocess.check_call(pin + [str(BUILD / "squid_oracle"), "-b", f"{spre}.bam", "-c", f"{spre}.chim.bam", "-o", str(work / "cpu_baseline")] + cli_flags, stdout=subprocess.DEVNULL)
+        tc = time.perf_counter() - t0
+        oracle_text = (work / "cpu_baseline_sv.txt").read_text()
+        if a.cpu_sample_records:
+            res = squid_amd.run_pipeline(f"{spre}.bam", f"{spre}.chim.bam", device=local_rank, **params)
+            n_s = res["counts"]["n_concordant"] + res["counts"]["n_chimeric_records"]
+            same = oracle_text == res["sv_text"]
+        else:
+            n_s, same = int(total_aln), oracle_text == text
         out["cpu_baseline"] = {"value": n_s / tc, "unit": "alignments/s", "cores": 1, "kind": "port",
-                               "sample": f"{a.workload} generated with --records {a.cpu_sample_records} ({n_s} records), BAM files -> _sv.txt incl. its three BAM decodes, {tc:.2f} s, " + ("taskset -c 0" if pin else "unpinned"),
-                               "cpu_model": cpu_model(), "host_cpus": os.cpu_count(), "sv_identical_to_gpu": same, "sv_rows": res["sv_text"].count("\n") - 1}
+                               "sample": f"{sample} ({n_s} records), BAM files -> _sv.txt incl. its three BAM decodes, {tc:.2f} s, " + ("taskset -c 0" if pin else "unpinned"),
+                               "cpu_model": cpu_model(), "host_cpus": os.cpu_count(), "sv_identical_to_gpu": same, "sv_rows": oracle_text.count("\n") - 1}
     if dist:
         dist.destroy_process_group()
     print(json.dumps(out))

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SQ_ABI_VERSION 2
+#define SQ_ABI_VERSION 3
 
 enum {
     SQ_OK = 0,
@@ -199,10 +199,15 @@ typedef struct sq_timing {
     const double* ms;
     const int64_t* launches;
     const double* bytes; /* algorithmic bytes moved by the kernel (0 for host stages) */
+    const double* busy_ms; /* kernels: time during which at least one launch of that name was running (launches of one name overlap
+                              when they sit on several streams -- the BGZF reader --; ms[i] is the SUM of their durations) */
 } sq_timing;
 int sq_get_timing(sq_ctx* c, sq_timing* t);
 /* keep = 1: sq_build_graph no longer clears the timing table, so it accumulates over repeated runs (bench loops read it once) */
 int sq_timing_accumulate(sq_ctx* c, int32_t keep);
+/* forget the process-wide mapping and BGZF block index of the last BAM file read: the next sq_ingest_*_file maps the file and walks its
+ * block headers again (measurements of a first read; the cache only saves time, never changes results) */
+int sq_drop_file_cache(void);
 int sq_reset(sq_ctx* c); /* drop graph results, keep ingested records resident in HBM (bench re-runs) */
 
 typedef struct sq_counts {

@@ -20,7 +20,7 @@ EXPORTS = [
     "sq_default_params", "sq_create", "sq_destroy", "sq_strerror", "sq_last_error", "sq_set_references",
     "sq_ingest_chimeric", "sq_chim_contains", "sq_ingest_concordant", "sq_ingest_concordant_bam", "sq_read_header", "sq_ingest_chimeric_file",
     "sq_ingest_concordant_file", "sq_build_graph", "sq_graph_view", "sq_order", "sq_call_sv", "sq_breakpoints",
-    "sq_set_shard", "sq_exchange_pack", "sq_exchange_unpack", "sq_get_timing", "sq_timing_accumulate", "sq_reset", "sq_ingest_files", "sq_stage_bam", "sq_clear_records", "sq_set_source", "sq_save_records", "sq_load_records", "sq_get_counts", "sq_debug_download", "sq_debug_bp_support", "sq_debug_order", "sq_debug_blocks",
+    "sq_set_shard", "sq_exchange_pack", "sq_exchange_unpack", "sq_get_timing", "sq_timing_accumulate", "sq_reset", "sq_ingest_files", "sq_stage_bam", "sq_clear_records", "sq_set_source", "sq_save_records", "sq_load_records", "sq_get_counts", "sq_debug_download", "sq_debug_bp_support", "sq_debug_order", "sq_debug_blocks", "sq_drop_file_cache",
 ]
 
 
@@ -62,7 +62,7 @@ class SqBpTable(C.Structure):
 
 class SqTiming(C.Structure):
     _fields_ = [("n", C.c_int32), ("names", C.POINTER(C.c_char_p)), ("ms", C.POINTER(C.c_double)), ("launches", C.POINTER(C.c_int64)),
-                ("bytes", C.POINTER(C.c_double))]
+                ("bytes", C.POINTER(C.c_double)), ("busy_ms", C.POINTER(C.c_double))]
 
 
 class SqCounts(C.Structure):
@@ -121,6 +121,11 @@ def load_library() -> C.CDLL:
         lib.sq_exchange_unpack.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.c_int32]
         _lib = lib
     return _lib
+
+
+def drop_file_cache():
+    """forget the process-wide mapping and block index of the last BAM read (sq_drop_file_cache)"""
+    load_library().sq_drop_file_cache()
 
 
 def read_header(bam_path: str):
@@ -255,6 +260,17 @@ class Context:
         self._chk(self.lib.sq_order(self.h, C.byref(o)), "sq_order")
         return [[o.nodes[j] for j in range(o.comp_off[k], o.comp_off[k + 1])] for k in range(o.n_components)]
 
+    def order_sizes(self):
+        """sq_order, returning only the number of nodes of every component (numpy array)"""
+        import numpy as np
+
+        o = SqOrders()
+        self._chk(self.lib.sq_order(self.h, C.byref(o)), "sq_order")
+        if o.n_components <= 0:
+            return np.zeros(0, np.int64)
+        off = np.ctypeslib.as_array(o.comp_off, shape=(o.n_components + 1,))
+        return np.diff(off.astype(np.int64))
+
     def call_sv_step(self) -> int:
         self._sv = SqSvTable()
         rc = self.lib.sq_call_sv(self.h, C.byref(self._sv))
@@ -325,12 +341,29 @@ class Context:
     def timing(self) -> dict:
         t = SqTiming()
         self._chk(self.lib.sq_get_timing(self.h, C.byref(t)), "sq_get_timing")
-        return {t.names[i].decode(): {"ms": t.ms[i], "launches": t.launches[i], "bytes": t.bytes[i]} for i in range(t.n)}
+        return {t.names[i].decode(): {"ms": t.ms[i], "launches": t.launches[i], "bytes": t.bytes[i], "busy_ms": t.busy_ms[i]} for i in range(t.n)}
 
     def counts(self) -> dict:
         k = SqCounts()
         self._chk(self.lib.sq_get_counts(self.h, C.byref(k)), "sq_get_counts")
         return {f: getattr(k, f) for f, _ in SqCounts._fields_}
+
+    def sv_text_fast(self) -> str:
+        """sv_text() without a Python tuple per row (dense samples have 1e5 rows)"""
+        import numpy as np
+
+        t = SqSvTable()
+        self._run_stage(lambda: self.lib.sq_call_sv(self.h, C.byref(t)), "sq_call_sv")
+        head = "# chrom1\tstart1\tend1\tchrom2\tstart2\tend2\tname\tscore\tstrand1\tstrand2\tnum_concordantfrag_bp1\tnum_concordantfrag_bp2\n"
+        n = t.n_rows
+        if n <= 0:
+            return head
+        col = lambda p: np.ctypeslib.as_array(p, shape=(n,)).tolist()
+        names = self.ref_names
+        c1, s1, e1, c2, s2, e2, sc, m1, m2, u1, u2 = (col(t.chr1), col(t.start1), col(t.end1), col(t.chr2), col(t.start2), col(t.end2), col(t.score),
+                                                      col(t.strand1_minus), col(t.strand2_minus), col(t.sup1), col(t.sup2))
+        pm = ("+", "-")
+        return head + "".join([f"{names[c1[i]]}\t{s1[i]}\t{e1[i]}\t{names[c2[i]]}\t{s2[i]}\t{e2[i]}\t.\t{sc[i]}\t{pm[m1[i]]}\t{pm[m2[i]]}\t{u1[i]}\t{u2[i]}\n" for i in range(n)])
 
     def sv_text(self) -> str:
         """The `_sv.txt` file content (src/WriteIO.cpp:49-123)."""

@@ -933,6 +933,11 @@ int find_records(const uint8_t* u, size_t begin, size_t limit, int nref, Pool& p
     return SQ_OK;
 }
 }  // namespace
+// forget the mapping and block index of the last file read (sq_drop_file_cache): the next read maps and indexes its file again
+void drop_file_cache() {
+    std::lock_guard<std::mutex> lk(g_map_cache.mu);
+    g_map_cache.index.reset(); g_map_cache.index_total = 0; g_map_cache.map.reset(); g_map_cache.path.clear();
+}
 
 // CPUs this process can really use: the affinity mask, cut by the cgroup's CPU quota (a container may see 256 logical
 // CPUs and be allowed 16 of them)

@@ -28,14 +28,15 @@ int chim_join(sq_ctx* c) {
 
 int Timer::slot(const char* name) {
     for (size_t i = 0; i < names.size(); ++i) if (names[i] == name || !std::strcmp(names[i], name)) return (int)i;
-    names.push_back(name); ms.push_back(0); bytes.push_back(0); launches.push_back(0);
+    names.push_back(name); ms.push_back(0); bytes.push_back(0); busy.push_back(0); launches.push_back(0);
     return (int)names.size() - 1;
 }
 void Timer::add(const char* name, double ms_, double bytes_, int64_t n) {
     int s = slot(name);
     ms[s] += ms_; bytes[s] += bytes_; launches[s] += n;
 }
-void Timer::clear() { names.clear(); ms.clear(); bytes.clear(); launches.clear(); }
+void Timer::add_busy(const char* name, double ms_) { busy[slot(name)] += ms_; }
+void Timer::clear() { names.clear(); ms.clear(); bytes.clear(); busy.clear(); launches.clear(); }
 
 void GraphSnap::take(const std::vector<Node>& N, const std::vector<Edge>& E, const std::vector<int32_t>* lab) {
     const size_t n = N.size(), m = E.size();
@@ -1070,9 +1071,10 @@ int sq_breakpoints(sq_ctx* c, sq_bp_table* t) {
 int sq_get_timing(sq_ctx* c, sq_timing* t) {
     if (!c || !t) return SQ_E_ARG;
     t->n = (int32_t)c->timer.names.size();
-    t->names = c->timer.names.data(); t->ms = c->timer.ms.data(); t->launches = c->timer.launches.data(); t->bytes = c->timer.bytes.data();
+    t->names = c->timer.names.data(); t->ms = c->timer.ms.data(); t->launches = c->timer.launches.data(); t->bytes = c->timer.bytes.data(); t->busy_ms = c->timer.busy.data();
     return SQ_OK;
 }
+int sq_drop_file_cache(void) { drop_file_cache(); return SQ_OK; }
 int sq_timing_accumulate(sq_ctx* c, int32_t keep) {
     if (!c) return SQ_E_ARG;
     c->timer_keep = keep != 0;

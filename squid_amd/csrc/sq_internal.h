@@ -93,10 +93,11 @@ enum : uint8_t { SR_HASBLK = 1, SR_CONC = 2, SR_PART = 4, SR_REV = 8, SR_MATE = 
 
 struct Timer {
     std::vector<const char*> names;
-    std::vector<double> ms, bytes;
+    std::vector<double> ms, bytes, busy;  // busy: time during which at least one launch of that name was running (kernels of one name on several streams overlap; ms is the sum of their durations)
     std::vector<int64_t> launches;
     int slot(const char* name);
     void add(const char* name, double ms_, double bytes_ = 0, int64_t n = 1);
+    void add_busy(const char* name, double ms_);
     void clear();
 };
 
@@ -231,6 +232,7 @@ struct HostBatch {  // owning storage behind an sq_aln_batch
     void view(sq_aln_batch* b, bool with_names) const;
     size_t size() const { return refid.size(); }
 };
+void drop_file_cache();
 int read_bam_header(const char* path, std::vector<std::string>& names, std::vector<int32_t>& lens, std::string& err);
 // streams the file; calls sink(batch) every `batch_records` records.  inchim may be null.
 struct ParseOpts { int phred_type, min_phred, max_lowphred_len; bool keep_names; const std::unordered_set<std::string>* inchim; };

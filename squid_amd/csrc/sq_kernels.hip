@@ -3017,11 +3017,31 @@ struct EvTimer {
 void dev_flush_timers(sq_ctx* c) {
     if (!c->dev) return;
     DeviceRecords& D = *c->dev;
+    // per name: sum of the launch durations, and the time during which at least one launch of the name was running (the launches of
+    // the BGZF reader sit on several streams and overlap) -- from the launches' start / end offsets against the first event of the batch
+    struct Iv { const char* name; float s, e; };
+    std::vector<Iv> iv;
+    iv.reserve(D.ev_pending.size());
+    hipEvent_t origin = D.ev_pending.empty() ? nullptr : D.ev_pool[D.ev_pending.front().slot].first;
     for (const DeviceRecords::Pending& p : D.ev_pending) {
-        float ms = 0;
+        float ms = 0, s0 = 0;
         (void)hipEventSynchronize(D.ev_pool[p.slot].second);
         (void)hipEventElapsedTime(&ms, D.ev_pool[p.slot].first, D.ev_pool[p.slot].second);
         c->timer.add(p.name, ms, p.bytes);
+        if (hipEventElapsedTime(&s0, origin, D.ev_pool[p.slot].first) != hipSuccess) s0 = 0;  // (may be negative: an event of another stream recorded earlier)
+        iv.push_back(Iv{p.name, s0, s0 + ms});
+    }
+    std::sort(iv.begin(), iv.end(), [](const Iv& a, const Iv& b) { return a.name != b.name ? a.name < b.name : a.s < b.s; });
+    for (size_t i = 0; i < iv.size();) {
+        size_t j = i;
+        double busy = 0, lo = iv[i].s, hi = iv[i].e;
+        for (; j < iv.size() && iv[j].name == iv[i].name; ++j) {
+            if (iv[j].s > hi) { busy += hi - lo; lo = iv[j].s; hi = iv[j].e; }
+            else if (iv[j].e > hi) hi = iv[j].e;
+        }
+        busy += hi - lo;
+        c->timer.add_busy(iv[i].name, busy);
+        i = j;
     }
     D.ev_pending.clear();
     D.ev_used = 0;
@@ -3335,7 +3355,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
             HIPCHK(hipStreamWaitEvent(sa, st.copied, 0));
         }
         if (variant == 0) {  // k_inflate_tok2 stays on the set's own stream: the token kernels of up to four batches run side by side
-            EvTimer t1(c, "k_inflate_tokens", (double)B.cbytes + (double)B.bbytes * 2, sa);
+            EvTimer t1(c, "k_inflate_tok2", (double)B.cbytes + (double)B.bbytes * 2, sa);
             if (tok_v1) hipLaunchKernelGGL(k_inflate_lanes<true>, dim3((nb + 63) / 64), dim3(64), IL_LDS_BYTES, sa, st.src, st.tab.p, nb, B.bbase, nullptr, st.flags.p, st.tok.p, st.ntok.p);
             else if (tok_prof && k == 8) hipLaunchKernelGGL(k_inflate_tok2<true>, dim3((nb + 63) / 64), dim3(64), T2_LDS_BYTES, sa, st.src, st.tab.p, nb, B.bbase, st.flags.p, st.tok.p, st.ntok.p, D.tok_prof.p);
             else hipLaunchKernelGGL(k_inflate_tok2<false>, dim3(((nb + 63) / 64 + tok_wpb - 1) / tok_wpb), dim3(64 * tok_wpb), tok_wpb * T2_LDS_BYTES, sa, st.src, st.tab.p, nb, B.bbase, st.flags.p, st.tok.p, st.ntok.p, nullptr);
@@ -3388,7 +3408,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
             EvTimer t(c, "k_inflate", (double)B.cbytes + (double)B.bbytes);
             hipLaunchKernelGGL(k_inflate_lanes<false>, dim3((nb + 63) / 64), dim3(64), IL_LDS_BYTES, s, st.src, st.tab.p, nb, B.bbase, out, P.flags.p, nullptr, nullptr);
         } else {
-            EvTimer t2(c, "k_lz_resolve", (double)B.bbytes * 3);
+            EvTimer t2(c, "k_lz_resolve2", (double)B.bbytes * 3);
             static const bool one_wave = std::getenv("SQUID_RESOLVE_1WAVE") != nullptr;  // one wave per block (round 1), for comparison
             if (one_wave) hipLaunchKernelGGL(k_lz_resolve, dim3(nb), dim3(64), 65536 + 16, s, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, out, P.flags.p);
             else hipLaunchKernelGGL(k_lz_resolve2, dim3(nb), dim3(128), 65536 + 16, s, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, out, P.flags.p);
@@ -3403,7 +3423,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
             int32_t* tot = P.flags.p + 8;
             long long* tail_d = P.rec_end.p + nsl;  // where the walk stopped: the start of the incomplete tail
             HIPCHK(hipMemsetAsync(tail_d, 0, 8, s));
-            { EvTimer t(c, "k_rec_boundaries", 2.0 * (double)(F.S.limit - F.S.begin));
+            { EvTimer t(c, "k_rec_sync+walk+check", 2.0 * (double)(F.S.limit - F.S.begin));
               hipLaunchKernelGGL(k_rec_sync, grid_for(nsl, 256), dim3(256), 0, s, F.S, nsl, (k > 0 || synced) ? 1 : 0, P.rec_sync.p);
               hipLaunchKernelGGL(k_rec_walk<false>, grid_for(nsl, 256), dim3(256), 0, s, F.S, nsl, P.rec_sync.p, P.rec_cnt.p, P.rec_end.p, nullptr, nullptr);
               hipLaunchKernelGGL(k_rec_check, grid_for(nsl, 256), dim3(256), 0, s, nsl, P.rec_sync.p, P.rec_end.p, P.flags.p, tail_d);
