@@ -79,7 +79,7 @@ struct Unpacker {
         at += (size_t)n * sizeof(T);
     }
 };
-enum : int32_t { X_DEDUP = 0x51a0, X_STREAM, X_SEEDS, X_GRAPH, X_BPSUP };  // payload tags (a mismatch means the ranks are out of step)
+enum : int32_t { X_DEDUP = 0x51a0, X_STREAM, X_SEEDS, X_GRAPH, X_BPSUP, X_OTHER };  // payload tags (a mismatch means the ranks are out of step)
 
 // locals of build_graph that have to survive an exchange
 struct GraphBuild {
@@ -89,7 +89,8 @@ struct GraphBuild {
     int64_t n_break = 0;
     int64_t trigger_last = 0;
     std::vector<Node> seeds;
-    std::vector<Edge> raw, conc;
+    std::vector<Edge> raw, conc, before;  // before: the edges in front of FilterEdges (the filter is repeated when a depth decision was ambiguous)
+    std::vector<uint8_t> keep;          // KeepEdge of FilterbyInterleaving
     std::vector<int32_t> sup, amb_plus, amb_minus;
     std::vector<int64_t> sl;
     bool tiny_boundary = false;
@@ -329,10 +330,11 @@ static int build_graph(sq_ctx* c) {
             return need_exchange(c);
         }
     }
-    if (g.stage != 4) return fail(c, SQ_E_ARG, "internal: bad build stage");
+    if (g.stage != 4 && g.stage != 5) return fail(c, SQ_E_ARG, "internal: bad build stage");
     std::vector<Node>& N = c->nodes;
     const int nn = (int)N.size();
-    if (sh.on) {
+    const bool resumed = g.stage == 5;  // back from the exchange of the ReadsOther lists (exact depth sweep of a sharded run)
+    if (sh.on && !resumed) {
         rc = take_exchange(c, X_GRAPH);
         if (rc) return rc;
         g.sup.assign(2 * nn + 1, 0); g.sl.assign(2 * nn, 0); g.amb_plus.assign(nn, 0); g.amb_minus.assign(nn, 0);
@@ -387,14 +389,15 @@ static int build_graph(sq_ctx* c) {
     const bool exact_mode = std::getenv("SQUID_EXACT_DEPTH") != nullptr && !sh.on;
     struct OtherR { int32_t chr, pos, len; };
     std::vector<OtherR> other_sorted;
+    auto sort_other = [&]() { std::sort(other_sorted.begin(), other_sorted.end(), [](const OtherR& a, const OtherR& b) { return a.chr != b.chr ? a.chr < b.chr : a.pos < b.pos; }); };
     auto exact_sort = [&]() -> int {
         std::vector<int32_t> ochr, opos, olen;
         bool has_tiny = false;
-        int r2 = dev_gather_other(c, g.n_break, has_tiny, ochr, opos, olen);
+        int r2 = dev_gather_other(c, g.n_break, has_tiny, ochr, opos, olen, false);
         if (r2) return r2;
         other_sorted.resize(has_tiny ? ochr.size() : 0);
         for (size_t i = 0; i < other_sorted.size(); ++i) other_sorted[i] = OtherR{ochr[i], opos[i], olen[i]};
-        std::sort(other_sorted.begin(), other_sorted.end(), [](const OtherR& a, const OtherR& b) { return a.chr != b.chr ? a.chr < b.chr : a.pos < b.pos; });
+        sort_other();
         return SQ_OK;
     };
     // combine in the reference's order: discordant, ReadsMain, ReadsOther, then the division (only when ReadsOther is
@@ -437,36 +440,66 @@ static int build_graph(sq_ctx* c) {
         if (!other_sorted.empty()) exact_sweep(ocnt, osum);
         set_depths(ocnt, osum, false);
     } else set_depths(ocnt, osum, g.tiny_boundary);
-    c->snap[1].take(c->nodes, c->edges, nullptr);
-    {
-        HostClock hc(c, "host_edge_reduce");
-        g.raw.insert(g.raw.end(), g.conc.begin(), g.conc.end());
-        reduce_edges(g.raw, c->edges);
+    static const bool host_filters = std::getenv("SQUID_HOST_FILTERS") != nullptr;
+    if (!resumed) {
+        c->snap[1].take(c->nodes, c->edges, nullptr);
+        {
+            HostClock hc(c, "host_edge_reduce");
+            g.raw.insert(g.raw.end(), g.conc.begin(), g.conc.end());
+            reduce_edges(g.raw, c->edges);
+        }
+        c->snap[2].take(c->nodes, c->edges, nullptr);
     }
-    c->snap[2].take(c->nodes, c->edges, nullptr);
     // K6 / K7 run on the device (sq_graph_kernels.inc); SQUID_HOST_FILTERS=1 takes the host restatements of sq_graph.cpp instead
     // (kept as a cross-check: tests compare the two stage by stage)
-    static const bool host_filters = std::getenv("SQUID_HOST_FILTERS") != nullptr;
     {
         HostClock hc(c, host_filters ? "host_filters" : "wall_filters");
-        if (host_filters) filter_by_weight(c); else if ((rc = dev_filter_by_weight(c))) return rc;
-        c->snap[3].take(c->nodes, c->edges, nullptr);
-        std::vector<uint8_t> keep;
-        if (host_filters) filter_by_interleaving(c, keep); else if ((rc = dev_filter_by_interleaving(c, keep))) return rc;
-        std::vector<Edge> before = c->edges;
-        if (host_filters) filter_edges(c, keep); else if ((rc = dev_filter_edges(c, keep))) return rc;
-        if (c->depth_ambiguous) {
+        if (!resumed) {
+            if (host_filters) filter_by_weight(c); else if ((rc = dev_filter_by_weight(c))) return rc;
+            c->snap[3].take(c->nodes, c->edges, nullptr);
+            if (host_filters) filter_by_interleaving(c, g.keep); else if ((rc = dev_filter_by_interleaving(c, g.keep))) return rc;
+            g.before = c->edges;
+            if (host_filters) filter_edges(c, g.keep); else if ((rc = dev_filter_edges(c, g.keep))) return rc;
+            if (std::getenv("SQUID_FORCE_DEPTH_RETRY")) c->depth_ambiguous = true;  // (tests: take the exact sweep whatever the bounds say)
+        }
+        if (c->depth_ambiguous || resumed) {
             // some coverage-ratio decision depends on the tie order: repeat the reference's sort and sweep, then redo the
-            // filter with the exact depths
-            if (sh.on) return fail(c, SQ_E_ASSERT, "sharded run: a FilterEdges decision depends on the tie order of the reference's ReadsOther sort; run unsharded");
+            // filter with the exact depths.  A sharded run needs every shard's ReadsOther for that (the tie order of the unstable
+            // sort depends on the whole list): one more exchange -- the lists, in rank order, are the unsharded stream order
             HostClock hc2(c, "host_depth_exact_retry");
-            rc = exact_sort();
-            if (rc) return rc;
+            if (sh.on && !resumed) {
+                std::vector<int32_t> ochr, opos, olen;
+                bool has_tiny = false;
+                rc = dev_gather_other(c, g.n_break, has_tiny, ochr, opos, olen, true);
+                if (rc) return rc;
+                Packer pk(c->xbuf);
+                pk.put<int32_t>(X_OTHER);
+                pk.put_vec(ochr); pk.put_vec(opos); pk.put_vec(olen);
+                g.stage = 5;
+                return need_exchange(c);
+            }
+            if (sh.on) {
+                rc = take_exchange(c, X_OTHER);
+                if (rc) return rc;
+                other_sorted.clear();
+                for (int r = 0; r < W; ++r) {
+                    Unpacker u(c->xgot[r]);
+                    u.get<int32_t>();
+                    std::vector<int32_t> a, b, d;
+                    u.get_vec(a); u.get_vec(b); u.get_vec(d);
+                    if (!u.ok || a.size() != b.size() || a.size() != d.size()) return fail(c, SQ_E_ARG, "sharded run: malformed ReadsOther payload");
+                    for (size_t i = 0; i < a.size(); ++i) other_sorted.push_back(OtherR{a[i], b[i], d[i]});
+                }
+                sort_other();
+            } else {
+                rc = exact_sort();
+                if (rc) return rc;
+            }
             exact_sweep(ocnt, osum);
             set_depths(ocnt, osum, false);
             c->depth_ambiguous = false;
-            c->edges = before;
-            if (host_filters) filter_edges(c, keep); else if ((rc = dev_filter_edges(c, keep))) return rc;
+            c->edges = g.before;
+            if (host_filters) filter_edges(c, g.keep); else if ((rc = dev_filter_edges(c, g.keep))) return rc;
         }
         c->snap[4].take(c->nodes, c->edges, nullptr);
     }

@@ -311,7 +311,7 @@ int dev_pass1(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<i
 int dev_segment_support(sq_ctx* c, int ncl, long long seed, SegSupport& out);
 int dev_fetch_stream(sq_ctx* c, const std::vector<std::pair<int64_t, int64_t>>& ranges, const StreamRec*& compact, std::vector<int64_t>& range_off, const StreamRec* term);
 int dev_classify(sq_ctx* c, int32_t last_info[4]);  // last_info (may be null): {has pass-1, its lists empty, has pass-2, its lists empty}
-int dev_gather_other(sq_ctx* c, int64_t n_break, bool& has_tiny, std::vector<int32_t>& other_chr, std::vector<int32_t>& other_pos, std::vector<int32_t>& other_len);
+int dev_gather_other(sq_ctx* c, int64_t n_break, bool& has_tiny, std::vector<int32_t>& other_chr, std::vector<int32_t>& other_pos, std::vector<int32_t>& other_len, bool always_fetch);
 int dev_upload_nodes(sq_ctx* c, const std::vector<Node>& nodes);  // node table + coarse position index, once per graph build
 int dev_node_depth(sq_ctx* c, const std::vector<Node>& nodes, int64_t n_break, std::vector<int32_t>& support, std::vector<int64_t>& sumlen,
                    bool& need_exact_other, std::vector<int32_t>& amb_plus, std::vector<int32_t>& amb_minus, std::vector<int32_t>& unused);

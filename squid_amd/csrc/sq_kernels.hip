@@ -3818,7 +3818,7 @@ static int set_r_break(sq_ctx* c, int64_t n_break) {
 // ReadsOther (non-first blocks of the consumed kept records) in stream order, pulled to the host only when it
 // contains a block of <= 3 bases (see k_gather_other); runs before the nodes exist so that the host can repeat the
 // reference's std::sort in the background
-int dev_gather_other(sq_ctx* c, int64_t n_break, bool& has_tiny, std::vector<int32_t>& other_chr, std::vector<int32_t>& other_pos, std::vector<int32_t>& other_len) {
+int dev_gather_other(sq_ctx* c, int64_t n_break, bool& has_tiny, std::vector<int32_t>& other_chr, std::vector<int32_t>& other_pos, std::vector<int32_t>& other_len, bool always_fetch) {
     DeviceRecords& D = *c->dev;
     hipStream_t s = c->stream;
     const int64_t n = D.n;
@@ -3842,7 +3842,7 @@ int dev_gather_other(sq_ctx* c, int64_t n_break, bool& has_tiny, std::vector<int
     HIPCHK(hipMemcpyAsync(&hf, D.flags.p, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     has_tiny = hf & 64;
-    if (!has_tiny) return SQ_OK;
+    if (!has_tiny && !always_fetch) return SQ_OK;
     auto t0 = std::chrono::steady_clock::now();
     other_chr.resize(cnt); other_pos.resize(cnt); other_len.resize(cnt);
     HIPCHK(hipMemcpyAsync(other_chr.data(), D.scratch_b.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(other_pos.data(), D.scratch_c.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, s));
