@@ -322,7 +322,8 @@ __global__ void k_pack_blocks(int64_t from, int64_t to, const int32_t* refpos, c
 }
 
 // ------------------------------------------------------------------------------------------------ scans
-// Three-phase device scan over int32 values produced by a functor: tile reduce -> spine -> tile down-sweep.
+// Device scans over int32 values produced by a functor (record parse, component labels, debug paths); the scans that run along the
+// record stream live inside the fused kernels of sq_pass_kernels.inc.
 constexpr int SCAN_THREADS = 256, SCAN_ITEMS = 16, SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 
 struct OpSum { typedef int T; static __device__ __forceinline__ int id() { return 0; } static __device__ __forceinline__ int op(int a, int b) { return a + b; } };
@@ -359,60 +360,6 @@ __device__ __forceinline__ typename Op::T block_scan_excl(typename Op::T v, type
     if (lane == 0) prev = wprefix;
     return prev;
 }
-
-template <typename Op, typename F>
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(int64_t n, F f, typename Op::T* tile_agg) {
-    typedef typename Op::T T;
-    __shared__ T lds[SCAN_THREADS / 64];
-    int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
-    T acc = Op::id();
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        int64_t idx = base + (int64_t)i * SCAN_THREADS + threadIdx.x;
-        if (idx < n) acc = Op::op(acc, f(idx));
-    }
-    T total;
-    block_scan_excl<Op>(acc, total, lds);
-    if (threadIdx.x == 0) tile_agg[blockIdx.x] = total;
-}
-template <typename Op>
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_spine(int ntiles, typename Op::T* tile_agg, typename Op::T* grand) {
-    typedef typename Op::T T;
-    __shared__ T lds[SCAN_THREADS / 64];
-    T carry = Op::id();
-    for (int base = 0; base < ntiles; base += SCAN_THREADS) {
-        int i = base + threadIdx.x;
-        T v = i < ntiles ? tile_agg[i] : Op::id();
-        T total;
-        T ex = block_scan_excl<Op>(v, total, lds);
-        if (i < ntiles) tile_agg[i] = Op::op(carry, ex);
-        carry = Op::op(carry, total);
-    }
-    if (threadIdx.x == 0 && grand) *grand = carry;
-}
-// exclusive (EXCL) or inclusive result; items are laid out blocked per thread so that order is preserved
-template <typename Op, bool EXCL, typename F>
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_down(int64_t n, F f, const typename Op::T* tile_prefix, typename Op::T* out) {
-    typedef typename Op::T T;
-    __shared__ T lds[SCAN_THREADS / 64];
-    int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
-    T v[SCAN_ITEMS];
-    T acc = Op::id();
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        v[i] = (base + i < n) ? (T)f(base + i) : Op::id();
-        acc = Op::op(acc, v[i]);
-    }
-    T total;
-    T ex = block_scan_excl<Op>(acc, total, lds);
-    T run = Op::op(tile_prefix[blockIdx.x], ex);
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        if (base + i < n) {
-            if (EXCL) { out[base + i] = run; run = Op::op(run, v[i]); }
-            else { run = Op::op(run, v[i]); out[base + i] = run; }
-        }
-    }
-}
-// NOTE: k_scan_reduce reads strided while k_scan_down reads blocked; both cover the same tile, and Op is
-// commutative for all instantiations, so the tile aggregates agree.
 
 // Single-pass scan with decoupled look-back (Merrill & Garland) for the 32-bit operators: every tile takes a ticket (tiles start
 // in ticket order, so a tile only ever waits for tiles that are already running), reads its 2048 inputs ONCE, publishes its
@@ -504,23 +451,13 @@ template <typename Op, bool EXCL, typename F>
 static hipError_t device_scan(hipStream_t s, int64_t n, F f, typename Op::T* out, DBuf<typename Op::T>& spine, typename Op::T* grand) {
     if (n <= 0) { if (grand) return hipMemsetAsync(grand, 0, sizeof(typename Op::T), s); return hipSuccess; }
     int ntiles = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
-    if constexpr (sizeof(typename Op::T) == 4) {
-        static const bool three_phase = std::getenv("SQUID_SCAN_3PHASE") != nullptr;  // (the round-1 scan, for comparison)
-        if (!three_phase) {
-            const size_t cap_before = spine.cap;
-            hipError_t e = spine.reserve(2 * (size_t)ntiles + 4);
-            if (e != hipSuccess) return e;
-            if (spine.cap != cap_before) { e = hipMemsetAsync(spine.p, 0, spine.cap * sizeof(typename Op::T), s); if (e != hipSuccess) return e; }  // fresh memory: no stale status words, ticket counter at zero
-            const uint32_t epoch = (g_scan_epoch.fetch_add(1) + 1) & 0x3fffffffu;
-            hipLaunchKernelGGL((k_scan_lookback<Op, EXCL, F>), dim3(ntiles), dim3(SCAN_THREADS), 0, s, n, f, (int*)out, (unsigned long long*)spine.p, epoch, ntiles, (int*)grand);
-            return hipGetLastError();
-        }
-    }
+    static_assert(sizeof(typename Op::T) == 4, "the look-back scan carries 32-bit values");
+    const size_t cap_before = spine.cap;
     hipError_t e = spine.reserve(2 * (size_t)ntiles + 4);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_scan_reduce<Op, F>), dim3(ntiles), dim3(SCAN_THREADS), 0, s, n, f, spine.p);
-    hipLaunchKernelGGL((k_scan_spine<Op>), dim3(1), dim3(SCAN_THREADS), 0, s, ntiles, spine.p, grand);
-    hipLaunchKernelGGL((k_scan_down<Op, EXCL, F>), dim3(ntiles), dim3(SCAN_THREADS), 0, s, n, f, spine.p, out);
+    if (spine.cap != cap_before) { e = hipMemsetAsync(spine.p, 0, spine.cap * sizeof(typename Op::T), s); if (e != hipSuccess) return e; }  // fresh memory: no stale status words, ticket counter at zero
+    const uint32_t epoch = (g_scan_epoch.fetch_add(1) + 1) & 0x3fffffffu;
+    hipLaunchKernelGGL((k_scan_lookback<Op, EXCL, F>), dim3(ntiles), dim3(SCAN_THREADS), 0, s, n, f, (int*)out, (unsigned long long*)spine.p, epoch, ntiles, (int*)grand);
     return hipGetLastError();
 }
 
@@ -1855,185 +1792,16 @@ __global__ __launch_bounds__(256) void k_order_mid(const SmallProblem* probs, co
 }
 
 // ------------------------------------------------------------------------------------------------ K-1: BGZF inflate
-// One wave per BGZF block (raw DEFLATE, <= 64 KiB out).  Every lane runs the same bit-serial decode on the same data
-// (uniform control flow, broadcast loads; the Huffman tables of the wave live in LDS): lane 0 stores the literals, all
-// lanes share the copy of a match.  A match reads bytes this wave has just written through global memory, so a fence
-// (which also drops stale L1 lines) is placed in front of every copy whose source reaches behind the last fence.
-// EXPERIMENTAL, off by default (SQUID_GPU_INFLATE=1): bit-exact against zlib on every test file, but a wave spends ~2 us per
-// symbol on what is scalar work (27-90 ms per 64 KiB block, all blocks of a 1 M-record file at once), so it only pays
-// for files with >> 10^5 blocks; the 16 host cores of the GPU box inflate ~9 GB/s with libdeflate.  Kept as the
-// starting point for a lane-per-block version.
-constexpr int INFL_LB = 10, INFL_DB = 8;
-struct InflHuff { uint16_t cnt[16]; uint16_t sym[288]; };
-struct InflLds { InflHuff ll, dd; uint16_t fast_ll[1 << INFL_LB]; uint16_t fast_dd[1 << INFL_DB]; uint8_t lens[352]; };
-// bit reader: 64-bit window refilled 32 bits at a time from a word that was requested one refill earlier (the load's
-// latency hides behind the decoding of the symbols in between; a byte-at-a-time reader costs a memory round trip per byte)
-struct InflBits { const uint8_t* p; uint32_t n, pos; unsigned long long buf; int cnt; uint32_t ahead; bool bad; };
-__device__ __forceinline__ uint32_t infl_word(const uint8_t* p) { uint32_t w; __builtin_memcpy(&w, p, 4); return w; }
-__device__ __forceinline__ void infl_init(InflBits& b) { b.buf = 0; b.cnt = 0; b.pos = 0; b.bad = false; b.ahead = infl_word(b.p); }
-__device__ __forceinline__ void infl_refill(InflBits& b) {
-    if (b.cnt <= 32) {
-        b.buf |= (unsigned long long)b.ahead << b.cnt;
-        b.cnt += 32; b.pos += 4;
-        if (b.pos > b.n + 8) b.bad = true;   // ran far past the end of the compressed block (its buffer is padded)
-        b.ahead = infl_word(b.p + b.pos);
-    }
-}
-__device__ __forceinline__ uint32_t infl_take(InflBits& b, int k) {  // k <= 16
-    infl_refill(b);
-    const uint32_t v = (uint32_t)(b.buf & ((1ull << k) - 1));
-    b.buf >>= k; b.cnt -= k;
-    return v;
-}
-// canonical Huffman code from lens[0..n): count/symbol arrays (slow path) + a 2^FB-entry table (sym << 4 | len) for the
-// codes of at most FB bits.  Returns false for an over-subscribed set.
-__device__ __noinline__ bool infl_build(InflHuff& H, uint16_t* fast, int FB, const uint8_t* lens, int n) {
-    for (int i = 0; i < 16; ++i) H.cnt[i] = 0;
-    for (int i = 0; i < n; ++i) H.cnt[lens[i]]++;
-    int left = 1;
-    for (int l = 1; l <= 15; ++l) { left <<= 1; left -= H.cnt[l]; if (left < 0) return false; }
-    uint16_t offs[16], next[16];
-    offs[1] = 0;
-    for (int l = 1; l < 15; ++l) offs[l + 1] = offs[l] + H.cnt[l];
-    for (int i = 0; i < n; ++i) if (lens[i]) H.sym[offs[lens[i]]++] = (uint16_t)i;
-    int code = 0;
-    next[0] = 0;
-    for (int l = 1; l <= 15; ++l) { code = (code + H.cnt[l - 1] * (l > 1 ? 1 : 0)) << 1; next[l] = (uint16_t)code; }
-    for (int i = 0; i < (1 << FB); ++i) fast[i] = 0;
-    for (int i = 0; i < n; ++i) {
-        const int l = lens[i];
-        if (!l) continue;
-        const uint32_t c = next[l]++;
-        if (l > FB) continue;
-        const uint32_t rev = __brev(c) >> (32 - l);
-        for (uint32_t j = rev; j < (1u << FB); j += 1u << l) fast[j] = (uint16_t)((i << 4) | l);
-    }
-    return true;
-}
-__device__ __noinline__ int infl_decode_slow(InflBits& b, const InflHuff& H) {
-    int code = 0, first = 0, index = 0;
-    unsigned long long bb = b.buf;
-    for (int len = 1; len <= 15; ++len) {
-        code |= (int)(bb & 1); bb >>= 1;
-        const int count = H.cnt[len];
-        if (code - count < first) { b.buf >>= len; b.cnt -= len; return H.sym[index + (code - first)]; }
-        index += count; first += count; first <<= 1; code <<= 1;
-    }
-    b.bad = true;
-    return -1;
-}
-__device__ __forceinline__ int infl_decode(InflBits& b, const InflHuff& H, const uint16_t* fast, int FB) {
-    infl_refill(b);
-    const uint16_t e = fast[b.buf & ((1u << FB) - 1)];
-    if (e & 15) { const int l = e & 15; b.buf >>= l; b.cnt -= l; return e >> 4; }
-    return infl_decode_slow(b, H);
-}
-__constant__ uint16_t c_lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__constant__ uint8_t c_lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__constant__ uint16_t c_dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__constant__ uint8_t c_dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
-__constant__ uint8_t c_clorder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-__global__ __launch_bounds__(256) void k_inflate(const uint8_t* file, const InflBlock* blocks, int first, int nblocks, unsigned long long out_base, uint8_t* outbuf, int32_t* flags) {
-    __shared__ InflLds lds[4];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int bi = blockIdx.x * 4 + wave;
-    if (bi >= nblocks) return;
-    const InflBlock blk = blocks[first + bi];
-    if (!blk.isize) return;
-    InflLds& L = lds[wave];
-    uint8_t* out = outbuf + (blk.uoff - out_base);
-    InflBits b;
-    b.p = file + blk.coff; b.n = blk.clen;
-    infl_init(b);
-    uint32_t outpos = 0, fenced = 0;
-    bool err = false;
-    for (bool last = false; !last && !err;) {
-        last = infl_take(b, 1);
-        const uint32_t type = infl_take(b, 2);
-        if (b.bad) { err = true; break; }
-        if (type == 0) {  // stored
-            b.buf >>= (b.cnt & 7); b.cnt -= (b.cnt & 7);
-            const uint32_t len = infl_take(b, 16), nlen = infl_take(b, 16);
-            if (b.bad || (len ^ 0xffff) != nlen) { err = true; break; }
-            // the bit window holds whole bytes now: hand them back and copy from the byte position
-            uint32_t at = b.pos - (uint32_t)(b.cnt >> 3);
-            if (at + len > b.n || outpos + len > blk.isize) { err = true; break; }
-            for (uint32_t i = lane; i < len; i += 64) out[outpos + i] = b.p[at + i];
-            outpos += len;
-            b.pos = at + len; b.buf = 0; b.cnt = 0; b.ahead = infl_word(b.p + b.pos);
-            continue;
-        }
-        if (type == 3) { err = true; break; }
-        if (type == 1) {  // fixed code
-            for (int i = 0; i < 144; ++i) L.lens[i] = 8;
-            for (int i = 144; i < 256; ++i) L.lens[i] = 9;
-            for (int i = 256; i < 280; ++i) L.lens[i] = 7;
-            for (int i = 280; i < 288; ++i) L.lens[i] = 8;
-            infl_build(L.ll, L.fast_ll, INFL_LB, L.lens, 288);
-            for (int i = 0; i < 30; ++i) L.lens[i] = 5;
-            infl_build(L.dd, L.fast_dd, INFL_DB, L.lens, 30);
-        } else {  // dynamic code
-            const int nlen = (int)infl_take(b, 5) + 257, ndist = (int)infl_take(b, 5) + 1, ncode = (int)infl_take(b, 4) + 4;
-            if (b.bad || nlen > 286 || ndist > 30) { err = true; break; }
-            for (int i = 0; i < 19; ++i) L.lens[i] = 0;
-            for (int i = 0; i < ncode; ++i) L.lens[c_clorder[i]] = (uint8_t)infl_take(b, 3);
-            if (b.bad || !infl_build(L.ll, L.fast_ll, 7, L.lens, 19)) { err = true; break; }  // (the code-length code, built in the litlen slot)
-            int idx = 0;
-            // the lengths are written behind each other: litlen [0, nlen), dist [nlen, nlen + ndist)
-            uint8_t tmp_prev = 0;
-            while (idx < nlen + ndist) {
-                int sym = infl_decode(b, L.ll, L.fast_ll, 7);
-                if (sym < 0) { err = true; break; }
-                if (sym < 16) { L.lens[19 + idx++] = (uint8_t)sym; tmp_prev = (uint8_t)sym; }
-                else {
-                    int rep; uint8_t v = 0;
-                    if (sym == 16) { if (idx == 0) { err = true; break; } v = tmp_prev; rep = 3 + (int)infl_take(b, 2); }
-                    else if (sym == 17) rep = 3 + (int)infl_take(b, 3);
-                    else rep = 11 + (int)infl_take(b, 7);
-                    if (b.bad || idx + rep > nlen + ndist) { err = true; break; }
-                    while (rep--) L.lens[19 + idx++] = v;
-                    tmp_prev = v;
-                }
-            }
-            if (err) break;
-            if (L.lens[19 + 256] == 0) { err = true; break; }  // no end-of-block code
-            // (lens[19..] is read by infl_build before it overwrites anything it still needs: the tables are separate arrays)
-            if (!infl_build(L.ll, L.fast_ll, INFL_LB, L.lens + 19, nlen)) { err = true; break; }
-            if (!infl_build(L.dd, L.fast_dd, INFL_DB, L.lens + 19 + nlen, ndist)) { err = true; break; }
-        }
-        for (;;) {  // symbols of this block
-            const int sym = infl_decode(b, L.ll, L.fast_ll, INFL_LB);
-            if (sym < 0) { err = true; break; }
-            if (sym < 256) {
-                if (outpos >= blk.isize) { err = true; break; }
-                if (lane == 0) out[outpos] = (uint8_t)sym;
-                ++outpos;
-                continue;
-            }
-            if (sym == 256) break;
-            const int ls = sym - 257;
-            if (ls >= 29) { err = true; break; }
-            const uint32_t len = c_lbase[ls] + infl_take(b, c_lext[ls]);
-            const int ds = infl_decode(b, L.dd, L.fast_dd, INFL_DB);
-            if (ds < 0 || ds >= 30) { err = true; break; }
-            const uint32_t dist = c_dbase[ds] + infl_take(b, c_dext[ds]);
-            if (b.bad || dist > outpos || outpos + len > blk.isize) { err = true; break; }
-            const uint32_t src = outpos - dist;
-            if (src + (dist < len ? dist : len) > fenced) { __threadfence(); fenced = outpos; }
-            for (uint32_t i = lane; i < len; i += 64) out[outpos + i] = out[src + (dist >= len ? i : i % dist)];
-            outpos += len;
-        }
-    }
-    if (err || outpos != blk.isize) { if (lane == 0) atomicOr(&flags[0], 512); }
-}
-
-// Lane-per-block variant: every lane of a wave decodes its own BGZF block (64 independent DEFLATE streams in lockstep),
-// so the vector unit takes 64 symbols per step instead of one.  Two kernels: k_inflate_lanes<true> turns the streams
-// into LZ77 tokens, k_lz_resolve (one wave per block, the 64 KiB window in LDS) turns the tokens into bytes.  The
-// one-kernel form k_inflate_lanes<false> (each lane also copies its matches, in global memory, eight bytes per step)
-// is kept behind SQUID_GPU_INFLATE_ONEPASS for comparison: a lane that reads back what it has just written makes the
-// whole wave wait for its stores.
-constexpr int IL_LB = 9, IL_DB = 7, IL_STAGE = 8;
+// DEFLATE is serial inside a block, so the parallelism is across blocks: every LANE of a wave decodes its own BGZF block (64
+// independent streams in lockstep; the vector unit takes 64 symbols per step).  Two kernels: k_inflate_tok2 turns the streams into
+// LZ77 tokens, k_lz_resolve2 (two waves per block, the 64 KiB window in LDS) turns the tokens into bytes -- a lane that reads back
+// what it has just written would make the whole wave wait for its stores, hence decoding and copying are apart.  (The round-1 /
+// early round-2 forms -- one wave per block, the table-driven lane kernel, the one-wave resolve -- are gone; `git log` has them.)
+__constant__ uint8_t c_clorder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};  // order of the code-length code lengths in a dynamic block header (RFC 1951)
+constexpr int IL_STAGE = 8;
+// headers are read and tables are built by every lane for itself, in lockstep with the other lanes that are at a block header: zlib
+// closes a block every 16383 symbols, so the lanes of a wave arrive together (a lane that is early waits up to IL_HDR_WAIT steps)
+constexpr int IL_HDR_WAIT = 48;
 // The compressed bytes of a lane go through a ring of IL_RING words in LDS (ring[(word % IL_RING) * 64], already offset
 // by the lane): the bit buffer refills from LDS, and the ring is topped up from global memory by all lanes in the same
 // step, when any of them runs low.  A load issued by one lane in one step would otherwise make the whole wave wait a
@@ -2081,323 +1849,9 @@ __device__ __forceinline__ uint32_t il_take(ILane& b, int k) {
 // Per-lane decoding tables, all in LDS and interleaved by lane (entry e of lane l at [e * 64 + l]); anything a lane
 // fetched from global memory would cost the whole wave a memory round trip per step, and with 64 streams some lane is on
 // the rare path nearly every step:
-//   literal/length code: two-level table as in zlib -- root[1 << IL_LB] (symbol << 4 | length, or 0x8000 | first
-//     sub-entry << 4 | sub-table bits) and sub[IL_SUB] (340 entries bound the sub-tables of a 9-bit root: zlib's ENOUGH);
-//   distance code (and the code-length code while a header is read): root[1 << IL_DB] plus the canonical decoder's
-//     cnt[16] / sym[32] / (first code, symbol index) after IL_DB lengths for the few longer codes.
-// Headers are read and tables are built by every lane for itself, in lockstep with the other lanes that are at a block
-// header: zlib closes a block every 16383 symbols and a lane takes one symbol per step, so the lanes of a wave arrive
-// together (a lane that is early waits up to IL_HDR_WAIT steps for company).
-constexpr int IL_SUB = 340, IL_LENS = 337, IL_CL_AT = 318, IL_HDR_WAIT = 48;  // (sizes to the byte: 160 KB of LDS per wave)
-struct ILds {
-    uint16_t *root_ll, *sub_ll, *root_dd, *cnt_dd, *sym_dd, *fst_dd, *tmp_a, *tmp_b;  // tmp_a/tmp_b: [16] per lane, builders' scratch
-    uint8_t* lens;  // [IL_LENS] per lane: code lengths 0..317, the code-length code's own lengths at IL_CL_AT..IL_CL_AT + 18
-};
-constexpr size_t IL_LDS_BYTES = (size_t)((1 << IL_LB) + IL_SUB + (1 << IL_DB) + 16 + 32 + 2 + 16 + 16) * 64 * sizeof(uint16_t) + (size_t)IL_LENS * 64 + (size_t)(IL_STAGE + IL_RING) * 64 * 4;
-__device__ __forceinline__ int il_decode_ll(ILane& b, const ILds& L, int lane) {
-    il_refill(b);
-    uint32_t e = L.root_ll[((uint32_t)b.buf & ((1u << IL_LB) - 1)) * 64 + lane];
-    if (e & 0x8000u) {
-        const uint32_t sb = e & 15, off = (e >> 4) & 0x7ff;
-        e = L.sub_ll[(off + ((uint32_t)(b.buf >> IL_LB) & ((1u << sb) - 1))) * 64 + lane];
-    }
-    const int l = e & 15;
-    if (!l) return -1;
-    b.buf >>= l; b.cnt -= l;
-    return (int)(e >> 4);
-}
-template <bool REFILL = true>
-__device__ __forceinline__ int il_decode_dd(ILane& b, const ILds& L, int lane) {
-    if (REFILL) il_refill(b);
-    const uint32_t root = (uint32_t)b.buf & ((1u << IL_DB) - 1);
-    const uint16_t e = L.root_dd[root * 64 + lane];
-    if (e & 15) { const int l = e & 15; b.buf >>= l; b.cnt -= l; return e >> 4; }
-    // longer than IL_DB bits: the canonical decoder, entered after IL_DB lengths
-    int code = (int)(__brev(root) >> (32 - IL_DB)) << 1, first = L.fst_dd[lane], index = L.fst_dd[64 + lane];
-    unsigned long long bb = b.buf >> IL_DB;
-    for (int len = IL_DB + 1; len <= 15; ++len) {
-        code |= (int)(bb & 1); bb >>= 1;
-        const int count = L.cnt_dd[len * 64 + lane];
-        if (code - count < first) { b.buf >>= len; b.cnt -= len; return L.sym_dd[(index + (code - first)) * 64 + lane]; }
-        index += count; first += count; first <<= 1; code <<= 1;
-    }
-    return -1;
-}
-// Builders: called by the lanes that are at a header (me), each for its own table; n and lo differ per lane, the loops
-// run to the longest.  Return false for an over-subscribed set of lengths.
-__device__ bool il_build_dd(const ILds& L, int lane, bool me, int lo, int n) {
-    uint16_t *cnt = L.cnt_dd + lane, *code = L.tmp_a + lane, *slot = L.tmp_b + lane;
-    const uint8_t* lens = L.lens + lane;
-    bool ok = true;
-    if (me) {
-        for (int l = 0; l < 16; ++l) cnt[l * 64] = 0;
-        for (int i = 0; i < n; ++i) { const int l = lens[(lo + i) * 64]; ++cnt[l * 64]; }
-        cnt[0] = 0;
-        int left = 1, c = 0, off = 0, first = 0, index = 0;
-        for (int l = 1; l <= 15; ++l) {
-            const int k = cnt[l * 64];
-            left <<= 1; left -= k; if (left < 0) ok = false;
-            c = (c + (l > 1 ? (int)cnt[(l - 1) * 64] : 0)) << 1;
-            code[l * 64] = (uint16_t)c; slot[l * 64] = (uint16_t)off;
-            off += k;
-            if (l <= IL_DB) { index += k; first += k; first <<= 1; }
-        }
-        L.fst_dd[lane] = (uint16_t)first; L.fst_dd[64 + lane] = (uint16_t)index;
-        for (int e = 0; e < (1 << IL_DB); ++e) L.root_dd[e * 64 + lane] = 0;
-        if (ok)
-            for (int i = 0; i < n; ++i) {
-                const int l = lens[(lo + i) * 64];
-                if (!l) continue;
-                const uint32_t c2 = code[l * 64]++; const int s2 = slot[l * 64]++;
-                L.sym_dd[s2 * 64 + lane] = (uint16_t)i;
-                if (l <= IL_DB) {
-                    const uint32_t rev = __brev(c2) >> (32 - l);
-                    for (uint32_t j = rev; j < (1u << IL_DB); j += 1u << l) L.root_dd[j * 64 + lane] = (uint16_t)((i << 4) | l);
-                }
-            }
-    }
-    return ok;
-}
-__device__ bool il_build_ll(const ILds& L, int lane, bool me, int n) {
-    uint16_t *cnt = L.tmp_a + lane, *code = L.tmp_b + lane, *root = L.root_ll + lane, *sub = L.sub_ll + lane;
-    const uint8_t* lens = L.lens + lane;
-    bool ok = true;
-    if (me) {
-        for (int l = 0; l < 16; ++l) cnt[l * 64] = 0;
-        for (int i = 0; i < n; ++i) { const int l = lens[i * 64]; ++cnt[l * 64]; }
-        cnt[0] = 0;
-        int left = 1;
-        for (int l = 1; l <= 15; ++l) { left <<= 1; left -= cnt[l * 64]; if (left < 0) ok = false; }
-        for (int e = 0; e < (1 << IL_LB); ++e) root[e * 64] = 0;
-        if (ok) {
-            // pass 1: codes of at most IL_LB bits fill the root; longer ones leave their length at their root slot
-            int c = 0;
-            for (int l = 1; l <= 15; ++l) { c = (c + (l > 1 ? (int)cnt[(l - 1) * 64] : 0)) << 1; code[l * 64] = (uint16_t)c; }
-            for (int i = 0; i < n; ++i) {
-                const int l = lens[i * 64];
-                if (!l) continue;
-                const uint32_t c2 = code[l * 64]++;
-                const uint32_t rev = __brev(c2) >> (32 - l);
-                if (l <= IL_LB)
-                    for (uint32_t j = rev; j < (1u << IL_LB); j += 1u << l) root[j * 64] = (uint16_t)((i << 4) | l);
-                else {
-                    const uint32_t r = rev & ((1u << IL_LB) - 1), m = root[r * 64] & 15u;
-                    if ((uint32_t)(l - IL_LB) > m) root[r * 64] = (uint16_t)(0x4000u | (uint32_t)(l - IL_LB));
-                }
-            }
-            // sub-tables: one per marked root slot, sized by the longest code below it
-            uint32_t off = 0;
-            for (int r = 0; r < (1 << IL_LB); ++r) {
-                const uint32_t e = root[r * 64];
-                if (e & 0x4000u) { const uint32_t sb = e & 15; root[r * 64] = (uint16_t)(0x8000u | (off << 4) | sb); off += 1u << sb; }
-            }
-            if (off > (uint32_t)IL_SUB) ok = false;
-            else {
-                for (uint32_t k = 0; k < off; ++k) sub[k * 64] = 0;
-                // pass 2: the long codes again, into their sub-tables
-                c = 0;
-                for (int l = 1; l <= 15; ++l) { c = (c + (l > 1 ? (int)cnt[(l - 1) * 64] : 0)) << 1; code[l * 64] = (uint16_t)c; }
-                for (int i = 0; i < n; ++i) {
-                    const int l = lens[i * 64];
-                    if (l <= IL_LB) continue;
-                    const uint32_t c2 = code[l * 64]++;
-                    const uint32_t rev = __brev(c2) >> (32 - l);
-                    const uint32_t e = root[(rev & ((1u << IL_LB) - 1)) * 64], sb = e & 15, o = (e >> 4) & 0x7ff;
-                    for (uint32_t j = rev >> IL_LB; j < (1u << sb); j += 1u << (l - IL_LB)) sub[(o + j) * 64] = (uint16_t)((i << 4) | l);
-                }
-            }
-        }
-    }
-    return ok;
-}
-// TOK: instead of the bytes, the lane writes its block's LZ77 tokens (a literal: the byte; a match: bit 31, length in bits
-// 16..24, distance - 1 in bits 0..14) at tok[uoff - out_base ...] and their number at ntok[block]; k_lz_resolve turns them
-// into bytes.  Decoding alone never reads what it wrote, so the lanes run without waiting for their stores.
-template <bool TOK>
-__global__ __launch_bounds__(64) void k_inflate_lanes(const uint8_t* file, const InflBlock* blocks, int nblocks, unsigned long long out_base, uint8_t* outbuf, int32_t* flags, uint32_t* tok, int32_t* ntok) {
-    extern __shared__ uint16_t il_lds[];  // IL_LDS_BYTES
-    __shared__ uint8_t sh_clo[32];
-    ILds L;
-    L.root_ll = il_lds;                          L.sub_ll = L.root_ll + (1 << IL_LB) * 64;
-    L.root_dd = L.sub_ll + IL_SUB * 64;          L.cnt_dd = L.root_dd + (1 << IL_DB) * 64;
-    L.sym_dd = L.cnt_dd + 16 * 64;               L.fst_dd = L.sym_dd + 32 * 64;
-    L.tmp_a = L.fst_dd + 2 * 64;                 L.tmp_b = L.tmp_a + 16 * 64;
-    L.lens = (uint8_t*)(L.tmp_b + 16 * 64);
-    uint32_t* stage = (uint32_t*)(L.lens + IL_LENS * 64);  // tokens on their way out: stage[(k % IL_STAGE) * 64 + lane]
-    uint32_t* ring = stage + IL_STAGE * 64;
-    const int lane = threadIdx.x;
-    if (lane < 19) sh_clo[lane] = c_clorder[lane];
-    wave_sync();
-    const int bi = blockIdx.x * 64 + lane;
-    const bool have = bi < nblocks;
-    InflBlock blk{0, 0, 0, 0};
-    if (have) blk = blocks[bi];
-    uint8_t* out = outbuf + (blk.uoff - out_base);
-    uint32_t* tk = TOK ? tok + (blk.uoff - out_base) : nullptr;
-    uint32_t nt = 0;
-    auto emit = [&](uint32_t v) {
-        stage[(nt % IL_STAGE) * 64 + lane] = v;
-        if ((++nt % IL_STAGE) == 0) {  // a full stage: IL_STAGE consecutive tokens in wide stores
-            uint32_t* dst = tk + nt - IL_STAGE;
-#pragma unroll
-            for (int q = 0; q < IL_STAGE; q += 4) {
-                uint4 w{stage[q * 64 + lane], stage[(q + 1) * 64 + lane], stage[(q + 2) * 64 + lane], stage[(q + 3) * 64 + lane]};
-                __builtin_memcpy(dst + q, &w, 16);
-            }
-        }
-    };
-    ILane b;
-    b.p = file + blk.coff; b.n = blk.clen; b.ring = ring + lane;
-    il_start(b, 0);
-    uint8_t* lens = L.lens + lane;
-    uint32_t outpos = 0, pend_len = 0, pend_src = 0;
-    bool done = !have || blk.isize == 0, err = false, in_block = false, last = false, stored = false;
-    uint32_t stored_left = 0, stored_at = 0;
-    int hdr_wait = 0;
-    uint32_t token = 0;       // what the step has decoded: stored at the top of the next step, where the lanes that took the
-    bool have_token = false;  // literal path and those that took the match path are together again (one copy of the store code)
-    while (__any(!done)) {
-        if (TOK && have_token) { emit(token); have_token = false; }
-        // ---- block headers, by all the lanes that are at one
-        const unsigned long long need = __ballot(!done && !in_block && !pend_len && !stored);
-        if (need && (need == __ballot(!done) || ++hdr_wait >= IL_HDR_WAIT)) {
-            hdr_wait = 0;
-            const bool me = (need >> lane) & 1;
-            int kind = -1, nlen = 0, ndist = 0;  // 0 stored, 1 fixed code, 2 dynamic code, -1 corrupt
-            if (me) {
-                if (il_low(b)) il_topup(b);
-                if (il_pos(b) <= b.n + 8) {
-                    last = il_take(b, 1);
-                    const uint32_t type = il_take(b, 2);
-                    if (type == 0) {
-                        b.buf >>= (b.cnt & 7); b.cnt -= (b.cnt & 7);
-                        const uint32_t len = il_take(b, 16), nl = il_take(b, 16);
-                        stored_at = il_pos(b) - (uint32_t)(b.cnt >> 3);
-                        if ((len ^ 0xffff) == nl && stored_at + len <= b.n && outpos + len <= blk.isize) {
-                            kind = 0;
-                            stored_left = len;
-                            if (len) stored = true; else { il_start(b, stored_at); if (last) done = true; }
-                        }
-                    } else if (type == 1) {
-                        for (int i = 0; i < 144; ++i) lens[i * 64] = 8;
-                        for (int i = 144; i < 256; ++i) lens[i * 64] = 9;
-                        for (int i = 256; i < 280; ++i) lens[i * 64] = 7;
-                        for (int i = 280; i < 288; ++i) lens[i * 64] = 8;
-                        for (int i = 0; i < 30; ++i) lens[(288 + i) * 64] = 5;
-                        kind = 1; nlen = 288; ndist = 30;
-                    } else if (type == 2) {
-                        nlen = (int)il_take(b, 5) + 257; ndist = (int)il_take(b, 5) + 1;
-                        const int ncode = (int)il_take(b, 4) + 4;
-                        if (nlen <= 286 && ndist <= 30) {
-                            for (int i = 0; i < 19; ++i) lens[(IL_CL_AT + i) * 64] = 0;
-                            for (int i = 0; i < ncode; ++i) lens[(IL_CL_AT + sh_clo[i]) * 64] = (uint8_t)il_take(b, 3);
-                            kind = 2;
-                        }
-                    }
-                }
-            }
-            if (__any(me && kind == 2)) {
-                // the code-length code (19 symbols) in the distance tables, then the literal/length + distance lengths with it
-                const bool dyn = me && kind == 2;
-                bool ok = il_build_dd(L, lane, dyn, IL_CL_AT, 19);
-                int idx = 0;
-                uint8_t prev = 0;
-                bool busy = dyn && ok;
-                while (__any(busy)) {
-                    if (busy) {
-                        if (il_low(b)) il_topup(b);
-                        const int sym = il_decode_dd(b, L, lane);
-                        if (sym < 0 || il_pos(b) > b.n + 8) { ok = false; busy = false; }
-                        else if (sym < 16) { lens[idx++ * 64] = (uint8_t)sym; prev = (uint8_t)sym; }
-                        else {
-                            int rep; uint8_t v = 0;
-                            if (sym == 16) { v = prev; rep = 3 + (int)il_take(b, 2); if (idx == 0) ok = false; }
-                            else if (sym == 17) rep = 3 + (int)il_take(b, 3);
-                            else rep = 11 + (int)il_take(b, 7);
-                            if (!ok || idx + rep > nlen + ndist) { ok = false; busy = false; }
-                            else { while (rep--) lens[idx++ * 64] = v; prev = v; }
-                        }
-                        if (busy && idx >= nlen + ndist) busy = false;
-                    }
-                }
-                if (dyn && ok && lens[256 * 64] == 0) ok = false;  // no end-of-block code
-                if (dyn && !ok) kind = -1;
-            }
-            if (__any(me && kind > 0)) {
-                const bool bld = me && kind > 0;
-                const bool ok_ll = il_build_ll(L, lane, bld, nlen), ok_dd = il_build_dd(L, lane, bld, nlen, ndist);
-                const bool ok = ok_ll && ok_dd;
-                if (bld && !ok) kind = -1;
-            }
-            if (me) { if (kind < 0) { err = true; done = true; } else if (kind > 0) in_block = true; }
-        }
-        if (__any(!done && il_low(b))) { if (!done) il_topup(b); }  // every lane, in the same step
-        if (done) continue;
-        if (!TOK && pend_len) {  // a slice of a pending match (source bytes were written by this lane)
-            // eight bytes per step: one wide load, one wide store (byte-wise, every byte waits for a memory round trip)
-            const uint32_t k = pend_len < 8 ? pend_len : 8, dist = outpos - pend_src;
-            unsigned long long w;
-            __builtin_memcpy(&w, out + pend_src, 8);  // (reads at most 7 bytes past what is written: inside the padded buffer)
-            if (dist < 8) {  // overlapping match: the first `dist` bytes repeat
-                unsigned long long r = 0;
-                for (uint32_t i = 0; i < 8; ++i) r |= ((w >> (8 * (i % dist))) & 0xffull) << (8 * i);
-                w = r;
-            }
-            if (k == 8) __builtin_memcpy(out + outpos, &w, 8);
-            else for (uint32_t i = 0; i < k; ++i) out[outpos + i] = (uint8_t)(w >> (8 * i));
-            outpos += k; pend_len -= k;
-            pend_src += k;  // (the distance stays the same: the next slice again starts from `dist` valid bytes)
-            continue;
-        }
-        if (stored) {  // a slice of a stored block
-            const uint32_t k = stored_left < 16 ? stored_left : 16;
-            if (TOK) for (uint32_t i = 0; i < k; ++i) emit(b.p[stored_at + i]);
-            else for (uint32_t i = 0; i < k; ++i) out[outpos + i] = b.p[stored_at + i];
-            outpos += k; stored_at += k; stored_left -= k;
-            if (!stored_left) { stored = false; il_start(b, stored_at); if (last) done = true; }
-            continue;
-        }
-        if (!in_block) continue;  // (waiting at a header)
-        // one symbol
-        const int sym = il_decode_ll(b, L, lane);
-        if (sym < 0 || il_pos(b) > b.n + 8) { err = true; done = true; continue; }
-        if (sym < 256) {
-            if (outpos >= blk.isize) { err = true; done = true; continue; }
-            if (TOK) { token = (uint32_t)sym; have_token = true; ++outpos; } else out[outpos++] = (uint8_t)sym;
-            continue;
-        }
-        if (sym == 256) { in_block = false; if (last) done = true; continue; }
-        const int ls = sym - 257;
-        if (ls >= 29) { err = true; done = true; continue; }
-        // base and extra bits of the length / distance symbol by arithmetic (RFC 1951 3.2.5: four symbols per extra-bit count,
-        // two for distances) rather than from tables: every table lookup is an LDS round trip in the longest path of the step.
-        // One refill covers the rest of the step: 5 + 15 + 13 bits at most.
-        il_refill(b);
-        const uint32_t lx = ls < 8 || ls == 28 ? 0u : (uint32_t)(ls - 4) >> 2;
-        const uint32_t lbase = ls < 8 ? 3u + (uint32_t)ls : (ls == 28 ? 258u : 3u + ((4u + ((uint32_t)ls & 3u)) << lx));
-        const uint32_t len = lbase + ((uint32_t)b.buf & ((1u << lx) - 1));
-        b.buf >>= lx; b.cnt -= (int)lx;
-        const int ds = il_decode_dd<false>(b, L, lane);
-        if (ds < 0 || ds >= 30) { err = true; done = true; continue; }
-        const uint32_t dx = ds < 4 ? 0u : (uint32_t)(ds - 2) >> 1;
-        const uint32_t dbase = ds < 4 ? 1u + (uint32_t)ds : 1u + ((2u + ((uint32_t)ds & 1u)) << dx);
-        const uint32_t dist = dbase + ((uint32_t)b.buf & ((1u << dx) - 1));
-        b.buf >>= dx; b.cnt -= (int)dx;
-        if (dist > outpos || outpos + len > blk.isize) { err = true; done = true; continue; }
-        if (TOK) { token = 0x80000000u | (len << 16) | (dist - 1); have_token = true; outpos += len; }
-        else { pend_len = len; pend_src = outpos - dist; }
-    }
-    if (TOK && have_token) emit(token);
-    if (have && (err || outpos != blk.isize)) atomicOr(&flags[0], 512);
-    if (TOK && have) {
-        for (uint32_t k = nt - nt % IL_STAGE; k < nt; ++k) tk[k] = stage[(k % IL_STAGE) * 64 + lane];
-        ntok[bi] = (int32_t)nt;
-    }
-}
-
-// ---- The token pass, second form (default): canonical Huffman decoding with the code limits in REGISTERS.
-// k_inflate_lanes keeps two-level lookup tables per lane -- 2.5 KB, 160 KB per wave, ONE wave per CU -- and every step is a chain
-// of dependent LDS round trips with nobody to hide them.  A canonical code needs no table of codes: with the next 15 bits of
+// ---- The token pass: canonical Huffman decoding with the code limits in REGISTERS.
+// (Two-level lookup tables per lane as in zlib cost 2.5 KB per lane, 160 KB per wave, ONE wave per CU, and every step was a chain
+// of dependent LDS round trips with nobody to hide them: round 1.)  A canonical code needs no table of codes: with the next 15 bits of
 // the stream read MSB-first as a number v, the codes of length L occupy [first[L] << (15 - L), (first[L] + count[L]) << (15 - L)),
 // ranges that ascend with L.  So the length of the next code is 1 + #{L : v >= limit[L]} -- fourteen compares against values
 // that live in 15 registers per code (literal/length and distance) -- and the symbol is sym[(v >> (15 - len)) + K[len]].  What
@@ -2712,78 +2166,6 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
 // their lengths places them, literals are stored at once, and the matches copy in as few sub-rounds as their dependencies
 // allow -- a match is ready when its source lies below the output of the first match still pending (everything below
 // that is final); a match overlapping its own output only needs the bytes in front of it, its pattern repeats.
-__global__ __launch_bounds__(64) void k_lz_resolve(const uint32_t* tok, const int32_t* ntok, const InflBlock* blocks, int nblocks, unsigned long long out_base, uint8_t* outbuf, int32_t* flags) {
-    extern __shared__ uint8_t lz_win[];
-    const int lane = threadIdx.x;
-    const InflBlock blk = blocks[blockIdx.x];
-    const uint32_t* t = tok + (blk.uoff - out_base);
-    const int n = ntok[blockIdx.x];
-    uint32_t base = 0;
-    uint32_t nxt = lane < n ? t[lane] : 0;
-    bool bad = false;
-    for (int r0 = 0; r0 < n; r0 += 64) {
-        const uint32_t tk = nxt;
-        const int i = r0 + lane;
-        if (i + 64 < n) nxt = t[i + 64];
-        const bool valid = i < n, is_m = valid && (tk >> 31);
-        const uint32_t nl = (tk >> 24) & 3u;  // a literal token carries 1..3 bytes (0 stands for 1: the one-literal tokens of the first token pass)
-        const uint32_t len = !valid ? 0u : (is_m ? (tk >> 16) & 0x1ffu : (nl ? nl : 1u));
-        const uint32_t inc = wave_scan_incl(len);
-        const uint32_t o = base + inc - len;
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-        if (base + total > blk.isize) { bad = true; break; }  // (uniform)
-        if (valid && !is_m) { lz_win[o] = (uint8_t)tk; if (len > 1) lz_win[o + 1] = (uint8_t)(tk >> 8); if (len > 2) lz_win[o + 2] = (uint8_t)(tk >> 16); }
-        const uint32_t dist = (tk & 0x7fffu) + 1;
-        bool pending = is_m;
-        if (pending && dist > o) { bad = true; pending = false; }
-        const uint32_t src = o - dist;
-        const uint32_t ready_at = src + len < o ? src + len : o;  // the match needs the bytes below this
-        unsigned long long pm = __ballot(pending);
-        while (pm) {
-            const int first = __ffsll((long long)pm) - 1;
-            const uint32_t hwm = (uint32_t)__builtin_amdgcn_readlane((int)o, __builtin_amdgcn_readfirstlane(first));
-            wave_sync();
-            if (pending && ready_at <= hwm) {
-                if (dist >= 8) {  // eight bytes per load and store (the source of a slice lies at least 8 bytes below its target)
-                    uint32_t k = 0;
-                    for (; k + 8 <= len; k += 8) { unsigned long long w; __builtin_memcpy(&w, lz_win + src + k, 8); __builtin_memcpy(lz_win + o + k, &w, 8); }
-                    for (; k < len; ++k) lz_win[o + k] = lz_win[src + k];
-                    pending = false;
-                }
-                // every byte comes from [src, src + min(dist, len)): final, so the reads of a slice go out together
-                uint32_t j = 0;  // k mod dist
-                for (uint32_t k = 0; pending && k < len; k += 8) {
-                    uint8_t v[8];
-                    uint32_t jj = j;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) { v[q] = lz_win[src + jj]; if (++jj == dist) jj = 0; }
-                    j = jj;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) if (k + q < len) lz_win[o + k + q] = v[q];
-                }
-                pending = false;
-            }
-            pm = __ballot(pending);
-        }
-        base += total;
-    }
-    if (__any(bad) || base != blk.isize) { if (lane == 0) atomicOr(&flags[0], 512); return; }
-    wave_sync();
-    uint8_t* out = outbuf + (blk.uoff - out_base);
-    if ((((uintptr_t)out) & 15) == 0) {
-        const uint32_t words = blk.isize >> 4;
-        for (uint32_t w = lane; w < words; w += 64) ((uint4*)out)[w] = ((const uint4*)lz_win)[w];
-        for (uint32_t k = (words << 4) + lane; k < blk.isize; k += 64) out[k] = lz_win[k];
-    } else
-        for (uint32_t k = lane; k < blk.isize; k += 64) out[k] = lz_win[k];
-}
-
-// The same with TWO waves per block, taking turns.  A round has two halves: (1) fetch 64 tokens, prefix-sum their lengths, store
-// the literals -- needs only where the round's output starts; (2) copy the matches -- needs everything the rounds before have
-// produced.  A wave that is alone on its SIMD pays every dependent instruction in full, and (2) is three times as long as (1);
-// so wave A copies the matches of round r while wave B prepares round r + 1 (its literals land behind everything round r
-// writes), one barrier, then B copies and A prepares round r + 2.  Same window, same LDS, the preparation of every round
-// hidden behind the copies of the one before.
 __global__ __launch_bounds__(128) void k_lz_resolve2(const uint32_t* tok, const int32_t* ntok, const InflBlock* blocks, int nblocks, unsigned long long out_base, uint8_t* outbuf, int32_t* flags) {
     extern __shared__ uint8_t lz_win[];
     __shared__ uint32_t s_base[2];  // [r & 1]: where the output of round r starts (written by the wave that prepares round r - 1 ... see below)
@@ -3262,17 +2644,12 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     // a batch = 256 waves of the token pass (1 GiB inflated): the token workgroups take two waves of every CU (see k_inflate_tok2),
     // 512 in all, so two batches fill the machine exactly; measured at C3: 512 MB 303 ms, 720 MB 238, 1 GiB 233, 1.4 GB 244, 2 GB 256
     const unsigned long long cap = std::getenv("SQUID_TOK_CAP_MB") ? (unsigned long long)std::atoll(std::getenv("SQUID_TOK_CAP_MB")) << 20 : 256ull * 64 * 65536;
-    const int variant = std::getenv("SQUID_GPU_INFLATE_WAVE") ? 2 : (std::getenv("SQUID_GPU_INFLATE_ONEPASS") ? 1 : 0);  // 0: tokens + resolve
-    HIPCHK(hipFuncSetAttribute((const void*)k_inflate_lanes<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)IL_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void*)k_inflate_lanes<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)IL_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void*)k_lz_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16));
     HIPCHK(hipFuncSetAttribute((const void*)k_lz_resolve2, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16));
     HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)T2_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)T2_LDS_BYTES));
     static const int tok_wpb = std::getenv("SQUID_TOK_WPB") ? std::max(1, std::min(2, std::atoi(std::getenv("SQUID_TOK_WPB")))) : 2;  // token waves per workgroup
     static const bool tok_prof = std::getenv("SQUID_TOK_PROF") != nullptr;
     if (tok_prof) HIPCHK(D.tok_prof.reserve(8 * 4096));
-    static const bool tok_v1 = std::getenv("SQUID_TOK_V1") != nullptr;  // the table-driven token pass (one wave per CU), kept for comparison
     for (auto& q : D.il_stream)
         if (!q) {
             // lowest priority: a token wave holds its CU for tens of milliseconds, and the resolve / boundary / parse kernels
@@ -3326,7 +2703,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         if (!plan(k)) return SQ_OK;
         const Batch B = batches[k];
         DeviceRecords::InflSet& st = D.il_set[k % DeviceRecords::IL_DEPTH];
-        hipStream_t sa = variant == 0 ? D.il_stream[k % DeviceRecords::IL_DEPTH] : s;  // (the other forms write the bytes themselves: one stream)
+        hipStream_t sa = D.il_stream[k % DeviceRecords::IL_DEPTH];
         const int nb = (int)(B.end - B.at);
         // largest compressed blocks first: the lanes of a wave get blocks of similar length (a wave takes as long as its
         // longest lane) and the long waves start first
@@ -3343,21 +2720,15 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         if (!dfile) HIPCHK(st.in.reserve(std::max((size_t)B.cbytes, (size_t)(cratio * 1.1 * (double)full)) + 256));  // (the input rings read up to 80 bytes ahead)
         st.src = dfile ? dfile + B.coff0 : st.in.p;
         HIPCHK(st.tab.reserve(std::max((size_t)nb, (size_t)(full / 60000)))); HIPCHK(st.flags.reserve(4));
-        if (variant == 0) { HIPCHK(st.tok.reserve((size_t)full + 64)); HIPCHK(st.ntok.reserve(std::max((size_t)nb, (size_t)(full / 60000)))); }
+        HIPCHK(st.tok.reserve((size_t)full + 64)); HIPCHK(st.ntok.reserve(std::max((size_t)nb, (size_t)(full / 60000))));
         const double wa1 = since_ms(wa0);
         if (!dfile) HIPCHK(hipMemcpyAsync(st.in.p, file + B.coff0, (size_t)B.cbytes, hipMemcpyHostToDevice, sa));
         if (report && k < 3) std::fprintf(stderr, "GPU ingest: batch %zu planned at %.1f ms, buffers %.1f ms, copy of %.2f GB returned after %.1f ms\n", k, std::chrono::duration<double, std::milli>(wa0 - w0).count(), wa1, (double)B.cbytes * 1e-9, since_ms(wa0) - wa1);
         HIPCHK(hipMemcpyAsync(st.tab.p, st.host_tab.data(), (size_t)nb * sizeof(InflBlock), hipMemcpyHostToDevice, sa));
         HIPCHK(hipMemsetAsync(st.flags.p, 0, 4 * 4, sa));
-        if (variant == 0 && tok_v1) {  // (one table-driven token kernel at a time: its waves fill a CU's LDS each)
-            HIPCHK(hipEventRecord(st.copied, sa));
-            sa = D.il_tok_stream;
-            HIPCHK(hipStreamWaitEvent(sa, st.copied, 0));
-        }
-        if (variant == 0) {  // k_inflate_tok2 stays on the set's own stream: the token kernels of up to four batches run side by side
+        {   // k_inflate_tok2 stays on the set's own stream: the token kernels of up to four batches run side by side
             EvTimer t1(c, "k_inflate_tok2", (double)B.cbytes + (double)B.bbytes * 2, sa);
-            if (tok_v1) hipLaunchKernelGGL(k_inflate_lanes<true>, dim3((nb + 63) / 64), dim3(64), IL_LDS_BYTES, sa, st.src, st.tab.p, nb, B.bbase, nullptr, st.flags.p, st.tok.p, st.ntok.p);
-            else if (tok_prof && k == 8) hipLaunchKernelGGL(k_inflate_tok2<true>, dim3((nb + 63) / 64), dim3(64), T2_LDS_BYTES, sa, st.src, st.tab.p, nb, B.bbase, st.flags.p, st.tok.p, st.ntok.p, D.tok_prof.p);
+            if (tok_prof && k == 8) hipLaunchKernelGGL(k_inflate_tok2<true>, dim3((nb + 63) / 64), dim3(64), T2_LDS_BYTES, sa, st.src, st.tab.p, nb, B.bbase, st.flags.p, st.tok.p, st.ntok.p, D.tok_prof.p);
             else hipLaunchKernelGGL(k_inflate_tok2<false>, dim3(((nb + 63) / 64 + tok_wpb - 1) / tok_wpb), dim3(64 * tok_wpb), tok_wpb * T2_LDS_BYTES, sa, st.src, st.tab.p, nb, B.bbase, st.flags.p, st.tok.p, st.ntok.p, nullptr);
         }
         HIPCHK(hipEventRecord(st.ready, sa));
@@ -3371,7 +2742,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         helper.f = std::async(std::launch::async, [&stage_a, c, k]() { if (hipSetDevice(c->P.device) != hipSuccess) return (int)SQ_E_HIP; return stage_a(k); });
         return SQ_OK;
     };
-    const size_t look = tok_v1 ? 2 : (size_t)DeviceRecords::IL_DEPTH - 1;  // batches queued ahead of the one being resolved
+    const size_t look = (size_t)DeviceRecords::IL_DEPTH - 1;  // batches queued ahead of the one being resolved
     { int rc = stage_a(0); if (rc) return rc; }
     for (size_t j = 1; j < look; ++j) { int rc = stage_a_async(j); if (rc) return rc; }
     const double w_first = since_ms(w0);
@@ -3401,17 +2772,9 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         if (carry_in) HIPCHK(hipMemcpyAsync(P.out.p + F.pad, carry_src, (size_t)carry_in, hipMemcpyDeviceToDevice, s));
         uint8_t* out = P.out.p + F.pad + carry_in;
         HIPCHK(hipStreamWaitEvent(s, st.ready, 0));
-        if (variant == 2) {  // one wave per block (the first version)
-            EvTimer t(c, "k_inflate", (double)B.cbytes + (double)B.bbytes);
-            hipLaunchKernelGGL(k_inflate, dim3((nb + 3) / 4), dim3(256), 0, s, st.src, st.tab.p, 0, nb, B.bbase, out, P.flags.p);
-        } else if (variant == 1) {
-            EvTimer t(c, "k_inflate", (double)B.cbytes + (double)B.bbytes);
-            hipLaunchKernelGGL(k_inflate_lanes<false>, dim3((nb + 63) / 64), dim3(64), IL_LDS_BYTES, s, st.src, st.tab.p, nb, B.bbase, out, P.flags.p, nullptr, nullptr);
-        } else {
+        {
             EvTimer t2(c, "k_lz_resolve2", (double)B.bbytes * 3);
-            static const bool one_wave = std::getenv("SQUID_RESOLVE_1WAVE") != nullptr;  // one wave per block (round 1), for comparison
-            if (one_wave) hipLaunchKernelGGL(k_lz_resolve, dim3(nb), dim3(64), 65536 + 16, s, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, out, P.flags.p);
-            else hipLaunchKernelGGL(k_lz_resolve2, dim3(nb), dim3(128), 65536 + 16, s, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, out, P.flags.p);
+            hipLaunchKernelGGL(k_lz_resolve2, dim3(nb), dim3(128), 65536 + 16, s, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, out, P.flags.p);
         }
         HIPCHK(hipEventRecord(st.freed, s));
         F.S = RecScan{P.out.p, k == 0 ? (unsigned long long)begin : F.pad, F.limit, nref, sh.on ? sh.first_ref : -1, sh.on ? sh.end_ref : 0, (sh.on && c->P.rank == c->P.world_size - 1) ? 1 : 0};

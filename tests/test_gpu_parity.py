@@ -727,8 +727,8 @@ def _rebgzf(src, dst, plan):
 
 
 def test_gpu_bgzf_inflate_and_boundary_search_give_the_same_records(built, synth, tmp_path):
-    """SQUID_GPU_INFLATE=1: BGZF blocks inflated by k_inflate_lanes + k_lz_resolve, record boundaries found by k_rec_*,
-    against the default host pipeline -- identical SoA.  Also: one block per token batch, the one-kernel forms, and the
+    """SQUID_GPU_INFLATE=1: BGZF blocks inflated by k_inflate_tok2 + k_lz_resolve2, record boundaries found by k_rec_*,
+    against the default host pipeline -- identical SoA.  Also: one block per token batch, single-wave token workgroups, and the
     same file rewritten with stored blocks, the fixed Huffman code, and all block types mixed inside one wave"""
     import json
     import os
@@ -750,8 +750,7 @@ def test_gpu_bgzf_inflate_and_boundary_search_give_the_same_records(built, synth
     gpu = {"SQUID_GPU_INFLATE": "1", "SQUID_INGEST_TIMING": "1"}
     assert run(f"{pre}.bam", gpu) == want
     assert run(f"{pre}.bam", dict(gpu, SQUID_TOK_CAP_MB="0")) == want
-    assert run(f"{pre}.bam", dict(gpu, SQUID_GPU_INFLATE_ONEPASS="1")) == want
-    assert run(f"{pre}.bam", dict(gpu, SQUID_GPU_INFLATE_WAVE="1")) == want
+    assert run(f"{pre}.bam", dict(gpu, SQUID_TOK_WPB="1")) == want
     # a chromosome shard reads a block range that starts and ends inside records
     names, _ = squid_amd.read_header(f"{pre}.bam")
     n = len(names)
@@ -764,8 +763,6 @@ def test_gpu_bgzf_inflate_and_boundary_search_give_the_same_records(built, synth
         assert run(f"{pre}.bam", gpu, shard, ctx) == want_shard, shard
         assert run(f"{pre}.bam", dict(gpu, SQUID_TOK_CAP_MB="0"), shard, ctx) == want_shard, shard
         assert run(f"{pre}.bam", dict(gpu, SQUID_NO_BAI="1"), shard, ctx) == want_shard, shard   # without the index: block range by probing
-        assert run(f"{pre}.bam", dict(gpu, SQUID_TOK_V1="1"), shard, ctx) == want_shard, shard    # the table-driven token pass
-    assert run(f"{pre}.bam", dict(gpu, SQUID_TOK_V1="1")) == want
     plans = {
         "stored": lambda i: (0, zlib.Z_DEFAULT_STRATEGY),
         "fixed": lambda i: (6, zlib.Z_FIXED),
@@ -776,11 +773,11 @@ def test_gpu_bgzf_inflate_and_boundary_search_give_the_same_records(built, synth
         _rebgzf(f"{pre}.bam", alt, plan)
         assert run(alt, {}) == want, name
         assert run(alt, gpu) == want, name
-        assert run(alt, dict(gpu, SQUID_GPU_INFLATE_ONEPASS="1")) == want, name
+        assert run(alt, dict(gpu, SQUID_TOK_WPB="1")) == want, name
 
 
 def test_gpu_reader_end_to_end_against_the_oracle(built, synth, tmp_path):
-    """the GPU reader (k_inflate_tok2 / k_inflate_lanes, k_lz_resolve, k_rec_*, K0) feeding the whole pipeline, checked against the
+    """the GPU reader (k_inflate_tok2, k_lz_resolve2, k_rec_*, K0) feeding the whole pipeline, checked against the
     ORACLE (which reads the files with its own zlib-based BAM reader) -- not only against the library's host reader: `squid`
     with SQUID_GPU_INFLATE=1 on the generator's file and on the same records re-compressed as stored blocks, with the fixed
     Huffman code and with every block type mixed inside one wave; _sv.txt and _graph.txt byte for byte"""
@@ -801,7 +798,7 @@ def test_gpu_reader_end_to_end_against_the_oracle(built, synth, tmp_path):
         if plan is not None:
             bam = tmp_path / f"{name}.bam"
             _rebgzf(f"{pre}.bam", bam, plan)
-        for env in ({"SQUID_GPU_INFLATE": "1"}, {"SQUID_GPU_INFLATE": "1", "SQUID_TOK_V1": "1"}):
+        for env in ({"SQUID_GPU_INFLATE": "1"}, {"SQUID_GPU_INFLATE": "1", "SQUID_TOK_WPB": "1"}):
             out = tmp_path / f"gpu_{name}_{len(env)}"
             subprocess.run([str(built / "squid"), "-b", str(bam), "-c", f"{pre}.chim.bam", "-o", str(out), "-G", "1"], check=True, env=dict(os.environ, **env),
                            stdout=subprocess.DEVNULL)
