@@ -9,7 +9,7 @@ CXX ?= g++
 ARCH ?= gfx950
 B := build
 CSRC := squid_amd/csrc
-LIBSRC := $(CSRC)/sq_kernels.hip $(CSRC)/sq_bam.cpp $(CSRC)/sq_chimeric.cpp $(CSRC)/sq_segment.cpp $(CSRC)/sq_graph.cpp $(CSRC)/sq_order.cpp $(CSRC)/sq_capi.cpp
+LIBSRC := $(CSRC)/sq_kernels.hip $(CSRC)/sq_bam.cpp $(CSRC)/sq_chimeric.cpp $(CSRC)/sq_segment.cpp $(CSRC)/sq_graph.cpp $(CSRC)/sq_order.cpp $(CSRC)/sq_exchange.cpp $(CSRC)/sq_capi.cpp
 
 all: $(B)/libsquid_hip.so $(B)/squid $(B)/squid_annotate $(B)/gen_synth_bam $(B)/squid_oracle $(B)/oracle_singlebamrec ref
 
@@ -20,7 +20,7 @@ ref:
 
 $(B)/libsquid_hip.so: $(LIBSRC) $(CSRC)/sq_internal.h $(CSRC)/sq_graph_kernels.inc $(CSRC)/sq_pass_kernels.inc include/squid_hip.h
 	mkdir -p $(B)
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function -o $@ $(LIBSRC) -lz -lpthread -ldl
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function -o $@ $(LIBSRC) -lz -lpthread -ldl -lrccl
 
 $(B)/squid: $(CSRC)/squid_main.cpp $(B)/libsquid_hip.so include/squid_hip.h
 	$(HIPCC) -O2 -std=c++17 -o $@ $(CSRC)/squid_main.cpp -L$(B) -lsquid_hip -Wl,-rpath,'$$ORIGIN'

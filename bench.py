@@ -184,17 +184,28 @@ def main() -> None:
     exchange, plan = None, None
     host_threads = max(1, (os.cpu_count() or 8) // max(1, world))
 
+    x_stats = [0, 0]  # all-gathers and payload bytes of the contexts closed so far
+
     def new_context():
         if sharded:
-            return squid_amd.Context(device=local_rank, rank=rank, world_size=world, exchange=exchange, **params)
+            from squid_amd.dist import install_native_exchange
+
+            c2 = squid_amd.Context(device=local_rank, rank=rank, world_size=world, **params)
+            install_native_exchange(c2, dist, dist.get_backend())  # sq_exchange: RCCL inside the library (nccl), or a gloo all-gather as its transport
+            return c2
         return squid_amd.Context(device=local_rank, **params)
 
+    def close_context(c2):
+        if sharded:
+            n, b = c2.exchange_stats()
+            x_stats[0] += n; x_stats[1] += b
+        c2.close()
+
     if sharded:
-        from squid_amd.dist import TorchExchange, plan_shards, shard_weights
+        from squid_amd.dist import plan_shards, shard_weights
 
         _, ref_len = squid_amd.read_header(bam)
         plan = plan_shards(shard_weights(bam, ref_len), world)  # balanced by compressed bytes per chromosome (from the .bai), else by reference length
-        exchange = TorchExchange(dist, device="cuda" if dist.get_backend() == "nccl" else "cpu")
     ctx = new_context()
     sv_path = work / f"bench_rank{rank}_sv.txt"
     comp_sizes = None
@@ -248,7 +259,7 @@ def main() -> None:
     # ---- the same step from the file in the page cache, nothing kept from earlier reads: the mapping and the block index are dropped
     # before every step (page-table fill + BGZF header walk + host -> device copy of the compressed bytes inside the step), in a
     # fresh context and AFTER the timed region
-    ctx.close()
+    close_context(ctx)
     ctx = new_context()
     squid_amd.drop_file_cache()
     step()
@@ -270,11 +281,16 @@ def main() -> None:
     t_file, total_conc = reduce_timing(t_file, float(n_conc), dist, device="cuda")
     t_res, total_blk = reduce_timing(t_res, float(n_blk), dist, device="cuda")
     if rank != 0:
-        ctx.close()
+        close_context(ctx)
         if dist:
             dist.destroy_process_group()
         return
 
+    n_passes = a.steps + a.warmup + n_file_steps + 1 + a.resident_steps
+    x_all = list(x_stats)
+    if sharded:
+        n_, b_ = ctx.exchange_stats()
+        x_all = [x_stats[0] + n_, x_stats[1] + b_]
     value = total_aln * a.steps / elapsed
     R = max(1, a.resident_steps)
     # the record-streaming kernels of the graph pass (K1-K5, K10), by accumulated HIP-event time on the library stream
@@ -309,7 +325,7 @@ def main() -> None:
         "dtype": "int32", "data": "synthetic",
         "config": {"workload": f"{a.workload}: " + WORKLOADS.get(a.workload, "generator config " + a.workload) + (f", --records {a.records}" if a.records else "") + (f", --tsv {a.tsv}" if a.tsv else ""),
                    "records": int(total_aln), "records_per_gpu": int(total_aln / world), "blocks_per_record": round(bbar, 4), "flags": " ".join(cli_flags) or "defaults",
-                   "parallelism": ("one sample sharded by chromosome over %d ranks, %d all-gathers (%.0f bytes) per step" % (world, exchange.calls // max(1, a.steps + a.warmup + n_file_steps + 1 + a.resident_steps), exchange.bytes / max(1, exchange.calls)) if sharded else "1 sample per GPU, no collective") if world > 1 else "single GPU",
+                   "parallelism": ("one sample sharded by chromosome over %d ranks, %.1f all-gathers (%.0f payload bytes) per step inside the library (sq_exchange over %s)" % (world, x_all[0] / max(1, n_passes), x_all[1] / max(1, n_passes), "RCCL" if dist.get_backend() == "nccl" else dist.get_backend()) if sharded else "1 sample per GPU, no collective") if world > 1 else "single GPU",
                    "step": "chimeric BAM decode (host) + concordant BAM decode on the GPU (BGZF inflate, record boundaries, record parse) + graph + ordering + SV calls + _sv.txt written; compressed BAM bytes resident in HBM at the start of every step"},
         "sv_sha256": digests[0], "sv_rows": text.count("\n") - 1, "steps_identical": True,
         "roofline": {"bound": "hbm", "kernel": "record-streaming kernels of one graph pass: " + " + ".join(sorted(gk_all, key=lambda k: -gk_all[k]["ms"])),
@@ -346,7 +362,7 @@ def main() -> None:
                              "ccs_per_s_ordering_stage": len(comp_sizes) / (order_ms * 1e-3) if order_ms > 0 else None,
                              "ccs_per_s_whole_step": len(comp_sizes) * a.steps / elapsed, "ordering_ms_per_pass": order_ms,
                              "n_order_unsolved": int(counts["n_order_unsolved"])}
-    ctx.close()
+    close_context(ctx)
     if not a.no_cold_cli and world == 1:
         # what a user runs once: a fresh process, nothing staged, nothing cached inside the process (the page cache is warm)
         cold_pre = work / "cold_cli"

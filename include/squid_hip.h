@@ -190,6 +190,23 @@ int sq_breakpoints(sq_ctx* c, sq_bp_table* t);
 int sq_set_shard(sq_ctx* c, int32_t first_ref, int32_t end_ref);
 int sq_exchange_pack(sq_ctx* c, const void** buf, int64_t* nbytes);
 int sq_exchange_unpack(sq_ctx* c, const void* gathered, const int64_t* nbytes_per_rank, int32_t world_size);
+/* The same exchange carried out by the library (SURVEY.md section 8(b) `sq_exchange(ctx, comm)`, 8(e) "one RCCL all-gather over xGMI"):
+ * after SQ_NEED_EXCHANGE call sq_exchange, then the stage function again -- no pack / unpack in the caller.  The transport is installed
+ * once per context:
+ *   sq_rccl_init    rank 0 makes an id with sq_rccl_unique_id (128 bytes) and gets it to the other ranks by any means; every rank
+ *                   passes it in and joins a communicator of sq_params.world_size ranks as sq_params.rank (ncclCommInitRank);
+ *   sq_rccl_attach  a communicator (ncclComm_t) the caller already has; it stays the caller's;
+ *   sq_set_allgather any fixed-size all-gather of host buffers: fn(user, send, nbytes, recv) fills recv with the world_size pieces
+ *                   in rank order and returns 0 (MPI_Allgather, a gloo shim in the tests).
+ * An exchange is ONE all-gather of 16 KiB pieces (length + payload; stream boundaries, seed nodes and breakpoint counts fit); only a
+ * payload beyond that -- the node sums and reduced edges of a large graph -- takes a second one for the remainders. */
+typedef int (*sq_allgather_fn)(void* user, const void* send, int64_t nbytes, void* recv);
+int sq_set_allgather(sq_ctx* c, sq_allgather_fn fn, void* user);
+int sq_rccl_unique_id(void* id128);
+int sq_rccl_init(sq_ctx* c, const void* id128);
+int sq_rccl_attach(sq_ctx* c, void* nccl_comm);
+int sq_exchange(sq_ctx* c);
+int sq_exchange_stats(sq_ctx* c, int64_t* collectives, int64_t* bytes); /* all-gathers issued by sq_exchange so far, payload bytes received */
 
 /* Timing of the last sq_build_graph/sq_order/sq_call_sv on this context, measured with HIP events on the
  * library's own stream.  names[i] is a static string; ms[i] the accumulated duration; launches[i] the count. */

@@ -21,6 +21,7 @@ EXPORTS = [
     "sq_ingest_chimeric", "sq_chim_contains", "sq_ingest_concordant", "sq_ingest_concordant_bam", "sq_read_header", "sq_ingest_chimeric_file",
     "sq_ingest_concordant_file", "sq_build_graph", "sq_graph_view", "sq_order", "sq_call_sv", "sq_breakpoints",
     "sq_set_shard", "sq_exchange_pack", "sq_exchange_unpack", "sq_get_timing", "sq_timing_accumulate", "sq_reset", "sq_ingest_files", "sq_stage_bam", "sq_clear_records", "sq_set_source", "sq_save_records", "sq_load_records", "sq_get_counts", "sq_debug_download", "sq_debug_bp_support", "sq_debug_order", "sq_debug_blocks", "sq_drop_file_cache",
+    "sq_set_allgather", "sq_rccl_unique_id", "sq_rccl_init", "sq_rccl_attach", "sq_exchange", "sq_exchange_stats",
 ]
 
 
@@ -121,6 +122,15 @@ def load_library() -> C.CDLL:
         lib.sq_exchange_unpack.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.c_int32]
         _lib = lib
     return _lib
+
+
+def rccl_unique_id() -> bytes:
+    """128 bytes that let world_size ranks join one RCCL communicator (rank 0 makes them, everybody passes them to Context.rccl_init)"""
+    buf = C.create_string_buffer(128)
+    rc = load_library().sq_rccl_unique_id(buf)
+    if rc:
+        raise SquidError("sq_rccl_unique_id failed")
+    return buf.raw
 
 
 def drop_file_cache():
@@ -234,7 +244,37 @@ class Context:
                 return
             if self.exchange is None:
                 raise SquidError(f"{what}: sharded context without an exchange callable")
-            self.exchange_unpack(self.exchange(self.exchange_pack()))
+            if self.exchange == "native":  # the library all-gathers itself (sq_exchange: RCCL, or the installed all-gather)
+                self._chk(self.lib.sq_exchange(self.h), "sq_exchange")
+            else:
+                self.exchange_unpack(self.exchange(self.exchange_pack()))
+
+    # ---- sq_exchange: the transport of a sharded context
+    def rccl_init(self, id128: bytes):
+        """join the RCCL communicator made from rank 0's id (rccl_unique_id()); the exchanges then run inside the library"""
+        self._chk(self.lib.sq_rccl_init(self.h, id128), "sq_rccl_init")
+        self.exchange = "native"
+
+    def set_allgather(self, fn):
+        """install a fixed-size all-gather of host buffers: fn(send: bytes) -> bytes of world_size pieces in rank order"""
+        FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+        def tramp(_user, send, nbytes, recv):
+            try:
+                out = fn(C.string_at(send, nbytes))
+                C.memmove(recv, out, len(out))
+                return 0
+            except Exception:  # noqa: BLE001 -- a Python exception must not unwind through the C caller
+                return -3
+        self._allgather_cb = FN(tramp)  # (keep the trampoline alive as long as the context)
+        self.lib.sq_set_allgather.argtypes = [C.c_void_p, FN, C.c_void_p]
+        self._chk(self.lib.sq_set_allgather(self.h, self._allgather_cb, None), "sq_set_allgather")
+        self.exchange = "native"
+
+    def exchange_stats(self) -> tuple:
+        n, b = C.c_int64(), C.c_int64()
+        self._chk(self.lib.sq_exchange_stats(self.h, C.byref(n), C.byref(b)), "sq_exchange_stats")
+        return n.value, b.value
 
     def build_graph_step(self) -> int:
         """one call of sq_build_graph: 0 = done, NEED_EXCHANGE = all-gather exchange_pack() into exchange_unpack()"""

@@ -728,6 +728,7 @@ int sq_create(const sq_params* p, sq_ctx** out) {
 void sq_destroy(sq_ctx* c) {
     if (!c) return;
     if (c->bp_future.valid()) (void)c->bp_future.get();
+    exchange_release(c);
     dev_destroy(c);
     delete c;
 }

@@ -159,6 +159,8 @@ struct Shard {
     int64_t n_break_global = 0;
 };
 struct GraphBuild;  // locals of sq_build_graph that survive an exchange (sq_capi.cpp)
+struct RcclTransport;  // sq_exchange.cpp
+void exchange_release(sq_ctx* c);
 struct SvBuild;     // same for sq_call_sv
 
 }  // namespace sq
@@ -212,6 +214,11 @@ struct sq_ctx {
     std::vector<uint8_t> xbuf;                 // this rank's contribution
     std::vector<std::vector<uint8_t>> xgot;    // what every rank contributed (by rank), set by sq_exchange_unpack
     bool x_pending = false, x_ready = false;
+    // sq_exchange: the installed all-gather (RCCL or the caller's)
+    sq_allgather_fn x_allgather = nullptr;
+    void* x_user = nullptr;
+    std::shared_ptr<sq::RcclTransport> rccl;
+    int64_t x_collectives = 0, x_bytes = 0;
 };
 
 namespace sq {

@@ -149,6 +149,40 @@ class TorchExchange:
         return [bytes(g[:s].cpu().numpy().tobytes()) for g, s in zip(got, sizes)]
 
 
+def install_native_exchange(ctx, dist, backend: str):
+    """Let the library carry out its own exchanges (sq_exchange) over torch.distributed's process group:
+    nccl -> an RCCL communicator inside the library (rank 0's id travels through the group's store once), ncclAllGather on device
+    buffers over xGMI; anything else (gloo: several ranks on one GPU, CPU-side tests) -> a fixed-size all-gather of host buffers
+    through the group, installed as the library's transport (sq_set_allgather)."""
+    import squid_amd
+
+    import torch
+
+    world = dist.get_world_size()
+    if backend == "nccl":
+        box = [squid_amd.rccl_unique_id() if dist.get_rank() == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ok = 1
+        try:
+            ctx.rccl_init(box[0])
+        except squid_amd.SquidError as e:  # (then on every rank, normally: the ranks agree below and fall back together)
+            print(f"squid_amd: sq_rccl_init failed ({e}); the exchanges go through torch.distributed instead", flush=True)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 1:
+            return
+    dev = "cuda" if backend == "nccl" else "cpu"
+
+    def allgather(blob: bytes) -> bytes:
+        mine = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+        got = [torch.zeros(len(blob), dtype=torch.uint8, device=dev) for _ in range(world)]
+        dist.all_gather(got, mine)
+        return b"".join(bytes(g.cpu().numpy().tobytes()) for g in got)
+
+    ctx.set_allgather(allgather)
+
+
 class VirtualWorld:
     """Drives `world` in-process contexts (one per virtual rank, possibly all on one GPU) in lockstep."""
 

@@ -4,8 +4,8 @@
         -m squid_amd.sharded_cli -b sorted.bam -c chimeric.bam -o out/prefix [any other squid flag]
 
 The flags are parsed by the drop-in CLI itself (`build/squid --print-config`, which follows src/Config.cpp:80-230),
-every rank ingests the chimeric BAM and the concordant records of its chromosome range, the library's exchanges
-(include/squid_hip.h, sq_set_shard) travel as RCCL all-gathers, and rank 0 writes `<prefix>_sv.txt` exactly as the
+every rank ingests the chimeric BAM and the concordant records of its chromosome range, the library carries out its exchanges
+itself (include/squid_hip.h, sq_exchange: one RCCL all-gather each, over a communicator made inside the library), and rank 0 writes `<prefix>_sv.txt` exactly as the
 single-GPU `squid` does (src/WriteIO.cpp:45-124).  SQUID_DIST_BACKEND=gloo lets the ranks share one GPU."""
 from __future__ import annotations
 
@@ -15,7 +15,7 @@ import sys
 from pathlib import Path
 
 import squid_amd
-from squid_amd.dist import TorchExchange, plan_shards, shard_weights
+from squid_amd.dist import install_native_exchange, plan_shards, shard_weights
 
 
 def parse_flags(argv: list) -> dict:
@@ -42,13 +42,14 @@ def main(argv: list) -> int:
             dist.init_process_group(backend)
     params = dict(phred_type=int(cfg["pt"]), max_lowphred_len=int(cfg["pl"]), min_phred=int(cfg["pm"]), min_mapqual=int(cfg["mq"]), concord_dist_pos=int(cfg["dp"]),
                   concord_dist_idx=int(cfg["di"]), min_edge_weight=int(cfg["w"]), discordant_ratio=float(cfg["r"]), max_allowed_degree=int(cfg["a"]))
-    shard, exchange = None, None
+    shard = None
     if world > 1:
         _, ref_len = squid_amd.read_header(cfg["b"])
         shard = plan_shards(shard_weights(cfg["b"], ref_len), world)[rank]
-        exchange = TorchExchange(dist, device="cuda" if backend == "nccl" else "cpu")
         params.update(rank=rank, world_size=world)
-    with squid_amd.Context(device=local, star_mapq=False, exchange=exchange, **params) as ctx:
+    with squid_amd.Context(device=local, star_mapq=False, **params) as ctx:
+        if world > 1:
+            install_native_exchange(ctx, dist, backend)  # sq_exchange: RCCL inside the library, or a gloo all-gather as its transport
         ctx.load(cfg["b"], cfg["c"], threads=max(1, (os.cpu_count() or 8) // world), shard=shard)
         ctx.build_graph()
         ctx.order()

@@ -426,6 +426,54 @@ def test_exact_depth_sweep_of_a_sharded_run(built, synth, tmp_path, cfg, extra, 
             c.close()
 
 
+@pytest.mark.parametrize("cfg,extra,world", [("T2", (), 3), ("C3", ("--records", "300000"), 4)])
+def test_library_side_exchange_over_an_installed_allgather(built, synth, tmp_path, cfg, extra, world, monkeypatch):
+    """sq_exchange: the library all-gathers its own payloads over the transport installed on the context (here a fixed-size
+    all-gather between threads, one per rank, through sq_set_allgather; on several GPUs the same entry point runs ncclAllGather).
+    One all-gather of 16 KiB pieces per exchange, a second one only when a payload is longer (the graph data of the C3 sample)."""
+    import threading
+    from squid_amd.dist import plan_shards
+
+    monkeypatch.delenv("SQUID_EXACT_DEPTH", raising=False)
+    pre = synth(cfg, *extra)
+    sv_path, _ = ou.run_oracle(built, pre, tmp_path)
+    _, lens = squid_amd.read_header(f"{pre}.bam")
+    plan = plan_shards(lens, world)
+    slots, bar = [None] * world, threading.Barrier(world)
+    texts, stats, errors = [None] * world, [None] * world, []
+
+    def rank_main(r):
+        try:
+            with squid_amd.Context(rank=r, world_size=world) as ctx:
+                def allgather(blob):
+                    slots[r] = blob
+                    bar.wait()
+                    out = b"".join(slots)
+                    bar.wait()
+                    return out
+                ctx.set_allgather(allgather)
+                ctx.load(f"{pre}.bam", f"{pre}.chim.bam", shard=plan[r])
+                ctx.build_graph()
+                ctx.order()
+                texts[r] = ctx.sv_text()
+                stats[r] = ctx.exchange_stats()
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+            bar.abort()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert all(t == sv_path.read_text() for t in texts)
+    n_coll = stats[0][0]
+    assert all(s == stats[0] for s in stats) and 5 <= n_coll <= 2 * (5 + world)
+    if cfg == "T2":
+        assert n_coll <= 5 + world  # every payload of the small sample fits one piece: one collective per exchange
+
+
 def test_sharded_context_refuses_to_run_without_its_exchange(built, synth):
     pre = synth("T2")
     ctxs = _sharded_contexts(pre, 2)
