@@ -9,7 +9,7 @@ CXX ?= g++
 ARCH ?= gfx950
 B := build
 CSRC := squid_amd/csrc
-LIBSRC := $(CSRC)/sq_kernels.hip $(CSRC)/sq_bam.cpp $(CSRC)/sq_chimeric.cpp $(CSRC)/sq_segment.cpp $(CSRC)/sq_graph.cpp $(CSRC)/sq_order.cpp $(CSRC)/sq_exchange.cpp $(CSRC)/sq_capi.cpp
+LIBSRC := $(CSRC)/sq_kernels.hip $(CSRC)/sq_bam.cpp $(CSRC)/sq_chimeric.cpp $(CSRC)/sq_segment.cpp $(CSRC)/sq_graph.cpp $(CSRC)/sq_order.cpp $(CSRC)/sq_post.cpp $(CSRC)/sq_exchange.cpp $(CSRC)/sq_capi.cpp
 
 all: $(B)/libsquid_hip.so $(B)/squid $(B)/squid_annotate $(B)/gen_synth_bam $(B)/squid_oracle $(B)/oracle_singlebamrec ref
 
@@ -33,7 +33,7 @@ $(B)/gen_synth_bam: squid_amd/synth/gen_synth_bam.cpp
 	mkdir -p $(B)
 	$(CXX) -O2 -std=c++17 -o $@ $< -lz -lpthread -ldl
 
-$(B)/squid_oracle: oracle/squid_oracle.cpp oracle/o_bam.h oracle/o_readrec.h oracle/o_graph.h oracle/o_order.h
+$(B)/squid_oracle: oracle/squid_oracle.cpp oracle/o_bam.h oracle/o_readrec.h oracle/o_graph.h oracle/o_order.h oracle/o_post.h
 	$(MAKE) -C oracle OUT=../$(B)
 
 $(B)/oracle_singlebamrec: oracle/singlebamrec_driver.cpp oracle/o_readrec.h oracle/o_bam.h

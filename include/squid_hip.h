@@ -157,6 +157,10 @@ typedef struct sq_orders {
     const int32_t* nodes;
 } sq_orders;
 int sq_order(sq_ctx* c, sq_orders* o);
+/* The per-component orders stitched into whole new chromosomes: SortComponents -> MergeSingleton -> SortComponents -> MergeComponents
+ * (src/main.cpp:45-48, src/SegmentGraph.cpp:4010-4504) -- what `-TO 1` prints as <prefix>_component.txt and `-RG 1` spells out as
+ * <prefix>_genome.fa.  The SV calls do not depend on it; only callers that want those two outputs need it. */
+int sq_total_order(sq_ctx* c, sq_orders* o);
 
 /* ExactBreakpoint + ExactBPConcordantSupport + DeMultiplyDisEdges + the row selection of WriteBEDPE
  * (src/SegmentGraph.cpp:3019-3221,3012-3017; src/WriteIO.cpp:45-124).  One row per printed _sv.txt line. */

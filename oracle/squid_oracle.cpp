@@ -5,9 +5,9 @@
 //   * by tests/ as the checker for the HIP path (stage dumps + `_sv.txt`), and
 //   * by bench.py's `cpu_baseline` leg (kind "port", 1 core).
 // It follows src/main.cpp:17-76, src/Config.cpp:80-230, src/WriteIO.cpp:33-124 and the files named in
-// o_readrec.h / o_graph.h / o_order.h.  Out of scope in the oracle: --bwa, -TO, -RG.
-// SortComponents/MergeSingleton/MergeComponents (src/main.cpp:45-48) are not restated: `_sv.txt` depends on a
-// component only through the relative rank and sign of an edge's two end nodes (src/WriteIO.cpp:57-63), both
+// o_readrec.h / o_graph.h / o_order.h / o_post.h.  Out of scope in the oracle: --bwa.
+// SortComponents/MergeSingleton/MergeComponents (src/main.cpp:45-48, restated in o_post.h) run only with -TO / -RG: `_sv.txt`
+// depends on a component only through the relative rank and sign of an edge's two end nodes (src/WriteIO.cpp:57-63), both
 // ends of an edge always share a connected component, and those three steps only move, reverse-and-negate or
 // interleave whole components (src/SegmentGraph.cpp:4034-4038,4236-4253,4400-4403,4457-4459,4494-4498).
 #include <chrono>
@@ -15,6 +15,7 @@
 #include <sstream>
 
 #include "o_order.h"
+#include "o_post.h"
 
 using namespace oracle;
 
@@ -281,7 +282,26 @@ int main(int argc, char* argv[]) {
         o << "components\t" << ord.stats.components << "\nsolved\t" << ord.stats.solved << "\nambiguous\t" << ord.stats.ambiguous << "\ntoo_large\t" << ord.stats.too_large
           << "\nmincut_splits\t" << ord.stats.mincut_splits << "\nkept_records\t" << G.n_kept_records << "\nbreak_record\t" << G.n_break_record << "\n";
     }
-    if (P.Print_Total_Ordering || P.Print_Rearranged_Genome) std::fprintf(stderr, "oracle: -TO / -RG outputs are out of scope (SURVEY.md section 8(f) next-2)\n");
+    // src/main.cpp:45-48 runs the component post-merge always; its result only reaches -TO / -RG (`_sv.txt` is invariant to it, SURVEY.md
+    // A.9) and MergeSingleton_Insert is quadratic (:4154-4225), so the oracle runs it only when one of the two outputs is asked for
+    const std::vector<std::vector<int>> PrimaryComponents = Components;
+    if (P.Print_Total_Ordering || P.Print_Rearranged_Genome) {
+        std::vector<opost::NodeGeo> geo(G.vNodes.size());
+        for (size_t i = 0; i < geo.size(); i++) geo[i] = opost::NodeGeo{G.vNodes[i].Chr, G.vNodes[i].Position, G.vNodes[i].Length};
+        Components = opost::SortComponents(Components);
+        Components = opost::MergeSingleton(geo, Components, RefLength);
+        Components = opost::SortComponents(Components);
+        Components = opost::MergeComponents(geo, Components);
+        lap("components merged");
+        if (P.Print_Total_Ordering) WriteComponents(P.Output_Prefix + "_component.txt", Components);
+        if (P.Print_Rearranged_Genome) {
+            std::map<std::string, int> RefTable;
+            for (size_t i = 0; i < RefName.size(); i++) RefTable[RefName[i]] = (int)i;
+            std::vector<std::string> RefSequence;
+            if (opost::BuildRefSeq(P.Input_FASTA, RefTable, RefLength, RefSequence)) opost::OutputNewGenome(geo, Components, RefSequence, RefName, P.Output_Prefix + "_genome.fa");
+            else std::cout << "FASTA file doesn't match BAM file" << std::endl;
+        }
+    }
 
     std::vector<pii> Node_NewChr(G.vNodes.size());
     for (size_t i = 0; i < Components.size(); i++)

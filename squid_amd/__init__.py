@@ -21,7 +21,7 @@ EXPORTS = [
     "sq_ingest_chimeric", "sq_chim_contains", "sq_ingest_concordant", "sq_ingest_concordant_bam", "sq_read_header", "sq_ingest_chimeric_file",
     "sq_ingest_concordant_file", "sq_build_graph", "sq_graph_view", "sq_order", "sq_call_sv", "sq_breakpoints",
     "sq_set_shard", "sq_exchange_pack", "sq_exchange_unpack", "sq_get_timing", "sq_timing_accumulate", "sq_reset", "sq_ingest_files", "sq_stage_bam", "sq_clear_records", "sq_set_source", "sq_save_records", "sq_load_records", "sq_get_counts", "sq_debug_download", "sq_debug_bp_support", "sq_debug_order", "sq_debug_blocks", "sq_drop_file_cache",
-    "sq_set_allgather", "sq_rccl_unique_id", "sq_rccl_init", "sq_rccl_attach", "sq_exchange", "sq_exchange_stats",
+    "sq_total_order", "sq_set_allgather", "sq_rccl_unique_id", "sq_rccl_init", "sq_rccl_attach", "sq_exchange", "sq_exchange_stats",
 ]
 
 
@@ -298,6 +298,12 @@ class Context:
     def order(self) -> list[list[int]]:
         o = SqOrders()
         self._chk(self.lib.sq_order(self.h, C.byref(o)), "sq_order")
+        return [[o.nodes[j] for j in range(o.comp_off[k], o.comp_off[k + 1])] for k in range(o.n_components)]
+
+    def total_order(self) -> list[list[int]]:
+        """the components stitched into whole new chromosomes (sq_total_order: what -TO prints)"""
+        o = SqOrders()
+        self._chk(self.lib.sq_total_order(self.h, C.byref(o)), "sq_total_order")
         return [[o.nodes[j] for j in range(o.comp_off[k], o.comp_off[k + 1])] for k in range(o.n_components)]
 
     def order_sizes(self):

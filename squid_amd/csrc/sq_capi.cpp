@@ -14,16 +14,19 @@
 
 namespace sq {
 
+// sq_ingest_files decodes the chimeric file on a second thread while the calling thread may report its own errors into c->err:
+// the helper's messages go to c->chim_err (this thread-local names it) and reach c->err when chim_join collects the result
+static thread_local std::string* tl_err_sink = nullptr;
 int fail(sq_ctx* c, int code, const std::string& msg) {
-    static std::mutex m;  // (sq_ingest_files decodes the chimeric file on a second thread)
-    std::lock_guard<std::mutex> g(m);
-    if (c) c->err = msg;
+    if (tl_err_sink) *tl_err_sink = msg;
+    else if (c) c->err = msg;
     return code;
 }
 int chim_join(sq_ctx* c) {
     if (!c->chim_future.valid()) return SQ_OK;
     const int rc = c->chim_future.get();
-    return rc ? rc : dev_upload_chim_names(c);
+    if (rc) { c->err = c->chim_err; return rc; }
+    return dev_upload_chim_names(c);
 }
 
 int Timer::slot(const char* name) {
@@ -852,7 +855,10 @@ int sq_ingest_files(sq_ctx* c, const char* chim_path, const char* bam_path, int3
         return rc ? rc : sq_ingest_concordant_file(c, bam_path, n_threads);
     }
     const std::string chim = chim_path;
+    c->chim_err.clear();
     c->chim_future = std::async(std::launch::async, [c, chim, n_threads]() {
+        tl_err_sink = &c->chim_err;
+        struct Unsink { ~Unsink() { tl_err_sink = nullptr; } } unsink;
         ParseOpts o{c->P.phred_type, c->P.min_phred, c->P.max_lowphred_len, true, nullptr};
         HostBatch all;
         all.clear();
@@ -892,7 +898,8 @@ int sq_ingest_concordant_file(sq_ctx* c, const char* path, int32_t n_threads) {
         struct DfileGuard { sq_ctx* c; ~DfileGuard() { c->ingest_dfile = nullptr; } } dfile_guard{c};
         if (staged) {
             struct stat st;
-            if (::stat(path, &st) != 0 || (size_t)st.st_size != c->staged_bytes) return fail(c, SQ_E_IO, "the file changed since sq_stage_bam");
+            if (::stat(path, &st) != 0 || (size_t)st.st_size != c->staged_bytes || (uint64_t)st.st_ino != c->staged_ino) return fail(c, SQ_E_IO, "the file changed since sq_stage_bam");
+            if (((uint64_t)st.st_mtim.tv_sec * 1000000000ull + (uint64_t)st.st_mtim.tv_nsec) != c->staged_mtime) return fail(c, SQ_E_IO, "the file changed since sq_stage_bam");
             int r0 = dev_stage_file(c, nullptr, 0, &c->ingest_dfile);
             if (r0) return r0;
         }
@@ -930,6 +937,8 @@ int sq_stage_bam(sq_ctx* c, const char* path) {
     munmap(m, n);
     if (rc) return rc;
     c->staged_path = path; c->staged_bytes = n;
+    c->staged_ino = (uint64_t)st.st_ino;
+    c->staged_mtime = (uint64_t)st.st_mtim.tv_sec * 1000000000ull + (uint64_t)st.st_mtim.tv_nsec;
     return SQ_OK;
 }
 int sq_clear_records(sq_ctx* c) {
@@ -1079,6 +1088,14 @@ int sq_order(sq_ctx* c, sq_orders* o) {
     if (!c || !c->graph_built) return SQ_E_ARG;
     if (!c->ordered) { int rc = order_components(c); dev_flush_timers(c); if (rc) return rc; }
     if (o) { o->n_components = (int32_t)c->ord_off.size() - 1; o->comp_off = c->ord_off.data(); o->nodes = c->ord_nodes.data(); }
+    return SQ_OK;
+}
+int sq_total_order(sq_ctx* c, sq_orders* o) {
+    if (!c || !o || !c->graph_built) return SQ_E_ARG;
+    if (!c->ordered) { int rc = order_components(c); dev_flush_timers(c); if (rc) return rc; }
+    const int rc = total_order(c);
+    if (rc) return rc;
+    o->n_components = (int32_t)c->tot_off.size() - 1; o->comp_off = c->tot_off.data(); o->nodes = c->tot_nodes.data();
     return SQ_OK;
 }
 int sq_call_sv(sq_ctx* c, sq_sv_table* t) {

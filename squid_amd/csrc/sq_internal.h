@@ -187,6 +187,7 @@ struct sq_ctx {
     bool depth_bounds = false;      // node depths are canonical values with [depth_lo, depth_hi] bounds
     bool depth_ambiguous = false;   // a FilterEdges decision depends on the position inside the bounds
     std::vector<int32_t> ord_off, ord_nodes;
+    std::vector<int32_t> tot_off, tot_nodes;  // sq_total_order: the components stitched into whole new chromosomes
     // sv output
     std::vector<int32_t> sv_cols[9];
     std::vector<uint8_t> sv_s1, sv_s2;
@@ -199,6 +200,7 @@ struct sq_ctx {
     uint64_t source_size = 0, source_mtime = 0;  // identity of the concordant BAM (sq_set_source / sq_ingest_concordant_file); 0,0 = unknown
     std::string staged_path;               // sq_stage_bam: the file whose compressed bytes are resident in HBM (DeviceRecords::staged)
     size_t staged_bytes = 0;
+    uint64_t staged_ino = 0, staged_mtime = 0;  // (size, inode and mtime of the staged file: a rewrite in between is refused)
     const uint8_t* ingest_dfile = nullptr; // device copy of the file being ingested (set for the duration of the call)
     size_t ingest_total_bytes = 0, ingest_seen_bytes = 0;  // file ingest in progress: inflated bytes in the file / handed to the GPU so far
     std::unique_ptr<sq::HostPool> pool;  // host threads of this context
@@ -206,6 +208,7 @@ struct sq_ctx {
     // ExactBreakpoint (host, chimeric fragments only) runs on a second thread from the end of sq_build_graph, next to
     // sq_order; sq_call_sv collects it
     std::future<int> bp_future;
+    std::string chim_err;          // (its error text; moved into `err` by chim_join)
     std::future<int> chim_future;  // sq_ingest_files: the chimeric decode running next to the concordant ingest (chim_join)
     std::shared_ptr<std::map<uint64_t, std::vector<std::pair<int, int>>>> bp_early;
     double bp_early_ms = 0;
@@ -295,6 +298,7 @@ int exact_breakpoints(sq_ctx* c, BPMap& bp);
 
 // ---- sq_order.cpp
 int order_components(sq_ctx* c);
+int total_order(sq_ctx* c);  // sq_post.cpp
 int order_problem_debug(sq_ctx* c, int n, const std::vector<int32_t>& edges5, bool use_gpu, int32_t& mask, std::vector<int32_t>& order, int64_t& value);
 
 // ---- sq_kernels.hip (device side; every function enqueues on c->stream and records HIP-event timings)

@@ -2693,9 +2693,9 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     // inflated size of the whole range, for sizing the record arrays once: exact with a full index, else from the file size
     auto range_bytes_estimate = [&]() -> unsigned long long {
         if (!index_more) { const size_t e = std::min(b1, blocks.size()); return blocks[e - 1].uoff + blocks[e - 1].isize - first_uoff; }
-        const BgzfRange& l = blocks.back();
-        const double ratio = (double)(l.uoff + l.isize) / (double)(l.coff + l.clen);
-        return (unsigned long long)(ratio * 1.03 * (double)file_bytes);
+        const BgzfRange &f = blocks.front(), &l = blocks.back();  // (a .bai shard's walk starts in the middle of the file: ratio over the walked part only)
+        const double ratio = (double)(l.uoff + l.isize - f.uoff) / (double)std::max<unsigned long long>(1, l.coff + l.clen - f.coff);
+        return (unsigned long long)(ratio * 1.03 * (double)(file_bytes - std::min<unsigned long long>(file_bytes, f.coff)));
     };
     const Shard& sh = c->shard;
     // stage A of batch k: compressed bytes and block table to the device, token pass

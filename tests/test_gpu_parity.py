@@ -106,6 +106,80 @@ def test_command_line_is_a_drop_in(built, synth, tmp_path):
         assert (tmp_path / f"p{suffix}").read_bytes() == (tmp_path / f"o{suffix}").read_bytes(), suffix
 
 
+def _fasta_for(pre, path, seed=5):
+    """a FASTA with the lengths of the BAM header (random bases, some lower case, IUPAC codes and N runs), plus a
+    contig the BAM does not know and ragged line widths -- BuildRefSeq (src/ReadRec.cpp:285-314) accepts all of it"""
+    import gzip, random, struct
+    with gzip.open(f"{pre}.bam", "rb") as f:
+        magic, l_text = struct.unpack("<4si", f.read(8))
+        f.read(l_text)
+        refs = []
+        for _ in range(struct.unpack("<i", f.read(4))[0]):
+            l_name = struct.unpack("<i", f.read(4))[0]
+            name = f.read(l_name)[:-1].decode()
+            refs.append((name, struct.unpack("<i", f.read(4))[0]))
+    rng = random.Random(seed)
+    with open(path, "w") as o:
+        o.write(">not_in_the_bam extra\nACGT\n")
+        for name, ln in reversed(refs):
+            o.write(f">{name} description of {name}\n")
+            seq = "".join(rng.choices("ACGTacgtNnRYKMSWBDHV", weights=[20] * 4 + [4] * 4 + [2, 1] + [1] * 10, k=ln))
+            at = 0
+            while at < ln:
+                w = rng.choice([60, 61, 70])
+                o.write(seq[at:at + w] + "\n")
+                at += w
+    return refs
+
+
+@pytest.mark.parametrize("cfg,flags", [("T2", ()), ("C2", ()), ("C5g", ("-w", "1", "-a", "50"))])
+def test_total_order_and_rearranged_genome_outputs(built, synth, tmp_path, cfg, flags):
+    """-TO / -RG: SortComponents, MergeSingleton, MergeComponents (src/main.cpp:45-48) and OutputNewGenome (src/WriteIO.cpp:172-209)
+    give the same `_component.txt` and `_genome.fa` bytes; `_sv.txt` does not move with the merges on"""
+    pre = synth(cfg, "--records", "200000", "--tsv", "400") if cfg == "C5g" else synth(cfg)
+    common = ["-b", f"{pre}.bam", "-c", f"{pre}.chim.bam", "-TO", "1", "-CO", "1", *flags]
+    outputs = ["_sv.txt", "_component_pri.txt", "_component.txt"]
+    if cfg != "C5g":  # (C5g has the 3 Gbp of a human genome: only the order is compared there)
+        fa = tmp_path / "ref.fa"
+        _fasta_for(pre, fa)
+        common += ["-f", str(fa), "-RG", "1"]
+        outputs.append("_genome.fa")
+    subprocess.check_call([str(built / "squid_oracle"), *common, "-o", str(tmp_path / "o")], stdout=subprocess.DEVNULL)
+    subprocess.check_call([str(built / "squid"), *common, "-o", str(tmp_path / "p")], stdout=subprocess.DEVNULL)
+    for suffix in outputs:
+        assert (tmp_path / f"p{suffix}").read_bytes() == (tmp_path / f"o{suffix}").read_bytes(), suffix
+    subprocess.check_call([str(built / "squid"), "-b", f"{pre}.bam", "-c", f"{pre}.chim.bam", *flags, "-o", str(tmp_path / "q")], stdout=subprocess.DEVNULL)
+    assert (tmp_path / "q_sv.txt").read_bytes() == (tmp_path / "p_sv.txt").read_bytes()
+    kw = {"min_edge_weight": 1, "max_allowed_degree": 50} if flags else {}
+    with squid_amd.Context(**kw) as ctx:
+        ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
+        ctx.build_graph()
+        pri = ctx.order()
+        tot = ctx.total_order()
+        assert tot == ou.read_orders(tmp_path / "o_component.txt")
+        assert sorted(abs(v) for comp in tot for v in comp) == sorted(abs(v) for comp in pri for v in comp)
+        assert len(tot) <= len(pri)
+        assert ctx.order() == pri  # the primary orders stay what -CO prints
+
+
+def test_rearranged_genome_refuses_a_fasta_of_other_lengths(built, synth, tmp_path):
+    pre = synth("T2")
+    fa = tmp_path / "ref.fa"
+    refs = _fasta_for(pre, fa)
+    text = fa.read_text().rstrip("\n")
+    fa.write_text(text[:-1] + "\n")  # one base short on the last contig
+    outs = []
+    for exe, tag in [("squid_oracle", "o"), ("squid", "p")]:
+        r = subprocess.run([str(built / exe), "-b", f"{pre}.bam", "-c", f"{pre}.chim.bam", "-f", str(fa), "-RG", "1", "-o", str(tmp_path / tag)], capture_output=True, text=True)
+        assert r.returncode == 0 and "FASTA file doesn't match BAM file" in r.stdout
+        assert not (tmp_path / f"{tag}_genome.fa").exists()
+        outs.append((tmp_path / f"{tag}_sv.txt").read_bytes())
+    assert outs[0] == outs[1]
+    r = subprocess.run([str(built / "squid"), "-b", f"{pre}.bam", "-c", f"{pre}.chim.bam", "-RG", "1", "-o", str(tmp_path / "r")], capture_output=True, text=True)
+    assert "reference FASTA needed to output rearranged genome sequence." in r.stdout and r.returncode == 0  # the reference's main falls off its end
+    assert not (tmp_path / "r_sv.txt").exists()
+
+
 def test_streaming_ingest_in_small_batches_is_equivalent(built, synth, tmp_path):
     """records appended to HBM batch by batch give the same graph as one shot (blk_off rebasing, grow_keep)"""
     import ctypes as C
