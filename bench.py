@@ -167,12 +167,18 @@ def main() -> None:
     cfgnum = int(a.workload[1:2]) if a.workload[1:2].isdigit() else 7
     seed = 20180000 + cfgnum + 1000 * srank  # rank 0 = the generator's default seed for that config
     t_gen0 = time.perf_counter()
+
+    def note(msg):  # progress on stderr (stdout carries the one JSON line)
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_gen0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
     if sharded:
         if rank == 0:
             synth(a.workload, seed, work, a.records, tsv=a.tsv)
         dist.barrier()
     pre = synth(a.workload, seed, work, a.records, tsv=a.tsv)
     t_gen = time.perf_counter() - t_gen0
+    note(f"synthetic BAM files ready: {pre}")
     bam, chim = f"{pre}.bam", f"{pre}.chim.bam"
 
     def barrier():
@@ -230,6 +236,7 @@ def main() -> None:
     for _ in range(a.warmup):
         step()
     barrier()
+    note("warm-up steps done")
     ctx.timing_accumulate(True)  # the library sums its HIP-event / host timers over the timed steps; read once afterwards
     digests = []
     t0 = time.perf_counter()
@@ -237,6 +244,7 @@ def main() -> None:
         digests.append(hashlib.sha256(step().encode()).hexdigest())
     barrier()
     elapsed = time.perf_counter() - t0
+    note(f"{a.steps} timed steps: {elapsed / a.steps * 1e3:.1f} ms per step")
     text = sv_path.read_text() if (rank == 0 or not sharded) else ""
     if len(set(digests)) != 1:
         raise SystemExit(f"the timed steps wrote different _sv.txt files: {sorted(set(digests))}")
@@ -254,6 +262,7 @@ def main() -> None:
         graph_pass()
     barrier()
     t_res = (time.perf_counter() - t0) / max(1, a.resident_steps)
+    note(f"resident passes: {t_res * 1e3:.1f} ms per pass")
     agg: dict[str, dict] = {k: dict(v) for k, v in ctx.timing().items()}
 
     # ---- the same step from the file in the page cache, nothing kept from earlier reads: the mapping and the block index are dropped
@@ -274,6 +283,7 @@ def main() -> None:
         barrier()
         t_file += time.perf_counter() - t0
     t_file /= n_file_steps
+    note(f"from-file steps: {t_file * 1e3:.1f} ms per step")
 
     from squid_amd.dist import reduce_timing
 
@@ -369,6 +379,7 @@ def main() -> None:
         t0 = time.perf_counter()
         r = subprocess.run([str(BUILD / "squid"), "-b", bam, "-c", chim, "-o", str(cold_pre)] + cli_flags, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
         tc = time.perf_counter() - t0
+        note(f"cold command line: {tc:.2f} s")
         same = r.returncode == 0 and Path(f"{cold_pre}_sv.txt").exists() and Path(f"{cold_pre}_sv.txt").read_text() == text
         out["cold_cli"] = {"value": total_aln / tc, "unit": "alignments/s", "wall_s": round(tc, 3), "sv_identical_to_steps": same,
                            "what": "one `build/squid -b -c -o` process, exec to exit: context creation, device allocations, both BAM files -> _sv.txt"}
@@ -384,6 +395,7 @@ def main() -> None:
         t0 = time.perf_counter()
         subprocess.check_call(pin + [str(BUILD / "squid_oracle"), "-b", f"{spre}.bam", "-c", f"{spre}.chim.bam", "-o", str(work / "cpu_baseline")] + cli_flags, stdout=subprocess.DEVNULL)
         tc = time.perf_counter() - t0
+        note(f"CPU oracle on {sample}: {tc:.1f} s")
         oracle_text = (work / "cpu_baseline_sv.txt").read_text()
         if a.cpu_sample_records:
             res = squid_amd.run_pipeline(f"{spre}.bam", f"{spre}.chim.bam", device=local_rank, **params)

@@ -44,6 +44,41 @@ void HostBatch::append(const HostBatch& o) {
     for (size_t i = 1; i < o.blk_off.size(); ++i) blk_off.push_back(o.blk_off[i] + b0);
     for (size_t i = 1; i < o.name_off.size(); ++i) name_off.push_back(o.name_off[i] + n0);
 }
+// the first `count` parts behind one another, every part copied by a thread of its own (a dense sample's chimeric file: millions of
+// records per chunk; the one-by-one form above spent more time here than the inflate and the decode together)
+void HostBatch::append_parts(const std::vector<HostBatch>& parts, int count) {
+    if (count <= 1) { if (count == 1) append(parts[0]); return; }
+    struct At { size_t rec, blk, name, boff, noff; };  // (boff / noff: entries of blk_off / name_off; the latter stay at 1 without names)
+    std::vector<At> at((size_t)count + 1);
+    at[0] = At{refid.size(), b_refpos.size(), names.size(), blk_off.size(), name_off.size()};
+    for (int t = 0; t < count; ++t) {
+        const HostBatch& o = parts[(size_t)t];
+        const At& a = at[(size_t)t];
+        at[(size_t)t + 1] = At{a.rec + o.refid.size(), a.blk + o.b_refpos.size(), a.name + o.names.size(), a.boff + o.blk_off.size() - 1, a.noff + o.name_off.size() - 1};
+    }
+    const At end = at[(size_t)count];
+    auto grow = [](auto& v, size_t n) { if (v.capacity() < n) v.reserve(std::max(n, v.capacity() * 2)); v.resize(n); };
+    grow(refid, end.rec); grow(pos, end.rec); grow(mrefid, end.rec); grow(mpos, end.rec); grow(endpos, end.rec);
+    grow(flag, end.rec); grow(totlen, end.rec); grow(mapq, end.rec); grow(aux, end.rec);
+    grow(b_refpos, end.blk); grow(b_matchref, end.blk); grow(b_readpos, end.blk); grow(b_matchread, end.blk);
+    grow(names, end.name);
+    grow(blk_off, end.boff); grow(name_off, end.noff);
+    auto work = [&](int t) {
+        const HostBatch& o = parts[(size_t)t];
+        const At a = at[(size_t)t];
+        auto put = [](auto& d, size_t off, const auto& s) { if (!s.empty()) std::memcpy(d.data() + off, s.data(), s.size() * sizeof(s[0])); };
+        put(refid, a.rec, o.refid); put(pos, a.rec, o.pos); put(mrefid, a.rec, o.mrefid); put(mpos, a.rec, o.mpos); put(endpos, a.rec, o.endpos);
+        put(flag, a.rec, o.flag); put(totlen, a.rec, o.totlen); put(mapq, a.rec, o.mapq); put(aux, a.rec, o.aux);
+        put(b_refpos, a.blk, o.b_refpos); put(b_matchref, a.blk, o.b_matchref); put(b_readpos, a.blk, o.b_readpos); put(b_matchread, a.blk, o.b_matchread);
+        put(names, a.name, o.names);
+        for (size_t i = 1; i < o.blk_off.size(); ++i) blk_off[a.boff + i - 1] = o.blk_off[i] + (uint32_t)a.blk;
+        for (size_t i = 1; i < o.name_off.size(); ++i) name_off[a.noff + i - 1] = o.name_off[i] + (uint32_t)a.name;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < count; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+}
 void HostBatch::view(sq_aln_batch* b, bool with_names) const {
     std::memset(b, 0, sizeof *b);
     b->n_rec = (int64_t)refid.size();
@@ -58,7 +93,7 @@ namespace {
 
 struct FileBytes {
     std::vector<uint8_t> data;
-    bool load(const char* path, long limit = -1) {
+    bool load(const char* path, long limit = -1, int threads = 1) {
         FILE* f = std::fopen(path, "rb");
         if (!f) return false;
         std::fseek(f, 0, SEEK_END);
@@ -66,6 +101,25 @@ struct FileBytes {
         std::fseek(f, 0, SEEK_SET);
         if (limit >= 0 && n > limit) n = limit;
         data.resize((size_t)n);
+        if ((size_t)n >= ((size_t)64 << 20) && threads > 1) {  // a large file: pieces side by side (a dense sample's chimeric BAM is over a gigabyte)
+            const int fd = fileno(f);
+            const int T = std::min(threads, 8);
+            std::vector<char> ok((size_t)T, 1);
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; ++t) th.emplace_back([&, t]() {
+                size_t at = (size_t)n * (size_t)t / (size_t)T;
+                const size_t end = (size_t)n * ((size_t)t + 1) / (size_t)T;
+                while (at < end) {
+                    const ssize_t k = pread(fd, data.data() + at, std::min<size_t>(end - at, (size_t)64 << 20), (off_t)at);
+                    if (k <= 0) { ok[(size_t)t] = 0; return; }
+                    at += (size_t)k;
+                }
+            });
+            for (auto& x : th) x.join();
+            std::fclose(f);
+            for (char c : ok) if (!c) return false;
+            return true;
+        }
         size_t got = n ? std::fread(data.data(), 1, (size_t)n, f) : 0;
         std::fclose(f);
         return got == (size_t)n;
@@ -396,7 +450,7 @@ static int parse_bam_impl(const char* path, const ParseOpts& o, size_t batch_rec
     struct Report { double &a, &b, &c, &d, &e, &f; const char* path; ~Report() { if (std::getenv("SQUID_INGEST_TIMING")) std::fprintf(stderr, "ingest %s: read %.1f inflate %.1f walk %.1f decode %.1f append %.1f sink %.1f ms\n", path, a, b, c, d, e, f); } } report{t_read, t_inflate, t_walk, t_decode, t_append, t_sink, path};
     auto tr0 = clk::now();
     FileBytes fb;
-    if (!fb.load(path)) { err = std::string("cannot open bamfile ") + path; return SQ_E_IO; }
+    if (!fb.load(path, -1, n_threads)) { err = std::string("cannot open bamfile ") + path; return SQ_E_IO; }
     std::vector<BgzfBlock> blocks;
     size_t total;
     if (!index_bgzf(fb.data, blocks, total)) { err = "not a BGZF file"; return SQ_E_IO; }
@@ -549,6 +603,11 @@ static int parse_bam_impl(const char* path, const ParseOpts& o, size_t batch_rec
                 if (!refill()) break;
                 continue;
             }
+            if (batch_records >= ((size_t)1 << 32)) {  // one batch for the whole file (the chimeric BAM): all parts at once
+                auto ta0 = clk::now();
+                hb.append_parts(parts, good);
+                t_append += since(ta0);
+            } else
             for (int t = 0; t < good; ++t) {
                 auto ta0 = clk::now();
                 hb.append(parts[t]);

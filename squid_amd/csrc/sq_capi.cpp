@@ -740,11 +740,21 @@ int sq_set_references(sq_ctx* c, int32_t n_ref, const int32_t* ref_len) {
     c->ref_len.assign(ref_len, ref_len + n_ref);
     return SQ_OK;
 }
+// frags0 = frags, side by side (millions of fragments on a dense sample; sq_reset copies the other way)
+static void copy_frags(sq_ctx* c, const std::vector<Frag>& src, std::vector<Frag>& dst) {
+    dst.resize(src.size());
+    HostPool* pool = c->pool.get();
+    const int64_t n = (int64_t)src.size();
+    const int pieces = (int)std::min<int64_t>(std::max<int64_t>(1, n / 4096), pool ? 4 * (pool->size() + 1) : 1);
+    auto piece = [&](int k) { for (int64_t i = n * k / pieces; i < n * (k + 1) / pieces; ++i) dst[(size_t)i] = src[(size_t)i]; };
+    if (pieces <= 1 || !pool) { for (int k = 0; k < pieces; ++k) piece(k); }
+    else pool->parallel_for(pieces, 15, piece);
+}
 int sq_ingest_chimeric(sq_ctx* c, const sq_aln_batch* b) {
     if (!c || !b) return SQ_E_ARG;
     int rc = build_fragments(c, b);
     if (rc) return rc;
-    c->frags0 = c->frags;
+    copy_frags(c, c->frags, c->frags0);
     return dev_upload_chim_names(c);
 }
 int sq_chim_contains(sq_ctx* c, const char* name, size_t len) {
@@ -830,20 +840,27 @@ int sq_read_header(const char* path, int32_t* n_ref, int32_t* ref_len, char* nam
     }
     return SQ_OK;
 }
-int sq_ingest_chimeric_file(sq_ctx* c, const char* path) {
-    if (!c || !path) return SQ_E_ARG;
+// the whole chimeric BAM as one batch -> fragments (the batch is consumed where the reader hands it over: no copy of it)
+static int chimeric_file_to_fragments(sq_ctx* c, const char* path, int nt, std::string& err) {
     ParseOpts o{c->P.phred_type, c->P.min_phred, c->P.max_lowphred_len, true, nullptr};
-    HostBatch all;
-    all.clear();
     bool got = false;
-    // (inflate and decode on a few threads: a dense sample has millions of chimeric records; the result does not depend on the count)
-    const int nt = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 4));
-    int rc = parse_bam_file(path, o, (size_t)1 << 40, nt, c->err, [&](const HostBatch& hb) { all = hb; got = true; return 0; });
+    int rc = parse_bam_file(path, o, (size_t)1 << 40, nt, err, [&](const HostBatch& hb) {
+        sq_aln_batch b;
+        hb.view(&b, true);
+        got = true;
+        return build_fragments(c, &b);
+    });
     if (rc) return rc;
     if (!got) return fail(c, SQ_E_EMPTYCHIM, "chimeric BAM holds no record");
-    sq_aln_batch b;
-    all.view(&b, true);
-    return sq_ingest_chimeric(c, &b);
+    copy_frags(c, c->frags, c->frags0);
+    return SQ_OK;
+}
+int sq_ingest_chimeric_file(sq_ctx* c, const char* path) {
+    if (!c || !path) return SQ_E_ARG;
+    // (inflate and decode on a few threads: a dense sample has millions of chimeric records; the result does not depend on the count)
+    const int nt = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 4));
+    int rc = chimeric_file_to_fragments(c, path, nt, c->err);
+    return rc ? rc : dev_upload_chim_names(c);
 }
 // both input files in one call: the chimeric BAM (1-2 % of the records, decoded on the host: 17 ms at C3) is read on a helper
 // thread while the GPU reader starts on the concordant BAM; the record parse -- the first consumer of the chimeric QNAME set --
@@ -859,20 +876,7 @@ int sq_ingest_files(sq_ctx* c, const char* chim_path, const char* bam_path, int3
     c->chim_future = std::async(std::launch::async, [c, chim, n_threads]() {
         tl_err_sink = &c->chim_err;
         struct Unsink { ~Unsink() { tl_err_sink = nullptr; } } unsink;
-        ParseOpts o{c->P.phred_type, c->P.min_phred, c->P.max_lowphred_len, true, nullptr};
-        HostBatch all;
-        all.clear();
-        bool got = false;
-        std::string err;
-        int rc = parse_bam_file(chim.c_str(), o, (size_t)1 << 40, std::max(1, std::min(n_threads, 16)), err, [&](const HostBatch& hb) { all = hb; got = true; return 0; });
-        if (rc) return fail(c, rc, err);
-        if (!got) return fail(c, SQ_E_EMPTYCHIM, "chimeric BAM holds no record");
-        sq_aln_batch b;
-        all.view(&b, true);
-        rc = build_fragments(c, &b);
-        if (rc) return rc;
-        c->frags0 = c->frags;
-        return (int)SQ_OK;
+        return chimeric_file_to_fragments(c, chim.c_str(), std::max(1, std::min(n_threads, 16)), c->chim_err);
     });
     const int rc_conc = sq_ingest_concordant_file(c, bam_path, n_threads);
     const int rc_chim = chim_join(c);  // (a concordant file without records never reached the parse)
@@ -1135,7 +1139,7 @@ int sq_timing_accumulate(sq_ctx* c, int32_t keep) {
 int sq_reset(sq_ctx* c) {
     if (!c) return SQ_E_ARG;
     if (c->bp_future.valid()) (void)c->bp_future.get();
-    c->frags = c->frags0;  // the graph stages trim the chimeric blocks in place, like the reference does
+    copy_frags(c, c->frags0, c->frags);  // the graph stages trim the chimeric blocks in place, like the reference does
     c->nodes.clear(); c->edges.clear(); c->label.clear();
     c->graph_built = false; c->ordered = false;
     c->bp_off.clear();

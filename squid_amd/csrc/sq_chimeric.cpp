@@ -8,6 +8,7 @@
 #include <functional>
 
 #include "sq_internal.h"
+#include "sq_parsort.h"
 
 namespace sq {
 
@@ -63,6 +64,14 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
         if (pieces <= 1 || !pool) { f(0, n); return; }
         pool->parallel_for(pieces, 15, [&](int k) { f(n * k / pieces, n * (k + 1) / pieces); });
     };
+    static const bool prof = std::getenv("SQUID_CHIM_PROF") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!prof) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "build_fragments: %-22s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     // one single-record fragment per usable record (mapped, not duplicate: ReadRec.cpp:344)
     std::vector<int64_t> usable;
     usable.reserve((size_t)b->n_rec);
@@ -101,16 +110,29 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
             nk[(size_t)k] = NameKey{h, l, (int32_t)k};
         }
     });
-    std::sort(nk.begin(), nk.end(), [&](const NameKey& x, const NameKey& y) {
+    lap("single-record frags");
+    // (std_sort_parallel: libstdc++'s introsort with its independent sub-ranges on several threads -- same comparisons, same result)
+    const int sort_threads = pool ? std::min(pool->size() + 1, 32) : 1;
+    std_sort_parallel(nk.begin(), nk.end(), [&](const NameKey& x, const NameKey& y) {
         if (x.hi != y.hi) return x.hi < y.hi;
         if (x.lo != y.lo) return x.lo < y.lo;
         return recs[(size_t)x.idx].name < recs[(size_t)y.idx].name;
-    });
+    }, sort_threads);
+    lap("name sort");
     // merge equal names (ReadRec.cpp:356-373): runs of equal names in the sorted order; the runs are independent of each other
     std::vector<size_t> run_start;
-    for (size_t k = 0; k < nr; ++k) {
-        const NameKey &x = nk[k];
-        if (k == 0 || x.hi != nk[k - 1].hi || x.lo != nk[k - 1].lo || recs[(size_t)x.idx].name != recs[(size_t)nk[k - 1].idx].name) run_start.push_back(k);
+    {
+        std::vector<uint8_t> starts(nr);
+        par((int64_t)nr, [&](int64_t lo, int64_t hi) {
+            for (int64_t k = lo; k < hi; ++k) {
+                const NameKey& x = nk[(size_t)k];
+                starts[(size_t)k] = k == 0 || x.hi != nk[(size_t)k - 1].hi || x.lo != nk[(size_t)k - 1].lo || recs[(size_t)x.idx].name != recs[(size_t)nk[(size_t)k - 1].idx].name;
+            }
+        });
+        size_t cnt = 0;
+        for (size_t k = 0; k < nr; ++k) cnt += starts[k];
+        run_start.reserve(cnt + 1);
+        for (size_t k = 0; k < nr; ++k) if (starts[k]) run_start.push_back(k);
     }
     run_start.push_back(nr);
     const size_t nm = run_start.size() - 1;
@@ -126,11 +148,13 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
                 if (m.btot == 0 && r.btot != 0) { m.btot = r.btot; m.blow = r.blow; }
                 m.a.insert(m.a.end(), r.a.begin(), r.a.end());
                 m.b.insert(m.b.end(), r.b.begin(), r.b.end());
+                std::vector<Blk>().swap(r.a); std::vector<Blk>().swap(r.b); std::string().swap(r.name);  // (freed here, on this thread, not one by one at the end)
             }
             std::sort(m.a.begin(), m.a.end(), by_readpos);  // SortbyReadPos (ReadRec.cpp:143-146)
             std::sort(m.b.begin(), m.b.end(), by_readpos);
         }
     });
+    lap("merge runs");
     std::sort(sample.begin(), sample.end());
     c->read_len = sample[sample.size() / 2];  // ReadRec.cpp:378-379
     // sort by front position (ReadRec.cpp:382; FrontSmallerThan is not a strict weak order, kept): again on small elements that
@@ -147,34 +171,58 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
             fk[(size_t)j] = k;
         }
     });
-    std::sort(fk.begin(), fk.end(), [](const FrontKey& l, const FrontKey& r) {  // == front_smaller(merged[l.idx], merged[r.idx])
+    std_sort_parallel(fk.begin(), fk.end(), [](const FrontKey& l, const FrontKey& r) {  // == front_smaller(merged[l.idx], merged[r.idx])
         if (l.has_a && r.has_a) return blk_less_pos(l.a, r.a);
         if (l.has_b && r.has_b) return blk_less_pos(l.b, r.b);
         if (l.has_a && r.has_b) return blk_less_pos(l.a, r.b);
         if (l.has_b && r.has_a) return blk_less_pos(l.b, r.a);
         return false;
-    });
+    }, sort_threads);
+    lap("front sort");
     // PCR duplicate removal (ReadRec.cpp:387-409)
+    // The loop of the reference keeps a fragment unless an equal one was kept among the fragments right in front of it that share its
+    // first first-in-pair block position; the backward search stops at the first kept fragment without such a block or with another
+    // position.  So the decisions fall into groups -- maximal runs, in this order, of fragments with a first-in-pair block at one
+    // position -- whose first member is always kept (what was kept before it lies in another group, or has no such block) and whose
+    // other members are compared with kept members of the same group only.  Groups are decided side by side.
     c->frags.clear();
     std::vector<Frag>& out = c->frags;
-    out.reserve(nm);
-    std::vector<uint8_t> kept(nm, 0);
-    for (const FrontKey& k : fk) {
-        Frag& f = merged[(size_t)k.idx];
-        bool keep;
-        if (out.empty()) keep = true;
-        else if (f.a.empty() || out.back().a.empty()) keep = true;
-        else if (f.a.front().refid != out.back().a.front().refid || f.a.front().refpos != out.back().a.front().refpos) keep = true;
-        else {
-            keep = true;
-            for (size_t q = out.size(); q-- > 0;) {
-                const Frag& g = out[q];
-                if (g.a.empty() || f.a.front().refid != g.a.front().refid || f.a.front().refpos != g.a.front().refpos) break;
-                if (frag_equal(f, g)) { keep = false; break; }
+    std::vector<uint8_t> kept(nm, 0);   // by merged index
+    std::vector<uint8_t> keep_at(nm, 0);  // by position in the sorted order
+    {
+        std::vector<uint8_t> gstart(nm);
+        par((int64_t)nm, [&](int64_t lo, int64_t hi) {
+            for (int64_t p = lo; p < hi; ++p) {
+                const FrontKey& k = fk[(size_t)p];
+                bool st = p == 0 || !k.has_a;
+                if (!st) { const FrontKey& q = fk[(size_t)p - 1]; st = !q.has_a || q.a.refid != k.a.refid || q.a.refpos != k.a.refpos; }
+                gstart[(size_t)p] = st;
             }
-        }
-        if (keep) { kept[(size_t)k.idx] = 1; out.push_back(std::move(f)); }
+        });
+        std::vector<size_t> groups;
+        for (size_t p = 0; p < nm; ++p) if (gstart[p]) groups.push_back(p);
+        groups.push_back(nm);
+        par((int64_t)groups.size() - 1, [&](int64_t lo, int64_t hi) {
+            std::vector<size_t> mine;  // kept members of the group so far
+            for (int64_t g = lo; g < hi; ++g) {
+                mine.clear();
+                for (size_t p = groups[(size_t)g]; p < groups[(size_t)g + 1]; ++p) {
+                    const Frag& f = merged[(size_t)fk[p].idx];
+                    bool keep = true;
+                    for (size_t q = mine.size(); q-- > 0 && keep;) if (frag_equal(f, merged[(size_t)fk[mine[q]].idx])) keep = false;
+                    if (keep) { mine.push_back(p); keep_at[p] = 1; }
+                }
+            }
+        });
+        std::vector<size_t> where_out(nm);
+        size_t total = 0;
+        for (size_t p = 0; p < nm; ++p) { where_out[p] = total; total += keep_at[p]; }
+        out.resize(total);
+        par((int64_t)nm, [&](int64_t lo, int64_t hi) {
+            for (int64_t p = lo; p < hi; ++p) if (keep_at[(size_t)p]) { kept[(size_t)fk[(size_t)p].idx] = 1; out[where_out[(size_t)p]] = std::move(merged[(size_t)fk[(size_t)p].idx]); }
+        });
     }
+    lap("duplicate removal");
     // ChimName: Chimrecord.size() empty strings + every Qname, sorted unique (SegmentGraph.cpp:196-201, ledger B9).  `merged` is in name
     // order and holds every name once, so the kept names in that order are already the sorted unique list (the names were moved into
     // `out`: read them back through a map from merged index to output position)
@@ -182,10 +230,15 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
     if (!out.empty()) {
         std::vector<int32_t> where(nm, -1);
         { int32_t o = 0; for (const FrontKey& k : fk) if (kept[(size_t)k.idx]) where[(size_t)k.idx] = o++; }
-        c->chim_names.reserve(out.size() + 1);
-        c->chim_names.push_back("");  // (sorts in front of everything; a fragment with an empty name falls together with it)
-        for (size_t j = 0; j < nm; ++j) if (where[j] >= 0 && !out[(size_t)where[j]].name.empty()) c->chim_names.push_back(out[(size_t)where[j]].name);
+        std::vector<size_t> slot(nm);
+        size_t cnt = 1;  // slot 0: "" (sorts in front of everything; a fragment with an empty name falls together with it)
+        for (size_t j = 0; j < nm; ++j) { slot[j] = cnt; cnt += where[j] >= 0 && !out[(size_t)where[j]].name.empty(); }
+        c->chim_names.resize(cnt);
+        par((int64_t)nm, [&](int64_t lo, int64_t hi) {
+            for (int64_t j = lo; j < hi; ++j) if (where[(size_t)j] >= 0 && !out[(size_t)where[(size_t)j]].name.empty()) c->chim_names[slot[(size_t)j]] = out[(size_t)where[(size_t)j]].name;
+        });
     }
+    lap("names");
     c->chim_set.clear();  // (only the host parser looks names up in a set: built there)
     c->counts.n_chimeric_records = b->n_rec;
     c->counts.n_chim_fragments = (int64_t)out.size();

@@ -239,6 +239,7 @@ struct HostBatch {  // owning storage behind an sq_aln_batch
     std::vector<char> names;
     void clear();
     void append(const HostBatch& o);  // concatenates (block / name offsets are rebased)
+    void append_parts(const std::vector<HostBatch>& parts, int count);  // the same for parts[0 .. count), copied side by side
     void view(sq_aln_batch* b, bool with_names) const;
     size_t size() const { return refid.size(); }
 };

@@ -933,9 +933,12 @@ __device__ __forceinline__ int hint_step(int x, int a, int b, int home) {
 }
 
 // wave-aggregated insert of (key,+w) into the global open-addressing table
+constexpr uint32_t HASH_PROBES = 256;
 __device__ __forceinline__ void hash_add(unsigned long long* hk, uint32_t* hv, uint32_t mask, unsigned long long key, uint32_t w, int32_t* flags) {
     uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & mask;
-    for (uint32_t probe = 0; probe <= mask; ++probe) {
+    // (at most HASH_PROBES slots are tried: a table that needs more is too full and the host repeats the pass with four times the
+    // slots -- without the limit every insert into a full table walked all of it, 26 s for the first pass over a dense sample)
+    for (uint32_t probe = 0; probe <= mask && probe < HASH_PROBES; ++probe) {
         unsigned long long cur = hk[h];
         if (cur == key) { atomicAdd(&hv[h], w); return; }
         if (cur == ~0ull) {
@@ -1210,8 +1213,10 @@ __device__ __forceinline__ void edges_record(const RecView& R, const NodeView& N
 }
 __global__ void k_edges(RecView R, NodeView N, EdgeParams2 P2, const uint8_t* keep, const uint32_t* list, const int32_t* count, unsigned long long* hk, uint32_t* hv, uint32_t hmask, int32_t* flags, int32_t* stripes) {
     const int n = *count;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x)
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+        if (__hip_atomic_load(&flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4) return;  // table too small: the pass is repeated anyway
         edges_record(R, N, P2, keep, (int64_t)list[idx], hk, hv, hmask, flags, stripes);
+    }
 }
 
 
@@ -3283,7 +3288,8 @@ int dev_concordant_edges(sq_ctx* c, const std::vector<Node>& nodes, std::vector<
     HIPCHK(D.stripes.reserve(NSTRIPE));
     if (n >= 0xffffffffll) return fail(c, SQ_E_CAPACITY, "more than 2^32 records");
     HIPCHK(D.scratch_a.reserve((size_t)n));  // the work list of the edge stage
-    for (;;) {  // the table starts small and doubles when it fills up (unique edges are few)
+    while (D.h_slots < (1u << 28) && (size_t)D.h_slots < 4 * nodes.size()) D.h_slots <<= 1;  // (unique concordant edges ~ number of segments)
+    for (;;) {  // the table starts small and grows when it fills up (unique edges are few)
         const uint32_t slots = D.h_slots;
         HIPCHK(D.h_key.reserve(slots)); HIPCHK(D.h_val.reserve(slots));
         HIPCHK(D.okey.reserve(slots)); HIPCHK(D.oval.reserve(slots));

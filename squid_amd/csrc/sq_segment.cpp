@@ -19,6 +19,7 @@
 #include <chrono>
 
 #include "sq_internal.h"
+#include "sq_parsort.h"
 
 namespace sq {
 
@@ -455,14 +456,16 @@ double segment_clusters(const sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::ve
         for (size_t i = 0; i < O.part.size(); ++i) if (!drop[i]) S.part.push_back(O.part[i]);
         D.insert(D.end(), O.D.begin(), O.D.end());
     }
-    std::sort(S.part.begin(), S.part.end());
+    const int sort_threads = c->pool ? std::min(c->pool->size() + 1, 32) : 1;
+    std_sort_parallel(S.part.begin(), S.part.end(), std::less<std::pair<int, int>>(), sort_threads);
     {   // ledger B8: operator< looks at (RefID, RefPos) only and the sort is not stable.  Sorting 12-byte (key, index) elements with the
         // same comparison takes libstdc++'s introsort through the same decisions, hence to the same permutation, at a fraction of
         // the memory traffic of sorting the blocks themselves
         struct PK { int32_t refid, refpos, idx; };
         std::vector<PK> pk(D.size());
         for (size_t i = 0; i < D.size(); ++i) pk[i] = PK{D[i].refid, D[i].refpos, (int32_t)i};
-        std::sort(pk.begin(), pk.end(), [](const PK& x, const PK& y) { return x.refid != y.refid ? x.refid < y.refid : x.refpos < y.refpos; });
+        // (std_sort_parallel, sq_parsort.h: the same introsort with its independent sub-ranges on several threads)
+        std_sort_parallel(pk.begin(), pk.end(), [](const PK& x, const PK& y) { return x.refid != y.refid ? x.refid < y.refid : x.refpos < y.refpos; }, sort_threads);
         std::vector<Blk> sorted(D.size());
         for (size_t i = 0; i < D.size(); ++i) sorted[i] = D[(size_t)pk[i].idx];
         D.swap(sorted);

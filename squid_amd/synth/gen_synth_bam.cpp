@@ -632,7 +632,7 @@ int main(int argc, char** argv) {
         }
         std::string ctext = "@HD\tVN:1.4\n";
         for (auto& c : contigs) ctext += "@SQ\tSN:" + c.name + "\tLN:" + std::to_string(c.len) + "\n";
-        BgzfWriter cw(out + ".chim.bam", level, 1);
+        BgzfWriter cw(out + ".chim.bam", level, threads);
         write_header(cw, ctext);
         for (auto& r : chim) cw.write(r.bytes.data(), r.bytes.size());
         cw.close();

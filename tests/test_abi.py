@@ -52,3 +52,15 @@ def test_context_fails_loudly_without_gpu(built):
         pytest.skip("a GPU is present")
     with pytest.raises(squid_amd.SquidError, match="no CPU fallback"):
         squid_amd.Context()
+
+
+def test_parallel_sort_reproduces_libstdcxx_sort(tmp_path):
+    """sq_parsort.h: std::sort's introsort with its independent sub-ranges on several threads gives std::sort's permutation"""
+    import subprocess
+    from pathlib import Path
+
+    src = Path(__file__).resolve().parent / "parsort_check.cpp"
+    exe = tmp_path / "parsort_check"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", str(exe), str(src), "-lpthread"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout
