@@ -56,14 +56,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s
 WORKLOADS = {
     "C2": "hg38 chr17 only, 1M synthetic paired-end records, 20 planted fusions (BASELINE.json configs[1])",
     "C3": "full hg38, 50M-record synthetic STAR concordant+chimeric BAM, 200 planted TSVs, zlib level 6 (BASELINE.json configs[2])",
-    "C5": "dense-graph stress (-w 1 -a 50): full hg38, 100M records, >= 1e5 planted TSVs in >= 1e5 small components (BASELINE.json configs[4])",
+    "C5": "dense-graph stress (-w 1 -a 50): full hg38, 100M records, 1.1e5 planted TSVs in >= 1e5 small components (BASELINE.json configs[4])",
     "C5g": "dense-graph stress (-w 1 -a 50), round-2 shape: junctions at inner exons, the segments chain into one giant component",
 }
 DENSE = {"min_edge_weight": 1, "max_allowed_degree": 50}  # -w 1 -a 50
 
 
-def synth(config: str, seed: int, outdir: Path, records: int | None = None, level: int | None = None, tsv: int | None = None) -> Path:
-    pre = outdir / (f"{config}_s{seed}" + (f"_r{records}" if records else "") + (f"_t{tsv}" if tsv else "") + (f"_l{level}" if level is not None else ""))
+def synth(config: str, seed: int, outdir: Path, records: int | None = None, level: int | None = None, tsv: int | None = None, support: str | None = None) -> Path:
+    pre = outdir / (f"{config}_s{seed}" + (f"_r{records}" if records else "") + (f"_t{tsv}" if tsv else "") + (f"_l{level}" if level is not None else "") + (f"_u{support.replace(',', '-')}" if support else ""))
     if not Path(f"{pre}.bam").exists():
         tmp = Path(f"{pre}.tmp{os.getpid()}")
         cmd = [str(BUILD / "gen_synth_bam"), "--config", config, "--seed", str(seed), "--out", str(tmp), "--threads", str(max(1, os.cpu_count() or 8))]
@@ -73,6 +73,8 @@ def synth(config: str, seed: int, outdir: Path, records: int | None = None, leve
             cmd += ["--tsv", str(tsv)]
         if level is not None:
             cmd += ["--level", str(level)]
+        if support:
+            cmd += ["--support", support]
         subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
         for ext in (".chim.bam", ".truth.txt", ".bam.bai", ".bam"):
             os.replace(f"{tmp}{ext}", f"{pre}{ext}")
@@ -121,6 +123,8 @@ def main() -> None:
     ap.add_argument("--shard", choices=["sample", "chromosome"], default="chromosome", help="what the ranks of a multi-GPU run divide (see the module docstring)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cold-cli", action="store_true")
+    ap.add_argument("--support", default=None, help="chimeric fragments per planted junction, lo,hi (generator --support, default 10,60)")
+    ap.add_argument("--cpu-sample-tsv", type=int, default=0, help="planted junctions of that sample (generator --tsv; 0 = as the workload)")
     ap.add_argument("--cpu-sample-records", type=int, default=0, help="time the CPU oracle on a sample of this many records instead of the bench's own BAM (0 = the bench's BAM)")
     ap.add_argument("--resident-steps", type=int, default=5, help="extra (untimed for `value`) graph passes over resident records, for the per-kernel roofline figures")
     ap.add_argument("--workdir", default=None)
@@ -174,9 +178,9 @@ def main() -> None:
 
     if sharded:
         if rank == 0:
-            synth(a.workload, seed, work, a.records, tsv=a.tsv)
+            synth(a.workload, seed, work, a.records, tsv=a.tsv, support=a.support)
         dist.barrier()
-    pre = synth(a.workload, seed, work, a.records, tsv=a.tsv)
+    pre = synth(a.workload, seed, work, a.records, tsv=a.tsv, support=a.support)
     t_gen = time.perf_counter() - t_gen0
     note(f"synthetic BAM files ready: {pre}")
     bam, chim = f"{pre}.bam", f"{pre}.chim.bam"
@@ -333,7 +337,7 @@ def main() -> None:
         "value": value, "unit": "alignments/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if sharded else ("weak" if world > 1 else "single GPU"), "vs_baseline": None,
         "dtype": "int32", "data": "synthetic",
-        "config": {"workload": f"{a.workload}: " + WORKLOADS.get(a.workload, "generator config " + a.workload) + (f", --records {a.records}" if a.records else "") + (f", --tsv {a.tsv}" if a.tsv else ""),
+        "config": {"workload": f"{a.workload}: " + WORKLOADS.get(a.workload, "generator config " + a.workload) + (f", --records {a.records}" if a.records else "") + (f", --tsv {a.tsv}" if a.tsv else "") + (f", --support {a.support}" if a.support else ""),
                    "records": int(total_aln), "records_per_gpu": int(total_aln / world), "blocks_per_record": round(bbar, 4), "flags": " ".join(cli_flags) or "defaults",
                    "parallelism": ("one sample sharded by chromosome over %d ranks, %.1f all-gathers (%.0f payload bytes) per step inside the library (sq_exchange over %s)" % (world, x_all[0] / max(1, n_passes), x_all[1] / max(1, n_passes), "RCCL" if dist.get_backend() == "nccl" else dist.get_backend()) if sharded else "1 sample per GPU, no collective") if world > 1 else "single GPU",
                    "step": "chimeric BAM decode (host) + concordant BAM decode on the GPU (BGZF inflate, record boundaries, record parse) + graph + ordering + SV calls + _sv.txt written; compressed BAM bytes resident in HBM at the start of every step"},
@@ -388,8 +392,8 @@ def main() -> None:
         # the timed steps'), or with --cpu-sample-records on a smaller sample of the same workload that the GPU path then runs too
         pin = ["taskset", "-c", "0"] if shutil.which("taskset") else []
         if a.cpu_sample_records:
-            spre = synth(a.workload, seed, work, a.cpu_sample_records, tsv=a.tsv)
-            sample = f"{a.workload} generated with --records {a.cpu_sample_records}"
+            spre = synth(a.workload, seed, work, a.cpu_sample_records, tsv=a.cpu_sample_tsv or a.tsv, support=a.support)
+            sample = f"{a.workload} generated with --records {a.cpu_sample_records}" + (f" --tsv {a.cpu_sample_tsv}" if a.cpu_sample_tsv else "")
         else:
             spre, sample = pre, "the bench's own BAM files"
         t0 = time.perf_counter()

@@ -91,9 +91,30 @@ void HostBatch::view(sq_aln_batch* b, bool with_names) const {
 
 namespace {
 
+struct ByteView {  // the bytes of a file: a vector's or a mapping's
+    const uint8_t* p; size_t n;
+    ByteView(const std::vector<uint8_t>& v) : p(v.data()), n(v.size()) {}
+    ByteView(const uint8_t* p_, size_t n_) : p(p_), n(n_) {}
+    size_t size() const { return n; }
+    const uint8_t& operator[](size_t i) const { return p[i]; }
+};
+
 struct FileBytes {
     std::vector<uint8_t> data;
-    bool load(const char* path, long limit = -1, int threads = 1) {
+    const uint8_t* map = nullptr;  // a large file read whole: mapped from the page cache instead of copied (a dense sample's chimeric BAM is over a gigabyte)
+    size_t map_n = 0;
+    ByteView view() const { return map ? ByteView(map, map_n) : ByteView(data); }
+    bool load(const char* path, long limit = -1) {
+        if (limit < 0) {
+            const int fd = ::open(path, O_RDONLY);
+            if (fd < 0) return false;
+            struct stat st;
+            if (fstat(fd, &st) == 0 && (size_t)st.st_size >= ((size_t)64 << 20)) {
+                void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+                if (m != MAP_FAILED) { ::close(fd); map = (const uint8_t*)m; map_n = (size_t)st.st_size; return true; }
+            }
+            ::close(fd);
+        }
         FILE* f = std::fopen(path, "rb");
         if (!f) return false;
         std::fseek(f, 0, SEEK_END);
@@ -101,29 +122,11 @@ struct FileBytes {
         std::fseek(f, 0, SEEK_SET);
         if (limit >= 0 && n > limit) n = limit;
         data.resize((size_t)n);
-        if ((size_t)n >= ((size_t)64 << 20) && threads > 1) {  // a large file: pieces side by side (a dense sample's chimeric BAM is over a gigabyte)
-            const int fd = fileno(f);
-            const int T = std::min(threads, 8);
-            std::vector<char> ok((size_t)T, 1);
-            std::vector<std::thread> th;
-            for (int t = 0; t < T; ++t) th.emplace_back([&, t]() {
-                size_t at = (size_t)n * (size_t)t / (size_t)T;
-                const size_t end = (size_t)n * ((size_t)t + 1) / (size_t)T;
-                while (at < end) {
-                    const ssize_t k = pread(fd, data.data() + at, std::min<size_t>(end - at, (size_t)64 << 20), (off_t)at);
-                    if (k <= 0) { ok[(size_t)t] = 0; return; }
-                    at += (size_t)k;
-                }
-            });
-            for (auto& x : th) x.join();
-            std::fclose(f);
-            for (char c : ok) if (!c) return false;
-            return true;
-        }
         size_t got = n ? std::fread(data.data(), 1, (size_t)n, f) : 0;
         std::fclose(f);
         return got == (size_t)n;
     }
+    ~FileBytes() { if (map) munmap((void*)map, map_n); }
 };
 
 // growable byte buffer WITHOUT value-initialisation (std::vector::resize would zero-fill hundreds of MB per chunk)
@@ -142,9 +145,8 @@ struct RawBuf {
 };
 
 struct BgzfBlock { size_t coff; uint32_t clen, isize; size_t uoff; };
-
 // walk the BGZF container: one entry per block (payload offset/length, inflated size)
-bool index_bgzf(const std::vector<uint8_t>& d, std::vector<BgzfBlock>& blocks, size_t& total) {
+bool index_bgzf(const ByteView& d, std::vector<BgzfBlock>& blocks, size_t& total) {
     size_t p = 0;
     total = 0;
     while (p + 18 <= d.size()) {
@@ -170,7 +172,7 @@ bool index_bgzf(const std::vector<uint8_t>& d, std::vector<BgzfBlock>& blocks, s
 }
 
 // like index_bgzf, but stops quietly at the first incomplete block (for file prefixes)
-void index_bgzf_prefix(const std::vector<uint8_t>& d, std::vector<BgzfBlock>& blocks, size_t& total) {
+void index_bgzf_prefix(const ByteView& d, std::vector<BgzfBlock>& blocks, size_t& total) {
     size_t p = 0;
     total = 0;
     while (p + 18 <= d.size()) {
@@ -194,7 +196,7 @@ void index_bgzf_prefix(const std::vector<uint8_t>& d, std::vector<BgzfBlock>& bl
     }
 }
 
-bool inflate_range(const std::vector<uint8_t>& d, const std::vector<BgzfBlock>& blocks, size_t b0, size_t b1, uint8_t* out, size_t out_base, int n_threads) {
+bool inflate_range(const ByteView& d, const std::vector<BgzfBlock>& blocks, size_t b0, size_t b1, uint8_t* out, size_t out_base, int n_threads) {
     std::vector<char> ok((size_t)std::max(1, n_threads), 1);
     auto work = [&](int t) {
         z_stream zs;
@@ -450,10 +452,11 @@ static int parse_bam_impl(const char* path, const ParseOpts& o, size_t batch_rec
     struct Report { double &a, &b, &c, &d, &e, &f; const char* path; ~Report() { if (std::getenv("SQUID_INGEST_TIMING")) std::fprintf(stderr, "ingest %s: read %.1f inflate %.1f walk %.1f decode %.1f append %.1f sink %.1f ms\n", path, a, b, c, d, e, f); } } report{t_read, t_inflate, t_walk, t_decode, t_append, t_sink, path};
     auto tr0 = clk::now();
     FileBytes fb;
-    if (!fb.load(path, -1, n_threads)) { err = std::string("cannot open bamfile ") + path; return SQ_E_IO; }
+    if (!fb.load(path)) { err = std::string("cannot open bamfile ") + path; return SQ_E_IO; }
     std::vector<BgzfBlock> blocks;
     size_t total;
-    if (!index_bgzf(fb.data, blocks, total)) { err = "not a BGZF file"; return SQ_E_IO; }
+    const ByteView file = fb.view();
+    if (!index_bgzf(file, blocks, total)) { err = "not a BGZF file"; return SQ_E_IO; }
     t_read = since(tr0);
     n_threads = std::max(1, n_threads);
 
@@ -469,7 +472,7 @@ static int parse_bam_impl(const char* path, const ParseOpts& o, size_t batch_rec
         size_t old = u.size();
         u.resize(old + bytes);
         auto ti0 = clk::now();
-        bool ok = inflate_range(fb.data, blocks, nb, b1, u.data() + old, base, n_threads);
+        bool ok = inflate_range(file, blocks, nb, b1, u.data() + old, base, n_threads);
         t_inflate += since(ti0);
         nb = b1;
         return ok;

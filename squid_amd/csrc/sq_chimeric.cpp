@@ -81,42 +81,43 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
     std::vector<uint16_t> sample;  // ReadLen = median of max(FirstTotalLen, SecondTotalLen) of the first five (ReadRec.cpp:336,347-348)
     for (size_t k = 0; k < usable.size() && k < 5; ++k) sample.push_back((uint16_t)b->totlen[usable[k]]);
     const size_t nr = usable.size();
-    std::vector<Frag> recs(nr);
     // sort by QNAME (ReadRec.cpp:354).  What is sorted is (first 16 bytes of the name as two big-endian words, index): most comparisons
-    // are decided inside the 24-byte elements, without touching the strings; the comparison results, and with them the permutation
-    // libstdc++'s introsort produces (ledger B8), are those of `name < name` on the reference's objects
-    struct NameKey { uint64_t hi, lo; int32_t idx; };
+    // are decided inside the 24-byte elements, without touching the names; the comparison results, and with them the permutation
+    // libstdc++'s introsort produces (ledger B8), are those of `name < name` on the reference's std::string objects (bytes compared as
+    // unsigned values, then the lengths).  The names stay where the batch has them: (offset, length) with a trailing /1 or /2 cut off
+    // (ReadRec.cpp:62-66); no per-record fragment object is built -- the merged fragments are put together from the sorted order.
+    struct NameKey { uint64_t hi, lo; int32_t idx; uint32_t len; };  // (names of up to 16 bytes are compared without leaving the element)
     std::vector<NameKey> nk(nr);
+    std::vector<uint32_t> nlen(nr);
+    auto name_ptr = [&](size_t k) { return b->name_blob + b->name_off[usable[k]]; };
     par((int64_t)nr, [&](int64_t lo, int64_t hi) {
         for (int64_t k = lo; k < hi; ++k) {
             const int64_t i = usable[(size_t)k];
-            Frag& f = recs[(size_t)k];
-            const int flag = b->flag[i];
-            f.name.assign(b->name_blob + b->name_off[i], b->name_blob + b->name_off[i + 1]);
-            size_t L = f.name.size();
-            if (L >= 2 && f.name[L - 2] == '/' && (f.name[L - 1] == '1' || f.name[L - 1] == '2')) f.name.resize(L - 2);
-            const bool first = flag & 0x40, rev = flag & 0x10;
-            std::vector<Blk>& dst = first ? f.a : f.b;
-            dst.reserve(b->blk_off[i + 1] - b->blk_off[i]);
-            for (uint32_t q = b->blk_off[i]; q < b->blk_off[i + 1]; ++q)
-                dst.push_back(Blk{b->refid[i], b->b_refpos[q], (int32_t)b->b_readpos[q], b->b_matchref[q], (int32_t)b->b_matchread[q], rev, first});
-            const bool low = b->aux[i] & SQ_AUX_LOWPHRED;
-            if (first) { f.atot = b->totlen[i]; f.alow = low; }
-            else { f.btot = b->totlen[i]; f.blow = low; }
+            const char* nm = b->name_blob + b->name_off[i];
+            size_t L = b->name_off[i + 1] - b->name_off[i];
+            if (L >= 2 && nm[L - 2] == '/' && (nm[L - 1] == '1' || nm[L - 1] == '2')) L -= 2;
+            nlen[(size_t)k] = (uint32_t)L;
             unsigned char buf[16] = {0};
-            std::memcpy(buf, f.name.data(), std::min<size_t>(16, f.name.size()));
+            std::memcpy(buf, nm, std::min<size_t>(16, L));
             uint64_t h = 0, l = 0;
             for (int q = 0; q < 8; ++q) { h = (h << 8) | buf[q]; l = (l << 8) | buf[8 + q]; }
-            nk[(size_t)k] = NameKey{h, l, (int32_t)k};
+            nk[(size_t)k] = NameKey{h, l, (int32_t)k, (uint32_t)L};
         }
     });
-    lap("single-record frags");
+    auto name_cmp = [&](int32_t x, int32_t y) {  // <0, 0, >0 like std::string::compare
+        const size_t lx = nlen[(size_t)x], ly = nlen[(size_t)y];
+        const int r = std::memcmp(name_ptr((size_t)x), name_ptr((size_t)y), std::min(lx, ly));
+        return r ? r : (lx < ly ? -1 : (lx > ly ? 1 : 0));
+    };
+    lap("name keys");
     // (std_sort_parallel: libstdc++'s introsort with its independent sub-ranges on several threads -- same comparisons, same result)
     const int sort_threads = pool ? std::min(pool->size() + 1, 32) : 1;
     std_sort_parallel(nk.begin(), nk.end(), [&](const NameKey& x, const NameKey& y) {
         if (x.hi != y.hi) return x.hi < y.hi;
         if (x.lo != y.lo) return x.lo < y.lo;
-        return recs[(size_t)x.idx].name < recs[(size_t)y.idx].name;
+        // equal first 16 bytes (zero padded; a name holds no NUL): two names of at most 16 bytes are then the same name
+        if (x.len <= 16 && y.len <= 16) return false;
+        return name_cmp(x.idx, y.idx) < 0;
     }, sort_threads);
     lap("name sort");
     // merge equal names (ReadRec.cpp:356-373): runs of equal names in the sorted order; the runs are independent of each other
@@ -126,7 +127,8 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
         par((int64_t)nr, [&](int64_t lo, int64_t hi) {
             for (int64_t k = lo; k < hi; ++k) {
                 const NameKey& x = nk[(size_t)k];
-                starts[(size_t)k] = k == 0 || x.hi != nk[(size_t)k - 1].hi || x.lo != nk[(size_t)k - 1].lo || recs[(size_t)x.idx].name != recs[(size_t)nk[(size_t)k - 1].idx].name;
+                const NameKey& w = nk[(size_t)k == 0 ? 0 : (size_t)k - 1];
+                starts[(size_t)k] = k == 0 || x.hi != w.hi || x.lo != w.lo || ((x.len > 16 || w.len > 16) && name_cmp(x.idx, w.idx) != 0);
             }
         });
         size_t cnt = 0;
@@ -140,15 +142,26 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
     auto by_readpos = blk_less_readpos;
     par((int64_t)nm, [&](int64_t lo, int64_t hi) {
         for (int64_t j = lo; j < hi; ++j) {
+            // the reference merges the records of a run into the first one, in the sorted order: blocks are appended mate by mate, and a
+            // mate's total length / low-quality flag come from the first record (whatever they are) unless its length is 0 and a later
+            // record brings one
             Frag& m = merged[(size_t)j];
-            m = std::move(recs[(size_t)nk[run_start[(size_t)j]].idx]);
-            for (size_t k = run_start[(size_t)j] + 1; k < run_start[(size_t)j + 1]; ++k) {
-                Frag& r = recs[(size_t)nk[k].idx];
-                if (m.atot == 0 && r.atot != 0) { m.atot = r.atot; m.alow = r.alow; }
-                if (m.btot == 0 && r.btot != 0) { m.btot = r.btot; m.blow = r.blow; }
-                m.a.insert(m.a.end(), r.a.begin(), r.a.end());
-                m.b.insert(m.b.end(), r.b.begin(), r.b.end());
-                std::vector<Blk>().swap(r.a); std::vector<Blk>().swap(r.b); std::string().swap(r.name);  // (freed here, on this thread, not one by one at the end)
+            const size_t k0 = run_start[(size_t)j], k1 = run_start[(size_t)j + 1];
+            m.name.assign(name_ptr((size_t)nk[k0].idx), nlen[(size_t)nk[k0].idx]);
+            size_t na = 0, nb = 0;
+            for (size_t k = k0; k < k1; ++k) { const int64_t i = usable[(size_t)nk[k].idx]; ((b->flag[i] & 0x40) ? na : nb) += b->blk_off[i + 1] - b->blk_off[i]; }
+            m.a.reserve(na); m.b.reserve(nb);
+            for (size_t k = k0; k < k1; ++k) {
+                const int64_t i = usable[(size_t)nk[k].idx];
+                const int flag = b->flag[i];
+                const bool first = flag & 0x40, rev = flag & 0x10, low = b->aux[i] & SQ_AUX_LOWPHRED;
+                const int tot = b->totlen[i];
+                std::vector<Blk>& dst = first ? m.a : m.b;
+                for (uint32_t q = b->blk_off[i]; q < b->blk_off[i + 1]; ++q)
+                    dst.push_back(Blk{b->refid[i], b->b_refpos[q], (int32_t)b->b_readpos[q], b->b_matchref[q], (int32_t)b->b_matchread[q], rev, first});
+                if (k == k0) { if (first) { m.atot = tot; m.alow = low; } else { m.btot = tot; m.blow = low; } }
+                else if (first) { if (m.atot == 0 && tot != 0) { m.atot = tot; m.alow = low; } }
+                else if (m.btot == 0 && tot != 0) { m.btot = tot; m.blow = low; }
             }
             std::sort(m.a.begin(), m.a.end(), by_readpos);  // SortbyReadPos (ReadRec.cpp:143-146)
             std::sort(m.b.begin(), m.b.end(), by_readpos);
@@ -185,6 +198,9 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
     // position.  So the decisions fall into groups -- maximal runs, in this order, of fragments with a first-in-pair block at one
     // position -- whose first member is always kept (what was kept before it lies in another group, or has no such block) and whose
     // other members are compared with kept members of the same group only.  Groups are decided side by side.
+    par((int64_t)c->frags.size(), [&](int64_t lo, int64_t hi) {  // (the fragments of an earlier ingest: freed side by side, not one by one)
+        for (int64_t k = lo; k < hi; ++k) { Frag& f = c->frags[(size_t)k]; std::vector<Blk>().swap(f.a); std::vector<Blk>().swap(f.b); std::string().swap(f.name); }
+    });
     c->frags.clear();
     std::vector<Frag>& out = c->frags;
     std::vector<uint8_t> kept(nm, 0);   // by merged index

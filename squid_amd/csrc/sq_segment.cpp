@@ -445,16 +445,28 @@ double segment_clusters(const sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::ve
         }
     };
     if (pieces > 1) c->pool->parallel_for(pieces, 15, work); else work(0);
-    for (Out& O : outs) {
+    auto par = [&](size_t n, const std::function<void(size_t, size_t)>& f) {  // [lo, hi) pieces on the context's host threads
+        const int np = (c->pool && n > 100000) ? 4 * (c->pool->size() + 1) : 1;
+        if (np <= 1) { f(0, n); return; }
+        c->pool->parallel_for(np, 15, [&](int k) { f(n * (size_t)k / (size_t)np, n * ((size_t)k + 1) / (size_t)np); });
+    };
+    {
         // the entries that were waiting for the last discordant block of the pieces in front: drop those that are the `Same` block
-        std::vector<char> drop(O.part.size(), 0);
-        for (const auto& q : O.ask) {
-            Blk z{0, 0, 0, 0, 0, false, false};
-            const Blk& l = D.empty() ? z : D.back();
-            if (blk_same(l, q.second)) drop[q.first] = 1;
+        std::vector<size_t> d_at(outs.size() + 1, 0);
+        for (size_t k = 0; k < outs.size(); ++k) d_at[k + 1] = d_at[k] + outs[k].D.size();
+        D.resize(d_at.back());
+        if (pieces > 1) c->pool->parallel_for(pieces, 15, [&](int k) { std::copy(outs[(size_t)k].D.begin(), outs[(size_t)k].D.end(), D.begin() + (std::ptrdiff_t)d_at[(size_t)k]); });
+        else std::copy(outs[0].D.begin(), outs[0].D.end(), D.begin());
+        for (size_t k = 0; k < outs.size(); ++k) {
+            Out& O = outs[k];
+            std::vector<char> drop(O.part.size(), 0);
+            for (const auto& q : O.ask) {
+                Blk z{0, 0, 0, 0, 0, false, false};
+                const Blk& l = d_at[k] == 0 ? z : D[d_at[k] - 1];  // the last discordant block of the pieces in front
+                if (blk_same(l, q.second)) drop[q.first] = 1;
+            }
+            for (size_t i = 0; i < O.part.size(); ++i) if (!drop[i]) S.part.push_back(O.part[i]);
         }
-        for (size_t i = 0; i < O.part.size(); ++i) if (!drop[i]) S.part.push_back(O.part[i]);
-        D.insert(D.end(), O.D.begin(), O.D.end());
     }
     const int sort_threads = c->pool ? std::min(c->pool->size() + 1, 32) : 1;
     std_sort_parallel(S.part.begin(), S.part.end(), std::less<std::pair<int, int>>(), sort_threads);
@@ -463,11 +475,11 @@ double segment_clusters(const sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::ve
         // the memory traffic of sorting the blocks themselves
         struct PK { int32_t refid, refpos, idx; };
         std::vector<PK> pk(D.size());
-        for (size_t i = 0; i < D.size(); ++i) pk[i] = PK{D[i].refid, D[i].refpos, (int32_t)i};
+        par(D.size(), [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) pk[i] = PK{D[i].refid, D[i].refpos, (int32_t)i}; });
         // (std_sort_parallel, sq_parsort.h: the same introsort with its independent sub-ranges on several threads)
         std_sort_parallel(pk.begin(), pk.end(), [](const PK& x, const PK& y) { return x.refid != y.refid ? x.refid < y.refid : x.refpos < y.refpos; }, sort_threads);
         std::vector<Blk> sorted(D.size());
-        for (size_t i = 0; i < D.size(); ++i) sorted[i] = D[(size_t)pk[i].idx];
+        par(D.size(), [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) sorted[i] = D[(size_t)pk[i].idx]; });
         D.swap(sorted);
     }
     S.nd = (int)D.size();
@@ -762,7 +774,11 @@ int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds, bool virt
     for (size_t a = 1; a < na && !serial_only; ++a) {
         const int j = active[a], jp = active[a - 1];
         const int64_t lo = Z[j - 1];                                   // j > 0 here
-        const int64_t hip = jp < nz ? Z[jp] : plan.K_eff - 1;          // last record the previous stretch looks at
+        // the last record the stretch before really works on: the one in front of its closing zero-coverage record.  (At that record
+        // the stretch only flushes its pending node end, SegmentGraph.cpp:621-636, which lies where its own records lie; the first record
+        // of a chromosome is such a closing record, so comparing with IT would never see a chromosome change.  Whatever a group
+        // assumes about the node in front of it is checked below.)
+        const int64_t hip = jp < nz ? std::max<int64_t>((int64_t)Z[jp] - 1, 0) : plan.K_eff - 1;
         if (rec_at(a, lo).refid > rec_at(a - 1, hip).refid) { starts.push_back(a); first_chr.push_back(rec_at(a, lo).refid); }
     }
     const size_t ng = starts.size();

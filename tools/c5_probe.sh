@@ -10,4 +10,6 @@ SQUID_INGEST_TIMING=1 SQUID_CHIM_PROF=1 timeout 300 /tmp/c5p/chim_probe /tmp/c5p
 ( time SQUID_TIMING=1 SQUID_INGEST_TIMING=1 SQUID_CHIM_PROF=1 timeout 600 build/squid -b /tmp/c5p/C5.bam -c /tmp/c5p/C5.chim.bam -o /tmp/c5p/cli -w 1 -a 50 --threads 16 ) > $OUT/cli.log 2>&1
 ( time SQUID_TIMING=1 SQUID_REPLAY_PROF=1 SQUID_ORDER_PROF=1 timeout 600 build/squid -b /tmp/c5p/C5.bam -c /tmp/c5p/C5.chim.bam -o /tmp/c5p/cli2 -w 1 -a 50 --threads 16 ) > $OUT/cli_replay_prof.log 2>&1
 cmp /tmp/c5p/cli_sv.txt /tmp/c5p/cli2_sv.txt && echo same_sv >> $OUT/cli.log
+( time SQUID_TIMING=1 SQUID_HOST_FILTERS=1 timeout 600 build/squid -b /tmp/c5p/C5.bam -c /tmp/c5p/C5.chim.bam -o /tmp/c5p/cli3 -w 1 -a 50 --threads 16 ) > $OUT/cli_host_filters.log 2>&1
+cmp /tmp/c5p/cli_sv.txt /tmp/c5p/cli3_sv.txt && echo same_sv >> $OUT/cli_host_filters.log
 nproc > $OUT/nproc.log; cat /sys/fs/cgroup/cpu.max >> $OUT/nproc.log 2>&1
