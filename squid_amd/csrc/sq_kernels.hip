@@ -183,6 +183,9 @@ struct DeviceRecords {
     DBuf<uint8_t> zflag;
     DBuf<int32_t> cl_chr, trig, cl_bucket;  // cl_chr: packed cluster table chr | start | right; cl_bucket: bucket_off | position index of the cluster table
     DBuf<int32_t> bp_ev, bp_before, bp_end, bp_valid, bp_bucket, stripes;
+    DBuf<unsigned int> depth_tiles;             // k_depth2: per tile its largest early node / cursor at its first record / list of tiles to correct
+    DBuf<unsigned long long> bp_key, bp_front;  // breakpoint cursor: largest (chromosome, fragment start) per 256 records (k_edges_near) / in front of every tile of k_bp2
+    int64_t bp_key_n = -1;                      // record count the keys were made for
     // pass 1 (k_pass1): look-back status words, kept records in front of every tile, tile sort keys, the three lists, scalars
     DBuf<unsigned long long> lb;
     DBuf<int32_t> tile_cnt, tile_zcnt2, zc_v, zc_K, zc_refid, zc_pos;
@@ -816,6 +819,15 @@ __device__ __forceinline__ void node_add_lds(NodeAcc& A, int32_t* cnt, int32_t* 
         active &= ~same;
     }
 }
+// one lane adds (n records, sum of lengths) for node k
+__device__ __forceinline__ void node_add_bulk(NodeAcc& A, int32_t* cnt, int32_t* sum, int nn, int k, int n, int v) {
+    for (int q = 0; q < 4; ++q) {
+        const int old = atomicCAS(&A.key[q], -1, k);
+        if (old == -1 || old == k) { atomicAdd(&A.cnt[q], n); atomicAdd(&A.sum[q], v); return; }
+    }
+    const size_t so = (size_t)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (NODE_STRIPES - 1)) * (size_t)nn;
+    atomicAdd(&cnt[so + k], n); atomicAdd(&sum[so + k], v);
+}
 __global__ void k_fold_stripes(int nn, const int32_t* a, const int32_t* b, const int32_t* c2, const int32_t* d, int32_t* out /* 4 x nn */) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nn) return;
@@ -988,13 +1000,29 @@ struct EdgeParams2 { int dp, di, ablate; };
 // sees both mates in one node (:1655-1685).  That is 99 % of the records of an RNA-seq sample.  This kernel is a plain
 // scan -- fixed fields, first and last own block, one node lookup -- in 40-odd registers, where the full rule set below
 // needs 90 and runs five waves per SIMD.
-__global__ void k_edges_near(RecView R, NodeView N, const uint8_t* keep, uint32_t* list, int32_t* count, int all /* SQUID_EDGES_ALL: clear nothing, every record takes the full rule set (cross-check) */) {
+// It also leaves, per workgroup of 256 records, what the breakpoint-support kernel of sq_call_sv would otherwise have to scan the stream
+// for: the largest (chromosome, fragment start) among its pass-3 records (bp_block_key; SegmentGraph.cpp:3147-3158 -- the cursor's bound
+// in front of a record is a monotone function of the largest such pair seen so far).  The fields are here anyway, except pos and class.
+__device__ __forceinline__ unsigned long long bp_record_key(uint8_t cls, int flag, int rid, int p, int mrid, int mp) {  // 0: not a pass-3 record
+    if (!(cls & C_P3)) return 0ull;
+    const int st = (!(flag & 0x8) && mrid == rid) ? mp : p;  // SegmentGraph.cpp:3147-3150
+    return (((unsigned long long)(uint32_t)rid << 32) | (uint32_t)((uint32_t)st ^ 0x80000000u)) + 1ull;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+    for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
+    return v;
+}
+__global__ __launch_bounds__(256) void k_edges_near(RecView R, NodeView N, const uint8_t* keep, const uint8_t* cls, unsigned long long* bp_block_key, uint32_t* list, int32_t* count, int all /* SQUID_EDGES_ALL: clear nothing, every record takes the full rule set (cross-check) */) {
+    __shared__ unsigned long long s_key[4];
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool need = false;
+    unsigned long long bkey = 0;
     if (r < R.n) {
         const uint8_t kp = keep[r];  // (the loads below do not wait for it: one memory round trip)
-        const int flag = R.flag[r], rid = R.refid[r], mrid = R.mrefid[r], mp = R.mpos[r];
+        const uint8_t cl = cls[r];
+        const int flag = R.flag[r], rid = R.refid[r], mrid = R.mrefid[r], mp = R.mpos[r], rpos = R.pos[r];
         const uint32_t bo = R.blk_off[r], bo1 = R.blk_off[r + 1];
+        bkey = bp_record_key(cl, flag, rid, rpos, mrid, mp);
         if (kp & K_BUILD) {
             const int nown = (int)(bo1 - bo);
             const bool first = flag & 0x40, rev = flag & 0x10, stub = !(flag & 0x8) && mrid != -1;
@@ -1019,13 +1047,62 @@ __global__ void k_edges_near(RecView R, NodeView N, const uint8_t* keep, uint32_
             }
         }
     }
+    const int lane = threadIdx.x & 63;
+    bkey = wave_max_u64(bkey);
+    if (lane == 0) s_key[threadIdx.x >> 6] = bkey;
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned long long k = s_key[0]; for (int w = 1; w < 4; ++w) k = s_key[w] > k ? s_key[w] : k; bp_block_key[blockIdx.x] = k; }
     const unsigned long long m = __ballot(need);
     if (!m) return;
-    const int lane = threadIdx.x & 63;
     int base = 0;
     if (lane == __ffsll((long long)m) - 1) base = atomicAdd(count, (int)__popcll(m));
     base = __shfl(base, __ffsll((long long)m) - 1, 64);
     if (need) list[base + (int)__popcll(m & ((1ull << lane) - 1))] = (uint32_t)r;
+}
+// the same keys by themselves (breakpoint support asked for without an edge stage over these records in front of it)
+__global__ __launch_bounds__(256) void k_bp_keys(RecView R, const uint8_t* cls, unsigned long long* bp_block_key) {
+    __shared__ unsigned long long s_key[4];
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long bkey = 0;
+    if (r < R.n) bkey = bp_record_key(cls[r], R.flag[r], R.refid[r], R.pos[r], R.mrefid[r], R.mpos[r]);
+    bkey = wave_max_u64(bkey);
+    if ((threadIdx.x & 63) == 0) s_key[threadIdx.x >> 6] = bkey;
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned long long k = s_key[0]; for (int w = 1; w < 4; ++w) k = s_key[w] > k ? s_key[w] : k; bp_block_key[blockIdx.x] = k; }
+}
+// front[t] = largest key in front of tile t of the breakpoint kernel (a tile = `per_tile` workgroups of 256 records).  Two small
+// launches over the keys, 1024 per workgroup, coalesced: the maximum of every 1024, then per workgroup the maximum of the groups in
+// front of it (a few hundred values) and an exclusive max-scan of its own 1024.
+__global__ __launch_bounds__(1024) void k_bp_key_reduce(const unsigned long long* key, int nkeys, unsigned long long* part) {
+    __shared__ unsigned long long s_w[16];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    unsigned long long v = wave_max_u64(i < nkeys ? key[i] : 0ull);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned long long m = 0; for (int w = 0; w < 16; ++w) m = s_w[w] > m ? s_w[w] : m; part[blockIdx.x] = m; }
+}
+__global__ __launch_bounds__(1024) void k_bp_key_scan(const unsigned long long* key, int nkeys, const unsigned long long* part, int per_tile, unsigned long long* front, int ntiles) {
+    __shared__ unsigned long long s_w[16];
+    __shared__ unsigned long long s_before;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int i = blockIdx.x * 1024 + t;
+    if (wave == 0) {  // everything in front of this workgroup
+        unsigned long long m = 0;
+        for (int b = lane; b < (int)blockIdx.x; b += 64) { const unsigned long long p = part[b]; m = p > m ? p : m; }
+        m = wave_max_u64(m);
+        if (lane == 0) s_before = m;
+    }
+    const unsigned long long own = i < nkeys ? key[i] : 0ull;
+    unsigned long long x = own;  // inclusive max-scan inside the wave
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long y = __shfl_up(x, d, 64); if (lane >= d && y > x) x = y; }
+    if (lane == 63) s_w[wave] = x;
+    __syncthreads();
+    unsigned long long run = s_before;
+    for (int w = 0; w < wave; ++w) run = s_w[w] > run ? s_w[w] : run;
+    unsigned long long e = __shfl_up(x, 1, 64);  // exclusive
+    if (lane == 0) e = 0;
+    e = e > run ? e : run;
+    if (i < nkeys && i % per_tile == 0 && i / per_tile < ntiles) front[i / per_tile] = e;
 }
 // Pass 2: the full rule set for one record of the work list
 __device__ __forceinline__ void edges_record(const RecView& R, const NodeView& N, const EdgeParams2& P2, const uint8_t* keep, int64_t r, unsigned long long* hk, uint32_t* hv, uint32_t hmask, int32_t* flags, int32_t* stripes) {
@@ -2470,7 +2547,7 @@ void dev_destroy(sq_ctx* c) {
     for (auto& ps : D.il_post) { ps.out.release(); ps.rec_sync.release(); ps.rec_end.release(); ps.rec_cnt.release(); ps.rec_base.release(); ps.flags.release(); ps.spine.release(); ps.bam_off.release(); }
     if (D.il_parse_stream) { (void)hipStreamDestroy(D.il_parse_stream); D.il_parse_stream = nullptr; }
     if (D.il_host) { (void)hipHostFree(D.il_host); D.il_host = nullptr; }
-    D.bgzf_out.release(); D.bgzf_carry.release(); D.staged.release(); D.rec_sync.release(); D.rec_end.release(); D.rec_cnt.release(); D.rec_base.release(); D.stripes.release(); D.bp_bucket.release(); D.bp_ev.release(); D.bp_end.release(); D.bp_valid.release();
+    D.bgzf_out.release(); D.bgzf_carry.release(); D.staged.release(); D.rec_sync.release(); D.rec_end.release(); D.rec_cnt.release(); D.rec_base.release(); D.stripes.release(); D.bp_bucket.release(); D.bp_key.release(); D.bp_front.release(); D.depth_tiles.release(); D.bp_ev.release(); D.bp_end.release(); D.bp_valid.release();
     for (auto& e : D.ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete c->dev;
     c->dev = nullptr;
@@ -3243,10 +3320,17 @@ int dev_node_depth(sq_ctx* c, const std::vector<Node>& nodes, int64_t n_break, s
     if (n > 0) {
         { const int rb = set_r_break(c, n_break); if (rb) return rb; }
         const int ntiles = (int)((n + ST_TILE - 1) / ST_TILE);
-        HIPCHK(lb_prepare(D.lb, LbView<1>::words(ntiles), s));
+        // per tile: its largest early node, the cursor at its first record; the tiles to correct and the cursor in front of them
+        HIPCHK(D.depth_tiles.reserve(4 * (size_t)ntiles + 4));
+        unsigned int *t_agg = D.depth_tiles.p, *t_first = t_agg + ntiles, *t_front = t_first + ntiles;
+        int32_t *t_flagged = (int32_t*)(t_front + ntiles), *n_flagged = D.flags.p + 7;  // (flags were just zeroed; read back with them)
+        const DepthTiles T{t_agg, t_first, n_flagged, t_flagged, t_front};
         // keep 1 + block offset 4 + refid 4 per record; 16 B per block of a consumed record (the cursor never leaves the kernel)
         { EvTimer t(c, "k_depth2", 9.0 * n + 16.0 * D.nb * ((double)D.k1 / (double)n));
-          hipLaunchKernelGGL(k_depth2, dim3(ntiles), dim3(ST_THREADS), 0, s, R, nv, D.keep.p, D.r_break.p, LbView<1>{D.lb.p, std::getenv("SQUID_LB_SKIP") ? 1 : 0}, ntiles, a_mc, a_ms, a_oc, a_os, a_ap, a_am, D.flags.p, stripes);
+          hipLaunchKernelGGL(k_depth2<false>, dim3(ntiles), dim3(ST_THREADS), 0, s, R, nv, D.keep.p, D.r_break.p, T, ntiles, a_mc, a_ms, a_oc, a_os, a_ap, a_am, D.flags.p, stripes); }
+        { EvTimer t(c, "k_depth_check+fix", 8.0 * ntiles);
+          hipLaunchKernelGGL(k_depth_check, dim3((ntiles + 1023) / 1024), dim3(1024), 0, s, t_agg, t_first, ntiles, n_flagged, t_flagged, t_front, ntiles);
+          hipLaunchKernelGGL(k_depth2<true>, dim3(64), dim3(ST_THREADS), 0, s, R, nv, D.keep.p, D.r_break.p, T, ntiles, a_mc, a_ms, a_oc, a_os, a_ap, a_am, D.flags.p, stripes);
           if (nn) hipLaunchKernelGGL(k_fold_stripes, dim3((nn + 255) / 256), dim3(256), 0, s, nn, a_mc, a_ms, a_oc, a_os, acc); }
     }
     D.pin.reset();
@@ -3258,6 +3342,7 @@ int dev_node_depth(sq_ctx* c, const std::vector<Node>& nodes, int64_t n_break, s
     HIPCHK(hipMemcpyAsync(hs, stripes, NSTRIPE * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (hf[0] & 1) return fail(c, SQ_E_UNSORTED, "concordant stream is not coordinate sorted (depth cursor left its chromosome)");
+    c->timer.add("depth_tiles_corrected", 0.0, (double)hf[7], 1);  // (a count, not bytes: tiles whose sweep cursor came from further ahead, k_depth2<true>)
     need_exact_other = hf[0] & 2;
     amb_plus.assign(ap, ap + nn); amb_minus.assign(am, am + nn);
     support.assign(nn * 2, 0);
@@ -3301,8 +3386,10 @@ int dev_concordant_edges(sq_ctx* c, const std::vector<Node>& nodes, std::vector<
         // pass 2 sees the ~1 % of the records that pass 1 could not clear (its bytes are not counted)
         uint32_t* list = (uint32_t*)D.scratch_a.p;
         int32_t* count = D.flags.p + 6;
-        { EvTimer t(c, "k_edges_near", 19.0 * n + 16.0 * D.nb);
-          hipLaunchKernelGGL(k_edges_near, grid_for(n, 256), dim3(256), 0, s, R, nv, D.keep.p, list, count, std::getenv("SQUID_EDGES_ALL") ? 1 : 0); }
+        HIPCHK(D.bp_key.reserve((size_t)((n + 255) / 256) + 1));
+        { EvTimer t(c, "k_edges_near", 24.0 * n + 16.0 * D.nb);  // (+ class 1 and pos 4 for the breakpoint-cursor keys)
+          hipLaunchKernelGGL(k_edges_near, grid_for(n, 256), dim3(256), 0, s, R, nv, D.keep.p, D.cls.p, D.bp_key.p, list, count, std::getenv("SQUID_EDGES_ALL") ? 1 : 0); }
+        D.bp_key_n = n;
         { EvTimer t(c, "k_edges", 0);
           hipLaunchKernelGGL(k_edges, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, s, R, nv, ep, D.keep.p, list, count, D.h_key.p, D.h_val.p, slots - 1, D.flags.p, D.stripes.p); }
         // compact right away (wasted only if the table turns out to have overflowed): one synchronisation for both
@@ -3451,10 +3538,16 @@ int dev_breakpoint_support(sq_ctx* c, const std::vector<std::pair<int, int>>& bp
     const int32_t minus1 = -1;
     HIPCHK(hipMemcpyAsync(agg + 1, &minus1, 4, hipMemcpyHostToDevice, s));
     {   // class 1 + refid, pos, mate refid, mate pos, end 4 each + flag 2 per record; nothing written per record
-        const int ntiles = (int)((n + ST_TILE - 1) / ST_TILE);
-        HIPCHK(lb_prepare(D.lb, LbView<1>::words(ntiles), s));
+        const int ntiles = (int)((n + ST_TILE - 1) / ST_TILE), nkeys = (int)((n + 255) / 256);
+        HIPCHK(D.bp_key.reserve((size_t)nkeys + 1)); HIPCHK(D.bp_front.reserve((size_t)ntiles + 1 + (size_t)(nkeys + 1023) / 1024 + 1));
+        if (D.bp_key_n != n) { hipLaunchKernelGGL(k_bp_keys, dim3(nkeys), dim3(256), 0, s, R, D.cls.p, D.bp_key.p); D.bp_key_n = n; }  // (normally left by the edge stage)
+        { EvTimer t(c, "k_bp_key_prefix", 8.0 * nkeys * 2 + 8.0 * ntiles);
+          const int ng = (nkeys + 1023) / 1024;
+          unsigned long long* part = D.bp_front.p + ntiles + 1;
+          hipLaunchKernelGGL(k_bp_key_reduce, dim3(ng), dim3(1024), 0, s, D.bp_key.p, nkeys, part);
+          hipLaunchKernelGGL(k_bp_key_scan, dim3(ng), dim3(1024), 0, s, D.bp_key.p, nkeys, part, ST_TILE / 256, D.bp_front.p, ntiles); }
         EvTimer t(c, "k_bp2", 23.0 * n);
-        hipLaunchKernelGGL(k_bp2, dim3(ntiles), dim3(ST_THREADS), 0, s, R, B, D.cls.p, cur_prev, LbView<1>{D.lb.p, std::getenv("SQUID_LB_SKIP") ? 1 : 0}, ntiles, D.bp_ev.p, D.bp_before.p, D.acc_c.p, agg);
+        hipLaunchKernelGGL(k_bp2, dim3(ntiles), dim3(ST_THREADS), 0, s, R, B, D.cls.p, cur_prev, D.bp_front.p, ntiles, D.bp_ev.p, D.bp_before.p, D.acc_c.p, agg);
     }
     { EvTimer t(c, "k_bp_walk", 0);
       hipLaunchKernelGGL(k_bp_walk2<false>, dim3(nb), dim3(64), 0, s, R, B, D.cls.p, cur_prev, D.bp_ev.p, D.bp_before.p, D.bp_end.p, D.bp_valid.p, D.acc_c.p, agg + 1);

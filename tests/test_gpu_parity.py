@@ -341,6 +341,55 @@ def test_gpu_record_parse_hand_made_records(built, tmp_path, monkeypatch):
 
 
 # ---- K10: the breakpoint cursor of ExactBPConcordantSupport (src/SegmentGraph.cpp:3129-3166) on dense breakpoint lists
+def _read_bam_records(path):
+    """(header bytes incl. references, [(refid, pos, record bytes)]) of a BAM file"""
+    import gzip, struct
+    data = gzip.open(path, "rb").read()
+    l_text = struct.unpack_from("<i", data, 4)[0]
+    at = 8 + l_text
+    n_ref = struct.unpack_from("<i", data, at)[0]
+    at += 4
+    contigs = []
+    for _ in range(n_ref):
+        l_name = struct.unpack_from("<i", data, at)[0]
+        name = data[at + 4:at + 4 + l_name - 1].decode()
+        contigs.append((name, struct.unpack_from("<i", data, at + 4 + l_name)[0]))
+        at += 8 + l_name
+    recs = []
+    while at < len(data):
+        bs, refid, pos = struct.unpack_from("<iii", data, at)
+        recs.append((refid, pos, data[at:at + 4 + bs]))
+        at += 4 + bs
+    return contigs, recs
+
+
+def test_depth_cursor_held_ahead_by_far_first_blocks(built, synth, tmp_path, exact_depth):
+    """ReadsMain's sweep cursor (SegmentGraph.cpp:787-799) never moves back: a record whose first aligned block lies kilobases behind
+    its position (a CIGAR that opens with a skip) parks it ahead of the records that follow.  k_depth2 works tile by tile on the
+    assumption that nothing in front of a tile lies ahead of its first record; here that fails for many tiles, k_depth_check finds
+    them and k_depth2<true> redoes their contributions -- Support / AvgDepth of every node must still equal the oracle's."""
+    import bamwriter as bw
+
+    pre = synth("T2")
+    contigs, recs = _read_bam_records(f"{pre}.bam")
+    out = []
+    for i, (refid, pos, raw) in enumerate(recs):
+        if refid >= 0 and i % 1500 == 700:
+            out.append(bw.record(f"far{i}", refid, pos, 255, 0x1 | 0x2 | 0x20 | 0x40, "4000N100M", refid, pos + 4200))
+        if refid >= 0 and i % 97 == 5:  # first blocks of one to three bases: the corner where the cursor lags one node behind
+            out.append(bw.record(f"tiny{i}", refid, pos, 255, 0x1 | 0x2 | 0x20 | 0x40, f"{1 + i % 3}M700N{99 - i % 3}M", refid, pos + 900))
+        out.append(raw)
+    new = tmp_path / "far"
+    bw.write_bam(f"{new}.bam", contigs, out)
+    (tmp_path / "far.chim.bam").write_bytes(Path(f"{pre}.chim.bam").read_bytes())
+    sv_path, dump = ou.run_oracle(built, new, tmp_path)
+    with squid_amd.Context() as ctx:
+        ctx.load(f"{new}.bam", f"{new}.chim.bam")
+        ctx.build_graph()
+        _compare(ctx, dump, sv_path)
+        assert ctx.timing()["depth_tiles_corrected"]["bytes"] >= 2  # (a count: the correction pass had work)
+
+
 def _bp_support_literal(rec, bps, min_mapq, dp):
     """the reference's loop, statement by statement, over downloaded records (pass-3 filter :3131-3142)"""
     cov = [0] * len(bps)
