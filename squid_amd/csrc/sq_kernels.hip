@@ -3099,13 +3099,16 @@ int dev_pass1(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<i
             static const bool prof = std::getenv("SQUID_P1_PROF") != nullptr;  // s_memtime sums per section of a tile (thread 0 of every workgroup)
             if (prof) {
                 HIPCHK(D.tok_prof.reserve(16)); HIPCHK(hipMemsetAsync(D.tok_prof.p, 0, 16 * 8, s));
-                hipLaunchKernelGGL(k_pass1<true>, dim3(ntiles), dim3(P1_THREADS), 0, s, R, C, A, D.tok_prof.p);
+                hipLaunchKernelGGL((k_pass1<true, 4>), dim3(ntiles), dim3(P1_THREADS), 0, s, R, C, A, D.tok_prof.p);
                 unsigned long long hp[8];
                 HIPCHK(hipMemcpyAsync(hp, D.tok_prof.p, sizeof hp, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
                 static const char* nm[7] = {"start", "load+classify+dedup", "scan", "clusters+z+triggers+rest", "run of slots", "emit", "-"};
                 for (int q = 0; q < 7; ++q) std::fprintf(stderr, "[k_pass1] %-28s %10.0f ticks per tile\n", nm[q], (double)hp[q] / (double)std::max<unsigned long long>(hp[7], 1));
             } else {
-                hipLaunchKernelGGL(k_pass1<false>, dim3(ntiles), dim3(P1_THREADS), 0, s, R, C, A, (unsigned long long*)nullptr);
+                static const int p1_waves = std::getenv("SQUID_P1_WAVES") ? std::atoi(std::getenv("SQUID_P1_WAVES")) : 5;  // (five waves per SIMD with 44 B of spills: 1.49 ms at C3; four without: 1.65; six: 2.49)
+                if (p1_waves == 5) hipLaunchKernelGGL((k_pass1<false, 5>), dim3(ntiles), dim3(P1_THREADS), 0, s, R, C, A, (unsigned long long*)nullptr);
+                else if (p1_waves == 6) hipLaunchKernelGGL((k_pass1<false, 6>), dim3(ntiles), dim3(P1_THREADS), 0, s, R, C, A, (unsigned long long*)nullptr);
+                else hipLaunchKernelGGL((k_pass1<false, 4>), dim3(ntiles), dim3(P1_THREADS), 0, s, R, C, A, (unsigned long long*)nullptr);
             }
         }
         {   // per tile: count 4 + pair 8 + two keys 16 in, rank 4 + pair 8 out

@@ -7,8 +7,21 @@ reads).  WRITE_SIZE does not carry the factor of two: the scan that writes exact
 200 690 counts, i.e. 1024 B per count -- so writes are scaled by half the read factor."""
 import csv
 import json
+import re
 import sys
 from collections import defaultdict
+
+# kernels that one HIP-event timer of the library brackets together (bench.py looks traffic up by timer name)
+GROUPS = {
+    "k_depth_check+fix": ["k_depth_check", "k_depth2<true>", "k_fold_stripes"],
+    "k_bp_key_prefix": ["k_bp_key_reduce", "k_bp_key_scan"],
+    "k_bp_walk": ["k_bp_walk2<false>", "k_bp_chain", "k_bp_walk2<true>"],
+}
+
+
+def short(name):
+    n = name.split("(")[0].replace("sq::", "").replace("void ", "").strip()
+    return n if n in sum(GROUPS.values(), []) else re.sub(r"<.*>$", "", n)  # k_pass1<false> -> k_pass1; the grouped ones keep their template argument
 
 
 def load(path):
@@ -17,7 +30,7 @@ def load(path):
         for row in csv.DictReader(f):
             name = row.get("Kernel_Name") or row.get("Kernel Name") or ""
             val = float(row.get("Counter_Value") or row.get("Counter Value") or 0)
-            per[name.split("(")[0].replace("sq::", "").replace("void ", "").strip()].append(val)
+            per[short(name)].append(val)
     return per
 
 
@@ -33,4 +46,8 @@ for k in sorted(fetch):
     w = sum(write.get(k, [0])) / max(1, len(write.get(k, [0])))
     out[k] = {"launches": len(fetch[k]), "fetch_bytes_per_launch": f * factor if factor else None, "write_bytes_per_launch": w * factor / 2 if factor else None,
               "hbm_bytes_per_launch": (f + w / 2) * factor if factor else None}
+for g, members in GROUPS.items():  # per launch of the group = one launch of each member
+    if all(m in out for m in members):
+        out[g] = {"launches": min(out[m]["launches"] for m in members), "members": members,
+                  **{f: sum(out[m][f] for m in members) for f in ("fetch_bytes_per_launch", "write_bytes_per_launch", "hbm_bytes_per_launch")}}
 print(json.dumps(out, indent=1))
