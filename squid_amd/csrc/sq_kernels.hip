@@ -3108,6 +3108,7 @@ int dev_pass1(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<i
                 static const int p1_waves = std::getenv("SQUID_P1_WAVES") ? std::atoi(std::getenv("SQUID_P1_WAVES")) : 5;  // (five waves per SIMD with 44 B of spills: 1.49 ms at C3; four without: 1.65; six: 2.49)
                 if (p1_waves == 5) hipLaunchKernelGGL((k_pass1<false, 5>), dim3(ntiles), dim3(P1_THREADS), 0, s, R, C, A, (unsigned long long*)nullptr);
                 else if (p1_waves == 6) hipLaunchKernelGGL((k_pass1<false, 6>), dim3(ntiles), dim3(P1_THREADS), 0, s, R, C, A, (unsigned long long*)nullptr);
+                else if (p1_waves == 8) hipLaunchKernelGGL((k_pass1<false, 8>), dim3(ntiles), dim3(P1_THREADS), 0, s, R, C, A, (unsigned long long*)nullptr);
                 else hipLaunchKernelGGL((k_pass1<false, 4>), dim3(ntiles), dim3(P1_THREADS), 0, s, R, C, A, (unsigned long long*)nullptr);
             }
         }
