@@ -187,7 +187,6 @@ struct DeviceRecords {
     DBuf<unsigned long long> bp_key, bp_front;  // breakpoint cursor: largest (chromosome, fragment start) per 256 records (k_edges_near) / in front of every tile of k_bp2
     int64_t bp_key_n = -1;                      // record count the keys were made for
     // pass 1 (k_pass1): look-back status words, kept records in front of every tile, tile sort keys, the three lists, scalars
-    DBuf<unsigned long long> lb;
     DBuf<int32_t> tile_cnt, tile_zcnt2, zc_v, zc_K, zc_refid, zc_pos;
     DBuf<unsigned long long> tile_ob, zc_ob;  // tile_ob: [ntiles] pair of every tile | [ntiles] pair in front of every tile
     DBuf<int32_t> tile_rank, tile_zbase, tile_zcnt, z_idx, z_chr, z_right, rc_cluster, rc_pos, rc_len, p1_sc;
@@ -2529,7 +2528,7 @@ void dev_destroy(sq_ctx* c) {
     D.b_pack.release(); D.n_pack.release();
     D.flag.release(); D.totlen.release(); D.b_readpos.release(); D.b_matchread.release(); D.mapq.release(); D.aux.release(); D.blk_off.release();
     D.tile_cnt.release(); D.tile_zcnt2.release(); D.zc_v.release(); D.zc_K.release(); D.zc_refid.release(); D.zc_pos.release(); D.tile_ob.release(); D.zc_ob.release();
-    D.lb.release(); D.tile_rank.release(); D.tile_zbase.release(); D.tile_zcnt.release(); D.z_idx.release(); D.z_chr.release(); D.z_right.release(); D.rc_cluster.release(); D.rc_pos.release(); D.rc_len.release(); D.p1_sc.release();
+    D.tile_rank.release(); D.tile_zbase.release(); D.tile_zcnt.release(); D.z_idx.release(); D.z_chr.release(); D.z_right.release(); D.rc_cluster.release(); D.rc_pos.release(); D.rc_len.release(); D.p1_sc.release();
     D.tile_first.release(); D.tile_max.release(); D.r_break.release(); D.sum_items.release(); D.bp_before.release();
     D.cls.release(); D.keep.release(); D.prev1.release(); D.prev2.release(); D.rank1.release(); D.restoff.release();
     D.scratch_a.release(); D.scratch_b.release(); D.scratch_c.release(); D.spine.release();
@@ -3004,13 +3003,6 @@ int dev_upload_nodes(sq_ctx* c, const std::vector<Node>& nodes) {
     if (total) { EvTimer t(c, "k_node_buckets", 4.0 * total); hipLaunchKernelGGL(k_node_buckets, dim3((total + 255) / 256), dim3(256), 0, s, nv, total, D.n_bucket.p); }
     HIPCHK(hipStreamSynchronize(s));  // the host vectors go out of scope
     return SQ_OK;
-}
-
-// the look-back status memory of one fused launch (sq_pass_kernels.inc): zeroed in front of every launch
-static hipError_t lb_prepare(DBuf<unsigned long long>& buf, size_t words, hipStream_t s) {
-    hipError_t e = buf.reserve(words);
-    if (e != hipSuccess) return e;
-    return hipMemsetAsync(buf.p, 0, words * sizeof(unsigned long long), s);
 }
 
 // sharded runs, exchange 1: what the last passing records of this shard look like to ReadRec_t::Equal.  (Unsharded: nothing to do --
