@@ -127,6 +127,7 @@ struct Pinned {
 };
 
 // one tile of k_summarise_tiles: kept records [lo, hi) of the tile at rec_base (rank_base kept records in front of it); output index = dst + (rank - lo)
+struct TilePart { unsigned long long ob; long long mx; int cnt, first; };  // of 1024 tiles: kept records, running pair, largest key, first tile with a kept record
 struct SumItem { int64_t rec_base; int32_t rank_base, lo, hi; int64_t dst; };
 
 struct DeviceRecords {
@@ -183,6 +184,7 @@ struct DeviceRecords {
     DBuf<uint8_t> zflag;
     DBuf<int32_t> cl_chr, trig, cl_bucket;  // cl_chr: packed cluster table chr | start | right; cl_bucket: bucket_off | position index of the cluster table
     DBuf<int32_t> bp_ev, bp_before, bp_end, bp_valid, bp_bucket, stripes;
+    DBuf<TilePart> tile_part;                   // k_tile_partial: sums / maxima of every 1024 tiles of k_pass1
     DBuf<unsigned int> depth_tiles;             // k_depth2: per tile its largest early node / cursor at its first record / list of tiles to correct
     DBuf<unsigned long long> bp_key, bp_front;  // breakpoint cursor: largest (chromosome, fragment start) per 256 records (k_edges_near) / in front of every tile of k_bp2
     int64_t bp_key_n = -1;                      // record count the keys were made for
@@ -216,7 +218,7 @@ struct DeviceRecords {
 // classification bits (cls)
 enum : uint8_t { C_P2 = 1, C_P1 = 2, C_P3 = 4, C_CONC = 8, C_PART = 16, C_HASSTUB = 32 };
 // keep bits
-enum : uint8_t { K_1 = 1, K_2 = 2, K_BUILD = 4 };
+enum : uint8_t { K_1 = 1, K_2 = 2, K_BUILD = 4, K_P3 = 8 /* copy of the class bit C_P3: the edge stage makes the breakpoint-cursor keys without reading the class byte */ };
 
 // ------------------------------------------------------------------------------------------------ device helpers
 struct DBlk { int32_t refid, refpos, matchref, readpos, matchread; bool rev; };
@@ -1011,14 +1013,14 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
     return v;
 }
-__global__ __launch_bounds__(256) void k_edges_near(RecView R, NodeView N, const uint8_t* keep, const uint8_t* cls, unsigned long long* bp_block_key, uint32_t* list, int32_t* count, int all /* SQUID_EDGES_ALL: clear nothing, every record takes the full rule set (cross-check) */) {
+__global__ __launch_bounds__(256) void k_edges_near(RecView R, NodeView N, const uint8_t* keep, unsigned long long* bp_block_key, uint32_t* list, int32_t* count, int all /* SQUID_EDGES_ALL: clear nothing, every record takes the full rule set (cross-check) */) {
     __shared__ unsigned long long s_key[4];
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool need = false;
     unsigned long long bkey = 0;
     if (r < R.n) {
         const uint8_t kp = keep[r];  // (the loads below do not wait for it: one memory round trip)
-        const uint8_t cl = cls[r];
+        const uint8_t cl = (kp & K_P3) ? C_P3 : 0;
         const int flag = R.flag[r], rid = R.refid[r], mrid = R.mrefid[r], mp = R.mpos[r], rpos = R.pos[r];
         const uint32_t bo = R.blk_off[r], bo1 = R.blk_off[r + 1];
         bkey = bp_record_key(cl, flag, rid, rpos, mrid, mp);
@@ -2546,7 +2548,7 @@ void dev_destroy(sq_ctx* c) {
     for (auto& ps : D.il_post) { ps.out.release(); ps.rec_sync.release(); ps.rec_end.release(); ps.rec_cnt.release(); ps.rec_base.release(); ps.flags.release(); ps.spine.release(); ps.bam_off.release(); }
     if (D.il_parse_stream) { (void)hipStreamDestroy(D.il_parse_stream); D.il_parse_stream = nullptr; }
     if (D.il_host) { (void)hipHostFree(D.il_host); D.il_host = nullptr; }
-    D.bgzf_out.release(); D.bgzf_carry.release(); D.staged.release(); D.rec_sync.release(); D.rec_end.release(); D.rec_cnt.release(); D.rec_base.release(); D.stripes.release(); D.bp_bucket.release(); D.bp_key.release(); D.bp_front.release(); D.depth_tiles.release(); D.bp_ev.release(); D.bp_end.release(); D.bp_valid.release();
+    D.bgzf_out.release(); D.bgzf_carry.release(); D.staged.release(); D.rec_sync.release(); D.rec_end.release(); D.rec_cnt.release(); D.rec_base.release(); D.stripes.release(); D.bp_bucket.release(); D.bp_key.release(); D.bp_front.release(); D.depth_tiles.release(); D.tile_part.release(); D.bp_ev.release(); D.bp_end.release(); D.bp_valid.release();
     for (auto& e : D.ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete c->dev;
     c->dev = nullptr;
@@ -3106,7 +3108,10 @@ int dev_pass1(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<i
         }
         {   // per tile: count 4 + pair 8 + two keys 16 in, rank 4 + pair 8 out
             EvTimer t(c, "k_tile_scan", 40.0 * ntiles);
-            hipLaunchKernelGGL(k_tile_scan, dim3((ntiles + TS_THREADS - 1) / TS_THREADS), dim3(TS_THREADS), 0, s, ntiles, D.tile_cnt.p, D.tile_ob.p, D.tile_first.p, D.tile_max.p, D.tile_rank.p, D.tile_ob.p + ntiles, D.p1_sc.p);
+            const int ngroups = (ntiles + TS_THREADS - 1) / TS_THREADS;
+            HIPCHK(D.tile_part.reserve((size_t)ngroups + 1));
+            hipLaunchKernelGGL(k_tile_partial, dim3(ngroups), dim3(TS_THREADS), 0, s, ntiles, D.tile_cnt.p, D.tile_ob.p, D.tile_max.p, D.tile_part.p);
+            hipLaunchKernelGGL(k_tile_scan, dim3(ngroups), dim3(TS_THREADS), 0, s, ntiles, D.tile_cnt.p, D.tile_ob.p, D.tile_first.p, D.tile_max.p, D.tile_part.p, D.tile_rank.p, D.tile_ob.p + ntiles, D.p1_sc.p);
             if (ncl) hipLaunchKernelGGL(k_trig_rank, dim3((ncl + 255) / 256), dim3(256), 0, s, ncl, ntiles, D.tile_rank.p, D.trig.p);
         }
         HIPCHK(hipMemcpyAsync(sc, D.p1_sc.p, sizeof sc, hipMemcpyDeviceToHost, s));
@@ -3383,8 +3388,8 @@ int dev_concordant_edges(sq_ctx* c, const std::vector<Node>& nodes, std::vector<
         uint32_t* list = (uint32_t*)D.scratch_a.p;
         int32_t* count = D.flags.p + 6;
         HIPCHK(D.bp_key.reserve((size_t)((n + 255) / 256) + 1));
-        { EvTimer t(c, "k_edges_near", 24.0 * n + 16.0 * D.nb);  // (+ class 1 and pos 4 for the breakpoint-cursor keys)
-          hipLaunchKernelGGL(k_edges_near, grid_for(n, 256), dim3(256), 0, s, R, nv, D.keep.p, D.cls.p, D.bp_key.p, list, count, std::getenv("SQUID_EDGES_ALL") ? 1 : 0); }
+        { EvTimer t(c, "k_edges_near", 23.0 * n + 16.0 * D.nb);  // (+ pos 4 for the breakpoint-cursor keys)
+          hipLaunchKernelGGL(k_edges_near, grid_for(n, 256), dim3(256), 0, s, R, nv, D.keep.p, D.bp_key.p, list, count, std::getenv("SQUID_EDGES_ALL") ? 1 : 0); }
         D.bp_key_n = n;
         { EvTimer t(c, "k_edges", 0);
           hipLaunchKernelGGL(k_edges, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, s, R, nv, ep, D.keep.p, list, count, D.h_key.p, D.h_val.p, slots - 1, D.flags.p, D.stripes.p); }
