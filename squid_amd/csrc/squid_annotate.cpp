@@ -103,7 +103,13 @@ void read_gtf(const std::string& path, const std::string& key_gene, const std::s
     // exon rows that did not follow their transcript row (:104-118), by transcript id (stable)
     std::stable_sort(extra.begin(), extra.end(), [](const Extra& x, const Extra& y) { return x.tid < y.tid; });
     for (const Extra& e : extra) {
-        if (Transcript* t = T.find(e.tid)) { t->exons.push_back({e.a, e.b}); continue; }
+        if (Transcript* t = T.find(e.tid)) {
+            t->exons.push_back({e.a, e.b});
+            // (in the script the loop variable IS the stored object of its id: an exon appended through the table reaches it too, and
+            // storing it again later -- T.set(cur) below -- must not lose that exon)
+            if (have && cur.id == e.tid) cur.exons.push_back({e.a, e.b});
+            continue;
+        }
         // a transcript known only from exon rows: the script keeps it in its loop variable and stores it when the NEXT unknown id
         // arrives -- the last one is never stored (kept)
         if (have && cur.id != e.tid) {

@@ -18,7 +18,7 @@ HERE = Path(__file__).resolve().parent
 REF = Path("/root/reference/utils/AnnotateSQUIDOutput.py")
 
 
-def make_case(name, seed, nchr, ngenes, nsv, gene_key="gene_id", sym_key="gene_name", out_of_order_exons=False):
+def make_case(name, seed, nchr, ngenes, nsv, gene_key="gene_id", sym_key="gene_name", out_of_order_exons=False, exon_only=False):
     rng = random.Random(seed)
     chrs = [f"chr{i + 1}" for i in range(nchr)] + (["chrX"] if nchr > 2 else [])
     lines = ["# synthetic annotation for the annotate fixtures\n"]
@@ -43,10 +43,17 @@ def make_case(name, seed, nchr, ngenes, nsv, gene_key="gene_id", sym_key="gene_n
             gstart = ts if gstart is None else min(gstart, ts)
             gend = te if gend is None else max(gend, te)
             attr = f'{gene_key} "{gid}"; transcript_id "{tid}"; {sym_key} "{gname}";'
-            lines.append(f"{c}\tsynth\ttranscript\t{ts}\t{te}\t.\t{strand}\t.\t{attr}\n")
+            last_tx = g == ngenes - 1 and t == ntx - 1
+            # exon_only: some transcripts have no transcript row at all (known from their exon rows only), and the last transcript of
+            # the file gets one of its exons late -- in the script that exon is appended through the table to the very object its loop
+            # variable still refers to
+            if not (exon_only and not last_tx and rng.random() < 0.2):
+                lines.append(f"{c}\tsynth\ttranscript\t{ts}\t{te}\t.\t{strand}\t.\t{attr}\n")
             for k, (a, b) in enumerate(exons):
                 row = f"{c}\tsynth\texon\t{a}\t{b}\t.\t{strand}\t.\t{attr} exon_number \"{k + 1}\";\n"
-                if out_of_order_exons and rng.random() < 0.15:
+                if exon_only and last_tx and k == len(exons) - 1 and len(exons) > 1:
+                    late.append(row)
+                elif out_of_order_exons and rng.random() < 0.15:
                     late.append(row)  # exon rows that come after another transcript's record (the script's extraExons path)
                 else:
                     lines.append(row)
@@ -86,4 +93,5 @@ if __name__ == "__main__":
     make_case("a3", 3, 4, 60, 50, "gene", "symbol")      # --geneid / --genesymbol
     make_case("a4", 4, 3, 50, 60, out_of_order_exons=True)
     make_case("a5", 5, 2, 3, 10)                         # fewer genes than the 20-step walks of LocatePosition_generange
+    make_case("a6", 6, 3, 50, 60, out_of_order_exons=True, exon_only=True)  # transcripts known from exon rows only + a late exon of the last transcript row
     print("fixtures written to", HERE)
