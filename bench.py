@@ -56,6 +56,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s
 WORKLOADS = {
     "C2": "hg38 chr17 only, 1M synthetic paired-end records, 20 planted fusions (BASELINE.json configs[1])",
     "C3": "full hg38, 50M-record synthetic STAR concordant+chimeric BAM, 200 planted TSVs, zlib level 6 (BASELINE.json configs[2])",
+    "C4": "full hg38, 200M-record synthetic sample (BASELINE.json configs[3]: the sample the 8-GPU chromosome-sharded run divides)",
     "C5": "dense-graph stress (-w 1 -a 50): full hg38, 100M records, 1.1e5 planted TSVs in >= 1e5 small components (BASELINE.json configs[4])",
     "C5g": "dense-graph stress (-w 1 -a 50), round-2 shape: junctions at inner exons, the segments chain into one giant component",
 }
