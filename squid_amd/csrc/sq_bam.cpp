@@ -196,22 +196,13 @@ void index_bgzf_prefix(const ByteView& d, std::vector<BgzfBlock>& blocks, size_t
     }
 }
 
+bool inflate_one(const uint8_t* d, const BgzfBlock& b, uint8_t* out);  // (libdeflate when present, zlib otherwise; below)
 bool inflate_range(const ByteView& d, const std::vector<BgzfBlock>& blocks, size_t b0, size_t b1, uint8_t* out, size_t out_base, int n_threads) {
     std::vector<char> ok((size_t)std::max(1, n_threads), 1);
     auto work = [&](int t) {
-        z_stream zs;
         for (size_t i = b0 + t; i < b1; i += (size_t)n_threads) {
             const BgzfBlock& b = blocks[i];
-            if (!b.isize) continue;
-            std::memset(&zs, 0, sizeof zs);
-            if (inflateInit2(&zs, -15) != Z_OK) { ok[t] = 0; return; }
-            zs.next_in = (Bytef*)&d[b.coff];
-            zs.avail_in = b.clen;
-            zs.next_out = out + (b.uoff - out_base);
-            zs.avail_out = b.isize;
-            int rc = inflate(&zs, Z_FINISH);
-            inflateEnd(&zs);
-            if (rc != Z_STREAM_END) { ok[t] = 0; return; }
+            if (!inflate_one(d.p, b, out + (b.uoff - out_base))) { ok[t] = 0; return; }
         }
     };
     if (n_threads <= 1) work(0);
