@@ -22,11 +22,19 @@ int fail(sq_ctx* c, int code, const std::string& msg) {
     else if (c) c->err = msg;
     return code;
 }
+int chim_join_names(sq_ctx* c) {
+    if (!c->chim_names_future.valid()) return SQ_OK;
+    const int rc = c->chim_names_future.get();  // (once: the future is invalid afterwards)
+    if (rc) { c->err = c->chim_err; return rc; }
+    return SQ_OK;
+}
 int chim_join(sq_ctx* c) {
     if (!c->chim_future.valid()) return SQ_OK;
+    const int rc_names = chim_join_names(c);  // (a concordant file without records never reached the parse)
     const int rc = c->chim_future.get();
     if (rc) { c->err = c->chim_err; return rc; }
-    return dev_upload_chim_names(c);
+    if (rc_names) return rc_names;
+    return dev_chim_finalize(c, c->chim_dead);
 }
 
 int Timer::slot(const char* name) {
@@ -841,17 +849,38 @@ int sq_read_header(const char* path, int32_t* n_ref, int32_t* ref_len, char* nam
     return SQ_OK;
 }
 // the whole chimeric BAM as one batch -> fragments (the batch is consumed where the reader hands it over: no copy of it)
-static int chimeric_file_to_fragments(sq_ctx* c, const char* path, int nt, std::string& err) {
+// `early` (sq_ingest_files): as soon as the records are decoded, the device gets the table of all their usable QNAMEs and the promise
+// the record parse of the concordant BAM waits for is kept -- the pairing goes on meanwhile
+static int chimeric_file_to_fragments(sq_ctx* c, const char* path, int nt, std::string& err, bool early = false) {
     ParseOpts o{c->P.phred_type, c->P.min_phred, c->P.max_lowphred_len, true, nullptr};
-    bool got = false;
+    bool got = false, promised = false;
+    auto promise = [&](int rc) { if (early && !promised) { promised = true; c->chim_names_promise.set_value(rc); } };
     int rc = parse_bam_file(path, o, (size_t)1 << 40, nt, err, [&](const HostBatch& hb) {
         sq_aln_batch b;
         hb.view(&b, true);
         got = true;
+        if (early) {
+            // one entry per usable record (mapped, not a duplicate: ReadRec.cpp:344), the name with a trailing /1 or /2 cut off
+            // (ReadRec.cpp:62-66), plus the empty name the reference's set always holds (SegmentGraph.cpp:196-201, ledger B9)
+            std::vector<uint32_t> off, len;
+            off.reserve((size_t)b.n_rec + 1); len.reserve((size_t)b.n_rec + 1);
+            for (int64_t i = 0; i < b.n_rec; ++i) {
+                if ((b.flag[i] & 0x4) || (b.flag[i] & 0x400)) continue;
+                const char* nm = b.name_blob + b.name_off[i];
+                size_t L = b.name_off[i + 1] - b.name_off[i];
+                if (L >= 2 && nm[L - 2] == '/' && (nm[L - 1] == '1' || nm[L - 1] == '2')) L -= 2;
+                off.push_back(b.name_off[i]); len.push_back((uint32_t)L);
+            }
+            if (!off.empty()) { off.push_back(0); len.push_back(0); }
+            const int rt = off.empty() ? SQ_OK : dev_chim_begin(c, b.name_blob, (size_t)b.name_off[b.n_rec], off.data(), len.data(), off.size());
+            promise(rt);
+            if (rt) return rt;
+        }
         return build_fragments(c, &b);
     });
+    if (!rc && !got) rc = fail(c, SQ_E_EMPTYCHIM, "chimeric BAM holds no record");
+    promise(rc ? rc : SQ_OK);  // (whatever happened: nobody waits for ever)
     if (rc) return rc;
-    if (!got) return fail(c, SQ_E_EMPTYCHIM, "chimeric BAM holds no record");
     copy_frags(c, c->frags, c->frags0);
     return SQ_OK;
 }
@@ -873,10 +902,12 @@ int sq_ingest_files(sq_ctx* c, const char* chim_path, const char* bam_path, int3
     }
     const std::string chim = chim_path;
     c->chim_err.clear();
+    c->chim_names_promise = std::promise<int>();
+    c->chim_names_future = c->chim_names_promise.get_future();
     c->chim_future = std::async(std::launch::async, [c, chim, n_threads]() {
         tl_err_sink = &c->chim_err;
         struct Unsink { ~Unsink() { tl_err_sink = nullptr; } } unsink;
-        return chimeric_file_to_fragments(c, chim.c_str(), std::max(1, std::min(n_threads, 16)), c->chim_err);
+        return chimeric_file_to_fragments(c, chim.c_str(), std::max(1, std::min(n_threads, 16)), c->chim_err, true);
     });
     const int rc_conc = sq_ingest_concordant_file(c, bam_path, n_threads);
     const int rc_chim = chim_join(c);  // (a concordant file without records never reached the parse)

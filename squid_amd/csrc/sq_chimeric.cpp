@@ -238,6 +238,9 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
             for (int64_t p = lo; p < hi; ++p) if (keep_at[(size_t)p]) { kept[(size_t)fk[(size_t)p].idx] = 1; out[where_out[(size_t)p]] = std::move(merged[(size_t)fk[(size_t)p].idx]); }
         });
     }
+    // the names that leave the reference's ChimName with their fragment (a name belongs to one merged fragment)
+    c->chim_dead.clear();
+    for (size_t j = 0; j < nm; ++j) if (!kept[j] && !merged[j].name.empty()) c->chim_dead.push_back(merged[j].name);
     lap("duplicate removal");
     // ChimName: Chimrecord.size() empty strings + every Qname, sorted unique (SegmentGraph.cpp:196-201, ledger B9).  `merged` is in name
     // order and holds every name once, so the kept names in that order are already the sorted unique list (the names were moved into

@@ -209,6 +209,9 @@ struct sq_ctx {
     // sq_order; sq_call_sv collects it
     std::future<int> bp_future;
     std::string chim_err;          // (its error text; moved into `err` by chim_join)
+    std::promise<int> chim_names_promise;  // set by the helper once the device holds the table of all usable chimeric QNAMEs
+    std::future<int> chim_names_future;
+    std::vector<std::string> chim_dead;    // QNAMEs of the fragments the PCR-duplicate removal dropped (they leave the set: dev_chim_finalize)
     std::future<int> chim_future;  // sq_ingest_files: the chimeric decode running next to the concordant ingest (chim_join)
     std::shared_ptr<std::map<uint64_t, std::vector<std::pair<int, int>>>> bp_early;
     double bp_early_ms = 0;
@@ -229,6 +232,8 @@ namespace sq {
 int fail(sq_ctx* c, int code, const std::string& msg);
 // waits for the chimeric decode started by sq_ingest_files and uploads its QNAME set; called in front of the first record parse
 int chim_join(sq_ctx* c);
+// waits only for the QNAME table the helper builds right after decoding the chimeric BAM (what the record parse needs)
+int chim_join_names(sq_ctx* c);
 
 // ---- sq_bam.cpp
 struct HostBatch {  // owning storage behind an sq_aln_batch
@@ -314,6 +319,8 @@ int dev_parse_append(sq_ctx* c, const uint8_t* bam, size_t nbytes, const unsigne
 int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& blocks, size_t b0, size_t b1, size_t begin, bool synced, int nref, const IndexMore& index_more, size_t file_bytes);
 struct HostBatch;
 int dev_download_records(sq_ctx* c, HostBatch& hb);
+int dev_chim_begin(sq_ctx* c, const char* blob, size_t blob_bytes, const uint32_t* off, const uint32_t* len, size_t n);
+int dev_chim_finalize(sq_ctx* c, const std::vector<std::string>& dead_names);
 struct SegSupport {
     std::vector<int32_t> trigger, zidx, z_ochr, z_oright, rest_cluster, rest_pos, rest_len;
 };

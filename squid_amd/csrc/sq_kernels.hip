@@ -179,6 +179,12 @@ struct DeviceRecords {
     DBuf<uint32_t> chim_off, chim_len;
     DBuf<char> chim_blob;
     uint32_t chim_mask = 0;
+    // the table built from the chimeric records themselves (dev_chim_begin): per-slot dead flags, per-record slot of the match, inputs
+    DBuf<uint8_t> chim_dead;
+    DBuf<int32_t> chim_slot_of;
+    DBuf<uint32_t> chim_in_off, chim_in_len;
+    bool chim_provisional = false;   // the table holds every usable chimeric QNAME; dev_chim_finalize has not run yet
+    hipStream_t chim_stream = nullptr;
     DBuf<int32_t> parse_nblk, parse_rel;
     DBuf<int32_t> calib;
     DBuf<uint8_t> zflag;
@@ -480,7 +486,7 @@ __global__ void k_calib_read4(const int32_t* a, int64_t n, int32_t* out) {
 // (src/ReadRec.cpp:10-88): TotalLen, longest low-Phred run, CIGAR -> aligned blocks with the poly-A/T filter and
 // strand-mirrored read offsets, GetEndPosition(), XA / IH tags (src/SegmentGraph.cpp:297-301) and the QNAME lookup in
 // the chimeric name set (:302) -- and writes the SoA layout directly.  Two passes: count blocks, scan, write.
-struct ChimSetView { uint32_t mask; const unsigned long long* hash; const uint32_t *off, *len; const char* blob; };
+struct ChimSetView { uint32_t mask; const unsigned long long* hash; const uint32_t *off, *len; const char* blob; const uint8_t* dead; /* per slot: the name was dropped from the set afterwards (may be null) */ };
 struct ParseParams { int qual_thr, max_lowphred_len, min_mapq; };
 __device__ __forceinline__ int ld32(const uint8_t* p) { return (int)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); }
 __device__ __forceinline__ int ld16(const uint8_t* p) { return (int)p[0] | ((int)p[1] << 8); }
@@ -495,21 +501,66 @@ __host__ __device__ __forceinline__ uint32_t chim_slot(unsigned long long h, uin
     h ^= h >> 33; h *= 0xff51afd7ed558ccdull; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 33;
     return (uint32_t)h & mask;
 }
-__device__ bool chim_contains(const ChimSetView& C, const uint8_t* name, int n) {
-    if (!C.hash) return false;
+__device__ __forceinline__ unsigned long long chim_hash_of(const uint8_t* name, int n) {
     unsigned long long h = 1469598103934665603ull;
     for (int i = 0; i < n; ++i) { h ^= name[i]; h *= 1099511628211ull; }
-    if (h == 0) h = 1;
+    return h ? h : 1;
+}
+// slot of `name` in the table (the first one on its probe chain: a table made from the records of the chimeric BAM holds a name once
+// per record), or -1
+__device__ int chim_find(const ChimSetView& C, const uint8_t* name, int n) {
+    if (!C.hash) return -1;
+    const unsigned long long h = chim_hash_of(name, n);
     for (uint32_t s = chim_slot(h, C.mask), probes = 0; probes <= C.mask; s = (s + 1) & C.mask, ++probes) {
         unsigned long long e = C.hash[s];
-        if (e == 0) return false;
+        if (e == 0) return -1;
         if (e == h && (int)C.len[s] == n) {
             bool same = true;
             for (int i = 0; i < n; ++i) if (C.blob[C.off[s] + i] != (char)name[i]) { same = false; break; }
-            if (same) return true;
+            if (same) return (int)s;
         }
     }
-    return false;
+    return -1;
+}
+// The table of the chimeric QNAMEs, built on the device from the decoded chimeric records as soon as they are decoded (sq_ingest_files:
+// the record parse of the concordant BAM only waits for THIS, not for the pairing of the chimeric records).  The reference's set holds
+// the names of the fragments that survive its PCR-duplicate removal (SegmentGraph.cpp:196-201); the names of the fragments dropped
+// there are marked dead afterwards (k_chim_mark_dead) and the records that matched one lose their bit again (k_chim_fixup).
+__global__ void k_chim_insert(const char* blob, const uint32_t* in_off, const uint32_t* in_len, int n, uint32_t mask, unsigned long long* hash, uint32_t* off, uint32_t* len) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t o = in_off[i], l = in_len[i];
+    const unsigned long long h = chim_hash_of((const uint8_t*)blob + o, (int)l);
+    for (uint32_t s = chim_slot(h, mask);; s = (s + 1) & mask)  // (every record takes a slot of its own: no name compare, nobody reads off / len in here)
+        if (atomicCAS(&hash[s], 0ull, h) == 0ull) { off[s] = o; len[s] = l; return; }
+}
+__global__ void k_chim_mark_dead(const char* dblob, const uint32_t* d_off, const uint32_t* d_len, int n, ChimSetView C, uint8_t* dead) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* name = (const uint8_t*)dblob + d_off[i];
+    const int l = (int)d_len[i];
+    const unsigned long long h = chim_hash_of(name, l);
+    for (uint32_t s = chim_slot(h, C.mask), probes = 0; probes <= C.mask; s = (s + 1) & C.mask, ++probes) {  // every slot that holds the name
+        const unsigned long long e = C.hash[s];
+        if (e == 0) return;
+        if (e == h && (int)C.len[s] == l) {
+            bool same = true;
+            for (int k = 0; k < l; ++k) if (C.blob[C.off[s] + k] != (char)name[k]) { same = false; break; }
+            if (same) dead[s] = 1;
+        }
+    }
+}
+// chim_slot[r]: 0 = the record's QNAME matched nothing; s + 1 = it matched slot s; -(s + 1) = it matched slot s and the reference would
+// have asserted on the record (ReadRec.cpp:64) had it not been filtered out by exactly that match
+__global__ void k_chim_fixup(int64_t n, const int32_t* chim_slot_of, const uint8_t* dead, uint8_t* aux, int32_t* flags) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int32_t cs = chim_slot_of[r];
+    if (cs == 0) return;
+    const int32_t slot = (cs < 0 ? -cs : cs) - 1;
+    if (!dead[slot]) return;
+    aux[r] = (uint8_t)(aux[r] & ~SQ_AUX_INCHIM);
+    if (cs < 0) atomicOr(&flags[0], 256);
 }
 // WRITE = false: only counts the kept blocks.  Returns the block count, or -1 when the reference's
 // assert(ReadPos >= HardClipOffset && ...) (ReadRec.cpp:64) would fire.
@@ -616,7 +667,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_parse_count(const uint8_t* ba
 struct FArrN { const int32_t* a; __device__ int operator()(int64_t i) const { return a[i]; } };
 __global__ __launch_bounds__(PARSE_THREADS) void k_parse_write(const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n, ChimSetView C, ParseParams P, const int32_t* blk_rel, uint32_t blk_base, int32_t* o_refid,
                               int32_t* o_pos, int32_t* o_mrefid, int32_t* o_mpos, int32_t* o_endpos, uint16_t* o_flag, uint16_t* o_totlen, uint8_t* o_mapq, uint8_t* o_aux, uint32_t* o_blkoff,
-                              int32_t* b_refpos, int32_t* b_matchref, uint16_t* b_readpos, uint16_t* b_matchread, int32_t* flags) {
+                              int32_t* b_refpos, int32_t* b_matchref, uint16_t* b_readpos, uint16_t* b_matchread, int32_t* o_chimslot, int32_t* flags) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[PARSE_LDS];
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     long long avail;
@@ -677,7 +728,9 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_parse_write(const uint8_t* ba
     uint8_t ax = 0;
     if (has_xa || ih > 1) ax |= SQ_AUX_MULTI;
     if (lowrun > P.max_lowphred_len) ax |= SQ_AUX_LOWPHRED;
-    if (chim_contains(C, name, lname > 0 ? lname - 1 : 0)) ax |= SQ_AUX_INCHIM;
+    const int cslot = chim_find(C, name, lname > 0 ? lname - 1 : 0);
+    if (cslot >= 0 && !(C.dead && C.dead[cslot])) ax |= SQ_AUX_INCHIM;
+    int32_t cs_out = (ax & SQ_AUX_INCHIM) ? cslot + 1 : 0;
     const uint32_t b0 = blk_base + (uint32_t)blk_rel[r];
     int nb = parse_blocks<true>(cg, ncig, seq, lseq, pos, flag & 0x10, totlen, b_refpos + b0, b_matchref + b0, b_readpos + b0, b_matchread + b0);
     // the SoA keeps TotalLen and the read offsets in 16 bits and the segmentation summary counts a record's further blocks in
@@ -687,7 +740,10 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_parse_write(const uint8_t* ba
         // the reference constructs a ReadRec_t only for records that pass its filters; for those the assert is live
         bool filtered = (ax & (SQ_AUX_MULTI | SQ_AUX_INCHIM)) || (flag & 0x400) || (flag & 0x4) || mapq < P.min_mapq;
         if (!filtered) atomicOr(&flags[0], 256);
+        const bool but_for_the_name = !(ax & SQ_AUX_MULTI) && !(flag & 0x400) && !(flag & 0x4) && mapq >= P.min_mapq;
+        if (filtered && but_for_the_name) cs_out = -cs_out;  // (k_chim_fixup raises the flag should the name leave the set)
     }
+    o_chimslot[r] = cs_out;
     o_refid[r] = refid; o_pos[r] = pos; o_mrefid[r] = mrefid; o_mpos[r] = mpos; o_endpos[r] = endpos;
     o_flag[r] = (uint16_t)flag; o_totlen[r] = (uint16_t)totlen; o_mapq[r] = (uint8_t)mapq; o_aux[r] = ax;
     o_blkoff[r] = b0;
@@ -2538,7 +2594,7 @@ void dev_destroy(sq_ctx* c) {
     D.srec.release(); D.rest_refpos.release(); D.rest_matchref.release();
     D.n_chr.release(); D.n_bucket.release();
     D.acc_a.release(); D.acc_b.release(); D.acc_c.release();
-    D.h_key.release(); D.h_val.release(); D.flags.release(); D.bam_chunk.release(); D.bam_off.release(); D.chim_hash.release(); D.chim_off.release(); D.chim_len.release(); D.chim_blob.release(); D.parse_nblk.release(); D.parse_rel.release();
+    D.h_key.release(); D.h_val.release(); D.flags.release(); D.bam_chunk.release(); D.bam_off.release(); D.chim_hash.release(); D.chim_off.release(); D.chim_len.release(); D.chim_blob.release(); D.chim_dead.release(); D.chim_slot_of.release(); D.chim_in_off.release(); D.chim_in_len.release(); D.parse_nblk.release(); D.parse_rel.release();
     D.calib.release(); D.okey.release(); D.oval.release(); D.other64.release(); D.spine64.release(); D.okey64.release(); D.zflag.release();
     D.cl_chr.release(); D.trig.release(); D.cl_bucket.release();
     D.ord_e.release(); D.ord_o.release(); D.ord_v.release(); D.ord_me.release(); D.ord_mo.release(); D.g_i.release(); D.g_x.release(); D.g_d.release(); D.g_b.release();
@@ -2630,6 +2686,61 @@ int dev_upload_chim_names(sq_ctx* c) {
     HIPCHK(hipMemcpyAsync(D.chim_len.p, len.data(), slots * 4, hipMemcpyHostToDevice, c->stream)); HIPCHK(hipMemcpyAsync(D.chim_blob.p, blob.data(), blob.size(), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     D.chim_mask = names.empty() ? 0 : slots - 1;
+    D.chim_provisional = false;
+    if (D.chim_dead.p) HIPCHK(hipMemsetAsync(D.chim_dead.p, 0, D.chim_dead.cap, c->stream));
+    return SQ_OK;
+}
+
+// The QNAME table straight from the decoded chimeric records (called on the helper thread of sq_ingest_files, on a stream of its own):
+// `blob` = the name bytes of the batch, (off, len) one entry per usable record (+ one of length 0: the reference's set always holds "").
+int dev_chim_begin(sq_ctx* c, const char* blob, size_t blob_bytes, const uint32_t* off, const uint32_t* len, size_t n) {
+    HIPCHK(hipSetDevice(c->P.device));
+    DeviceRecords& D = *c->dev;
+    if (!D.chim_stream) HIPCHK(hipStreamCreateWithFlags(&D.chim_stream, hipStreamNonBlocking));
+    hipStream_t s = D.chim_stream;
+    uint32_t slots = 16;
+    while ((size_t)slots < 2 * n + 2) slots <<= 1;
+    HIPCHK(D.chim_hash.reserve(slots)); HIPCHK(D.chim_off.reserve(slots)); HIPCHK(D.chim_len.reserve(slots)); HIPCHK(D.chim_dead.reserve(slots));
+    HIPCHK(D.chim_blob.reserve(blob_bytes + 1)); HIPCHK(D.chim_in_off.reserve(n)); HIPCHK(D.chim_in_len.reserve(n));
+    HIPCHK(hipMemsetAsync(D.chim_hash.p, 0, (size_t)slots * 8, s));
+    HIPCHK(hipMemsetAsync(D.chim_dead.p, 0, D.chim_dead.cap, s));
+    if (blob_bytes) HIPCHK(hipMemcpyAsync(D.chim_blob.p, blob, blob_bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(D.chim_in_off.p, off, n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(D.chim_in_len.p, len, n * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_chim_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, D.chim_blob.p, D.chim_in_off.p, D.chim_in_len.p, (int)n, slots - 1, D.chim_hash.p, D.chim_off.p, D.chim_len.p);
+    HIPCHK(hipStreamSynchronize(s));
+    D.chim_mask = slots - 1;
+    D.chim_provisional = true;
+    return SQ_OK;
+}
+// after the pairing: the names of the fragments its PCR-duplicate removal dropped leave the set, and the records that matched one of them
+// lose their bit (library stream; every record parse is over)
+int dev_chim_finalize(sq_ctx* c, const std::vector<std::string>& dead_names) {
+    DeviceRecords& D = *c->dev;
+    if (!D.chim_provisional) return SQ_OK;
+    D.chim_provisional = false;
+    if (dead_names.empty()) return SQ_OK;
+    hipStream_t s = c->stream;
+    std::vector<char> blob;
+    std::vector<uint32_t> off, len;
+    for (const std::string& nm : dead_names) { off.push_back((uint32_t)blob.size()); len.push_back((uint32_t)nm.size()); blob.insert(blob.end(), nm.begin(), nm.end()); }
+    const size_t n = off.size();
+    DBuf<char> dblob; DBuf<uint32_t> doff, dlen;
+    HIPCHK(dblob.reserve(blob.size() + 1)); HIPCHK(doff.reserve(n)); HIPCHK(dlen.reserve(n));
+    HIPCHK(hipMemcpyAsync(dblob.p, blob.data(), blob.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(doff.p, off.data(), n * 4, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(dlen.p, len.data(), n * 4, hipMemcpyHostToDevice, s));
+    const ChimSetView C{D.chim_mask, D.chim_hash.p, D.chim_off.p, D.chim_len.p, D.chim_blob.p, nullptr};
+    hipLaunchKernelGGL(k_chim_mark_dead, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dblob.p, doff.p, dlen.p, (int)n, C, D.chim_dead.p);
+    int32_t hf = 0;
+    if (D.n > 0) {
+        HIPCHK(D.flags.reserve(64));
+        HIPCHK(hipMemsetAsync(D.flags.p, 0, 8 * 4, s));
+        hipLaunchKernelGGL(k_chim_fixup, grid_for(D.n, 256), dim3(256), 0, s, D.n, D.chim_slot_of.p, D.chim_dead.p, D.aux.p, D.flags.p);
+        HIPCHK(hipMemcpyAsync(&hf, D.flags.p, 4, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    dblob.release(); doff.release(); dlen.release();
+    if (hf & 256) return fail(c, SQ_E_ASSERT, "record without stored bases for an aligned block (reference asserts, ReadRec.cpp:64)");
     return SQ_OK;
 }
 
@@ -2648,7 +2759,7 @@ int dev_parse_append(sq_ctx* c, const uint8_t* bam, size_t nbytes, const unsigne
 // the records at d_off[0..n_rec) of the inflated bytes d_bam (both in device memory) -> appended to the resident SoA
 // (`on`, `flags16`, `scan_state`: the stream, a 16-int flag block and the scan state to use -- the file ingest parses on its own stream)
 static int parse_device(sq_ctx* c, const uint8_t* d_bam, size_t nbytes, const unsigned long long* d_off, int64_t n_rec, hipStream_t on, int32_t* flags16, DBuf<int32_t>* scan_state) {
-    { const int rc = chim_join(c); if (rc) return rc; }  // the QNAME set of the chimeric BAM (sq_ingest_files reads that file meanwhile)
+    { const int rc = chim_join_names(c); if (rc) return rc; }  // the QNAME table of the chimeric BAM (sq_ingest_files decodes that file meanwhile)
     DeviceRecords& D = *c->dev;
     hipStream_t s = on ? on : c->stream;
     int32_t* const fl = flags16 ? flags16 : D.flags.p;
@@ -2676,16 +2787,17 @@ static int parse_device(sq_ctx* c, const uint8_t* d_bam, size_t nbytes, const un
 #define GROW(buf, used, want) HIPCHK(D.buf.grow_keep(used, want, s))
     if (D.refid.cap < n1) { GROW(refid, n0, rec_want); GROW(pos, n0, rec_want); GROW(mrefid, n0, rec_want); GROW(mpos, n0, rec_want); GROW(endpos, n0, rec_want);
                             GROW(flag, n0, rec_want); GROW(totlen, n0, rec_want); GROW(mapq, n0, rec_want); GROW(aux, n0, rec_want); }
+    if (D.chim_slot_of.cap < n1) GROW(chim_slot_of, std::min(n0, D.chim_slot_of.cap), rec_want);
     if (D.blk_off.cap < n1 + 1) GROW(blk_off, n0 ? n0 + 1 : 0, rec_want + 1);
     if (D.b_refpos.cap < nb1 + 1) { GROW(b_refpos, nb0, blk_want); GROW(b_matchref, nb0, blk_want); GROW(b_readpos, nb0, blk_want); GROW(b_matchread, nb0, blk_want); }
     if (D.b_pack.cap < nb1 + 1) GROW(b_pack, nb0, blk_want);
 #undef GROW
-    ChimSetView C{D.chim_mask, D.chim_mask ? D.chim_hash.p : nullptr, D.chim_off.p, D.chim_len.p, D.chim_blob.p};
+    ChimSetView C{D.chim_mask, D.chim_mask ? D.chim_hash.p : nullptr, D.chim_off.p, D.chim_len.p, D.chim_blob.p, D.chim_dead.p};
     ParseParams P{(int)(signed char)(((c->P.phred_type ? 33 : 64) + c->P.min_phred) & 0xff), c->P.max_lowphred_len, c->P.min_mapqual};
     { EvTimer t(c, "k_parse_write", (double)nbytes + 32.0 * n_rec + 12.0 * nblk_total, s);
       hipLaunchKernelGGL(k_parse_write, grid_for(n_rec, PARSE_THREADS), dim3(PARSE_THREADS), 0, s, d_bam, nbytes, d_off, n_rec, C, P, D.parse_rel.p, (uint32_t)nb0, D.refid.p + n0, D.pos.p + n0, D.mrefid.p + n0,
                          D.mpos.p + n0, D.endpos.p + n0, D.flag.p + n0, D.totlen.p + n0, D.mapq.p + n0, D.aux.p + n0, D.blk_off.p + n0, D.b_refpos.p, D.b_matchref.p, D.b_readpos.p, D.b_matchread.p,
-                         fl); }
+                         D.chim_slot_of.p + n0, fl); }
     if (nb1 > nb0) hipLaunchKernelGGL(k_pack_blocks, dim3((unsigned)((nb1 - nb0 + 255) / 256)), dim3(256), 0, s, (int64_t)nb0, (int64_t)nb1, D.b_refpos.p, D.b_matchref.p, D.b_readpos.p, D.b_matchread.p, D.b_pack.p);
     const uint32_t endoff = (uint32_t)nb1;
     HIPCHK(hipMemcpyAsync(D.blk_off.p + n1, &endoff, 4, hipMemcpyHostToDevice, s));

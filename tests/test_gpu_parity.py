@@ -390,6 +390,60 @@ def test_depth_cursor_held_ahead_by_far_first_blocks(built, synth, tmp_path, exa
         assert ctx.timing()["depth_tiles_corrected"]["bytes"] >= 2  # (a count: the correction pass had work)
 
 
+def _rename_record(raw, name):
+    """the BAM record `raw` (with its block_size) under another QNAME"""
+    import struct
+    l_old = raw[12]
+    body = raw[4:36] + name.encode() + b"\0" + raw[36 + l_old:]
+    body = body[:8] + bytes([len(name) + 1]) + body[9:]
+    return struct.pack("<i", len(body)) + body
+
+
+def test_names_of_dropped_pcr_duplicates_leave_the_chimeric_name_set(built, synth, tmp_path, exact_depth, monkeypatch):
+    """sq_ingest_files gives the device the QNAMEs of ALL usable chimeric records as soon as they are decoded (the record parse of the
+    concordant BAM does not wait for the pairing); the reference's set only holds the names of the fragments that survive its
+    PCR-duplicate removal (SegmentGraph.cpp:196-201, ReadRec.cpp:387-409), so the dropped names are taken out again afterwards and
+    the concordant records that matched one get their filter bit back.  Chimeric fragments copied under new names + concordant
+    records carrying the names of both copies; every stage against the oracle, through both ingest entry points."""
+    import bamwriter as bw
+
+    pre = synth("T2")
+    contigs, conc = _read_bam_records(f"{pre}.bam")
+    _, chim = _read_bam_records(f"{pre}.chim.bam")
+    by_name = {}
+    for refid, pos, raw in chim:
+        by_name.setdefault(raw[36:36 + raw[12] - 1].decode(), []).append(raw)
+    picked = sorted(by_name)[::7][:40]
+    chim_out = [raw for _, _, raw in chim]
+    for k, nm in enumerate(picked):
+        chim_out += [_rename_record(raw, f"pcrdup{k}") for raw in by_name[nm]]  # an exact copy of the fragment: one of the two is dropped
+    extra = []
+    for k, nm in enumerate(picked):
+        refid, pos, _ = conc[(997 * k + 13) % len(conc)]
+        if refid < 0:
+            continue
+        for who in (nm, f"pcrdup{k}"):
+            extra.append((refid, pos, bw.record(who, refid, pos, 255, 0x1 | 0x2 | 0x20 | 0x40, "100M", refid, pos + 250)))
+    merged = sorted([(r if r >= 0 else 1 << 30, p, i, raw) for i, (r, p, raw) in enumerate(conc + extra)])
+    new = tmp_path / "dups"
+    bw.write_bam(f"{new}.bam", contigs, [raw for _, _, _, raw in merged])
+    bw.write_bam(f"{new}.chim.bam", contigs, chim_out, sort_order="unsorted")
+    sv_path, dump = ou.run_oracle(built, new, tmp_path)
+    with squid_amd.Context() as ctx:
+        ctx.load(f"{new}.bam", f"{new}.chim.bam")  # sq_ingest_files: early table + correction
+        n_frag = ctx.counts()["n_chim_fragments"]
+        ctx.build_graph()
+        _compare(ctx, dump, sv_path)
+    with squid_amd.Context() as ctx:  # the two calls one after the other: the final set from the start
+        ctx.ref_names = [n for n, _ in contigs]
+        ctx._chk(ctx.lib.sq_set_references(ctx.h, len(contigs), (squid_amd.C.c_int32 * len(contigs))(*[l for _, l in contigs])), "refs")
+        ctx._chk(ctx.lib.sq_ingest_chimeric_file(ctx.h, f"{new}.chim.bam".encode()), "chim")
+        ctx._chk(ctx.lib.sq_ingest_concordant_file(ctx.h, f"{new}.bam".encode(), 3), "conc")
+        assert ctx.counts()["n_chim_fragments"] == n_frag < len(by_name) + len(picked)  # (fragments were dropped)
+        ctx.build_graph()
+        _compare(ctx, dump, sv_path)
+
+
 def _bp_support_literal(rec, bps, min_mapq, dp):
     """the reference's loop, statement by statement, over downloaded records (pass-3 filter :3131-3142)"""
     cov = [0] * len(bps)
