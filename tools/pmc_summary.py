@@ -16,12 +16,13 @@ GROUPS = {
     "k_depth_check+fix": ["k_depth_check", "k_depth2<true>", "k_fold_stripes"],
     "k_bp_key_prefix": ["k_bp_key_reduce", "k_bp_key_scan"],
     "k_bp_walk": ["k_bp_walk2<false>", "k_bp_chain", "k_bp_walk2<true>"],
+    "k_tile_scan": ["k_tile_partial", "k_tile_scan"],
 }
 
 
 def short(name):
     n = name.split("(")[0].replace("sq::", "").replace("void ", "").strip()
-    return n if n in sum(GROUPS.values(), []) else re.sub(r"<.*>$", "", n)  # k_pass1<false> -> k_pass1; the grouped ones keep their template argument
+    return n if n in sum(GROUPS.values(), []) else re.sub(r"<.*>$", "", n)  # (k_pass1<false, 5> -> k_pass1)  # k_pass1<false> -> k_pass1; the grouped ones keep their template argument
 
 
 def load(path):
