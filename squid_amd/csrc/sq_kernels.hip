@@ -174,6 +174,12 @@ struct DeviceRecords {
     PostSet il_post[2];
     hipStream_t il_parse_stream = nullptr;
     int32_t* il_host = nullptr;            // page-locked: the small results of the two sets (32 ints each)
+    // host -> device copies of file bytes: four threads stage 16 MiB pieces through page-locked buffers (h2d_parallel)
+    static constexpr int H2D_THREADS = 4;
+    uint8_t* h2d_pin[H2D_THREADS][2] = {};
+    hipStream_t h2d_stream[H2D_THREADS] = {};
+    hipEvent_t h2d_ev[H2D_THREADS][2] = {};
+    std::mutex h2d_mu;
     DBuf<int32_t> rec_cnt, rec_base;
     DBuf<unsigned long long> bam_off, chim_hash;
     DBuf<uint32_t> chim_off, chim_len;
@@ -2604,6 +2610,11 @@ void dev_destroy(sq_ctx* c) {
     for (auto& ps : D.il_post) { ps.out.release(); ps.rec_sync.release(); ps.rec_end.release(); ps.rec_cnt.release(); ps.rec_base.release(); ps.flags.release(); ps.spine.release(); ps.bam_off.release(); }
     if (D.il_parse_stream) { (void)hipStreamDestroy(D.il_parse_stream); D.il_parse_stream = nullptr; }
     if (D.il_host) { (void)hipHostFree(D.il_host); D.il_host = nullptr; }
+    for (int t = 0; t < DeviceRecords::H2D_THREADS; ++t) {
+        for (int b = 0; b < 2; ++b) { if (D.h2d_pin[t][b]) (void)hipHostFree(D.h2d_pin[t][b]); D.h2d_pin[t][b] = nullptr; if (D.h2d_ev[t][b]) (void)hipEventDestroy(D.h2d_ev[t][b]); D.h2d_ev[t][b] = nullptr; }
+        if (D.h2d_stream[t]) (void)hipStreamDestroy(D.h2d_stream[t]);
+        D.h2d_stream[t] = nullptr;
+    }
     D.bgzf_out.release(); D.bgzf_carry.release(); D.staged.release(); D.rec_sync.release(); D.rec_end.release(); D.rec_cnt.release(); D.rec_base.release(); D.stripes.release(); D.bp_bucket.release(); D.bp_key.release(); D.bp_front.release(); D.depth_tiles.release(); D.tile_part.release(); D.bp_ev.release(); D.bp_end.release(); D.bp_valid.release();
     for (auto& e : D.ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete c->dev;
@@ -2650,12 +2661,55 @@ void dev_clear_records(sq_ctx* c) {
     c->dev->n = 0; c->dev->nb = 0; c->dev->k1 = 0;
 }
 // sq_stage_bam: bytes != null copies a file into HBM; bytes == null returns the resident copy
+// File bytes (a mapping of the page cache: pageable memory) to the device.  One hipMemcpy of pageable memory goes through the
+// runtime's staging buffer on the calling thread, 15-18 GB/s here -- the longest chain of an ingest that does not find the file in
+// HBM.  Four threads copy 16 MiB pieces into page-locked buffers of their own and send them off asynchronously (two buffers each, so
+// the next piece is being copied while the last one travels).  Returns when all of it has arrived.
+static int h2d_parallel(sq_ctx* c, uint8_t* dst, const uint8_t* src, size_t n) {
+    DeviceRecords& D = *c->dev;
+    constexpr int T = DeviceRecords::H2D_THREADS;
+    constexpr size_t CH = (size_t)16 << 20;
+    if (n < 8 * CH || std::getenv("SQUID_H2D_SERIAL")) { HIPCHK(hipMemcpy(dst, src, n, hipMemcpyHostToDevice)); return SQ_OK; }
+    std::lock_guard<std::mutex> lk(D.h2d_mu);
+    for (int t = 0; t < T; ++t) {
+        if (!D.h2d_stream[t]) HIPCHK(hipStreamCreateWithFlags(&D.h2d_stream[t], hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b) {
+            if (!D.h2d_pin[t][b]) HIPCHK(hipHostMalloc((void**)&D.h2d_pin[t][b], CH, hipHostMallocDefault));
+            if (!D.h2d_ev[t][b]) HIPCHK(hipEventCreateWithFlags(&D.h2d_ev[t][b], hipEventDisableTiming));
+        }
+    }
+    std::atomic<size_t> next{0};
+    std::atomic<int> bad{0};
+    const int device = c->P.device;
+    auto work = [&](int t) {
+        if (hipSetDevice(device) != hipSuccess) { bad = 1; return; }
+        bool used[2] = {false, false};
+        int b = 0;
+        for (;;) {
+            const size_t off = next.fetch_add(CH);
+            if (off >= n || bad.load()) break;
+            const size_t len = std::min(CH, n - off);
+            if (used[b] && hipEventSynchronize(D.h2d_ev[t][b]) != hipSuccess) { bad = 1; break; }
+            std::memcpy(D.h2d_pin[t][b], src + off, len);
+            if (hipMemcpyAsync(dst + off, D.h2d_pin[t][b], len, hipMemcpyHostToDevice, D.h2d_stream[t]) != hipSuccess || hipEventRecord(D.h2d_ev[t][b], D.h2d_stream[t]) != hipSuccess) { bad = 1; break; }
+            used[b] = true;
+            b ^= 1;
+        }
+        if (hipStreamSynchronize(D.h2d_stream[t]) != hipSuccess) bad = 1;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    if (bad.load()) { (void)hipGetLastError(); return fail(c, SQ_E_HIP, "host to device copy of the file bytes failed"); }
+    return SQ_OK;
+}
 int dev_stage_file(sq_ctx* c, const uint8_t* bytes, size_t n, const uint8_t** dptr) {
     DeviceRecords& D = *c->dev;
     HIPCHK(hipSetDevice(c->P.device));
     if (bytes) {
         HIPCHK(D.staged.reserve(n + 512));
-        HIPCHK(hipMemcpy(D.staged.p, bytes, n, hipMemcpyHostToDevice));
+        { const int rc = h2d_parallel(c, D.staged.p, bytes, n); if (rc) return rc; }
         HIPCHK(hipMemset(D.staged.p + n, 0, 512));
     }
     if (!D.staged.p) return fail(c, SQ_E_ARG, "no staged file");
@@ -2917,7 +2971,12 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         HIPCHK(st.tab.reserve(std::max((size_t)nb, (size_t)(full / 60000)))); HIPCHK(st.flags.reserve(4));
         HIPCHK(st.tok.reserve((size_t)full + 64)); HIPCHK(st.ntok.reserve(std::max((size_t)nb, (size_t)(full / 60000))));
         const double wa1 = since_ms(wa0);
-        if (!dfile) HIPCHK(hipMemcpyAsync(st.in.p, file + B.coff0, (size_t)B.cbytes, hipMemcpyHostToDevice, sa));
+        if (!dfile) {
+            // (the copy no longer travels on the set's stream: the token pass and the resolve that last read this buffer are waited for here)
+            if (k >= (size_t)DeviceRecords::IL_DEPTH) HIPCHK(hipEventSynchronize(st.freed));
+            const int rc = h2d_parallel(c, st.in.p, file + B.coff0, (size_t)B.cbytes);
+            if (rc) return rc;
+        }
         if (report && k < 3) std::fprintf(stderr, "GPU ingest: batch %zu planned at %.1f ms, buffers %.1f ms, copy of %.2f GB returned after %.1f ms\n", k, std::chrono::duration<double, std::milli>(wa0 - w0).count(), wa1, (double)B.cbytes * 1e-9, since_ms(wa0) - wa1);
         HIPCHK(hipMemcpyAsync(st.tab.p, st.host_tab.data(), (size_t)nb * sizeof(InflBlock), hipMemcpyHostToDevice, sa));
         HIPCHK(hipMemsetAsync(st.flags.p, 0, 4 * 4, sa));
