@@ -9,14 +9,42 @@
 // nodes, breakpoint counts are a few hundred bytes) and are ONE collective.  Only when some rank's payload is longer -- the data
 // exchange of a large graph -- a second all-gather carries the remainders, padded to the longest.
 #include <cstring>
+#include <dlfcn.h>
 
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>  // (types and prototypes only: the library itself is bound at run time, below)
 
 #include "sq_internal.h"
 
 namespace sq {
 
 constexpr int64_t SQ_X_PIECE = 16384;
+
+// RCCL is bound when a sharded run first asks for it (dlopen): librccl.so carries half a gigabyte of device code for every
+// architecture, and a single-GPU `squid` process that links it pays for mapping and registering all of it at start-up.
+struct RcclApi {
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+    RcclApi() {
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        GetUniqueId = (decltype(GetUniqueId))dlsym(h, "ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))dlsym(h, "ncclCommInitRank");
+        CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
+        AllGather = (decltype(AllGather))dlsym(h, "ncclAllGather");
+        CommCount = (decltype(CommCount))dlsym(h, "ncclCommCount");
+        CommUserRank = (decltype(CommUserRank))dlsym(h, "ncclCommUserRank");
+        GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
+        ok = GetUniqueId && CommInitRank && CommDestroy && AllGather && CommCount && CommUserRank && GetErrorString;
+    }
+};
+static const RcclApi& rccl() { static RcclApi api; return api; }
 
 struct RcclTransport {
     ncclComm_t comm = nullptr;
@@ -30,7 +58,7 @@ struct RcclTransport {
         if (d_recv) (void)hipFree(d_recv);
         if (h_pin) (void)hipHostFree(h_pin);
         if (stream) (void)hipStreamDestroy(stream);
-        if (comm && own_comm) (void)ncclCommDestroy(comm);
+        if (comm && own_comm) (void)rccl().CommDestroy(comm);
     }
     int allgather(const void* send, int64_t nbytes, void* recv, int world) {
         if (hipSetDevice(device) != hipSuccess) return SQ_E_HIP;
@@ -38,7 +66,7 @@ struct RcclTransport {
         if (ns > cap_send) { if (d_send) (void)hipFree(d_send); d_send = nullptr; cap_send = 0; if (hipMalloc((void**)&d_send, ns + ns / 2) != hipSuccess) return SQ_E_HIP; cap_send = ns + ns / 2; }
         if (nr > cap_recv) { if (d_recv) (void)hipFree(d_recv); d_recv = nullptr; cap_recv = 0; if (hipMalloc((void**)&d_recv, nr + nr / 2) != hipSuccess) return SQ_E_HIP; cap_recv = nr + nr / 2; }
         if (hipMemcpyAsync(d_send, send, ns, hipMemcpyHostToDevice, stream) != hipSuccess) return SQ_E_HIP;
-        if (ncclAllGather(d_send, d_recv, ns, ncclUint8, comm, stream) != ncclSuccess) return SQ_E_HIP;
+        if (rccl().AllGather(d_send, d_recv, ns, ncclUint8, comm, stream) != ncclSuccess) return SQ_E_HIP;
         if (hipMemcpyAsync(recv, d_recv, nr, hipMemcpyDeviceToHost, stream) != hipSuccess) return SQ_E_HIP;
         if (hipStreamSynchronize(stream) != hipSuccess) return SQ_E_HIP;
         return SQ_OK;
@@ -68,7 +96,7 @@ int sq_rccl_unique_id(void* id128) {
     if (!id128) return SQ_E_ARG;
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId travels as 128 bytes");
     ncclUniqueId id;
-    if (ncclGetUniqueId(&id) != ncclSuccess) return SQ_E_HIP;
+    if (!rccl().ok || rccl().GetUniqueId(&id) != ncclSuccess) return SQ_E_HIP;
     std::memcpy(id128, &id, sizeof id);
     return SQ_OK;
 }
@@ -88,16 +116,18 @@ int sq_rccl_init(sq_ctx* c, const void* id128) {
     if (hipSetDevice(c->P.device) != hipSuccess) return fail(c, SQ_E_HIP, "hipSetDevice");
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof id);
+    if (!rccl().ok) return fail(c, SQ_E_HIP, "librccl.so.1 cannot be loaded");
     ncclComm_t comm = nullptr;
-    const ncclResult_t r = ncclCommInitRank(&comm, c->P.world_size, id, c->P.rank);
-    if (r != ncclSuccess) return fail(c, SQ_E_HIP, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+    const ncclResult_t r = rccl().CommInitRank(&comm, c->P.world_size, id, c->P.rank);
+    if (r != ncclSuccess) return fail(c, SQ_E_HIP, std::string("ncclCommInitRank: ") + rccl().GetErrorString(r));
     return rccl_install(c, comm, true);
 }
 
 int sq_rccl_attach(sq_ctx* c, void* nccl_comm) {
     if (!c || !nccl_comm) return SQ_E_ARG;
     int n = 0, r = -1;
-    if (ncclCommCount((ncclComm_t)nccl_comm, &n) != ncclSuccess || ncclCommUserRank((ncclComm_t)nccl_comm, &r) != ncclSuccess) return fail(c, SQ_E_ARG, "not a communicator");
+    if (!rccl().ok) return fail(c, SQ_E_HIP, "librccl.so.1 cannot be loaded");
+    if (rccl().CommCount((ncclComm_t)nccl_comm, &n) != ncclSuccess || rccl().CommUserRank((ncclComm_t)nccl_comm, &r) != ncclSuccess) return fail(c, SQ_E_ARG, "not a communicator");
     if (n != c->P.world_size || r != c->P.rank) return fail(c, SQ_E_ARG, "communicator size / rank differ from sq_params.world_size / rank");
     return rccl_install(c, (ncclComm_t)nccl_comm, false);
 }
