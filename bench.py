@@ -128,6 +128,7 @@ def main() -> None:
     ap.add_argument("--cpu-sample-tsv", type=int, default=0, help="planted junctions of that sample (generator --tsv; 0 = as the workload)")
     ap.add_argument("--cpu-sample-records", type=int, default=0, help="time the CPU oracle on a sample of this many records instead of the bench's own BAM (0 = the bench's BAM)")
     ap.add_argument("--resident-steps", type=int, default=5, help="extra (untimed for `value`) graph passes over resident records, for the per-kernel roofline figures")
+    ap.add_argument("--level", type=int, default=None, help="zlib level of the synthetic BAM (generator --level; 0 = stored blocks: SURVEY.md 8(d)'s variant that separates inflate from parse cost)")
     ap.add_argument("--workdir", default=None)
     a = ap.parse_args()
 
@@ -179,9 +180,9 @@ def main() -> None:
 
     if sharded:
         if rank == 0:
-            synth(a.workload, seed, work, a.records, tsv=a.tsv, support=a.support)
+            synth(a.workload, seed, work, a.records, level=a.level, tsv=a.tsv, support=a.support)
         dist.barrier()
-    pre = synth(a.workload, seed, work, a.records, tsv=a.tsv, support=a.support)
+    pre = synth(a.workload, seed, work, a.records, level=a.level, tsv=a.tsv, support=a.support)
     t_gen = time.perf_counter() - t_gen0
     note(f"synthetic BAM files ready: {pre}")
     bam, chim = f"{pre}.bam", f"{pre}.chim.bam"
@@ -338,7 +339,7 @@ def main() -> None:
         "value": value, "unit": "alignments/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if sharded else ("weak" if world > 1 else "single GPU"), "vs_baseline": None,
         "dtype": "int32", "data": "synthetic",
-        "config": {"workload": f"{a.workload}: " + WORKLOADS.get(a.workload, "generator config " + a.workload) + (f", --records {a.records}" if a.records else "") + (f", --tsv {a.tsv}" if a.tsv else "") + (f", --support {a.support}" if a.support else ""),
+        "config": {"workload": f"{a.workload}: " + WORKLOADS.get(a.workload, "generator config " + a.workload) + (f", --records {a.records}" if a.records else "") + (f", --tsv {a.tsv}" if a.tsv else "") + (f", --support {a.support}" if a.support else "") + (f", --level {a.level}" if a.level is not None else ""),
                    "records": int(total_aln), "records_per_gpu": int(total_aln / world), "blocks_per_record": round(bbar, 4), "flags": " ".join(cli_flags) or "defaults",
                    "parallelism": ("one sample sharded by chromosome over %d ranks, %.1f all-gathers (%.0f payload bytes) per step inside the library (sq_exchange over %s)" % (world, x_all[0] / max(1, n_passes), x_all[1] / max(1, n_passes), "RCCL" if dist.get_backend() == "nccl" else dist.get_backend()) if sharded else "1 sample per GPU, no collective") if world > 1 else "single GPU",
                    "step": "chimeric BAM decode (host) + concordant BAM decode on the GPU (BGZF inflate, record boundaries, record parse) + graph + ordering + SV calls + _sv.txt written; compressed BAM bytes resident in HBM at the start of every step"},
@@ -376,7 +377,7 @@ def main() -> None:
                              "size_histogram": {("20+" if s == 20 else str(s)): int(c) for s, c in enumerate(hist) if c},
                              "ccs_per_s_ordering_stage": len(comp_sizes) / (order_ms * 1e-3) if order_ms > 0 else None,
                              "ccs_per_s_whole_step": len(comp_sizes) * a.steps / elapsed, "ordering_ms_per_pass": order_ms,
-                             "n_order_unsolved": int(counts["n_order_unsolved"])}
+                             "n_components_ge20": int((comp_sizes >= 20).sum()), "n_order_unsolved": int(counts["n_order_unsolved"])}
     close_context(ctx)
     if not a.no_cold_cli and world == 1:
         # what a user runs once: a fresh process, nothing staged, nothing cached inside the process (the page cache is warm)
@@ -397,9 +398,12 @@ def main() -> None:
             sample = f"{a.workload} generated with --records {a.cpu_sample_records}" + (f" --tsv {a.cpu_sample_tsv}" if a.cpu_sample_tsv else "")
         else:
             spre, sample = pre, "the bench's own BAM files"
+        stats_file = work / "cpu_baseline_order_stats.txt"
         t0 = time.perf_counter()
-        subprocess.check_call(pin + [str(BUILD / "squid_oracle"), "-b", f"{spre}.bam", "-c", f"{spre}.chim.bam", "-o", str(work / "cpu_baseline")] + cli_flags, stdout=subprocess.DEVNULL)
+        subprocess.check_call(pin + [str(BUILD / "squid_oracle"), "-b", f"{spre}.bam", "-c", f"{spre}.chim.bam", "-o", str(work / "cpu_baseline")] + cli_flags, stdout=subprocess.DEVNULL,
+                              env=dict(os.environ, ORACLE_STATS_FILE=str(stats_file)))
         tc = time.perf_counter() - t0
+        ostats = dict(l.split("\t", 1) for l in stats_file.read_text().splitlines() if not l.startswith("ambiguous_problem"))
         note(f"CPU oracle on {sample}: {tc:.1f} s")
         oracle_text = (work / "cpu_baseline_sv.txt").read_text()
         if a.cpu_sample_records:
@@ -410,7 +414,14 @@ def main() -> None:
             n_s, same = int(total_aln), oracle_text == text
         out["cpu_baseline"] = {"value": n_s / tc, "unit": "alignments/s", "cores": 1, "kind": "port",
                                "sample": f"{sample} ({n_s} records), BAM files -> _sv.txt incl. its three BAM decodes, {tc:.2f} s, " + ("taskset -c 0" if pin else "unpinned"),
-                               "cpu_model": cpu_model(), "host_cpus": os.cpu_count(), "sv_identical_to_gpu": same, "sv_rows": oracle_text.count("\n") - 1}
+                               "cpu_model": cpu_model(), "host_cpus": os.cpu_count(), "sv_identical_to_gpu": same, "sv_rows": oracle_text.count("\n") - 1,
+                               # the uniqueness gate: ordering problems whose optimal orders disagree on the satisfied discordant edges of the
+                               # graph (an SV row would hang on GLPK's choice among ties) -- must be 0 --, and the components that go through the min-cut
+                               # recursion, whose bridge choice (Boost's in the reference) tests/test_bridge_rule.py shows _sv.txt not to depend on
+                               "ambiguous": int(ostats["ambiguous"]), "n_components_ge20": int(ostats["n_components_ge20"]), "mincut_splits": int(ostats["mincut_splits"]),
+                               "unsolved": int(ostats["too_large"])}
+        if "components" in out and not a.cpu_sample_records:
+            out["components"]["ambiguous"] = int(ostats["ambiguous"])
     if dist:
         dist.destroy_process_group()
     print(json.dumps(out))

@@ -209,6 +209,11 @@ int sq_set_allgather(sq_ctx* c, sq_allgather_fn fn, void* user);
 int sq_rccl_unique_id(void* id128);
 int sq_rccl_init(sq_ctx* c, const void* id128);
 int sq_rccl_attach(sq_ctx* c, void* nccl_comm);
+/* 1 when librccl can be bound in this process (dlopen; no communicator is made, no collective entered): the ranks of a sharded run agree
+ * on this BEFORE any of them enters the collective ncclCommInitRank of sq_rccl_init.  sq_rccl_release drops the context's RCCL
+ * transport (and a communicator the library made itself) when the caller falls back to sq_set_allgather. */
+int sq_rccl_available(void);
+int sq_rccl_release(sq_ctx* c);
 int sq_exchange(sq_ctx* c);
 int sq_exchange_stats(sq_ctx* c, int64_t* collectives, int64_t* bytes); /* all-gathers issued by sq_exchange so far, payload bytes received */
 
@@ -255,6 +260,10 @@ int sq_debug_order(sq_ctx* c, int32_t n, int32_t n_edges, const int32_t* edges5,
  * rel5 receives the five n*n relation matrices (0/1 bytes, in that order), perm_pos / perm_readpos the permutations the
  * library's sorts produce with operator< (SegmentGraph.cpp:264) and CompReadPos (ReadRec.cpp:144-145). */
 int sq_debug_blocks(int32_t n, const int32_t* fields7, uint8_t* rel5, int32_t* perm_pos, int32_t* perm_readpos);
+/* tests: the RCCL transport of sq_exchange end to end on the context's device with a world of ONE rank -- librccl bound at run time,
+ * ncclGetUniqueId, ncclCommInitRank(1 rank), the transport's all-gather of the fixed 16 KiB piece and of a 1 MiB remainder
+ * (host -> device -> ncclAllGather -> host), bytes compared, communicator destroyed. */
+int sq_debug_rccl_selftest(sq_ctx* c);
 
 #ifdef __cplusplus
 }

@@ -370,12 +370,26 @@ public:
         return false;
     }
 
+    // every (sub-)problem whose optima disagree on the satisfied discordant edges, for the dump (ambiguous.txt): global node ids of
+    // the problem and its discordant edges -- what a reader needs to see whether an SV row hangs on the solver's choice among ties
+    std::vector<std::string> ambiguous_notes;
 private:
+    void NoteAmbiguous(const std::map<int, int>& CompNodes, const std::vector<LocalEdge>& E) {
+        std::vector<int> ids(CompNodes.size());
+        for (auto& kv : CompNodes) ids[kv.second] = kv.first;
+        std::string s = "nodes";
+        for (int id : ids) s += " " + std::to_string(id);
+        s += "\tdiscordant_edges";
+        for (const LocalEdge& e : E)
+            if (e.discordant) s += " " + std::to_string(ids[e.u]) + (e.hu ? "H" : "T") + "-" + std::to_string(ids[e.v]) + (e.hv ? "H" : "T") + ":" + std::to_string(e.w);
+        ambiguous_notes.push_back(s);
+    }
     // backbone edges + exact solve + decode (:3271-3314 and :3326-3370)
     std::vector<int> SolveWhole(std::map<int, int>& CompNodes, std::vector<Edge_t> CompEdges) {
         const int n = (int)CompNodes.size();
         std::vector<int> BestOrder(n, 0);
         size_t edgeidx = 0;
+        const size_t n_real = CompEdges.size();  // (the backbone edges appended below are not edges of the graph: they can never become an SV row)
         std::map<int, int>::iterator itnodeend = CompNodes.end();
         itnodeend--;
         for (std::map<int, int>::iterator itnode = CompNodes.begin(); itnode != itnodeend; itnode++) {
@@ -389,19 +403,19 @@ private:
             }
         }
         std::vector<LocalEdge> E;
-        for (const Edge_t& e : CompEdges) E.push_back(LocalEdge{CompNodes[e.Ind1], CompNodes[e.Ind2], e.Head1, e.Head2, e.Weight, G.IsDiscordant(e)});
+        for (const Edge_t& e : CompEdges) E.push_back(LocalEdge{CompNodes[e.Ind1], CompNodes[e.Ind2], e.Head1, e.Head2, e.Weight, E.size() < n_real && G.IsDiscordant(e)});
         std::vector<int> order;
         unsigned mask = 0;
         long val = 0;
         if (n <= brute_max) {
             bool amb = false;
             SolveBrute(n, E, order, mask, val, &amb);
-            if (amb) stats.ambiguous++;
+            if (amb) { stats.ambiguous++; NoteAmbiguous(CompNodes, E); }
             stats.solved++;
         } else if (n <= exact_max) {
             SolveDP(n, E, order, mask, val);
             stats.solved++;
-            if (n < 20 && Ambiguous(n, E, order, mask, val)) stats.ambiguous++;
+            if (n < 20 && Ambiguous(n, E, order, mask, val)) { stats.ambiguous++; NoteAmbiguous(CompNodes, E); }
         } else if (n <= 128) {
             WideSolver ws(n, E, wide_budget);
             ws.Run();
@@ -442,8 +456,23 @@ private:
     // The brute force is quadratic; components above 64 nodes (dense-graph configs have ones with 10^5) use
     // BridgeSplitChains, a linear-time restatement of the same rule.  ORACLE_BRIDGE_CHECK=1 runs both on every call
     // up to 2000 nodes and aborts on a difference (tests/test_oracle_kat.py does that on a dense parameter set).
+    // ORACLE_BRIDGE_RULE = balanced (default) | first | last | least_balanced picks another bridge instead (position in the sorted
+    // component edge list / the most lopsided one): tests/test_bridge_rule.py runs the oracle under every rule and asserts that
+    // _sv.txt and the satisfied discordant edges do not depend on the choice Boost would have made.
+    static int BridgeRule() {
+        static const int rule = []() {
+            const char* v = std::getenv("ORACLE_BRIDGE_RULE");
+            if (!v || !std::strcmp(v, "balanced")) return 0;
+            if (!std::strcmp(v, "first")) return 1;
+            if (!std::strcmp(v, "last")) return 2;
+            if (!std::strcmp(v, "least_balanced")) return 3;
+            std::fprintf(stderr, "ORACLE_BRIDGE_RULE: unknown rule '%s'\n", v); std::abort();
+        }();
+        return rule;
+    }
     static int BridgeSplit(int n, const std::vector<std::pair<int, int>>& edges, std::vector<bool>& parity) {
         static const bool check = std::getenv("ORACLE_BRIDGE_CHECK") != nullptr;
+        if (BridgeRule() != 0) return BridgeSplitChains(n, edges, parity, BridgeRule());
         if (n > 64 && !(check && n <= 2000)) return BridgeSplitChains(n, edges, parity);
         const int w = BridgeSplitBrute(n, edges, parity);
         if (check) {
@@ -456,7 +485,7 @@ private:
     // Same rule in O(n + m): bridges by chain decomposition (Schmidt 2013: DFS tree, then every back edge walks up from
     // its lower end until it meets a visited vertex; tree edges never walked are the bridges), side sizes from DFS
     // subtree sizes.  `parity` = the side that contains the bridge's second endpoint, as in the brute force.
-    static int BridgeSplitChains(int n, const std::vector<std::pair<int, int>>& edges, std::vector<bool>& parity) {
+    static int BridgeSplitChains(int n, const std::vector<std::pair<int, int>>& edges, std::vector<bool>& parity, int rule = 0) {
         const int m = (int)edges.size();
         std::vector<std::vector<std::pair<int, int>>> adj(n);  // (neighbour, edge id)
         for (int i = 0; i < m; i++) { adj[edges[i].first].push_back({edges[i].second, i}); adj[edges[i].second].push_back({edges[i].first, i}); }
@@ -485,7 +514,10 @@ private:
             const int child = pedge[edges[i].first] == i ? edges[i].first : edges[i].second;
             if (pedge[child] != i) continue;  // (cannot happen: an unwalked non-loop edge is a tree edge)
             const int bal = std::abs(n - 2 * sub[child]);
-            if (bestbal < 0 || bal < bestbal) { bestbal = bal; beste = i; }
+            if (rule == 1) { if (beste < 0) beste = i; }                                        // first bridge of the edge list
+            else if (rule == 2) beste = i;                                                      // last
+            else if (rule == 3) { if (bestbal < 0 || bal > bestbal) { bestbal = bal; beste = i; } }  // the most lopsided
+            else if (bestbal < 0 || bal < bestbal) { bestbal = bal; beste = i; }
         }
         parity.assign(n, false);
         if (beste < 0) return 2;

@@ -276,8 +276,17 @@ int main(int argc, char* argv[]) {
     std::vector<std::vector<int>> Components = ord.Ordering();
     lap("components ordered");
     if (P.Print_Components_Ordering) WriteComponents(P.Output_Prefix + "_component_pri.txt", Components);
+    if (const char* sf = std::getenv("ORACLE_STATS_FILE")) {  // (bench.py's cpu_baseline leg: the uniqueness gate without the stage dumps)
+        size_t ge20 = 0, largest = 0;
+        for (const auto& comp : Components) { ge20 += comp.size() >= 20; largest = std::max(largest, comp.size()); }
+        std::ofstream o(sf);
+        o << "components\t" << ord.stats.components << "\nambiguous\t" << ord.stats.ambiguous << "\ntoo_large\t" << ord.stats.too_large << "\nmincut_splits\t" << ord.stats.mincut_splits
+          << "\nn_components_ge20\t" << ge20 << "\nlargest\t" << largest << "\n";
+        for (const std::string& ln : ord.ambiguous_notes) o << "ambiguous_problem\t" << ln << "\n";
+    }
     if (!dumpdir.empty()) {
         WriteComponents(dumpdir + "/orders.txt", Components);
+        { std::ofstream a(dumpdir + "/ambiguous.txt"); for (const std::string& ln : ord.ambiguous_notes) a << ln << "\n"; }
         std::ofstream o(dumpdir + "/order_stats.txt");
         o << "components\t" << ord.stats.components << "\nsolved\t" << ord.stats.solved << "\nambiguous\t" << ord.stats.ambiguous << "\ntoo_large\t" << ord.stats.too_large
           << "\nmincut_splits\t" << ord.stats.mincut_splits << "\nkept_records\t" << G.n_kept_records << "\nbreak_record\t" << G.n_break_record << "\n";

@@ -22,6 +22,7 @@ EXPORTS = [
     "sq_ingest_concordant_file", "sq_build_graph", "sq_graph_view", "sq_order", "sq_call_sv", "sq_breakpoints",
     "sq_set_shard", "sq_exchange_pack", "sq_exchange_unpack", "sq_get_timing", "sq_timing_accumulate", "sq_reset", "sq_ingest_files", "sq_stage_bam", "sq_clear_records", "sq_set_source", "sq_save_records", "sq_load_records", "sq_get_counts", "sq_debug_download", "sq_debug_bp_support", "sq_debug_order", "sq_debug_blocks", "sq_drop_file_cache",
     "sq_total_order", "sq_set_allgather", "sq_rccl_unique_id", "sq_rccl_init", "sq_rccl_attach", "sq_exchange", "sq_exchange_stats",
+    "sq_rccl_available", "sq_rccl_release", "sq_debug_rccl_selftest",
 ]
 
 
@@ -122,6 +123,11 @@ def load_library() -> C.CDLL:
         lib.sq_exchange_unpack.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.c_int32]
         _lib = lib
     return _lib
+
+
+def rccl_available() -> bool:
+    """librccl can be bound in this process (no communicator is made)"""
+    return bool(load_library().sq_rccl_available())
 
 
 def rccl_unique_id() -> bytes:
@@ -255,6 +261,14 @@ class Context:
         self._chk(self.lib.sq_rccl_init(self.h, id128), "sq_rccl_init")
         self.exchange = "native"
 
+    def rccl_release(self):
+        self._chk(self.lib.sq_rccl_release(self.h), "sq_rccl_release")
+        self.exchange = None
+
+    def rccl_selftest(self):
+        """the library's RCCL transport on this context's device with a communicator of one rank (see sq_debug_rccl_selftest)"""
+        self._chk(self.lib.sq_debug_rccl_selftest(self.h), "sq_debug_rccl_selftest")
+
     def set_allgather(self, fn):
         """install a fixed-size all-gather of host buffers: fn(send: bytes) -> bytes of world_size pieces in rank order"""
         FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
@@ -262,6 +276,8 @@ class Context:
         def tramp(_user, send, nbytes, recv):
             try:
                 out = fn(C.string_at(send, nbytes))
+                if len(out) != nbytes * max(int(self.params.world_size), 1):  # (never write past the C buffer)
+                    return -1
                 C.memmove(recv, out, len(out))
                 return 0
             except Exception:  # noqa: BLE001 -- a Python exception must not unwind through the C caller

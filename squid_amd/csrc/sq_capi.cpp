@@ -401,12 +401,12 @@ static int build_graph(sq_ctx* c) {
     struct OtherR { int32_t chr, pos, len; };
     std::vector<OtherR> other_sorted;
     auto sort_other = [&]() { std::sort(other_sorted.begin(), other_sorted.end(), [](const OtherR& a, const OtherR& b) { return a.chr != b.chr ? a.chr < b.chr : a.pos < b.pos; }); };
-    auto exact_sort = [&]() -> int {
+    auto exact_sort = [&](bool always) -> int {  // always: fetch the list even when no block sits in a corner (the forced retry of the tests)
         std::vector<int32_t> ochr, opos, olen;
         bool has_tiny = false;
-        int r2 = dev_gather_other(c, g.n_break, has_tiny, ochr, opos, olen, false);
+        int r2 = dev_gather_other(c, g.n_break, has_tiny, ochr, opos, olen, always);
         if (r2) return r2;
-        other_sorted.resize(has_tiny ? ochr.size() : 0);
+        other_sorted.resize(has_tiny || always ? ochr.size() : 0);
         for (size_t i = 0; i < other_sorted.size(); ++i) other_sorted[i] = OtherR{ochr[i], opos[i], olen[i]};
         sort_other();
         return SQ_OK;
@@ -446,7 +446,7 @@ static int build_graph(sq_ctx* c) {
     c->depth_ambiguous = false;
     if (exact_mode && g.tiny_boundary) {
         HostClock hc(c, "host_depth_exact_sweep");
-        rc = exact_sort();
+        rc = exact_sort(false);
         if (rc) return rc;
         if (!other_sorted.empty()) exact_sweep(ocnt, osum);
         set_depths(ocnt, osum, false);
@@ -503,7 +503,7 @@ static int build_graph(sq_ctx* c) {
                 }
                 sort_other();
             } else {
-                rc = exact_sort();
+                rc = exact_sort(true);  // (with nothing fetched the sweep below would zero every ReadsOther contribution)
                 if (rc) return rc;
             }
             exact_sweep(ocnt, osum);
@@ -1109,8 +1109,14 @@ int sq_build_graph(sq_ctx* c) {
     if (c->shard.on != (c->P.world_size > 1)) return fail(c, SQ_E_ARG, "world_size > 1 needs sq_set_shard (and the other way round)");
     if (c->bp_future.valid()) (void)c->bp_future.get();
     if (!c->gb && !c->timer_keep) c->timer.clear();
+    if (!c->gb) c->ablated = false;
     int rc = build_graph(c);
     dev_flush_timers(c);
+    if (rc == SQ_OK && c->ablated) {  // (the timers of the run stay readable; its graph does not exist)
+        if (c->bp_future.valid()) (void)c->bp_future.get();
+        c->graph_built = false;
+        rc = fail(c, SQ_E_ARG, "a timing-only switch (SQUID_P1_ABLATE / SQUID_EDGES_ABLATE) is set: the graph of this run is wrong and is not handed out");
+    }
     if (rc < 0) { c->gb.reset(); c->x_pending = false; }
     return rc;
 }

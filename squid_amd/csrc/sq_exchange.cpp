@@ -18,6 +18,7 @@
 namespace sq {
 
 constexpr int64_t SQ_X_PIECE = 16384;
+constexpr int64_t SQ_X_MAX_PAYLOAD = (int64_t)1 << 34;  // no rank's payload is anywhere near (node sums + reduced edges: megabytes); beyond = a corrupt length
 
 // RCCL is bound when a sharded run first asks for it (dlopen): librccl.so carries half a gigabyte of device code for every
 // architecture, and a single-GPU `squid` process that links it pays for mapping and registering all of it at start-up.
@@ -110,6 +111,42 @@ static int rccl_install(sq_ctx* c, ncclComm_t comm, bool own) {
     return SQ_OK;
 }
 
+int sq_rccl_available(void) { return rccl().ok ? 1 : 0; }
+
+int sq_rccl_release(sq_ctx* c) {
+    if (!c) return SQ_E_ARG;
+    if (c->rccl) { c->rccl.reset(); if (c->x_allgather == rccl_trampoline) { c->x_allgather = nullptr; c->x_user = nullptr; } }
+    return SQ_OK;
+}
+
+// The whole RCCL path of sq_exchange on ONE device: dlopen, ncclGetUniqueId, ncclCommInitRank with a world of one, the transport's
+// all-gather (host piece -> device -> ncclAllGather -> host) for the fixed 16 KiB piece and for a 1 MiB remainder, bytes compared.
+int sq_debug_rccl_selftest(sq_ctx* c) {
+    if (!c) return SQ_E_ARG;
+    if (hipSetDevice(c->P.device) != hipSuccess) return fail(c, SQ_E_HIP, "hipSetDevice");
+    if (!rccl().ok) return fail(c, SQ_E_HIP, "librccl.so.1 cannot be loaded");
+    ncclUniqueId id;
+    ncclResult_t r = rccl().GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(c, SQ_E_HIP, std::string("ncclGetUniqueId: ") + rccl().GetErrorString(r));
+    ncclComm_t comm = nullptr;
+    r = rccl().CommInitRank(&comm, 1, id, 0);
+    if (r != ncclSuccess) return fail(c, SQ_E_HIP, std::string("ncclCommInitRank: ") + rccl().GetErrorString(r));
+    RcclTransport t;
+    t.comm = comm; t.own_comm = true; t.device = c->P.device;
+    if (hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking) != hipSuccess) return fail(c, SQ_E_HIP, "cannot create the exchange stream");
+    int n = 0, me = -1;
+    if (rccl().CommCount(comm, &n) != ncclSuccess || rccl().CommUserRank(comm, &me) != ncclSuccess || n != 1 || me != 0) return fail(c, SQ_E_HIP, "self-test communicator is not {1 rank, rank 0}");
+    for (const int64_t nbytes : {SQ_X_PIECE, (int64_t)1 << 20}) {
+        std::vector<uint8_t> send((size_t)nbytes), recv((size_t)nbytes, 0);
+        uint64_t x = 0x9E3779B97F4A7C15ull ^ (uint64_t)nbytes;
+        for (auto& b : send) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; b = (uint8_t)x; }
+        const int rc = t.allgather(send.data(), nbytes, recv.data(), 1);
+        if (rc) return fail(c, rc, "self-test all-gather failed");
+        if (send != recv) return fail(c, SQ_E_HIP, "self-test all-gather returned different bytes");
+    }
+    return SQ_OK;
+}
+
 int sq_rccl_init(sq_ctx* c, const void* id128) {
     if (!c || !id128) return SQ_E_ARG;
     if (c->P.world_size <= 1) return fail(c, SQ_E_ARG, "sq_rccl_init needs sq_params.world_size > 1");
@@ -132,8 +169,14 @@ int sq_rccl_attach(sq_ctx* c, void* nccl_comm) {
     return rccl_install(c, (ncclComm_t)nccl_comm, false);
 }
 
+static int exchange_body(sq_ctx* c);
 int sq_exchange(sq_ctx* c) {
     if (!c) return SQ_E_ARG;
+    try { return exchange_body(c); }
+    catch (const std::bad_alloc&) { return fail(c, SQ_E_CAPACITY, "sharded run: out of host memory during an exchange"); }
+    catch (const std::exception& e) { return fail(c, SQ_E_ARG, std::string("sharded run: ") + e.what()); }
+}
+static int exchange_body(sq_ctx* c) {
     if (!c->x_pending) return fail(c, SQ_E_ARG, "no exchange is pending (sq_build_graph / sq_call_sv return SQ_NEED_EXCHANGE first)");
     if (!c->x_allgather) return fail(c, SQ_E_ARG, "no transport installed (sq_rccl_init / sq_rccl_attach / sq_set_allgather)");
     const int W = c->P.world_size;
@@ -148,7 +191,7 @@ int sq_exchange(sq_ctx* c) {
     int64_t longest = 0;
     for (int r = 0; r < W; ++r) {
         std::memcpy(&len[(size_t)r], got.data() + (size_t)r * SQ_X_PIECE, 8);
-        if (len[(size_t)r] < 0) return fail(c, SQ_E_ARG, "sharded run: malformed exchange piece");
+        if (len[(size_t)r] < 0 || len[(size_t)r] > SQ_X_MAX_PAYLOAD) return fail(c, SQ_E_ARG, "sharded run: malformed exchange piece (a peer is out of step)");
         longest = std::max(longest, len[(size_t)r]);
     }
     std::vector<uint8_t> rest_got;

@@ -184,6 +184,7 @@ struct sq_ctx {
     std::vector<int32_t> label;
     sq::GraphSnap snap[6];
     bool graph_built = false, ordered = false;
+    bool ablated = false;  // a timing-only switch (SQUID_P1_ABLATE / SQUID_EDGES_ABLATE) cut a kernel short: sq_build_graph refuses to return a graph
     bool depth_bounds = false;      // node depths are canonical values with [depth_lo, depth_hi] bounds
     bool depth_ambiguous = false;   // a FilterEdges decision depends on the position inside the bounds
     std::vector<int32_t> ord_off, ord_nodes;

@@ -3180,6 +3180,18 @@ int dev_upload_nodes(sq_ctx* c, const std::vector<Node>& nodes) {
 
 // sharded runs, exchange 1: what the last passing records of this shard look like to ReadRec_t::Equal.  (Unsharded: nothing to do --
 // the filters run inside k_pass1.)
+// Timing-only switches that cut a kernel short: never silently.  The pass still runs (the timers are what such a run is for), a line goes
+// to stderr, and sq_build_graph ends with SQ_E_ARG instead of handing out the graph made from the mutilated pass.
+static int ablate_switch(sq_ctx* c, const char* name) {
+    const char* v = std::getenv(name);
+    const int level = v ? std::atoi(v) : 0;
+    if (level) {
+        if (!c->ablated) std::fprintf(stderr, "squid_hip: %s=%d cuts a kernel short (timing only): no graph, no SV calls from this run\n", name, level);
+        c->ablated = true;
+    }
+    return level;
+}
+
 int dev_classify(sq_ctx* c, int32_t last_info[4]) {
     DeviceRecords& D = *c->dev;
     hipStream_t s = c->stream;
@@ -3254,7 +3266,7 @@ int dev_pass1(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<i
         if (ncl) HIPCHK(hipMemsetAsync(D.trig.p, 0x7f, (size_t)ncl * 4, s));
         P1Args A;
         A.min_mapq = c->P.min_mapqual; A.prior_mask = c->shard.on ? c->shard.dedup_mask : 0; A.RL = c->read_len;
-        A.ablate = std::getenv("SQUID_P1_ABLATE") ? std::atoi(std::getenv("SQUID_P1_ABLATE")) : 0;
+        A.ablate = ablate_switch(c, "SQUID_P1_ABLATE");
         A.cls = D.cls.p; A.keep = D.keep.p; A.tile_cnt = D.tile_cnt.p; A.tile_ob = D.tile_ob.p; A.tile_first = D.tile_first.p; A.tile_max = D.tile_max.p;
         A.zc_v = D.zc_v.p; A.zc_K = D.zc_K.p; A.zc_refid = D.zc_refid.p; A.zc_pos = D.zc_pos.p; A.zc_ob = D.zc_ob.p; A.zcap = (int)D.zcap; A.zfix_end = ntiles * P1_ZFIX; A.tile_zbase = D.tile_zbase.p; A.tile_zcnt = D.tile_zcnt.p;
         A.trig = D.trig.p; A.rc_cluster = D.rc_cluster.p; A.rc_pos = D.rc_pos.p; A.rc_len = D.rc_len.p; A.rc_cap = (int)D.rc_cap;
@@ -3538,7 +3550,7 @@ int dev_concordant_edges(sq_ctx* c, const std::vector<Node>& nodes, std::vector<
     if (D.nv.n != (int)nodes.size()) return fail(c, SQ_E_ARG, "internal: dev_upload_nodes first");
     const NodeView nv = D.nv;
     RecView R = D.view();
-    EdgeParams2 ep{c->P.concord_dist_pos, c->P.concord_dist_idx, std::getenv("SQUID_EDGES_ABLATE") ? std::atoi(std::getenv("SQUID_EDGES_ABLATE")) : 0};  // (debugging: parts of k_edges switched off, timing only)
+    EdgeParams2 ep{c->P.concord_dist_pos, c->P.concord_dist_idx, ablate_switch(c, "SQUID_EDGES_ABLATE")};  // (debugging: parts of k_edges switched off, timing only)
     D.pin.reset();
     int32_t* h = D.pin.take_n<int32_t>(8 + NSTRIPE);
     if (!h) return fail(c, SQ_E_HIP, "hipHostMalloc failed");

@@ -23,6 +23,11 @@ template <class It, class Cmp>
 void std_sort_parallel(It first, It last, Cmp comp, int threads) {
     const long n = (long)(last - first);
     if (threads <= 1 || n < (1 << 16)) { std::sort(first, last, comp); return; }
+#if !defined(__GLIBCXX__)
+    // The threaded form below is put together from libstdc++'s own introsort pieces; with another standard library there is
+    // nothing to reproduce (its std::sort has tie orders of its own) and the plain call is all that can be said.
+    std::sort(first, last, comp); return;
+#else
     auto cmp = __gnu_cxx::__ops::__iter_comp_iter(comp);
     struct Task { It first, last; long depth; };
     std::mutex mu;
@@ -64,6 +69,7 @@ void std_sort_parallel(It first, It last, Cmp comp, int threads) {
     worker();
     for (auto& t : th) t.join();
     std::__final_insertion_sort(first, last, cmp);
+#endif
 }
 
 }  // namespace sq

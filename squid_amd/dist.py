@@ -160,18 +160,26 @@ def install_native_exchange(ctx, dist, backend: str):
 
     world = dist.get_world_size()
     if backend == "nccl":
-        box = [squid_amd.rccl_unique_id() if dist.get_rank() == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        ok = 1
-        try:
-            ctx.rccl_init(box[0])
-        except squid_amd.SquidError as e:  # (then on every rank, normally: the ranks agree below and fall back together)
-            print(f"squid_amd: sq_rccl_init failed ({e}); the exchanges go through torch.distributed instead", flush=True)
-            ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag[0]) == 1:
-            return
+        # ncclCommInitRank is collective: a rank that cannot even bind librccl must not leave the others waiting inside it.  So the
+        # ranks first agree that every one of them can (a dlopen, no collective), and only then join the communicator.
+        can = torch.tensor([1 if squid_amd.rccl_available() else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(can, op=dist.ReduceOp.MIN)
+        if int(can[0]) == 1:
+            box = [squid_amd.rccl_unique_id() if dist.get_rank() == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ok = 1
+            try:
+                ctx.rccl_init(box[0])
+            except squid_amd.SquidError as e:  # (then on every rank, normally: the ranks agree below and fall back together)
+                print(f"squid_amd: sq_rccl_init failed ({e}); the exchanges go through torch.distributed instead", flush=True)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag[0]) == 1:
+                return
+            ctx.rccl_release()  # (a rank that did join gives its communicator back before the fallback transport goes in)
+        else:
+            print("squid_amd: librccl cannot be loaded on every rank; the exchanges go through torch.distributed instead", flush=True)
     dev = "cuda" if backend == "nccl" else "cpu"
 
     def allgather(blob: bytes) -> bytes:

@@ -16,6 +16,10 @@ GOLD = Path(__file__).resolve().parent / "golden"
 def _compare(ctx, dump, sv_path, depth_exact=True):
     """depth_exact=False: default mode -- Support/AvgDepth of the intermediate nodes are canonical values (DESIGN.md
     section 3, "depth bounds"); node coordinates and everything downstream must still be identical"""
+    # the uniqueness gate of SURVEY.md 8(c): no ordering problem of this input has optimal orders that disagree on the satisfied
+    # discordant edges -- otherwise "identical to the oracle" would only mean "identical under our rule for GLPK's ties"
+    stats = dict(line.split("\t") for line in (dump / "order_stats.txt").read_text().splitlines())
+    assert stats["ambiguous"] == "0", (dump / "ambiguous.txt").read_text()
     g1 = ctx.graph(1)
     k = 5 if depth_exact else 3
     assert [n[:k] for n in g1["nodes"]] == [n[:k] for n in ou.read_nodes(dump / "nodes_build.txt")], "BuildNode_STAR nodes / Support / AvgDepth"
@@ -1265,3 +1269,43 @@ def test_c3_at_four_million_records_through_the_gpu_reader(built, synth, tmp_pat
             ctx.build_graph()
             ctx.order()
             assert ctx.sv_text() == sv
+
+
+def test_rccl_transport_of_the_exchange_on_one_rank(built):
+    """the RCCL path of sq_exchange has never had two GPUs to run on here: run all of it that one GPU can -- librccl bound with dlopen,
+    ncclGetUniqueId, ncclCommInitRank (a world of one), the transport's all-gather of the fixed 16 KiB piece and of a 1 MiB
+    remainder through device buffers, bytes compared (sq_debug_rccl_selftest).  The driver's record of loaded libraries then shows
+    librccl.so mapped by a test process."""
+    assert squid_amd.rccl_available()
+    with squid_amd.Context() as ctx:
+        ctx.rccl_selftest()
+        ctx.rccl_selftest()  # (a second communicator in the same process)
+    assert "librccl" in Path("/proc/self/maps").read_text()
+
+
+def test_forced_exact_depth_retry_of_an_unsharded_run(built, synth, tmp_path, monkeypatch):
+    """SQUID_FORCE_DEPTH_RETRY on an unsharded context: the retry fetches the whole ReadsOther list (it used to sweep an empty one
+    and drop every ReadsOther contribution when no block sat in a corner)"""
+    monkeypatch.delenv("SQUID_EXACT_DEPTH", raising=False)
+    monkeypatch.setenv("SQUID_FORCE_DEPTH_RETRY", "1")
+    pre = synth("T2")
+    sv_path, dump = ou.run_oracle(built, pre, tmp_path)
+    with squid_amd.Context() as ctx:
+        ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
+        ctx.build_graph()
+        assert "host_depth_exact_retry" in ctx.timing()
+        _compare(ctx, dump, sv_path)  # (the retry leaves exact depths: the intermediate Support / AvgDepth are compared too)
+
+
+def test_timing_only_switches_do_not_hand_out_a_graph(built, synth, monkeypatch):
+    pre = synth("C1")
+    with squid_amd.Context() as ctx:
+        ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
+        monkeypatch.setenv("SQUID_P1_ABLATE", "2")
+        with pytest.raises(squid_amd.SquidError, match="timing-only"):
+            ctx.build_graph()
+        assert "k_pass1" in ctx.timing()
+        monkeypatch.delenv("SQUID_P1_ABLATE")
+        ctx.reset()
+        ctx.build_graph()
+        assert ctx.sv_text().count("\n") > 1
