@@ -33,7 +33,7 @@ $(B)/gen_synth_bam: squid_amd/synth/gen_synth_bam.cpp
 	mkdir -p $(B)
 	$(CXX) -O2 -std=c++17 -o $@ $< -lz -lpthread -ldl
 
-$(B)/squid_oracle: oracle/squid_oracle.cpp oracle/o_bam.h oracle/o_readrec.h oracle/o_graph.h oracle/o_order.h oracle/o_post.h
+$(B)/squid_oracle: oracle/squid_oracle.cpp oracle/o_bam.h oracle/o_readrec.h oracle/o_graph.h oracle/o_order.h oracle/o_post.h oracle/o_bwa.h
 	$(MAKE) -C oracle OUT=../$(B)
 
 $(B)/oracle_singlebamrec: oracle/singlebamrec_driver.cpp oracle/o_readrec.h oracle/o_bam.h

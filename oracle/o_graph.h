@@ -143,9 +143,11 @@ public:
     }
 
     // ---- src/SegmentGraph.cpp:104-124
-    void Construct(const std::vector<int>& RefLength, SBamrecord_t& Chimrecord, const std::string& bamfile, StageSink* sink);
+    void Construct(const std::vector<int>& RefLength, SBamrecord_t& Chimrecord, const std::string& bamfile, StageSink* sink, uint16_t* ReadLen = nullptr);
 
     void BuildNode_STAR(const std::vector<int>& RefLength, SBamrecord_t& Chimrecord, const std::string& bamfile);
+    void BuildNode_BWA(const std::vector<int>& RefLength, const std::string& bamfile, uint16_t& ReadLen);  // o_bwa.h
+    void RawEdges(SBamrecord_t& Chimrecord, const std::string& bamfile);                                   // o_bwa.h
     std::vector<int> LocateRead(int initialguess, ReadRec_t& ReadRec) const;
     void RawEdgesChim(SBamrecord_t& Chimrecord);
     void RawEdgesOther(SBamrecord_t& Chimrecord, const std::string& bamfile);
@@ -821,8 +823,10 @@ inline void SegmentGraph_t::RawEdgesOther(SBamrecord_t& Chimrecord, const std::s
 
 // src/SegmentGraph.cpp:1932-1966
 inline void SegmentGraph_t::BuildEdges(SBamrecord_t& Chimrecord, const std::string& bamfile) {
-    RawEdgesChim(Chimrecord);
-    RawEdgesOther(Chimrecord, bamfile);
+    if (P.UsingSTAR) {
+        RawEdgesChim(Chimrecord);
+        RawEdgesOther(Chimrecord, bamfile);
+    } else RawEdges(Chimrecord, bamfile);
     std::sort(vEdges.begin(), vEdges.end());
     std::vector<Edge_t> tmpEdges;
     for (size_t i = 0; i < vEdges.size(); i++) {

@@ -15,6 +15,7 @@
 #include <sstream>
 
 #include "o_order.h"
+#include "o_bwa.h"
 #include "o_post.h"
 
 using namespace oracle;
@@ -47,8 +48,9 @@ struct StageSink {
 };
 
 // src/SegmentGraph.cpp:104-124
-void SegmentGraph_t::Construct(const std::vector<int>& RefLength, SBamrecord_t& Chimrecord, const std::string& bamfile, StageSink* sink) {
-    BuildNode_STAR(RefLength, Chimrecord, bamfile);
+void SegmentGraph_t::Construct(const std::vector<int>& RefLength, SBamrecord_t& Chimrecord, const std::string& bamfile, StageSink* sink, uint16_t* ReadLen) {
+    if (P.UsingSTAR) BuildNode_STAR(RefLength, Chimrecord, bamfile);
+    else BuildNode_BWA(RefLength, bamfile, *ReadLen);
     if (sink) { sink->nodes("nodes_seed.txt", seedNodes); sink->nodes("nodes_build.txt", vNodes); }
     BuildEdges(Chimrecord, bamfile);
     if (sink) sink->edges("edges_build.txt", vEdges);
@@ -238,7 +240,6 @@ int main(int argc, char* argv[]) {
         return 0;
     }
     if (!parse_arguments(argc, argv, P, dumpdir)) return 0;  // the reference's main returns 0 either way
-    if (!P.UsingSTAR) { std::fprintf(stderr, "oracle: --bwa is out of scope (SURVEY.md section 8(f) next-1)\n"); return 0; }
     auto T0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count();
@@ -252,24 +253,28 @@ int main(int argc, char* argv[]) {
     for (auto& kv : RefTable) std::cout << "Reference name " << kv.first << "\t-->\t" << kv.second << std::endl;
 
     SBamrecord_t Chimrecord;
-    BuildChimericSBamRecord(Chimrecord, P.Input_Chim_BAM, P);
+    if (P.Input_Chim_BAM.size() != 0) BuildChimericSBamRecord(Chimrecord, P.Input_Chim_BAM, P);  // (src/main.cpp:34-36: --bwa runs without one)
     lap("chimeric records merged");
-    if (!dumpdir.empty()) {
-        std::ofstream o(dumpdir + "/chimrecord.txt");
-        o << "# ReadLen=" << P.ReadLen << "\n";
-        for (const ReadRec_t& r : Chimrecord) {
-            o << r.Qname << '\t' << r.FirstTotalLen << '\t' << r.SecondTotalLen << '\t' << (r.FirstRead.empty() ? 0 : (int)r.FirstLowPhred) << '\t'
-              << (r.SecondMate.empty() ? 0 : (int)r.SecondLowPhred);
-            for (int m = 0; m < 2; m++) {
-                o << (m ? "\tS" : "\tF");
-                for (const SingleBamRec_t& b : (m ? r.SecondMate : r.FirstRead))
-                    o << ' ' << b.RefID << ',' << b.RefPos << ',' << b.ReadPos << ',' << b.MatchRef << ',' << b.MatchRead << ',' << (int)b.IsReverse;
+    auto dump_chimrecord = [&]() {
+        if (!dumpdir.empty()) {
+            std::ofstream o(dumpdir + "/chimrecord.txt");
+            o << "# ReadLen=" << P.ReadLen << "\n";
+            for (const ReadRec_t& r : Chimrecord) {
+                o << r.Qname << '\t' << r.FirstTotalLen << '\t' << r.SecondTotalLen << '\t' << (r.FirstRead.empty() ? 0 : (int)r.FirstLowPhred) << '\t'
+                  << (r.SecondMate.empty() ? 0 : (int)r.SecondLowPhred);
+                for (int m = 0; m < 2; m++) {
+                    o << (m ? "\tS" : "\tF");
+                    for (const SingleBamRec_t& b : (m ? r.SecondMate : r.FirstRead))
+                        o << ' ' << b.RefID << ',' << b.RefPos << ',' << b.ReadPos << ',' << b.MatchRef << ',' << b.MatchRead << ',' << (int)b.IsReverse;
+                }
+                o << '\n';
             }
-            o << '\n';
         }
-    }
+    };
+    if (P.UsingSTAR) dump_chimrecord();
     SegmentGraph_t G(P);
-    G.Construct(RefLength, Chimrecord, P.Input_BAM, dumpdir.empty() ? nullptr : &sink);
+    G.Construct(RefLength, Chimrecord, P.Input_BAM, dumpdir.empty() ? nullptr : &sink, &P.ReadLen);
+    if (!P.UsingSTAR) dump_chimrecord();  // (--bwa: RawEdges has rebuilt the fragments from the partially aligned reads)
     lap("segment graph built");
     if (P.Print_Graph) OutputGraph(P.Output_Prefix + "_graph.txt", G);
     Orderer ord(G);

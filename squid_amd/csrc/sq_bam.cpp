@@ -1014,7 +1014,7 @@ static int usable_cpus() {
     }
     return std::max(1, n);
 }
-int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSink& sink, const std::function<void(size_t)>& on_total, const RefRange* only, const GpuIngest& gpu, bool force_gpu, bool allow_bai) {
+int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSink& sink, const std::function<void(size_t)>& on_total, const RefRange* only, const GpuIngest& gpu, bool force_gpu, bool allow_bai, bool gpu_streams) {
     using clk = std::chrono::steady_clock;
     auto since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
     double t_map = 0, t_inflate = 0, t_find = 0, t_wait = 0;
@@ -1026,7 +1026,9 @@ int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSi
     const char* gpu_env = std::getenv("SQUID_GPU_INFLATE");
     struct stat fst;
     const size_t file_bytes = ::stat(path, &fst) == 0 ? (size_t)fst.st_size : 0;
-    const bool gpu_auto = file_bytes >= ((size_t)1 << 30) && std::min(n_threads, usable_cpus()) <= 24;
+    // (round 3 left files to the host pipeline when more than 24 host threads could run; with the streamed read the GPU reader is ahead
+    // of any number of them)
+    const bool gpu_auto = file_bytes >= ((size_t)1 << 30);
     bool try_gpu = gpu && (force_gpu || (gpu_env ? std::atoi(gpu_env) != 0 : gpu_auto));
     // A chromosome shard with a .bai next to the BAM starts at the virtual offset of its first record and walks only the BGZF
     // blocks of its own range (lazily, like a whole file); without one, the whole file is indexed and the range is found by probing.
@@ -1066,7 +1068,9 @@ int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSi
     // allocations, thread stacks, large vectors -- queues behind it)
     const size_t prefault_ahead = (size_t)1400 << 20;
     prefault.upto = prefault_ahead;
-    if (lazy && !map_reused) prefault.start(fm.p, fm.n);  // (a reused mapping has its page tables filled)
+    // (a reused mapping has its page tables filled; a GPU reader that streams the file itself never looks at the mapping beyond the header)
+    const bool streams = lazy && gpu_streams && std::getenv("SQUID_NO_STREAM") == nullptr;
+    if (lazy && !map_reused && !streams) prefault.start(fm.p, fm.n);
     std::vector<BgzfBlock> blocks;
     size_t total = 0;
     BgzfIndexer ix{fm.p, fm.n};
@@ -1121,7 +1125,7 @@ int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSi
     size_t gpu_file_bytes = fm.n;
     if (only && use_bai && (int)bai.ref_beg.size() != nref) {
         // an index of another file: take the probing path (it wants the whole block index)
-        return scan_bam_file(path, n_threads, err, sink, on_total, only, gpu, force_gpu, false);
+        return scan_bam_file(path, n_threads, err, sink, on_total, only, gpu, force_gpu, false, gpu_streams);
     }
     if (only && use_bai) {
         // first record of the first owned reference that has records; the range ends at the first record of the first later
@@ -1133,20 +1137,20 @@ int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSi
             // no owned reference has records, but the unplaced ones (behind every mapped record) are this rank's: start at the
             // last reference that has records -- the device side keeps only what the rank owns
             for (int r = nref - 1; r >= 0; --r) if (bai.ref_beg[(size_t)r] != ~0ull) { vb = bai.ref_beg[(size_t)r]; break; }
-            if (vb == ~0ull) return scan_bam_file(path, n_threads, err, sink, on_total, only, gpu, force_gpu, false);  // (no mapped record at all: probing path)
+            if (vb == ~0ull) return scan_bam_file(path, n_threads, err, sink, on_total, only, gpu, force_gpu, false, gpu_streams);  // (no mapped record at all: probing path)
         }
         if (vb == ~0ull) return SQ_OK;  // nothing of this rank's in the file
         const size_t cb = (size_t)(vb >> 16), ce = ve == ~0ull ? (size_t)-1 : (size_t)(ve >> 16);
-        if (cb >= fm.n || (ce != (size_t)-1 && ce < cb)) return scan_bam_file(path, n_threads, err, sink, on_total, only, gpu, force_gpu, false);  // (a stale index)
+        if (cb >= fm.n || (ce != (size_t)-1 && ce < cb)) return scan_bam_file(path, n_threads, err, sink, on_total, only, gpu, force_gpu, false, gpu_streams);  // (a stale index)
         blocks.clear();
         ix.p = cb; ix.total = 0; ix.stop = ce; ix.bad = false;
         prefault.from = cb;
         prefault.upto = cb + prefault_ahead;
-        if (!ix.more(blocks, 64) || ix.bad) return scan_bam_file(path, n_threads, err, sink, on_total, only, gpu, force_gpu, false);
+        if (!ix.more(blocks, 64) || ix.bad) return scan_bam_file(path, n_threads, err, sink, on_total, only, gpu, force_gpu, false, gpu_streams);
         nb = 0; first_rec_block = 0;
         only_begin = (size_t)(vb & 0xffff);
         unsynced = false;
-        if (only_begin >= blocks[0].isize) return scan_bam_file(path, n_threads, err, sink, on_total, only, gpu, force_gpu, false);
+        if (only_begin >= blocks[0].isize) return scan_bam_file(path, n_threads, err, sink, on_total, only, gpu, force_gpu, false, gpu_streams);
         gpu_file_bytes = (ce == (size_t)-1 ? fm.n : std::min(fm.n, ce + (size_t)(1 << 17))) - cb;  // sizes the record arrays: the shard's share of the file
     }
     if (only && !use_bai) {
@@ -1195,7 +1199,13 @@ int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSi
             return any;
         };
         const double t_before_gpu = since(t_all);
-        const int r2 = gpu(fm.p, br, nb, lazy ? (size_t)-1 : nb_end, only_begin, !unsynced, nref, lazy ? more : IndexMore(), gpu_file_bytes);
+        GpuFileSrc src{path, ix.p, ix.total, ix.stop, false, false};
+        const int r2 = gpu(fm.p, br, nb, lazy ? (size_t)-1 : nb_end, only_begin, !unsynced, nref, lazy ? more : IndexMore(), gpu_file_bytes, gpu_streams && !std::getenv("SQUID_NO_STREAM") ? &src : nullptr);
+        if (r2 == SQ_OK && src.streamed && lazy && !index_cached) {  // the device side has walked the headers: its index is the index
+            ix.p = src.walk_p; ix.total = src.walk_total; ix.bad = src.bad;
+            blocks.resize(br.size());
+            for (size_t i = 0; i < br.size(); ++i) { blocks[i].coff = br[i].coff; blocks[i].clen = br[i].clen; blocks[i].isize = br[i].isize; blocks[i].uoff = br[i].uoff; }
+        }
         if (std::getenv("SQUID_INGEST_TIMING")) std::fprintf(stderr, "ingest %s: map+index %.1f, header %.1f, GPU inflate+parse path total %.1f ms (rc %d)\n", path, t_map, t_before_gpu, since(t_all), r2);
         if (r2 != 2) {
             if (r2 == SQ_OK && lazy && !ix.complete()) { err = "not a BGZF file"; return SQ_E_IO; }
@@ -1208,7 +1218,7 @@ int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSi
             if (std::getenv("SQUID_INGEST_TIMING")) std::fprintf(stderr, "ingest %s: returning after %.1f ms\n", path, since(t_all));
             return r2;
         }
-        if (lazy && use_bai) { prefault.finish(); return scan_bam_file(path, n_threads, err, sink, on_total, only, gpu, force_gpu, false); }  // (start over on the probing path)
+        if (lazy && use_bai) { prefault.finish(); return scan_bam_file(path, n_threads, err, sink, on_total, only, gpu, force_gpu, false, gpu_streams); }  // (start over on the probing path)
         if (lazy) {  // the host pipeline wants the whole index (and its helpers)
             prefault.finish();
             pool_holder.reset(new Pool(n_threads - 1));

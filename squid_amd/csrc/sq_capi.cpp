@@ -940,8 +940,8 @@ int sq_ingest_concordant_file(sq_ctx* c, const char* path, int32_t n_threads) {
         }
         int rc = scan_bam_file(path, n_threads, c->err, [&](const uint8_t* bam, size_t nbytes, const unsigned long long* off, int64_t n) { c->ingest_seen_bytes += nbytes; return ingest_raw(c, bam, nbytes, off, n); },
                                [&](size_t total) { c->ingest_total_bytes = c->shard.on ? 0 : total; }, c->shard.on ? &rr : nullptr,
-                               [&](const uint8_t* file, std::vector<BgzfRange>& blocks, size_t b0, size_t b1, size_t begin, bool synced, int nref, const IndexMore& more, size_t file_bytes) {
-                                   return dev_ingest_bgzf(c, file, blocks, b0, b1, begin, synced, nref, more, file_bytes); }, staged);
+                               [&](const uint8_t* file, std::vector<BgzfRange>& blocks, size_t b0, size_t b1, size_t begin, bool synced, int nref, const IndexMore& more, size_t file_bytes, GpuFileSrc* src) {
+                                   return dev_ingest_bgzf(c, file, blocks, b0, b1, begin, synced, nref, more, file_bytes, src); }, staged, true, !staged);
         c->ingest_total_bytes = 0;
         const double t_scan = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_file0).count();
         dev_flush_timers(c);
@@ -1112,7 +1112,7 @@ int sq_build_graph(sq_ctx* c) {
     if (!c->gb) c->ablated = false;
     int rc = build_graph(c);
     dev_flush_timers(c);
-    if (rc == SQ_OK && c->ablated) {  // (the timers of the run stay readable; its graph does not exist)
+    if (rc <= 0 && c->ablated) {  // (the timers of the run stay readable; its graph does not exist -- whatever the mutilated pass ran into)
         if (c->bp_future.valid()) (void)c->bp_future.get();
         c->graph_built = false;
         rc = fail(c, SQ_E_ARG, "a timing-only switch (SQUID_P1_ABLATE / SQUID_EDGES_ABLATE) is set: the graph of this run is wrong and is not handed out");

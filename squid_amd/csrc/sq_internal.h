@@ -262,10 +262,15 @@ struct RefRange { int first_ref, end_ref; bool with_unplaced; };  // chromosome 
 // index_more, file bytes).  index_more (may be null) appends the next blocks of the file to `blocks` and returns false at
 // the end of the file: the block index is then built batch by batch, while the GPU works on the batches before
 typedef std::function<bool(std::vector<BgzfRange>&)> IndexMore;
-typedef std::function<int(const uint8_t*, std::vector<BgzfRange>&, size_t, size_t, size_t, bool, int, const IndexMore&, size_t)> GpuIngest;
+// When the compressed bytes are not in HBM yet, the GPU reader streams the file itself (FileFeeder, sq_kernels.hip: pread into
+// page-locked buffers, copies that run ahead of the token pass) and walks the BGZF headers in the bytes it has just read, from
+// `walk_p` (file offset of the next header, `walk_total` inflated bytes in front of it) up to the last block that starts at or
+// before `stop`; on return the three say where that walk ended.
+struct GpuFileSrc { const char* path; size_t walk_p, walk_total, stop; bool bad, streamed; };
+typedef std::function<int(const uint8_t*, std::vector<BgzfRange>&, size_t, size_t, size_t, bool, int, const IndexMore&, size_t, GpuFileSrc*)> GpuIngest;
 int scan_bam_file(const char* path, int n_threads, std::string& err, const std::function<int(const uint8_t*, size_t, const unsigned long long*, int64_t)>& sink,
                   const std::function<void(size_t)>& on_total = nullptr, const RefRange* only = nullptr,
-                  const GpuIngest& gpu = nullptr, bool force_gpu = false, bool allow_bai = true);
+                  const GpuIngest& gpu = nullptr, bool force_gpu = false, bool allow_bai = true, bool gpu_streams = false);
 
 // ---- sq_chimeric.cpp
 int build_fragments(sq_ctx* c, const sq_aln_batch* b);
@@ -317,7 +322,7 @@ void dev_clear_records(sq_ctx* c);
 int dev_stage_file(sq_ctx* c, const uint8_t* bytes, size_t n, const uint8_t** dptr);
 int dev_upload_chim_names(sq_ctx* c);
 int dev_parse_append(sq_ctx* c, const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n_rec);
-int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& blocks, size_t b0, size_t b1, size_t begin, bool synced, int nref, const IndexMore& index_more, size_t file_bytes);
+int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& blocks, size_t b0, size_t b1, size_t begin, bool synced, int nref, const IndexMore& index_more, size_t file_bytes, GpuFileSrc* src);
 struct HostBatch;
 int dev_download_records(sq_ctx* c, HostBatch& hb);
 int dev_chim_begin(sq_ctx* c, const char* blob, size_t blob_bytes, const uint32_t* off, const uint32_t* len, size_t n);

@@ -139,6 +139,12 @@ int reg2bin(int beg, int end) {
     return 0;
 }
 
+// --bwa: ONE coordinate-sorted BAM in the shape `bwa mem` writes (what squid --bwa reads, src/SegmentGraph.cpp:833-1205,1698-1930):
+// MAPQ 60 / 0 instead of STAR's 255 / 3, multi-mappers carry an XA:Z tag, the pieces of a split read are a soft-clipped primary and
+// a hard-clipped SUPPLEMENTARY record (0x800) of the same name and mate, every record knows its mate, and the junction-supporting
+// fragments sit in the sorted stream among the concordant ones (no second file).
+static bool g_bwa = false;
+
 struct Rec {
     int32_t refid, pos;
     std::vector<uint8_t> bytes;  // full BAM record incl. block_size
@@ -163,6 +169,7 @@ Rec make_record(Rng& rng, const std::string& name, int refid, int pos, int mapq,
     put32(b, refid);
     put32(b, pos);
     b.push_back((uint8_t)(name.size() + 1));
+    if (g_bwa) mapq = mapq >= 255 ? 60 : 0;
     b.push_back((uint8_t)mapq);
     put16(b, reg2bin(pos, pos + std::max(reflen, 1)));
     put16(b, (int)cigar.size());
@@ -193,9 +200,14 @@ Rec make_record(Rng& rng, const std::string& name, int refid, int pos, int mapq,
         int len = rng.range(12, 20), st = rng.range(0, seqlen - len);
         for (int i = 0; i < len; ++i) b[qoff + st + i] = 2;
     }
-    // tags NH:i:nh HI:i:1 (STAR default attributes), types 'C'
-    b.push_back('N'); b.push_back('H'); b.push_back('C'); b.push_back((uint8_t)nh);
-    b.push_back('H'); b.push_back('I'); b.push_back('C'); b.push_back(1);
+    if (g_bwa) {  // NM:i:0, and XA:Z:<alternative hit> on a multi-mapper
+        b.push_back('N'); b.push_back('M'); b.push_back('C'); b.push_back(0);
+        if (nh > 1) { static const char xa[] = "XAZchr1,+12345,100M,0;"; b.insert(b.end(), xa, xa + sizeof xa); }
+    } else {
+        // tags NH:i:nh HI:i:1 (STAR default attributes), types 'C'
+        b.push_back('N'); b.push_back('H'); b.push_back('C'); b.push_back((uint8_t)nh);
+        b.push_back('H'); b.push_back('I'); b.push_back('C'); b.push_back(1);
+    }
     int32_t bs = (int32_t)b.size() - 4;
     std::memcpy(b.data(), &bs, 4);
     return r;
@@ -280,6 +292,7 @@ int main(int argc, char** argv) {
         else if (a == "--genes") genes_override = std::atoi(val().c_str());
         else if (a == "--chim-copy-frac") chim_copy_frac = std::atof(val().c_str());
         else if (a == "--indel-frac") indel_frac = std::atof(val().c_str());
+        else if (a == "--bwa") g_bwa = true;
         else { std::fprintf(stderr, "unknown arg %s\n", a.c_str()); return 2; }
     }
     std::vector<Contig> contigs;
@@ -418,6 +431,7 @@ int main(int argc, char** argv) {
             struct MateSpec { int a, b; bool rc; bool first; };
             MateSpec mates[2] = {{s, s + RL, false, !swapmates}, {s + L - RL, s + L, true, swapmates}};
             std::vector<Rec> recs;
+            std::vector<int> rec_mate, rec_primary;  // (--bwa) which mate a record belongs to, and whether it is that mate's first piece
             for (auto& m : mates) {
                 // split the mate's F interval at the junction
                 struct Sub { bool isx; int k0, k1; };
@@ -449,9 +463,40 @@ int main(int argc, char** argv) {
                     int flag = 0x1 | (reverse ? 0x10 : 0) | (m.first ? 0x40 : 0x80);
                     if (npieces == 2 && si == 1) flag |= 0x100;
                     recs.push_back(make_record(rng, name, g.chr, p.refpos, 255, flag, cg, -1, -1, 0, 1, false));
+                    rec_mate.push_back((int)(&m - mates));
+                    rec_primary.push_back(1);
+                    for (size_t q = 0; q + 1 < recs.size(); ++q) if (rec_mate[q] == rec_mate.back()) rec_primary.back() = 0;
                 }
             }
             if (recs.size() < 2) continue;
+            if (g_bwa) {
+                // mate fields from the other mate's primary piece, supplementary flag on the later pieces, then into the sorted
+                // stream of the gene island the record lies in
+                for (size_t q = 0; q < recs.size(); ++q) {
+                    int other = -1;
+                    for (size_t o = 0; o < recs.size(); ++o) if (rec_mate[o] != rec_mate[q] && rec_primary[o]) other = (int)o;
+                    std::vector<uint8_t>& b = recs[q].bytes;
+                    uint16_t fl;
+                    std::memcpy(&fl, b.data() + 18, 2);
+                    fl &= (uint16_t)~0x100;
+                    if (!rec_primary[q]) fl |= 0x800;
+                    int32_t mr = -1, mp = -1;
+                    if (other >= 0) {
+                        uint16_t ofl;
+                        std::memcpy(&ofl, recs[(size_t)other].bytes.data() + 18, 2);
+                        if (ofl & 0x10) fl |= 0x20;
+                        mr = recs[(size_t)other].refid; mp = recs[(size_t)other].pos;
+                    } else fl |= 0x8;
+                    std::memcpy(b.data() + 18, &fl, 2);
+                    std::memcpy(b.data() + 24, &mr, 4);
+                    std::memcpy(b.data() + 28, &mp, 4);
+                    int gi = -1;
+                    for (int cand : {v.gx, v.gy})
+                        if (genes[cand].chr == recs[q].refid && recs[q].pos >= genes[cand].es.front() - 10 && recs[q].pos < genes[cand].ee.back()) gi = cand;
+                    if (gi >= 0) gene_extra[gi].push_back(recs[q]);
+                }
+                continue;
+            }
             // a copy of the un-split mate sometimes also sits in the concordant BAM (filtered there by name)
             if (rng.uni() < chim_copy_frac) {
                 const Rec& r0 = recs.back();
@@ -473,8 +518,11 @@ int main(int argc, char** argv) {
         std::vector<CigarOp> c1 = {{'S', 20}};
         c1.insert(c1.end(), p1.cig.begin(), p1.cig.end());
         Piece p2 = map_interval(g, t0 + 200, t0 + 300);
-        chim.push_back(make_record(rng, name, g.chr, p1.refpos, 255, 0x1 | 0x2 | 0x20 | 0x40, c1, g.chr, p2.refpos, 300, 1, false));
-        chim.push_back(make_record(rng, name, g.chr, p2.refpos, 255, 0x1 | 0x2 | 0x10 | 0x80, p2.cig, g.chr, p1.refpos, -300, 1, false));
+        Rec ra = make_record(rng, name, g.chr, p1.refpos, 255, 0x1 | 0x2 | 0x20 | 0x40, c1, g.chr, p2.refpos, 300, 1, false);
+        Rec rb = make_record(rng, name, g.chr, p2.refpos, 255, 0x1 | 0x2 | 0x10 | 0x80, p2.cig, g.chr, p1.refpos, -300, 1, false);
+        if (g_bwa) { gene_extra[gi].push_back(ra); gene_extra[gi].push_back(rb); continue; }
+        chim.push_back(ra);
+        chim.push_back(rb);
     }
 
     // ---- header
@@ -628,7 +676,7 @@ int main(int argc, char** argv) {
     }
 
     // ---- chimeric BAM (unsorted; shuffle so that name order != file order)
-    {
+    if (!g_bwa) {
         // keep the first five records full-length (they fix ReadLen, ReadRec.cpp:347-348,378-379)
         Rng srng(seed ^ 0xC0FFEEull);
         for (size_t i = chim.size(); i > 6; --i) {

@@ -1302,7 +1302,7 @@ def test_timing_only_switches_do_not_hand_out_a_graph(built, synth, monkeypatch)
     with squid_amd.Context() as ctx:
         ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
         monkeypatch.setenv("SQUID_P1_ABLATE", "2")
-        with pytest.raises(squid_amd.SquidError, match="timing-only"):
+        with pytest.raises(squid_amd.SquidError, match="timing-only"):  # (whatever else the mutilated pass ran into)
             ctx.build_graph()
         assert "k_pass1" in ctx.timing()
         monkeypatch.delenv("SQUID_P1_ABLATE")
