@@ -9,7 +9,7 @@ CXX ?= g++
 ARCH ?= gfx950
 B := build
 CSRC := squid_amd/csrc
-LIBSRC := $(CSRC)/sq_kernels.hip $(CSRC)/sq_bam.cpp $(CSRC)/sq_chimeric.cpp $(CSRC)/sq_segment.cpp $(CSRC)/sq_graph.cpp $(CSRC)/sq_order.cpp $(CSRC)/sq_post.cpp $(CSRC)/sq_exchange.cpp $(CSRC)/sq_capi.cpp
+LIBSRC := $(CSRC)/sq_kernels.hip $(CSRC)/sq_bam.cpp $(CSRC)/sq_chimeric.cpp $(CSRC)/sq_segment.cpp $(CSRC)/sq_graph.cpp $(CSRC)/sq_order.cpp $(CSRC)/sq_post.cpp $(CSRC)/sq_bwa.cpp $(CSRC)/sq_exchange.cpp $(CSRC)/sq_capi.cpp
 
 all: $(B)/libsquid_hip.so $(B)/squid $(B)/squid_annotate $(B)/gen_synth_bam $(B)/squid_oracle $(B)/oracle_singlebamrec ref
 

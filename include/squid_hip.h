@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SQ_ABI_VERSION 3
+#define SQ_ABI_VERSION 4
 
 enum {
     SQ_OK = 0,
@@ -113,6 +113,14 @@ int sq_ingest_concordant_file(sq_ctx* c, const char* bam_path, int32_t n_threads
  * reference reads them one after the other: src/main.cpp:33-36 and src/SegmentGraph.cpp:293).  Same state afterwards as
  * sq_ingest_chimeric_file followed by sq_ingest_concordant_file; an error of either file is returned. */
 int sq_ingest_files(sq_ctx* c, const char* chim_bam_path, const char* bam_path, int32_t n_threads);
+/* `squid --bwa` (src/Config.cpp:98-100, src/main.cpp:33-37): ONE coordinate-sorted BAM in which split reads are supplementary records
+ * and no separate chimeric file exists.  The records are decoded on host threads together with their QNAMEs and stay on the host;
+ * sq_build_graph then runs BuildNode_BWA (src/SegmentGraph.cpp:833-1205) and RawEdges (:1698-1930, which also rebuilds the chimeric
+ * fragments from the partially aligned reads) over them and continues with the same graph stages as the STAR path; sq_call_sv counts
+ * the breakpoint support over the same batch.  sq_params.min_mapqual is the caller's (-mq, default 1: the STAR => 255 rule of
+ * Config.cpp:221-222 does not apply).  A chimeric file ingested before (`-c` next to `--bwa`) only contributes its ReadLen, as in
+ * the reference.  Not available to a chromosome-sharded context. */
+int sq_ingest_bwa_file(sq_ctx* c, const char* bam_path, int32_t n_threads);
 /* Benchmarks and repeated runs: sq_stage_bam copies the compressed bytes of a BAM file into HBM once; a later
  * sq_ingest_concordant_file on the same path then takes the GPU reader (BGZF inflate, record boundaries and record parse
  * on the device) straight from that copy, with no host->device transfer of the file (the host still walks the BGZF block

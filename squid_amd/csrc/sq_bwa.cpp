@@ -1,0 +1,392 @@
+// `squid --bwa`: the single-file mode of the reference.  With BWA-MEM input there is no separate
+// chimeric BAM: split reads are supplementary records of the one coordinate-sorted file, and the reference swaps three functions --
+//   BuildNode_BWA             src/SegmentGraph.cpp:833-1205   (for BuildNode_STAR)
+//   RawEdges                  src/SegmentGraph.cpp:1698-1930  (for RawEdgesChim + RawEdgesOther; it also REBUILDS Chimrecord from the
+//                                                              partially aligned reads, :1883-1926)
+//   the BAM loops' filters    MapQuality == 0 instead of < Min_MapQual (:871,1723), first mates only (:1723-1726)
+// -- and shares everything from BuildEdges' sort on.  Division of labour here: the records are decoded on host threads WITH their
+// QNAMEs (RawEdges sorts, merges and matches reads by name: the device-side record layout of the STAR path keeps no names), the two
+// order-dependent loops run on the host over that batch, and the graph from the edge reduction on takes the same kernels as the STAR
+// path (filters, compression, components, ordering).  The breakpoint support (ExactBPConcordantSupport, mode-independent in the
+// reference) is counted on the host, over the same batch.  Not the path BASELINE.json measures; built for drop-in completeness and
+// held to the same parity bar (tests/test_bwa.py).
+//
+// Quirks of the reference reproduced (ledger W1-W6): capacity-driven window compaction, front() for [offset],
+// the last Qname group never flushed, LocateRead hint left over from the BAM loop, weight -1 edges of multi-aligned second mates, the
+// one-way depth cursor.
+#include <algorithm>
+#include <cstring>
+
+#include "sq_internal.h"
+#include "sq_parsort.h"
+
+namespace sq {
+
+namespace {
+
+struct RecRef {  // one record of the host batch, in the reference's vocabulary
+    const HostBatch& hb; size_t i;
+    int refid() const { return hb.refid[i]; }
+    int pos() const { return hb.pos[i]; }
+    int mrefid() const { return hb.mrefid[i]; }
+    int mpos() const { return hb.mpos[i]; }
+    int flag() const { return hb.flag[i]; }
+    bool mapped() const { return !(flag() & 0x4); }
+    bool mate_mapped() const { return !(flag() & 0x8); }
+    bool rev() const { return flag() & 0x10; }
+    bool mate_rev() const { return flag() & 0x20; }
+    bool first() const { return flag() & 0x40; }
+    bool proper() const { return flag() & 0x2; }
+    bool dup() const { return flag() & 0x400; }
+    bool multi() const { return hb.aux[i] & SQ_AUX_MULTI; }       // HasTag("XA") || IH > 1
+    bool lowphred() const { return hb.aux[i] & SQ_AUX_LOWPHRED; } // of the record's own mate side
+    int totlen() const { return hb.totlen[i]; }
+    size_t nblk() const { return hb.blk_off[i + 1] - hb.blk_off[i]; }
+    Blk blk(size_t k) const {
+        const size_t b = hb.blk_off[i] + k;
+        return Blk{refid(), hb.b_refpos[b], hb.b_readpos[b], hb.b_matchref[b], hb.b_matchread[b], rev(), first()};
+    }
+    std::string raw_name() const { return std::string(hb.names.data() + hb.name_off[i], hb.names.data() + hb.name_off[i + 1]); }
+    std::string qname() const {  // ReadRec.cpp:11-13
+        std::string q = raw_name();
+        if (q.size() >= 2 && (q.compare(q.size() - 2, 2, "/1") == 0 || q.compare(q.size() - 2, 2, "/2") == 0)) q.resize(q.size() - 2);
+        return q;
+    }
+    // the pair is "concordant" for the node builder (:1037-1040)
+    bool pair_concordant() const {
+        if (!(mapped() && mate_mapped() && mrefid() != -1 && refid() == mrefid() && proper())) return false;
+        if (rev() && !mate_rev()) return pos() >= mpos() && pos() - mpos() <= 750000;
+        if (!rev() && mate_rev()) return mpos() >= pos() && mpos() - pos() <= 750000;
+        return false;
+    }
+};
+
+// more than 15 bases of the read hang over at either end of its aligned blocks, and its qualities are fine (:1050-1065, :1730-1737)
+inline bool clipped_end(const std::vector<Blk>& r, int totlen, bool low) {
+    if (r.empty() || low) return false;
+    return r.front().readpos > 15 || totlen - r.back().readpos - r.back().matchread > 15;
+}
+
+// a sliding window of BuildNode_BWA: storage, front offset and the capacity the reference's compaction test looks at (W1)
+struct Window {
+    std::vector<Blk> v;
+    int off = 0;
+    size_t cap = 65536;
+    bool none() const { return off == (int)v.size(); }
+    const Blk& head() const { return v[(size_t)off]; }
+    int end_of(size_t k) const { return v[k].refpos + v[k].matchref; }
+    void drop_left_of(int refid, int pos, int read_len) { while (!none() && (head().refid != refid || head().refpos + head().matchref + read_len < pos)) ++off; }
+    // chromosome of the oldest of the (at most four) newest elements, if there is one (:1002-1013)
+    void vote_chr(int& chr) const { for (int i = (int)v.size() - 1; i >= off && (int)v.size() - i < 5; --i) chr = v[(size_t)i].refid; }
+};
+
+}  // namespace
+
+// ---- BuildNode_BWA up to the seed nodes, plus the Reads list of :878-881
+static int bwa_seed_nodes(sq_ctx* c, const HostBatch& hb, std::vector<Node>& seeds, std::vector<Blk>& reads) {
+    const int thresh = 3;
+    int RL = c->read_len;  // (a chimeric file given next to --bwa has set it already: src/main.cpp:34-36)
+    int counted = 0, prev0 = 0, mark_start = -1, mark_chr = -1, dis_right = 0, other_right = 0;
+    Window conc, dis, part;
+    auto push_node = [&](int chr, int from, int to, int& cur_start, int& cur_end) {
+        seeds.push_back(Node{chr, from, to - from, 0, 0.0});
+        cur_start = to; cur_end = to; mark_start = to; mark_chr = chr;
+    };
+    std::vector<int> margins;
+    for (size_t ri = 0; ri < hb.size(); ++ri) {
+        const RecRef r{hb, ri};
+        if (counted < 5) { RL = std::max(RL, r.totlen()); ++counted; }  // :857-864 (over ALL records, in front of the filter)
+        if (r.multi() || hb.mapq[ri] == 0 || r.dup() || !r.mapped() || r.refid() == -1) continue;
+        if ((!dis.none() && r.refid() != dis.head().refid) || (!conc.none() && r.refid() != conc.head().refid) || (!part.none() && r.refid() != part.head().refid)) other_right = 0;
+        const size_t nb = r.nblk();
+        if (nb == 0) continue;
+        for (size_t k = 0; k < nb; ++k) reads.push_back(r.blk(k));
+        const Blk b0 = r.blk(0), blast = r.blk(nb - 1);
+        if (conc.none() && part.none() && dis.none()) prev0 = r.pos();
+        if (!dis.none() && (dis.v.back().refid != r.refid() || dis_right + RL < r.pos())) {
+            // the discordant window is complete: decide the segment boundaries inside it (:888-998)
+            int cur_end = 0, cur_start = std::max(prev0, mark_start);
+            int d_start = -1, d_end = -1, d_count = -1;
+            bool split = false;
+            auto dense = [&]() { return d_start != -1 && !split && d_count > std::min(5.0, 4.0 * (d_end - d_start) / RL); };
+            while (!dis.none()) {
+                if (dense()) push_node(dis.head().refid, d_start, d_end, cur_start, cur_end);
+                split = false;
+                margins.clear();
+                size_t i = (size_t)dis.off;
+                for (; i < dis.v.size(); ++i) {  // the leading run of blocks that touch each other
+                    margins.push_back(dis.v[i].refpos); margins.push_back(dis.end_of(i));
+                    cur_end = std::max(cur_end, margins.back());
+                    if (i + 1 < dis.v.size() && dis.v[i + 1].refpos > dis.end_of(i)) break;
+                }
+                d_start = std::max(cur_start, dis.head().refpos);
+                d_end = cur_end;
+                d_count = (int)i - dis.off;
+                for (++i; i < dis.v.size() && dis.v[i].refpos < cur_end + thresh; ++i) { margins.push_back(dis.v[i].refpos); margins.push_back(dis.end_of(i)); }
+                const int m0 = margins.front(), dchr = dis.head().refid;
+                for (size_t k = (size_t)part.off; k < part.v.size(); ++k) {  // clip positions of the partially aligned reads next to the run
+                    const Blk& p = part.v[k];
+                    if (p.refid != dchr) continue;
+                    const int pe = p.refpos + p.matchref;
+                    if (p.readpos > 15 && p.refpos > m0 - thresh && p.refpos < cur_end + thresh) margins.push_back(p.rev ? pe : p.refpos);
+                    else if (pe > m0 - thresh && pe < cur_end + thresh) margins.push_back(p.rev ? p.refpos : pe);
+                }
+                std::sort(margins.begin(), margins.end());
+                int last_cursor = -1, last_support = 0;
+                const int chr0 = dis.v.front().refid;  // (W2: element 0 of the storage, not the window's head)
+                for (size_t at = 0; at < margins.size();) {
+                    const int x = margins[at];
+                    if (!seeds.empty() && seeds.back().chr == chr0 && x - seeds.back().pos - seeds.back().len < thresh * 20) { ++at; continue; }
+                    int sr = 0, left_fwd = 0, right_rev = 0;
+                    for (size_t q = 0; q < margins.size() && margins[q] < x + thresh; ++q) sr += std::abs(x - margins[q]) < thresh;
+                    for (size_t q = (size_t)dis.off; q < dis.v.size(); ++q) {
+                        const int e = dis.end_of(q);
+                        if (e < x && e > x - RL && !dis.v[q].rev) ++left_fwd;
+                        else if (dis.v[q].refpos > x && dis.v[q].refpos < x + RL && dis.v[q].rev) ++right_rev;
+                    }
+                    bool cut_here = false;
+                    if (sr > 3 || sr + left_fwd > 4 || sr + right_rev > 4) {
+                        int cover = 0;
+                        for (size_t q = (size_t)conc.off; q < conc.v.size(); ++q) cover += conc.end_of(q) >= x + thresh && conc.v[q].refpos < x - thresh;
+                        if (sr > std::max(cover - sr, 0) + 2) {
+                            const int strength = sr + std::max(left_fwd, right_rev);
+                            if (last_cursor == -1 && x - cur_start < thresh * 20) { mark_start = cur_start; mark_chr = chr0; }
+                            else if ((last_cursor == -1 || x - last_cursor < thresh * 20) && strength > last_support) { last_cursor = x; last_support = strength; }
+                            else if (x - last_cursor >= thresh * 20) { split = true; push_node(chr0, cur_start, last_cursor, cur_start, cur_end); cut_here = true; }
+                        }
+                    }
+                    if (cut_here) break;
+                    size_t nx = at;
+                    while (nx < margins.size() && margins[nx] == x) ++nx;  // on to the next distinct position
+                    if (nx >= margins.size()) break;
+                    at = nx;
+                }
+                if (last_cursor != -1 && !split) { split = true; push_node(dis.head().refid, cur_start, last_cursor, cur_start, cur_end); }
+                while (!dis.none() && dis.head().refpos + dis.head().matchref <= cur_end) ++dis.off;
+            }
+            if (dense()) push_node(dis.v[0].refid, d_start, d_end, cur_start, cur_end);  // (W2)
+            if (dis.none()) { dis.v.clear(); dis.off = 0; }
+            conc.drop_left_of(r.refid(), r.pos(), RL); part.drop_left_of(r.refid(), r.pos(), RL);
+        }
+        // zero coverage in front of this record (:1000-1026)
+        const int rightmost = std::max(dis_right, other_right);
+        int cur_chr = 0;
+        conc.vote_chr(cur_chr); part.vote_chr(cur_chr); dis.vote_chr(cur_chr);
+        const bool zero = r.refid() != cur_chr || r.pos() > rightmost + RL;
+        if (zero && mark_start != -1) {
+            if (rightmost > mark_start && rightmost - mark_start < thresh * 20 && !seeds.empty() && mark_start == seeds.back().pos + seeds.back().len) seeds.back().len += rightmost - mark_start;
+            else if (rightmost > mark_start && rightmost - mark_start >= thresh * 20) seeds.push_back(Node{mark_chr, mark_start, rightmost - mark_start, 0, 0.0});
+            mark_start = -1; mark_chr = -1;
+        }
+        if (zero) prev0 = r.pos();
+        if (dis.none()) { conc.drop_left_of(r.refid(), r.pos(), RL); part.drop_left_of(r.refid(), r.pos(), RL); }
+        // the record joins a window (:1035-1086)
+        const int e0 = b0.refpos + b0.matchref;
+        if (r.pair_concordant()) {
+            other_right = (!conc.none() || !part.none()) ? std::max(other_right, e0) : e0;
+            const bool clipped = !r.lowphred() && (b0.readpos > 15 || r.totlen() - blast.readpos - blast.matchread > 15);
+            (clipped ? part : conc).v.push_back(b0);
+        } else {
+            dis_right = !dis.v.empty() ? std::max(dis_right, e0) : e0;
+            dis.v.push_back(b0);
+        }
+        // compaction at capacity (:1087-1112, W1)
+        for (Window* w : {&conc, &part}) {
+            if (w->v.size() != w->cap) continue;
+            const int from = !dis.none() ? std::min(r.pos(), dis.head().refpos) : r.pos();
+            std::vector<Blk> kept;
+            for (size_t q = (size_t)w->off; q < w->v.size(); ++q) if (w->v[q].refid == r.refid() && w->end_of(q) + RL >= from) kept.push_back(w->v[q]);
+            w->v.swap(kept); w->off = 0;
+            if (w->v.size() == w->cap) w->cap *= 2;
+        }
+    }
+    c->read_len = RL;
+    return SQ_OK;
+}
+
+// Support / AvgDepth of the tiled nodes (:1180-1204): one pass, the cursor never goes back (W6)
+static void bwa_node_depth(std::vector<Node>& N, const std::vector<Blk>& reads) {
+    if (reads.empty()) return;
+    size_t it = 0;
+    for (Node& n : N) {
+        int cnt = 0, sum = 0;
+        for (; it != reads.size(); ++it) {
+            const Blk& b = reads[it];
+            if (b.refid == n.chr && b.refpos >= n.pos && b.refpos + b.matchref <= n.pos + n.len) { ++cnt; sum += b.matchref; }
+            else if (b.refpos >= n.pos + n.len || b.refid != n.chr) break;
+        }
+        n.support = cnt;
+        n.depth = 1.0 * sum / n.len;
+        n.depth_lo = n.depth_hi = n.depth;
+    }
+}
+
+static int bwa_home_node(const std::vector<Node>& N, int start, const Blk& b) {  // the two walks of :1757-1758 as binary searches
+    const int n = (int)N.size();
+    const int j0 = (int)(std::partition_point(N.begin(), N.end(), [&](const Node& x) { return x.chr < b.refid || (x.chr == b.refid && x.pos + x.len < b.refpos); }) - N.begin());
+    const int i = std::max(start, j0);
+    if (i >= n) return -2;
+    const int j1 = (int)(std::partition_point(N.begin(), N.end(), [&](const Node& x) { return x.chr < b.refid || (x.chr == b.refid && x.pos <= b.refpos); }) - N.begin()) - 1;
+    return std::min(i, j1);
+}
+
+// ---- RawEdges (:1698-1930): the edges of the BAM loop, the -1 edges of multi-aligned second mates, the fragments rebuilt from the
+// partially aligned reads and their split edges
+static int bwa_raw_edges(sq_ctx* c, const HostBatch& hb, std::vector<Edge>& raw) {
+    const std::vector<Node>& N = c->nodes;
+    const int nn = (int)N.size();
+    int hint = 0;
+    std::vector<Frag> partial;
+    std::vector<std::string> first_dis, second_names;
+    std::vector<Edge> second_edges;
+    std::vector<int> rn;
+    auto in_range = [&](int i) { return i >= 0 && i < nn; };
+    auto discordant = [&](const Edge& e) { return edge_discordant(c, N, e); };
+    auto add = [&](int i, bool hi, int j, bool hj, int w) -> int {
+        if (!in_range(i) || !in_range(j)) return fail(c, SQ_E_ASSERT, "an edge would leave the node table (the reference asserts, SegmentGraph.cpp:1760)");
+        raw.push_back(make_edge(i, hi, j, hj, w));
+        return SQ_OK;
+    };
+    auto split_edges = [&](const std::vector<Blk>& r, size_t base) -> int {
+        for (size_t k = 0; k + 1 < r.size(); ++k) {
+            const int i = rn[base + k], j = rn[base + k + 1];
+            if (i != j && i != -1 && j != -1) { const int rc = add(i, r[k].rev, j, !r[k + 1].rev, 1); if (rc) return rc; }
+        }
+        return SQ_OK;
+    };
+    for (size_t ri = 0; ri < hb.size(); ++ri) {
+        const RecRef r{hb, ri};
+        if (r.dup() || !r.mapped()) continue;
+        if (r.first() ? (r.multi() || hb.mapq[ri] == 0) : !r.multi()) continue;  // :1723-1726 (W5)
+        Frag f;
+        f.name = r.qname();
+        std::vector<Blk>& own = r.first() ? f.a : f.b;
+        for (size_t k = 0; k < r.nblk(); ++k) own.push_back(r.blk(k));
+        std::sort(own.begin(), own.end(), blk_less_readpos);
+        (r.first() ? f.atot : f.btot) = r.totlen();
+        (r.first() ? f.alow : f.blow) = r.lowphred();
+        if (!r.multi() && (clipped_end(f.a, f.atot, f.alow) || clipped_end(f.b, f.btot, f.blow))) partial.push_back(f);
+        if (r.mate_mapped() && r.mrefid() != -1) (r.first() ? f.b : f.a).push_back(Blk{r.mrefid(), r.mpos(), 0, 15, 15, r.mate_rev(), false});
+        const size_t na = f.a.size();
+        if (r.first() && !f.a.empty() && (f.a.front().readpos <= 15 || f.alow)) {
+            locate_fragment(N, hint, f, rn);
+            if (rn[0] != -1) hint = rn[0];
+            for (size_t k = 0; k < rn.size(); ++k)
+                if (rn[k] == -1) {
+                    const int i = bwa_home_node(N, hint, k < na ? f.a[k] : f.b[k - na]);
+                    const int rc = i == -2 ? fail(c, SQ_E_ASSERT, "a block lies behind the last node (the reference reads past its node table, SegmentGraph.cpp:1757)") : add(i, false, i + 1, true, 1);
+                    if (rc) return rc;
+                }
+            int rc = split_edges(f.a, 0);
+            if (!rc) rc = split_edges(f.b, na);
+            if (rc) return rc;
+            if (!f.b.empty() && !frag_end_discordant(f, true) && !frag_end_discordant(f, false)) {
+                const int i = rn[na - 1], j = rn.back();
+                if (i != j && i != -1 && j != -1 && !pair_overlap(f, rn, i, j)) {
+                    rc = add(i, f.a.back().rev, j, f.b.back().rev, 1);
+                    if (rc) return rc;
+                    if (discordant(raw.back())) first_dis.push_back(f.name);
+                }
+            }
+        } else if (!r.first() && !f.b.empty()) {
+            f.b.resize(1);
+            f.b[0].matchref = 15; f.b[0].matchread = 15;
+            locate_fragment(N, hint, f, rn);
+            if (rn[0] != -1) hint = rn[0];
+            if (!f.a.empty() && !frag_end_discordant(f, true)) {
+                const int i = rn[f.a.size() - 1], j = rn.back();
+                bool overlap = false;
+                for (size_t k = 0; k < f.a.size(); ++k) overlap |= j == rn[k];
+                overlap |= i == rn[f.a.size()];
+                if (i != j && i != -1 && j != -1 && !overlap) {
+                    if (!in_range(i) || !in_range(j)) return fail(c, SQ_E_ASSERT, "an edge would leave the node table (the reference asserts, SegmentGraph.cpp:1852)");
+                    const Edge e = make_edge(i, f.a.back().rev, j, f.b.back().rev, -1);
+                    if (discordant(e)) { second_names.push_back(f.name); second_edges.push_back(e); }
+                }
+            }
+        }
+    }
+    std::sort(first_dis.begin(), first_dis.end());
+    for (size_t k = 0; k < second_names.size(); ++k)
+        if (std::binary_search(first_dis.begin(), first_dis.end(), second_names[k])) raw.push_back(second_edges[k]);
+    // the fragments of the partially aligned reads: grouped by name (the sort of :1883 is libstdc++'s introsort on the names, ledger B8),
+    // merged, stored untrimmed, located from the hint the loop above left behind (W4); the last group is dropped (W3)
+    std::sort(partial.begin(), partial.end(), [](const Frag& x, const Frag& y) { return x.name < y.name; });
+    std::vector<Frag> rebuilt;
+    Frag cur;
+    for (const Frag& p : partial) {
+        if (cur.a.empty() && cur.b.empty()) { cur = p; continue; }
+        if (cur.name == p.name) { cur.a.insert(cur.a.end(), p.a.begin(), p.a.end()); cur.b.insert(cur.b.end(), p.b.begin(), p.b.end()); continue; }
+        std::sort(cur.a.begin(), cur.a.end(), blk_less_readpos);
+        std::sort(cur.b.begin(), cur.b.end(), blk_less_readpos);
+        if (cur.a.size() > 1 || cur.b.size() > 1) {
+            rebuilt.push_back(cur);
+            locate_fragment(N, hint, cur, rn);
+            int rc = split_edges(cur.a, 0);
+            if (!rc) rc = split_edges(cur.b, cur.a.size());
+            if (rc) return rc;
+        }
+        cur = p;
+    }
+    // ReadRec_t::FrontSmallerThan (ReadRec.cpp:90-117; not a strict weak order, kept as it is)
+    std::sort(rebuilt.begin(), rebuilt.end(), [](const Frag& x, const Frag& y) {
+        const Blk* p = !x.a.empty() && !y.a.empty() ? &x.a.front() : !x.b.empty() && !y.b.empty() ? &x.b.front() : !x.a.empty() && !y.b.empty() ? &x.a.front() : !x.b.empty() && !y.a.empty() ? &x.b.front() : nullptr;
+        const Blk* q = !x.a.empty() && !y.a.empty() ? &y.a.front() : !x.b.empty() && !y.b.empty() ? &y.b.front() : !x.a.empty() && !y.b.empty() ? &y.b.front() : !x.b.empty() && !y.a.empty() ? &y.a.front() : nullptr;
+        return p && q && blk_less_pos(*p, *q);
+    });
+    c->frags = rebuilt;
+    c->frags0 = c->frags;
+    // the name set ExactBPConcordantSupport tests raw QNAMEs against (:3113-3118; the sized-then-appended vector also holds "", ledger B9)
+    c->chim_names.clear();
+    if (!rebuilt.empty()) c->chim_names.push_back(std::string());
+    for (const Frag& f : rebuilt) c->chim_names.push_back(f.name);
+    std::sort(c->chim_names.begin(), c->chim_names.end());
+    c->chim_names.erase(std::unique(c->chim_names.begin(), c->chim_names.end()), c->chim_names.end());
+    c->counts.n_chim_fragments = (int64_t)rebuilt.size();
+    return SQ_OK;
+}
+
+// BuildNode_BWA + RawEdges: c->nodes, c->frags and the raw edge list
+int bwa_nodes_and_edges(sq_ctx* c, std::vector<Edge>& raw) {
+    if (!c->bwa) return fail(c, SQ_E_ARG, "sq_ingest_bwa_file first");
+    const HostBatch& hb = *c->bwa;
+    std::vector<Node> seeds;
+    std::vector<Blk> reads;
+    int rc;
+    { HostClock hc(c, "host_bwa_seed_nodes"); rc = bwa_seed_nodes(c, hb, seeds, reads); }
+    if (rc) return rc;
+    c->counts.read_len = c->read_len;
+    { HostClock hc(c, "host_tile_genome"); rc = tile_genome(c, seeds, c->nodes); }
+    if (rc) return rc;
+    { HostClock hc(c, "host_bwa_node_depth"); bwa_node_depth(c->nodes, reads); }
+    c->snap[1].take(c->nodes, std::vector<Edge>(), nullptr);
+    raw.clear();
+    { HostClock hc(c, "host_bwa_raw_edges"); rc = bwa_raw_edges(c, hb, raw); }
+    return rc;
+}
+
+// ExactBPConcordantSupport's counting loop (:3129-3166) over the host batch: `bps` sorted (chr, pos)
+int bwa_breakpoint_support(sq_ctx* c, const std::vector<std::pair<int, int>>& bps, std::vector<int32_t>& cov) {
+    if (!c->bwa) return fail(c, SQ_E_ARG, "sq_ingest_bwa_file first");
+    const HostBatch& hb = *c->bwa;
+    HostClock hc(c, "host_bwa_bp_support");
+    cov.assign(bps.size(), 0);
+    size_t cur = 0;
+    for (size_t ri = 0; ri < hb.size(); ++ri) {
+        const RecRef r{hb, ri};
+        if (r.multi() || (int)hb.mapq[ri] < c->P.min_mapqual || r.dup() || !r.mapped() || r.refid() == -1) continue;
+        if (!c->chim_names.empty() && std::binary_search(c->chim_names.begin(), c->chim_names.end(), r.raw_name())) continue;
+        const bool same_chr_mate = r.mate_mapped() && r.mrefid() == r.refid();
+        if (same_chr_mate && (r.mpos() > r.pos() || (r.mpos() == r.pos() && (r.flag() & 0x80)))) continue;  // only the right-hand record of a pair
+        if (cur == bps.size()) break;
+        const int chr = r.refid(), start = same_chr_mate ? r.mpos() : r.pos(), end = hb.endpos[ri];
+        if (chr > bps[cur].first || (chr == bps[cur].first && start > bps[cur].second + c->P.concord_dist_pos)) ++cur;
+        for (size_t k = cur; k < bps.size(); ++k) {
+            if (chr == bps[k].first && start <= bps[k].second && end > bps[k].second) ++cov[k];
+            else if (chr < bps[k].first || (chr == bps[k].first && end <= bps[k].second)) break;
+        }
+    }
+    return SQ_OK;
+}
+
+}  // namespace sq

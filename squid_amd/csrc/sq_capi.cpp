@@ -65,11 +65,6 @@ void GraphSnap::view(sq_graph* g) const {
 
 int dev_breakpoint_support_exact(sq_ctx* c, const std::vector<std::pair<int, int>>& bps, std::vector<int32_t>& coverage);
 
-struct HostClock {
-    sq_ctx* c; const char* name; std::chrono::steady_clock::time_point t0;
-    HostClock(sq_ctx* c, const char* name) : c(c), name(name), t0(std::chrono::steady_clock::now()) {}
-    ~HostClock() { c->timer.add(name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
-};
 
 // ---- exchange payloads (chromosome-sharded runs): plain little-endian PODs appended to a byte vector
 struct Packer {
@@ -138,6 +133,64 @@ static void pack_seeds(sq_ctx* c, const GraphBuild& g) {
     pk.put<int32_t>(g.hasC ? 1 : 0);
     pk.put<int32_t>(g.seedC.chr); pk.put<int32_t>(g.seedC.pos); pk.put<int32_t>(g.seedC.len);
     pk.put_vec(flat(g.seedsC));
+}
+
+// CompressNode .. MultiplyDisEdges of the constructor (SegmentGraph.cpp:117-122), shared by the STAR and the --bwa path
+static int finish_graph(sq_ctx* c, bool host_filters) {
+    int rc;
+    {
+        HostClock hc(c, host_filters ? "host_compress" : "wall_compress");
+        rc = host_filters ? compress_nodes(c) : dev_compress_nodes(c);
+        if (rc) return rc;
+        c->snap[5].take(c->nodes, c->edges, nullptr);
+        rc = host_filters ? further_compress(c) : dev_further_compress(c);
+        if (rc == 2) rc = further_compress(c);  // a node with more discordant edges than the kernel's lists hold
+        if (rc) return rc;
+    }
+    rc = dev_connected_components(c, (int)c->nodes.size(), c->edges, c->label);
+    if (rc) return rc;
+    multiply_discordant(c, false);
+    c->snap[0].take(c->nodes, c->edges, &c->label);
+    c->graph_built = true;
+    c->gb.reset();
+    // ExactBreakpoint only needs the final graph and the trimmed fragments: start it now, sq_call_sv collects it
+    c->bp_early = std::make_shared<BPMap>();
+    c->bp_future = c->pool->submit([c]() {
+        const auto t0 = std::chrono::steady_clock::now();
+        const int r2 = exact_breakpoints(c, *c->bp_early);
+        c->bp_early_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return r2;
+    });
+    return SQ_OK;
+}
+
+// `squid --bwa`: BuildNode_BWA and RawEdges on the host over the decoded batch (sq_bwa.cpp), then the same edge reduction, filters,
+// compression and component labelling as the STAR path (SegmentGraph.cpp:104-124 with UsingSTAR == false).  Node depths are exact
+// here (no unstable sort in this mode's depth sweep), so the coverage-ratio test needs no bounds.
+static int build_graph_bwa(sq_ctx* c) {
+    HostClock wall(c, "wall_build_graph");
+    if (c->shard.on) return fail(c, SQ_E_ARG, "--bwa input is not chromosome-sharded");
+    c->graph_built = false; c->ordered = false;
+    c->depth_bounds = false; c->depth_ambiguous = false;
+    std::vector<Edge> raw;
+    int rc = bwa_nodes_and_edges(c, raw);
+    if (rc) return rc;
+    c->counts.n_raw_edges = (int64_t)raw.size();
+    c->edges.clear();
+    { HostClock hc(c, "host_edge_reduce"); reduce_edges(raw, c->edges); }
+    c->counts.n_unique_edges = (int64_t)c->edges.size();
+    c->snap[2].take(c->nodes, c->edges, nullptr);
+    static const bool host_filters = std::getenv("SQUID_HOST_FILTERS") != nullptr;
+    {
+        HostClock hc(c, host_filters ? "host_filters" : "wall_filters");
+        std::vector<uint8_t> keep;
+        if (host_filters) filter_by_weight(c); else if ((rc = dev_filter_by_weight(c))) return rc;
+        c->snap[3].take(c->nodes, c->edges, nullptr);
+        if (host_filters) filter_by_interleaving(c, keep); else if ((rc = dev_filter_by_interleaving(c, keep))) return rc;
+        if (host_filters) filter_edges(c, keep); else if ((rc = dev_filter_edges(c, keep))) return rc;
+        c->snap[4].take(c->nodes, c->edges, nullptr);
+    }
+    return finish_graph(c, host_filters);
 }
 
 static int build_graph(sq_ctx* c) {
@@ -514,30 +567,7 @@ static int build_graph(sq_ctx* c) {
         }
         c->snap[4].take(c->nodes, c->edges, nullptr);
     }
-    {
-        HostClock hc(c, host_filters ? "host_compress" : "wall_compress");
-        rc = host_filters ? compress_nodes(c) : dev_compress_nodes(c);
-        if (rc) return rc;
-        c->snap[5].take(c->nodes, c->edges, nullptr);
-        rc = host_filters ? further_compress(c) : dev_further_compress(c);
-        if (rc == 2) rc = further_compress(c);  // a node with more discordant edges than the kernel's lists hold
-        if (rc) return rc;
-    }
-    rc = dev_connected_components(c, (int)c->nodes.size(), c->edges, c->label);
-    if (rc) return rc;
-    multiply_discordant(c, false);
-    c->snap[0].take(c->nodes, c->edges, &c->label);
-    c->graph_built = true;
-    c->gb.reset();
-    // ExactBreakpoint only needs the final graph and the trimmed fragments: start it now, sq_call_sv collects it
-    c->bp_early = std::make_shared<BPMap>();
-    c->bp_future = c->pool->submit([c]() {
-        const auto t0 = std::chrono::steady_clock::now();
-        const int r2 = exact_breakpoints(c, *c->bp_early);
-        c->bp_early_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        return r2;
-    });
-    return SQ_OK;
+    return finish_graph(c, host_filters);
 }
 
 struct SvBuild {
@@ -593,7 +623,10 @@ static int call_sv(sq_ctx* c) {
         for (const Edge& e : E) { edge_bps(e, tmp, exact); for (auto& p : tmp) { BPs.push_back(p.first); BPs.push_back(p.second); } }
         std::sort(BPs.begin(), BPs.end());
         static const bool bp_host = getenv("SQUID_BP_HOST") != nullptr;  // debug cross-check of k_bp_walk
-        if (!sh.on) {
+        if (c->bwa) {  // (--bwa: the records and their names are on the host)
+            rc = bwa_breakpoint_support(c, BPs, cov);
+            if (rc) return rc;
+        } else if (!sh.on) {
             rc = bp_host ? dev_breakpoint_support_exact(c, BPs, cov) : dev_breakpoint_support(c, BPs, cov);
             if (rc) return rc;
         } else {
@@ -956,6 +989,27 @@ int sq_ingest_concordant_file(sq_ctx* c, const char* path, int32_t n_threads) {
         return sq_ingest_concordant(c, &b);
     });
 }
+// `squid --bwa -b <bam>` (src/Config.cpp:98-100; src/main.cpp:33-37 runs without a chimeric file): every record of the one BAM file,
+// decoded on host threads with its QNAME, stays on the host; sq_build_graph then takes BuildNode_BWA / RawEdges (sq_bwa.cpp)
+int sq_ingest_bwa_file(sq_ctx* c, const char* path, int32_t n_threads) {
+    if (!c || !path) return SQ_E_ARG;
+    if (c->shard.on) return fail(c, SQ_E_ARG, "--bwa input is not chromosome-sharded");
+    if (c->ref_len.empty()) return fail(c, SQ_E_ARG, "sq_set_references first");
+    { int r0 = sq_set_source(c, path); if (r0) return r0; }
+    std::shared_ptr<HostBatch> all = std::make_shared<HostBatch>();
+    all->blk_off.assign(1, 0); all->name_off.assign(1, 0);
+    ParseOpts o{c->P.phred_type, c->P.min_phred, c->P.max_lowphred_len, true, nullptr};
+    const int rc = parse_bam_file(path, o, (size_t)1 << 21, std::max(1, (int)n_threads), c->err, [&](const HostBatch& hb) {
+        if (all->names.size() + hb.names.size() >= 0xffffffffull || all->b_refpos.size() + hb.b_refpos.size() >= 0xffffffffull) return fail(c, SQ_E_CAPACITY, "--bwa input beyond 4 GB of read names or 2^32 aligned blocks");
+        all->append(hb);
+        return (int)SQ_OK;
+    });
+    if (rc) return rc;
+    c->bwa = all;
+    c->counts.n_concordant = (int64_t)all->size();
+    c->counts.n_blocks = (int64_t)all->b_refpos.size();
+    return SQ_OK;
+}
 int sq_stage_bam(sq_ctx* c, const char* path) {
     if (!c || !path) return SQ_E_ARG;
     const int fd = ::open(path, O_RDONLY);
@@ -981,6 +1035,7 @@ int sq_clear_records(sq_ctx* c) {
     int rc = sq_reset(c);
     if (rc) return rc;
     dev_clear_records(c);
+    c->bwa.reset();
     c->counts = sq_counts{};
     c->counts.n_chimeric_records = c->n_chim_records; c->counts.n_chim_fragments = (int64_t)c->frags.size(); c->counts.read_len = c->read_len;
     return SQ_OK;
@@ -1105,12 +1160,12 @@ int sq_load_records(sq_ctx* c, const char* path) {
 int sq_build_graph(sq_ctx* c) {
     if (!c) return SQ_E_ARG;
     if (c->ref_len.empty()) return fail(c, SQ_E_ARG, "sq_set_references first");
-    if (c->read_len <= 0) return fail(c, SQ_E_ARG, "sq_ingest_chimeric first (ReadLen comes from the chimeric BAM)");
+    if (c->read_len <= 0 && !c->bwa) return fail(c, SQ_E_ARG, "sq_ingest_chimeric first (ReadLen comes from the chimeric BAM)");
     if (c->shard.on != (c->P.world_size > 1)) return fail(c, SQ_E_ARG, "world_size > 1 needs sq_set_shard (and the other way round)");
     if (c->bp_future.valid()) (void)c->bp_future.get();
     if (!c->gb && !c->timer_keep) c->timer.clear();
     if (!c->gb) c->ablated = false;
-    int rc = build_graph(c);
+    int rc = c->bwa ? build_graph_bwa(c) : build_graph(c);
     dev_flush_timers(c);
     if (rc <= 0 && c->ablated) {  // (the timers of the run stay readable; its graph does not exist -- whatever the mutilated pass ran into)
         if (c->bp_future.valid()) (void)c->bp_future.get();

@@ -82,7 +82,7 @@ static std::pair<int, int> split_breakpoints(const Blk& x, const Blk& y) {  // :
     return std::make_pair(b1, b2);
 }
 
-static bool pair_overlap(const Frag& f, const std::vector<int>& rn, int i, int j) {  // :1484-1502
+bool pair_overlap(const Frag& f, const std::vector<int>& rn, int i, int j) {  // :1484-1502
     const int na = (int)f.a.size(), nb = (int)f.b.size();
     bool ov = false;
     for (int k = 0; k < na; ++k) if (j == rn[k]) ov = true;

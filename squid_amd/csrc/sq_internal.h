@@ -143,6 +143,7 @@ public:
 };
 
 struct DeviceRecords;  // HBM-resident SoA + scratch (sq_kernels.hip)
+struct HostBatch;      // decoded records on the host (below)
 
 // Chromosome sharding: rank r holds the concordant records of a contiguous RefID range and
 // everything that is small (chimeric fragments, cluster table, node and edge tables) is replicated.  The fields
@@ -178,6 +179,8 @@ struct sq_ctx {
     int64_t n_chim_records = 0;
     // concordant side (device)
     sq::DeviceRecords* dev = nullptr;
+    // --bwa (sq_ingest_bwa_file): every record of the one BAM file on the host, with its QNAME (sq_bwa.cpp)
+    std::shared_ptr<sq::HostBatch> bwa;
     // graph state (host, small)
     std::vector<sq::Node> nodes;
     std::vector<sq::Edge> edges;
@@ -231,6 +234,11 @@ struct sq_ctx {
 namespace sq {
 
 int fail(sq_ctx* c, int code, const std::string& msg);
+struct HostClock {  // wall clock of a host stage into the context's timing table
+    sq_ctx* c; const char* name; std::chrono::steady_clock::time_point t0;
+    HostClock(sq_ctx* c, const char* name) : c(c), name(name), t0(std::chrono::steady_clock::now()) {}
+    ~HostClock() { c->timer.add(name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
+};
 // waits for the chimeric decode started by sq_ingest_files and uploads its QNAME set; called in front of the first record parse
 int chim_join(sq_ctx* c);
 // waits only for the QNAME table the helper builds right after decoding the chimeric BAM (what the record parse needs)
@@ -298,6 +306,10 @@ struct Located { std::vector<int> node; };
 bool edge_discordant(const sq_ctx* c, const std::vector<Node>& N, const Edge& e);
 int locate_fragment(const std::vector<Node>& N, int hint, Frag& f, std::vector<int>& out);  // trims f in place
 int chimeric_edges(sq_ctx* c, std::vector<Edge>& raw);
+bool pair_overlap(const Frag& f, const std::vector<int>& rn, int i, int j);  // the pair-edge suppression test of :1484-1502 / :1801-1819
+// ---- sq_bwa.cpp (`squid --bwa`)
+int bwa_nodes_and_edges(sq_ctx* c, std::vector<Edge>& raw);  // BuildNode_BWA + RawEdges over the host batch: c->nodes (+ snapshot 1), c->frags, raw edges
+int bwa_breakpoint_support(sq_ctx* c, const std::vector<std::pair<int, int>>& bps, std::vector<int32_t>& cov);
 void reduce_edges(std::vector<Edge>& raw, std::vector<Edge>& out);
 void filter_by_weight(sq_ctx* c);
 void filter_by_interleaving(sq_ctx* c, std::vector<uint8_t>& keep);

@@ -20,3 +20,15 @@ for cfg in ["C1", "T2"]:
         for name in ["nodes_build.txt", "edges_build.txt", "edges_filter.txt", "nodes_final.txt", "edges_final.txt", "orders.txt", "breakpoints.txt"]:
             shutil.copy(dump / name, ROOT / "tests" / "golden" / f"{cfg}_{name}")
 print("golden files written")
+
+# --bwa mode (one BAM, supplementary alignments): regression pins of the oracle's BuildNode_BWA / RawEdges restatement
+for cfg in ["C1", "T2"]:
+    with tempfile.TemporaryDirectory() as td:
+        pre = Path(td) / cfg
+        subprocess.check_call([str(ROOT / "build" / "gen_synth_bam"), "--config", cfg, "--bwa", "--out", str(pre)], stdout=subprocess.DEVNULL)
+        dump = Path(td) / "dump"
+        dump.mkdir()
+        subprocess.check_call([str(ROOT / "build" / "squid_oracle"), "--bwa", "-b", f"{pre}.bam", "-o", str(Path(td) / "oracle"), "--dump", str(dump)], stdout=subprocess.DEVNULL)
+        shutil.copy(Path(td) / "oracle_sv.txt", ROOT / "tests" / "golden" / f"{cfg}bwa_sv.txt")
+        shutil.copy(dump / "orders.txt", ROOT / "tests" / "golden" / f"{cfg}bwa_orders.txt")
+print("golden files of the --bwa mode written")

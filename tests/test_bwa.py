@@ -1,0 +1,99 @@
+"""`squid --bwa`: one coordinate-sorted BAM, split reads as supplementary records, no chimeric file.
+BuildNode_BWA (src/SegmentGraph.cpp:833-1205) and RawEdges (:1698-1930) replace the STAR node builder and edge generators; everything
+behind BuildEdges' sort is shared.  CPU part: the oracle's restatement finds the planted junctions and is pinned by golden files;
+GPU part: the HIP library (host loops of sq_bwa.cpp + the graph kernels) against the oracle stage by stage, and the command line."""
+import subprocess
+from pathlib import Path
+
+import pytest
+
+import oracle_util as ou
+
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+def _oracle_bwa(built, pre, outdir, *flags):
+    outdir = Path(outdir)
+    dump = outdir / "dump"
+    dump.mkdir(parents=True, exist_ok=True)
+    subprocess.check_call([str(built / "squid_oracle"), "--bwa", "-b", f"{pre}.bam", "-o", str(outdir / "oracle"), "--dump", str(dump), *flags], stdout=subprocess.DEVNULL)
+    return outdir / "oracle_sv.txt", dump
+
+
+def _rows(text):
+    return [line.split("\t") for line in text.splitlines() if line and not line.startswith("#")]
+
+
+@pytest.mark.parametrize("cfg,bwa", [("C1", True), ("T2", True), ("C1", False), ("T2", False)])
+def test_oracle_calls_the_planted_junctions(built, synth, tmp_path, cfg, bwa):
+    """(both modes: the STAR path gets the same check here)  a known answer that does not come from the restatement itself: the junctions the generator planted (truth.txt: chromosome,
+    breakpoint and end type of both sides) -- every SV row of the oracle must sit on one of them, exact to the base where split reads
+    support it, and most planted junctions must be found"""
+    if bwa:
+        pre = synth(cfg, "--bwa")
+        sv_path, dump = _oracle_bwa(built, pre, tmp_path)
+    else:
+        pre = synth(cfg)
+        sv_path, dump = ou.run_oracle(built, pre, tmp_path)
+    truth = []
+    for f in _rows(Path(f"{pre}.truth.txt").read_text()):
+        truth.append(((f[0], int(f[1]), f[2]), (f[3], int(f[4]), f[5])))
+    rows = _rows(sv_path.read_text())
+    assert len(rows) >= max(3, (len(truth) * 2) // 3)
+    hit = set()
+    for r in rows:
+        # a row's side is "-" when the segment's HEAD (its start) is the junction end, "+" when its tail (end) is
+        sides = [(r[0], int(r[1]) if r[8] == "-" else int(r[2]), "H" if r[8] == "-" else "T"), (r[3], int(r[4]) if r[9] == "-" else int(r[5]), "H" if r[9] == "-" else "T")]
+        match = [k for k, (x, y) in enumerate(truth) if {x, y} == set(sides) or (x == sides[0] and y == sides[1]) or (x == sides[1] and y == sides[0])]
+        assert match, f"SV row {r[:6]} {r[8:10]} is not a planted junction"
+        hit.add(match[0])
+    assert len(hit) == len(rows)  # no junction called twice
+    stats = dict(line.split("\t") for line in (dump / "order_stats.txt").read_text().splitlines())
+    assert stats["ambiguous"] == "0"
+
+
+@pytest.mark.parametrize("cfg", ["C1", "T2"])
+def test_oracle_bwa_mode_golden_files(built, synth, tmp_path, cfg):
+    pre = synth(cfg, "--bwa")
+    sv_path, dump = _oracle_bwa(built, pre, tmp_path)
+    assert sv_path.read_text() == (GOLD / f"{cfg}bwa_sv.txt").read_text()
+    assert (dump / "orders.txt").read_text() == (GOLD / f"{cfg}bwa_orders.txt").read_text()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,extra,flags,params", [
+    ("C1", (), (), {}),
+    ("T2", (), (), {}),
+    ("T2", ("--seed", "4242"), (), {}),
+    ("C2", (), (), {}),
+    ("T2", (), ("-w", "2", "-a", "20", "-mq", "30"), dict(min_edge_weight=2, max_allowed_degree=20, min_mapqual=30)),
+])
+def test_stage_parity_bwa(built, synth, tmp_path, cfg, extra, flags, params):
+    import squid_amd
+    from test_gpu_parity import _compare
+
+    pre = synth(cfg, "--bwa", *extra)
+    sv_path, dump = _oracle_bwa(built, pre, tmp_path, *flags)
+    kw = dict(min_mapqual=1)
+    kw.update(params)
+    with squid_amd.Context(star_mapq=False, **kw) as ctx:
+        ctx.load_bwa(f"{pre}.bam")
+        ctx.build_graph()
+        sv = _compare(ctx, dump, sv_path)
+        assert sv.count("\n") > 1
+        # the fragments RawEdges rebuilt from the partially aligned reads (:1883-1926)
+        want_frags = sum(1 for line in (dump / "chimrecord.txt").read_text().splitlines() if not line.startswith("#"))
+        assert ctx.counts()["n_chim_fragments"] == want_frags > 0
+        ctx.reset()
+        ctx.build_graph()
+        ctx.order()
+        assert ctx.sv_text() == sv
+
+
+@pytest.mark.gpu
+def test_bwa_command_line_is_a_drop_in(built, synth, tmp_path):
+    pre = synth("T2", "--bwa")
+    subprocess.check_call([str(built / "squid_oracle"), "--bwa", "-b", f"{pre}.bam", "-o", str(tmp_path / "o"), "-G", "1", "-CO", "1"], stdout=subprocess.DEVNULL)
+    subprocess.check_call([str(built / "squid"), "--bwa", "-b", f"{pre}.bam", "-o", str(tmp_path / "p"), "-G", "1", "-CO", "1"], stdout=subprocess.DEVNULL)
+    for suffix in ("_sv.txt", "_graph.txt", "_component_pri.txt"):
+        assert (tmp_path / f"p{suffix}").read_bytes() == (tmp_path / f"o{suffix}").read_bytes(), suffix

@@ -1308,4 +1308,5 @@ def test_timing_only_switches_do_not_hand_out_a_graph(built, synth, monkeypatch)
         monkeypatch.delenv("SQUID_P1_ABLATE")
         ctx.reset()
         ctx.build_graph()
+        ctx.order()
         assert ctx.sv_text().count("\n") > 1
