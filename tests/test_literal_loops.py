@@ -13,12 +13,116 @@ reference's statements as Python allows, of
 The only inputs taken from elsewhere: the merged chimeric fragments (the oracle's dump of BuildChimericSBamRecord's result), the
 node coordinates of stage 1 and the number of kept records the stream loop consumes before its `break` (`:338-339`).
 """
+import gzip
+import struct
+
+import numpy as np
 import pytest
 
 import oracle_util as ou
-import squid_amd
 
-pytestmark = pytest.mark.gpu
+
+# ---- a BAM record the way BamTools hands it to ReadRec_t::ReadRec_t (ReadRec.cpp:10-88), from the SAM/BAM specification: the fields the
+# loops below read, and the aligned blocks of the constructor (CIGAR walk :45-87, the poly-A/T test :62-72, strand mirroring :74-75)
+def _records_from_bam(path, chim_names):
+    data = gzip.open(path, "rb").read()
+    l_text = struct.unpack_from("<i", data, 4)[0]
+    at = 8 + l_text
+    n_ref = struct.unpack_from("<i", data, at)[0]
+    at += 4
+    for _ in range(n_ref):
+        at += 8 + struct.unpack_from("<i", data, at)[0]
+    rec = {k: [] for k in ("refid", "pos", "mate_refid", "mate_pos", "end_pos", "flag", "mapq", "aux", "totlen", "blk_off", "b_refpos", "b_matchref", "b_readpos", "b_matchread")}
+    rec["blk_off"].append(0)
+    while at < len(data):
+        bs, refid, pos, lname, mapq, _bin, ncig, flag, lseq, mref, mpos, _tlen = struct.unpack_from("<iiiBBHHHiiii", data, at)
+        p = at + 36
+        name = data[p:p + lname - 1].decode()
+        p += lname
+        cig = []
+        for k in range(ncig):
+            v = struct.unpack_from("<I", data, p + 4 * k)[0]
+            cig.append(("MIDNSHP=X"[v & 15], v >> 4))
+        p += 4 * ncig
+        seq = data[p:p + (lseq + 1) // 2]
+        p += (lseq + 1) // 2
+        qual = data[p:p + lseq]
+        p += lseq
+        tags = data[p:at + 4 + bs]
+        totlen = sum(ln for t, ln in cig if t in "MSHI=X")
+        rev = bool(flag & 0x10)
+        readpos, refpos, hard, i = 0, pos, 0, 0
+        while i < len(cig):
+            t, ln = cig[i]
+            if t in "SH":
+                readpos += ln
+                if t == "H":
+                    hard += ln
+            elif t in "M=":
+                tr = tf = 0
+                j = i
+                while j < len(cig) and cig[j][0] not in "SHN":
+                    if cig[j][0] != "D":
+                        tr += cig[j][1]
+                    if cig[j][0] != "I":
+                        tf += cig[j][1]
+                    j += 1
+                na = nt = 0
+                for q in range(readpos - hard, readpos + tr - hard):
+                    code = (seq[q >> 1] >> (4 if q % 2 == 0 else 0)) & 15  # "=ACMGRSVTWYHKDBN": A = 1, T = 8
+                    na += code == 1
+                    nt += code == 8
+                if 1.0 * na / tr < 0.75 and 1.0 * nt / tr < 0.75:
+                    rec["b_refpos"].append(refpos)
+                    rec["b_matchref"].append(tf)
+                    rec["b_readpos"].append(totlen - readpos - tr if rev else readpos)
+                    rec["b_matchread"].append(tr)
+                readpos += tr
+                refpos += tf
+                i = j - 1
+            elif t == "N":
+                refpos += ln
+            i += 1
+        # aux bits of the library's record layout: 1 = HasTag("XA") || IH > 1, 2 = raw name in ChimName, 4 = low-Phred run > Max_LowPhred_Len (10) below 33 + Min_Phred (4)
+        aux, run, longest = 0, 0, 0
+        for qv in qual:
+            run = run + 1 if qv + 33 < 33 + 4 else 0
+            longest = max(longest, run)
+        if longest > 10:
+            aux |= 4
+        tp, has_xa, ih = 0, False, 0
+        while tp + 3 <= len(tags):
+            tag, ty = tags[tp:tp + 2], chr(tags[tp + 2])
+            size = {"A": 1, "c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4}.get(ty)
+            if tag == b"XA":
+                has_xa = True
+            if tag == b"IH" and ty in "cCsSi":
+                ih = int.from_bytes(tags[tp + 3:tp + 3 + size], "little")
+            if size is not None:
+                tp += 3 + size
+            elif ty in "ZH":
+                tp = tags.index(0, tp + 3) + 1
+            else:  # B array
+                sub = {"c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4}[chr(tags[tp + 3])]
+                tp += 8 + sub * struct.unpack_from("<i", tags, tp + 4)[0]
+        if has_xa or ih > 1:
+            aux |= 1
+        if name in chim_names:
+            aux |= 2
+        end = pos + sum(ln for t, ln in cig if t in "MDN=X")
+        for k, v in (("refid", refid), ("pos", pos), ("mate_refid", mref), ("mate_pos", mpos), ("end_pos", end), ("flag", flag), ("mapq", mapq), ("aux", aux), ("totlen", totlen)):
+            rec[k].append(v)
+        rec["blk_off"].append(len(rec["b_refpos"]))
+        at += 4 + bs
+    return {k: np.array(v, dtype=np.int64) for k, v in rec.items()}
+
+
+def _chim_names(dump):
+    names = {""}  # (the sized-then-appended vector of :196-201 also holds "", ledger B9)
+    for line in open(dump / "chimrecord.txt"):
+        if not line.startswith("#"):
+            names.add(line.split("\t")[0])
+    return names
 
 
 def _read_chimrecord(path):
@@ -163,6 +267,71 @@ def _pass1_literal(rec, min_mapq, n_break):
     return main, other, kept
 
 
+# ---- libstdc++'s std::sort (bits/stl_algo.h: __introsort_loop, __unguarded_partition_pivot, __move_median_to_first, __final_insertion_sort),
+# statement by statement: the reference sorts ReadsOther with it (:781) under a comparator that only looks at (chr, pos), the sort is not
+# stable, and a block of <= 3 bases right behind a node boundary is counted for the node in front or the node behind depending on
+# where it ends up among its ties.  (The heap-sort fallback of a recursion that has gone 2*log2(n) deep is not restated: it raises.)
+def _std_sort(a, less):
+    def median_to_first(result, x, y, z):
+        if less(a[x], a[y]):
+            pick = y if less(a[y], a[z]) else (z if less(a[x], a[z]) else x)
+        else:
+            pick = x if less(a[x], a[z]) else (z if less(a[y], a[z]) else y)
+        a[result], a[pick] = a[pick], a[result]
+
+    def partition(first, last, pivot):
+        while True:
+            while less(a[first], a[pivot]):
+                first += 1
+            last -= 1
+            while less(a[pivot], a[last]):
+                last -= 1
+            if not first < last:
+                return first
+            a[first], a[last] = a[last], a[first]
+            first += 1
+
+    def introsort_loop(first, last, depth):
+        while last - first > 16:
+            if depth == 0:
+                raise NotImplementedError("heap-sort fallback of std::sort")
+            depth -= 1
+            median_to_first(first, first + 1, first + (last - first) // 2, last - 1)
+            cut = partition(first + 1, last, first)
+            introsort_loop(cut, last, depth)
+            last = cut
+
+    def linear_insert(last, guarded_first=None):
+        val = a[last]
+        nxt = last - 1
+        while less(val, a[nxt]):
+            a[last] = a[nxt]
+            last = nxt
+            nxt -= 1
+        a[last] = val
+
+    def insertion_sort(first, last):
+        for i in range(first + 1, last):
+            if less(a[i], a[first]):
+                val = a[i]
+                a[first + 1:i + 1] = a[first:i]
+                a[first] = val
+            else:
+                linear_insert(i)
+
+    n = len(a)
+    if n == 0:
+        return a
+    introsort_loop(0, n, 2 * (n.bit_length() - 1))
+    if n > 16:
+        insertion_sort(0, 16)
+        for i in range(16, n):
+            linear_insert(i)
+    else:
+        insertion_sort(0, n)
+    return a
+
+
 # ---- SegmentGraph.cpp:766-826
 def _depth_literal(nodes, bamdiscordant, main, other):
     thresh = 3
@@ -178,7 +347,7 @@ def _depth_literal(nodes, bamdiscordant, main, other):
             itdis += 1
         support[i] = count
         depth[i] = sumlen
-    other = sorted(other, key=lambda r: (r[0], r[1]))  # (std::sort, unstable: ties can differ from libstdc++'s -- see the test)
+    other = _std_sort(list(other), lambda x, y: x[0] < y[0] if x[0] != y[0] else x[1] < y[1])  # the lambda of :781, under std::sort
     for reads, divide in ((main, False), (other, True)):
         if len(reads) == 0:
             continue
@@ -200,24 +369,47 @@ def _depth_literal(nodes, bamdiscordant, main, other):
     return support, depth
 
 
+def _check(rec, chim, nodes, n_break, kept_total):
+    main, other, kept = _pass1_literal(rec, 255, n_break)
+    assert kept == n_break
+    if kept_total is not None:  # the whole stream without the break: records that pass the filter and the duplicate drop
+        _, _, kept_all = _pass1_literal(rec, 255, -1)
+        assert kept_all == kept_total >= n_break
+    support, depth = _depth_literal([n[:3] for n in nodes], _bamdiscordant_literal(chim), main, other)
+    assert [n[3] for n in nodes] == support
+    assert [n[4] for n in nodes] == depth  # the same IEEE doubles: integer sums, one division
+
+
 @pytest.mark.parametrize("cfg", ["C1", "T2"])
-def test_pass1_filter_duplicate_drop_and_node_depths_against_literal_loops(built, synth, tmp_path, cfg, monkeypatch):
+def test_oracle_against_the_literal_loops(built, synth, tmp_path, cfg):
+    """CPU: the oracle's BuildNode_STAR bookkeeping (kept records, the record the loop breaks at) and its per-node Support / AvgDepth
+    against the literal loops over records decoded by the literal constructor above -- a reading of the reference that shares no
+    code with oracle/"""
+    pre = synth(cfg)
+    _, dump = ou.run_oracle(built, pre, tmp_path)
+    stats = dict(line.split("\t") for line in (dump / "order_stats.txt").read_text().splitlines())
+    rec = _records_from_bam(f"{pre}.bam", _chim_names(dump))
+    _check(rec, _read_chimrecord(dump / "chimrecord.txt"), ou.read_nodes(dump / "nodes_build.txt"), int(stats["break_record"]), None)
+    assert stats["kept_records"] == stats["break_record"]  # (the oracle's loop counts up to its break)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["C1", "T2"])
+def test_hip_path_against_the_literal_loops(built, synth, tmp_path, cfg, monkeypatch):
+    """GPU: the records K0 leaves in HBM field by field against the literal constructor, then the library's pass-1 counts and stage-1
+    Support / AvgDepth against the literal loops run over ITS records"""
+    import squid_amd
+
     monkeypatch.setenv("SQUID_EXACT_DEPTH", "1")
     pre = synth(cfg)
     _, dump = ou.run_oracle(built, pre, tmp_path)  # (only for the merged chimeric fragments of its dump)
-    chim = _read_chimrecord(dump / "chimrecord.txt")
     with squid_amd.Context() as ctx:
         ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
         ctx.build_graph()
         rec = ctx.records()
         counts = ctx.counts()
         nodes = ctx.graph(1)["nodes"]
-    main, other, kept = _pass1_literal(rec, 255, counts["n_break"])
-    assert kept == counts["n_break"] <= counts["n_kept_p1"]
-    # the whole stream without the break: the library's count of records that pass the filter and the duplicate drop
-    _, _, kept_all = _pass1_literal(rec, 255, -1)
-    assert kept_all == counts["n_kept_p1"]
-    dis = _bamdiscordant_literal(chim)
-    support, depth = _depth_literal([n[:3] for n in nodes], dis, main, other)
-    assert [n[3] for n in nodes] == support
-    assert [n[4] for n in nodes] == depth  # the same IEEE doubles: integer sums, one division
+    want = _records_from_bam(f"{pre}.bam", _chim_names(dump))
+    for k in want:
+        assert np.array_equal(np.asarray(rec[k]).astype(np.int64), want[k]), k
+    _check(rec, _read_chimrecord(dump / "chimrecord.txt"), nodes, counts["n_break"], counts["n_kept_p1"])
