@@ -99,7 +99,9 @@ struct DBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
-struct InflBlock { unsigned long long coff; uint32_t clen, isize; unsigned long long uoff; };  // one BGZF block for k_inflate
+// one BGZF block for the inflate kernels: payload in the compressed bytes, inflated size and place, and where its tokens go (toff, in
+// tokens from the start of the batch's token buffer: t2_tok_cap(isize) slots per block)
+struct InflBlock { unsigned long long coff; uint32_t clen, isize; unsigned long long uoff, toff; };
 // page-locked host staging for the small device->host results of a stage: the copies are queued without blocking and
 // one stream synchronisation makes all of them visible.  A slice stays valid until the next reset().
 struct Pinned {
@@ -171,7 +173,7 @@ struct DeviceRecords {
     DBuf<uint8_t> staged;  // sq_stage_bam: the compressed bytes of a whole BAM file (+ padding for the input rings' read-ahead)
     DBuf<long long> rec_sync, rec_end;
     // GPU ingest, two batches in flight: compressed bytes + block table + tokens of a batch
-    struct InflSet { DBuf<uint8_t> in; DBuf<InflBlock> tab; DBuf<uint32_t> tok; DBuf<int32_t> ntok, flags; hipEvent_t ready = nullptr, freed = nullptr, copied = nullptr; std::vector<InflBlock> host_tab; const uint8_t* src = nullptr; /* compressed bytes of the batch: `in`, or inside the staged file */ };
+    struct InflSet { DBuf<uint8_t> in; DBuf<InflBlock> tab; DBuf<uint32_t> tok, lens; DBuf<int32_t> ntok, flags; hipEvent_t ready = nullptr, freed = nullptr, copied = nullptr; std::vector<InflBlock> host_tab; const uint8_t* src = nullptr; /* compressed bytes of the batch: `in`, or inside the staged file */ };
     static constexpr int IL_DEPTH = 5;  // buffer sets: batch k is resolved / parsed, the three behind it are in the token pass, the next is being copied
     InflSet il_set[IL_DEPTH];
     hipStream_t il_stream[IL_DEPTH] = {};  // one per set: its host->device copies
@@ -1966,7 +1968,7 @@ __global__ __launch_bounds__(256) void k_order_mid(const SmallProblem* probs, co
 // what it has just written would make the whole wave wait for its stores, hence decoding and copying are apart.  (The round-1 /
 // early round-2 forms -- one wave per block, the table-driven lane kernel, the one-wave resolve -- are gone; `git log` has them.)
 __constant__ uint8_t c_clorder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};  // order of the code-length code lengths in a dynamic block header (RFC 1951)
-constexpr int IL_STAGE = 8;
+constexpr int IL_STAGE = 4;
 // headers are read and tables are built by every lane for itself, in lockstep with the other lanes that are at a block header: zlib
 // closes a block every 16383 symbols, so the lanes of a wave arrive together (a lane that is early waits up to IL_HDR_WAIT steps)
 constexpr int IL_HDR_WAIT = 48;
@@ -2027,57 +2029,84 @@ __device__ __forceinline__ uint32_t il_take(ILane& b, int k) {
 // its length group, where the literals come first), two 16-entry tables per code, the code lengths packed to 4 bits while a
 // header is read (170), the input ring and the token stage: 746 bytes, 46.6 KB per wave, THREE waves per CU -- three times the
 // streams in flight, and a step is two LDS round trips per code instead of up to nine.
-constexpr int T2_SYM_LL = 288, T2_SYM_DD = 32, T2_CL_AT = 320, T2_LENS4 = 170, T2_LITS = 4;
-constexpr size_t T2_LDS_BYTES = (size_t)(T2_SYM_LL + T2_SYM_DD + T2_LENS4) * 64 + (size_t)(5 * 16) * 64 * 2 + (size_t)(IL_STAGE + IL_RING) * 64 * 4;
+constexpr int T2_SYM_LL = 288, T2_SYM_DD = 32, T2_LITS = 4;
+// Round 4: 496 bytes per lane (round 3: 746).  What went: the 4-bit code lengths of a header (170 B) -- they are only needed between
+// reading a header and scattering its symbols, once per ~16 k symbols, and now travel through a per-lane strip of GLOBAL memory, eight
+// to a word, written and read back sequentially (T2_LENS_WORDS words per lane; a wave's word k lies side by side: [k * 64 + lane]);
+// the two scratch tables of the builder (64 B) -- the counts are taken while the header is read, straight into the table that will
+// hold the slot offsets, the scatter uses that table as its cursors and a 15-step pass turns cursors back into offsets; half the token
+// stage (16 B).  31 KB per wave: THREE token waves per workgroup (93 KB) beside the 64 KB slot of a resolve workgroup on every CU, a
+// third SIMD of every CU decoding -- the token pass is issue-bound at one wave per SIMD, so its throughput is the number of SIMDs it
+// gets.
+constexpr int T2_LENS_WORDS = 40;  // 320 code lengths of 4 bits
+constexpr size_t T2_LDS_BYTES = (size_t)(T2_SYM_LL + T2_SYM_DD) * 64 + (size_t)(3 * 16) * 64 * 2 + (size_t)(IL_STAGE + IL_RING) * 64 * 4;
+// token slots of a block: a token is a match (>= 3 bytes) or up to three literals, and a literal run is cut short only in front of a match
+// or at the end of a deflate block -- at most one token per two bytes but for the (few) deflate-block ends.  A stream that still needs more
+// (thousands of tiny deflate blocks) raises the error flag and the file goes to the host reader.
+__host__ __device__ inline uint32_t t2_tok_cap(uint32_t isize) { return ((isize >> 1) + 64u + (IL_STAGE - 1)) & ~(uint32_t)(IL_STAGE - 1); }
 struct T2Lds {
-    uint8_t *sym_ll, *sym_dd, *lens4;        // [e * 64 + lane]
+    uint8_t *sym_ll, *sym_dd;                // [e * 64 + lane]
     int16_t *k_ll, *k_dd;                    // [len * 64 + lane]: symbol slot of a code = (v >> (15 - len)) + k[len]
-    uint16_t *nl_ll, *tmp_a, *tmp_b;         // nl_ll[len]: slot where the symbols >= 256 of that length begin; tmp: builders' scratch
+    uint16_t* nl_ll;                         // nl_ll[len]: slot where the symbols >= 256 of that length begin (while a header is read: the counts of the distance code)
 };
-__device__ __forceinline__ int t2_getlen(const T2Lds& L, int lane, int i) { return (L.lens4[(i >> 1) * 64 + lane] >> ((i & 1) << 2)) & 15; }
-__device__ __forceinline__ void t2_setlen(const T2Lds& L, int lane, int i, int v) {
-    uint8_t* p = L.lens4 + (i >> 1) * 64 + lane;
-    const int sh = (i & 1) << 2;
-    *p = (uint8_t)((*p & (0xf0 >> sh)) | (v << sh));
+// the code lengths of a header on their way through global memory: eight to a word, strictly sequential
+struct LensOut { uint32_t* w; uint32_t acc; int n; };  // w: the lane's strip (word k at w[k * 64])
+__device__ __forceinline__ void lens_put(LensOut& o, int v) {
+    o.acc |= (uint32_t)v << ((o.n & 7) << 2);
+    if ((o.n & 7) == 7) { o.w[(o.n >> 3) * 64] = o.acc; o.acc = 0; }
+    ++o.n;
 }
-// canonical tables of one code from the lengths lens[lo .. lo + n): limits into lim[1..15], slots / symbols into LDS.
-// Called by the lanes that are at a header (me), each for its own code.  Returns false for an over-subscribed set.
-// canonical tables of one code from the lengths lens[lo .. lo + n).  The code limits go into REGISTERS, two 16-bit values per
-// register (limit - 1, so that the sign of (limit - 1 - v) in 16 bits says v >= limit): lp[j] holds lengths 2j + 1 and 2j + 2,
-// lp[7] the limit of length 15 alone.  Slots / symbols go into LDS.  Called by the lanes that are at a header (me), each for
+__device__ __forceinline__ void lens_flush(LensOut& o) { if (o.n & 7) o.w[(o.n >> 3) * 64] = o.acc; }
+struct LensIn { const uint32_t* w; uint32_t acc; int i; };
+__device__ __forceinline__ void lens_seek(LensIn& r, const uint32_t* w, int at) { r.w = w; r.i = at; r.acc = (at & 7) ? w[(at >> 3) * 64] : 0u; }
+__device__ __forceinline__ int lens_get(LensIn& r) {
+    if ((r.i & 7) == 0) r.acc = r.w[(r.i >> 3) * 64];
+    const int v = (int)((r.acc >> ((r.i & 7) << 2)) & 15u);
+    ++r.i;
+    return v;
+}
+// canonical tables of one code.  In: cnt[l * 64 + lane] = number of symbols of length l (l = 1..15; cnt may BE ktab), get(i) = length
+// of symbol i, asked for i = 0 .. n - 1 in order.  Out: the code limits in REGISTERS, two 16-bit values per register (limit - 1, so that
+// the sign of (limit - 1 - v) in 16 bits says v >= limit): lp[j] holds lengths 2j + 1 and 2j + 2, lp[7] the limit of length 15 alone;
+// slot offsets in ktab, symbols in symtab, nl_ll for the literal/length code.  Called by the lanes that are at a header (me), each for
 // its own code.  Returns false for an over-subscribed set.
 typedef short t2_s16x2 __attribute__((ext_vector_type(2)));
-template <bool LL>
-__device__ bool t2_build(const T2Lds& L, int lane, bool me, int lo, int n, uint32_t (&lp)[8], uint8_t* symtab, int16_t* ktab) {
+template <bool LL, class Get>
+__device__ bool t2_build(const T2Lds& L, int lane, bool me, int n, const uint16_t* cnt, Get get, uint32_t (&lp)[8], uint8_t* symtab, int16_t* ktab) {
     bool ok = true;
     if (me) {
-        uint16_t *cnt = L.tmp_a + lane, *slot = L.tmp_b + lane;
-        for (int l = 0; l < 16; ++l) cnt[l * 64] = 0;
-        for (int i = 0; i < n; ++i) ++cnt[t2_getlen(L, lane, lo + i) * 64];
         int left = 1, first = 0, off = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) lp[j] = 0;
 #pragma unroll
         for (int l = 1; l <= 15; ++l) {
-            const int k = cnt[l * 64];
+            const int k = cnt[l * 64 + lane];
             left = (left << 1) - k;
             if (left < 0) ok = false;
             const uint32_t lim = (uint32_t)(first + k) << (15 - l);  // <= 32768
             lp[(l - 1) >> 1] |= ((lim - 1u) & 0xffffu) << (((l - 1) & 1) << 4);
-            ktab[l * 64 + lane] = (int16_t)(off - first);
-            slot[l * 64] = (uint16_t)off;
+            ktab[l * 64 + lane] = (int16_t)off;  // (the scatter's cursor of this length; turned into the slot offset below)
             if (LL) L.nl_ll[l * 64 + lane] = (uint16_t)off;
             off += k;
             first = (first + k) << 1;
         }
-        if (ok)
+        if (ok) {
             for (int i = 0; i < n; ++i) {
-                const int l = t2_getlen(L, lane, lo + i);
+                const int l = get(i);
                 if (!l) continue;
-                const int at = slot[l * 64]++;
+                const int at = ktab[l * 64 + lane]++;
                 symtab[at * 64 + lane] = (uint8_t)i;
                 if (LL && i < 256) ++L.nl_ll[l * 64 + lane];
             }
+            off = 0; first = 0;
+#pragma unroll
+            for (int l = 1; l <= 15; ++l) {  // the cursor of a length has arrived at the end of its group = the start of the next
+                const int end = ktab[l * 64 + lane], k = end - off;
+                ktab[l * 64 + lane] = (int16_t)(off - first);
+                off = end;
+                first = (first + k) << 1;
+            }
+        }
     }
     return ok;
 }
@@ -2115,12 +2144,12 @@ __device__ __forceinline__ uint32_t t2_take(ILane& b, uint32_t& ahead, int k) {
     return v;
 }
 template <bool PROF>
-__global__ __launch_bounds__(128, 1) void k_inflate_tok2(const uint8_t* file, const InflBlock* blocks, int nblocks, unsigned long long out_base, int32_t* flags, uint32_t* tok, int32_t* ntok,
+__global__ __launch_bounds__(192, 1) void k_inflate_tok2(const uint8_t* file, const InflBlock* blocks, int nblocks, int32_t* flags, uint32_t* tok, int32_t* ntok, uint32_t* lens_strips,
                                                     unsigned long long* prof) {
-    // One or two waves per workgroup, each with its own T2_LDS_BYTES and its own 64 blocks; they never talk to each other.  Two
-    // waves make a workgroup of 96 KB: a CU takes one of them and no second -- at most two token waves per CU, and the 64 KB
-    // that remain are exactly the slot of a resolve workgroup (with single-wave workgroups a CU fills up with three token
-    // waves for 36 ms and the resolve, which is what the wall time follows, finds no room there).
+    // One to three waves per workgroup, each with its own T2_LDS_BYTES and its own 64 blocks; they never talk to each other.  Three
+    // waves make a workgroup of 93 KB: a CU takes one of them and no second -- three token waves per CU, on three of its SIMDs, and
+    // the 64 KB that remain are exactly the slot of a resolve workgroup (with single-wave workgroups a CU fills up with token waves
+    // for tens of milliseconds and the resolve, which is what the wall time follows, finds no room there).
     extern __shared__ uint16_t il_lds_all[];  // T2_LDS_BYTES per wave
     uint16_t* il_lds = il_lds_all + (size_t)(threadIdx.x >> 6) * (T2_LDS_BYTES / 2);
     unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pc = 0;
@@ -2129,28 +2158,30 @@ __global__ __launch_bounds__(128, 1) void k_inflate_tok2(const uint8_t* file, co
     __shared__ uint8_t sh_clo[32];
     T2Lds L;
     L.k_ll = (int16_t*)il_lds;                 L.k_dd = L.k_ll + 16 * 64;
-    L.nl_ll = (uint16_t*)(L.k_dd + 16 * 64);   L.tmp_a = L.nl_ll + 16 * 64;   L.tmp_b = L.tmp_a + 16 * 64;
-    uint32_t* stage = (uint32_t*)(L.tmp_b + 16 * 64);  // tokens on their way out: stage[(k % IL_STAGE) * 64 + lane]
+    L.nl_ll = (uint16_t*)(L.k_dd + 16 * 64);
+    uint32_t* stage = (uint32_t*)(L.nl_ll + 16 * 64);  // tokens on their way out: stage[(k % IL_STAGE) * 64 + lane]
     uint32_t* ring = stage + IL_STAGE * 64;
-    L.sym_ll = (uint8_t*)(ring + IL_RING * 64);  L.sym_dd = L.sym_ll + T2_SYM_LL * 64;  L.lens4 = L.sym_dd + T2_SYM_DD * 64;
+    L.sym_ll = (uint8_t*)(ring + IL_RING * 64);  L.sym_dd = L.sym_ll + T2_SYM_LL * 64;
     const int lane = threadIdx.x & 63;
-    if (lane < 19) sh_clo[lane] = c_clorder[lane];  // (both waves write the same values)
+    if (lane < 19) sh_clo[lane] = c_clorder[lane];  // (all waves write the same values)
     wave_sync();
-    const int bi = (blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6)) * 64 + lane;
+    const int gwave = blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+    const int bi = gwave * 64 + lane;
     const bool have = bi < nblocks;
-    InflBlock blk{0, 0, 0, 0};
+    InflBlock blk{0, 0, 0, 0, 0};
     if (have) blk = blocks[bi];
-    uint32_t* tk = tok + (blk.uoff - out_base);
+    uint32_t* tk = tok + blk.toff;
+    const uint32_t tcap = t2_tok_cap(blk.isize);
+    uint32_t* lens_w = lens_strips + (size_t)gwave * (64 * T2_LENS_WORDS) + lane;  // this lane's strip of code lengths (word k at [k * 64])
     uint32_t nt = 0;
+    bool done = !have || blk.isize == 0, err = false;
     auto emit = [&](uint32_t v) {
+        if (nt >= tcap) { err = true; done = true; return; }  // (more tokens than the block's slots hold: see t2_tok_cap)
         stage[(nt % IL_STAGE) * 64 + lane] = v;
-        if ((++nt % IL_STAGE) == 0) {  // a full stage: IL_STAGE consecutive tokens in wide stores
-            uint32_t* dst = tk + nt - IL_STAGE;
-#pragma unroll
-            for (int q = 0; q < IL_STAGE; q += 4) {
-                uint4 w{stage[q * 64 + lane], stage[(q + 1) * 64 + lane], stage[(q + 2) * 64 + lane], stage[(q + 3) * 64 + lane]};
-                __builtin_memcpy(dst + q, &w, 16);
-            }
+        if ((++nt % IL_STAGE) == 0) {  // a full stage: IL_STAGE consecutive tokens in one wide store
+            static_assert(IL_STAGE == 4, "one 16-byte store per stage");
+            uint4 w{stage[lane], stage[64 + lane], stage[2 * 64 + lane], stage[3 * 64 + lane]};
+            __builtin_memcpy(tk + nt - IL_STAGE, &w, 16);
         }
     };
     ILane b;
@@ -2161,7 +2192,7 @@ __global__ __launch_bounds__(128, 1) void k_inflate_tok2(const uint8_t* file, co
     for (int q = 0; q < 8; ++q) { lp_ll[q] = 0; lp_dd[q] = 0; }
     uint32_t ahead = b.ring[0];  // (il_start has filled the ring)
     uint32_t outpos = 0;
-    bool done = !have || blk.isize == 0, err = false, in_block = false, last = false, stored = false;
+    bool in_block = false, last = false, stored = false;
     uint32_t stored_left = 0, stored_at = 0;
     int hdr_wait = 0;
     // what the step has produced -- with four literal/length symbols per step at most three tokens (two pending literals + one
@@ -2183,7 +2214,16 @@ __global__ __launch_bounds__(128, 1) void k_inflate_tok2(const uint8_t* file, co
         if (need && (need == __ballot(!done) || ++hdr_wait >= IL_HDR_WAIT)) {
             hdr_wait = 0;
             const bool me = (need >> lane) & 1;
-            int kind = -1, nlen = 0, ndist = 0;  // 0 stored, 1 fixed code, 2 dynamic code, -1 corrupt
+            int kind = -1, nlen = 0, ndist = 0, ncode = 0;  // 0 stored, 1 fixed code, 2 dynamic code, -1 corrupt
+            // the code lengths go out to the lane's strip as they are decoded, counted on the way: literal/length counts into k_ll (the
+            // table the builder turns into slot offsets), distance counts into nl_ll (free until the literal/length code is built)
+            LensOut lo{lens_w, 0, 0};
+            int eob_len = 0;
+            auto put = [&](int v) {
+                if (lo.n == 256) eob_len = v;
+                if (v) { if (lo.n < nlen) ++L.k_ll[v * 64 + lane]; else ++L.nl_ll[v * 64 + lane]; }
+                lens_put(lo, v);
+            };
             if (me) {
                 if (il_low(b)) il_topup(b);
                 if (il_pos(b) <= b.n + 8) {
@@ -2198,29 +2238,35 @@ __global__ __launch_bounds__(128, 1) void k_inflate_tok2(const uint8_t* file, co
                             stored_left = len;
                             if (len) stored = true; else { il_start(b, stored_at); ahead = b.ring[0]; if (last) done = true; }
                         }
-                    } else if (type == 1) {
-                        for (int i = 0; i < 144; ++i) t2_setlen(L, lane, i, 8);
-                        for (int i = 144; i < 256; ++i) t2_setlen(L, lane, i, 9);
-                        for (int i = 256; i < 280; ++i) t2_setlen(L, lane, i, 7);
-                        for (int i = 280; i < 288; ++i) t2_setlen(L, lane, i, 8);
-                        for (int i = 0; i < 30; ++i) t2_setlen(L, lane, 288 + i, 5);
-                        kind = 1; nlen = 288; ndist = 30;
-                    } else if (type == 2) {
-                        nlen = (int)t2_take(b, ahead, 5) + 257; ndist = (int)t2_take(b, ahead, 5) + 1;
-                        const int ncode = (int)t2_take(b, ahead, 4) + 4;
-                        if (nlen <= 286 && ndist <= 30) {
-                            for (int i = 0; i < 19; ++i) t2_setlen(L, lane, T2_CL_AT + i, 0);
-                            for (int i = 0; i < ncode; ++i) t2_setlen(L, lane, T2_CL_AT + sh_clo[i], (int)t2_take(b, ahead, 3));
-                            kind = 2;
+                    } else if (type == 1 || type == 2) {
+                        for (int l = 0; l < 16; ++l) { L.k_ll[l * 64 + lane] = 0; L.nl_ll[l * 64 + lane] = 0; }
+                        if (type == 1) {  // the fixed code of RFC 1951 3.2.6, through the same door as a dynamic one
+                            kind = 1; nlen = 288; ndist = 30;
+                            for (int i = 0; i < 144; ++i) put(8);
+                            for (int i = 144; i < 256; ++i) put(9);
+                            for (int i = 256; i < 280; ++i) put(7);
+                            for (int i = 280; i < 288; ++i) put(8);
+                            for (int i = 0; i < 30; ++i) put(5);
+                            lens_flush(lo);
+                        } else {
+                            nlen = (int)t2_take(b, ahead, 5) + 257; ndist = (int)t2_take(b, ahead, 5) + 1;
+                            ncode = (int)t2_take(b, ahead, 4) + 4;
+                            if (nlen <= 286 && ndist <= 30) kind = 2;
                         }
                     }
                 }
             }
             if (__any(me && kind == 2)) {
-                // the code-length code (19 symbols) in the distance tables, then the literal/length + distance lengths with it
+                // the code-length code (19 symbols of 3-bit lengths, in a register) in the distance tables, then the literal/length +
+                // distance lengths with it
                 const bool dyn = me && kind == 2;
-                bool ok = t2_build<false>(L, lane, dyn, T2_CL_AT, 19, lp_dd, L.sym_dd, L.k_dd);
-                int idx = 0, prev = 0;
+                unsigned long long cl_lens = 0;
+                if (dyn) {
+                    for (int l = 0; l < 16; ++l) L.k_dd[l * 64 + lane] = 0;
+                    for (int i = 0; i < ncode; ++i) { const int v = (int)t2_take(b, ahead, 3); cl_lens |= (unsigned long long)v << (3 * sh_clo[i]); if (v) ++L.k_dd[v * 64 + lane]; }
+                }
+                bool ok = t2_build<false>(L, lane, dyn, 19, (const uint16_t*)L.k_dd, [&](int i) { return (int)((cl_lens >> (3 * i)) & 7); }, lp_dd, L.sym_dd, L.k_dd);
+                int prev = 0;
                 bool busy = dyn && ok;
                 while (__any(busy)) {
                     if (busy) {
@@ -2230,25 +2276,30 @@ __global__ __launch_bounds__(128, 1) void k_inflate_tok2(const uint8_t* file, co
                         const int at = t2_slot(b, lp_dd, L.k_dd, lane, cl);
                         const int sym = at < 0 ? -1 : (int)L.sym_dd[(at & 31) * 64 + lane];
                         if (sym < 0 || sym > 18 || il_pos(b) > b.n + 8) { ok = false; busy = false; }
-                        else if (sym < 16) { t2_setlen(L, lane, idx++, sym); prev = sym; }
+                        else if (sym < 16) { put(sym); prev = sym; }
                         else {
                             int rep, v = 0;
-                            if (sym == 16) { v = prev; rep = 3 + (int)t2_take(b, ahead, 2); if (idx == 0) ok = false; }
+                            if (sym == 16) { v = prev; rep = 3 + (int)t2_take(b, ahead, 2); if (lo.n == 0) ok = false; }
                             else if (sym == 17) rep = 3 + (int)t2_take(b, ahead, 3);
                             else rep = 11 + (int)t2_take(b, ahead, 7);
-                            if (!ok || idx + rep > nlen + ndist) { ok = false; busy = false; }
-                            else { while (rep--) t2_setlen(L, lane, idx++, v); prev = v; }
+                            if (!ok || lo.n + rep > nlen + ndist) { ok = false; busy = false; }
+                            else { while (rep--) put(v); prev = v; }
                         }
-                        if (busy && idx >= nlen + ndist) busy = false;
+                        if (busy && lo.n >= nlen + ndist) busy = false;
                     }
                 }
-                if (dyn && ok && t2_getlen(L, lane, 256) == 0) ok = false;  // no end-of-block code
+                if (dyn && ok) lens_flush(lo);
+                if (dyn && ok && eob_len == 0) ok = false;  // no end-of-block code
                 if (dyn && !ok) kind = -1;
             }
             if (__any(me && kind > 0)) {
+                // the distance code first: its counts sit in nl_ll, which the literal/length build then takes for its own use
                 const bool bld = me && kind > 0;
-                const bool ok_ll = t2_build<true>(L, lane, bld, 0, nlen, lp_ll, L.sym_ll, L.k_ll);
-                const bool ok_dd = t2_build<false>(L, lane, bld, nlen, ndist, lp_dd, L.sym_dd, L.k_dd);
+                LensIn ri{lens_w, 0, 0};
+                if (bld) lens_seek(ri, lens_w, nlen);
+                const bool ok_dd = t2_build<false>(L, lane, bld, ndist, L.nl_ll, [&](int) { return lens_get(ri); }, lp_dd, L.sym_dd, L.k_dd);
+                if (bld) lens_seek(ri, lens_w, 0);
+                const bool ok_ll = t2_build<true>(L, lane, bld, nlen, (const uint16_t*)L.k_ll, [&](int) { return lens_get(ri); }, lp_ll, L.sym_ll, L.k_ll);
                 if (bld && !(ok_ll && ok_dd)) kind = -1;
             }
             if (me) { if (kind < 0) { err = true; done = true; } else if (kind > 0) in_block = true; }
@@ -2258,8 +2309,13 @@ __global__ __launch_bounds__(128, 1) void k_inflate_tok2(const uint8_t* file, co
         tick(2);
         if (done) continue;
         if (stored) {  // a slice of a stored block
-            const uint32_t k = stored_left < 16 ? stored_left : 16;
-            for (uint32_t i = 0; i < k; ++i) emit(b.p[stored_at + i]);
+            const uint32_t k = stored_left < 15 ? stored_left : 15;  // five literal tokens of three bytes
+            for (uint32_t i = 0; i < k; i += 3) {
+                const uint32_t m = k - i < 3 ? k - i : 3;
+                uint32_t t_ = m << 24;
+                for (uint32_t q = 0; q < m; ++q) t_ |= (uint32_t)b.p[stored_at + i + q] << (8 * q);
+                emit(t_);
+            }
             outpos += k; stored_at += k; stored_left -= k;
             if (!stored_left) { stored = false; il_start(b, stored_at); ahead = b.ring[0]; if (last) done = true; }
             continue;
@@ -2340,7 +2396,7 @@ __global__ __launch_bounds__(128) void k_lz_resolve2(const uint32_t* tok, const 
     __shared__ int s_bad;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const InflBlock blk = blocks[blockIdx.x];
-    const uint32_t* t = tok + (blk.uoff - out_base);
+    const uint32_t* t = tok + blk.toff;
     const int n = ntok[blockIdx.x];
     const int nr = (n + 63) / 64;  // rounds; wave w prepares and copies the rounds r with (r & 1) == w
     if (threadIdx.x == 0) { s_base[0] = 0; s_base[1] = 0; s_bad = 0; }
@@ -2627,7 +2683,7 @@ void dev_destroy(sq_ctx* c) {
     D.calib.release(); D.okey.release(); D.oval.release(); D.other64.release(); D.spine64.release(); D.okey64.release(); D.zflag.release();
     D.cl_chr.release(); D.trig.release(); D.cl_bucket.release();
     D.ord_e.release(); D.ord_o.release(); D.ord_v.release(); D.ord_me.release(); D.ord_mo.release(); D.g_i.release(); D.g_x.release(); D.g_d.release(); D.g_b.release();
-    D.pin.release(); for (auto& st : D.il_set) { st.in.release(); st.tab.release(); st.tok.release(); st.ntok.release(); st.flags.release(); if (st.ready) (void)hipEventDestroy(st.ready); if (st.freed) (void)hipEventDestroy(st.freed); if (st.copied) (void)hipEventDestroy(st.copied); st.ready = st.freed = st.copied = nullptr; }
+    D.pin.release(); for (auto& st : D.il_set) { st.in.release(); st.tab.release(); st.tok.release(); st.lens.release(); st.ntok.release(); st.flags.release(); if (st.ready) (void)hipEventDestroy(st.ready); if (st.freed) (void)hipEventDestroy(st.freed); if (st.copied) (void)hipEventDestroy(st.copied); st.ready = st.freed = st.copied = nullptr; }
     if (D.il_tok_stream) { (void)hipStreamDestroy(D.il_tok_stream); D.il_tok_stream = nullptr; }
     for (auto& q : D.il_stream) if (q) { (void)hipStreamDestroy(q); q = nullptr; }
     for (auto& ps : D.il_post) { ps.out.release(); ps.rec_sync.release(); ps.rec_end.release(); ps.rec_cnt.release(); ps.rec_base.release(); ps.flags.release(); ps.spine.release(); ps.bam_off.release(); }
@@ -3101,9 +3157,9 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     // 512 in all, so two batches fill the machine exactly; measured at C3: 512 MB 303 ms, 720 MB 238, 1 GiB 233, 1.4 GB 244, 2 GB 256
     const unsigned long long cap = std::getenv("SQUID_TOK_CAP_MB") ? (unsigned long long)std::atoll(std::getenv("SQUID_TOK_CAP_MB")) << 20 : 256ull * 64 * 65536;
     HIPCHK(hipFuncSetAttribute((const void*)k_lz_resolve2, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16));
-    HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)T2_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)T2_LDS_BYTES));
-    static const int tok_wpb = std::getenv("SQUID_TOK_WPB") ? std::max(1, std::min(2, std::atoi(std::getenv("SQUID_TOK_WPB")))) : 2;  // token waves per workgroup
+    HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (int)T2_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (int)T2_LDS_BYTES));
+    static const int tok_wpb = std::getenv("SQUID_TOK_WPB") ? std::max(1, std::min(3, std::atoi(std::getenv("SQUID_TOK_WPB")))) : 3;  // token waves per workgroup
     static const bool tok_prof = std::getenv("SQUID_TOK_PROF") != nullptr;
     if (tok_prof) HIPCHK(D.tok_prof.reserve(8 * 4096));
     for (auto& q : D.il_stream)
@@ -3184,8 +3240,10 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         // largest compressed blocks first: the lanes of a wave get blocks of similar length (a wave takes as long as its
         // longest lane) and the long waves start first
         st.host_tab.resize((size_t)nb);
-        for (int i = 0; i < nb; ++i) { const BgzfRange& b = blocks[B.at + (size_t)i]; st.host_tab[(size_t)i] = InflBlock{b.coff - B.coff0, b.clen, b.isize, b.uoff}; }
+        for (int i = 0; i < nb; ++i) { const BgzfRange& b = blocks[B.at + (size_t)i]; st.host_tab[(size_t)i] = InflBlock{b.coff - B.coff0, b.clen, b.isize, b.uoff, 0}; }
         std::stable_sort(st.host_tab.begin(), st.host_tab.end(), [](const InflBlock& x, const InflBlock& y) { return x.clen > y.clen; });
+        unsigned long long tok_slots = 0;  // token slots of the batch: half a slot per inflated byte (t2_tok_cap), block after block in table order
+        for (InflBlock& ib : st.host_tab) { ib.toff = tok_slots; tok_slots += t2_tok_cap(ib.isize); }
         if (k >= (size_t)DeviceRecords::IL_DEPTH) HIPCHK(hipStreamWaitEvent(sa, st.freed, 0));  // the resolve of batch k - IL_DEPTH has read its tokens
         const auto wa0 = std::chrono::steady_clock::now();
         // sized for a full batch at once (the first batches are small): growing a buffer later frees the old one, and freeing
@@ -3196,7 +3254,8 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         if (!dfile) HIPCHK(st.in.reserve(std::max((size_t)B.cbytes, (size_t)(cratio * 1.1 * (double)full)) + 256));  // (the input rings read up to 80 bytes ahead)
         st.src = dfile ? dfile + B.coff0 : st.in.p;
         HIPCHK(st.tab.reserve(std::max((size_t)nb, (size_t)(full / 60000)))); HIPCHK(st.flags.reserve(4));
-        HIPCHK(st.tok.reserve((size_t)full + 64)); HIPCHK(st.ntok.reserve(std::max((size_t)nb, (size_t)(full / 60000))));
+        HIPCHK(st.tok.reserve(std::max((size_t)tok_slots, (size_t)(full / 2 + 80 * (full / 60000 + 1))) + 64)); HIPCHK(st.ntok.reserve(std::max((size_t)nb, (size_t)(full / 60000))));
+        HIPCHK(st.lens.reserve((std::max((size_t)nb, (size_t)(full / 60000)) + 64) * T2_LENS_WORDS));  // (one strip of code lengths per lane of the token pass)
         const double wa1 = since_ms(wa0);
         if (!dfile) {
             // (the copy no longer travels on the set's stream: the token pass and the resolve that last read this buffer are waited for here)
@@ -3210,8 +3269,8 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         HIPCHK(hipMemsetAsync(st.flags.p, 0, 4 * 4, sa));
         {   // k_inflate_tok2 stays on the set's own stream: the token kernels of up to four batches run side by side
             EvTimer t1(c, "k_inflate_tok2", (double)B.cbytes + (double)B.bbytes * 2, sa);
-            if (tok_prof && k == 8) hipLaunchKernelGGL(k_inflate_tok2<true>, dim3((nb + 63) / 64), dim3(64), T2_LDS_BYTES, sa, st.src, st.tab.p, nb, B.bbase, st.flags.p, st.tok.p, st.ntok.p, D.tok_prof.p);
-            else hipLaunchKernelGGL(k_inflate_tok2<false>, dim3(((nb + 63) / 64 + tok_wpb - 1) / tok_wpb), dim3(64 * tok_wpb), tok_wpb * T2_LDS_BYTES, sa, st.src, st.tab.p, nb, B.bbase, st.flags.p, st.tok.p, st.ntok.p, nullptr);
+            if (tok_prof && k == 8) hipLaunchKernelGGL(k_inflate_tok2<true>, dim3((nb + 63) / 64), dim3(64), T2_LDS_BYTES, sa, st.src, st.tab.p, nb, st.flags.p, st.tok.p, st.ntok.p, st.lens.p, D.tok_prof.p);
+            else hipLaunchKernelGGL(k_inflate_tok2<false>, dim3(((nb + 63) / 64 + tok_wpb - 1) / tok_wpb), dim3(64 * tok_wpb), tok_wpb * T2_LDS_BYTES, sa, st.src, st.tab.p, nb, st.flags.p, st.tok.p, st.ntok.p, st.lens.p, nullptr);
         }
         HIPCHK(hipEventRecord(st.ready, sa));
         return SQ_OK;
