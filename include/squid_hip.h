@@ -225,6 +225,12 @@ int sq_rccl_release(sq_ctx* c);
 int sq_exchange(sq_ctx* c);
 int sq_exchange_stats(sq_ctx* c, int64_t* collectives, int64_t* bytes); /* all-gathers issued by sq_exchange so far, payload bytes received */
 
+/* utils/JunctionSequence.cpp (`junctionsequence <BEDPE> <Chim_BAM> <FA_genome> <OUTPrefix>`, :527-557): the junction sequences of the SV
+ * calls of a `_sv.txt` -- <prefix>_junc_precise.fa (calls narrowed to the bases split reads cover, with their split-read support),
+ * _junc_relax.fa (every call; exact ones widened by 1000 bases) and _junc_alt.fa (alternative junction points within 5 bases).  A
+ * consumer of the hot path's output: host work only, no context and no device needed.  On failure `errbuf` gets the detail. */
+int sq_junction_sequences(const char* bedpe_path, const char* chim_bam_path, const char* fasta_path, const char* out_prefix, char* errbuf, size_t errcap);
+
 /* Timing of the last sq_build_graph/sq_order/sq_call_sv on this context, measured with HIP events on the
  * library's own stream.  names[i] is a static string; ms[i] the accumulated duration; launches[i] the count. */
 typedef struct sq_timing {

@@ -16,6 +16,7 @@
 
 #include "o_order.h"
 #include "o_bwa.h"
+#include "o_junction.h"
 #include "o_post.h"
 
 using namespace oracle;
@@ -229,6 +230,7 @@ static int solve_order_cli(const std::string& method) {
 int main(int argc, char* argv[]) {
     if (argc >= 2 && std::string(argv[1]) == "--selftest") return solver_selftest(argc >= 3 ? std::atoi(argv[2]) : 2000);
     if (argc >= 3 && std::string(argv[1]) == "--solve-order") return solve_order_cli(argv[2]);
+    if (argc >= 6 && std::string(argv[1]) == "--junction") return oracle::junction::Run(argv[2], argv[3], argv[4], argv[5]);  // utils/JunctionSequence.cpp
     Params P;
     std::string dumpdir;
     if (argc >= 2 && std::string(argv[1]) == "--print-config") {  // same line as oracle/ref_config_driver.cpp prints for the real parser

@@ -917,6 +917,10 @@ static int chimeric_file_to_fragments(sq_ctx* c, const char* path, int nt, std::
     copy_frags(c, c->frags, c->frags0);
     return SQ_OK;
 }
+// BuildChimericSBamRecord on a context that has no device side (the junction-sequence utility): c->frags0
+}  // extern "C"
+int sq::chimeric_fragments_host(sq_ctx* c, const char* path, int threads) { return chimeric_file_to_fragments(c, path, std::max(1, threads), c->err); }
+extern "C" {
 int sq_ingest_chimeric_file(sq_ctx* c, const char* path) {
     if (!c || !path) return SQ_E_ARG;
     // (inflate and decode on a few threads: a dense sample has millions of chimeric records; the result does not depend on the count)
@@ -1009,6 +1013,20 @@ int sq_ingest_bwa_file(sq_ctx* c, const char* path, int32_t n_threads) {
     c->counts.n_concordant = (int64_t)all->size();
     c->counts.n_blocks = (int64_t)all->b_refpos.size();
     return SQ_OK;
+}
+// utils/JunctionSequence.cpp as a library call: host work only (no context, no device)
+int sq_junction_sequences(const char* bedpe_path, const char* chim_bam_path, const char* fasta_path, const char* out_prefix, char* errbuf, size_t errcap) {
+    if (!bedpe_path || !chim_bam_path || !fasta_path || !out_prefix) return SQ_E_ARG;
+    sq_ctx local;  // (never sees a device: only the host pool and the parse parameters -- the utility's own defaults, :520-524)
+    sq_default_params(&local.P);
+    local.pool.reset(new HostPool((int)std::min(15u, std::max(1u, std::thread::hardware_concurrency()) - 1)));
+    std::vector<std::string> names;
+    std::vector<int32_t> lens;
+    int rc = read_bam_header(chim_bam_path, names, lens, local.err);
+    if (!rc) { local.ref_len = lens; rc = chimeric_fragments_host(&local, chim_bam_path, 8); }
+    if (!rc) rc = junction_sequences(&local, names, bedpe_path, fasta_path, out_prefix);
+    if (rc && errbuf && errcap) { std::strncpy(errbuf, local.err.c_str(), errcap - 1); errbuf[errcap - 1] = 0; }
+    return rc;
 }
 int sq_stage_bam(sq_ctx* c, const char* path) {
     if (!c || !path) return SQ_E_ARG;

@@ -307,6 +307,9 @@ bool edge_discordant(const sq_ctx* c, const std::vector<Node>& N, const Edge& e)
 int locate_fragment(const std::vector<Node>& N, int hint, Frag& f, std::vector<int>& out);  // trims f in place
 int chimeric_edges(sq_ctx* c, std::vector<Edge>& raw);
 bool pair_overlap(const Frag& f, const std::vector<int>& rn, int i, int j);  // the pair-edge suppression test of :1484-1502 / :1801-1819
+// ---- sq_junction.cpp (utils/JunctionSequence.cpp)
+int chimeric_fragments_host(sq_ctx* c, const char* path, int threads);
+int junction_sequences(sq_ctx* c, const std::vector<std::string>& ref_names, const char* bedpe, const char* fasta, const char* out_prefix);
 // ---- sq_bwa.cpp (`squid --bwa`)
 int bwa_nodes_and_edges(sq_ctx* c, std::vector<Edge>& raw);  // BuildNode_BWA + RawEdges over the host batch: c->nodes (+ snapshot 1), c->frags, raw edges
 int bwa_breakpoint_support(sq_ctx* c, const std::vector<std::pair<int, int>>& bps, std::vector<int32_t>& cov);

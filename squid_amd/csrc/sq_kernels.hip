@@ -2825,6 +2825,8 @@ struct FileFeeder {
     bool walk_bad = false;
     std::string what;
     double t_setup_ms = 0;
+    std::chrono::steady_clock::time_point t_start;
+    std::unique_ptr<std::atomic<float>[]> t_issued;  // per piece: milliseconds after start() at which its copy was queued (SQUID_INGEST_TIMING)
 
     FileFeeder(sq_ctx* c_) : c(c_), D(*c_->dev) {}
     ~FileFeeder() { finish(); if (fd >= 0) ::close(fd); }
@@ -2848,7 +2850,8 @@ struct FileFeeder {
         HIPCHK(hipMemsetAsync(D.stream_file.p + (hi - lo), 0, 512, c->stream));  // (the input rings of the token pass read up to 80 bytes ahead)
         while (D.feed_piece_ev.size() < npieces) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); D.feed_piece_ev.push_back(e); }
         issued.reset(new std::atomic<uint8_t>[npieces]);
-        for (size_t j = 0; j < npieces; ++j) issued[j].store(0, std::memory_order_relaxed);
+        t_issued.reset(new std::atomic<float>[npieces]);
+        for (size_t j = 0; j < npieces; ++j) { issued[j].store(0, std::memory_order_relaxed); t_issued[j].store(0.f, std::memory_order_relaxed); }
         walk = do_walk; stop = walk_stop;
         in_state.assign(npieces + 1, WalkState{}); state_ready.assign(npieces + 1, 0); walked.assign(npieces, 0); found.assign(npieces, {});
         if (walk) {
@@ -2859,6 +2862,7 @@ struct FileFeeder {
             end_state = in_state[first_walk_piece];
         }
         t_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        t_start = std::chrono::steady_clock::now();
         for (int t = 0; t < T; ++t) th.emplace_back([this, t]() { work(t); });
         return SQ_OK;
     }
@@ -2884,6 +2888,7 @@ struct FileFeeder {
             if (got < want) { fail_with("cannot read the bamfile"); break; }
             if (hipMemcpyAsync(D.stream_file.p + (off - lo), buf, len, hipMemcpyHostToDevice, D.feed_stream[t]) != hipSuccess || hipEventRecord(D.feed_piece_ev[j], D.feed_stream[t]) != hipSuccess ||
                 hipEventRecord(D.feed_buf_ev[t][b], D.feed_stream[t]) != hipSuccess) { fail_with("host to device copy of the file bytes failed"); break; }
+            t_issued[j].store(std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_start).count(), std::memory_order_relaxed);
             issued[j].store(1, std::memory_order_release);
             used[b] = true;
             if (walk && j >= first_walk_piece) {
@@ -3400,6 +3405,11 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         { const int rc = helper.get(); if (rc) return rc; }
         feed->finish();
         if (feed->failed.load()) return fail(c, SQ_E_IO, feed->error());
+        if (report) {
+            const size_t np = feed->npieces;
+            std::fprintf(stderr, "GPU ingest: file pieces queued for copy (ms after the feeder started): #0 %.1f, #15 %.1f, #40 %.1f, #%zu %.1f, last %.1f\n", feed->t_issued[0].load(), feed->t_issued[std::min<size_t>(15, np - 1)].load(),
+                         feed->t_issued[std::min<size_t>(40, np - 1)].load(), np / 2, feed->t_issued[np / 2].load(), feed->t_issued[np - 1].load());
+        }
         src->streamed = true;
         if (feed->walk) { std::lock_guard<std::mutex> lk(feed->mu); src->walk_p = feed->end_state.p; src->walk_total = feed->end_state.total; src->bad = feed->walk_bad; }
     }

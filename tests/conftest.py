@@ -16,7 +16,7 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def built():
     """Native artefacts (generator, oracle, library); built on demand so that a fresh checkout works."""
-    need = [BUILD / "gen_synth_bam", BUILD / "squid_oracle", BUILD / "libsquid_hip.so", BUILD / "squid"]
+    need = [BUILD / "gen_synth_bam", BUILD / "squid_oracle", BUILD / "libsquid_hip.so", BUILD / "squid", BUILD / "squid_junction"]
     if not all(p.exists() for p in need):
         subprocess.check_call(["make", "-C", str(ROOT), "-j4", "all"])
     return BUILD
