@@ -2144,7 +2144,7 @@ __device__ __forceinline__ uint32_t t2_take(ILane& b, uint32_t& ahead, int k) {
     return v;
 }
 template <bool PROF>
-__global__ __launch_bounds__(192, 1) void k_inflate_tok2(const uint8_t* file, const InflBlock* blocks, int nblocks, int32_t* flags, uint32_t* tok, int32_t* ntok, uint32_t* lens_strips,
+__global__ __launch_bounds__(320, 1) void k_inflate_tok2(const uint8_t* file, const InflBlock* blocks, int nblocks, int32_t* flags, uint32_t* tok, int32_t* ntok, uint32_t* lens_strips,
                                                     unsigned long long* prof) {
     // One to three waves per workgroup, each with its own T2_LDS_BYTES and its own 64 blocks; they never talk to each other.  Three
     // waves make a workgroup of 93 KB: a CU takes one of them and no second -- three token waves per CU, on three of its SIMDs, and
@@ -2803,33 +2803,33 @@ static int h2d_parallel(sq_ctx* c, uint8_t* dst, const uint8_t* src, size_t n) {
 // batch one blocking copy by four threads in front of the batch's token pass -- 390 ms per C3 step where the same step from a
 // copy already in HBM takes 256.
 struct FileFeeder {
-    static constexpr size_t P = (size_t)8 << 20, OVER = 65536 + 64;  // a piece, and how far a block that starts in it can reach into the next
+    const size_t P = std::getenv("SQUID_FEED_PIECE_MB") ? (size_t)std::max(1, std::atoi(std::getenv("SQUID_FEED_PIECE_MB"))) << 20 : (size_t)8 << 20;  // a piece
     sq_ctx* c;
     DeviceRecords& D;
     int fd = -1, T = 0;
     size_t file_n = 0, lo = 0, hi = 0, npieces = 0;
     std::vector<std::thread> th;
+    std::thread walker;
     std::atomic<size_t> next{0};
     std::atomic<bool> abort{false}, failed{false};
     std::unique_ptr<std::atomic<uint8_t>[]> issued;  // per piece: its copy is queued and its event recorded
     struct WalkState { size_t p = 0, total = 0; bool done = false; };
     bool walk = false;
-    size_t first_walk_piece = 0, stop = (size_t)-1;
+    size_t stop = (size_t)-1;
     std::mutex mu;
     std::condition_variable cv;
-    std::vector<WalkState> in_state;          // (mu) state in front of a piece
-    std::vector<uint8_t> state_ready, walked; // (mu)
-    std::vector<std::vector<BgzfRange>> found;  // (mu) blocks whose header lies in the piece
-    size_t handed = 0;                        // pieces whose blocks more() has passed on
+    std::vector<BgzfRange> found;             // (mu) blocks walked and not yet passed on
+    bool walk_over = false;                   // (mu)
     WalkState end_state;                      // (mu) where the walk ended
     bool walk_bad = false;
     std::string what;
-    double t_setup_ms = 0;
+    double t_setup_ms = 0, walk_ms = 0;
     std::chrono::steady_clock::time_point t_start;
     std::unique_ptr<std::atomic<float>[]> t_issued;  // per piece: milliseconds after start() at which its copy was queued (SQUID_INGEST_TIMING)
+    std::atomic<long long> us_pread{0}, us_bufwait{0};  // summed over the threads (SQUID_INGEST_TIMING)
 
     FileFeeder(sq_ctx* c_) : c(c_), D(*c_->dev) {}
-    ~FileFeeder() { finish(); if (fd >= 0) ::close(fd); }
+    ~FileFeeder() { cancel(); if (fd >= 0) ::close(fd); }
     const uint8_t* dfile() const { return D.stream_file.p - lo; }  // "device address of file offset 0" (only offsets in [lo, hi) exist)
 
     int start(const char* path, size_t from, size_t upto, bool do_walk, size_t walk_p, size_t walk_total, size_t walk_stop) {
@@ -2853,102 +2853,106 @@ struct FileFeeder {
         t_issued.reset(new std::atomic<float>[npieces]);
         for (size_t j = 0; j < npieces; ++j) { issued[j].store(0, std::memory_order_relaxed); t_issued[j].store(0.f, std::memory_order_relaxed); }
         walk = do_walk; stop = walk_stop;
-        in_state.assign(npieces + 1, WalkState{}); state_ready.assign(npieces + 1, 0); walked.assign(npieces, 0); found.assign(npieces, {});
-        if (walk) {
-            if (walk_p < lo) return fail(c, SQ_E_ARG, "internal: header walk starts in front of the streamed range");
-            first_walk_piece = std::min(npieces, (walk_p - lo) / P);
-            in_state[first_walk_piece] = WalkState{walk_p, walk_total, walk_p + 18 > file_n || walk_p > stop};
-            state_ready[first_walk_piece] = 1;
-            end_state = in_state[first_walk_piece];
-        }
+        end_state = WalkState{walk_p, walk_total, false};
+        walk_over = !walk;
         t_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         t_start = std::chrono::steady_clock::now();
+        if (walk) walker = std::thread([this]() { walk_headers(); });
         for (int t = 0; t < T; ++t) th.emplace_back([this, t]() { work(t); });
         return SQ_OK;
     }
     void fail_with(const char* msg) { { std::lock_guard<std::mutex> lk(mu); if (what.empty()) what = msg; } failed = true; cv.notify_all(); }
+    // The BGZF block headers, on a thread of its own: one small pread per block -- the 4 bytes in front of a header are the inflated size
+    // of the block before, so one read yields both -- 1.8 M blocks a second, ahead of any copy.  (The first form of this walked the
+    // headers inside the copy threads' buffers, piece after piece: where a piece's first header lies is known once the piece before has
+    // been walked, and that chain put all sixteen threads in lockstep with whichever of them was waiting for a free buffer.)
+    void walk_headers() {
+        const auto t0 = std::chrono::steady_clock::now();
+        WalkState w = end_state;
+        std::vector<BgzfRange> batch;
+        bool have_prev = false, bad = false;
+        BgzfRange prev{};
+        auto publish = [&](bool over) {
+            std::lock_guard<std::mutex> lk(mu);
+            found.insert(found.end(), batch.begin(), batch.end());
+            batch.clear();
+            end_state = w;
+            if (over) { walk_over = true; walk_bad = bad; }
+        };
+        uint8_t h[64];
+        for (;;) {
+            if (abort.load() || failed.load()) { publish(true); break; }
+            const bool more = !bad && w.p + 18 <= file_n && w.p <= stop;
+            const size_t at = have_prev ? w.p - 4 : w.p, need = (more ? 18 : 0) + (have_prev ? 4 : 0);
+            ssize_t got = 0;
+            if (need) { got = ::pread(fd, h, std::min<size_t>(sizeof h, file_n - at), (off_t)at); if (got < (ssize_t)need) { fail_with("cannot read the bamfile"); publish(true); break; } }
+            const uint8_t* d = h + (have_prev ? 4 : 0);
+            if (have_prev) { std::memcpy(&prev.isize, h, 4); prev.uoff = w.total; w.total += prev.isize; batch.push_back(prev); have_prev = false; }
+            if (!more) { w.done = true; publish(true); break; }
+            if (d[0] != 0x1f || d[1] != 0x8b || !(d[3] & 4)) { bad = true; continue; }
+            const uint32_t xlen = d[10] | (d[11] << 8);
+            int bsize = -1;
+            std::vector<uint8_t> extra;
+            const uint8_t* x = d + 12;
+            if (12 + (size_t)xlen > (size_t)got - (size_t)(d - h)) {  // (an extra field longer than the usual six bytes: fetch it whole)
+                extra.resize(xlen);
+                if (::pread(fd, extra.data(), xlen, (off_t)(w.p + 12)) != (ssize_t)xlen) { bad = true; continue; }
+                x = extra.data();
+            }
+            for (size_t o = 0; o + 4 <= xlen;) {
+                const uint32_t slen = x[o + 2] | (x[o + 3] << 8);
+                if (x[o] == 'B' && x[o + 1] == 'C' && slen == 2 && o + 6 <= xlen) bsize = (x[o + 4] | (x[o + 5] << 8)) + 1;
+                o += 4 + slen;
+            }
+            if (bsize < (int)(12 + xlen + 8) || w.p + (size_t)bsize > file_n) { bad = true; continue; }
+            prev.coff = w.p + 12 + xlen; prev.clen = (uint32_t)(bsize - 12 - (int)xlen - 8);
+            have_prev = true;
+            w.p += (size_t)bsize;
+            if (batch.size() >= 512) { publish(false); cv.notify_all(); }
+        }
+        cv.notify_all();
+        walk_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
     void work(int t) {
         if (hipSetDevice(c->P.device) != hipSuccess) { fail_with("hipSetDevice"); return; }
         // the thread's own stream and its two page-locked buffers (kept by the context: the next read finds them)
         if (!D.feed_stream[t] && hipStreamCreateWithFlags(&D.feed_stream[t], hipStreamNonBlocking) != hipSuccess) { fail_with("hipStreamCreate"); return; }
         for (int b = 0; b < 2; ++b) {
-            if (!D.feed_pin[t][b] && hipHostMalloc((void**)&D.feed_pin[t][b], P + OVER, hipHostMallocDefault) != hipSuccess) { fail_with("hipHostMalloc"); return; }
+            if (!D.feed_pin[t][b] && hipHostMalloc((void**)&D.feed_pin[t][b], P, hipHostMallocDefault) != hipSuccess) { fail_with("hipHostMalloc"); return; }
             if (!D.feed_buf_ev[t][b] && hipEventCreateWithFlags(&D.feed_buf_ev[t][b], hipEventDisableTiming) != hipSuccess) { fail_with("hipEventCreate"); return; }
         }
         bool used[2] = {false, false};
         int b = 0;
+        auto tick = [](std::chrono::steady_clock::time_point& t0) { const auto now = std::chrono::steady_clock::now(); const long long us = std::chrono::duration_cast<std::chrono::microseconds>(now - t0).count(); t0 = now; return us; };
         for (;;) {
             const size_t j = next.fetch_add(1);
             if (j >= npieces || abort.load() || failed.load()) break;
-            const size_t off = lo + j * P, len = std::min(P, hi - off), want = std::min(P + OVER, file_n - off);
+            const size_t off = lo + j * P, len = std::min(P, hi - off);
             uint8_t* buf = D.feed_pin[t][b];
+            auto tk = std::chrono::steady_clock::now();
             if (used[b] && hipEventSynchronize(D.feed_buf_ev[t][b]) != hipSuccess) { fail_with("hipEventSynchronize"); break; }
+            us_bufwait += tick(tk);
             size_t got = 0;
-            while (got < want) { const ssize_t r = ::pread(fd, buf + got, want - got, (off_t)(off + got)); if (r <= 0) break; got += (size_t)r; }
-            if (got < want) { fail_with("cannot read the bamfile"); break; }
+            while (got < len) { const ssize_t r = ::pread(fd, buf + got, len - got, (off_t)(off + got)); if (r <= 0) break; got += (size_t)r; }
+            us_pread += tick(tk);
+            if (got < len) { fail_with("cannot read the bamfile"); break; }
             if (hipMemcpyAsync(D.stream_file.p + (off - lo), buf, len, hipMemcpyHostToDevice, D.feed_stream[t]) != hipSuccess || hipEventRecord(D.feed_piece_ev[j], D.feed_stream[t]) != hipSuccess ||
                 hipEventRecord(D.feed_buf_ev[t][b], D.feed_stream[t]) != hipSuccess) { fail_with("host to device copy of the file bytes failed"); break; }
             t_issued[j].store(std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_start).count(), std::memory_order_relaxed);
             issued[j].store(1, std::memory_order_release);
             used[b] = true;
-            if (walk && j >= first_walk_piece) {
-                WalkState w;
-                {
-                    std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&]() { return state_ready[j] || abort.load() || failed.load(); });
-                    if (!state_ready[j]) break;
-                    w = in_state[j];
-                }
-                std::vector<BgzfRange> mine;
-                bool bad_here = false;
-                while (!w.done && w.p < off + P) {
-                    if (w.p + 18 > file_n || w.p > stop) { w.done = true; break; }
-                    const uint8_t* d = buf + (w.p - off);  // (w.p - off < P and a block is at most 64 KiB: inside the OVER bytes behind the piece)
-                    if (d[0] != 0x1f || d[1] != 0x8b || !(d[3] & 4)) { bad_here = true; break; }
-                    const uint32_t xlen = d[10] | (d[11] << 8);
-                    int bsize = -1;
-                    for (size_t o = 12; o + 4 <= 12 + (size_t)xlen && w.p + o + 6 <= file_n && o + 6 <= OVER;) {
-                        const uint32_t slen = d[o + 2] | (d[o + 3] << 8);
-                        if (d[o] == 'B' && d[o + 1] == 'C' && slen == 2) bsize = (d[o + 4] | (d[o + 5] << 8)) + 1;
-                        o += 4 + slen;
-                    }
-                    if (bsize < (int)(12 + xlen + 8) || w.p + (size_t)bsize > file_n) { bad_here = true; break; }
-                    BgzfRange r;
-                    r.coff = w.p + 12 + xlen; r.clen = (uint32_t)(bsize - 12 - (int)xlen - 8);
-                    std::memcpy(&r.isize, d + bsize - 4, 4);
-                    r.uoff = w.total;
-                    w.total += r.isize;
-                    mine.push_back(r);
-                    w.p += (size_t)bsize;
-                }
-                if (!w.done && !bad_here && (w.p + 18 > file_n || w.p > stop)) w.done = true;
-                {
-                    std::lock_guard<std::mutex> lk(mu);
-                    found[j].swap(mine);
-                    walked[j] = 1;
-                    if (bad_here) { walk_bad = true; w.done = true; }
-                    in_state[j + 1] = w; state_ready[j + 1] = 1;
-                    end_state = w;
-                }
-                cv.notify_all();
-            } else if (walk) { std::lock_guard<std::mutex> lk(mu); walked[j] = 1; cv.notify_all(); }
             b ^= 1;
         }
         (void)hipStreamSynchronize(D.feed_stream[t]);
     }
-    // the IndexMore of a streamed read: the blocks of the next walked piece(s); false when the walk is over and everything has been passed on
+    // the IndexMore of a streamed read: the blocks walked since the last call; false when the walk is over and everything has been passed on
     bool more(std::vector<BgzfRange>& v) {
         std::unique_lock<std::mutex> lk(mu);
-        while (handed < npieces) {
-            cv.wait(lk, [&]() { return walked[handed] || failed.load() || abort.load(); });
-            if (!walked[handed]) return false;
-            const bool any = !found[handed].empty();
-            v.insert(v.end(), found[handed].begin(), found[handed].end());
-            std::vector<BgzfRange>().swap(found[handed]);
-            ++handed;
-            if (any) return true;
-        }
-        return false;
+        cv.wait(lk, [&]() { return !found.empty() || walk_over || failed.load() || abort.load(); });
+        if (found.empty()) return false;
+        v.insert(v.end(), found.begin(), found.end());
+        found.clear();
+        return true;
     }
     // the file bytes [from, to) must have arrived before anything queued on `s` after this call runs
     int wait_bytes(size_t from, size_t to, hipStream_t s) {
@@ -2964,9 +2968,10 @@ struct FileFeeder {
         return SQ_OK;
     }
     std::string error() { std::lock_guard<std::mutex> lk(mu); return what.empty() ? std::string("the read of the bamfile was given up") : what; }
-    void finish() {  // (idempotent) every piece copied or the threads told to stop
+    void finish() {  // (idempotent) every piece copied and the walk over, or the threads told to stop
         for (auto& x : th) if (x.joinable()) x.join();
         th.clear();
+        if (walker.joinable()) walker.join();
     }
     void cancel() { abort = true; cv.notify_all(); finish(); }
 };
@@ -3162,9 +3167,11 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     // 512 in all, so two batches fill the machine exactly; measured at C3: 512 MB 303 ms, 720 MB 238, 1 GiB 233, 1.4 GB 244, 2 GB 256
     const unsigned long long cap = std::getenv("SQUID_TOK_CAP_MB") ? (unsigned long long)std::atoll(std::getenv("SQUID_TOK_CAP_MB")) << 20 : 256ull * 64 * 65536;
     HIPCHK(hipFuncSetAttribute((const void*)k_lz_resolve2, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16));
-    HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (int)T2_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (int)T2_LDS_BYTES));
-    static const int tok_wpb = std::getenv("SQUID_TOK_WPB") ? std::max(1, std::min(3, std::atoi(std::getenv("SQUID_TOK_WPB")))) : 3;  // token waves per workgroup
+    HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * (int)T2_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * (int)T2_LDS_BYTES));
+    // token waves per workgroup: 3 (93 KB) leave the 64 KB slot of a resolve workgroup free on every CU; 4 or 5 take the whole CU and the
+    // resolve workgroups -- on a stream of higher priority -- get the CUs that token workgroups leave (SQUID_TOK_WPB, measured in DESIGN.md)
+    static const int tok_wpb = std::getenv("SQUID_TOK_WPB") ? std::max(1, std::min(5, std::atoi(std::getenv("SQUID_TOK_WPB")))) : 3;
     static const bool tok_prof = std::getenv("SQUID_TOK_PROF") != nullptr;
     if (tok_prof) HIPCHK(D.tok_prof.reserve(8 * 4096));
     for (auto& q : D.il_stream)
@@ -3407,6 +3414,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         if (feed->failed.load()) return fail(c, SQ_E_IO, feed->error());
         if (report) {
             const size_t np = feed->npieces;
+            std::fprintf(stderr, "GPU ingest: copy threads together: pread %.1f ms, waiting for a free buffer %.1f ms; header walk %.1f ms on its own thread\n", feed->us_pread.load() * 1e-3, feed->us_bufwait.load() * 1e-3, feed->walk_ms);
             std::fprintf(stderr, "GPU ingest: file pieces queued for copy (ms after the feeder started): #0 %.1f, #15 %.1f, #40 %.1f, #%zu %.1f, last %.1f\n", feed->t_issued[0].load(), feed->t_issued[std::min<size_t>(15, np - 1)].load(),
                          feed->t_issued[std::min<size_t>(40, np - 1)].load(), np / 2, feed->t_issued[np / 2].load(), feed->t_issued[np - 1].load());
         }

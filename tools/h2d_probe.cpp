@@ -20,6 +20,14 @@ using clk = std::chrono::steady_clock;
 static double ms(clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); }
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1); } } while (0)
 
+// keeps every CU busy with a workgroup that holds 96 KB of LDS and spins on it (the shape of the token pass), for about `spin` rounds
+__global__ void k_busy(unsigned long long spin, unsigned* sink) {
+    extern __shared__ unsigned lds[];
+    unsigned x = threadIdx.x;
+    for (unsigned long long i = 0; i < spin; ++i) { lds[(x * 17 + i) & 16383] = x; x = x * 1664525u + lds[(x >> 7) & 16383]; }
+    if (x == 0x12345678u) *sink = x;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) return 2;
     auto t0 = clk::now();
@@ -51,9 +59,16 @@ int main(int argc, char** argv) {
     }
     uint8_t* dst = nullptr;
     CHK(hipMalloc((void**)&dst, n + 4096));
-    const size_t P = (size_t)8 << 20;
-    for (int mode = 0; mode < 2; ++mode) {  // 0: pread, 1: memcpy from a fresh mapping (faults included)
+    unsigned* sink = nullptr;
+    CHK(hipMalloc((void**)&sink, 4));
+    CHK(hipFuncSetAttribute((const void*)k_busy, hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10));
+    hipStream_t busy_stream;
+    CHK(hipStreamCreateWithFlags(&busy_stream, hipStreamNonBlocking));
+    for (int mode = 0; mode < 4; ++mode) {  // 0: pread, 1: memcpy from a fresh mapping (faults included), 2: pread beside a kernel that fills every CU, 3: the same with 32 MiB pieces
+        const size_t P = (size_t)(mode == 3 ? 32 : 8) << 20;
         for (int T : {4, 8, 16, 32}) {
+            if (mode >= 2 && T != 16) continue;
+            if (mode >= 2) hipLaunchKernelGGL(k_busy, dim3(256), dim3(192), 96 << 10, busy_stream, 3000000ull, sink);
             const uint8_t* map = nullptr;
             if (mode == 1) map = (const uint8_t*)mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
             std::vector<uint8_t*> pin((size_t)2 * T);
@@ -77,7 +92,7 @@ int main(int argc, char** argv) {
                         if (off >= n) break;
                         const size_t len = std::min(P, n - off);
                         if (used[b]) (void)hipEventSynchronize(ev[(size_t)2 * t + b]);
-                        if (mode == 0) { size_t got = 0; while (got < len) { ssize_t r = pread(fd, pin[(size_t)2 * t + b] + got, len - got, (off_t)(off + got)); if (r <= 0) break; got += (size_t)r; } }
+                        if (mode != 1) { size_t got = 0; while (got < len) { ssize_t r = pread(fd, pin[(size_t)2 * t + b] + got, len - got, (off_t)(off + got)); if (r <= 0) break; got += (size_t)r; } }
                         else std::memcpy(pin[(size_t)2 * t + b], map + off, len);
                         (void)hipMemcpyAsync(dst + off, pin[(size_t)2 * t + b], len, hipMemcpyHostToDevice, sq[(size_t)t]);
                         (void)hipEventRecord(ev[(size_t)2 * t + b], sq[(size_t)t]);
@@ -87,7 +102,9 @@ int main(int argc, char** argv) {
                 });
             for (auto& x : th) x.join();
             const double w = ms(a);
-            std::printf("%s, %2d threads: %.1f ms = %.1f GB/s (setup of buffers/streams/events %.1f ms)\n", mode ? "memcpy from fresh mmap" : "pread", T, w, (double)n / w / 1e6, setup);
+            const char* what[4] = {"pread", "memcpy from fresh mmap", "pread beside a busy kernel", "pread beside a busy kernel, 32 MiB pieces"};
+            std::printf("%s, %2d threads: %.1f ms = %.1f GB/s (setup of buffers/streams/events %.1f ms)\n", what[mode], T, w, (double)n / w / 1e6, setup);
+            if (mode >= 2) { auto b0 = clk::now(); CHK(hipStreamSynchronize(busy_stream)); std::printf("  (the busy kernel ran %.1f ms longer)\n", ms(b0)); }
             for (auto& p : pin) CHK(hipHostFree(p));
             for (auto& s : sq) CHK(hipStreamDestroy(s));
             for (auto& e : ev) CHK(hipEventDestroy(e));
