@@ -139,6 +139,41 @@ struct Pinned {
 struct TilePart { unsigned long long ob; long long mx; int cnt, first; };  // of 1024 tiles: kept records, running pair, largest key, first tile with a kept record
 struct SumItem { int64_t rec_base; int32_t rank_base, lo, hi; int64_t dst; };
 
+// Threads that live as long as the context and run one job at a time, job(t) on thread t = 0 .. count-1 (FileFeeder's copy threads and
+// its header walker).  A thread's first HIP call sets up per-thread state inside the runtime, a few milliseconds each and one after
+// the other: sixteen fresh threads per ingest had the last of them queue its first piece 30-50 ms after the first (measured), and the
+// token pass of the second batch waited for exactly that piece.
+struct FeedPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv, done_cv;
+    std::function<void(int)> job;
+    int generation = 0, count = 0, running = 0;
+    bool stop = false;
+    explicit FeedPool(int n) {
+        for (int t = 0; t < n; ++t) th.emplace_back([this, t]() {
+            int seen = 0;
+            for (;;) {
+                std::function<void(int)> f;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&]() { return stop || generation != seen; });
+                    if (stop) return;
+                    seen = generation;
+                    if (t >= count) continue;
+                    f = job;
+                }
+                f(t);
+                { std::lock_guard<std::mutex> lk(mu); if (--running == 0) done_cv.notify_all(); }
+            }
+        });
+    }
+    ~FeedPool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (auto& t : th) t.join(); }
+    int size() const { return (int)th.size(); }
+    void start(int n, std::function<void(int)> f) { { std::lock_guard<std::mutex> lk(mu); job = std::move(f); count = std::min(n, size()); running = count; ++generation; } cv.notify_all(); }
+    void wait() { std::unique_lock<std::mutex> lk(mu); done_cv.wait(lk, [&]() { return running == 0; }); }
+};
+
 struct DeviceRecords {
     int64_t n = 0, nb = 0;
     Pinned pin;
@@ -194,6 +229,7 @@ struct DeviceRecords {
     hipStream_t feed_stream[FEED_THREADS_MAX] = {};
     hipEvent_t feed_buf_ev[FEED_THREADS_MAX][2] = {};
     std::vector<hipEvent_t> feed_piece_ev;
+    std::unique_ptr<FeedPool> feed_pool;  // FEED_THREADS_MAX copy threads + the header walker
     uint8_t* h2d_pin[H2D_THREADS][2] = {};
     hipStream_t h2d_stream[H2D_THREADS] = {};
     hipEvent_t h2d_ev[H2D_THREADS][2] = {};
@@ -2694,6 +2730,7 @@ void dev_destroy(sq_ctx* c) {
         if (D.h2d_stream[t]) (void)hipStreamDestroy(D.h2d_stream[t]);
         D.h2d_stream[t] = nullptr;
     }
+    D.feed_pool.reset();
     for (int t = 0; t < DeviceRecords::FEED_THREADS_MAX; ++t) {
         for (int b = 0; b < 2; ++b) { if (D.feed_pin[t][b]) (void)hipHostFree(D.feed_pin[t][b]); D.feed_pin[t][b] = nullptr; if (D.feed_buf_ev[t][b]) (void)hipEventDestroy(D.feed_buf_ev[t][b]); D.feed_buf_ev[t][b] = nullptr; }
         if (D.feed_stream[t]) (void)hipStreamDestroy(D.feed_stream[t]);
@@ -2808,8 +2845,7 @@ struct FileFeeder {
     DeviceRecords& D;
     int fd = -1, T = 0;
     size_t file_n = 0, lo = 0, hi = 0, npieces = 0;
-    std::vector<std::thread> th;
-    std::thread walker;
+    bool started = false;
     std::atomic<size_t> next{0};
     std::atomic<bool> abort{false}, failed{false};
     std::unique_ptr<std::atomic<uint8_t>[]> issued;  // per piece: its copy is queued and its event recorded
@@ -2845,6 +2881,7 @@ struct FileFeeder {
         static const int env_t = std::getenv("SQUID_FEED_THREADS") ? std::atoi(std::getenv("SQUID_FEED_THREADS")) : 0;
         T = env_t > 0 ? env_t : (int)std::thread::hardware_concurrency() / 4;
         T = std::max(2, std::min({T, 16, (int)DeviceRecords::FEED_THREADS_MAX, (int)npieces}));
+        if (env_t > 0) T = std::max(1, std::min({env_t, (int)DeviceRecords::FEED_THREADS_MAX, (int)npieces}));
         if (npieces < 2) T = 1;
         HIPCHK(D.stream_file.reserve(hi - lo + 512));
         HIPCHK(hipMemsetAsync(D.stream_file.p + (hi - lo), 0, 512, c->stream));  // (the input rings of the token pass read up to 80 bytes ahead)
@@ -2857,11 +2894,15 @@ struct FileFeeder {
         walk_over = !walk;
         t_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         t_start = std::chrono::steady_clock::now();
-        if (walk) walker = std::thread([this]() { walk_headers(); });
-        for (int t = 0; t < T; ++t) th.emplace_back([this, t]() { work(t); });
+        bufs.assign((size_t)std::min(2 * T, 2 * (int)DeviceRecords::FEED_THREADS_MAX), Buf{});  // page-locked buffers, two per reader: made by the issuer thread as it starts
+        if (!D.feed_pool) D.feed_pool.reset(new FeedPool(DeviceRecords::FEED_THREADS_MAX + 2));
+        started = true;
+        // threads 0 .. T-1 read, thread T queues the copies, thread T + 1 walks the headers
+        D.feed_pool->start(T + 1 + (walk ? 1 : 0), [this](int t) { if (t == T) issue(); else if (t == T + 1) walk_headers(); else work(t); });
         return SQ_OK;
     }
     void fail_with(const char* msg) { { std::lock_guard<std::mutex> lk(mu); if (what.empty()) what = msg; } failed = true; cv.notify_all(); }
+    void wake_all() { cv.notify_all(); bcv.notify_all(); }
     // The BGZF block headers, on a thread of its own: one small pread per block -- the 4 bytes in front of a header are the inflated size
     // of the block before, so one read yields both -- 1.8 M blocks a second, ahead of any copy.  (The first form of this walked the
     // headers inside the copy threads' buffers, piece after piece: where a piece's first header lies is known once the piece before has
@@ -2913,37 +2954,85 @@ struct FileFeeder {
         cv.notify_all();
         walk_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
-    void work(int t) {
-        if (hipSetDevice(c->P.device) != hipSuccess) { fail_with("hipSetDevice"); return; }
-        // the thread's own stream and its two page-locked buffers (kept by the context: the next read finds them)
-        if (!D.feed_stream[t] && hipStreamCreateWithFlags(&D.feed_stream[t], hipStreamNonBlocking) != hipSuccess) { fail_with("hipStreamCreate"); return; }
-        for (int b = 0; b < 2; ++b) {
-            if (!D.feed_pin[t][b] && hipHostMalloc((void**)&D.feed_pin[t][b], P, hipHostMallocDefault) != hipSuccess) { fail_with("hipHostMalloc"); return; }
-            if (!D.feed_buf_ev[t][b] && hipEventCreateWithFlags(&D.feed_buf_ev[t][b], hipEventDisableTiming) != hipSuccess) { fail_with("hipEventCreate"); return; }
-        }
-        bool used[2] = {false, false};
-        int b = 0;
+    // ---- copy: reader threads only pread() into page-locked buffers; ONE thread talks to the HIP runtime (queues the copies, records the
+    // events, polls for finished ones).  With sixteen threads each queueing copies and blocking in hipEventSynchronize for a free buffer,
+    // the thread that launches the kernels found the runtime's locks taken most of the time: the first batches were queued 80-120 ms
+    // into the ingest although their bytes had long arrived (measured), and the whole pipeline ran a third slower than from HBM.
+    struct Buf { uint8_t* p = nullptr; size_t piece = 0; };
+    std::vector<Buf> bufs;
+    std::mutex bmu;
+    std::condition_variable bcv;
+    std::vector<int> free_bufs, filled_bufs;   // (bmu) indices into bufs
+    size_t pieces_issued = 0;                  // (issuer only)
+    void work(int t) {  // a reader
         auto tick = [](std::chrono::steady_clock::time_point& t0) { const auto now = std::chrono::steady_clock::now(); const long long us = std::chrono::duration_cast<std::chrono::microseconds>(now - t0).count(); t0 = now; return us; };
+        (void)t;
         for (;;) {
             const size_t j = next.fetch_add(1);
             if (j >= npieces || abort.load() || failed.load()) break;
             const size_t off = lo + j * P, len = std::min(P, hi - off);
-            uint8_t* buf = D.feed_pin[t][b];
             auto tk = std::chrono::steady_clock::now();
-            if (used[b] && hipEventSynchronize(D.feed_buf_ev[t][b]) != hipSuccess) { fail_with("hipEventSynchronize"); break; }
+            int bi = -1;
+            {
+                std::unique_lock<std::mutex> lk(bmu);
+                bcv.wait(lk, [&]() { return !free_bufs.empty() || abort.load() || failed.load(); });
+                if (free_bufs.empty()) break;
+                bi = free_bufs.back(); free_bufs.pop_back();
+            }
             us_bufwait += tick(tk);
+            uint8_t* buf = bufs[(size_t)bi].p;
             size_t got = 0;
             while (got < len) { const ssize_t r = ::pread(fd, buf + got, len - got, (off_t)(off + got)); if (r <= 0) break; got += (size_t)r; }
             us_pread += tick(tk);
-            if (got < len) { fail_with("cannot read the bamfile"); break; }
-            if (hipMemcpyAsync(D.stream_file.p + (off - lo), buf, len, hipMemcpyHostToDevice, D.feed_stream[t]) != hipSuccess || hipEventRecord(D.feed_piece_ev[j], D.feed_stream[t]) != hipSuccess ||
-                hipEventRecord(D.feed_buf_ev[t][b], D.feed_stream[t]) != hipSuccess) { fail_with("host to device copy of the file bytes failed"); break; }
-            t_issued[j].store(std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_start).count(), std::memory_order_relaxed);
-            issued[j].store(1, std::memory_order_release);
-            used[b] = true;
-            b ^= 1;
+            if (got < len) { fail_with("cannot read the bamfile"); bcv.notify_all(); break; }
+            { std::lock_guard<std::mutex> lk(bmu); bufs[(size_t)bi].piece = j; filled_bufs.push_back(bi); }
+            bcv.notify_all();
         }
-        (void)hipStreamSynchronize(D.feed_stream[t]);
+    }
+    void issue() {  // the one thread of the feeder that makes HIP calls
+        if (hipSetDevice(c->P.device) != hipSuccess) { fail_with("hipSetDevice"); bcv.notify_all(); return; }
+        constexpr int NS = 4;
+        for (int q = 0; q < NS; ++q) if (!D.feed_stream[q] && hipStreamCreateWithFlags(&D.feed_stream[q], hipStreamNonBlocking) != hipSuccess) { fail_with("hipStreamCreate"); bcv.notify_all(); return; }
+        // the buffers (kept by the context: the next read finds them); the readers start with the first one that exists -- pinning 256 MiB
+        // takes 50-80 ms the first time and would otherwise stand in front of a cold start's first copy
+        for (size_t i = 0; i < bufs.size(); ++i) {
+            if (!D.feed_pin[i / 2][i % 2] && hipHostMalloc((void**)&D.feed_pin[i / 2][i % 2], P, hipHostMallocDefault) != hipSuccess) { fail_with("hipHostMalloc"); bcv.notify_all(); return; }
+            if (!D.feed_buf_ev[i / 2][i % 2] && hipEventCreateWithFlags(&D.feed_buf_ev[i / 2][i % 2], hipEventDisableTiming) != hipSuccess) { fail_with("hipEventCreate"); bcv.notify_all(); return; }
+            bufs[i].p = D.feed_pin[i / 2][i % 2];
+            { std::lock_guard<std::mutex> lk(bmu); free_bufs.push_back((int)i); }
+            bcv.notify_all();
+        }
+        std::vector<int> inflight;
+        size_t done = 0, rr = 0;
+        while (done < npieces && !abort.load() && !failed.load()) {
+            std::vector<int> take;
+            {
+                std::unique_lock<std::mutex> lk(bmu);
+                if (filled_bufs.empty()) bcv.wait_for(lk, std::chrono::microseconds(inflight.empty() ? 200 : 30));
+                take.swap(filled_bufs);
+            }
+            for (int bi : take) {
+                const size_t j = bufs[(size_t)bi].piece, off = lo + j * P, len = std::min(P, hi - off);
+                hipStream_t st = D.feed_stream[rr++ % NS];
+                int slot = bi / 1;  // the buffer's own event
+                if (hipMemcpyAsync(D.stream_file.p + (off - lo), bufs[(size_t)bi].p, len, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(D.feed_piece_ev[j], st) != hipSuccess ||
+                    hipEventRecord(D.feed_buf_ev[slot / 2][slot % 2], st) != hipSuccess) { fail_with("host to device copy of the file bytes failed"); break; }
+                t_issued[j].store(std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_start).count(), std::memory_order_relaxed);
+                issued[j].store(1, std::memory_order_release);
+                inflight.push_back(bi);
+            }
+            bool freed = false;
+            for (size_t k = 0; k < inflight.size();) {
+                const int bi = inflight[k];
+                const hipError_t e = hipEventQuery(D.feed_buf_ev[bi / 2][bi % 2]);
+                if (e == hipSuccess) { { std::lock_guard<std::mutex> lk(bmu); free_bufs.push_back(bi); } inflight[k] = inflight.back(); inflight.pop_back(); ++done; freed = true; }
+                else if (e == hipErrorNotReady) { (void)hipGetLastError(); ++k; }
+                else { fail_with("host to device copy of the file bytes failed"); break; }
+            }
+            if (freed) bcv.notify_all();
+        }
+        for (int q = 0; q < NS; ++q) (void)hipStreamSynchronize(D.feed_stream[q]);
+        bcv.notify_all();
     }
     // the IndexMore of a streamed read: the blocks walked since the last call; false when the walk is over and everything has been passed on
     bool more(std::vector<BgzfRange>& v) {
@@ -2969,11 +3058,9 @@ struct FileFeeder {
     }
     std::string error() { std::lock_guard<std::mutex> lk(mu); return what.empty() ? std::string("the read of the bamfile was given up") : what; }
     void finish() {  // (idempotent) every piece copied and the walk over, or the threads told to stop
-        for (auto& x : th) if (x.joinable()) x.join();
-        th.clear();
-        if (walker.joinable()) walker.join();
+        if (started) { D.feed_pool->wait(); started = false; }
     }
-    void cancel() { abort = true; cv.notify_all(); finish(); }
+    void cancel() { abort = true; wake_all(); finish(); }
 };
 
 int dev_stage_file(sq_ctx* c, const uint8_t* bytes, size_t n, const uint8_t** dptr) {
