@@ -3002,33 +3002,38 @@ struct FileFeeder {
             { std::lock_guard<std::mutex> lk(bmu); free_bufs.push_back((int)i); }
             bcv.notify_all();
         }
-        std::vector<int> inflight;
-        size_t done = 0, rr = 0;
+        // copies on one stream finish in order: only the oldest copy of every stream is asked about (a poll of all thirty-two buffers
+        // every few microseconds kept the runtime's lock busy for the thread that launches the kernels)
+        std::deque<int> inflight[NS];
+        size_t done = 0, rr = 0, n_inflight = 0;
         while (done < npieces && !abort.load() && !failed.load()) {
             std::vector<int> take;
             {
                 std::unique_lock<std::mutex> lk(bmu);
-                if (filled_bufs.empty()) bcv.wait_for(lk, std::chrono::microseconds(inflight.empty() ? 200 : 30));
+                if (filled_bufs.empty()) bcv.wait_for(lk, std::chrono::microseconds(n_inflight ? 100 : 500));
                 take.swap(filled_bufs);
             }
             for (int bi : take) {
                 const size_t j = bufs[(size_t)bi].piece, off = lo + j * P, len = std::min(P, hi - off);
-                hipStream_t st = D.feed_stream[rr++ % NS];
-                int slot = bi / 1;  // the buffer's own event
-                if (hipMemcpyAsync(D.stream_file.p + (off - lo), bufs[(size_t)bi].p, len, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(D.feed_piece_ev[j], st) != hipSuccess ||
-                    hipEventRecord(D.feed_buf_ev[slot / 2][slot % 2], st) != hipSuccess) { fail_with("host to device copy of the file bytes failed"); break; }
+                const int q = (int)(rr++ % NS);
+                hipStream_t st = D.feed_stream[q];
+                if (hipMemcpyAsync(D.stream_file.p + (off - lo), bufs[(size_t)bi].p, len, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(D.feed_piece_ev[j], st) != hipSuccess) { fail_with("host to device copy of the file bytes failed"); break; }
                 t_issued[j].store(std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_start).count(), std::memory_order_relaxed);
                 issued[j].store(1, std::memory_order_release);
-                inflight.push_back(bi);
+                inflight[q].push_back(bi);
+                ++n_inflight;
             }
             bool freed = false;
-            for (size_t k = 0; k < inflight.size();) {
-                const int bi = inflight[k];
-                const hipError_t e = hipEventQuery(D.feed_buf_ev[bi / 2][bi % 2]);
-                if (e == hipSuccess) { { std::lock_guard<std::mutex> lk(bmu); free_bufs.push_back(bi); } inflight[k] = inflight.back(); inflight.pop_back(); ++done; freed = true; }
-                else if (e == hipErrorNotReady) { (void)hipGetLastError(); ++k; }
-                else { fail_with("host to device copy of the file bytes failed"); break; }
-            }
+            for (int q = 0; q < NS; ++q)
+                while (!inflight[q].empty()) {
+                    const int bi = inflight[q].front();
+                    const hipError_t e = hipEventQuery(D.feed_piece_ev[bufs[(size_t)bi].piece]);
+                    if (e == hipErrorNotReady) { (void)hipGetLastError(); break; }
+                    if (e != hipSuccess) { fail_with("host to device copy of the file bytes failed"); break; }
+                    { std::lock_guard<std::mutex> lk(bmu); free_bufs.push_back(bi); }
+                    inflight[q].pop_front();
+                    --n_inflight; ++done; freed = true;
+                }
             if (freed) bcv.notify_all();
         }
         for (int q = 0; q < NS; ++q) (void)hipStreamSynchronize(D.feed_stream[q]);
