@@ -275,6 +275,10 @@ def main() -> None:
     # before every step (page-table fill + BGZF header walk + host -> device copy of the compressed bytes inside the step), in a
     # fresh context and AFTER the timed region
     close_context(ctx)
+    # (the driver wipes the ~30 GB the closed context released, on the same DMA engines that carry the host -> device copies of the steps
+    # below: measured 315 ms per step right behind the release against 247-262 ms on a GPU left alone -- let it finish first, as for cold_cli)
+    settle_s = float(os.environ.get("BENCH_COLD_SETTLE_S", "4"))
+    time.sleep(settle_s)
     ctx = new_context()
     squid_amd.drop_file_cache()
     step()
@@ -387,7 +391,6 @@ def main() -> None:
         # The driver wipes the VRAM a process releases, and a process that starts while the ~30 GB of the context closed a moment ago are
         # still being wiped waits for it in its first device allocations (measured: 4 GiB hipMalloc 0.2 ms on an idle GPU, 150-240 ms
         # right behind a release).  That wait belongs to this harness, not to a cold start: give the GPU a moment to itself first.
-        settle_s = float(os.environ.get("BENCH_COLD_SETTLE_S", "4"))
         time.sleep(settle_s)
         t0 = time.perf_counter()
         r = subprocess.run([str(BUILD / "squid"), "-b", bam, "-c", chim, "-o", str(cold_pre)] + cli_flags, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
