@@ -12,10 +12,13 @@ Workload: BASELINE.json configs[2] -- "Full hg38, 50M-read synthetic STAR concor
 generator config C3 (50.8 M concordant records, zlib level 6), the largest single-GPU configuration.
 `--workload C5` = configs[4], the dense-graph stress (-w 1 -a 50, >= 1e5 small components): reports components/s.
 
-  value            alignments/s with the COMPRESSED BAM BYTES STAGED IN HBM when the timed region starts (sq_stage_bam)
-  from_file_value  the same step from the file in the page cache, the mapping / block index dropped before every step
-                   (sq_drop_file_cache): page-table fill, BGZF header walk and host->device copy inside the step
-  cold_cli         ONE fresh `build/squid -b -c -o` process (wall clock from exec to exit, page cache warm, nothing staged)
+  value            alignments/s with the COMPRESSED BAM BYTES STAGED IN HBM when the timed region starts (sq_stage_bam) -- the bench
+                   contract's "inputs already resident in HBM"; the two PCIe-inclusive figures of the same step stand beside it:
+  from_file_value  the same step from the file in the page cache, nothing kept from earlier reads (sq_drop_file_cache before every
+                   step): the file streamed into HBM (pread -> page-locked buffers -> copies running ahead of the token pass) and
+                   its BGZF headers walked inside the step
+  cold_cli         ONE fresh `build/squid -b -c -o` process (wall clock from exec to exit, page cache warm, nothing staged), started
+                   a few seconds after this process released its device memory (see the comment at the call)
   resident_pass    the graph pass alone over records already decoded in HBM
   roofline         SURVEY.md 8(d): N_c * (80 + 24 b) algorithmic bytes / summed time of the record-streaming kernels of one
                    pass / 8 TB/s; the per-kernel table sits beside it

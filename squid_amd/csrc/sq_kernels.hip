@@ -2062,9 +2062,8 @@ __device__ __forceinline__ uint32_t il_take(ILane& b, int k) {
 // ranges that ascend with L.  So the length of the next code is 1 + #{L : v >= limit[L]} -- fourteen compares against values
 // that live in 15 registers per code (literal/length and distance) -- and the symbol is sym[(v >> (15 - len)) + K[len]].  What
 // stays in LDS per lane: the symbol permutation as bytes (288 + 32; a literal/length symbol >= 256 is told from its rank inside
-// its length group, where the literals come first), two 16-entry tables per code, the code lengths packed to 4 bits while a
-// header is read (170), the input ring and the token stage: 746 bytes, 46.6 KB per wave, THREE waves per CU -- three times the
-// streams in flight, and a step is two LDS round trips per code instead of up to nine.
+// its length group, where the literals come first), three 16-entry tables, the input ring and the token stage (the sizes: "Round 4"
+// below) -- several waves per CU, and a step is two LDS round trips per code instead of up to nine.
 constexpr int T2_SYM_LL = 288, T2_SYM_DD = 32, T2_LITS = 4;
 // Round 4: 496 bytes per lane (round 3: 746).  What went: the 4-bit code lengths of a header (170 B) -- they are only needed between
 // reading a header and scattering its symbols, once per ~16 k symbols, and now travel through a per-lane strip of GLOBAL memory, eight
@@ -3004,15 +3003,21 @@ struct FileFeeder {
         }
         // copies on one stream finish in order: only the oldest copy of every stream is asked about (a poll of all thirty-two buffers
         // every few microseconds kept the runtime's lock busy for the thread that launches the kernels)
+        // few copies queued at a time: the small device -> host read-backs of the batch loop (flags, record counts) travel on the same DMA
+        // engines, and every 8 MiB piece queued in front of one of them is 160 us of waiting for the thread that drives the pipeline
+        static const size_t max_inflight = std::getenv("SQUID_FEED_INFLIGHT") ? (size_t)std::max(1, std::atoi(std::getenv("SQUID_FEED_INFLIGHT"))) : 8;
         std::deque<int> inflight[NS];
+        std::deque<int> waiting;  // filled, not yet queued
         size_t done = 0, rr = 0, n_inflight = 0;
         while (done < npieces && !abort.load() && !failed.load()) {
-            std::vector<int> take;
             {
                 std::unique_lock<std::mutex> lk(bmu);
-                if (filled_bufs.empty()) bcv.wait_for(lk, std::chrono::microseconds(n_inflight ? 100 : 500));
-                take.swap(filled_bufs);
+                if (filled_bufs.empty() && (waiting.empty() || n_inflight >= max_inflight)) bcv.wait_for(lk, std::chrono::microseconds(n_inflight ? 50 : 500));
+                for (int bi : filled_bufs) waiting.push_back(bi);
+                filled_bufs.clear();
             }
+            std::vector<int> take;
+            while (!waiting.empty() && n_inflight + take.size() < max_inflight) { take.push_back(waiting.front()); waiting.pop_front(); }
             for (int bi : take) {
                 const size_t j = bufs[(size_t)bi].piece, off = lo + j * P, len = std::min(P, hi - off);
                 const int q = (int)(rr++ % NS);

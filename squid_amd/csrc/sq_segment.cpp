@@ -1,8 +1,8 @@
 // Genome segmentation (BuildNode_STAR of src/SegmentGraph.cpp:192-761).
 //
-// Split of work: the GPU (k_classify/k_dedup/k_summarise) reduces the concordant stream to one 20-byte summary per
-// kept record (record key, first aligned block, classification) and -- because the discordant-cluster list is static
-// -- also finds, with scans over those summaries (dev_segment_support): the trigger record of every cluster, every
+// Split of work: the GPU (k_pass1, then k_tile_scan / k_zfinal / k_summarise_tiles: sq_pass_kernels.inc) classifies the concordant stream,
+// writes 24-byte summaries (record key, first aligned block, classification) of just the stretches the host replays and -- because
+// the discordant-cluster list is static -- also finds, tile by tile (dev_pass1, dev_segment_support): the trigger record of every cluster, every
 // "zero coverage" record together with the running (otherChr, otherrightmost) pair in front of it, and per cluster
 // the non-first blocks that can span one of its break candidates.  At a zero-coverage record the reference flushes
 // a pending node end and empties both sliding windows (SegmentGraph.cpp:616-636), so the stream falls into
