@@ -2530,6 +2530,83 @@ __global__ __launch_bounds__(128) void k_lz_resolve2(const uint32_t* tok, const 
 // plausible record headers (as the host reader does), walk from there, and a check kernel verifies that every slice ends
 // exactly where the next one started (any disagreement sends the file through the host reader instead).
 constexpr int REC_SLICE = 8192;
+// LZ77 resolution WITHOUT a window in LDS (round 4, SQUID_RESOLVE_GLOBAL): one wave per BGZF block, the block's output written to its
+// place in HBM as it is produced and the matches read from there (a block's 64 KiB sit in L2 while it is worked on).  A match costs a
+// memory round trip instead of an LDS one, so a block takes ten times longer than in k_lz_resolve2 -- but the kernel needs no LDS and
+// few registers: thousands of blocks are in flight instead of one per CU, and the 64 KB the LDS form reserves on every CU go to the token
+// pass (five token waves per CU instead of three).  Same rounds of 64 tokens and the same readiness rule as k_lz_resolve2; between the
+// stores of a sub-round and the loads of the next a workgroup-scope fence (one wave per workgroup on one CU: its L1 is the only cache in
+// between, the fence is the wait for the stores).
+__global__ __launch_bounds__(64) void k_lz_resolve3(const uint32_t* tok, const int32_t* ntok, const InflBlock* blocks, int nblocks, unsigned long long out_base, uint8_t* outbuf, int32_t* flags) {
+    const int lane = threadIdx.x;
+    const InflBlock blk = blocks[blockIdx.x];
+    const uint32_t* t = tok + blk.toff;
+    const int n = ntok[blockIdx.x];
+    uint8_t* out = outbuf + (blk.uoff - out_base);
+    uint32_t base = 0;
+    bool bad = false;
+    uint32_t nxt = lane < n ? t[lane] : 0;
+    for (int r0 = 0; r0 < n; r0 += 64) {
+        const uint32_t tk = nxt;
+        const int i = r0 + lane;
+        if (i + 64 < n) nxt = t[i + 64];
+        const bool valid = i < n, is_m = valid && (tk >> 31);
+        const uint32_t nl = (tk >> 24) & 3u;
+        const uint32_t len = !valid ? 0u : (is_m ? (tk >> 16) & 0x1ffu : (nl ? nl : 1u));
+        const uint32_t inc = wave_scan_incl(len);
+        const uint32_t o = base + inc - len;
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        if (base + total > blk.isize) { bad = true; break; }  // (uniform)
+        if (valid && !is_m) { out[o] = (uint8_t)tk; if (len > 1) out[o + 1] = (uint8_t)(tk >> 8); if (len > 2) out[o + 2] = (uint8_t)(tk >> 16); }
+        const uint32_t dist = (tk & 0x7fffu) + 1;
+        bool pending = is_m;
+        if (__any(pending && dist > o)) { bad = true; break; }
+        const uint32_t src = o - dist;
+        const uint32_t ready_at = src + len < o ? src + len : o;  // the match needs the bytes below this
+        unsigned long long pm = __ballot(pending);
+        while (pm) {
+            const int first = __ffsll((long long)pm) - 1;
+            const uint32_t hwm = (uint32_t)__builtin_amdgcn_readlane((int)o, __builtin_amdgcn_readfirstlane(first));  // everything below the first pending match is final
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // ... and written
+            if (pending && ready_at <= hwm) {
+                if (dist >= 8) {
+                    if (len <= 8) {
+                        unsigned long long w;
+                        __builtin_memcpy(&w, out + src, 8);  // (the bytes behind the match are read, not stored; the block buffers carry slack behind their last block)
+                        if (len >= 4) {
+                            const uint32_t lo4 = (uint32_t)w, hi4 = (uint32_t)(w >> (8 * (len - 4)));
+                            __builtin_memcpy(out + o, &lo4, 4); __builtin_memcpy(out + o + len - 4, &hi4, 4);
+                        } else {
+                            const uint16_t lo2 = (uint16_t)w; const uint8_t b2 = (uint8_t)(w >> 16);
+                            __builtin_memcpy(out + o, &lo2, 2); out[o + 2] = b2;
+                        }
+                    } else {
+                        uint32_t k = 0;
+                        for (; k + 8 <= len; k += 8) { unsigned long long w; __builtin_memcpy(&w, out + src + k, 8); __builtin_memcpy(out + o + k, &w, 8); }
+                        if (k < len) { unsigned long long w; __builtin_memcpy(&w, out + src + len - 8, 8); __builtin_memcpy(out + o + len - 8, &w, 8); }
+                    }
+                } else {
+                    // every byte comes from [src, src + min(dist, len)): final
+                    uint32_t j = 0;
+                    for (uint32_t k = 0; k < len; k += 8) {
+                        uint8_t v[8];
+                        uint32_t jj = j;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { v[q] = out[src + jj]; if (++jj == dist) jj = 0; }
+                        j = jj;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) if (k + q < len) out[o + k + q] = v[q];
+                    }
+                }
+                pending = false;
+            }
+            pm = __ballot(pending);
+        }
+        base += total;
+    }
+    if (bad || base != blk.isize) { if (lane == 0) atomicOr(&flags[0], 512); }
+}
+
 struct RecScan { const uint8_t* u; unsigned long long begin, limit; int nref; int first_ref, end_ref, with_unplaced; /* first_ref < 0: keep everything */ };
 __device__ __forceinline__ int ld32u(const uint8_t* p) { return (int)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); }
 __device__ __forceinline__ long rec_plausible(const RecScan& S, unsigned long long p) {
@@ -3268,7 +3345,8 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * (int)T2_LDS_BYTES));
     // token waves per workgroup: 3 (93 KB) leave the 64 KB slot of a resolve workgroup free on every CU; 4 or 5 take the whole CU and the
     // resolve workgroups -- on a stream of higher priority -- get the CUs that token workgroups leave (SQUID_TOK_WPB, measured in DESIGN.md)
-    static const int tok_wpb = std::getenv("SQUID_TOK_WPB") ? std::max(1, std::min(5, std::atoi(std::getenv("SQUID_TOK_WPB")))) : 3;
+    static const bool resolve_global = std::getenv("SQUID_RESOLVE_GLOBAL") != nullptr && std::atoi(std::getenv("SQUID_RESOLVE_GLOBAL")) != 0;  // k_lz_resolve3: no LDS window
+    static const int tok_wpb = std::getenv("SQUID_TOK_WPB") ? std::max(1, std::min(5, std::atoi(std::getenv("SQUID_TOK_WPB")))) : (resolve_global ? 5 : 3);
     static const bool tok_prof = std::getenv("SQUID_TOK_PROF") != nullptr;
     if (tok_prof) HIPCHK(D.tok_prof.reserve(8 * 4096));
     for (auto& q : D.il_stream)
@@ -3424,7 +3502,8 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         HIPCHK(hipStreamWaitEvent(s, st.ready, 0));
         {
             EvTimer t2(c, "k_lz_resolve2", (double)B.bbytes * 3);
-            hipLaunchKernelGGL(k_lz_resolve2, dim3(nb), dim3(128), 65536 + 16, s, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, out, P.flags.p);
+            if (resolve_global) hipLaunchKernelGGL(k_lz_resolve3, dim3(nb), dim3(64), 0, s, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, out, P.flags.p);
+            else hipLaunchKernelGGL(k_lz_resolve2, dim3(nb), dim3(128), 65536 + 16, s, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, out, P.flags.p);
         }
         HIPCHK(hipEventRecord(st.freed, s));
         F.S = RecScan{P.out.p, k == 0 ? (unsigned long long)begin : F.pad, F.limit, nref, sh.on ? sh.first_ref : -1, sh.on ? sh.end_ref : 0, (sh.on && c->P.rank == c->P.world_size - 1) ? 1 : 0};
