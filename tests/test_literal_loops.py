@@ -8,7 +8,10 @@ reference's statements as Python allows, of
   `ReadRec.cpp:119-141`) -> ReadsMain / ReadsOther;
 * the discordant block list `bamdiscordant` (`:203-264`; `IsEndDiscordant / IsSingleAnchored / IsPairDiscordant`,
   `ReadRec.cpp:171-228`) from the merged chimeric fragments;
-* per-node Support / AvgDepth (`:766-826`), three sweeps with their lagging cursors and the final division.
+* per-node Support / AvgDepth (`:766-826`), three sweeps with their lagging cursors and the final division;
+* the whole of stage 2: `LocateRead` with its running cursor and its trimming of the blocks (`:1207-1293`), `RawEdgesChim`
+  (`:1394-1555`), `RawEdgesOther` over every concordant record (`:1557-1690`), `Edge_t`'s constructor and order (`BPEdge.h:31-74`),
+  `IsDiscordant` (`:181-190`) and the sort/merge of `BuildEdges` (`:1932-1959`) -> the edge list with its weights.
 
 The only inputs taken from elsewhere: the merged chimeric fragments (the oracle's dump of BuildChimericSBamRecord's result), the
 node coordinates of stage 1 and the number of kept records the stream loop consumes before its `break` (`:338-339`).
@@ -369,7 +372,233 @@ def _depth_literal(nodes, bamdiscordant, main, other):
     return support, depth
 
 
-def _check(rec, chim, nodes, n_break, kept_total):
+# ---- SegmentGraph.cpp:1207-1293: both halves of the function are the same statements over FirstRead and then SecondMate with one
+# running cursor `i`; the blocks are trimmed to the node they land in (mutating the caller's record, as the reference does)
+def _locate_read(nodes, initialguess, F, S):
+    n = len(nodes)
+    out = [0] * (len(F) + len(S))
+    i, thresh = initialguess, 5
+
+    def inside(i, b):
+        chr_, p, ln = nodes[i]
+        return chr_ == b["RefID"] and b["RefPos"] >= p - thresh and b["RefPos"] + b["MatchRef"] <= p + ln + thresh
+
+    for base, L in ((0, F), (len(F), S)):
+        for k, b in enumerate(L):
+            if i < 0 or i >= n:
+                i = initialguess
+            if not inside(i, b):
+                if nodes[i][0] < b["RefID"] or (nodes[i][0] == b["RefID"] and nodes[i][1] <= b["RefPos"]):
+                    while i < n and nodes[i][0] <= b["RefID"]:
+                        if inside(i, b):
+                            break
+                        i += 1
+                else:
+                    while i > -1 and nodes[i][0] >= b["RefID"]:
+                        if inside(i, b):
+                            break
+                        i -= 1
+            if i < 0 or i >= n or nodes[i][0] != b["RefID"]:
+                out[base + k] = -1
+            else:
+                out[base + k] = i
+                _, p, ln = nodes[i]
+                if b["RefPos"] < p:
+                    d = p - b["RefPos"]
+                    if not b["IsReverse"]:
+                        b["ReadPos"] += d
+                    b["MatchRef"] -= d
+                    b["MatchRead"] -= d
+                    b["RefPos"] = p
+                if b["RefPos"] + b["MatchRef"] > p + ln:
+                    d = b["RefPos"] + b["MatchRef"] - p - ln
+                    if b["IsReverse"]:
+                        b["ReadPos"] += d
+                    b["MatchRef"] -= d
+                    b["MatchRead"] -= d
+    return out
+
+
+class _Edges:
+    """vEdges plus Edge_t's constructor (BPEdge.h:31-52: the smaller index first, heads swapped with it) and IsDiscordant (:181-190)"""
+
+    def __init__(self, nodes):
+        self.nodes, self.v = nodes, []
+
+    @staticmethod
+    def make(i1, h1, i2, h2):
+        return (i2, i1, h2, h1) if i1 > i2 else (i1, i2, h1, h2)  # (Ind1, Ind2, Head1, Head2): the member order of operator<
+
+    def is_discordant(self, e):
+        i1, i2, h1, h2 = e
+        if self.nodes[i1][0] != self.nodes[i2][0]:
+            return True
+        elif self.nodes[i2][1] - self.nodes[i1][1] - self.nodes[i1][2] > 50000 and i2 - i1 > 20:  # Concord_Dist_Pos, Concord_Dist_Idx (Config.cpp:24-25)
+            return True
+        elif h1 is not False or h2 is not True:
+            return True
+        return False
+
+    def push(self, e, w=1):
+        self.v.append((e, w))
+
+    def unlocated(self, firstfrontindex, b):  # the two cursor walks of :1408-1411 / :1614-1616 for a block LocateRead could not place
+        nodes, i = self.nodes, firstfrontindex
+        while i < len(nodes) and (nodes[i][0] < b["RefID"] or (nodes[i][0] == b["RefID"] and nodes[i][1] + nodes[i][2] < b["RefPos"])):
+            i += 1
+        while i > -1 and (nodes[min(i, len(nodes) - 1)][0] > b["RefID"] or (nodes[min(i, len(nodes) - 1)][0] == b["RefID"] and nodes[min(i, len(nodes) - 1)][1] > b["RefPos"])):
+            assert i < len(nodes)  # (the reference would read vNodes[size()] here)
+            i -= 1
+        self.push(self.make(i, False, i + 1, True))
+
+
+def _pair_overlap(r, rn, i, j):  # :1487-1506 == :1655-1674
+    nf = len(r["F"])
+    isoverlap = False
+    for k in range(nf):
+        if j == rn[k]:
+            isoverlap = True
+    for k in range(len(r["S"])):
+        if i == rn[nf + k]:
+            isoverlap = True
+    if nf > 1:
+        if _is_end_discordant(r, True) and ((rn[0] <= j and rn[nf - 1] >= j) or (rn[0] >= j and rn[nf - 1] <= j)):
+            isoverlap = True
+        elif not _is_end_discordant(r, True) and abs(i - j) < 3:
+            isoverlap = True
+    if len(r["S"]) > 1:
+        if _is_end_discordant(r, False) and ((rn[nf] <= i and rn[-1] >= i) or (rn[nf] >= i and rn[-1] <= i)):
+            isoverlap = True
+        elif not _is_end_discordant(r, False) and abs(i - j) < 3:
+            isoverlap = True
+    return isoverlap
+
+
+def _is_pair_discordant_nocheck(r):  # IsPairDiscordant(false), ReadRec.cpp:209-228 without the needcheck part
+    F, S = r["F"], r["S"]
+    if len(F) == 0 or len(S) == 0:
+        return False
+    if F[0]["RefID"] != S[-1]["RefID"] or F[0]["IsReverse"] == S[-1]["IsReverse"]:
+        return True
+    elif not F[0]["IsReverse"] and F[0]["RefPos"] - F[0]["ReadPos"] > S[-1]["RefPos"] - (r["stl"] - S[-1]["ReadPos"] - S[-1]["MatchRead"]):
+        return True
+    elif not S[0]["IsReverse"] and S[0]["RefPos"] - S[0]["ReadPos"] > F[-1]["RefPos"] - (r["ftl"] - F[-1]["ReadPos"] - F[-1]["MatchRead"]):
+        return True
+    return False
+
+
+# ---- SegmentGraph.cpp:1394-1555.  The breakpoint pairs of a discordant edge are only counted here (:1529-1554 keeps every one of them:
+# the group filter is commented out at :1547), so PairBreakpoints is a counter
+def _raw_edges_chim(E, chim):
+    firstfrontindex = 0
+    pair_bp = {}
+    for it in chim:
+        F, S = it["F"], it["S"]
+        if len(F) == 0 and len(S) == 0:
+            continue
+        rn = _locate_read(E.nodes, firstfrontindex, F, S)
+        if rn[0] != -1:
+            firstfrontindex = rn[0]
+        for k in range(len(rn)):
+            if rn[k] == -1:
+                E.unlocated(firstfrontindex, F[k] if k < len(F) else S[k - len(F)])
+        for base, L in ((0, F), (len(F), S)):
+            for k in range(len(L) - 1):
+                i, j = rn[base + k], rn[base + k + 1]
+                if i != j and i != -1 and j != -1:
+                    tmp = E.make(i, bool(L[k]["IsReverse"]), j, not L[k + 1]["IsReverse"])
+                    if not E.is_discordant(tmp):
+                        E.push(tmp)
+                    else:
+                        pair_bp[tmp] = pair_bp.get(tmp, 0) + 1
+        if len(F) > 0 and len(S) > 0:
+            if not _is_single_anchored(it) and not _is_end_discordant(it, True) and not _is_end_discordant(it, False):
+                i, j = rn[len(F) - 1], rn[-1]
+                if i != j and i != -1 and j != -1 and not _pair_overlap(it, rn, i, j):
+                    tmp = E.make(i, bool(F[-1]["IsReverse"]), j, bool(S[-1]["IsReverse"]))
+                    if not E.is_discordant(tmp):
+                        E.push(tmp)
+                    elif _is_pair_discordant_nocheck(it):
+                        pair_bp[tmp] = pair_bp.get(tmp, 0) + 1
+    for tmp in sorted(pair_bp):  # map<Edge_t, ...> iteration order; (False < True as (int)Head)
+        E.push(tmp, pair_bp[tmp])
+
+
+# ---- SegmentGraph.cpp:1557-1690 over the whole concordant stream
+def _raw_edges_other(E, rec, min_mapq):
+    refid, pos, mref, mpos, flag, mapq, aux, off, totlen = (rec[k].tolist() for k in ("refid", "pos", "mate_refid", "mate_pos", "flag", "mapq", "aux", "blk_off", "totlen"))
+    b_refpos, b_matchref, b_readpos, b_matchread = (rec[k].tolist() for k in ("b_refpos", "b_matchref", "b_readpos", "b_matchread"))
+    firstfrontindex = 0
+    last = ([], [])
+    for r in range(len(refid)):
+        f = flag[r]
+        if aux[r] & 1 or f & 0x400 or mapq[r] < min_mapq or f & 0x4 or aux[r] & 2:
+            continue
+        rev = bool(f & 0x10)
+        own = [{"RefID": refid[r], "RefPos": b_refpos[k], "ReadPos": b_readpos[k], "MatchRef": b_matchref[k], "MatchRead": b_matchread[k], "IsReverse": rev} for k in range(off[r], off[r + 1])]
+        own.sort(key=lambda b: b["ReadPos"])  # readrec.SortbyReadPos() (a handful of blocks: libstdc++ sorts <= 16 elements by insertion, stable)
+        isfirst = bool(f & 0x40)
+        rr = {"F": own if isfirst else [], "S": [] if isfirst else own, "ftl": totlen[r] if isfirst else 0, "stl": 0 if isfirst else totlen[r]}
+        low_own = bool(aux[r] & 4)
+        if not (f & 0x8) and mref[r] != -1:
+            stub = {"RefID": mref[r], "RefPos": mpos[r], "ReadPos": 0, "MatchRef": 15, "MatchRead": 15, "IsReverse": bool(f & 0x20)}
+            (rr["S"] if isfirst else rr["F"]).append(stub)
+        key = ([(b["RefID"], b["RefPos"], b["MatchRef"]) for b in rr["F"]], [(b["RefID"], b["RefPos"], b["MatchRef"]) for b in rr["S"]])
+        if _equal(last, key):
+            continue
+        last = key
+        F, S = rr["F"], rr["S"]
+        whether = False
+        if len(F) == 0 or len(S) == 0:
+            whether = True
+        else:
+            # (the LowPhred flag of the side the record is not on was never set by the constructor; that side is the mate stub with
+            #  ReadPos 0 whenever this branch is reached, so `||` never gets to it)
+            first_ok = F[0]["ReadPos"] <= 15 or (low_own if isfirst else _never())
+            second_ok = first_ok and (S[0]["ReadPos"] <= 15 or (low_own if not isfirst else _never()))
+            whether = first_ok and second_ok
+        if not whether:
+            continue
+        rn = _locate_read(E.nodes, firstfrontindex, F, S)
+        if len(rn) != 0 and rn[0] != -1:
+            firstfrontindex = rn[0]
+        for k in range(len(rn)):
+            if rn[k] == -1:
+                E.unlocated(firstfrontindex, F[k] if k < len(F) else S[k - len(F)])
+        for base, L in ((0, F), (len(F), S)):
+            for k in range(len(L) - 1):
+                i, j = rn[base + k], rn[base + k + 1]
+                if i != j and i != -1 and j != -1:
+                    E.push(E.make(i, bool(L[k]["IsReverse"]), j, not L[k + 1]["IsReverse"]))
+        if isfirst and len(F) > 0 and len(S) > 0:
+            if not _is_single_anchored(rr) and not _is_end_discordant(rr, True) and not _is_end_discordant(rr, False):
+                i, j = rn[len(F) - 1], rn[-1]
+                if i != j and i != -1 and j != -1 and not _pair_overlap(rr, rn, i, j):
+                    tmp = E.make(i, bool(F[-1]["IsReverse"]), j, bool(S[-1]["IsReverse"]))
+                    if _is_pair_discordant_nocheck(rr) == E.is_discordant(tmp):
+                        E.push(tmp)
+
+
+def _never():
+    raise AssertionError("the reference would read an uninitialised LowPhred flag here")
+
+
+# ---- SegmentGraph.cpp:1932-1959: sort, merge equal edges by adding their weights, keep Weight > 0
+def _build_edges_literal(nodes, chim, rec, min_mapq):
+    E = _Edges([n[:3] for n in nodes])
+    _raw_edges_chim(E, chim)
+    _raw_edges_other(E, rec, min_mapq)
+    E.v.sort(key=lambda ew: ew[0])  # operator< reads (Ind1, Ind2, Head1, Head2) only; the weights of equal edges are summed, so tie order is immaterial
+    out = []
+    for e, w in E.v:
+        if len(out) == 0 or out[-1][0] != e:
+            out.append([e, w])
+        else:
+            out[-1][1] += w
+    return [(e[0], int(e[2]), e[1], int(e[3]), w) for e, w in out if w > 0]
+
+
+def _check(rec, chim, nodes, n_break, kept_total, edges=None):
     main, other, kept = _pass1_literal(rec, 255, n_break)
     assert kept == n_break
     if kept_total is not None:  # the whole stream without the break: records that pass the filter and the duplicate drop
@@ -378,6 +607,10 @@ def _check(rec, chim, nodes, n_break, kept_total):
     support, depth = _depth_literal([n[:3] for n in nodes], _bamdiscordant_literal(chim), main, other)
     assert [n[3] for n in nodes] == support
     assert [n[4] for n in nodes] == depth  # the same IEEE doubles: integer sums, one division
+    if edges is not None:
+        import copy
+
+        assert _build_edges_literal(nodes, copy.deepcopy(chim), rec, 255) == [tuple(e[:5]) for e in edges]
 
 
 @pytest.mark.parametrize("cfg", ["C1", "T2"])
@@ -389,7 +622,7 @@ def test_oracle_against_the_literal_loops(built, synth, tmp_path, cfg):
     _, dump = ou.run_oracle(built, pre, tmp_path)
     stats = dict(line.split("\t") for line in (dump / "order_stats.txt").read_text().splitlines())
     rec = _records_from_bam(f"{pre}.bam", _chim_names(dump))
-    _check(rec, _read_chimrecord(dump / "chimrecord.txt"), ou.read_nodes(dump / "nodes_build.txt"), int(stats["break_record"]), None)
+    _check(rec, _read_chimrecord(dump / "chimrecord.txt"), ou.read_nodes(dump / "nodes_build.txt"), int(stats["break_record"]), None, ou.read_edges(dump / "edges_build.txt"))
     assert stats["kept_records"] == stats["break_record"]  # (the oracle's loop counts up to its break)
 
 
@@ -408,8 +641,8 @@ def test_hip_path_against_the_literal_loops(built, synth, tmp_path, cfg, monkeyp
         ctx.build_graph()
         rec = ctx.records()
         counts = ctx.counts()
-        nodes = ctx.graph(1)["nodes"]
+        nodes, edges = ctx.graph(1)["nodes"], ctx.graph(2)["edges"]
     want = _records_from_bam(f"{pre}.bam", _chim_names(dump))
     for k in want:
         assert np.array_equal(np.asarray(rec[k]).astype(np.int64), want[k]), k
-    _check(rec, _read_chimrecord(dump / "chimrecord.txt"), nodes, counts["n_break"], counts["n_kept_p1"])
+    _check(rec, _read_chimrecord(dump / "chimrecord.txt"), nodes, counts["n_break"], counts["n_kept_p1"], edges)
