@@ -46,6 +46,8 @@ import tempfile
 import time
 from pathlib import Path
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before torch's first HIP call: the ingest overlaps up to eight kernels (squid_amd/csrc/sq_kernels.hip, HwQueueRequest)
+
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 BUILD = ROOT / "build"

@@ -10,6 +10,8 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (the library asks for the same when it is loaded; this also covers a torch that makes the first HIP call)
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent

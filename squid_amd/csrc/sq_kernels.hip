@@ -209,10 +209,10 @@ struct DeviceRecords {
     DBuf<long long> rec_sync, rec_end;
     // GPU ingest, two batches in flight: compressed bytes + block table + tokens of a batch
     struct InflSet { DBuf<uint8_t> in; DBuf<InflBlock> tab; DBuf<uint32_t> tok, lens; DBuf<int32_t> ntok, flags; hipEvent_t ready = nullptr, freed = nullptr, copied = nullptr; std::vector<InflBlock> host_tab; const uint8_t* src = nullptr; /* compressed bytes of the batch: `in`, or inside the staged file */ };
-    static constexpr int IL_DEPTH = 5;  // buffer sets: batch k is resolved / parsed, the three behind it are in the token pass, the next is being copied
-    InflSet il_set[IL_DEPTH];
-    hipStream_t il_stream[IL_DEPTH] = {};  // one per set: its host->device copies
-    hipStream_t il_tok_stream = nullptr;   // the token passes, one after the other
+    static constexpr int IL_DEPTH_MAX = 8;
+    int il_depth = 5;  // buffer sets in use (SQUID_IL_DEPTH, 3..8): batch k is resolved / parsed, the ones behind it are in the token pass, the last is being copied
+    InflSet il_set[IL_DEPTH_MAX];
+    hipStream_t il_stream[IL_DEPTH_MAX] = {};  // one per set: its host->device copies and its token pass
     // everything behind the token pass exists twice: while batch k is parsed (parse stream), batch k + 1 is resolved and cut into
     // records (library stream)
     struct PostSet { DBuf<uint8_t> out; DBuf<long long> rec_sync, rec_end; DBuf<int32_t> rec_cnt, rec_base, flags, spine; DBuf<unsigned long long> bam_off; };
@@ -2765,6 +2765,13 @@ void dev_flush_timers(sq_ctx* c) {
     D.ev_used = 0;
 }
 
+// The ingest keeps the token passes of up to seven batches, the resolve of the batch in front of them and the record parse of the one
+// before on the GPU side by side.  The HIP runtime maps all streams of one priority onto four hardware queues unless it is told otherwise
+// when it initialises, and kernels that share a queue run one after the other: with four queues at most four token passes overlap and
+// a C3 step takes 205 ms instead of 147.  Loading this library therefore asks for eight queues unless the variable
+// is set already; the request only counts if the process has not made its first HIP call yet (INTEGRATION.md says so to a host that has).
+namespace { struct HwQueueRequest { HwQueueRequest() { (void)::setenv("GPU_MAX_HW_QUEUES", "8", 0); } } g_hw_queue_request; }
+
 int dev_create(sq_ctx* c) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(c, SQ_E_NODEVICE, "no HIP device visible; libsquid_hip has no CPU path");
@@ -2796,7 +2803,6 @@ void dev_destroy(sq_ctx* c) {
     D.cl_chr.release(); D.trig.release(); D.cl_bucket.release();
     D.ord_e.release(); D.ord_o.release(); D.ord_v.release(); D.ord_me.release(); D.ord_mo.release(); D.g_i.release(); D.g_x.release(); D.g_d.release(); D.g_b.release();
     D.pin.release(); for (auto& st : D.il_set) { st.in.release(); st.tab.release(); st.tok.release(); st.lens.release(); st.ntok.release(); st.flags.release(); if (st.ready) (void)hipEventDestroy(st.ready); if (st.freed) (void)hipEventDestroy(st.freed); if (st.copied) (void)hipEventDestroy(st.copied); st.ready = st.freed = st.copied = nullptr; }
-    if (D.il_tok_stream) { (void)hipStreamDestroy(D.il_tok_stream); D.il_tok_stream = nullptr; }
     for (auto& q : D.il_stream) if (q) { (void)hipStreamDestroy(q); q = nullptr; }
     for (auto& ps : D.il_post) { ps.out.release(); ps.rec_sync.release(); ps.rec_end.release(); ps.rec_cnt.release(); ps.rec_base.release(); ps.flags.release(); ps.spine.release(); ps.bam_off.release(); }
     if (D.il_parse_stream) { (void)hipStreamDestroy(D.il_parse_stream); D.il_parse_stream = nullptr; }
@@ -3345,24 +3351,26 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * (int)T2_LDS_BYTES));
     // token waves per workgroup: 3 (93 KB) leave the 64 KB slot of a resolve workgroup free on every CU; 4 or 5 take the whole CU and the
     // resolve workgroups -- on a stream of higher priority -- get the CUs that token workgroups leave (SQUID_TOK_WPB, measured in DESIGN.md)
-    static const bool resolve_global = std::getenv("SQUID_RESOLVE_GLOBAL") != nullptr && std::atoi(std::getenv("SQUID_RESOLVE_GLOBAL")) != 0;  // k_lz_resolve3: no LDS window
-    static const int tok_wpb = std::getenv("SQUID_TOK_WPB") ? std::max(1, std::min(5, std::atoi(std::getenv("SQUID_TOK_WPB")))) : (resolve_global ? 5 : 3);
+    static const bool resolve_global = std::getenv("SQUID_RESOLVE_GLOBAL") == nullptr || std::atoi(std::getenv("SQUID_RESOLVE_GLOBAL")) != 0;  // k_lz_resolve3 (no LDS window); 0: k_lz_resolve2
+    static const int tok_wpb = std::getenv("SQUID_TOK_WPB") ? std::max(1, std::min(5, std::atoi(std::getenv("SQUID_TOK_WPB")))) : (resolve_global ? 1 : 3);
     static const bool tok_prof = std::getenv("SQUID_TOK_PROF") != nullptr;
     if (tok_prof) HIPCHK(D.tok_prof.reserve(8 * 4096));
-    for (auto& q : D.il_stream)
+    static const int il_depth = std::getenv("SQUID_IL_DEPTH") ? std::max(3, std::min((int)DeviceRecords::IL_DEPTH_MAX, std::atoi(std::getenv("SQUID_IL_DEPTH")))) : (resolve_global ? 8 : 5);
+    D.il_depth = il_depth;
+    for (int qi = 0; qi < D.il_depth; ++qi) {
+        hipStream_t& q = D.il_stream[qi];
         if (!q) {
             // lowest priority: a token wave holds its CU for tens of milliseconds, and the resolve / boundary / parse kernels
             // of the batch in front (library stream) should get the CUs that come free first
             int lo = 0, hi = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            if (hipStreamCreateWithPriority(&q, hipStreamNonBlocking, lo) != hipSuccess) { (void)hipGetLastError(); HIPCHK(hipStreamCreate(&q)); }
+            static const bool spread = std::getenv("SQUID_IL_SPREAD") != nullptr && std::atoi(std::getenv("SQUID_IL_SPREAD")) != 0;
+            const int prio = spread && qi >= 4 ? (lo + hi) / 2 : lo;  // (experiment: the runtime keeps a pool of hardware queues per priority level)
+            if (hipStreamCreateWithPriority(&q, hipStreamNonBlocking, prio) != hipSuccess) { (void)hipGetLastError(); HIPCHK(hipStreamCreate(&q)); }
         }
-    if (!D.il_tok_stream) {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (hipStreamCreateWithPriority(&D.il_tok_stream, hipStreamNonBlocking, lo) != hipSuccess) { (void)hipGetLastError(); HIPCHK(hipStreamCreate(&D.il_tok_stream)); }
     }
-    for (auto& st : D.il_set) {
+    for (int qi = 0; qi < D.il_depth; ++qi) {
+        DeviceRecords::InflSet& st = D.il_set[qi];
         if (!st.ready) HIPCHK(hipEventCreateWithFlags(&st.ready, hipEventDisableTiming));
         if (!st.freed) HIPCHK(hipEventCreateWithFlags(&st.freed, hipEventDisableTiming));
         if (!st.copied) HIPCHK(hipEventCreateWithFlags(&st.copied, hipEventDisableTiming));
@@ -3396,7 +3404,9 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         while (batches.size() <= k) {
             const size_t at = plan_at;
             // the first batches are small, so that the GPU has work after a few milliseconds of index walk and copy
-            static const unsigned long long ramp0 = std::getenv("SQUID_TOK_RAMP_MB") ? (unsigned long long)std::atoll(std::getenv("SQUID_TOK_RAMP_MB")) : 128;
+            // (no ramp when the file is in HBM already: small batches only leave CUs empty for the length of a token wave)
+            static const unsigned long long ramp_env = std::getenv("SQUID_TOK_RAMP_MB") ? (unsigned long long)std::atoll(std::getenv("SQUID_TOK_RAMP_MB")) : 0;
+            const unsigned long long ramp0 = ramp_env ? ramp_env : (c->ingest_dfile ? 1024 : 128);
             const unsigned long long ramp = ramp0 << (20 + std::min<size_t>(batches.size(), 8)), bcap = std::min(cap, ramp);
             while (more_blocks && (blocks.size() <= at || blocks.back().uoff + blocks.back().isize - blocks[at].uoff <= bcap)) more_blocks = index_more(blocks);
             const size_t stop = more_blocks || b1 == (size_t)-1 ? blocks.size() : std::min(b1, blocks.size());
@@ -3421,8 +3431,8 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     auto stage_a = [&](size_t k) -> int {  // (SQ_OK also when there is no batch k)
         if (!plan(k)) return SQ_OK;
         const Batch B = batches[k];
-        DeviceRecords::InflSet& st = D.il_set[k % DeviceRecords::IL_DEPTH];
-        hipStream_t sa = D.il_stream[k % DeviceRecords::IL_DEPTH];
+        DeviceRecords::InflSet& st = D.il_set[k % (size_t)D.il_depth];
+        hipStream_t sa = D.il_stream[k % (size_t)D.il_depth];
         const int nb = (int)(B.end - B.at);
         // largest compressed blocks first: the lanes of a wave get blocks of similar length (a wave takes as long as its
         // longest lane) and the long waves start first
@@ -3431,7 +3441,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         std::stable_sort(st.host_tab.begin(), st.host_tab.end(), [](const InflBlock& x, const InflBlock& y) { return x.clen > y.clen; });
         unsigned long long tok_slots = 0;  // token slots of the batch: half a slot per inflated byte (t2_tok_cap), block after block in table order
         for (InflBlock& ib : st.host_tab) { ib.toff = tok_slots; tok_slots += t2_tok_cap(ib.isize); }
-        if (k >= (size_t)DeviceRecords::IL_DEPTH) HIPCHK(hipStreamWaitEvent(sa, st.freed, 0));  // the resolve of batch k - IL_DEPTH has read its tokens
+        if (k >= (size_t)D.il_depth) HIPCHK(hipStreamWaitEvent(sa, st.freed, 0));  // the resolve of batch k - IL_DEPTH has read its tokens
         const auto wa0 = std::chrono::steady_clock::now();
         // sized for a full batch at once (the first batches are small): growing a buffer later frees the old one, and freeing
         // device memory waits for the kernels of the other batches
@@ -3446,7 +3456,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         const double wa1 = since_ms(wa0);
         if (!dfile) {
             // (the copy no longer travels on the set's stream: the token pass and the resolve that last read this buffer are waited for here)
-            if (k >= (size_t)DeviceRecords::IL_DEPTH) HIPCHK(hipEventSynchronize(st.freed));
+            if (k >= (size_t)D.il_depth) HIPCHK(hipEventSynchronize(st.freed));
             const int rc = h2d_parallel(c, st.in.p, file + B.coff0, (size_t)B.cbytes);
             if (rc) return rc;
         }
@@ -3470,7 +3480,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         helper.f = std::async(std::launch::async, [&stage_a, c, k]() { if (hipSetDevice(c->P.device) != hipSuccess) return (int)SQ_E_HIP; return stage_a(k); });
         return SQ_OK;
     };
-    const size_t look = (size_t)DeviceRecords::IL_DEPTH - 1;  // batches queued ahead of the one being resolved
+    const size_t look = (size_t)D.il_depth - 1;  // batches queued ahead of the one being resolved
     { int rc = stage_a(0); if (rc) return rc; }
     for (size_t j = 1; j < look; ++j) { int rc = stage_a_async(j); if (rc) return rc; }
     const double w_first = since_ms(w0);
@@ -3486,7 +3496,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     Front fr[2];
     auto issue_front = [&](size_t k, unsigned long long carry_in, const uint8_t* carry_src) -> int {
         const Batch B = batches[k];
-        DeviceRecords::InflSet& st = D.il_set[k % DeviceRecords::IL_DEPTH];
+        DeviceRecords::InflSet& st = D.il_set[k % (size_t)D.il_depth];
         DeviceRecords::PostSet& P = D.il_post[k & 1];
         Front& F = fr[k & 1];
         int32_t* hk = D.il_host + 32 * (k & 1);  // [0..9] flags of the front, [10..13] of the token pass, [16..17] where the walk stopped
@@ -3582,8 +3592,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         if (k + 1 == batches.size() && report) std::fprintf(stderr, "GPU ingest: %llu bytes left incomplete at the end\n", carry);
     }
     HIPCHK(hipStreamSynchronize(sp));
-    for (auto& q : D.il_stream) HIPCHK(hipStreamSynchronize(q));
-    HIPCHK(hipStreamSynchronize(D.il_tok_stream));
+    for (auto& q : D.il_stream) if (q) HIPCHK(hipStreamSynchronize(q));
     if (feed) {
         { const int rc = helper.get(); if (rc) return rc; }
         feed->finish();
