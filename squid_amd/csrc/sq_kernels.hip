@@ -218,6 +218,7 @@ struct DeviceRecords {
     struct PostSet { DBuf<uint8_t> out; DBuf<long long> rec_sync, rec_end; DBuf<int32_t> rec_cnt, rec_base, flags, spine; DBuf<unsigned long long> bam_off; };
     PostSet il_post[2];
     hipStream_t il_parse_stream = nullptr;
+    std::future<void> warm;                // dev_create: the code object being loaded
     int32_t* il_host = nullptr;            // page-locked: the small results of the two sets (32 ints each)
     // host -> device copies of file bytes: four threads stage 16 MiB pieces through page-locked buffers (h2d_parallel)
     static constexpr int H2D_THREADS = 4;
@@ -2780,11 +2781,20 @@ int dev_create(sq_ctx* c) {
     HIPCHK(hipStreamCreate(&c->stream));
     c->dev = new DeviceRecords();
     HIPCHK(c->dev->flags.reserve(64));
+    // the runtime loads this library's code object for the device when the first of its kernels is asked for (tens of milliseconds for its
+    // hundred-odd kernels): asked for here, on a thread of its own, it loads while the caller reads its first file
+    const int device = c->P.device;
+    c->dev->warm = std::async(std::launch::async, [device]() {
+        if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return; }
+        hipFuncAttributes a;
+        if (hipFuncGetAttributes(&a, (const void*)k_lz_resolve3) != hipSuccess) (void)hipGetLastError();
+    });
     return SQ_OK;
 }
 
 void dev_destroy(sq_ctx* c) {
     if (!c->dev) return;
+    if (c->dev->warm.valid()) c->dev->warm.wait();
     DeviceRecords& D = *c->dev;
     D.refid.release(); D.pos.release(); D.mrefid.release(); D.mpos.release(); D.endpos.release(); D.b_refpos.release(); D.b_matchref.release();
     D.b_pack.release(); D.n_pack.release(); D.r_pack.release();
@@ -3077,13 +3087,19 @@ struct FileFeeder {
         for (int q = 0; q < NS; ++q) if (!D.feed_stream[q] && hipStreamCreateWithFlags(&D.feed_stream[q], hipStreamNonBlocking) != hipSuccess) { fail_with("hipStreamCreate"); bcv.notify_all(); return; }
         // the buffers (kept by the context: the next read finds them); the readers start with the first one that exists -- pinning 256 MiB
         // takes 50-80 ms the first time and would otherwise stand in front of a cold start's first copy
-        for (size_t i = 0; i < bufs.size(); ++i) {
-            if (!D.feed_pin[i / 2][i % 2] && hipHostMalloc((void**)&D.feed_pin[i / 2][i % 2], P, hipHostMallocDefault) != hipSuccess) { fail_with("hipHostMalloc"); bcv.notify_all(); return; }
-            if (!D.feed_buf_ev[i / 2][i % 2] && hipEventCreateWithFlags(&D.feed_buf_ev[i / 2][i % 2], hipEventDisableTiming) != hipSuccess) { fail_with("hipEventCreate"); bcv.notify_all(); return; }
+        // (... so they are made one per turn of the loop below, between the copies of the pieces that the first ones already carry)
+        size_t made = 0;
+        auto make_buffer = [&]() -> bool {
+            const size_t i = made;
+            if (!D.feed_pin[i / 2][i % 2] && hipHostMalloc((void**)&D.feed_pin[i / 2][i % 2], P, hipHostMallocDefault) != hipSuccess) { fail_with("hipHostMalloc"); bcv.notify_all(); return false; }
+            if (!D.feed_buf_ev[i / 2][i % 2] && hipEventCreateWithFlags(&D.feed_buf_ev[i / 2][i % 2], hipEventDisableTiming) != hipSuccess) { fail_with("hipEventCreate"); bcv.notify_all(); return false; }
             bufs[i].p = D.feed_pin[i / 2][i % 2];
             { std::lock_guard<std::mutex> lk(bmu); free_bufs.push_back((int)i); }
             bcv.notify_all();
-        }
+            ++made;
+            return true;
+        };
+        for (int i = 0; i < 2 && made < bufs.size(); ++i) if (!make_buffer()) return;
         // copies on one stream finish in order: only the oldest copy of every stream is asked about (a poll of all thirty-two buffers
         // every few microseconds kept the runtime's lock busy for the thread that launches the kernels)
         // few copies queued at a time: the small device -> host read-backs of the batch loop (flags, record counts) travel on the same DMA
@@ -3093,9 +3109,10 @@ struct FileFeeder {
         std::deque<int> waiting;  // filled, not yet queued
         size_t done = 0, rr = 0, n_inflight = 0;
         while (done < npieces && !abort.load() && !failed.load()) {
+            if (made < bufs.size() && !make_buffer()) return;
             {
                 std::unique_lock<std::mutex> lk(bmu);
-                if (filled_bufs.empty() && (waiting.empty() || n_inflight >= max_inflight)) bcv.wait_for(lk, std::chrono::microseconds(n_inflight ? 50 : 500));
+                if (made == bufs.size() && filled_bufs.empty() && (waiting.empty() || n_inflight >= max_inflight)) bcv.wait_for(lk, std::chrono::microseconds(n_inflight ? 50 : 500));
                 for (int bi : filled_bufs) waiting.push_back(bi);
                 filled_bufs.clear();
             }
@@ -3397,6 +3414,8 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     struct FeedGuard { std::unique_ptr<FileFeeder>& f; ~FeedGuard() { if (f) f->cancel(); } } feed_guard{feed};  // (every way out stops the threads)
     struct Batch { size_t at, end; unsigned long long coff0, cbytes, bbase, bbytes; };
     std::vector<Batch> batches;
+    std::mutex bm;  // `batches` and `blocks` grow on the planner thread (below); the batch loop reads them through batch_of()
+    auto batch_of = [&](size_t k) { std::lock_guard<std::mutex> lk(bm); return batches[k]; };
     // batches are planned as they are needed: with index_more the block index itself grows batch by batch (b1 = npos)
     bool more_blocks = (bool)index_more;
     size_t plan_at = b0;
@@ -3408,12 +3427,17 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
             static const unsigned long long ramp_env = std::getenv("SQUID_TOK_RAMP_MB") ? (unsigned long long)std::atoll(std::getenv("SQUID_TOK_RAMP_MB")) : 0;
             const unsigned long long ramp0 = ramp_env ? ramp_env : (c->ingest_dfile ? 1024 : 128);
             const unsigned long long ramp = ramp0 << (20 + std::min<size_t>(batches.size(), 8)), bcap = std::min(cap, ramp);
-            while (more_blocks && (blocks.size() <= at || blocks.back().uoff + blocks.back().isize - blocks[at].uoff <= bcap)) more_blocks = index_more(blocks);
+            while (more_blocks && (blocks.size() <= at || blocks.back().uoff + blocks.back().isize - blocks[at].uoff <= bcap)) {
+                std::vector<BgzfRange> got;  // (the wait for the walk happens outside the lock)
+                more_blocks = index_more(got);
+                std::lock_guard<std::mutex> lk(bm);
+                blocks.insert(blocks.end(), got.begin(), got.end());
+            }
             const size_t stop = more_blocks || b1 == (size_t)-1 ? blocks.size() : std::min(b1, blocks.size());
             if (at >= stop) return false;
             size_t end = at;
             while (end < stop && (end == at || blocks[end].uoff + blocks[end].isize - blocks[at].uoff <= bcap)) ++end;
-            batches.push_back(Batch{at, end, blocks[at].coff, blocks[end - 1].coff + blocks[end - 1].clen - blocks[at].coff, blocks[at].uoff, blocks[end - 1].uoff + blocks[end - 1].isize - blocks[at].uoff});
+            { std::lock_guard<std::mutex> lk(bm); batches.push_back(Batch{at, end, blocks[at].coff, blocks[end - 1].coff + blocks[end - 1].clen - blocks[at].coff, blocks[at].uoff, blocks[end - 1].uoff + blocks[end - 1].isize - blocks[at].uoff}); }
             plan_at = end;
         }
         return true;
@@ -3421,6 +3445,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     const unsigned long long first_uoff = blocks[b0].uoff;
     // inflated size of the whole range, for sizing the record arrays once: exact with a full index, else from the file size
     auto range_bytes_estimate = [&]() -> unsigned long long {
+        std::lock_guard<std::mutex> lk(bm);
         if (!index_more) { const size_t e = std::min(b1, blocks.size()); return blocks[e - 1].uoff + blocks[e - 1].isize - first_uoff; }
         const BgzfRange &f = blocks.front(), &l = blocks.back();  // (a .bai shard's walk starts in the middle of the file: ratio over the walked part only)
         const double ratio = (double)(l.uoff + l.isize - f.uoff) / (double)std::max<unsigned long long>(1, l.coff + l.clen - f.coff);
@@ -3460,8 +3485,11 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
             const int rc = h2d_parallel(c, st.in.p, file + B.coff0, (size_t)B.cbytes);
             if (rc) return rc;
         }
-        if (report && k < 3) std::fprintf(stderr, "GPU ingest: batch %zu planned at %.1f ms, buffers %.1f ms, copy of %.2f GB returned after %.1f ms\n", k, std::chrono::duration<double, std::milli>(wa0 - w0).count(), wa1, (double)B.cbytes * 1e-9, since_ms(wa0) - wa1);
+        const double wa2 = since_ms(wa0);
         if (feed) { const int rc = feed->wait_bytes((size_t)B.coff0, (size_t)(B.coff0 + B.cbytes) + 256, sa); if (rc) return rc; }  // the token pass waits for its own pieces only
+        const double wa3 = since_ms(wa0);
+        struct Rep { bool on; size_t k; double at, a1, a2, a3, gb; std::chrono::steady_clock::time_point t0; ~Rep() { if (on) std::fprintf(stderr, "GPU ingest: batch %zu planned at %.1f ms, buffers %.1f ms, copy of %.2f GB returned after %.1f ms, its pieces queued after %.1f ms, table + token pass queued after %.1f ms\n", k, at, a1, gb, a2 - a1, a3 - a2, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() - a3); } }
+            rep{report && k < 3, k, std::chrono::duration<double, std::milli>(wa0 - w0).count(), wa1, wa2, wa3, (double)B.cbytes * 1e-9, wa0};
         HIPCHK(hipMemcpyAsync(st.tab.p, st.host_tab.data(), (size_t)nb * sizeof(InflBlock), hipMemcpyHostToDevice, sa));
         HIPCHK(hipMemsetAsync(st.flags.p, 0, 4 * 4, sa));
         {   // k_inflate_tok2 stays on the set's own stream: the token kernels of up to four batches run side by side
@@ -3472,17 +3500,39 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         HIPCHK(hipEventRecord(st.ready, sa));
         return SQ_OK;
     };
-    // stage A runs on a helper thread (one at a time): the copy of pageable memory blocks its caller for its whole duration
-    struct Joined { std::future<int> f; int get() { return f.valid() ? f.get() : SQ_OK; } ~Joined() { if (f.valid()) (void)f.get(); } } helper;
-    auto stage_a_async = [&](size_t k) -> int {
-        int rc = helper.get();  // the one before (it reads `batches` and `blocks`: nothing of those changes while it runs)
-        if (rc || !plan(k)) return rc;
-        helper.f = std::async(std::launch::async, [&stage_a, c, k]() { if (hipSetDevice(c->P.device) != hipSuccess) return (int)SQ_E_HIP; return stage_a(k); });
-        return SQ_OK;
+    // Stage A runs on a planner thread, batch after batch, as far ahead of the batch loop as there are buffer sets: set k % depth is free
+    // for batch k once the resolve of batch k - depth has been QUEUED (its `freed` event is recorded by issue_front).  The thread blocks
+    // where stage A blocks -- in the header walk, in the wait for a batch's file pieces to be queued for copy, in the copy of pageable
+    // memory -- and the batch loop does not: round 4's first form queued depth - 1 batches before the first resolve, which with eight sets
+    // meant waiting for 40 % of a streamed file before anything was resolved.
+    std::mutex pm;
+    std::condition_variable pcv;
+    size_t staged = 0, fronts = 0;  // (pm) batches through stage A; issue_front calls made
+    bool planner_over = false, planner_stop = false;
+    int planner_rc = SQ_OK;
+    std::thread planner([&]() {
+        int rc = hipSetDevice(c->P.device) == hipSuccess ? SQ_OK : (int)SQ_E_HIP;
+        for (size_t k = 0; rc == SQ_OK; ++k) {
+            { std::unique_lock<std::mutex> lk(pm); pcv.wait(lk, [&]() { return planner_stop || k < fronts + (size_t)D.il_depth; }); if (planner_stop) break; }
+            if (!plan(k)) break;
+            rc = stage_a(k);
+            if (rc == SQ_OK) { std::lock_guard<std::mutex> lk(pm); staged = k + 1; }
+            pcv.notify_all();
+        }
+        { std::lock_guard<std::mutex> lk(pm); planner_rc = rc; planner_over = true; }
+        pcv.notify_all();
+    });
+    // (declared behind feed_guard: runs first on every way out -- the feeder is cancelled here too, so that a planner blocked in it returns)
+    struct PlannerGuard { std::thread& t; std::mutex& m; std::condition_variable& cv; bool& stop; std::unique_ptr<FileFeeder>& f; bool& over;
+        ~PlannerGuard() { bool done; { std::lock_guard<std::mutex> lk(m); stop = true; done = over; } cv.notify_all(); if (!done && f) f->cancel(); if (t.joinable()) t.join(); } } planner_guard{planner, pm, pcv, planner_stop, feed, planner_over};
+    auto wait_staged = [&](size_t k) -> int {  // 1: batch k is through stage A; 0: there is no batch k; < 0 / 2: stage A failed
+        std::unique_lock<std::mutex> lk(pm);
+        pcv.wait(lk, [&]() { return staged > k || planner_over; });
+        if (staged > k) return 1;
+        return planner_rc > 0 ? (int)SQ_E_HIP : planner_rc;  // (error codes are negative)
     };
-    const size_t look = (size_t)D.il_depth - 1;  // batches queued ahead of the one being resolved
-    { int rc = stage_a(0); if (rc) return rc; }
-    for (size_t j = 1; j < look; ++j) { int rc = stage_a_async(j); if (rc) return rc; }
+    auto front_issued = [&]() { { std::lock_guard<std::mutex> lk(pm); ++fronts; } pcv.notify_all(); };
+    { const int r = wait_staged(0); if (r <= 0) return r; }
     const double w_first = since_ms(w0);
     // Everything behind the token pass is double-buffered (DeviceRecords::PostSet): the front of batch k + 1 -- resolve, slice
     // boundaries -- is queued on the library stream before batch k is parsed on the parse stream, so the two overlap; in round 1
@@ -3495,7 +3545,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     struct Front { unsigned long long pad = 0, carry = 0, limit = 0; long long nsl = 0; RecScan S{}; };
     Front fr[2];
     auto issue_front = [&](size_t k, unsigned long long carry_in, const uint8_t* carry_src) -> int {
-        const Batch B = batches[k];
+        const Batch B = batch_of(k);
         DeviceRecords::InflSet& st = D.il_set[k % (size_t)D.il_depth];
         DeviceRecords::PostSet& P = D.il_post[k & 1];
         Front& F = fr[k & 1];
@@ -3516,6 +3566,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
             else hipLaunchKernelGGL(k_lz_resolve2, dim3(nb), dim3(128), 65536 + 16, s, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, out, P.flags.p);
         }
         HIPCHK(hipEventRecord(st.freed, s));
+        front_issued();
         F.S = RecScan{P.out.p, k == 0 ? (unsigned long long)begin : F.pad, F.limit, nref, sh.on ? sh.first_ref : -1, sh.on ? sh.end_ref : 0, (sh.on && c->P.rank == c->P.world_size - 1) ? 1 : 0};
         F.nsl = F.S.limit > F.S.begin ? (long long)((F.S.limit - F.S.begin + REC_SLICE - 1) / REC_SLICE) : 0;
         hk[16] = 0; hk[17] = 0;
@@ -3538,11 +3589,8 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     };
     long check_bad = 0;
     { int rc = issue_front(0, 0, nullptr); if (rc) { (void)give_up(); return rc; } }
-    for (size_t k = 0; k < batches.size(); ++k) {
-        // the copy of batch k+2 and its token pass (queued behind that of batch k+1) go out first: the host blocks in the copy
-        // while the GPU works on the batches before
-        { int rc = stage_a_async(k + look); if (rc) { (void)give_up(); return rc; } }
-        const Batch B = batches[k];
+    for (size_t k = 0;; ++k) {
+        const Batch B = batch_of(k);
         DeviceRecords::PostSet& P = D.il_post[k & 1];
         const Front F = fr[k & 1];
         const int32_t* hk = D.il_host + 32 * (k & 1);
@@ -3557,7 +3605,8 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
             std::vector<uint8_t> got((size_t)B.bbytes), want;
             HIPCHK(hipMemcpy(got.data(), out, (size_t)B.bbytes, hipMemcpyDeviceToHost));
             for (size_t i = B.at; i < B.end; ++i) {
-                const BgzfRange& b = blocks[i];
+                BgzfRange b;
+                { std::lock_guard<std::mutex> lk(bm); b = blocks[i]; }
                 want.resize(b.isize);
                 z_stream zs; std::memset(&zs, 0, sizeof zs);
                 inflateInit2(&zs, -15);
@@ -3575,7 +3624,9 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         // batch is parsed
         const unsigned long long tail_at = tail > 0 ? (unsigned long long)tail : F.S.begin;
         const unsigned long long carry = F.limit > tail_at ? F.limit - tail_at : 0;
-        if (plan(k + 1)) { int rc = issue_front(k + 1, carry, P.out.p + tail_at); if (rc) { (void)give_up(); return rc; } }
+        const int has_next = wait_staged(k + 1);
+        if (has_next < 0) { (void)give_up(); return has_next; }
+        if (has_next) { int rc = issue_front(k + 1, carry, P.out.p + tail_at); if (rc) { (void)give_up(); return rc; } }
         const int64_t n_rec = h[8];
         if (n_rec > 0) {
             HIPCHK(P.bam_off.reserve((size_t)n_rec));
@@ -3589,12 +3640,12 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
                 if (rc) { (void)give_up(); return rc; }
             }
         }
-        if (k + 1 == batches.size() && report) std::fprintf(stderr, "GPU ingest: %llu bytes left incomplete at the end\n", carry);
+        if (!has_next) { if (report) std::fprintf(stderr, "GPU ingest: %llu bytes left incomplete at the end\n", carry); break; }
     }
+    planner.join();  // (over: the loop above ended on its word)
     HIPCHK(hipStreamSynchronize(sp));
     for (auto& q : D.il_stream) if (q) HIPCHK(hipStreamSynchronize(q));
     if (feed) {
-        { const int rc = helper.get(); if (rc) return rc; }
         feed->finish();
         if (feed->failed.load()) return fail(c, SQ_E_IO, feed->error());
         if (report) {
