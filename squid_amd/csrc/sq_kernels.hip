@@ -2093,12 +2093,14 @@ __device__ __forceinline__ void lens_put(LensOut& o, int v) {
     ++o.n;
 }
 __device__ __forceinline__ void lens_flush(LensOut& o) { if (o.n & 7) o.w[(o.n >> 3) * 64] = o.acc; }
-struct LensIn { const uint32_t* w; uint32_t acc; int i; };
-__device__ __forceinline__ void lens_seek(LensIn& r, const uint32_t* w, int at) { r.w = w; r.i = at; r.acc = (at & 7) ? w[(at >> 3) * 64] : 0u; }
+// (read one word ahead: the builder spends three LDS round trips on a symbol, and a word asked for when its first symbol is needed costs a
+// memory round trip per eight symbols on top; the word behind a strip's last one belongs to the next strip or to the slack behind the last)
+struct LensIn { const uint32_t* w; uint32_t acc, nxt; int i; };
+__device__ __forceinline__ void lens_seek(LensIn& r, const uint32_t* w, int at) { r.w = w; r.i = at; r.acc = w[(at >> 3) * 64]; r.nxt = w[((at >> 3) + 1) * 64]; }
 __device__ __forceinline__ int lens_get(LensIn& r) {
-    if ((r.i & 7) == 0) r.acc = r.w[(r.i >> 3) * 64];
     const int v = (int)((r.acc >> ((r.i & 7) << 2)) & 15u);
     ++r.i;
+    if ((r.i & 7) == 0) { r.acc = r.nxt; r.nxt = r.w[((r.i >> 3) + 1) * 64]; }
     return v;
 }
 // canonical tables of one code.  In: cnt[l * 64 + lane] = number of symbols of length l (l = 1..15; cnt may BE ktab), get(i) = length
@@ -2331,7 +2333,7 @@ __global__ __launch_bounds__(320, 1) void k_inflate_tok2(const uint8_t* file, co
             if (__any(me && kind > 0)) {
                 // the distance code first: its counts sit in nl_ll, which the literal/length build then takes for its own use
                 const bool bld = me && kind > 0;
-                LensIn ri{lens_w, 0, 0};
+                LensIn ri{lens_w, 0, 0, 0};
                 if (bld) lens_seek(ri, lens_w, nlen);
                 const bool ok_dd = t2_build<false>(L, lane, bld, ndist, L.nl_ll, [&](int) { return lens_get(ri); }, lp_dd, L.sym_dd, L.k_dd);
                 if (bld) lens_seek(ri, lens_w, 0);
@@ -3477,7 +3479,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         st.src = dfile ? dfile + B.coff0 : st.in.p;
         HIPCHK(st.tab.reserve(std::max((size_t)nb, (size_t)(full / 60000)))); HIPCHK(st.flags.reserve(4));
         HIPCHK(st.tok.reserve(std::max((size_t)tok_slots, (size_t)(full / 2 + 80 * (full / 60000 + 1))) + 64)); HIPCHK(st.ntok.reserve(std::max((size_t)nb, (size_t)(full / 60000))));
-        HIPCHK(st.lens.reserve((std::max((size_t)nb, (size_t)(full / 60000)) + 64) * T2_LENS_WORDS));  // (one strip of code lengths per lane of the token pass)
+        HIPCHK(st.lens.reserve((std::max((size_t)nb, (size_t)(full / 60000)) + 128) * T2_LENS_WORDS));  // (one strip of code lengths per lane of the token pass)
         const double wa1 = since_ms(wa0);
         if (!dfile) {
             // (the copy no longer travels on the set's stream: the token pass and the resolve that last read this buffer are waited for here)
