@@ -3526,7 +3526,12 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     });
     // (declared behind feed_guard: runs first on every way out -- the feeder is cancelled here too, so that a planner blocked in it returns)
     struct PlannerGuard { std::thread& t; std::mutex& m; std::condition_variable& cv; bool& stop; std::unique_ptr<FileFeeder>& f; bool& over;
-        ~PlannerGuard() { bool done; { std::lock_guard<std::mutex> lk(m); stop = true; done = over; } cv.notify_all(); if (!done && f) f->cancel(); if (t.joinable()) t.join(); } } planner_guard{planner, pm, pcv, planner_stop, feed, planner_over};
+        ~PlannerGuard() {
+            bool done; { std::lock_guard<std::mutex> lk(m); stop = true; done = over; } cv.notify_all();
+            if (!done && f) f->cancel();
+            if (t.joinable()) t.join();
+            if (!done) (void)hipDeviceSynchronize();  // (given up half way: what the thread queued last reads buffers the caller is about to reuse)
+        } } planner_guard{planner, pm, pcv, planner_stop, feed, planner_over};
     auto wait_staged = [&](size_t k) -> int {  // 1: batch k is through stage A; 0: there is no batch k; < 0 / 2: stage A failed
         std::unique_lock<std::mutex> lk(pm);
         pcv.wait(lk, [&]() { return staged > k || planner_over; });
@@ -3563,7 +3568,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         uint8_t* out = P.out.p + F.pad + carry_in;
         HIPCHK(hipStreamWaitEvent(s, st.ready, 0));
         {
-            EvTimer t2(c, "k_lz_resolve2", (double)B.bbytes * 3);
+            EvTimer t2(c, resolve_global ? "k_lz_resolve3" : "k_lz_resolve2", (double)B.bbytes * 3);
             if (resolve_global) hipLaunchKernelGGL(k_lz_resolve3, dim3(nb), dim3(64), 0, s, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, out, P.flags.p);
             else hipLaunchKernelGGL(k_lz_resolve2, dim3(nb), dim3(128), 65536 + 16, s, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, out, P.flags.p);
         }

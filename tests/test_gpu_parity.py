@@ -956,8 +956,8 @@ def _rebgzf(src, dst, plan):
 
 
 def test_gpu_bgzf_inflate_and_boundary_search_give_the_same_records(built, synth, tmp_path):
-    """SQUID_GPU_INFLATE=1: BGZF blocks inflated by k_inflate_tok2 + k_lz_resolve2, record boundaries found by k_rec_*,
-    against the default host pipeline -- identical SoA.  Also: one block per token batch, single-wave token workgroups, and the
+    """SQUID_GPU_INFLATE=1: BGZF blocks inflated by k_inflate_tok2 + k_lz_resolve3 (or k_lz_resolve2), record boundaries found by k_rec_*,
+    against the default host pipeline -- identical SoA.  Also: one block per token batch, five-wave token workgroups, and the
     same file rewritten with stored blocks, the fixed Huffman code, and all block types mixed inside one wave"""
     import json
     import os
@@ -979,7 +979,12 @@ def test_gpu_bgzf_inflate_and_boundary_search_give_the_same_records(built, synth
     gpu = {"SQUID_GPU_INFLATE": "1", "SQUID_INGEST_TIMING": "1"}
     assert run(f"{pre}.bam", gpu) == want
     assert run(f"{pre}.bam", dict(gpu, SQUID_TOK_CAP_MB="0")) == want
-    assert run(f"{pre}.bam", dict(gpu, SQUID_TOK_WPB="1")) == want
+    assert run(f"{pre}.bam", dict(gpu, SQUID_TOK_WPB="5")) == want
+    # the LDS-window resolve (k_lz_resolve2; the default is k_lz_resolve3, which keeps its window in HBM), three buffer sets, and a runtime
+    # left at its four hardware queues
+    assert run(f"{pre}.bam", dict(gpu, SQUID_RESOLVE_GLOBAL="0")) == want
+    assert run(f"{pre}.bam", dict(gpu, SQUID_RESOLVE_GLOBAL="0", SQUID_TOK_CAP_MB="0")) == want
+    assert run(f"{pre}.bam", dict(gpu, SQUID_IL_DEPTH="3", SQUID_TOK_CAP_MB="0", GPU_MAX_HW_QUEUES="4")) == want
     # a chromosome shard reads a block range that starts and ends inside records
     names, _ = squid_amd.read_header(f"{pre}.bam")
     n = len(names)
@@ -1002,11 +1007,11 @@ def test_gpu_bgzf_inflate_and_boundary_search_give_the_same_records(built, synth
         _rebgzf(f"{pre}.bam", alt, plan)
         assert run(alt, {}) == want, name
         assert run(alt, gpu) == want, name
-        assert run(alt, dict(gpu, SQUID_TOK_WPB="1")) == want, name
+        assert run(alt, dict(gpu, SQUID_TOK_WPB="3", SQUID_RESOLVE_GLOBAL="0")) == want, name
 
 
 def test_gpu_reader_end_to_end_against_the_oracle(built, synth, tmp_path):
-    """the GPU reader (k_inflate_tok2, k_lz_resolve2, k_rec_*, K0) feeding the whole pipeline, checked against the
+    """the GPU reader (k_inflate_tok2, k_lz_resolve3, k_rec_*, K0) feeding the whole pipeline, checked against the
     ORACLE (which reads the files with its own zlib-based BAM reader) -- not only against the library's host reader: `squid`
     with SQUID_GPU_INFLATE=1 on the generator's file and on the same records re-compressed as stored blocks, with the fixed
     Huffman code and with every block type mixed inside one wave; _sv.txt and _graph.txt byte for byte"""

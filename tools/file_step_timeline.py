@@ -4,6 +4,9 @@ import os, subprocess, sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
+if os.environ.get("WITH_TORCH"):
+    import torch
+    torch.cuda.init(); torch.zeros(8, device="cuda:0"); torch.cuda.synchronize()
 import squid_amd
 pre = sys.argv[1] if len(sys.argv) > 1 else "/tmp/squid_bench/C3_s20180003"
 os.environ["SQUID_INGEST_TIMING"] = "1"
