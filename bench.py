@@ -46,7 +46,10 @@ import tempfile
 import time
 from pathlib import Path
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before torch's first HIP call: the ingest overlaps up to eight kernels (squid_amd/csrc/sq_kernels.hip, HwQueueRequest)
+# before torch's first HIP call: the ingest overlaps up to eight kernels (squid_amd/csrc/sq_kernels.hip, HwQueueRequest).  Ranks that share ONE
+# GPU (SQUID_DIST_BACKEND=gloo, a functional check) stay at the runtime's four: two processes with eight queues per priority level
+# oversubscribe the device's queue slots and get time-sliced (C3 as two shards on one GPU: 404 ms per step against 159)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4" if os.environ.get("SQUID_DIST_BACKEND") == "gloo" else "8")
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))

@@ -193,6 +193,7 @@ static int build_graph_bwa(sq_ctx* c) {
     return finish_graph(c, host_filters);
 }
 
+static void drop_early_clusters(sq_ctx* c) { c->plan_early.reset(); c->disc_early.clear(); c->disc_early.shrink_to_fit(); c->clusters_early_ms = -1; }
 static int build_graph(sq_ctx* c) {
     HostClock wall(c, "wall_build_graph");
     Shard& sh = c->shard;
@@ -204,7 +205,13 @@ static int build_graph(sq_ctx* c) {
         c->graph_built = false;
         c->ordered = false;
         // the cluster table only needs the chimeric fragments: build it on a second thread next to the record kernels
-        g.clusters = c->pool->submit([c, &g]() { return segment_clusters(c, g.plan, g.disc); });
+        if (c->clusters_early_ms >= 0 && c->plan_early) {  // (built beside the ingest: sq_ingest_files)
+            g.plan = std::move(c->plan_early); g.disc.swap(c->disc_early);
+            std::promise<double> done;
+            done.set_value(c->clusters_early_ms);
+            g.clusters = done.get_future();
+            drop_early_clusters(c);
+        } else g.clusters = c->pool->submit([c, &g]() { return segment_clusters(c, g.plan, g.disc); });
         int32_t last[4];
         rc = dev_classify(c, sh.on ? last : nullptr);
         if (rc) { (void)g.clusters.get(); return rc; }
@@ -779,6 +786,7 @@ void sq_destroy(sq_ctx* c) {
 int sq_set_references(sq_ctx* c, int32_t n_ref, const int32_t* ref_len) {
     if (!c || n_ref < 0 || (n_ref && !ref_len)) return SQ_E_ARG;
     c->ref_len.assign(ref_len, ref_len + n_ref);
+    drop_early_clusters(c);
     return SQ_OK;
 }
 // frags0 = frags, side by side (millions of fragments on a dense sample; sq_reset copies the other way)
@@ -793,6 +801,7 @@ static void copy_frags(sq_ctx* c, const std::vector<Frag>& src, std::vector<Frag
 }
 int sq_ingest_chimeric(sq_ctx* c, const sq_aln_batch* b) {
     if (!c || !b) return SQ_E_ARG;
+    drop_early_clusters(c);
     int rc = build_fragments(c, b);
     if (rc) return rc;
     copy_frags(c, c->frags, c->frags0);
@@ -885,6 +894,7 @@ int sq_read_header(const char* path, int32_t* n_ref, int32_t* ref_len, char* nam
 // `early` (sq_ingest_files): as soon as the records are decoded, the device gets the table of all their usable QNAMEs and the promise
 // the record parse of the concordant BAM waits for is kept -- the pairing goes on meanwhile
 static int chimeric_file_to_fragments(sq_ctx* c, const char* path, int nt, std::string& err, bool early = false) {
+    drop_early_clusters(c);
     ParseOpts o{c->P.phred_type, c->P.min_phred, c->P.max_lowphred_len, true, nullptr};
     bool got = false, promised = false;
     auto promise = [&](int rc) { if (early && !promised) { promised = true; c->chim_names_promise.set_value(rc); } };
@@ -915,6 +925,10 @@ static int chimeric_file_to_fragments(sq_ctx* c, const char* path, int nt, std::
     promise(rc ? rc : SQ_OK);  // (whatever happened: nobody waits for ever)
     if (rc) return rc;
     copy_frags(c, c->frags, c->frags0);
+    if (early && !c->ref_len.empty()) {  // this thread has nothing else to do, the concordant file is still being read
+        c->plan_early.reset(); c->disc_early.clear();
+        c->clusters_early_ms = segment_clusters(c, c->plan_early, c->disc_early);
+    }
     return SQ_OK;
 }
 // BuildChimericSBamRecord on a context that has no device side (the junction-sequence utility): c->frags0
@@ -1250,6 +1264,7 @@ int sq_reset(sq_ctx* c) {
     if (!c) return SQ_E_ARG;
     if (c->bp_future.valid()) (void)c->bp_future.get();
     copy_frags(c, c->frags0, c->frags);  // the graph stages trim the chimeric blocks in place, like the reference does
+    drop_early_clusters(c);
     c->nodes.clear(); c->edges.clear(); c->label.clear();
     c->graph_built = false; c->ordered = false;
     c->bp_off.clear();

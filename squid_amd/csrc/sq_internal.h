@@ -160,6 +160,7 @@ struct Shard {
     int64_t n_break_global = 0;
 };
 struct GraphBuild;  // locals of sq_build_graph that survive an exchange (sq_capi.cpp)
+struct SegPlan;     // sq_segment.cpp
 struct RcclTransport;  // sq_exchange.cpp
 void exchange_release(sq_ctx* c);
 struct SvBuild;     // same for sq_call_sv
@@ -219,6 +220,12 @@ struct sq_ctx {
     std::future<int> chim_future;  // sq_ingest_files: the chimeric decode running next to the concordant ingest (chim_join)
     std::shared_ptr<std::map<uint64_t, std::vector<std::pair<int, int>>>> bp_early;
     double bp_early_ms = 0;
+    // the discordant-cluster table (segment_clusters) only needs the chimeric fragments: sq_ingest_files builds it on the chimeric helper
+    // thread while the concordant file is still being read, and the first sq_build_graph after the ingest takes it (sq_reset drops it: a
+    // graph pass over resident records builds its own)
+    std::shared_ptr<sq::SegPlan> plan_early;
+    std::vector<sq::Blk> disc_early;
+    double clusters_early_ms = -1;  // < 0: none
     std::shared_ptr<sq::GraphBuild> gb;
     std::shared_ptr<sq::SvBuild> svb;
     std::vector<uint8_t> xbuf;                 // this rank's contribution
@@ -237,7 +244,15 @@ int fail(sq_ctx* c, int code, const std::string& msg);
 struct HostClock {  // wall clock of a host stage into the context's timing table
     sq_ctx* c; const char* name; std::chrono::steady_clock::time_point t0;
     HostClock(sq_ctx* c, const char* name) : c(c), name(name), t0(std::chrono::steady_clock::now()) {}
-    ~HostClock() { c->timer.add(name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
+    ~HostClock() {
+        const auto t1 = std::chrono::steady_clock::now();
+        c->timer.add(name, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        static const bool trace = std::getenv("SQUID_HOST_TRACE") != nullptr;  // one line per stage: start (since the first stage of the process) and length
+        if (trace) {
+            static const std::chrono::steady_clock::time_point origin = t0;
+            std::fprintf(stderr, "[host %10.3f ms] %-28s %8.3f ms\n", std::chrono::duration<double, std::milli>(t0 - origin).count(), name, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        }
+    }
 };
 // waits for the chimeric decode started by sq_ingest_files and uploads its QNAME set; called in front of the first record parse
 int chim_join(sq_ctx* c);
