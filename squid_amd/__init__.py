@@ -16,7 +16,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 BUILD = ROOT / "build"
-LIB_PATH = BUILD / "libsquid_hip.so"
+LIB_PATH = Path(os.environ["SQUID_LIB"]) if os.environ.get("SQUID_LIB") else BUILD / "libsquid_hip.so"  # (SQUID_LIB: another build of the same library, for A/B runs)
 
 EXPORTS = [
     "sq_default_params", "sq_create", "sq_destroy", "sq_strerror", "sq_last_error", "sq_set_references",

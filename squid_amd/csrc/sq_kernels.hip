@@ -2008,7 +2008,10 @@ __constant__ uint8_t c_clorder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 1
 constexpr int IL_STAGE = 4;
 // headers are read and tables are built by every lane for itself, in lockstep with the other lanes that are at a block header: zlib
 // closes a block every 16383 symbols, so the lanes of a wave arrive together (a lane that is early waits up to IL_HDR_WAIT steps)
-constexpr int IL_HDR_WAIT = 48;
+#ifndef SQ_IL_HDR_WAIT
+#define SQ_IL_HDR_WAIT 48
+#endif
+constexpr int IL_HDR_WAIT = SQ_IL_HDR_WAIT;
 // The compressed bytes of a lane go through a ring of IL_RING words in LDS (ring[(word % IL_RING) * 64], already offset
 // by the lane): the bit buffer refills from LDS, and the ring is topped up from global memory by all lanes in the same
 // step, when any of them runs low.  A load issued by one lane in one step would otherwise make the whole wave wait a
@@ -2065,7 +2068,10 @@ __device__ __forceinline__ uint32_t il_take(ILane& b, int k) {
 // stays in LDS per lane: the symbol permutation as bytes (288 + 32; a literal/length symbol >= 256 is told from its rank inside
 // its length group, where the literals come first), three 16-entry tables, the input ring and the token stage (the sizes: "Round 4"
 // below) -- several waves per CU, and a step is two LDS round trips per code instead of up to nine.
-constexpr int T2_SYM_LL = 288, T2_SYM_DD = 32, T2_LITS = 4;
+#ifndef SQ_T2_LITS
+#define SQ_T2_LITS 4
+#endif
+constexpr int T2_SYM_LL = 288, T2_SYM_DD = 32, T2_LITS = SQ_T2_LITS;
 // Round 4: 496 bytes per lane (round 3: 746).  What went: the 4-bit code lengths of a header (170 B) -- they are only needed between
 // reading a header and scattering its symbols, once per ~16 k symbols, and now travel through a per-lane strip of GLOBAL memory, eight
 // to a word, written and read back sequentially (T2_LENS_WORDS words per lane; a wave's word k lies side by side: [k * 64 + lane]);

@@ -11,7 +11,7 @@ if not Path(f"{pre}.bam").exists():
     subprocess.check_call([str(ROOT / "build" / "gen_synth_bam"), "--config", "C3", "--records", str(rec), "--out", str(pre), "--threads", str(os.cpu_count() or 8)], stdout=subprocess.DEVNULL)
 with squid_amd.Context() as ctx:
     ctx.load(f"{pre}.bam", f"{pre}.chim.bam", threads=16)
-    for ab in (1, 2, 3, 4, 5, 0):
+    for ab in (1, 2, 3, 4, 5, 6, 9, 7, 8, 10, 0):
         os.environ["SQUID_P1_ABLATE"] = str(ab)
         ms = []
         for it in range(4):
