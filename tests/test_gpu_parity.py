@@ -1183,12 +1183,15 @@ def test_damaged_files_are_reported_by_both_readers(built, synth, tmp_path):
         bam = tmp_path / f"{name}.bam"
         bam.write_bytes(blob)
         outs = []
-        for mode in ("0", "1"):
-            p = subprocess.run([sys.executable, "-c", code, str(bam)], env=dict(os.environ, SQUID_GPU_INFLATE=mode), capture_output=True, text=True, check=True)
+        # (the third run: one block per token batch, so the damage sits in a batch far behind the first and the planner thread of the
+        # reader is several batches ahead of the batch loop when it is found)
+        for env in ({"SQUID_GPU_INFLATE": "0"}, {"SQUID_GPU_INFLATE": "1"}, {"SQUID_GPU_INFLATE": "1", "SQUID_TOK_CAP_MB": "0"}, {"SQUID_GPU_INFLATE": "1", "SQUID_TOK_CAP_MB": "0", "SQUID_IL_DEPTH": "3"}):
+            p = subprocess.run([sys.executable, "-c", code, str(bam)], env=dict(os.environ, **env), capture_output=True, text=True, check=True, timeout=600)
             outs.append(p.stdout.strip().splitlines()[-1])
-        assert outs[0].split()[0] == outs[1].split()[0], (name, outs)
-        if outs[0].startswith("ok"):
-            assert outs[0] == outs[1], (name, outs)
+        for o in outs[1:]:
+            assert outs[0].split()[0] == o.split()[0], (name, outs)
+            if outs[0].startswith("ok"):
+                assert outs[0] == o, (name, outs)
         assert outs[0].startswith("ok" if name == "cut_between_blocks" else "error"), (name, outs)
 
 
