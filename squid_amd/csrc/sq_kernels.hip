@@ -402,7 +402,10 @@ __global__ void k_pack_blocks(int64_t from, int64_t to, const int32_t* refpos, c
 // ------------------------------------------------------------------------------------------------ scans
 // Device scans over int32 values produced by a functor (record parse, component labels, debug paths); the scans that run along the
 // record stream live inside the fused kernels of sq_pass_kernels.inc.
-constexpr int SCAN_THREADS = 256, SCAN_ITEMS = 16, SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+#ifndef SQ_SCAN_ITEMS
+#define SQ_SCAN_ITEMS 16
+#endif
+constexpr int SCAN_THREADS = 256, SCAN_ITEMS = SQ_SCAN_ITEMS, SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 
 struct OpSum { typedef int T; static __device__ __forceinline__ int id() { return 0; } static __device__ __forceinline__ int op(int a, int b) { return a + b; } };
 struct OpMax { typedef int T; static __device__ __forceinline__ int id() { return INT_MIN; } static __device__ __forceinline__ int op(int a, int b) { return a > b ? a : b; } };
@@ -679,7 +682,11 @@ __device__ int parse_blocks(const uint8_t* cg, int ncig, const uint8_t* seq, int
 // byte per lane, 260 bytes apart from the neighbouring lane: straight from global memory every load touches 64 cache
 // lines and the chunk is fetched from HBM ~20 times over.  So the range is first copied into LDS with coalesced 16-byte
 // loads and the lanes parse from there (a range that does not fit -- very long records -- is parsed in place).
-constexpr int PARSE_THREADS = 128, PARSE_LDS = 40960;  // 4 workgroups = 8 waves per CU (64 threads x 32 KB gave 5)
+#ifndef SQ_PARSE_THREADS
+#define SQ_PARSE_THREADS 64
+#define SQ_PARSE_LDS 18432
+#endif
+constexpr int PARSE_THREADS = SQ_PARSE_THREADS, PARSE_LDS = SQ_PARSE_LDS;  // 4 workgroups = 8 waves per CU (64 threads x 32 KB gave 5)
 // `avail` receives the bytes the record may occupy: up to the next record's offset, the end of the chunk and (when staged) the
 // end of the staged range; -1 when the offsets handed in by the caller are not ascending or lie outside the chunk.
 __device__ __forceinline__ const uint8_t* stage_records(const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n, uint8_t* lds, long long& avail) {
@@ -3552,7 +3559,14 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     // resolve -> boundaries -> parse of one batch after the other was the chain the wall time followed.  The front needs the
     // bytes of the incomplete record at the end of the batch before (`carry`, known once that batch's boundaries are): they are
     // copied from the one inflated buffer to the front of the other.
-    if (!D.il_parse_stream) HIPCHK(hipStreamCreateWithFlags(&D.il_parse_stream, hipStreamNonBlocking));
+    if (!D.il_parse_stream) {
+        // (highest priority: the parse of batch k shares the machine with the resolve of batch k + 1 -- sixteen thousand one-wave workgroups
+        // that take every free wave slot -- and the batch loop waits for the parse)
+        static const bool parse_hi = std::getenv("SQUID_PARSE_PRIO") == nullptr || std::atoi(std::getenv("SQUID_PARSE_PRIO")) != 0;
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (!parse_hi || hipStreamCreateWithPriority(&D.il_parse_stream, hipStreamNonBlocking, hi) != hipSuccess) { (void)hipGetLastError(); HIPCHK(hipStreamCreateWithFlags(&D.il_parse_stream, hipStreamNonBlocking)); }
+    }
     if (!D.il_host) HIPCHK(hipHostMalloc((void**)&D.il_host, 64 * sizeof(int32_t)));
     hipStream_t sp = D.il_parse_stream;
     struct Front { unsigned long long pad = 0, carry = 0, limit = 0; long long nsl = 0; RecScan S{}; };

@@ -26,6 +26,8 @@ print(f"{'kernel':32s} {'n':>5s} {'mean ms':>9s} {'sum ms':>9s} {'union ms':>9s}
 for k, iv in sorted(by.items(), key=lambda kv: -sum(e - s for s, e in kv[1]))[:14]:
     print(f"{k[:32]:32s} {len(iv):5d} {sum(e - s for s, e in iv) / len(iv) / 1e6:9.3f} {sum(e - s for s, e in iv) / 1e6:9.2f} {union(iv) / 1e6:9.2f} {(min(s for s, e in iv) - t0) / 1e6:7.1f} {(max(e for s, e in iv) - t0) / 1e6:8.1f}")
 print("token launches (start, end ms):", " ".join(f"{(s - t0) / 1e6:.0f}-{(e - t0) / 1e6:.0f}" for s, e in sorted(by.get("k_inflate_tok2<false>", by.get("k_inflate_tok2", [])))))
+tail0 = max(e for s, e in by.get("k_inflate_tok2<false>", [(t0, t0)]))
+print(f"after the last token pass ended (+{(tail0 - t0) / 1e6:.1f} ms): " + " ".join(f"{k[:18]}@{(s - tail0) / 1e6:.2f}+{(e - s) / 1e6:.2f}" for s, e, k in last if s >= tail0 and e - s > 30e3))
 for name in by:
     if name.startswith("k_lz_resolve"):
         print(name, "launches:", " ".join(f"{(s - t0) / 1e6:.0f}-{(e - t0) / 1e6:.0f}" for s, e in sorted(by[name])))
