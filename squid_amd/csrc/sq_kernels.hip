@@ -3592,6 +3592,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
             if (resolve_global) hipLaunchKernelGGL(k_lz_resolve3, dim3(nb), dim3(64), 0, s, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, out, P.flags.p);
             else hipLaunchKernelGGL(k_lz_resolve2, dim3(nb), dim3(128), 65536 + 16, s, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, out, P.flags.p);
         }
+        HIPCHK(hipMemcpyAsync(hk + 10, st.flags.p, 4 * 4, hipMemcpyDeviceToHost, s));  // (before the set goes back to the planner, whose next batch clears them)
         HIPCHK(hipEventRecord(st.freed, s));
         front_issued();
         F.S = RecScan{P.out.p, k == 0 ? (unsigned long long)begin : F.pad, F.limit, nref, sh.on ? sh.first_ref : -1, sh.on ? sh.end_ref : 0, (sh.on && c->P.rank == c->P.world_size - 1) ? 1 : 0};
@@ -3604,14 +3605,15 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
             long long* tail_d = P.rec_end.p + nsl;  // where the walk stopped: the start of the incomplete tail
             HIPCHK(hipMemsetAsync(tail_d, 0, 8, s));
             { EvTimer t(c, "k_rec_sync+walk+check", 2.0 * (double)(F.S.limit - F.S.begin));
-              hipLaunchKernelGGL(k_rec_sync, grid_for(nsl, 256), dim3(256), 0, s, F.S, nsl, (k > 0 || synced) ? 1 : 0, P.rec_sync.p);
-              hipLaunchKernelGGL(k_rec_walk<false>, grid_for(nsl, 256), dim3(256), 0, s, F.S, nsl, P.rec_sync.p, P.rec_cnt.p, P.rec_end.p, nullptr, nullptr);
-              hipLaunchKernelGGL(k_rec_check, grid_for(nsl, 256), dim3(256), 0, s, nsl, P.rec_sync.p, P.rec_end.p, P.flags.p, tail_d);
+              // (single-wave workgroups: these kernels run beside the resolve of the next batch and the token waves, whose one-wave
+              // workgroups take wave slots one at a time as they come free -- a workgroup that needs four on one CU at once waited 3 ms)
+              hipLaunchKernelGGL(k_rec_sync, grid_for(nsl, 64), dim3(64), 0, s, F.S, nsl, (k > 0 || synced) ? 1 : 0, P.rec_sync.p);
+              hipLaunchKernelGGL(k_rec_walk<false>, grid_for(nsl, 64), dim3(64), 0, s, F.S, nsl, P.rec_sync.p, P.rec_cnt.p, P.rec_end.p, nullptr, nullptr);
+              hipLaunchKernelGGL(k_rec_check, grid_for(nsl, 64), dim3(64), 0, s, nsl, P.rec_sync.p, P.rec_end.p, P.flags.p, tail_d);
               HIPCHK((device_scan<OpSum, true>(s, nsl, FArr{P.rec_cnt.p}, P.rec_base.p, P.spine, tot))); }
             HIPCHK(hipMemcpyAsync(hk + 16, tail_d, 8, hipMemcpyDeviceToHost, s));
         }
         HIPCHK(hipMemcpyAsync(hk, P.flags.p, 10 * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(hk + 10, st.flags.p, 4 * 4, hipMemcpyDeviceToHost, s));
         return SQ_OK;
     };
     long check_bad = 0;
@@ -3657,7 +3659,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         const int64_t n_rec = h[8];
         if (n_rec > 0) {
             HIPCHK(P.bam_off.reserve((size_t)n_rec));
-            hipLaunchKernelGGL(k_rec_walk<true>, grid_for(F.nsl, 256), dim3(256), 0, sp, F.S, F.nsl, P.rec_sync.p, nullptr, nullptr, P.rec_base.p, P.bam_off.p);
+            hipLaunchKernelGGL(k_rec_walk<true>, grid_for(F.nsl, 64), dim3(64), 0, sp, F.S, F.nsl, P.rec_sync.p, nullptr, nullptr, P.rec_base.p, P.bam_off.p);
             // (sub-batches: the per-launch temporaries and the 32-bit block counters stay small)
             const int64_t kBatch = (int64_t)1 << 24;
             for (int64_t r0 = 0; r0 < n_rec; r0 += kBatch) {
