@@ -207,7 +207,7 @@ struct DeviceRecords {
     DBuf<uint8_t> bam_chunk, bgzf_out, bgzf_carry;
     DBuf<uint8_t> staged;  // sq_stage_bam: the compressed bytes of a whole BAM file (+ padding for the input rings' read-ahead)
     DBuf<long long> rec_sync, rec_end;
-    // GPU ingest, two batches in flight: compressed bytes + block table + tokens of a batch
+    // GPU ingest, up to il_depth batches in flight: compressed bytes + block table + tokens of a batch
     struct InflSet { DBuf<uint8_t> in; DBuf<InflBlock> tab; DBuf<uint32_t> tok, lens; DBuf<int32_t> ntok, flags; hipEvent_t ready = nullptr, freed = nullptr, copied = nullptr; std::vector<InflBlock> host_tab; const uint8_t* src = nullptr; /* compressed bytes of the batch: `in`, or inside the staged file */ };
     static constexpr int IL_DEPTH_MAX = 8;
     int il_depth = 5;  // buffer sets in use (SQUID_IL_DEPTH, 3..8): batch k is resolved / parsed, the ones behind it are in the token pass, the last is being copied
@@ -269,7 +269,7 @@ struct DeviceRecords {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     std::vector<Pending> ev_pending;
     size_t ev_used = 0;
-    std::mutex ev_mu;  // (the GPU reader's helper thread brackets its kernel too)
+    std::mutex ev_mu;  // (the GPU reader's planner thread brackets its kernel too)
     int64_t k1 = 0;  // kept pass-1 records
     int cl_n = 0;    // clusters in the packed table cl_chr
     RecView view() const {
@@ -2197,10 +2197,10 @@ __device__ __forceinline__ uint32_t t2_take(ILane& b, uint32_t& ahead, int k) {
 template <bool PROF>
 __global__ __launch_bounds__(320, 1) void k_inflate_tok2(const uint8_t* file, const InflBlock* blocks, int nblocks, int32_t* flags, uint32_t* tok, int32_t* ntok, uint32_t* lens_strips,
                                                     unsigned long long* prof) {
-    // One to three waves per workgroup, each with its own T2_LDS_BYTES and its own 64 blocks; they never talk to each other.  Three
-    // waves make a workgroup of 93 KB: a CU takes one of them and no second -- three token waves per CU, on three of its SIMDs, and
-    // the 64 KB that remain are exactly the slot of a resolve workgroup (with single-wave workgroups a CU fills up with token waves
-    // for tens of milliseconds and the resolve, which is what the wall time follows, finds no room there).
+    // One to five waves per workgroup (SQUID_TOK_WPB), each with its own T2_LDS_BYTES and its own 64 blocks; they never talk to each other.
+    // With the resolve that keeps no window in LDS (k_lz_resolve3, the default) the workgroups are single waves and the dispatcher packs five
+    // of them onto a CU (158.7 of its 160 KB); with the LDS resolve (k_lz_resolve2) three waves make a workgroup of 93 KB, a CU takes one of
+    // them and no second, and the 64 KB that remain are exactly the slot of a resolve workgroup.
     extern __shared__ uint16_t il_lds_all[];  // T2_LDS_BYTES per wave
     uint16_t* il_lds = il_lds_all + (size_t)(threadIdx.x >> 6) * (T2_LDS_BYTES / 2);
     unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pc = 0;
@@ -3355,9 +3355,9 @@ static int parse_device(sq_ctx* c, const uint8_t* d_bam, size_t nbytes, const un
 
 // K-1 + K0 for a whole file (or a shard's block range): compressed bytes -> HBM, inflate, record boundaries, parse -- the
 // host only indexes the BGZF blocks.  The range is streamed in batches of SQUID_TOK_CAP_MB of inflated bytes (fixed-size
-// device buffers whatever the file size), two in flight: while batch k is resolved, cut into records and parsed on the
-// library stream, the compressed bytes of batches k+1 and k+2 are copied and turned into tokens on two more streams
-// (the token pass of a batch ends with a few long waves; the next batch fills the CUs they leave idle).  The incomplete record at
+// device buffers whatever the file size), up to eight in flight: while batch k is resolved and cut into records on the library stream
+// and batch k - 1 is parsed on the parse stream, the batches behind are in the token pass on their own streams, queued by a planner
+// thread as buffer sets come free (the compressed bytes are in HBM already or arrive there through the feeder).  The incomplete record at
 // the end of a batch is carried in front of the next one.  Returns 2 when the device-side boundary check (or the
 // inflate) is not satisfied: the records appended so far are dropped again and the caller takes the host reader.
 int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& blocks, size_t b0, size_t b1, size_t begin, bool synced, int nref, const IndexMore& index_more_in, size_t file_bytes, GpuFileSrc* src) {
@@ -3375,14 +3375,14 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     const bool report = std::getenv("SQUID_INGEST_TIMING") != nullptr, check = std::getenv("SQUID_INFLATE_CHECK") != nullptr;
     const auto w0 = std::chrono::steady_clock::now();
     auto since_ms = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
-    // a batch = 256 waves of the token pass (1 GiB inflated): the token workgroups take two waves of every CU (see k_inflate_tok2),
-    // 512 in all, so two batches fill the machine exactly; measured at C3: 512 MB 303 ms, 720 MB 238, 1 GiB 233, 1.4 GB 244, 2 GB 256
+    // a batch = 256 waves of the token pass (1 GiB inflated); five batches fill the 1280 token slots of the machine (five waves per CU).
+    // Measured at C3 (round 4, eight sets): 512 MB 157 ms per step, 640 MB 141, 768 MB 137, 1 GiB 136, 1.25 GB 135
     const unsigned long long cap = std::getenv("SQUID_TOK_CAP_MB") ? (unsigned long long)std::atoll(std::getenv("SQUID_TOK_CAP_MB")) << 20 : 256ull * 64 * 65536;
     HIPCHK(hipFuncSetAttribute((const void*)k_lz_resolve2, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16));
     HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * (int)T2_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * (int)T2_LDS_BYTES));
-    // token waves per workgroup: 3 (93 KB) leave the 64 KB slot of a resolve workgroup free on every CU; 4 or 5 take the whole CU and the
-    // resolve workgroups -- on a stream of higher priority -- get the CUs that token workgroups leave (SQUID_TOK_WPB, measured in DESIGN.md)
+    // token waves per workgroup (SQUID_TOK_WPB, measured in DESIGN.md): 1 with the LDS-free resolve -- five single-wave workgroups per CU --;
+    // with the LDS resolve 3 (93 KB), which leave the 64 KB slot of a resolve workgroup free on every CU
     static const bool resolve_global = std::getenv("SQUID_RESOLVE_GLOBAL") == nullptr || std::atoi(std::getenv("SQUID_RESOLVE_GLOBAL")) != 0;  // k_lz_resolve3 (no LDS window); 0: k_lz_resolve2
     static const int tok_wpb = std::getenv("SQUID_TOK_WPB") ? std::max(1, std::min(5, std::atoi(std::getenv("SQUID_TOK_WPB")))) : (resolve_global ? 1 : 3);
     static const bool tok_prof = std::getenv("SQUID_TOK_PROF") != nullptr;
