@@ -3527,12 +3527,16 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     int planner_rc = SQ_OK;
     std::thread planner([&]() {
         int rc = hipSetDevice(c->P.device) == hipSuccess ? SQ_OK : (int)SQ_E_HIP;
-        for (size_t k = 0; rc == SQ_OK; ++k) {
-            { std::unique_lock<std::mutex> lk(pm); pcv.wait(lk, [&]() { return planner_stop || k < fronts + (size_t)D.il_depth; }); if (planner_stop) break; }
-            if (!plan(k)) break;
-            rc = stage_a(k);
-            if (rc == SQ_OK) { std::lock_guard<std::mutex> lk(pm); staged = k + 1; }
-            pcv.notify_all();
+        try {
+            for (size_t k = 0; rc == SQ_OK; ++k) {
+                { std::unique_lock<std::mutex> lk(pm); pcv.wait(lk, [&]() { return planner_stop || k < fronts + (size_t)D.il_depth; }); if (planner_stop) break; }
+                if (!plan(k)) break;
+                rc = stage_a(k);
+                if (rc == SQ_OK) { std::lock_guard<std::mutex> lk(pm); staged = k + 1; }
+                pcv.notify_all();
+            }
+        } catch (const std::exception& e) {  // (the block index and the batch tables grow on this thread: out of memory must not end the process)
+            rc = fail(c, SQ_E_CAPACITY, std::string("GPU reader, planner thread: ") + e.what());
         }
         { std::lock_guard<std::mutex> lk(pm); planner_rc = rc; planner_over = true; }
         pcv.notify_all();
