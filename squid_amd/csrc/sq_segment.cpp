@@ -393,6 +393,8 @@ double segment_clusters(const sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::ve
     plan = std::make_shared<SegPlan>();
     SegStatic& S = plan->st;
     const auto t_begin = std::chrono::steady_clock::now();
+    static const bool laps = std::getenv("SQUID_PREP_DEBUG") != nullptr;
+    auto lap = [&](const char* what) { if (laps) std::fprintf(stderr, "[clusters] %-22s at %.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count()); };
     // ---- discordant blocks and clip positions of the chimeric fragments (SegmentGraph.cpp:203-264)
     S.part.assign(c->ref_len.size(), std::make_pair(0, 0));  // ledger B10
     std::vector<Blk>& D = S.D;
@@ -445,6 +447,7 @@ double segment_clusters(const sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::ve
         }
     };
     if (pieces > 1) c->pool->parallel_for(pieces, 15, work); else work(0);
+    lap("fragments walked");
     auto par = [&](size_t n, const std::function<void(size_t, size_t)>& f) {  // [lo, hi) pieces on the context's host threads
         const int np = (c->pool && n > 100000) ? 4 * (c->pool->size() + 1) : 1;
         if (np <= 1) { f(0, n); return; }
@@ -468,8 +471,10 @@ double segment_clusters(const sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::ve
             for (size_t i = 0; i < O.part.size(); ++i) if (!drop[i]) S.part.push_back(O.part[i]);
         }
     }
+    lap("pieces strung");
     const int sort_threads = c->pool ? std::min(c->pool->size() + 1, 32) : 1;
     std_sort_parallel(S.part.begin(), S.part.end(), std::less<std::pair<int, int>>(), sort_threads);
+    lap("clip positions sorted");
     {   // ledger B8: operator< looks at (RefID, RefPos) only and the sort is not stable.  Sorting 12-byte (key, index) elements with the
         // same comparison takes libstdc++'s introsort through the same decisions, hence to the same permutation, at a fraction of
         // the memory traffic of sorting the blocks themselves
@@ -482,12 +487,14 @@ double segment_clusters(const sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::ve
         par(D.size(), [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) sorted[i] = D[(size_t)pk[i].idx]; });
         D.swap(sorted);
     }
+    lap("blocks sorted");
     S.nd = (int)D.size();
     disc_sorted = D;
     D.push_back(Blk{0, 0, 0, 0, 0, false, false});  // ledger B21 sentinel
 
     // ---- static cluster table; everything stream-sized comes from the GPU
     S.build_clusters(c->read_len);
+    lap("clusters built");
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
 }
 // pass 1 over the records (k_pass1; the cluster table is uploaded here).  A sharded run calls this before it knows the running pair
