@@ -64,3 +64,19 @@ def test_parallel_sort_reproduces_libstdcxx_sort(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", str(exe), str(src), "-lpthread"])
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout
+
+
+def test_loading_the_library_asks_for_eight_hardware_queues_unless_told_otherwise(built):
+    """the GPU reader overlaps up to eight kernels; the HIP runtime gives a process four hardware queues per priority unless
+    GPU_MAX_HW_QUEUES says otherwise when it initialises: loading the library sets the variable in
+    the process environment, and leaves a value that is there already alone"""
+    import os
+    import subprocess
+    import sys
+
+    code = ("import ctypes, sys; libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p\n"
+            "ctypes.CDLL(sys.argv[1]); print((libc.getenv(b'GPU_MAX_HW_QUEUES') or b'-').decode())")
+    lib = str(squid_amd.LIB_PATH)
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    assert subprocess.run([sys.executable, "-c", code, lib], env=env, capture_output=True, text=True, check=True).stdout.strip() == "8"
+    assert subprocess.run([sys.executable, "-c", code, lib], env=dict(env, GPU_MAX_HW_QUEUES="4"), capture_output=True, text=True, check=True).stdout.strip() == "4"
