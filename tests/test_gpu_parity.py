@@ -970,7 +970,8 @@ def test_gpu_bgzf_inflate_and_boundary_search_give_the_same_records(built, synth
             "print(json.dumps({k: hashlib.sha256(v.tobytes()).hexdigest() for k, v in r.items()}))") % (str(Path(__file__).resolve().parent.parent), f"{pre}.chim.bam")
 
     def run(bam, env, shard="None", ctx=""):
-        p = subprocess.run([sys.executable, "-c", code.replace("SHARD", shard).replace("CTX", ctx), str(bam)], env=dict(os.environ, **env), capture_output=True, text=True, check=True)
+        p = subprocess.run([sys.executable, "-c", code.replace("SHARD", shard).replace("CTX", ctx), str(bam)], env=dict(os.environ, **env), capture_output=True, text=True)
+        assert p.returncode == 0, (p.returncode, env, shard, ctx, p.stderr[-4000:])
         if env:
             assert "GPU inflate+parse path" in p.stderr and "(rc 0)" in p.stderr, p.stderr
         return json.loads(p.stdout.strip().splitlines()[-1])
