@@ -218,7 +218,6 @@ struct DeviceRecords {
     struct PostSet { DBuf<uint8_t> out; DBuf<long long> rec_sync, rec_end; DBuf<int32_t> rec_cnt, rec_base, flags, spine; DBuf<unsigned long long> bam_off; };
     PostSet il_post[2];
     hipStream_t il_parse_stream = nullptr;
-    std::future<void> warm;                // dev_create: the code object being loaded
     int32_t* il_host = nullptr;            // page-locked: the small results of the two sets (32 ints each)
     // host -> device copies of file bytes: four threads stage 16 MiB pieces through page-locked buffers (h2d_parallel)
     static constexpr int H2D_THREADS = 4;
@@ -2796,20 +2795,19 @@ int dev_create(sq_ctx* c) {
     HIPCHK(hipStreamCreate(&c->stream));
     c->dev = new DeviceRecords();
     HIPCHK(c->dev->flags.reserve(64));
-    // the runtime loads this library's code object for the device when the first of its kernels is asked for (tens of milliseconds for its
-    // hundred-odd kernels): asked for here, on a thread of its own, it loads while the caller reads its first file
-    const int device = c->P.device;
-    c->dev->warm = std::async(std::launch::async, [device]() {
-        if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return; }
+    // The runtime loads this library's code object for the device when the first of its kernels is asked for, and two threads asking while
+    // it is still being loaded is a race inside the runtime ("Cannot find Symbol with name ...", abort): seen once in some twenty processes
+    // when round 4 let a helper thread do the asking beside the caller, and possible ever since sq_ingest_files decodes the chimeric BAM (and
+    // launches its first kernel) on a thread of its own.  So the load happens HERE, on the creating thread, before any other thread exists.
+    {
         hipFuncAttributes a;
         if (hipFuncGetAttributes(&a, (const void*)k_lz_resolve3) != hipSuccess) (void)hipGetLastError();
-    });
+    }
     return SQ_OK;
 }
 
 void dev_destroy(sq_ctx* c) {
     if (!c->dev) return;
-    if (c->dev->warm.valid()) c->dev->warm.wait();
     DeviceRecords& D = *c->dev;
     D.refid.release(); D.pos.release(); D.mrefid.release(); D.mpos.release(); D.endpos.release(); D.b_refpos.release(); D.b_matchref.release();
     D.b_pack.release(); D.n_pack.release(); D.r_pack.release();
