@@ -3376,6 +3376,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     // a batch = 256 waves of the token pass (1 GiB inflated); five batches fill the 1280 token slots of the machine (five waves per CU).
     // Measured at C3 (round 4, eight sets): 512 MB 157 ms per step, 640 MB 141, 768 MB 137, 1 GiB 136, 1.25 GB 135
     const unsigned long long cap = std::getenv("SQUID_TOK_CAP_MB") ? (unsigned long long)std::atoll(std::getenv("SQUID_TOK_CAP_MB")) << 20 : 256ull * 64 * 65536;
+    if (report) std::fprintf(stderr, "GPU ingest: entry + %.1f ms: device chosen, memory asked about\n", since_ms(w_entry));
     HIPCHK(hipFuncSetAttribute((const void*)k_lz_resolve2, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16));
     HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * (int)T2_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * (int)T2_LDS_BYTES));
@@ -3387,7 +3388,10 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     if (tok_prof) HIPCHK(D.tok_prof.reserve(8 * 4096));
     static const int il_depth = std::getenv("SQUID_IL_DEPTH") ? std::max(3, std::min((int)DeviceRecords::IL_DEPTH_MAX, std::atoi(std::getenv("SQUID_IL_DEPTH")))) : (resolve_global ? 8 : 5);
     D.il_depth = il_depth;
-    for (int qi = 0; qi < D.il_depth; ++qi) {
+    // the stream and the events of a buffer set are made when its first batch is staged (on the planner thread): a stream of a priority
+    // level that has none yet costs the runtime a hardware queue, 7-8 ms each in a process that has just started -- eight of them in
+    // front of the first batch were 60 ms of a cold start
+    auto ensure_set = [&D](int qi) -> int {
         hipStream_t& q = D.il_stream[qi];
         if (!q) {
             // lowest priority: a token wave holds its CU for tens of milliseconds, and the resolve / boundary / parse kernels
@@ -3396,15 +3400,15 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
             (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
             static const bool spread = std::getenv("SQUID_IL_SPREAD") != nullptr && std::atoi(std::getenv("SQUID_IL_SPREAD")) != 0;
             const int prio = spread && qi >= 4 ? (lo + hi) / 2 : lo;  // (experiment: the runtime keeps a pool of hardware queues per priority level)
-            if (hipStreamCreateWithPriority(&q, hipStreamNonBlocking, prio) != hipSuccess) { (void)hipGetLastError(); HIPCHK(hipStreamCreate(&q)); }
+            if (hipStreamCreateWithPriority(&q, hipStreamNonBlocking, prio) != hipSuccess) { (void)hipGetLastError(); if (hipStreamCreate(&q) != hipSuccess) return (int)SQ_E_HIP; }
         }
-    }
-    for (int qi = 0; qi < D.il_depth; ++qi) {
         DeviceRecords::InflSet& st = D.il_set[qi];
-        if (!st.ready) HIPCHK(hipEventCreateWithFlags(&st.ready, hipEventDisableTiming));
-        if (!st.freed) HIPCHK(hipEventCreateWithFlags(&st.freed, hipEventDisableTiming));
-        if (!st.copied) HIPCHK(hipEventCreateWithFlags(&st.copied, hipEventDisableTiming));
-    }
+        if (!st.ready && hipEventCreateWithFlags(&st.ready, hipEventDisableTiming) != hipSuccess) return (int)SQ_E_HIP;
+        if (!st.freed && hipEventCreateWithFlags(&st.freed, hipEventDisableTiming) != hipSuccess) return (int)SQ_E_HIP;
+        if (!st.copied && hipEventCreateWithFlags(&st.copied, hipEventDisableTiming) != hipSuccess) return (int)SQ_E_HIP;
+        return SQ_OK;
+    };
+    if (report) std::fprintf(stderr, "GPU ingest: entry + %.1f ms: kernel attributes\n", since_ms(w_entry));
     // The compressed bytes: in HBM already (sq_stage_bam), or streamed there now by the feeder, which then also walks the block
     // headers (its more() replaces the caller's index walk over a mapping); the per-batch blocking copy of round 3 only remains for
     // files that would not fit beside the batch buffers.
@@ -3421,7 +3425,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
             const int rc = feed->start(src->path, from, upto, walk, src->walk_p, src->walk_total, src->stop);
             if (rc) return rc;
             if (walk) index_more = [&feed](std::vector<BgzfRange>& v) { return feed->more(v); };
-            if (report) std::fprintf(stderr, "GPU ingest: file streamed by %d threads, %zu pieces, set-up %.1f ms\n", feed->T, feed->npieces, feed->t_setup_ms);
+            if (report) std::fprintf(stderr, "GPU ingest: entry + %.1f ms: file streamed by %d threads, %zu pieces, set-up %.1f ms\n", since_ms(w_entry), feed->T, feed->npieces, feed->t_setup_ms);
         } else (void)hipGetLastError();
     }
     struct FeedGuard { std::unique_ptr<FileFeeder>& f; ~FeedGuard() { if (f) f->cancel(); } } feed_guard{feed};  // (every way out stops the threads)
@@ -3469,6 +3473,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     auto stage_a = [&](size_t k) -> int {  // (SQ_OK also when there is no batch k)
         if (!plan(k)) return SQ_OK;
         const Batch B = batches[k];
+        { const int rc = ensure_set((int)(k % (size_t)D.il_depth)); if (rc) return fail(c, rc, "cannot create the stream of a buffer set"); }
         DeviceRecords::InflSet& st = D.il_set[k % (size_t)D.il_depth];
         hipStream_t sa = D.il_stream[k % (size_t)D.il_depth];
         const int nb = (int)(B.end - B.at);
