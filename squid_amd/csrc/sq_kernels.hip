@@ -2075,7 +2075,7 @@ __device__ __forceinline__ uint32_t il_take(ILane& b, int k) {
 // its length group, where the literals come first), three 16-entry tables, the input ring and the token stage (the sizes: "Round 4"
 // below) -- several waves per CU, and a step is two LDS round trips per code instead of up to nine.
 #ifndef SQ_T2_LITS
-#define SQ_T2_LITS 4
+#define SQ_T2_LITS 3  // literal/length symbols per step (4 until the second half of round 4: with five waves per CU three is 1 % faster, 140.2 against 141.7 ms per C3 step in three A/B pairs)
 #endif
 constexpr int T2_SYM_LL = 288, T2_SYM_DD = 32, T2_LITS = SQ_T2_LITS;
 // Round 4: 496 bytes per lane (round 3: 746).  What went: the 4-bit code lengths of a header (170 B) -- they are only needed between
@@ -2245,7 +2245,7 @@ __global__ __launch_bounds__(320, 1) void k_inflate_tok2(const uint8_t* file, co
     bool in_block = false, last = false, stored = false;
     uint32_t stored_left = 0, stored_at = 0;
     int hdr_wait = 0;
-    // what the step has produced -- with four literal/length symbols per step at most three tokens (two pending literals + one
+    // what the step has produced -- with up to four literal/length symbols per step at most three tokens (two pending literals + one
     // fill a token, two more wait, a match flushes them and adds its own): stored at the top of the next step, where all lanes
     // are together again (one copy of the store code)
     uint32_t tq0 = 0, tq1 = 0, tq2 = 0;

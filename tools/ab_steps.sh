@@ -2,10 +2,7 @@
 # A/B of builds (SQUID_LIB=...) and switches of the library on staged C3 steps (GPU box); edit the run lines
 build/gen_synth_bam --config C3 --out /tmp/c3 --threads 64 > /dev/null
 run() { echo "-- $*"; env "$@" timeout 120 python3 tools/staged_steps.py /tmp/c3 9 2>&1 | grep "^== steps"; }
-for rep in 1 2; do
+for rep in 1 2 3; do
 run X=base
-run SQUID_IL_DEPTH=7
-run SQUID_IL_DEPTH=6
-run SQUID_TOK_CAP_MB=1280
-run SQUID_IL_DEPTH=7 SQUID_TOK_CAP_MB=1280
+run SQUID_LIB=$PWD/build/ab/lib_lits3.so
 done
