@@ -351,7 +351,7 @@ def main() -> None:
     out = {
         "metric": "paired-end alignments/sec BAM->_sv.txt (BGZF/BAM decode included, compressed BAM bytes staged in HBM; bit-exact SV calls vs CPU oracle)",
         "value": value, "unit": "alignments/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if sharded else ("weak" if world > 1 else "single GPU"), "vs_baseline": None,
+        "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if (sharded or (world == 1 and a.shard == "chromosome")) else "weak",  # (at N = 1 the label of the mode the same flags select at N > 1) "vs_baseline": None,
         "dtype": "int32", "data": "synthetic",
         "config": {"workload": f"{a.workload}: " + WORKLOADS.get(a.workload, "generator config " + a.workload) + (f", --records {a.records}" if a.records else "") + (f", --tsv {a.tsv}" if a.tsv else "") + (f", --support {a.support}" if a.support else "") + (f", --level {a.level}" if a.level is not None else ""),
                    "records": int(total_aln), "records_per_gpu": int(total_aln / world), "blocks_per_record": round(bbar, 4), "flags": " ".join(cli_flags) or "defaults",
