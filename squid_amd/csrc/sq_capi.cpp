@@ -17,6 +17,10 @@ namespace sq {
 // sq_ingest_files decodes the chimeric file on a second thread while the calling thread may report its own errors into c->err:
 // the helper's messages go to c->chim_err (this thread-local names it) and reach c->err when chim_join collects the result
 static thread_local std::string* tl_err_sink = nullptr;
+// a helper thread of the library sends its error texts to a string of its own (the thread that owns the context moves it into c->err once
+// the helper has been joined): the chimeric decode of sq_ingest_files, the planner thread of the GPU reader
+ErrSink::ErrSink(std::string* to) { tl_err_sink = to; }
+ErrSink::~ErrSink() { tl_err_sink = nullptr; }
 int fail(sq_ctx* c, int code, const std::string& msg) {
     if (tl_err_sink) *tl_err_sink = msg;
     else if (c) c->err = msg;

@@ -241,6 +241,7 @@ struct sq_ctx {
 namespace sq {
 
 int fail(sq_ctx* c, int code, const std::string& msg);
+struct ErrSink { explicit ErrSink(std::string* to); ~ErrSink(); };  // while it lives, fail() on this thread writes to *to instead of c->err (sq_capi.cpp)
 struct HostClock {  // wall clock of a host stage into the context's timing table
     sq_ctx* c; const char* name; std::chrono::steady_clock::time_point t0;
     HostClock(sq_ctx* c, const char* name) : c(c), name(name), t0(std::chrono::steady_clock::now()) {}

@@ -3528,7 +3528,9 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     size_t staged = 0, fronts = 0;  // (pm) batches through stage A; issue_front calls made
     bool planner_over = false, planner_stop = false;
     int planner_rc = SQ_OK;
+    std::string planner_err;  // (its error text: moved into c->err by this thread once the planner is over)
     std::thread planner([&]() {
+        ErrSink sink(&planner_err);
         int rc = hipSetDevice(c->P.device) == hipSuccess ? SQ_OK : (int)SQ_E_HIP;
         try {
             for (size_t k = 0; rc == SQ_OK; ++k) {
@@ -3556,6 +3558,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         std::unique_lock<std::mutex> lk(pm);
         pcv.wait(lk, [&]() { return staged > k || planner_over; });
         if (staged > k) return 1;
+        if (planner_rc && !planner_err.empty()) c->err = planner_err;  // (the planner is over: nobody else writes it)
         return planner_rc > 0 ? (int)SQ_E_HIP : planner_rc;  // (error codes are negative)
     };
     auto front_issued = [&]() { { std::lock_guard<std::mutex> lk(pm); ++fronts; } pcv.notify_all(); };
