@@ -13,8 +13,12 @@ reference's statements as Python allows, of
   (`:1394-1555`), `RawEdgesOther` over every concordant record (`:1557-1690`), `Edge_t`'s constructor and order (`BPEdge.h:31-74`),
   `IsDiscordant` (`:181-190`) and the sort/merge of `BuildEdges` (`:1932-1959`) -> the edge list with its weights.
 
-The only inputs taken from elsewhere: the merged chimeric fragments (the oracle's dump of BuildChimericSBamRecord's result), the
-node coordinates of stage 1 and the number of kept records the stream loop consumes before its `break` (`:338-339`).
+* `BuildChimericSBamRecord` itself (`ReadRec.cpp:329-413`): the sort by name, the merge of a name's records, `SortbyReadPos`, the read
+  length, the sort under `FrontSmallerThan` (`:90-117`, not a strict weak order: the permutation is whatever introsort makes of it) and the
+  PCR-duplicate pass -> the fragment list every loop above starts from, against the oracle's dump of it.
+
+The only inputs taken from elsewhere: the node coordinates of stage 1 and the number of kept records the stream loop consumes before its
+`break` (`:338-339`); the loops that need the merged chimeric fragments read the oracle's dump of them, which the last item checks.
 """
 import gzip
 import struct
@@ -120,6 +124,131 @@ def _records_from_bam(path, chim_names):
     return {k: np.array(v, dtype=np.int64) for k, v in rec.items()}
 
 
+# ---- the chimeric BAM the way BuildChimericSBamRecord reads it (ReadRec.cpp:329-413): every mapped, non-duplicate record through the
+# constructor (ReadRec.cpp:10-88, restated once more here with the name and the per-block strand kept), std::sort by Qname, the merge of
+# equal names, SortbyReadPos, the read length as the median of the first five records, std::sort under FrontSmallerThan (which is not a
+# strict weak order: what comes out is what libstdc++'s introsort does with it), and the PCR-duplicate pass
+def _chim_readrecs(path):
+    data = gzip.open(path, "rb").read()
+    l_text = struct.unpack_from("<i", data, 4)[0]
+    at = 8 + l_text
+    n_ref = struct.unpack_from("<i", data, at)[0]
+    at += 4
+    for _ in range(n_ref):
+        at += 8 + struct.unpack_from("<i", data, at)[0]
+    out = []
+    while at < len(data):
+        bs, refid, pos, lname, mapq, _bin, ncig, flag, lseq, _mref, _mpos, _tlen = struct.unpack_from("<iiiBBHHHiiii", data, at)
+        p = at + 36
+        name = data[p:p + lname - 1].decode()
+        p += lname
+        cig = []
+        for k in range(ncig):
+            v = struct.unpack_from("<I", data, p + 4 * k)[0]
+            cig.append(("MIDNSHP=X"[v & 15], v >> 4))
+        p += 4 * ncig
+        seq = data[p:p + (lseq + 1) // 2]
+        p += (lseq + 1) // 2
+        qual = data[p:p + lseq]
+        at += 4 + bs
+        if flag & 0x4 or flag & 0x400:  # record.IsMapped() && !record.IsDuplicate()
+            continue
+        if len(name) >= 2 and name[-2:] in ("/1", "/2"):
+            name = name[:-2]
+        totlen = sum(ln for t, ln in cig if t in "MSHI=X")
+        run = longest = 0
+        for qv in qual:
+            run = run + 1 if qv + 33 < 33 + 4 else 0
+            longest = max(longest, run)
+        low = longest > 10
+        rev, first = bool(flag & 0x10), bool(flag & 0x40)
+        blocks = []
+        readpos, refpos, hard, i = 0, pos, 0, 0
+        while i < len(cig):
+            t, ln = cig[i]
+            if t in "SH":
+                readpos += ln
+                if t == "H":
+                    hard += ln
+            elif t in "M=":
+                tr = tf = 0
+                j = i
+                while j < len(cig) and cig[j][0] not in "SHN":
+                    if cig[j][0] != "D":
+                        tr += cig[j][1]
+                    if cig[j][0] != "I":
+                        tf += cig[j][1]
+                    j += 1
+                na = nt = 0
+                for q in range(readpos - hard, readpos + tr - hard):
+                    code = (seq[q >> 1] >> (4 if q % 2 == 0 else 0)) & 15
+                    na += code == 1
+                    nt += code == 8
+                if 1.0 * na / tr < 0.75 and 1.0 * nt / tr < 0.75:
+                    blocks.append({"RefID": refid, "RefPos": refpos, "ReadPos": totlen - readpos - tr if rev else readpos, "MatchRef": tf, "MatchRead": tr, "IsReverse": rev})
+                readpos += tr
+                refpos += tf
+                i = j - 1
+            elif t == "N":
+                refpos += ln
+            i += 1
+        out.append({"Qname": name, "F": blocks if first else [], "S": [] if first else blocks, "ftl": totlen if first else 0, "stl": 0 if first else totlen,
+                    "flow": low if first else None, "slow": None if first else low})  # (None: the constructor leaves the other side's flag unset)
+    return out
+
+
+def _build_chimeric_literal(path):
+    recs = _chim_readrecs(path)
+    sample = [max(r["ftl"], r["stl"]) for r in recs[:5]]
+    _std_sort(recs, lambda a, b: a["Qname"] < b["Qname"])  # sort(SBamrecord.begin(), SBamrecord.end()): operator< compares the names
+    merged = []
+    for it in recs:
+        if len(merged) == 0 or it["Qname"] != merged[-1]["Qname"]:
+            merged.append({k: (list(v) if isinstance(v, list) else v) for k, v in it.items()})
+        else:
+            back = merged[-1]
+            if back["ftl"] == 0 and it["ftl"] != 0:
+                back["ftl"], back["flow"] = it["ftl"], it["flow"]
+            if back["stl"] == 0 and it["stl"] != 0:
+                back["stl"], back["slow"] = it["stl"], it["slow"]
+            back["F"].extend(it["F"])
+            back["S"].extend(it["S"])
+    for r in merged:
+        _std_sort(r["F"], lambda a, b: a["ReadPos"] < b["ReadPos"])
+        _std_sort(r["S"], lambda a, b: a["ReadPos"] < b["ReadPos"])
+    sample.sort()
+    read_len = sample[len(sample) // 2]
+
+    def front_smaller(l, r):  # ReadRec.cpp:90-117
+        for x, y in (("F", "F"), ("S", "S"), ("F", "S"), ("S", "F")):
+            if len(l[x]) != 0 and len(r[y]) != 0:
+                a, b = l[x][0], r[y][0]
+                return a["RefID"] < b["RefID"] if a["RefID"] != b["RefID"] else a["RefPos"] < b["RefPos"]
+        return False
+
+    _std_sort(merged, front_smaller)
+    key = lambda r: ([(b["RefID"], b["RefPos"], b["MatchRef"]) for b in r["F"]], [(b["RefID"], b["RefPos"], b["MatchRef"]) for b in r["S"]])
+    kept = []
+    for it in merged:
+        if len(kept) == 0:
+            kept.append(it)
+        elif len(it["F"]) == 0 or len(kept[-1]["F"]) == 0:
+            kept.append(it)
+        elif it["F"][0]["RefID"] != kept[-1]["F"][0]["RefID"] or it["F"][0]["RefPos"] != kept[-1]["F"][0]["RefPos"]:
+            kept.append(it)
+        else:
+            isdup = False
+            for it2 in reversed(kept):
+                if len(it2["F"]) == 0 or it["F"][0]["RefID"] != it2["F"][0]["RefID"] or it["F"][0]["RefPos"] != it2["F"][0]["RefPos"]:
+                    break
+                if _equal(key(it), key(it2)):
+                    isdup = True
+                    break
+            if not isdup:
+                kept.append(it)
+    return kept, read_len
+
+
 def _chim_names(dump):
     names = {""}  # (the sized-then-appended vector of :196-201 also holds "", ledger B9)
     for line in open(dump / "chimrecord.txt"):
@@ -134,7 +263,7 @@ def _read_chimrecord(path):
         if line.startswith("#"):
             continue
         f = line.rstrip("\n").split("\t")
-        fr = {"ftl": int(f[1]), "stl": int(f[2]), "flow": int(f[3]), "slow": int(f[4]), "F": [], "S": []}
+        fr = {"Qname": f[0], "ftl": int(f[1]), "stl": int(f[2]), "flow": int(f[3]), "slow": int(f[4]), "F": [], "S": []}
         for part in f[5:]:
             toks = part.split(" ")
             for b in toks[1:]:
@@ -646,3 +775,61 @@ def test_hip_path_against_the_literal_loops(built, synth, tmp_path, cfg, monkeyp
     for k in want:
         assert np.array_equal(np.asarray(rec[k]).astype(np.int64), want[k]), k
     _check(rec, _read_chimrecord(dump / "chimrecord.txt"), nodes, counts["n_break"], counts["n_kept_p1"], edges)
+
+
+@pytest.mark.parametrize("cfg", ["C1", "T2", "C2"])
+def test_oracle_chimeric_fragments_against_the_literal_build(built, synth, tmp_path, cfg):
+    """CPU: the merged, sorted, de-duplicated chimeric fragments the oracle dumps (what every other literal loop takes as given) against
+    the literal BuildChimericSBamRecord over the chimeric BAM decoded by the literal constructor -- names, lengths, low-Phred flags of the
+    sides that have blocks, every block, the order of the fragments, and the read length"""
+    pre = synth(cfg)
+    _, dump = ou.run_oracle(built, pre, tmp_path)
+    want = _read_chimrecord(dump / "chimrecord.txt")
+    want_len = int(open(dump / "chimrecord.txt").readline().split("=")[1])
+    got, read_len = _build_chimeric_literal(f"{pre}.chim.bam")
+    assert read_len == want_len
+    assert len(got) == len(want) > 0
+    for g, w in zip(got, want):
+        assert g["Qname"] == w["Qname"]
+        assert (g["ftl"], g["stl"]) == (w["ftl"], w["stl"])
+        assert int(bool(g["flow"])) == w["flow"] or len(g["F"]) == 0  # (the dump prints 0 for a side without blocks)
+        assert int(bool(g["slow"])) == w["slow"] or len(g["S"]) == 0
+        assert g["F"] == w["F"] and g["S"] == w["S"]
+
+
+def test_oracle_chimeric_fragments_with_pcr_duplicates_against_the_literal_build(built, synth, tmp_path):
+    """the same with every seventh chimeric fragment copied under a new name (exact copies: the PCR-duplicate pass, ReadRec.cpp:387-409,
+    drops one of each pair) and a few copies shifted by one base (kept): the branch the generator's own files never reach"""
+    import os
+    import struct
+
+    import bamwriter as bw
+    from test_gpu_parity import _read_bam_records, _rename_record
+
+    pre = synth("T2")
+    contigs, _ = _read_bam_records(f"{pre}.bam")
+    _, chim = _read_bam_records(f"{pre}.chim.bam")
+    by_name = {}
+    for refid, pos, raw in chim:
+        by_name.setdefault(raw[36:36 + raw[12] - 1].decode(), []).append(raw)
+    picked = sorted(by_name)[::7][:40]
+    out = [raw for _, _, raw in chim]
+    for k, nm in enumerate(picked):
+        out += [_rename_record(raw, f"pcrdup{k}") for raw in by_name[nm]]
+    for k, nm in enumerate(picked[:10]):  # same front position only when the first block does not move: shift every record by one base instead -> no duplicate
+        for raw in by_name[nm]:
+            moved = bytearray(_rename_record(raw, f"shifted{k}"))
+            struct.pack_into("<i", moved, 8, struct.unpack_from("<i", moved, 8)[0] + 1)
+            out.append(bytes(moved))
+    new = tmp_path / "dups"
+    os.symlink(f"{pre}.bam", f"{new}.bam")
+    if os.path.exists(f"{pre}.bam.bai"):
+        os.symlink(f"{pre}.bam.bai", f"{new}.bam.bai")
+    bw.write_bam(f"{new}.chim.bam", contigs, out, sort_order="unsorted")
+    _, dump = ou.run_oracle(built, new, tmp_path)
+    want = _read_chimrecord(dump / "chimrecord.txt")
+    got, read_len = _build_chimeric_literal(f"{new}.chim.bam")
+    n_names = len(by_name) + len(picked) + 10
+    assert len(want) < n_names  # (fragments were dropped)
+    assert [(g["Qname"], g["ftl"], g["stl"], g["F"], g["S"]) for g in got] == [(w["Qname"], w["ftl"], w["stl"], w["F"], w["S"]) for w in want]
+    assert read_len == int(open(dump / "chimrecord.txt").readline().split("=")[1])
