@@ -17,6 +17,9 @@ reference's statements as Python allows, of
   length, the sort under `FrontSmallerThan` (`:90-117`, not a strict weak order: the permutation is whatever introsort makes of it) and the
   PCR-duplicate pass -> the fragment list every loop above starts from, against the oracle's dump of it.
 
+* `ExactBreakpoint` and `CountTop` (`SegmentGraph.cpp:3019-3081`, `:51-104`): the breakpoint pairs `_sv.txt` prints, per edge of the final
+  graph, over the fragments as the literal `RawEdgesChim` has trimmed them.
+
 The only inputs taken from elsewhere: the node coordinates of stage 1 and the number of kept records the stream loop consumes before its
 `break` (`:338-339`); the loops that need the merged chimeric fragments read the oracle's dump of them, which the last item checks.
 """
@@ -833,3 +836,85 @@ def test_oracle_chimeric_fragments_with_pcr_duplicates_against_the_literal_build
     assert len(want) < n_names  # (fragments were dropped)
     assert [(g["Qname"], g["ftl"], g["stl"], g["F"], g["S"]) for g in got] == [(w["Qname"], w["ftl"], w["stl"], w["F"], w["S"]) for w in want]
     assert read_len == int(open(dump / "chimrecord.txt").readline().split("=")[1])
+
+
+# ---- SegmentGraph.cpp:51-104 (CountTop) and :3019-3081 (ExactBreakpoint), over the fragments as RawEdgesChim has left them (LocateRead trims
+# the blocks to the nodes of the build stage; ExactBreakpoint locates -- and trims -- them again in the final node table)
+def _count_top(e, x):
+    x = sorted(x)
+    y = sorted(set(x))
+    count = [0.0] * len(y)
+    for i, yi in enumerate(y):
+        for xj in x:
+            if yi == xj:
+                count[i] += 1
+            elif abs(yi[0] - xj[0]) + abs(yi[1] - xj[1]) < 10:
+                count[i] += 0.5
+    out = []
+    while len(out) < 5:
+        it = max(range(len(count)), key=lambda i: (count[i], -i))  # max_element: the first of the largest
+        if count[it] > 3:
+            if all(abs(o[0] - y[it][0]) + abs(o[1] - y[it][1]) >= 50 for o in out):
+                out.append(y[it])
+        else:
+            break
+        count[it] = 0
+    if len(out) == 0:
+        lo1, hi1 = min(p[0] for p in y), max(max(p[0] for p in y), 0)
+        lo2, hi2 = min(p[1] for p in y), max(max(p[1] for p in y), 0)
+        _, _, head1, head2 = e
+        out.append((lo1 if head1 else hi1, lo2 if head2 else hi2))
+    return out
+
+
+def _exact_breakpoints_literal(nodes, chim):
+    E = _Edges([n[:3] for n in nodes])
+    bp = {}
+    firstfrontindex = 0
+    for it in chim:
+        F, S = it["F"], it["S"]
+        if len(F) <= 1 and len(S) <= 1:
+            continue
+        rn = _locate_read(E.nodes, firstfrontindex, F, S)
+        if rn[0] != -1:
+            firstfrontindex = rn[0]
+        for base, L in ((0, F), (len(F), S)):
+            if len(L) > 1:
+                for k in range(len(L) - 1):
+                    i, j = rn[base + k], rn[base + k + 1]
+                    if i != j and i != -1 and j != -1:
+                        tmp = E.make(i, bool(L[k]["IsReverse"]), j, not L[k + 1]["IsReverse"])
+                        if E.is_discordant(tmp):
+                            a, b = L[k], L[k + 1]
+                            b1 = a["RefPos"] if a["IsReverse"] else a["RefPos"] + a["MatchRef"]
+                            b2 = b["RefPos"] + b["MatchRef"] if b["IsReverse"] else b["RefPos"]
+                            if (a["RefID"], a["RefPos"]) > (b["RefID"], b["RefPos"]):  # SingleBamRec_t::operator>
+                                b1, b2 = b2, b1
+                            bp.setdefault(tmp, []).append((b1, b2))
+    return {e: _count_top(e, x) for e, x in bp.items()}
+
+
+@pytest.mark.parametrize("cfg", ["C1", "T2", "C2"])
+def test_oracle_exact_breakpoints_against_the_literal_loop(built, synth, tmp_path, cfg):
+    """CPU: the breakpoint pairs of every edge of the final graph (what `_sv.txt` prints as positions) from the literal ExactBreakpoint +
+    CountTop, run over the fragments after the literal RawEdgesChim has trimmed them, against the oracle's breakpoints.txt"""
+    import copy
+
+    pre = synth(cfg)
+    _, dump = ou.run_oracle(built, pre, tmp_path)
+    chim = _read_chimrecord(dump / "chimrecord.txt")
+    _raw_edges_chim(_Edges([n[:3] for n in ou.read_nodes(dump / "nodes_build.txt")]), chim)  # (trims the blocks in place, as the reference does)
+    got = _exact_breakpoints_literal(ou.read_nodes(dump / "nodes_final.txt"), copy.deepcopy(chim))
+    edges = ou.read_edges(dump / "edges_final.txt")
+    want = ou.read_breakpoints(dump / "breakpoints.txt")
+    assert len(edges) == len(want) > 0
+    n_exact = 0
+    for e, w in zip(edges, want):
+        key = (e[0], e[2], bool(e[1]), bool(e[3]))
+        g = got.get(key, [])
+        if g:
+            n_exact += 1
+            assert [(b1, b2) for b1, b2, _, _ in w] == g, (e, w, g)
+        else:
+            assert all(b1 == -1 and b2 == -1 for b1, b2, _, _ in w), (e, w)
+    assert n_exact > 0
