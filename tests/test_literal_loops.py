@@ -20,6 +20,8 @@ reference's statements as Python allows, of
 * `ExactBreakpoint` and `CountTop` (`SegmentGraph.cpp:3019-3081`, `:51-104`): the breakpoint pairs `_sv.txt` prints, per edge of the final
   graph, over the fragments as the literal `RawEdgesChim` has trimmed them.
 
+* `FilterEdges` with `GroupConnection` / `GroupSelect` (`:2394-2527`): which edges survive, from the stage in front of it.
+
 The only inputs taken from elsewhere: the node coordinates of stage 1 and the number of kept records the stream loop consumes before its
 `break` (`:338-339`); the loops that need the merged chimeric fragments read the oracle's dump of them, which the last item checks.
 """
@@ -918,3 +920,126 @@ def test_oracle_exact_breakpoints_against_the_literal_loop(built, synth, tmp_pat
         else:
             assert all(b1 == -1 and b2 == -1 for b1, b2, _, _ in w), (e, w)
     assert n_exact > 0
+
+
+# ---- SegmentGraph.cpp:2394-2527: GroupConnection, GroupSelect, FilterEdges (and UpdateNodeLink :2894-2910 for the per-node edge lists);
+# Min_Edge_Weight 5, MaxAllowedDegree 5, Concord_Dist_Pos 50000, Concord_Dist_Idx 20 (Config.cpp:24-28)
+def _filter_edges_literal(nodes, edges, keep, min_w=5, max_deg=5, dist_pos=50000, dist_idx=20):
+    chr_, pos, ln, depth = [n[0] for n in nodes], [n[1] for n in nodes], [n[2] for n in nodes], [n[4] for n in nodes]
+    head, tail = [[] for _ in nodes], [[] for _ in nodes]
+    for e in edges:  # e = (Ind1, Head1, Ind2, Head2, Weight, GroupWeight)
+        (head if e[1] else tail)[e[0]].append(e)
+        (head if e[3] else tail)[e[2]].append(e)
+    weak = lambda e, s: e[5] <= 0.01 * s and e[5] <= min_w
+    strong = lambda e, s: e[5] > 0.01 * s or e[5] > min_w
+
+    def group_connection(node, E, sumweight):
+        conn = sorted((e[0] if e[0] != node else e[2]) for e in E if strong(e, sumweight))
+        label = [-1] * len(conn)
+        mindist, index = -1, -1
+        for i, cn in enumerate(conn):
+            if chr_[cn] == chr_[node] and pos[node] - pos[cn] - ln[cn] <= dist_pos and pos[cn] - pos[node] - ln[node] <= dist_pos:
+                if mindist == -1 or mindist > abs(node - cn):
+                    mindist, index = abs(node - cn), i
+        if index != -1:
+            label[index] = 0
+            for i in range(index + 1, len(conn)):
+                if chr_[conn[i]] == chr_[node] and pos[conn[i]] - pos[conn[i - 1]] - ln[conn[i - 1]] <= dist_pos:
+                    label[i] = 0
+                else:
+                    break
+            for i in range(index - 1, -1, -1):
+                if chr_[conn[i]] == chr_[node] and pos[conn[i + 1]] - pos[conn[i]] - ln[conn[i]] <= dist_pos:
+                    label[i] = 0
+                else:
+                    break
+        count = 0
+        if len(label) != 0:
+            count = 1 if label[0] == -1 else 0
+            if label[0] == -1:
+                label[0] = 1
+            for i in range(1, len(conn)):
+                if label[i] != -1:
+                    continue
+                elif chr_[conn[i]] != chr_[conn[i - 1]] or pos[conn[i]] - pos[conn[i - 1]] - ln[conn[i - 1]] > dist_pos:
+                    count += 1
+                label[i] = count
+        return count, conn, label
+
+    def group_select(node, E, sumweight, count, conn, label, todelete):
+        lw = [0] * (count + 1)
+        for e in E:
+            if strong(e, sumweight):
+                lw[label[conn.index(e[0] if e[0] != node else e[2])]] += e[4]
+        maxlabel = 1
+        for i in range(1, len(lw)):
+            if lw[i] > lw[maxlabel]:
+                maxlabel = i
+        for e in E:
+            if strong(e, sumweight):
+                lb = label[conn.index(e[0] if e[0] != node else e[2])]
+                if lb != maxlabel and lb != 0:
+                    todelete.append(e)
+
+    bad, todelete = [], []
+    for i in range(len(nodes)):
+        hw, tw = sum(e[4] for e in head[i]), sum(e[4] for e in tail[i])
+        s = hw + tw
+        todelete += [e for e in head[i] if weak(e, s)] + [e for e in tail[i] if weak(e, s)]
+        hc, hconn, hlab = group_connection(i, head[i], s) if head[i] else (0, [], [])
+        tc, tconn, tlab = group_connection(i, tail[i], s) if tail[i] else (0, [], [])
+        if hc + tc >= max_deg:
+            bad.append(i)
+        else:
+            for cnt, E, w, conn, lab in ((hc, head[i], hw, hconn, hlab), (tc, tail[i], tw, tconn, tlab)):
+                if cnt > 1:
+                    group_select(i, E, s, cnt, conn, lab, todelete)
+                else:
+                    todelete += [e for e in E if not weak(e, s) and e[5] < 0.01 * w]
+    okey = lambda e: (e[0], e[2], e[1], e[3])  # Edge_t::operator<
+    todelete.sort(key=okey)
+    bad = set(bad)
+    tmp = []
+    for i, e in enumerate(edges):
+        cond1, cond2 = False, True
+        if e[0] not in bad and e[2] not in bad and e[5] > min_w:
+            cond1 = True
+        elif chr_[e[0]] == chr_[e[2]] and abs(pos[e[2]] - pos[e[0]] - ln[e[0]]) <= dist_pos and e[5] > min_w:
+            cond1 = True
+        if cond1 and (e[2] - e[0] > dist_idx or e[1] != 0 or e[3] != 1):
+            c1, c2 = depth[e[0]], depth[e[2]]
+            num, den = (c1, c2) if c1 > c2 else (c2, c1)
+            ratio = num / den if den != 0 else (float("inf") if num > 0 else float("nan"))  # (what the double division gives)
+            if (e[4] <= min_w + 2 and ratio > 3) or (e[4] > min_w + 2 and ratio > 50):
+                cond2 = False
+        if keep[i] and cond1 and cond2:
+            tmp.append(e)
+    tmp.sort(key=okey)
+    out, a, b = [], 0, 0  # std::set_difference over the two sorted ranges
+    while a < len(tmp):
+        if b == len(todelete):
+            out.append(tmp[a]); a += 1
+        elif okey(tmp[a]) < okey(todelete[b]):
+            out.append(tmp[a]); a += 1
+        elif okey(todelete[b]) < okey(tmp[a]):
+            b += 1
+        else:
+            a += 1; b += 1
+    return out
+
+
+@pytest.mark.parametrize("cfg,gen,flags", [("C1", (), ()), ("T2", (), ()), ("C2", (), ()), ("T2", (), ("-w", "2")), ("C2", ("--support", "2,6"), ("-w", "1", "-a", "50")),
+                                           ("C5", ("--records", "300000", "--tsv", "1500"), ("-w", "1", "-a", "50")), ("C5", ("--records", "300000", "--tsv", "1500", "--support", "2,8"), ())])
+def test_oracle_filter_edges_against_the_literal_loop(built, synth, tmp_path, cfg, gen, flags):
+    """CPU: the edges that survive FilterEdges (GroupConnection / GroupSelect per node, the depth-ratio rule, the set difference with the
+    deleted edges) from the literal loop over the oracle's stage in front of it (nodes with depths, edges with group weights, KeepEdge of
+    FilterbyInterleaving), against the oracle's stage behind it"""
+    pre = synth(cfg, *gen)
+    _, dump = ou.run_oracle(built, pre, tmp_path, *flags)
+    nodes = ou.read_nodes(dump / "nodes_build.txt")
+    rows = ou.read_edges(dump / "edges_interleave.txt")
+    opts = dict(zip(flags[::2], flags[1::2]))
+    got = _filter_edges_literal(nodes, [r[:6] for r in rows], [r[6] for r in rows], min_w=int(opts.get("-w", 5)), max_deg=int(opts.get("-a", 5)))
+    want = ou.read_edges(dump / "edges_filter.txt")
+    assert got == [tuple(w[:6]) for w in want]
+    assert 0 < len(want) <= len(rows)
