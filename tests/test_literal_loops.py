@@ -20,7 +20,8 @@ reference's statements as Python allows, of
 * `ExactBreakpoint` and `CountTop` (`SegmentGraph.cpp:3019-3081`, `:51-104`): the breakpoint pairs `_sv.txt` prints, per edge of the final
   graph, over the fragments as the literal `RawEdgesChim` has trimmed them.
 
-* `FilterEdges` with `GroupConnection` / `GroupSelect` (`:2394-2527`): which edges survive, from the stage in front of it.
+* `FilterbyWeight` (`:1968-2124`, its slips included) and `FilterEdges` with `GroupConnection` / `GroupSelect` (`:2394-2527`): group
+  weights and which edges survive, each from the stage in front of it.
 
 The only inputs taken from elsewhere: the node coordinates of stage 1 and the number of kept records the stream loop consumes before its
 `break` (`:338-339`); the loops that need the merged chimeric fragments read the oracle's dump of them, which the last item checks.
@@ -1043,3 +1044,122 @@ def test_oracle_filter_edges_against_the_literal_loop(built, synth, tmp_path, cf
     want = ou.read_edges(dump / "edges_filter.txt")
     assert got == [tuple(w[:6]) for w in want]
     assert 0 < len(want) <= len(rows)
+
+
+# ---- SegmentGraph.cpp:1968-2124, statement by statement, its slips included (`vEdges[i].Ind1` / `vEdges[i].Ind2` where the neighbour j is
+# meant at :2002, :2006, :2021, :2054, and the forward loop's opposite-orientation branch moving the lower ends of its ranges, :2058-2059)
+def _filter_by_weight_literal(nodes, edges, min_w=5, dist_pos=50000, dist_idx=20):
+    chr_, pos, ln = [n[0] for n in nodes], [n[1] for n in nodes], [n[2] for n in nodes]
+    E = [list(e[:6]) for e in edges]  # [Ind1, Head1, Ind2, Head2, Weight, GroupWeight]
+    n = len(E)
+    p1 = lambda e: pos[e[0]] if e[1] else pos[e[0]] + ln[e[0]]
+    p2 = lambda e: pos[e[2]] if e[3] else pos[e[2]] + ln[e[2]]
+
+    def is_disc(e):  # IsDiscordant(int), :159-168
+        if chr_[e[0]] != chr_[e[2]]:
+            return True
+        elif pos[e[2]] - pos[e[0]] - ln[e[0]] > dist_pos and e[2] - e[0] > dist_idx:
+            return True
+        elif e[1] != 0 or e[3] != 1:
+            return True
+        return False
+
+    seen = [False] * n
+    for i in range(n):
+        if seen[i]:
+            continue
+        ei = E[i]
+        chr1, chr2 = chr_[ei[0]], chr_[ei[2]]
+        near = [i]
+        seen[i] = True
+        if ei[1] or not ei[3] or chr1 != chr2:
+            I1s, P1s, I2s, P2s = [ei[0], ei[0]], [p1(ei), p1(ei)], [ei[2], ei[2]], [p2(ei), p2(ei)]
+            I1o, P1o, I2o, P2o = list(I1s), list(P1s), list(I2s), list(P2s)
+            long_group = False
+            j = i - 1
+            while j > -1 and chr_[E[j][0]] == chr1:
+                ej = E[j]
+                np1, np2 = p1(ej), p2(ej)
+                if ei[0] < min(I1s[0], I1o[0]) - dist_idx or np1 < min(P1s[0], P1o[0]) - dist_pos:
+                    break
+                if ej[1] == ei[1] and ej[3] == ei[3]:
+                    if is_disc(ej) and ej[2] >= I2s[0] - dist_idx and ei[2] <= I2s[1] + dist_idx and np2 >= P2s[0] - dist_pos and np2 <= P2s[1] + dist_pos:
+                        near.append(j)
+                        I1s[0] = min(I1s[0], ej[0]); P1s[0] = min(P1s[0], np1)
+                        I2s[0] = min(I2s[0], ej[2]); I2s[1] = max(I2s[1], ej[2])
+                        P2s[0] = min(P2s[0], np2); P2s[1] = max(P2s[1], np2)
+                        if I1s[1] >= I2s[0]:
+                            long_group = True
+                elif ej[1] != ei[1] and ej[3] != ei[3]:
+                    if is_disc(ej) and ej[2] >= I2o[0] - dist_idx and ei[2] <= I2o[1] + dist_idx and np2 >= P2o[0] - dist_pos and np2 <= P2o[1] + dist_pos:
+                        near.append(j)
+                        I1o[0] = min(I1o[0], ej[0]); P1o[0] = min(P1o[0], np1)
+                        I2o[0] = min(I2o[0], ej[2]); I2o[1] = max(I2o[1], ej[2])
+                        P2o[0] = min(P2o[0], np2); P2o[1] = max(P2o[1], np2)
+                        if I1o[1] >= I2o[0]:
+                            long_group = True
+                j -= 1
+            j = i + 1
+            while j < n and chr_[E[j][0]] == chr1:
+                ej = E[j]
+                np1, np2 = p1(ej), p2(ej)
+                if ej[0] > max(I1s[1], I1o[1]) + dist_idx or np1 > max(P1s[1], P1o[1]) + dist_pos:
+                    break
+                if ej[1] == ei[1] and ej[3] == ei[3]:
+                    if is_disc(ej) and ej[2] >= I2s[0] - dist_idx and ej[2] <= I2s[1] + dist_idx and np2 >= P2s[0] - dist_pos and np2 <= P2s[1] + dist_pos:
+                        near.append(j)
+                        I1s[1] = max(I1s[1], ej[0]); P1s[1] = max(P1s[1], np1)
+                        I2s[0] = min(I2s[0], ej[2]); I2s[1] = max(I2s[1], ej[2])
+                        P2s[0] = min(P2s[0], np2); P2s[1] = max(P2s[1], np2)
+                        if I1s[1] >= I2s[0]:
+                            long_group = True
+                elif ej[1] != ei[1] and ej[3] != ei[3]:
+                    if is_disc(ej) and ej[2] >= I2o[0] - dist_idx and ei[2] <= I2o[1] + dist_idx and np2 >= P2o[0] - dist_pos and np2 <= P2o[1] + dist_pos:
+                        near.append(j)
+                        I1o[0] = min(I1o[0], ej[0]); P1o[0] = min(P1o[0], np1)
+                        I2o[0] = min(I2o[0], ej[2]); I2o[1] = max(I2o[1], ej[2])
+                        P2o[0] = min(P2o[0], np2); P2o[1] = max(P2o[1], np2)
+                        if I1o[1] >= I2o[0]:
+                            long_group = True
+                j += 1
+            near = sorted(set(near))
+            if not long_group:
+                s = sum(E[k][4] for k in near)
+                for k in near:
+                    E[k][5] = s if E[k][5] < s else E[k][5]
+                    seen[k] = True
+            else:
+                for k in near:
+                    E[k][5] = E[k][4]
+                    seen[k] = True
+        else:
+            pos1, pos2 = p1(ei), p2(ei)
+            j = i - 1
+            while j > -1 and E[j][0] >= ei[0] - dist_idx and chr_[E[j][0]] == chr1 and pos[E[j][0]] + ln[E[j][0]] >= pos1 - dist_pos:
+                ej = E[j]
+                if ej[2] > ei[0] and ei[1] == ej[1] and ei[3] == ej[3] and chr_[ej[0]] == chr1 and chr_[ej[2]] == chr2 and abs(ej[2] - ei[2]) <= dist_idx and abs(p1(ej) - pos1) <= dist_pos and abs(p2(ej) - pos2) <= dist_pos:
+                    near.append(j)
+                j -= 1
+            j = i + 1
+            while j < n and E[j][0] <= ei[0] + dist_idx and chr_[E[j][0]] == chr1 and pos[E[j][0]] <= pos1 + dist_pos:
+                ej = E[j]
+                if ej[0] < ei[2] and ei[1] == ej[1] and ei[3] == ej[3] and chr_[ej[0]] == chr1 and chr_[ej[2]] == chr2 and abs(ej[2] - ei[2]) <= dist_idx and abs(p1(ej) - pos1) <= dist_pos and abs(p2(ej) - pos2) <= dist_pos:
+                    near.append(j)
+                j += 1
+            ei[5] = sum(E[k][4] for k in sorted(set(near)))
+    return [tuple(e) for e in E if e[5] > min_w - 2]
+
+
+@pytest.mark.parametrize("cfg,gen,flags", [("C1", (), ()), ("T2", (), ()), ("C2", (), ("-w", "2")), ("C2", ("--support", "2,6"), ("-w", "1", "-a", "50")),
+                                           ("C5", ("--records", "300000", "--tsv", "1500"), ("-w", "1", "-a", "50")), ("C5", ("--records", "300000", "--tsv", "1500", "--support", "2,8"), ())])
+def test_oracle_filter_by_weight_against_the_literal_loop(built, synth, tmp_path, cfg, gen, flags):
+    """CPU: the group weight of every edge and the edges that pass the relaxed threshold, from the literal FilterbyWeight over the oracle's
+    BuildEdges stage, against the oracle's stage behind it"""
+    pre = synth(cfg, *gen)
+    _, dump = ou.run_oracle(built, pre, tmp_path, *flags)
+    opts = dict(zip(flags[::2], flags[1::2]))
+    rows = ou.read_edges(dump / "edges_build.txt")
+    got = _filter_by_weight_literal(ou.read_nodes(dump / "nodes_build.txt"), rows, min_w=int(opts.get("-w", 5)))
+    want = [tuple(w[:6]) for w in ou.read_edges(dump / "edges_weight.txt")]
+    assert got == want
+    assert 0 < len(want) <= len(rows) and any(w[5] != w[4] for w in want)
