@@ -21,7 +21,7 @@ reference's statements as Python allows, of
   graph, over the fragments as the literal `RawEdgesChim` has trimmed them.
 
 * `FilterbyWeight` (`:1968-2124`, its slips included) and `FilterEdges` with `GroupConnection` / `GroupSelect` (`:2394-2527`): group
-  weights and which edges survive, each from the stage in front of it.
+  weights and which edges survive, each from the stage in front of it; `CompressNode` (`:2528-2604`) the same way.
 
 The only inputs taken from elsewhere: the node coordinates of stage 1 and the number of kept records the stream loop consumes before its
 `break` (`:338-339`); the loops that need the merged chimeric fragments read the oracle's dump of them, which the last item checks.
@@ -1163,3 +1163,49 @@ def test_oracle_filter_by_weight_against_the_literal_loop(built, synth, tmp_path
     want = [tuple(w[:6]) for w in ou.read_edges(dump / "edges_weight.txt")]
     assert got == want
     assert 0 < len(want) <= len(rows) and any(w[5] != w[4] for w in want)
+
+
+# ---- SegmentGraph.cpp:2528-2604: nodes no edge touches are merged run by run (never across a chromosome), Support summed, AvgDepth the
+# length-weighted mean in the order the reference adds it up; edges re-indexed
+def _compress_node_literal(nodes, edges):
+    linked = sorted(set([e[0] for e in edges] + [e[2] for e in edges]))
+    assert linked
+    new, old_new = [], {}
+
+    def merged(lo, hi):  # one node for vNodes[lo .. hi)
+        length = nodes[hi - 1][1] + nodes[hi - 1][2] - nodes[lo][1]
+        support, depth = 0, 0.0
+        for k in range(lo, hi):
+            support += nodes[k][3]
+            depth += nodes[k][4] * nodes[k][2]
+        return (nodes[lo][0], nodes[lo][1], length, support, depth / length)
+
+    def run(startidx, endidx):
+        lastinsert = startidx
+        for j in range(startidx, endidx):
+            if nodes[j][0] != nodes[lastinsert][0]:
+                new.append(merged(lastinsert, j))
+                lastinsert = j
+        if lastinsert != endidx:
+            new.append(merged(lastinsert, endidx))
+
+    for i, endidx in enumerate(linked):
+        run(0 if i == 0 else linked[i - 1] + 1, endidx)
+        new.append(tuple(nodes[endidx][:5]))
+        old_new[endidx] = len(new) - 1
+    if linked[-1] != len(nodes) - 1:
+        run(linked[-1] + 1, len(nodes))
+    return new, [(old_new[e[0]], e[1], old_new[e[2]], e[3]) + tuple(e[4:6]) for e in edges]
+
+
+@pytest.mark.parametrize("cfg,gen,flags", [("C1", (), ()), ("T2", (), ()), ("C2", (), ()), ("C5", ("--records", "300000", "--tsv", "1500", "--support", "2,8"), ())])
+def test_oracle_compress_node_against_the_literal_loop(built, synth, tmp_path, cfg, gen, flags):
+    """CPU: node table and re-indexed edges behind CompressNode from the literal loop over the oracle's stage in front of it -- the merged
+    nodes' AvgDepth as the same IEEE doubles (summed and divided in the reference's order)"""
+    pre = synth(cfg, *gen)
+    _, dump = ou.run_oracle(built, pre, tmp_path, *flags)
+    nodes, edges = _compress_node_literal(ou.read_nodes(dump / "nodes_build.txt"), ou.read_edges(dump / "edges_filter.txt"))
+    assert nodes == [tuple(n[:5]) for n in ou.read_nodes(dump / "nodes_compress.txt")]
+    assert edges == [tuple(e[:6]) for e in ou.read_edges(dump / "edges_compress.txt")]
+    # (on the small samples every node carries an edge and nothing is merged; the filtered dense sample has unlinked runs)
+    assert len(nodes) < len(ou.read_nodes(dump / "nodes_build.txt")) or cfg != "C5"
