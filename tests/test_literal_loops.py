@@ -21,7 +21,8 @@ reference's statements as Python allows, of
   graph, over the fragments as the literal `RawEdgesChim` has trimmed them.
 
 * `FilterbyWeight` (`:1968-2124`, its slips included) and `FilterEdges` with `GroupConnection` / `GroupSelect` (`:2394-2527`): group
-  weights and which edges survive, each from the stage in front of it; `CompressNode` (`:2528-2604`) the same way.
+  weights and which edges survive, each from the stage in front of it; `CompressNode` (`:2528-2604`) the same way; and
+  `FurtherCompressNode` + `ConnectedComponent` + `MultiplyDisEdges` (`:2693-2892`, `:2911-3003`, `:3005-3010`) -> the final graph.
 
 The only inputs taken from elsewhere: the node coordinates of stage 1 and the number of kept records the stream loop consumes before its
 `break` (`:338-339`); the loops that need the merged chimeric fragments read the oracle's dump of them, which the last item checks.
@@ -1209,3 +1210,180 @@ def test_oracle_compress_node_against_the_literal_loop(built, synth, tmp_path, c
     assert edges == [tuple(e[:6]) for e in ou.read_edges(dump / "edges_compress.txt")]
     # (on the small samples every node carries an edge and nothing is merged; the filtered dense sample has unlinked runs)
     assert len(nodes) < len(ou.read_nodes(dump / "nodes_build.txt")) or cfg != "C5"
+
+
+# ---- SegmentGraph.cpp:2693-2892 (FurtherCompressNode), :2911-3003 (DFS, ConnectedComponent), :3005-3010 (MultiplyDisEdges, DiscordantRatio 8)
+def _further_compress_literal(nodes, edges, dist_pos=50000, dist_idx=20, ratio=8):
+    chr_, pos, ln = [n[0] for n in nodes], [n[1] for n in nodes], [n[2] for n in nodes]
+    n = len(nodes)
+
+    def link(nn, E):
+        head, tail = [[] for _ in range(nn)], [[] for _ in range(nn)]
+        for e in E:
+            (head if e[1] else tail)[e[0]].append(e)
+            (head if e[3] else tail)[e[2]].append(e)
+        return head, tail
+
+    def is_disc(e, c=chr_, p=pos, l=ln):
+        if c[e[0]] != c[e[2]]:
+            return True
+        elif p[e[2]] - p[e[0]] - l[e[0]] > dist_pos and e[2] - e[0] > dist_idx:
+            return True
+        elif e[1] != 0 or e[3] != 1:
+            return True
+        return False
+
+    head, tail = link(n, edges)
+    close = lambda a, b: abs(a[0] - b[0]) <= dist_idx and abs(a[2] - b[2]) <= dist_idx
+    samehd = lambda a, b: a[1] == b[1] and a[3] == b[3]
+    samechr = lambda a, b: chr_[a[0]] == chr_[b[0]] and chr_[a[2]] == chr_[b[2]]
+    merge = [-1] * n
+    cur = rightmost = 0
+    unset_uses = 0
+
+    def next_with(i, mindis):
+        nxt = []
+        j = i + 1
+        while j < n and j < i + 20 and j < mindis and chr_[i] == chr_[j]:
+            nxt += [e for e in head[j] if is_disc(e)] + [e for e in tail[j] if is_disc(e)]
+            if nxt:
+                break
+            j += 1
+        return j, nxt
+
+    def squeeze(V, at=None):  # keeps V[k + 1] unless it belongs to the group of V[k]
+        out = [V[0]]
+        for k in range(len(V) - 1):
+            e1, e2 = V[k], V[k + 1]
+            if at is None:
+                same = close(e1, e2) and samechr(e1, e2) and samehd(e1, e2)
+            else:
+                same = ((e1[0] == at and e2[0] == at) or (e1[2] == at and e2[2] == at)) and close(e1, e2) and samechr(e1, e2) and samehd(e1, e2)
+            if not same:
+                out.append(e2)
+        return out
+
+    def cross(A, B):
+        a_eq, b_eq = [False] * len(A), [False] * len(B)
+        for k, e1 in enumerate(A):
+            for l, e2 in enumerate(B):
+                if e1[2] > e2[0] and e2[2] > e1[0] and samechr(e1, e2) and close(e1, e2) and samehd(e1, e2):
+                    a_eq[k] = b_eq[l] = True
+        return all(a_eq) and all(b_eq)
+
+    for i in range(n):
+        this = []
+        mindis = None
+        if i != 0 and chr_[i] != chr_[i - 1] and cur == merge[i - 1]:
+            cur += 1
+        for e in head[i] + tail[i]:
+            if is_disc(e):
+                this.append(e)
+            else:
+                rightmost = max(rightmost, e[0], e[2])
+        if this:
+            mindis = this[0][2] if this[0][0] == i else i + 20
+            tmp = [this[0]]
+            for k in range(len(this) - 1):
+                e1, e2 = this[k], this[k + 1]
+                same = (e1[0] == i and e2[0] == i) or (e1[2] == i and e2[2] == i)
+                if not (close(e1, e2) and samehd(e1, e2)):  # (:2721: no chromosome test in this one)
+                    same = False
+                if not same:
+                    tmp.append(e2)
+                mindis = min(mindis, e2[2] if e2[0] == i else i + 20)
+            this = tmp
+        if merge[i] == -1:
+            if not this and i < rightmost:
+                merge[i] = cur
+            elif not this and i == rightmost:
+                merge[i] = cur
+                cur += 1
+                rightmost += 1
+            else:
+                if mindis is None:  # (the reference reads it unset here: a node without discordant edges behind `rightmost`)
+                    unset_uses += 1
+                    mindis = i + 20
+                if i != 0 and cur == merge[i - 1]:
+                    cur += 1
+                j, nxt = next_with(i, mindis)
+                equivalent = len(nxt) != 0
+                if nxt:
+                    equivalent = cross(this, squeeze(nxt, at=j))
+                if not equivalent:
+                    merge[i] = cur
+                    cur += 1
+                else:
+                    for k in range(i, j + 1):
+                        merge[k] = cur
+                rightmost = i + 1
+        elif this:
+            j, nxt = next_with(i, mindis)
+            equivalent = len(nxt) != 0
+            if nxt:
+                equivalent = cross(squeeze(this), squeeze(nxt))
+            if not equivalent:
+                cur += 1
+            else:
+                for k in range(i, j + 1):
+                    merge[k] = cur
+            rightmost = i + 1
+    for i in range(n - 1):
+        assert merge[i] == merge[i + 1] or merge[i] + 1 == merge[i + 1]
+    new_nodes = []
+    ind = 0
+    while ind < n:
+        j = ind
+        while j < n and merge[j] == merge[ind]:
+            j += 1
+        new_nodes.append((chr_[ind], pos[ind], pos[j - 1] + ln[j - 1] - pos[ind]))
+        ind = j
+    raw = []
+    for e in edges:
+        if merge[e[0]] != merge[e[2]]:
+            a, b = merge[e[0]], merge[e[2]]
+            raw.append((b, e[3], a, e[1], e[4]) if a > b else (a, e[1], b, e[3], e[4]))  # Edge_t's constructor
+    raw.sort(key=lambda e: (e[0], e[2], e[1], e[3]))
+    new_edges = []
+    for e in raw:
+        if not new_edges or new_edges[-1][:4] != list(e[:4]):
+            new_edges.append(list(e))
+        else:
+            new_edges[-1][4] += e[4]
+    # ConnectedComponent: labels in the order of the first node of every component (the traversal order does not reach the labels)
+    nn = len(new_nodes)
+    h2, t2 = link(nn, [tuple(e) for e in new_edges])
+    label, cur_label = [-1] * nn, 0
+    for start in range(nn):
+        if label[start] != -1:
+            continue
+        stack = [start]
+        while stack:
+            v = stack.pop()
+            if label[v] == -1:
+                label[v] = cur_label
+                for e in h2[v] + t2[v]:
+                    stack.append(e[0] if e[0] != v else e[2])
+        cur_label += 1
+    c2, p2, l2 = [x[0] for x in new_nodes], [x[1] for x in new_nodes], [x[2] for x in new_nodes]
+    for e in new_edges:  # MultiplyDisEdges
+        if is_disc(e, c2, p2, l2):
+            e[4] = int(ratio) * e[4]
+    return new_nodes, label, [tuple(e) for e in new_edges], unset_uses
+
+
+@pytest.mark.parametrize("cfg,gen,flags", [("C1", (), ()), ("T2", (), ()), ("C2", (), ()), ("C2", ("--support", "2,6"), ("-w", "1", "-a", "50")),
+                                           ("C5", ("--records", "300000", "--tsv", "1500"), ("-w", "1", "-a", "50")), ("C5", ("--records", "300000", "--tsv", "1500", "--support", "2,8"), ())])
+def test_oracle_final_graph_against_the_literal_loops(built, synth, tmp_path, cfg, gen, flags):
+    """CPU: the final node table, the component labels and the final edges (weights of discordant edges multiplied) from the literal
+    FurtherCompressNode + ConnectedComponent + MultiplyDisEdges over the oracle's stage behind CompressNode, against the oracle's final
+    graph"""
+    pre = synth(cfg, *gen)
+    _, dump = ou.run_oracle(built, pre, tmp_path, *flags)
+    nodes, label, edges, unset = _further_compress_literal(ou.read_nodes(dump / "nodes_compress.txt"), ou.read_edges(dump / "edges_compress.txt"))
+    want_nodes = ou.read_nodes(dump / "nodes_final.txt")
+    assert nodes == [n[:3] for n in want_nodes]
+    assert all(n[3] == 0 and n[4] == 0.0 for n in want_nodes)  # (Support / AvgDepth are reset, ledger B15)
+    assert label == [n[5] for n in want_nodes]
+    assert edges == [tuple(e[:5]) for e in ou.read_edges(dump / "edges_final.txt")]
+    assert len(nodes) < len(ou.read_nodes(dump / "nodes_compress.txt"))
