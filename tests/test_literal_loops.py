@@ -24,6 +24,9 @@ reference's statements as Python allows, of
   weights and which edges survive, each from the stage in front of it; `CompressNode` (`:2528-2604`) the same way; and
   `FurtherCompressNode` + `ConnectedComponent` + `MultiplyDisEdges` (`:2693-2892`, `:2911-3003`, `:3005-3010`) -> the final graph.
 
+* `WriteBEDPE` (`WriteIO.cpp:45-124`) with `Node_NewChr` and `DeMultiplyDisEdges`: the text of `_sv.txt`, byte for byte, from the final graph,
+  the component orders and the breakpoints.
+
 The only inputs taken from elsewhere: the node coordinates of stage 1 and the number of kept records the stream loop consumes before its
 `break` (`:338-339`); the loops that need the merged chimeric fragments read the oracle's dump of them, which the last item checks.
 """
@@ -1387,3 +1390,72 @@ def test_oracle_final_graph_against_the_literal_loops(built, synth, tmp_path, cf
     assert label == [n[5] for n in want_nodes]
     assert edges == [tuple(e[:5]) for e in ou.read_edges(dump / "edges_final.txt")]
     assert len(nodes) < len(ou.read_nodes(dump / "nodes_compress.txt"))
+
+
+# ---- main.cpp:50-53 (Node_NewChr), SegmentGraph.cpp:3012-3017 (DeMultiplyDisEdges), WriteIO.cpp:45-124 (WriteBEDPE): the text of `_sv.txt`
+# from the final graph, the component orders and the breakpoints with their support.  std::sort by weight is not stable: the row order among
+# equal weights is what introsort makes of it (`_std_sort`).
+def _write_bedpe_literal(refnames, nodes, edges, bps, orders, ratio=8, dist_pos=50000, dist_idx=20):
+    chr_, pos, ln = [n[0] for n in nodes], [n[1] for n in nodes], [n[2] for n in nodes]
+
+    def is_disc(e):
+        if chr_[e[0]] != chr_[e[2]]:
+            return True
+        elif pos[e[2]] - pos[e[0]] - ln[e[0]] > dist_pos and e[2] - e[0] > dist_idx:
+            return True
+        elif e[1] != 0 or e[3] != 1:
+            return True
+        return False
+
+    E = []
+    for e, bp in zip(edges, bps):
+        w = int(e[4] / ratio) if is_disc(e) and ratio != 1 else e[4]
+        E.append((e[0], e[1], e[2], e[3], w, bp))
+    _std_sort(E, lambda a, b: a[4] > b[4])
+    where = [None] * len(nodes)
+    for i, comp in enumerate(orders):
+        for j, v in enumerate(comp):
+            where[abs(v) - 1] = (i, j)
+    out = ["# chrom1\tstart1\tend1\tchrom2\tstart2\tend2\tname\tscore\tstrand1\tstrand2\tnum_concordantfrag_bp1\tnum_concordantfrag_bp2\n"]
+    for i1, h1, i2, h2, w, bp in E:
+        flag_chr = chr_[i1] == chr_[i2]
+        flag_ori = h1 == 0 and h2 == 1
+        flag_dist = pos[i2] - pos[i1] - ln[i1] <= dist_pos or i2 - i1 <= dist_idx
+        if flag_chr and flag_ori and flag_dist:
+            continue
+        p1, p2 = where[i1], where[i2]
+        flag = False
+        if p1[0] == p2[0] and p1[1] < p2[1] and bool(h1) == (orders[p1[0]][p1[1]] < 0) and bool(h2) == (orders[p2[0]][p2[1]] > 0):
+            flag = True
+        elif p1[0] == p2[0] and p1[1] > p2[1] and bool(h2) == (orders[p2[0]][p2[1]] < 0) and bool(h1) == (orders[p1[0]][p1[1]] > 0):
+            flag = True
+        if not flag:
+            continue
+        if all(b[0] == -1 and b[1] == -1 for b in bp):  # no exact breakpoint: the node ends the edge leaves from
+            pairs = [(pos[i1] if h1 else pos[i1] + ln[i1], pos[i2] if h2 else pos[i2] + ln[i2])]
+        else:
+            pairs = [(b[0], b[1]) for b in bp]
+        assert len(pairs) == len(bp)
+        for (b1, b2), sup in zip(pairs, bp):
+            row = [refnames[chr_[i1]]] + ([str(b1), str(pos[i1] + ln[i1])] if h1 else [str(pos[i1]), str(b1)])
+            row += [refnames[chr_[i2]]] + ([str(b2), str(pos[i2] + ln[i2])] if h2 else [str(pos[i2]), str(b2)])
+            row += [".", str(w), "-" if h1 else "+", "-" if h2 else "+", str(sup[2]), str(sup[3])]
+            out.append("\t".join(row) + "\n")
+    return "".join(out)
+
+
+@pytest.mark.parametrize("cfg,gen,flags", [("C1", (), ()), ("T2", (), ()), ("C2", (), ()), ("C2", ("--support", "2,6"), ("-w", "1", "-a", "50")),
+                                           ("C5", ("--records", "300000", "--tsv", "1500"), ("-w", "1", "-a", "50"))])
+def test_oracle_sv_text_against_the_literal_writer(built, synth, tmp_path, cfg, gen, flags):
+    """CPU: `_sv.txt` byte for byte from the literal WriteBEDPE over the oracle's final graph, component orders and breakpoints (row order
+    among equal scores included)"""
+    import squid_amd
+
+    pre = synth(cfg, *gen)
+    sv_path, dump = ou.run_oracle(built, pre, tmp_path, *flags)
+    names, _ = squid_amd.read_header(f"{pre}.bam")
+    got = _write_bedpe_literal(names, ou.read_nodes(dump / "nodes_final.txt"), ou.read_edges(dump / "edges_final.txt"), ou.read_breakpoints(dump / "breakpoints.txt"),
+                               ou.read_orders(dump / "orders.txt"))
+    want = open(sv_path).read()
+    assert got == want
+    assert want.count("\n") > 1
