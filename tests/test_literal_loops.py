@@ -22,7 +22,8 @@ reference's statements as Python allows, of
 
 * `FilterbyWeight` (`:1968-2124`, its slips included) and `FilterEdges` with `GroupConnection` / `GroupSelect` (`:2394-2527`): group
   weights and which edges survive, each from the stage in front of it; `CompressNode` (`:2528-2604`) the same way; and
-  `FurtherCompressNode` + `ConnectedComponent` + `MultiplyDisEdges` (`:2693-2892`, `:2911-3003`, `:3005-3010`) -> the final graph.
+  `FurtherCompressNode` + `ConnectedComponent` + `MultiplyDisEdges` (`:2693-2892`, `:2911-3003`, `:3005-3010`) -> the final graph;
+  `FilterbyInterleaving` (`:2161-2277`) -> KeepEdge (all "keep" on the generator's files: the walks and the long-group rule, not the overlap rule).
 
 * `WriteBEDPE` (`WriteIO.cpp:45-124`) with `Node_NewChr` and `DeMultiplyDisEdges`: the text of `_sv.txt`, byte for byte, from the final graph,
   the component orders and the breakpoints.
@@ -1459,3 +1460,95 @@ def test_oracle_sv_text_against_the_literal_writer(built, synth, tmp_path, cfg, 
     want = open(sv_path).read()
     assert got == want
     assert want.count("\n") > 1
+
+
+# ---- SegmentGraph.cpp:2161-2277 (FilterbyInterleaving), slips kept: `vEdges[i].Ind1` / `vEdges[i].Ind2` for the neighbour at :2192 and
+# :2194, and the stray `;` of :2267 that lets overlapInd1 be computed from value-initialised (0, 0) ranges when a side has no edge
+def _filter_by_interleaving_literal(nodes, edges, dist_pos=50000, dist_idx=20):
+    chr_, pos, ln = [n[0] for n in nodes], [n[1] for n in nodes], [n[2] for n in nodes]
+    E = edges
+    n = len(E)
+    p1 = lambda e: pos[e[0]] if e[1] else pos[e[0]] + ln[e[0]]
+    p2 = lambda e: pos[e[2]] if e[3] else pos[e[2]] + ln[e[2]]
+    seen, keep = [False] * n, [True] * n
+    for i in range(n):
+        if seen[i]:
+            continue
+        ei = E[i]
+        if ei[2] - ei[0] <= dist_idx or (chr_[ei[0]] == chr_[ei[2]] and abs(pos[ei[0]] - pos[ei[2]]) <= dist_pos):
+            seen[i] = True
+            keep[i] = True
+            continue
+        chr1 = chr_[ei[0]]
+        minpos1 = maxpos1 = p1(ei)
+        minidx1 = maxidx1 = ei[0]
+        minpos2 = maxpos2 = p2(ei)
+        minidx2 = maxidx2 = ei[2]
+        long_group = False
+        near = [i]
+        j = i - 1
+        while j > -1 and chr_[E[j][0]] == chr1:
+            ej = E[j]
+            np1, np2 = p1(ej), p2(ej)
+            if ei[0] < minidx1 - dist_idx or np1 < minpos1 - dist_pos:
+                break
+            if ej[2] >= minidx2 - dist_idx and ei[2] <= maxidx2 + dist_idx and np2 >= minpos2 - dist_pos and np2 <= maxpos2 + dist_pos:
+                near.append(j)
+                minidx1 = min(minidx1, ej[0]); minpos1 = min(minpos1, np1)
+                minidx2 = min(minidx2, ej[2]); maxidx2 = max(maxidx2, ej[2])
+                minpos2 = min(minpos2, np2); maxpos2 = max(maxpos2, np2)
+                if maxidx1 >= minidx2:
+                    long_group = True
+                    break
+            j -= 1
+        j = i + 1
+        while j < n and chr_[E[j][0]] == chr1:
+            ej = E[j]
+            np1, np2 = p1(ej), p2(ej)
+            if ej[0] > maxidx1 + dist_idx or np1 > maxpos1 + dist_pos:
+                break
+            if ej[2] >= minidx2 - dist_idx and ej[2] <= maxidx2 + dist_idx and np2 >= minpos2 - dist_pos and np2 <= maxpos2 + dist_pos:
+                near.append(j)
+                maxidx1 = max(maxidx1, ej[0]); maxpos1 = max(maxpos1, np1)
+                minidx2 = min(minidx2, ej[2]); maxidx2 = max(maxidx2, ej[2])
+                minpos2 = min(minpos2, np2); maxpos2 = max(maxpos2, np2)
+                if maxidx1 >= minidx2:
+                    long_group = True
+                    break
+            j += 1
+        if long_group:
+            for k in near:
+                seen[k] = True
+            continue
+        near.sort()
+        g1h, g1t, g2h, g2t = [], [], [], []
+        for k in near:
+            e = E[k]
+            (g1h if e[1] else g1t).append(e[2])
+            (g2h if e[3] else g2t).append(e[0])
+        rng = lambda v: (min(v), max(v)) if v else (0, 0)
+        r1h, r1t, r2h, r2t = rng(g1h), rng(g1t), rng(g2h), rng(g2t)
+        overlap1 = min(r1h[1], r1t[1]) >= max(r1h[0], r1t[0])  # (computed whatever the group sizes: the `if` in front of it ends in `;`)
+        overlap2 = False
+        if g2h and g2t:
+            overlap2 = min(r2h[1], r2t[1]) >= max(r2h[0], r2t[0])
+        if overlap1 and overlap2:
+            for k in near:
+                keep[k] = False
+        for k in near:
+            seen[k] = True
+    return keep
+
+
+@pytest.mark.parametrize("cfg,gen,flags", [("C1", (), ()), ("T2", (), ()), ("C2", ("--support", "2,6"), ("-w", "1", "-a", "50")),
+                                           ("C5", ("--records", "300000", "--tsv", "1500"), ("-w", "1", "-a", "50")), ("C5", ("--records", "300000", "--tsv", "1500", "--support", "2,8"), ())])
+def test_oracle_filter_by_interleaving_against_the_literal_loop(built, synth, tmp_path, cfg, gen, flags):
+    """CPU: KeepEdge of FilterbyInterleaving from the literal loop over the oracle's stage behind FilterbyWeight, against the oracle's.  (The
+    generator plants no interleaved junction pairs: the answer is "keep" everywhere, so this pins the walks and the long-group rule, not the
+    overlap rule.)"""
+    pre = synth(cfg, *gen)
+    _, dump = ou.run_oracle(built, pre, tmp_path, *flags)
+    rows = ou.read_edges(dump / "edges_interleave.txt")
+    assert [tuple(r[:6]) for r in rows] == [tuple(r[:6]) for r in ou.read_edges(dump / "edges_weight.txt")]  # (the stage only decides KeepEdge)
+    got = _filter_by_interleaving_literal(ou.read_nodes(dump / "nodes_build.txt"), [r[:6] for r in rows])
+    assert got == [bool(r[6]) for r in rows]
