@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SQ_ABI_VERSION 4
+#define SQ_ABI_VERSION 5
 
 enum {
     SQ_OK = 0,
@@ -249,12 +249,21 @@ int sq_timing_accumulate(sq_ctx* c, int32_t keep);
  * block headers again (measurements of a first read; the cache only saves time, never changes results) */
 int sq_drop_file_cache(void);
 int sq_reset(sq_ctx* c); /* drop graph results, keep ingested records resident in HBM (bench re-runs) */
+/* give back the device memory the GPU reader keeps between ingests -- the compressed bytes of the file range last streamed to HBM
+ * (file-sized: 5.9 GB for C3), the staged copy of sq_stage_bam, the token / inflate buffers of the batch pipeline (~20 GB) -- and its
+ * page-locked host buffers.  The resident records, the graph and every result stay.  The next ingest allocates again (what a first
+ * ingest does anyway); a process that keeps a context for parameter sweeps over resident records calls this once after the ingest. */
+int sq_release_reader_buffers(sq_ctx* c);
 
 typedef struct sq_counts {
     int64_t n_concordant, n_blocks, n_chimeric_records, n_chim_fragments, read_len;
     int64_t n_kept_p1, n_break, n_kept_p2, n_raw_edges, n_unique_edges;
     int64_t n_order_unsolved; /* components whose ordering problem was beyond the exact solver: identity order kept, what the reference
                                  keeps when GLPK fails within its 300 s (SegmentGraph.cpp:3287-3292,3964,3984); 0 on every test input */
+    int64_t token_passes_side_by_side; /* GPU reader: the largest number of token passes (one per buffer set, each on its own stream) that were
+                                 running at the same time during the ingests of this context -- 0: the GPU reader has not run (or took fewer
+                                 than eight batches); <= 4 with eight sets in flight: the HIP runtime of the process works with four hardware
+                                 queues, see INTEGRATION.md (GPU_MAX_HW_QUEUES) */
 } sq_counts;
 int sq_get_counts(sq_ctx* c, sq_counts* k);
 

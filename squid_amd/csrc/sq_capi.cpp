@@ -824,6 +824,7 @@ static inline bool shard_owns(const sq_ctx* c, int32_t id) {
 }
 int sq_ingest_concordant(sq_ctx* c, const sq_aln_batch* b) {
     if (!c || !b) return SQ_E_ARG;
+    if (c->bwa) return fail(c, SQ_E_ARG, "this context holds a --bwa batch (sq_ingest_bwa_file): sq_clear_records before a STAR-mode ingest -- the mode is per context");
     if (!c->shard.on) return dev_append_records(c, b);
     // sharded: keep the runs of records this rank owns (one run per batch on a sorted stream)
     int64_t i = 0;
@@ -867,6 +868,7 @@ static int ingest_raw(sq_ctx* c, const uint8_t* bam, size_t nbytes, const unsign
 }
 int sq_ingest_concordant_bam(sq_ctx* c, const uint8_t* bam, size_t nbytes, const uint64_t* rec_off, int64_t n_rec) {
     if (!c || (n_rec && (!bam || !rec_off))) return SQ_E_ARG;
+    if (c->bwa) return fail(c, SQ_E_ARG, "this context holds a --bwa batch (sq_ingest_bwa_file): sq_clear_records before a STAR-mode ingest -- the mode is per context");
     int rc = ingest_raw(c, bam, nbytes, (const unsigned long long*)rec_off, n_rec);
     dev_flush_timers(c);
     return rc;
@@ -951,6 +953,7 @@ int sq_ingest_chimeric_file(sq_ctx* c, const char* path) {
 // waits for it (chim_join).  Same result as sq_ingest_chimeric_file followed by sq_ingest_concordant_file.
 int sq_ingest_files(sq_ctx* c, const char* chim_path, const char* bam_path, int32_t n_threads) {
     if (!c || !chim_path || !bam_path) return SQ_E_ARG;
+    if (c->bwa) return fail(c, SQ_E_ARG, "this context holds a --bwa batch (sq_ingest_bwa_file): sq_clear_records before a STAR-mode ingest -- the mode is per context");
     if (std::getenv("SQUID_HOST_PARSE") || std::getenv("SQUID_SERIAL_LOAD")) {  // (the host parser consults the name set record by record)
         const int rc = sq_ingest_chimeric_file(c, chim_path);
         return rc ? rc : sq_ingest_concordant_file(c, bam_path, n_threads);
@@ -978,6 +981,7 @@ int sq_set_source(sq_ctx* c, const char* path) {
 }
 int sq_ingest_concordant_file(sq_ctx* c, const char* path, int32_t n_threads) {
     if (!c || !path) return SQ_E_ARG;
+    if (c->bwa) return fail(c, SQ_E_ARG, "this context holds a --bwa batch (sq_ingest_bwa_file): sq_clear_records before a STAR-mode ingest -- the mode is per context");
     { int r0 = sq_set_source(c, path); if (r0) return r0; }
     if (!std::getenv("SQUID_HOST_PARSE")) {
         // default: the host only inflates BGZF and finds record boundaries; K0 parses the records on the GPU
@@ -1072,7 +1076,9 @@ int sq_clear_records(sq_ctx* c) {
     if (rc) return rc;
     dev_clear_records(c);
     c->bwa.reset();
+    const int64_t side_by_side = c->counts.token_passes_side_by_side;  // (a property of the process, not of the records)
     c->counts = sq_counts{};
+    c->counts.token_passes_side_by_side = side_by_side;
     c->counts.n_chimeric_records = c->n_chim_records; c->counts.n_chim_fragments = (int64_t)c->frags.size(); c->counts.read_len = c->read_len;
     return SQ_OK;
 }
@@ -1258,6 +1264,11 @@ int sq_get_timing(sq_ctx* c, sq_timing* t) {
     return SQ_OK;
 }
 int sq_drop_file_cache(void) { drop_file_cache(); return SQ_OK; }
+int sq_release_reader_buffers(sq_ctx* c) {
+    if (!c) return SQ_E_ARG;
+    c->staged_path.clear(); c->staged_bytes = 0;
+    return dev_release_reader(c);
+}
 int sq_timing_accumulate(sq_ctx* c, int32_t keep) {
     if (!c) return SQ_E_ARG;
     c->timer_keep = keep != 0;

@@ -350,6 +350,7 @@ void dev_destroy(sq_ctx* c);
 void dev_flush_timers(sq_ctx* c);
 int dev_append_records(sq_ctx* c, const sq_aln_batch* b);
 void dev_clear_records(sq_ctx* c);
+int dev_release_reader(sq_ctx* c);
 int dev_stage_file(sq_ctx* c, const uint8_t* bytes, size_t n, const uint8_t** dptr);
 int dev_upload_chim_names(sq_ctx* c);
 int dev_parse_append(sq_ctx* c, const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n_rec);

@@ -2774,6 +2774,22 @@ void dev_flush_timers(sq_ctx* c) {
         }
         busy += hi - lo;
         c->timer.add_busy(iv[i].name, busy);
+        if (!std::strcmp(iv[i].name, "k_inflate_tok2") && j - i >= 8) {
+            // how many token passes the runtime really ran side by side (its hardware queues: each buffer set has a stream of its own and
+            // kernels that share a queue run one after the other).  The launches are sorted by start; a sweep over starts and ends.
+            std::vector<std::pair<float, int>> evs;
+            for (size_t q = i; q < j; ++q) { evs.push_back(std::make_pair(iv[q].s, 1)); evs.push_back(std::make_pair(iv[q].e, -1)); }
+            std::sort(evs.begin(), evs.end());
+            int cur = 0, mx = 0;
+            for (const auto& e : evs) { cur += e.second; mx = std::max(mx, cur); }
+            c->counts.token_passes_side_by_side = std::max<int64_t>(c->counts.token_passes_side_by_side, mx);
+            const char* env = std::getenv("GPU_MAX_HW_QUEUES");
+            static std::atomic<bool> warned{false};
+            if (mx <= 4 && D.il_depth > 4 && (!env || std::atoi(env) > 4) && !warned.exchange(true))
+                std::fprintf(stderr, "squid_hip: at most %d token passes ran side by side although %d buffer sets were in flight: the HIP runtime of this process works with its "
+                                     "default of four hardware queues (GPU_MAX_HW_QUEUES=8 has to be in the environment BEFORE the process makes its first HIP call, INTEGRATION.md); "
+                                     "the GPU reader is about 1.4x slower than it could be\n", mx, D.il_depth);
+        }
         i = j;
     }
     D.ev_pending.clear();
@@ -2783,9 +2799,11 @@ void dev_flush_timers(sq_ctx* c) {
 // The ingest keeps the token passes of up to seven batches, the resolve of the batch in front of them and the record parse of the one
 // before on the GPU side by side.  The HIP runtime maps all streams of one priority onto four hardware queues unless it is told otherwise
 // when it initialises, and kernels that share a queue run one after the other: with four queues at most four token passes overlap and
-// a C3 step takes 205 ms instead of 147.  Loading this library therefore asks for eight queues unless the variable
-// is set already; the request only counts if the process has not made its first HIP call yet (INTEGRATION.md says so to a host that has).
-namespace { struct HwQueueRequest { HwQueueRequest() { (void)::setenv("GPU_MAX_HW_QUEUES", "8", 0); } } g_hw_queue_request; }
+// a C3 step takes 205 ms instead of 147.  The variable has to be set by the HOST PROGRAM before its first HIP call
+// (`build/squid` does in main, `squid_amd/__init__.py` and `bench.py` at import; round 4 set it from a static constructor of this library --
+// a setenv at dlopen time, unsafe beside other threads of the host and silent about hosts that had initialised HIP already).  What the
+// library does instead: dev_flush_timers counts how many token passes really ran side by side (sq_counts.token_passes_side_by_side) and says
+// so on stderr when that is four or fewer although more buffer sets were in flight.
 
 int dev_create(sq_ctx* c) {
     int ndev = 0;
@@ -2888,6 +2906,20 @@ int dev_append_records(sq_ctx* c, const sq_aln_batch* b) {
 void dev_clear_records(sq_ctx* c) {
     if (!c->dev) return;
     c->dev->n = 0; c->dev->nb = 0; c->dev->k1 = 0; c->dev->r_pack_n = 0;
+}
+// sq_release_reader_buffers: what the GPU reader keeps between ingests (every buffer is made again by the ingest that next needs it)
+int dev_release_reader(sq_ctx* c) {
+    if (!c->dev) return SQ_OK;
+    DeviceRecords& D = *c->dev;
+    HIPCHK(hipSetDevice(c->P.device));
+    HIPCHK(hipDeviceSynchronize());
+    D.stream_file.release(); D.staged.release();
+    for (auto& st : D.il_set) { st.in.release(); st.tab.release(); st.tok.release(); st.lens.release(); st.ntok.release(); st.flags.release(); }
+    for (auto& ps : D.il_post) { ps.out.release(); ps.rec_sync.release(); ps.rec_end.release(); ps.rec_cnt.release(); ps.rec_base.release(); ps.flags.release(); ps.spine.release(); ps.bam_off.release(); }
+    D.bgzf_out.release(); D.bgzf_carry.release();
+    for (auto& pr : D.feed_pin) for (auto& b : pr) if (b) { (void)hipHostFree(b); b = nullptr; }
+    D.feed_pin_bytes = 0;
+    return SQ_OK;
 }
 // sq_stage_bam: bytes != null copies a file into HBM; bytes == null returns the resident copy
 // File bytes (a mapping of the page cache: pageable memory) to the device.  One hipMemcpy of pageable memory goes through the
@@ -3006,7 +3038,14 @@ struct FileFeeder {
         D.feed_pool->start(T + 1 + (walk ? 1 : 0), [this](int t) { if (t == T) issue(); else if (t == T + 1) walk_headers(); else work(t); });
         return SQ_OK;
     }
-    void fail_with(const char* msg) { { std::lock_guard<std::mutex> lk(mu); if (what.empty()) what = msg; } failed = true; cv.notify_all(); }
+    // `failed` / `abort` are tested by the waiters under `mu` (more) and `bmu` (work): they are stored with BOTH mutexes held, so a waiter
+    // is either in front of its test -- and sees the flag -- or already blocked -- and gets the notification (a store outside the mutexes
+    // could land between a waiter's test and its block: the notification was lost and a reader slept for good)
+    void raise(std::atomic<bool>& flag, const char* msg) {
+        { std::lock_guard<std::mutex> lb(bmu); std::lock_guard<std::mutex> lk(mu); if (msg && what.empty()) what = msg; flag = true; }
+        wake_all();
+    }
+    void fail_with(const char* msg) { raise(failed, msg); }
     void wake_all() { cv.notify_all(); bcv.notify_all(); }
     // The BGZF block headers, on a thread of its own: one small pread per block -- the 4 bytes in front of a header are the inflated size
     // of the block before, so one read yields both -- 1.8 M blocks a second, ahead of any copy.  (The first form of this walked the
@@ -3075,6 +3114,8 @@ struct FileFeeder {
         for (;;) {
             const size_t j = next.fetch_add(1);
             if (j >= npieces || abort.load() || failed.load()) break;
+            static const long fail_at = std::getenv("SQUID_FEED_FAIL_AT") ? std::atol(std::getenv("SQUID_FEED_FAIL_AT")) : -1;  // (tests: a read error at that piece)
+            if (fail_at >= 0 && (long)j == fail_at) { fail_with("cannot read the bamfile (injected by SQUID_FEED_FAIL_AT)"); break; }
             const size_t off = lo + j * P, len = std::min(P, hi - off);
             auto tk = std::chrono::steady_clock::now();
             int bi = -1;
@@ -3102,6 +3143,10 @@ struct FileFeeder {
         // takes 50-80 ms the first time and would otherwise stand in front of a cold start's first copy
         // (... so they are made one per turn of the loop below, between the copies of the pieces that the first ones already carry)
         size_t made = 0;
+        if (D.feed_pin_bytes != P) {  // buffers of an earlier read with another piece size (SQUID_FEED_PIECE_MB changed inside the process): made again
+            for (auto& pr : D.feed_pin) for (auto& b : pr) if (b) { (void)hipHostFree(b); b = nullptr; }
+            D.feed_pin_bytes = P;
+        }
         auto make_buffer = [&]() -> bool {
             const size_t i = made;
             if (!D.feed_pin[i / 2][i % 2] && hipHostMalloc((void**)&D.feed_pin[i / 2][i % 2], P, hipHostMallocDefault) != hipSuccess) { fail_with("hipHostMalloc"); bcv.notify_all(); return false; }
@@ -3183,7 +3228,7 @@ struct FileFeeder {
     void finish() {  // (idempotent) every piece copied and the walk over, or the threads told to stop
         if (started) { D.feed_pool->wait(); started = false; }
     }
-    void cancel() { abort = true; wake_all(); finish(); }
+    void cancel() { raise(abort, nullptr); finish(); }
 };
 
 int dev_stage_file(sq_ctx* c, const uint8_t* bytes, size_t n, const uint8_t** dptr) {

@@ -276,6 +276,7 @@ int main(int argc, char** argv) {
     int ntsv = -1, level = 6, threads = 4, genes_override = -1;
     double chim_copy_frac = 0.2;
     int sup_lo = 10, sup_hi = 60;  // chimeric fragments per planted junction (--support lo,hi)
+    int n_interleave = 0;          // --interleave K: K PAIRS of junctions that FilterbyInterleaving removes (see the planting loop)
     bool small_cc = false;  // config C5: compact genes, junctions in the last exon (see below)
     double indel_frac = 0.0;  // fraction of concordant pairs whose left read gets an I / D / =X CIGAR variant (off by default: C1..C5 unchanged)
     for (int i = 1; i < argc; ++i) {
@@ -293,6 +294,7 @@ int main(int argc, char** argv) {
         else if (a == "--chim-copy-frac") chim_copy_frac = std::atof(val().c_str());
         else if (a == "--indel-frac") indel_frac = std::atof(val().c_str());
         else if (a == "--bwa") g_bwa = true;
+        else if (a == "--interleave") n_interleave = std::atoi(val().c_str());
         else { std::fprintf(stderr, "unknown arg %s\n", a.c_str()); return 2; }
     }
     std::vector<Contig> contigs;
@@ -382,6 +384,30 @@ int main(int argc, char** argv) {
             // keep the two partner genes at comparable depth so the coverage-ratio filter passes
             genes[v.gy].weight = genes[v.gx].weight * (0.6 + 0.8 * rng.uni());
             tsvs.push_back(v);
+        }
+        // --interleave K (off by default: no draw from the random stream, C1..C5 unchanged): K pairs of junctions between the SAME two
+        // exons -- exon start with exon start (head-head) and exon end with exon end (tail-tail).  Both breakpoints of an exon become
+        // segment boundaries, so the two junctions are two edges between one pair of segments; FilterbyInterleaving puts them into one
+        // group whose Ind1 side is reached from the heads AND from the tails of the Ind2 side and vice versa ("Ind1 is in the middle of
+        // Ind2, Ind2 is in the middle of Ind1", SegmentGraph.cpp:2260-2273) and drops the whole group: KeepEdge = false.
+        for (int t = 0; t < n_interleave && cur + 1 < order.size(); ++t) {
+            const int gxi = order[cur++], gyi = order[cur++];
+            const Gene& gx = genes[gxi];
+            const Gene& gy = genes[gyi];
+            const int nx = (int)gx.es.size(), ny = (int)gy.es.size();
+            const int ex = small_cc ? nx - 1 : rng.range(1, nx - 2), ey = small_cc ? ny - 1 : rng.range(1, ny - 2);
+            genes[gyi].weight = genes[gxi].weight * (0.6 + 0.8 * rng.uni());
+            for (int side = 0; side < 2; ++side) {
+                Tsv v;
+                v.gx = gxi; v.gy = gyi; v.ex = ex; v.ey = ey;
+                v.xhead = v.yhead = side == 0;
+                v.bpx = side == 0 ? gx.es[ex] : gx.ee[ex]; v.txx = side == 0 ? gx.cum[ex] : gx.cum[ex + 1];
+                v.bpy = side == 0 ? gy.es[ey] : gy.ee[ey]; v.txy = side == 0 ? gy.cum[ey] : gy.cum[ey + 1];
+                const int sup = rng.range(sup_lo, sup_hi);
+                v.nsplit = sup / 2;
+                v.npair = sup - v.nsplit;
+                tsvs.push_back(v);
+            }
         }
     }
 

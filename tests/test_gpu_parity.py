@@ -101,6 +101,54 @@ def test_stage_parity_other_parameters(built, synth, tmp_path, flags, params, ex
         _compare(ctx, dump, sv_path)
 
 
+# Samples on which the filters BITE: with 2-8 supporting fragments per junction FilterbyWeight and FilterEdges
+# delete hundreds of edges (C5 --support 2,8 at default flags: 978 of 3 388), where the default generator settings leave them next to
+# nothing to do.  The same samples pin the oracle's filters against the literal loops in tests/test_literal_loops.py (CPU suite).
+LOW_SUPPORT_SAMPLES = [
+    ("C5", ("--records", "300000", "--tsv", "1500", "--support", "2,8"), (), {}),
+    ("C5", ("--records", "300000", "--tsv", "1500"), ("-w", "1", "-a", "50"), dict(min_edge_weight=1, max_allowed_degree=50)),
+    ("C2", ("--support", "2,6"), ("-w", "1", "-a", "50"), dict(min_edge_weight=1, max_allowed_degree=50)),
+    ("C2", ("--support", "2,6"), (), {}),
+]
+
+
+@pytest.mark.parametrize("cfg,gen,flags,params", LOW_SUPPORT_SAMPLES)
+def test_stage_parity_where_the_filters_delete_edges(built, synth, tmp_path, cfg, gen, flags, params, exact_depth):
+    """k_filter_weight / k_filter_interleave / k_fe_* against the oracle on inputs where they remove a large share of the edges; the test
+    asserts that they do (otherwise it would compare kernels that had nothing to decide)"""
+    pre = synth(cfg, *gen)
+    sv_path, dump = ou.run_oracle(built, pre, tmp_path, *flags)
+    n_build = len(ou.read_edges(dump / "edges_build.txt"))
+    n_weight = len(ou.read_edges(dump / "edges_weight.txt"))
+    n_filter = len(ou.read_edges(dump / "edges_filter.txt"))
+    assert n_build - n_filter >= 10, (n_build, n_weight, n_filter)
+    with squid_amd.Context(**params) as ctx:
+        ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
+        ctx.build_graph()
+        _compare(ctx, dump, sv_path)
+
+
+@pytest.mark.parametrize("cfg,gen,flags,params", [("T2", ("--interleave", "3"), (), {}), ("C2", ("--interleave", "6"), (), {}),
+                                                   ("C5", ("--records", "300000", "--tsv", "1500", "--interleave", "40"), ("-w", "1", "-a", "50"), dict(min_edge_weight=1, max_allowed_degree=50))])
+def test_interleaved_junction_pairs_lose_their_edges(built, synth, tmp_path, cfg, gen, flags, params, exact_depth):
+    """FilterbyInterleaving's overlap rule (SegmentGraph.cpp:2264-2273) on inputs where it fires: `gen_synth_bam --interleave K` plants K pairs
+    of junctions between the same two exons (head-head and tail-tail), the oracle's KeepEdge is false for their edges (asserted), and
+    k_filter_interleave + k_fe_* must drop exactly what the oracle drops -- every stage, the orders and `_sv.txt` identical.  (The literal
+    reading of the rule agrees with the oracle on the same samples: tests/test_literal_loops.py, CPU suite.)"""
+    pre = synth(cfg, *gen)
+    sv_path, dump = ou.run_oracle(built, pre, tmp_path, *flags)
+    rows = ou.read_edges(dump / "edges_interleave.txt")
+    k = int(gen[gen.index("--interleave") + 1])
+    dropped = [r for r in rows if not r[6]]
+    assert len(dropped) >= k, (len(dropped), len(rows))
+    kept_after = {tuple(r[:4]) for r in ou.read_edges(dump / "edges_filter.txt")}
+    assert not any(tuple(r[:4]) in kept_after for r in dropped)  # (FilterEdges honours KeepEdge)
+    with squid_amd.Context(**params) as ctx:
+        ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
+        ctx.build_graph()
+        _compare(ctx, dump, sv_path)
+
+
 def test_command_line_is_a_drop_in(built, synth, tmp_path):
     """`squid -b -c -o` writes the same _sv.txt, _graph.txt (-G 1) and _component_pri.txt (-CO 1) bytes"""
     pre = synth("T2")

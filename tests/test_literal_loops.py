@@ -1541,14 +1541,19 @@ def _filter_by_interleaving_literal(nodes, edges, dist_pos=50000, dist_idx=20):
 
 
 @pytest.mark.parametrize("cfg,gen,flags", [("C1", (), ()), ("T2", (), ()), ("C2", ("--support", "2,6"), ("-w", "1", "-a", "50")),
-                                           ("C5", ("--records", "300000", "--tsv", "1500"), ("-w", "1", "-a", "50")), ("C5", ("--records", "300000", "--tsv", "1500", "--support", "2,8"), ())])
+                                           ("C5", ("--records", "300000", "--tsv", "1500"), ("-w", "1", "-a", "50")), ("C5", ("--records", "300000", "--tsv", "1500", "--support", "2,8"), ()),
+                                           ("T2", ("--interleave", "3"), ()), ("C2", ("--interleave", "6"), ()), ("C5", ("--records", "300000", "--tsv", "1500", "--interleave", "40"), ("-w", "1", "-a", "50"))])
 def test_oracle_filter_by_interleaving_against_the_literal_loop(built, synth, tmp_path, cfg, gen, flags):
-    """CPU: KeepEdge of FilterbyInterleaving from the literal loop over the oracle's stage behind FilterbyWeight, against the oracle's.  (The
-    generator plants no interleaved junction pairs: the answer is "keep" everywhere, so this pins the walks and the long-group rule, not the
-    overlap rule.)"""
+    """CPU: KeepEdge of FilterbyInterleaving from the literal loop over the oracle's stage behind FilterbyWeight, against the oracle's.  The
+    default generator settings plant no interleaved junction pairs (the answer is "keep" everywhere: those samples pin the walks and the
+    long-group rule); `--interleave K` plants K pairs of junctions between the same two exons, head-head and tail-tail, on which the overlap
+    rule (:2264-2273) fires -- the test asserts that it does."""
     pre = synth(cfg, *gen)
     _, dump = ou.run_oracle(built, pre, tmp_path, *flags)
     rows = ou.read_edges(dump / "edges_interleave.txt")
     assert [tuple(r[:6]) for r in rows] == [tuple(r[:6]) for r in ou.read_edges(dump / "edges_weight.txt")]  # (the stage only decides KeepEdge)
     got = _filter_by_interleaving_literal(ou.read_nodes(dump / "nodes_build.txt"), [r[:6] for r in rows])
     assert got == [bool(r[6]) for r in rows]
+    if "--interleave" in gen:
+        k = int(gen[gen.index("--interleave") + 1])
+        assert sum(1 for r in rows if not r[6]) >= k, "planted interleaved pairs must lose their edges"
