@@ -21,7 +21,7 @@ ref:
 
 $(B)/libsquid_hip.so: $(LIBSRC) $(CSRC)/sq_internal.h $(CSRC)/sq_parsort.h $(CSRC)/sq_graph_kernels.inc $(CSRC)/sq_pass_kernels.inc include/squid_hip.h
 	mkdir -p $(B)
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function -o $@ $(LIBSRC) -lz -lpthread -ldl
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wall -Wno-unused-function -o $@ $(LIBSRC) -lz -lpthread -ldl
 
 $(B)/squid: $(CSRC)/squid_main.cpp $(B)/libsquid_hip.so include/squid_hip.h
 	$(HIPCC) -O2 -std=c++17 -o $@ $(CSRC)/squid_main.cpp -L$(B) -lsquid_hip -Wl,-rpath,'$$ORIGIN'

@@ -261,8 +261,8 @@ typedef struct sq_counts {
     int64_t n_order_unsolved; /* components whose ordering problem was beyond the exact solver: identity order kept, what the reference
                                  keeps when GLPK fails within its 300 s (SegmentGraph.cpp:3287-3292,3964,3984); 0 on every test input */
     int64_t token_passes_side_by_side; /* GPU reader: the largest number of token passes (one per buffer set, each on its own stream) that were
-                                 running at the same time during the ingests of this context -- 0: the GPU reader has not run (or took fewer
-                                 than eight batches); <= 4 with eight sets in flight: the HIP runtime of the process works with four hardware
+                                 running at the same time during the ingests of a STAGED file (sq_stage_bam) by this context -- 0: no such ingest (or one
+                                 of fewer than eight batches); <= 4 with eight sets in flight: the HIP runtime of the process works with four hardware
                                  queues, see INTEGRATION.md (GPU_MAX_HW_QUEUES) */
 } sq_counts;
 int sq_get_counts(sq_ctx* c, sq_counts* k);

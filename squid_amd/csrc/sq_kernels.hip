@@ -255,7 +255,7 @@ struct DeviceRecords {
     DBuf<unsigned long long> bp_key, bp_front;  // breakpoint cursor: largest (chromosome, fragment start) per 256 records (k_edges_near) / in front of every tile of k_bp2
     int64_t bp_key_n = -1;                      // record count the keys were made for
     // pass 1 (k_pass1): look-back status words, kept records in front of every tile, tile sort keys, the three lists, scalars
-    DBuf<int32_t> tile_cnt, tile_zcnt2, zc_v, zc_K, zc_refid, zc_pos;
+    DBuf<int32_t> tile_cnt, tile_K, tile_zcnt2, zc_v, zc_K, zc_refid, zc_pos;
     DBuf<unsigned long long> tile_ob, zc_ob;  // tile_ob: [ntiles] pair of every tile | [ntiles] pair in front of every tile
     DBuf<int32_t> tile_rank, tile_zbase, tile_zcnt, z_idx, z_chr, z_right, rc_cluster, rc_pos, rc_len, p1_sc;
     DBuf<long long> tile_first, tile_max, r_break;
@@ -2782,10 +2782,11 @@ void dev_flush_timers(sq_ctx* c) {
             std::sort(evs.begin(), evs.end());
             int cur = 0, mx = 0;
             for (const auto& e : evs) { cur += e.second; mx = std::max(mx, cur); }
-            c->counts.token_passes_side_by_side = std::max<int64_t>(c->counts.token_passes_side_by_side, mx);
+            if (c->ingest_dfile) c->counts.token_passes_side_by_side = std::max<int64_t>(c->counts.token_passes_side_by_side, mx);
             const char* env = std::getenv("GPU_MAX_HW_QUEUES");
             static std::atomic<bool> warned{false};
-            if (mx <= 4 && D.il_depth > 4 && (!env || std::atoi(env) > 4) && !warned.exchange(true))
+            // (only a STAGED file says something about the queues: a file that is still arriving feeds four token passes at a time by itself)
+            if (mx <= 4 && c->ingest_dfile && j - i >= 10 && D.il_depth > 4 && (!env || std::atoi(env) > 4) && !warned.exchange(true))
                 std::fprintf(stderr, "squid_hip: at most %d token passes ran side by side although %d buffer sets were in flight: the HIP runtime of this process works with its "
                                      "default of four hardware queues (GPU_MAX_HW_QUEUES=8 has to be in the environment BEFORE the process makes its first HIP call, INTEGRATION.md); "
                                      "the GPU reader is about 1.4x slower than it could be\n", mx, D.il_depth);
@@ -2830,7 +2831,7 @@ void dev_destroy(sq_ctx* c) {
     D.refid.release(); D.pos.release(); D.mrefid.release(); D.mpos.release(); D.endpos.release(); D.b_refpos.release(); D.b_matchref.release();
     D.b_pack.release(); D.n_pack.release(); D.r_pack.release();
     D.flag.release(); D.totlen.release(); D.b_readpos.release(); D.b_matchread.release(); D.mapq.release(); D.aux.release(); D.blk_off.release();
-    D.tile_cnt.release(); D.tile_zcnt2.release(); D.zc_v.release(); D.zc_K.release(); D.zc_refid.release(); D.zc_pos.release(); D.tile_ob.release(); D.zc_ob.release();
+    D.tile_cnt.release(); D.tile_K.release(); D.tile_zcnt2.release(); D.zc_v.release(); D.zc_K.release(); D.zc_refid.release(); D.zc_pos.release(); D.tile_ob.release(); D.zc_ob.release();
     D.tile_rank.release(); D.tile_zbase.release(); D.tile_zcnt.release(); D.z_idx.release(); D.z_chr.release(); D.z_right.release(); D.rc_cluster.release(); D.rc_pos.release(); D.rc_len.release(); D.p1_sc.release();
     D.tile_first.release(); D.tile_max.release(); D.r_break.release(); D.sum_items.release(); D.bp_before.release();
     D.cls.release(); D.keep.release(); D.prev1.release(); D.prev2.release(); D.rank1.release(); D.restoff.release();
@@ -3893,7 +3894,7 @@ int dev_pass1(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<i
     RecView R = D.view();
     HIPCHK(D.cls.reserve(n + 4)); HIPCHK(D.keep.reserve(n + 4));
     HIPCHK(D.tile_rank.reserve((size_t)ntiles + 1)); HIPCHK(D.tile_first.reserve(ntiles)); HIPCHK(D.tile_max.reserve(ntiles)); HIPCHK(D.tile_zbase.reserve(ntiles)); HIPCHK(D.tile_zcnt.reserve(ntiles));
-    HIPCHK(D.tile_cnt.reserve(ntiles)); HIPCHK(D.tile_zcnt2.reserve(ntiles)); HIPCHK(D.tile_ob.reserve(2 * (size_t)ntiles));
+    HIPCHK(D.tile_cnt.reserve(ntiles)); HIPCHK(D.tile_K.reserve(ntiles)); HIPCHK(D.tile_zcnt2.reserve(ntiles)); HIPCHK(D.tile_ob.reserve(2 * (size_t)ntiles));
     HIPCHK(D.p1_sc.reserve(P1S_WORDS));
     int32_t sc[P1S_WORDS], trig_last = INT32_MAX;
     if (D.zcap < (size_t)ntiles * P1_ZFIX + ((size_t)1 << 16)) D.zcap = (size_t)ntiles * P1_ZFIX + ((size_t)1 << 16);
@@ -3906,12 +3907,20 @@ int dev_pass1(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<i
         P1Args A;
         A.min_mapq = c->P.min_mapqual; A.prior_mask = c->shard.on ? c->shard.dedup_mask : 0; A.RL = c->read_len;
         A.ablate = ablate_switch(c, "SQUID_P1_ABLATE");
-        A.cls = D.cls.p; A.keep = D.keep.p; A.tile_cnt = D.tile_cnt.p; A.tile_ob = D.tile_ob.p; A.tile_first = D.tile_first.p; A.tile_max = D.tile_max.p;
+        A.cls = D.cls.p; A.keep = D.keep.p; A.tile_cnt = D.tile_cnt.p; A.tile_K = D.tile_K.p; A.tile_ob = D.tile_ob.p; A.tile_first = D.tile_first.p; A.tile_max = D.tile_max.p;
         A.zc_v = D.zc_v.p; A.zc_K = D.zc_K.p; A.zc_refid = D.zc_refid.p; A.zc_pos = D.zc_pos.p; A.zc_ob = D.zc_ob.p; A.zcap = (int)D.zcap; A.zfix_end = ntiles * P1_ZFIX; A.tile_zbase = D.tile_zbase.p; A.tile_zcnt = D.tile_zcnt.p;
         A.trig = D.trig.p; A.rc_cluster = D.rc_cluster.p; A.rc_pos = D.rc_pos.p; A.rc_len = D.rc_len.p; A.rc_cap = (int)D.rc_cap;
         A.sc = D.p1_sc.p;
         {   // reads: 32 B of fixed fields per record (two 16-byte words) + its first and last block (16 B each); writes: class and keep byte
             EvTimer t(c, "k_pass1", 32.0 * n + 16.0 * D.nb);
+#if SQ_P1W_ITEMS > 0
+            static const int p1_waves = std::getenv("SQUID_P1_WAVES") ? std::atoi(std::getenv("SQUID_P1_WAVES")) : (P1_ITEMS >= 4 ? 3 : 4);  // (measured at C3: four records per lane at three waves per SIMD 0.85 ms, two at four waves 0.98)
+            if (p1_waves == 4) hipLaunchKernelGGL((k_pass1w<4>), dim3(ntiles), dim3(P1_THREADS), 0, s, R, C, A);
+            else if (p1_waves == 3) hipLaunchKernelGGL((k_pass1w<3>), dim3(ntiles), dim3(P1_THREADS), 0, s, R, C, A);
+            else if (p1_waves == 5) hipLaunchKernelGGL((k_pass1w<5>), dim3(ntiles), dim3(P1_THREADS), 0, s, R, C, A);
+            else if (p1_waves == 6) hipLaunchKernelGGL((k_pass1w<6>), dim3(ntiles), dim3(P1_THREADS), 0, s, R, C, A);
+            else hipLaunchKernelGGL((k_pass1w<8>), dim3(ntiles), dim3(P1_THREADS), 0, s, R, C, A);
+#else
             static const bool prof = std::getenv("SQUID_P1_PROF") != nullptr;  // s_memtime sums per section of a tile (thread 0 of every workgroup)
             if (prof) {
                 HIPCHK(D.tok_prof.reserve(16)); HIPCHK(hipMemsetAsync(D.tok_prof.p, 0, 16 * 8, s));
@@ -3927,13 +3936,14 @@ int dev_pass1(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<i
                 else if (p1_waves == 8) hipLaunchKernelGGL((k_pass1<false, 8>), dim3(ntiles), dim3(P1_THREADS), 0, s, R, C, A, (unsigned long long*)nullptr);
                 else hipLaunchKernelGGL((k_pass1<false, 4>), dim3(ntiles), dim3(P1_THREADS), 0, s, R, C, A, (unsigned long long*)nullptr);
             }
+#endif
         }
         {   // per tile: count 4 + pair 8 + two keys 16 in, rank 4 + pair 8 out
             EvTimer t(c, "k_tile_scan", 40.0 * ntiles);
             const int ngroups = (ntiles + TS_THREADS - 1) / TS_THREADS;
             HIPCHK(D.tile_part.reserve((size_t)ngroups + 1));
             hipLaunchKernelGGL(k_tile_partial, dim3(ngroups), dim3(TS_THREADS), 0, s, ntiles, D.tile_cnt.p, D.tile_ob.p, D.tile_max.p, D.tile_part.p);
-            hipLaunchKernelGGL(k_tile_scan, dim3(ngroups), dim3(TS_THREADS), 0, s, ntiles, D.tile_cnt.p, D.tile_ob.p, D.tile_first.p, D.tile_max.p, D.tile_part.p, D.tile_rank.p, D.tile_ob.p + ntiles, D.p1_sc.p);
+            hipLaunchKernelGGL(k_tile_scan, dim3(ngroups), dim3(TS_THREADS), 0, s, ntiles, D.tile_cnt.p, D.tile_ob.p, D.tile_first.p, D.tile_max.p, D.tile_part.p, D.tile_rank.p, D.tile_ob.p + ntiles, D.p1_sc.p, SQ_P1W_ITEMS > 0 ? D.tile_K.p : (const int32_t*)nullptr, D.trig.p);
             if (ncl) hipLaunchKernelGGL(k_trig_rank, dim3((ncl + 255) / 256), dim3(256), 0, s, ncl, ntiles, D.tile_rank.p, D.trig.p);
         }
         HIPCHK(hipMemcpyAsync(sc, D.p1_sc.p, sizeof sc, hipMemcpyDeviceToHost, s));
@@ -3973,7 +3983,7 @@ int dev_segment_support(sq_ctx* c, int ncl, long long seed, SegSupport& out) {
     ClusterView C{ncl, D.cl_chr.p, D.cl_chr.p + ncl, D.cl_chr.p + 2 * (size_t)ncl, n_ref, D.cl_bucket.p, D.cl_bucket.p + n_ref + 1};
     {   // per candidate 24 B in, per zero-coverage record 12 B out; per tile its run descriptor
         EvTimer t(c, "k_zfinal", 24.0 * zc + 24.0 * ntiles);
-        hipLaunchKernelGGL(k_zfinal, dim3((ntiles + 3) / 4), dim3(256), 0, s, ntiles, C, seed, c->read_len, D.tile_rank.p, D.tile_ob.p + ntiles, D.tile_zbase.p, D.tile_zcnt.p, (int)D.zcap, D.zc_v.p, D.zc_K.p, D.zc_ob.p,
+        hipLaunchKernelGGL(k_zfinal, dim3((ntiles + 255) / 256), dim3(256), 0, s, ntiles, C, seed, c->read_len, D.tile_rank.p, D.tile_ob.p + ntiles, D.tile_zbase.p, D.tile_zcnt.p, (int)D.zcap, D.zc_v.p, D.zc_K.p, D.zc_ob.p,
                            D.zc_refid.p, D.zc_pos.p, D.tile_zcnt2.p, D.z_idx.p, D.z_chr.p, D.z_right.p);
     }
     D.pin.reset();
@@ -4147,7 +4157,7 @@ int dev_node_depth(sq_ctx* c, const std::vector<Node>& nodes, int64_t n_break, s
         HIPCHK(D.depth_tiles.reserve(4 * (size_t)ntiles + 4));
         unsigned int *t_agg = D.depth_tiles.p, *t_first = t_agg + ntiles, *t_front = t_first + ntiles;
         int32_t *t_flagged = (int32_t*)(t_front + ntiles), *n_flagged = D.flags.p + 7;  // (flags were just zeroed; read back with them)
-        const DepthTiles T{t_agg, t_first, n_flagged, t_flagged, t_front};
+        const DepthTiles T{t_agg, t_first, n_flagged, t_flagged, t_front, ablate_switch(c, "SQUID_D2_ABLATE")};
         // keep 1 + block offset 4 + refid 4 per record; 16 B per block of a consumed record (the cursor never leaves the kernel)
         { EvTimer t(c, "k_depth2", 9.0 * n + 16.0 * D.nb * ((double)D.k1 / (double)n));
           hipLaunchKernelGGL(k_depth2<false>, dim3(ntiles), dim3(ST_THREADS), 0, s, R, nv, D.keep.p, D.r_break.p, T, ntiles, a_mc, a_ms, a_oc, a_os, a_ap, a_am, D.flags.p, stripes); }
