@@ -994,7 +994,7 @@ void drop_file_cache() {
 
 // CPUs this process can really use: the affinity mask, cut by the cgroup's CPU quota (a container may see 256 logical
 // CPUs and be allowed 16 of them)
-static int usable_cpus() {
+int usable_cpus() {
     int n = (int)std::thread::hardware_concurrency();
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);

@@ -774,7 +774,7 @@ int sq_create(const sq_params* p, sq_ctx** out) {
     if (!p || !out || p->abi_version != SQ_ABI_VERSION) return SQ_E_ARG;
     sq_ctx* c = new sq_ctx();
     c->P = *p;
-    c->pool.reset(new HostPool((int)std::min(15u, std::max(1u, std::thread::hardware_concurrency()) - 1)));
+    c->pool.reset(new HostPool(host_workers(p->world_size)));
     int rc = dev_create(c);
     if (rc) { std::fprintf(stderr, "libsquid_hip: %s\n", c->err.c_str()); dev_destroy(c); delete c; return rc; }
     *out = c;
@@ -801,7 +801,7 @@ static void copy_frags(sq_ctx* c, const std::vector<Frag>& src, std::vector<Frag
     const int pieces = (int)std::min<int64_t>(std::max<int64_t>(1, n / 4096), pool ? 4 * (pool->size() + 1) : 1);
     auto piece = [&](int k) { for (int64_t i = n * k / pieces; i < n * (k + 1) / pieces; ++i) dst[(size_t)i] = src[(size_t)i]; };
     if (pieces <= 1 || !pool) { for (int k = 0; k < pieces; ++k) piece(k); }
-    else pool->parallel_for(pieces, 15, piece);
+    else pool->parallel_for(pieces, 1 << 20, piece);
 }
 int sq_ingest_chimeric(sq_ctx* c, const sq_aln_batch* b) {
     if (!c || !b) return SQ_E_ARG;
@@ -965,7 +965,7 @@ int sq_ingest_files(sq_ctx* c, const char* chim_path, const char* bam_path, int3
     c->chim_future = std::async(std::launch::async, [c, chim, n_threads]() {
         tl_err_sink = &c->chim_err;
         struct Unsink { ~Unsink() { tl_err_sink = nullptr; } } unsink;
-        return chimeric_file_to_fragments(c, chim.c_str(), std::max(1, std::min(n_threads, 16)), c->chim_err, true);
+        return chimeric_file_to_fragments(c, chim.c_str(), std::max(1, std::min(n_threads, c->pool ? c->pool->size() + 1 : 16)), c->chim_err, true);
     });
     const int rc_conc = sq_ingest_concordant_file(c, bam_path, n_threads);
     const int rc_chim = chim_join(c);  // (a concordant file without records never reached the parse)

@@ -195,7 +195,7 @@ int chimeric_edges(sq_ctx* c, std::vector<Edge>& raw) {
             }
         }
     };
-    if (np > 1 && c->pool) c->pool->parallel_for(np, 15, [&](int pi) { run(pi); }); else for (int pi = 0; pi < np; ++pi) run(pi);
+    if (np > 1 && c->pool) c->pool->parallel_for(np, 1 << 20, [&](int pi) { run(pi); }); else for (int pi = 0; pi < np; ++pi) run(pi);
     std::vector<uint64_t> disc;
     for (Piece& P : out) {
         if (P.bad) return fail(c, SQ_E_ASSERT, "chimeric block outside the node table (reference: out-of-range edge, SegmentGraph.cpp:1410)");
@@ -661,7 +661,7 @@ int exact_breakpoints(sq_ctx* c, BPMap& bp) {
             collect(f.b, (int)f.a.size());
         }
     };
-    if (np > 1 && c->pool) c->pool->parallel_for(np, 15, [&](int pi) { run(pi); }); else for (int pi = 0; pi < np; ++pi) run(pi);
+    if (np > 1 && c->pool) c->pool->parallel_for(np, 1 << 20, [&](int pi) { run(pi); }); else for (int pi = 0; pi < np; ++pi) run(pi);
     std::vector<Hit> all;
     for (auto& H : out) all.insert(all.end(), H.begin(), H.end());
     std::sort(all.begin(), all.end(), [](const Hit& x, const Hit& y) { return x.key != y.key ? x.key < y.key : (x.b1 != y.b1 ? x.b1 < y.b1 : x.b2 < y.b2); });  // (count_top sorts the pairs anyway)
@@ -680,7 +680,7 @@ int exact_breakpoints(sq_ctx* c, BPMap& bp) {
     };
     if (ng > 256 && c->pool) {
         const int pieces = std::min(ng, 8 * (c->pool->size() + 1));
-        c->pool->parallel_for(pieces, 15, [&](int k) { for (int g = (int)((int64_t)ng * k / pieces); g < (int)((int64_t)ng * (k + 1) / pieces); ++g) top(g); });
+        c->pool->parallel_for(pieces, 1 << 20, [&](int k) { for (int g = (int)((int64_t)ng * k / pieces); g < (int)((int64_t)ng * (k + 1) / pieces); ++g) top(g); });
     } else for (int g = 0; g < ng; ++g) top(g);
     for (int g = 0; g < ng; ++g) bp.emplace_hint(bp.end(), all[grp[(size_t)g]].key, std::move(lists[(size_t)g]));
     return SQ_OK;

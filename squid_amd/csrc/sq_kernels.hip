@@ -252,6 +252,10 @@ struct DeviceRecords {
     DBuf<int32_t> bp_ev, bp_before, bp_end, bp_valid, bp_bucket, stripes;
     DBuf<TilePart> tile_part;                   // k_tile_partial: sums / maxima of every 1024 tiles of k_pass1
     DBuf<unsigned int> depth_tiles;             // k_depth2: per tile its largest early node / cursor at its first record / list of tiles to correct
+    DBuf<int32_t> g_win;                        // windows of the sorted edge list for the group filters (edge_windows)
+    DBuf<uint32_t> p2_list;                     // k_pass2w: the work list of k_edges (kept from the depth stage to the edge stage of the same pass)
+    DBuf<int32_t> p2_words;                     // k_pass2w: [0] length of that list, [1] tiles on the list of the general depth sweep, [2..] those tiles
+    int64_t p2_valid_n = -1;                    // records the list was made for (-1: none)
     DBuf<unsigned long long> bp_key, bp_front;  // breakpoint cursor: largest (chromosome, fragment start) per 256 records (k_edges_near) / in front of every tile of k_bp2
     int64_t bp_key_n = -1;                      // record count the keys were made for
     // pass 1 (k_pass1): look-back status words, kept records in front of every tile, tile sort keys, the three lists, scalars
@@ -2831,7 +2835,7 @@ void dev_destroy(sq_ctx* c) {
     D.refid.release(); D.pos.release(); D.mrefid.release(); D.mpos.release(); D.endpos.release(); D.b_refpos.release(); D.b_matchref.release();
     D.b_pack.release(); D.n_pack.release(); D.r_pack.release();
     D.flag.release(); D.totlen.release(); D.b_readpos.release(); D.b_matchread.release(); D.mapq.release(); D.aux.release(); D.blk_off.release();
-    D.tile_cnt.release(); D.tile_K.release(); D.tile_zcnt2.release(); D.zc_v.release(); D.zc_K.release(); D.zc_refid.release(); D.zc_pos.release(); D.tile_ob.release(); D.zc_ob.release();
+    D.g_win.release(); D.p2_list.release(); D.p2_words.release(); D.tile_cnt.release(); D.tile_K.release(); D.tile_zcnt2.release(); D.zc_v.release(); D.zc_K.release(); D.zc_refid.release(); D.zc_pos.release(); D.tile_ob.release(); D.zc_ob.release();
     D.tile_rank.release(); D.tile_zbase.release(); D.tile_zcnt.release(); D.z_idx.release(); D.z_chr.release(); D.z_right.release(); D.rc_cluster.release(); D.rc_pos.release(); D.rc_len.release(); D.p1_sc.release();
     D.tile_first.release(); D.tile_max.release(); D.r_break.release(); D.sum_items.release(); D.bp_before.release();
     D.cls.release(); D.keep.release(); D.prev1.release(); D.prev2.release(); D.rank1.release(); D.restoff.release();
@@ -2906,7 +2910,7 @@ int dev_append_records(sq_ctx* c, const sq_aln_batch* b) {
 
 void dev_clear_records(sq_ctx* c) {
     if (!c->dev) return;
-    c->dev->n = 0; c->dev->nb = 0; c->dev->k1 = 0; c->dev->r_pack_n = 0;
+    c->dev->n = 0; c->dev->nb = 0; c->dev->k1 = 0; c->dev->r_pack_n = 0; c->dev->p2_valid_n = -1;
 }
 // sq_release_reader_buffers: what the GPU reader keeps between ingests (every buffer is made again by the ingest that next needs it)
 int dev_release_reader(sq_ctx* c) {
@@ -4154,15 +4158,40 @@ int dev_node_depth(sq_ctx* c, const std::vector<Node>& nodes, int64_t n_break, s
         { const int rb = set_r_break(c, n_break); if (rb) return rb; }
         const int ntiles = (int)((n + ST_TILE - 1) / ST_TILE);
         // per tile: its largest early node, the cursor at its first record; the tiles to correct and the cursor in front of them
-        HIPCHK(D.depth_tiles.reserve(4 * (size_t)ntiles + 4));
+        HIPCHK(D.depth_tiles.reserve(4 * (size_t)ntiles + 4 + (size_t)(ntiles + 1023) / 1024));
         unsigned int *t_agg = D.depth_tiles.p, *t_first = t_agg + ntiles, *t_front = t_first + ntiles;
         int32_t *t_flagged = (int32_t*)(t_front + ntiles), *n_flagged = D.flags.p + 7;  // (flags were just zeroed; read back with them)
-        const DepthTiles T{t_agg, t_first, n_flagged, t_flagged, t_front, ablate_switch(c, "SQUID_D2_ABLATE")};
+        DepthTiles T{t_agg, t_first, n_flagged, t_flagged, t_front, ablate_switch(c, "SQUID_D2_ABLATE"), nullptr, nullptr};
+        static const bool fuse = ST_THREADS == 64 && !(std::getenv("SQUID_NO_FUSE") && std::atoi(std::getenv("SQUID_NO_FUSE")));
+        D.p2_valid_n = -1;
+        if (fuse && D.r_pack_n >= n && n < 0xffffffffll) {
+            // k_pass2w: the depth sums of the tiles that lie inside one node AND the first pass of the edge stage, in one read of the records
+            // (record rows 32 + keep 1 per record, first and last block 16 each); k_depth2 then sweeps only the tiles left on the list
+            HIPCHK(D.p2_list.reserve((size_t)n)); HIPCHK(D.p2_words.reserve((size_t)ntiles + 4)); HIPCHK(D.bp_key.reserve((size_t)((n + 255) / 256) + 1));
+            HIPCHK(hipMemsetAsync(D.p2_words.p, 0, 8, s));
+            P2Args A2{D.keep.p, D.r_break.p, T, a_mc, a_ms, a_oc, a_os, D.flags.p, stripes, D.p2_words.p + 2, D.p2_words.p + 1, D.bp_key.p, D.p2_list.p, D.p2_words.p, std::getenv("SQUID_EDGES_ALL") ? 1 : 0};
+            { EvTimer t(c, "k_pass2w", 33.0 * n + 32.0 * n);
+              static const int p2_waves = std::getenv("SQUID_P2_WAVES") ? std::atoi(std::getenv("SQUID_P2_WAVES")) : 6;  // (C3: 3 waves per SIMD 0.77 ms, 4 0.64, 5 0.56, 6 0.51)
+              if (p2_waves == 3) hipLaunchKernelGGL((k_pass2w<3>), dim3(ntiles), dim3(64), 0, s, R, nv, A2);
+              else if (p2_waves == 4) hipLaunchKernelGGL((k_pass2w<4>), dim3(ntiles), dim3(64), 0, s, R, nv, A2);
+              else if (p2_waves == 7) hipLaunchKernelGGL((k_pass2w<7>), dim3(ntiles), dim3(64), 0, s, R, nv, A2);
+              else if (p2_waves == 8) hipLaunchKernelGGL((k_pass2w<8>), dim3(ntiles), dim3(64), 0, s, R, nv, A2);
+              else if (p2_waves == 5) hipLaunchKernelGGL((k_pass2w<5>), dim3(ntiles), dim3(64), 0, s, R, nv, A2);
+              else if (p2_waves == 6) hipLaunchKernelGGL((k_pass2w<6>), dim3(ntiles), dim3(64), 0, s, R, nv, A2);
+              else hipLaunchKernelGGL((k_pass2w<6>), dim3(ntiles), dim3(64), 0, s, R, nv, A2); }
+            D.p2_valid_n = n; D.bp_key_n = n;
+            T.list = D.p2_words.p + 2; T.n_list = D.p2_words.p + 1;
+            { EvTimer t(c, "k_depth2", 0);  // (the tiles k_pass2w left: their bytes are part of its read)
+              hipLaunchKernelGGL(k_depth2<false>, dim3((unsigned)std::min(ntiles, 1024)), dim3(ST_THREADS), 0, s, R, nv, D.keep.p, D.r_break.p, T, ntiles, a_mc, a_ms, a_oc, a_os, a_ap, a_am, D.flags.p, stripes); }
+        } else {
         // keep 1 + block offset 4 + refid 4 per record; 16 B per block of a consumed record (the cursor never leaves the kernel)
-        { EvTimer t(c, "k_depth2", 9.0 * n + 16.0 * D.nb * ((double)D.k1 / (double)n));
-          hipLaunchKernelGGL(k_depth2<false>, dim3(ntiles), dim3(ST_THREADS), 0, s, R, nv, D.keep.p, D.r_break.p, T, ntiles, a_mc, a_ms, a_oc, a_os, a_ap, a_am, D.flags.p, stripes); }
+        EvTimer t(c, "k_depth2", 9.0 * n + 16.0 * D.nb * ((double)D.k1 / (double)n));
+        hipLaunchKernelGGL(k_depth2<false>, dim3(ntiles), dim3(ST_THREADS), 0, s, R, nv, D.keep.p, D.r_break.p, T, ntiles, a_mc, a_ms, a_oc, a_os, a_ap, a_am, D.flags.p, stripes);
+        }
         { EvTimer t(c, "k_depth_check+fix", 8.0 * ntiles);
-          hipLaunchKernelGGL(k_depth_check, dim3((ntiles + 1023) / 1024), dim3(1024), 0, s, t_agg, t_first, ntiles, n_flagged, t_flagged, t_front, ntiles);
+          unsigned int* t_part = (unsigned int*)(t_flagged + ntiles) + 4;
+          hipLaunchKernelGGL(k_depth_partial, dim3((ntiles + 1023) / 1024), dim3(1024), 0, s, t_agg, ntiles, t_part);
+          hipLaunchKernelGGL(k_depth_check, dim3((ntiles + 1023) / 1024), dim3(1024), 0, s, t_agg, t_part, t_first, ntiles, n_flagged, t_flagged, t_front, ntiles);
           hipLaunchKernelGGL(k_depth2<true>, dim3(64), dim3(ST_THREADS), 0, s, R, nv, D.keep.p, D.r_break.p, T, ntiles, a_mc, a_ms, a_oc, a_os, a_ap, a_am, D.flags.p, stripes);
           if (nn) hipLaunchKernelGGL(k_fold_stripes, dim3((nn + 255) / 256), dim3(256), 0, s, nn, a_mc, a_ms, a_oc, a_os, acc); }
     }
@@ -4220,8 +4249,13 @@ int dev_concordant_edges(sq_ctx* c, const std::vector<Node>& nodes, std::vector<
         uint32_t* list = (uint32_t*)D.scratch_a.p;
         int32_t* count = D.flags.p + 6;
         HIPCHK(D.bp_key.reserve((size_t)((n + 255) / 256) + 1));
-        { EvTimer t(c, "k_edges_near", 23.0 * n + 16.0 * D.nb);  // (+ pos 4 for the breakpoint-cursor keys)
-          hipLaunchKernelGGL(k_edges_near, grid_for(n, 256), dim3(256), 0, s, R, nv, D.keep.p, D.bp_key.p, list, count, std::getenv("SQUID_EDGES_ALL") ? 1 : 0); }
+        if (D.p2_valid_n == n) {  // the depth stage of this pass has made the work list and the cursor keys already (k_pass2w)
+            list = D.p2_list.p;
+            HIPCHK(hipMemcpyAsync(count, D.p2_words.p, 4, hipMemcpyDeviceToDevice, s));
+        } else {
+            EvTimer t(c, "k_edges_near", 23.0 * n + 16.0 * D.nb);  // (+ pos 4 for the breakpoint-cursor keys)
+            hipLaunchKernelGGL(k_edges_near, grid_for(n, 256), dim3(256), 0, s, R, nv, D.keep.p, D.bp_key.p, list, count, std::getenv("SQUID_EDGES_ALL") ? 1 : 0);
+        }
         D.bp_key_n = n;
         { EvTimer t(c, "k_edges", 0);
           hipLaunchKernelGGL(k_edges, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, s, R, nv, ep, D.keep.p, list, count, D.h_key.p, D.h_val.p, slots - 1, D.flags.p, D.stripes.p); }
@@ -4234,6 +4268,7 @@ int dev_concordant_edges(sq_ctx* c, const std::vector<Node>& nodes, std::vector<
         if (D.h_slots >= (1u << 28)) return fail(c, SQ_E_CAPACITY, "edge hash table full");
         D.h_slots <<= 2;
     }
+    D.p2_valid_n = -1;  // (the list belongs to this pass)
     if (h[0] & 8) return fail(c, SQ_E_ASSERT, "edge node index out of range (the reference asserts at SegmentGraph.cpp:1617)");
     if (h[0] & 16) return fail(c, SQ_E_CAPACITY, "record with more aligned blocks than the edge kernel handles");
     long long n_raw = 0;

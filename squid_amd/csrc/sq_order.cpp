@@ -639,7 +639,7 @@ int order_components(sq_ctx* c) {
     std::sort(large.begin(), large.end(), [&](int x, int y) { return B.pieces[x].ids.size() > B.pieces[y].ids.size(); });
     // (a handful of pieces is done before a helper would have picked one up)
     if (large.size() <= 4) for (int pi : large) solve(pi);
-    else c->pool->parallel_for((int)large.size(), 15, [&](int i) { solve(large[(size_t)i]); });
+    else c->pool->parallel_for((int)large.size(), 1 << 20, [&](int i) { solve(large[(size_t)i]); });
     c->counts.n_order_unsolved = unsolved.load();
     if (unsolved.load()) std::fprintf(stderr, "libsquid_hip: %ld component(s) beyond the exact ordering solver (more than %d nodes without a bridge, or search budget exhausted): identity order kept, as the reference does when GLPK gives up\n", unsolved.load(), HOST_NMAX);
     c->timer.add("host_order_large", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());

@@ -446,19 +446,19 @@ double segment_clusters(const sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::ve
         }
         }
     };
-    if (pieces > 1) c->pool->parallel_for(pieces, 15, work); else work(0);
+    if (pieces > 1) c->pool->parallel_for(pieces, 1 << 20, work); else work(0);
     lap("fragments walked");
     auto par = [&](size_t n, const std::function<void(size_t, size_t)>& f) {  // [lo, hi) pieces on the context's host threads
         const int np = (c->pool && n > 100000) ? 4 * (c->pool->size() + 1) : 1;
         if (np <= 1) { f(0, n); return; }
-        c->pool->parallel_for(np, 15, [&](int k) { f(n * (size_t)k / (size_t)np, n * ((size_t)k + 1) / (size_t)np); });
+        c->pool->parallel_for(np, 1 << 20, [&](int k) { f(n * (size_t)k / (size_t)np, n * ((size_t)k + 1) / (size_t)np); });
     };
     {
         // the entries that were waiting for the last discordant block of the pieces in front: drop those that are the `Same` block
         std::vector<size_t> d_at(outs.size() + 1, 0);
         for (size_t k = 0; k < outs.size(); ++k) d_at[k + 1] = d_at[k] + outs[k].D.size();
         D.resize(d_at.back());
-        if (pieces > 1) c->pool->parallel_for(pieces, 15, [&](int k) { std::copy(outs[(size_t)k].D.begin(), outs[(size_t)k].D.end(), D.begin() + (std::ptrdiff_t)d_at[(size_t)k]); });
+        if (pieces > 1) c->pool->parallel_for(pieces, 1 << 20, [&](int k) { std::copy(outs[(size_t)k].D.begin(), outs[(size_t)k].D.end(), D.begin() + (std::ptrdiff_t)d_at[(size_t)k]); });
         else std::copy(outs[0].D.begin(), outs[0].D.end(), D.begin());
         for (size_t k = 0; k < outs.size(); ++k) {
             Out& O = outs[k];
@@ -793,7 +793,7 @@ int segment_replay(sq_ctx* c, SegPlan& plan, std::vector<Node>& seeds, bool virt
     starts.push_back(na);
     struct Out { std::vector<Node> seeds; std::vector<int32_t> sens; int rc = 0; std::string err; };
     std::vector<Out> res(ng);
-    c->pool->parallel_for((int)ng, 15, [&](int gi) {
+    c->pool->parallel_for((int)ng, 1 << 20, [&](int gi) {
         const size_t g = (size_t)gi;
         res[g].rc = replay_range(c, plan, starts[g], starts[g + 1], res[g].seeds, g == 0 ? virtual_back : true, &res[g].sens, res[g].err);
     });

@@ -66,17 +66,21 @@ def test_parallel_sort_reproduces_libstdcxx_sort(tmp_path):
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout
 
 
-def test_loading_the_library_asks_for_eight_hardware_queues_unless_told_otherwise(built):
+def test_the_host_program_asks_for_eight_hardware_queues_not_the_library(built):
     """the GPU reader overlaps up to eight kernels; the HIP runtime gives a process four hardware queues per priority unless
-    GPU_MAX_HW_QUEUES says otherwise when it initialises: loading the library sets the variable in
-    the process environment, and leaves a value that is there already alone"""
+    GPU_MAX_HW_QUEUES says otherwise when it initialises.  Asking is the HOST PROGRAM's business:
+    loading the library leaves the environment alone (round 4 called setenv from a static constructor), the Python binding sets
+    the variable at import unless it is there already -- and so does `build/squid` in main (squid_main.cpp)"""
     import os
     import subprocess
     import sys
 
-    code = ("import ctypes, sys; libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p\n"
-            "ctypes.CDLL(sys.argv[1]); print((libc.getenv(b'GPU_MAX_HW_QUEUES') or b'-').decode())")
+    probe = "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; print((libc.getenv(b'GPU_MAX_HW_QUEUES') or b'-').decode())"
     lib = str(squid_amd.LIB_PATH)
     env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
-    assert subprocess.run([sys.executable, "-c", code, lib], env=env, capture_output=True, text=True, check=True).stdout.strip() == "8"
-    assert subprocess.run([sys.executable, "-c", code, lib], env=dict(env, GPU_MAX_HW_QUEUES="4"), capture_output=True, text=True, check=True).stdout.strip() == "4"
+    run = lambda code, e: subprocess.run([sys.executable, "-c", code, lib], env=e, capture_output=True, text=True, check=True).stdout.strip()
+    assert run("import ctypes, sys; ctypes.CDLL(sys.argv[1]); " + probe, env) == "-"
+    root = str(squid_amd.ROOT)
+    assert run(f"import ctypes, sys; sys.path.insert(0, {root!r}); import squid_amd; " + probe, env) == "8"
+    assert run(f"import ctypes, sys; sys.path.insert(0, {root!r}); import squid_amd; " + probe, dict(env, GPU_MAX_HW_QUEUES="4")) == "4"
+    assert 'setenv("GPU_MAX_HW_QUEUES"' in (squid_amd.ROOT / "squid_amd" / "csrc" / "squid_main.cpp").read_text()
