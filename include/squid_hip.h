@@ -264,6 +264,10 @@ typedef struct sq_counts {
                                  running at the same time during the ingests of a STAGED file (sq_stage_bam) by this context -- 0: no such ingest (or one
                                  of fewer than eight batches); <= 4 with eight sets in flight: the HIP runtime of the process works with four hardware
                                  queues, see INTEGRATION.md (GPU_MAX_HW_QUEUES) */
+    int64_t replay_candidates_checked, replay_count_mismatches; /* with SQUID_REPLAY_CHECK in the environment: break candidates of the segmentation
+                                 (SegmentGraph.cpp:440-481) whose counts -- split-read support, paired-end support left / right, spanning
+                                 coverage of both windows, the cluster's blocks and ConcordRest -- were recounted with the reference's linear
+                                 passes, and how many of them disagreed with the counts the library had used (must be 0); else 0, 0 */
 } sq_counts;
 int sq_get_counts(sq_ctx* c, sq_counts* k);
 

@@ -900,6 +900,9 @@ int sq_read_header(const char* path, int32_t* n_ref, int32_t* ref_len, char* nam
 // `early` (sq_ingest_files): as soon as the records are decoded, the device gets the table of all their usable QNAMEs and the promise
 // the record parse of the concordant BAM waits for is kept -- the pairing goes on meanwhile
 static int chimeric_file_to_fragments(sq_ctx* c, const char* path, int nt, std::string& err, bool early = false) {
+    const auto t_chim0 = std::chrono::steady_clock::now();
+    static const bool chim_prof = std::getenv("SQUID_CHIM_PROF") != nullptr;
+    auto lap = [&](const char* what) { if (chim_prof) std::fprintf(stderr, "chimeric file: %-28s at %8.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_chim0).count()); };
     drop_early_clusters(c);
     ParseOpts o{c->P.phred_type, c->P.min_phred, c->P.max_lowphred_len, true, nullptr};
     bool got = false, promised = false;
@@ -921,19 +924,26 @@ static int chimeric_file_to_fragments(sq_ctx* c, const char* path, int nt, std::
                 off.push_back(b.name_off[i]); len.push_back((uint32_t)L);
             }
             if (!off.empty()) { off.push_back(0); len.push_back(0); }
+            lap("records decoded");
             const int rt = off.empty() ? SQ_OK : dev_chim_begin(c, b.name_blob, (size_t)b.name_off[b.n_rec], off.data(), len.data(), off.size());
             promise(rt);
+            lap("name table handed to the device");
             if (rt) return rt;
         }
-        return build_fragments(c, &b);
+        const int rf = build_fragments(c, &b);
+        lap("fragments built");
+        return rf;
     });
+    lap("reader returned");
     if (!rc && !got) rc = fail(c, SQ_E_EMPTYCHIM, "chimeric BAM holds no record");
     promise(rc ? rc : SQ_OK);  // (whatever happened: nobody waits for ever)
     if (rc) return rc;
     copy_frags(c, c->frags, c->frags0);
+    lap("fragments copied");
     if (early && !c->ref_len.empty()) {  // this thread has nothing else to do, the concordant file is still being read
         c->plan_early.reset(); c->disc_early.clear();
         c->clusters_early_ms = segment_clusters(c, c->plan_early, c->disc_early);
+        lap("cluster table");
     }
     return SQ_OK;
 }
@@ -1289,6 +1299,7 @@ int sq_reset(sq_ctx* c) {
 int sq_get_counts(sq_ctx* c, sq_counts* k) {
     if (!c || !k) return SQ_E_ARG;
     *k = c->counts;
+    k->replay_candidates_checked = c->replay_checked.load(); k->replay_count_mismatches = c->replay_mismatch.load();
     return SQ_OK;
 }
 int sq_debug_download(sq_ctx* c, sq_aln_batch* b) {

@@ -192,6 +192,9 @@ struct sq_ctx {
     std::vector<int32_t> label;
     sq::GraphSnap snap[6];
     bool graph_built = false, ordered = false;
+    // SQUID_REPLAY_CHECK: every break candidate the segmentation replay tests (SegmentGraph.cpp:440-481) is counted a second time with the
+    // reference's linear passes over the same windows and compared with the binary-search / span-index counts the replay uses
+    mutable std::atomic<long long> replay_checked{0}, replay_mismatch{0};
     bool ablated = false;  // a timing-only switch (SQUID_P1_ABLATE / SQUID_EDGES_ABLATE) cut a kernel short: sq_build_graph refuses to return a graph
     bool depth_bounds = false;      // node depths are canonical values with [depth_lo, depth_hi] bounds
     bool depth_ambiguous = false;   // a FilterEdges decision depends on the position inside the bounds

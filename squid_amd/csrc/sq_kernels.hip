@@ -3916,7 +3916,7 @@ int dev_pass1(sq_ctx* c, const std::vector<int32_t>& cl_chr, const std::vector<i
         A.trig = D.trig.p; A.rc_cluster = D.rc_cluster.p; A.rc_pos = D.rc_pos.p; A.rc_len = D.rc_len.p; A.rc_cap = (int)D.rc_cap;
         A.sc = D.p1_sc.p;
         {   // reads: 32 B of fixed fields per record (two 16-byte words) + its first and last block (16 B each); writes: class and keep byte
-            EvTimer t(c, "k_pass1", 32.0 * n + 16.0 * D.nb);
+            EvTimer t(c, SQ_P1W_ITEMS > 0 ? "k_pass1w" : "k_pass1", 32.0 * n + 16.0 * D.nb);
 #if SQ_P1W_ITEMS > 0
             static const int p1_waves = std::getenv("SQUID_P1_WAVES") ? std::atoi(std::getenv("SQUID_P1_WAVES")) : (P1_ITEMS >= 4 ? 3 : 4);  // (measured at C3: four records per lane at three waves per SIMD 0.85 ms, two at four waves 0.98)
             if (p1_waves == 4) hipLaunchKernelGGL((k_pass1w<4>), dim3(ntiles), dim3(P1_THREADS), 0, s, R, C, A);

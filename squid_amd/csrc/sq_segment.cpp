@@ -161,6 +161,7 @@ struct Seg {
     size_t ps = 0, pe = 0;
     int disChr = 0, otherChr = 0, nextdisChr = 0, disright = 0, otherright = 0, nextdisright = 0;
     int markStart = -1, markChr = -1;
+    const bool recount = std::getenv("SQUID_REPLAY_CHECK") != nullptr;  // (tests: every candidate counted twice, check_candidate)
 
     Seg(const sq_ctx* c, const StreamRec* recs, const SegStatic& st, std::vector<Node>& out)
         : c(c), recs(recs), RL(c->read_len), D(st.D), nd(st.nd), part(st.part), clusters(st.clusters), st(st), out(out) {}
@@ -200,6 +201,35 @@ struct Seg {
         markStart = lastC; markChr = chr;
     }
 
+    // SQUID_REPLAY_CHECK (tests): the counts of one break candidate once more, with the linear passes of SegmentGraph.cpp:445-474 over
+    // MarginPositions, the cluster's blocks, both windows from their offsets on and the ConcordRest content, against what the sorted
+    // arrays and the span indices gave (sr, pl, pr, and the spanning coverage in both of its stages)
+    void check_candidate(int brk, int chr, const std::vector<int>& M, int sr, int pl, int pr) {
+        int sr2 = 0, pl2 = 0, pr2 = 0;
+        for (size_t k = 0; k < M.size() && M[k] < brk + T; ++k) if (std::abs(brk - M[k]) < T) ++sr2;
+        for (int d = ds; d != de; ++d) {
+            const int e = D[d].refpos + D[d].matchref;
+            if (e < brk && e > brk - RL && !D[d].rev) ++pl2;
+            else if (D[d].refpos > brk && D[d].refpos < brk + RL && D[d].rev) ++pr2;
+        }
+        bool bad = sr2 != sr || pl2 != pl || pr2 != pr;
+        if (sr > 3 || sr + pl > 4 || sr + pr > 4) {
+            auto spans = [&](int id, int p, int m) { return id == chr && p + m >= brk + T && p < brk - T; };
+            int cov_c = 0, cov_d = 0, cov_p = 0, cov_r = 0;
+            for (int i = co; i < (int)cw.size(); ++i) { const El it = el(cw[i]); if (spans(it.refid, it.refpos, it.matchref)) ++cov_c; }
+            for (int d = ds; d != de; ++d) if (spans(D[d].refid, D[d].refpos, D[d].matchref)) ++cov_d;
+            for (int i = po; i != (int)pw.size(); ++i) { const El it = el(pw[i]); if (spans(it.refid, it.refpos, it.matchref)) ++cov_p; }
+            for (int i = 0; i < rest_n; ++i) if (rest_p[i] + rest_l[i] >= brk + T && rest_p[i] < brk - T) ++cov_r;
+            int d2 = 0;
+            const int dmax = [&]() { int m = 0; for (int d = ds; d != de; ++d) m = std::max(m, D[d].matchref); return m; }();
+            auto blk_lb = [&](long long x) { int a = ds, b = de; while (a < b) { int m = (a + b) >> 1; if (D[m].refpos < x) a = m + 1; else b = m; } return a; };
+            for (int d = blk_lb((long long)brk + T - dmax), d1 = blk_lb((long long)brk - T); d < d1; ++d) if (spans(D[d].refid, D[d].refpos, D[d].matchref)) ++d2;
+            if (cset.ix.count(brk, T) != cov_c || pset.ix.count(brk, T) != cov_p || d2 != cov_d) bad = true;
+            if (rest_n && rspan.count(brk, T) != cov_r) bad = true;
+        }
+        c->replay_checked.fetch_add(1, std::memory_order_relaxed);
+        if (bad) c->replay_mismatch.fetch_add(1, std::memory_order_relaxed);
+    }
     // one discordant cluster has been passed by record (recChr, recPos): SegmentGraph.cpp:354-611
     void process_cluster(int recChr, int recPos) {
         int curEnd = 0, curStart = 0, disStart = -1, disEnd = -1, disCount = -1;
@@ -289,6 +319,7 @@ struct Seg {
                     const int pl = adv(fwd_ends, f_hi, brk) - adv(fwd_ends, f_lo, brk - RL + 1);              // forward block ending in (brk-RL, brk)
                     const int pr = adv(rev_starts, r_hi, brk + RL) - adv(rev_starts, r_lo, brk + 1);          // reverse block starting in (brk, brk+RL)
                     tock(3, tq, 0);
+                    if (recount) check_candidate(brk, chr, M, sr, pl, pr);
                     if (sr > 3 || sr + pl > 4 || sr + pr > 4) {
                         auto tw = tick();
                         auto spans = [&](int id, int p, int m) { return id == chr && p + m >= brk + T && p < brk - T; };

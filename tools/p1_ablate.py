@@ -20,6 +20,6 @@ with squid_amd.Context() as ctx:
                 ctx.build_graph()
             except Exception as e:
                 pass
-            t = ctx.timing().get("k_pass1")
+            t = ctx.timing().get("k_pass1w") or ctx.timing().get("k_pass1")
             if t and it: ms.append(t["ms"] / max(1, t["launches"]))
         print(f"ablate {ab}: k_pass1 {sum(ms) / max(1, len(ms)):.4f} ms")
