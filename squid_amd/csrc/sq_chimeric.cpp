@@ -62,7 +62,7 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
     auto par = [&](int64_t n, const std::function<void(int64_t, int64_t)>& f) {  // [lo, hi) pieces on the context's host threads
         const int pieces = (int)std::min<int64_t>(std::max<int64_t>(1, n / 4096), pool ? 4 * (pool->size() + 1) : 1);
         if (pieces <= 1 || !pool) { f(0, n); return; }
-        pool->parallel_for(pieces, 1 << 20, [&](int k) { f(n * k / pieces, n * (k + 1) / pieces); });
+        pool->parallel_for(pieces, 15, [&](int k) { f(n * k / pieces, n * (k + 1) / pieces); });  // (allocation-heavy loops: measured on 9.6 M records, 'merge runs' 277 ms with 16 threads, 410 ms with 64 -- glibc's arenas)
     };
     static const bool prof = std::getenv("SQUID_CHIM_PROF") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
