@@ -11,6 +11,7 @@
 #include <unistd.h>
 
 #include "sq_internal.h"
+#include "sq_parsort.h"
 
 namespace sq {
 
@@ -584,6 +585,10 @@ static int build_graph(sq_ctx* c) {
 struct SvBuild {
     int stage = 0;
     BPMap bpmap;
+    // the breakpoint pairs of every edge, once (edge i: entries [eoff[i], eoff[i + 1]); round 4 looked every edge up three times in the map)
+    std::vector<int32_t> eoff;
+    std::vector<std::pair<std::pair<int, int>, std::pair<int, int>>> ebp;
+    std::vector<uint8_t> eexact;
     std::vector<std::pair<int, int>> BPs;
     std::vector<int32_t> diff;  // this shard's difference array
     int cur_prev = 0;
@@ -599,17 +604,35 @@ static int call_sv(sq_ctx* c) {
     if (!c->svb) c->svb = std::make_shared<SvBuild>();
     SvBuild& v = *c->svb;
     BPMap& bpmap = v.bpmap;
-    // breakpoint list of every edge (SegmentGraph.cpp:3091-3109)
-    auto edge_bps = [&](const Edge& e, std::vector<std::pair<std::pair<int, int>, std::pair<int, int>>>& out, bool& exact) {
-        out.clear();
-        BPMap::const_iterator it = bpmap.find(edge_pack(e));
-        exact = it != bpmap.end() && !it->second.empty();
-        if (exact) for (const auto& p : it->second) out.push_back({{N[e.a].chr, p.first}, {N[e.b].chr, p.second}});
-        else out.push_back({{N[e.a].chr, e.ha ? N[e.a].pos : N[e.a].pos + N[e.a].len}, {N[e.b].chr, e.hb ? N[e.b].pos : N[e.b].pos + N[e.b].len}});
+    // breakpoint list of every edge (SegmentGraph.cpp:3091-3109): the pairs ExactBreakpoint found, else the node ends the edge touches
+    const size_t m = E.size();
+    auto par = [&](size_t n, const std::function<void(size_t, size_t)>& f) {  // [lo, hi) pieces on the context's host threads
+        const int np = (c->pool && n > 20000) ? 4 * (c->pool->size() + 1) : 1;
+        if (np <= 1) { f(0, n); return; }
+        c->pool->parallel_for(np, 1 << 20, [&](int k) { f(n * (size_t)k / (size_t)np, n * ((size_t)k + 1) / (size_t)np); });
+    };
+    auto build_edge_table = [&]() {
+        v.eoff.assign(m + 1, 0); v.eexact.assign(m, 0);
+        std::vector<const std::vector<std::pair<int, int>>*> hit(m, nullptr);
+        par(m, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) {
+                BPMap::const_iterator it = bpmap.find(edge_pack(E[i]));
+                if (it != bpmap.end() && !it->second.empty()) { hit[i] = &it->second; v.eexact[i] = 1; v.eoff[i + 1] = (int32_t)it->second.size(); }
+                else v.eoff[i + 1] = 1;
+            }
+        });
+        for (size_t i = 0; i < m; ++i) v.eoff[i + 1] += v.eoff[i];
+        v.ebp.resize((size_t)v.eoff[m]);
+        par(m, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) {
+                const Edge& e = E[i];
+                size_t o = (size_t)v.eoff[i];
+                if (hit[i]) for (const auto& p : *hit[i]) v.ebp[o++] = {{N[e.a].chr, p.first}, {N[e.b].chr, p.second}};
+                else v.ebp[o] = {{N[e.a].chr, e.ha ? N[e.a].pos : N[e.a].pos + N[e.a].len}, {N[e.b].chr, e.hb ? N[e.b].pos : N[e.b].pos + N[e.b].len}};
+            }
+        });
     };
     std::vector<std::pair<int, int>>& BPs = v.BPs;
-    std::vector<std::pair<std::pair<int, int>, std::pair<int, int>>> tmp;
-    bool exact;
     std::vector<int32_t> cov;
     int rc;
     auto pack_bpsup = [&]() {
@@ -631,8 +654,11 @@ static int call_sv(sq_ctx* c) {
             rc = exact_breakpoints(c, bpmap);
             if (rc) return rc;
         }
-        for (const Edge& e : E) { edge_bps(e, tmp, exact); for (auto& p : tmp) { BPs.push_back(p.first); BPs.push_back(p.second); } }
-        std::sort(BPs.begin(), BPs.end());
+        build_edge_table();
+        BPs.resize(2 * v.ebp.size());
+        par(v.ebp.size(), [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) { BPs[2 * k] = v.ebp[k].first; BPs[2 * k + 1] = v.ebp[k].second; } });
+        // (equal elements are indistinguishable pairs: any sort gives the reference's sorted list; the threaded introsort of sq_parsort.h)
+        std_sort_parallel(BPs.begin(), BPs.end(), std::less<std::pair<int, int>>(), c->pool ? std::min(c->pool->size() + 1, 32) : 1);
         static const bool bp_host = getenv("SQUID_BP_HOST") != nullptr;  // debug cross-check of k_bp_walk
         if (c->bwa) {  // (--bwa: the records and their names are on the host)
             rc = bwa_breakpoint_support(c, BPs, cov);
@@ -690,34 +716,41 @@ static int call_sv(sq_ctx* c) {
         for (size_t i = 0; i < nb; ++i) { run += total[i]; cov[i] = (int32_t)run; }
     }
     // per-edge table in key order (parity tests) -- before the weight sort
-    c->bp_off.assign(1, 0); c->bp1.clear(); c->bp2.clear(); c->bsup1.clear(); c->bsup2.clear();
-    std::map<uint64_t, std::vector<std::pair<int, int>>> support;
-    for (const Edge& e : E) {
-        edge_bps(e, tmp, exact);
-        std::vector<std::pair<int, int>>& s = support[edge_pack(e)];
-        for (auto& p : tmp) {
-            int i1 = (int)(std::lower_bound(BPs.begin(), BPs.end(), p.first) - BPs.begin()), i2 = (int)(std::lower_bound(BPs.begin(), BPs.end(), p.second) - BPs.begin());
-            s.push_back({cov[i1], cov[i2]});
-            c->bp1.push_back(exact ? p.first.second : -1); c->bp2.push_back(exact ? p.second.second : -1);
-            c->bsup1.push_back(cov[i1]); c->bsup2.push_back(cov[i2]);
+    const size_t nbp = v.ebp.size();
+    std::vector<int32_t> sup1(nbp), sup2(nbp);
+    par(nbp, [&](size_t lo, size_t hi) {
+        for (size_t k = lo; k < hi; ++k) {
+            sup1[k] = cov[(size_t)(std::lower_bound(BPs.begin(), BPs.end(), v.ebp[k].first) - BPs.begin())];
+            sup2[k] = cov[(size_t)(std::lower_bound(BPs.begin(), BPs.end(), v.ebp[k].second) - BPs.begin())];
         }
-        c->bp_off.push_back((int32_t)c->bp1.size());
-    }
+    });
+    c->bp_off.assign(v.eoff.begin(), v.eoff.end());
+    c->bp1.resize(nbp); c->bp2.resize(nbp);
+    c->bsup1 = sup1; c->bsup2 = sup2;
+    par(m, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i)
+            for (int32_t k = v.eoff[i]; k < v.eoff[i + 1]; ++k) { c->bp1[(size_t)k] = v.eexact[i] ? v.ebp[(size_t)k].first.second : -1; c->bp2[(size_t)k] = v.eexact[i] ? v.ebp[(size_t)k].second.second : -1; }
+    });
     multiply_discordant(c, true);
-    // WriteBEDPE (src/WriteIO.cpp:45-124): unstable sort by weight on the key-sorted edge list (ledger B8)
+    // WriteBEDPE (src/WriteIO.cpp:45-124): unstable sort by weight on the key-sorted edge list (ledger B8).  What is sorted is the index of
+    // every edge with the reference's comparison on the weights: libstdc++'s introsort takes the same decisions, hence the same order
     HostClock hc(c, "host_select_sv");
-    std::vector<Edge> W = E;
-    std::sort(W.begin(), W.end(), [](Edge a, Edge b) { return a.w > b.w; });
+    std::vector<int32_t> W(m);
+    for (size_t i = 0; i < m; ++i) W[i] = (int32_t)i;
+    std::sort(W.begin(), W.end(), [&](int32_t a, int32_t b) { return E[(size_t)a].w > E[(size_t)b].w; });
     // rank / sign of every node in its component order
     std::vector<int> comp(N.size(), -1), rank(N.size(), -1), sign(N.size(), 1);
-    for (size_t k = 0; k + 1 < c->ord_off.size(); ++k)
-        for (int j = c->ord_off[k]; j < c->ord_off[k + 1]; ++j) {
-            int v = std::abs(c->ord_nodes[j]) - 1;
-            comp[v] = (int)k; rank[v] = j - c->ord_off[k]; sign[v] = c->ord_nodes[j] < 0 ? -1 : 1;
-        }
+    par(c->ord_off.size() - 1, [&](size_t lo, size_t hi) {
+        for (size_t k = lo; k < hi; ++k)
+            for (int j = c->ord_off[k]; j < c->ord_off[k + 1]; ++j) {
+                int nd = std::abs(c->ord_nodes[j]) - 1;
+                comp[nd] = (int)k; rank[nd] = j - c->ord_off[k]; sign[nd] = c->ord_nodes[j] < 0 ? -1 : 1;
+            }
+    });
     for (auto& col : c->sv_cols) col.clear();
     c->sv_s1.clear(); c->sv_s2.clear();
-    for (const Edge& e : W) {
+    for (const int32_t wi : W) {
+        const Edge& e = E[(size_t)wi];
         const Node &a = N[e.a], &b = N[e.b];
         bool conc = a.chr == b.chr && e.ha == 0 && e.hb == 1 && (b.pos - a.pos - a.len <= c->P.concord_dist_pos || e.b - e.a <= c->P.concord_dist_idx);
         if (conc) continue;
@@ -725,13 +758,11 @@ static int call_sv(sq_ctx* c) {
         if (comp[e.a] == comp[e.b] && rank[e.a] < rank[e.b] && (bool)e.ha == (sign[e.a] < 0) && (bool)e.hb == (sign[e.b] > 0)) ok = true;
         else if (comp[e.a] == comp[e.b] && rank[e.a] > rank[e.b] && (bool)e.hb == (sign[e.b] < 0) && (bool)e.ha == (sign[e.a] > 0)) ok = true;
         if (!ok) continue;
-        edge_bps(e, tmp, exact);
-        const std::vector<std::pair<int, int>>& s = support[edge_pack(e)];
-        for (size_t k = 0; k < tmp.size(); ++k) {
-            int b1 = tmp[k].first.second, b2 = tmp[k].second.second;
+        for (int32_t k = v.eoff[(size_t)wi]; k < v.eoff[(size_t)wi + 1]; ++k) {
+            int b1 = v.ebp[(size_t)k].first.second, b2 = v.ebp[(size_t)k].second.second;
             c->sv_cols[0].push_back(a.chr); c->sv_cols[1].push_back(e.ha ? b1 : a.pos); c->sv_cols[2].push_back(e.ha ? a.pos + a.len : b1);
             c->sv_cols[3].push_back(b.chr); c->sv_cols[4].push_back(e.hb ? b2 : b.pos); c->sv_cols[5].push_back(e.hb ? b.pos + b.len : b2);
-            c->sv_cols[6].push_back(e.w); c->sv_cols[7].push_back(s[k].first); c->sv_cols[8].push_back(s[k].second);
+            c->sv_cols[6].push_back(e.w); c->sv_cols[7].push_back(sup1[(size_t)k]); c->sv_cols[8].push_back(sup2[(size_t)k]);
             c->sv_s1.push_back(e.ha); c->sv_s2.push_back(e.hb);
         }
     }

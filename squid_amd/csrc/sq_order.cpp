@@ -550,69 +550,120 @@ int order_components(sq_ctx* c) {
     const int n = (int)c->nodes.size();
     int ncomp = 0;
     for (int l : c->label) ncomp = std::max(ncomp, l + 1);
-    // bucket nodes and edges per component (the reference rescans everything per component, :3248-3253)
-    std::vector<std::vector<int>> cn(ncomp);
-    std::vector<std::vector<Edge>> ce(ncomp);
-    for (int i = 0; i < n; ++i) cn[c->label[i]].push_back(i);
-    for (const Edge& e : c->edges) if (e.a != e.b) ce[c->label[e.a]].push_back(e);
-    Builder B;
-    std::vector<int> roots(ncomp);
-    auto t0 = std::chrono::steady_clock::now();
-    std::vector<int> ends(ncomp);
-    for (int k = 0; k < ncomp; ++k) { roots[k] = B.build(cn[k], ce[k]); ends[k] = (int)B.tree.size(); }
-    c->timer.add("host_mincut_tree", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-    // ---- leaves: <= 8 nodes and 9..19 nodes on the GPU (one batch each, one component per workgroup); larger bridge-free
-    // pieces -- and the few the mid-size kernel hands back -- on host threads
+    // nodes and edges per component as two CSR tables (the reference rescans everything per component, :3248-3253): ids ascending, edges in
+    // the order of the sorted edge list.  Round 5: the components are worked on in GROUPS of consecutive components, every group with its own
+    // builder on the context's host threads -- min-cut trees, problem packing, decoding and the joining of the halves are per component; only
+    // the two GPU batches see all of them at once.  (Round 4 walked 125 k components one after the other: 100-140 ms around a 1 ms kernel.)
+    std::vector<int32_t> noff((size_t)ncomp + 1, 0), eoffc((size_t)ncomp + 1, 0);
+    for (int i = 0; i < n; ++i) noff[(size_t)c->label[i] + 1]++;
+    for (const Edge& e : c->edges) if (e.a != e.b) eoffc[(size_t)c->label[e.a] + 1]++;
+    for (int k = 0; k < ncomp; ++k) { noff[(size_t)k + 1] += noff[k]; eoffc[(size_t)k + 1] += eoffc[k]; }
+    std::vector<int32_t> cnode((size_t)n);
+    std::vector<Edge> cedge((size_t)eoffc[ncomp]);
+    {
+        std::vector<int32_t> fn(noff.begin(), noff.end() - 1), fe(eoffc.begin(), eoffc.end() - 1);
+        for (int i = 0; i < n; ++i) cnode[(size_t)fn[c->label[i]]++] = i;
+        for (const Edge& e : c->edges) if (e.a != e.b) cedge[(size_t)fe[c->label[e.a]]++] = e;
+    }
     const int GPU_NMAX = 8;
     static const long order_budget = std::getenv("SQUID_ORDER_BUDGET") ? std::atol(std::getenv("SQUID_ORDER_BUDGET")) : 20000000L;
     static const bool order_host_mid = std::getenv("SQUID_ORDER_HOST_MID") != nullptr;  // debugging: 9..19 nodes on the host as well
+    struct Group {
+        int k0 = 0, k1 = 0;
+        Builder B;
+        std::vector<int> roots, ends;
+        std::vector<SmallProblem> probs, mprobs;
+        std::vector<int32_t> e5, me5;
+        std::vector<int> gpu_piece, mid_piece, large;
+        size_t p_base = 0, m_base = 0;  // first problem of the group in the two batches
+        std::vector<int> ord_nodes, ord_off;
+    };
+    const int ngroups = std::max(1, std::min(ncomp, (c->pool && ncomp > 256) ? 8 * (c->pool->size() + 1) : 1));
+    std::vector<Group> groups((size_t)ngroups);
+    auto each_group = [&](const std::function<void(Group&)>& f) {
+        if (ngroups == 1) f(groups[0]);
+        else c->pool->parallel_for(ngroups, 1 << 20, [&](int g) { f(groups[(size_t)g]); });
+    };
+    for (int g = 0; g < ngroups; ++g) { groups[(size_t)g].k0 = (int)((int64_t)ncomp * g / ngroups); groups[(size_t)g].k1 = (int)((int64_t)ncomp * (g + 1) / ngroups); }
+    auto t0 = std::chrono::steady_clock::now();
+    each_group([&](Group& G) {
+        std::vector<int> ids;
+        std::vector<Edge> es;
+        for (int k = G.k0; k < G.k1; ++k) {
+            ids.assign(cnode.begin() + noff[k], cnode.begin() + noff[(size_t)k + 1]);
+            es.assign(cedge.begin() + eoffc[k], cedge.begin() + eoffc[(size_t)k + 1]);
+            G.roots.push_back(G.B.build(ids, es));
+            G.ends.push_back((int)G.B.tree.size());
+        }
+        // ---- leaves: <= 8 nodes and 9..19 nodes on the GPU (one batch each, one component per workgroup); larger bridge-free
+        // pieces -- and the few the mid-size kernel hands back -- on host threads
+        for (size_t pi = 0; pi < G.B.pieces.size(); ++pi) {
+            Piece& p = G.B.pieces[pi];
+            const int pn = (int)p.ids.size();
+            if (pn == 1) continue;
+            const bool small = pn <= GPU_NMAX, mid = !small && pn <= ORDER_MID_NMAX && !order_host_mid;
+            if (!small && !mid) { G.large.push_back((int)pi); continue; }
+            std::vector<int32_t>& e5 = small ? G.e5 : G.me5;
+            SmallProblem sp{pn, (int)(e5.size() / 5), (int)p.edges.size()};
+            for (const LEdge& e : p.edges) { e5.push_back(e.u); e5.push_back(e.v); e5.push_back(e.hu); e5.push_back(e.hv); e5.push_back(e.w); }
+            (small ? G.probs : G.mprobs).push_back(sp);
+            (small ? G.gpu_piece : G.mid_piece).push_back((int)pi);
+        }
+    });
+    c->timer.add("host_mincut_tree", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    // the two batches: the groups' problems one after the other (edge offsets rebased)
     std::vector<SmallProblem> probs, mprobs;
     std::vector<int32_t> edges5, medges5;
-    std::vector<int> gpu_piece, mid_piece, large;
-    for (size_t pi = 0; pi < B.pieces.size(); ++pi) {
-        Piece& p = B.pieces[pi];
-        const int pn = (int)p.ids.size();
-        if (pn == 1) continue;
-        const bool small = pn <= GPU_NMAX, mid = !small && pn <= ORDER_MID_NMAX && !order_host_mid;
-        if (!small && !mid) { large.push_back((int)pi); continue; }
-        std::vector<int32_t>& e5 = small ? edges5 : medges5;
-        SmallProblem sp{pn, (int)(e5.size() / 5), (int)p.edges.size()};
-        for (const LEdge& e : p.edges) { e5.push_back(e.u); e5.push_back(e.v); e5.push_back(e.hu); e5.push_back(e.hv); e5.push_back(e.w); }
-        (small ? probs : mprobs).push_back(sp);
-        (small ? gpu_piece : mid_piece).push_back((int)pi);
+    {
+        size_t np = 0, nm = 0, ne = 0, nme = 0;
+        for (Group& G : groups) { G.p_base = np; G.m_base = nm; np += G.probs.size(); nm += G.mprobs.size(); ne += G.e5.size(); nme += G.me5.size(); }
+        probs.resize(np); mprobs.resize(nm); edges5.resize(ne); medges5.resize(nme);
+        std::vector<size_t> eb(groups.size()), meb(groups.size());
+        { size_t a = 0, b2 = 0; for (size_t g = 0; g < groups.size(); ++g) { eb[g] = a; meb[g] = b2; a += groups[g].e5.size(); b2 += groups[g].me5.size(); } }
+        auto place = [&](int g) {
+            Group& G = groups[(size_t)g];
+            for (size_t q = 0; q < G.probs.size(); ++q) { SmallProblem sp = G.probs[q]; sp.eoff += (int)(eb[(size_t)g] / 5); probs[G.p_base + q] = sp; }
+            for (size_t q = 0; q < G.mprobs.size(); ++q) { SmallProblem sp = G.mprobs[q]; sp.eoff += (int)(meb[(size_t)g] / 5); mprobs[G.m_base + q] = sp; }
+            std::copy(G.e5.begin(), G.e5.end(), edges5.begin() + (std::ptrdiff_t)eb[(size_t)g]);
+            std::copy(G.me5.begin(), G.me5.end(), medges5.begin() + (std::ptrdiff_t)meb[(size_t)g]);
+        };
+        if (ngroups == 1) place(0); else c->pool->parallel_for(ngroups, 1 << 20, place);
     }
     std::vector<int32_t> gmask, gorder;
     int rc = dev_order_small(c, probs, edges5, gmask, gorder, GPU_NMAX);
     if (rc) return rc;
-    for (size_t q = 0; q < gpu_piece.size(); ++q) {
-        Piece& p = B.pieces[gpu_piece[q]];
-        const int pn = (int)p.ids.size();
-        p.order.resize(pn);
-        for (int pos = 0; pos < pn; ++pos) {
-            int l = gorder[q * 8 + pos];
-            p.order[pos] = ((gmask[q] >> l) & 1) ? -(p.ids[l] + 1) : (p.ids[l] + 1);
-        }
-    }
+    std::vector<int32_t> mmask, morder, mvalue, mstatus;
     if (!mprobs.empty()) {
-        std::vector<int32_t> mmask, morder, mvalue, mstatus;
         rc = dev_order_mid(c, mprobs, medges5, mmask, morder, mvalue, mstatus);
         if (rc) return rc;
-        for (size_t q = 0; q < mid_piece.size(); ++q) {
-            Piece& p = B.pieces[mid_piece[q]];
-            if (mstatus[q]) { large.push_back(mid_piece[q]); continue; }  // beyond the kernel's capacities: host solver
+    }
+    each_group([&](Group& G) {
+        for (size_t q = 0; q < G.gpu_piece.size(); ++q) {
+            Piece& p = G.B.pieces[(size_t)G.gpu_piece[q]];
+            const int pn = (int)p.ids.size();
+            const size_t gq = G.p_base + q;
+            p.order.resize(pn);
+            for (int pos = 0; pos < pn; ++pos) {
+                int l = gorder[gq * 8 + pos];
+                p.order[pos] = ((gmask[gq] >> l) & 1) ? -(p.ids[l] + 1) : (p.ids[l] + 1);
+            }
+        }
+        for (size_t q = 0; q < G.mid_piece.size(); ++q) {
+            Piece& p = G.B.pieces[(size_t)G.mid_piece[q]];
+            const size_t gq = G.m_base + q;
+            if (mstatus[gq]) { G.large.push_back(G.mid_piece[q]); continue; }  // beyond the kernel's capacities: host solver
             const int pn = (int)p.ids.size();
             p.order.resize(pn);
             for (int pos = 0; pos < pn; ++pos) {
-                int l = morder[q * ORDER_MID_NMAX + pos];
-                p.order[pos] = ((mmask[q] >> l) & 1) ? -(p.ids[l] + 1) : (p.ids[l] + 1);
+                int l = morder[gq * ORDER_MID_NMAX + pos];
+                p.order[pos] = ((mmask[gq] >> l) & 1) ? -(p.ids[l] + 1) : (p.ids[l] + 1);
             }
         }
-    }
+    });
     t0 = std::chrono::steady_clock::now();
     static const bool order_prof = std::getenv("SQUID_ORDER_PROF") != nullptr;
     std::atomic<long> unsolved{0};
-    auto solve = [&](int pi) {
-        Piece& p = B.pieces[pi];
+    auto solve = [&](Piece& p) {
         const int pn = (int)p.ids.size();
         p.order.resize(pn);
         bool ok = pn <= HOST_NMAX;
@@ -636,20 +687,30 @@ int order_components(sq_ctx* c) {
         }
     };
     // the pieces are independent: solve them on a few host threads (biggest first)
-    std::sort(large.begin(), large.end(), [&](int x, int y) { return B.pieces[x].ids.size() > B.pieces[y].ids.size(); });
+    std::vector<Piece*> large;
+    for (Group& G : groups) for (int pi : G.large) large.push_back(&G.B.pieces[(size_t)pi]);
+    std::sort(large.begin(), large.end(), [](const Piece* x, const Piece* y) { return x->ids.size() > y->ids.size(); });
     // (a handful of pieces is done before a helper would have picked one up)
-    if (large.size() <= 4) for (int pi : large) solve(pi);
-    else c->pool->parallel_for((int)large.size(), 1 << 20, [&](int i) { solve(large[(size_t)i]); });
+    if (large.size() <= 4) for (Piece* p : large) solve(*p);
+    else c->pool->parallel_for((int)large.size(), 1 << 20, [&](int i) { solve(*large[(size_t)i]); });
     c->counts.n_order_unsolved = unsolved.load();
     if (unsolved.load()) std::fprintf(stderr, "libsquid_hip: %ld component(s) beyond the exact ordering solver (more than %d nodes without a bridge, or search budget exhausted): identity order kept, as the reference does when GLPK gives up\n", unsolved.load(), HOST_NMAX);
     c->timer.add("host_order_large", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-    std::vector<int> sign_scratch((size_t)n, 1);
+    std::vector<int> sign_scratch((size_t)n, 1);  // (indexed by node id: the groups' components are disjoint)
+    each_group([&](Group& G) {
+        G.ord_off.assign(1, 0);
+        for (int k = G.k0; k < G.k1; ++k) {
+            std::vector<int> o = G.B.combine(G.roots[(size_t)(k - G.k0)], G.ends[(size_t)(k - G.k0)], sign_scratch);
+            G.ord_nodes.insert(G.ord_nodes.end(), o.begin(), o.end());
+            G.ord_off.push_back((int)G.ord_nodes.size());
+        }
+    });
     c->ord_off.assign(1, 0);
     c->ord_nodes.clear();
-    for (int k = 0; k < ncomp; ++k) {
-        std::vector<int> o = B.combine(roots[k], ends[k], sign_scratch);
-        c->ord_nodes.insert(c->ord_nodes.end(), o.begin(), o.end());
-        c->ord_off.push_back((int32_t)c->ord_nodes.size());
+    for (Group& G : groups) {
+        const int32_t base = (int32_t)c->ord_nodes.size();
+        c->ord_nodes.insert(c->ord_nodes.end(), G.ord_nodes.begin(), G.ord_nodes.end());
+        for (size_t q = 1; q < G.ord_off.size(); ++q) c->ord_off.push_back(base + (int32_t)G.ord_off[q]);
     }
     c->ordered = true;
     return SQ_OK;
