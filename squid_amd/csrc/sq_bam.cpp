@@ -435,6 +435,21 @@ static int read_bam_header_bytes(const std::vector<uint8_t>& d, bool whole_file,
 }
 
 typedef std::function<int(const uint8_t*, size_t, const unsigned long long*, int64_t)> RawSink;
+// Scratch of a whole-file read (the chimeric BAM as one batch), kept by the process between reads: the inflated rounds and the decoded
+// batch.  A dense sample's chimeric BAM is 2.9 GB inflated and 0.6 GB decoded; as fresh allocations every read pays for them in page faults
+// (measured on the box: inflate 270 ms on 64 threads, the final concatenation 170 ms -- both mostly first touches).  One read at a time
+// uses the cache (a second concurrent one allocates its own); sq_release_reader_buffers gives the memory back (it holds no file content that a
+// later read would trust: every read fills it again).
+namespace {
+struct WholeFileScratch { std::mutex mu; bool busy = false; RawBuf u; HostBatch hb; };
+WholeFileScratch g_whole_file;
+}
+void drop_whole_file_scratch() {
+    std::lock_guard<std::mutex> lk(g_whole_file.mu);
+    if (g_whole_file.busy) return;
+    std::free(g_whole_file.u.p); g_whole_file.u.p = nullptr; g_whole_file.u.n = g_whole_file.u.cap = 0;
+    g_whole_file.hb = HostBatch();
+}
 static int parse_bam_impl(const char* path, const ParseOpts& o, size_t batch_records, int n_threads, std::string& err,
                           const std::function<int(const HostBatch&)>& sink, const RawSink* raw_sink) {
     using clk = std::chrono::steady_clock;
@@ -451,8 +466,20 @@ static int parse_bam_impl(const char* path, const ParseOpts& o, size_t batch_rec
     t_read = since(tr0);
     n_threads = std::max(1, n_threads);
 
-    const size_t kChunkBlocks = 2048;  // <= 128 MiB inflated per round
-    RawBuf u;                          // inflated bytes not yet consumed
+    // <= 128 MiB inflated per round; the whole-file mode (the chimeric BAM: one batch, millions of records on the dense config) takes 512 MiB
+    // rounds, inflates them on as many threads as the machine gives (the decode stays at n_threads: more of those were slower, DESIGN.md
+    // section 5) and strings the decoded parts together ONCE at the end -- round 4 grew sixteen vectors round by round, 0.18 s of a 0.72 s read
+    const bool whole_file = batch_records >= ((size_t)1 << 32) && !raw_sink;
+    const size_t kChunkBlocks = whole_file ? 8192 : 2048;
+    const int inflate_threads = whole_file ? std::max(n_threads, std::min(64, usable_cpus() / 4)) : n_threads;
+    std::vector<HostBatch> kept;  // whole-file mode: the decoded parts of all rounds, in stream order
+    bool cached = false;
+    if (whole_file) { std::lock_guard<std::mutex> lk(g_whole_file.mu); if (!g_whole_file.busy) { g_whole_file.busy = true; cached = true; } }
+    struct Unbusy { bool on; ~Unbusy() { if (on) { std::lock_guard<std::mutex> lk(g_whole_file.mu); g_whole_file.busy = false; } } } unbusy{cached};
+    RawBuf u_local;
+    HostBatch hb_local;
+    RawBuf& u = cached ? g_whole_file.u : u_local;  // inflated bytes not yet consumed
+    u.n = 0;
     size_t nb = 0;
     size_t consumed = 0;
     auto refill = [&]() -> bool {
@@ -463,7 +490,7 @@ static int parse_bam_impl(const char* path, const ParseOpts& o, size_t batch_rec
         size_t old = u.size();
         u.resize(old + bytes);
         auto ti0 = clk::now();
-        bool ok = inflate_range(file, blocks, nb, b1, u.data() + old, base, n_threads);
+        bool ok = inflate_range(file, blocks, nb, b1, u.data() + old, base, inflate_threads);
         t_inflate += since(ti0);
         nb = b1;
         return ok;
@@ -489,7 +516,7 @@ static int parse_bam_impl(const char* path, const ParseOpts& o, size_t batch_rec
     // inflated chunk, finds the first record boundary inside it by validating a chain of plausible record headers,
     // and walks + decodes from there; afterwards the slices are stitched: slice t must end exactly where slice t+1
     // started, otherwise (a false synchronisation -- never seen in practice) the tail of the chunk is redone serially.
-    HostBatch hb;
+    HostBatch& hb = cached ? g_whole_file.hb : hb_local;
     hb.clear();
     RecordDecoder dec(o);
     std::vector<HostBatch> parts((size_t)n_threads);
@@ -597,10 +624,8 @@ static int parse_bam_impl(const char* path, const ParseOpts& o, size_t batch_rec
                 if (!refill()) break;
                 continue;
             }
-            if (batch_records >= ((size_t)1 << 32)) {  // one batch for the whole file (the chimeric BAM): all parts at once
-                auto ta0 = clk::now();
-                hb.append_parts(parts, good);
-                t_append += since(ta0);
+            if (whole_file) {  // one batch for the whole file (the chimeric BAM): the parts are kept and strung together at the end
+                for (int t = 0; t < good; ++t) { kept.push_back(std::move(parts[(size_t)t])); parts[(size_t)t] = HostBatch(); parts[(size_t)t].clear(); }
             } else
             for (int t = 0; t < good; ++t) {
                 auto ta0 = clk::now();
@@ -628,7 +653,8 @@ static int parse_bam_impl(const char* path, const ParseOpts& o, size_t batch_rec
                     if (rc) return rc;
                     p += 4 + (size_t)bs;
                 }
-                hb.append(part);
+                if (whole_file) { kept.push_back(std::move(part)); parts[0] = HostBatch(); parts[0].clear(); }
+                else hb.append(part);
                 good_end = p;
                 t_walk += since(tw0);
             }
@@ -637,6 +663,12 @@ static int parse_bam_impl(const char* path, const ParseOpts& o, size_t batch_rec
         if (!refill()) break;
     }
     if (u.size() - consumed >= 4) { err = "truncated record"; return SQ_E_IO; }
+    if (whole_file && !kept.empty()) {
+        auto ta0 = clk::now();
+        hb.append_parts(kept, (int)kept.size());
+        std::vector<HostBatch>().swap(kept);
+        t_append += since(ta0);
+    }
     if (hb.size()) {
         auto ts0 = clk::now();
         int rc = sink(hb);

@@ -1308,6 +1308,7 @@ int sq_drop_file_cache(void) { drop_file_cache(); return SQ_OK; }
 int sq_release_reader_buffers(sq_ctx* c) {
     if (!c) return SQ_E_ARG;
     c->staged_path.clear(); c->staged_bytes = 0;
+    drop_whole_file_scratch();
     return dev_release_reader(c);
 }
 int sq_timing_accumulate(sq_ctx* c, int32_t keep) {

@@ -281,6 +281,7 @@ struct HostBatch {  // owning storage behind an sq_aln_batch
     size_t size() const { return refid.size(); }
 };
 void drop_file_cache();
+void drop_whole_file_scratch();  // host scratch of whole-file reads (sq_release_reader_buffers)
 int read_bam_header(const char* path, std::vector<std::string>& names, std::vector<int32_t>& lens, std::string& err);
 // streams the file; calls sink(batch) every `batch_records` records.  inchim may be null.
 struct ParseOpts { int phred_type, min_phred, max_lowphred_len; bool keep_names; const std::unordered_set<std::string>* inchim; };
