@@ -210,13 +210,16 @@ static int build_graph(sq_ctx* c) {
         c->graph_built = false;
         c->ordered = false;
         // the cluster table only needs the chimeric fragments: build it on a second thread next to the record kernels
-        if (c->clusters_early_ms >= 0 && c->plan_early) {  // (built beside the ingest: sq_ingest_files)
-            g.plan = std::move(c->plan_early); g.disc.swap(c->disc_early);
+        // (the table is a function of the chimeric fragments and ReadLen alone: built beside the ingest by sq_ingest_files, or by the first pass,
+        // and KEPT by the context until the fragments change -- a later pass over the same records, sq_reset and a new set of -w/-r/-a, takes
+        // it as it is; everything a pass writes into the plan is written again by the next one)
+        if (c->clusters_early_ms >= 0 && c->plan_early) {
+            g.plan = c->plan_early; g.disc = c->disc_early;
             std::promise<double> done;
             done.set_value(c->clusters_early_ms);
             g.clusters = done.get_future();
-            drop_early_clusters(c);
-        } else g.clusters = c->pool->submit([c, &g]() { return segment_clusters(c, g.plan, g.disc); });
+            c->clusters_early_ms = 0;  // (a second use costs nothing)
+        } else g.clusters = c->pool->submit([c, &g]() { const double ms = segment_clusters(c, g.plan, g.disc); c->plan_early = g.plan; c->disc_early = g.disc; c->clusters_early_ms = 0; return ms; });
         int32_t last[4];
         rc = dev_classify(c, sh.on ? last : nullptr);
         if (rc) { (void)g.clusters.get(); return rc; }
@@ -1321,7 +1324,6 @@ int sq_reset(sq_ctx* c) {
     if (!c) return SQ_E_ARG;
     if (c->bp_future.valid()) (void)c->bp_future.get();
     copy_frags(c, c->frags0, c->frags);  // the graph stages trim the chimeric blocks in place, like the reference does
-    drop_early_clusters(c);
     c->nodes.clear(); c->edges.clear(); c->label.clear();
     c->graph_built = false; c->ordered = false;
     c->bp_off.clear();

@@ -393,7 +393,7 @@ int dev_order_small(sq_ctx* c, const std::vector<SmallProblem>& probs, const std
                     std::vector<int32_t>& out_order, int nmax);
 constexpr int ORDER_MID_NMAX = 19;  // k_order_mid: components of 9..19 nodes (out_order has this stride)
 int dev_order_mid(sq_ctx* c, const std::vector<SmallProblem>& probs, const std::vector<int32_t>& edges5, std::vector<int32_t>& out_mask, std::vector<int32_t>& out_order,
-                  std::vector<int32_t>& out_value, std::vector<int32_t>& out_status);
+                  std::vector<int32_t>& out_value, std::vector<int32_t>& out_status, bool own_stream = false);
 // cur_prev: cursor position left by the records of earlier shards
 struct BpBoundary {  // what the next shard needs to know about the breakpoint cursor (SegmentGraph.cpp:3157)
     int cur_end = 0;          // cursor after this shard's records, given the cur_prev it started from

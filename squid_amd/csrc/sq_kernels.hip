@@ -218,6 +218,7 @@ struct DeviceRecords {
     struct PostSet { DBuf<uint8_t> out; DBuf<long long> rec_sync, rec_end; DBuf<int32_t> rec_cnt, rec_base, flags, spine; DBuf<unsigned long long> bam_off; };
     PostSet il_post[2];
     hipStream_t il_parse_stream = nullptr;
+    hipStream_t order_stream = nullptr;     // k_order_mid beside k_order_small (dev_order_mid)
     int32_t* il_host = nullptr;            // page-locked: the small results of the two sets (32 ints each)
     // host -> device copies of file bytes: four threads stage 16 MiB pieces through page-locked buffers (h2d_parallel)
     static constexpr int H2D_THREADS = 4;
@@ -2852,6 +2853,7 @@ void dev_destroy(sq_ctx* c) {
     for (auto& q : D.il_stream) if (q) { (void)hipStreamDestroy(q); q = nullptr; }
     for (auto& ps : D.il_post) { ps.out.release(); ps.rec_sync.release(); ps.rec_end.release(); ps.rec_cnt.release(); ps.rec_base.release(); ps.flags.release(); ps.spine.release(); ps.bam_off.release(); }
     if (D.il_parse_stream) { (void)hipStreamDestroy(D.il_parse_stream); D.il_parse_stream = nullptr; }
+    if (D.order_stream) { (void)hipStreamDestroy(D.order_stream); D.order_stream = nullptr; }
     if (D.il_host) { (void)hipHostFree(D.il_host); D.il_host = nullptr; }
     for (int t = 0; t < DeviceRecords::H2D_THREADS; ++t) {
         for (int b = 0; b < 2; ++b) { if (D.h2d_pin[t][b]) (void)hipHostFree(D.h2d_pin[t][b]); D.h2d_pin[t][b] = nullptr; if (D.h2d_ev[t][b]) (void)hipEventDestroy(D.h2d_ev[t][b]); D.h2d_ev[t][b] = nullptr; }
@@ -3990,14 +3992,22 @@ int dev_segment_support(sq_ctx* c, int ncl, long long seed, SegSupport& out) {
         hipLaunchKernelGGL(k_zfinal, dim3((ntiles + 255) / 256), dim3(256), 0, s, ntiles, C, seed, c->read_len, D.tile_rank.p, D.tile_ob.p + ntiles, D.tile_zbase.p, D.tile_zcnt.p, (int)D.zcap, D.zc_v.p, D.zc_K.p, D.zc_ob.p,
                            D.zc_refid.p, D.zc_pos.p, D.tile_zcnt2.p, D.z_idx.p, D.z_chr.p, D.z_right.p);
     }
-    D.pin.reset();
-    int32_t *hz = D.pin.take_n<int32_t>(3 * (size_t)zc), *hr = D.pin.take_n<int32_t>(3 * (size_t)cnt), *ht = D.pin.take_n<int32_t>(ncl), *hk = D.pin.take_n<int32_t>(3 * (size_t)ntiles + 1);
-    if (!hz || !hr || !ht || !hk) return fail(c, SQ_E_HIP, "hipHostMalloc failed");
+    // the survivors in stream order: offsets of the tiles' runs by a scan, one gather kernel, then three dense arrays come back
+    int32_t nz_dev = 0;
+    HIPCHK(D.scratch_b.reserve((size_t)ntiles + 1));
+    int32_t* tot = D.flags.p + 8;
     if (zc) {
-        HIPCHK(hipMemcpyAsync(hz, D.z_idx.p, (size_t)zc * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(hz + zc, D.z_chr.p, (size_t)zc * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(hz + 2 * (size_t)zc, D.z_right.p, (size_t)zc * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(hk + ntiles + 1, D.tile_zbase.p, (size_t)ntiles * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(hk + 2 * (size_t)ntiles + 1, D.tile_zcnt2.p, (size_t)ntiles * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK((device_scan<OpSum, true>(s, ntiles, FArr{D.tile_zcnt2.p}, D.scratch_b.p, D.spine, tot)));
+        HIPCHK(hipMemcpyAsync(&nz_dev, tot, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (nz_dev < 0 || nz_dev > zc) return fail(c, SQ_E_ARG, "internal: zero-coverage run outside the list");
+        HIPCHK(D.scratch_c.reserve(3 * (size_t)std::max(nz_dev, 1)));
+        if (nz_dev) hipLaunchKernelGGL(k_zcompact, grid_for(ntiles, 256), dim3(256), 0, s, ntiles, D.tile_zbase.p, D.tile_zcnt2.p, D.scratch_b.p, D.z_idx.p, D.z_chr.p, D.z_right.p, D.scratch_c.p, (int)nz_dev);
     }
+    D.pin.reset();
+    int32_t *hz = D.pin.take_n<int32_t>(3 * (size_t)nz_dev), *hr = D.pin.take_n<int32_t>(3 * (size_t)cnt), *ht = D.pin.take_n<int32_t>(ncl), *hk = D.pin.take_n<int32_t>((size_t)ntiles + 1);
+    if (!hz || !hr || !ht || !hk) return fail(c, SQ_E_HIP, "hipHostMalloc failed");
+    if (nz_dev) HIPCHK(hipMemcpyAsync(hz, D.scratch_c.p, 3 * (size_t)nz_dev * 4, hipMemcpyDeviceToHost, s));
     if (cnt) {
         HIPCHK(hipMemcpyAsync(hr, D.rc_cluster.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(hr + cnt, D.rc_pos.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(hr + 2 * (size_t)cnt, D.rc_len.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, s));
@@ -4005,16 +4015,7 @@ int dev_segment_support(sq_ctx* c, int ncl, long long seed, SegSupport& out) {
     if (ncl) HIPCHK(hipMemcpyAsync(ht, D.trig.p, (size_t)ncl * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(hk, D.tile_rank.p, ((size_t)ntiles + 1) * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    // the zero-coverage records in stream order: the tiles' runs one after the other
-    if (zc) {
-        const int32_t *zb = hk + ntiles + 1, *zn = hk + 2 * (size_t)ntiles + 1;
-        for (int t = 0; t < ntiles; ++t) {
-            const int32_t b = zb[t], m = zn[t];
-            if (!m) continue;
-            if (b < 0 || (size_t)b + (size_t)m > (size_t)zc) return fail(c, SQ_E_ARG, "internal: zero-coverage run outside the list");
-            out.zidx.insert(out.zidx.end(), hz + b, hz + b + m); out.z_ochr.insert(out.z_ochr.end(), hz + zc + b, hz + zc + b + m); out.z_oright.insert(out.z_oright.end(), hz + 2 * (size_t)zc + b, hz + 2 * (size_t)zc + b + m);
-        }
-    }
+    out.zidx.assign(hz, hz + nz_dev); out.z_ochr.assign(hz + nz_dev, hz + 2 * (size_t)nz_dev); out.z_oright.assign(hz + 2 * (size_t)nz_dev, hz + 3 * (size_t)nz_dev);
     const int nz = (int)out.zidx.size();
     out.rest_cluster.assign(hr, hr + cnt); out.rest_pos.assign(hr + cnt, hr + 2 * (size_t)cnt); out.rest_len.assign(hr + 2 * (size_t)cnt, hr + 3 * (size_t)cnt);
     // trigger of cluster c = first kept record with more than c clusters behind it: the kernel left, per cluster, the first record
@@ -4347,8 +4348,15 @@ int dev_order_small(sq_ctx* c, const std::vector<SmallProblem>& probs, const std
 
 // K9b: components of 9..19 nodes; status[i] != 0 => the kernel's capacities were exceeded, the caller solves problem i on the host
 int dev_order_mid(sq_ctx* c, const std::vector<SmallProblem>& probs, const std::vector<int32_t>& edges5, std::vector<int32_t>& out_mask, std::vector<int32_t>& out_order,
-                  std::vector<int32_t>& out_value, std::vector<int32_t>& out_status) {
+                  std::vector<int32_t>& out_value, std::vector<int32_t>& out_status, bool own_stream) {
+    // own_stream: called from a helper thread while the caller's thread runs k_order_small on the library stream -- the two batches are
+    // independent and a dozen workgroups each: side by side they take the time of the longer one (C3: 1.25 + 0.48 -> 1.25 ms)
     hipStream_t s = c->stream;
+    if (own_stream) {
+        HIPCHK(hipSetDevice(c->P.device));
+        if (!c->dev->order_stream) HIPCHK(hipStreamCreateWithFlags(&c->dev->order_stream, hipStreamNonBlocking));
+        s = c->dev->order_stream;
+    }
     const int np = (int)probs.size();
     out_mask.assign(np, 0); out_value.assign(np, -1); out_status.assign(np, 1);
     out_order.assign((size_t)np * OM_NMAX, 0);
@@ -4362,7 +4370,7 @@ int dev_order_mid(sq_ctx* c, const std::vector<SmallProblem>& probs, const std::
     if (edges5.size()) std::memcpy(hin.data() + 3 * (size_t)np, edges5.data(), edges5.size() * 4);
     HIPCHK(hipMemcpyAsync(din.p, hin.data(), in_words * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipFuncSetAttribute((const void*)k_order_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(OrdMidLds)));
-    { EvTimer t(c, "k_order_mid", 0);
+    { EvTimer t(c, "k_order_mid", 0, s);
       hipLaunchKernelGGL(k_order_mid, dim3(np), dim3(256), sizeof(OrdMidLds), s, (const SmallProblem*)din.p, din.p + 3 * (size_t)np, dout.p, dout.p + 3 * (size_t)np, dout.p + np, dout.p + 2 * (size_t)np); }
     HIPCHK(hipMemcpyAsync(hout.data(), dout.p, out_words * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

@@ -9,6 +9,7 @@
 // GLPK's pick among equal-valued optima and Boost's pick among equal min-cuts are not reproducible (neither
 // library is available, nothing in the reference pins them); DESIGN.md lists this as "parity unpinned".
 #include <algorithm>
+#include <future>
 #include <deque>
 #include <memory>
 #include <ext/pb_ds/assoc_container.hpp>
@@ -630,13 +631,13 @@ int order_components(sq_ctx* c) {
         if (ngroups == 1) place(0); else c->pool->parallel_for(ngroups, 1 << 20, place);
     }
     std::vector<int32_t> gmask, gorder;
-    int rc = dev_order_small(c, probs, edges5, gmask, gorder, GPU_NMAX);
-    if (rc) return rc;
     std::vector<int32_t> mmask, morder, mvalue, mstatus;
-    if (!mprobs.empty()) {
-        rc = dev_order_mid(c, mprobs, medges5, mmask, morder, mvalue, mstatus);
-        if (rc) return rc;
-    }
+    std::future<int> mid;  // (the mid-size batch on a helper thread and a stream of its own, beside the small one)
+    if (!mprobs.empty() && !probs.empty()) mid = c->pool->submit([&]() { return dev_order_mid(c, mprobs, medges5, mmask, morder, mvalue, mstatus, true); });
+    int rc = dev_order_small(c, probs, edges5, gmask, gorder, GPU_NMAX);
+    if (mid.valid()) { const int rm = mid.get(); if (!rc) rc = rm; }
+    else if (!rc && !mprobs.empty()) rc = dev_order_mid(c, mprobs, medges5, mmask, morder, mvalue, mstatus);
+    if (rc) return rc;
     each_group([&](Group& G) {
         for (size_t q = 0; q < G.gpu_piece.size(); ++q) {
             Piece& p = G.B.pieces[(size_t)G.gpu_piece[q]];

@@ -602,13 +602,17 @@ int segment_prepare(sq_ctx* c, SegPlan& P, int64_t& n_break) {
         std::vector<int32_t> fill(S.rest_off.begin(), S.rest_off.end() - 1);
         for (size_t i = 0; i < cnt; ++i) tmp[(size_t)fill[sup.rest_cluster[i]]++] = std::make_pair(sup.rest_pos[i], sup.rest_len[i]);
         S.rest_pos.resize(cnt); S.rest_len.resize(cnt);
-        for (int k = 0; k < ncl; ++k) {
+        auto one = [&](int k) {
             auto b = tmp.begin() + S.rest_off[k], e = tmp.begin() + S.rest_off[k + 1];
             if (e - b > 1) std::sort(b, e);
             int mx = 0;
             for (auto it = b; it != e; ++it) { const size_t i = (size_t)(it - tmp.begin()); S.rest_pos[i] = it->first; S.rest_len[i] = it->second; mx = std::max(mx, it->second); }
             S.rest_max[k] = mx;
-        }
+        };
+        // (the clusters' groups are independent: sorted side by side on a few host threads once there is enough to sort)
+        const int pieces = (c->pool && cnt > 20000 && ncl > 64) ? 32 : 1;
+        if (pieces == 1) for (int k = 0; k < ncl; ++k) one(k);
+        else c->pool->parallel_for(pieces, 15, [&](int p) { for (int k = (int)((int64_t)ncl * p / pieces); k < (int)((int64_t)ncl * (p + 1) / pieces); ++k) one(k); });
     }
     lap("host_prep_rest");
     // ReadsMain/ReadsOther stop growing at the first record after the last cluster's trigger (SegmentGraph.cpp:338-339, B12)
