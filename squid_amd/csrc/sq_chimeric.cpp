@@ -4,6 +4,10 @@
 // (ledger B8) are issued on index arrays with the same comparators, so libstdc++'s introsort takes the same
 // decisions as it does on the reference's objects.
 #include <algorithm>
+#include <cstdlib>
+#include <functional>
+#include <new>
+#include <type_traits>
 #include <cstring>
 #include <functional>
 
@@ -56,6 +60,23 @@ bool frag_equal(const Frag& x, const Frag& y) {  // ReadRec.cpp:119-141
     return false;
 }
 
+// Scratch of build_fragments without the serial part of a std::vector: `std::vector<T> v(n)` fills n elements on the calling thread --
+// for the dense config's 9.6 M records that is ~0.9 GB of zeroes and page faults on ONE thread before the parallel loop that overwrites
+// them starts (measured: a third of the 0.9 s this function takes).  Raw<T> is malloc'ed and left alone: the pages are touched by the
+// threads that write them first.
+namespace {
+template <class T> struct Raw {
+    T* p; size_t n;
+    explicit Raw(size_t n_) : p((T*)std::malloc(std::max<size_t>(1, n_) * sizeof(T))), n(n_) { static_assert(std::is_trivially_copyable<T>::value, "scratch of plain values"); }
+    ~Raw() { std::free(p); }
+    Raw(const Raw&) = delete; Raw& operator=(const Raw&) = delete;
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+    T* begin() { return p; } T* end() { return p + n; }
+    const T* begin() const { return p; } const T* end() const { return p + n; }
+    size_t size() const { return n; }
+};
+}  // namespace
 int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
     if (!b->name_off || !b->name_blob) return fail(c, SQ_E_ARG, "chimeric batch needs names");
     HostPool* pool = c->pool.get();
@@ -87,8 +108,8 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
     // unsigned values, then the lengths).  The names stay where the batch has them: (offset, length) with a trailing /1 or /2 cut off
     // (ReadRec.cpp:62-66); no per-record fragment object is built -- the merged fragments are put together from the sorted order.
     struct NameKey { uint64_t hi, lo; int32_t idx; uint32_t len; };  // (names of up to 16 bytes are compared without leaving the element)
-    std::vector<NameKey> nk(nr);
-    std::vector<uint32_t> nlen(nr);
+    Raw<NameKey> nk(nr);
+    Raw<uint32_t> nlen(nr);
     auto name_ptr = [&](size_t k) { return b->name_blob + b->name_off[usable[k]]; };
     par((int64_t)nr, [&](int64_t lo, int64_t hi) {
         for (int64_t k = lo; k < hi; ++k) {
@@ -123,7 +144,7 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
     // merge equal names (ReadRec.cpp:356-373): runs of equal names in the sorted order; the runs are independent of each other
     std::vector<size_t> run_start;
     {
-        std::vector<uint8_t> starts(nr);
+        Raw<uint8_t> starts(nr);
         par((int64_t)nr, [&](int64_t lo, int64_t hi) {
             for (int64_t k = lo; k < hi; ++k) {
                 const NameKey& x = nk[(size_t)k];
@@ -138,14 +159,22 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
     }
     run_start.push_back(nr);
     const size_t nm = run_start.size() - 1;
-    std::vector<Frag> merged(nm);
+    // (the merged fragments: raw storage, every element constructed by the thread that fills it and destroyed side by side at the end)
+    struct FragStore {
+        Frag* p; size_t n; const std::function<void(int64_t, const std::function<void(int64_t, int64_t)>&)>* par_; std::vector<uint8_t> made;
+        ~FragStore() { if (par_) (*par_)((int64_t)n, [&](int64_t lo, int64_t hi) { for (int64_t j = lo; j < hi; ++j) if (made[(size_t)j]) p[j].~Frag(); }); std::free(p); }
+    };
+    const std::function<void(int64_t, const std::function<void(int64_t, int64_t)>&)> par_fn = par;
+    FragStore store{(Frag*)std::malloc(std::max<size_t>(1, nm) * sizeof(Frag)), nm, &par_fn, std::vector<uint8_t>(nm, 0)};
+    Frag* merged = store.p;
     auto by_readpos = blk_less_readpos;
     par((int64_t)nm, [&](int64_t lo, int64_t hi) {
         for (int64_t j = lo; j < hi; ++j) {
             // the reference merges the records of a run into the first one, in the sorted order: blocks are appended mate by mate, and a
             // mate's total length / low-quality flag come from the first record (whatever they are) unless its length is 0 and a later
             // record brings one
-            Frag& m = merged[(size_t)j];
+            Frag& m = *new (&merged[(size_t)j]) Frag();
+            store.made[(size_t)j] = 1;
             const size_t k0 = run_start[(size_t)j], k1 = run_start[(size_t)j + 1];
             m.name.assign(name_ptr((size_t)nk[k0].idx), nlen[(size_t)nk[k0].idx]);
             size_t na = 0, nb = 0;
@@ -173,7 +202,7 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
     // sort by front position (ReadRec.cpp:382; FrontSmallerThan is not a strict weak order, kept): again on small elements that
     // carry everything the comparator looks at
     struct FrontKey { Blk a, b; bool has_a, has_b; int32_t idx; };
-    std::vector<FrontKey> fk(nm);
+    Raw<FrontKey> fk(nm);
     par((int64_t)nm, [&](int64_t lo, int64_t hi) {
         for (int64_t j = lo; j < hi; ++j) {
             const Frag& m = merged[(size_t)j];
@@ -206,7 +235,7 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
     std::vector<uint8_t> kept(nm, 0);   // by merged index
     std::vector<uint8_t> keep_at(nm, 0);  // by position in the sorted order
     {
-        std::vector<uint8_t> gstart(nm);
+        Raw<uint8_t> gstart(nm);
         par((int64_t)nm, [&](int64_t lo, int64_t hi) {
             for (int64_t p = lo; p < hi; ++p) {
                 const FrontKey& k = fk[(size_t)p];
@@ -248,7 +277,7 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
     c->chim_names.clear();
     if (!out.empty()) {
         std::vector<int32_t> where(nm, -1);
-        { int32_t o = 0; for (const FrontKey& k : fk) if (kept[(size_t)k.idx]) where[(size_t)k.idx] = o++; }
+        { int32_t o = 0; for (size_t q = 0; q < fk.size(); ++q) { const FrontKey& k = fk[q]; if (kept[(size_t)k.idx]) where[(size_t)k.idx] = o++; } }
         std::vector<size_t> slot(nm);
         size_t cnt = 1;  // slot 0: "" (sorts in front of everything; a fragment with an empty name falls together with it)
         for (size_t j = 0; j < nm; ++j) { slot[j] = cnt; cnt += where[j] >= 0 && !out[(size_t)where[j]].name.empty(); }
