@@ -142,10 +142,11 @@ public:
     }
 };
 
-// CPUs this process can really use (affinity mask, cgroup quota); host_workers: helper threads of a context's pool -- a quarter of them per
-// rank, between 1 and 63 (round 4 stopped at 15 whatever the machine: the dense config spends its time in host stages that scale)
+// CPUs this process can really use (affinity mask, cgroup CPU quota: the GPU boxes of this pool show 256 logical CPUs and allow 16 CPUs of
+// time -- more runnable threads than that are not faster, they are THROTTLED for the rest of the scheduler period); host_workers: helper
+// threads of a context's pool = the rank's share of those CPUs minus the calling thread, between 1 and 63
 int usable_cpus();
-inline int host_workers(int world_size) { const int n = usable_cpus() / (4 * (world_size > 0 ? world_size : 1)); return n < 15 ? (usable_cpus() > 16 ? 15 : (usable_cpus() > 1 ? usable_cpus() - 1 : 1)) : (n > 63 ? 63 : n); }
+inline int host_workers(int world_size) { const int n = usable_cpus() / (world_size > 0 ? world_size : 1) - 1; return n < 1 ? 1 : (n > 63 ? 63 : n); }
 struct DeviceRecords;  // HBM-resident SoA + scratch (sq_kernels.hip)
 struct HostBatch;      // decoded records on the host (below)
 

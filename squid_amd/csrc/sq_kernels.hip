@@ -3023,7 +3023,7 @@ struct FileFeeder {
         if (hi <= lo) return fail(c, SQ_E_ARG, "internal: empty file range");
         npieces = (hi - lo + P - 1) / P;
         static const int env_t = std::getenv("SQUID_FEED_THREADS") ? std::atoi(std::getenv("SQUID_FEED_THREADS")) : 0;
-        T = env_t > 0 ? env_t : (int)std::thread::hardware_concurrency() / 4;
+        T = env_t > 0 ? env_t : usable_cpus() / std::max(1, c->P.world_size);  // (the rank's share of the CPUs the process may really use: cgroup quota, not the CPUs it can see)
         T = std::max(2, std::min({T, 16, (int)DeviceRecords::FEED_THREADS_MAX, (int)npieces}));
         if (env_t > 0) T = std::max(1, std::min({env_t, (int)DeviceRecords::FEED_THREADS_MAX, (int)npieces}));
         if (npieces < 2) T = 1;
