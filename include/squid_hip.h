@@ -268,6 +268,9 @@ typedef struct sq_counts {
                                  (SegmentGraph.cpp:440-481) whose counts -- split-read support, paired-end support left / right, spanning
                                  coverage of both windows, the cluster's blocks and ConcordRest -- were recounted with the reference's linear
                                  passes, and how many of them disagreed with the counts the library had used (must be 0); else 0, 0 */
+    int64_t chimeric_through_gpu_reader; /* sq_ingest_files: 1 when the chimeric BAM of the last call was inflated, cut into records and parsed on the
+                                 device like the concordant one (files of 128 MiB and more; SQUID_CHIM_GPU=1 / =0 forces / forbids it), 0 when
+                                 the host decoder read it */
 } sq_counts;
 int sq_get_counts(sq_ctx* c, sq_counts* k);
 

@@ -71,7 +71,7 @@ class SqTiming(C.Structure):
 
 class SqCounts(C.Structure):
     _fields_ = [(k, C.c_int64) for k in ("n_concordant", "n_blocks", "n_chimeric_records", "n_chim_fragments", "read_len", "n_kept_p1", "n_break",
-                                          "n_kept_p2", "n_raw_edges", "n_unique_edges", "n_order_unsolved", "token_passes_side_by_side", "replay_candidates_checked", "replay_count_mismatches")]
+                                          "n_kept_p2", "n_raw_edges", "n_unique_edges", "n_order_unsolved", "token_passes_side_by_side", "replay_candidates_checked", "replay_count_mismatches", "chimeric_through_gpu_reader")]
 
 
 class SquidError(RuntimeError):

@@ -933,7 +933,7 @@ int sq_read_header(const char* path, int32_t* n_ref, int32_t* ref_len, char* nam
 // the whole chimeric BAM as one batch -> fragments (the batch is consumed where the reader hands it over: no copy of it)
 // `early` (sq_ingest_files): as soon as the records are decoded, the device gets the table of all their usable QNAMEs and the promise
 // the record parse of the concordant BAM waits for is kept -- the pairing goes on meanwhile
-static int chimeric_file_to_fragments(sq_ctx* c, const char* path, int nt, std::string& err, bool early = false) {
+static int chimeric_file_to_fragments(sq_ctx* c, const char* path, int nt, std::string& err, bool early = false, const HostBatch* decoded = nullptr) {
     const auto t_chim0 = std::chrono::steady_clock::now();
     static const bool chim_prof = std::getenv("SQUID_CHIM_PROF") != nullptr;
     auto lap = [&](const char* what) { if (chim_prof) std::fprintf(stderr, "chimeric file: %-28s at %8.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_chim0).count()); };
@@ -941,7 +941,7 @@ static int chimeric_file_to_fragments(sq_ctx* c, const char* path, int nt, std::
     ParseOpts o{c->P.phred_type, c->P.min_phred, c->P.max_lowphred_len, true, nullptr};
     bool got = false, promised = false;
     auto promise = [&](int rc) { if (early && !promised) { promised = true; c->chim_names_promise.set_value(rc); } };
-    int rc = parse_bam_file(path, o, (size_t)1 << 40, nt, err, [&](const HostBatch& hb) {
+    const std::function<int(const HostBatch&)> take = [&](const HostBatch& hb) {
         sq_aln_batch b;
         hb.view(&b, true);
         got = true;
@@ -967,7 +967,9 @@ static int chimeric_file_to_fragments(sq_ctx* c, const char* path, int nt, std::
         const int rf = build_fragments(c, &b);
         lap("fragments built");
         return rf;
-    });
+    };
+    // `decoded`: the records came through the GPU reader (chimeric_records_through_the_device); otherwise the host decoder reads the file
+    int rc = decoded ? (decoded->refid.empty() ? SQ_OK : take(*decoded)) : parse_bam_file(path, o, (size_t)1 << 40, nt, err, take);
     lap("reader returned");
     if (!rc && !got) rc = fail(c, SQ_E_EMPTYCHIM, "chimeric BAM holds no record");
     promise(rc ? rc : SQ_OK);  // (whatever happened: nobody waits for ever)
@@ -992,6 +994,27 @@ int sq_ingest_chimeric_file(sq_ctx* c, const char* path) {
     int rc = chimeric_file_to_fragments(c, path, nt, c->err);
     return rc ? rc : dev_upload_chim_names(c);
 }
+// The chimeric BAM through the GPU reader (K-1 + K0 with sq_ctx::capture_names): BGZF inflate, record boundaries and the record parse on
+// the device, the decoded records and their QNAMEs copied back as one batch -- the batch the host decoder (parse_bam_file, keep_names) makes
+// of the same file, field for field.  On the dense config the host decoder is 0.6 s of sixteen threads = 9 of the 16 CPU-seconds per second
+// a box gives the process; the device does it in the time it takes to get the file there.  Needs an empty record
+// store (the records pass through it).  Returns 2 when the route is not taken or gave up: the caller runs the host decoder, whose
+// error messages are then the ones the user sees.
+static int chimeric_records_through_the_device(sq_ctx* c, const char* path, int n_threads, HostBatch& hb) {
+    if (!c->dev || c->counts.n_concordant != 0) return 2;
+    struct Mode { sq_ctx* c; Mode(sq_ctx* c) : c(c) { c->capture_names = true; } ~Mode() { c->capture_names = false; dev_clear_records(c); c->counts.n_concordant = 0; c->counts.n_blocks = 0; c->ingest_total_bytes = 0; c->ingest_seen_bytes = 0; } } mode(c);
+    std::string err;
+    c->ingest_total_bytes = 0; c->ingest_seen_bytes = 0;
+    std::string saved_err = c->err;
+    int rc = scan_bam_file(path, n_threads, err, [&](const uint8_t* bam, size_t nbytes, const unsigned long long* off, int64_t n) { c->ingest_seen_bytes += nbytes; return dev_parse_append(c, bam, nbytes, off, n); },
+                           [&](size_t total) { c->ingest_total_bytes = total; }, nullptr,
+                           [&](const uint8_t* file, std::vector<BgzfRange>& blocks, size_t b0, size_t b1, size_t begin, bool synced, int nref, const IndexMore& more, size_t file_bytes, GpuFileSrc* src) {
+                               return dev_ingest_bgzf(c, file, blocks, b0, b1, begin, synced, nref, more, file_bytes, src); }, false, true, true);
+    if (rc == SQ_OK) rc = dev_download_records(c, hb);
+    if (rc == SQ_OK) rc = dev_download_names(c, hb);
+    if (rc != SQ_OK) { c->err = saved_err; hb.clear(); return 2; }
+    return SQ_OK;
+}
 // both input files in one call: the chimeric BAM (1-2 % of the records, decoded on the host: 17 ms at C3) is read on a helper
 // thread while the GPU reader starts on the concordant BAM; the record parse -- the first consumer of the chimeric QNAME set --
 // waits for it (chim_join).  Same result as sq_ingest_chimeric_file followed by sq_ingest_concordant_file.
@@ -1006,10 +1029,23 @@ int sq_ingest_files(sq_ctx* c, const char* chim_path, const char* bam_path, int3
     c->chim_err.clear();
     c->chim_names_promise = std::promise<int>();
     c->chim_names_future = c->chim_names_promise.get_future();
-    c->chim_future = std::async(std::launch::async, [c, chim, n_threads]() {
+    // a chimeric BAM of some size goes through the GPU reader first (SQUID_CHIM_GPU=1 / =0 forces / forbids it): the helper thread then
+    // starts from decoded records
+    std::shared_ptr<HostBatch> decoded;
+    {
+        struct stat st;
+        const char* env = std::getenv("SQUID_CHIM_GPU");
+        const bool want = env ? std::atoi(env) != 0 : (::stat(chim_path, &st) == 0 && (size_t)st.st_size >= ((size_t)128 << 20));
+        if (want) {
+            decoded = std::make_shared<HostBatch>();
+            if (chimeric_records_through_the_device(c, chim_path, n_threads, *decoded) != SQ_OK) decoded.reset();
+        }
+        c->counts.chimeric_through_gpu_reader = decoded ? 1 : 0;
+    }
+    c->chim_future = std::async(std::launch::async, [c, chim, n_threads, decoded]() {
         tl_err_sink = &c->chim_err;
         struct Unsink { ~Unsink() { tl_err_sink = nullptr; } } unsink;
-        return chimeric_file_to_fragments(c, chim.c_str(), std::max(1, std::min(n_threads, 16)), c->chim_err, true);  // (the host decoder of the chimeric BAM: 16 threads 96 ms of decode per 9.6 M records, 64 threads 254 ms)
+        return chimeric_file_to_fragments(c, chim.c_str(), std::max(1, std::min(n_threads, 16)), c->chim_err, true, decoded.get());  // (the host decoder of the chimeric BAM: 16 threads 96 ms of decode per 9.6 M records, 64 threads 254 ms)
     });
     const int rc_conc = sq_ingest_concordant_file(c, bam_path, n_threads);
     const int rc_chim = chim_join(c);  // (a concordant file without records never reached the parse)

@@ -196,6 +196,7 @@ struct sq_ctx {
     // SQUID_REPLAY_CHECK: every break candidate the segmentation replay tests (SegmentGraph.cpp:440-481) is counted a second time with the
     // reference's linear passes over the same windows and compared with the binary-search / span-index counts the replay uses
     mutable std::atomic<long long> replay_checked{0}, replay_mismatch{0};
+    bool capture_names = false;  // the records being parsed by K0 are the chimeric BAM's: no name-set lookups, their QNAMEs are kept on the device (dev_download_names)
     bool ablated = false;  // a timing-only switch (SQUID_P1_ABLATE / SQUID_EDGES_ABLATE) cut a kernel short: sq_build_graph refuses to return a graph
     bool depth_bounds = false;      // node depths are canonical values with [depth_lo, depth_hi] bounds
     bool depth_ambiguous = false;   // a FilterEdges decision depends on the position inside the bounds
@@ -366,6 +367,7 @@ int dev_parse_append(sq_ctx* c, const uint8_t* bam, size_t nbytes, const unsigne
 int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& blocks, size_t b0, size_t b1, size_t begin, bool synced, int nref, const IndexMore& index_more, size_t file_bytes, GpuFileSrc* src);
 struct HostBatch;
 int dev_download_records(sq_ctx* c, HostBatch& hb);
+int dev_download_names(sq_ctx* c, HostBatch& hb);
 int dev_chim_begin(sq_ctx* c, const char* blob, size_t blob_bytes, const uint32_t* off, const uint32_t* len, size_t n);
 int dev_chim_finalize(sq_ctx* c, const std::vector<std::string>& dead_names);
 struct SegSupport {

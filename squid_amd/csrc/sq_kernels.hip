@@ -253,6 +253,7 @@ struct DeviceRecords {
     DBuf<int32_t> bp_ev, bp_before, bp_end, bp_valid, bp_bucket, stripes;
     DBuf<TilePart> tile_part;                   // k_tile_partial: sums / maxima of every 1024 tiles of k_pass1
     DBuf<unsigned int> depth_tiles;             // k_depth2: per tile its largest early node / cursor at its first record / list of tiles to correct
+    DBuf<char> nm_blob; DBuf<uint32_t> nm_off; size_t nm_bytes = 0;  // QNAMEs of the records parsed while sq_ctx::capture_names is set (the chimeric BAM through K0)
     DBuf<int32_t> g_win;                        // windows of the sorted edge list for the group filters (edge_windows)
     DBuf<uint32_t> p2_list;                     // k_pass2w: the work list of k_edges (kept from the depth stage to the edge stage of the same pass)
     DBuf<int32_t> p2_words;                     // k_pass2w: [0] length of that list, [1] tiles on the list of the general depth sweep, [2..] those tiles
@@ -562,7 +563,7 @@ __global__ void k_calib_read4(const int32_t* a, int64_t n, int32_t* out) {
 // strand-mirrored read offsets, GetEndPosition(), XA / IH tags (src/SegmentGraph.cpp:297-301) and the QNAME lookup in
 // the chimeric name set (:302) -- and writes the SoA layout directly.  Two passes: count blocks, scan, write.
 struct ChimSetView { uint32_t mask; const unsigned long long* hash; const uint32_t *off, *len; const char* blob; const uint8_t* dead; /* per slot: the name was dropped from the set afterwards (may be null) */ };
-struct ParseParams { int qual_thr, max_lowphred_len, min_mapq; };
+struct ParseParams { int qual_thr, max_lowphred_len, min_mapq, chim; /* chim: the records are the chimeric BAM's (the violated-assert rule of BuildChimericSBamRecord's reader) */ };
 __device__ __forceinline__ int ld32(const uint8_t* p) { return (int)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); }
 __device__ __forceinline__ int ld16(const uint8_t* p) { return (int)p[0] | ((int)p[1] << 8); }
 __device__ __forceinline__ char cig_type(uint32_t v) {  // "MIDNSHP=X", packed into registers (an indexed local array becomes a memory load per op)
@@ -641,7 +642,7 @@ __global__ void k_chim_fixup(int64_t n, const int32_t* chim_slot_of, const uint8
 // assert(ReadPos >= HardClipOffset && ...) (ReadRec.cpp:64) would fire.
 template <bool WRITE>
 __device__ int parse_blocks(const uint8_t* cg, int ncig, const uint8_t* seq, int lseq, int pos, bool rev, int totlen, int32_t* o_refpos, int32_t* o_matchref, uint16_t* o_readpos,
-                            uint16_t* o_matchread) {
+                            uint16_t* o_matchread, int cap = 0) {  // cap: the slots the record owns (a record that trips the assert owns none: its leading blocks are not written)
     int readpos = 0, refpos = pos, hardclip = 0, nb = 0;
     for (int ic = 0; ic < ncig; ++ic) {
         uint32_t v = (uint32_t)ld32(cg + 4 * ic);
@@ -668,7 +669,7 @@ __device__ int parse_blocks(const uint8_t* cg, int ncig, const uint8_t* seq, int
                 nt += code == 8;
             }
             if (4 * na < 3 * tr && 4 * nt < 3 * tr) {
-                if (WRITE) {
+                if (WRITE && nb < cap) {
                     o_refpos[nb] = refpos; o_matchref[nb] = tf;
                     o_readpos[nb] = (uint16_t)(rev ? totlen - readpos - tr : readpos); o_matchread[nb] = (uint16_t)tr;
                 }
@@ -744,7 +745,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_parse_count(const uint8_t* ba
     nblk[r] = nb < 0 ? 0 : nb;
 }
 struct FArrN { const int32_t* a; __device__ int operator()(int64_t i) const { return a[i]; } };
-__global__ __launch_bounds__(PARSE_THREADS) void k_parse_write(const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n, ChimSetView C, ParseParams P, const int32_t* blk_rel, uint32_t blk_base, int32_t* o_refid,
+__global__ __launch_bounds__(PARSE_THREADS) void k_parse_write(const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n, ChimSetView C, ParseParams P, const int32_t* blk_cnt, const int32_t* blk_rel, uint32_t blk_base, int32_t* o_refid,
                               int32_t* o_pos, int32_t* o_mrefid, int32_t* o_mpos, int32_t* o_endpos, uint16_t* o_flag, uint16_t* o_totlen, uint8_t* o_mapq, uint8_t* o_aux, uint32_t* o_blkoff,
                               int32_t* b_refpos, int32_t* b_matchref, uint16_t* b_readpos, uint16_t* b_matchread, int32_t* o_chimslot, int32_t* flags) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[PARSE_LDS];
@@ -811,13 +812,14 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_parse_write(const uint8_t* ba
     if (cslot >= 0 && !(C.dead && C.dead[cslot])) ax |= SQ_AUX_INCHIM;
     int32_t cs_out = (ax & SQ_AUX_INCHIM) ? cslot + 1 : 0;
     const uint32_t b0 = blk_base + (uint32_t)blk_rel[r];
-    int nb = parse_blocks<true>(cg, ncig, seq, lseq, pos, flag & 0x10, totlen, b_refpos + b0, b_matchref + b0, b_readpos + b0, b_matchread + b0);
+    int nb = parse_blocks<true>(cg, ncig, seq, lseq, pos, flag & 0x10, totlen, b_refpos + b0, b_matchref + b0, b_readpos + b0, b_matchread + b0, blk_cnt[r]);
     // the SoA keeps TotalLen and the read offsets in 16 bits and the segmentation summary counts a record's further blocks in
     // 8 bits: longer reads / more blocks are refused instead of wrapping silently
     if (totlen > 65535 || nb > 256) atomicOr(&flags[0], 2048);
     if (nb < 0) {
         // the reference constructs a ReadRec_t only for records that pass its filters; for those the assert is live
         bool filtered = (ax & (SQ_AUX_MULTI | SQ_AUX_INCHIM)) || (flag & 0x400) || (flag & 0x4) || mapq < P.min_mapq;
+        if (P.chim) filtered = (flag & 0x400) || (flag & 0x4);  // (BuildChimericSBamRecord constructs a ReadRec_t for every mapped non-duplicate, SegmentGraph.cpp:196-201)
         if (!filtered) atomicOr(&flags[0], 256);
         const bool but_for_the_name = !(ax & SQ_AUX_MULTI) && !(flag & 0x400) && !(flag & 0x4) && mapq >= P.min_mapq;
         if (filtered && but_for_the_name) cs_out = -cs_out;  // (k_chim_fixup raises the flag should the name leave the set)
@@ -2836,7 +2838,7 @@ void dev_destroy(sq_ctx* c) {
     D.refid.release(); D.pos.release(); D.mrefid.release(); D.mpos.release(); D.endpos.release(); D.b_refpos.release(); D.b_matchref.release();
     D.b_pack.release(); D.n_pack.release(); D.r_pack.release();
     D.flag.release(); D.totlen.release(); D.b_readpos.release(); D.b_matchread.release(); D.mapq.release(); D.aux.release(); D.blk_off.release();
-    D.g_win.release(); D.p2_list.release(); D.p2_words.release(); D.tile_cnt.release(); D.tile_K.release(); D.tile_zcnt2.release(); D.zc_v.release(); D.zc_K.release(); D.zc_refid.release(); D.zc_pos.release(); D.tile_ob.release(); D.zc_ob.release();
+    D.nm_blob.release(); D.nm_off.release(); D.g_win.release(); D.p2_list.release(); D.p2_words.release(); D.tile_cnt.release(); D.tile_K.release(); D.tile_zcnt2.release(); D.zc_v.release(); D.zc_K.release(); D.zc_refid.release(); D.zc_pos.release(); D.tile_ob.release(); D.zc_ob.release();
     D.tile_rank.release(); D.tile_zbase.release(); D.tile_zcnt.release(); D.z_idx.release(); D.z_chr.release(); D.z_right.release(); D.rc_cluster.release(); D.rc_pos.release(); D.rc_len.release(); D.p1_sc.release();
     D.tile_first.release(); D.tile_max.release(); D.r_break.release(); D.sum_items.release(); D.bp_before.release();
     D.cls.release(); D.keep.release(); D.prev1.release(); D.prev2.release(); D.rank1.release(); D.restoff.release();
@@ -3333,6 +3335,23 @@ int dev_chim_finalize(sq_ctx* c, const std::vector<std::string>& dead_names) {
     return SQ_OK;
 }
 
+// QNAMEs of the records of a parsed chunk (the chimeric BAM through K0, sq_ctx::capture_names): lengths, then -- behind a scan -- the bytes,
+// without the terminating NUL, one name behind the other as the host decoder leaves them (HostBatch::names / name_off)
+__global__ void k_name_len(const uint8_t* bam, const unsigned long long* rec_off, int64_t n, int32_t* len) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int lname = bam[rec_off[r] + 4 + 8];
+    len[r] = lname > 0 ? lname - 1 : 0;
+}
+__global__ void k_name_copy(const uint8_t* bam, const unsigned long long* rec_off, int64_t n, const int32_t* rel, uint32_t base, char* blob, uint32_t* off_out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const uint8_t* src = bam + rec_off[r] + 4 + 32;
+    const int lname = bam[rec_off[r] + 4 + 8], L = lname > 0 ? lname - 1 : 0;
+    char* dst = blob + base + (uint32_t)rel[r];
+    for (int i = 0; i < L; ++i) dst[i] = (char)src[i];
+    off_out[r] = base + (uint32_t)rel[r];
+}
 // K0: parse `n_rec` BAM records of an inflated chunk on the device and append them to the resident SoA
 static int parse_device(sq_ctx* c, const uint8_t* d_bam, size_t nbytes, const unsigned long long* d_off, int64_t n_rec, hipStream_t on = nullptr, int32_t* flags16 = nullptr, DBuf<int32_t>* scan_state = nullptr);
 int dev_parse_append(sq_ctx* c, const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n_rec) {
@@ -3348,7 +3367,7 @@ int dev_parse_append(sq_ctx* c, const uint8_t* bam, size_t nbytes, const unsigne
 // the records at d_off[0..n_rec) of the inflated bytes d_bam (both in device memory) -> appended to the resident SoA
 // (`on`, `flags16`, `scan_state`: the stream, a 16-int flag block and the scan state to use -- the file ingest parses on its own stream)
 static int parse_device(sq_ctx* c, const uint8_t* d_bam, size_t nbytes, const unsigned long long* d_off, int64_t n_rec, hipStream_t on, int32_t* flags16, DBuf<int32_t>* scan_state) {
-    { const int rc = chim_join_names(c); if (rc) return rc; }  // the QNAME table of the chimeric BAM (sq_ingest_files decodes that file meanwhile)
+    if (!c->capture_names) { const int rc = chim_join_names(c); if (rc) return rc; }  // the QNAME table of the chimeric BAM (sq_ingest_files decodes that file meanwhile)
     DeviceRecords& D = *c->dev;
     hipStream_t s = on ? on : c->stream;
     int32_t* const fl = flags16 ? flags16 : D.flags.p;
@@ -3382,9 +3401,10 @@ static int parse_device(sq_ctx* c, const uint8_t* d_bam, size_t nbytes, const un
     if (D.b_pack.cap < nb1 + 1) GROW(b_pack, nb0, blk_want);
 #undef GROW
     ChimSetView C{D.chim_mask, D.chim_mask ? D.chim_hash.p : nullptr, D.chim_off.p, D.chim_len.p, D.chim_blob.p, D.chim_dead.p};
-    ParseParams P{(int)(signed char)(((c->P.phred_type ? 33 : 64) + c->P.min_phred) & 0xff), c->P.max_lowphred_len, c->P.min_mapqual};
+    if (c->capture_names) C = ChimSetView{0, nullptr, D.chim_off.p, D.chim_len.p, D.chim_blob.p, D.chim_dead.p};  // (the chimeric BAM itself: no name set to look its records up in)
+    ParseParams P{(int)(signed char)(((c->P.phred_type ? 33 : 64) + c->P.min_phred) & 0xff), c->P.max_lowphred_len, c->P.min_mapqual, c->capture_names ? 1 : 0};
     { EvTimer t(c, "k_parse_write", (double)nbytes + 32.0 * n_rec + 12.0 * nblk_total, s);
-      hipLaunchKernelGGL(k_parse_write, grid_for(n_rec, PARSE_THREADS), dim3(PARSE_THREADS), 0, s, d_bam, nbytes, d_off, n_rec, C, P, D.parse_rel.p, (uint32_t)nb0, D.refid.p + n0, D.pos.p + n0, D.mrefid.p + n0,
+      hipLaunchKernelGGL(k_parse_write, grid_for(n_rec, PARSE_THREADS), dim3(PARSE_THREADS), 0, s, d_bam, nbytes, d_off, n_rec, C, P, D.parse_nblk.p, D.parse_rel.p, (uint32_t)nb0, D.refid.p + n0, D.pos.p + n0, D.mrefid.p + n0,
                          D.mpos.p + n0, D.endpos.p + n0, D.flag.p + n0, D.totlen.p + n0, D.mapq.p + n0, D.aux.p + n0, D.blk_off.p + n0, D.b_refpos.p, D.b_matchref.p, D.b_readpos.p, D.b_matchread.p,
                          D.chim_slot_of.p + n0, fl); }
     if (nb1 > nb0) hipLaunchKernelGGL(k_pack_blocks, dim3((unsigned)((nb1 - nb0 + 255) / 256)), dim3(256), 0, s, (int64_t)nb0, (int64_t)nb1, D.b_refpos.p, D.b_matchref.p, D.b_readpos.p, D.b_matchread.p, D.b_pack.p);
@@ -3396,6 +3416,21 @@ static int parse_device(sq_ctx* c, const uint8_t* d_bam, size_t nbytes, const un
     if (hf & 128) return fail(c, SQ_E_IO, "corrupt BAM record");
     if (hf & 2048) return fail(c, SQ_E_CAPACITY, "a read longer than 65535 bases or with more than 256 aligned blocks (the record layout keeps 16-bit read offsets)");
     if (hf & 256) return fail(c, SQ_E_ASSERT, "record without stored bases for an aligned block (reference asserts, ReadRec.cpp:64)");
+    if (c->capture_names) {
+        if (n0 == 0) D.nm_bytes = 0;
+        { EvTimer t(c, "k_names", (double)n_rec * 48.0, s);
+          hipLaunchKernelGGL(k_name_len, grid_for(n_rec, 256), dim3(256), 0, s, d_bam, d_off, n_rec, D.parse_nblk.p);
+          HIPCHK((device_scan<OpSum, true>(s, n_rec, FArrN{D.parse_nblk.p}, D.parse_rel.p, spine, tot))); }
+        int32_t nm_total = 0;
+        HIPCHK(hipMemcpyAsync(&nm_total, tot, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (D.nm_bytes + (size_t)nm_total >= 0xffffffffull) return fail(c, SQ_E_CAPACITY, "more than 4 GB of read names");
+        HIPCHK(D.nm_blob.grow_keep(D.nm_bytes, std::max<size_t>(D.nm_bytes + (size_t)nm_total + 64, rec_want * 16), s));
+        HIPCHK(D.nm_off.grow_keep(n0, rec_want + 1, s));
+        hipLaunchKernelGGL(k_name_copy, grid_for(n_rec, 256), dim3(256), 0, s, d_bam, d_off, n_rec, D.parse_rel.p, (uint32_t)D.nm_bytes, D.nm_blob.p, D.nm_off.p + n0);
+        HIPCHK(hipStreamSynchronize(s));  // (the chunk's bytes belong to the caller again)
+        D.nm_bytes += (size_t)nm_total;
+    }
     D.n = (int64_t)n1;
     D.nb = (int64_t)nb1;
     c->counts.n_concordant = D.n;
@@ -3520,7 +3555,9 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         const double ratio = (double)(l.uoff + l.isize - f.uoff) / (double)std::max<unsigned long long>(1, l.coff + l.clen - f.coff);
         return (unsigned long long)(ratio * 1.03 * (double)(file_bytes - std::min<unsigned long long>(file_bytes, f.coff)));
     };
-    const Shard& sh = c->shard;
+    Shard sh_here = c->shard;
+    if (c->capture_names) sh_here.on = false;  // (the chimeric BAM is every rank's, whole)
+    const Shard& sh = sh_here;
     // stage A of batch k: compressed bytes and block table to the device, token pass
     auto stage_a = [&](size_t k) -> int {  // (SQ_OK also when there is no batch k)
         if (!plan(k)) return SQ_OK;
@@ -3763,6 +3800,16 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
 }
 
 // debugging / tests: copy the resident SoA back to the host
+// the QNAMEs captured beside the resident records (sq_ctx::capture_names) into hb.names / hb.name_off
+int dev_download_names(sq_ctx* c, HostBatch& hb) {
+    DeviceRecords& D = *c->dev;
+    const size_t n = (size_t)D.n;
+    hb.names.resize(D.nm_bytes); hb.name_off.resize(n + 1);
+    if (n) HIPCHK(hipMemcpy(hb.name_off.data(), D.nm_off.p, n * 4, hipMemcpyDeviceToHost));
+    if (D.nm_bytes) HIPCHK(hipMemcpy(hb.names.data(), D.nm_blob.p, D.nm_bytes, hipMemcpyDeviceToHost));
+    hb.name_off[n] = (uint32_t)D.nm_bytes;
+    return SQ_OK;
+}
 int dev_download_records(sq_ctx* c, HostBatch& hb) {
     DeviceRecords& D = *c->dev;
     const size_t n = (size_t)D.n, nb = (size_t)D.nb;

@@ -28,9 +28,11 @@ def parse_cigar(s):
     return out
 
 
-def record(name, refid, pos, mapq, flag, cigar, mrefid=-1, mpos=-1, seq=None, qual=None, tags=b"NHC\x01"):
+def record(name, refid, pos, mapq, flag, cigar, mrefid=-1, mpos=-1, seq=None, qual=None, tags=b"NHC\x01", lseq=None):
+    """`lseq`: store fewer bases than the CIGAR consumes (a secondary line with SEQ cut short or '*': the reference's assert, ReadRec.cpp:64)"""
     cig = parse_cigar(cigar) if isinstance(cigar, str) else cigar
-    lseq = sum(l for op, l in cig if op in "MIS=X")
+    if lseq is None:
+        lseq = sum(l for op, l in cig if op in "MIS=X")
     if seq is None:
         seq = "ACGT" * (lseq // 4 + 1)
         seq = seq[:lseq]

@@ -1385,3 +1385,87 @@ def test_break_candidate_counts_against_the_reference_s_linear_passes(built, syn
         k = ctx.counts()
     assert k["replay_candidates_checked"] > 20, k
     assert k["replay_count_mismatches"] == 0, k
+
+
+# ---------------------------------------------------------------------------------------------- the chimeric BAM through the GPU reader
+@pytest.mark.parametrize("cfg,extra,kw", [("T2", [], {}), ("C2", [], {}), ("C2", ["--support", "2,6"], {}),
+                                          ("C5g", ["--records", "300000", "--tsv", "600"], {"min_edge_weight": 1, "max_allowed_degree": 50})])
+def test_chimeric_bam_through_the_gpu_reader_gives_the_host_decoder_s_fragments(built, synth, tmp_path, monkeypatch, cfg, extra, kw):
+    """sq_ingest_files with SQUID_CHIM_GPU=1: the chimeric BAM is inflated, cut into records and parsed by K-1 + K0 (QNAMEs kept on the
+    device, k_name_len / k_name_copy) and copied back as one batch; BuildChimericSBamRecord then starts from it.  Same chimeric record and
+    fragment counts, same concordant records (the early QNAME table is built from the downloaded names), every graph stage, the orders and
+    _sv.txt as with the host decoder (SQUID_CHIM_GPU=0) -- and as the oracle"""
+    import hashlib
+
+    pre = synth(cfg, *extra)
+    sv_path, dump = ou.run_oracle(built, pre, tmp_path, *(["-w", str(kw["min_edge_weight"]), "-a", str(kw["max_allowed_degree"])] if kw else []))
+
+    def run(route):
+        monkeypatch.setenv("SQUID_CHIM_GPU", route)
+        with squid_amd.Context(**kw) as ctx:
+            ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
+            recs = {k: hashlib.sha256(v.tobytes()).hexdigest() for k, v in ctx.records().items()}
+            k = ctx.counts()
+            assert k["chimeric_through_gpu_reader"] == int(route)
+            ctx.build_graph()
+            return recs, k["n_concordant"], k["n_blocks"], k["n_chimeric_records"], k["n_chim_fragments"], ctx.graph(2), ctx.graph(0), ctx.order(), ctx.breakpoints(), ctx.sv_text()
+
+    host, dev = run("0"), run("1")
+    assert dev == host
+    assert dev[3] > 0 and dev[4] > 0
+    assert dev[-1] == sv_path.read_text()
+
+
+def test_chimeric_record_without_stored_bases_is_refused_on_both_routes(built, tmp_path, monkeypatch):
+    """BuildChimericSBamRecord constructs a ReadRec_t for every mapped non-duplicate record of the chimeric BAM, multi-mapped or not
+    (SegmentGraph.cpp:196-201), so the assert of ReadRec.cpp:64 is live for a multi-mapped line whose SEQ is shorter than its CIGAR says:
+    the library refuses the file (SQ_E_ASSERT) whichever reader decoded it; the same line flagged as a duplicate is skipped by both"""
+    import bamwriter as bw
+
+    def chim(flag_extra):
+        return [bw.record("q1", 0, 5000, 255, 0x1 | 0x40, "60M40S"), bw.record("q1", 1, 7000, 255, 0x1 | 0x40 | 0x100, "60H40M"),
+                bw.record("q1", 1, 7300, 255, 0x1 | 0x80 | 0x10, "100M"),
+                bw.record("q2", 0, 9000, 255, 0x1 | 0x40 | flag_extra, "50M100N50M", lseq=60, tags=b"NHC\x03")]
+
+    for route in ("0", "1"):
+        monkeypatch.setenv("SQUID_CHIM_GPU", route)
+        pre = _tiny_inputs(tmp_path, _pairs(), chim(0))
+        with squid_amd.Context() as ctx:
+            with pytest.raises(squid_amd.SquidError, match="without stored bases"):
+                ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
+        pre = _tiny_inputs(tmp_path, _pairs(), chim(0x400))
+        with squid_amd.Context() as ctx:
+            ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
+            assert ctx.counts()["chimeric_through_gpu_reader"] == int(route)
+            assert ctx.counts()["n_chimeric_records"] == 4
+
+
+def test_filtered_record_that_trips_the_assert_halfway_leaves_its_neighbours_blocks_alone(built, tmp_path, monkeypatch):
+    """a duplicate-flagged concordant line whose SEQ covers its first aligned block but not its second: the reference never constructs it;
+    the host decoder drops the block it had already pushed, and K0 -- whose count pass gives such a record no slot -- must not write that
+    block into the slot of the record behind it (parse_blocks' cap).  Device-parsed and host-parsed record arrays are identical"""
+    import bamwriter as bw
+    import numpy as np
+
+    recs = []
+    for i in range(200):
+        p = 1000 + 11 * i
+        recs.append((p, bw.record(f"r{i}", 0, p, 255, 0x1 | 0x2 | 0x20 | 0x40, "40M500N60M", 0, p + 900)))
+        if i % 3 == 0:
+            recs.append((p + 1, bw.record(f"d{i}", 0, p + 1, 255, 0x1 | 0x2 | 0x40 | 0x400, "50M100N50M", 0, p + 900, lseq=60)))
+    recs.sort(key=lambda t: t[0])
+    chim = [bw.record("q1", 0, 5000, 255, 0x1 | 0x40, "60M40S"), bw.record("q1", 1, 7000, 255, 0x1 | 0x40 | 0x100, "60H40M"),
+            bw.record("q1", 1, 7300, 255, 0x1 | 0x80 | 0x10, "100M")]
+    pre = _tiny_inputs(tmp_path, [r for _, r in recs], chim)
+    got = {}
+    for mode in ("device", "host"):
+        if mode == "host":
+            monkeypatch.setenv("SQUID_HOST_PARSE", "1")
+        with squid_amd.Context() as ctx:
+            ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
+            got[mode] = {k: np.array(v) for k, v in ctx.records().items()}
+    monkeypatch.delenv("SQUID_HOST_PARSE", raising=False)
+    assert got["device"].keys() == got["host"].keys()
+    for k in got["host"]:
+        assert np.array_equal(got["device"][k], got["host"][k]), k
+    assert len(got["host"]["refid"]) == len(recs)
