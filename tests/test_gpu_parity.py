@@ -1408,7 +1408,8 @@ def test_chimeric_bam_through_the_gpu_reader_gives_the_host_decoder_s_fragments(
             k = ctx.counts()
             assert k["chimeric_through_gpu_reader"] == int(route)
             ctx.build_graph()
-            return recs, k["n_concordant"], k["n_blocks"], k["n_chimeric_records"], k["n_chim_fragments"], ctx.graph(2), ctx.graph(0), ctx.order(), ctx.breakpoints(), ctx.sv_text()
+            g2, g0, order, sv = ctx.graph(2), ctx.graph(0), ctx.order(), ctx.sv_text()
+            return recs, k["n_concordant"], k["n_blocks"], k["n_chimeric_records"], k["n_chim_fragments"], g2, g0, order, ctx.breakpoints(), sv
 
     host, dev = run("0"), run("1")
     assert dev == host
