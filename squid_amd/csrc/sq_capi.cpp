@@ -945,7 +945,8 @@ static int chimeric_file_to_fragments(sq_ctx* c, const char* path, int nt, std::
         sq_aln_batch b;
         hb.view(&b, true);
         got = true;
-        if (early) {
+        if (early && decoded) promise(SQ_OK);  // (chimeric_records_through_the_device has made the table from the names on the device: dev_chim_begin_captured)
+        else if (early) {
             // one entry per usable record (mapped, not a duplicate: ReadRec.cpp:344), the name with a trailing /1 or /2 cut off
             // (ReadRec.cpp:62-66), plus the empty name the reference's set always holds (SegmentGraph.cpp:196-201, ledger B9)
             std::vector<uint32_t> off, len;
@@ -1010,8 +1011,16 @@ static int chimeric_records_through_the_device(sq_ctx* c, const char* path, int 
                            [&](size_t total) { c->ingest_total_bytes = total; }, nullptr,
                            [&](const uint8_t* file, std::vector<BgzfRange>& blocks, size_t b0, size_t b1, size_t begin, bool synced, int nref, const IndexMore& more, size_t file_bytes, GpuFileSrc* src) {
                                return dev_ingest_bgzf(c, file, blocks, b0, b1, begin, synced, nref, more, file_bytes, src); }, false, true, true);
+    static const bool prof = std::getenv("SQUID_CHIM_PROF") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (prof) std::fprintf(stderr, "chimeric file on the device: %-24s at %8.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); };
+    lap("reader returned (since then)");
+    if (rc == SQ_OK) rc = dev_chim_begin_captured(c);
+    lap("name table");
     if (rc == SQ_OK) rc = dev_download_records(c, hb);
     if (rc == SQ_OK) rc = dev_download_names(c, hb);
+    lap("records and names copied back");
+    dev_flush_timers(c);  // (its launches are not the concordant ingest's)
     if (rc != SQ_OK) { c->err = saved_err; hb.clear(); return 2; }
     return SQ_OK;
 }
@@ -1037,7 +1046,10 @@ int sq_ingest_files(sq_ctx* c, const char* chim_path, const char* bam_path, int3
         const char* env = std::getenv("SQUID_CHIM_GPU");
         const bool want = env ? std::atoi(env) != 0 : (::stat(chim_path, &st) == 0 && (size_t)st.st_size >= ((size_t)128 << 20));
         if (want) {
-            decoded = std::make_shared<HostBatch>();
+            // (the batch is the context's between calls, like the scratch of a whole-file read on the host: 0.5 GB of pages on the dense
+            // config that the next read of a chimeric file finds in place; sq_release_reader_buffers gives them back)
+            if (!c->chim_decoded || c->chim_decoded.use_count() > 1) c->chim_decoded = std::make_shared<HostBatch>();
+            decoded = c->chim_decoded;
             if (chimeric_records_through_the_device(c, chim_path, n_threads, *decoded) != SQ_OK) decoded.reset();
         }
         c->counts.chimeric_through_gpu_reader = decoded ? 1 : 0;
@@ -1348,6 +1360,7 @@ int sq_release_reader_buffers(sq_ctx* c) {
     if (!c) return SQ_E_ARG;
     c->staged_path.clear(); c->staged_bytes = 0;
     drop_whole_file_scratch();
+    if (!c->chim_future.valid()) c->chim_decoded.reset();  // (a pairing still running reads it)
     return dev_release_reader(c);
 }
 int sq_timing_accumulate(sq_ctx* c, int32_t keep) {

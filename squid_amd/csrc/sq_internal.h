@@ -187,6 +187,7 @@ struct sq_ctx {
     sq::DeviceRecords* dev = nullptr;
     // --bwa (sq_ingest_bwa_file): every record of the one BAM file on the host, with its QNAME (sq_bwa.cpp)
     std::shared_ptr<sq::HostBatch> bwa;
+    std::shared_ptr<sq::HostBatch> chim_decoded;  // the chimeric records as the GPU reader decoded them (sq_ingest_files), kept for the next call's pages
     // graph state (host, small)
     std::vector<sq::Node> nodes;
     std::vector<sq::Edge> edges;
@@ -368,6 +369,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
 struct HostBatch;
 int dev_download_records(sq_ctx* c, HostBatch& hb);
 int dev_download_names(sq_ctx* c, HostBatch& hb);
+int dev_chim_begin_captured(sq_ctx* c);
 int dev_chim_begin(sq_ctx* c, const char* blob, size_t blob_bytes, const uint32_t* off, const uint32_t* len, size_t n);
 int dev_chim_finalize(sq_ctx* c, const std::vector<std::string>& dead_names);
 struct SegSupport {

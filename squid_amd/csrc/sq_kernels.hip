@@ -606,9 +606,24 @@ __global__ void k_chim_insert(const char* blob, const uint32_t* in_off, const ui
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t o = in_off[i], l = in_len[i];
+    if (l == 0xffffffffu) return;  // (k_chim_entries: a record that is not usable)
     const unsigned long long h = chim_hash_of((const uint8_t*)blob + o, (int)l);
     for (uint32_t s = chim_slot(h, mask);; s = (s + 1) & mask)  // (every record takes a slot of its own: no name compare, nobody reads off / len in here)
         if (atomicCAS(&hash[s], 0ull, h) == 0ull) { off[s] = o; len[s] = l; return; }
+}
+// the same entries from the records of the chimeric BAM where K0 left them (sq_ctx::capture_names): one per usable record -- mapped, not a
+// duplicate (ReadRec.cpp:344) --, the name with a trailing /1 or /2 cut off (ReadRec.cpp:62-66); entry n is the empty name the reference's
+// set always holds (SegmentGraph.cpp:196-201, ledger B9)
+__global__ void k_chim_entries(const char* blob, const uint32_t* nm_off, uint32_t nm_end, const uint16_t* flag, int64_t n, uint32_t* in_off, uint32_t* in_len) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { in_off[i] = 0; in_len[i] = 0; return; }
+    const uint32_t o = nm_off[i], e = i + 1 < n ? nm_off[i + 1] : nm_end;
+    uint32_t L = e - o;
+    if (L >= 2 && blob[o + L - 2] == '/' && (blob[o + L - 1] == '1' || blob[o + L - 1] == '2')) L -= 2;
+    const int f = flag[i];
+    in_off[i] = o;
+    in_len[i] = ((f & 0x4) || (f & 0x400)) ? 0xffffffffu : L;
 }
 __global__ void k_chim_mark_dead(const char* dblob, const uint32_t* d_off, const uint32_t* d_len, int n, ChimSetView C, uint8_t* dead) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3303,6 +3318,27 @@ int dev_chim_begin(sq_ctx* c, const char* blob, size_t blob_bytes, const uint32_
     D.chim_provisional = true;
     return SQ_OK;
 }
+// dev_chim_begin for records that came through the GPU reader: their names and flags are on the device (library stream; the caller has
+// nothing else in flight)
+int dev_chim_begin_captured(sq_ctx* c) {
+    HIPCHK(hipSetDevice(c->P.device));
+    DeviceRecords& D = *c->dev;
+    hipStream_t s = c->stream;
+    const size_t n = (size_t)D.n + 1;
+    uint32_t slots = 16;
+    while ((size_t)slots < 2 * n + 2) slots <<= 1;
+    HIPCHK(D.chim_hash.reserve(slots)); HIPCHK(D.chim_off.reserve(slots)); HIPCHK(D.chim_len.reserve(slots)); HIPCHK(D.chim_dead.reserve(slots));
+    HIPCHK(D.chim_blob.reserve(D.nm_bytes + 1)); HIPCHK(D.chim_in_off.reserve(n)); HIPCHK(D.chim_in_len.reserve(n));
+    HIPCHK(hipMemsetAsync(D.chim_hash.p, 0, (size_t)slots * 8, s));
+    HIPCHK(hipMemsetAsync(D.chim_dead.p, 0, D.chim_dead.cap, s));
+    if (D.nm_bytes) HIPCHK(hipMemcpyAsync(D.chim_blob.p, D.nm_blob.p, D.nm_bytes, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_chim_entries, grid_for((int64_t)n, 256), dim3(256), 0, s, D.chim_blob.p, D.nm_off.p, (uint32_t)D.nm_bytes, D.flag.p, D.n, D.chim_in_off.p, D.chim_in_len.p);
+    hipLaunchKernelGGL(k_chim_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, D.chim_blob.p, D.chim_in_off.p, D.chim_in_len.p, (int)n, slots - 1, D.chim_hash.p, D.chim_off.p, D.chim_len.p);
+    HIPCHK(hipStreamSynchronize(s));
+    D.chim_mask = slots - 1;
+    D.chim_provisional = true;
+    return SQ_OK;
+}
 // after the pairing: the names of the fragments its PCR-duplicate removal dropped leave the set, and the records that matched one of them
 // lose their bit (library stream; every record parse is over)
 int dev_chim_finalize(sq_ctx* c, const std::vector<std::string>& dead_names) {
@@ -3813,7 +3849,8 @@ int dev_download_names(sq_ctx* c, HostBatch& hb) {
 int dev_download_records(sq_ctx* c, HostBatch& hb) {
     DeviceRecords& D = *c->dev;
     const size_t n = (size_t)D.n, nb = (size_t)D.nb;
-    hb.clear();
+    // (no clear(): a batch the caller keeps between calls has its pages already -- resize() to the size it had costs nothing)
+    hb.names.clear(); hb.name_off.assign(1, 0);
     hb.refid.resize(n); hb.pos.resize(n); hb.mrefid.resize(n); hb.mpos.resize(n); hb.endpos.resize(n); hb.flag.resize(n); hb.totlen.resize(n); hb.mapq.resize(n); hb.aux.resize(n);
     hb.blk_off.resize(n + 1); hb.b_refpos.resize(nb); hb.b_matchref.resize(nb); hb.b_readpos.resize(nb); hb.b_matchread.resize(nb);
     if (n) {

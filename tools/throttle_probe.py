@@ -15,11 +15,15 @@ def stat():
         pass
     return d
 
-wl = sys.argv[1] if len(sys.argv) > 1 else "C3"
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+staged = "--staged" in sys.argv
+wl = args[0] if args else "C3"
 pre = {"C3": "/tmp/squid_bench/C3_s20180003", "C5": "/tmp/squid_bench/C5_s20180005"}[wl]
 kw = dict(min_edge_weight=1, max_allowed_degree=50) if wl == "C5" else {}
 print("cpu.max:", open("/sys/fs/cgroup/cpu.max").read().strip())
 with squid_amd.Context(**kw) as ctx:
+    if staged:
+        ctx.stage_bam(f"{pre}.bam")
     for it in range(5):
         squid_amd.drop_file_cache(); ctx.clear_records()
         a = stat(); t0 = time.perf_counter()
