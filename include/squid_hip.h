@@ -254,6 +254,12 @@ int sq_reset(sq_ctx* c); /* drop graph results, keep ingested records resident i
  * page-locked host buffers.  The resident records, the graph and every result stay.  The next ingest allocates again (what a first
  * ingest does anyway); a process that keeps a context for parameter sweeps over resident records calls this once after the ingest. */
 int sq_release_reader_buffers(sq_ctx* c);
+/* For a host program that runs sample after sample in ONE process (a service, bench.py): tell the C library's allocator to keep the
+ * memory the host stages free instead of handing it back to the kernel after every sample (glibc: mallopt M_TRIM_THRESHOLD, M_TOP_PAD,
+ * M_MMAP_THRESHOLD) -- the pairing of the chimeric records and the graph stages allocate and free gigabytes per sample, and fresh pages
+ * cost a fault each (dense config: 0.2 s of 2.5 s per sample).  Process-wide and the host program's decision, so never done behind its
+ * back: the library only does it when asked here; `build/squid`, one sample per process, does not ask.  Results are unaffected. */
+int sq_keep_host_memory(void);
 
 typedef struct sq_counts {
     int64_t n_concordant, n_blocks, n_chimeric_records, n_chim_fragments, read_len;

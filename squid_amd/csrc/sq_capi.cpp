@@ -11,6 +11,7 @@
 #include <unistd.h>
 
 #include "sq_internal.h"
+#include <malloc.h>
 #include "sq_parsort.h"
 
 namespace sq {
@@ -975,13 +976,18 @@ static int chimeric_file_to_fragments(sq_ctx* c, const char* path, int nt, std::
     if (!rc && !got) rc = fail(c, SQ_E_EMPTYCHIM, "chimeric BAM holds no record");
     promise(rc ? rc : SQ_OK);  // (whatever happened: nobody waits for ever)
     if (rc) return rc;
-    copy_frags(c, c->frags, c->frags0);
-    lap("fragments copied");
     if (early && !c->ref_len.empty()) {  // this thread has nothing else to do, the concordant file is still being read
+        // (the copy sq_reset restores the fragments from is made next to the cluster table: both only read c->frags)
+        std::future<void> copied = std::async(std::launch::async, [c]() { copy_frags(c, c->frags, c->frags0); });
         c->plan_early.reset(); c->disc_early.clear();
         c->clusters_early_ms = segment_clusters(c, c->plan_early, c->disc_early);
         lap("cluster table");
+        copied.get();
+        lap("fragments copied");
+        return SQ_OK;
     }
+    copy_frags(c, c->frags, c->frags0);
+    lap("fragments copied");
     return SQ_OK;
 }
 // BuildChimericSBamRecord on a context that has no device side (the junction-sequence utility): c->frags0
@@ -1362,6 +1368,12 @@ int sq_release_reader_buffers(sq_ctx* c) {
     drop_whole_file_scratch();
     if (!c->chim_future.valid()) c->chim_decoded.reset();  // (a pairing still running reads it)
     return dev_release_reader(c);
+}
+int sq_keep_host_memory(void) {
+    // (mallopt takes ints: the thresholds stop at 2 GiB - 1; thread arenas -- where the context's host threads allocate -- are kept
+    // whole by the top pad: an arena heap is only unmapped when more than the pad would stay free in the one before it)
+    const int ok = mallopt(M_TRIM_THRESHOLD, INT32_MAX) & mallopt(M_TOP_PAD, INT32_MAX & ~4095) & mallopt(M_MMAP_THRESHOLD, 32 << 20);
+    return ok ? SQ_OK : SQ_E_ARG;
 }
 int sq_timing_accumulate(sq_ctx* c, int32_t keep) {
     if (!c) return SQ_E_ARG;

@@ -12,6 +12,7 @@
 #include <functional>
 
 #include "sq_internal.h"
+#include <future>
 #include "sq_parsort.h"
 
 namespace sq {
@@ -94,9 +95,20 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
         t_prev = now;
     };
     // one single-record fragment per usable record (mapped, not duplicate: ReadRec.cpp:344)
+    // (the indices i in [0, n) with pred(i), ascending: counted and written piece by piece on the host threads)
+    auto select = [&](int64_t n, const std::function<bool(int64_t)>& pred, std::vector<int64_t>& out, size_t extra = 0) {
+        const int pieces = (int)std::min<int64_t>(std::max<int64_t>(1, n / 65536), pool ? 4 * (pool->size() + 1) : 1);
+        std::vector<size_t> at((size_t)pieces + 1, 0);
+        auto count = [&](int k) { size_t cnt = 0; for (int64_t i = n * k / pieces; i < n * (k + 1) / pieces; ++i) cnt += pred(i) ? 1 : 0; at[(size_t)k + 1] = cnt; };
+        if (pieces > 1) pool->parallel_for(pieces, 15, count); else count(0);
+        for (int k = 0; k < pieces; ++k) at[(size_t)k + 1] += at[(size_t)k];
+        out.reserve(at.back() + extra);
+        out.resize(at.back());
+        auto fill = [&](int k) { size_t o = at[(size_t)k]; for (int64_t i = n * k / pieces; i < n * (k + 1) / pieces; ++i) if (pred(i)) out[o++] = i; };
+        if (pieces > 1) pool->parallel_for(pieces, 15, fill); else fill(0);
+    };
     std::vector<int64_t> usable;
-    usable.reserve((size_t)b->n_rec);
-    for (int64_t i = 0; i < b->n_rec; ++i) if (!(b->flag[i] & 0x4) && !(b->flag[i] & 0x400)) usable.push_back(i);
+    select(b->n_rec, [&](int64_t i) { return !(b->flag[i] & 0x4) && !(b->flag[i] & 0x400); }, usable);
     c->n_chim_records = b->n_rec;
     if (usable.empty()) return fail(c, SQ_E_EMPTYCHIM, "chimeric input has no mapped, non-duplicate record");
     std::vector<uint16_t> sample;  // ReadLen = median of max(FirstTotalLen, SecondTotalLen) of the first five (ReadRec.cpp:336,347-348)
@@ -142,7 +154,7 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
     }, sort_threads);
     lap("name sort");
     // merge equal names (ReadRec.cpp:356-373): runs of equal names in the sorted order; the runs are independent of each other
-    std::vector<size_t> run_start;
+    std::vector<int64_t> run_start;
     {
         Raw<uint8_t> starts(nr);
         par((int64_t)nr, [&](int64_t lo, int64_t hi) {
@@ -152,12 +164,9 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
                 starts[(size_t)k] = k == 0 || x.hi != w.hi || x.lo != w.lo || ((x.len > 16 || w.len > 16) && name_cmp(x.idx, w.idx) != 0);
             }
         });
-        size_t cnt = 0;
-        for (size_t k = 0; k < nr; ++k) cnt += starts[k];
-        run_start.reserve(cnt + 1);
-        for (size_t k = 0; k < nr; ++k) if (starts[k]) run_start.push_back(k);
+        select((int64_t)nr, [&](int64_t k) { return starts[(size_t)k] != 0; }, run_start, 1);
     }
-    run_start.push_back(nr);
+    run_start.push_back((int64_t)nr);
     const size_t nm = run_start.size() - 1;
     // (the merged fragments: raw storage, every element constructed by the thread that fills it and destroyed side by side at the end)
     struct FragStore {
@@ -175,7 +184,7 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
             // record brings one
             Frag& m = *new (&merged[(size_t)j]) Frag();
             store.made[(size_t)j] = 1;
-            const size_t k0 = run_start[(size_t)j], k1 = run_start[(size_t)j + 1];
+            const size_t k0 = (size_t)run_start[(size_t)j], k1 = (size_t)run_start[(size_t)j + 1];
             m.name.assign(name_ptr((size_t)nk[k0].idx), nlen[(size_t)nk[k0].idx]);
             size_t na = 0, nb = 0;
             for (size_t k = k0; k < k1; ++k) { const int64_t i = usable[(size_t)nk[k].idx]; ((b->flag[i] & 0x40) ? na : nb) += b->blk_off[i + 1] - b->blk_off[i]; }
@@ -232,8 +241,10 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
     });
     c->frags.clear();
     std::vector<Frag>& out = c->frags;
-    std::vector<uint8_t> kept(nm, 0);   // by merged index
+    std::vector<uint8_t> kept(nm, 0);     // by merged index
     std::vector<uint8_t> keep_at(nm, 0);  // by position in the sorted order
+    std::vector<uint8_t> named(nm, 0);    // by merged index: kept, and the name is not empty
+    std::vector<int32_t> where(nm, -1);   // by merged index: position in the output
     {
         Raw<uint8_t> gstart(nm);
         par((int64_t)nm, [&](int64_t lo, int64_t hi) {
@@ -244,14 +255,14 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
                 gstart[(size_t)p] = st;
             }
         });
-        std::vector<size_t> groups;
-        for (size_t p = 0; p < nm; ++p) if (gstart[p]) groups.push_back(p);
-        groups.push_back(nm);
+        std::vector<int64_t> groups;
+        select((int64_t)nm, [&](int64_t p) { return gstart[(size_t)p] != 0; }, groups, 1);
+        groups.push_back((int64_t)nm);
         par((int64_t)groups.size() - 1, [&](int64_t lo, int64_t hi) {
             std::vector<size_t> mine;  // kept members of the group so far
             for (int64_t g = lo; g < hi; ++g) {
                 mine.clear();
-                for (size_t p = groups[(size_t)g]; p < groups[(size_t)g + 1]; ++p) {
+                for (size_t p = (size_t)groups[(size_t)g]; p < (size_t)groups[(size_t)g + 1]; ++p) {
                     const Frag& f = merged[(size_t)fk[p].idx];
                     bool keep = true;
                     for (size_t q = mine.size(); q-- > 0 && keep;) if (frag_equal(f, merged[(size_t)fk[mine[q]].idx])) keep = false;
@@ -259,31 +270,50 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
                 }
             }
         });
-        std::vector<size_t> where_out(nm);
-        size_t total = 0;
-        for (size_t p = 0; p < nm; ++p) { where_out[p] = total; total += keep_at[p]; }
-        out.resize(total);
+        // output position of every kept fragment: a prefix sum over the sorted order, piece by piece
+        const int pieces = (int)std::min<int64_t>(std::max<int64_t>(1, (int64_t)nm / 65536), pool ? 4 * (pool->size() + 1) : 1);
+        std::vector<size_t> at((size_t)pieces + 1, 0);
+        auto piece_of = [&](int k) { return std::make_pair(nm * (size_t)k / (size_t)pieces, nm * ((size_t)k + 1) / (size_t)pieces); };
+        auto count = [&](int k) { size_t cnt = 0; for (size_t p = piece_of(k).first; p < piece_of(k).second; ++p) cnt += keep_at[p]; at[(size_t)k + 1] = cnt; };
+        if (pieces > 1) pool->parallel_for(pieces, 15, count); else count(0);
+        for (int k = 0; k < pieces; ++k) at[(size_t)k + 1] += at[(size_t)k];
+        const size_t total = at.back();
+        // (the room for the output -- one default-constructed Frag per kept fragment, a third of a gigabyte on the dense config and one
+        // thread's work -- is made while the other threads settle who goes where)
+        std::future<void> room;
+        if (pool && total > 100000) room = pool->submit([&out, total]() { out.resize(total); }); else out.resize(total);
+        auto place = [&](int k) {
+            size_t o = at[(size_t)k];
+            for (size_t p = piece_of(k).first; p < piece_of(k).second; ++p) if (keep_at[p]) {
+                const size_t j = (size_t)fk[p].idx;
+                kept[j] = 1; where[j] = (int32_t)o++; named[j] = !merged[j].name.empty();
+            }
+        };
+        if (pieces > 1) pool->parallel_for(pieces, 15, place); else place(0);
+        // the names that leave the reference's ChimName with their fragment (a name belongs to one merged fragment), in name order
+        c->chim_dead.clear();
+        {
+            std::vector<int64_t> dead;
+            select((int64_t)nm, [&](int64_t j) { return !kept[(size_t)j] && !merged[(size_t)j].name.empty(); }, dead);
+            c->chim_dead.resize(dead.size());
+            par((int64_t)dead.size(), [&](int64_t lo, int64_t hi) { for (int64_t q = lo; q < hi; ++q) c->chim_dead[(size_t)q] = merged[(size_t)dead[(size_t)q]].name; });
+        }
+        if (room.valid()) room.get();
         par((int64_t)nm, [&](int64_t lo, int64_t hi) {
-            for (int64_t p = lo; p < hi; ++p) if (keep_at[(size_t)p]) { kept[(size_t)fk[(size_t)p].idx] = 1; out[where_out[(size_t)p]] = std::move(merged[(size_t)fk[(size_t)p].idx]); }
+            for (int64_t j = lo; j < hi; ++j) if (kept[(size_t)j]) out[(size_t)where[(size_t)j]] = std::move(merged[(size_t)j]);
         });
     }
-    // the names that leave the reference's ChimName with their fragment (a name belongs to one merged fragment)
-    c->chim_dead.clear();
-    for (size_t j = 0; j < nm; ++j) if (!kept[j] && !merged[j].name.empty()) c->chim_dead.push_back(merged[j].name);
     lap("duplicate removal");
     // ChimName: Chimrecord.size() empty strings + every Qname, sorted unique (SegmentGraph.cpp:196-201, ledger B9).  `merged` is in name
     // order and holds every name once, so the kept names in that order are already the sorted unique list (the names were moved into
-    // `out`: read them back through a map from merged index to output position)
+    // `out`: read them back through the map from merged index to output position)
     c->chim_names.clear();
     if (!out.empty()) {
-        std::vector<int32_t> where(nm, -1);
-        { int32_t o = 0; for (size_t q = 0; q < fk.size(); ++q) { const FrontKey& k = fk[q]; if (kept[(size_t)k.idx]) where[(size_t)k.idx] = o++; } }
-        std::vector<size_t> slot(nm);
-        size_t cnt = 1;  // slot 0: "" (sorts in front of everything; a fragment with an empty name falls together with it)
-        for (size_t j = 0; j < nm; ++j) { slot[j] = cnt; cnt += where[j] >= 0 && !out[(size_t)where[j]].name.empty(); }
-        c->chim_names.resize(cnt);
-        par((int64_t)nm, [&](int64_t lo, int64_t hi) {
-            for (int64_t j = lo; j < hi; ++j) if (where[(size_t)j] >= 0 && !out[(size_t)where[(size_t)j]].name.empty()) c->chim_names[slot[(size_t)j]] = out[(size_t)where[(size_t)j]].name;
+        std::vector<int64_t> with_name;  // merged indices, ascending = name order
+        select((int64_t)nm, [&](int64_t j) { return named[(size_t)j] != 0; }, with_name);
+        c->chim_names.resize(with_name.size() + 1);  // slot 0: "" (sorts in front of everything; a fragment with an empty name falls together with it)
+        par((int64_t)with_name.size(), [&](int64_t lo, int64_t hi) {
+            for (int64_t q = lo; q < hi; ++q) c->chim_names[(size_t)q + 1] = out[(size_t)where[(size_t)with_name[(size_t)q]]].name;
         });
     }
     lap("names");

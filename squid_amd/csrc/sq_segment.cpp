@@ -40,14 +40,27 @@ struct SegStatic {
     // live ConcordRest content per cluster as CSR, sorted by refpos inside a cluster (only ever counted); rest_max = longest block
     std::vector<int32_t> rest_off, rest_pos, rest_len, rest_max;
     // the clusters are fixed by the sorted discordant blocks alone (SegmentGraph.cpp:341-348 / 604-611)
-    void build_clusters(int RL) {
-        int s0 = 0;
-        while (s0 != nd) {
-            int right = D[s0].refpos + D[s0].matchref, e = s0;
-            for (; e != nd && D[e].refid == D[s0].refid && D[e].refpos < right + RL; ++e) right = std::max(right, D[e].refpos + D[e].matchref);
-            clusters.push_back(Cluster{s0, e, D[s0].refid, D[s0].refpos, right});
-            s0 = e;
+    // (a cluster never crosses a chromosome: the runs of one RefID in the sorted list are walked side by side and strung together)
+    void build_clusters(int RL, HostPool* pool = nullptr) {
+        auto walk = [&](int s0, int end, std::vector<Cluster>& out) {
+            while (s0 != end) {
+                int right = D[s0].refpos + D[s0].matchref, e = s0;
+                for (; e != end && D[e].refid == D[s0].refid && D[e].refpos < right + RL; ++e) right = std::max(right, D[e].refpos + D[e].matchref);
+                out.push_back(Cluster{s0, e, D[s0].refid, D[s0].refpos, right});
+                s0 = e;
+            }
+        };
+        if (!pool || nd < 200000) { walk(0, nd, clusters); return; }
+        std::vector<int> cut{0};  // first block of every chromosome: binary searches (the list is sorted by RefID first)
+        while (cut.back() != nd) {
+            const int rid = D[cut.back()].refid;
+            int a = cut.back(), b = nd;
+            while (a < b) { const int m = a + (b - a) / 2; if (D[m].refid <= rid) a = m + 1; else b = m; }
+            cut.push_back(a);
         }
+        std::vector<std::vector<Cluster>> per(cut.size() - 1);
+        pool->parallel_for((int)per.size(), 1 << 20, [&](int k) { walk(cut[(size_t)k], cut[(size_t)k + 1], per[(size_t)k]); });
+        for (const auto& v : per) clusters.insert(clusters.end(), v.begin(), v.end());
     }
 };
 
@@ -484,22 +497,21 @@ double segment_clusters(const sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::ve
         if (np <= 1) { f(0, n); return; }
         c->pool->parallel_for(np, 1 << 20, [&](int k) { f(n * (size_t)k / (size_t)np, n * ((size_t)k + 1) / (size_t)np); });
     };
+    // (the pieces are not strung together: the sort below works on (key, index) elements, and the sorted list is gathered straight from
+    // the pieces -- d_at[k] = global index of piece k's first block)
+    std::vector<size_t> d_at(outs.size() + 1, 0);
+    for (size_t k = 0; k < outs.size(); ++k) d_at[k + 1] = d_at[k] + outs[k].D.size();
+    const size_t nD = d_at.back();
     {
         // the entries that were waiting for the last discordant block of the pieces in front: drop those that are the `Same` block
-        std::vector<size_t> d_at(outs.size() + 1, 0);
-        for (size_t k = 0; k < outs.size(); ++k) d_at[k + 1] = d_at[k] + outs[k].D.size();
-        D.resize(d_at.back());
-        if (pieces > 1) c->pool->parallel_for(pieces, 1 << 20, [&](int k) { std::copy(outs[(size_t)k].D.begin(), outs[(size_t)k].D.end(), D.begin() + (std::ptrdiff_t)d_at[(size_t)k]); });
-        else std::copy(outs[0].D.begin(), outs[0].D.end(), D.begin());
+        const Blk z{0, 0, 0, 0, 0, false, false};
+        const Blk* last = &z;  // the last discordant block of the pieces in front
         for (size_t k = 0; k < outs.size(); ++k) {
             Out& O = outs[k];
             std::vector<char> drop(O.part.size(), 0);
-            for (const auto& q : O.ask) {
-                Blk z{0, 0, 0, 0, 0, false, false};
-                const Blk& l = d_at[k] == 0 ? z : D[d_at[k] - 1];  // the last discordant block of the pieces in front
-                if (blk_same(l, q.second)) drop[q.first] = 1;
-            }
+            for (const auto& q : O.ask) if (blk_same(*last, q.second)) drop[q.first] = 1;
             for (size_t i = 0; i < O.part.size(); ++i) if (!drop[i]) S.part.push_back(O.part[i]);
+            if (!O.D.empty()) last = &O.D.back();
         }
     }
     lap("pieces strung");
@@ -510,22 +522,43 @@ double segment_clusters(const sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::ve
         // same comparison takes libstdc++'s introsort through the same decisions, hence to the same permutation, at a fraction of
         // the memory traffic of sorting the blocks themselves
         struct PK { int32_t refid, refpos, idx; };
-        std::vector<PK> pk(D.size());
-        par(D.size(), [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) pk[i] = PK{D[i].refid, D[i].refpos, (int32_t)i}; });
+        struct RawPK { PK* p; explicit RawPK(size_t n) : p((PK*)std::malloc(std::max<size_t>(1, n) * sizeof(PK))) {} ~RawPK() { std::free(p); } } pk(nD);  // (every element is written below)
+        // the room for the sorted list is made (230 MB of zeroes on the dense config, one thread's work) while the keys are being sorted
+        std::future<void> room;
+        std::vector<Blk> sorted;
+        if (c->pool && nD > 100000) room = c->pool->submit([&sorted, nD]() { sorted.resize(nD); }); else sorted.resize(nD);
+        if (pieces > 1) c->pool->parallel_for(pieces, 1 << 20, [&](int k) { const std::vector<Blk>& P = outs[(size_t)k].D; const size_t at = d_at[(size_t)k]; for (size_t i = 0; i < P.size(); ++i) pk.p[at + i] = PK{P[i].refid, P[i].refpos, (int32_t)(at + i)}; });
+        else for (size_t i = 0; i < nD; ++i) pk.p[i] = PK{outs[0].D[i].refid, outs[0].D[i].refpos, (int32_t)i};
+        lap("  block keys");
         // (std_sort_parallel, sq_parsort.h: the same introsort with its independent sub-ranges on several threads)
-        std_sort_parallel(pk.begin(), pk.end(), [](const PK& x, const PK& y) { return x.refid != y.refid ? x.refid < y.refid : x.refpos < y.refpos; }, sort_threads);
-        std::vector<Blk> sorted(D.size());
-        par(D.size(), [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) sorted[i] = D[(size_t)pk[i].idx]; });
+        std_sort_parallel(pk.p, pk.p + nD, [](const PK& x, const PK& y) { return x.refid != y.refid ? x.refid < y.refid : x.refpos < y.refpos; }, sort_threads);
+        lap("  block keys sorted");
+        if (room.valid()) room.get();
+        lap("  room for the sorted blocks");
+        par(nD, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) {
+                const size_t g = (size_t)pk.p[i].idx;
+                const size_t k = (size_t)(std::upper_bound(d_at.begin(), d_at.end(), g) - d_at.begin()) - 1;
+                sorted[i] = outs[k].D[g - d_at[k]];
+            }
+        });
         D.swap(sorted);
+        lap("  blocks gathered");
     }
     lap("blocks sorted");
     S.nd = (int)D.size();
-    disc_sorted = D;
-    D.push_back(Blk{0, 0, 0, 0, 0, false, false});  // ledger B21 sentinel
+    // the copy the edge stage reads, made next to the cluster table (both only read the sorted list); the pieces are freed on the way
+    std::future<void> copy_made;
+    if (c->pool && nD > 100000) copy_made = c->pool->submit([&disc_sorted, &D, &outs]() { disc_sorted = D; std::vector<Out>().swap(outs); });
+    else disc_sorted = D;
+    if (laps) std::fprintf(stderr, "[clusters] %zu discordant blocks, %zu clip positions\n", D.size(), S.part.size());
 
     // ---- static cluster table; everything stream-sized comes from the GPU
-    S.build_clusters(c->read_len);
+    S.build_clusters(c->read_len, c->pool.get());
     lap("clusters built");
+    if (copy_made.valid()) copy_made.get();
+    D.push_back(Blk{0, 0, 0, 0, 0, false, false});  // ledger B21 sentinel
+    lap("copy for the edge stage");
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
 }
 // pass 1 over the records (k_pass1; the cluster table is uploaded here).  A sharded run calls this before it knows the running pair

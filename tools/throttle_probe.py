@@ -17,8 +17,14 @@ def stat():
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 staged = "--staged" in sys.argv
+if "--keep" in sys.argv:
+    squid_amd.keep_host_memory()
 wl = args[0] if args else "C3"
 pre = {"C3": "/tmp/squid_bench/C3_s20180003", "C5": "/tmp/squid_bench/C5_s20180005"}[wl]
+if not os.path.exists(pre + ".bam"):  # (a fresh box: make the sample the way bench.py does)
+    import subprocess
+    os.makedirs(os.path.dirname(pre), exist_ok=True)
+    subprocess.check_call([str(ROOT / "build" / "gen_synth_bam"), "--config", wl, "--seed", pre.rsplit("_s", 1)[1], "--out", pre, "--threads", "128"], stdout=subprocess.DEVNULL)
 kw = dict(min_edge_weight=1, max_allowed_degree=50) if wl == "C5" else {}
 print("cpu.max:", open("/sys/fs/cgroup/cpu.max").read().strip())
 with squid_amd.Context(**kw) as ctx:
