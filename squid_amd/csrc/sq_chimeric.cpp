@@ -281,7 +281,7 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
         // (the room for the output -- one default-constructed Frag per kept fragment, a third of a gigabyte on the dense config and one
         // thread's work -- is made while the other threads settle who goes where)
         std::future<void> room;
-        if (pool && total > 100000) room = pool->submit([&out, total]() { out.resize(total); }); else out.resize(total);
+        if (pool && total > 100000) room = std::async(std::launch::async, [&out, total]() { out.resize(total); }); else out.resize(total);
         auto place = [&](int k) {
             size_t o = at[(size_t)k];
             for (size_t p = piece_of(k).first; p < piece_of(k).second; ++p) if (keep_at[p]) {

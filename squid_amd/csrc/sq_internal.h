@@ -130,15 +130,29 @@ public:
         cv.notify_one();
         return fut;
     }
+    // The caller takes part and returns when every index has been worked on -- NOT when every helper task has had its turn: a helper that
+    // is still queued when the work is done finds nothing to do whenever it runs (it shares the loop state, never `f`).  So a loop started
+    // from a pooled task cannot starve, even on a pool of one thread that is the caller itself (round 5 waited for the helpers' futures:
+    // with eight ranks sharing the box's 16 CPUs a context has ONE helper thread, and the cluster table, a task of that thread, waited
+    // for a helper that only that thread could have run).
     void parallel_for(int count, int max_helpers, const std::function<void(int)>& f) {
         if (count <= 0) return;
-        auto next = std::make_shared<std::atomic<int>>(0);
-        auto body = [next, count, &f]() { for (int i; (i = next->fetch_add(1)) < count;) f(i); };
-        std::vector<std::future<void>> helpers;
+        struct Loop { std::atomic<int> next{0}, done{0}; std::mutex m; std::condition_variable cv; };
+        auto st = std::make_shared<Loop>();
+        const std::function<void(int)>* fp = &f;
+        auto body = [st, count, fp]() {
+            int mine = 0;
+            for (int i; (i = st->next.fetch_add(1)) < count;) { (*fp)(i); ++mine; }
+            if (mine && st->done.fetch_add(mine) + mine == count) { std::lock_guard<std::mutex> lk(st->m); st->cv.notify_all(); }
+        };
         const int nh = std::min(std::min(count - 1, max_helpers), size());
-        for (int h = 0; h < nh; ++h) helpers.push_back(submit(body));
+        if (nh > 0) {
+            { std::lock_guard<std::mutex> lk(mu); for (int h = 0; h < nh; ++h) q.emplace_back(body); }
+            cv.notify_all();
+        }
         body();
-        for (auto& h : helpers) h.get();
+        std::unique_lock<std::mutex> lk(st->m);
+        st->cv.wait(lk, [&]() { return st->done.load() == count; });
     }
 };
 

@@ -526,7 +526,7 @@ double segment_clusters(const sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::ve
         // the room for the sorted list is made (230 MB of zeroes on the dense config, one thread's work) while the keys are being sorted
         std::future<void> room;
         std::vector<Blk> sorted;
-        if (c->pool && nD > 100000) room = c->pool->submit([&sorted, nD]() { sorted.resize(nD); }); else sorted.resize(nD);
+        if (c->pool && nD > 100000) room = std::async(std::launch::async, [&sorted, nD]() { sorted.resize(nD); }); else sorted.resize(nD);  // (a thread of its own: this function may itself be a task of the pool, and a task that waits for another task can starve)
         if (pieces > 1) c->pool->parallel_for(pieces, 1 << 20, [&](int k) { const std::vector<Blk>& P = outs[(size_t)k].D; const size_t at = d_at[(size_t)k]; for (size_t i = 0; i < P.size(); ++i) pk.p[at + i] = PK{P[i].refid, P[i].refpos, (int32_t)(at + i)}; });
         else for (size_t i = 0; i < nD; ++i) pk.p[i] = PK{outs[0].D[i].refid, outs[0].D[i].refpos, (int32_t)i};
         lap("  block keys");
@@ -549,7 +549,7 @@ double segment_clusters(const sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::ve
     S.nd = (int)D.size();
     // the copy the edge stage reads, made next to the cluster table (both only read the sorted list); the pieces are freed on the way
     std::future<void> copy_made;
-    if (c->pool && nD > 100000) copy_made = c->pool->submit([&disc_sorted, &D, &outs]() { disc_sorted = D; std::vector<Out>().swap(outs); });
+    if (c->pool && nD > 100000) copy_made = std::async(std::launch::async, [&disc_sorted, &D, &outs]() { disc_sorted = D; std::vector<Out>().swap(outs); });
     else disc_sorted = D;
     if (laps) std::fprintf(stderr, "[clusters] %zu discordant blocks, %zu clip positions\n", D.size(), S.part.size());
 

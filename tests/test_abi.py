@@ -84,3 +84,17 @@ def test_the_host_program_asks_for_eight_hardware_queues_not_the_library(built):
     assert run(f"import ctypes, sys; sys.path.insert(0, {root!r}); import squid_amd; " + probe, env) == "8"
     assert run(f"import ctypes, sys; sys.path.insert(0, {root!r}); import squid_amd; " + probe, dict(env, GPU_MAX_HW_QUEUES="4")) == "4"
     assert 'setenv("GPU_MAX_HW_QUEUES"' in (squid_amd.ROOT / "squid_amd" / "csrc" / "squid_main.cpp").read_text()
+
+
+def test_host_pool_loops_return_when_started_from_a_task_of_the_pool(tmp_path):
+    """HostPool::parallel_for returns when every index is done, not when every helper task has had its turn: a loop started from a task of
+    a one-thread pool (eight ranks sharing a 16-CPU box: the cluster table runs as such a task) used to wait for a helper only its own
+    thread could have run"""
+    import subprocess
+    from pathlib import Path
+
+    src = Path(__file__).resolve().parent / "pool_check.cpp"
+    exe = tmp_path / "pool_check"
+    subprocess.check_call(["hipcc", "-O2", "-std=c++17", "-I", str(squid_amd.ROOT / "include"), "-o", str(exe), str(src), "-lpthread"], stderr=subprocess.DEVNULL)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout
