@@ -281,6 +281,9 @@ def main() -> None:
             squid_amd.build()
         if dist:
             dist.barrier()
+    # this process runs sample after sample: the C allocator keeps what the host stages free between steps (sq_keep_host_memory; the
+    # cold command line, one sample per process, runs without it)
+    squid_amd.keep_host_memory()
 
     work = Path(a.workdir) if a.workdir else Path(tempfile.gettempdir()) / "squid_bench"
     work.mkdir(parents=True, exist_ok=True)

@@ -518,6 +518,7 @@ double segment_clusters(const sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::ve
     const int sort_threads = c->pool ? std::min(c->pool->size() + 1, 32) : 1;
     std_sort_parallel(S.part.begin(), S.part.end(), std::less<std::pair<int, int>>(), sort_threads);
     lap("clip positions sorted");
+    std::future<void> room2;  // (the room for the copy the edge stage reads: made next to the sort as well)
     {   // ledger B8: operator< looks at (RefID, RefPos) only and the sort is not stable.  Sorting 12-byte (key, index) elements with the
         // same comparison takes libstdc++'s introsort through the same decisions, hence to the same permutation, at a fraction of
         // the memory traffic of sorting the blocks themselves
@@ -526,7 +527,8 @@ double segment_clusters(const sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::ve
         // the room for the sorted list is made (230 MB of zeroes on the dense config, one thread's work) while the keys are being sorted
         std::future<void> room;
         std::vector<Blk> sorted;
-        if (c->pool && nD > 100000) room = std::async(std::launch::async, [&sorted, nD]() { sorted.resize(nD); }); else sorted.resize(nD);  // (a thread of its own: this function may itself be a task of the pool, and a task that waits for another task can starve)
+        if (c->pool && nD > 100000) room2 = std::async(std::launch::async, [&disc_sorted, nD]() { disc_sorted.clear(); disc_sorted.resize(nD); });
+        if (c->pool && nD > 100000) room = std::async(std::launch::async, [&sorted, nD]() { sorted.reserve(nD + 1); sorted.resize(nD); }); else { sorted.reserve(nD + 1); sorted.resize(nD); }  // (+ 1: the sentinel pushed below must not move the list)  // (a thread of its own: this function may itself be a task of the pool, and a task that waits for another task can starve)
         if (pieces > 1) c->pool->parallel_for(pieces, 1 << 20, [&](int k) { const std::vector<Blk>& P = outs[(size_t)k].D; const size_t at = d_at[(size_t)k]; for (size_t i = 0; i < P.size(); ++i) pk.p[at + i] = PK{P[i].refid, P[i].refpos, (int32_t)(at + i)}; });
         else for (size_t i = 0; i < nD; ++i) pk.p[i] = PK{outs[0].D[i].refid, outs[0].D[i].refpos, (int32_t)i};
         lap("  block keys");
@@ -547,18 +549,20 @@ double segment_clusters(const sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::ve
     }
     lap("blocks sorted");
     S.nd = (int)D.size();
-    // the copy the edge stage reads, made next to the cluster table (both only read the sorted list); the pieces are freed on the way
-    std::future<void> copy_made;
-    if (c->pool && nD > 100000) copy_made = std::async(std::launch::async, [&disc_sorted, &D, &outs]() { disc_sorted = D; std::vector<Out>().swap(outs); });
-    else disc_sorted = D;
+    // the copy the edge stage reads; the pieces are freed behind the caller's back (64 unmaps of a few megabytes each)
+    if (room2.valid()) {
+        room2.get();
+        par(nD, [&](size_t lo, size_t hi) { std::copy(D.begin() + (std::ptrdiff_t)lo, D.begin() + (std::ptrdiff_t)hi, disc_sorted.begin() + (std::ptrdiff_t)lo); });
+        auto* junk = new std::vector<Out>(std::move(outs));
+        std::thread([junk]() { delete junk; }).detach();
+    } else disc_sorted = D;
+    lap("copy for the edge stage");
     if (laps) std::fprintf(stderr, "[clusters] %zu discordant blocks, %zu clip positions\n", D.size(), S.part.size());
 
     // ---- static cluster table; everything stream-sized comes from the GPU
     S.build_clusters(c->read_len, c->pool.get());
     lap("clusters built");
-    if (copy_made.valid()) copy_made.get();
     D.push_back(Blk{0, 0, 0, 0, 0, false, false});  // ledger B21 sentinel
-    lap("copy for the edge stage");
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
 }
 // pass 1 over the records (k_pass1; the cluster table is uploaded here).  A sharded run calls this before it knows the running pair
