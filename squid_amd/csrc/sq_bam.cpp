@@ -747,7 +747,21 @@ struct MapCache {
         return m;
     }
 };
-static MapCache g_map_cache;
+// Two files are remembered: a sample is a pair of BAM files, and since round 5 both go through this reader (sq_ingest_files sends the
+// chimeric BAM of a dense sample through the GPU reader too) -- with one slot every read of the one file threw the mapping and the block
+// index of the other away.  A third file takes the slot that was used longest ago.
+static MapCache g_map_slots[2];
+static std::mutex g_map_pick_mu;
+static unsigned long g_map_tick = 0, g_map_used[2] = {0, 0};
+static MapCache& map_cache_for(const char* pth) {
+    std::lock_guard<std::mutex> lk(g_map_pick_mu);
+    int k = -1;
+    for (int i = 0; i < 2; ++i) { std::lock_guard<std::mutex> l2(g_map_slots[i].mu); if (g_map_slots[i].map && g_map_slots[i].path == pth) k = i; }
+    if (k < 0) for (int i = 0; i < 2; ++i) { std::lock_guard<std::mutex> l2(g_map_slots[i].mu); if (!g_map_slots[i].map) { k = i; break; } }
+    if (k < 0) k = g_map_used[0] <= g_map_used[1] ? 0 : 1;
+    g_map_used[k] = ++g_map_tick;
+    return g_map_slots[k];
+}
 // `count` jobs on the calling thread + helpers; the helpers live as long as the pool (no spawn per chunk)
 struct Pool {
     std::vector<std::thread> th;
@@ -1020,8 +1034,10 @@ int find_records(const uint8_t* u, size_t begin, size_t limit, int nref, Pool& p
 }  // namespace
 // forget the mapping and block index of the last file read (sq_drop_file_cache): the next read maps and indexes its file again
 void drop_file_cache() {
-    std::lock_guard<std::mutex> lk(g_map_cache.mu);
-    g_map_cache.index.reset(); g_map_cache.index_total = 0; g_map_cache.map.reset(); g_map_cache.path.clear();
+    for (MapCache& mc : g_map_slots) {
+        std::lock_guard<std::mutex> lk(mc.mu);
+        mc.index.reset(); mc.index_total = 0; mc.map.reset(); mc.path.clear();
+    }
 }
 
 // CPUs this process can really use: the affinity mask, cut by the cgroup's CPU quota (a container may see 256 logical
@@ -1069,6 +1085,7 @@ int scan_bam_file(const char* path, int n_threads, std::string& err, const RawSi
     bool use_bai = only && try_gpu && allow_bai && !no_bai_env && bai.load(path, -1);
     const bool lazy = try_gpu && (!only || use_bai);
     bool map_reused = false;
+    MapCache& g_map_cache = map_cache_for(path);
     std::shared_ptr<FileMap> fm_hold = g_map_cache.acquire(path, !lazy, map_reused);
     if (!fm_hold) { err = std::string("cannot open bamfile ") + path; return SQ_E_IO; }
     struct { const uint8_t* p; size_t n; } fm{fm_hold->p, fm_hold->n};

@@ -662,7 +662,7 @@ static int call_sv(sq_ctx* c) {
         BPs.resize(2 * v.ebp.size());
         par(v.ebp.size(), [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) { BPs[2 * k] = v.ebp[k].first; BPs[2 * k + 1] = v.ebp[k].second; } });
         // (equal elements are indistinguishable pairs: any sort gives the reference's sorted list; the threaded introsort of sq_parsort.h)
-        std_sort_parallel(BPs.begin(), BPs.end(), std::less<std::pair<int, int>>(), c->pool ? std::min(c->pool->size() + 1, 32) : 1);
+        std_sort_parallel(BPs.begin(), BPs.end(), std::less<std::pair<int, int>>(), c->pool ? std::min(c->pool->size() + 1, 32) : 1, true);
         static const bool bp_host = getenv("SQUID_BP_HOST") != nullptr;  // debug cross-check of k_bp_walk
         if (c->bwa) {  // (--bwa: the records and their names are on the host)
             rc = bwa_breakpoint_support(c, BPs, cov);

@@ -151,7 +151,7 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
         // equal first 16 bytes (zero padded; a name holds no NUL): two names of at most 16 bytes are then the same name
         if (x.len <= 16 && y.len <= 16) return false;
         return name_cmp(x.idx, y.idx) < 0;
-    }, sort_threads);
+    }, sort_threads, true);  // (`name < name` is a strict weak order: the final insertion pass is split as well; FrontSmallerThan below is not one)
     lap("name sort");
     // merge equal names (ReadRec.cpp:356-373): runs of equal names in the sorted order; the runs are independent of each other
     std::vector<int64_t> run_start;

@@ -516,7 +516,7 @@ double segment_clusters(const sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::ve
     }
     lap("pieces strung");
     const int sort_threads = c->pool ? std::min(c->pool->size() + 1, 32) : 1;
-    std_sort_parallel(S.part.begin(), S.part.end(), std::less<std::pair<int, int>>(), sort_threads);
+    std_sort_parallel(S.part.begin(), S.part.end(), std::less<std::pair<int, int>>(), sort_threads, true);
     lap("clip positions sorted");
     std::future<void> room2;  // (the room for the copy the edge stage reads: made next to the sort as well)
     {   // ledger B8: operator< looks at (RefID, RefPos) only and the sort is not stable.  Sorting 12-byte (key, index) elements with the
@@ -533,7 +533,7 @@ double segment_clusters(const sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::ve
         else for (size_t i = 0; i < nD; ++i) pk.p[i] = PK{outs[0].D[i].refid, outs[0].D[i].refpos, (int32_t)i};
         lap("  block keys");
         // (std_sort_parallel, sq_parsort.h: the same introsort with its independent sub-ranges on several threads)
-        std_sort_parallel(pk.p, pk.p + nD, [](const PK& x, const PK& y) { return x.refid != y.refid ? x.refid < y.refid : x.refpos < y.refpos; }, sort_threads);
+        std_sort_parallel(pk.p, pk.p + nD, [](const PK& x, const PK& y) { return x.refid != y.refid ? x.refid < y.refid : x.refpos < y.refpos; }, sort_threads, true);  // (a strict weak order: the final insertion pass is split too)
         lap("  block keys sorted");
         if (room.valid()) room.get();
         lap("  room for the sorted blocks");

@@ -24,6 +24,17 @@ int main() {
         bool same = true;
         for (size_t i = 0; i < n; ++i) if (a[i].id != b[i].id) { same = false; break; }
         if (!same) { std::printf("trial %d differs\n", trial); return 1; }
+        {   // a strict weak order: the final insertion pass split at the cuts of the loop
+            std::vector<E> c2(n);
+            { std::mt19937 r2(trial); for (size_t i = 0; i < n; ++i) c2[i] = E{(int)(r2() % range), (int)i, {0, 0}}; }
+            if (trial == 4) std::sort(c2.begin(), c2.end(), [](const E& x, const E& y) { return x.key < y.key; });
+            if (trial == 5) for (size_t i = 0; i < n; ++i) c2[i].key = (int)(n - i) / 3;
+            auto t3 = std::chrono::steady_clock::now();
+            sq::std_sort_parallel(c2.begin(), c2.end(), cmp, 8, true);
+            auto t4 = std::chrono::steady_clock::now();
+            for (size_t i = 0; i < n; ++i) if (a[i].id != c2[i].id) { std::printf("trial %d differs with the split final pass at %zu\n", trial, i); return 1; }
+            std::printf("        split final pass %.3f s\n", std::chrono::duration<double>(t4 - t3).count());
+        }
         std::printf("trial %d n %zu same %d  std %.3f s par %.3f s\n", trial, n, (int)same, std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(t2 - t1).count());
     }
     {   // a comparator without transitivity of equivalence: elements compare by `key` only when both are "typed" the same way
