@@ -153,6 +153,20 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
         return name_cmp(x.idx, y.idx) < 0;
     }, sort_threads, true);  // (`name < name` is a strict weak order: the final insertion pass is split as well; FrontSmallerThan below is not one)
     lap("name sort");
+    // what the merge below reads of a record and of its blocks, packed: the runs visit the records in NAME order -- random order in the
+    // batch -- and nine arrays cost nine cache misses per record where two packed ones cost two
+    struct PRec { int32_t refid; uint32_t b0, nb; uint16_t flag, tot; uint8_t low; };
+    struct PBlk { int32_t refpos, matchref; uint16_t readpos, matchread; };
+    Raw<PRec> prec(nr);
+    const size_t nblk_all = b->n_rec ? (size_t)b->blk_off[b->n_rec] : 0;
+    Raw<PBlk> pblk(nblk_all);
+    par((int64_t)nr, [&](int64_t lo, int64_t hi) {
+        for (int64_t k = lo; k < hi; ++k) {
+            const int64_t i = usable[(size_t)k];
+            prec[(size_t)k] = PRec{b->refid[i], b->blk_off[i], b->blk_off[i + 1] - b->blk_off[i], b->flag[i], b->totlen[i], (uint8_t)((b->aux[i] & SQ_AUX_LOWPHRED) ? 1 : 0)};
+        }
+    });
+    par((int64_t)nblk_all, [&](int64_t lo, int64_t hi) { for (int64_t q = lo; q < hi; ++q) pblk[(size_t)q] = PBlk{b->b_refpos[q], b->b_matchref[q], b->b_readpos[q], b->b_matchread[q]}; });
     // merge equal names (ReadRec.cpp:356-373): runs of equal names in the sorted order; the runs are independent of each other
     std::vector<int64_t> run_start;
     {
@@ -182,21 +196,23 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
             // the reference merges the records of a run into the first one, in the sorted order: blocks are appended mate by mate, and a
             // mate's total length / low-quality flag come from the first record (whatever they are) unless its length is 0 and a later
             // record brings one
+            if ((size_t)j + 8 < nm) __builtin_prefetch(&prec[(size_t)nk[(size_t)run_start[(size_t)j + 8]].idx]);  // (the records of the runs ahead: random places)
+            if ((size_t)j + 3 < nm) __builtin_prefetch(&pblk[prec[(size_t)nk[(size_t)run_start[(size_t)j + 3]].idx].b0]);
             Frag& m = *new (&merged[(size_t)j]) Frag();
             store.made[(size_t)j] = 1;
             const size_t k0 = (size_t)run_start[(size_t)j], k1 = (size_t)run_start[(size_t)j + 1];
             m.name.assign(name_ptr((size_t)nk[k0].idx), nlen[(size_t)nk[k0].idx]);
             size_t na = 0, nb = 0;
-            for (size_t k = k0; k < k1; ++k) { const int64_t i = usable[(size_t)nk[k].idx]; ((b->flag[i] & 0x40) ? na : nb) += b->blk_off[i + 1] - b->blk_off[i]; }
+            for (size_t k = k0; k < k1; ++k) { const PRec& r = prec[(size_t)nk[k].idx]; ((r.flag & 0x40) ? na : nb) += r.nb; }
             m.a.reserve(na); m.b.reserve(nb);
             for (size_t k = k0; k < k1; ++k) {
-                const int64_t i = usable[(size_t)nk[k].idx];
-                const int flag = b->flag[i];
-                const bool first = flag & 0x40, rev = flag & 0x10, low = b->aux[i] & SQ_AUX_LOWPHRED;
-                const int tot = b->totlen[i];
+                const PRec& r = prec[(size_t)nk[k].idx];
+                const int flag = r.flag;
+                const bool first = flag & 0x40, rev = flag & 0x10, low = r.low != 0;
+                const int tot = r.tot;
                 std::vector<Blk>& dst = first ? m.a : m.b;
-                for (uint32_t q = b->blk_off[i]; q < b->blk_off[i + 1]; ++q)
-                    dst.push_back(Blk{b->refid[i], b->b_refpos[q], (int32_t)b->b_readpos[q], b->b_matchref[q], (int32_t)b->b_matchread[q], rev, first});
+                for (uint32_t q = r.b0; q < r.b0 + r.nb; ++q)
+                    dst.push_back(Blk{r.refid, pblk[q].refpos, (int32_t)pblk[q].readpos, pblk[q].matchref, (int32_t)pblk[q].matchread, rev, first});
                 if (k == k0) { if (first) { m.atot = tot; m.alow = low; } else { m.btot = tot; m.blow = low; } }
                 else if (first) { if (m.atot == 0 && tot != 0) { m.atot = tot; m.alow = low; } }
                 else if (m.btot == 0 && tot != 0) { m.btot = tot; m.blow = low; }

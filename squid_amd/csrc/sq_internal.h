@@ -211,6 +211,7 @@ struct sq_ctx {
     // SQUID_REPLAY_CHECK: every break candidate the segmentation replay tests (SegmentGraph.cpp:440-481) is counted a second time with the
     // reference's linear passes over the same windows and compared with the binary-search / span-index counts the replay uses
     mutable std::atomic<long long> replay_checked{0}, replay_mismatch{0};
+    std::atomic<bool> chim_pairing_running{false};  // sq_ingest_files: BuildChimericSBamRecord of a large chimeric BAM is busy on the host threads (the file feeder takes fewer readers)
     bool capture_names = false;  // the records being parsed by K0 are the chimeric BAM's: no name-set lookups, their QNAMEs are kept on the device (dev_download_names)
     bool ablated = false;  // a timing-only switch (SQUID_P1_ABLATE / SQUID_EDGES_ABLATE) cut a kernel short: sq_build_graph refuses to return a graph
     bool depth_bounds = false;      // node depths are canonical values with [depth_lo, depth_hi] bounds
