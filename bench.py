@@ -164,6 +164,7 @@ def dense_record(work: Path, local_rank: int, note, steps: int = 3, records: int
     bam, chim = f"{pre}.bam", f"{pre}.chim.bam"
     host_threads = max(1, os.cpu_count() or 8)
     ctx = squid_amd.Context(device=local_rank, **DENSE)
+    ctx.keep_stage_graphs(False)  # (inspection copies of the intermediate graphs: nobody reads them here, like in `build/squid`)
     sizes = None
 
     def step() -> str:
@@ -321,9 +322,12 @@ def main() -> None:
             from squid_amd.dist import install_native_exchange
 
             c2 = squid_amd.Context(device=local_rank, rank=rank, world_size=world, **params)
+            c2.keep_stage_graphs(False)  # (inspection copies of the intermediate graphs: nobody reads them here, like in `build/squid`)
             install_native_exchange(c2, dist, dist.get_backend())  # sq_exchange: RCCL inside the library (nccl), or a gloo all-gather as its transport
             return c2
-        return squid_amd.Context(device=local_rank, **params)
+        c2 = squid_amd.Context(device=local_rank, **params)
+        c2.keep_stage_graphs(False)
+        return c2
 
     def close_context(c2):
         if sharded:

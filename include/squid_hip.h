@@ -157,6 +157,10 @@ typedef struct sq_graph {
  *        1 = after BuildNode_STAR, 2 = after BuildEdges, 3 = after FilterbyWeight, 4 = after FilterEdges,
  *        5 = after CompressNode  (intermediate snapshots are kept for the parity tests) */
 int sq_graph_view(sq_ctx* c, int32_t stage, sq_graph* g);
+/* on = 0: sq_build_graph no longer keeps the flat copies of the INTERMEDIATE graphs (stages 1-5 above; five copies of up to millions of
+ * nodes and edges on a dense sample, made for inspection and the parity tests -- the result does not need them); sq_graph_view then only
+ * answers for stage 0.  Default: kept.  `build/squid` and bench.py switch them off. */
+int sq_keep_stage_graphs(sq_ctx* c, int32_t on);
 
 /* vector<vector<int>> Ordering() -- src/SegmentGraph.cpp:3236-3262: CSR of signed 1-based node ids */
 typedef struct sq_orders {

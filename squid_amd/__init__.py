@@ -24,7 +24,7 @@ EXPORTS = [
     "sq_ingest_concordant_file", "sq_build_graph", "sq_graph_view", "sq_order", "sq_call_sv", "sq_breakpoints",
     "sq_set_shard", "sq_exchange_pack", "sq_exchange_unpack", "sq_get_timing", "sq_timing_accumulate", "sq_reset", "sq_ingest_files", "sq_stage_bam", "sq_clear_records", "sq_set_source", "sq_save_records", "sq_load_records", "sq_get_counts", "sq_debug_download", "sq_debug_bp_support", "sq_debug_order", "sq_debug_blocks", "sq_drop_file_cache",
     "sq_total_order", "sq_set_allgather", "sq_rccl_unique_id", "sq_rccl_init", "sq_rccl_attach", "sq_exchange", "sq_exchange_stats",
-    "sq_rccl_available", "sq_rccl_release", "sq_debug_rccl_selftest", "sq_ingest_bwa_file", "sq_junction_sequences", "sq_release_reader_buffers", "sq_keep_host_memory",
+    "sq_rccl_available", "sq_rccl_release", "sq_debug_rccl_selftest", "sq_ingest_bwa_file", "sq_junction_sequences", "sq_release_reader_buffers", "sq_keep_host_memory", "sq_keep_stage_graphs",
 ]
 
 
@@ -106,6 +106,7 @@ def load_library() -> C.CDLL:
         lib.sq_ingest_concordant_file.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
         lib.sq_ingest_files.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int32]
         lib.sq_stage_bam.argtypes = [C.c_void_p, C.c_char_p]
+        lib.sq_keep_stage_graphs.argtypes = [C.c_void_p, C.c_int32]
         lib.sq_clear_records.argtypes = [C.c_void_p]
         lib.sq_release_reader_buffers.argtypes = [C.c_void_p]
         lib.sq_set_source.argtypes = [C.c_void_p, C.c_char_p]
@@ -222,6 +223,10 @@ class Context:
     def clear_records(self):
         """drop the resident concordant records and all results, keep the device buffers (sq_clear_records)"""
         self._chk(self.lib.sq_clear_records(self.h), "sq_clear_records")
+
+    def keep_stage_graphs(self, on: bool = True):
+        """sq_keep_stage_graphs: keep (default) or skip the copies of the intermediate graphs that graph(1..5) hands out"""
+        self._chk(self.lib.sq_keep_stage_graphs(self.h, 1 if on else 0), "sq_keep_stage_graphs")
 
     def release_reader_buffers(self):
         """give back the device / page-locked memory the GPU reader keeps between ingests (sq_release_reader_buffers)"""

@@ -148,7 +148,7 @@ static int finish_graph(sq_ctx* c, bool host_filters) {
         HostClock hc(c, host_filters ? "host_compress" : "wall_compress");
         rc = host_filters ? compress_nodes(c) : dev_compress_nodes(c);
         if (rc) return rc;
-        c->snap[5].take(c->nodes, c->edges, nullptr);
+        if (c->keep_stages) c->snap[5].take(c->nodes, c->edges, nullptr);
         rc = host_filters ? further_compress(c) : dev_further_compress(c);
         if (rc == 2) rc = further_compress(c);  // a node with more discordant edges than the kernel's lists hold
         if (rc) return rc;
@@ -185,16 +185,16 @@ static int build_graph_bwa(sq_ctx* c) {
     c->edges.clear();
     { HostClock hc(c, "host_edge_reduce"); reduce_edges(raw, c->edges); }
     c->counts.n_unique_edges = (int64_t)c->edges.size();
-    c->snap[2].take(c->nodes, c->edges, nullptr);
+    if (c->keep_stages) c->snap[2].take(c->nodes, c->edges, nullptr);
     static const bool host_filters = std::getenv("SQUID_HOST_FILTERS") != nullptr;
     {
         HostClock hc(c, host_filters ? "host_filters" : "wall_filters");
         std::vector<uint8_t> keep;
         if (host_filters) filter_by_weight(c); else if ((rc = dev_filter_by_weight(c))) return rc;
-        c->snap[3].take(c->nodes, c->edges, nullptr);
+        if (c->keep_stages) c->snap[3].take(c->nodes, c->edges, nullptr);
         if (host_filters) filter_by_interleaving(c, keep); else if ((rc = dev_filter_by_interleaving(c, keep))) return rc;
         if (host_filters) filter_edges(c, keep); else if ((rc = dev_filter_edges(c, keep))) return rc;
-        c->snap[4].take(c->nodes, c->edges, nullptr);
+        if (c->keep_stages) c->snap[4].take(c->nodes, c->edges, nullptr);
     }
     return finish_graph(c, host_filters);
 }
@@ -522,13 +522,13 @@ static int build_graph(sq_ctx* c) {
     } else set_depths(ocnt, osum, g.tiny_boundary);
     static const bool host_filters = std::getenv("SQUID_HOST_FILTERS") != nullptr;
     if (!resumed) {
-        c->snap[1].take(c->nodes, c->edges, nullptr);
+        if (c->keep_stages) c->snap[1].take(c->nodes, c->edges, nullptr);
         {
             HostClock hc(c, "host_edge_reduce");
             g.raw.insert(g.raw.end(), g.conc.begin(), g.conc.end());
-            reduce_edges(g.raw, c->edges);
+            reduce_edges(g.raw, c->edges, c->pool ? std::min(c->pool->size() + 1, 32) : 1);
         }
-        c->snap[2].take(c->nodes, c->edges, nullptr);
+        if (c->keep_stages) c->snap[2].take(c->nodes, c->edges, nullptr);
     }
     // K6 / K7 run on the device (sq_graph_kernels.inc); SQUID_HOST_FILTERS=1 takes the host restatements of sq_graph.cpp instead
     // (kept as a cross-check: tests compare the two stage by stage)
@@ -536,7 +536,7 @@ static int build_graph(sq_ctx* c) {
         HostClock hc(c, host_filters ? "host_filters" : "wall_filters");
         if (!resumed) {
             if (host_filters) filter_by_weight(c); else if ((rc = dev_filter_by_weight(c))) return rc;
-            c->snap[3].take(c->nodes, c->edges, nullptr);
+            if (c->keep_stages) c->snap[3].take(c->nodes, c->edges, nullptr);
             if (host_filters) filter_by_interleaving(c, g.keep); else if ((rc = dev_filter_by_interleaving(c, g.keep))) return rc;
             g.before = c->edges;
             if (host_filters) filter_edges(c, g.keep); else if ((rc = dev_filter_edges(c, g.keep))) return rc;
@@ -581,7 +581,7 @@ static int build_graph(sq_ctx* c) {
             c->edges = g.before;
             if (host_filters) filter_edges(c, g.keep); else if ((rc = dev_filter_edges(c, g.keep))) return rc;
         }
-        c->snap[4].take(c->nodes, c->edges, nullptr);
+        if (c->keep_stages) c->snap[4].take(c->nodes, c->edges, nullptr);
     }
     return finish_graph(c, host_filters);
 }
@@ -1318,6 +1318,7 @@ int sq_build_graph(sq_ctx* c) {
 }
 int sq_graph_view(sq_ctx* c, int32_t stage, sq_graph* g) {
     if (!c || !g || stage < 0 || stage > 5 || !c->graph_built) return SQ_E_ARG;
+    if (stage != 0 && !c->keep_stages) return fail(c, SQ_E_ARG, "the intermediate graphs were not kept (sq_keep_stage_graphs(ctx, 0) before sq_build_graph)");
     c->snap[stage].view(g);
     return SQ_OK;
 }
@@ -1369,6 +1370,11 @@ int sq_release_reader_buffers(sq_ctx* c) {
     drop_whole_file_scratch();
     if (!c->chim_future.valid()) c->chim_decoded.reset();  // (a pairing still running reads it)
     return dev_release_reader(c);
+}
+int sq_keep_stage_graphs(sq_ctx* c, int32_t on) {
+    if (!c) return SQ_E_ARG;
+    c->keep_stages = on != 0;
+    return SQ_OK;
 }
 int sq_keep_host_memory(void) {
     // (mallopt takes ints: the thresholds stop at 2 GiB - 1; thread arenas -- where the context's host threads allocate -- are kept

@@ -8,6 +8,7 @@
 #include <limits>
 
 #include "sq_internal.h"
+#include "sq_parsort.h"
 
 namespace sq {
 
@@ -197,13 +198,19 @@ int chimeric_edges(sq_ctx* c, std::vector<Edge>& raw) {
     };
     if (np > 1 && c->pool) c->pool->parallel_for(np, 1 << 20, [&](int pi) { run(pi); }); else for (int pi = 0; pi < np; ++pi) run(pi);
     std::vector<uint64_t> disc;
-    for (Piece& P : out) {
-        if (P.bad) return fail(c, SQ_E_ASSERT, "chimeric block outside the node table (reference: out-of-range edge, SegmentGraph.cpp:1410)");
-        raw.insert(raw.end(), P.raw.begin(), P.raw.end());
-        disc.insert(disc.end(), P.disc.begin(), P.disc.end());
+    {   // the pieces strung together in order, side by side (millions of entries on a dense sample)
+        std::vector<size_t> r_at((size_t)np + 1, raw.size()), d_at((size_t)np + 1, 0);
+        for (int pi = 0; pi < np; ++pi) {
+            if (out[(size_t)pi].bad) return fail(c, SQ_E_ASSERT, "chimeric block outside the node table (reference: out-of-range edge, SegmentGraph.cpp:1410)");
+            r_at[(size_t)pi + 1] = r_at[(size_t)pi] + out[(size_t)pi].raw.size(); d_at[(size_t)pi + 1] = d_at[(size_t)pi] + out[(size_t)pi].disc.size();
+        }
+        raw.resize(r_at.back()); disc.resize(d_at.back());
+        auto put = [&](int pi) { std::copy(out[(size_t)pi].raw.begin(), out[(size_t)pi].raw.end(), raw.begin() + (std::ptrdiff_t)r_at[(size_t)pi]); std::copy(out[(size_t)pi].disc.begin(), out[(size_t)pi].disc.end(), disc.begin() + (std::ptrdiff_t)d_at[(size_t)pi]); };
+        if (np > 1 && c->pool) c->pool->parallel_for(np, 1 << 20, put); else for (int pi = 0; pi < np; ++pi) put(pi);
     }
     // discordant edges: one raw edge per key, Weight = number of supporting junctions (:1551); the later sort makes the order irrelevant
-    std::sort(disc.begin(), disc.end());
+    // (equal keys are equal values: any sorting order is THE sorted order -- the threaded introsort, final pass split)
+    std_sort_parallel(disc.begin(), disc.end(), std::less<uint64_t>(), c->pool ? std::min(c->pool->size() + 1, 32) : 1, true);
     for (size_t i = 0; i < disc.size();) {
         size_t j = i;
         while (j < disc.size() && disc[j] == disc[i]) ++j;
@@ -216,8 +223,9 @@ int chimeric_edges(sq_ctx* c, std::vector<Edge>& raw) {
 }
 
 // sort + sum equal keys + drop non-positive (:1943-1957)
-void reduce_edges(std::vector<Edge>& raw, std::vector<Edge>& out) {
-    std::sort(raw.begin(), raw.end(), edge_key_less);
+void reduce_edges(std::vector<Edge>& raw, std::vector<Edge>& out, int threads) {
+    // (the key is a total order and edges of one key differ in Weight only, which is summed: the tie order cannot be seen)
+    std_sort_parallel(raw.begin(), raw.end(), edge_key_less, threads, true);
     out.clear();
     for (const Edge& e : raw) {
         if (out.empty() || !edge_key_eq(e, out.back())) out.push_back(e);

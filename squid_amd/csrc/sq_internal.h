@@ -212,6 +212,7 @@ struct sq_ctx {
     // reference's linear passes over the same windows and compared with the binary-search / span-index counts the replay uses
     mutable std::atomic<long long> replay_checked{0}, replay_mismatch{0};
     std::atomic<bool> chim_pairing_running{false};  // sq_ingest_files: BuildChimericSBamRecord of a large chimeric BAM is busy on the host threads (the file feeder takes fewer readers)
+    bool keep_stages = true;  // sq_keep_stage_graphs: flat copies of the graph after BuildNode / BuildEdges / the filters / CompressNode for sq_graph_view (inspection; the result does not need them)
     bool capture_names = false;  // the records being parsed by K0 are the chimeric BAM's: no name-set lookups, their QNAMEs are kept on the device (dev_download_names)
     bool ablated = false;  // a timing-only switch (SQUID_P1_ABLATE / SQUID_EDGES_ABLATE) cut a kernel short: sq_build_graph refuses to return a graph
     bool depth_bounds = false;      // node depths are canonical values with [depth_lo, depth_hi] bounds
@@ -355,7 +356,7 @@ int junction_sequences(sq_ctx* c, const std::vector<std::string>& ref_names, con
 // ---- sq_bwa.cpp (`squid --bwa`)
 int bwa_nodes_and_edges(sq_ctx* c, std::vector<Edge>& raw);  // BuildNode_BWA + RawEdges over the host batch: c->nodes (+ snapshot 1), c->frags, raw edges
 int bwa_breakpoint_support(sq_ctx* c, const std::vector<std::pair<int, int>>& bps, std::vector<int32_t>& cov);
-void reduce_edges(std::vector<Edge>& raw, std::vector<Edge>& out);
+void reduce_edges(std::vector<Edge>& raw, std::vector<Edge>& out, int threads = 1);
 void filter_by_weight(sq_ctx* c);
 void filter_by_interleaving(sq_ctx* c, std::vector<uint8_t>& keep);
 void filter_edges(sq_ctx* c, const std::vector<uint8_t>& keep);

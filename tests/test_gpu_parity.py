@@ -1470,3 +1470,24 @@ def test_filtered_record_that_trips_the_assert_halfway_leaves_its_neighbours_blo
     for k in got["host"]:
         assert np.array_equal(got["device"][k], got["host"][k]), k
     assert len(got["host"]["refid"]) == len(recs)
+
+
+def test_without_the_inspection_copies_of_the_intermediate_graphs(built, synth, tmp_path):
+    """sq_keep_stage_graphs(ctx, 0) -- what `build/squid` and bench.py run with: the final graph, the orders and _sv.txt are what they are
+    with the copies; sq_graph_view refuses the stages it no longer has"""
+    pre = synth("C2")
+    sv_path, _ = ou.run_oracle(built, pre, tmp_path)
+    got = {}
+    for keep in (True, False):
+        with squid_amd.Context() as ctx:
+            ctx.keep_stage_graphs(keep)
+            ctx.load(f"{pre}.bam", f"{pre}.chim.bam")
+            ctx.build_graph()
+            got[keep] = (ctx.graph(0), ctx.order(), ctx.sv_text())
+            if keep:
+                assert ctx.graph(2)["edges"]
+            else:
+                with pytest.raises(squid_amd.SquidError, match="not kept"):
+                    ctx.graph(2)
+    assert got[True] == got[False]
+    assert got[False][2] == sv_path.read_text()

@@ -28,6 +28,7 @@ if not os.path.exists(pre + ".bam"):  # (a fresh box: make the sample the way be
 kw = dict(min_edge_weight=1, max_allowed_degree=50) if wl == "C5" else {}
 print("cpu.max:", open("/sys/fs/cgroup/cpu.max").read().strip())
 with squid_amd.Context(**kw) as ctx:
+    ctx.keep_stage_graphs(False)
     if staged:
         ctx.stage_bam(f"{pre}.bam")
     for it in range(5):
