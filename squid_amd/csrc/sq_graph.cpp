@@ -671,12 +671,22 @@ int exact_breakpoints(sq_ctx* c, BPMap& bp) {
     };
     if (np > 1 && c->pool) c->pool->parallel_for(np, 1 << 20, [&](int pi) { run(pi); }); else for (int pi = 0; pi < np; ++pi) run(pi);
     std::vector<Hit> all;
-    for (auto& H : out) all.insert(all.end(), H.begin(), H.end());
-    std::sort(all.begin(), all.end(), [](const Hit& x, const Hit& y) { return x.key != y.key ? x.key < y.key : (x.b1 != y.b1 ? x.b1 < y.b1 : x.b2 < y.b2); });  // (count_top sorts the pairs anyway)
+    {
+        std::vector<size_t> at((size_t)np + 1, 0);
+        for (int pi = 0; pi < np; ++pi) at[(size_t)pi + 1] = at[(size_t)pi] + out[(size_t)pi].size();
+        all.resize(at.back());
+        auto put = [&](int pi) { std::copy(out[(size_t)pi].begin(), out[(size_t)pi].end(), all.begin() + (std::ptrdiff_t)at[(size_t)pi]); };
+        if (np > 1 && c->pool) c->pool->parallel_for(np, 1 << 20, put); else for (int pi = 0; pi < np; ++pi) put(pi);
+    }
+    // (count_top sorts the pairs anyway; a total order on all three fields: equal elements are equal values, any sort gives this list)
+    std_sort_parallel(all.begin(), all.end(), [](const Hit& x, const Hit& y) { return x.key != y.key ? x.key < y.key : (x.b1 != y.b1 ? x.b1 < y.b1 : x.b2 < y.b2); },
+                      c->pool ? std::min(c->pool->size() + 1, 32) : 1, true);
     std::vector<size_t> grp;
     for (size_t i = 0; i < all.size(); ++i) if (i == 0 || all[i].key != all[i - 1].key) grp.push_back(i);
     grp.push_back(all.size());
     const int ng = (int)grp.size() - 1;
+    static const bool prof = std::getenv("SQUID_BP_PROF") != nullptr;
+    if (prof) std::fprintf(stderr, "exact_breakpoints: %zu hits in %d groups, %d pieces\n", all.size(), ng, np);
     std::vector<std::vector<std::pair<int, int>>> lists((size_t)ng);
     auto top = [&](int g) {
         std::vector<std::pair<int, int>>& x = lists[(size_t)g];
