@@ -280,7 +280,8 @@ typedef struct sq_counts {
                                  passes, and how many of them disagreed with the counts the library had used (must be 0); else 0, 0 */
     int64_t chimeric_through_gpu_reader; /* sq_ingest_files: 1 when the chimeric BAM of the last call was inflated, cut into records and parsed on the
                                  device like the concordant one (files of 128 MiB and more; SQUID_CHIM_GPU=1 / =0 forces / forbids it), 0 when
-                                 the host decoder read it */
+                                 the host decoder read it.  sq_ingest_bwa_file: the same for the one file of --bwa mode, whose records need their
+                                 QNAMEs too (files of 1 GiB and more; SQUID_BWA_GPU=1 / =0) */
 } sq_counts;
 int sq_get_counts(sq_ctx* c, sq_counts* k);
 

@@ -4,9 +4,10 @@
 //   RawEdges                  src/SegmentGraph.cpp:1698-1930  (for RawEdgesChim + RawEdgesOther; it also REBUILDS Chimrecord from the
 //                                                              partially aligned reads, :1883-1926)
 //   the BAM loops' filters    MapQuality == 0 instead of < Min_MapQual (:871,1723), first mates only (:1723-1726)
-// -- and shares everything from BuildEdges' sort on.  Division of labour here: the records are decoded on host threads WITH their
-// QNAMEs (RawEdges sorts, merges and matches reads by name: the device-side record layout of the STAR path keeps no names), the two
-// order-dependent loops run on the host over that batch, and the graph from the edge reduction on takes the same kernels as the STAR
+// -- and shares everything from BuildEdges' sort on.  Division of labour here: the records are decoded WITH their QNAMEs (RawEdges
+// sorts, merges and matches reads by name) -- by the GPU reader for files of 1 GiB and more (K-1 + K0 with sq_ctx::capture_names: the
+// names kept next to the records on the device and copied back with them, round 5; 0.3-0.6 s for 50.8 M records where sixteen host
+// threads took 3.3-4.5 s), on host threads otherwise --, the two order-dependent loops run on the host over that batch, and the graph from the edge reduction on takes the same kernels as the STAR
 // path (filters, compression, components, ordering).  The breakpoint support (ExactBPConcordantSupport, mode-independent in the
 // reference) is counted on the host, over the same batch.  Not the path BASELINE.json measures; built for drop-in completeness and
 // held to the same parity bar (tests/test_bwa.py).

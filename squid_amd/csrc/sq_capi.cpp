@@ -1007,7 +1007,7 @@ int sq_ingest_chimeric_file(sq_ctx* c, const char* path) {
 // a box gives the process; the device does it in the time it takes to get the file there.  Needs an empty record
 // store (the records pass through it).  Returns 2 when the route is not taken or gave up: the caller runs the host decoder, whose
 // error messages are then the ones the user sees.
-static int chimeric_records_through_the_device(sq_ctx* c, const char* path, int n_threads, HostBatch& hb) {
+static int chimeric_records_through_the_device(sq_ctx* c, const char* path, int n_threads, HostBatch& hb, bool name_table = true) {
     if (!c->dev || c->counts.n_concordant != 0) return 2;
     struct Mode { sq_ctx* c; Mode(sq_ctx* c) : c(c) { c->capture_names = true; } ~Mode() { c->capture_names = false; dev_clear_records(c); c->counts.n_concordant = 0; c->counts.n_blocks = 0; c->ingest_total_bytes = 0; c->ingest_seen_bytes = 0; } } mode(c);
     std::string err;
@@ -1021,7 +1021,7 @@ static int chimeric_records_through_the_device(sq_ctx* c, const char* path, int 
     const auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (prof) std::fprintf(stderr, "chimeric file on the device: %-24s at %8.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); };
     lap("reader returned (since then)");
-    if (rc == SQ_OK) rc = dev_chim_begin_captured(c);
+    if (rc == SQ_OK && name_table) rc = dev_chim_begin_captured(c);
     lap("name table");
     if (rc == SQ_OK) rc = dev_download_records(c, hb);
     if (rc == SQ_OK) rc = dev_download_names(c, hb);
@@ -1123,6 +1123,22 @@ int sq_ingest_bwa_file(sq_ctx* c, const char* path, int32_t n_threads) {
     { int r0 = sq_set_source(c, path); if (r0) return r0; }
     std::shared_ptr<HostBatch> all = std::make_shared<HostBatch>();
     all->blk_off.assign(1, 0); all->name_off.assign(1, 0);
+    {   // a file of 1 GiB and more through the GPU reader (SQUID_BWA_GPU=1 / =0 forces / forbids it): BGZF inflate, record boundaries and the
+        // record parse on the device, the QNAMEs kept next to the records (sq_ctx::capture_names, as for a large chimeric BAM), one copy
+        // back -- the batch the host decoder below makes, field for field; the two order-dependent loops of the mode then run on it
+        struct stat st;
+        const char* env = std::getenv("SQUID_BWA_GPU");
+        const bool want = env ? std::atoi(env) != 0 : (::stat(path, &st) == 0 && (size_t)st.st_size >= ((size_t)1 << 30));
+        if (want && chimeric_records_through_the_device(c, path, n_threads, *all, false) == SQ_OK) {
+            c->bwa = all;
+            c->counts.n_concordant = (int64_t)all->size();
+            c->counts.n_blocks = (int64_t)all->b_refpos.size();
+            c->counts.chimeric_through_gpu_reader = 1;
+            return SQ_OK;
+        }
+        all->clear();
+        c->counts.chimeric_through_gpu_reader = 0;
+    }
     ParseOpts o{c->P.phred_type, c->P.min_phred, c->P.max_lowphred_len, true, nullptr};
     const int rc = parse_bam_file(path, o, (size_t)1 << 21, std::max(1, (int)n_threads), c->err, [&](const HostBatch& hb) {
         if (all->names.size() + hb.names.size() >= 0xffffffffull || all->b_refpos.size() + hb.b_refpos.size() >= 0xffffffffull) return fail(c, SQ_E_CAPACITY, "--bwa input beyond 4 GB of read names or 2^32 aligned blocks");

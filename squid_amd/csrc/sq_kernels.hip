@@ -3855,15 +3855,29 @@ int dev_download_records(sq_ctx* c, HostBatch& hb) {
     const size_t n = (size_t)D.n, nb = (size_t)D.nb;
     // (no clear(): a batch the caller keeps between calls has its pages already -- resize() to the size it had costs nothing)
     hb.names.clear(); hb.name_off.assign(1, 0);
-    hb.refid.resize(n); hb.pos.resize(n); hb.mrefid.resize(n); hb.mpos.resize(n); hb.endpos.resize(n); hb.flag.resize(n); hb.totlen.resize(n); hb.mapq.resize(n); hb.aux.resize(n);
-    hb.blk_off.resize(n + 1); hb.b_refpos.resize(nb); hb.b_matchref.resize(nb); hb.b_readpos.resize(nb); hb.b_matchread.resize(nb);
-    if (n) {
-#define DOWN(dst, src, cnt) HIPCHK(hipMemcpy(hb.dst.data(), D.src.p, (cnt) * sizeof(*D.src.p), hipMemcpyDeviceToHost))
-        DOWN(refid, refid, n); DOWN(pos, pos, n); DOWN(mrefid, mrefid, n); DOWN(mpos, mpos, n); DOWN(endpos, endpos, n); DOWN(flag, flag, n); DOWN(totlen, totlen, n); DOWN(mapq, mapq, n);
-        DOWN(aux, aux, n); DOWN(blk_off, blk_off, n + 1);
-        if (nb) { DOWN(b_refpos, b_refpos, nb); DOWN(b_matchref, b_matchref, nb); DOWN(b_readpos, b_readpos, nb); DOWN(b_matchread, b_matchread, nb); }
-#undef DOWN
-    }
+    // every array on a thread of its own when there is something to copy: the room for an array (resize: zeroes and fresh pages, one
+    // thread's work per array) is most of the time for a --bwa batch of tens of millions of records
+    const int dev = c->P.device;
+    std::vector<std::future<hipError_t>> jobs;
+    const bool side_by_side = n > 1000000;
+    auto down = [&](auto& vec, const auto* src, size_t cnt) {
+        auto job = [&vec, src, cnt, dev]() -> hipError_t {
+            vec.resize(cnt);
+            if (!cnt) return hipSuccess;
+            hipError_t e = hipSetDevice(dev);
+            return e != hipSuccess ? e : hipMemcpy(vec.data(), src, cnt * sizeof(*src), hipMemcpyDeviceToHost);
+        };
+        if (side_by_side) jobs.push_back(std::async(std::launch::async, job));
+        else { std::promise<hipError_t> p; p.set_value(job()); jobs.push_back(p.get_future()); }
+    };
+    down(hb.refid, D.refid.p, n); down(hb.pos, D.pos.p, n); down(hb.mrefid, D.mrefid.p, n); down(hb.mpos, D.mpos.p, n); down(hb.endpos, D.endpos.p, n);
+    down(hb.flag, D.flag.p, n); down(hb.totlen, D.totlen.p, n); down(hb.mapq, D.mapq.p, n); down(hb.aux, D.aux.p, n);
+    down(hb.blk_off, D.blk_off.p, n ? n + 1 : 0);
+    down(hb.b_refpos, D.b_refpos.p, nb); down(hb.b_matchref, D.b_matchref.p, nb); down(hb.b_readpos, D.b_readpos.p, nb); down(hb.b_matchread, D.b_matchread.p, nb);
+    hipError_t bad = hipSuccess;
+    for (auto& j : jobs) { const hipError_t e = j.get(); if (e != hipSuccess) bad = e; }
+    if (!n) hb.blk_off.assign(1, 0);
+    HIPCHK(bad);
     return SQ_OK;
 }
 

@@ -91,6 +91,29 @@ def test_stage_parity_bwa(built, synth, tmp_path, cfg, extra, flags, params):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["T2", "C2"])
+def test_bwa_batch_through_the_gpu_reader(built, synth, tmp_path, monkeypatch, cfg):
+    """SQUID_BWA_GPU=1 (what a --bwa file of 1 GiB and more gets): the records AND their QNAMEs are inflated and parsed on the device
+    (K-1 + K0 with the names kept, as for a large chimeric BAM) and come back as the batch the host decoder makes -- every stage, the
+    rebuilt fragments and _sv.txt equal the oracle's, as they do on the host route"""
+    import squid_amd
+    from test_gpu_parity import _compare
+
+    pre = synth(cfg, "--bwa")
+    sv_path, dump = _oracle_bwa(built, pre, tmp_path)
+    texts = {}
+    for route in ("1", "0"):
+        monkeypatch.setenv("SQUID_BWA_GPU", route)
+        with squid_amd.Context(star_mapq=False, min_mapqual=1) as ctx:
+            ctx.load_bwa(f"{pre}.bam")
+            assert ctx.counts()["chimeric_through_gpu_reader"] == int(route)
+            ctx.build_graph()
+            texts[route] = _compare(ctx, dump, sv_path)
+            assert ctx.counts()["n_chim_fragments"] == sum(1 for line in (dump / "chimrecord.txt").read_text().splitlines() if not line.startswith("#"))
+    assert texts["0"] == texts["1"] and texts["1"].count("\n") > 1
+
+
+@pytest.mark.gpu
 def test_bwa_command_line_is_a_drop_in(built, synth, tmp_path):
     pre = synth("T2", "--bwa")
     subprocess.check_call([str(built / "squid_oracle"), "--bwa", "-b", f"{pre}.bam", "-o", str(tmp_path / "o"), "-G", "1", "-CO", "1"], stdout=subprocess.DEVNULL)
