@@ -94,6 +94,7 @@ static int bwa_seed_nodes(sq_ctx* c, const HostBatch& hb, std::vector<Node>& see
         cur_start = to; cur_end = to; mark_start = to; mark_chr = chr;
     };
     std::vector<int> margins;
+    reads.reserve(hb.b_refpos.size());  // (at most every block of the batch: one allocation instead of thirty doublings of a list that ends at 1.7 GB for C3)
     for (size_t ri = 0; ri < hb.size(); ++ri) {
         const RecRef r{hb, ri};
         if (counted < 5) { RL = std::max(RL, r.totlen()); ++counted; }  // :857-864 (over ALL records, in front of the filter)
@@ -236,13 +237,144 @@ static int bwa_home_node(const std::vector<Node>& N, int start, const Blk& b) { 
 static int bwa_raw_edges(sq_ctx* c, const HostBatch& hb, std::vector<Edge>& raw) {
     const std::vector<Node>& N = c->nodes;
     const int nn = (int)N.size();
+    auto in_range = [&](int i) { return i >= 0 && i < nn; };
+    auto discordant = [&](const Edge& e) { return edge_discordant(c, N, e); };
+    // What the BAM loop (:1712-1880) leaves behind, per stretch of records: the loop carries ONE thing from record to record -- the
+    // position LocateRead starts from (`hint`: the node of the last located first block) -- and appends to lists whose order is either
+    // the record order (PartialAlign: sorted by name afterwards with an unstable sort, so the order going in counts) or does not matter
+    // (the edges are sorted and summed, the names of FirstDisInserted are sorted, the -1 edges are looked up one by one).  A stretch can
+    // therefore start behind any record whose first block lies deep inside ONE node -- LocateRead ends there from any start (sq_graph.cpp,
+    // frag_first_block_pins) --, and the stretches are worked on side by side and strung together in order.
+    struct Piece {
+        int hint = 0;
+        std::vector<Edge> raw, second_edges;
+        std::vector<Frag> partial;
+        std::vector<std::string> first_dis, second_names;
+        int rc = SQ_OK; const char* err = nullptr;
+    };
+    // the fragment of record ri as the loop builds it up to its LocateRead call: 0 = the record is skipped or locates nothing,
+    // 1 = first mate (:1745-1806), 2 = multi-aligned second mate (:1807-1860); `part`: it also goes to PartialAlign
+    auto prepare = [&](size_t ri, Frag& f, bool& part) -> int {
+        const RecRef r{hb, ri};
+        part = false;
+        if (r.dup() || !r.mapped()) return 0;
+        if (r.first() ? (r.multi() || hb.mapq[ri] == 0) : !r.multi()) return 0;  // :1723-1726 (W5)
+        f.name = r.qname();
+        std::vector<Blk>& own = r.first() ? f.a : f.b;
+        for (size_t k = 0; k < r.nblk(); ++k) own.push_back(r.blk(k));
+        std::sort(own.begin(), own.end(), blk_less_readpos);
+        (r.first() ? f.atot : f.btot) = r.totlen();
+        (r.first() ? f.alow : f.blow) = r.lowphred();
+        part = !r.multi() && (clipped_end(f.a, f.atot, f.alow) || clipped_end(f.b, f.btot, f.blow));
+        return r.first() ? ((!f.a.empty() && (f.a.front().readpos <= 15 || f.alow)) ? 1 : 0) : (!f.b.empty() ? 2 : 0);
+    };
+    // (the mate stub and, for a second mate, the shortened own block: what LocateRead sees -- after the copy for PartialAlign was taken)
+    auto finish_prepare = [&](size_t ri, Frag& f, int kind) {
+        const RecRef r{hb, ri};
+        if (r.mate_mapped() && r.mrefid() != -1) (r.first() ? f.b : f.a).push_back(Blk{r.mrefid(), r.mpos(), 0, 15, 15, r.mate_rev(), false});
+        if (kind == 2) { f.b.resize(1); f.b[0].matchref = 15; f.b[0].matchread = 15; }
+    };
+    auto run = [&](size_t lo, size_t hi, Piece& P) {
+        std::vector<int> rn;
+        int& hint = P.hint;
+        auto add = [&](int i, bool hi_, int j, bool hj, int w) -> bool {
+            if (!in_range(i) || !in_range(j)) { P.rc = SQ_E_ASSERT; P.err = "an edge would leave the node table (the reference asserts, SegmentGraph.cpp:1760)"; return false; }
+            P.raw.push_back(make_edge(i, hi_, j, hj, w));
+            return true;
+        };
+        auto split_edges = [&](const std::vector<Blk>& r, size_t base) -> bool {
+            for (size_t k = 0; k + 1 < r.size(); ++k) {
+                const int i = rn[base + k], j = rn[base + k + 1];
+                if (i != j && i != -1 && j != -1 && !add(i, r[k].rev, j, !r[k + 1].rev, 1)) return false;
+            }
+            return true;
+        };
+        for (size_t ri = lo; ri < hi; ++ri) {
+            Frag f;
+            bool part;
+            const int kind = prepare(ri, f, part);
+            if (part) P.partial.push_back(f);
+            if (kind == 0) continue;  // (a record that locates nothing leaves nothing else behind: its mate stub is only looked at by LocateRead)
+            finish_prepare(ri, f, kind);
+            const size_t na = f.a.size();
+            if (kind == 1) {
+                locate_fragment(N, hint, f, rn);
+                if (rn[0] != -1) hint = rn[0];
+                for (size_t k = 0; k < rn.size(); ++k)
+                    if (rn[k] == -1) {
+                        const int i = bwa_home_node(N, hint, k < na ? f.a[k] : f.b[k - na]);
+                        if (i == -2) { P.rc = SQ_E_ASSERT; P.err = "a block lies behind the last node (the reference reads past its node table, SegmentGraph.cpp:1757)"; return; }
+                        if (!add(i, false, i + 1, true, 1)) return;
+                    }
+                if (!split_edges(f.a, 0) || !split_edges(f.b, na)) return;
+                if (!f.b.empty() && !frag_end_discordant(f, true) && !frag_end_discordant(f, false)) {
+                    const int i = rn[na - 1], j = rn.back();
+                    if (i != j && i != -1 && j != -1 && !pair_overlap(f, rn, i, j)) {
+                        if (!add(i, f.a.back().rev, j, f.b.back().rev, 1)) return;
+                        if (discordant(P.raw.back())) P.first_dis.push_back(f.name);
+                    }
+                }
+            } else {
+                locate_fragment(N, hint, f, rn);
+                if (rn[0] != -1) hint = rn[0];
+                if (!f.a.empty() && !frag_end_discordant(f, true)) {
+                    const int i = rn[f.a.size() - 1], j = rn.back();
+                    bool overlap = false;
+                    for (size_t k = 0; k < f.a.size(); ++k) overlap |= j == rn[k];
+                    overlap |= i == rn[f.a.size()];
+                    if (i != j && i != -1 && j != -1 && !overlap) {
+                        if (!in_range(i) || !in_range(j)) { P.rc = SQ_E_ASSERT; P.err = "an edge would leave the node table (the reference asserts, SegmentGraph.cpp:1852)"; return; }
+                        const Edge e = make_edge(i, f.a.back().rev, j, f.b.back().rev, -1);
+                        if (discordant(e)) { P.second_names.push_back(f.name); P.second_edges.push_back(e); }
+                    }
+                }
+            }
+        }
+    };
+    // stretch boundaries: behind the nearest record in front of an even cut that pins the position (looked for among the 4096 records
+    // in front of the cut; none there: that cut is left out).  SQUID_BWA_PIECE=<records> sets the stretch length (tests: small inputs)
+    const long piece_env = std::getenv("SQUID_BWA_PIECE") ? std::atol(std::getenv("SQUID_BWA_PIECE")) : 0;
+    const size_t nrec = hb.size();
+    const int threads = c->pool ? c->pool->size() + 1 : 1;
+    std::vector<size_t> cut{0};
+    std::vector<int> start{0};
+    if (threads > 1 && (piece_env > 0 || nrec >= 200000)) {
+        const size_t want = piece_env > 0 ? std::max<size_t>(1, nrec / (size_t)piece_env) : (size_t)(4 * threads);
+        for (size_t k = 1; k < want; ++k) {
+            const size_t at = nrec * k / want;
+            if (at <= cut.back()) continue;
+            for (size_t q = at; q-- > cut.back() && at - q <= 4096;) {
+                Frag f;
+                bool part;
+                const int kind = prepare(q, f, part);
+                if (kind == 0) continue;
+                finish_prepare(q, f, kind);
+                int node = -1;
+                if (frag_first_block_pins(N, f, node)) { cut.push_back(q + 1); start.push_back(node); break; }
+            }
+        }
+    }
+    cut.push_back(nrec);
+    const int np = (int)cut.size() - 1;
+    c->timer.add("bwa_raw_edge_stretches", 0.0, 0.0, np);  // (how many stretches the loop ran in: tests)
+    std::vector<Piece> pieces((size_t)np);
+    for (int k = 0; k < np; ++k) pieces[(size_t)k].hint = start[(size_t)k];
+    if (np > 1) c->pool->parallel_for(np, 1 << 20, [&](int k) { run(cut[(size_t)k], cut[(size_t)k + 1], pieces[(size_t)k]); });
+    else run(0, nrec, pieces[0]);
     int hint = 0;
     std::vector<Frag> partial;
     std::vector<std::string> first_dis, second_names;
     std::vector<Edge> second_edges;
     std::vector<int> rn;
-    auto in_range = [&](int i) { return i >= 0 && i < nn; };
-    auto discordant = [&](const Edge& e) { return edge_discordant(c, N, e); };
+    for (Piece& P : pieces) {
+        if (P.rc) return fail(c, P.rc, P.err);  // (the first stretch in record order that ran into one: what the loop in one go would have hit first)
+        raw.insert(raw.end(), P.raw.begin(), P.raw.end());
+        partial.insert(partial.end(), std::make_move_iterator(P.partial.begin()), std::make_move_iterator(P.partial.end()));
+        first_dis.insert(first_dis.end(), std::make_move_iterator(P.first_dis.begin()), std::make_move_iterator(P.first_dis.end()));
+        second_names.insert(second_names.end(), std::make_move_iterator(P.second_names.begin()), std::make_move_iterator(P.second_names.end()));
+        second_edges.insert(second_edges.end(), P.second_edges.begin(), P.second_edges.end());
+        hint = P.hint;
+    }
     auto add = [&](int i, bool hi, int j, bool hj, int w) -> int {
         if (!in_range(i) || !in_range(j)) return fail(c, SQ_E_ASSERT, "an edge would leave the node table (the reference asserts, SegmentGraph.cpp:1760)");
         raw.push_back(make_edge(i, hi, j, hj, w));
@@ -255,58 +387,6 @@ static int bwa_raw_edges(sq_ctx* c, const HostBatch& hb, std::vector<Edge>& raw)
         }
         return SQ_OK;
     };
-    for (size_t ri = 0; ri < hb.size(); ++ri) {
-        const RecRef r{hb, ri};
-        if (r.dup() || !r.mapped()) continue;
-        if (r.first() ? (r.multi() || hb.mapq[ri] == 0) : !r.multi()) continue;  // :1723-1726 (W5)
-        Frag f;
-        f.name = r.qname();
-        std::vector<Blk>& own = r.first() ? f.a : f.b;
-        for (size_t k = 0; k < r.nblk(); ++k) own.push_back(r.blk(k));
-        std::sort(own.begin(), own.end(), blk_less_readpos);
-        (r.first() ? f.atot : f.btot) = r.totlen();
-        (r.first() ? f.alow : f.blow) = r.lowphred();
-        if (!r.multi() && (clipped_end(f.a, f.atot, f.alow) || clipped_end(f.b, f.btot, f.blow))) partial.push_back(f);
-        if (r.mate_mapped() && r.mrefid() != -1) (r.first() ? f.b : f.a).push_back(Blk{r.mrefid(), r.mpos(), 0, 15, 15, r.mate_rev(), false});
-        const size_t na = f.a.size();
-        if (r.first() && !f.a.empty() && (f.a.front().readpos <= 15 || f.alow)) {
-            locate_fragment(N, hint, f, rn);
-            if (rn[0] != -1) hint = rn[0];
-            for (size_t k = 0; k < rn.size(); ++k)
-                if (rn[k] == -1) {
-                    const int i = bwa_home_node(N, hint, k < na ? f.a[k] : f.b[k - na]);
-                    const int rc = i == -2 ? fail(c, SQ_E_ASSERT, "a block lies behind the last node (the reference reads past its node table, SegmentGraph.cpp:1757)") : add(i, false, i + 1, true, 1);
-                    if (rc) return rc;
-                }
-            int rc = split_edges(f.a, 0);
-            if (!rc) rc = split_edges(f.b, na);
-            if (rc) return rc;
-            if (!f.b.empty() && !frag_end_discordant(f, true) && !frag_end_discordant(f, false)) {
-                const int i = rn[na - 1], j = rn.back();
-                if (i != j && i != -1 && j != -1 && !pair_overlap(f, rn, i, j)) {
-                    rc = add(i, f.a.back().rev, j, f.b.back().rev, 1);
-                    if (rc) return rc;
-                    if (discordant(raw.back())) first_dis.push_back(f.name);
-                }
-            }
-        } else if (!r.first() && !f.b.empty()) {
-            f.b.resize(1);
-            f.b[0].matchref = 15; f.b[0].matchread = 15;
-            locate_fragment(N, hint, f, rn);
-            if (rn[0] != -1) hint = rn[0];
-            if (!f.a.empty() && !frag_end_discordant(f, true)) {
-                const int i = rn[f.a.size() - 1], j = rn.back();
-                bool overlap = false;
-                for (size_t k = 0; k < f.a.size(); ++k) overlap |= j == rn[k];
-                overlap |= i == rn[f.a.size()];
-                if (i != j && i != -1 && j != -1 && !overlap) {
-                    if (!in_range(i) || !in_range(j)) return fail(c, SQ_E_ASSERT, "an edge would leave the node table (the reference asserts, SegmentGraph.cpp:1852)");
-                    const Edge e = make_edge(i, f.a.back().rev, j, f.b.back().rev, -1);
-                    if (discordant(e)) { second_names.push_back(f.name); second_edges.push_back(e); }
-                }
-            }
-        }
-    }
     std::sort(first_dis.begin(), first_dis.end());
     for (size_t k = 0; k < second_names.size(); ++k)
         if (std::binary_search(first_dis.begin(), first_dis.end(), second_names[k])) raw.push_back(second_edges[k]);

@@ -119,6 +119,15 @@ inline FirstFit first_block_fit(const std::vector<Node>& N, const Frag& f) {
     if (a == bb) { const Node& u = N[a]; if (b.refpos >= u.pos && end <= u.pos + u.len && end > u.pos + 5 && b.refpos < u.pos + u.len - 5) return FirstFit{true, false, a}; }
     return FirstFit{false, false, -1};
 }
+}  // namespace
+// (for the record loop of --bwa mode, sq_bwa.cpp: is the fragment's first block located in one node from ANY start of the search?)
+bool frag_first_block_pins(const std::vector<Node>& N, const Frag& f, int& node) {
+    if (f.a.empty() && f.b.empty()) return false;
+    const FirstFit ff = first_block_fit(N, f);
+    node = ff.node;
+    return ff.deep;
+}
+namespace {
 // piece boundaries over the fragments `skip` does not drop, and the search start of every piece; false: run serially
 template <class Skip>
 bool plan_pieces(const sq_ctx* c, const std::vector<Node>& N, Skip skip, std::vector<size_t>& cut, std::vector<int>& start) {

@@ -348,6 +348,7 @@ int tile_genome(sq_ctx* c, std::vector<Node>& seeds, std::vector<Node>& out);
 struct Located { std::vector<int> node; };
 bool edge_discordant(const sq_ctx* c, const std::vector<Node>& N, const Edge& e);
 int locate_fragment(const std::vector<Node>& N, int hint, Frag& f, std::vector<int>& out);  // trims f in place
+bool frag_first_block_pins(const std::vector<Node>& N, const Frag& f, int& node);  // the first block lies deep inside ONE node: LocateRead ends there from any start
 int chimeric_edges(sq_ctx* c, std::vector<Edge>& raw);
 bool pair_overlap(const Frag& f, const std::vector<int>& rn, int i, int j);  // the pair-edge suppression test of :1484-1502 / :1801-1819
 // ---- sq_junction.cpp (utils/JunctionSequence.cpp)

@@ -114,6 +114,28 @@ def test_bwa_batch_through_the_gpu_reader(built, synth, tmp_path, monkeypatch, c
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg,piece", [("T2", "300"), ("C2", "1000"), ("C2", "97")])
+def test_bwa_record_loops_in_stretches_on_the_host_threads(built, synth, tmp_path, monkeypatch, cfg, piece):
+    """SQUID_BWA_PIECE=<records>: the BAM loop of RawEdges cut into stretches that start behind a record whose first block pins
+    LocateRead's position, and BuildNode_BWA's loop cut at the zero-coverage gaps its state empties at -- what a sample of tens of
+    millions of records gets by itself; every stage, the rebuilt fragments and _sv.txt equal the oracle's"""
+    import squid_amd
+    from test_gpu_parity import _compare
+
+    pre = synth(cfg, "--bwa")
+    sv_path, dump = _oracle_bwa(built, pre, tmp_path)
+    monkeypatch.setenv("SQUID_BWA_PIECE", piece)
+    with squid_amd.Context(star_mapq=False, min_mapqual=1) as ctx:
+        ctx.load_bwa(f"{pre}.bam")
+        ctx.build_graph()
+        sv = _compare(ctx, dump, sv_path)
+        assert sv.count("\n") > 1
+        assert ctx.counts()["n_chim_fragments"] == sum(1 for line in (dump / "chimrecord.txt").read_text().splitlines() if not line.startswith("#"))
+        stretches = ctx.timing().get("bwa_raw_edge_stretches", {}).get("launches", 0)
+        assert stretches > 3, stretches
+
+
+@pytest.mark.gpu
 def test_bwa_command_line_is_a_drop_in(built, synth, tmp_path):
     pre = synth("T2", "--bwa")
     subprocess.check_call([str(built / "squid_oracle"), "--bwa", "-b", f"{pre}.bam", "-o", str(tmp_path / "o"), "-G", "1", "-CO", "1"], stdout=subprocess.DEVNULL)
