@@ -84,136 +84,215 @@ struct Window {
 }  // namespace
 
 // ---- BuildNode_BWA up to the seed nodes, plus the Reads list of :878-881
-static int bwa_seed_nodes(sq_ctx* c, const HostBatch& hb, std::vector<Node>& seeds, std::vector<Blk>& reads) {
-    const int thresh = 3;
-    int RL = c->read_len;  // (a chimeric file given next to --bwa has set it already: src/main.cpp:34-36)
-    int counted = 0, prev0 = 0, mark_start = -1, mark_chr = -1, dis_right = 0, other_right = 0;
+// The loop (:855-1114) is one automaton over all records, but everything it carries from record to record dies at a gap in the coverage:
+// a record r that starts more than  Lmax + RL + 64  bases behind the start of the passing record in front of it (Lmax = the longest
+// first block of the batch; or r opens a chromosome) finds -- after the work it triggers on the windows BEFORE it -- all three windows
+// empty, the discordant run flushed, no pending mark, and every seed emitted so far more than 60 bases (thresh * 20, the only distance
+// a seed is ever compared over) in front of anything it or its successors will look at.  So the stream is cut at such records: a
+// stretch runs from its gap record with the state a fresh automaton has, and ends by letting the NEXT stretch's first record close it
+// (the flush of the discordant window and the zero-coverage rule, :888-1026, without the record joining a window).  The one thing a
+// fresh stretch does not reproduce is the fill of the windows' storage, which decides WHEN the capacity-driven compaction (W1) runs --
+// not what the loop computes: the compaction only removes elements that end more than RL in front of the current record (and of the
+// discordant run's head), which no later test can see: the clip-position and cover counts look at positions behind that head, emptiness
+// and the voted chromosome do not change while an element that is NOT removable is still in front of them.
+// SQUID_BWA_PIECE=<records> sets the stretch length (tests); samples of 200 k records and more are cut into 4 x threads stretches.
+namespace {
+struct SeedRun {
+    int RL = 0, counted = 0, prev0 = 0, mark_start = -1, mark_chr = -1, dis_right = 0, other_right = 0;
     Window conc, dis, part;
+    std::vector<Node> seeds;
+    std::vector<Blk> reads;
+    std::vector<int> margins;
+};
+inline bool seed_record_passes(const HostBatch& hb, size_t ri) {
+    const RecRef r{hb, ri};
+    return !(r.multi() || hb.mapq[ri] == 0 || r.dup() || !r.mapped() || r.refid() == -1) && r.nblk() != 0;
+}
+// one turn of the loop for record ri; `closing`: the record only closes the stretch in front of it (it belongs to the next one)
+void seed_step(SeedRun& S, const HostBatch& hb, size_t ri, bool closing) {
+    const int thresh = 3;
+    int &RL = S.RL, &prev0 = S.prev0, &mark_start = S.mark_start, &mark_chr = S.mark_chr, &dis_right = S.dis_right, &other_right = S.other_right;
+    Window &conc = S.conc, &dis = S.dis, &part = S.part;
+    std::vector<Node>& seeds = S.seeds;
+    std::vector<int>& margins = S.margins;
     auto push_node = [&](int chr, int from, int to, int& cur_start, int& cur_end) {
         seeds.push_back(Node{chr, from, to - from, 0, 0.0});
         cur_start = to; cur_end = to; mark_start = to; mark_chr = chr;
     };
-    std::vector<int> margins;
-    reads.reserve(hb.b_refpos.size());  // (at most every block of the batch: one allocation instead of thirty doublings of a list that ends at 1.7 GB for C3)
-    for (size_t ri = 0; ri < hb.size(); ++ri) {
-        const RecRef r{hb, ri};
-        if (counted < 5) { RL = std::max(RL, r.totlen()); ++counted; }  // :857-864 (over ALL records, in front of the filter)
-        if (r.multi() || hb.mapq[ri] == 0 || r.dup() || !r.mapped() || r.refid() == -1) continue;
-        if ((!dis.none() && r.refid() != dis.head().refid) || (!conc.none() && r.refid() != conc.head().refid) || (!part.none() && r.refid() != part.head().refid)) other_right = 0;
-        const size_t nb = r.nblk();
-        if (nb == 0) continue;
-        for (size_t k = 0; k < nb; ++k) reads.push_back(r.blk(k));
-        const Blk b0 = r.blk(0), blast = r.blk(nb - 1);
-        if (conc.none() && part.none() && dis.none()) prev0 = r.pos();
-        if (!dis.none() && (dis.v.back().refid != r.refid() || dis_right + RL < r.pos())) {
-            // the discordant window is complete: decide the segment boundaries inside it (:888-998)
-            int cur_end = 0, cur_start = std::max(prev0, mark_start);
-            int d_start = -1, d_end = -1, d_count = -1;
-            bool split = false;
-            auto dense = [&]() { return d_start != -1 && !split && d_count > std::min(5.0, 4.0 * (d_end - d_start) / RL); };
-            while (!dis.none()) {
-                if (dense()) push_node(dis.head().refid, d_start, d_end, cur_start, cur_end);
-                split = false;
-                margins.clear();
-                size_t i = (size_t)dis.off;
-                for (; i < dis.v.size(); ++i) {  // the leading run of blocks that touch each other
-                    margins.push_back(dis.v[i].refpos); margins.push_back(dis.end_of(i));
-                    cur_end = std::max(cur_end, margins.back());
-                    if (i + 1 < dis.v.size() && dis.v[i + 1].refpos > dis.end_of(i)) break;
-                }
-                d_start = std::max(cur_start, dis.head().refpos);
-                d_end = cur_end;
-                d_count = (int)i - dis.off;
-                for (++i; i < dis.v.size() && dis.v[i].refpos < cur_end + thresh; ++i) { margins.push_back(dis.v[i].refpos); margins.push_back(dis.end_of(i)); }
-                const int m0 = margins.front(), dchr = dis.head().refid;
-                for (size_t k = (size_t)part.off; k < part.v.size(); ++k) {  // clip positions of the partially aligned reads next to the run
-                    const Blk& p = part.v[k];
-                    if (p.refid != dchr) continue;
-                    const int pe = p.refpos + p.matchref;
-                    if (p.readpos > 15 && p.refpos > m0 - thresh && p.refpos < cur_end + thresh) margins.push_back(p.rev ? pe : p.refpos);
-                    else if (pe > m0 - thresh && pe < cur_end + thresh) margins.push_back(p.rev ? p.refpos : pe);
-                }
-                std::sort(margins.begin(), margins.end());
-                int last_cursor = -1, last_support = 0;
-                const int chr0 = dis.v.front().refid;  // (W2: element 0 of the storage, not the window's head)
-                for (size_t at = 0; at < margins.size();) {
-                    const int x = margins[at];
-                    if (!seeds.empty() && seeds.back().chr == chr0 && x - seeds.back().pos - seeds.back().len < thresh * 20) { ++at; continue; }
-                    int sr = 0, left_fwd = 0, right_rev = 0;
-                    for (size_t q = 0; q < margins.size() && margins[q] < x + thresh; ++q) sr += std::abs(x - margins[q]) < thresh;
-                    for (size_t q = (size_t)dis.off; q < dis.v.size(); ++q) {
-                        const int e = dis.end_of(q);
-                        if (e < x && e > x - RL && !dis.v[q].rev) ++left_fwd;
-                        else if (dis.v[q].refpos > x && dis.v[q].refpos < x + RL && dis.v[q].rev) ++right_rev;
-                    }
-                    bool cut_here = false;
-                    if (sr > 3 || sr + left_fwd > 4 || sr + right_rev > 4) {
-                        int cover = 0;
-                        for (size_t q = (size_t)conc.off; q < conc.v.size(); ++q) cover += conc.end_of(q) >= x + thresh && conc.v[q].refpos < x - thresh;
-                        if (sr > std::max(cover - sr, 0) + 2) {
-                            const int strength = sr + std::max(left_fwd, right_rev);
-                            if (last_cursor == -1 && x - cur_start < thresh * 20) { mark_start = cur_start; mark_chr = chr0; }
-                            else if ((last_cursor == -1 || x - last_cursor < thresh * 20) && strength > last_support) { last_cursor = x; last_support = strength; }
-                            else if (x - last_cursor >= thresh * 20) { split = true; push_node(chr0, cur_start, last_cursor, cur_start, cur_end); cut_here = true; }
-                        }
-                    }
-                    if (cut_here) break;
-                    size_t nx = at;
-                    while (nx < margins.size() && margins[nx] == x) ++nx;  // on to the next distinct position
-                    if (nx >= margins.size()) break;
-                    at = nx;
-                }
-                if (last_cursor != -1 && !split) { split = true; push_node(dis.head().refid, cur_start, last_cursor, cur_start, cur_end); }
-                while (!dis.none() && dis.head().refpos + dis.head().matchref <= cur_end) ++dis.off;
+    const RecRef r{hb, ri};
+    if (S.counted < 5 && !closing) { RL = std::max(RL, r.totlen()); ++S.counted; }  // :857-864 (over ALL records, in front of the filter)
+    if (r.multi() || hb.mapq[ri] == 0 || r.dup() || !r.mapped() || r.refid() == -1) return;
+    if ((!dis.none() && r.refid() != dis.head().refid) || (!conc.none() && r.refid() != conc.head().refid) || (!part.none() && r.refid() != part.head().refid)) other_right = 0;
+    const size_t nb = r.nblk();
+    if (nb == 0) return;
+    if (!closing) for (size_t k = 0; k < nb; ++k) S.reads.push_back(r.blk(k));
+    const Blk b0 = r.blk(0), blast = r.blk(nb - 1);
+    if (conc.none() && part.none() && dis.none()) prev0 = r.pos();
+    if (!dis.none() && (dis.v.back().refid != r.refid() || dis_right + RL < r.pos())) {
+        // the discordant window is complete: decide the segment boundaries inside it (:888-998)
+        int cur_end = 0, cur_start = std::max(prev0, mark_start);
+        int d_start = -1, d_end = -1, d_count = -1;
+        bool split = false;
+        auto dense = [&]() { return d_start != -1 && !split && d_count > std::min(5.0, 4.0 * (d_end - d_start) / RL); };
+        while (!dis.none()) {
+            if (dense()) push_node(dis.head().refid, d_start, d_end, cur_start, cur_end);
+            split = false;
+            margins.clear();
+            size_t i = (size_t)dis.off;
+            for (; i < dis.v.size(); ++i) {  // the leading run of blocks that touch each other
+                margins.push_back(dis.v[i].refpos); margins.push_back(dis.end_of(i));
+                cur_end = std::max(cur_end, margins.back());
+                if (i + 1 < dis.v.size() && dis.v[i + 1].refpos > dis.end_of(i)) break;
             }
-            if (dense()) push_node(dis.v[0].refid, d_start, d_end, cur_start, cur_end);  // (W2)
-            if (dis.none()) { dis.v.clear(); dis.off = 0; }
-            conc.drop_left_of(r.refid(), r.pos(), RL); part.drop_left_of(r.refid(), r.pos(), RL);
+            d_start = std::max(cur_start, dis.head().refpos);
+            d_end = cur_end;
+            d_count = (int)i - dis.off;
+            for (++i; i < dis.v.size() && dis.v[i].refpos < cur_end + thresh; ++i) { margins.push_back(dis.v[i].refpos); margins.push_back(dis.end_of(i)); }
+            const int m0 = margins.front(), dchr = dis.head().refid;
+            for (size_t k = (size_t)part.off; k < part.v.size(); ++k) {  // clip positions of the partially aligned reads next to the run
+                const Blk& p = part.v[k];
+                if (p.refid != dchr) continue;
+                const int pe = p.refpos + p.matchref;
+                if (p.readpos > 15 && p.refpos > m0 - thresh && p.refpos < cur_end + thresh) margins.push_back(p.rev ? pe : p.refpos);
+                else if (pe > m0 - thresh && pe < cur_end + thresh) margins.push_back(p.rev ? p.refpos : pe);
+            }
+            std::sort(margins.begin(), margins.end());
+            int last_cursor = -1, last_support = 0;
+            const int chr0 = dis.v.front().refid;  // (W2: element 0 of the storage, not the window's head)
+            for (size_t at = 0; at < margins.size();) {
+                const int x = margins[at];
+                if (!seeds.empty() && seeds.back().chr == chr0 && x - seeds.back().pos - seeds.back().len < thresh * 20) { ++at; continue; }
+                int sr = 0, left_fwd = 0, right_rev = 0;
+                for (size_t q = 0; q < margins.size() && margins[q] < x + thresh; ++q) sr += std::abs(x - margins[q]) < thresh;
+                for (size_t q = (size_t)dis.off; q < dis.v.size(); ++q) {
+                    const int e = dis.end_of(q);
+                    if (e < x && e > x - RL && !dis.v[q].rev) ++left_fwd;
+                    else if (dis.v[q].refpos > x && dis.v[q].refpos < x + RL && dis.v[q].rev) ++right_rev;
+                }
+                bool cut_here = false;
+                if (sr > 3 || sr + left_fwd > 4 || sr + right_rev > 4) {
+                    int cover = 0;
+                    for (size_t q = (size_t)conc.off; q < conc.v.size(); ++q) cover += conc.end_of(q) >= x + thresh && conc.v[q].refpos < x - thresh;
+                    if (sr > std::max(cover - sr, 0) + 2) {
+                        const int strength = sr + std::max(left_fwd, right_rev);
+                        if (last_cursor == -1 && x - cur_start < thresh * 20) { mark_start = cur_start; mark_chr = chr0; }
+                        else if ((last_cursor == -1 || x - last_cursor < thresh * 20) && strength > last_support) { last_cursor = x; last_support = strength; }
+                        else if (x - last_cursor >= thresh * 20) { split = true; push_node(chr0, cur_start, last_cursor, cur_start, cur_end); cut_here = true; }
+                    }
+                }
+                if (cut_here) break;
+                size_t nx = at;
+                while (nx < margins.size() && margins[nx] == x) ++nx;  // on to the next distinct position
+                if (nx >= margins.size()) break;
+                at = nx;
+            }
+            if (last_cursor != -1 && !split) { split = true; push_node(dis.head().refid, cur_start, last_cursor, cur_start, cur_end); }
+            while (!dis.none() && dis.head().refpos + dis.head().matchref <= cur_end) ++dis.off;
         }
-        // zero coverage in front of this record (:1000-1026)
-        const int rightmost = std::max(dis_right, other_right);
-        int cur_chr = 0;
-        conc.vote_chr(cur_chr); part.vote_chr(cur_chr); dis.vote_chr(cur_chr);
-        const bool zero = r.refid() != cur_chr || r.pos() > rightmost + RL;
-        if (zero && mark_start != -1) {
-            if (rightmost > mark_start && rightmost - mark_start < thresh * 20 && !seeds.empty() && mark_start == seeds.back().pos + seeds.back().len) seeds.back().len += rightmost - mark_start;
-            else if (rightmost > mark_start && rightmost - mark_start >= thresh * 20) seeds.push_back(Node{mark_chr, mark_start, rightmost - mark_start, 0, 0.0});
-            mark_start = -1; mark_chr = -1;
-        }
-        if (zero) prev0 = r.pos();
-        if (dis.none()) { conc.drop_left_of(r.refid(), r.pos(), RL); part.drop_left_of(r.refid(), r.pos(), RL); }
-        // the record joins a window (:1035-1086)
-        const int e0 = b0.refpos + b0.matchref;
-        if (r.pair_concordant()) {
-            other_right = (!conc.none() || !part.none()) ? std::max(other_right, e0) : e0;
-            const bool clipped = !r.lowphred() && (b0.readpos > 15 || r.totlen() - blast.readpos - blast.matchread > 15);
-            (clipped ? part : conc).v.push_back(b0);
-        } else {
-            dis_right = !dis.v.empty() ? std::max(dis_right, e0) : e0;
-            dis.v.push_back(b0);
-        }
-        // compaction at capacity (:1087-1112, W1)
-        for (Window* w : {&conc, &part}) {
-            if (w->v.size() != w->cap) continue;
-            const int from = !dis.none() ? std::min(r.pos(), dis.head().refpos) : r.pos();
-            std::vector<Blk> kept;
-            for (size_t q = (size_t)w->off; q < w->v.size(); ++q) if (w->v[q].refid == r.refid() && w->end_of(q) + RL >= from) kept.push_back(w->v[q]);
-            w->v.swap(kept); w->off = 0;
-            if (w->v.size() == w->cap) w->cap *= 2;
-        }
+        if (dense()) push_node(dis.v[0].refid, d_start, d_end, cur_start, cur_end);  // (W2)
+        if (dis.none()) { dis.v.clear(); dis.off = 0; }
+        conc.drop_left_of(r.refid(), r.pos(), RL); part.drop_left_of(r.refid(), r.pos(), RL);
     }
-    c->read_len = RL;
+    // zero coverage in front of this record (:1000-1026)
+    const int rightmost = std::max(dis_right, other_right);
+    int cur_chr = 0;
+    conc.vote_chr(cur_chr); part.vote_chr(cur_chr); dis.vote_chr(cur_chr);
+    const bool zero = r.refid() != cur_chr || r.pos() > rightmost + RL;
+    if (zero && mark_start != -1) {
+        if (rightmost > mark_start && rightmost - mark_start < thresh * 20 && !seeds.empty() && mark_start == seeds.back().pos + seeds.back().len) seeds.back().len += rightmost - mark_start;
+        else if (rightmost > mark_start && rightmost - mark_start >= thresh * 20) seeds.push_back(Node{mark_chr, mark_start, rightmost - mark_start, 0, 0.0});
+        mark_start = -1; mark_chr = -1;
+    }
+    if (closing) return;
+    if (zero) prev0 = r.pos();
+    if (dis.none()) { conc.drop_left_of(r.refid(), r.pos(), RL); part.drop_left_of(r.refid(), r.pos(), RL); }
+    // the record joins a window (:1035-1086)
+    const int e0 = b0.refpos + b0.matchref;
+    if (r.pair_concordant()) {
+        other_right = (!conc.none() || !part.none()) ? std::max(other_right, e0) : e0;
+        const bool clipped = !r.lowphred() && (b0.readpos > 15 || r.totlen() - blast.readpos - blast.matchread > 15);
+        (clipped ? part : conc).v.push_back(b0);
+    } else {
+        dis_right = !dis.v.empty() ? std::max(dis_right, e0) : e0;
+        dis.v.push_back(b0);
+    }
+    // compaction at capacity (:1087-1112, W1)
+    for (Window* w : {&conc, &part}) {
+        if (w->v.size() != w->cap) continue;
+        const int from = !dis.none() ? std::min(r.pos(), dis.head().refpos) : r.pos();
+        std::vector<Blk> kept;
+        for (size_t q = (size_t)w->off; q < w->v.size(); ++q) if (w->v[q].refid == r.refid() && w->end_of(q) + RL >= from) kept.push_back(w->v[q]);
+        w->v.swap(kept); w->off = 0;
+        if (w->v.size() == w->cap) w->cap *= 2;
+    }
+}
+}  // namespace
+static int bwa_seed_nodes(sq_ctx* c, const HostBatch& hb, std::vector<Node>& seeds, std::vector<std::vector<Blk>>& reads) {
+    const size_t nrec = hb.size();
+    // ReadLen as the loop leaves it (:857-864): the chimeric file's value, raised by the first five records
+    int RL_final = c->read_len;
+    for (size_t ri = 0; ri < nrec && ri < 5; ++ri) RL_final = std::max(RL_final, (int)hb.totlen[ri]);
+    const long piece_env = std::getenv("SQUID_BWA_PIECE") ? std::atol(std::getenv("SQUID_BWA_PIECE")) : 0;
+    const int threads = c->pool ? c->pool->size() + 1 : 1;
+    std::vector<size_t> cut{0};
+    if (threads > 1 && nrec > 16 && (piece_env > 0 || nrec >= 200000)) {
+        // even pieces; per piece the largest (RefID, end of the first block) of its passing records -- the records are sorted, so the
+        // running maximum of that key in front of a record is "the farthest a window element of the current chromosome reaches" --,
+        // then every piece looks for its first passing record that starts more than RL + 64 behind that reach (or on a later chromosome)
+        const int np0 = (int)std::min<size_t>(piece_env > 0 ? std::max<size_t>(1, nrec / (size_t)piece_env) : (size_t)(4 * threads), nrec / 8);
+        auto key_of = [&](size_t ri) { const uint32_t b = hb.blk_off[ri]; return ((long long)hb.refid[ri] << 32) | (uint32_t)(hb.b_refpos[b] + hb.b_matchref[b]); };
+        auto lo_of = [&](int k) { return nrec * (size_t)k / (size_t)np0; };
+        std::vector<long long> reach((size_t)np0 + 1, -1);
+        c->pool->parallel_for(np0, 1 << 20, [&](int k) {
+            long long m = -1;
+            for (size_t ri = lo_of(k); ri < lo_of(k + 1); ++ri) if (seed_record_passes(hb, ri)) m = std::max(m, key_of(ri));
+            reach[(size_t)k + 1] = m;
+        });
+        for (int k = 0; k < np0; ++k) reach[(size_t)k + 1] = std::max(reach[(size_t)k + 1], reach[(size_t)k]);  // reach[k]: of everything in front of piece k
+        std::vector<size_t> found((size_t)np0, 0);
+        c->pool->parallel_for(np0, 1 << 20, [&](int k) {
+            if (k == 0 || reach[(size_t)k] < 0) return;  // (a stretch starts behind the first five records, and behind a passing record)
+            long long run = reach[(size_t)k];
+            for (size_t ri = std::max<size_t>(lo_of(k), 8); ri < lo_of(k + 1); ++ri) {
+                if (!seed_record_passes(hb, ri)) continue;
+                const int chr = (int)(run >> 32), end = (int)(uint32_t)run;
+                if (hb.refid[ri] != chr || (long long)hb.pos[ri] > (long long)end + RL_final + 64) { found[(size_t)k] = ri; return; }
+                run = std::max(run, key_of(ri));
+            }
+        });
+        for (int k = 1; k < np0; ++k) if (found[(size_t)k] > cut.back()) cut.push_back(found[(size_t)k]);
+    }
+    cut.push_back(nrec);
+    const int np = (int)cut.size() - 1;
+    c->timer.add("bwa_seed_node_stretches", 0.0, 0.0, np);
+    std::vector<SeedRun> runs((size_t)np);
+    auto work = [&](int k) {
+        SeedRun& S = runs[(size_t)k];
+        S.RL = k == 0 ? c->read_len : RL_final;
+        S.counted = k == 0 ? 0 : 5;
+        size_t nblk = 0;
+        for (size_t ri = cut[(size_t)k]; ri < cut[(size_t)k + 1]; ++ri) nblk += hb.blk_off[ri + 1] - hb.blk_off[ri];
+        S.reads.reserve(nblk);  // (at most every block of the stretch: one allocation)
+        for (size_t ri = cut[(size_t)k]; ri < cut[(size_t)k + 1]; ++ri) seed_step(S, hb, ri, false);
+        if (k + 1 < np) seed_step(S, hb, cut[(size_t)k + 1], true);  // (the next stretch's gap record closes this one)
+    };
+    if (np > 1) c->pool->parallel_for(np, 1 << 20, work); else work(0);
+    reads.clear();
+    for (SeedRun& S : runs) { seeds.insert(seeds.end(), S.seeds.begin(), S.seeds.end()); reads.push_back(std::move(S.reads)); }
+    c->read_len = runs.back().RL;
     return SQ_OK;
 }
 
 // Support / AvgDepth of the tiled nodes (:1180-1204): one pass, the cursor never goes back (W6)
-static void bwa_node_depth(std::vector<Node>& N, const std::vector<Blk>& reads) {
-    if (reads.empty()) return;
-    size_t it = 0;
+static void bwa_node_depth(std::vector<Node>& N, const std::vector<std::vector<Blk>>& parts) {
+    size_t pi = 0, it = 0;
+    auto skip_empty = [&]() { while (pi < parts.size() && it == parts[pi].size()) { ++pi; it = 0; } };
+    skip_empty();
+    if (pi == parts.size()) return;  // (no read at all: the reference leaves Support / AvgDepth as constructed)
     for (Node& n : N) {
         int cnt = 0, sum = 0;
-        for (; it != reads.size(); ++it) {
-            const Blk& b = reads[it];
+        for (; pi < parts.size(); ++it, skip_empty()) {
+            const Blk& b = parts[pi][it];
             if (b.refid == n.chr && b.refpos >= n.pos && b.refpos + b.matchref <= n.pos + n.len) { ++cnt; sum += b.matchref; }
             else if (b.refpos >= n.pos + n.len || b.refid != n.chr) break;
         }
@@ -432,7 +511,7 @@ int bwa_nodes_and_edges(sq_ctx* c, std::vector<Edge>& raw) {
     if (!c->bwa) return fail(c, SQ_E_ARG, "sq_ingest_bwa_file first");
     const HostBatch& hb = *c->bwa;
     std::vector<Node> seeds;
-    std::vector<Blk> reads;
+    std::vector<std::vector<Blk>> reads;  // (the Reads list, stretch by stretch)
     int rc;
     { HostClock hc(c, "host_bwa_seed_nodes"); rc = bwa_seed_nodes(c, hb, seeds, reads); }
     if (rc) return rc;

@@ -131,8 +131,9 @@ def test_bwa_record_loops_in_stretches_on_the_host_threads(built, synth, tmp_pat
         sv = _compare(ctx, dump, sv_path)
         assert sv.count("\n") > 1
         assert ctx.counts()["n_chim_fragments"] == sum(1 for line in (dump / "chimrecord.txt").read_text().splitlines() if not line.startswith("#"))
-        stretches = ctx.timing().get("bwa_raw_edge_stretches", {}).get("launches", 0)
-        assert stretches > 3, stretches
+        t = ctx.timing()
+        stretches = (t.get("bwa_raw_edge_stretches", {}).get("launches", 0), t.get("bwa_seed_node_stretches", {}).get("launches", 0))
+        assert stretches[0] > 3 and stretches[1] > 3, stretches
 
 
 @pytest.mark.gpu
