@@ -16,6 +16,7 @@
 // the last Qname group never flushed, LocateRead hint left over from the BAM loop, weight -1 edges of multi-aligned second mates, the
 // one-way depth cursor.
 #include <algorithm>
+#include <cstdint>
 #include <cstring>
 
 #include "sq_internal.h"
@@ -99,6 +100,11 @@ struct Window {
 namespace {
 struct SeedRun {
     int RL = 0, counted = 0, prev0 = 0, mark_start = -1, mark_chr = -1, dis_right = 0, other_right = 0;
+    // what a stretch that was started on a guess must report (bwa_seed_nodes): were the two "rightmost" values assigned inside it, the
+    // smallest position at which the zero-coverage test came out true by its position half while each was still the caller's, and the
+    // outcome of that test for the record that closed the stretch
+    bool dis_set = false, oth_set = false, closing_zero = true;
+    int minpos_dis = INT32_MAX, minpos_oth = INT32_MAX;
     Window conc, dis, part;
     std::vector<Node> seeds;
     std::vector<Blk> reads;
@@ -109,7 +115,8 @@ inline bool seed_record_passes(const HostBatch& hb, size_t ri) {
     return !(r.multi() || hb.mapq[ri] == 0 || r.dup() || !r.mapped() || r.refid() == -1) && r.nblk() != 0;
 }
 // one turn of the loop for record ri; `closing`: the record only closes the stretch in front of it (it belongs to the next one)
-void seed_step(SeedRun& S, const HostBatch& hb, size_t ri, bool closing) {
+// opening_zero >= 0: the record's turn up to the zero-coverage rule was the closing turn of the stretch in front (which found `zero` = opening_zero)
+void seed_step(SeedRun& S, const HostBatch& hb, size_t ri, bool closing, int opening_zero = -1) {
     const int thresh = 3;
     int &RL = S.RL, &prev0 = S.prev0, &mark_start = S.mark_start, &mark_chr = S.mark_chr, &dis_right = S.dis_right, &other_right = S.other_right;
     Window &conc = S.conc, &dis = S.dis, &part = S.part;
@@ -122,13 +129,14 @@ void seed_step(SeedRun& S, const HostBatch& hb, size_t ri, bool closing) {
     const RecRef r{hb, ri};
     if (S.counted < 5 && !closing) { RL = std::max(RL, r.totlen()); ++S.counted; }  // :857-864 (over ALL records, in front of the filter)
     if (r.multi() || hb.mapq[ri] == 0 || r.dup() || !r.mapped() || r.refid() == -1) return;
-    if ((!dis.none() && r.refid() != dis.head().refid) || (!conc.none() && r.refid() != conc.head().refid) || (!part.none() && r.refid() != part.head().refid)) other_right = 0;
+    const bool opening = opening_zero >= 0;
+    if (!opening && ((!dis.none() && r.refid() != dis.head().refid) || (!conc.none() && r.refid() != conc.head().refid) || (!part.none() && r.refid() != part.head().refid))) { other_right = 0; S.oth_set = true; }
     const size_t nb = r.nblk();
     if (nb == 0) return;
     if (!closing) for (size_t k = 0; k < nb; ++k) S.reads.push_back(r.blk(k));
     const Blk b0 = r.blk(0), blast = r.blk(nb - 1);
-    if (conc.none() && part.none() && dis.none()) prev0 = r.pos();
-    if (!dis.none() && (dis.v.back().refid != r.refid() || dis_right + RL < r.pos())) {
+    if (!opening && conc.none() && part.none() && dis.none()) prev0 = r.pos();
+    if (!opening && !dis.none() && (dis.v.back().refid != r.refid() || dis_right + RL < r.pos())) {
         // the discordant window is complete: decide the segment boundaries inside it (:888-998)
         int cur_end = 0, cur_start = std::max(prev0, mark_start);
         int d_start = -1, d_end = -1, d_count = -1;
@@ -197,8 +205,15 @@ void seed_step(SeedRun& S, const HostBatch& hb, size_t ri, bool closing) {
     const int rightmost = std::max(dis_right, other_right);
     int cur_chr = 0;
     conc.vote_chr(cur_chr); part.vote_chr(cur_chr); dis.vote_chr(cur_chr);
-    const bool zero = r.refid() != cur_chr || r.pos() > rightmost + RL;
-    if (zero && mark_start != -1) {
+    const bool zero = opening ? opening_zero != 0 : (r.refid() != cur_chr || r.pos() > rightmost + RL);
+    if (!opening && zero && r.refid() == cur_chr) {  // (true by its position half alone: a larger value handed in by the caller could have turned it)
+        if (!S.dis_set) S.minpos_dis = std::min(S.minpos_dis, r.pos());
+        if (!S.oth_set) S.minpos_oth = std::min(S.minpos_oth, r.pos());
+    }
+    if (closing) S.closing_zero = zero;
+    { static const long trace = std::getenv("SQUID_BWA_TRACE") ? std::atol(std::getenv("SQUID_BWA_TRACE")) : -1;
+      if (trace >= 0 && (long)ri >= trace && (long)ri < trace + 3) std::fprintf(stderr, "record %zu (%d, %d) closing %d: zero %d cur_chr %d rightmost %d (dis %d other %d) RL %d prev0 %d mark %d windows %zu/%zu/%zu live %d/%d/%d\n", ri, r.refid(), r.pos(), (int)closing, (int)zero, cur_chr, rightmost, dis_right, other_right, RL, prev0, mark_start, conc.v.size(), part.v.size(), dis.v.size(), (int)conc.v.size() - conc.off, (int)part.v.size() - part.off, (int)dis.v.size() - dis.off); }
+    if (!opening && zero && mark_start != -1) {
         if (rightmost > mark_start && rightmost - mark_start < thresh * 20 && !seeds.empty() && mark_start == seeds.back().pos + seeds.back().len) seeds.back().len += rightmost - mark_start;
         else if (rightmost > mark_start && rightmost - mark_start >= thresh * 20) seeds.push_back(Node{mark_chr, mark_start, rightmost - mark_start, 0, 0.0});
         mark_start = -1; mark_chr = -1;
@@ -209,10 +224,12 @@ void seed_step(SeedRun& S, const HostBatch& hb, size_t ri, bool closing) {
     // the record joins a window (:1035-1086)
     const int e0 = b0.refpos + b0.matchref;
     if (r.pair_concordant()) {
+        S.oth_set = true;  // (the first such record of a stretch finds both windows empty: assigned, not compared)
         other_right = (!conc.none() || !part.none()) ? std::max(other_right, e0) : e0;
         const bool clipped = !r.lowphred() && (b0.readpos > 15 || r.totlen() - blast.readpos - blast.matchread > 15);
         (clipped ? part : conc).v.push_back(b0);
     } else {
+        S.dis_set = true;
         dis_right = !dis.v.empty() ? std::max(dis_right, e0) : e0;
         dis.v.push_back(b0);
     }
@@ -265,18 +282,52 @@ static int bwa_seed_nodes(sq_ctx* c, const HostBatch& hb, std::vector<Node>& see
     cut.push_back(nrec);
     const int np = (int)cut.size() - 1;
     c->timer.add("bwa_seed_node_stretches", 0.0, 0.0, np);
+    // A stretch is started on a GUESS of the values that do cross a gap: the outcome of the zero-coverage test for its first record (guess:
+    // true -- then prev0 and the mark are reset by that record itself) and the two "rightmost" values the test compares with (guess: 0).
+    // They are stale whenever they matter -- the end of the last discordant / concordant run in front, possibly on an EARLIER CHROMOSOME:
+    // the reference compares positions of different chromosomes there (DiscordantRightmost outlives the chromosome, :1002-1013) -- and
+    // neither depends on anything the test decides, so every stretch reports what it assigned, the stretches are then walked in order
+    // with the real values, and a stretch whose guess was wrong where it counted is run again from the real state.
+    struct Carry { int zero, prev0, mark_start, mark_chr, dis_right, other_right; };
     std::vector<SeedRun> runs((size_t)np);
-    auto work = [&](int k) {
+    auto work = [&](int k, const Carry* real) {
         SeedRun& S = runs[(size_t)k];
+        S = SeedRun();
         S.RL = k == 0 ? c->read_len : RL_final;
         S.counted = k == 0 ? 0 : 5;
+        if (real) { S.prev0 = real->prev0; S.mark_start = real->mark_start; S.mark_chr = real->mark_chr; S.dis_right = real->dis_right; S.other_right = real->other_right; }
         size_t nblk = 0;
         for (size_t ri = cut[(size_t)k]; ri < cut[(size_t)k + 1]; ++ri) nblk += hb.blk_off[ri + 1] - hb.blk_off[ri];
         S.reads.reserve(nblk);  // (at most every block of the stretch: one allocation)
-        for (size_t ri = cut[(size_t)k]; ri < cut[(size_t)k + 1]; ++ri) seed_step(S, hb, ri, false);
+        for (size_t ri = cut[(size_t)k]; ri < cut[(size_t)k + 1]; ++ri) seed_step(S, hb, ri, false, (k > 0 && ri == cut[(size_t)k]) ? (real ? real->zero : 1) : -1);
         if (k + 1 < np) seed_step(S, hb, cut[(size_t)k + 1], true);  // (the next stretch's gap record closes this one)
     };
-    if (np > 1) c->pool->parallel_for(np, 1 << 20, work); else work(0);
+    if (np > 1) c->pool->parallel_for(np, 1 << 20, [&](int k) { work(k, nullptr); }); else work(0, nullptr);
+    int again = 0;
+    for (int k = 1; k < np; ++k) {
+        const SeedRun& P = runs[(size_t)k - 1];  // (final: run from the real state, or checked)
+        const Carry real{P.closing_zero ? 1 : 0, P.prev0, P.mark_start, P.mark_chr, P.dis_right, P.other_right};
+        SeedRun& S = runs[(size_t)k];
+        // with `zero` true the first record resets prev0 and the mark by itself; the rightmost values only enter through the position half
+        // of later tests, and only until the stretch assigns them (smaller than every position a test came out true at: same outcomes)
+        const bool fine = real.zero && (real.dis_right == 0 || S.minpos_dis == INT32_MAX || (long)real.dis_right + RL_final < (long)S.minpos_dis) &&
+                          (real.other_right == 0 || S.minpos_oth == INT32_MAX || (long)real.other_right + RL_final < (long)S.minpos_oth);
+        if (fine) {  // (what the stretch did not assign stays the caller's)
+            if (!S.dis_set) S.dis_right = real.dis_right;
+            if (!S.oth_set) S.other_right = real.other_right;
+            continue;
+        }
+        work(k, &real);
+        ++again;
+    }
+    c->timer.add("bwa_seed_node_stretches_run_again", 0.0, 0.0, again);
+    if (std::getenv("SQUID_BWA_DEBUG")) {
+        for (int k = 0; k < np; ++k) {
+            std::fprintf(stderr, "stretch %d: records [%zu, %zu) first (%d, %d); seeds:", k, cut[(size_t)k], cut[(size_t)k + 1], hb.refid[cut[(size_t)k]], hb.pos[cut[(size_t)k]]);
+            for (const Node& n : runs[(size_t)k].seeds) std::fprintf(stderr, " (%d %d %d)", n.chr, n.pos, n.len);
+            std::fprintf(stderr, "\n");
+        }
+    }
     reads.clear();
     for (SeedRun& S : runs) { seeds.insert(seeds.end(), S.seeds.begin(), S.seeds.end()); reads.push_back(std::move(S.reads)); }
     c->read_len = runs.back().RL;

@@ -113,6 +113,23 @@ def test_bwa_batch_through_the_gpu_reader(built, synth, tmp_path, monkeypatch, c
     assert texts["0"] == texts["1"] and texts["1"].count("\n") > 1
 
 
+@pytest.mark.parametrize("cfg,extra", [("T2", ()), ("C2", ()), ("T2", ("--seed", "4242")), ("C3", ("--records", "400000"))])
+def test_bwa_record_loops_in_stretches_equal_the_loops_in_one_go(built, synth, tmp_path, cfg, extra):
+    """host only (tools/bwa_pieces_check.cpp, no device): BuildNode_BWA's automaton cut at coverage gaps -- every stretch started on a guess
+    of the few values that cross a gap, checked in order, run again where the guess was wrong (T2: DiscordantRightmost of chromosome 0
+    decides the zero-coverage test on chromosome 1) -- and RawEdges' loop cut behind records that pin LocateRead's position give the
+    nodes with their Support / AvgDepth, the raw edges and the rebuilt fragments of the loops run in one go, for several stretch lengths"""
+    import squid_amd
+
+    exe = tmp_path / "bwa_pieces_check"
+    subprocess.check_call(["hipcc", "-O1", "-std=c++17", "-I", str(squid_amd.ROOT / "include"), "-o", str(exe), str(squid_amd.ROOT / "tools" / "bwa_pieces_check.cpp"),
+                           "-L", str(built), "-lsquid_hip", f"-Wl,-rpath,{built}", "-lpthread"], stderr=subprocess.DEVNULL)
+    pre = synth(cfg, "--bwa", *extra)
+    for piece in ("37", "300", "5000"):
+        out = subprocess.run([str(exe), f"{pre}.bam", piece, "5"], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and out.stdout.strip().endswith("same"), (piece, out.stdout[-2000:])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg,piece", [("T2", "300"), ("C2", "1000"), ("C2", "97")])
 def test_bwa_record_loops_in_stretches_on_the_host_threads(built, synth, tmp_path, monkeypatch, cfg, piece):
