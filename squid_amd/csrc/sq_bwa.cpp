@@ -283,18 +283,41 @@ static int bwa_seed_nodes(sq_ctx* c, const HostBatch& hb, std::vector<Node>& see
     const int np = (int)cut.size() - 1;
     c->timer.add("bwa_seed_node_stretches", 0.0, 0.0, np);
     // A stretch is started on a GUESS of the values that do cross a gap: the outcome of the zero-coverage test for its first record (guess:
-    // true -- then prev0 and the mark are reset by that record itself) and the two "rightmost" values the test compares with (guess: 0).
+    // true -- then prev0 and the mark are reset by that record itself) and the two "rightmost" values the test compares with (the
+    // discordant one: computed in advance, above; the other one: 0).
     // They are stale whenever they matter -- the end of the last discordant / concordant run in front, possibly on an EARLIER CHROMOSOME:
     // the reference compares positions of different chromosomes there (DiscordantRightmost outlives the chromosome, :1002-1013) -- and
     // neither depends on anything the test decides, so every stretch reports what it assigned, the stretches are then walked in order
     // with the real values, and a stretch whose guess was wrong where it counted is run again from the real state.
     struct Carry { int zero, prev0, mark_start, mark_chr, dis_right, other_right; };
+    // DiscordantRightmost is known in advance: it follows a rule of its own -- a discordant record assigns it (or raises it while the
+    // discordant window holds something), and the window is emptied by the first record on another chromosome or more than RL behind it --
+    // that a pass over (filter, pair type, end of the first block) reproduces, stretch by stretch, each from an empty window (a gap
+    // record finds it empty or empties it).  A stretch without a discordant record hands on what it was given.
+    std::vector<int> dis_in((size_t)np + 1, 0);
+    if (np > 1) {
+        std::vector<std::pair<bool, int>> sum((size_t)np, std::make_pair(false, 0));
+        c->pool->parallel_for(np, 1 << 20, [&](int k) {
+            bool nonempty = false, has = false;
+            int dr = 0, last = -1, RL = k == 0 ? c->read_len : RL_final;
+            for (size_t ri = cut[(size_t)k]; ri < cut[(size_t)k + 1]; ++ri) {
+                if (k == 0 && ri < 5) RL = std::max(RL, (int)hb.totlen[ri]);
+                if (!seed_record_passes(hb, ri)) continue;
+                const RecRef r{hb, ri};
+                if (nonempty && (last != r.refid() || dr + RL < r.pos())) nonempty = false;
+                if (!r.pair_concordant()) { const Blk b0 = r.blk(0); const int e0 = b0.refpos + b0.matchref; dr = nonempty ? std::max(dr, e0) : e0; nonempty = true; last = r.refid(); has = true; }
+            }
+            sum[(size_t)k] = std::make_pair(has, dr);
+        });
+        for (int k = 0; k < np; ++k) dis_in[(size_t)k + 1] = sum[(size_t)k].first ? sum[(size_t)k].second : dis_in[(size_t)k];
+    }
     std::vector<SeedRun> runs((size_t)np);
     auto work = [&](int k, const Carry* real) {
         SeedRun& S = runs[(size_t)k];
         S = SeedRun();
         S.RL = k == 0 ? c->read_len : RL_final;
         S.counted = k == 0 ? 0 : 5;
+        S.dis_right = dis_in[(size_t)k];
         if (real) { S.prev0 = real->prev0; S.mark_start = real->mark_start; S.mark_chr = real->mark_chr; S.dis_right = real->dis_right; S.other_right = real->other_right; }
         size_t nblk = 0;
         for (size_t ri = cut[(size_t)k]; ri < cut[(size_t)k + 1]; ++ri) nblk += hb.blk_off[ri + 1] - hb.blk_off[ri];
@@ -310,13 +333,13 @@ static int bwa_seed_nodes(sq_ctx* c, const HostBatch& hb, std::vector<Node>& see
         SeedRun& S = runs[(size_t)k];
         // with `zero` true the first record resets prev0 and the mark by itself; the rightmost values only enter through the position half
         // of later tests, and only until the stretch assigns them (smaller than every position a test came out true at: same outcomes)
-        const bool fine = real.zero && (real.dis_right == 0 || S.minpos_dis == INT32_MAX || (long)real.dis_right + RL_final < (long)S.minpos_dis) &&
+        const bool fine = real.zero && real.dis_right == dis_in[(size_t)k] &&
                           (real.other_right == 0 || S.minpos_oth == INT32_MAX || (long)real.other_right + RL_final < (long)S.minpos_oth);
         if (fine) {  // (what the stretch did not assign stays the caller's)
-            if (!S.dis_set) S.dis_right = real.dis_right;
             if (!S.oth_set) S.other_right = real.other_right;
             continue;
         }
+        if (std::getenv("SQUID_BWA_DEBUG")) std::fprintf(stderr, "stretch %d (%d, %d) again: zero %d, rightmost values %d / %d against first true tests at %d / %d\n", k, hb.refid[cut[(size_t)k]], hb.pos[cut[(size_t)k]], real.zero, real.dis_right, real.other_right, S.minpos_dis, S.minpos_oth);
         work(k, &real);
         ++again;
     }

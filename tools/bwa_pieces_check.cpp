@@ -3,6 +3,7 @@
 #include "../squid_amd/csrc/sq_internal.h"
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 using namespace sq;
 int main(int argc, char** argv) {
     if (argc < 3) return 2;
@@ -28,6 +29,8 @@ int main(int argc, char** argv) {
         if (rc) { std::printf("mode %d: rc %d %s\n", mode, rc, c.err.c_str()); return 1; }
         nodes[mode] = c.nodes; frags[mode] = c.frags;
         std::sort(raw[mode].begin(), raw[mode].end(), [](const Edge& x, const Edge& y) { return edge_key_less(x, y) || (edge_key_eq(x, y) && x.w < y.w); });
+        for (size_t t = 0; t < c.timer.names.size(); ++t) if (std::strstr(c.timer.names[t], "stretches")) { std::printf("   %s: %lld\n", c.timer.names[t], (long long)c.timer.launches[t]); }
+        c.timer.clear();
         std::printf("mode %d: %zu records, %zu nodes, %zu raw edges, %zu fragments, read_len %d\n", mode, all->size(), nodes[mode].size(), raw[mode].size(), frags[mode].size(), c.read_len);
     }
     int bad = 0;
