@@ -512,8 +512,20 @@ static int bwa_raw_edges(sq_ctx* c, const HostBatch& hb, std::vector<Edge>& raw)
     c->timer.add("bwa_raw_edge_stretches", 0.0, 0.0, np);  // (how many stretches the loop ran in: tests)
     std::vector<Piece> pieces((size_t)np);
     for (int k = 0; k < np; ++k) pieces[(size_t)k].hint = start[(size_t)k];
-    if (np > 1) c->pool->parallel_for(np, 1 << 20, [&](int k) { run(cut[(size_t)k], cut[(size_t)k + 1], pieces[(size_t)k]); });
-    else run(0, nrec, pieces[0]);
+    // (the edges of a stretch are summed per key before they are strung together -- BuildEdges sorts the list and adds the weights of equal
+    // keys up, :1943-1957, so neither the order nor the grouping of the addends shows; tens of millions of unit edges shrink to the
+    // distinct keys of the stretch.  Nothing is dropped here: a sum <= 0 is only final when every stretch and the -1 edges are in)
+    std::vector<int64_t> emitted((size_t)np, 0);
+    auto presum = [](std::vector<Edge>& v) {
+        std::sort(v.begin(), v.end(), edge_key_less);
+        size_t o = 0;
+        for (size_t i = 0; i < v.size(); ++i) { if (o && edge_key_eq(v[i], v[o - 1])) v[o - 1].w += v[i].w; else v[o++] = v[i]; }
+        v.resize(o);
+    };
+    if (np > 1) c->pool->parallel_for(np, 1 << 20, [&](int k) { run(cut[(size_t)k], cut[(size_t)k + 1], pieces[(size_t)k]); emitted[(size_t)k] = (int64_t)pieces[(size_t)k].raw.size(); if (!pieces[(size_t)k].rc) presum(pieces[(size_t)k].raw); });
+    else { run(0, nrec, pieces[0]); emitted[0] = (int64_t)pieces[0].raw.size(); }
+    int64_t n_emitted = 0;
+    for (int64_t e : emitted) n_emitted += e;
     int hint = 0;
     std::vector<Frag> partial;
     std::vector<std::string> first_dis, second_names;
@@ -528,6 +540,7 @@ static int bwa_raw_edges(sq_ctx* c, const HostBatch& hb, std::vector<Edge>& raw)
         second_edges.insert(second_edges.end(), P.second_edges.begin(), P.second_edges.end());
         hint = P.hint;
     }
+    const size_t raw_strung = raw.size();
     auto add = [&](int i, bool hi, int j, bool hj, int w) -> int {
         if (!in_range(i) || !in_range(j)) return fail(c, SQ_E_ASSERT, "an edge would leave the node table (the reference asserts, SegmentGraph.cpp:1760)");
         raw.push_back(make_edge(i, hi, j, hj, w));
@@ -577,6 +590,7 @@ static int bwa_raw_edges(sq_ctx* c, const HostBatch& hb, std::vector<Edge>& raw)
     std::sort(c->chim_names.begin(), c->chim_names.end());
     c->chim_names.erase(std::unique(c->chim_names.begin(), c->chim_names.end()), c->chim_names.end());
     c->counts.n_chim_fragments = (int64_t)rebuilt.size();
+    c->counts.n_raw_edges = n_emitted + (int64_t)(raw.size() - raw_strung);  // (as the loops emitted them: the stretches' edges arrive summed)
     return SQ_OK;
 }
 

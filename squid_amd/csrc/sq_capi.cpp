@@ -181,9 +181,9 @@ static int build_graph_bwa(sq_ctx* c) {
     std::vector<Edge> raw;
     int rc = bwa_nodes_and_edges(c, raw);
     if (rc) return rc;
-    c->counts.n_raw_edges = (int64_t)raw.size();
+    // (counts.n_raw_edges: set by bwa_raw_edges -- the edges as the loop emitted them; `raw` arrives summed per stretch)
     c->edges.clear();
-    { HostClock hc(c, "host_edge_reduce"); reduce_edges(raw, c->edges); }
+    { HostClock hc(c, "host_edge_reduce"); reduce_edges(raw, c->edges, c->pool ? std::min(c->pool->size() + 1, 32) : 1); }
     c->counts.n_unique_edges = (int64_t)c->edges.size();
     if (c->keep_stages) c->snap[2].take(c->nodes, c->edges, nullptr);
     static const bool host_filters = std::getenv("SQUID_HOST_FILTERS") != nullptr;

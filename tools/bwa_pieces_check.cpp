@@ -28,10 +28,10 @@ int main(int argc, char** argv) {
         const int rc = bwa_nodes_and_edges(&c, raw[mode]);
         if (rc) { std::printf("mode %d: rc %d %s\n", mode, rc, c.err.c_str()); return 1; }
         nodes[mode] = c.nodes; frags[mode] = c.frags;
-        std::sort(raw[mode].begin(), raw[mode].end(), [](const Edge& x, const Edge& y) { return edge_key_less(x, y) || (edge_key_eq(x, y) && x.w < y.w); });
+        { std::vector<Edge> summed; reduce_edges(raw[mode], summed); raw[mode].swap(summed); }  // (BuildEdges' sort + sum + drop, :1943-1957: what the list is for)
         for (size_t t = 0; t < c.timer.names.size(); ++t) if (std::strstr(c.timer.names[t], "stretches")) { std::printf("   %s: %lld\n", c.timer.names[t], (long long)c.timer.launches[t]); }
         c.timer.clear();
-        std::printf("mode %d: %zu records, %zu nodes, %zu raw edges, %zu fragments, read_len %d\n", mode, all->size(), nodes[mode].size(), raw[mode].size(), frags[mode].size(), c.read_len);
+        std::printf("mode %d: %zu records, %zu nodes, %zu edges after BuildEdges' reduction, %zu fragments, read_len %d\n", mode, all->size(), nodes[mode].size(), raw[mode].size(), frags[mode].size(), c.read_len);
     }
     int bad = 0;
     if (nodes[0].size() != nodes[1].size()) { std::printf("node counts differ\n"); bad = 1; }
