@@ -412,8 +412,7 @@ static int bwa_raw_edges(sq_ctx* c, const HostBatch& hb, std::vector<Edge>& raw)
         part = false;
         if (r.dup() || !r.mapped()) return 0;
         if (r.first() ? (r.multi() || hb.mapq[ri] == 0) : !r.multi()) return 0;  // :1723-1726 (W5)
-        f.name = r.qname();
-        std::vector<Blk>& own = r.first() ? f.a : f.b;
+        std::vector<Blk>& own = r.first() ? f.a : f.b;  // (f.name: given by the caller where a list keeps it -- two std::strings per record otherwise, most of this loop's time)
         for (size_t k = 0; k < r.nblk(); ++k) own.push_back(r.blk(k));
         std::sort(own.begin(), own.end(), blk_less_readpos);
         (r.first() ? f.atot : f.btot) = r.totlen();
@@ -446,7 +445,7 @@ static int bwa_raw_edges(sq_ctx* c, const HostBatch& hb, std::vector<Edge>& raw)
             Frag f;
             bool part;
             const int kind = prepare(ri, f, part);
-            if (part) P.partial.push_back(f);
+            if (part) { f.name = RecRef{hb, ri}.qname(); P.partial.push_back(f); }
             if (kind == 0) continue;  // (a record that locates nothing leaves nothing else behind: its mate stub is only looked at by LocateRead)
             finish_prepare(ri, f, kind);
             const size_t na = f.a.size();
@@ -464,7 +463,7 @@ static int bwa_raw_edges(sq_ctx* c, const HostBatch& hb, std::vector<Edge>& raw)
                     const int i = rn[na - 1], j = rn.back();
                     if (i != j && i != -1 && j != -1 && !pair_overlap(f, rn, i, j)) {
                         if (!add(i, f.a.back().rev, j, f.b.back().rev, 1)) return;
-                        if (discordant(P.raw.back())) P.first_dis.push_back(f.name);
+                        if (discordant(P.raw.back())) P.first_dis.push_back(RecRef{hb, ri}.qname());
                     }
                 }
             } else {
@@ -478,7 +477,7 @@ static int bwa_raw_edges(sq_ctx* c, const HostBatch& hb, std::vector<Edge>& raw)
                     if (i != j && i != -1 && j != -1 && !overlap) {
                         if (!in_range(i) || !in_range(j)) { P.rc = SQ_E_ASSERT; P.err = "an edge would leave the node table (the reference asserts, SegmentGraph.cpp:1852)"; return; }
                         const Edge e = make_edge(i, f.a.back().rev, j, f.b.back().rev, -1);
-                        if (discordant(e)) { P.second_names.push_back(f.name); P.second_edges.push_back(e); }
+                        if (discordant(e)) { P.second_names.push_back(RecRef{hb, ri}.qname()); P.second_edges.push_back(e); }
                     }
                 }
             }
