@@ -17,6 +17,7 @@
 // one-way depth cursor.
 #include <algorithm>
 #include <cstdint>
+#include <chrono>
 #include <cstring>
 
 #include "sq_internal.h"
@@ -441,8 +442,9 @@ static int bwa_raw_edges(sq_ctx* c, const HostBatch& hb, std::vector<Edge>& raw)
             }
             return true;
         };
+        Frag f;  // (one object for the stretch, emptied per record: its two block lists keep their storage -- a fresh Frag per record was two or three allocations per record on every thread)
         for (size_t ri = lo; ri < hi; ++ri) {
-            Frag f;
+            f.a.clear(); f.b.clear(); f.name.clear(); f.atot = 0; f.btot = 0; f.alow = false; f.blow = false;
             bool part;
             const int kind = prepare(ri, f, part);
             if (part) { f.name = RecRef{hb, ri}.qname(); P.partial.push_back(f); }
@@ -483,6 +485,8 @@ static int bwa_raw_edges(sq_ctx* c, const HostBatch& hb, std::vector<Edge>& raw)
             }
         }
     };
+    const auto t_re0 = std::chrono::steady_clock::now();
+    auto re_lap = [&](const char* what) { if (std::getenv("SQUID_BWA_DEBUG")) std::fprintf(stderr, "RawEdges: %-28s at %8.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_re0).count()); };
     // stretch boundaries: behind the nearest record in front of an even cut that pins the position (looked for among the 4096 records
     // in front of the cut; none there: that cut is left out).  SQUID_BWA_PIECE=<records> sets the stretch length (tests: small inputs)
     const long piece_env = std::getenv("SQUID_BWA_PIECE") ? std::atol(std::getenv("SQUID_BWA_PIECE")) : 0;
@@ -507,6 +511,7 @@ static int bwa_raw_edges(sq_ctx* c, const HostBatch& hb, std::vector<Edge>& raw)
         }
     }
     cut.push_back(nrec);
+    re_lap("stretches planned");
     const int np = (int)cut.size() - 1;
     c->timer.add("bwa_raw_edge_stretches", 0.0, 0.0, np);  // (how many stretches the loop ran in: tests)
     std::vector<Piece> pieces((size_t)np);
@@ -525,6 +530,7 @@ static int bwa_raw_edges(sq_ctx* c, const HostBatch& hb, std::vector<Edge>& raw)
     else { run(0, nrec, pieces[0]); emitted[0] = (int64_t)pieces[0].raw.size(); }
     int64_t n_emitted = 0;
     for (int64_t e : emitted) n_emitted += e;
+    re_lap("record loop");
     int hint = 0;
     std::vector<Frag> partial;
     std::vector<std::string> first_dis, second_names;
@@ -540,6 +546,7 @@ static int bwa_raw_edges(sq_ctx* c, const HostBatch& hb, std::vector<Edge>& raw)
         hint = P.hint;
     }
     const size_t raw_strung = raw.size();
+    re_lap("stretches strung");
     auto add = [&](int i, bool hi, int j, bool hj, int w) -> int {
         if (!in_range(i) || !in_range(j)) return fail(c, SQ_E_ASSERT, "an edge would leave the node table (the reference asserts, SegmentGraph.cpp:1760)");
         raw.push_back(make_edge(i, hi, j, hj, w));
@@ -589,6 +596,7 @@ static int bwa_raw_edges(sq_ctx* c, const HostBatch& hb, std::vector<Edge>& raw)
     std::sort(c->chim_names.begin(), c->chim_names.end());
     c->chim_names.erase(std::unique(c->chim_names.begin(), c->chim_names.end()), c->chim_names.end());
     c->counts.n_chim_fragments = (int64_t)rebuilt.size();
+    re_lap("fragments rebuilt");
     c->counts.n_raw_edges = n_emitted + (int64_t)(raw.size() - raw_strung);  // (as the loops emitted them: the stretches' edges arrive summed)
     return SQ_OK;
 }
