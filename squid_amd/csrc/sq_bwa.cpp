@@ -564,10 +564,16 @@ static int bwa_raw_edges(sq_ctx* c, const HostBatch& hb, std::vector<Edge>& raw)
         if (std::binary_search(first_dis.begin(), first_dis.end(), second_names[k])) raw.push_back(second_edges[k]);
     // the fragments of the partially aligned reads: grouped by name (the sort of :1883 is libstdc++'s introsort on the names, ledger B8),
     // merged, stored untrimmed, located from the hint the loop above left behind (W4); the last group is dropped (W3)
-    std::sort(partial.begin(), partial.end(), [](const Frag& x, const Frag& y) { return x.name < y.name; });
+    // (what is sorted is the index of every fragment with the same comparison: introsort takes the same decisions, hence the same order, without
+    // moving 100-byte objects around; `name < name` is a strict weak order, so the threaded form with the split final pass applies, sq_parsort.h)
+    std::vector<uint32_t> by_name(partial.size());
+    for (size_t i = 0; i < by_name.size(); ++i) by_name[i] = (uint32_t)i;
+    std_sort_parallel(by_name.begin(), by_name.end(), [&](uint32_t x, uint32_t y) { return partial[x].name < partial[y].name; }, c->pool ? std::min(c->pool->size() + 1, 32) : 1, true);
+    re_lap("partial reads sorted by name");
     std::vector<Frag> rebuilt;
     Frag cur;
-    for (const Frag& p : partial) {
+    for (const uint32_t pi : by_name) {
+        const Frag& p = partial[pi];
         if (cur.a.empty() && cur.b.empty()) { cur = p; continue; }
         if (cur.name == p.name) { cur.a.insert(cur.a.end(), p.a.begin(), p.a.end()); cur.b.insert(cur.b.end(), p.b.begin(), p.b.end()); continue; }
         std::sort(cur.a.begin(), cur.a.end(), blk_less_readpos);
@@ -643,6 +649,16 @@ int bwa_breakpoint_support(sq_ctx* c, const std::vector<std::pair<int, int>>& bp
         }
         return lo < names.size() && names[lo].size() == L && std::memcmp(names[lo].data(), p, L) == 0;
     };
+    // (in front of the binary search: one bit per name hash -- 15 k names in 4 M bits; all but one record in a few thousand end here)
+    auto hash_of = [](const char* p, size_t L) { unsigned long long h = 1469598103934665603ull; for (size_t i = 0; i < L; ++i) { h ^= (unsigned char)p[i]; h *= 1099511628211ull; } h ^= h >> 29; return h; };
+    const size_t nbits = (size_t)1 << 22;
+    std::vector<uint64_t> maybe(nbits / 64, 0);
+    for (const std::string& nm : names) { const unsigned long long h = hash_of(nm.data(), nm.size()) & (nbits - 1); maybe[h >> 6] |= 1ull << (h & 63); }
+    auto in_names_fast = [&](size_t ri) {
+        const char* p = hb.names.data() + hb.name_off[ri];
+        const unsigned long long h = hash_of(p, hb.name_off[ri + 1] - hb.name_off[ri]) & (nbits - 1);
+        return ((maybe[h >> 6] >> (h & 63)) & 1) && in_names(ri);
+    };
     const size_t nrec = hb.size();
     std::vector<uint8_t> look(nrec, 0);
     auto decide = [&](size_t lo, size_t hi) {
@@ -651,7 +667,7 @@ int bwa_breakpoint_support(sq_ctx* c, const std::vector<std::pair<int, int>>& bp
             if (r.multi() || (int)hb.mapq[ri] < c->P.min_mapqual || r.dup() || !r.mapped() || r.refid() == -1) continue;
             const bool same_chr_mate = r.mate_mapped() && r.mrefid() == r.refid();
             if (same_chr_mate && (r.mpos() > r.pos() || (r.mpos() == r.pos() && (r.flag() & 0x80)))) continue;  // only the right-hand record of a pair
-            if (!names.empty() && in_names(ri)) continue;
+            if (!names.empty() && in_names_fast(ri)) continue;
             look[ri] = 1;
         }
     };
