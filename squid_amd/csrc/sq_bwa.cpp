@@ -673,19 +673,52 @@ int bwa_breakpoint_support(sq_ctx* c, const std::vector<std::pair<int, int>>& bp
     };
     if (c->pool && nrec > 100000) { const int np = 8 * (c->pool->size() + 1); c->pool->parallel_for(np, 1 << 20, [&](int k) { decide(nrec * (size_t)k / (size_t)np, nrec * ((size_t)k + 1) / (size_t)np); }); }
     else decide(0, nrec);
-    size_t cur = 0;
-    for (size_t ri = 0; ri < nrec; ++ri) {
-        if (!look[ri]) continue;
-        const RecRef r{hb, ri};
-        const bool same_chr_mate = r.mate_mapped() && r.mrefid() == r.refid();
-        if (cur == bps.size()) break;
-        const int chr = r.refid(), start = same_chr_mate ? r.mpos() : r.pos(), end = hb.endpos[ri];
-        if (chr > bps[cur].first || (chr == bps[cur].first && start > bps[cur].second + c->P.concord_dist_pos)) ++cur;
-        for (size_t k = cur; k < bps.size(); ++k) {
-            if (chr == bps[k].first && start <= bps[k].second && end > bps[k].second) ++cov[k];
-            else if (chr < bps[k].first || (chr == bps[k].first && end <= bps[k].second)) break;
+    // The walk itself: the cursor moves one entry per record at most and never back (:3157), so where it stands depends on every record
+    // before -- but it is a small number that a walk from 0 over a few ten thousand records in front of a stretch usually reproduces (two
+    // cursors fed the same records never cross, and meet for good once the one behind has caught up).  Every stretch walks from such a
+    // guess into counts of its own; the stretches are then checked in order -- a guess that is not the cursor the stretch in front ended
+    // with: that stretch is walked again from the real one -- and the counts added up.
+    auto walk = [&](size_t lo, size_t hi, size_t cur, std::vector<int32_t>* into) -> size_t {
+        for (size_t ri = lo; ri < hi; ++ri) {
+            if (!look[ri]) continue;
+            if (cur == bps.size()) break;
+            const RecRef r{hb, ri};
+            const bool same_chr_mate = r.mate_mapped() && r.mrefid() == r.refid();
+            const int chr = r.refid(), start = same_chr_mate ? r.mpos() : r.pos(), end = hb.endpos[ri];
+            if (chr > bps[cur].first || (chr == bps[cur].first && start > bps[cur].second + c->P.concord_dist_pos)) ++cur;
+            if (!into) continue;
+            for (size_t k = cur; k < bps.size(); ++k) {
+                if (chr == bps[k].first && start <= bps[k].second && end > bps[k].second) ++(*into)[k];
+                else if (chr < bps[k].first || (chr == bps[k].first && end <= bps[k].second)) break;
+            }
         }
+        return cur;
+    };
+    const long piece_env = std::getenv("SQUID_BWA_PIECE") ? std::atol(std::getenv("SQUID_BWA_PIECE")) : 0;  // (tests: short stretches and a short warm-up on small inputs)
+    const int np = !c->pool ? 1 : piece_env > 0 ? (int)std::min<size_t>(4096, std::max<size_t>(1, nrec / (size_t)piece_env)) : (nrec > 400000 ? 4 * (c->pool->size() + 1) : 1);
+    const size_t warm_len = piece_env > 0 ? (size_t)piece_env : 65536;
+    if (np == 1) { walk(0, nrec, 0, &cov); return SQ_OK; }
+    auto lo_of = [&](int k) { return nrec * (size_t)k / (size_t)np; };
+    struct Part { size_t guess = 0, end = 0; std::vector<int32_t> cov; };
+    std::vector<Part> parts((size_t)np);
+    c->pool->parallel_for(np, 1 << 20, [&](int k) {
+        Part& P = parts[(size_t)k];
+        const size_t lo = lo_of(k), warm = lo > warm_len ? lo - warm_len : 0;
+        P.guess = k == 0 ? 0 : walk(warm, lo, 0, nullptr);
+        P.cov.assign(bps.size(), 0);
+        P.end = walk(lo, lo_of(k + 1), P.guess, &P.cov);
+    });
+    int again = 0;
+    for (int k = 1; k < np; ++k) {
+        Part& P = parts[(size_t)k];
+        const size_t real = parts[(size_t)k - 1].end;
+        if (P.guess == real) continue;
+        P.cov.assign(bps.size(), 0);
+        P.end = walk(lo_of(k), lo_of(k + 1), real, &P.cov);
+        ++again;
     }
+    c->timer.add("bwa_bp_support_stretches_walked_again", 0.0, 0.0, again);
+    for (const Part& P : parts) for (size_t k = 0; k < bps.size(); ++k) cov[k] += P.cov[k];
     return SQ_OK;
 }
 

@@ -151,6 +151,7 @@ def test_bwa_record_loops_in_stretches_on_the_host_threads(built, synth, tmp_pat
         t = ctx.timing()
         stretches = (t.get("bwa_raw_edge_stretches", {}).get("launches", 0), t.get("bwa_seed_node_stretches", {}).get("launches", 0))
         assert stretches[0] > 3 and stretches[1] > 3, stretches
+        assert "bwa_bp_support_stretches_walked_again" in t  # (ExactBPConcordantSupport's walk took the stretched form too; the breakpoint table was compared above)
 
 
 @pytest.mark.gpu
