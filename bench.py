@@ -27,6 +27,8 @@ generator config C3 (50.8 M concordant records, zlib level 6), the largest singl
                    compared with the timed steps' (`--cpu-sample-records N` times it on a smaller sample instead)
   dense            (default invocation, N = 1) BASELINE.json configs[4] -- C5, 100 M records, -w 1 -a 50 -- as a sub-record: from-file
                    steps, resident pass, components/s, `_sv.txt` of a 1 M-record sample of it compared with the CPU oracle
+  bwa              (default invocation, N = 1) `squid --bwa` on the C3 sample in the shape `bwa mem` writes, as a
+                   sub-record: from-file steps, `_sv.txt` of a 1 M-record sample of it compared with the CPU oracle
 
 N > 1 (`--gpus N`; the script launches its own ranks through torch.distributed.run when WORLD_SIZE is not set):
 ONE sample sharded by chromosome (BASELINE.json configs[3] layout), rank r decodes and holds the records of a
@@ -74,8 +76,8 @@ WORKLOADS = {
 DENSE = {"min_edge_weight": 1, "max_allowed_degree": 50}  # -w 1 -a 50
 
 
-def synth(config: str, seed: int, outdir: Path, records: int | None = None, level: int | None = None, tsv: int | None = None, support: str | None = None) -> Path:
-    pre = outdir / (f"{config}_s{seed}" + (f"_r{records}" if records else "") + (f"_t{tsv}" if tsv else "") + (f"_l{level}" if level is not None else "") + (f"_u{support.replace(',', '-')}" if support else ""))
+def synth(config: str, seed: int, outdir: Path, records: int | None = None, level: int | None = None, tsv: int | None = None, support: str | None = None, bwa: bool = False) -> Path:
+    pre = outdir / (f"{config}{'bwa' if bwa else ''}_s{seed}" + (f"_r{records}" if records else "") + (f"_t{tsv}" if tsv else "") + (f"_l{level}" if level is not None else "") + (f"_u{support.replace(',', '-')}" if support else ""))
     if not Path(f"{pre}.bam").exists():
         tmp = Path(f"{pre}.tmp{os.getpid()}")
         cmd = [str(BUILD / "gen_synth_bam"), "--config", config, "--seed", str(seed), "--out", str(tmp), "--threads", str(max(1, os.cpu_count() or 8))]
@@ -87,9 +89,12 @@ def synth(config: str, seed: int, outdir: Path, records: int | None = None, leve
             cmd += ["--level", str(level)]
         if support:
             cmd += ["--support", support]
+        if bwa:
+            cmd += ["--bwa"]
         subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
         for ext in (".chim.bam", ".truth.txt", ".bam.bai", ".bam"):
-            os.replace(f"{tmp}{ext}", f"{pre}{ext}")
+            if os.path.exists(f"{tmp}{ext}"):  # (--bwa: one file, no chimeric BAM)
+                os.replace(f"{tmp}{ext}", f"{pre}{ext}")
     return pre
 
 
@@ -226,6 +231,68 @@ def dense_record(work: Path, local_rank: int, note, steps: int = 3, records: int
     return rec
 
 
+def bwa_record(work: Path, local_rank: int, note, steps: int = 3, sample_records: int = 1_000_000) -> dict:
+    """`squid --bwa` (one coordinate-sorted file, split reads as supplementary records) at the size of C3 as a sub-record
+    of the bench line: steps from the file (GPU reader with the QNAMEs kept, the mode's record loops in stretches on the host threads, the
+    shared graph kernels), and the `_sv.txt` of a 1 M-record sample of the same generator mode against the CPU oracle
+    (the full-size comparison: profiles/r05_bwa_C3.json, tools/bwa_probe.py)."""
+    import squid_amd
+
+    t0 = time.perf_counter()
+    pre = synth("C3", 20180003, work, bwa=True)
+    t_gen = time.perf_counter() - t0
+    note(f"--bwa sample generated: {pre} ({t_gen:.0f} s)")
+    ctx = squid_amd.Context(device=local_rank, star_mapq=False, min_mapqual=1)
+    ctx.keep_stage_graphs(False)
+
+    def step() -> str:
+        squid_amd.drop_file_cache()
+        ctx.clear_records()
+        ctx.load_bwa(f"{pre}.bam", threads=max(1, os.cpu_count() or 8))
+        ctx.build_graph()
+        ctx.order_sizes()
+        text = ctx.sv_text_fast()
+        with open(work / "bwa_sv.txt", "w") as f:
+            f.write(text)
+        return text
+
+    step()
+    ctx.timing_accumulate(True)
+    digests, ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        t1 = time.perf_counter()
+        text = step()
+        digests.append(hashlib.sha256(text.encode()).hexdigest())
+        ms.append((time.perf_counter() - t1) * 1e3)
+    elapsed = time.perf_counter() - t0
+    e2e = {k: dict(v) for k, v in ctx.timing().items()}
+    counts = ctx.counts()
+    ctx.close()
+    n_aln = counts["n_concordant"]
+    note(f"--bwa: {elapsed / steps * 1e3:.0f} ms per step")
+    rec = {"workload": "gen_synth_bam --config C3 --bwa (hg38, one BAM file, split reads as supplementary records)", "flags": "--bwa", "records": int(n_aln), "steps": steps,
+           "value": n_aln * steps / elapsed, "unit": "alignments/s", "ms_per_step": elapsed / steps * 1e3, "ms_each": [round(x, 1) for x in ms],
+           "steps_identical": len(set(digests)) == 1, "sv_sha256": digests[0], "sv_rows": text.count("\n") - 1, "ingest_through_gpu_reader": bool(counts["chimeric_through_gpu_reader"]),
+           "stage_ms_per_step": {k: round(v["ms"] / steps, 2) for k, v in sorted(e2e.items(), key=lambda kv: -kv[1]["ms"]) if k not in INGEST_KERNELS and v["ms"] / steps >= 5.0},
+           "stretches_per_step": {k: v["launches"] / steps for k, v in e2e.items() if "stretches" in k}, "synth_s": round(t_gen, 1)}
+    spre = synth("C3", 20180003, work, sample_records, bwa=True)
+    pin = ["taskset", "-c", "0"] if shutil.which("taskset") else []
+    t0 = time.perf_counter()
+    subprocess.check_call(pin + [str(BUILD / "squid_oracle"), "--bwa", "-b", f"{spre}.bam", "-o", str(work / "bwa_cpu")], stdout=subprocess.DEVNULL)
+    tc = time.perf_counter() - t0
+    oracle_text = (work / "bwa_cpu_sv.txt").read_text()
+    with squid_amd.Context(device=local_rank, star_mapq=False, min_mapqual=1) as c2:
+        c2.load_bwa(f"{spre}.bam")
+        c2.build_graph()
+        c2.order_sizes()
+        small_text = c2.sv_text_fast()
+        n_s = c2.counts()["n_concordant"]
+    rec["cpu_baseline"] = {"value": n_s / tc, "unit": "alignments/s", "cores": 1, "kind": "port", "sample": f"C3 --bwa generated with --records {sample_records} ({n_s} records), {tc:.2f} s",
+                           "sv_identical_to_gpu": oracle_text == small_text, "sv_rows": oracle_text.count("\n") - 1}
+    return rec
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -244,6 +311,7 @@ def main() -> None:
     ap.add_argument("--level", type=int, default=None, help="zlib level of the synthetic BAM (generator --level; 0 = stored blocks: SURVEY.md 8(d)'s variant that separates inflate from parse cost)")
     ap.add_argument("--staged-steps", type=int, default=8, help="steps of the staged variant (compressed BAM bytes already in HBM) behind the timed from-file steps; at most --steps")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-config sub-record (C5, BASELINE.json configs[4]) that the default invocation appends")
+    ap.add_argument("--no-bwa", action="store_true", help="skip the --bwa sub-record (the C3 sample in the shape `bwa mem` writes, read in --bwa mode) that the default invocation appends")
     ap.add_argument("--dense-records", type=int, default=None, help="record count of the dense sub-record (generator --records; default: the config's 100 M)")
     ap.add_argument("--workdir", default=None)
     a = ap.parse_args()
@@ -557,6 +625,8 @@ def main() -> None:
             out["components"]["ambiguous"] = int(ostats["ambiguous"])
     if world == 1 and a.workload == "C3" and not a.records and not a.no_dense:
         out["dense"] = dense_record(work, local_rank, note, records=a.dense_records)
+    if world == 1 and a.workload == "C3" and not a.records and not a.no_bwa:
+        out["bwa"] = bwa_record(work, local_rank, note)
     if dist:
         dist.destroy_process_group()
     print(json.dumps(out))
