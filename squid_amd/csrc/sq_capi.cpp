@@ -1190,6 +1190,10 @@ int sq_clear_records(sq_ctx* c) {
     int rc = sq_reset(c);
     if (rc) return rc;
     dev_clear_records(c);
+    if (c->bwa) {  // (a --bwa batch is gigabytes in fourteen arrays: unmapped behind the caller's back, 0.2 s at C3 otherwise)
+        auto* junk = new std::shared_ptr<HostBatch>(std::move(c->bwa));
+        std::thread([junk]() { delete junk; }).detach();
+    }
     c->bwa.reset();
     const int64_t side_by_side = c->counts.token_passes_side_by_side;  // (a property of the process, not of the records)
     c->counts = sq_counts{};

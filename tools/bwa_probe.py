@@ -22,6 +22,8 @@ with squid_amd.Context(star_mapq=False, min_mapqual=1) as ctx:
     ctx.keep_stage_graphs(False)
     for it in range(steps + 1):
         ctx.clear_records()
+        if "--drop" in sys.argv:
+            squid_amd.drop_file_cache()  # (as bench.py's steps: nothing kept from earlier reads of the file)
         t0 = time.perf_counter()
         ctx.load_bwa(f"{pre}.bam", threads=16)
         t1 = time.perf_counter()
