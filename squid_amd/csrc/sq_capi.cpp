@@ -1121,8 +1121,9 @@ int sq_ingest_bwa_file(sq_ctx* c, const char* path, int32_t n_threads) {
     if (c->shard.on) return fail(c, SQ_E_ARG, "--bwa input is not chromosome-sharded");
     if (c->ref_len.empty()) return fail(c, SQ_E_ARG, "sq_set_references first");
     { int r0 = sq_set_source(c, path); if (r0) return r0; }
-    std::shared_ptr<HostBatch> all = std::make_shared<HostBatch>();
-    all->blk_off.assign(1, 0); all->name_off.assign(1, 0);
+    std::shared_ptr<HostBatch> all = c->bwa_spare ? std::move(c->bwa_spare) : std::make_shared<HostBatch>();
+    c->bwa_spare.reset();
+    // (the arrays keep their storage -- and, on the way through the GPU reader, their sizes: every element is overwritten by the copy back)
     {   // a file of 1 GiB and more through the GPU reader (SQUID_BWA_GPU=1 / =0 forces / forbids it): BGZF inflate, record boundaries and the
         // record parse on the device, the QNAMEs kept next to the records (sq_ctx::capture_names, as for a large chimeric BAM), one copy
         // back -- the batch the host decoder below makes, field for field; the two order-dependent loops of the mode then run on it
@@ -1190,10 +1191,9 @@ int sq_clear_records(sq_ctx* c) {
     int rc = sq_reset(c);
     if (rc) return rc;
     dev_clear_records(c);
-    if (c->bwa) {  // (a --bwa batch is gigabytes in fourteen arrays: unmapped behind the caller's back, 0.2 s at C3 otherwise)
-        auto* junk = new std::shared_ptr<HostBatch>(std::move(c->bwa));
-        std::thread([junk]() { delete junk; }).detach();
-    }
+    // (a --bwa batch is gigabytes in fourteen arrays: the context keeps its storage for the next --bwa ingest -- unmapping it and faulting
+    // fresh pages in again was 0.25 s per sample at C3 --; sq_release_reader_buffers gives it back)
+    if (c->bwa && c->bwa.use_count() == 1) c->bwa_spare = std::move(c->bwa);
     c->bwa.reset();
     const int64_t side_by_side = c->counts.token_passes_side_by_side;  // (a property of the process, not of the records)
     c->counts = sq_counts{};
@@ -1389,6 +1389,7 @@ int sq_release_reader_buffers(sq_ctx* c) {
     c->staged_path.clear(); c->staged_bytes = 0;
     drop_whole_file_scratch();
     if (!c->chim_future.valid()) c->chim_decoded.reset();  // (a pairing still running reads it)
+    c->bwa_spare.reset();
     return dev_release_reader(c);
 }
 int sq_keep_stage_graphs(sq_ctx* c, int32_t on) {

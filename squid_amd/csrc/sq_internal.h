@@ -200,7 +200,7 @@ struct sq_ctx {
     // concordant side (device)
     sq::DeviceRecords* dev = nullptr;
     // --bwa (sq_ingest_bwa_file): every record of the one BAM file on the host, with its QNAME (sq_bwa.cpp)
-    std::shared_ptr<sq::HostBatch> bwa;
+    std::shared_ptr<sq::HostBatch> bwa, bwa_spare;  // bwa_spare: the storage of the last --bwa batch, kept by sq_clear_records for the next one
     std::shared_ptr<sq::HostBatch> chim_decoded;  // the chimeric records as the GPU reader decoded them (sq_ingest_files), kept for the next call's pages
     // graph state (host, small)
     std::vector<sq::Node> nodes;
