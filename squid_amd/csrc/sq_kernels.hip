@@ -3044,7 +3044,7 @@ struct FileFeeder {
         // (while the pairing of a large chimeric BAM runs on the host threads -- sq_ingest_files, the chimeric records came through this
         // reader just before -- the file is not what the step waits for and the readers only take CPU time from what it does wait for:
         // a third of the share.  Dense config, load 1.11-1.27 s with the full share, 0.95-1.08 s with five readers, same boxes, interleaved)
-        if (env_t <= 0 && c->chim_pairing_running) T = std::max(4, T / 3);
+        if (env_t <= 0 && c->chim_pairing_running) T = std::max(std::min(T, 4), T / 3);  // (never more than the share)
         T = std::max(2, std::min({T, 16, (int)DeviceRecords::FEED_THREADS_MAX, (int)npieces}));
         if (env_t > 0) T = std::max(1, std::min({env_t, (int)DeviceRecords::FEED_THREADS_MAX, (int)npieces}));
         if (npieces < 2) T = 1;
