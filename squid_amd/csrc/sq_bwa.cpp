@@ -212,8 +212,6 @@ void seed_step(SeedRun& S, const HostBatch& hb, size_t ri, bool closing, int ope
         if (!S.oth_set) S.minpos_oth = std::min(S.minpos_oth, r.pos());
     }
     if (closing) S.closing_zero = zero;
-    { static const long trace = std::getenv("SQUID_BWA_TRACE") ? std::atol(std::getenv("SQUID_BWA_TRACE")) : -1;
-      if (trace >= 0 && (long)ri >= trace && (long)ri < trace + 3) std::fprintf(stderr, "record %zu (%d, %d) closing %d: zero %d cur_chr %d rightmost %d (dis %d other %d) RL %d prev0 %d mark %d windows %zu/%zu/%zu live %d/%d/%d\n", ri, r.refid(), r.pos(), (int)closing, (int)zero, cur_chr, rightmost, dis_right, other_right, RL, prev0, mark_start, conc.v.size(), part.v.size(), dis.v.size(), (int)conc.v.size() - conc.off, (int)part.v.size() - part.off, (int)dis.v.size() - dis.off); }
     if (!opening && zero && mark_start != -1) {
         if (rightmost > mark_start && rightmost - mark_start < thresh * 20 && !seeds.empty() && mark_start == seeds.back().pos + seeds.back().len) seeds.back().len += rightmost - mark_start;
         else if (rightmost > mark_start && rightmost - mark_start >= thresh * 20) seeds.push_back(Node{mark_chr, mark_start, rightmost - mark_start, 0, 0.0});
