@@ -1064,7 +1064,8 @@ int sq_ingest_files(sq_ctx* c, const char* chim_path, const char* bam_path, int3
     c->chim_future = std::async(std::launch::async, [c, chim, n_threads, decoded]() {
         tl_err_sink = &c->chim_err;
         struct Unsink { sq_ctx* c; ~Unsink() { tl_err_sink = nullptr; c->chim_pairing_running = false; } } unsink{c};
-        return chimeric_file_to_fragments(c, chim.c_str(), std::max(1, std::min(n_threads, 16)), c->chim_err, true, decoded.get());  // (the host decoder of the chimeric BAM: 16 threads 96 ms of decode per 9.6 M records, 64 threads 254 ms)
+        // (decode threads: the rank's share of the CPUs the process may really use -- eight ranks on one host decode the same file side by side)
+        return chimeric_file_to_fragments(c, chim.c_str(), std::max(1, std::min({(int)n_threads, 16, usable_cpus() / std::max(1, c->P.world_size)})), c->chim_err, true, decoded.get());  // (the host decoder of the chimeric BAM: 16 threads 96 ms of decode per 9.6 M records, 64 threads 254 ms)
     });
     const int rc_conc = sq_ingest_concordant_file(c, bam_path, n_threads);
     const int rc_chim = chim_join(c);  // (a concordant file without records never reached the parse)
