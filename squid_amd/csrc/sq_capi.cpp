@@ -199,15 +199,7 @@ static int build_graph_bwa(sq_ctx* c) {
     return finish_graph(c, host_filters);
 }
 
-// (the table of a dense sample is half a gigabyte in a few large blocks: unmapped behind the caller's back -- this runs at the head of the
-// chimeric pairing, the chain such a sample's graph pass waits for)
-static void drop_early_clusters(sq_ctx* c) {
-    if (c->disc_early.size() > 100000) {
-        auto* junk = new std::pair<std::shared_ptr<SegPlan>, std::vector<Blk>>(std::move(c->plan_early), std::move(c->disc_early));
-        std::thread([junk]() { delete junk; }).detach();
-    }
-    c->plan_early.reset(); c->disc_early.clear(); c->disc_early.shrink_to_fit(); c->clusters_early_ms = -1;
-}
+static void drop_early_clusters(sq_ctx* c) { c->plan_early.reset(); c->disc_early.clear(); c->disc_early.shrink_to_fit(); c->clusters_early_ms = -1; }
 static int build_graph(sq_ctx* c) {
     HostClock wall(c, "wall_build_graph");
     Shard& sh = c->shard;

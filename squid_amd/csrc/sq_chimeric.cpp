@@ -353,15 +353,6 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
     c->counts.n_chimeric_records = b->n_rec;
     c->counts.n_chim_fragments = (int64_t)out.size();
     c->counts.read_len = c->read_len;
-    if (nm > 100000) {
-        // (what is left of the merged fragments -- the dropped duplicates and 0.4 GB of storage -- goes away behind the caller's back as well)
-        Frag* p = store.p;
-        const size_t n = store.n;
-        auto* made = new std::vector<uint8_t>(std::move(store.made));
-        store.p = nullptr; store.n = 0; store.par_ = nullptr;
-        std::thread([p, n, made]() { for (size_t j = 0; j < n; ++j) if ((*made)[j]) p[j].~Frag(); std::free(p); delete made; }).detach();
-    }
-    lap("scratch handed to the background");
     return SQ_OK;
 }
 

@@ -32,11 +32,11 @@ with squid_amd.Context(**kw) as ctx:
     if staged:
         ctx.stage_bam(f"{pre}.bam")
     for it in range(5):
-        tc0 = time.perf_counter(); squid_amd.drop_file_cache(); ctx.clear_records(); t_clear = time.perf_counter() - tc0
+        squid_amd.drop_file_cache(); ctx.clear_records()
         a = stat(); t0 = time.perf_counter()
         ctx.load(f"{pre}.bam", f"{pre}.chim.bam", threads=256)
         t1 = time.perf_counter()
         ctx.build_graph(); ctx.order_sizes(); ctx.sv_text_fast()
         t2 = time.perf_counter(); b = stat()
-        print(f"step {it}: clear {1e3*t_clear:.1f} ms, load {1e3*(t1-t0):.1f} ms, pass {1e3*(t2-t1):.1f} ms; cpu used {(b.get('usage_usec',0)-a.get('usage_usec',0))/1e3:.0f} ms, "
+        print(f"step {it}: load {1e3*(t1-t0):.1f} ms, pass {1e3*(t2-t1):.1f} ms; cpu used {(b.get('usage_usec',0)-a.get('usage_usec',0))/1e3:.0f} ms, "
               f"periods {b.get('nr_periods',0)-a.get('nr_periods',0)}, throttled {b.get('nr_throttled',0)-a.get('nr_throttled',0)} times for {(b.get('throttled_usec',0)-a.get('throttled_usec',0))/1e3:.0f} ms")
