@@ -13,7 +13,6 @@
 
 #include "sq_internal.h"
 #include <future>
-#include <thread>
 #include "sq_parsort.h"
 
 namespace sq {
@@ -95,13 +94,6 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
         std::fprintf(stderr, "build_fragments: %-22s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
         t_prev = now;
     };
-    // (the fragments of an earlier ingest go away behind this call's back: three million objects with two heap lists each were 0.11 s of
-    // all host threads in the middle of the duplicate removal, on the chain a dense sample's graph pass waits for)
-    if (c->frags.size() > 100000) {
-        auto* old = new std::vector<Frag>();
-        old->swap(c->frags);
-        std::thread([old]() { delete old; }).detach();
-    }
     // one single-record fragment per usable record (mapped, not duplicate: ReadRec.cpp:344)
     // (the indices i in [0, n) with pred(i), ascending: counted and written piece by piece on the host threads)
     auto select = [&](int64_t n, const std::function<bool(int64_t)>& pred, std::vector<int64_t>& out, size_t extra = 0) {
@@ -175,7 +167,6 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
         }
     });
     par((int64_t)nblk_all, [&](int64_t lo, int64_t hi) { for (int64_t q = lo; q < hi; ++q) pblk[(size_t)q] = PBlk{b->b_refpos[q], b->b_matchref[q], b->b_readpos[q], b->b_matchread[q]}; });
-    lap("  records and blocks packed");
     // merge equal names (ReadRec.cpp:356-373): runs of equal names in the sorted order; the runs are independent of each other
     std::vector<int64_t> run_start;
     {
@@ -190,7 +181,6 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
         select((int64_t)nr, [&](int64_t k) { return starts[(size_t)k] != 0; }, run_start, 1);
     }
     run_start.push_back((int64_t)nr);
-    lap("  runs found");
     const size_t nm = run_start.size() - 1;
     // (the merged fragments: raw storage, every element constructed by the thread that fills it and destroyed side by side at the end)
     struct FragStore {
@@ -200,7 +190,6 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
     const std::function<void(int64_t, const std::function<void(int64_t, int64_t)>&)> par_fn = par;
     FragStore store{(Frag*)std::malloc(std::max<size_t>(1, nm) * sizeof(Frag)), nm, &par_fn, std::vector<uint8_t>(nm, 0)};
     Frag* merged = store.p;
-    lap("  room for the merged fragments");
     auto by_readpos = blk_less_readpos;
     par((int64_t)nm, [&](int64_t lo, int64_t hi) {
         for (int64_t j = lo; j < hi; ++j) {
@@ -282,7 +271,6 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
                 gstart[(size_t)p] = st;
             }
         });
-        lap("  old fragments freed, group starts");
         std::vector<int64_t> groups;
         select((int64_t)nm, [&](int64_t p) { return gstart[(size_t)p] != 0; }, groups, 1);
         groups.push_back((int64_t)nm);
@@ -298,7 +286,6 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
                 }
             }
         });
-        lap("  groups decided");
         // output position of every kept fragment: a prefix sum over the sorted order, piece by piece
         const int pieces = (int)std::min<int64_t>(std::max<int64_t>(1, (int64_t)nm / 65536), pool ? 4 * (pool->size() + 1) : 1);
         std::vector<size_t> at((size_t)pieces + 1, 0);
@@ -327,13 +314,10 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
             c->chim_dead.resize(dead.size());
             par((int64_t)dead.size(), [&](int64_t lo, int64_t hi) { for (int64_t q = lo; q < hi; ++q) c->chim_dead[(size_t)q] = merged[(size_t)dead[(size_t)q]].name; });
         }
-        lap("  places and dropped names");
         if (room.valid()) room.get();
-        lap("  room for the output");
         par((int64_t)nm, [&](int64_t lo, int64_t hi) {
             for (int64_t j = lo; j < hi; ++j) if (kept[(size_t)j]) out[(size_t)where[(size_t)j]] = std::move(merged[(size_t)j]);
         });
-        lap("  fragments moved");
     }
     lap("duplicate removal");
     // ChimName: Chimrecord.size() empty strings + every Qname, sorted unique (SegmentGraph.cpp:196-201, ledger B9).  `merged` is in name
