@@ -12,6 +12,7 @@
 #include <functional>
 
 #include "sq_internal.h"
+#include <atomic>
 #include <future>
 #include "sq_parsort.h"
 
@@ -228,24 +229,32 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
     // carry everything the comparator looks at
     struct FrontKey { Blk a, b; bool has_a, has_b; int32_t idx; };
     Raw<FrontKey> fk(nm);
+    std::atomic<long> without_a{0};
     par((int64_t)nm, [&](int64_t lo, int64_t hi) {
+        long none = 0;
         for (int64_t j = lo; j < hi; ++j) {
             const Frag& m = merged[(size_t)j];
             FrontKey k{};
             k.has_a = !m.a.empty(); k.has_b = !m.b.empty(); k.idx = (int32_t)j;
             if (k.has_a) k.a = m.a.front();
             if (k.has_b) k.b = m.b.front();
+            none += !k.has_a;
             fk[(size_t)j] = k;
         }
+        without_a += none;
     });
+    // FrontSmallerThan (ReadRec.cpp:90-117) is not a strict weak order in general -- which pair of blocks it compares depends on which mates
+    // BOTH fragments have -- but when every fragment has a first-mate block it IS the comparison of those blocks by (RefID, RefPos), a
+    // strict weak order: the threaded introsort may then split its final insertion pass (sq_parsort.h)
+    const bool front_is_strict = without_a.load() == 0;
     std_sort_parallel(fk.begin(), fk.end(), [](const FrontKey& l, const FrontKey& r) {  // == front_smaller(merged[l.idx], merged[r.idx])
         if (l.has_a && r.has_a) return blk_less_pos(l.a, r.a);
         if (l.has_b && r.has_b) return blk_less_pos(l.b, r.b);
         if (l.has_a && r.has_b) return blk_less_pos(l.a, r.b);
         if (l.has_b && r.has_a) return blk_less_pos(l.b, r.a);
         return false;
-    }, sort_threads);
-    lap("front sort");
+    }, sort_threads, front_is_strict);
+    lap(front_is_strict ? "front sort (strict)" : "front sort");
     // PCR duplicate removal (ReadRec.cpp:387-409)
     // The loop of the reference keeps a fragment unless an equal one was kept among the fragments right in front of it that share its
     // first first-in-pair block position; the backward search stops at the first kept fragment without such a block or with another
