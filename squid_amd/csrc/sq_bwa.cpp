@@ -65,7 +65,7 @@ struct RecRef {  // one record of the host batch, in the reference's vocabulary
 };
 
 // more than 15 bases of the read hang over at either end of its aligned blocks, and its qualities are fine (:1050-1065, :1730-1737)
-inline bool clipped_end(const std::vector<Blk>& r, int totlen, bool low) {
+inline bool clipped_end(const BlkList& r, int totlen, bool low) {
     if (r.empty() || low) return false;
     return r.front().readpos > 15 || totlen - r.back().readpos - r.back().matchread > 15;
 }
@@ -411,7 +411,7 @@ static int bwa_raw_edges(sq_ctx* c, const HostBatch& hb, std::vector<Edge>& raw)
         part = false;
         if (r.dup() || !r.mapped()) return 0;
         if (r.first() ? (r.multi() || hb.mapq[ri] == 0) : !r.multi()) return 0;  // :1723-1726 (W5)
-        std::vector<Blk>& own = r.first() ? f.a : f.b;  // (f.name: given by the caller where a list keeps it -- two std::strings per record otherwise, most of this loop's time)
+        BlkList& own = r.first() ? f.a : f.b;  // (f.name: given by the caller where a list keeps it -- two std::strings per record otherwise, most of this loop's time)
         for (size_t k = 0; k < r.nblk(); ++k) own.push_back(r.blk(k));
         std::sort(own.begin(), own.end(), blk_less_readpos);
         (r.first() ? f.atot : f.btot) = r.totlen();
@@ -433,7 +433,7 @@ static int bwa_raw_edges(sq_ctx* c, const HostBatch& hb, std::vector<Edge>& raw)
             P.raw.push_back(make_edge(i, hi_, j, hj, w));
             return true;
         };
-        auto split_edges = [&](const std::vector<Blk>& r, size_t base) -> bool {
+        auto split_edges = [&](const BlkList& r, size_t base) -> bool {
             for (size_t k = 0; k + 1 < r.size(); ++k) {
                 const int i = rn[base + k], j = rn[base + k + 1];
                 if (i != j && i != -1 && j != -1 && !add(i, r[k].rev, j, !r[k + 1].rev, 1)) return false;
@@ -550,7 +550,7 @@ static int bwa_raw_edges(sq_ctx* c, const HostBatch& hb, std::vector<Edge>& raw)
         raw.push_back(make_edge(i, hi, j, hj, w));
         return SQ_OK;
     };
-    auto split_edges = [&](const std::vector<Blk>& r, size_t base) -> int {
+    auto split_edges = [&](const BlkList& r, size_t base) -> int {
         for (size_t k = 0; k + 1 < r.size(); ++k) {
             const int i = rn[base + k], j = rn[base + k + 1];
             if (i != j && i != -1 && j != -1) { const int rc = add(i, r[k].rev, j, !r[k + 1].rev, 1); if (rc) return rc; }

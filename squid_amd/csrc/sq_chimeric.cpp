@@ -21,7 +21,7 @@ namespace sq {
 bool frag_single_anchored(const Frag& f) { return f.a.empty() || f.b.empty(); }  // MultiFilter is never set (ReadRec.cpp:14)
 
 bool frag_end_discordant(const Frag& f, bool first) {  // ReadRec.cpp:178-209
-    const std::vector<Blk>& R = first ? f.a : f.b;
+    const BlkList& R = first ? f.a : f.b;
     if (R.size() <= 1) return false;
     for (size_t i = 0; i + 1 < R.size(); ++i) {
         const Blk &x = R[i], &y = R[i + 1];
@@ -44,7 +44,7 @@ bool frag_pair_discordant(const Frag& f, bool needcheck) {  // ReadRec.cpp:211-2
 }
 
 bool frag_equal(const Frag& x, const Frag& y) {  // ReadRec.cpp:119-141
-    auto same = [](const std::vector<Blk>& p, const std::vector<Blk>& q) {
+    auto same = [](const BlkList& p, const BlkList& q) {
         if (p.size() != q.size()) return false;
         for (size_t i = 0; i < p.size(); ++i)
             if (p[i].refid != q[i].refid || p[i].refpos != q[i].refpos || p[i].matchref != q[i].matchref) return false;
@@ -211,7 +211,7 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
                 const int flag = r.flag;
                 const bool first = flag & 0x40, rev = flag & 0x10, low = r.low != 0;
                 const int tot = r.tot;
-                std::vector<Blk>& dst = first ? m.a : m.b;
+                BlkList& dst = first ? m.a : m.b;
                 for (uint32_t q = r.b0; q < r.b0 + r.nb; ++q)
                     dst.push_back(Blk{r.refid, pblk[q].refpos, (int32_t)pblk[q].readpos, pblk[q].matchref, (int32_t)pblk[q].matchread, rev, first});
                 if (k == k0) { if (first) { m.atot = tot; m.alow = low; } else { m.btot = tot; m.blow = low; } }
@@ -262,7 +262,7 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
     // position -- whose first member is always kept (what was kept before it lies in another group, or has no such block) and whose
     // other members are compared with kept members of the same group only.  Groups are decided side by side.
     par((int64_t)c->frags.size(), [&](int64_t lo, int64_t hi) {  // (the fragments of an earlier ingest: freed side by side, not one by one)
-        for (int64_t k = lo; k < hi; ++k) { Frag& f = c->frags[(size_t)k]; std::vector<Blk>().swap(f.a); std::vector<Blk>().swap(f.b); std::string().swap(f.name); }
+        for (int64_t k = lo; k < hi; ++k) { Frag& f = c->frags[(size_t)k]; f.a.release(); f.b.release(); std::string().swap(f.name); }
     });
     c->frags.clear();
     std::vector<Frag>& out = c->frags;

@@ -184,7 +184,7 @@ int chimeric_edges(sq_ctx* c, std::vector<Edge>& raw) {
                     if (i < 0 || i + 1 >= n) { P.bad = true; return; }
                     P.raw.push_back(make_edge(i, false, i + 1, true));
                 }
-            auto split = [&](const std::vector<Blk>& R, int base) {
+            auto split = [&](const BlkList& R, int base) {
                 for (int k = 0; k + 1 < (int)R.size(); ++k) {
                     int i = rn[base + k], j = rn[base + k + 1];
                     if (i == j || i == -1 || j == -1) continue;
@@ -666,7 +666,7 @@ int exact_breakpoints(sq_ctx* c, BPMap& bp) {
             if (skip(f)) continue;
             locate_fragment(N, hint, f, rn);
             if (rn[0] != -1) hint = rn[0];
-            auto collect = [&](const std::vector<Blk>& R, int base) {
+            auto collect = [&](const BlkList& R, int base) {
                 for (int k = 0; k + 1 < (int)R.size(); ++k) {
                     int i = rn[base + k], j = rn[base + k + 1];
                     if (i == j || i == -1 || j == -1) continue;

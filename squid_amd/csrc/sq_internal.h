@@ -11,6 +11,9 @@
 #include <cstdint>
 #include <functional>
 #include <future>
+#include <type_traits>
+#include <cstring>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <string>
@@ -37,9 +40,59 @@ inline bool blk_less_readpos(const Blk& x, const Blk& y) { return x.readpos < y.
 inline bool blk_same(const Blk& x, const Blk& y) {                                                                                  // Same
     return x.refid == y.refid && x.refpos == y.refpos && x.readpos == y.readpos && x.matchread == y.matchread && x.matchref == y.matchref && x.rev == y.rev && x.first == y.first;
 }
+// The block list of one mate of a fragment: nearly always one or two blocks (a split read has two), so two live inside the object and
+// only a longer list goes to the heap.  Millions of fragments with two std::vectors each were millions of small heap blocks -- made by
+// one thread, freed by another (glibc then takes the maker's arena lock), chased through a pointer by every loop over the fragments; on
+// the dense config the pairing, the cluster walk, the chimeric edges and the frees all paid for that layout.
+// The subset of std::vector's interface the library uses, for trivially copyable T; iterators are pointers.
+template <class T, int N>
+class SmallVec {
+    static_assert(std::is_trivially_copyable<T>::value, "plain values");
+    T* p_;
+    uint32_t n_, cap_;
+    alignas(T) unsigned char in_[N * sizeof(T)];
+    T* inl() { return reinterpret_cast<T*>(in_); }
+    void grow(size_t c) {
+        T* q = (T*)std::malloc(c * sizeof(T));
+        std::memcpy((void*)q, (const void*)p_, (size_t)n_ * sizeof(T));
+        if (p_ != inl()) std::free(p_);
+        p_ = q; cap_ = (uint32_t)c;
+    }
+public:
+    typedef T value_type; typedef T* iterator; typedef const T* const_iterator;
+    SmallVec() : p_(inl()), n_(0), cap_(N) {}
+    SmallVec(const SmallVec& o) : SmallVec() { insert(end(), o.begin(), o.end()); }
+    SmallVec(SmallVec&& o) noexcept : SmallVec() { take(o); }
+    SmallVec& operator=(const SmallVec& o) { if (this != &o) { n_ = 0; insert(end(), o.begin(), o.end()); } return *this; }
+    SmallVec& operator=(SmallVec&& o) noexcept { if (this != &o) { release(); take(o); } return *this; }
+    ~SmallVec() { if (p_ != inl()) std::free(p_); }
+    void release() { if (p_ != inl()) std::free(p_); p_ = inl(); n_ = 0; cap_ = N; }  // back to the empty state, heap block returned
+    void take(SmallVec& o) {  // (*this is empty and inline)
+        if (o.p_ != o.inl()) { p_ = o.p_; n_ = o.n_; cap_ = o.cap_; o.p_ = o.inl(); o.n_ = 0; o.cap_ = N; }
+        else { std::memcpy((void*)inl(), (const void*)o.inl(), (size_t)o.n_ * sizeof(T)); n_ = o.n_; o.n_ = 0; }
+    }
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    T* begin() { return p_; } T* end() { return p_ + n_; }
+    const T* begin() const { return p_; } const T* end() const { return p_ + n_; }
+    T& front() { return p_[0]; } const T& front() const { return p_[0]; }
+    T& back() { return p_[n_ - 1]; } const T& back() const { return p_[n_ - 1]; }
+    T& operator[](size_t i) { return p_[i]; } const T& operator[](size_t i) const { return p_[i]; }
+    void reserve(size_t c) { if (c > cap_) grow(c); }
+    void clear() { n_ = 0; }
+    void push_back(const T& v) { if (n_ == cap_) { const T keep = v; grow((size_t)cap_ * 2 > 4 ? (size_t)cap_ * 2 : 4); p_[n_++] = keep; } else p_[n_++] = v; }
+    void resize(size_t n) { reserve(n); for (size_t i = n_; i < n; ++i) p_[i] = T(); n_ = (uint32_t)n; }
+    template <class It> void insert(const T* at, It first, It last) {  // (only at the end: what the library does)
+        (void)at;
+        const size_t k = (size_t)(last - first);
+        if (n_ + k > cap_) grow(std::max<size_t>(n_ + k, (size_t)cap_ * 2));
+        for (; first != last; ++first) p_[n_++] = *first;
+    }
+};
+typedef SmallVec<Blk, 2> BlkList;
 struct Frag {  // merged chimeric fragment = ReadRec_t after BuildChimericSBamRecord
     std::string name;
-    std::vector<Blk> a, b;  // first-in-pair blocks, second-in-pair blocks (sorted by read offset)
+    BlkList a, b;  // first-in-pair blocks, second-in-pair blocks (sorted by read offset)
     int atot = 0, btot = 0;
     bool alow = false, blow = false;
 };

@@ -40,7 +40,7 @@ End end_of(const Blk& b, bool left) { return End{b.refid, b.refpos, b.refpos + b
 // mates' last blocks when the pair is discordant and some read end hangs over by more than 12 good bases
 void junctions_of(const Frag& f, std::vector<Junction>& out) {
     out.clear();
-    for (const std::vector<Blk>* m : {&f.a, &f.b})
+    for (const BlkList* m : {&f.a, &f.b})
         for (size_t i = 0; i + 1 < m->size(); ++i) {
             const Blk &x = (*m)[i], &y = (*m)[i + 1];
             const bool order_ref = x.refpos < y.refpos, order_read = x.readpos < y.readpos;

@@ -460,7 +460,7 @@ double segment_clusters(const sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::ve
             continue;
         }
         bool ains = false, bins = false;
-        auto far = [&](const std::vector<Blk>& R, bool& ins) {
+        auto far = [&](const BlkList& R, bool& ins) {
             int prev = -1;
             for (int i = 0; i + 1 < (int)R.size(); ++i)
                 if (std::abs(R[i].refpos - R[i + 1].refpos) > 750000) {
