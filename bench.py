@@ -62,7 +62,7 @@ BUILD = ROOT / "build"
 
 GPU_KERNELS_PREFIX = ("k_", "scan_")
 # timers of the BGZF reader, named like the kernels they bracket (profiles/*_kernel_stats.csv carries the same names)
-INGEST_KERNELS = ("k_inflate_tok2", "k_lz_resolve3", "k_lz_resolve2", "k_rec_sync+walk+check", "k_parse_count", "k_parse_write", "k_inflate", "k_pack_records")
+INGEST_KERNELS = ("k_inflate_spec", "k_inflate_tok2", "k_lz_resolve3", "k_lz_resolve2", "k_rec_sync+walk+check", "k_parse_count", "k_parse_write", "k_inflate", "k_pack_records")
 SMALL_GRAPH_KERNELS = ("k_filter_weight", "k_filter_interleave", "k_filter_edges", "k_compress_nodes", "k_further_compress", "k_order_small", "k_order_mid", "k_cc", "k_hash_compact",
                        "k_node_buckets", "k_bp_walk")
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
@@ -156,6 +156,36 @@ def cold_cli(bam: str, chim: str, cold_pre: Path, cli_flags: list, text: str, to
     return settled
 
 
+def oracle_order_stats(path: Path) -> dict:
+    """order_stats of the oracle (ORACLE_STATS_FILE): components, ambiguous, too_large (components beyond its exact solver), ..."""
+    try:
+        return {k: int(v) for k, v in (l.split("\t", 1) for l in path.read_text().splitlines() if not l.startswith("ambiguous_problem"))}
+    except (OSError, ValueError):
+        return {}
+
+
+def parity_failures(out: dict) -> list:
+    """what must not be reported as a result: an _sv.txt that differs from the oracle's, ordering problems one side solved and the other gave up
+    on, and any component left unsolved on the BASELINE configs (C3: the main line, C5: `dense`)"""
+    bad = []
+    cb = out.get("cpu_baseline")
+    if cb:
+        if not cb.get("sv_identical_to_gpu"): bad.append("main line: _sv.txt differs from the oracle's")
+        if cb.get("unsolved"): bad.append(f"main line: the oracle left {cb['unsolved']} component(s) unsolved")
+        if cb.get("ambiguous"): bad.append(f"main line: {cb['ambiguous']} ordering problem(s) with optima that disagree on discordant edges")
+    if (out.get("components") or {}).get("n_order_unsolved"): bad.append("main line: the library left component(s) unsolved")
+    if not out.get("steps_identical", True): bad.append("main line: the timed steps wrote different _sv.txt files")
+    for name in ("dense", "bwa"):
+        r = out.get(name)
+        if not r: continue
+        if not r.get("steps_identical", True): bad.append(f"{name}: the timed steps wrote different _sv.txt files")
+        c = r.get("cpu_baseline") or {}
+        if c and not c.get("sv_identical_to_gpu"): bad.append(f"{name}: _sv.txt of the sample differs from the oracle's")
+        if c and c.get("unsolved") is not None and c.get("unsolved") != c.get("gpu_n_order_unsolved"): bad.append(f"{name}: oracle gave up on {c.get('unsolved')} component(s), the library on {c.get('gpu_n_order_unsolved')}")
+        if name == "dense" and (r.get("n_order_unsolved") or c.get("unsolved")): bad.append("dense: component(s) left unsolved on a BASELINE config")
+    return bad
+
+
 def dense_record(work: Path, local_rank: int, note, steps: int = 3, records: int | None = None, sample_records: int = 1_000_000, sample_tsv: int = 3000) -> dict:
     """BASELINE.json configs[4] (C5: 100 M records, -w 1 -a 50, >= 1e5 small components) as a sub-record of the bench line: from-file steps,
     the resident pass, components/s, and the `_sv.txt` of a small sample of the same generator config against the CPU oracle."""
@@ -221,13 +251,19 @@ def dense_record(work: Path, local_rank: int, note, steps: int = 3, records: int
     spre = synth("C5", 20180005, work, sample_records, tsv=sample_tsv)
     pin = ["taskset", "-c", "0"] if shutil.which("taskset") else []
     t0 = time.perf_counter()
-    subprocess.check_call(pin + [str(BUILD / "squid_oracle"), "-b", f"{spre}.bam", "-c", f"{spre}.chim.bam", "-o", str(work / "dense_cpu"), "-w", "1", "-a", "50"], stdout=subprocess.DEVNULL)
+    stats_file = work / "dense_cpu_order_stats.txt"
+    subprocess.check_call(pin + [str(BUILD / "squid_oracle"), "-b", f"{spre}.bam", "-c", f"{spre}.chim.bam", "-o", str(work / "dense_cpu"), "-w", "1", "-a", "50"], stdout=subprocess.DEVNULL,
+                          env=dict(os.environ, ORACLE_STATS_FILE=str(stats_file)))
     tc = time.perf_counter() - t0
     oracle_text = (work / "dense_cpu_sv.txt").read_text()
+    ostats = oracle_order_stats(stats_file)
     res = squid_amd.run_pipeline(f"{spre}.bam", f"{spre}.chim.bam", device=local_rank, **DENSE)
     n_s = res["counts"]["n_concordant"] + res["counts"]["n_chimeric_records"]
+    rec["n_order_unsolved"] = int(counts["n_order_unsolved"])  # (full size; must be 0: C5 is a BASELINE config)
     rec["cpu_baseline"] = {"value": n_s / tc, "unit": "alignments/s", "cores": 1, "kind": "port", "sample": f"C5 generated with --records {sample_records} --tsv {sample_tsv} ({n_s} records), {tc:.2f} s",
-                           "sv_identical_to_gpu": oracle_text == res["sv_text"], "sv_rows": oracle_text.count("\n") - 1}
+                           "sv_identical_to_gpu": oracle_text == res["sv_text"], "sv_rows": oracle_text.count("\n") - 1,
+                           # components whose exact ordering either side gave up on (identity order kept, what the reference keeps when GLPK fails): "identical" must not mean "both gave up"
+                           "unsolved": ostats.get("too_large"), "ambiguous": ostats.get("ambiguous"), "gpu_n_order_unsolved": int(res["counts"]["n_order_unsolved"])}
     return rec
 
 
@@ -284,17 +320,22 @@ def bwa_record(work: Path, local_rank: int, note, steps: int = 3, sample_records
     spre = synth("C3", 20180003, work, sample_records, bwa=True)
     pin = ["taskset", "-c", "0"] if shutil.which("taskset") else []
     t0 = time.perf_counter()
-    subprocess.check_call(pin + [str(BUILD / "squid_oracle"), "--bwa", "-b", f"{spre}.bam", "-o", str(work / "bwa_cpu")], stdout=subprocess.DEVNULL)
+    stats_file = work / "bwa_cpu_order_stats.txt"
+    subprocess.check_call(pin + [str(BUILD / "squid_oracle"), "--bwa", "-b", f"{spre}.bam", "-o", str(work / "bwa_cpu")], stdout=subprocess.DEVNULL, env=dict(os.environ, ORACLE_STATS_FILE=str(stats_file)))
     tc = time.perf_counter() - t0
     oracle_text = (work / "bwa_cpu_sv.txt").read_text()
+    ostats = oracle_order_stats(stats_file)
     with squid_amd.Context(device=local_rank, star_mapq=False, min_mapqual=1) as c2:
         c2.load_bwa(f"{spre}.bam")
         c2.build_graph()
         c2.order_sizes()
         small_text = c2.sv_text_fast()
         n_s = c2.counts()["n_concordant"]
+        small_unsolved = int(c2.counts()["n_order_unsolved"])
+    rec["n_order_unsolved"] = int(counts["n_order_unsolved"])  # (full size)
     rec["cpu_baseline"] = {"value": n_s / tc, "unit": "alignments/s", "cores": 1, "kind": "port", "sample": f"C3 --bwa generated with --records {sample_records} ({n_s} records), {tc:.2f} s",
-                           "sv_identical_to_gpu": oracle_text == small_text, "sv_rows": oracle_text.count("\n") - 1}
+                           "sv_identical_to_gpu": oracle_text == small_text, "sv_rows": oracle_text.count("\n") - 1,
+                           "unsolved": ostats.get("too_large"), "ambiguous": ostats.get("ambiguous"), "gpu_n_order_unsolved": small_unsolved}
     return rec
 
 
@@ -634,7 +675,14 @@ def main() -> None:
         out["bwa"] = bwa_record(work, local_rank, note)
     if dist:
         dist.destroy_process_group()
+    bad = parity_failures(out)
+    if bad:
+        out["parity_failures"] = bad
     print(json.dumps(out))
+    if bad:
+        for b in bad:
+            print("bench: " + b, file=sys.stderr)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -301,6 +301,11 @@ int sq_debug_order(sq_ctx* c, int32_t n, int32_t n_edges, const int32_t* edges5,
  * rel5 receives the five n*n relation matrices (0/1 bytes, in that order), perm_pos / perm_readpos the permutations the
  * library's sorts produce with operator< (SegmentGraph.cpp:264) and CompReadPos (ReadRec.cpp:144-145). */
 int sq_debug_blocks(int32_t n, const int32_t* fields7, uint8_t* rel5, int32_t* perm_pos, int32_t* perm_readpos);
+/* tuning: the two BGZF inflate kernels on the first max_blocks blocks of a file, each ALONE on the device, timed with HIP events (the
+ * reader overlaps them with everything else).  variant: 2 = the lane-per-block token pass (k_inflate_tok2), else CH * 100 + PB of the
+ * wave-per-block pass (k_inflate_spec: 51211, 51210, 25610, 25611, 38411, 102411).  check != 0 compares every block with zlib.
+ * out7: token pass ms, resolve ms (averages over reps), inflated bytes, file bytes, blocks, tokens, blocks that differ (-1: error flag). */
+int sq_debug_token_bench(sq_ctx* c, const char* path, int32_t variant, int32_t max_blocks, int32_t reps, int32_t check, double* out7);
 /* tests: the RCCL transport of sq_exchange end to end on the context's device with a world of ONE rank -- librccl bound at run time,
  * ncclGetUniqueId, ncclCommInitRank(1 rank), the transport's all-gather of the fixed 16 KiB piece and of a 1 MiB remainder
  * (host -> device -> ncclAllGather -> host), bytes compared, communicator destroyed. */

@@ -24,7 +24,7 @@ EXPORTS = [
     "sq_ingest_concordant_file", "sq_build_graph", "sq_graph_view", "sq_order", "sq_call_sv", "sq_breakpoints",
     "sq_set_shard", "sq_exchange_pack", "sq_exchange_unpack", "sq_get_timing", "sq_timing_accumulate", "sq_reset", "sq_ingest_files", "sq_stage_bam", "sq_clear_records", "sq_set_source", "sq_save_records", "sq_load_records", "sq_get_counts", "sq_debug_download", "sq_debug_bp_support", "sq_debug_order", "sq_debug_blocks", "sq_drop_file_cache",
     "sq_total_order", "sq_set_allgather", "sq_rccl_unique_id", "sq_rccl_init", "sq_rccl_attach", "sq_exchange", "sq_exchange_stats",
-    "sq_rccl_available", "sq_rccl_release", "sq_debug_rccl_selftest", "sq_ingest_bwa_file", "sq_junction_sequences", "sq_release_reader_buffers", "sq_keep_host_memory", "sq_keep_stage_graphs",
+    "sq_rccl_available", "sq_rccl_release", "sq_debug_rccl_selftest", "sq_debug_token_bench", "sq_ingest_bwa_file", "sq_junction_sequences", "sq_release_reader_buffers", "sq_keep_host_memory", "sq_keep_stage_graphs",
 ]
 
 

@@ -778,6 +778,14 @@ static int call_sv(sq_ctx* c) {
 
 using namespace sq;
 
+// No exception leaves the library: the host stages allocate (std::bad_alloc from the vectors, the raw scratch blocks and the bodies of
+// HostPool::parallel_for, which hands a helper's exception to its caller) -- at the C boundary that becomes SQ_E_CAPACITY with a message.
+template <class F> static int abi_guard(sq_ctx* c, const char* what, F f) {
+    try { return f(); }
+    catch (const std::bad_alloc&) { return c ? sq::fail(c, SQ_E_CAPACITY, std::string(what) + ": out of host memory") : (int)SQ_E_CAPACITY; }
+    catch (const std::exception& e) { return c ? sq::fail(c, SQ_E_CAPACITY, std::string(what) + ": " + e.what()) : (int)SQ_E_CAPACITY; }
+}
+
 extern "C" {
 
 void sq_default_params(sq_params* p) {
@@ -838,7 +846,7 @@ static void copy_frags(sq_ctx* c, const std::vector<Frag>& src, std::vector<Frag
     if (pieces <= 1 || !pool) { for (int k = 0; k < pieces; ++k) piece(k); }
     else pool->parallel_for(pieces, 1 << 20, piece);
 }
-int sq_ingest_chimeric(sq_ctx* c, const sq_aln_batch* b) {
+static int sq_ingest_chimeric_impl(sq_ctx* c, const sq_aln_batch* b) {
     if (!c || !b) return SQ_E_ARG;
     drop_early_clusters(c);
     int rc = build_fragments(c, b);
@@ -846,6 +854,7 @@ int sq_ingest_chimeric(sq_ctx* c, const sq_aln_batch* b) {
     copy_frags(c, c->frags, c->frags0);
     return dev_upload_chim_names(c);
 }
+int sq_ingest_chimeric(sq_ctx* c, const sq_aln_batch* b) { return abi_guard(c, "sq_ingest_chimeric", [&]() { return sq_ingest_chimeric_impl(c, b); }); }
 int sq_chim_contains(sq_ctx* c, const char* name, size_t len) {
     if (!c) return SQ_E_ARG;
     return std::binary_search(c->chim_names.begin(), c->chim_names.end(), std::string(name, len)) ? 1 : 0;
@@ -857,7 +866,7 @@ static inline bool shard_owns(const sq_ctx* c, int32_t id) {
     if (id < 0) return c->P.rank == c->P.world_size - 1;
     return id >= sh.first_ref && id < sh.end_ref;
 }
-int sq_ingest_concordant(sq_ctx* c, const sq_aln_batch* b) {
+static int sq_ingest_concordant_impl(sq_ctx* c, const sq_aln_batch* b) {
     if (!c || !b) return SQ_E_ARG;
     if (c->bwa) return fail(c, SQ_E_ARG, "this context holds a --bwa batch (sq_ingest_bwa_file): sq_clear_records before a STAR-mode ingest -- the mode is per context");
     if (!c->shard.on) return dev_append_records(c, b);
@@ -880,6 +889,7 @@ int sq_ingest_concordant(sq_ctx* c, const sq_aln_batch* b) {
     }
     return SQ_OK;
 }
+int sq_ingest_concordant(sq_ctx* c, const sq_aln_batch* b) { return abi_guard(c, "sq_ingest_concordant", [&]() { return sq_ingest_concordant_impl(c, b); }); }
 static int ingest_raw(sq_ctx* c, const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n_rec) {
     if (!c->shard.on) return dev_parse_append(c, bam, nbytes, rec_off, n_rec);
     // sharded: RefID sits 4 bytes into a record; upload only the byte range of the runs this rank owns
@@ -994,13 +1004,14 @@ static int chimeric_file_to_fragments(sq_ctx* c, const char* path, int nt, std::
 }  // extern "C"
 int sq::chimeric_fragments_host(sq_ctx* c, const char* path, int threads) { return chimeric_file_to_fragments(c, path, std::max(1, threads), c->err); }
 extern "C" {
-int sq_ingest_chimeric_file(sq_ctx* c, const char* path) {
+static int sq_ingest_chimeric_file_impl(sq_ctx* c, const char* path) {
     if (!c || !path) return SQ_E_ARG;
     // (inflate and decode on a few threads: a dense sample has millions of chimeric records; the result does not depend on the count)
     const int nt = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 4));
     int rc = chimeric_file_to_fragments(c, path, nt, c->err);
     return rc ? rc : dev_upload_chim_names(c);
 }
+int sq_ingest_chimeric_file(sq_ctx* c, const char* path) { return abi_guard(c, "sq_ingest_chimeric_file", [&]() { return sq_ingest_chimeric_file_impl(c, path); }); }
 // The chimeric BAM through the GPU reader (K-1 + K0 with sq_ctx::capture_names): BGZF inflate, record boundaries and the record parse on
 // the device, the decoded records and their QNAMEs copied back as one batch -- the batch the host decoder (parse_bam_file, keep_names) makes
 // of the same file, field for field.  On the dense config the host decoder is 0.6 s of sixteen threads = 9 of the 16 CPU-seconds per second
@@ -1033,7 +1044,7 @@ static int chimeric_records_through_the_device(sq_ctx* c, const char* path, int 
 // both input files in one call: the chimeric BAM (1-2 % of the records, decoded on the host: 17 ms at C3) is read on a helper
 // thread while the GPU reader starts on the concordant BAM; the record parse -- the first consumer of the chimeric QNAME set --
 // waits for it (chim_join).  Same result as sq_ingest_chimeric_file followed by sq_ingest_concordant_file.
-int sq_ingest_files(sq_ctx* c, const char* chim_path, const char* bam_path, int32_t n_threads) {
+static int sq_ingest_files_impl(sq_ctx* c, const char* chim_path, const char* bam_path, int32_t n_threads) {
     if (!c || !chim_path || !bam_path) return SQ_E_ARG;
     if (c->bwa) return fail(c, SQ_E_ARG, "this context holds a --bwa batch (sq_ingest_bwa_file): sq_clear_records before a STAR-mode ingest -- the mode is per context");
     if (std::getenv("SQUID_HOST_PARSE") || std::getenv("SQUID_SERIAL_LOAD")) {  // (the host parser consults the name set record by record)
@@ -1071,6 +1082,7 @@ int sq_ingest_files(sq_ctx* c, const char* chim_path, const char* bam_path, int3
     const int rc_chim = chim_join(c);  // (a concordant file without records never reached the parse)
     return rc_chim ? rc_chim : rc_conc;
 }
+int sq_ingest_files(sq_ctx* c, const char* chim_path, const char* bam_path, int32_t n_threads) { return abi_guard(c, "sq_ingest_files", [&]() { return sq_ingest_files_impl(c, chim_path, bam_path, n_threads); }); }
 int sq_set_source(sq_ctx* c, const char* path) {
     if (!c || !path) return SQ_E_ARG;
     struct stat st;
@@ -1079,7 +1091,7 @@ int sq_set_source(sq_ctx* c, const char* path) {
     c->source_mtime = (uint64_t)st.st_mtim.tv_sec * 1000000000ull + (uint64_t)st.st_mtim.tv_nsec;
     return SQ_OK;
 }
-int sq_ingest_concordant_file(sq_ctx* c, const char* path, int32_t n_threads) {
+static int sq_ingest_concordant_file_impl(sq_ctx* c, const char* path, int32_t n_threads) {
     if (!c || !path) return SQ_E_ARG;
     if (c->bwa) return fail(c, SQ_E_ARG, "this context holds a --bwa batch (sq_ingest_bwa_file): sq_clear_records before a STAR-mode ingest -- the mode is per context");
     { int r0 = sq_set_source(c, path); if (r0) return r0; }
@@ -1115,9 +1127,10 @@ int sq_ingest_concordant_file(sq_ctx* c, const char* path, int32_t n_threads) {
         return sq_ingest_concordant(c, &b);
     });
 }
+int sq_ingest_concordant_file(sq_ctx* c, const char* path, int32_t n_threads) { return abi_guard(c, "sq_ingest_concordant_file", [&]() { return sq_ingest_concordant_file_impl(c, path, n_threads); }); }
 // `squid --bwa -b <bam>` (src/Config.cpp:98-100; src/main.cpp:33-37 runs without a chimeric file): every record of the one BAM file,
 // decoded on host threads with its QNAME, stays on the host; sq_build_graph then takes BuildNode_BWA / RawEdges (sq_bwa.cpp)
-int sq_ingest_bwa_file(sq_ctx* c, const char* path, int32_t n_threads) {
+static int sq_ingest_bwa_file_impl(sq_ctx* c, const char* path, int32_t n_threads) {
     if (!c || !path) return SQ_E_ARG;
     if (c->shard.on) return fail(c, SQ_E_ARG, "--bwa input is not chromosome-sharded");
     if (c->ref_len.empty()) return fail(c, SQ_E_ARG, "sq_set_references first");
@@ -1153,6 +1166,7 @@ int sq_ingest_bwa_file(sq_ctx* c, const char* path, int32_t n_threads) {
     c->counts.n_blocks = (int64_t)all->b_refpos.size();
     return SQ_OK;
 }
+int sq_ingest_bwa_file(sq_ctx* c, const char* path, int32_t n_threads) { return abi_guard(c, "sq_ingest_bwa_file", [&]() { return sq_ingest_bwa_file_impl(c, path, n_threads); }); }
 // utils/JunctionSequence.cpp as a library call: host work only (no context, no device)
 int sq_junction_sequences(const char* bedpe_path, const char* chim_bam_path, const char* fasta_path, const char* out_prefix, char* errbuf, size_t errcap) {
     if (!bedpe_path || !chim_bam_path || !fasta_path || !out_prefix) return SQ_E_ARG;
@@ -1256,7 +1270,7 @@ int sq_save_records(sq_ctx* c, const char* path) {
     if (!ok) return fail(c, SQ_E_IO, std::string("short write to ") + path);
     return SQ_OK;
 }
-int sq_load_records(sq_ctx* c, const char* path) {
+static int sq_load_records_impl(sq_ctx* c, const char* path) {
     if (!c || !path) return SQ_E_ARG;
     if (c->ref_len.empty()) return fail(c, SQ_E_ARG, "sq_set_references first");
     FILE* f = std::fopen(path, "rb");
@@ -1319,7 +1333,8 @@ int sq_load_records(sq_ctx* c, const char* path) {
     if (!ok) return fail(c, SQ_E_IO, std::string("truncated or corrupt record cache ") + path);
     return rc;
 }
-int sq_build_graph(sq_ctx* c) {
+int sq_load_records(sq_ctx* c, const char* path) { return abi_guard(c, "sq_load_records", [&]() { return sq_load_records_impl(c, path); }); }
+static int sq_build_graph_impl(sq_ctx* c) {
     if (!c) return SQ_E_ARG;
     if (c->ref_len.empty()) return fail(c, SQ_E_ARG, "sq_set_references first");
     if (c->read_len <= 0 && !c->bwa) return fail(c, SQ_E_ARG, "sq_ingest_chimeric first (ReadLen comes from the chimeric BAM)");
@@ -1337,19 +1352,21 @@ int sq_build_graph(sq_ctx* c) {
     if (rc < 0) { c->gb.reset(); c->x_pending = false; }
     return rc;
 }
+int sq_build_graph(sq_ctx* c) { return abi_guard(c, "sq_build_graph", [&]() { return sq_build_graph_impl(c); }); }
 int sq_graph_view(sq_ctx* c, int32_t stage, sq_graph* g) {
     if (!c || !g || stage < 0 || stage > 5 || !c->graph_built) return SQ_E_ARG;
     if (stage != 0 && !c->keep_stages) return fail(c, SQ_E_ARG, "the intermediate graphs were not kept (sq_keep_stage_graphs(ctx, 0) before sq_build_graph)");
     c->snap[stage].view(g);
     return SQ_OK;
 }
-int sq_order(sq_ctx* c, sq_orders* o) {
+static int sq_order_impl(sq_ctx* c, sq_orders* o) {
     if (!c || !c->graph_built) return SQ_E_ARG;
     if (!c->ordered) { int rc = order_components(c); dev_flush_timers(c); if (rc) return rc; }
     if (o) { o->n_components = (int32_t)c->ord_off.size() - 1; o->comp_off = c->ord_off.data(); o->nodes = c->ord_nodes.data(); }
     return SQ_OK;
 }
-int sq_total_order(sq_ctx* c, sq_orders* o) {
+int sq_order(sq_ctx* c, sq_orders* o) { return abi_guard(c, "sq_order", [&]() { return sq_order_impl(c, o); }); }
+static int sq_total_order_impl(sq_ctx* c, sq_orders* o) {
     if (!c || !o || !c->graph_built) return SQ_E_ARG;
     if (!c->ordered) { int rc = order_components(c); dev_flush_timers(c); if (rc) return rc; }
     const int rc = total_order(c);
@@ -1357,7 +1374,8 @@ int sq_total_order(sq_ctx* c, sq_orders* o) {
     o->n_components = (int32_t)c->tot_off.size() - 1; o->comp_off = c->tot_off.data(); o->nodes = c->tot_nodes.data();
     return SQ_OK;
 }
-int sq_call_sv(sq_ctx* c, sq_sv_table* t) {
+int sq_total_order(sq_ctx* c, sq_orders* o) { return abi_guard(c, "sq_total_order", [&]() { return sq_total_order_impl(c, o); }); }
+static int sq_call_sv_impl(sq_ctx* c, sq_sv_table* t) {
     if (!c || !c->graph_built) return SQ_E_ARG;
     int rc = call_sv(c);
     dev_flush_timers(c);
@@ -1372,11 +1390,17 @@ int sq_call_sv(sq_ctx* c, sq_sv_table* t) {
     }
     return SQ_OK;
 }
-int sq_breakpoints(sq_ctx* c, sq_bp_table* t) {
+int sq_call_sv(sq_ctx* c, sq_sv_table* t) { return abi_guard(c, "sq_call_sv", [&]() { return sq_call_sv_impl(c, t); }); }
+static int sq_breakpoints_impl(sq_ctx* c, sq_bp_table* t) {
     if (!c || !t || c->bp_off.empty()) return SQ_E_ARG;
     t->n_edges = (int32_t)c->bp_off.size() - 1;
     t->bp_off = c->bp_off.data(); t->bp1 = c->bp1.data(); t->bp2 = c->bp2.data(); t->sup1 = c->bsup1.data(); t->sup2 = c->bsup2.data();
     return SQ_OK;
+}
+int sq_breakpoints(sq_ctx* c, sq_bp_table* t) { return abi_guard(c, "sq_breakpoints", [&]() { return sq_breakpoints_impl(c, t); }); }
+int sq_debug_token_bench(sq_ctx* c, const char* path, int32_t variant, int32_t max_blocks, int32_t reps, int32_t check, double* out7) {
+    if (!c || !path || !out7 || max_blocks <= 0 || reps <= 0) return SQ_E_ARG;
+    return abi_guard(c, "sq_debug_token_bench", [&]() { return dev_token_bench(c, path, variant, max_blocks, reps, check, out7); });
 }
 int sq_get_timing(sq_ctx* c, sq_timing* t) {
     if (!c || !t) return SQ_E_ARG;
@@ -1497,7 +1521,7 @@ int sq_exchange_pack(sq_ctx* c, const void** buf, int64_t* nbytes) {
     *buf = c->xbuf.data(); *nbytes = (int64_t)c->xbuf.size();
     return SQ_OK;
 }
-int sq_exchange_unpack(sq_ctx* c, const void* gathered, const int64_t* nbytes_per_rank, int32_t world_size) {
+static int sq_exchange_unpack_impl(sq_ctx* c, const void* gathered, const int64_t* nbytes_per_rank, int32_t world_size) {
     if (!c || !nbytes_per_rank || world_size != c->P.world_size) return SQ_E_ARG;
     if (!c->x_pending) return fail(c, SQ_E_ARG, "no exchange is pending");
     c->xgot.assign(world_size, {});
@@ -1511,5 +1535,6 @@ int sq_exchange_unpack(sq_ctx* c, const void* gathered, const int64_t* nbytes_pe
     c->x_pending = false; c->x_ready = true;
     return SQ_OK;
 }
+int sq_exchange_unpack(sq_ctx* c, const void* gathered, const int64_t* nbytes_per_rank, int32_t world_size) { return abi_guard(c, "sq_exchange_unpack", [&]() { return sq_exchange_unpack_impl(c, gathered, nbytes_per_rank, world_size); }); }
 
 }  // extern "C"

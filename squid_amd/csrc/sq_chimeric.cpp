@@ -69,7 +69,7 @@ bool frag_equal(const Frag& x, const Frag& y) {  // ReadRec.cpp:119-141
 namespace {
 template <class T> struct Raw {
     T* p; size_t n;
-    explicit Raw(size_t n_) : p((T*)std::malloc(std::max<size_t>(1, n_) * sizeof(T))), n(n_) { static_assert(std::is_trivially_copyable<T>::value, "scratch of plain values"); }
+    explicit Raw(size_t n_) : p((T*)std::malloc(std::max<size_t>(1, n_) * sizeof(T))), n(n_) { static_assert(std::is_trivially_copyable<T>::value, "scratch of plain values"); if (!p) throw std::bad_alloc(); }
     ~Raw() { std::free(p); }
     Raw(const Raw&) = delete; Raw& operator=(const Raw&) = delete;
     T& operator[](size_t i) { return p[i]; }
@@ -190,6 +190,7 @@ int build_fragments(sq_ctx* c, const sq_aln_batch* b) {
     };
     const std::function<void(int64_t, const std::function<void(int64_t, int64_t)>&)> par_fn = par;
     FragStore store{(Frag*)std::malloc(std::max<size_t>(1, nm) * sizeof(Frag)), nm, &par_fn, std::vector<uint8_t>(nm, 0)};
+    if (!store.p) throw std::bad_alloc();
     Frag* merged = store.p;
     auto by_readpos = blk_less_readpos;
     par((int64_t)nm, [&](int64_t lo, int64_t hi) {

@@ -6,6 +6,8 @@
 #include <thread>
 #include <mutex>
 #include <deque>
+#include <exception>
+#include <new>
 #include <condition_variable>
 #include <atomic>
 #include <cstdint>
@@ -54,6 +56,7 @@ class SmallVec {
     T* inl() { return reinterpret_cast<T*>(in_); }
     void grow(size_t c) {
         T* q = (T*)std::malloc(c * sizeof(T));
+        if (!q) throw std::bad_alloc();  // (the object is unchanged)
         std::memcpy((void*)q, (const void*)p_, (size_t)n_ * sizeof(T));
         if (p_ != inl()) std::free(p_);
         p_ = q; cap_ = (uint32_t)c;
@@ -190,12 +193,21 @@ public:
     // for a helper that only that thread could have run).
     void parallel_for(int count, int max_helpers, const std::function<void(int)>& f) {
         if (count <= 0) return;
-        struct Loop { std::atomic<int> next{0}, done{0}; std::mutex m; std::condition_variable cv; };
+        // An exception thrown by `f` (the bodies allocate: std::bad_alloc) is caught where it is thrown -- on a helper thread it would end the
+        // process, on the calling thread it would unwind past helpers that still hold `fp` and the body's by-reference captures --, the first
+        // one is kept, the indices that are left are claimed without being run, and the caller rethrows it once every index is accounted for.
+        struct Loop { std::atomic<int> next{0}, done{0}; std::atomic<bool> failed{false}; std::mutex m; std::condition_variable cv; std::exception_ptr first; };
         auto st = std::make_shared<Loop>();
         const std::function<void(int)>* fp = &f;
         auto body = [st, count, fp]() {
             int mine = 0;
-            for (int i; (i = st->next.fetch_add(1)) < count;) { (*fp)(i); ++mine; }
+            for (int i; (i = st->next.fetch_add(1)) < count;) {
+                if (!st->failed.load(std::memory_order_relaxed)) {
+                    try { (*fp)(i); }
+                    catch (...) { std::lock_guard<std::mutex> lk(st->m); if (!st->first) st->first = std::current_exception(); st->failed.store(true); }
+                }
+                ++mine;
+            }
             if (mine && st->done.fetch_add(mine) + mine == count) { std::lock_guard<std::mutex> lk(st->m); st->cv.notify_all(); }
         };
         const int nh = std::min(std::min(count - 1, max_helpers), size());
@@ -206,6 +218,7 @@ public:
         body();
         std::unique_lock<std::mutex> lk(st->m);
         st->cv.wait(lk, [&]() { return st->done.load() == count; });
+        if (st->first) std::rethrow_exception(st->first);
     }
 };
 
@@ -429,6 +442,7 @@ int order_problem_debug(sq_ctx* c, int n, const std::vector<int32_t>& edges5, bo
 int dev_create(sq_ctx* c);
 void dev_destroy(sq_ctx* c);
 void dev_flush_timers(sq_ctx* c);
+int dev_token_bench(sq_ctx* c, const char* path, int variant, int max_blocks, int reps, int check, double* out);
 int dev_append_records(sq_ctx* c, const sq_aln_batch* b);
 void dev_clear_records(sq_ctx* c);
 int dev_release_reader(sq_ctx* c);

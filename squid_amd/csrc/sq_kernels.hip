@@ -32,6 +32,7 @@
 #include <zlib.h>
 
 #include "sq_internal.h"
+#include "sq_inflate_spec.inc"
 
 #define HIPCHK(call)                                                                                         \
     do {                                                                                                     \
@@ -2448,6 +2449,50 @@ __global__ __launch_bounds__(320, 1) void k_inflate_tok2(const uint8_t* file, co
     }
 }
 
+// The token pass of round 6: one wave per BGZF block, the lanes on 64 consecutive stretches of its bit stream (sq_inflate_spec.inc).
+template <int CH, int PB>
+__global__ __launch_bounds__(64) void k_inflate_spec(const uint8_t* file, const InflBlock* blocks, int nblocks, int32_t* flags, uint32_t* tok, int32_t* ntok) {
+    extern __shared__ uint32_t isp_lds[];
+    const int bi = (int)blockIdx.x;
+    if (bi >= nblocks) return;
+    const InflBlock blk = blocks[bi];
+    bool err = false;
+    uint32_t nt = 0;
+    if (blk.isize) nt = isp::inflate_block_spec<CH, PB>((wv::lds_u32*)isp_lds, file + blk.coff, blk.clen, tok + blk.toff, isp::tok_cap_spec(blk.isize, blk.clen), err);
+    if (threadIdx.x == 0) { ntok[bi] = (int32_t)nt; if (err) atomicOr(&flags[0], 512); }
+}
+struct SpecProf {  // cycles per phase of the block, summed over the launch (one atomic per counter and block)
+    unsigned long long* g; unsigned long long t0; unsigned long long c[9];
+    __device__ SpecProf(unsigned long long* g_) : g(g_), t0(__builtin_amdgcn_s_memtime()) { for (int i = 0; i < 9; ++i) c[i] = 0; }
+    __device__ __forceinline__ void tick(int k) { const unsigned long long now = __builtin_amdgcn_s_memtime(); c[k] += now - t0; t0 = now; }
+    __device__ __forceinline__ void count(int k, uint32_t n = 1) { c[k] += n; }
+    __device__ __forceinline__ void finish() { if ((threadIdx.x & 63u) == 0) for (int i = 0; i < 9; ++i) atomicAdd(&g[i], c[i]); }
+};
+template <int CH, int PB>
+__global__ __launch_bounds__(64) void k_inflate_spec_prof(const uint8_t* file, const InflBlock* blocks, int nblocks, int32_t* flags, uint32_t* tok, int32_t* ntok, unsigned long long* prof) {
+    extern __shared__ uint32_t isp_lds[];
+    const int bi = (int)blockIdx.x;
+    if (bi >= nblocks) return;
+    const InflBlock blk = blocks[bi];
+    bool err = false;
+    uint32_t nt = 0;
+    if (blk.isize) nt = isp::inflate_block_spec<CH, PB, SpecProf>((wv::lds_u32*)isp_lds, file + blk.coff, blk.clen, tok + blk.toff, isp::tok_cap_spec(blk.isize, blk.clen), err, SpecProf(prof));
+    if (threadIdx.x == 0) { ntok[bi] = (int32_t)nt; if (err) atomicOr(&flags[0], 512); }
+}
+// (the variants the tuning entry sq_debug_token_bench can time; the reader runs SPEC_CH / SPEC_PB)
+#ifndef SQ_SPEC_CH
+#define SQ_SPEC_CH 256
+#endif
+#ifndef SQ_SPEC_PB
+#define SQ_SPEC_PB 10
+#endif
+constexpr int SPEC_CH = SQ_SPEC_CH, SPEC_PB = SQ_SPEC_PB;
+template <int CH, int PB>
+static void launch_inflate_spec(hipStream_t s, const uint8_t* file, const InflBlock* blocks, int nb, int32_t* flags, uint32_t* tok, int32_t* ntok) {
+    typedef isp::Lay<CH, PB> Y;
+    hipLaunchKernelGGL((k_inflate_spec<CH, PB>), dim3(nb), dim3(64), (size_t)Y::BYTES, s, file, blocks, nb, flags, tok, ntok);
+}
+
 // Inclusive prefix sum over the wave with DPP row shifts (no LDS traffic).
 __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
     x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
@@ -3478,6 +3523,104 @@ static int parse_device(sq_ctx* c, const uint8_t* d_bam, size_t nbytes, const un
     return SQ_OK;
 }
 
+// Tuning entry (tools/tok_bench.py): the token pass and the resolve of the first blocks of a BGZF file, each kernel ALONE on the device and
+// timed with HIP events -- what the reader's overlapped launches cannot show.  variant: CH * 100 + PB of k_inflate_spec (51211, 25610, ...),
+// 2 = k_inflate_tok2.  check != 0: the resolved bytes of every block against zlib.  out[0] token pass ms, out[1] resolve ms (averages over
+// reps), out[2] inflated bytes, out[3] compressed bytes, out[4] blocks, out[5] tokens, out[6] blocks that differ from zlib.
+int dev_token_bench(sq_ctx* c, const char* path, int variant, int max_blocks, int reps, int check, double* out) {
+    HIPCHK(hipSetDevice(c->P.device));
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return fail(c, SQ_E_IO, std::string("cannot open ") + path);
+    std::vector<uint8_t> raw;
+    std::vector<InflBlock> tab;
+    unsigned long long uoff = 0;
+    const bool spec = variant != 2;
+    for (int b = 0; b < max_blocks; ++b) {
+        uint8_t h[18];
+        if (std::fread(h, 1, 18, f) != 18) break;
+        const size_t bsize = (size_t)(h[16] | (h[17] << 8)) + 1;
+        const size_t at = raw.size();
+        raw.resize(at + bsize);
+        std::memcpy(raw.data() + at, h, 18);
+        if (std::fread(raw.data() + at + 18, 1, bsize - 18, f) != bsize - 18) { raw.resize(at); break; }
+        uint32_t isize; std::memcpy(&isize, raw.data() + at + bsize - 4, 4);
+        tab.push_back(InflBlock{at + 18, (uint32_t)(bsize - 26), isize, uoff, 0});
+        uoff += isize;
+    }
+    std::fclose(f);
+    if (tab.empty()) return fail(c, SQ_E_IO, "no BGZF block read");
+    unsigned long long slots = 0;
+    for (InflBlock& ib : tab) { ib.toff = slots; slots += spec ? isp::tok_cap_spec(ib.isize, ib.clen) : t2_tok_cap(ib.isize); }
+    const int nb = (int)tab.size();
+    DBuf<uint8_t> d_in, d_out; DBuf<InflBlock> d_tab; DBuf<uint32_t> d_tok, d_lens; DBuf<int32_t> d_ntok, d_flags;
+    struct Rel { DBuf<uint8_t>&a, &b; DBuf<InflBlock>& t; DBuf<uint32_t>&k, &l; DBuf<int32_t>&n, &fl; ~Rel() { a.release(); b.release(); t.release(); k.release(); l.release(); n.release(); fl.release(); } } rel{d_in, d_out, d_tab, d_tok, d_lens, d_ntok, d_flags};
+    HIPCHK(d_in.reserve(raw.size() + 512)); HIPCHK(d_out.reserve((size_t)uoff + 512)); HIPCHK(d_tab.reserve((size_t)nb)); HIPCHK(d_tok.reserve((size_t)slots + 64));
+    HIPCHK(d_ntok.reserve((size_t)nb)); HIPCHK(d_flags.reserve(16)); HIPCHK(d_lens.reserve(((size_t)nb + 128) * T2_LENS_WORDS));
+    HIPCHK(hipMemcpy(d_in.p, raw.data(), raw.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_tab.p, tab.data(), (size_t)nb * sizeof(InflBlock), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(d_flags.p, 0, 64));
+    HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * (int)T2_LDS_BYTES));
+    hipStream_t s = c->stream;
+    hipEvent_t e0, e1, e2;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreate(&e2));
+    double tok_ms = 0, res_ms = 0;
+    for (int r = 0; r < reps + 1; ++r) {  // (the first round warms up)
+        HIPCHK(hipEventRecord(e0, s));
+        switch (variant) {
+            case 2: hipLaunchKernelGGL(k_inflate_tok2<false>, dim3((nb + 63) / 64), dim3(64), T2_LDS_BYTES, s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p, d_lens.p, nullptr); break;
+            case 51211: launch_inflate_spec<512, 11>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
+            case 51210: launch_inflate_spec<512, 10>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
+            case 25610: launch_inflate_spec<256, 10>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
+            case 25611: launch_inflate_spec<256, 11>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
+            case 38411: launch_inflate_spec<384, 11>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
+            case 102411: launch_inflate_spec<1024, 11>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
+            default: return fail(c, SQ_E_ARG, "unknown token pass variant");
+        }
+        HIPCHK(hipEventRecord(e1, s));
+        hipLaunchKernelGGL(k_lz_resolve3, dim3(nb), dim3(64), 0, s, d_tok.p, d_ntok.p, d_tab.p, nb, 0ull, d_out.p, d_flags.p + 4);
+        HIPCHK(hipEventRecord(e2, s));
+        HIPCHK(hipStreamSynchronize(s));
+        float a = 0, b = 0;
+        HIPCHK(hipEventElapsedTime(&a, e0, e1)); HIPCHK(hipEventElapsedTime(&b, e1, e2));
+        if (r) { tok_ms += a; res_ms += b; }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+    if (variant == 51211 || variant == 25610) {  // where the cycles go: one more launch with the phase clock
+        DBuf<unsigned long long> d_prof;
+        HIPCHK(d_prof.reserve(16)); HIPCHK(hipMemset(d_prof.p, 0, 16 * 8));
+        if (variant == 51211) { typedef isp::Lay<512, 11> Y; hipLaunchKernelGGL((k_inflate_spec_prof<512, 11>), dim3(nb), dim3(64), (size_t)Y::BYTES, s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p, d_prof.p); }
+        else { typedef isp::Lay<256, 10> Y; hipLaunchKernelGGL((k_inflate_spec_prof<256, 10>), dim3(nb), dim3(64), (size_t)Y::BYTES, s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p, d_prof.p); }
+        unsigned long long pr[9];
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipMemcpy(pr, d_prof.p, sizeof pr, hipMemcpyDeviceToHost));
+        d_prof.release();
+        double tot = 0; for (int i = 0; i < 6; ++i) tot += (double)pr[i];
+        std::fprintf(stderr, "token pass %d, cycles of a block (s_memtime, 100 MHz ticks?): %.0f | headers %.1f %% tables %.1f %% window loads %.1f %% scans %.1f %% token writing %.1f %% rest %.1f %% | per block: %.1f deflate blocks, %.1f windows, %.2f scan rounds per window\n",
+                     variant, tot / nb, 100.0 * pr[0] / tot, 100.0 * pr[1] / tot, 100.0 * pr[2] / tot, 100.0 * pr[3] / tot, 100.0 * pr[4] / tot, 100.0 * pr[5] / tot, (double)pr[8] / nb, (double)pr[6] / nb, (double)pr[7] / std::max<double>(1, (double)pr[6]));
+    }
+    int32_t fl[8];
+    HIPCHK(hipMemcpy(fl, d_flags.p, sizeof fl, hipMemcpyDeviceToHost));
+    std::vector<int32_t> nt((size_t)nb);
+    HIPCHK(hipMemcpy(nt.data(), d_ntok.p, (size_t)nb * 4, hipMemcpyDeviceToHost));
+    long long ntok = 0;
+    for (int32_t v : nt) ntok += v;
+    long bad = (fl[0] | fl[4]) ? -1 : 0;
+    if (check && bad == 0) {
+        std::vector<uint8_t> got((size_t)uoff), want;
+        HIPCHK(hipMemcpy(got.data(), d_out.p, (size_t)uoff, hipMemcpyDeviceToHost));
+        for (const InflBlock& b : tab) {
+            want.resize(b.isize);
+            z_stream zs; std::memset(&zs, 0, sizeof zs);
+            inflateInit2(&zs, -15);
+            zs.next_in = (Bytef*)(raw.data() + b.coff); zs.avail_in = b.clen; zs.next_out = want.data(); zs.avail_out = b.isize;
+            inflate(&zs, Z_FINISH); inflateEnd(&zs);
+            if (b.isize && std::memcmp(want.data(), got.data() + b.uoff, b.isize) != 0) ++bad;
+        }
+    }
+    out[0] = tok_ms / std::max(1, reps); out[1] = res_ms / std::max(1, reps); out[2] = (double)uoff; out[3] = (double)raw.size(); out[4] = nb; out[5] = (double)ntok; out[6] = (double)bad;
+    return SQ_OK;
+}
+
 // K-1 + K0 for a whole file (or a shard's block range): compressed bytes -> HBM, inflate, record boundaries, parse -- the
 // host only indexes the BGZF blocks.  The range is streamed in batches of SQUID_TOK_CAP_MB of inflated bytes (fixed-size
 // device buffers whatever the file size), up to eight in flight: while batch k is resolved and cut into records on the library stream
@@ -3511,6 +3654,8 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     // with the LDS resolve 3 (93 KB), which leave the 64 KB slot of a resolve workgroup free on every CU
     static const bool resolve_global = std::getenv("SQUID_RESOLVE_GLOBAL") == nullptr || std::atoi(std::getenv("SQUID_RESOLVE_GLOBAL")) != 0;  // k_lz_resolve3 (no LDS window); 0: k_lz_resolve2
     static const int tok_wpb = std::getenv("SQUID_TOK_WPB") ? std::max(1, std::min(5, std::atoi(std::getenv("SQUID_TOK_WPB")))) : (resolve_global ? 1 : 3);
+    // round 6: the token pass as one wave per BGZF block (k_inflate_spec, sq_inflate_spec.inc); SQUID_TOK_SPEC=0 runs the lane-per-block pass
+    const bool tok_spec = std::getenv("SQUID_TOK_SPEC") == nullptr || std::atoi(std::getenv("SQUID_TOK_SPEC")) != 0;
     static const bool tok_prof = std::getenv("SQUID_TOK_PROF") != nullptr;
     if (tok_prof) HIPCHK(D.tok_prof.reserve(8 * 4096));
     static const int il_depth = std::getenv("SQUID_IL_DEPTH") ? std::max(3, std::min((int)DeviceRecords::IL_DEPTH_MAX, std::atoi(std::getenv("SQUID_IL_DEPTH")))) : (resolve_global ? 8 : 5);
@@ -3612,7 +3757,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         for (int i = 0; i < nb; ++i) { const BgzfRange& b = blocks[B.at + (size_t)i]; st.host_tab[(size_t)i] = InflBlock{b.coff - B.coff0, b.clen, b.isize, b.uoff, 0}; }
         std::stable_sort(st.host_tab.begin(), st.host_tab.end(), [](const InflBlock& x, const InflBlock& y) { return x.clen > y.clen; });
         unsigned long long tok_slots = 0;  // token slots of the batch: half a slot per inflated byte (t2_tok_cap), block after block in table order
-        for (InflBlock& ib : st.host_tab) { ib.toff = tok_slots; tok_slots += t2_tok_cap(ib.isize); }
+        for (InflBlock& ib : st.host_tab) { ib.toff = tok_slots; tok_slots += tok_spec ? isp::tok_cap_spec(ib.isize, ib.clen) : t2_tok_cap(ib.isize); }
         if (k >= (size_t)D.il_depth) HIPCHK(hipStreamWaitEvent(sa, st.freed, 0));  // the resolve of batch k - IL_DEPTH has read its tokens
         const auto wa0 = std::chrono::steady_clock::now();
         // sized for a full batch at once (the first batches are small): growing a buffer later frees the old one, and freeing
@@ -3623,8 +3768,10 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         if (!dfile) HIPCHK(st.in.reserve(std::max((size_t)B.cbytes, (size_t)(cratio * 1.1 * (double)full)) + 256));  // (the input rings read up to 80 bytes ahead)
         st.src = dfile ? dfile + B.coff0 : st.in.p;
         HIPCHK(st.tab.reserve(std::max((size_t)nb, (size_t)(full / 60000)))); HIPCHK(st.flags.reserve(4));
-        HIPCHK(st.tok.reserve(std::max((size_t)tok_slots, (size_t)(full / 2 + 80 * (full / 60000 + 1))) + 64)); HIPCHK(st.ntok.reserve(std::max((size_t)nb, (size_t)(full / 60000))));
-        HIPCHK(st.lens.reserve((std::max((size_t)nb, (size_t)(full / 60000)) + 128) * T2_LENS_WORDS));  // (one strip of code lengths per lane of the token pass)
+        // (a full batch's token slots: half a slot per inflated byte + per block the slack of t2_tok_cap / tok_cap_spec, which also takes an eighth of a slot per compressed byte)
+        const size_t tok_full = tok_spec ? (size_t)(full / 2 + (unsigned long long)(cratio * 1.1 * (double)full) / 8 + 260 * (full / 60000 + 1)) : (size_t)(full / 2 + 80 * (full / 60000 + 1));
+        HIPCHK(st.tok.reserve(std::max((size_t)tok_slots, tok_full) + 64)); HIPCHK(st.ntok.reserve(std::max((size_t)nb, (size_t)(full / 60000))));
+        if (!tok_spec) HIPCHK(st.lens.reserve((std::max((size_t)nb, (size_t)(full / 60000)) + 128) * T2_LENS_WORDS));  // (one strip of code lengths per lane of the token pass)
         const double wa1 = since_ms(wa0);
         if (!dfile) {
             // (the copy no longer travels on the set's stream: the token pass and the resolve that last read this buffer are waited for here)
@@ -3639,7 +3786,10 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
             rep{report && k < 3, k, std::chrono::duration<double, std::milli>(wa0 - w0).count(), wa1, wa2, wa3, (double)B.cbytes * 1e-9, wa0};
         HIPCHK(hipMemcpyAsync(st.tab.p, st.host_tab.data(), (size_t)nb * sizeof(InflBlock), hipMemcpyHostToDevice, sa));
         HIPCHK(hipMemsetAsync(st.flags.p, 0, 4 * 4, sa));
-        {   // k_inflate_tok2 stays on the set's own stream: the token kernels of up to four batches run side by side
+        if (tok_spec) {
+            EvTimer t1(c, "k_inflate_spec", (double)B.cbytes + (double)B.bbytes * 2, sa);
+            launch_inflate_spec<SPEC_CH, SPEC_PB>(sa, st.src, st.tab.p, nb, st.flags.p, st.tok.p, st.ntok.p);
+        } else {   // k_inflate_tok2 stays on the set's own stream: the token kernels of up to four batches run side by side
             EvTimer t1(c, "k_inflate_tok2", (double)B.cbytes + (double)B.bbytes * 2, sa);
             if (tok_prof && k == 8) hipLaunchKernelGGL(k_inflate_tok2<true>, dim3((nb + 63) / 64), dim3(64), T2_LDS_BYTES, sa, st.src, st.tab.p, nb, st.flags.p, st.tok.p, st.ntok.p, st.lens.p, D.tok_prof.p);
             else hipLaunchKernelGGL(k_inflate_tok2<false>, dim3(((nb + 63) / 64 + tok_wpb - 1) / tok_wpb), dim3(64 * tok_wpb), tok_wpb * T2_LDS_BYTES, sa, st.src, st.tab.p, nb, st.flags.p, st.tok.p, st.ntok.p, st.lens.p, nullptr);

@@ -523,7 +523,7 @@ double segment_clusters(const sq_ctx* c, std::shared_ptr<SegPlan>& plan, std::ve
         // same comparison takes libstdc++'s introsort through the same decisions, hence to the same permutation, at a fraction of
         // the memory traffic of sorting the blocks themselves
         struct PK { int32_t refid, refpos, idx; };
-        struct RawPK { PK* p; explicit RawPK(size_t n) : p((PK*)std::malloc(std::max<size_t>(1, n) * sizeof(PK))) {} ~RawPK() { std::free(p); } } pk(nD);  // (every element is written below)
+        struct RawPK { PK* p; explicit RawPK(size_t n) : p((PK*)std::malloc(std::max<size_t>(1, n) * sizeof(PK))) { if (!p) throw std::bad_alloc(); } ~RawPK() { std::free(p); } } pk(nD);  // (every element is written below)
         // the room for the sorted list is made (230 MB of zeroes on the dense config, one thread's work) while the keys are being sorted
         std::future<void> room;
         std::vector<Blk> sorted;

@@ -1491,3 +1491,25 @@ def test_without_the_inspection_copies_of_the_intermediate_graphs(built, synth, 
                     ctx.graph(2)
     assert got[True] == got[False]
     assert got[False][2] == sv_path.read_text()
+
+
+@pytest.mark.gpu
+def test_the_suite_s_default_route_is_the_device_reader(built, synth, monkeypatch):
+    """tests/conftest.py sends every BAM of the GPU suite through the device reader (SQUID_GPU_INFLATE=1 unless a test says otherwise):
+    the stage-parity tests above therefore ran the token pass (k_inflate_spec; k_inflate_tok2 with SQUID_TOK_SPEC=0), the resolve and the
+    boundary kernels -- checked here on the timers of a plain load, for both token passes, whose records must be the same"""
+    import os
+    assert os.environ.get("SQUID_GPU_INFLATE") == "1"
+    pre = synth("T2")
+    seen = {}
+    for spec in ("1", "0"):
+        monkeypatch.setenv("SQUID_TOK_SPEC", spec)
+        with squid_amd.Context() as ctx:
+            ctx.load(f"{pre}.bam", f"{pre}.chim.bam", threads=4)
+            names = set(ctx.timing())
+            assert ("k_inflate_spec" if spec == "1" else "k_inflate_tok2") in names, names
+            assert "k_lz_resolve3" in names and "k_rec_sync+walk+check" in names, names
+            ctx.build_graph()
+            ctx.order()
+            seen[spec] = (ctx.counts()["n_concordant"], ctx.counts()["n_blocks"], ctx.sv_text())
+    assert seen["1"] == seen["0"]

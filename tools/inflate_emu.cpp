@@ -1,0 +1,177 @@
+// The speculative token pass (squid_amd/csrc/sq_inflate_spec.inc) run on the CPU -- the kernel source itself, its 64 lanes as coroutines
+// (sq_wave.h, SQ_WAVE_EMU) -- and compared with zlib: on the BGZF blocks of a BAM file, and on fuzzed streams of every block type.
+//   g++ -O1 -g -std=c++17 -DSQ_WAVE_EMU -o build/inflate_emu tools/inflate_emu.cpp -lz
+//   build/inflate_emu file.bam [blocks]      |      build/inflate_emu --fuzz [cases] [seed]
+// Test infrastructure only.
+#define __host__
+#define __device__
+#include "../squid_amd/csrc/sq_inflate_spec.inc"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <random>
+#include <string>
+#include <vector>
+
+struct Job { std::vector<uint32_t> lds; const uint8_t* payload; uint32_t clen, tcap; std::vector<uint32_t> tok; uint32_t nt[64]; bool err[64]; int cfg; };
+template <int CH, int PB>
+static void lane_main(void* p) {
+    Job& j = *(Job*)p;
+    bool err = false;
+    const uint32_t nt = isp::inflate_block_spec<CH, PB>(j.lds.data(), j.payload, j.clen, j.tok.data(), j.tcap, err);
+    j.nt[wv::lane()] = nt; j.err[wv::lane()] = err;
+}
+// tokens -> bytes, as k_lz_resolve3 reads them
+static bool resolve(const std::vector<uint32_t>& tok, uint32_t nt, std::vector<uint8_t>& out, uint32_t isize) {
+    out.clear();
+    for (uint32_t i = 0; i < nt; ++i) {
+        const uint32_t t = tok[i];
+        if (t >> 31) {
+            const uint32_t len = (t >> 16) & 0x1ffu, dist = (t & 0x7fffu) + 1u;
+            if (dist > out.size() || out.size() + len > isize) return false;
+            for (uint32_t k = 0; k < len; ++k) out.push_back(out[out.size() - dist]);
+        } else {
+            const uint32_t nl = (t >> 24) & 3u, n = nl ? nl : 1u;
+            if (out.size() + n > isize) return false;
+            for (uint32_t k = 0; k < n; ++k) out.push_back((uint8_t)(t >> (8 * k)));
+        }
+    }
+    return out.size() == isize;
+}
+// returns 0 same bytes as zlib, 1 error flag raised, 2 WRONG
+static int run_block(const uint8_t* payload, uint32_t clen, const std::vector<uint8_t>& want, int cfg, uint32_t* ntok_out = nullptr) {
+    Job j;
+    j.lds.assign(65536, 0xdeadbeefu);
+    j.payload = payload; j.clen = clen; j.cfg = cfg;
+    j.tcap = isp::tok_cap_spec((uint32_t)want.size(), clen);
+    j.tok.assign(j.tcap + 64, 0x55555555u);
+    switch (cfg) {
+        case 0: wv::run_wave(lane_main<512, 11>, &j); break;
+        case 1: wv::run_wave(lane_main<256, 10>, &j); break;
+        case 2: wv::run_wave(lane_main<128, 10>, &j); break;
+        default: wv::run_wave(lane_main<1024, 11>, &j); break;
+    }
+    for (int l = 1; l < 64; ++l) if (j.nt[l] != j.nt[0] || j.err[l] != j.err[0]) { std::fprintf(stderr, "lanes disagree on the result\n"); return 2; }
+    for (uint32_t k = j.tcap; k < j.tcap + 64; ++k) if (j.tok[k] != 0x55555555u) { std::fprintf(stderr, "token written behind the block's slots\n"); return 2; }
+    if (ntok_out) *ntok_out = j.nt[0];
+    if (j.err[0]) return 1;
+    std::vector<uint8_t> got;
+    if (!resolve(j.tok, j.nt[0], got, (uint32_t)want.size())) { std::fprintf(stderr, "tokens do not resolve to %zu bytes (got %zu)\n", want.size(), got.size()); return 2; }
+    if (got != want) { size_t q = 0; while (got[q] == want[q]) ++q; std::fprintf(stderr, "bytes differ at %zu\n", q); return 2; }
+    return 0;
+}
+static bool zinflate(const uint8_t* p, uint32_t clen, std::vector<uint8_t>& out, uint32_t cap) {
+    out.assign(cap, 0);
+    z_stream zs; std::memset(&zs, 0, sizeof zs);
+    inflateInit2(&zs, -15);
+    zs.next_in = (Bytef*)p; zs.avail_in = clen; zs.next_out = out.data(); zs.avail_out = cap;
+    const int rc = inflate(&zs, Z_FINISH);
+    out.resize(zs.total_out);
+    inflateEnd(&zs);
+    return rc == Z_STREAM_END;
+}
+static std::vector<uint8_t> zdeflate(const std::vector<uint8_t>& in, int level, int strategy, int memlevel, std::mt19937& rng, bool flushes) {
+    z_stream zs; std::memset(&zs, 0, sizeof zs);
+    deflateInit2(&zs, level, Z_DEFLATED, -15, memlevel, strategy);
+    std::vector<uint8_t> out(deflateBound(&zs, in.size()) + 4096 + in.size() / 8);
+    zs.next_out = out.data(); zs.avail_out = (uInt)out.size();
+    size_t at = 0;
+    while (flushes && at < in.size()) {  // pieces closed by flushes: several deflate blocks, empty stored blocks in between, other parameters
+        const size_t n = std::min(in.size() - at, (size_t)(1 + rng() % 20000));
+        zs.next_in = (Bytef*)in.data() + at; zs.avail_in = (uInt)n;
+        const int fl = rng() % 3 == 0 ? Z_FULL_FLUSH : (rng() % 2 ? Z_SYNC_FLUSH : Z_BLOCK);
+        deflate(&zs, fl);
+        at += n;
+        if (rng() % 3 == 0) deflateParams(&zs, (int)(rng() % 10), (int)(rng() % 5));
+    }
+    zs.next_in = (Bytef*)in.data() + at; zs.avail_in = (uInt)(in.size() - at);
+    deflate(&zs, Z_FINISH);
+    out.resize(zs.total_out);
+    deflateEnd(&zs);
+    return out;
+}
+static std::vector<uint8_t> make_data(std::mt19937& rng, size_t n) {
+    std::vector<uint8_t> d(n);
+    const int kind = (int)(rng() % 8);
+    switch (kind) {
+        case 0: for (auto& b : d) b = (uint8_t)rng(); break;                                   // incompressible
+        case 1: for (auto& b : d) b = (uint8_t)("ACGT"[rng() % 4]); break;                     // four symbols
+        case 2: { uint8_t v = 0; for (size_t i = 0; i < n; ++i) { if (rng() % 50 == 0) v = (uint8_t)rng(); d[i] = v; } break; }  // long runs (distance 1, length 258)
+        case 3: for (size_t i = 0; i < n; ++i) d[i] = (uint8_t)(i < 300 ? rng() : d[i - 1 - rng() % 300] ^ (rng() % 20 == 0)); break;  // near repeats
+        case 4: { std::geometric_distribution<int> g(0.05); for (auto& b : d) b = (uint8_t)std::min(255, g(rng)); break; }  // skewed: long and short codes
+        case 5: for (size_t i = 0; i < n; ++i) d[i] = (uint8_t)(i % 7 == 0 ? rng() : 'a' + rng() % 3); break;
+        case 6: { std::geometric_distribution<int> g(0.3); for (auto& b : d) b = (uint8_t)(g(rng) * 37); break; }
+        default: for (size_t i = 0; i < n; ++i) d[i] = (uint8_t)(i & 0xff); break;             // every byte value, far matches
+    }
+    return d;
+}
+int main(int argc, char** argv) {
+    if (argc < 2) { std::fprintf(stderr, "usage: inflate_emu file.bam [blocks] | --fuzz [cases] [seed]\n"); return 1; }
+    long n_ok = 0, n_flag = 0, n_wrong = 0;
+    if (std::string(argv[1]) == "--fuzz") {
+        const long cases = argc > 2 ? std::atol(argv[2]) : 200;
+        std::mt19937 rng(argc > 3 ? (unsigned)std::atol(argv[3]) : 12345u);
+        for (long c = 0; c < cases; ++c) {
+            const size_t sizes[6] = {0, 1, 2, 300, 5000, 65280};
+            const size_t n = rng() % 3 == 0 ? sizes[rng() % 6] : rng() % 65281;
+            const std::vector<uint8_t> data = make_data(rng, n);
+            const int level = (int)(rng() % 10), strat = (int)(rng() % 5), mem = 1 + (int)(rng() % 9);
+            std::vector<uint8_t> comp = zdeflate(data, level, strat, mem, rng, rng() % 3 == 0);
+            if (comp.size() > 65535 + 4096) continue;
+            const uint32_t off = rng() % 16;  // the payload anywhere relative to a 16-byte boundary
+            std::vector<uint8_t> buf(comp.size() + 64 + 16 + 16);
+            uint8_t* base = buf.data() + ((16 - ((uintptr_t)buf.data() & 15)) & 15);
+            for (size_t i = 0; i < buf.size() - (size_t)(base - buf.data()); ++i) base[i] = (uint8_t)rng();  // (noise around the payload)
+            std::memcpy(base + off, comp.data(), comp.size());
+            const int cfg = (int)(rng() % 4);
+            const int rc = run_block(base + off, (uint32_t)comp.size(), data, cfg);
+            if (rc == 0) ++n_ok; else if (rc == 1) { ++n_flag; std::fprintf(stderr, "case %ld: error flag on a valid stream (n %zu level %d strategy %d cfg %d)\n", c, n, level, strat, cfg); } else { ++n_wrong; std::fprintf(stderr, "case %ld WRONG (n %zu level %d strategy %d mem %d cfg %d off %u)\n", c, n, level, strat, mem, cfg, off); }
+        }
+        // damaged streams: whatever comes out, no token may land outside the block's slots and the lanes must agree (run_block checks both)
+        long n_dam = 0, n_dam_flag = 0;
+        for (long c = 0; c < cases / 4; ++c) {
+            const std::vector<uint8_t> data = make_data(rng, 1 + rng() % 20000);
+            std::vector<uint8_t> comp = zdeflate(data, 6, 0, 8, rng, false);
+            for (int k = 0; k < 3; ++k) comp[rng() % comp.size()] ^= (uint8_t)(1u << (rng() % 8));
+            std::vector<uint8_t> buf(comp.size() + 96);
+            uint8_t* base = buf.data() + ((16 - ((uintptr_t)buf.data() & 15)) & 15);
+            std::memcpy(base, comp.data(), comp.size());
+            std::vector<uint8_t> want;
+            const bool zok = zinflate(base, (uint32_t)comp.size(), want, (uint32_t)data.size());
+            std::vector<uint8_t> ref = zok && want.size() == data.size() ? want : data;
+            const int rc = run_block(base, (uint32_t)comp.size(), ref, (int)(rng() % 4));
+            ++n_dam;
+            if (rc == 1) ++n_dam_flag;
+            if (rc == 0 && !(zok && want.size() == data.size())) { std::fprintf(stderr, "damaged case %ld: accepted where zlib refuses\n", c); }
+        }
+        std::printf("fuzz: %ld identical to zlib, %ld flagged, %ld WRONG; damaged streams: %ld run, %ld flagged\n", n_ok, n_flag, n_wrong, n_dam, n_dam_flag);
+        return n_wrong || n_flag ? 2 : 0;
+    }
+    FILE* f = std::fopen(argv[1], "rb");
+    if (!f) { std::perror(argv[1]); return 1; }
+    const long maxb = argc > 2 ? std::atol(argv[2]) : 50;
+    const int cfg = argc > 3 ? std::atoi(argv[3]) : 0;
+    std::vector<uint8_t> raw;
+    unsigned long long tot_tok = 0, tot_bytes = 0;
+    for (long bi = 0; bi < maxb; ++bi) {
+        uint8_t h[18];
+        if (std::fread(h, 1, 18, f) != 18) break;
+        const int bsize = (h[16] | (h[17] << 8)) + 1;
+        raw.assign((size_t)bsize - 18 + 80, 0);
+        uint8_t* base = raw.data() + ((16 - ((uintptr_t)raw.data() & 15)) & 15) + (bi % 16);
+        if (std::fread(base, 1, (size_t)bsize - 18, f) != (size_t)bsize - 18) break;
+        const uint32_t clen = (uint32_t)bsize - 18 - 8;
+        uint32_t isize; std::memcpy(&isize, base + clen + 4, 4);
+        std::vector<uint8_t> want;
+        if (!zinflate(base, clen, want, isize) || want.size() != isize) { std::fprintf(stderr, "block %ld: zlib refuses it\n", bi); return 2; }
+        uint32_t nt = 0;
+        const int rc = run_block(base, clen, want, cfg, &nt);
+        tot_tok += nt; tot_bytes += isize;
+        if (rc == 0) ++n_ok; else if (rc == 1) { ++n_flag; std::fprintf(stderr, "block %ld: error flag\n", bi); } else { ++n_wrong; std::fprintf(stderr, "block %ld WRONG\n", bi); }
+    }
+    std::printf("%ld blocks identical to zlib, %ld flagged, %ld WRONG; %.3f tokens per inflated byte\n", n_ok, n_flag, n_wrong, tot_bytes ? (double)tot_tok / (double)tot_bytes : 0.0);
+    const isp::EmuStat& st = isp::emu_stat();
+    std::printf("writing pass: %llu steps for %llu literals (%llu as pairs: %.1f %% of the literals) and %llu matches: %.2f symbols per step\n", st.iters, st.lits, st.pairs, st.lits ? 200.0 * st.pairs / st.lits : 0.0, st.matches, st.iters ? (double)(st.lits + st.matches) / st.iters : 0.0);
+    return n_wrong || n_flag ? 2 : 0;
+}
