@@ -3645,7 +3645,10 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     auto since_ms = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     // a batch = 256 waves of the token pass (1 GiB inflated); five batches fill the 1280 token slots of the machine (five waves per CU).
     // Measured at C3 (round 4, eight sets): 512 MB 157 ms per step, 640 MB 141, 768 MB 137, 1 GiB 136, 1.25 GB 135
-    const unsigned long long cap = std::getenv("SQUID_TOK_CAP_MB") ? (unsigned long long)std::atoll(std::getenv("SQUID_TOK_CAP_MB")) << 20 : 256ull * 64 * 65536;
+    // (round 6, wave-per-block token pass: a launch is over in a few milliseconds whatever its size, so the batches are as small as the chain
+    // behind them -- resolve, boundaries, parse -- allows: 512 MB; from the page cache 156-161 ms per C3 step against 170-198 with 1 GiB)
+    const bool tok_spec_early = std::getenv("SQUID_TOK_SPEC") == nullptr || std::atoi(std::getenv("SQUID_TOK_SPEC")) != 0;
+    const unsigned long long cap = std::getenv("SQUID_TOK_CAP_MB") ? (unsigned long long)std::atoll(std::getenv("SQUID_TOK_CAP_MB")) << 20 : (tok_spec_early ? 128ull : 256ull) * 64 * 65536;
     if (report) std::fprintf(stderr, "GPU ingest: entry + %.1f ms: device chosen, memory asked about\n", since_ms(w_entry));
     HIPCHK(hipFuncSetAttribute((const void*)k_lz_resolve2, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16));
     HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * (int)T2_LDS_BYTES));
@@ -3658,7 +3661,9 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     const bool tok_spec = std::getenv("SQUID_TOK_SPEC") == nullptr || std::atoi(std::getenv("SQUID_TOK_SPEC")) != 0;
     static const bool tok_prof = std::getenv("SQUID_TOK_PROF") != nullptr;
     if (tok_prof) HIPCHK(D.tok_prof.reserve(8 * 4096));
-    static const int il_depth = std::getenv("SQUID_IL_DEPTH") ? std::max(3, std::min((int)DeviceRecords::IL_DEPTH_MAX, std::atoi(std::getenv("SQUID_IL_DEPTH")))) : (resolve_global ? 8 : 5);
+    // (buffer sets in flight: the lane-per-block pass wants eight -- 1280 token waves resident --, the wave-per-block pass fills the machine from one
+    // launch: three sets keep the token pass a batch or two ahead of the resolve)
+    const int il_depth = std::getenv("SQUID_IL_DEPTH") ? std::max(2, std::min((int)DeviceRecords::IL_DEPTH_MAX, std::atoi(std::getenv("SQUID_IL_DEPTH")))) : (tok_spec ? 3 : (resolve_global ? 8 : 5));
     D.il_depth = il_depth;
     // the stream and the events of a buffer set are made when its first batch is staged (on the planner thread): a stream of a priority
     // level that has none yet costs the runtime a hardware queue, 7-8 ms each in a process that has just started -- eight of them in

@@ -1004,8 +1004,8 @@ def _rebgzf(src, dst, plan):
 
 
 def test_gpu_bgzf_inflate_and_boundary_search_give_the_same_records(built, synth, tmp_path):
-    """SQUID_GPU_INFLATE=1: BGZF blocks inflated by k_inflate_tok2 + k_lz_resolve3 (or k_lz_resolve2), record boundaries found by k_rec_*,
-    against the default host pipeline -- identical SoA.  Also: one block per token batch, five-wave token workgroups, and the
+    """SQUID_GPU_INFLATE=1: BGZF blocks inflated by k_inflate_spec (or k_inflate_tok2, SQUID_TOK_SPEC=0) + k_lz_resolve3 (or k_lz_resolve2),
+    record boundaries found by k_rec_*, against the host pipeline -- identical SoA.  Also: one block per token batch, five-wave token workgroups, and the
     same file rewritten with stored blocks, the fixed Huffman code, and all block types mixed inside one wave"""
     import json
     import os
@@ -1020,26 +1020,32 @@ def test_gpu_bgzf_inflate_and_boundary_search_give_the_same_records(built, synth
     def run(bam, env, shard="None", ctx=""):
         p = subprocess.run([sys.executable, "-c", code.replace("SHARD", shard).replace("CTX", ctx), str(bam)], env=dict(os.environ, **env), capture_output=True, text=True)
         assert p.returncode == 0, (p.returncode, env, shard, ctx, p.stderr[-4000:])
-        if env:
+        if env.get("SQUID_GPU_INFLATE") == "1":
             assert "GPU inflate+parse path" in p.stderr and "(rc 0)" in p.stderr, p.stderr
         return json.loads(p.stdout.strip().splitlines()[-1])
 
-    want = run(f"{pre}.bam", {})
-    gpu = {"SQUID_GPU_INFLATE": "1", "SQUID_INGEST_TIMING": "1"}
+    host = {"SQUID_GPU_INFLATE": "0"}  # (tests/conftest.py makes the device reader the suite's default)
+    want = run(f"{pre}.bam", host)
+    gpu = {"SQUID_GPU_INFLATE": "1", "SQUID_INGEST_TIMING": "1"}  # the wave-per-block token pass (k_inflate_spec)
+    old = dict(gpu, SQUID_TOK_SPEC="0")                           # the lane-per-block token pass (k_inflate_tok2)
     assert run(f"{pre}.bam", gpu) == want
+    assert run(f"{pre}.bam", old) == want
     assert run(f"{pre}.bam", dict(gpu, SQUID_TOK_CAP_MB="0")) == want
-    assert run(f"{pre}.bam", dict(gpu, SQUID_TOK_WPB="5")) == want
+    assert run(f"{pre}.bam", dict(gpu, SQUID_TOK_CAP_MB="0", SQUID_IL_DEPTH="2")) == want
+    assert run(f"{pre}.bam", dict(old, SQUID_TOK_CAP_MB="0")) == want
+    assert run(f"{pre}.bam", dict(old, SQUID_TOK_WPB="5")) == want
     # the LDS-window resolve (k_lz_resolve2; the default is k_lz_resolve3, which keeps its window in HBM), three buffer sets, and a runtime
     # left at its four hardware queues
     assert run(f"{pre}.bam", dict(gpu, SQUID_RESOLVE_GLOBAL="0")) == want
-    assert run(f"{pre}.bam", dict(gpu, SQUID_RESOLVE_GLOBAL="0", SQUID_TOK_CAP_MB="0")) == want
-    assert run(f"{pre}.bam", dict(gpu, SQUID_IL_DEPTH="3", SQUID_TOK_CAP_MB="0", GPU_MAX_HW_QUEUES="4")) == want
+    assert run(f"{pre}.bam", dict(old, SQUID_RESOLVE_GLOBAL="0")) == want
+    assert run(f"{pre}.bam", dict(old, SQUID_RESOLVE_GLOBAL="0", SQUID_TOK_CAP_MB="0")) == want
+    assert run(f"{pre}.bam", dict(old, SQUID_IL_DEPTH="3", SQUID_TOK_CAP_MB="0", GPU_MAX_HW_QUEUES="4")) == want
     # a chromosome shard reads a block range that starts and ends inside records
     names, _ = squid_amd.read_header(f"{pre}.bam")
     n = len(names)
     for rank, shard in enumerate(("(0, 1)", f"(1, {n - 1})", f"({n - 1}, {n})")):
         ctx = f"rank={rank}, world_size=3"
-        want_shard = run(f"{pre}.bam", {}, shard, ctx)
+        want_shard = run(f"{pre}.bam", host, shard, ctx)
         assert want_shard != want
         # (the generator writes <bam>.bai: the shard starts at the virtual offset of its first record, sq_bam.cpp BaiIndex;
         # "BAI shard" in the timing log tells that this path was taken)
@@ -1054,13 +1060,14 @@ def test_gpu_bgzf_inflate_and_boundary_search_give_the_same_records(built, synth
     for name, plan in plans.items():
         alt = tmp_path / f"{name}.bam"
         _rebgzf(f"{pre}.bam", alt, plan)
-        assert run(alt, {}) == want, name
+        assert run(alt, host) == want, name
         assert run(alt, gpu) == want, name
-        assert run(alt, dict(gpu, SQUID_TOK_WPB="3", SQUID_RESOLVE_GLOBAL="0")) == want, name
+        assert run(alt, old) == want, name
+        assert run(alt, dict(old, SQUID_TOK_WPB="3", SQUID_RESOLVE_GLOBAL="0")) == want, name
 
 
 def test_gpu_reader_end_to_end_against_the_oracle(built, synth, tmp_path):
-    """the GPU reader (k_inflate_tok2, k_lz_resolve3, k_rec_*, K0) feeding the whole pipeline, checked against the
+    """the GPU reader (k_inflate_spec / k_inflate_tok2, k_lz_resolve3, k_rec_*, K0) feeding the whole pipeline, checked against the
     ORACLE (which reads the files with its own zlib-based BAM reader) -- not only against the library's host reader: `squid`
     with SQUID_GPU_INFLATE=1 on the generator's file and on the same records re-compressed as stored blocks, with the fixed
     Huffman code and with every block type mixed inside one wave; _sv.txt and _graph.txt byte for byte"""
@@ -1081,7 +1088,7 @@ def test_gpu_reader_end_to_end_against_the_oracle(built, synth, tmp_path):
         if plan is not None:
             bam = tmp_path / f"{name}.bam"
             _rebgzf(f"{pre}.bam", bam, plan)
-        for env in ({"SQUID_GPU_INFLATE": "1"}, {"SQUID_GPU_INFLATE": "1", "SQUID_TOK_WPB": "1"}):
+        for env in ({"SQUID_GPU_INFLATE": "1"}, {"SQUID_GPU_INFLATE": "1", "SQUID_TOK_SPEC": "0", "SQUID_TOK_WPB": "1"}):  # (either token pass)
             out = tmp_path / f"gpu_{name}_{len(env)}"
             subprocess.run([str(built / "squid"), "-b", str(bam), "-c", f"{pre}.chim.bam", "-o", str(out), "-G", "1"], check=True, env=dict(os.environ, **env),
                            stdout=subprocess.DEVNULL)
