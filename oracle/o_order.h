@@ -309,7 +309,82 @@ struct WideSolver {
         Rec(rev, k - 1);                       // forward first: masks are met in increasing numeric order
         if (k != n - 1) { rev[k] = true; Rec(rev, k - 1); rev[k] = false; }  // (the mirror image of a solution has the last node reversed and a larger mask)
     }
-    void Run() { std::vector<bool> rev(n, false); Rec(rev, n - 1); if (!ok) bestval = -1; }
+    void Run() { std::vector<bool> rev(n, false); Rec(rev, n - 1); if (bestorder.empty()) ok = false; if (!ok) bestval = -1; }
+};
+
+// ---- the optimum VALUE of a wide problem by another road (round 6): which edges to give up.
+// A set of edges can be satisfied together iff (a) the orientations they ask for agree -- a parity per node against the root of its tree of
+// kept edges: tail->head and head->tail edges want equal orientations, tail-tail and head-head edges opposite ones -- and (b) their
+// precedence arcs, which the orientations determine up to reversing a whole tree, have no directed cycle.  Depth-first over the edges by
+// descending weight, keeping an edge first and dropping it second, cut when what is kept plus what is still undecided cannot beat the best
+// set so far: exact, and fast on graphs whose edges nearly all fit together (a backbone plus a few heavy discordant edges: the 75-node
+// component of the --bwa sample that neither orientation search could finish takes 1 221 steps).  WideSolver then starts from value - 1
+// and only has to find the canonical solution of that value.  `steps` is a work budget; when it runs out, the best set found so far
+// is still a lower bound.
+struct KeepDrop {
+    int n;
+    const std::vector<LocalEdge>& E;
+    std::vector<int> idx, par, rel, size;
+    std::vector<long> suffix;
+    std::vector<std::vector<int>> adj;
+    long best = -1, steps = 0, budget;
+    bool complete = true;
+    KeepDrop(int n, const std::vector<LocalEdge>& E, long budget) : n(n), E(E), budget(budget) {
+        idx.resize(E.size());
+        for (size_t i = 0; i < E.size(); i++) idx[i] = (int)i;
+        std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return E[x].w > E[y].w; });
+        suffix.assign(E.size() + 1, 0);
+        for (size_t i = E.size(); i-- > 0;) suffix[i] = suffix[i + 1] + E[idx[i]].w;
+        par.resize(n); rel.assign(n, 0); size.assign(n, 1); adj.assign(n, {});
+        for (int i = 0; i < n; i++) par[i] = i;
+    }
+    int Find(int x, int& p) const { p = 0; while (par[x] != x) { p ^= rel[x]; x = par[x]; } return x; }
+    void Arc(const LocalEdge& e, int& from, int& to) const {
+        int pu, pv;
+        Find(e.u, pu); Find(e.v, pv);
+        const bool yu = !pu, yv = !pv;
+        bool ufirst;
+        if (!e.hu && e.hv) ufirst = yu; else if (!e.hu && !e.hv) ufirst = yu; else if (e.hu && e.hv) ufirst = yv; else ufirst = !yu;  // (rows of GenerateILP, as in BuildArcs)
+        from = ufirst ? e.u : e.v; to = ufirst ? e.v : e.u;
+    }
+    bool Reaches(int a, int b) const {
+        std::vector<char> seen(n, 0);
+        std::vector<int> st(1, a);
+        seen[a] = 1;
+        while (!st.empty()) {
+            int x = st.back(); st.pop_back();
+            if (x == b) return true;
+            for (int ei : adj[x]) { int f, t; Arc(E[ei], f, t); if (f == x && !seen[t]) { seen[t] = 1; st.push_back(t); } }
+        }
+        return false;
+    }
+    void Rec(size_t i, long val) {
+        if (++steps > budget) { complete = false; return; }
+        if (val + suffix[i] <= best) return;
+        if (i == idx.size()) { best = val; return; }
+        const LocalEdge& e = E[idx[i]];
+        int pu, pv, ru = Find(e.u, pu), rv = Find(e.v, pv);
+        const int want = (e.hu != e.hv) ? 0 : 1;
+        bool ok = true;
+        if (ru == rv) {
+            if ((pu ^ pv) != want) ok = false;
+            else { int f, t; Arc(e, f, t); if (Reaches(t, f)) ok = false; }
+        }
+        if (ok) {
+            int joined = -1;
+            if (ru != rv) {
+                if (size[ru] < size[rv]) { std::swap(ru, rv); std::swap(pu, pv); }
+                par[rv] = ru; rel[rv] = pu ^ pv ^ want; size[ru] += size[rv]; joined = rv;
+            }
+            adj[e.u].push_back(idx[i]); adj[e.v].push_back(idx[i]);
+            Rec(i + 1, val + e.w);
+            adj[e.u].pop_back(); adj[e.v].pop_back();
+            if (joined >= 0) { size[par[joined]] -= size[joined]; par[joined] = joined; rel[joined] = 0; }
+            if (!complete) return;
+        }
+        Rec(i + 1, val);
+    }
+    long Run() { Rec(0, 0); return best; }
 };
 
 class Orderer {
@@ -417,7 +492,17 @@ private:
             stats.solved++;
             if (n < 20 && Ambiguous(n, E, order, mask, val)) { stats.ambiguous++; NoteAmbiguous(CompNodes, E); }
         } else if (n <= 128) {
+            if (const char* df = std::getenv("ORACLE_DUMP_WIDE")) {  // (tests: the instances beyond the subset DP, one per line: n, then u v hu hv w per edge)
+                std::ofstream o(df, std::ios::app);
+                o << n;
+                for (const LocalEdge& e : E) o << ' ' << e.u << ' ' << e.v << ' ' << e.hu << ' ' << e.hv << ' ' << e.w;
+                o << '\n';
+            }
             WideSolver ws(n, E, wide_budget);
+            {   // the value first (KeepDrop), then the canonical solution of that value; ORACLE_NO_KEEPDROP: the orientation search from nothing
+                static const bool off = std::getenv("ORACLE_NO_KEEPDROP") != nullptr;
+                if (!off) { KeepDrop kd(n, E, 5000000L); const long v = kd.Run(); if (v > 0) ws.bestval = v - 1; }
+            }
             ws.Run();
             if (ws.ok && ws.bestval >= 0) {
                 stats.solved++;

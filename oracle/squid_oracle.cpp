@@ -197,7 +197,8 @@ static int solver_selftest(int rounds) {
 }
 
 // one ordering problem from stdin ("n m" then m lines "u v head_u head_v weight", u < v): prints "value s_1 ... s_n" with
-// s = +(node + 1) / -(node + 1) left to right.  method: brute (all signed permutations), bnb (n <= 26), wide (n <= 128)
+// s = +(node + 1) / -(node + 1) left to right.  method: brute (all signed permutations), bnb (n <= 26), wide / wide_seeded (n <= 128),
+// kdvalue (the value alone)
 static int solve_order_cli(const std::string& method) {
     int n = 0, m = 0;
     if (std::scanf("%d %d", &n, &m) != 2 || n < 2 || n > 128) return 2;
@@ -210,8 +211,16 @@ static int solve_order_cli(const std::string& method) {
     std::vector<int> order;
     std::vector<bool> rev(n, false);
     long val = -1;
-    if (method == "wide") {
+    if (method == "kdvalue") {  // the optimum value alone, by the edge search (KeepDrop)
+        KeepDrop kd(n, E, 50000000L);
+        const long v = kd.Run();
+        if (!kd.complete) { std::printf("FAILED\n"); return 0; }
+        std::printf("%ld\n", v);
+        return 0;
+    }
+    if (method == "wide" || method == "wide_seeded") {  // wide: the orientation search from nothing; wide_seeded: from the edge search's value, as Orderer does
         WideSolver ws(n, E, 50000000L);
+        if (method == "wide_seeded") { KeepDrop kd(n, E, 5000000L); const long v = kd.Run(); if (v > 0) ws.bestval = v - 1; }
         ws.Run();
         if (!ws.ok) { std::printf("FAILED\n"); return 0; }
         order = ws.bestorder; rev = ws.bestrev; val = ws.bestval;

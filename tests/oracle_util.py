@@ -70,6 +70,13 @@ def solve_order(build_dir, method, n, edges):
     return int(out[0]), sum(1 << (-x - 1) for x in seq if x < 0), [abs(x) - 1 for x in seq]
 
 
+def solve_order_value(build_dir, n, edges):
+    """the optimum value of one ordering problem by the oracle's edge search (KeepDrop, squid_oracle --solve-order kdvalue)"""
+    text = f"{n} {len(edges)}\n" + "".join(" ".join(str(int(x)) for x in e) + "\n" for e in edges)
+    out = subprocess.run([str(Path(build_dir) / "squid_oracle"), "--solve-order", "kdvalue"], input=text, capture_output=True, text=True, check=True).stdout.split()
+    return None if out[0] == "FAILED" else int(out[0])
+
+
 def order_value(n, edges, mask, order):
     """weight of the edges satisfied by (orientation mask, left-to-right order): the four head patterns of GenerateILP
     (src/SegmentGraph.cpp:3763-3983) as restated in oracle/o_order.h EdgeSatisfied"""

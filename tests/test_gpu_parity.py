@@ -924,6 +924,15 @@ def test_host_solver_on_components_above_26_nodes_against_oracle(built):
             hm, ho, hv = ctx.order_problem(n, edges, use_gpu=False)
             assert (hv, hm, ho) == want, f"n={n} {edges}"
             compared += 1
+        # the 75-node component of the --bwa bench sample that neither side could finish in round 5 (tests/test_order_oracle.py): the library's
+        # search starts from the weight of a greedily kept edge set, the oracle's from the value of its exact edge search
+        text = (Path(__file__).resolve().parent / "golden" / "order" / "bwa_c3_1m_component_75.txt").read_text().split()
+        n, m = int(text[0]), int(text[1])
+        edges = [tuple(int(x) for x in text[2 + 5 * i: 7 + 5 * i]) for i in range(m)]
+        want = ou.solve_order(built, "wide_seeded", n, edges)
+        assert want is not None and want[0] == 8985
+        hm, ho, hv = ctx.order_problem(n, edges, use_gpu=False)
+        assert (hv, hm, ho) == want
     assert compared >= 7
 
 
