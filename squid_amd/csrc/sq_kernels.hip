@@ -3574,6 +3574,10 @@ int dev_token_bench(sq_ctx* c, const char* path, int variant, int max_blocks, in
             case 25611: launch_inflate_spec<256, 11>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
             case 38411: launch_inflate_spec<384, 11>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
             case 102411: launch_inflate_spec<1024, 11>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
+            case 25609: launch_inflate_spec<256, 9>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
+            case 12809: launch_inflate_spec<128, 9>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
+            case 12810: launch_inflate_spec<128, 10>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
+            case 51209: launch_inflate_spec<512, 9>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
             default: return fail(c, SQ_E_ARG, "unknown token pass variant");
         }
         HIPCHK(hipEventRecord(e1, s));
