@@ -3680,7 +3680,8 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
             int lo = 0, hi = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
             static const bool spread = std::getenv("SQUID_IL_SPREAD") != nullptr && std::atoi(std::getenv("SQUID_IL_SPREAD")) != 0;
-            const int prio = spread && qi >= 4 ? (lo + hi) / 2 : lo;  // (experiment: the runtime keeps a pool of hardware queues per priority level)
+            static const int tok_prio = std::getenv("SQUID_TOK_PRIO") ? std::atoi(std::getenv("SQUID_TOK_PRIO")) : 0;  // 0: lowest (default), 1: the library stream's, 2: highest
+            const int prio = tok_prio == 1 ? 0 : tok_prio == 2 ? hi : (spread && qi >= 4 ? (lo + hi) / 2 : lo);  // (experiment: the runtime keeps a pool of hardware queues per priority level)
             if (hipStreamCreateWithPriority(&q, hipStreamNonBlocking, prio) != hipSuccess) { (void)hipGetLastError(); if (hipStreamCreate(&q) != hipSuccess) return (int)SQ_E_HIP; }
         }
         DeviceRecords::InflSet& st = D.il_set[qi];
