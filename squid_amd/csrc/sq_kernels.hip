@@ -2731,24 +2731,34 @@ __device__ __forceinline__ long rec_plausible(const RecScan& S, unsigned long lo
     }
     return bs;
 }
-__global__ void k_rec_sync(RecScan S, long long nslices, int synced, long long* sync) {
-    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+// One WAVE per slice (round 6; one thread per slice until then: a serial walk over the ~130 byte positions in front of the slice's first
+// record, every step a dependent load -- 1 ms per 512 MB batch, as long as a third of the token pass): the 64 lanes test 64 consecutive positions
+// at once, each with the same chain test as before, and the lowest position that passes wins -- the same answer, in two or three rounds.
+__global__ __launch_bounds__(64) void k_rec_sync(RecScan S, long long nslices, int synced, long long* sync) {
+    const long long s = (long long)blockIdx.x;
+    const int lane = (int)threadIdx.x;
     if (s >= nslices) return;
     const unsigned long long lo = S.begin + (unsigned long long)s * REC_SLICE, hi = lo + REC_SLICE < S.limit ? lo + REC_SLICE : S.limit;
-    if (s == 0 && synced) { sync[0] = (long long)S.begin; return; }
+    if (s == 0 && synced) { if (lane == 0) sync[0] = (long long)S.begin; return; }
     long long found = -1;
-    for (unsigned long long p = lo; p < hi && found < 0; ++p) {
-        unsigned long long q = p;
-        int ok = 0;
-        for (;;) {
-            const long bs = rec_plausible(S, q);
-            if (bs < 0) break;
-            if (q + 4 + (unsigned long long)bs > S.limit) { if (ok >= 2) found = (long long)p; break; }
-            q += 4 + (unsigned long long)bs;
-            if (++ok == 4 || q == S.limit) { found = (long long)p; break; }
+    for (unsigned long long base = lo; base < hi; base += 64) {
+        const unsigned long long p = base + (unsigned long long)lane;
+        bool good = false;
+        if (p < hi) {
+            unsigned long long q = p;
+            int ok = 0;
+            for (;;) {
+                const long bs = rec_plausible(S, q);
+                if (bs < 0) break;
+                if (q + 4 + (unsigned long long)bs > S.limit) { if (ok >= 2) good = true; break; }
+                q += 4 + (unsigned long long)bs;
+                if (++ok == 4 || q == S.limit) { good = true; break; }
+            }
         }
+        const unsigned long long m = __ballot(good);
+        if (m) { found = (long long)(base + (unsigned long long)(__ffsll((long long)m) - 1)); break; }
     }
-    sync[s] = found;
+    if (lane == 0) sync[s] = found;
 }
 __device__ __forceinline__ bool rec_owned(const RecScan& S, int refid) {
     if (S.first_ref < 0) return true;
@@ -3906,7 +3916,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
             { EvTimer t(c, "k_rec_sync+walk+check", 2.0 * (double)(F.S.limit - F.S.begin));
               // (single-wave workgroups: these kernels run beside the resolve of the next batch and the token waves, whose one-wave
               // workgroups take wave slots one at a time as they come free -- a workgroup that needs four on one CU at once waited 3 ms)
-              hipLaunchKernelGGL(k_rec_sync, grid_for(nsl, 64), dim3(64), 0, s, F.S, nsl, (k > 0 || synced) ? 1 : 0, P.rec_sync.p);
+              hipLaunchKernelGGL(k_rec_sync, dim3((unsigned)nsl), dim3(64), 0, s, F.S, nsl, (k > 0 || synced) ? 1 : 0, P.rec_sync.p);
               hipLaunchKernelGGL(k_rec_walk<false>, grid_for(nsl, 64), dim3(64), 0, s, F.S, nsl, P.rec_sync.p, P.rec_cnt.p, P.rec_end.p, nullptr, nullptr);
               hipLaunchKernelGGL(k_rec_check, grid_for(nsl, 64), dim3(64), 0, s, nsl, P.rec_sync.p, P.rec_end.p, P.flags.p, tail_d);
               HIPCHK((device_scan<OpSum, true>(s, nsl, FArr{P.rec_cnt.p}, P.rec_base.p, P.spine, tot))); }
