@@ -66,6 +66,7 @@ WV_FN unsigned long long lanemask_lt() { return lane() ? (~0ull >> (64 - lane())
 WV_FN uint32_t uniform(uint32_t v) { return v; }
 WV_FN int popc64(unsigned long long m) { return __builtin_popcountll(m); }
 WV_FN int ctz64(unsigned long long m) { return m ? __builtin_ctzll(m) : 64; }
+WV_FN int clz64(unsigned long long m) { return m ? __builtin_clzll(m) : 64; }
 WV_FN uint32_t brev32(uint32_t v) { uint32_t r = 0; for (int i = 0; i < 32; ++i) if (v >> i & 1) r |= 1u << (31 - i); return r; }
 WV_FN uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { sh &= 31; return sh ? (lo >> sh) | (hi << (32 - sh)) : lo; }
 WV_FN uint32_t bfe(uint32_t v, uint32_t off, uint32_t width) { return width ? (v >> off) & (0xffffffffu >> (32 - width)) : 0u; }
@@ -132,6 +133,7 @@ WV_FN unsigned long long lanemask_lt() { return ~0ull >> 1 >> (63 - lane()); }
 WV_FN uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 WV_FN int popc64(unsigned long long m) { return __popcll(m); }
 WV_FN int ctz64(unsigned long long m) { return m ? __builtin_ctzll(m) : 64; }
+WV_FN int clz64(unsigned long long m) { return m ? __builtin_clzll(m) : 64; }
 WV_FN uint32_t brev32(uint32_t v) { return __brev(v); }
 WV_FN uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 WV_FN uint32_t bfe(uint32_t v, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(v, off, width); }
