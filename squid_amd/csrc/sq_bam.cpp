@@ -471,7 +471,7 @@ static int parse_bam_impl(const char* path, const ParseOpts& o, size_t batch_rec
     // section 5) and strings the decoded parts together ONCE at the end -- round 4 grew sixteen vectors round by round, 0.18 s of a 0.72 s read
     const bool whole_file = batch_records >= ((size_t)1 << 32) && !raw_sink;
     const size_t kChunkBlocks = whole_file ? 8192 : 2048;
-    const int inflate_threads = whole_file ? std::max(n_threads, std::min(64, usable_cpus() / 4)) : n_threads;
+    const int inflate_threads = whole_file ? std::max(n_threads, std::min(64, usable_cpus() / (4 * local_process_count(1)))) : n_threads;  // (its share of the host: the processes side by side divide the CPUs)
     std::vector<HostBatch> kept;  // whole-file mode: the decoded parts of all rounds, in stream order
     bool cached = false;
     if (whole_file) { std::lock_guard<std::mutex> lk(g_whole_file.mu); if (!g_whole_file.busy) { g_whole_file.busy = true; cached = true; } }

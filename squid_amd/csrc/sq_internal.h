@@ -226,7 +226,13 @@ public:
 // time -- more runnable threads than that are not faster, they are THROTTLED for the rest of the scheduler period); host_workers: helper
 // threads of a context's pool = the rank's share of those CPUs minus the calling thread, between 1 and 63
 int usable_cpus();
-inline int host_workers(int world_size) { const int n = usable_cpus() / (world_size > 0 ? world_size : 1) - 1; return n < 1 ? 1 : (n > 63 ? 63 : n); }
+// (the share is by the processes that run side by side on this host, which is not always the shard world: N independent samples on N GPUs are N
+// contexts of world size 1 -- torchrun tells through LOCAL_WORLD_SIZE)
+inline int local_process_count(int world_size) {
+    static const int env = []() { const char* v = std::getenv("LOCAL_WORLD_SIZE"); const int n = v ? std::atoi(v) : 0; return n > 0 ? n : 1; }();
+    return world_size > env ? world_size : env;
+}
+inline int host_workers(int world_size) { const int n = usable_cpus() / local_process_count(world_size) - 1; return n < 1 ? 1 : (n > 63 ? 63 : n); }
 struct DeviceRecords;  // HBM-resident SoA + scratch (sq_kernels.hip)
 struct HostBatch;      // decoded records on the host (below)
 

@@ -657,7 +657,8 @@ int segment_prepare(sq_ctx* c, SegPlan& P, int64_t& n_break) {
         if (ncl == 0) n_break = std::min<int64_t>(K, 1);
         else n_break = std::min<int64_t>(K, (int64_t)sup.trigger[ncl - 1] + 2);
     } else n_break = std::max<int64_t>(0, std::min<int64_t>(K, sh.n_break_global - sh.kept_before));
-    P.active.clear(); P.first_cluster.clear();
+    // (the plan object is kept across passes, sq_capi.cpp: every per-pass field is put back before the early way out)
+    P.active.clear(); P.first_cluster.clear(); P.shift.clear(); P.compact = nullptr; P.skip_first = false; P.k0 = 0;
     if (nd == 0 || K == 0) return SQ_OK;
 
     // ---- stretches between zero-coverage records; a stretch j covers: the push step of its first record lo (a
