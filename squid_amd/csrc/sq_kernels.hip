@@ -3662,7 +3662,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     // (round 6, wave-per-block token pass: a launch is over in a few milliseconds whatever its size, so the batches are as small as the chain
     // behind them -- resolve, boundaries, parse -- allows: 512 MB; from the page cache 156-161 ms per C3 step against 170-198 with 1 GiB)
     const bool tok_spec_early = std::getenv("SQUID_TOK_SPEC") == nullptr || std::atoi(std::getenv("SQUID_TOK_SPEC")) != 0;
-    const unsigned long long cap = std::getenv("SQUID_TOK_CAP_MB") ? (unsigned long long)std::atoll(std::getenv("SQUID_TOK_CAP_MB")) << 20 : (tok_spec_early ? 128ull : 256ull) * 64 * 65536;
+    unsigned long long cap = std::getenv("SQUID_TOK_CAP_MB") ? (unsigned long long)std::atoll(std::getenv("SQUID_TOK_CAP_MB")) << 20 : (tok_spec_early ? 128ull : 256ull) * 64 * 65536;  // (made smaller below for a short range)
     if (report) std::fprintf(stderr, "GPU ingest: entry + %.1f ms: device chosen, memory asked about\n", since_ms(w_entry));
     HIPCHK(hipFuncSetAttribute((const void*)k_lz_resolve2, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16));
     HIPCHK(hipFuncSetAttribute((const void*)k_inflate_tok2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * (int)T2_LDS_BYTES));
@@ -3760,6 +3760,19 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         const double ratio = (double)(l.uoff + l.isize - f.uoff) / (double)std::max<unsigned long long>(1, l.coff + l.clen - f.coff);
         return (unsigned long long)(ratio * 1.03 * (double)(file_bytes - std::min<unsigned long long>(file_bytes, f.coff)));
     };
+    // A short range -- a chromosome shard of an eight-rank run holds an eighth of the file -- is cut into as many batches as a whole file, so that
+    // the stages behind the token pass overlap as they do there: with 512 MB batches such a shard was three batches that went through the pipeline
+    // nearly one after the other (tools/shard_project.py: 36-55 ms per rank where 21 would be its share).
+    if (tok_spec_early && !std::getenv("SQUID_TOK_CAP_MB")) {
+        unsigned long long est = range_bytes_estimate();
+        if (index_more && src && src->stop != (size_t)-1) {
+            std::lock_guard<std::mutex> lk(bm);
+            const BgzfRange &f = blocks.front(), &l = blocks.back();
+            const double ratio = (double)(l.uoff + l.isize - f.uoff) / (double)std::max<unsigned long long>(1, l.coff + l.clen - f.coff);
+            if (src->stop > f.coff) est = (unsigned long long)(ratio * 1.03 * (double)(std::min<unsigned long long>(src->stop, file_bytes) - f.coff));
+        }
+        cap = std::max<unsigned long long>((unsigned long long)64 << 20, std::min(cap, est / 24));
+    }
     Shard sh_here = c->shard;
     if (c->capture_names) sh_here.on = false;  // (the chimeric BAM is every rank's, whole)
     const Shard& sh = sh_here;
