@@ -568,6 +568,11 @@ def main() -> None:
     bbar = total_blk / max(1.0, total_conc)
     sec8d_bytes = total_conc / world * (80.0 + 24.0 * bbar) if sharded else n_conc * (80.0 + 24.0 * bbar)
     achieved = sec8d_bytes / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else 0.0
+    # the same figure with the small helpers of K5 / K10 that SURVEY.md 8(d)'s sum also names (bucket and fold kernels, the breakpoint-cursor walks, the hash
+    # compaction: launches that touch kilobytes -- their time counts, they have no bytes of their own)
+    helpers = {k: v for k, v in agg.items() if k in ("k_hash_compact", "k_node_buckets", "k_bp_walk", "k_bp_key_prefix") and k not in gk_all}
+    helper_ms = sum(v["ms"] for v in helpers.values()) / R
+    achieved_h = sec8d_bytes / ((gpu_ms + helper_ms) * 1e-3) / 1e9 if gpu_ms > 0 else 0.0
     traffic = None
     tfile = ROOT / "profiles" / "pmc_traffic.json"  # written by tools/profile_pmc.sh from the rocprofv3 --pmc passes
     per_kernel_traffic = {}
@@ -598,6 +603,7 @@ def main() -> None:
                      "bytes_per_launch": sec8d_bytes, "us_per_launch": gpu_ms * 1e3,
                      "sum_of_kernel_bytes_per_pass": scan_bytes, "kernel_bytes_over_algorithmic": scan_bytes / sec8d_bytes if sec8d_bytes else None,
                      "frac_of_measured_copy_peak_6290": achieved / 6290.0,
+                     "frac_incl_helpers": achieved_h / HBM_PEAK_GBS, "helper_us_per_pass": {k: round(v["ms"] / R * 1e3, 1) for k, v in sorted(helpers.items(), key=lambda kv: -kv[1]["ms"])},
                      "dominant_kernel": {"name": dom, "us": d["ms"] / d["launches"] * 1e3, "bytes_per_launch": d["bytes"] / d["launches"], "GBs": d["bytes"] / d["ms"] / 1e6,
                                          "frac": d["bytes"] / d["ms"] / 1e6 / HBM_PEAK_GBS, "traffic": per_kernel_traffic.get(dom)},
                      # every record-streaming kernel of the pass: us per launch, achieved GB/s of its own bytes, fraction of the HBM peak
