@@ -3735,7 +3735,16 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
             // (no ramp when the file is in HBM already: small batches only leave CUs empty for the length of a token wave)
             static const unsigned long long ramp_env = std::getenv("SQUID_TOK_RAMP_MB") ? (unsigned long long)std::atoll(std::getenv("SQUID_TOK_RAMP_MB")) : 0;
             const unsigned long long ramp0 = ramp_env ? ramp_env : (c->ingest_dfile ? 1024 : 128);
-            const unsigned long long ramp = ramp0 << (20 + std::min<size_t>(batches.size(), 8)), bcap = std::min(cap, ramp);
+            const unsigned long long ramp = ramp0 << (20 + std::min<size_t>(batches.size(), 8));
+            unsigned long long bcap = std::min(cap, ramp);
+            // (the end of the range in smaller batches: what stands behind the last byte is one batch's way through token pass, resolve, boundaries and parse)
+            if (tok_spec_early && !more_blocks && at < blocks.size()) {
+                const size_t stop0 = b1 == (size_t)-1 ? blocks.size() : std::min(b1, blocks.size());
+                if (stop0 > at) {
+                    const unsigned long long left = blocks[stop0 - 1].uoff + blocks[stop0 - 1].isize - blocks[at].uoff;
+                    if (left < 2 * cap) bcap = std::min(bcap, std::max<unsigned long long>((unsigned long long)64 << 20, cap / 4));
+                }
+            }
             while (more_blocks && (blocks.size() <= at || blocks.back().uoff + blocks.back().isize - blocks[at].uoff <= bcap)) {
                 std::vector<BgzfRange> got;  // (the wait for the walk happens outside the lock)
                 more_blocks = index_more(got);
