@@ -482,6 +482,9 @@ def _build_node_star_literal(rec, chim, ReadLen, ref_len, min_mapq):
 
 
 CASES = [("C1", (), ()), ("T2", (), ()), ("C2", (), ()), ("C2", ("--support", "2,6"), ("-w", "1", "-a", "50")), ("C2", ("--interleave", "6"), ())]
+# (a C2 case is a minute of Python loops: the CPU suite keeps four inputs, the GPU suite three, all five are covered; every case passed in both when the test was written)
+CPU_CASES = [CASES[0], CASES[1], CASES[2], CASES[4]]
+GPU_CASES = [CASES[0], CASES[1], CASES[3]]
 
 
 def _inputs(built, synth, tmp_path, cfg, gen, flags):
@@ -505,7 +508,7 @@ def _dumped_nodes(path):
     return out
 
 
-@pytest.mark.parametrize("cfg,gen,flags", CASES)
+@pytest.mark.parametrize("cfg,gen,flags", CPU_CASES)
 def test_oracle_nodes_against_the_literal_automaton(built, synth, tmp_path, cfg, gen, flags):
     pre, dump, chim, rec, read_len, ref_len = _inputs(built, synth, tmp_path, cfg, gen, flags)
     seeds, nodes, kept, n_break = _build_node_star_literal(rec, chim, read_len, ref_len, min_mapq=255)  # (STAR mode: Min_MapQual 255, ledger B2)
@@ -517,7 +520,7 @@ def test_oracle_nodes_against_the_literal_automaton(built, synth, tmp_path, cfg,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg,gen,flags", CASES)
+@pytest.mark.parametrize("cfg,gen,flags", GPU_CASES)
 def test_hip_path_nodes_against_the_literal_automaton(built, synth, tmp_path, cfg, gen, flags):
     """the library's node table (cluster triggers, zero-coverage candidates and window summaries from the kernels, the event-driven replay on the
     host, tiling) against the same literal reading"""
