@@ -1529,3 +1529,30 @@ def test_the_suite_s_default_route_is_the_device_reader(built, synth, monkeypatc
             ctx.order()
             seen[spec] = (ctx.counts()["n_concordant"], ctx.counts()["n_blocks"], ctx.sv_text())
     assert seen["1"] == seen["0"]
+
+
+@pytest.mark.gpu
+def test_every_token_pass_variant_alone_against_zlib(built, synth, tmp_path):
+    """sq_debug_token_bench: the token pass and the resolve, each alone on the device, every block's bytes compared with zlib inside the library -- for
+    every stretch length / table size the entry knows (the reader runs one of them) and for the lane-per-block pass, on the generator's file and on the
+    same file rewritten with stored blocks, the fixed Huffman code and all block types mixed"""
+    import ctypes as C
+    import zlib
+
+    pre = synth("T2", "--indel-frac", "0.2")
+    files = {"asis": f"{pre}.bam"}
+    plans = {"stored": lambda i: (0, zlib.Z_DEFAULT_STRATEGY), "fixed": lambda i: (6, zlib.Z_FIXED),
+             "mixed": lambda i: [(0, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (9, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE)][i % 5]}
+    for name, plan in plans.items():
+        files[name] = str(tmp_path / f"{name}.bam")
+        _rebgzf(f"{pre}.bam", files[name], plan)
+    lib = squid_amd.load_library()
+    lib.sq_debug_token_bench.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
+    with squid_amd.Context() as ctx:
+        for name, path in files.items():
+            for variant in (25610, 25609, 25611, 51210, 51211, 51209, 38411, 12810, 12809, 102411, 2):
+                out = (C.c_double * 7)()
+                rc = lib.sq_debug_token_bench(ctx.h, path.encode(), variant, 4096, 1, 1, out)
+                assert rc == 0, (name, variant, rc)
+                assert out[4] >= 50 and out[2] > 1e6, (name, variant, list(out))  # blocks, inflated bytes
+                assert out[6] == 0, f"{name}, variant {variant}: {int(out[6])} block(s) differ from zlib (-1: error flag)"
