@@ -248,6 +248,7 @@ struct DeviceRecords {
     bool chim_provisional = false;   // the table holds every usable chimeric QNAME; dev_chim_finalize has not run yet
     hipStream_t chim_stream = nullptr;
     DBuf<int32_t> parse_nblk, parse_rel;
+    DBuf<int4> parse_first2;  // k_parse_records: the first two blocks of every record of the chunk being parsed
     DBuf<int32_t> calib;
     DBuf<uint8_t> zflag;
     DBuf<int32_t> cl_chr, trig, cl_bucket;  // cl_chr: packed cluster table chr | start | right; cl_bucket: bucket_off | position index of the cluster table
@@ -654,14 +655,33 @@ __global__ void k_chim_fixup(int64_t n, const int32_t* chim_slot_of, const uint8
     aux[r] = (uint8_t)(aux[r] & ~SQ_AUX_INCHIM);
     if (cs < 0) atomicOr(&flags[0], 256);
 }
-// WRITE = false: only counts the kept blocks.  Returns the block count, or -1 when the reference's
-// assert(ReadPos >= HardClipOffset && ...) (ReadRec.cpp:64) would fire.
-template <bool WRITE>
-__device__ int parse_blocks(const uint8_t* cg, int ncig, const uint8_t* seq, int lseq, int pos, bool rev, int totlen, int32_t* o_refpos, int32_t* o_matchref, uint16_t* o_readpos,
-                            uint16_t* o_matchread, int cap = 0) {  // cap: the slots the record owns (a record that trips the assert owns none: its leading blocks are not written)
+// Byte reads of the record parse, from LDS (the staged records of a workgroup) or from global memory (a range that does not fit):
+// typed by address space, so the staged path is ds_read and not a flat load that has to find out where it goes, and up to eight bytes
+// per load at any alignment (gfx950 takes unaligned LDS and global accesses; a read may run up to 7 bytes past what it needs:
+// the staging buffer and the chunk buffer are padded)
+typedef wv::lds_u8 lds_u8;
+typedef uint64_t __attribute__((aligned(1))) u64_any;
+typedef uint32_t __attribute__((aligned(1))) u32_any;
+typedef uint16_t __attribute__((aligned(1))) u16_any;
+__device__ __forceinline__ uint32_t rd8(const uint8_t* p) { return *p; }
+__device__ __forceinline__ uint32_t rd8(const lds_u8* p) { return *p; }
+__device__ __forceinline__ uint32_t rd16(const uint8_t* p) { return *(const u16_any*)p; }
+__device__ __forceinline__ uint32_t rd16(const lds_u8* p) { return *(const __attribute__((address_space(3))) u16_any*)p; }
+__device__ __forceinline__ uint32_t rd32(const uint8_t* p) { return *(const u32_any*)p; }
+__device__ __forceinline__ uint32_t rd32(const lds_u8* p) { return *(const __attribute__((address_space(3))) u32_any*)p; }
+__device__ __forceinline__ unsigned long long rd64(const uint8_t* p) { return *(const u64_any*)p; }
+__device__ __forceinline__ unsigned long long rd64(const lds_u8* p) { return *(const __attribute__((address_space(3))) u64_any*)p; }
+// CIGAR -> aligned blocks (ReadRec.cpp:23-60), 16 bytes each as b_pack holds them (refpos, matchref, readpos | matchread << 16, 0).
+// PLACE = false: the first two kept blocks are returned in q0 / q1; PLACE = true: kept block k < cap goes to S's arrays at b0 + k.
+// Returns the block count, or -1 when the reference's assert(ReadPos >= HardClipOffset && ...) (ReadRec.cpp:64) would fire.
+// The poly-A/T filter counts the 4-bit base codes 1 (A) and 8 (T) of the block's stretch of the read sixteen bases per load.
+struct BlockSink { int32_t *refpos, *matchref; uint16_t *readpos, *matchread; int4* pack;
+    __device__ __forceinline__ void put(uint32_t at, int4 q) const { refpos[at] = q.x; matchref[at] = q.y; readpos[at] = (uint16_t)((uint32_t)q.z & 0xffffu); matchread[at] = (uint16_t)((uint32_t)q.z >> 16); pack[at] = q; } };
+template <bool PLACE, class PTR>
+__device__ __forceinline__ int parse_blocks(PTR cg, int ncig, PTR seq, int lseq, int pos, bool rev, int totlen, int4& q0, int4& q1, const BlockSink& S, uint32_t b0, int cap) {
     int readpos = 0, refpos = pos, hardclip = 0, nb = 0;
     for (int ic = 0; ic < ncig; ++ic) {
-        uint32_t v = (uint32_t)ld32(cg + 4 * ic);
+        uint32_t v = rd32(cg + 4 * ic);
         char t = cig_type(v);
         int len = (int)(v >> 4);
         if (t == 'S' || t == 'H') {
@@ -670,7 +690,7 @@ __device__ int parse_blocks(const uint8_t* cg, int ncig, const uint8_t* seq, int
         } else if (t == 'M' || t == '=') {
             int tr = 0, tf = 0, ic2;
             for (ic2 = ic; ic2 < ncig; ++ic2) {
-                uint32_t v2 = (uint32_t)ld32(cg + 4 * ic2);
+                uint32_t v2 = rd32(cg + 4 * ic2);
                 char t2 = cig_type(v2);
                 if (t2 == 'S' || t2 == 'H' || t2 == 'N') break;
                 if (t2 != 'D') tr += (int)(v2 >> 4);
@@ -679,16 +699,24 @@ __device__ int parse_blocks(const uint8_t* cg, int ncig, const uint8_t* seq, int
             int s0 = readpos - hardclip, s1 = readpos + tr - hardclip;
             if (!(readpos >= hardclip && s1 <= lseq)) return -1;
             int na = 0, nt = 0;
-            for (int i = s0; i < s1; ++i) {
-                int code = (seq[i >> 1] >> ((~i & 1) << 2)) & 0xf;
-                na += code == 1;
-                nt += code == 8;
+            // base i sits in byte i >> 1, high nibble first: swapping the nibbles of every byte of a little-endian word puts base
+            // wb + k at nibble k, and a nibble equals c when (word ^ c c c ...) has no bit set in it
+            for (int wb = s0 & ~1; wb < s1; wb += 16) {
+                unsigned long long w = rd64(seq + (wb >> 1));
+                w = ((w & 0x0f0f0f0f0f0f0f0full) << 4) | ((w >> 4) & 0x0f0f0f0f0f0f0f0full);
+                const int a = s0 > wb ? s0 - wb : 0, b = s1 - wb < 16 ? s1 - wb : 16;
+                const unsigned long long lo = (1ull << (4 * a)) - 1, hi = b == 16 ? ~0ull : (1ull << (4 * b)) - 1;
+                const unsigned long long ones = 0x1111111111111111ull & hi & ~lo;
+                unsigned long long x = w ^ 0x1111111111111111ull, y = w ^ 0x8888888888888888ull;
+                x |= x >> 1; x |= x >> 2;
+                y |= y >> 1; y |= y >> 2;
+                na += __popcll(~x & ones);
+                nt += __popcll(~y & ones);
             }
             if (4 * na < 3 * tr && 4 * nt < 3 * tr) {
-                if (WRITE && nb < cap) {
-                    o_refpos[nb] = refpos; o_matchref[nb] = tf;
-                    o_readpos[nb] = (uint16_t)(rev ? totlen - readpos - tr : readpos); o_matchread[nb] = (uint16_t)tr;
-                }
+                const int4 q = make_int4(refpos, tf, (int)((uint32_t)(uint16_t)(rev ? totlen - readpos - tr : readpos) | ((uint32_t)(uint16_t)tr << 16)), 0);
+                if (PLACE) { if (nb < cap) S.put(b0 + (uint32_t)nb, q); }
+                else { if (nb == 0) q0 = q; if (nb == 1) q1 = q; }
                 ++nb;
             }
             readpos += tr;
@@ -699,23 +727,33 @@ __device__ int parse_blocks(const uint8_t* cg, int ncig, const uint8_t* seq, int
     }
     return nb;
 }
-// The records of a workgroup are one contiguous byte range of the chunk (64 records, ~17 KB).  Parsing walks them byte by
-// byte per lane, 260 bytes apart from the neighbouring lane: straight from global memory every load touches 64 cache
-// lines and the chunk is fetched from HBM ~20 times over.  So the range is first copied into LDS with coalesced 16-byte
-// loads and the lanes parse from there (a range that does not fit -- very long records -- is parsed in place).
+// The records of a workgroup are one contiguous byte range of the chunk (64 records, ~17 KB).  Parsing walks them per lane, 260 bytes
+// apart from the neighbouring lane: straight from global memory every load touches 64 cache lines and the chunk is fetched from
+// HBM ~20 times over.  So the range is first copied into LDS with coalesced 16-byte loads and the lanes parse from there (a range
+// that does not fit -- very long records -- is parsed in place).
 #ifndef SQ_PARSE_THREADS
 #define SQ_PARSE_THREADS 64
 #define SQ_PARSE_LDS 18432
 #endif
 constexpr int PARSE_THREADS = SQ_PARSE_THREADS, PARSE_LDS = SQ_PARSE_LDS;  // 4 workgroups = 8 waves per CU (64 threads x 32 KB gave 5)
-// `avail` receives the bytes the record may occupy: up to the next record's offset, the end of the chunk and (when staged) the
-// end of the staged range; -1 when the offsets handed in by the caller are not ascending or lie outside the chunk.
-__device__ __forceinline__ const uint8_t* stage_records(const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n, uint8_t* lds, long long& avail) {
+// Copies the workgroup's records into `lds` when they fit; returns whether they did (uniform).  For its record every lane gets the
+// offset into the staged range / the chunk and `avail`, the bytes the record may occupy: up to the next record's offset, the end of the
+// chunk and (when staged) the end of the staged range; -1 when the offsets handed in by the caller are not ascending or lie outside the chunk.
+__device__ __forceinline__ bool stage_records(const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n, uint8_t* lds, unsigned long long& at, long long& avail) {
     const int64_t r0 = (int64_t)blockIdx.x * blockDim.x, r1 = r0 + blockDim.x < n ? r0 + blockDim.x : n;
     const unsigned long long first = rec_off[r0], lo = first & ~15ull;
     unsigned long long hi = r1 < n ? rec_off[r1] : (unsigned long long)nbytes;
     if (hi > (unsigned long long)nbytes) hi = (unsigned long long)nbytes;
-    const bool fits = first <= hi && hi - lo <= (unsigned long long)PARSE_LDS;  // uniform over the workgroup
+    bool fits = first <= hi && hi - lo <= (unsigned long long)PARSE_LDS;  // uniform over the workgroup
+    const int64_t r = r0 + threadIdx.x;
+    avail = -1; at = 0;
+    bool mine = true;  // my record lies inside the staged range
+    unsigned long long o = 0, e = 0;
+    if (r < n) {
+        o = rec_off[r]; e = r + 1 < n ? rec_off[r + 1] : (unsigned long long)nbytes;
+        mine = o >= first && o <= hi;
+    }
+    fits = __syncthreads_and(fits && mine) != 0;
     if (fits) {
         const uint4* src = (const uint4*)(bam + lo);  // (the chunk buffer is 256-byte aligned and padded by 64 bytes)
         uint4* dst = (uint4*)lds;
@@ -723,112 +761,134 @@ __device__ __forceinline__ const uint8_t* stage_records(const uint8_t* bam, size
         for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
-    const int64_t r = r0 + threadIdx.x;
-    avail = -1;
-    if (r >= n) return nullptr;
-    const unsigned long long o = rec_off[r], e = r + 1 < n ? rec_off[r + 1] : (unsigned long long)nbytes;
-    if (o > (unsigned long long)nbytes || e > (unsigned long long)nbytes || e < o) return bam;  // (avail stays -1: the caller flags the record)
-    const bool staged = fits && o >= first && o <= hi;
-    const unsigned long long lim = staged ? hi - o : (unsigned long long)nbytes - o;
+    if (r >= n) return fits;
+    if (o > (unsigned long long)nbytes || e > (unsigned long long)nbytes || e < o) return fits;  // (avail stays -1: the caller flags the record)
+    const unsigned long long lim = fits ? hi - o : (unsigned long long)nbytes - o;
     avail = (long long)(e - o < lim ? e - o : lim);
-    return staged ? lds + (o - lo) : bam + o;
+    at = fits ? o - lo : o;
+    return fits;
 }
 // block_size and the fixed fields must fit into `avail`, the variable-length fields into block_size (a malformed record would
-// otherwise send the cigar / sequence / quality / tag walks past the chunk or the 32 KB staging buffer)
-__device__ __forceinline__ bool rec_header_ok(const uint8_t* rec, long long avail) {
+// otherwise send the cigar / sequence / quality / tag walks past the chunk or the staging buffer)
+template <class PTR>
+__device__ __forceinline__ bool rec_header_ok(PTR rec, long long avail) {
     if (avail < 36) return false;
-    const long long bs = ld32(rec);
+    const long long bs = (int)rd32(rec);
     if (bs < 32 || 4 + bs > avail) return false;
-    const uint8_t* p = rec + 4;
-    const long long lname = p[8], ncig = ld16(p + 12), lseq = ld32(p + 16);
+    const long long lname = rd8(rec + 12), ncig = rd16(rec + 16), lseq = (int)rd32(rec + 20);
     if (lseq < 0) return false;
     return 32 + lname + 4 * ncig + (lseq + 1) / 2 + lseq <= bs;
 }
-__global__ __launch_bounds__(PARSE_THREADS) void k_parse_count(const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n, int32_t* nblk, int32_t* flags) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[PARSE_LDS];
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    long long avail;
-    const uint8_t* rec = stage_records(bam, nbytes, rec_off, n, lds, avail);
-    if (!rec) return;
-    if (!rec_header_ok(rec, avail)) { atomicOr(&flags[0], 128); nblk[r] = 0; return; }
-    const uint8_t* p = rec + 4;
-    int lname = p[8], ncig = ld16(p + 12), flag = ld16(p + 14), lseq = ld32(p + 16), pos = ld32(p + 4);
-    const uint8_t* cg = p + 32 + lname;
-    const uint8_t* seq = cg + 4 * (size_t)ncig;
-    int totlen = 0;
-    for (int i = 0; i < ncig; ++i) { uint32_t v = (uint32_t)ld32(cg + 4 * i); char t = cig_type(v); if (t == 'M' || t == 'S' || t == 'H' || t == 'I' || t == '=' || t == 'X') totlen += (int)(v >> 4); }
-    int nb = parse_blocks<false>(cg, ncig, seq, lseq, pos, flag & 0x10, totlen, nullptr, nullptr, nullptr, nullptr);
-    nblk[r] = nb < 0 ? 0 : nb;
+// slot of `name` (n bytes at `name`) in the table of the chimeric QNAMEs, as chim_find; the name is hashed eight bytes per load
+template <class PTR>
+__device__ __forceinline__ int chim_find_at(const ChimSetView& C, PTR name, int n) {
+    if (!C.hash) return -1;
+    unsigned long long h = 1469598103934665603ull;
+    for (int i = 0; i < n; i += 8) {
+        unsigned long long w = rd64(name + i);
+        const int m = n - i < 8 ? n - i : 8;
+        for (int j = 0; j < m; ++j) { h ^= w & 0xff; h *= 1099511628211ull; w >>= 8; }
+    }
+    if (!h) h = 1;
+    for (uint32_t s = chim_slot(h, C.mask), probes = 0; probes <= C.mask; s = (s + 1) & C.mask, ++probes) {
+        unsigned long long e = C.hash[s];
+        if (e == 0) return -1;
+        if (e == h && (int)C.len[s] == n) {
+            bool same = true;
+            for (int i = 0; i < n; ++i) if (C.blob[C.off[s] + i] != (char)rd8(name + i)) { same = false; break; }
+            if (same) return (int)s;
+        }
+    }
+    return -1;
 }
-struct FArrN { const int32_t* a; __device__ int operator()(int64_t i) const { return a[i]; } };
-__global__ __launch_bounds__(PARSE_THREADS) void k_parse_write(const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n, ChimSetView C, ParseParams P, const int32_t* blk_cnt, const int32_t* blk_rel, uint32_t blk_base, int32_t* o_refid,
-                              int32_t* o_pos, int32_t* o_mrefid, int32_t* o_mpos, int32_t* o_endpos, uint16_t* o_flag, uint16_t* o_totlen, uint8_t* o_mapq, uint8_t* o_aux, uint32_t* o_blkoff,
-                              int32_t* b_refpos, int32_t* b_matchref, uint16_t* b_readpos, uint16_t* b_matchread, int32_t* o_chimslot, int32_t* flags) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[PARSE_LDS];
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    long long avail;
-    const uint8_t* rec = stage_records(bam, nbytes, rec_off, n, lds, avail);
-    if (!rec) return;
-    if (!rec_header_ok(rec, avail)) { atomicOr(&flags[0], 128); return; }
-    const uint8_t* p = rec + 4;
-    const int bs = ld32(p - 4);
-    const uint8_t* pend = p + bs;
-    const int refid = ld32(p), pos = ld32(p + 4), lname = p[8], mapq = p[9], ncig = ld16(p + 12), flag = ld16(p + 14), lseq = ld32(p + 16), mrefid = ld32(p + 20), mpos = ld32(p + 24);
-    const uint8_t* name = p + 32;
-    const uint8_t* cg = name + lname;
-    const uint8_t* seq = cg + 4 * (size_t)ncig;
-    const uint8_t* qual = seq + (lseq + 1) / 2;
-    const uint8_t* aux = qual + lseq;
-    if (aux > pend) { atomicOr(&flags[0], 128); return; }
+// Everything of one record except where its blocks go: the record's SoA fields, the number of kept blocks, and the first two of them
+// (16 bytes each, as b_pack holds them) in a scratch array -- k_parse_place moves them behind a scan of the counts and parses the
+// CIGAR of a record with more blocks a second time.  One pass over the inflated bytes instead of the two (count, write) of rounds 1-5.
+struct ParseOut {
+    int32_t *refid, *pos, *mrefid, *mpos, *endpos; uint16_t *flag, *totlen; uint8_t *mapq, *aux; int32_t* chimslot;
+    int32_t* nblk; int4* first2;
+};
+template <class PTR>
+__device__ __forceinline__ void parse_record(PTR rec, long long avail, int64_t r, const ChimSetView& C, const ParseParams& P, const ParseOut& O, int32_t* flags) {
+    if (!rec_header_ok(rec, avail)) { atomicOr(&flags[0], 128); O.nblk[r] = 0; return; }
+    PTR p = rec + 4;
+    const int bs = (int)rd32(rec);
+    PTR pend = p + bs;
+    const int refid = (int)rd32(p), pos = (int)rd32(p + 4), lname = (int)rd8(p + 8), mapq = (int)rd8(p + 9), ncig = (int)rd16(p + 12), flag = (int)rd16(p + 14), lseq = (int)rd32(p + 16),
+              mrefid = (int)rd32(p + 20), mpos = (int)rd32(p + 24);
+    PTR name = p + 32;
+    PTR cg = name + lname;
+    PTR seq = cg + 4 * (size_t)ncig;
+    PTR qual = seq + (lseq + 1) / 2;
+    PTR aux = qual + lseq;
+    if (aux > pend) { atomicOr(&flags[0], 128); O.nblk[r] = 0; return; }
     int totlen = 0, endpos = pos;
     for (int i = 0; i < ncig; ++i) {
-        uint32_t v = (uint32_t)ld32(cg + 4 * i);
+        uint32_t v = rd32(cg + 4 * i);
         char t = cig_type(v);
         int len = (int)(v >> 4);
         if (t == 'M' || t == 'S' || t == 'H' || t == 'I' || t == '=' || t == 'X') totlen += len;
         if (t == 'M' || t == 'D' || t == 'N' || t == '=' || t == 'X') endpos += len;
     }
     int lowrun = 0, run = 0;
-    for (int i = 0; i < lseq; ++i) {
-        int c = (signed char)((qual[i] + 33) & 0xff);
-        run = (c < P.qual_thr) ? run + 1 : 0;
-        if (run > lowrun) lowrun = run;
+    for (int i = 0; i < lseq; i += 8) {
+        unsigned long long w = rd64(qual + i);
+        const int m = lseq - i < 8 ? lseq - i : 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int c = (signed char)(((uint32_t)(w >> (8 * j)) + 33) & 0xff);
+            run = (j < m && c < P.qual_thr) ? run + 1 : 0;
+            if (run > lowrun) lowrun = run;
+        }
     }
     // aux: XA present, first IH value (integer typed)
     bool has_xa = false, has_ih = false, bad = false;
     int ih = 0;
-    for (const uint8_t* q = aux; q + 3 <= pend;) {
-        uint8_t t0 = q[0], t1 = q[1], ty = q[2];
-        const uint8_t* v = q + 3;
+    for (PTR q = aux; q + 3 <= pend;) {
+        const uint32_t hd = rd32(q);  // tag, type and the first byte of the value (or of whatever follows a value-less end: checked below)
+        const uint8_t t0 = hd & 0xff, t1 = (hd >> 8) & 0xff, ty = (hd >> 16) & 0xff;
+        PTR v = q + 3;
         size_t sz;
         if (ty == 'A' || ty == 'c' || ty == 'C') sz = 1;
         else if (ty == 's' || ty == 'S') sz = 2;
         else if (ty == 'i' || ty == 'I' || ty == 'f') sz = 4;
-        else if (ty == 'Z' || ty == 'H') { const uint8_t* z = v; while (z < pend && *z) ++z; if (z >= pend) { bad = true; break; } sz = (size_t)(z - v) + 1; }
-        else if (ty == 'B') {
+        else if (ty == 'Z' || ty == 'H') {
+            // the terminating NUL, eight bytes per load
+            PTR z = v;
+            bool found = false;
+            while (z < pend) {
+                const unsigned long long w = rd64(z);
+                const unsigned long long zero = (w - 0x0101010101010101ull) & ~w & 0x8080808080808080ull;
+                if (zero) { z += (__ffsll((long long)zero) - 1) >> 3; found = z < pend; break; }
+                z += 8;
+            }
+            if (!found) { bad = true; break; }
+            sz = (size_t)(z - v) + 1;
+        } else if (ty == 'B') {
             if (v + 5 > pend) { bad = true; break; }
-            size_t es = (v[0] == 'c' || v[0] == 'C') ? 1 : ((v[0] == 's' || v[0] == 'S') ? 2 : 4);
-            sz = 5 + es * (size_t)(uint32_t)ld32(v + 1);
+            const uint32_t et = rd8(v);
+            size_t es = (et == 'c' || et == 'C') ? 1 : ((et == 's' || et == 'S') ? 2 : 4);
+            sz = 5 + es * (size_t)rd32(v + 1);
         } else { bad = true; break; }
         if (v + sz > pend) { bad = true; break; }
         if (t0 == 'X' && t1 == 'A') has_xa = true;
         if (t0 == 'I' && t1 == 'H' && !has_ih) {
             has_ih = true;
-            if (ty == 'c' || ty == 'C' || ty == 'A') ih = v[0];
-            else if (ty == 's' || ty == 'S') ih = ld16(v);
-            else if (ty == 'i') ih = ld32(v);  // (BamTools' GetTag<int> refuses a UINT32 value: IHtagvalue stays 0)
+            if (ty == 'c' || ty == 'C' || ty == 'A') ih = (int)rd8(v);
+            else if (ty == 's' || ty == 'S') ih = (int)rd16(v);
+            else if (ty == 'i') ih = (int)rd32(v);  // (BamTools' GetTag<int> refuses a UINT32 value: IHtagvalue stays 0)
         }
         q = v + sz;
     }
-    if (bad) { atomicOr(&flags[0], 128); return; }
+    if (bad) { atomicOr(&flags[0], 128); O.nblk[r] = 0; return; }
     uint8_t ax = 0;
     if (has_xa || ih > 1) ax |= SQ_AUX_MULTI;
     if (lowrun > P.max_lowphred_len) ax |= SQ_AUX_LOWPHRED;
-    const int cslot = chim_find(C, name, lname > 0 ? lname - 1 : 0);
+    const int cslot = chim_find_at(C, name, lname > 0 ? lname - 1 : 0);
     if (cslot >= 0 && !(C.dead && C.dead[cslot])) ax |= SQ_AUX_INCHIM;
     int32_t cs_out = (ax & SQ_AUX_INCHIM) ? cslot + 1 : 0;
-    const uint32_t b0 = blk_base + (uint32_t)blk_rel[r];
-    int nb = parse_blocks<true>(cg, ncig, seq, lseq, pos, flag & 0x10, totlen, b_refpos + b0, b_matchref + b0, b_readpos + b0, b_matchread + b0, blk_cnt[r]);
+    int4 q0 = make_int4(0, 0, 0, 0), q1 = q0;
+    const int nb = parse_blocks<false>(cg, ncig, seq, lseq, pos, flag & 0x10, totlen, q0, q1, BlockSink{}, 0u, 0);
     // the SoA keeps TotalLen and the read offsets in 16 bits and the segmentation summary counts a record's further blocks in
     // 8 bits: longer reads / more blocks are refused instead of wrapping silently
     if (totlen > 65535 || nb > 256) atomicOr(&flags[0], 2048);
@@ -840,10 +900,44 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_parse_write(const uint8_t* ba
         const bool but_for_the_name = !(ax & SQ_AUX_MULTI) && !(flag & 0x400) && !(flag & 0x4) && mapq >= P.min_mapq;
         if (filtered && but_for_the_name) cs_out = -cs_out;  // (k_chim_fixup raises the flag should the name leave the set)
     }
-    o_chimslot[r] = cs_out;
-    o_refid[r] = refid; o_pos[r] = pos; o_mrefid[r] = mrefid; o_mpos[r] = mpos; o_endpos[r] = endpos;
-    o_flag[r] = (uint16_t)flag; o_totlen[r] = (uint16_t)totlen; o_mapq[r] = (uint8_t)mapq; o_aux[r] = ax;
+    O.nblk[r] = nb < 0 ? 0 : nb;  // (a record that trips the assert owns no slots: its leading blocks are not written)
+    O.first2[2 * r] = q0; O.first2[2 * r + 1] = q1;
+    O.chimslot[r] = cs_out;
+    O.refid[r] = refid; O.pos[r] = pos; O.mrefid[r] = mrefid; O.mpos[r] = mpos; O.endpos[r] = endpos;
+    O.flag[r] = (uint16_t)flag; O.totlen[r] = (uint16_t)totlen; O.mapq[r] = (uint8_t)mapq; O.aux[r] = ax;
+}
+__global__ __launch_bounds__(PARSE_THREADS) void k_parse_records(const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n, ChimSetView C, ParseParams P, ParseOut O, int32_t* flags) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[PARSE_LDS + 32];
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long at;
+    long long avail;
+    const bool staged = stage_records(bam, nbytes, rec_off, n, lds, at, avail);
+    if (r >= n) return;
+    if (staged) parse_record((const lds_u8*)lds + at, avail, r, C, P, O, flags);
+    else parse_record(bam + at, avail, r, C, P, O, flags);
+}
+// the blocks of the records to their places behind the scan of the counts (blk_rel), in both layouts (the four arrays and b_pack), and
+// the records' block offsets.  A record with more than two blocks has its CIGAR parsed again, from the chunk.
+struct FArrN { const int32_t* a; __device__ int operator()(int64_t i) const { return a[i]; } };
+__global__ void k_parse_place(const uint8_t* bam, const unsigned long long* rec_off, int64_t n, const int32_t* blk_cnt, const int32_t* blk_rel, const int4* first2, uint32_t blk_base, const uint16_t* o_totlen,
+                              uint32_t* o_blkoff, int32_t* b_refpos, int32_t* b_matchref, uint16_t* b_readpos, uint16_t* b_matchread, int4* b_pack) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int nb = blk_cnt[r];
+    const uint32_t b0 = blk_base + (uint32_t)blk_rel[r];
     o_blkoff[r] = b0;
+    const BlockSink S{b_refpos, b_matchref, b_readpos, b_matchread, b_pack};
+    if (nb == 0) return;
+    if (nb <= 2) {
+        S.put(b0, first2[2 * r]);
+        if (nb == 2) S.put(b0 + 1, first2[2 * r + 1]);
+        return;
+    }
+    const uint8_t* p = bam + rec_off[r] + 4;  // (k_parse_records has checked the record)
+    const int pos = (int)rd32(p + 4), lname = (int)rd8(p + 8), ncig = (int)rd16(p + 12), flag = (int)rd16(p + 14), lseq = (int)rd32(p + 16);
+    const uint8_t* cg = p + 32 + lname;
+    int4 q0, q1;
+    parse_blocks<true>(cg, ncig, cg + 4 * (size_t)ncig, lseq, pos, flag & 0x10, (int)o_totlen[r], q0, q1, S, b0, nb);
 }
 
 // ------------------------------------------------------------------------------------------------ K1: record keys (the filters, the duplicate drop and the stream scans are k_pass1, sq_pass_kernels.inc)
@@ -2917,7 +3011,7 @@ void dev_destroy(sq_ctx* c) {
     D.srec.release(); D.rest_refpos.release(); D.rest_matchref.release();
     D.n_chr.release(); D.n_bucket.release();
     D.acc_a.release(); D.acc_b.release(); D.acc_c.release();
-    D.h_key.release(); D.h_val.release(); D.flags.release(); D.bam_chunk.release(); D.bam_off.release(); D.chim_hash.release(); D.chim_off.release(); D.chim_len.release(); D.chim_blob.release(); D.chim_dead.release(); D.chim_slot_of.release(); D.chim_in_off.release(); D.chim_in_len.release(); D.parse_nblk.release(); D.parse_rel.release();
+    D.h_key.release(); D.h_val.release(); D.flags.release(); D.bam_chunk.release(); D.bam_off.release(); D.chim_hash.release(); D.chim_off.release(); D.chim_len.release(); D.chim_blob.release(); D.chim_dead.release(); D.chim_slot_of.release(); D.chim_in_off.release(); D.chim_in_len.release(); D.parse_nblk.release(); D.parse_rel.release(); D.parse_first2.release();
     D.calib.release(); D.okey.release(); D.oval.release(); D.other64.release(); D.spine64.release(); D.okey64.release(); D.zflag.release();
     D.cl_chr.release(); D.trig.release(); D.cl_bucket.release();
     D.ord_e.release(); D.ord_o.release(); D.ord_v.release(); D.ord_me.release(); D.ord_mo.release(); D.g_i.release(); D.g_x.release(); D.g_d.release(); D.g_b.release();
@@ -3468,41 +3562,39 @@ static int parse_device(sq_ctx* c, const uint8_t* d_bam, size_t nbytes, const un
     int32_t* const fl = flags16 ? flags16 : D.flags.p;
     DBuf<int32_t>& spine = scan_state ? *scan_state : D.spine;
     const size_t n0 = (size_t)D.n, nb0 = (size_t)D.nb, n1 = n0 + (size_t)n_rec;
-    HIPCHK(D.parse_nblk.reserve((size_t)n_rec)); HIPCHK(D.parse_rel.reserve((size_t)n_rec));
+    HIPCHK(D.parse_nblk.reserve((size_t)n_rec)); HIPCHK(D.parse_rel.reserve((size_t)n_rec)); HIPCHK(D.parse_first2.reserve(2 * (size_t)n_rec));
     HIPCHK(hipMemsetAsync(fl, 0, 8 * 4, s));
     int32_t* tot = fl + 8;
-    { EvTimer t(c, "k_parse_count", (double)nbytes, s);
-      hipLaunchKernelGGL(k_parse_count, grid_for(n_rec, PARSE_THREADS), dim3(PARSE_THREADS), 0, s, d_bam, nbytes, d_off, n_rec, D.parse_nblk.p, fl);
+    // a file ingest tells how much is still to come: size the arrays for all of it at the first growth instead of
+    // reallocating (and copying) them chunk after chunk
+    const double scale = (c->ingest_total_bytes && c->ingest_seen_bytes) ? 1.02 * (double)c->ingest_total_bytes / (double)c->ingest_seen_bytes : 0.0;
+    const size_t rec_want = scale > 0 ? std::max(n1, (size_t)((double)n1 * scale) + 1024) : n1;
+#define GROW(buf, used, want) HIPCHK(D.buf.grow_keep(used, want, s))
+    if (D.refid.cap < n1) { GROW(refid, n0, rec_want); GROW(pos, n0, rec_want); GROW(mrefid, n0, rec_want); GROW(mpos, n0, rec_want); GROW(endpos, n0, rec_want);
+                            GROW(flag, n0, rec_want); GROW(totlen, n0, rec_want); GROW(mapq, n0, rec_want); GROW(aux, n0, rec_want); }
+    if (D.chim_slot_of.cap < n1) GROW(chim_slot_of, std::min(n0, D.chim_slot_of.cap), rec_want);
+    if (D.blk_off.cap < n1 + 1) GROW(blk_off, n0 ? n0 + 1 : 0, rec_want + 1);
+    ChimSetView C{D.chim_mask, D.chim_mask ? D.chim_hash.p : nullptr, D.chim_off.p, D.chim_len.p, D.chim_blob.p, D.chim_dead.p};
+    if (c->capture_names) C = ChimSetView{0, nullptr, D.chim_off.p, D.chim_len.p, D.chim_blob.p, D.chim_dead.p};  // (the chimeric BAM itself: no name set to look its records up in)
+    ParseParams P{(int)(signed char)(((c->P.phred_type ? 33 : 64) + c->P.min_phred) & 0xff), c->P.max_lowphred_len, c->P.min_mapqual, c->capture_names ? 1 : 0};
+    // one pass over the inflated bytes: every field of a record, its block count and its first two blocks (k_parse_records); the blocks
+    // go to their places behind the scan of the counts (k_parse_place)
+    { EvTimer t(c, "k_parse_records", (double)nbytes + 64.0 * n_rec, s);
+      const ParseOut O{D.refid.p + n0, D.pos.p + n0, D.mrefid.p + n0, D.mpos.p + n0, D.endpos.p + n0, D.flag.p + n0, D.totlen.p + n0, D.mapq.p + n0, D.aux.p + n0, D.chim_slot_of.p + n0, D.parse_nblk.p, D.parse_first2.p};
+      hipLaunchKernelGGL(k_parse_records, grid_for(n_rec, PARSE_THREADS), dim3(PARSE_THREADS), 0, s, d_bam, nbytes, d_off, n_rec, C, P, O, fl);
       HIPCHK((device_scan<OpSum, true>(s, n_rec, FArrN{D.parse_nblk.p}, D.parse_rel.p, spine, tot))); }
     int32_t nblk_total = 0;
     HIPCHK(hipMemcpyAsync(&nblk_total, tot, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const size_t nb1 = nb0 + (size_t)nblk_total;
     if (nb1 >= 0xffffffffull) return fail(c, SQ_E_CAPACITY, "more than 2^32 aligned blocks");
-    // a file ingest tells how much is still to come: size the arrays for all of it at the first growth instead of
-    // reallocating (and copying) them chunk after chunk
-    size_t rec_want = n1, blk_want = nb1 + 1;
-    if (c->ingest_total_bytes && c->ingest_seen_bytes) {
-        const double scale = 1.02 * (double)c->ingest_total_bytes / (double)c->ingest_seen_bytes;
-        rec_want = std::max(rec_want, (size_t)((double)n1 * scale) + 1024);
-        blk_want = std::max(blk_want, (size_t)((double)(nb1 + 1) * scale) + 1024);
-    }
-#define GROW(buf, used, want) HIPCHK(D.buf.grow_keep(used, want, s))
-    if (D.refid.cap < n1) { GROW(refid, n0, rec_want); GROW(pos, n0, rec_want); GROW(mrefid, n0, rec_want); GROW(mpos, n0, rec_want); GROW(endpos, n0, rec_want);
-                            GROW(flag, n0, rec_want); GROW(totlen, n0, rec_want); GROW(mapq, n0, rec_want); GROW(aux, n0, rec_want); }
-    if (D.chim_slot_of.cap < n1) GROW(chim_slot_of, std::min(n0, D.chim_slot_of.cap), rec_want);
-    if (D.blk_off.cap < n1 + 1) GROW(blk_off, n0 ? n0 + 1 : 0, rec_want + 1);
+    const size_t blk_want = scale > 0 ? std::max(nb1 + 1, (size_t)((double)(nb1 + 1) * scale) + 1024) : nb1 + 1;
     if (D.b_refpos.cap < nb1 + 1) { GROW(b_refpos, nb0, blk_want); GROW(b_matchref, nb0, blk_want); GROW(b_readpos, nb0, blk_want); GROW(b_matchread, nb0, blk_want); }
     if (D.b_pack.cap < nb1 + 1) GROW(b_pack, nb0, blk_want);
 #undef GROW
-    ChimSetView C{D.chim_mask, D.chim_mask ? D.chim_hash.p : nullptr, D.chim_off.p, D.chim_len.p, D.chim_blob.p, D.chim_dead.p};
-    if (c->capture_names) C = ChimSetView{0, nullptr, D.chim_off.p, D.chim_len.p, D.chim_blob.p, D.chim_dead.p};  // (the chimeric BAM itself: no name set to look its records up in)
-    ParseParams P{(int)(signed char)(((c->P.phred_type ? 33 : 64) + c->P.min_phred) & 0xff), c->P.max_lowphred_len, c->P.min_mapqual, c->capture_names ? 1 : 0};
-    { EvTimer t(c, "k_parse_write", (double)nbytes + 32.0 * n_rec + 12.0 * nblk_total, s);
-      hipLaunchKernelGGL(k_parse_write, grid_for(n_rec, PARSE_THREADS), dim3(PARSE_THREADS), 0, s, d_bam, nbytes, d_off, n_rec, C, P, D.parse_nblk.p, D.parse_rel.p, (uint32_t)nb0, D.refid.p + n0, D.pos.p + n0, D.mrefid.p + n0,
-                         D.mpos.p + n0, D.endpos.p + n0, D.flag.p + n0, D.totlen.p + n0, D.mapq.p + n0, D.aux.p + n0, D.blk_off.p + n0, D.b_refpos.p, D.b_matchref.p, D.b_readpos.p, D.b_matchread.p,
-                         D.chim_slot_of.p + n0, fl); }
-    if (nb1 > nb0) hipLaunchKernelGGL(k_pack_blocks, dim3((unsigned)((nb1 - nb0 + 255) / 256)), dim3(256), 0, s, (int64_t)nb0, (int64_t)nb1, D.b_refpos.p, D.b_matchref.p, D.b_readpos.p, D.b_matchread.p, D.b_pack.p);
+    { EvTimer t(c, "k_parse_place", 44.0 * n_rec + 28.0 * nblk_total, s);
+      hipLaunchKernelGGL(k_parse_place, grid_for(n_rec, 256), dim3(256), 0, s, d_bam, d_off, n_rec, D.parse_nblk.p, D.parse_rel.p, D.parse_first2.p, (uint32_t)nb0, D.totlen.p + n0, D.blk_off.p + n0,
+                         D.b_refpos.p, D.b_matchref.p, D.b_readpos.p, D.b_matchread.p, D.b_pack.p); }
     const uint32_t endoff = (uint32_t)nb1;
     HIPCHK(hipMemcpyAsync(D.blk_off.p + n1, &endoff, 4, hipMemcpyHostToDevice, s));
     int32_t hf = 0;

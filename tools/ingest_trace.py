@@ -32,6 +32,6 @@ print(f"after the last token pass ended (+{(tail0 - t0) / 1e6:.1f} ms): " + " ".
 for name in by:
     if name.startswith("k_lz_resolve"):
         print(name, "launches:", " ".join(f"{(s - t0) / 1e6:.1f}-{(e - t0) / 1e6:.1f}" for s, e in sorted(by[name])))
-for name in ("k_parse_write", "k_rec_sync"):
+for name in ("k_parse_records", "k_rec_sync"):
     for k in by:
         if k.startswith(name): print(k, "launches:", " ".join(f"{(s - t0) / 1e6:.1f}-{(e - t0) / 1e6:.1f}" for s, e in sorted(by[k])))
