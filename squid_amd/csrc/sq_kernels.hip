@@ -214,10 +214,10 @@ struct DeviceRecords {
     int il_depth = 5;  // buffer sets in use (SQUID_IL_DEPTH, 3..8): batch k is resolved / parsed, the ones behind it are in the token pass, the last is being copied
     InflSet il_set[IL_DEPTH_MAX];
     hipStream_t il_stream[IL_DEPTH_MAX] = {};  // one per set: its host->device copies and its token pass
-    // everything behind the token pass exists twice: while batch k is parsed (parse stream), batch k + 1 is resolved and cut into
-    // records (library stream)
-    struct PostSet { DBuf<uint8_t> out; DBuf<long long> rec_sync, rec_end; DBuf<int32_t> rec_cnt, rec_base, flags, spine; DBuf<unsigned long long> bam_off; };
-    PostSet il_post[2];
+    // everything behind the token pass, per buffer set as well (round 6: the resolve follows the token pass on the set's stream, into the set's
+    // own inflated buffer; what runs one batch after the other is only the boundary search on the library stream and the parse on the parse stream)
+    struct PostSet { DBuf<uint8_t> out, big; DBuf<long long> rec_sync, rec_end; DBuf<int32_t> rec_cnt, rec_base, flags, spine; DBuf<unsigned long long> bam_off; hipEvent_t carried = nullptr; /* the tail of `out` has been copied in front of the next batch */ };
+    PostSet il_post[IL_DEPTH_MAX];
     hipStream_t il_parse_stream = nullptr;
     hipStream_t order_stream = nullptr;     // k_order_mid beside k_order_small (dev_order_mid)
     int32_t* il_host = nullptr;            // page-locked: the small results of the two sets (32 ints each)
@@ -758,7 +758,16 @@ __device__ __forceinline__ bool stage_records(const uint8_t* bam, size_t nbytes,
         const uint4* src = (const uint4*)(bam + lo);  // (the chunk buffer is 256-byte aligned and padded by 64 bytes)
         uint4* dst = (uint4*)lds;
         const int words = (int)((hi - lo + 15) >> 4);
-        for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+        // (every load is in flight before the first store: written as a loop the copy waits for memory once per 16 bytes and lane,
+        // eighteen round trips to HBM one after the other -- four fifths of the kernel's time in round 6's first form)
+        constexpr int PER = (PARSE_LDS / 16 + PARSE_THREADS - 1) / PARSE_THREADS + 1;
+        uint4 v[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { const int i = (int)threadIdx.x + k * PARSE_THREADS; v[k] = src[i < words ? i : words - 1]; }  // (no branch around a load: the array stays in registers)
+#pragma unroll
+        for (int k = 0; k < PER; ++k) asm volatile("" : "+v"(v[k].x), "+v"(v[k].y), "+v"(v[k].z), "+v"(v[k].w));  // (and the loads stay in front of the stores)
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { const int i = (int)threadIdx.x + k * PARSE_THREADS; if (i < words) dst[i] = v[k]; }
     }
     __syncthreads();
     if (r >= n) return fits;
@@ -3017,7 +3026,7 @@ void dev_destroy(sq_ctx* c) {
     D.ord_e.release(); D.ord_o.release(); D.ord_v.release(); D.ord_me.release(); D.ord_mo.release(); D.g_i.release(); D.g_x.release(); D.g_d.release(); D.g_b.release();
     D.pin.release(); for (auto& st : D.il_set) { st.in.release(); st.tab.release(); st.tok.release(); st.lens.release(); st.ntok.release(); st.flags.release(); if (st.ready) (void)hipEventDestroy(st.ready); if (st.freed) (void)hipEventDestroy(st.freed); if (st.copied) (void)hipEventDestroy(st.copied); st.ready = st.freed = st.copied = nullptr; }
     for (auto& q : D.il_stream) if (q) { (void)hipStreamDestroy(q); q = nullptr; }
-    for (auto& ps : D.il_post) { ps.out.release(); ps.rec_sync.release(); ps.rec_end.release(); ps.rec_cnt.release(); ps.rec_base.release(); ps.flags.release(); ps.spine.release(); ps.bam_off.release(); }
+    for (auto& ps : D.il_post) { ps.out.release(); ps.big.release(); ps.rec_sync.release(); ps.rec_end.release(); ps.rec_cnt.release(); ps.rec_base.release(); ps.flags.release(); ps.spine.release(); ps.bam_off.release(); if (ps.carried) { (void)hipEventDestroy(ps.carried); ps.carried = nullptr; } }
     if (D.il_parse_stream) { (void)hipStreamDestroy(D.il_parse_stream); D.il_parse_stream = nullptr; }
     if (D.order_stream) { (void)hipStreamDestroy(D.order_stream); D.order_stream = nullptr; }
     if (D.il_host) { (void)hipHostFree(D.il_host); D.il_host = nullptr; }
@@ -3088,7 +3097,7 @@ int dev_release_reader(sq_ctx* c) {
     HIPCHK(hipDeviceSynchronize());
     D.stream_file.release(); D.staged.release();
     for (auto& st : D.il_set) { st.in.release(); st.tab.release(); st.tok.release(); st.lens.release(); st.ntok.release(); st.flags.release(); }
-    for (auto& ps : D.il_post) { ps.out.release(); ps.rec_sync.release(); ps.rec_end.release(); ps.rec_cnt.release(); ps.rec_base.release(); ps.flags.release(); ps.spine.release(); ps.bam_off.release(); }
+    for (auto& ps : D.il_post) { ps.out.release(); ps.big.release(); ps.rec_sync.release(); ps.rec_end.release(); ps.rec_cnt.release(); ps.rec_base.release(); ps.flags.release(); ps.spine.release(); ps.bam_off.release(); }
     D.bgzf_out.release(); D.bgzf_carry.release();
     for (auto& pr : D.feed_pin) for (auto& b : pr) if (b) { (void)hipHostFree(b); b = nullptr; }
     D.feed_pin_bytes = 0;
@@ -3771,6 +3780,10 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     // launch: three sets keep the token pass a batch or two ahead of the resolve)
     const int il_depth = std::getenv("SQUID_IL_DEPTH") ? std::max(2, std::min((int)DeviceRecords::IL_DEPTH_MAX, std::atoi(std::getenv("SQUID_IL_DEPTH")))) : (tok_spec ? 3 : (resolve_global ? 8 : 5));
     D.il_depth = il_depth;
+    // The resolve of a batch writes at a fixed place of the set's inflated buffer, `room` bytes in: the incomplete record the batch in front
+    // ends with (known only when that batch's boundaries are) is copied in front of it afterwards.  A longer tail -- a single record of more
+    // than a megabyte -- moves the batch to a buffer of its own (PostSet::big).  SQUID_CARRY_ROOM=<bytes, a multiple of 16> (tests: 64 takes nearly every batch that way).
+    const unsigned long long room = std::getenv("SQUID_CARRY_ROOM") ? ((unsigned long long)std::max(0ll, std::atoll(std::getenv("SQUID_CARRY_ROOM"))) + 15) / 16 * 16 : (unsigned long long)1 << 20;
     // the stream and the events of a buffer set are made when its first batch is staged (on the planner thread): a stream of a priority
     // level that has none yet costs the runtime a hardware queue, 7-8 ms each in a process that has just started -- eight of them in
     // front of the first batch were 60 ms of a cold start
@@ -3790,6 +3803,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         if (!st.ready && hipEventCreateWithFlags(&st.ready, hipEventDisableTiming) != hipSuccess) return (int)SQ_E_HIP;
         if (!st.freed && hipEventCreateWithFlags(&st.freed, hipEventDisableTiming) != hipSuccess) return (int)SQ_E_HIP;
         if (!st.copied && hipEventCreateWithFlags(&st.copied, hipEventDisableTiming) != hipSuccess) return (int)SQ_E_HIP;
+        if (!D.il_post[qi].carried && hipEventCreateWithFlags(&D.il_post[qi].carried, hipEventDisableTiming) != hipSuccess) return (int)SQ_E_HIP;
         return SQ_OK;
     };
     if (report) std::fprintf(stderr, "GPU ingest: entry + %.1f ms: kernel attributes\n", since_ms(w_entry));
@@ -3892,7 +3906,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         std::stable_sort(st.host_tab.begin(), st.host_tab.end(), [](const InflBlock& x, const InflBlock& y) { return x.clen > y.clen; });
         unsigned long long tok_slots = 0;  // token slots of the batch: half a slot per inflated byte (t2_tok_cap), block after block in table order
         for (InflBlock& ib : st.host_tab) { ib.toff = tok_slots; tok_slots += tok_spec ? isp::tok_cap_spec(ib.isize, ib.clen) : t2_tok_cap(ib.isize); }
-        if (k >= (size_t)D.il_depth) HIPCHK(hipStreamWaitEvent(sa, st.freed, 0));  // the resolve of batch k - IL_DEPTH has read its tokens
+        // (the set's stream runs token pass and resolve of batch k - depth in front of this batch's: its tokens have been read by then)
         const auto wa0 = std::chrono::steady_clock::now();
         // sized for a full batch at once (the first batches are small): growing a buffer later frees the old one, and freeing
         // device memory waits for the kernels of the other batches
@@ -3909,7 +3923,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         const double wa1 = since_ms(wa0);
         if (!dfile) {
             // (the copy no longer travels on the set's stream: the token pass and the resolve that last read this buffer are waited for here)
-            if (k >= (size_t)D.il_depth) HIPCHK(hipEventSynchronize(st.freed));
+            if (k >= (size_t)D.il_depth) HIPCHK(hipEventSynchronize(st.ready));  // (of batch k - depth: recorded behind its resolve)
             const int rc = h2d_parallel(c, st.in.p, file + B.coff0, (size_t)B.cbytes);
             if (rc) return rc;
         }
@@ -3928,17 +3942,27 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
             if (tok_prof && k == 8) hipLaunchKernelGGL(k_inflate_tok2<true>, dim3((nb + 63) / 64), dim3(64), T2_LDS_BYTES, sa, st.src, st.tab.p, nb, st.flags.p, st.tok.p, st.ntok.p, st.lens.p, D.tok_prof.p);
             else hipLaunchKernelGGL(k_inflate_tok2<false>, dim3(((nb + 63) / 64 + tok_wpb - 1) / tok_wpb), dim3(64 * tok_wpb), tok_wpb * T2_LDS_BYTES, sa, st.src, st.tab.p, nb, st.flags.p, st.tok.p, st.ntok.p, st.lens.p, nullptr);
         }
+        // the resolve, right behind: into the set's inflated buffer, which batch k - depth has left -- its parse is over (the planner waits for
+        // that iteration of the batch loop) and its tail has been copied in front of the batch behind it (`carried`)
+        DeviceRecords::PostSet& P = D.il_post[k % (size_t)D.il_depth];
+        HIPCHK(P.out.reserve((size_t)room + (size_t)full + ((size_t)1 << 20) + 64));
+        if (k >= (size_t)D.il_depth) HIPCHK(hipStreamWaitEvent(sa, P.carried, 0));
+        {
+            EvTimer t2(c, resolve_global ? "k_lz_resolve3" : "k_lz_resolve2", (double)B.bbytes * 3, sa);
+            if (resolve_global) hipLaunchKernelGGL(k_lz_resolve3, dim3(nb), dim3(64), 0, sa, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, P.out.p + room, st.flags.p);
+            else hipLaunchKernelGGL(k_lz_resolve2, dim3(nb), dim3(128), 65536 + 16, sa, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, P.out.p + room, st.flags.p);
+        }
         HIPCHK(hipEventRecord(st.ready, sa));
         return SQ_OK;
     };
     // Stage A runs on a planner thread, batch after batch, as far ahead of the batch loop as there are buffer sets: set k % depth is free
-    // for batch k once the resolve of batch k - depth has been QUEUED (its `freed` event is recorded by issue_front).  The thread blocks
+    // for batch k once the batch loop is through with batch k - depth (its parse is over, the front of the batch behind it queued).  The thread blocks
     // where stage A blocks -- in the header walk, in the wait for a batch's file pieces to be queued for copy, in the copy of pageable
     // memory -- and the batch loop does not: round 4's first form queued depth - 1 batches before the first resolve, which with eight sets
     // meant waiting for 40 % of a streamed file before anything was resolved.
     std::mutex pm;
     std::condition_variable pcv;
-    size_t staged = 0, fronts = 0;  // (pm) batches through stage A; issue_front calls made
+    size_t staged = 0, iters_done = 0;  // (pm) batches through stage A; batches the loop below is through with
     bool planner_over = false, planner_stop = false;
     int planner_rc = SQ_OK;
     std::string planner_err;  // (its error text: moved into c->err by this thread once the planner is over)
@@ -3947,7 +3971,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         int rc = hipSetDevice(c->P.device) == hipSuccess ? SQ_OK : (int)SQ_E_HIP;
         try {
             for (size_t k = 0; rc == SQ_OK; ++k) {
-                { std::unique_lock<std::mutex> lk(pm); pcv.wait(lk, [&]() { return planner_stop || k < fronts + (size_t)D.il_depth; }); if (planner_stop) break; }
+                { std::unique_lock<std::mutex> lk(pm); pcv.wait(lk, [&]() { return planner_stop || k < iters_done + (size_t)D.il_depth; }); if (planner_stop) break; }
                 if (!plan(k)) break;
                 rc = stage_a(k);
                 if (rc == SQ_OK) { std::lock_guard<std::mutex> lk(pm); staged = k + 1; }
@@ -3974,17 +3998,18 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         if (planner_rc && !planner_err.empty()) c->err = planner_err;  // (the planner is over: nobody else writes it)
         return planner_rc > 0 ? (int)SQ_E_HIP : planner_rc;  // (error codes are negative)
     };
-    auto front_issued = [&]() { { std::lock_guard<std::mutex> lk(pm); ++fronts; } pcv.notify_all(); };
+    auto batch_done = [&]() { { std::lock_guard<std::mutex> lk(pm); ++iters_done; } pcv.notify_all(); };
     { const int r = wait_staged(0); if (r <= 0) return r; }
     const double w_first = since_ms(w0);
-    // Everything behind the token pass is double-buffered (DeviceRecords::PostSet): the front of batch k + 1 -- resolve, slice
-    // boundaries -- is queued on the library stream before batch k is parsed on the parse stream, so the two overlap; in round 1
-    // resolve -> boundaries -> parse of one batch after the other was the chain the wall time followed.  The front needs the
-    // bytes of the incomplete record at the end of the batch before (`carry`, known once that batch's boundaries are): they are
-    // copied from the one inflated buffer to the front of the other.
+    // Behind the resolve: the front of batch k + 1 -- the tail of batch k copied in front of its bytes, slice boundaries -- is queued on the
+    // library stream before batch k is parsed on the parse stream, so the two overlap.  The front needs the bytes of the incomplete record
+    // at the end of the batch before (`carry`, known once that batch's boundaries are): this is the one chain that runs from batch to
+    // batch, and since round 6 the resolve is no longer part of it (rounds 1-5 resolved batch k + 1 behind its carry: token passes
+    // waited for resolves, resolves for the boundary search of the batch in front and a trip to the host -- a period of 4.0 ms per
+    // 512 MB batch of which the token pass, the longest kernel, took 2.8).
     if (!D.il_parse_stream) {
-        // (highest priority: the parse of batch k shares the machine with the resolve of batch k + 1 -- sixteen thousand one-wave workgroups
-        // that take every free wave slot -- and the batch loop waits for the parse)
+        // (highest priority: the parse of batch k shares the machine with the resolves and token passes of the batches behind -- thousands of
+        // one-wave workgroups that take every free wave slot -- and the batch loop waits for the parse)
         static const bool parse_hi = std::getenv("SQUID_PARSE_PRIO") == nullptr || std::atoi(std::getenv("SQUID_PARSE_PRIO")) != 0;
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
@@ -3992,33 +4017,31 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     }
     if (!D.il_host) HIPCHK(hipHostMalloc((void**)&D.il_host, 64 * sizeof(int32_t)));
     hipStream_t sp = D.il_parse_stream;
-    struct Front { unsigned long long pad = 0, carry = 0, limit = 0; long long nsl = 0; RecScan S{}; };
+    struct Front { const uint8_t* base = nullptr; /* the set's inflated buffer, or PostSet::big */ unsigned long long at = 0 /* where the carried bytes start */, carry = 0, limit = 0; long long nsl = 0; RecScan S{}; };
     Front fr[2];
     auto issue_front = [&](size_t k, unsigned long long carry_in, const uint8_t* carry_src) -> int {
         const Batch B = batch_of(k);
         DeviceRecords::InflSet& st = D.il_set[k % (size_t)D.il_depth];
-        DeviceRecords::PostSet& P = D.il_post[k & 1];
+        DeviceRecords::PostSet& P = D.il_post[k % (size_t)D.il_depth];
         Front& F = fr[k & 1];
-        int32_t* hk = D.il_host + 32 * (k & 1);  // [0..9] flags of the front, [10..13] of the token pass, [16..17] where the walk stopped
-        const int nb = (int)(B.end - B.at);
+        int32_t* hk = D.il_host + 32 * (k & 1);  // [0..9] flags of the front, [10..13] of the token pass and the resolve, [16..17] where the walk stopped
         F.carry = carry_in;
-        F.pad = (16 - carry_in % 16) % 16;  // the batch's own bytes start 16-byte aligned
-        F.limit = F.pad + carry_in + B.bbytes;
-        HIPCHK(P.out.reserve(std::max((size_t)F.limit, (size_t)std::min<unsigned long long>(cap, range_bytes_estimate()) + ((size_t)1 << 20)) + 64));
         HIPCHK(P.flags.reserve(16));
         HIPCHK(hipMemsetAsync(P.flags.p, 0, 16 * 4, s));
-        if (carry_in) HIPCHK(hipMemcpyAsync(P.out.p + F.pad, carry_src, (size_t)carry_in, hipMemcpyDeviceToDevice, s));
-        uint8_t* out = P.out.p + F.pad + carry_in;
-        HIPCHK(hipStreamWaitEvent(s, st.ready, 0));
-        {
-            EvTimer t2(c, resolve_global ? "k_lz_resolve3" : "k_lz_resolve2", (double)B.bbytes * 3);
-            if (resolve_global) hipLaunchKernelGGL(k_lz_resolve3, dim3(nb), dim3(64), 0, s, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, out, P.flags.p);
-            else hipLaunchKernelGGL(k_lz_resolve2, dim3(nb), dim3(128), 65536 + 16, s, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, out, P.flags.p);
+        HIPCHK(hipStreamWaitEvent(s, st.ready, 0));  // token pass and resolve of the batch
+        if (carry_in <= room) {
+            F.base = P.out.p; F.at = room - carry_in; F.limit = room + B.bbytes;
+            if (carry_in) HIPCHK(hipMemcpyAsync(P.out.p + F.at, carry_src, (size_t)carry_in, hipMemcpyDeviceToDevice, s));
+        } else {  // (the batch's own bytes start 16-byte aligned there as well)
+            const unsigned long long pad = (16 - carry_in % 16) % 16;
+            HIPCHK(P.big.reserve((size_t)(pad + carry_in + B.bbytes) + ((size_t)1 << 20) + 64));
+            F.base = P.big.p; F.at = pad; F.limit = pad + carry_in + B.bbytes;
+            HIPCHK(hipMemcpyAsync(P.big.p + pad, carry_src, (size_t)carry_in, hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipMemcpyAsync(P.big.p + pad + carry_in, P.out.p + room, (size_t)B.bbytes, hipMemcpyDeviceToDevice, s));
         }
+        if (k > 0) HIPCHK(hipEventRecord(D.il_post[(k - 1) % (size_t)D.il_depth].carried, s));  // the buffer of batch k - 1 is read by its parse only from here on
         HIPCHK(hipMemcpyAsync(hk + 10, st.flags.p, 4 * 4, hipMemcpyDeviceToHost, s));  // (before the set goes back to the planner, whose next batch clears them)
-        HIPCHK(hipEventRecord(st.freed, s));
-        front_issued();
-        F.S = RecScan{P.out.p, k == 0 ? (unsigned long long)begin : F.pad, F.limit, nref, sh.on ? sh.first_ref : -1, sh.on ? sh.end_ref : 0, (sh.on && c->P.rank == c->P.world_size - 1) ? 1 : 0};
+        F.S = RecScan{F.base, F.at + (k == 0 ? (unsigned long long)begin : 0ull), F.limit, nref, sh.on ? sh.first_ref : -1, sh.on ? sh.end_ref : 0, (sh.on && c->P.rank == c->P.world_size - 1) ? 1 : 0};
         F.nsl = F.S.limit > F.S.begin ? (long long)((F.S.limit - F.S.begin + REC_SLICE - 1) / REC_SLICE) : 0;
         hk[16] = 0; hk[17] = 0;
         if (F.nsl > 0) {
@@ -4028,7 +4051,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
             long long* tail_d = P.rec_end.p + nsl;  // where the walk stopped: the start of the incomplete tail
             HIPCHK(hipMemsetAsync(tail_d, 0, 8, s));
             { EvTimer t(c, "k_rec_sync+walk+check", 2.0 * (double)(F.S.limit - F.S.begin));
-              // (single-wave workgroups: these kernels run beside the resolve of the next batch and the token waves, whose one-wave
+              // (single-wave workgroups: these kernels run beside the resolves and the token waves, whose one-wave
               // workgroups take wave slots one at a time as they come free -- a workgroup that needs four on one CU at once waited 3 ms)
               hipLaunchKernelGGL(k_rec_sync, dim3((unsigned)nsl), dim3(64), 0, s, F.S, nsl, (k > 0 || synced) ? 1 : 0, P.rec_sync.p);
               hipLaunchKernelGGL(k_rec_walk<false>, grid_for(nsl, 64), dim3(64), 0, s, F.S, nsl, P.rec_sync.p, P.rec_cnt.p, P.rec_end.p, nullptr, nullptr);
@@ -4043,7 +4066,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
     { int rc = issue_front(0, 0, nullptr); if (rc) { (void)give_up(); return rc; } }
     for (size_t k = 0;; ++k) {
         const Batch B = batch_of(k);
-        DeviceRecords::PostSet& P = D.il_post[k & 1];
+        DeviceRecords::PostSet& P = D.il_post[k % (size_t)D.il_depth];
         const Front F = fr[k & 1];
         const int32_t* hk = D.il_host + 32 * (k & 1);
         HIPCHK(hipStreamSynchronize(s));  // the front of batch k
@@ -4053,7 +4076,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         long long tail = 0;
         std::memcpy(&tail, hk + 16, 8);
         if (check) {  // debugging: every block against zlib
-            const uint8_t* out = P.out.p + F.pad + F.carry;
+            const uint8_t* out = F.base + F.at + F.carry;
             std::vector<uint8_t> got((size_t)B.bbytes), want;
             HIPCHK(hipMemcpy(got.data(), out, (size_t)B.bbytes, hipMemcpyDeviceToHost));
             for (size_t i = B.at; i < B.end; ++i) {
@@ -4078,7 +4101,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         const unsigned long long carry = F.limit > tail_at ? F.limit - tail_at : 0;
         const int has_next = wait_staged(k + 1);
         if (has_next < 0) { (void)give_up(); return has_next; }
-        if (has_next) { int rc = issue_front(k + 1, carry, P.out.p + tail_at); if (rc) { (void)give_up(); return rc; } }
+        if (has_next) { int rc = issue_front(k + 1, carry, F.base + tail_at); if (rc) { (void)give_up(); return rc; } }
         const int64_t n_rec = h[8];
         if (n_rec > 0) {
             HIPCHK(P.bam_off.reserve((size_t)n_rec));
@@ -4087,12 +4110,13 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
             const int64_t kBatch = (int64_t)1 << 24;
             for (int64_t r0 = 0; r0 < n_rec; r0 += kBatch) {
                 c->ingest_total_bytes = (size_t)range_bytes_estimate(); c->ingest_seen_bytes = (size_t)(B.bbase + B.bbytes - first_uoff);  // sizes the arrays for the whole range at once
-                int rc = parse_device(c, P.out.p, (size_t)F.limit, P.bam_off.p + r0, std::min(kBatch, n_rec - r0), sp, P.flags.p, &P.spine);
+                int rc = parse_device(c, F.base, (size_t)F.limit, P.bam_off.p + r0, std::min(kBatch, n_rec - r0), sp, P.flags.p, &P.spine);
                 c->ingest_total_bytes = 0; c->ingest_seen_bytes = 0;
                 if (rc) { (void)give_up(); return rc; }
             }
         }
         if (!has_next) { if (report) std::fprintf(stderr, "GPU ingest: %llu bytes left incomplete at the end\n", carry); break; }
+        batch_done();  // (the parse is over: parse_device returns behind its last kernel)
     }
     planner.join();  // (over: the loop above ended on its word)
     HIPCHK(hipStreamSynchronize(sp));

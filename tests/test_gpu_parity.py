@@ -1041,6 +1041,10 @@ def test_gpu_bgzf_inflate_and_boundary_search_give_the_same_records(built, synth
     assert run(f"{pre}.bam", old) == want
     assert run(f"{pre}.bam", dict(gpu, SQUID_TOK_CAP_MB="0")) == want
     assert run(f"{pre}.bam", dict(gpu, SQUID_TOK_CAP_MB="0", SQUID_IL_DEPTH="2")) == want
+    # the resolve writes `SQUID_CARRY_ROOM` bytes into its buffer and the tail of the batch in front is copied below it; a longer tail moves
+    # the batch to a buffer of its own (the default room is 1 MB: 64 bytes and none at all send nearly every batch that way)
+    assert run(f"{pre}.bam", dict(gpu, SQUID_TOK_CAP_MB="0", SQUID_CARRY_ROOM="64", SQUID_IL_DEPTH="4")) == want
+    assert run(f"{pre}.bam", dict(gpu, SQUID_TOK_CAP_MB="1", SQUID_CARRY_ROOM="0")) == want
     assert run(f"{pre}.bam", dict(old, SQUID_TOK_CAP_MB="0")) == want
     assert run(f"{pre}.bam", dict(old, SQUID_TOK_WPB="5")) == want
     # the LDS-window resolve (k_lz_resolve2; the default is k_lz_resolve3, which keeps its window in HBM), three buffer sets, and a runtime
@@ -1217,6 +1221,8 @@ def test_gpu_reader_carries_records_larger_than_a_block(built, tmp_path):
         assert run(bam, {"SQUID_GPU_INFLATE": "0"}) == want
         for cap in ("0", "1", "1024"):
             assert run(bam, {"SQUID_GPU_INFLATE": "1", "SQUID_INGEST_TIMING": "1", "SQUID_TOK_CAP_MB": cap}) == want, (bam, cap)
+            # (a tail of 100-200 KB in front of a batch: inside the default room of the resolve's buffer above, beyond a room of 4 KB here)
+            assert run(bam, {"SQUID_GPU_INFLATE": "1", "SQUID_INGEST_TIMING": "1", "SQUID_TOK_CAP_MB": cap, "SQUID_CARRY_ROOM": "4096"}) == want, (bam, cap)
 
 
 def test_damaged_files_are_reported_by_both_readers(built, synth, tmp_path):
