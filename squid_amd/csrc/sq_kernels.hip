@@ -2722,6 +2722,8 @@ constexpr int REC_SLICE = 8192;
 // pass (five token waves per CU instead of three).  Same rounds of 64 tokens and the same readiness rule as k_lz_resolve2; between the
 // stores of a sub-round and the loads of the next a workgroup-scope fence (one wave per workgroup on one CU: its L1 is the only cache in
 // between, the fence is the wait for the stores).
+// (experiment: SQUID_RESOLVE_LDS=<bytes> of unused dynamic LDS per resolve wave = a cap on the waves a CU holds -- 160 KB / bytes)
+static unsigned resolve_lds_pad() { static const unsigned v = std::getenv("SQUID_RESOLVE_LDS") ? (unsigned)std::atoi(std::getenv("SQUID_RESOLVE_LDS")) : 0u; return v; }
 __global__ __launch_bounds__(64) void k_lz_resolve3(const uint32_t* tok, const int32_t* ntok, const InflBlock* blocks, int nblocks, unsigned long long out_base, uint8_t* outbuf, int32_t* flags) {
     const int lane = threadIdx.x;
     const InflBlock blk = blocks[blockIdx.x];
@@ -3692,7 +3694,7 @@ int dev_token_bench(sq_ctx* c, const char* path, int variant, int max_blocks, in
             default: return fail(c, SQ_E_ARG, "unknown token pass variant");
         }
         HIPCHK(hipEventRecord(e1, s));
-        hipLaunchKernelGGL(k_lz_resolve3, dim3(nb), dim3(64), 0, s, d_tok.p, d_ntok.p, d_tab.p, nb, 0ull, d_out.p, d_flags.p + 4);
+        hipLaunchKernelGGL(k_lz_resolve3, dim3(nb), dim3(64), resolve_lds_pad(), s, d_tok.p, d_ntok.p, d_tab.p, nb, 0ull, d_out.p, d_flags.p + 4);
         HIPCHK(hipEventRecord(e2, s));
         HIPCHK(hipStreamSynchronize(s));
         float a = 0, b = 0;
@@ -3949,7 +3951,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         if (k >= (size_t)D.il_depth) HIPCHK(hipStreamWaitEvent(sa, P.carried, 0));
         {
             EvTimer t2(c, resolve_global ? "k_lz_resolve3" : "k_lz_resolve2", (double)B.bbytes * 3, sa);
-            if (resolve_global) hipLaunchKernelGGL(k_lz_resolve3, dim3(nb), dim3(64), 0, sa, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, P.out.p + room, st.flags.p);
+            if (resolve_global) hipLaunchKernelGGL(k_lz_resolve3, dim3(nb), dim3(64), resolve_lds_pad(), sa, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, P.out.p + room, st.flags.p);
             else hipLaunchKernelGGL(k_lz_resolve2, dim3(nb), dim3(128), 65536 + 16, sa, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, P.out.p + room, st.flags.p);
         }
         HIPCHK(hipEventRecord(st.ready, sa));

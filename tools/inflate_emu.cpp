@@ -40,6 +40,56 @@ static bool resolve(const std::vector<uint32_t>& tok, uint32_t nt, std::vector<u
     return out.size() == isize;
 }
 // returns 0 same bytes as zlib, 1 error flag raised, 2 WRONG
+// SQ_EMU_RSTAT: how many dependent rounds of copies a resolve needs per block when it takes W tokens at a time -- under the rule of
+// k_lz_resolve3 (a match may go when its source ends below the output of the first pending match) and under the exact rule (its source
+// touches no pending match's output)
+struct RStat { unsigned long long blocks = 0, tokens = 0, matches = 0, trips_hwm[4] = {0, 0, 0, 0}, trips_exact[4] = {0, 0, 0, 0}, windows[4] = {0, 0, 0, 0}, far[4] = {0, 0, 0, 0}; };
+static RStat& rstat() { static RStat r; return r; }
+template <class TOK>
+static void resolve_stats(const TOK& tok, uint32_t nt) {
+    RStat& R = rstat();
+    ++R.blocks; R.tokens += nt;
+    std::vector<uint32_t> o(nt), len(nt), src(nt); std::vector<char> ism(nt);
+    uint32_t at = 0;
+    for (uint32_t i = 0; i < nt; ++i) {
+        const uint32_t tk = tok[i];
+        ism[i] = (char)(tk >> 31);
+        const uint32_t nl = (tk >> 24) & 3u;
+        len[i] = ism[i] ? (tk >> 16) & 0x1ffu : (nl ? nl : 1u);
+        o[i] = at; src[i] = ism[i] ? at - ((tk & 0x7fffu) + 1) : 0; at += len[i];
+        if (ism[i]) ++R.matches;
+    }
+    const int Ws[4] = {64, 128, 256, 512};
+    for (int wi = 0; wi < 4; ++wi) {
+        const uint32_t W = (uint32_t)Ws[wi];
+        for (uint32_t w0 = 0; w0 < nt; w0 += W) {
+            const uint32_t w1 = std::min(nt, w0 + W);
+            ++R.windows[wi];
+            for (int rule = 0; rule < 2; ++rule) {
+                std::vector<char> pend(w1 - w0);
+                bool any = false;
+                for (uint32_t i = w0; i < w1; ++i) { pend[i - w0] = ism[i]; any |= ism[i]; if (rule == 0 && ism[i] && std::min(src[i] + len[i], o[i]) <= o[w0]) ++R.far[wi]; }
+                while (any) {
+                    ++(rule == 0 ? R.trips_hwm : R.trips_exact)[wi];
+                    uint32_t first = w1;
+                    for (uint32_t i = w0; i < w1; ++i) if (pend[i - w0]) { first = i; break; }
+                    std::vector<uint32_t> go;
+                    for (uint32_t i = w0; i < w1; ++i) {
+                        if (!pend[i - w0]) continue;
+                        const uint32_t need_end = std::min(src[i] + len[i], o[i]);
+                        bool ok;
+                        if (rule == 0) ok = need_end <= o[first];
+                        else { ok = true; for (uint32_t j = w0; j < i && ok; ++j) if (pend[j - w0] && o[j] < need_end && o[j] + len[j] > src[i]) ok = false; }
+                        if (ok) go.push_back(i);
+                    }
+                    for (uint32_t i : go) pend[i - w0] = 0;
+                    any = false;
+                    for (char c : pend) any |= (bool)c;
+                }
+            }
+        }
+    }
+}
 static int run_block(const uint8_t* payload, uint32_t clen, const std::vector<uint8_t>& want, int cfg, uint32_t* ntok_out = nullptr) {
     Job j;
     j.lds.assign(65536, 0xdeadbeefu);
@@ -58,6 +108,7 @@ static int run_block(const uint8_t* payload, uint32_t clen, const std::vector<ui
     for (uint32_t k = j.tcap; k < j.tcap + 64; ++k) if (j.tok[k] != 0x55555555u) { std::fprintf(stderr, "token written behind the block's slots\n"); return 2; }
     if (ntok_out) *ntok_out = j.nt[0];
     if (j.err[0]) return 1;
+    if (std::getenv("SQ_EMU_RSTAT")) resolve_stats(j.tok, j.nt[0]);
     std::vector<uint8_t> got;
     if (!resolve(j.tok, j.nt[0], got, (uint32_t)want.size())) { std::fprintf(stderr, "tokens do not resolve to %zu bytes (got %zu)\n", want.size(), got.size()); return 2; }
     if (got != want) { size_t q = 0; while (got[q] == want[q]) ++q; std::fprintf(stderr, "bytes differ at %zu\n", q); return 2; }
@@ -173,6 +224,13 @@ int main(int argc, char** argv) {
         if (rc == 0) ++n_ok; else if (rc == 1) { ++n_flag; std::fprintf(stderr, "block %ld: error flag\n", bi); } else { ++n_wrong; std::fprintf(stderr, "block %ld WRONG\n", bi); }
     }
     std::printf("%ld blocks identical to zlib, %ld flagged, %ld WRONG; %.3f tokens per inflated byte\n", n_ok, n_flag, n_wrong, tot_bytes ? (double)tot_tok / (double)tot_bytes : 0.0);
+    if (std::getenv("SQ_EMU_RSTAT")) {
+        const RStat& R = rstat();
+        std::printf("resolve: %.0f tokens per block, %.0f of them matches\n", (double)R.tokens / R.blocks, (double)R.matches / R.blocks);
+        const int Ws[4] = {64, 128, 256, 512};
+        for (int wi = 0; wi < 4; ++wi) std::printf("  %3d tokens at a time: %.0f windows per block, rounds of copies per block %.0f (rule of k_lz_resolve3) / %.0f (exact), %.1f / %.1f per window; matches whose source lies in front of the window %.0f %%\n", Ws[wi],
+            (double)R.windows[wi] / R.blocks, (double)R.trips_hwm[wi] / R.blocks, (double)R.trips_exact[wi] / R.blocks, (double)R.trips_hwm[wi] / R.windows[wi], (double)R.trips_exact[wi] / R.windows[wi], 100.0 * R.far[wi] / std::max<unsigned long long>(1, R.matches));
+    }
     const isp::EmuStat& st = isp::emu_stat();
     std::printf("writing pass: %llu steps for %llu literals (%llu as pairs: %.1f %% of the literals) and %llu matches: %.2f symbols per step\n", st.iters, st.lits, st.pairs, st.lits ? 200.0 * st.pairs / st.lits : 0.0, st.matches, st.iters ? (double)(st.lits + st.matches) / st.iters : 0.0);
     return n_wrong || n_flag ? 2 : 0;
