@@ -3846,9 +3846,9 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
             const unsigned long long ramp = ramp0 << (20 + std::min<size_t>(batches.size(), 8));
             unsigned long long bcap = std::min(cap, ramp);
             // (the end of the range in smaller batches: what stands behind the last byte is one batch's way through token pass, resolve, boundaries and parse)
-            // (and smaller still as the end comes near -- a quarter of what is left, 16 MB at least: behind the last byte of a streamed file there is then a
-            // token pass of a few hundred blocks, one block's latency, instead of two passes of two thousand.  While the block index is still being
-            // walked the rest of the range is an estimate from the file's size.)
+            // (While the block index is still being walked the rest of the range is an estimate from the file's size; SQUID_TOK_TAPER=0: only with a
+            // full index, as until round 6.  Measured and dropped: batches that keep shrinking to 16 MB -- twelve more batches per C3 step, each with its
+            // trip through the boundary chain: staged 94 -> 102 ms.)
             static const bool taper = std::getenv("SQUID_TOK_TAPER") == nullptr || std::atoi(std::getenv("SQUID_TOK_TAPER")) != 0;
             if (tok_spec_early && at < blocks.size()) {
                 const size_t stop0 = more_blocks || b1 == (size_t)-1 ? blocks.size() : std::min(b1, blocks.size());
@@ -3860,7 +3860,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
                     const unsigned long long end_c = (src && src->stop != (size_t)-1) ? std::min<unsigned long long>(src->stop, file_bytes) : (unsigned long long)file_bytes;
                     left = end_c > a.coff ? (unsigned long long)(ratio * (double)(end_c - a.coff)) : 0;
                 }
-                if (left < 2 * cap) bcap = std::min(bcap, taper ? std::max<unsigned long long>((unsigned long long)16 << 20, std::min(cap / 4, left / 4)) : std::max<unsigned long long>((unsigned long long)64 << 20, cap / 4));
+                if (left < 2 * cap) bcap = std::min(bcap, std::max<unsigned long long>((unsigned long long)64 << 20, cap / 4));
             }
             while (more_blocks && (blocks.size() <= at || blocks.back().uoff + blocks.back().isize - blocks[at].uoff <= bcap)) {
                 std::vector<BgzfRange> got;  // (the wait for the walk happens outside the lock)
