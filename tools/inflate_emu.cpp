@@ -232,6 +232,9 @@ int main(int argc, char** argv) {
         for (int wi = 0; wi < 4; ++wi) std::printf("  %3d tokens at a time: %.0f windows per block, rounds of copies per block %.0f (rule of k_lz_resolve3) / %.0f (exact), %.1f / %.1f per window; matches whose source lies in front of the window %.0f %%\n", Ws[wi],
             (double)R.windows[wi] / R.blocks, (double)R.trips_hwm[wi] / R.blocks, (double)R.trips_exact[wi] / R.blocks, (double)R.trips_hwm[wi] / R.windows[wi], (double)R.trips_exact[wi] / R.windows[wi], 100.0 * R.far[wi] / std::max<unsigned long long>(1, R.matches));
     }
+    { const isp::EmuStat& e = isp::emu_stat();
+      if (e.windows) std::printf("wave cost model (SQ_SPEC_PRE %d): %.2f rounds of scans per window; per window %.1f steps in those rounds (sum over the lanes %.0f) + %.1f steps writing tokens\n", SQ_SPEC_PRE,
+          (double)e.rounds / e.windows, (double)e.wave_steps_fix / e.windows, (double)e.lane_steps_fix / e.windows, (double)e.wave_steps_emit / e.windows); }
     const isp::EmuStat& st = isp::emu_stat();
     std::printf("writing pass: %llu steps for %llu literals (%llu as pairs: %.1f %% of the literals) and %llu matches: %.2f symbols per step\n", st.iters, st.lits, st.pairs, st.lits ? 200.0 * st.pairs / st.lits : 0.0, st.matches, st.iters ? (double)(st.lits + st.matches) / st.iters : 0.0);
     return n_wrong || n_flag ? 2 : 0;
