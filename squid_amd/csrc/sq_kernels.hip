@@ -2722,7 +2722,109 @@ constexpr int REC_SLICE = 8192;
 // pass (five token waves per CU instead of three).  Same rounds of 64 tokens and the same readiness rule as k_lz_resolve2; between the
 // stores of a sub-round and the loads of the next a workgroup-scope fence (one wave per workgroup on one CU: its L1 is the only cache in
 // between, the fence is the wait for the stores).
+// The same resolve with the bytes of a round assembled in LDS and stored as whole words (round 6).  k_lz_resolve3 writes a round's output where the
+// tokens put it: three byte stores per literal token, two or three short stores per match -- 164 M write requests per GiB of output, 6.5 bytes each --, and reads
+// the sources of its matches from memory even when the same round wrote them.  tools/l2_probe.cpp: a wave that writes 192 bytes per round and reads 8 bytes per lane
+// from a few hundred bytes behind takes 1.4-2.6 us per round with byte stores and 0.7-1.2 us with 4- or 16-byte stores; the reads leave the L2 either way.
+// Here a round's literals and the copies of its matches go to a per-wave staging area of RS_STAGE bytes (768: sixteen resolve waves beside sixteen token
+// waves still fit a CU's 160 KB), matches whose source lies inside the round are copied there from the staging area itself, and the round leaves with one
+// 4-byte store per lane.  A round of more than RS_STAGE bytes (long matches) takes k_lz_resolve3's way.
+#ifndef SQ_RS_STAGE
+#define SQ_RS_STAGE 496
+#endif
+constexpr int RS_STAGE = SQ_RS_STAGE;  // (+ 16 bytes of slack = one 512-byte LDS allocation at 496)
+__global__ __launch_bounds__(64) void k_lz_resolve5(const uint32_t* tok, const int32_t* ntok, const InflBlock* blocks, int nblocks, unsigned long long out_base, uint8_t* outbuf, int32_t* flags) {
+    __shared__ __attribute__((aligned(16))) uint8_t st_mem[RS_STAGE + 16];
+    lds_u8* const st = (lds_u8*)st_mem;
+    typedef __attribute__((address_space(3))) u32_any lds_u32_any;
+    typedef __attribute__((address_space(3))) u64_any lds_u64_any;
+    const int lane = threadIdx.x;
+    const InflBlock blk = blocks[blockIdx.x];
+    const uint32_t* t = tok + blk.toff;
+    const int n = ntok[blockIdx.x];
+    uint8_t* out = outbuf + (blk.uoff - out_base);
+    uint32_t base = 0;
+    bool bad = false;
+    uint32_t nxt = lane < n ? t[lane] : 0;
+    for (int r0 = 0; r0 < n; r0 += 64) {
+        const uint32_t tk = nxt;
+        const int i = r0 + lane;
+        if (i + 64 < n) nxt = t[i + 64];
+        const bool valid = i < n, is_m = valid && (tk >> 31);
+        const uint32_t nl = (tk >> 24) & 3u;
+        const uint32_t len = !valid ? 0u : (is_m ? (tk >> 16) & 0x1ffu : (nl ? nl : 1u));
+        const uint32_t inc = wave_scan_incl(len);
+        const uint32_t o = base + inc - len;
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        if (base + total > blk.isize) { bad = true; break; }  // (uniform)
+        const uint32_t dist = (tk & 0x7fffu) + 1;
+        if (__any(is_m && dist > o)) { bad = true; break; }
+        const uint32_t src = o - dist;
+        if (total <= (uint32_t)RS_STAGE) {
+            const uint32_t lo = o - base;  // where the token's bytes go in the staging area
+            if (valid && !is_m) { st[lo] = (uint8_t)tk; if (len > 1) st[lo + 1] = (uint8_t)(tk >> 8); if (len > 2) st[lo + 2] = (uint8_t)(tk >> 16); }
+            // a match whose source ends in front of the round: those bytes are final and in memory (earlier rounds of this wave stored them)
+            const bool far = is_m && src + len <= base;
+            if (far) {
+                if (len <= 8) {
+                    unsigned long long w;
+                    __builtin_memcpy(&w, out + src, 8);  // (bytes behind the match are read, not used)
+                    if (len >= 4) { *(lds_u32_any*)(st + lo) = (uint32_t)w; *(lds_u32_any*)(st + lo + len - 4) = (uint32_t)(w >> (8 * (len - 4))); }
+                    else { st[lo] = (uint8_t)w; st[lo + 1] = (uint8_t)(w >> 8); st[lo + 2] = (uint8_t)(w >> 16); }  // (len == 3: the shortest match)
+                } else {
+                    uint32_t k = 0;
+                    for (; k + 8 <= len; k += 8) { unsigned long long w; __builtin_memcpy(&w, out + src + k, 8); *(lds_u64_any*)(st + lo + k) = w; }
+                    if (k < len) { unsigned long long w; __builtin_memcpy(&w, out + src + len - 8, 8); *(lds_u64_any*)(st + lo + len - 8) = w; }
+                }
+            }
+            // the others take their bytes from the staging area (and from memory below the round's first byte), first pending match first: everything
+            // below its output is final
+            bool pending = is_m && !far;
+            const uint32_t ready_at = src + len < o ? src + len : o;
+            unsigned long long pm = __ballot(pending);
+            while (pm) {
+                const int first = __ffsll((long long)pm) - 1;
+                const uint32_t hwm = (uint32_t)__builtin_amdgcn_readlane((int)o, __builtin_amdgcn_readfirstlane(first));
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                if (pending && ready_at <= hwm) {
+                    for (uint32_t k = 0; k < len; ++k) {  // (byte by byte: a match may overlap its own output)
+                        const uint32_t p = src + k;
+                        st[lo + k] = p < base ? out[p] : st[p - base];
+                    }
+                    pending = false;
+                }
+                pm = __ballot(pending);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            // the round leaves: four bytes per lane and store
+            for (uint32_t q = 4u * (uint32_t)lane; q < total; q += 256u) {
+                if (q + 4 <= total) { const uint32_t w = *(const __attribute__((address_space(3))) uint32_t*)(st + q); __builtin_memcpy(out + base + q, &w, 4); }
+                else for (uint32_t k = q; k < total; ++k) out[base + k] = st[k];
+            }
+        } else {
+            // (k_lz_resolve3's round)
+            if (valid && !is_m) { out[o] = (uint8_t)tk; if (len > 1) out[o + 1] = (uint8_t)(tk >> 8); if (len > 2) out[o + 2] = (uint8_t)(tk >> 16); }
+            bool pending = is_m;
+            const uint32_t ready_at = src + len < o ? src + len : o;
+            unsigned long long pm = __ballot(pending);
+            while (pm) {
+                const int first = __ffsll((long long)pm) - 1;
+                const uint32_t hwm = (uint32_t)__builtin_amdgcn_readlane((int)o, __builtin_amdgcn_readfirstlane(first));
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                if (pending && ready_at <= hwm) {
+                    uint32_t j = 0;
+                    for (uint32_t k = 0; k < len; ++k) { out[o + k] = out[src + j]; if (++j == dist) j = 0; }
+                    pending = false;
+                }
+                pm = __ballot(pending);
+            }
+        }
+        base += total;
+    }
+    if (bad || base != blk.isize) { if (lane == 0) atomicOr(&flags[0], 512); }
+}
 // (experiment: SQUID_RESOLVE_LDS=<bytes> of unused dynamic LDS per resolve wave = a cap on the waves a CU holds -- 160 KB / bytes)
+static bool resolve_staged() { return std::getenv("SQUID_RESOLVE_STAGED") == nullptr || std::atoi(std::getenv("SQUID_RESOLVE_STAGED")) != 0; }  // (the default; 0: k_lz_resolve3.  Read per call: tests switch it)
 static unsigned resolve_lds_pad() { static const unsigned v = std::getenv("SQUID_RESOLVE_LDS") ? (unsigned)std::atoi(std::getenv("SQUID_RESOLVE_LDS")) : 0u; return v; }
 __global__ __launch_bounds__(64) void k_lz_resolve3(const uint32_t* tok, const int32_t* ntok, const InflBlock* blocks, int nblocks, unsigned long long out_base, uint8_t* outbuf, int32_t* flags) {
     const int lane = threadIdx.x;
@@ -3694,7 +3796,8 @@ int dev_token_bench(sq_ctx* c, const char* path, int variant, int max_blocks, in
             default: return fail(c, SQ_E_ARG, "unknown token pass variant");
         }
         HIPCHK(hipEventRecord(e1, s));
-        hipLaunchKernelGGL(k_lz_resolve3, dim3(nb), dim3(64), resolve_lds_pad(), s, d_tok.p, d_ntok.p, d_tab.p, nb, 0ull, d_out.p, d_flags.p + 4);
+        if (resolve_staged()) hipLaunchKernelGGL(k_lz_resolve5, dim3(nb), dim3(64), 0, s, d_tok.p, d_ntok.p, d_tab.p, nb, 0ull, d_out.p, d_flags.p + 4);
+        else hipLaunchKernelGGL(k_lz_resolve3, dim3(nb), dim3(64), resolve_lds_pad(), s, d_tok.p, d_ntok.p, d_tab.p, nb, 0ull, d_out.p, d_flags.p + 4);
         HIPCHK(hipEventRecord(e2, s));
         HIPCHK(hipStreamSynchronize(s));
         float a = 0, b = 0;
@@ -3960,7 +4063,8 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         if (k >= (size_t)D.il_depth) HIPCHK(hipStreamWaitEvent(sa, P.carried, 0));
         {
             EvTimer t2(c, resolve_global ? "k_lz_resolve3" : "k_lz_resolve2", (double)B.bbytes * 3, sa);
-            if (resolve_global) hipLaunchKernelGGL(k_lz_resolve3, dim3(nb), dim3(64), resolve_lds_pad(), sa, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, P.out.p + room, st.flags.p);
+            if (resolve_global && resolve_staged()) hipLaunchKernelGGL(k_lz_resolve5, dim3(nb), dim3(64), 0, sa, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, P.out.p + room, st.flags.p);
+            else if (resolve_global) hipLaunchKernelGGL(k_lz_resolve3, dim3(nb), dim3(64), resolve_lds_pad(), sa, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, P.out.p + room, st.flags.p);
             else hipLaunchKernelGGL(k_lz_resolve2, dim3(nb), dim3(128), 65536 + 16, sa, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, P.out.p + room, st.flags.p);
         }
         HIPCHK(hipEventRecord(st.ready, sa));

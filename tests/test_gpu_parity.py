@@ -1045,6 +1045,7 @@ def test_gpu_bgzf_inflate_and_boundary_search_give_the_same_records(built, synth
     # the batch to a buffer of its own (the default room is 1 MB: 64 bytes and none at all send nearly every batch that way)
     assert run(f"{pre}.bam", dict(gpu, SQUID_TOK_CAP_MB="0", SQUID_CARRY_ROOM="64", SQUID_IL_DEPTH="4")) == want
     assert run(f"{pre}.bam", dict(gpu, SQUID_TOK_CAP_MB="1", SQUID_CARRY_ROOM="0")) == want
+    assert run(f"{pre}.bam", dict(gpu, SQUID_RESOLVE_STAGED="0")) == want  # k_lz_resolve3 (the default stages a round's bytes in LDS: k_lz_resolve5)
     assert run(f"{pre}.bam", dict(old, SQUID_TOK_CAP_MB="0")) == want
     assert run(f"{pre}.bam", dict(old, SQUID_TOK_WPB="5")) == want
     # the LDS-window resolve (k_lz_resolve2; the default is k_lz_resolve3, which keeps its window in HBM), three buffer sets, and a runtime
@@ -1223,6 +1224,51 @@ def test_gpu_reader_carries_records_larger_than_a_block(built, tmp_path):
             assert run(bam, {"SQUID_GPU_INFLATE": "1", "SQUID_INGEST_TIMING": "1", "SQUID_TOK_CAP_MB": cap}) == want, (bam, cap)
             # (a tail of 100-200 KB in front of a batch: inside the default room of the resolve's buffer above, beyond a room of 4 KB here)
             assert run(bam, {"SQUID_GPU_INFLATE": "1", "SQUID_INGEST_TIMING": "1", "SQUID_TOK_CAP_MB": cap, "SQUID_CARRY_ROOM": "4096"}) == want, (bam, cap)
+
+
+def test_gpu_reader_on_long_matches(built, tmp_path):
+    """thousands of identical records (DEFLATE then writes matches of 258 bytes at the distance of a record), runs of one byte inside the tags (distance 1:
+    a match that overlaps its own output) and stretches of random tags in between: rounds of 64 tokens that write far more than the staging area of the
+    resolve holds (k_lz_resolve5 then takes k_lz_resolve3's way for the round), rounds that fit, and matches whose source lies inside their own round.
+    Same arrays as the host reader, with either resolve"""
+    import hashlib
+    import os
+    import random
+    import sys
+
+    import bamwriter as bw
+
+    rng = random.Random(11)
+    recs = []
+    for i in range(6000):
+        p = 1000 + i // 40
+        kind = (i // 500) % 3
+        if kind == 0:
+            tags = b"NHC\x01" + b"ZZZ" + b"ACGTTGCA" * 30 + b"\0"                      # identical records
+        elif kind == 1:
+            tags = b"NHC\x01" + b"ZZZ" + bytes([65 + i % 3]) * rng.randrange(40, 700) + b"\0"  # runs of one byte
+        else:
+            tags = b"NHC\x01" + b"ZZZ" + bytes(rng.choice(b"ACGTNacgtn0123456789") for _ in range(rng.randrange(10, 300))) + b"\0"
+        recs.append(bw.record("same" if kind == 0 else f"r{i}", 0, p, 255, 0x1 | 0x2 | 0x20 | 0x40, "100M", 0, p + 200, tags=tags))
+    chim = [bw.record("q1", 0, 5000, 255, 0x1 | 0x40, "60M40S"), bw.record("q1", 1, 7000, 255, 0x1 | 0x40 | 0x100, "60H40M"),
+            bw.record("q1", 1, 7300, 255, 0x1 | 0x80 | 0x10, "100M")]
+    pre = _tiny_inputs(tmp_path, recs, chim)
+    code = ("import sys, json, hashlib; sys.path.insert(0, %r); import squid_amd\n"
+            "ctx = squid_amd.Context(); ctx.load(sys.argv[1], %r); r = ctx.records()\n"
+            "print(json.dumps({k: hashlib.sha256(v.tobytes()).hexdigest() for k, v in r.items()}), ctx.counts()['n_concordant'])") % (str(Path(__file__).resolve().parent.parent), f"{pre}.chim.bam")
+
+    def run(env):
+        p = subprocess.run([sys.executable, "-c", code, f"{pre}.bam"], env=dict(os.environ, **env), capture_output=True, text=True)
+        assert p.returncode == 0, (env, p.stderr[-3000:])
+        if env.get("SQUID_GPU_INFLATE") == "1":
+            assert "(rc 0)" in p.stderr, p.stderr[-3000:]
+        return p.stdout.strip().splitlines()[-1]
+
+    want = run({"SQUID_GPU_INFLATE": "0"})
+    assert want.endswith(" 6000")
+    for staged in ("1", "0"):
+        for cap in ("0", "1024"):
+            assert run({"SQUID_GPU_INFLATE": "1", "SQUID_INGEST_TIMING": "1", "SQUID_INFLATE_CHECK": "1", "SQUID_RESOLVE_STAGED": staged, "SQUID_TOK_CAP_MB": cap}) == want, (staged, cap)
 
 
 def test_damaged_files_are_reported_by_both_readers(built, synth, tmp_path):

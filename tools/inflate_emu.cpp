@@ -43,7 +43,7 @@ static bool resolve(const std::vector<uint32_t>& tok, uint32_t nt, std::vector<u
 // SQ_EMU_RSTAT: how many dependent rounds of copies a resolve needs per block when it takes W tokens at a time -- under the rule of
 // k_lz_resolve3 (a match may go when its source ends below the output of the first pending match) and under the exact rule (its source
 // touches no pending match's output)
-struct RStat { unsigned long long dist_le[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mbytes = 0; unsigned long long blocks = 0, tokens = 0, matches = 0, trips_hwm[4] = {0, 0, 0, 0}, trips_exact[4] = {0, 0, 0, 0}, windows[4] = {0, 0, 0, 0}, far[4] = {0, 0, 0, 0}; };
+struct RStat { unsigned long long round_gt[3] = {0, 0, 0}, rounds64 = 0; unsigned long long dist_le[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mbytes = 0; unsigned long long blocks = 0, tokens = 0, matches = 0, trips_hwm[4] = {0, 0, 0, 0}, trips_exact[4] = {0, 0, 0, 0}, windows[4] = {0, 0, 0, 0}, far[4] = {0, 0, 0, 0}; };
 static RStat& rstat() { static RStat r; return r; }
 template <class TOK>
 static void resolve_stats(const TOK& tok, uint32_t nt) {
@@ -59,6 +59,7 @@ static void resolve_stats(const TOK& tok, uint32_t nt) {
         o[i] = at; src[i] = ism[i] ? at - ((tk & 0x7fffu) + 1) : 0; at += len[i];
         if (ism[i]) { ++R.matches; R.mbytes += len[i]; const uint32_t d = (tk & 0x7fffu) + 1; for (int q = 0; q < 8; ++q) if (d <= (128u << q)) ++R.dist_le[q]; }
     }
+    for (uint32_t w0 = 0; w0 < nt; w0 += 64) { const uint32_t w1 = std::min(nt, w0 + 64), tot = o[w1 - 1] + len[w1 - 1] - o[w0]; ++R.rounds64; R.round_gt[0] += tot > 496; R.round_gt[1] += tot > 752; R.round_gt[2] += tot > 1008; }
     const int Ws[4] = {64, 128, 256, 512};
     for (int wi = 0; wi < 4; ++wi) {
         const uint32_t W = (uint32_t)Ws[wi];
@@ -227,6 +228,7 @@ int main(int argc, char** argv) {
     if (std::getenv("SQ_EMU_RSTAT")) {
         const RStat& R = rstat();
         std::printf("resolve: %.0f tokens per block, %.0f of them matches\n", (double)R.tokens / R.blocks, (double)R.matches / R.blocks);
+        std::printf("  rounds of 64 tokens that write more than 496 / 752 / 1008 bytes: %.2f / %.2f / %.2f %%\n", 100.0 * R.round_gt[0] / R.rounds64, 100.0 * R.round_gt[1] / R.rounds64, 100.0 * R.round_gt[2] / R.rounds64);
         std::printf("  match distances: " ); for (int q = 0; q < 8; ++q) std::printf("<= %u: %.1f %%  ", 128u << q, 100.0 * R.dist_le[q] / std::max<unsigned long long>(1, R.matches)); std::printf("| %.1f bytes per match\n", (double)R.mbytes / std::max<unsigned long long>(1, R.matches));
         const int Ws[4] = {64, 128, 256, 512};
         for (int wi = 0; wi < 4; ++wi) std::printf("  %3d tokens at a time: %.0f windows per block, rounds of copies per block %.0f (rule of k_lz_resolve3) / %.0f (exact), %.1f / %.1f per window; matches whose source lies in front of the window %.0f %%\n", Ws[wi],
