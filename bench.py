@@ -62,7 +62,7 @@ BUILD = ROOT / "build"
 
 GPU_KERNELS_PREFIX = ("k_", "scan_")
 # timers of the BGZF reader, named like the kernels they bracket (profiles/*_kernel_stats.csv carries the same names)
-INGEST_KERNELS = ("k_inflate_spec", "k_inflate_tok2", "k_lz_resolve3", "k_lz_resolve2", "k_rec_sync+walk+check", "k_parse_records", "k_parse_place", "k_parse_count", "k_parse_write", "k_inflate", "k_pack_records")
+INGEST_KERNELS = ("k_inflate_spec", "k_inflate_tok2", "k_lz_resolve5", "k_lz_resolve3", "k_lz_resolve2", "k_rec_sync+walk+check", "k_parse_records", "k_parse_place", "k_parse_count", "k_parse_write", "k_inflate", "k_pack_records")
 SMALL_GRAPH_KERNELS = ("k_filter_weight", "k_filter_interleave", "k_filter_edges", "k_compress_nodes", "k_further_compress", "k_order_small", "k_order_mid", "k_cc", "k_hash_compact",
                        "k_node_buckets", "k_bp_walk")
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling

@@ -4062,7 +4062,7 @@ int dev_ingest_bgzf(sq_ctx* c, const uint8_t* file, std::vector<BgzfRange>& bloc
         HIPCHK(P.out.reserve((size_t)room + (size_t)full + ((size_t)1 << 20) + 64));
         if (k >= (size_t)D.il_depth) HIPCHK(hipStreamWaitEvent(sa, P.carried, 0));
         {
-            EvTimer t2(c, resolve_global ? "k_lz_resolve3" : "k_lz_resolve2", (double)B.bbytes * 3, sa);
+            EvTimer t2(c, resolve_global ? (resolve_staged() ? "k_lz_resolve5" : "k_lz_resolve3") : "k_lz_resolve2", (double)B.bbytes * 3, sa);
             if (resolve_global && resolve_staged()) hipLaunchKernelGGL(k_lz_resolve5, dim3(nb), dim3(64), 0, sa, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, P.out.p + room, st.flags.p);
             else if (resolve_global) hipLaunchKernelGGL(k_lz_resolve3, dim3(nb), dim3(64), resolve_lds_pad(), sa, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, P.out.p + room, st.flags.p);
             else hipLaunchKernelGGL(k_lz_resolve2, dim3(nb), dim3(128), 65536 + 16, sa, st.tok.p, st.ntok.p, st.tab.p, nb, B.bbase, P.out.p + room, st.flags.p);
