@@ -397,7 +397,7 @@ __global__ void k_node_pack(int n, const int32_t* chr, const int32_t* pos, const
 __global__ void k_pack_records(int64_t from, int64_t to, RecView R, int4* pack) {
     const int64_t r = from + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= to) return;
-    const uint32_t bo = R.blk_off[r], nblk = R.blk_off[r + 1] - bo;  // (at most 256 own blocks: k_parse_write refuses more)
+    const uint32_t bo = R.blk_off[r], nblk = R.blk_off[r + 1] - bo;  // (at most 256 own blocks: k_parse_records refuses more)
     pack[2 * r] = make_int4(R.refid[r], R.pos[r], R.mrefid[r], R.mpos[r]);
     pack[2 * r + 1] = make_int4((int)((uint32_t)R.flag[r] | ((uint32_t)R.totlen[r] << 16)), (int)((uint32_t)R.mapq[r] | ((uint32_t)R.aux[r] << 8) | (nblk << 16)), (int)bo, R.endpos[r]);
 }
