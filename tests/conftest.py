@@ -11,7 +11,7 @@ BUILD = ROOT / "build"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # The GPU suite reads every BAM file through the DEVICE reader (BGZF inflate by k_inflate_spec + k_lz_resolve3, record boundaries by
+    # The GPU suite reads every BAM file through the DEVICE reader (BGZF inflate by k_inflate_spec + k_lz_resolve5, record boundaries by
     # k_rec_*): in production only files of 1 GiB and more take that route, and until round 6 only the nine tests that forced it ever ran
     # the kernels the headline number depends on.  Tests that compare the two readers (or want the host one) set the variable themselves.
     import os

@@ -1564,23 +1564,25 @@ def test_without_the_inspection_copies_of_the_intermediate_graphs(built, synth, 
 @pytest.mark.gpu
 def test_the_suite_s_default_route_is_the_device_reader(built, synth, monkeypatch):
     """tests/conftest.py sends every BAM of the GPU suite through the device reader (SQUID_GPU_INFLATE=1 unless a test says otherwise):
-    the stage-parity tests above therefore ran the token pass (k_inflate_spec; k_inflate_tok2 with SQUID_TOK_SPEC=0), the resolve and the
-    boundary kernels -- checked here on the timers of a plain load, for both token passes, whose records must be the same"""
+    the stage-parity tests above therefore ran the token pass (k_inflate_spec; k_inflate_tok2 with SQUID_TOK_SPEC=0), the resolve (k_lz_resolve5;
+    k_lz_resolve3 with SQUID_RESOLVE_STAGED=0), the boundary kernels and the record parse -- checked here on the timers of a plain load, for both token passes, whose records must be the same"""
     import os
     assert os.environ.get("SQUID_GPU_INFLATE") == "1"
     pre = synth("T2")
     seen = {}
-    for spec in ("1", "0"):
+    for spec, staged in (("1", "1"), ("0", "1"), ("1", "0")):  # (either token pass; the resolve that stages a round's bytes in LDS -- the default -- and the one that does not)
         monkeypatch.setenv("SQUID_TOK_SPEC", spec)
+        monkeypatch.setenv("SQUID_RESOLVE_STAGED", staged)
         with squid_amd.Context() as ctx:
             ctx.load(f"{pre}.bam", f"{pre}.chim.bam", threads=4)
             names = set(ctx.timing())
             assert ("k_inflate_spec" if spec == "1" else "k_inflate_tok2") in names, names
-            assert "k_lz_resolve3" in names and "k_rec_sync+walk+check" in names, names
+            assert ("k_lz_resolve5" if staged == "1" else "k_lz_resolve3") in names and "k_rec_sync+walk+check" in names, names
+            assert "k_parse_records" in names and "k_parse_place" in names, names
             ctx.build_graph()
             ctx.order()
-            seen[spec] = (ctx.counts()["n_concordant"], ctx.counts()["n_blocks"], ctx.sv_text())
-    assert seen["1"] == seen["0"]
+            seen[spec, staged] = (ctx.counts()["n_concordant"], ctx.counts()["n_blocks"], ctx.sv_text())
+    assert seen["1", "1"] == seen["0", "1"] == seen["1", "0"]
 
 
 @pytest.mark.gpu
