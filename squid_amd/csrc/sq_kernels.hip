@@ -2726,7 +2726,7 @@ constexpr int REC_SLICE = 8192;
 // tokens put it: three byte stores per literal token, two or three short stores per match -- 164 M write requests per GiB of output, 6.5 bytes each --, and reads
 // the sources of its matches from memory even when the same round wrote them.  tools/l2_probe.cpp: a wave that writes 192 bytes per round and reads 8 bytes per lane
 // from a few hundred bytes behind takes 1.4-2.6 us per round with byte stores and 0.7-1.2 us with 4- or 16-byte stores; the reads leave the L2 either way.
-// Here a round's literals and the copies of its matches go to a per-wave staging area of RS_STAGE bytes (768: sixteen resolve waves beside sixteen token
+// Here a round's literals and the copies of its matches go to a per-wave staging area of RS_STAGE bytes (496, 512 with its slack: sixteen resolve waves beside sixteen token
 // waves still fit a CU's 160 KB), matches whose source lies inside the round are copied there from the staging area itself, and the round leaves with one
 // 4-byte store per lane.  A round of more than RS_STAGE bytes (long matches) takes k_lz_resolve3's way.
 #ifndef SQ_RS_STAGE
