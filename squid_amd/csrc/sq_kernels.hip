@@ -2812,8 +2812,35 @@ __global__ __launch_bounds__(64) void k_lz_resolve5(const uint32_t* tok, const i
                 const uint32_t hwm = (uint32_t)__builtin_amdgcn_readlane((int)o, __builtin_amdgcn_readfirstlane(first));
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 if (pending && ready_at <= hwm) {
-                    uint32_t j = 0;
-                    for (uint32_t k = 0; k < len; ++k) { out[o + k] = out[src + j]; if (++j == dist) j = 0; }
+                    if (dist >= 8) {
+                        if (len <= 8) {
+                            unsigned long long w;
+                            __builtin_memcpy(&w, out + src, 8);
+                            if (len >= 4) {
+                                const uint32_t lo4 = (uint32_t)w, hi4 = (uint32_t)(w >> (8 * (len - 4)));
+                                __builtin_memcpy(out + o, &lo4, 4); __builtin_memcpy(out + o + len - 4, &hi4, 4);
+                            } else {
+                                const uint16_t lo2 = (uint16_t)w; const uint8_t b2 = (uint8_t)(w >> 16);
+                                __builtin_memcpy(out + o, &lo2, 2); out[o + 2] = b2;
+                            }
+                        } else {
+                            uint32_t k = 0;
+                            for (; k + 8 <= len; k += 8) { unsigned long long w; __builtin_memcpy(&w, out + src + k, 8); __builtin_memcpy(out + o + k, &w, 8); }
+                            if (k < len) { unsigned long long w; __builtin_memcpy(&w, out + src + len - 8, 8); __builtin_memcpy(out + o + len - 8, &w, 8); }
+                        }
+                    } else {
+                        // every byte comes from [src, src + min(dist, len)): final
+                        uint32_t j = 0;
+                        for (uint32_t k = 0; k < len; k += 8) {
+                            uint8_t v[8];
+                            uint32_t jj = j;
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) { v[q] = out[src + jj]; if (++jj == dist) jj = 0; }
+                            j = jj;
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) if (k + q < len) out[o + k + q] = v[q];
+                        }
+                    }
                     pending = false;
                 }
                 pm = __ballot(pending);
