@@ -2584,7 +2584,7 @@ __global__ __launch_bounds__(64) void k_inflate_spec_prof(const uint8_t* file, c
 }
 // (the variants the tuning entry sq_debug_token_bench can time; the reader runs SPEC_CH / SPEC_PB)
 #ifndef SQ_SPEC_CH
-#define SQ_SPEC_CH 256
+#define SQ_SPEC_CH 384  // (round 6, last: 384-bit stretches -- 12.6 windows per block instead of 19.2 at 10.1 instead of 9.1 KB per wave: 4.5 against 5.1 ms per GiB alone)
 #endif
 #ifndef SQ_SPEC_PB
 #define SQ_SPEC_PB 10
@@ -3815,6 +3815,9 @@ int dev_token_bench(sq_ctx* c, const char* path, int variant, int max_blocks, in
             case 25610: launch_inflate_spec<256, 10>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
             case 25611: launch_inflate_spec<256, 11>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
             case 38411: launch_inflate_spec<384, 11>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
+            case 38410: launch_inflate_spec<384, 10>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
+            case 32010: launch_inflate_spec<320, 10>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
+            case 19210: launch_inflate_spec<192, 10>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
             case 102411: launch_inflate_spec<1024, 11>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
             case 25609: launch_inflate_spec<256, 9>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
             case 12809: launch_inflate_spec<128, 9>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;

@@ -1604,7 +1604,7 @@ def test_every_token_pass_variant_alone_against_zlib(built, synth, tmp_path):
     lib.sq_debug_token_bench.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
     with squid_amd.Context() as ctx:
         for name, path in files.items():
-            for variant in (25610, 25609, 25611, 51210, 51211, 51209, 38411, 12810, 12809, 102411, 2):
+            for variant in (38410, 25610, 25609, 25611, 51210, 51211, 51209, 38411, 32010, 19210, 12810, 12809, 102411, 2):
                 out = (C.c_double * 7)()
                 rc = lib.sq_debug_token_bench(ctx.h, path.encode(), variant, 4096, 1, 1, out)
                 assert rc == 0, (name, variant, rc)

@@ -18,7 +18,7 @@ def emu(built, tmp_path_factory):
 
 def test_emulated_token_pass_inflates_bam_blocks_like_zlib(emu, synth):
     pre = synth("T2")
-    for cfg in ("0", "1", "2", "3", "4", "5"):
+    for cfg in ("0", "1", "2", "3", "4", "5", "6"):  # (3 = <384, 10>, what the reader runs; 6 = <1024, 11>)
         out = subprocess.run([str(emu), f"{pre}.bam", "12", cfg], capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and " 0 flagged, 0 WRONG" in out.stdout, (cfg, out.stdout, out.stderr[-2000:])
 

@@ -101,6 +101,7 @@ static int run_block(const uint8_t* payload, uint32_t clen, const std::vector<ui
         case 0: wv::run_wave(lane_main<512, 11>, &j); break;
         case 1: wv::run_wave(lane_main<256, 10>, &j); break;
         case 2: wv::run_wave(lane_main<128, 10>, &j); break;
+        case 3: wv::run_wave(lane_main<384, 10>, &j); break;
         case 4: wv::run_wave(lane_main<256, 9>, &j); break;
         case 5: wv::run_wave(lane_main<128, 9>, &j); break;
         default: wv::run_wave(lane_main<1024, 11>, &j); break;
@@ -178,7 +179,7 @@ int main(int argc, char** argv) {
             uint8_t* base = buf.data() + ((16 - ((uintptr_t)buf.data() & 15)) & 15);
             for (size_t i = 0; i < buf.size() - (size_t)(base - buf.data()); ++i) base[i] = (uint8_t)rng();  // (noise around the payload)
             std::memcpy(base + off, comp.data(), comp.size());
-            const int cfg = (int)(rng() % 6);
+            const int cfg = (int)(rng() % 7);
             const int rc = run_block(base + off, (uint32_t)comp.size(), data, cfg);
             if (rc == 0) ++n_ok; else if (rc == 1) { ++n_flag; std::fprintf(stderr, "case %ld: error flag on a valid stream (n %zu level %d strategy %d cfg %d)\n", c, n, level, strat, cfg); } else { ++n_wrong; std::fprintf(stderr, "case %ld WRONG (n %zu level %d strategy %d mem %d cfg %d off %u)\n", c, n, level, strat, mem, cfg, off); }
         }
