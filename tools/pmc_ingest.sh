@@ -19,7 +19,7 @@ acc = defaultdict(lambda: defaultdict(float)); n = defaultdict(set)
 for r in csv.DictReader(open(sys.argv[1])):
     k = (r.get("Kernel_Name") or "").split("(")[0].replace("void ", "").replace("sq::", "")
     acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k].add(r.get("Dispatch_Id"))
-for k in ("k_inflate_spec<256, 10>", "k_inflate_tok2<false>", "k_lz_resolve5", "k_lz_resolve3", "k_parse_records", "k_parse_place", "k_rec_sync"):
+for k in ("k_inflate_spec<384, 10>", "k_inflate_spec<256, 10>", "k_inflate_tok2<false>", "k_lz_resolve5", "k_lz_resolve3", "k_parse_records", "k_parse_place", "k_rec_sync"):
     if k in acc:
         c = acc[k]; w = c.get("SQ_WAVES", 0) or 1
         print(f"{k:24s} launches {len(n[k]):3d} waves {w:9.0f} | " + " ".join(f"{name[3:]}/wave {v / w:.4g}" for name, v in sorted(c.items()) if name != "SQ_WAVES"))
