@@ -3816,6 +3816,10 @@ int dev_token_bench(sq_ctx* c, const char* path, int variant, int max_blocks, in
             case 25611: launch_inflate_spec<256, 11>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
             case 38411: launch_inflate_spec<384, 11>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
             case 38410: launch_inflate_spec<384, 10>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
+            case 35210: launch_inflate_spec<352, 10>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
+            case 41610: launch_inflate_spec<416, 10>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
+            case 44810: launch_inflate_spec<448, 10>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
+            case 38409: launch_inflate_spec<384, 9>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
             case 32010: launch_inflate_spec<320, 10>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
             case 19210: launch_inflate_spec<192, 10>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
             case 102411: launch_inflate_spec<1024, 11>(s, d_in.p, d_tab.p, nb, d_flags.p, d_tok.p, d_ntok.p); break;
