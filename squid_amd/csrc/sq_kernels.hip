@@ -739,12 +739,13 @@ constexpr int PARSE_THREADS = SQ_PARSE_THREADS, PARSE_LDS = SQ_PARSE_LDS;  // 4 
 // Copies the workgroup's records into `lds` when they fit; returns whether they did (uniform).  For its record every lane gets the
 // offset into the staged range / the chunk and `avail`, the bytes the record may occupy: up to the next record's offset, the end of the
 // chunk and (when staged) the end of the staged range; -1 when the offsets handed in by the caller are not ascending or lie outside the chunk.
+template <int LDS_BYTES>
 __device__ __forceinline__ bool stage_records(const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n, uint8_t* lds, unsigned long long& at, long long& avail) {
     const int64_t r0 = (int64_t)blockIdx.x * blockDim.x, r1 = r0 + blockDim.x < n ? r0 + blockDim.x : n;
     const unsigned long long first = rec_off[r0], lo = first & ~15ull;
     unsigned long long hi = r1 < n ? rec_off[r1] : (unsigned long long)nbytes;
     if (hi > (unsigned long long)nbytes) hi = (unsigned long long)nbytes;
-    bool fits = first <= hi && hi - lo <= (unsigned long long)PARSE_LDS;  // uniform over the workgroup
+    bool fits = first <= hi && hi - lo <= (unsigned long long)LDS_BYTES;  // uniform over the workgroup
     const int64_t r = r0 + threadIdx.x;
     avail = -1; at = 0;
     bool mine = true;  // my record lies inside the staged range
@@ -760,14 +761,17 @@ __device__ __forceinline__ bool stage_records(const uint8_t* bam, size_t nbytes,
         const int words = (int)((hi - lo + 15) >> 4);
         // (every load is in flight before the first store: written as a loop the copy waits for memory once per 16 bytes and lane,
         // eighteen round trips to HBM one after the other -- four fifths of the kernel's time in round 6's first form)
-        constexpr int PER = (PARSE_LDS / 16 + PARSE_THREADS - 1) / PARSE_THREADS + 1;
-        uint4 v[PER];
+        // (up to 23 loads per lane and pass: the 18 and 22 KB staging sizes in one pass, the larger ones -- longer reads -- in two or three)
+        constexpr int PER_ALL = (LDS_BYTES / 16 + PARSE_THREADS - 1) / PARSE_THREADS + 1, PER = PER_ALL < 23 ? PER_ALL : 23;
+        for (int w0 = 0; w0 < words; w0 += PER * PARSE_THREADS) {
+            uint4 v[PER];
 #pragma unroll
-        for (int k = 0; k < PER; ++k) { const int i = (int)threadIdx.x + k * PARSE_THREADS; v[k] = src[i < words ? i : words - 1]; }  // (no branch around a load: the array stays in registers)
+            for (int k = 0; k < PER; ++k) { const int i = w0 + (int)threadIdx.x + k * PARSE_THREADS; v[k] = src[i < words ? i : words - 1]; }  // (no branch around a load: the array stays in registers)
 #pragma unroll
-        for (int k = 0; k < PER; ++k) asm volatile("" : "+v"(v[k].x), "+v"(v[k].y), "+v"(v[k].z), "+v"(v[k].w));  // (and the loads stay in front of the stores)
+            for (int k = 0; k < PER; ++k) asm volatile("" : "+v"(v[k].x), "+v"(v[k].y), "+v"(v[k].z), "+v"(v[k].w));  // (and the loads stay in front of the stores)
 #pragma unroll
-        for (int k = 0; k < PER; ++k) { const int i = (int)threadIdx.x + k * PARSE_THREADS; if (i < words) dst[i] = v[k]; }
+            for (int k = 0; k < PER; ++k) { const int i = w0 + (int)threadIdx.x + k * PARSE_THREADS; if (i < words) dst[i] = v[k]; }
+        }
     }
     __syncthreads();
     if (r >= n) return fits;
@@ -915,12 +919,15 @@ __device__ __forceinline__ void parse_record(PTR rec, long long avail, int64_t r
     O.refid[r] = refid; O.pos[r] = pos; O.mrefid[r] = mrefid; O.mpos[r] = mpos; O.endpos[r] = endpos;
     O.flag[r] = (uint16_t)flag; O.totlen[r] = (uint16_t)totlen; O.mapq[r] = (uint8_t)mapq; O.aux[r] = ax;
 }
+// LDS_BYTES: the staging size -- 18 KB holds 64 records of up to 288 bytes (reads of 100-150 bases), the larger sizes the records of longer reads (the host picks by
+// the batch's mean record length; tools/parse_probe.py: records of 437 bytes took 4.6 times as long as records of 212 through the in-place path)
+template <int LDS_BYTES>
 __global__ __launch_bounds__(PARSE_THREADS) void k_parse_records(const uint8_t* bam, size_t nbytes, const unsigned long long* rec_off, int64_t n, ChimSetView C, ParseParams P, ParseOut O, int32_t* flags) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[PARSE_LDS + 32];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES + 32];
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long at;
     long long avail;
-    const bool staged = stage_records(bam, nbytes, rec_off, n, lds, at, avail);
+    const bool staged = stage_records<LDS_BYTES>(bam, nbytes, rec_off, n, lds, at, avail);
     if (r >= n) return;
     if (staged) parse_record((const lds_u8*)lds + at, avail, r, C, P, O, flags);
     else parse_record(bam + at, avail, r, C, P, O, flags);
@@ -3721,7 +3728,15 @@ static int parse_device(sq_ctx* c, const uint8_t* d_bam, size_t nbytes, const un
     // go to their places behind the scan of the counts (k_parse_place)
     { EvTimer t(c, "k_parse_records", (double)nbytes + 64.0 * n_rec, s);
       const ParseOut O{D.refid.p + n0, D.pos.p + n0, D.mrefid.p + n0, D.mpos.p + n0, D.endpos.p + n0, D.flag.p + n0, D.totlen.p + n0, D.mapq.p + n0, D.aux.p + n0, D.chim_slot_of.p + n0, D.parse_nblk.p, D.parse_first2.p};
-      hipLaunchKernelGGL(k_parse_records, grid_for(n_rec, PARSE_THREADS), dim3(PARSE_THREADS), 0, s, d_bam, nbytes, d_off, n_rec, C, P, O, fl);
+      // (staging size by the mean record length of the chunk -- the bytes in front of its first record count in, which only errs towards the larger size)
+      const double need = 64.0 * 1.08 * (double)nbytes / (double)n_rec + 64.0;
+      static const int force = std::getenv("SQUID_PARSE_LDS_KB") ? std::atoi(std::getenv("SQUID_PARSE_LDS_KB")) : 0;  // (tests: 18 / 22 / 28 / 40 / 63)
+      const int kb = force ? force : need <= PARSE_LDS ? 18 : need <= 22528 ? 22 : need <= 28672 ? 28 : need <= 40960 ? 40 : 63;
+      if (kb <= 18) hipLaunchKernelGGL(k_parse_records<PARSE_LDS>, grid_for(n_rec, PARSE_THREADS), dim3(PARSE_THREADS), 0, s, d_bam, nbytes, d_off, n_rec, C, P, O, fl);
+      else if (kb <= 22) hipLaunchKernelGGL(k_parse_records<22528>, grid_for(n_rec, PARSE_THREADS), dim3(PARSE_THREADS), 0, s, d_bam, nbytes, d_off, n_rec, C, P, O, fl);
+      else if (kb <= 28) hipLaunchKernelGGL(k_parse_records<28672>, grid_for(n_rec, PARSE_THREADS), dim3(PARSE_THREADS), 0, s, d_bam, nbytes, d_off, n_rec, C, P, O, fl);
+      else if (kb <= 40) hipLaunchKernelGGL(k_parse_records<40960>, grid_for(n_rec, PARSE_THREADS), dim3(PARSE_THREADS), 0, s, d_bam, nbytes, d_off, n_rec, C, P, O, fl);
+      else hipLaunchKernelGGL(k_parse_records<65536 - 64>, grid_for(n_rec, PARSE_THREADS), dim3(PARSE_THREADS), 0, s, d_bam, nbytes, d_off, n_rec, C, P, O, fl);
       HIPCHK((device_scan<OpSum, true>(s, n_rec, FArrN{D.parse_nblk.p}, D.parse_rel.p, spine, tot))); }
     int32_t nblk_total = 0;
     HIPCHK(hipMemcpyAsync(&nblk_total, tot, 4, hipMemcpyDeviceToHost, s));

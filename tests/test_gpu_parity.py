@@ -1046,6 +1046,9 @@ def test_gpu_bgzf_inflate_and_boundary_search_give_the_same_records(built, synth
     assert run(f"{pre}.bam", dict(gpu, SQUID_TOK_CAP_MB="0", SQUID_CARRY_ROOM="64", SQUID_IL_DEPTH="4")) == want
     assert run(f"{pre}.bam", dict(gpu, SQUID_TOK_CAP_MB="1", SQUID_CARRY_ROOM="0")) == want
     assert run(f"{pre}.bam", dict(gpu, SQUID_RESOLVE_STAGED="0")) == want  # k_lz_resolve3 (the default stages a round's bytes in LDS: k_lz_resolve5)
+    # the record parse stages the 64 records of a workgroup in 18 / 22 / 28 / 40 / 63 KB of LDS, picked by the chunk's mean record length
+    for kb in ("18", "22", "28", "40", "63"):
+        assert run(f"{pre}.bam", dict(gpu, SQUID_PARSE_LDS_KB=kb)) == want, kb
     assert run(f"{pre}.bam", dict(old, SQUID_TOK_CAP_MB="0")) == want
     assert run(f"{pre}.bam", dict(old, SQUID_TOK_WPB="5")) == want
     # the LDS-window resolve (k_lz_resolve2; the default is k_lz_resolve3, which keeps its window in HBM), three buffer sets, and a runtime
