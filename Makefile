@@ -19,7 +19,7 @@ all: $(B)/libsquid_hip.so $(B)/squid $(B)/squid_junction $(B)/squid_annotate $(B
 ref:
 	$(MAKE) -C oracle ref
 
-$(B)/libsquid_hip.so: $(LIBSRC) $(CSRC)/sq_internal.h $(CSRC)/sq_parsort.h $(CSRC)/sq_graph_kernels.inc $(CSRC)/sq_pass_kernels.inc $(CSRC)/sq_inflate_spec.inc $(CSRC)/sq_wave.h include/squid_hip.h
+$(B)/libsquid_hip.so: $(LIBSRC) $(CSRC)/sq_internal.h $(CSRC)/sq_parsort.h $(CSRC)/sq_graph_kernels.inc $(CSRC)/sq_pass_kernels.inc $(CSRC)/sq_inflate_spec.inc $(CSRC)/sq_resolve.inc $(CSRC)/sq_wave.h include/squid_hip.h
 	mkdir -p $(B)
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wall -Wno-unused-function -o $@ $(LIBSRC) -lz -lpthread -ldl
 

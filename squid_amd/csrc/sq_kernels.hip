@@ -33,6 +33,7 @@
 
 #include "sq_internal.h"
 #include "sq_inflate_spec.inc"
+#include "sq_resolve.inc"
 
 #define HIPCHK(call)                                                                                         \
     do {                                                                                                     \
@@ -2742,120 +2743,9 @@ constexpr int REC_SLICE = 8192;
 constexpr int RS_STAGE = SQ_RS_STAGE;  // (+ 16 bytes of slack = one 512-byte LDS allocation at 496)
 __global__ __launch_bounds__(64) void k_lz_resolve5(const uint32_t* tok, const int32_t* ntok, const InflBlock* blocks, int nblocks, unsigned long long out_base, uint8_t* outbuf, int32_t* flags) {
     __shared__ __attribute__((aligned(16))) uint8_t st_mem[RS_STAGE + 16];
-    lds_u8* const st = (lds_u8*)st_mem;
-    typedef __attribute__((address_space(3))) u32_any lds_u32_any;
-    typedef __attribute__((address_space(3))) u64_any lds_u64_any;
-    const int lane = threadIdx.x;
     const InflBlock blk = blocks[blockIdx.x];
-    const uint32_t* t = tok + blk.toff;
-    const int n = ntok[blockIdx.x];
-    uint8_t* out = outbuf + (blk.uoff - out_base);
-    uint32_t base = 0;
-    bool bad = false;
-    uint32_t nxt = lane < n ? t[lane] : 0;
-    for (int r0 = 0; r0 < n; r0 += 64) {
-        const uint32_t tk = nxt;
-        const int i = r0 + lane;
-        if (i + 64 < n) nxt = t[i + 64];
-        const bool valid = i < n, is_m = valid && (tk >> 31);
-        const uint32_t nl = (tk >> 24) & 3u;
-        const uint32_t len = !valid ? 0u : (is_m ? (tk >> 16) & 0x1ffu : (nl ? nl : 1u));
-        const uint32_t inc = wave_scan_incl(len);
-        const uint32_t o = base + inc - len;
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-        if (base + total > blk.isize) { bad = true; break; }  // (uniform)
-        const uint32_t dist = (tk & 0x7fffu) + 1;
-        if (__any(is_m && dist > o)) { bad = true; break; }
-        const uint32_t src = o - dist;
-        if (total <= (uint32_t)RS_STAGE) {
-            const uint32_t lo = o - base;  // where the token's bytes go in the staging area
-            if (valid && !is_m) { st[lo] = (uint8_t)tk; if (len > 1) st[lo + 1] = (uint8_t)(tk >> 8); if (len > 2) st[lo + 2] = (uint8_t)(tk >> 16); }
-            // a match whose source ends in front of the round: those bytes are final and in memory (earlier rounds of this wave stored them)
-            const bool far = is_m && src + len <= base;
-            if (far) {
-                if (len <= 8) {
-                    unsigned long long w;
-                    __builtin_memcpy(&w, out + src, 8);  // (bytes behind the match are read, not used)
-                    if (len >= 4) { *(lds_u32_any*)(st + lo) = (uint32_t)w; *(lds_u32_any*)(st + lo + len - 4) = (uint32_t)(w >> (8 * (len - 4))); }
-                    else { st[lo] = (uint8_t)w; st[lo + 1] = (uint8_t)(w >> 8); st[lo + 2] = (uint8_t)(w >> 16); }  // (len == 3: the shortest match)
-                } else {
-                    uint32_t k = 0;
-                    for (; k + 8 <= len; k += 8) { unsigned long long w; __builtin_memcpy(&w, out + src + k, 8); *(lds_u64_any*)(st + lo + k) = w; }
-                    if (k < len) { unsigned long long w; __builtin_memcpy(&w, out + src + len - 8, 8); *(lds_u64_any*)(st + lo + len - 8) = w; }
-                }
-            }
-            // the others take their bytes from the staging area (and from memory below the round's first byte), first pending match first: everything
-            // below its output is final
-            bool pending = is_m && !far;
-            const uint32_t ready_at = src + len < o ? src + len : o;
-            unsigned long long pm = __ballot(pending);
-            while (pm) {
-                const int first = __ffsll((long long)pm) - 1;
-                const uint32_t hwm = (uint32_t)__builtin_amdgcn_readlane((int)o, __builtin_amdgcn_readfirstlane(first));
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-                if (pending && ready_at <= hwm) {
-                    for (uint32_t k = 0; k < len; ++k) {  // (byte by byte: a match may overlap its own output)
-                        const uint32_t p = src + k;
-                        st[lo + k] = p < base ? out[p] : st[p - base];
-                    }
-                    pending = false;
-                }
-                pm = __ballot(pending);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-            // the round leaves: four bytes per lane and store
-            for (uint32_t q = 4u * (uint32_t)lane; q < total; q += 256u) {
-                if (q + 4 <= total) { const uint32_t w = *(const __attribute__((address_space(3))) uint32_t*)(st + q); __builtin_memcpy(out + base + q, &w, 4); }
-                else for (uint32_t k = q; k < total; ++k) out[base + k] = st[k];
-            }
-        } else {
-            // (k_lz_resolve3's round)
-            if (valid && !is_m) { out[o] = (uint8_t)tk; if (len > 1) out[o + 1] = (uint8_t)(tk >> 8); if (len > 2) out[o + 2] = (uint8_t)(tk >> 16); }
-            bool pending = is_m;
-            const uint32_t ready_at = src + len < o ? src + len : o;
-            unsigned long long pm = __ballot(pending);
-            while (pm) {
-                const int first = __ffsll((long long)pm) - 1;
-                const uint32_t hwm = (uint32_t)__builtin_amdgcn_readlane((int)o, __builtin_amdgcn_readfirstlane(first));
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                if (pending && ready_at <= hwm) {
-                    if (dist >= 8) {
-                        if (len <= 8) {
-                            unsigned long long w;
-                            __builtin_memcpy(&w, out + src, 8);
-                            if (len >= 4) {
-                                const uint32_t lo4 = (uint32_t)w, hi4 = (uint32_t)(w >> (8 * (len - 4)));
-                                __builtin_memcpy(out + o, &lo4, 4); __builtin_memcpy(out + o + len - 4, &hi4, 4);
-                            } else {
-                                const uint16_t lo2 = (uint16_t)w; const uint8_t b2 = (uint8_t)(w >> 16);
-                                __builtin_memcpy(out + o, &lo2, 2); out[o + 2] = b2;
-                            }
-                        } else {
-                            uint32_t k = 0;
-                            for (; k + 8 <= len; k += 8) { unsigned long long w; __builtin_memcpy(&w, out + src + k, 8); __builtin_memcpy(out + o + k, &w, 8); }
-                            if (k < len) { unsigned long long w; __builtin_memcpy(&w, out + src + len - 8, 8); __builtin_memcpy(out + o + len - 8, &w, 8); }
-                        }
-                    } else {
-                        // every byte comes from [src, src + min(dist, len)): final
-                        uint32_t j = 0;
-                        for (uint32_t k = 0; k < len; k += 8) {
-                            uint8_t v[8];
-                            uint32_t jj = j;
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) { v[q] = out[src + jj]; if (++jj == dist) jj = 0; }
-                            j = jj;
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) if (k + q < len) out[o + k + q] = v[q];
-                        }
-                    }
-                    pending = false;
-                }
-                pm = __ballot(pending);
-            }
-        }
-        base += total;
-    }
-    if (bad || base != blk.isize) { if (lane == 0) atomicOr(&flags[0], 512); }
+    const bool ok = rsv::resolve_block<RS_STAGE>(tok + blk.toff, ntok[blockIdx.x], outbuf + (blk.uoff - out_base), blk.isize, (wv::lds_u8*)st_mem);  // (sq_resolve.inc)
+    if (!ok && threadIdx.x == 0) atomicOr(&flags[0], 512);
 }
 // (experiment: SQUID_RESOLVE_LDS=<bytes> of unused dynamic LDS per resolve wave = a cap on the waves a CU holds -- 160 KB / bytes)
 static bool resolve_staged() { return std::getenv("SQUID_RESOLVE_STAGED") == nullptr || std::atoi(std::getenv("SQUID_RESOLVE_STAGED")) != 0; }  // (the default; 0: k_lz_resolve3.  Read per call: tests switch it)

@@ -74,6 +74,10 @@ WV_FN uint32_t lds_atomic_max(lds_u32* p, uint32_t v) { const uint32_t o = *p; i
 WV_FN uint32_t lds_atomic_add(lds_u32* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
 struct u32x4 { uint32_t x, y, z, w; };
 WV_FN u32x4 load16(const uint32_t* p) { return u32x4{p[0], p[1], p[2], p[3]}; }
+// (LDS accesses of any alignment)
+WV_FN void lds_st32(lds_u8* p, uint32_t v) { std::memcpy(p, &v, 4); }
+WV_FN void lds_st64(lds_u8* p, unsigned long long v) { std::memcpy(p, &v, 8); }
+WV_FN uint32_t lds_ld32(const lds_u8* p) { uint32_t v; std::memcpy(&v, p, 4); return v; }
 // run fn(arg) as a wave of 64 lanes; returns when every lane has returned
 inline void run_wave(void (*fn)(void*), void* arg, size_t stack_bytes = 256 << 10) {
     Emu e;
@@ -141,5 +145,9 @@ WV_FN uint32_t lds_atomic_max(lds_u32* p, uint32_t v) { return __hip_atomic_fetc
 WV_FN uint32_t lds_atomic_add(lds_u32* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 typedef uint4 u32x4;
 WV_FN u32x4 load16(const uint32_t* p) { return *(const uint4*)p; }
+// (LDS accesses of any alignment: gfx950 takes them)
+WV_FN void lds_st32(lds_u8* p, uint32_t v) { typedef uint32_t __attribute__((aligned(1))) u; *(__attribute__((address_space(3))) u*)p = v; }
+WV_FN void lds_st64(lds_u8* p, unsigned long long v) { typedef unsigned long long __attribute__((aligned(1))) u; *(__attribute__((address_space(3))) u*)p = v; }
+WV_FN uint32_t lds_ld32(const lds_u8* p) { typedef uint32_t __attribute__((aligned(1))) u; return *(const __attribute__((address_space(3))) u*)p; }
 }  // namespace wv
 #endif

@@ -2,7 +2,9 @@
 its 64 lanes as coroutines (sq_wave.h with SQ_WAVE_EMU, tools/inflate_emu.cpp), compared with zlib -- on the BGZF blocks of a synthetic
 BAM for every stretch length / table size the tuning entry knows, and on fuzzed streams of every block type (stored, fixed, dynamic, flushes
 in the middle, payloads at every offset from a 16-byte boundary), plus damaged streams, which may be flagged but must never write outside
-their token slots.  The GPU suite runs the same source on the device against the host reader and zlib (SQUID_INFLATE_CHECK)."""
+their token slots.  Behind every block's token pass the emulator also runs the resolve the device runs (squid_amd/csrc/sq_resolve.inc, k_lz_resolve5: a round's bytes
+staged in LDS) with staging areas of 496, 64 and 16 bytes -- rounds that fit, rounds that take the direct way, matches that overlap their own output -- and
+compares its bytes with zlib's.  The GPU suite runs the same sources on the device against the host reader and zlib (SQUID_INFLATE_CHECK)."""
 import subprocess
 
 import pytest

@@ -6,6 +6,7 @@
 #define __host__
 #define __device__
 #include "../squid_amd/csrc/sq_inflate_spec.inc"
+#include "../squid_amd/csrc/sq_resolve.inc"
 
 #include <zlib.h>
 
@@ -21,6 +22,24 @@ static void lane_main(void* p) {
     bool err = false;
     const uint32_t nt = isp::inflate_block_spec<CH, PB>(j.lds.data(), j.payload, j.clen, j.tok.data(), j.tcap, err);
     j.nt[wv::lane()] = nt; j.err[wv::lane()] = err;
+}
+// the staged resolve (sq_resolve.inc, k_lz_resolve5's body) as a wave of the emulator
+struct RJob { const uint32_t* tok; int n; uint8_t* out; uint32_t isize; std::vector<uint8_t> st; bool ok[64]; };
+template <int STAGE>
+static void resolve_lane_main(void* p) {
+    RJob& j = *(RJob*)p;
+    j.ok[wv::lane()] = rsv::resolve_block<STAGE>(j.tok, j.n, j.out, j.isize, j.st.data());
+}
+template <int STAGE>
+static int emu_resolve(const std::vector<uint32_t>& tok, uint32_t nt, const std::vector<uint8_t>& want) {
+    std::vector<uint8_t> out(want.size() + 64, 0xee);
+    RJob j{tok.data(), (int)nt, out.data(), (uint32_t)want.size(), std::vector<uint8_t>((size_t)STAGE + 16, 0xdd), {}};
+    wv::run_wave(resolve_lane_main<STAGE>, &j);
+    for (int l = 1; l < 64; ++l) if (j.ok[l] != j.ok[0]) { std::fprintf(stderr, "staged resolve <%d>: lanes disagree on the result\n", STAGE); return 2; }
+    if (!j.ok[0]) { std::fprintf(stderr, "staged resolve <%d>: refuses tokens that the plain resolve takes\n", STAGE); return 2; }
+    if (std::memcmp(out.data(), want.data(), want.size()) != 0) { size_t q = 0; while (out[q] == want[q]) ++q; std::fprintf(stderr, "staged resolve <%d>: bytes differ at %zu of %zu\n", STAGE, q, want.size()); return 2; }
+    for (size_t k = want.size(); k < out.size(); ++k) if (out[k] != 0xee) { std::fprintf(stderr, "staged resolve <%d>: byte written behind the block\n", STAGE); return 2; }
+    return 0;
 }
 // tokens -> bytes, as k_lz_resolve3 reads them
 static bool resolve(const std::vector<uint32_t>& tok, uint32_t nt, std::vector<uint8_t>& out, uint32_t isize) {
@@ -114,6 +133,8 @@ static int run_block(const uint8_t* payload, uint32_t clen, const std::vector<ui
     std::vector<uint8_t> got;
     if (!resolve(j.tok, j.nt[0], got, (uint32_t)want.size())) { std::fprintf(stderr, "tokens do not resolve to %zu bytes (got %zu)\n", want.size(), got.size()); return 2; }
     if (got != want) { size_t q = 0; while (got[q] == want[q]) ++q; std::fprintf(stderr, "bytes differ at %zu\n", q); return 2; }
+    // ... and through the resolve the device runs, with staging areas that nearly every round / hardly any round fits
+    if (want.size()) { if (int rc = emu_resolve<496>(j.tok, j.nt[0], want)) return rc; if (int rc = emu_resolve<64>(j.tok, j.nt[0], want)) return rc; if (int rc = emu_resolve<16>(j.tok, j.nt[0], want)) return rc; }
     return 0;
 }
 static bool zinflate(const uint8_t* p, uint32_t clen, std::vector<uint8_t>& out, uint32_t cap) {
