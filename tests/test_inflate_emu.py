@@ -21,11 +21,11 @@ def emu(built, tmp_path_factory):
 def test_emulated_token_pass_inflates_bam_blocks_like_zlib(emu, synth):
     pre = synth("T2")
     for cfg in ("0", "1", "2", "3", "4", "5", "6"):  # (3 = <384, 10>, what the reader runs; 6 = <1024, 11>)
-        out = subprocess.run([str(emu), f"{pre}.bam", "12", cfg], capture_output=True, text=True, timeout=600)
+        out = subprocess.run([str(emu), f"{pre}.bam", "12" if cfg == "3" else "6", cfg], capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and " 0 flagged, 0 WRONG" in out.stdout, (cfg, out.stdout, out.stderr[-2000:])
 
 
 def test_emulated_token_pass_on_fuzzed_streams(emu):
-    out = subprocess.run([str(emu), "--fuzz", "120", "20261004"], capture_output=True, text=True, timeout=900)
+    out = subprocess.run([str(emu), "--fuzz", "90", "20261004"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and " 0 flagged, 0 WRONG" in out.stdout, (out.stdout, out.stderr[-2000:])
     assert "accepted where zlib refuses" not in out.stderr
