@@ -29,3 +29,12 @@ def test_emulated_token_pass_on_fuzzed_streams(emu):
     out = subprocess.run([str(emu), "--fuzz", "90", "20261004"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and " 0 flagged, 0 WRONG" in out.stdout, (out.stdout, out.stderr[-2000:])
     assert "accepted where zlib refuses" not in out.stderr
+
+
+def test_emulated_staged_resolve_on_random_token_lists(emu):
+    """token lists made here, not by a token pass -- matches of every length and distance the format allows, distances shorter than the match (overlaps),
+    lists that are mostly literals or mostly 258-byte matches, lists that end inside a round -- through sq_resolve.inc with three staging sizes against a plain
+    loop over the tokens; every fifth list is damaged (a distance beyond the block's start, a match that overruns the block) and must be refused"""
+    out = subprocess.run([str(emu), "--resolve-fuzz", "160", "20261004"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and " 0 WRONG" in out.stdout, (out.stdout, out.stderr[-2000:])
+    assert "128 identical to the plain resolve, 32 damaged lists refused" in out.stdout, out.stdout

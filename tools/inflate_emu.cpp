@@ -1,7 +1,7 @@
 // The speculative token pass (squid_amd/csrc/sq_inflate_spec.inc) run on the CPU -- the kernel source itself, its 64 lanes as coroutines
 // (sq_wave.h, SQ_WAVE_EMU) -- and compared with zlib: on the BGZF blocks of a BAM file, and on fuzzed streams of every block type.
 //   g++ -O1 -g -std=c++17 -DSQ_WAVE_EMU -o build/inflate_emu tools/inflate_emu.cpp -lz
-//   build/inflate_emu file.bam [blocks]      |      build/inflate_emu --fuzz [cases] [seed]
+//   build/inflate_emu file.bam [blocks] [cfg]   |   build/inflate_emu --fuzz [cases] [seed]   |   build/inflate_emu --resolve-fuzz [cases] [seed]
 // Test infrastructure only.
 #define __host__
 #define __device__
@@ -185,6 +185,65 @@ static std::vector<uint8_t> make_data(std::mt19937& rng, size_t n) {
 int main(int argc, char** argv) {
     if (argc < 2) { std::fprintf(stderr, "usage: inflate_emu file.bam [blocks] | --fuzz [cases] [seed]\n"); return 1; }
     long n_ok = 0, n_flag = 0, n_wrong = 0;
+    if (std::string(argv[1]) == "--resolve-fuzz") {
+        // random token lists straight into the staged resolve (sq_resolve.inc): matches of every length 3..258 and distance 1..32768 (as far as the bytes in front
+        // allow), runs of literals, lists that end inside a round, and damaged lists (a distance beyond the block's start, a length that overruns the block), which
+        // must be refused without a byte behind the block
+        const long cases = argc > 2 ? std::atol(argv[2]) : 200;
+        std::mt19937 rng(argc > 3 ? (unsigned)std::atol(argv[3]) : 4242u);
+        long ok = 0, refused = 0, wrong = 0;
+        for (long c = 0; c < cases; ++c) {
+            const uint32_t target = 1 + rng() % 65536;
+            const int flavour = (int)(rng() % 4);  // 0 mixed, 1 long matches, 2 short distances (overlaps), 3 literals mostly
+            std::vector<uint32_t> tok;
+            std::vector<uint8_t> want;
+            while (want.size() < target) {
+                const bool match = want.size() >= 1 && (flavour == 3 ? rng() % 8 == 0 : rng() % 2 == 0);
+                if (match) {
+                    uint32_t len = flavour == 1 ? 200 + rng() % 59 : 3 + rng() % (rng() % 4 == 0 ? 256 : 12);
+                    if (len > 258) len = 258;
+                    uint32_t dist = flavour == 2 ? 1 + rng() % 9 : 1 + rng() % 32768;
+                    if (dist > want.size()) dist = 1 + rng() % (uint32_t)want.size();
+                    if (want.size() + len > target) { len = (uint32_t)(target - want.size()); if (len < 3) { for (uint32_t k = 0; k < len; ++k) { tok.push_back((1u << 24) | (rng() & 0xffu)); want.push_back((uint8_t)tok.back()); } continue; } }
+                    tok.push_back(0x80000000u | (len << 16) | (dist - 1));
+                    for (uint32_t k = 0; k < len; ++k) want.push_back(want[want.size() - dist]);
+                } else {
+                    uint32_t n = 1 + rng() % 3;
+                    if (want.size() + n > target) n = (uint32_t)(target - want.size());
+                    uint32_t t = n << 24;
+                    for (uint32_t k = 0; k < n; ++k) { const uint8_t b = (uint8_t)rng(); t |= (uint32_t)b << (8 * k); want.push_back(b); }
+                    tok.push_back(t);
+                }
+            }
+            const bool damage = c % 5 == 4;
+            if (damage && !tok.empty()) {
+                const size_t at = rng() % tok.size();
+                if (rng() % 2) tok[at] = 0x80000000u | ((3 + rng() % 256) << 16) | 0x7fffu;  // a distance of 32768 (beyond the start unless the block is nearly full there)
+                else tok.push_back(0x80000000u | (258u << 16));                                 // one match too many: overruns the block
+            }
+            tok.resize(tok.size() + 64, 0);
+            const uint32_t nt = (uint32_t)tok.size() - 64;
+            std::vector<uint8_t> host;
+            const bool host_ok = resolve(tok, nt, host, (uint32_t)want.size()) && host == want;
+            int rcs[3] = {0, 0, 0};
+            if (!damage || host_ok) { rcs[0] = emu_resolve<496>(tok, nt, want); rcs[1] = emu_resolve<64>(tok, nt, want); rcs[2] = emu_resolve<16>(tok, nt, want); if (rcs[0] || rcs[1] || rcs[2]) { ++wrong; std::fprintf(stderr, "case %ld WRONG (flavour %d, %u tokens, %zu bytes)\n", c, flavour, nt, want.size()); } else ++ok; }
+            else {
+                // a damaged list: every staging size must refuse it and leave the bytes behind the block alone
+                bool all_refuse = true;
+                const int stages[3] = {496, 64, 16};
+                for (int q = 0; q < 3; ++q) {
+                    std::vector<uint8_t> out(want.size() + 512, 0xee);
+                    RJob j{tok.data(), (int)nt, out.data(), (uint32_t)want.size(), std::vector<uint8_t>((size_t)stages[q] + 16, 0xdd), {}};
+                    if (q == 0) wv::run_wave(resolve_lane_main<496>, &j); else if (q == 1) wv::run_wave(resolve_lane_main<64>, &j); else wv::run_wave(resolve_lane_main<16>, &j);
+                    if (j.ok[0]) all_refuse = false;
+                    for (size_t k = want.size() + 264; k < out.size(); ++k) if (out[k] != 0xee) all_refuse = false;  // (a refused round may have stored its literals and one match's bytes: not further)
+                }
+                if (all_refuse) ++refused; else { ++wrong; std::fprintf(stderr, "case %ld: a damaged token list was taken (or bytes were written far behind the block)\n", c); }
+            }
+        }
+        std::printf("resolve fuzz: %ld identical to the plain resolve, %ld damaged lists refused, %ld WRONG\n", ok, refused, wrong);
+        return wrong ? 2 : 0;
+    }
     if (std::string(argv[1]) == "--fuzz") {
         const long cases = argc > 2 ? std::atol(argv[2]) : 200;
         std::mt19937 rng(argc > 3 ? (unsigned)std::atol(argv[3]) : 12345u);
